@@ -1,0 +1,224 @@
+/* oracle/capi.cpp — TEST INFRASTRUCTURE: flat C entry points (ctypes) over the CPU oracle. */
+#include "oracle.h"
+#include "match_oracle.h"
+#include "../include/drfe_math.h"
+
+#include <chrono>
+#include <cstring>
+#include <exception>
+#include <string>
+
+using namespace orc;
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+void* orc_orb_create(int nf, float sf, int nl, int ini, int mn) { return new OrbExtractor(nf, sf, nl, ini, mn); }
+void orc_orb_destroy(void* h) { delete (OrbExtractor*)h; }
+
+int orc_orb_extract(void* h, const uint8_t* gray, int w, int hh, long stride)
+{
+    try { return ((OrbExtractor*)h)->extract(gray, w, hh, (size_t)stride); }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+void orc_orb_get_keypoints(void* h, KeyPoint* out)
+{
+    OrbExtractor* o = (OrbExtractor*)h;
+    if (!o->keypoints.empty()) std::memcpy(out, o->keypoints.data(), o->keypoints.size() * sizeof(KeyPoint));
+}
+void orc_orb_get_descriptors(void* h, uint8_t* out)
+{
+    OrbExtractor* o = (OrbExtractor*)h;
+    if (!o->descriptors.empty()) std::memcpy(out, o->descriptors.data(), o->descriptors.size());
+}
+void orc_orb_tables(void* h, float* scale, float* invScale, float* sigma2, float* invSigma2, int* quota, int* umax)
+{
+    OrbExtractor* o = (OrbExtractor*)h;
+    for (int i = 0; i < o->nlevels; i++) {
+        scale[i] = o->scale[i]; invScale[i] = o->invScale[i];
+        sigma2[i] = o->sigma2[i]; invSigma2[i] = o->invSigma2[i];
+        quota[i] = o->quota[i];
+    }
+    for (int i = 0; i <= kHalfPatch; i++) umax[i] = o->umax[i];
+}
+int orc_orb_geometry(void* h, int w, int hh, int* out /* nlevels x 11 */)
+{
+    OrbExtractor* o = (OrbExtractor*)h;
+    try { o->computeGeometry(w, hh); }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+    for (int l = 0; l < o->nlevels; l++) {
+        const LevelGeom& g = o->geom[l];
+        int* p = out + l * 11;
+        p[0] = g.w; p[1] = g.h; p[2] = g.quota; p[3] = g.minBX; p[4] = g.minBY; p[5] = g.maxBX; p[6] = g.maxBY;
+        p[7] = g.nCols; p[8] = g.nRows; p[9] = g.wCell; p[10] = g.hCell;
+    }
+    return 0;
+}
+void orc_orb_get_pyramid(void* h, int l, uint8_t* out)
+{
+    const Image& im = ((OrbExtractor*)h)->pyramid[l];
+    std::memcpy(out, im.px.data(), im.px.size());
+}
+int orc_orb_get_blurred(void* h, int l, uint8_t* out)
+{
+    const Image& im = ((OrbExtractor*)h)->blurred[l];
+    if (im.px.empty()) return 0;
+    std::memcpy(out, im.px.data(), im.px.size());
+    return 1;
+}
+int orc_orb_num_candidates(void* h, int l) { return (int)((OrbExtractor*)h)->candidates[l].size(); }
+void orc_orb_get_candidates(void* h, int l, int32_t* out /* n x 3 */)
+{
+    const auto& c = ((OrbExtractor*)h)->candidates[l];
+    for (size_t i = 0; i < c.size(); i++) { out[3 * i] = c[i].x; out[3 * i + 1] = c[i].y; out[3 * i + 2] = c[i].response; }
+}
+
+/* stage functions */
+void orc_resize_linear_u8(const uint8_t* s, int sw, int sh, long ss, uint8_t* d, int dw, int dh, long ds)
+{
+    resize_linear_u8(s, sw, sh, (size_t)ss, d, dw, dh, (size_t)ds);
+}
+int orc_reflect101(int p, int n) { return reflect101(p, n); }
+int orc_fast_detect(const uint8_t* img, int w, int h, long stride, int thr, int32_t* out, int cap)
+{
+    std::vector<Candidate> c;
+    fast_detect(img, w, h, (size_t)stride, thr, c);
+    for (size_t i = 0; i < c.size() && (int)i < cap; i++) { out[3 * i] = c[i].x; out[3 * i + 1] = c[i].y; out[3 * i + 2] = c[i].response; }
+    return (int)c.size();
+}
+/* raw strength map: cornerScore<16>(p, 0) on rows/cols [3,n-3), -1 elsewhere */
+void orc_fast_score_map(const uint8_t* img, int w, int h, long stride, int32_t* out)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            out[(size_t)y * w + x] = (y >= 3 && y < h - 3 && x >= 3 && x < w - 3)
+                                         ? fast_score_9_16(img + (size_t)y * stride + x, (size_t)stride) : -1;
+}
+void orc_gaussian_blur(const uint8_t* s, int w, int h, long ss, uint8_t* d, long ds)
+{
+    gaussian_blur_7x7_s2_u8(s, w, h, (size_t)ss, d, (size_t)ds);
+}
+float orc_fast_atan2(float y, float x) { return drfe_fast_atan2(y, x); }
+void orc_sincos(float r, float* s, float* c) { drfe_sincos(r, s, c); }
+float orc_ic_angle(void* h, const uint8_t* img, long stride, int x, int y)
+{
+    return ic_angle(img + (size_t)y * stride + x, (size_t)stride, ((OrbExtractor*)h)->umax);
+}
+void orc_orb_descriptor(const uint8_t* img, long stride, int x, int y, float angle, uint8_t* desc)
+{
+    orb_descriptor(img + (size_t)y * stride + x, (size_t)stride, angle, desc);
+}
+int orc_distribute_octtree(void* h, const int32_t* keys3, int n, int minX, int maxX, int minY, int maxY, int N,
+                           int32_t* out)
+{
+    std::vector<Candidate> K(n);
+    for (int i = 0; i < n; i++) K[i] = {keys3[3 * i], keys3[3 * i + 1], keys3[3 * i + 2]};
+    try {
+        std::vector<int> r = ((OrbExtractor*)h)->distributeOctTree(K, minX, maxX, minY, maxY, N);
+        for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
+        return (int)r.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int orc_hamming_swar(const uint8_t* a, const uint8_t* b) { return descriptor_distance_swar(a, b); }
+
+/* imDepth.convertTo(depth, CV_32F, factor), src/Frame.cc:113-115: float(src)*float(scale) (+0) */
+void orc_depth_to_float(const uint16_t* d, long n, float factor, float* out)
+{
+    for (long i = 0; i < n; i++) out[i] = (float)d[i] * factor;
+}
+
+/* Frame (no-distortion path: mvKeysUn = mvKeys, bounds = image, src/Frame.cc:836-838, 884-889) */
+void* orc_frame_create(const KeyPoint* kps, const uint8_t* desc, int N, const float* depth, int dw, int dh,
+                       const float K[4], float bf, int imw, int imh, const float* scaleFactors, int nlevels)
+{
+    Frame* f = new Frame();
+    f->N = N;
+    f->keys.assign(kps, kps + N);
+    f->keysUn = f->keys;
+    f->desc.assign(desc, desc + (size_t)N * 32);
+    f->scaleFactors.assign(scaleFactors, scaleFactors + nlevels);
+    f->fx = K[0]; f->fy = K[1]; f->cx = K[2]; f->cy = K[3];
+    f->bf = bf; f->mb = bf / f->fx;
+    f->minX = 0.f; f->maxX = (float)imw; f->minY = 0.f; f->maxY = (float)imh;
+    f->gridInvW = (float)kGridCols / (float)(f->maxX - f->minX);
+    f->gridInvH = (float)kGridRows / (float)(f->maxY - f->minY);
+    f->computeStereoFromRGBD(depth, dw, dh);
+    f->assignFeaturesToGrid();
+    return f;
+}
+void orc_frame_destroy(void* h) { delete (Frame*)h; }
+void orc_frame_get_stereo(void* h, float* uRight, float* depth)
+{
+    Frame* f = (Frame*)h;
+    std::memcpy(uRight, f->uRight.data(), f->N * sizeof(float));
+    std::memcpy(depth, f->depth.data(), f->N * sizeof(float));
+}
+/* CSR in the reference's iteration order: cell id = ix*48 + iy (mGrid[ix][iy]) */
+void orc_frame_grid_csr(void* h, int32_t* offsets /* 64*48+1 */, int32_t* indices /* N */)
+{
+    Frame* f = (Frame*)h;
+    int o = 0;
+    for (int ix = 0; ix < kGridCols; ix++)
+        for (int iy = 0; iy < kGridRows; iy++) {
+            offsets[ix * kGridRows + iy] = o;
+            for (int idx : f->grid[ix][iy]) indices[o++] = idx;
+        }
+    offsets[kGridCols * kGridRows] = o;
+}
+int orc_frame_features_in_area(void* h, float x, float y, float r, int minL, int maxL, int32_t* out, int cap)
+{
+    std::vector<int> v;
+    ((Frame*)h)->getFeaturesInArea(x, y, r, minL, maxL, v);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+/* Frame::UnprojectStereo, src/Frame.cc:913-923: world = Rwc*x3Dc + Ow (float gemm small path) */
+void orc_frame_unproject(void* h, const float Twc[16], float* world /* N x 3 */, uint8_t* valid)
+{
+    Frame* f = (Frame*)h;
+    const float invfx = 1.0f / f->fx, invfy = 1.0f / f->fy;
+    for (int i = 0; i < f->N; i++) {
+        const float z = f->depth[i];
+        valid[i] = z > 0;
+        if (!(z > 0)) { world[3 * i] = world[3 * i + 1] = world[3 * i + 2] = 0; continue; }
+        const float u = f->keysUn[i].x, v = f->keysUn[i].y;
+        const float x = (u - f->cx) * z * invfx;
+        const float y = (v - f->cy) * z * invfy;
+        const float p[3] = {x, y, z};
+        for (int r = 0; r < 3; r++) {
+            const float d = Twc[r * 4 + 0] * p[0] + Twc[r * 4 + 1] * p[1] + Twc[r * 4 + 2] * p[2];
+            world[3 * i + r] = (float)((double)d * 1.0 + (double)Twc[r * 4 + 3] * 1.0);
+        }
+    }
+}
+
+int orc_search_by_projection_last(void* cur, void* last, const float* TcwCur, const float* TcwLast,
+                                  const MapPointRec* lastMP, float th, int bMono, int checkOri,
+                                  const uint8_t* curObs, int32_t* curMP)
+{
+    return search_by_projection_last(*(Frame*)cur, *(Frame*)last, TcwCur, TcwLast, lastMP, th, bMono != 0,
+                                     checkOri != 0, curObs, curMP);
+}
+int orc_search_by_projection_map(void* f, const TrackedPointRec* mps, int M, float th, float nnratio,
+                                 const uint8_t* claimObs, int32_t* frameMP)
+{
+    return search_by_projection_map(*(Frame*)f, mps, M, th, nnratio, claimObs, frameMP);
+}
+void orc_bf_knn_hamming(const uint8_t* Q, int nq, const uint8_t* T, int nt, int k, int32_t* idx, int32_t* dist)
+{
+    bf_knn_hamming(Q, nq, T, nt, k, idx, dist);
+}
+int orc_match_orb_points(const uint8_t* cd, int cn, const uint8_t* ld, int ln, const int32_t* lastMP,
+                         const uint8_t* lastOutlier, int32_t* curMP)
+{
+    return match_orb_points(cd, cn, ld, ln, lastMP, lastOutlier, curMP);
+}
+
+int orc_sizeof_keypoint() { return (int)sizeof(KeyPoint); }
+int orc_sizeof_mappointrec() { return (int)sizeof(MapPointRec); }
+int orc_sizeof_trackedpointrec() { return (int)sizeof(TrackedPointRec); }
+
+} // extern "C"

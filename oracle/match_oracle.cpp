@@ -1,0 +1,266 @@
+/* oracle/match_oracle.cpp — TEST INFRASTRUCTURE (see oracle.h; parity unpinned vs OpenCV BFMatcher/gemm).
+ *
+ * CPU restatement of the Frame glue and ORBmatcher paths on the hot path (SURVEY.md §8a a-9..a-12,
+ * a-16, a-21).  Map points are modelled as plain records (world position, descriptor,
+ * Observations()>0 flag); MapPoint* identity becomes an int id (-1 == NULL).
+ */
+#include "oracle.h"
+#include "match_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace orc {
+
+/* Frame::ComputeStereoFromRGBD, src/Frame.cc:893-911 (float->int truncation of (v,u), §9.13) */
+void Frame::computeStereoFromRGBD(const float* depth, int dw, int dh)
+{
+    uRight.assign(N, -1.f);
+    this->depth.assign(N, -1.f);
+    for (int i = 0; i < N; i++) {
+        const int v = (int)keys[i].y, u = (int)keys[i].x;
+        if (v < 0 || v >= dh || u < 0 || u >= dw) continue; /* reference would read out of bounds */
+        const float d = depth[(size_t)v * dw + u];
+        if (d > 0) {
+            this->depth[i] = d;
+            uRight[i] = keysUn[i].x - bf / d;
+        }
+    }
+}
+
+/* Frame::PosInGrid + AssignFeaturesToGrid, src/Frame.cc:224-237, 816-825 (C round(), §9.19) */
+void Frame::assignFeaturesToGrid()
+{
+    for (int i = 0; i < kGridCols; i++)
+        for (int j = 0; j < kGridRows; j++) grid[i][j].clear();
+    for (int i = 0; i < N; i++) {
+        const int px = (int)std::round((keysUn[i].x - minX) * gridInvW);
+        const int py = (int)std::round((keysUn[i].y - minY) * gridInvH);
+        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
+        grid[px][py].push_back(i);
+    }
+}
+
+/* Frame::GetFeaturesInArea, src/Frame.cc:730-779 */
+void Frame::getFeaturesInArea(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const
+{
+    out.clear();
+    const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * gridInvW));
+    if (nMinCellX >= kGridCols) return;
+    const int nMaxCellX = std::min(kGridCols - 1, (int)std::ceil((x - minX + r) * gridInvW));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * gridInvH));
+    if (nMinCellY >= kGridRows) return;
+    const int nMaxCellY = std::min(kGridRows - 1, (int)std::ceil((y - minY + r) * gridInvH));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int>& cell = grid[ix][iy];
+            for (int idx : cell) {
+                const KeyPoint& kp = keysUn[idx];
+                if (bCheckLevels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                const float dx = kp.x - x, dy = kp.y - y;
+                if (std::fabs(dx) < r && std::fabs(dy) < r) out.push_back(idx);
+            }
+        }
+}
+
+/* cv::Mat (3x3)*(3x1)+(3x1) CV_32F: OpenCV gemm small-matrix path: float dot, then
+ * (float)(t*alpha + c*beta) in double (exact for two floats). */
+static void mat3_mul_add(const float R[9], const float x[3], const float t[3], float out[3])
+{
+    for (int r = 0; r < 3; r++) {
+        const float d = R[r * 3 + 0] * x[0] + R[r * 3 + 1] * x[1] + R[r * 3 + 2] * x[2];
+        out[r] = (float)((double)d * 1.0 + (double)t[r] * 1.0);
+    }
+}
+
+/* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1666-1707 */
+static void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1396-1535 */
+int search_by_projection_last(const Frame& Cur, const Frame& Last, const float TcwCur[16], const float TcwLast[16],
+                              const MapPointRec* lastMP, float th, bool bMono, bool checkOri,
+                              const uint8_t* curClaimObsPositive, int* curMP)
+{
+    const int HISTO_LENGTH = 30, TH_HIGH = 100;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    float Rcw[9], tcw[3], Rlw[9], tlw[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) { Rcw[r * 3 + c] = TcwCur[r * 4 + c]; Rlw[r * 3 + c] = TcwLast[r * 4 + c]; }
+        tcw[r] = TcwCur[r * 4 + 3];
+        tlw[r] = TcwLast[r * 4 + 3];
+    }
+    /* twc = -Rcw.t()*tcw : general gemm path (transposed operand), double accumulation, alpha = -1 */
+    float twc[3];
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Rcw[k * 3 + i] * (double)tcw[k];
+        twc[i] = (float)(s * -1.0);
+    }
+    float tlc[3];
+    mat3_mul_add(Rlw, twc, tlw, tlc);
+    const bool bForward = tlc[2] > Cur.mb && !bMono;
+    const bool bBackward = -tlc[2] > Cur.mb && !bMono;
+    /* claim bookkeeping: obs flag of whatever currently sits in curMP[i2] */
+    std::vector<uint8_t> claimObs(Cur.N, 0);
+    for (int i = 0; i < Cur.N; i++)
+        if (curMP[i] >= 0) claimObs[i] = curClaimObsPositive ? curClaimObsPositive[i] : 1;
+    std::vector<int> cand;
+    for (int i = 0; i < Last.N; i++) {
+        const MapPointRec& mp = lastMP[i];
+        if (!mp.valid) continue; /* pMP && !mvbOutlier[i] */
+        float x3Dc[3];
+        mat3_mul_add(Rcw, mp.world, tcw, x3Dc);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / (double)x3Dc[2]);
+        if (invzc < 0) continue;
+        const float u = Cur.fx * xc * invzc + Cur.cx;
+        const float v = Cur.fy * yc * invzc + Cur.cy;
+        if (u < Cur.minX || u > Cur.maxX) continue;
+        if (v < Cur.minY || v > Cur.maxY) continue;
+        const int nLastOctave = Last.keys[i].octave;
+        const float radius = th * Cur.scaleFactors[nLastOctave];
+        if (bForward) Cur.getFeaturesInArea(u, v, radius, nLastOctave, -1, cand);
+        else if (bBackward) Cur.getFeaturesInArea(u, v, radius, 0, nLastOctave, cand);
+        else Cur.getFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1, cand);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : cand) {
+            if (curMP[i2] >= 0 && claimObs[i2]) continue;
+            if (Cur.uRight[i2] > 0) {
+                const float ur = u - Cur.bf * invzc;
+                const float er = std::fabs(ur - Cur.uRight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = descriptor_distance_swar(mp.desc, &Cur.desc[(size_t)i2 * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            curMP[bestIdx2] = i;
+            claimObs[bestIdx2] = mp.obsPositive;
+            nmatches++;
+            if (checkOri) {
+                float rot = Last.keysUn[i].angle - Cur.keysUn[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { curMP[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:46-138 */
+int search_by_projection_map(const Frame& F, const TrackedPointRec* mps, int M, float th, float nnratio,
+                             const uint8_t* claimObsPositive, int* frameMP)
+{
+    const int TH_HIGH = 100;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<uint8_t> claimObs(F.N, 0);
+    for (int i = 0; i < F.N; i++)
+        if (frameMP[i] >= 0) claimObs[i] = claimObsPositive ? claimObsPositive[i] : 1;
+    std::vector<int> cand;
+    for (int iMP = 0; iMP < M; iMP++) {
+        const TrackedPointRec& mp = mps[iMP];
+        if (!mp.trackInView) continue;
+        if (mp.bad) continue;
+        const int lvl = mp.level;
+        float r = ((double)mp.viewCos > 0.998) ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        F.getFeaturesInArea(mp.projX, mp.projY, r * F.scaleFactors[lvl], lvl - 1, lvl, cand);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : cand) {
+            if (frameMP[idx] >= 0 && claimObs[idx]) continue;
+            if (F.uRight[idx] > 0) {
+                const float er = std::fabs(mp.projXR - F.uRight[idx]);
+                if (er > r * F.scaleFactors[lvl]) continue;
+            }
+            const int dist = descriptor_distance_swar(mp.desc, &F.desc[(size_t)idx * 32]);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = F.keysUn[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F.keysUn[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            frameMP[bestIdx] = iMP;
+            claimObs[bestIdx] = mp.obsPositive;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch / match, SURVEY.md §10.7: ascending distance, ties -> lower
+ * train index. idx/dist are nq x k, missing entries -1. */
+void bf_knn_hamming(const uint8_t* Q, int nq, const uint8_t* T, int nt, int k, int32_t* idx, int32_t* dist)
+{
+    for (int q = 0; q < nq; q++) {
+        int bi[2] = {-1, -1}, bd[2] = {1 << 30, 1 << 30};
+        for (int t = 0; t < nt; t++) {
+            const int d = descriptor_distance_swar(Q + (size_t)q * 32, T + (size_t)t * 32);
+            if (d < bd[0]) { bd[1] = bd[0]; bi[1] = bi[0]; bd[0] = d; bi[0] = t; }
+            else if (d < bd[1]) { bd[1] = d; bi[1] = t; }
+        }
+        for (int j = 0; j < k; j++) {
+            idx[(size_t)q * k + j] = bi[j];
+            dist[(size_t)q * k + j] = bi[j] >= 0 ? bd[j] : -1;
+        }
+    }
+}
+
+/* ORBmatcher::MatchORBPoints, src/ORBmatcher.cc:1332-1394 (incl. the mvbOutlier[i] quirk, §9.12) */
+int match_orb_points(const uint8_t* curDesc, int curN, const uint8_t* lastDesc, int lastN,
+                     const int32_t* lastMP /* id or -1 */, const uint8_t* lastOutlier, int32_t* curMP)
+{
+    if (curN == 0 || lastN == 0) return 0;
+    std::vector<int32_t> idx(curN), dist(curN);
+    bf_knn_hamming(curDesc, curN, lastDesc, lastN, 1, idx.data(), dist.data());
+    double min_dist = 1000;
+    for (int i = 0; i < curN; i++)
+        if ((float)dist[i] < min_dist) min_dist = (float)dist[i];
+    std::vector<int> good;
+    for (int i = 0; i < curN; i++)
+        if ((float)dist[i] < std::max(2 * min_dist, 15.0)) good.push_back(i);
+    const int NPair = (int)good.size();
+    for (int i = 0; i < NPair; i++) {
+        const int mp = lastMP[idx[good[i]]];
+        if (mp >= 0 && i < lastN && !lastOutlier[i]) curMP[good[i]] = mp;
+    }
+    return NPair;
+}
+
+} // namespace orc

@@ -1,0 +1,294 @@
+"""ctypes wrapper over oracle/libdrfe_oracle.so — TEST INFRASTRUCTURE (see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+MAPPOINT_DTYPE = np.dtype([("valid", "u1"), ("obsPositive", "u1"), ("pad", "u1", (2,)), ("world", "<f4", (3,)),
+                           ("desc", "u1", (32,))])
+TRACKED_DTYPE = np.dtype([("trackInView", "u1"), ("bad", "u1"), ("obsPositive", "u1"), ("pad", "u1"),
+                          ("level", "<i4"), ("projX", "<f4"), ("projY", "<f4"), ("projXR", "<f4"),
+                          ("viewCos", "<f4"), ("desc", "u1", (32,))])
+
+
+def build(force: bool = False) -> str:
+    path = os.path.join(_HERE, "libdrfe_oracle.so")
+    if force or not os.path.exists(path):
+        subprocess.check_call(["make", "-C", _HERE, "-j4"], stdout=subprocess.DEVNULL)
+    return path
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_orb_create.restype = C.c_void_p
+        L.orc_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_orb_destroy.argtypes = [C.c_void_p]
+        L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long]
+        for n in ("orc_orb_get_keypoints", "orc_orb_get_descriptors"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_orb_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_orb_get_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_orb_get_blurred.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_orb_num_candidates.argtypes = [C.c_void_p, C.c_int]
+        L.orc_orb_get_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_long]
+        L.orc_reflect101.argtypes = [C.c_int, C.c_int]
+        L.orc_fast_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_score_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p]
+        L.orc_gaussian_blur.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_long]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int]
+        L.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_distribute_octtree.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p]
+        L.orc_hamming_swar.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_depth_to_float.argtypes = [C.c_void_p, C.c_long, C.c_float, C.c_void_p]
+        L.orc_frame_create.restype = C.c_void_p
+        L.orc_frame_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_frame_destroy.argtypes = [C.c_void_p]
+        L.orc_frame_get_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_frame_grid_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_frame_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_int]
+        L.orc_frame_unproject.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                                   C.c_void_p, C.c_void_p]
+        L.orc_bf_knn_hamming.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_match_orb_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert L.orc_sizeof_keypoint() == KP_DTYPE.itemsize
+        assert L.orc_sizeof_mappointrec() == MAPPOINT_DTYPE.itemsize
+        assert L.orc_sizeof_trackedpointrec() == TRACKED_DTYPE.itemsize
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class OrbOracle:
+    """Restatement of ORBextractor (reference include/ORBextractor.h:51-85)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orc_orb_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+        sc, isc, s2, is2 = (np.zeros(nlevels, np.float32) for _ in range(4))
+        q = np.zeros(nlevels, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.orc_orb_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(q), _p(um))
+        self.scale, self.inv_scale, self.sigma2, self.inv_sigma2, self.quota, self.umax = sc, isc, s2, is2, q, um
+        self.geom = None
+
+    def __del__(self):
+        try:
+            self.L.orc_orb_destroy(self.h)
+        except Exception:
+            pass
+
+    def geometry(self, w, h):
+        g = np.zeros((self.nlevels, 11), np.int32)
+        if self.L.orc_orb_geometry(self.h, w, h, _p(g)) != 0:
+            raise RuntimeError(self.L.orc_last_error().decode())
+        return g  # w,h,quota,minBX,minBY,maxBX,maxBY,nCols,nRows,wCell,hCell
+
+    def __call__(self, gray):
+        gray = _c(gray, np.uint8)
+        hh, w = gray.shape
+        n = self.L.orc_orb_extract(self.h, _p(gray), w, hh, gray.strides[0])
+        if n < 0:
+            raise RuntimeError(self.L.orc_last_error().decode())
+        kps = np.zeros(n, KP_DTYPE)
+        desc = np.zeros((n, 32), np.uint8)
+        self.L.orc_orb_get_keypoints(self.h, _p(kps))
+        self.L.orc_orb_get_descriptors(self.h, _p(desc))
+        self.geom = self.geometry(w, hh)
+        return kps, desc
+
+    def pyramid(self, l):
+        g = self.geom[l]
+        out = np.zeros((g[1] + 38, g[0] + 38), np.uint8)
+        self.L.orc_orb_get_pyramid(self.h, l, _p(out))
+        return out
+
+    def blurred(self, l):
+        g = self.geom[l]
+        out = np.zeros((g[1], g[0]), np.uint8)
+        ok = self.L.orc_orb_get_blurred(self.h, l, _p(out))
+        return out if ok else None
+
+    def candidates(self, l):
+        n = self.L.orc_orb_num_candidates(self.h, l)
+        out = np.zeros((n, 3), np.int32)
+        self.L.orc_orb_get_candidates(self.h, l, _p(out))
+        return out
+
+    def distribute(self, keys3, minX, maxX, minY, maxY, N):
+        keys3 = _c(keys3, np.int32)
+        out = np.zeros(max(len(keys3), 1), np.int32)
+        n = self.L.orc_distribute_octtree(self.h, _p(keys3), len(keys3), minX, maxX, minY, maxY, N, _p(out))
+        if n < 0:
+            raise RuntimeError(self.L.orc_last_error().decode())
+        return out[:n]
+
+    def ic_angle(self, img, x, y):
+        img = _c(img, np.uint8)
+        return self.L.orc_ic_angle(self.h, _p(img), img.strides[0], x, y)
+
+
+def resize_linear(src, dw, dh):
+    src = _c(src, np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(out), dw, dh, out.strides[0])
+    return out
+
+
+def fast_detect(img, thr):
+    img = _c(img, np.uint8)
+    cap = img.size
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast_detect(_p(img), img.shape[1], img.shape[0], img.strides[0], thr, _p(out), cap)
+    return out[:n]
+
+
+def fast_score_map(img):
+    img = _c(img, np.uint8)
+    out = np.zeros(img.shape, np.int32)
+    lib().orc_fast_score_map(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(out))
+    return out
+
+
+def gaussian_blur(img):
+    img = _c(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_gaussian_blur(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(out), out.strides[0])
+    return out
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(y, x)
+
+
+def sincos(r):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos(r, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def orb_descriptor(img, x, y, angle):
+    img = _c(img, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_orb_descriptor(_p(img), img.strides[0], x, y, angle, _p(d))
+    return d
+
+
+def hamming_swar(a, b):
+    return lib().orc_hamming_swar(_p(_c(a, np.uint8)), _p(_c(b, np.uint8)))
+
+
+def depth_to_float(d16, factor):
+    d16 = _c(d16, np.uint16)
+    out = np.zeros(d16.shape, np.float32)
+    lib().orc_depth_to_float(_p(d16), d16.size, np.float32(factor), _p(out))
+    return out
+
+
+class FrameOracle:
+    """Restatement of the parts of Frame the matchers read (reference include/Frame.h:183-299)."""
+
+    def __init__(self, kps, desc, depth_f32, K4, bf, imw, imh, scale_factors):
+        self.L = lib()
+        self.kps = _c(kps, KP_DTYPE)
+        self.desc = _c(desc, np.uint8)
+        self.N = len(self.kps)
+        depth_f32 = _c(depth_f32, np.float32)
+        K4 = _c(K4, np.float32)
+        sf = _c(scale_factors, np.float32)
+        self.h = self.L.orc_frame_create(_p(self.kps), _p(self.desc), self.N, _p(depth_f32), depth_f32.shape[1],
+                                         depth_f32.shape[0], _p(K4), np.float32(bf), imw, imh, _p(sf), len(sf))
+        self.uRight = np.zeros(self.N, np.float32)
+        self.depth = np.zeros(self.N, np.float32)
+        self.L.orc_frame_get_stereo(self.h, _p(self.uRight), _p(self.depth))
+
+    def __del__(self):
+        try:
+            self.L.orc_frame_destroy(self.h)
+        except Exception:
+            pass
+
+    def grid_csr(self):
+        off = np.zeros(64 * 48 + 1, np.int32)
+        idx = np.zeros(max(self.N, 1), np.int32)
+        self.L.orc_frame_grid_csr(self.h, _p(off), _p(idx))
+        return off, idx[:off[-1]]
+
+    def features_in_area(self, x, y, r, minL=-1, maxL=-1):
+        out = np.zeros(max(self.N, 1), np.int32)
+        n = self.L.orc_frame_features_in_area(self.h, x, y, r, minL, maxL, _p(out), len(out))
+        return out[:n]
+
+    def unproject(self, Twc):
+        Twc = _c(Twc, np.float32)
+        w = np.zeros((self.N, 3), np.float32)
+        v = np.zeros(self.N, np.uint8)
+        self.L.orc_frame_unproject(self.h, _p(Twc), _p(w), _p(v))
+        return w, v
+
+
+def search_by_projection_last(cur: FrameOracle, last: FrameOracle, Tcw_cur, Tcw_last, last_mp, th=15.0,
+                              mono=False, check_ori=True, cur_mp=None, cur_obs=None):
+    last_mp = _c(last_mp, MAPPOINT_DTYPE)
+    out = np.full(cur.N, -1, np.int32) if cur_mp is None else _c(cur_mp, np.int32).copy()
+    n = lib().orc_search_by_projection_last(cur.h, last.h, _p(_c(Tcw_cur, np.float32)), _p(_c(Tcw_last, np.float32)),
+                                            _p(last_mp), th, int(mono), int(check_ori),
+                                            _p(None if cur_obs is None else _c(cur_obs, np.uint8)), _p(out))
+    return n, out
+
+
+def search_by_projection_map(frame: FrameOracle, mps, th, nnratio, frame_mp=None, claim_obs=None):
+    mps = _c(mps, TRACKED_DTYPE)
+    out = np.full(frame.N, -1, np.int32) if frame_mp is None else _c(frame_mp, np.int32).copy()
+    n = lib().orc_search_by_projection_map(frame.h, _p(mps), len(mps), th, nnratio,
+                                           _p(None if claim_obs is None else _c(claim_obs, np.uint8)), _p(out))
+    return n, out
+
+
+def bf_knn(Q, T, k):
+    Q, T = _c(Q, np.uint8), _c(T, np.uint8)
+    idx = np.zeros((len(Q), k), np.int32)
+    dist = np.zeros((len(Q), k), np.int32)
+    lib().orc_bf_knn_hamming(_p(Q), len(Q), _p(T), len(T), k, _p(idx), _p(dist))
+    return idx, dist
+
+
+def match_orb_points(cur_desc, last_desc, last_mp, last_outlier):
+    cd, ld = _c(cur_desc, np.uint8), _c(last_desc, np.uint8)
+    out = np.full(len(cd), -1, np.int32)
+    n = lib().orc_match_orb_points(_p(cd), len(cd), _p(ld), len(ld), _p(_c(last_mp, np.int32)),
+                                   _p(_c(last_outlier, np.uint8)), _p(out))
+    return n, out
