@@ -1,0 +1,395 @@
+/* capi.cpp — the C-ABI of libdrfe.so (include/drfe.h): context lifetime, HBM arenas, host<->device
+ * staging.  No compute happens on the host: every entry point either launches the HIP kernels or
+ * copies their results.  There is no CPU fallback — a missing GPU / HIP failure is DRFE_ERR_HIP. */
+#include "drfe_internal.h"
+#include "match_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+static std::string g_create_err;
+
+static const int8_t kPatternHost[1024] = {
+#include "../../include/drfe_orb_pattern.inc"
+};
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return DRFE_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+template <class T>
+static hipError_t dalloc(T** p, size_t n)
+{
+    *p = nullptr;
+    return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+static int upload_geometry(drfe_ctx* c, int w, int h)
+{
+    if (c->geom.imgW == w && c->geom.imgH == h) return DRFE_OK;
+    if (w > c->cfg.max_width || h > c->cfg.max_height) {
+        c->err = "frame larger than drfe_config.max_width/max_height";
+        return DRFE_ERR_INVALID;
+    }
+    DevGeom g;
+    std::memset(&g, 0, sizeof(g));
+    std::vector<FastCell> cells;
+    std::vector<BlurTile> tiles;
+    std::vector<ResizeTap> taps;
+    int rc = drfe_build_geometry(c, w, h, &g, &cells, &tiles, &taps);
+    if (rc != DRFE_OK) return rc;
+    if ((size_t)g.pyrSlotBytes > c->pyrSlotBytesMax || (size_t)g.blurSlotBytes > c->blurSlotBytesMax ||
+        (size_t)g.candSlotElems > c->candSlotElemsMax || g.kpSlotElems > c->maxKp ||
+        (int)cells.size() > c->cellsCap || (int)tiles.size() > c->tilesCap || (int)taps.size() > c->tapsCap) {
+        c->err = "geometry exceeds the arenas sized at drfe_create";
+        return DRFE_ERR_CAPACITY;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(c->d_geom, &g, sizeof(g), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_cells, cells.data(), cells.size() * sizeof(FastCell), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
+    if (!taps.empty())
+        HIPCHK(c, hipMemcpy(c->d_taps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    c->geom = g;
+    c->lastBatch = 0;
+    c->glueValid = false;
+    return DRFE_OK;
+}
+
+extern "C" {
+
+const char* drfe_version(void) { return "drfe 0.1 (gfx950)"; }
+
+const char* drfe_last_error(const drfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+void drfe_destroy(drfe_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drfe_match_buffers_free(c);
+    void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
+                    c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_desc,
+                    c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_match,
+                    c->d_matchCount, c->d_poses, c->d_stage};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < DRFE_STAGE_COUNT; i++)
+        for (int j = 0; j < 2; j++)
+            if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int drfe_create(const drfe_config* cfg, drfe_ctx** out)
+{
+    if (!cfg || !out) { g_create_err = "null argument"; return DRFE_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > DRFE_MAX_LEVELS || cfg->max_batch < 1 || cfg->nfeatures < 1 ||
+        !(cfg->scale_factor > 1.0f) || cfg->max_width < 64 || cfg->max_height < 64 || cfg->max_width > 4095 ||
+        cfg->max_height > 4095) {
+        g_create_err = "invalid drfe_config";
+        return DRFE_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_err = "no HIP device: libdrfe has no CPU path";
+        return DRFE_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "device ordinal out of range"; return DRFE_ERR_INVALID; }
+    drfe_ctx* c = new (std::nothrow) drfe_ctx();
+    if (!c) { g_create_err = "out of host memory"; return DRFE_ERR_INVALID; }
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->stream = nullptr;
+    c->profile = false;
+    c->lastBatch = 0;
+    c->glueValid = false;
+    c->mb = nullptr;
+    std::memset(&c->cam, 0, sizeof(c->cam));
+    std::memset(&c->geom, 0, sizeof(c->geom));
+    std::memset(c->ev, 0, sizeof(c->ev));
+    std::memset(c->evUsed, 0, sizeof(c->evUsed));
+    c->d_geom = nullptr; c->d_cells = nullptr; c->d_tiles = nullptr; c->d_taps = nullptr; c->d_pattern = nullptr;
+    c->d_disc = nullptr; c->d_pyr = nullptr; c->d_blur = nullptr; c->d_cand0 = nullptr; c->d_cand1 = nullptr;
+    c->d_node = nullptr; c->d_candCount = nullptr; c->d_sel = nullptr; c->d_selCount = nullptr; c->d_kps = nullptr;
+    c->d_desc = nullptr; c->d_kpCount = nullptr; c->d_status = nullptr; c->d_uRight = nullptr; c->d_depth = nullptr;
+    c->d_gridOff = nullptr; c->d_gridIdx = nullptr; c->d_match = nullptr; c->d_matchCount = nullptr;
+    c->d_poses = nullptr; c->d_stage = nullptr;
+
+#define CREATE_FAIL(code)                 \
+    do {                                  \
+        g_create_err = c->err;            \
+        drfe_destroy(c);                  \
+        return (code);                    \
+    } while (0)
+#define CHIP(call)                                                                  \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess) {                                                    \
+            c->err = std::string(#call) + ": " + hipGetErrorString(e__);            \
+            CREATE_FAIL(DRFE_ERR_HIP);                                              \
+        }                                                                           \
+    } while (0)
+
+    CHIP(hipSetDevice(c->device));
+    CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < DRFE_STAGE_COUNT; i++)
+        for (int j = 0; j < 2; j++) CHIP(hipEventCreate(&c->ev[i][j]));
+    drfe_build_tables(c);
+
+    /* size the arenas with the geometry of the largest frame */
+    DevGeom gmax;
+    std::memset(&gmax, 0, sizeof(gmax));
+    std::vector<FastCell> cells;
+    std::vector<BlurTile> tiles;
+    std::vector<ResizeTap> taps;
+    int rc = drfe_build_geometry(c, cfg->max_width, cfg->max_height, &gmax, &cells, &tiles, &taps);
+    if (rc != DRFE_OK) CREATE_FAIL(rc);
+    const size_t B = (size_t)cfg->max_batch;
+    c->pyrSlotBytesMax = (size_t)gmax.pyrSlotBytes;
+    c->blurSlotBytesMax = (size_t)gmax.blurSlotBytes;
+    c->candSlotElemsMax = (size_t)gmax.candSlotElems;
+    c->maxKp = gmax.kpSlotElems;
+    c->cellsCap = (int)cells.size() + 64;
+    c->tilesCap = (int)tiles.size() + 64;
+    c->tapsCap = (int)taps.size() + 64;
+    const int nl = cfg->nlevels;
+
+    CHIP(dalloc(&c->d_geom, 1));
+    CHIP(dalloc(&c->d_cells, (size_t)c->cellsCap));
+    CHIP(dalloc(&c->d_tiles, (size_t)c->tilesCap));
+    CHIP(dalloc(&c->d_taps, (size_t)c->tapsCap));
+    CHIP(dalloc(&c->d_pattern, 1024));
+    CHIP(hipMemcpy(c->d_pattern, kPatternHost, 1024, hipMemcpyHostToDevice));
+    {   /* disc offsets of IC_Angle: rows v = -15..15, u = -umax[|v|]..umax[|v|] (749 pixels) */
+        std::vector<int16_t> disc;
+        for (int v = -DRFE_HALF_PATCH; v <= DRFE_HALF_PATCH; v++) {
+            const int d = c->umax[v < 0 ? -v : v];
+            for (int u = -d; u <= d; u++) { disc.push_back((int16_t)u); disc.push_back((int16_t)v); }
+        }
+        c->discCount = (int)disc.size() / 2;
+        CHIP(dalloc(&c->d_disc, disc.size()));
+        CHIP(hipMemcpy(c->d_disc, disc.data(), disc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    }
+    CHIP(dalloc(&c->d_pyr, B * c->pyrSlotBytesMax));
+    CHIP(dalloc(&c->d_blur, B * c->blurSlotBytesMax));
+    CHIP(dalloc(&c->d_cand0, B * c->candSlotElemsMax));
+    CHIP(dalloc(&c->d_cand1, B * c->candSlotElemsMax));
+    CHIP(dalloc(&c->d_node, B * c->candSlotElemsMax));
+    CHIP(dalloc(&c->d_candCount, B * nl));
+    CHIP(dalloc(&c->d_sel, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_selCount, B * nl));
+    CHIP(dalloc(&c->d_kps, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_desc, B * (size_t)c->maxKp * 32));
+    CHIP(dalloc(&c->d_kpCount, B));
+    CHIP(dalloc(&c->d_status, 4));
+    CHIP(dalloc(&c->d_uRight, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_depth, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_gridOff, B * (DRFE_GRID_CELLS + 1)));
+    CHIP(dalloc(&c->d_gridIdx, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_match, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_matchCount, B));
+    CHIP(dalloc(&c->d_poses, 2 * B * 16));
+    c->stageBytes = (size_t)cfg->max_width * cfg->max_height * 2;
+    CHIP(dalloc(&c->d_stage, c->stageBytes));
+    CHIP(hipMemset(c->d_kpCount, 0, sizeof(int) * B));
+    CHIP(hipMemset(c->d_selCount, 0, sizeof(int) * B * nl));
+    CHIP(hipMemset(c->d_status, 0, sizeof(int) * 4));
+#undef CHIP
+#undef CREATE_FAIL
+    *out = c;
+    return DRFE_OK;
+}
+
+int drfe_orb_scale_tables(const drfe_ctx* c, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    for (int i = 0; i < c->cfg.nlevels; i++) {
+        if (scale) scale[i] = c->scale[i];
+        if (inv_scale) inv_scale[i] = c->invScale[i];
+        if (sigma2) sigma2[i] = c->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = c->invSigma2[i];
+    }
+    return DRFE_OK;
+}
+
+int drfe_orb_max_keypoints(const drfe_ctx* c) { return c ? c->maxKp : DRFE_ERR_INVALID; }
+
+static int check_status(drfe_ctx* c)
+{
+    int st = 0;
+    HIPCHK(c, hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st & 1) { c->err = "FAST candidate arena overflow"; return DRFE_ERR_CAPACITY; }
+    if (st & 2) { c->err = "quadtree node pool overflow"; return DRFE_ERR_CAPACITY; }
+    if (st & 4) { c->err = "match candidate list overflow"; return DRFE_ERR_CAPACITY; }
+    return DRFE_OK;
+}
+
+int drfe_orb_extract_batch(drfe_ctx* c, const uint8_t* d_gray, size_t frame_stride, size_t row_stride, int w, int h,
+                           int nframes, void* stream)
+{
+    if (!c || !d_gray || nframes < 1 || nframes > c->cfg.max_batch || w < 1 || h < 1 || row_stride < (size_t)w) {
+        if (c) c->err = "drfe_orb_extract_batch: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = upload_geometry(c, w, h);
+    if (rc != DRFE_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, drfe_launch_orb(c, d_gray, frame_stride, row_stride, nframes, s));
+    c->lastBatch = nframes;
+    c->glueValid = false;
+    return DRFE_OK;
+}
+
+int drfe_stream_sync(drfe_ctx* c)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    return DRFE_OK;
+}
+
+int drfe_orb_counts(drfe_ctx* c, int nframes, int* counts)
+{
+    if (!c || !counts || nframes < 1 || nframes > c->lastBatch) return DRFE_ERR_INVALID;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    rc = check_status(c);
+    if (rc != DRFE_OK) return rc;
+    HIPCHK(c, hipMemcpy(counts, c->d_kpCount, sizeof(int) * nframes, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_orb_download(drfe_ctx* c, int slot, drfe_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!c || !n_out || slot < 0 || slot >= c->lastBatch) {
+        if (c) c->err = "drfe_orb_download: invalid slot";
+        return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    }
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    rc = check_status(c);
+    if (rc != DRFE_OK) return rc;
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > cap) { c->err = "keypoint buffer too small"; return DRFE_ERR_CAPACITY; }
+    if (n > 0 && kps)
+        HIPCHK(c, hipMemcpy(kps, c->d_kps + (size_t)slot * c->maxKp, sizeof(drfe_keypoint) * n, hipMemcpyDeviceToHost));
+    if (n > 0 && desc)
+        HIPCHK(c, hipMemcpy(desc, c->d_desc + (size_t)slot * c->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_orb_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stride, drfe_keypoint* kps, uint8_t* desc,
+                     int cap, int* n_out)
+{
+    if (!c || !n_out) return DRFE_ERR_INVALID;
+    *n_out = 0;
+    if (!gray || w == 0 || h == 0) return DRFE_OK; /* reference: silent return on empty image */
+    if (w < 0 || h < 0 || stride < (size_t)w || (size_t)w * h > c->stageBytes) {
+        c->err = "drfe_orb_extract: invalid image";
+        return DRFE_ERR_INVALID;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_stage, (size_t)w, gray, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice,
+                               c->stream));
+    int rc = drfe_orb_extract_batch(c, c->d_stage, (size_t)w * h, (size_t)w, w, h, 1, c->stream);
+    if (rc != DRFE_OK) return rc;
+    return drfe_orb_download(c, 0, kps, desc, cap, n_out);
+}
+
+int drfe_orb_pyramid_level(drfe_ctx* c, int slot, int level, uint8_t* out, int* bw, int* bh)
+{
+    if (!c || slot < 0 || slot >= c->lastBatch || level < 0 || level >= c->cfg.nlevels) return DRFE_ERR_INVALID;
+    const DevLevel& L = c->geom.lv[level];
+    const int W = L.w + 2 * DRFE_EDGE, H = L.h + 2 * DRFE_EDGE;
+    if (bw) *bw = W;
+    if (bh) *bh = H;
+    if (!out) return DRFE_OK;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    HIPCHK(c, hipMemcpy2D(out, (size_t)W, c->d_pyr + (size_t)slot * c->geom.pyrSlotBytes + L.pyrOff, (size_t)L.pyrPitch,
+                          (size_t)W, (size_t)H, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_orb_blurred_level(drfe_ctx* c, int slot, int level, uint8_t* out, int* w, int* h)
+{
+    if (!c || slot < 0 || slot >= c->lastBatch || level < 0 || level >= c->cfg.nlevels) return DRFE_ERR_INVALID;
+    const DevLevel& L = c->geom.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (!out) return DRFE_OK;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, c->d_blur + (size_t)slot * c->geom.blurSlotBytes + L.blurOff,
+                          (size_t)L.blurPitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_orb_candidates(drfe_ctx* c, int slot, int level, int32_t* xyr, int cap, int* n_out)
+{
+    if (!c || !n_out || slot < 0 || slot >= c->lastBatch || level < 0 || level >= c->cfg.nlevels) return DRFE_ERR_INVALID;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    rc = check_status(c);
+    if (rc != DRFE_OK) return rc;
+    const DevLevel& L = c->geom.lv[level];
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_candCount + (size_t)slot * c->cfg.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (!xyr) return DRFE_OK;
+    if (n > cap) return DRFE_ERR_CAPACITY;
+    std::vector<uint32_t> k0(n), k1(n);
+    const size_t off = (size_t)slot * c->geom.candSlotElems + L.candOff;
+    if (n) {
+        HIPCHK(c, hipMemcpy(k0.data(), c->d_cand0 + off, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(k1.data(), c->d_cand1 + off, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    }
+    /* report in emission order (the order key is unique) */
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; i++) perm[i] = i;
+    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return k1[a] < k1[b]; });
+    for (int i = 0; i < n; i++) {
+        const uint32_t k = k0[perm[i]];
+        xyr[3 * i] = (int32_t)(k & 0xFFF);
+        xyr[3 * i + 1] = (int32_t)((k >> 12) & 0xFFF);
+        xyr[3 * i + 2] = (int32_t)(k >> 24);
+    }
+    return DRFE_OK;
+}
+
+int drfe_profile_enable(drfe_ctx* c, int on)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    c->profile = on != 0;
+    std::memset(c->evUsed, 0, sizeof(c->evUsed));
+    return DRFE_OK;
+}
+
+int drfe_profile_stage_ms(drfe_ctx* c, float* ms)
+{
+    if (!c || !ms) return DRFE_ERR_INVALID;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    for (int i = 0; i < DRFE_STAGE_COUNT; i++) {
+        ms[i] = 0.f;
+        if (c->evUsed[i]) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, c->ev[i][0], c->ev[i][1]) == hipSuccess) ms[i] = t;
+        }
+    }
+    return DRFE_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,300 @@
+/* capi_match.cpp — C-ABI entry points of the Frame glue and the matchers (include/drfe.h). */
+#include "drfe_internal.h"
+#include "match_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return DRFE_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+template <class T>
+static hipError_t dalloc(T** p, size_t n)
+{
+    *p = nullptr;
+    return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+void drfe_match_buffers_free(drfe_ctx* c)
+{
+    MatchBuffers* m = c->mb;
+    if (!m) return;
+    void* ptrs[] = {m->d_pairs, m->d_queries, m->d_mps, m->d_scale, m->d_candIdx, m->d_candKey, m->d_candCnt,
+                    m->d_hist, m->d_initObs, m->d_bfIdx, m->d_bfDist, m->d_bfQ, m->d_bfT};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete m;
+    c->mb = nullptr;
+}
+
+MatchBuffers* drfe_match_buffers(drfe_ctx* c)
+{
+    if (c->mb) return c->mb;
+    MatchBuffers* m = new (std::nothrow) MatchBuffers();
+    if (!m) return nullptr;
+    std::memset(m, 0, sizeof(*m));
+    c->mb = m;
+    const size_t B = (size_t)c->cfg.max_batch, Q = B * (size_t)c->maxKp;
+    m->queryCap = Q;
+    m->bfCap = std::max<size_t>(Q, 4096);
+    bool ok = dalloc(&m->d_pairs, B) == hipSuccess && dalloc(&m->d_queries, Q) == hipSuccess &&
+              dalloc(&m->d_mps, Q) == hipSuccess && dalloc(&m->d_scale, DRFE_MAX_LEVELS) == hipSuccess &&
+              dalloc(&m->d_candIdx, Q * DRFE_MATCH_MAX_CAND) == hipSuccess &&
+              dalloc(&m->d_candKey, Q * DRFE_MATCH_MAX_CAND) == hipSuccess && dalloc(&m->d_candCnt, Q) == hipSuccess &&
+              dalloc(&m->d_hist, B * 2 * (size_t)c->maxKp) == hipSuccess &&
+              dalloc(&m->d_initObs, (size_t)c->maxKp) == hipSuccess && dalloc(&m->d_bfIdx, m->bfCap * 2) == hipSuccess &&
+              dalloc(&m->d_bfDist, m->bfCap * 2) == hipSuccess && dalloc(&m->d_bfQ, m->bfCap * 32) == hipSuccess &&
+              dalloc(&m->d_bfT, m->bfCap * 32) == hipSuccess;
+    if (ok)
+        ok = hipMemcpy(m->d_scale, c->scale.data(), sizeof(float) * c->cfg.nlevels, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        c->err = "matcher scratch allocation failed";
+        drfe_match_buffers_free(c);
+        return nullptr;
+    }
+    return m;
+}
+
+/* bForward / bBackward of reference src/ORBmatcher.cc:1406-1414.  `-Rcw.t()*tcw` takes OpenCV's general
+ * gemm path (double accumulation, alpha = -1); `Rlw*twc+tlw` the float small-matrix path. */
+static void motion_flags(const float* TcwCur, const float* TcwLast, float mb, int mono, int* fwd, int* bwd)
+{
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)TcwCur[k * 4 + i] * (double)TcwCur[k * 4 + 3];
+        twc[i] = (float)(s * -1.0);
+    }
+    for (int r = 0; r < 3; r++) {
+        const float d = TcwLast[r * 4 + 0] * twc[0] + TcwLast[r * 4 + 1] * twc[1] + TcwLast[r * 4 + 2] * twc[2];
+        tlc[r] = d + TcwLast[r * 4 + 3];
+    }
+    *fwd = (tlc[2] > mb && !mono) ? 1 : 0;
+    *bwd = (-tlc[2] > mb && !mono) ? 1 : 0;
+}
+
+static int match_status(drfe_ctx* c)
+{
+    int st = 0;
+    HIPCHK(c, hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st & 4) { c->err = "match candidate list overflow (DRFE_MATCH_MAX_CAND)"; return DRFE_ERR_CAPACITY; }
+    return DRFE_OK;
+}
+
+extern "C" {
+
+int drfe_frame_stereo_grid_batch(drfe_ctx* c, const uint16_t* d_depth, size_t frame_stride, size_t row_stride,
+                                 const drfe_camera* cam, int nframes, void* stream)
+{
+    if (!c || !d_depth || !cam) return DRFE_ERR_INVALID;
+    if (nframes < 1 || nframes > c->lastBatch) { c->err = "glue: extract the batch first"; return DRFE_ERR_STATE; }
+    if (!(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { c->err = "glue: empty image bounds"; return DRFE_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, drfe_launch_glue(c, d_depth, frame_stride, row_stride, *cam, nframes, s));
+    c->glueValid = true;
+    c->cam = *cam;
+    return DRFE_OK;
+}
+
+int drfe_frame_download_stereo(drfe_ctx* c, int slot, float* u_right, float* depth, int cap)
+{
+    if (!c || slot < 0 || slot >= c->lastBatch || !c->glueValid) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) return DRFE_ERR_CAPACITY;
+    if (n && u_right) HIPCHK(c, hipMemcpy(u_right, c->d_uRight + (size_t)slot * c->maxKp, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (n && depth) HIPCHK(c, hipMemcpy(depth, c->d_depth + (size_t)slot * c->maxKp, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_frame_download_grid(drfe_ctx* c, int slot, int32_t* offsets, int32_t* indices, int cap)
+{
+    if (!c || !offsets || slot < 0 || slot >= c->lastBatch || !c->glueValid) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    HIPCHK(c, hipMemcpy(offsets, c->d_gridOff + (size_t)slot * (DRFE_GRID_CELLS + 1), sizeof(int) * (DRFE_GRID_CELLS + 1),
+                        hipMemcpyDeviceToHost));
+    const int n = offsets[DRFE_GRID_CELLS];
+    if (n > cap) return DRFE_ERR_CAPACITY;
+    if (n && indices) HIPCHK(c, hipMemcpy(indices, c->d_gridIdx + (size_t)slot * c->maxKp, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc, const drfe_camera* cam, float th,
+                                 int mono, int check_ori, int nframes, void* stream)
+{
+    if (!c || !Tcw || !Twc || !cam) return DRFE_ERR_INVALID;
+    if (nframes < 2 || nframes > c->lastBatch || !c->glueValid) {
+        c->err = "match: needs an extracted batch of >= 2 frames with stereo/grid computed";
+        return DRFE_ERR_STATE;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const int np = nframes - 1;
+    std::vector<MatchPair> pairs(np);
+    const float mb = cam->bf / cam->fx;
+    for (int p = 0; p < np; p++) {
+        MatchPair& P = pairs[p];
+        P.curSlot = p + 1; P.lastSlot = p; P.mpSlot = p; P.nQueries = 0;
+        P.queryBase = p * c->maxKp;
+        P.mpBase = p * c->maxKp;   /* k_mappoints_last writes slot-major */
+        std::memcpy(P.Tcw, Tcw + (size_t)(p + 1) * 16, sizeof(float) * 16);
+        motion_flags(Tcw + (size_t)(p + 1) * 16, Tcw + (size_t)p * 16, mb, mono, &P.forward, &P.backward);
+    }
+    /* the launch stream must not overtake these host staging copies */
+    HIPCHK(c, hipMemcpyAsync(m->d_pairs, pairs.data(), sizeof(MatchPair) * np, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, Twc, sizeof(float) * 16 * nframes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (c->profile) { (void)hipEventRecord(c->ev[DRFE_STAGE_MATCH][0], s); c->evUsed[DRFE_STAGE_MATCH] = true; }
+    HIPCHK(c, hipMemsetAsync(c->d_match, 0xFF, sizeof(int) * (size_t)nframes * c->maxKp, s));
+    HIPCHK(c, hipMemsetAsync(c->d_matchCount, 0, sizeof(int) * nframes, s));
+    HIPCHK(c, drfe_launch_mappoints_last(c, *m, *cam, c->d_poses, nframes, s));
+    HIPCHK(c, drfe_launch_window_match(c, *m, *cam, np, c->maxKp, 0, th, 0.f, check_ori, nullptr, s));
+    if (c->profile) (void)hipEventRecord(c->ev[DRFE_STAGE_MATCH][1], s);
+    return DRFE_OK;
+}
+
+int drfe_match_download(drfe_ctx* c, int slot, int32_t* cur_to_last, int cap, int* nmatches)
+{
+    if (!c || slot < 0 || slot >= c->lastBatch) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    rc = match_status(c);
+    if (rc != DRFE_OK) return rc;
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) return DRFE_ERR_CAPACITY;
+    if (n && cur_to_last)
+        HIPCHK(c, hipMemcpy(cur_to_last, c->d_match + (size_t)slot * c->maxKp, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (nmatches) HIPCHK(c, hipMemcpy(nmatches, c->d_matchCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_search_by_projection_last(drfe_ctx* c, int cur_slot, int last_slot, const float* Tcw_cur, const float* Tcw_last,
+                                   const drfe_camera* cam, const drfe_map_point* last_mp, int n_last, float th, int mono,
+                                   int check_ori, const uint8_t* cur_obs, int32_t* cur_mp, int n_cur, int* nmatches)
+{
+    if (!c || !Tcw_cur || !Tcw_last || !cam || !last_mp || !cur_mp || !nmatches) return DRFE_ERR_INVALID;
+    if (cur_slot < 0 || cur_slot >= c->lastBatch || last_slot < 0 || last_slot >= c->lastBatch || !c->glueValid) {
+        c->err = "search_by_projection_last: slots not ready";
+        return DRFE_ERR_STATE;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int counts[2];
+    HIPCHK(c, hipMemcpy(&counts[0], c->d_kpCount + cur_slot, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&counts[1], c->d_kpCount + last_slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_cur != counts[0] || n_last != counts[1]) { c->err = "search_by_projection_last: N mismatch"; return DRFE_ERR_INVALID; }
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    MatchPair P;
+    P.curSlot = cur_slot; P.lastSlot = last_slot; P.mpSlot = -1; P.nQueries = n_last; P.queryBase = 0; P.mpBase = 0;
+    std::memcpy(P.Tcw, Tcw_cur, sizeof(float) * 16);
+    motion_flags(Tcw_cur, Tcw_last, cam->bf / cam->fx, mono, &P.forward, &P.backward);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpy(m->d_pairs, &P, sizeof(P), hipMemcpyHostToDevice));
+    if (n_last) HIPCHK(c, hipMemcpy(m->d_mps, last_mp, sizeof(drfe_map_point) * n_last, hipMemcpyHostToDevice));
+    if (n_cur) HIPCHK(c, hipMemcpy(c->d_match + (size_t)cur_slot * c->maxKp, cur_mp, sizeof(int) * n_cur, hipMemcpyHostToDevice));
+    const uint8_t* d_obs = nullptr;
+    if (cur_obs && n_cur) {
+        HIPCHK(c, hipMemcpy(m->d_initObs, cur_obs, n_cur, hipMemcpyHostToDevice));
+        d_obs = m->d_initObs;
+    }
+    *nmatches = 0;
+    if (n_last == 0 || n_cur == 0) return DRFE_OK;
+    HIPCHK(c, drfe_launch_window_match(c, *m, *cam, 1, n_last, 0, th, 0.f, check_ori, d_obs, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    rc = match_status(c);
+    if (rc != DRFE_OK) return rc;
+    HIPCHK(c, hipMemcpy(cur_mp, c->d_match + (size_t)cur_slot * c->maxKp, sizeof(int) * n_cur, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nmatches, c->d_matchCount + cur_slot, sizeof(int), hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_search_by_projection_map(drfe_ctx* c, int slot, const drfe_tracked_point* mps, int mcount, float th,
+                                  float nnratio, const uint8_t* claim_obs, int32_t* frame_mp, int n, int* nmatches)
+{
+    if (!c || !mps || !frame_mp || !nmatches || mcount < 0) return DRFE_ERR_INVALID;
+    if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = "search_by_projection_map: slot not ready"; return DRFE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int cnt = 0;
+    HIPCHK(c, hipMemcpy(&cnt, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n != cnt) { c->err = "search_by_projection_map: N mismatch"; return DRFE_ERR_INVALID; }
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    if ((size_t)mcount > m->queryCap) { c->err = "search_by_projection_map: too many map points for the scratch"; return DRFE_ERR_CAPACITY; }
+    *nmatches = 0;
+    if (mcount == 0 || n == 0) return DRFE_OK;
+    /* window parameters per map point, src/ORBmatcher.cc:62-70 (RadiusByViewingCos, r*=th) */
+    std::vector<MatchQuery> q(mcount);
+    const bool bFactor = th != 1.0;
+    for (int i = 0; i < mcount; i++) {
+        const drfe_tracked_point& t = mps[i];
+        MatchQuery& Q = q[i];
+        std::memset(&Q, 0, sizeof(Q));
+        Q.valid = (t.track_in_view && !t.bad) ? 1 : 0;
+        if (Q.valid && (t.level < 0 || t.level >= c->cfg.nlevels)) { c->err = "tracked point level out of range"; return DRFE_ERR_INVALID; }
+        float r = ((double)t.view_cos > 0.998) ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        const float rs = Q.valid ? r * c->scale[t.level] : 0.f;
+        Q.u = t.proj_x; Q.v = t.proj_y; Q.radius = rs; Q.ur = t.proj_xr; Q.thrR = rs;
+        Q.minLevel = t.level - 1; Q.maxLevel = t.level;
+        Q.obs = t.obs_positive;
+        std::memcpy(Q.desc, t.desc, 32);
+    }
+    MatchPair P;
+    std::memset(&P, 0, sizeof(P));
+    P.curSlot = slot; P.lastSlot = slot; P.mpSlot = -1; P.nQueries = mcount; P.queryBase = 0; P.mpBase = 0;
+    const drfe_camera cam = c->cam;   /* frame bounds / grid of the glue call that built this slot */
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpy(m->d_pairs, &P, sizeof(P), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(m->d_queries, q.data(), sizeof(MatchQuery) * mcount, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_match + (size_t)slot * c->maxKp, frame_mp, sizeof(int) * n, hipMemcpyHostToDevice));
+    const uint8_t* d_obs = nullptr;
+    if (claim_obs) {
+        HIPCHK(c, hipMemcpy(m->d_initObs, claim_obs, n, hipMemcpyHostToDevice));
+        d_obs = m->d_initObs;
+    }
+    HIPCHK(c, drfe_launch_window_match(c, *m, cam, 1, mcount, 1, th, nnratio, 0, d_obs, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    rc = match_status(c);
+    if (rc != DRFE_OK) return rc;
+    HIPCHK(c, hipMemcpy(frame_mp, c->d_match + (size_t)slot * c->maxKp, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nmatches, c->d_matchCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_match_bf_knn(drfe_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, int32_t* dist)
+{
+    if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || k < 1 || k > 2) return DRFE_ERR_INVALID;
+    if (nq == 0) return DRFE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    if ((size_t)nq > m->bfCap || (size_t)nt > m->bfCap) { c->err = "bf_knn: descriptor set larger than the scratch"; return DRFE_ERR_CAPACITY; }
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(m->d_bfQ, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if (nt) HIPCHK(c, hipMemcpyAsync(m->d_bfT, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(c, drfe_launch_bf_knn(m->d_bfQ, nq, m->d_bfT, nt, k, m->d_bfIdx, m->d_bfDist, s));
+    HIPCHK(c, hipMemcpyAsync(idx, m->d_bfIdx, sizeof(int) * (size_t)nq * k, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(dist, m->d_bfDist, sizeof(int) * (size_t)nq * k, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return DRFE_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,146 @@
+/* drfe_internal.h — host-side context and the HBM layout of a batch.
+ *
+ * One context owns, for `max_batch` frame slots, frame-major arenas:
+ *   pyr    bordered pyramid, all levels of a slot contiguous (level l at lv[l].pyrOff, row pitch
+ *          lv[l].pyrPitch = align64(w_l + 38))
+ *   blur   blurred interior levels (pitch align64(w_l))
+ *   cand   FAST candidates per (slot, level): key0 = x | y<<12 | response<<24, key1 = emission-order key
+ *   node   quadtree scratch: node id per candidate (u16)
+ *   sel    keypoints chosen by the quadtree per (slot, level), list order
+ *   kps / desc / counts   final outputs, level-major per slot
+ *   glue   depth, uRight, 64x48 grid CSR per slot; match results per slot
+ */
+#ifndef DRFE_INTERNAL_H
+#define DRFE_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/drfe.h"
+
+#define DRFE_MAX_LEVELS 16
+#define DRFE_EDGE 19          /* EDGE_THRESHOLD, reference src/ORBextractor.cc:72 */
+#define DRFE_HALF_PATCH 15    /* HALF_PATCH_SIZE, :71 */
+#define DRFE_GRID_COLS 64     /* FRAME_GRID_COLS, reference include/Frame.h:40 */
+#define DRFE_GRID_ROWS 48     /* FRAME_GRID_ROWS, :39 */
+#define DRFE_GRID_CELLS (DRFE_GRID_COLS * DRFE_GRID_ROWS)
+#define DRFE_FAST_TILE_PITCH 72   /* LDS pitch of a FAST cell window (<= 68 px wide) */
+#define DRFE_FAST_MAX_WIN 68
+#define DRFE_QT_MAX_NODES 1024    /* quadtree list capacity per level (>= quota + 4) */
+#define DRFE_MATCH_MAX_CAND 256   /* candidates kept per query by the window gather */
+
+/* per-level constants shared by host and kernels (passed by value inside DevGeom) */
+struct DevLevel {
+    int w, h;                 /* interior */
+    int pyrPitch, pyrOff;     /* bordered image: pitch, byte offset inside the slot's pyramid block */
+    int blurPitch, blurOff;
+    int quota;
+    int minBX, minBY, maxBX, maxBY;
+    int nCols, nRows, wCell, hCell;
+    int candCap, candOff;     /* element offset inside the slot's candidate arrays */
+    int kpCap, kpOff;         /* element offset inside the slot's sel/kps arrays */
+    int nIni;
+    float hX;
+    float scale;              /* mvScaleFactor[l] */
+    float kpSize;             /* (float)(int)(31*scale) */
+    int xtabOff, ytabOff;     /* resize coefficient tables (level >= 1), element offsets */
+    int cellBegin, cellEnd;   /* range in the FAST cell table */
+    int tileBegin, tileEnd;   /* range in the blur tile table */
+};
+
+struct DevGeom {
+    int nlevels;
+    int iniTh, minTh;
+    int imgW, imgH;
+    int pyrSlotBytes, blurSlotBytes;
+    int candSlotElems, kpSlotElems; /* per-slot element counts */
+    int totalCells, totalTiles;
+    DevLevel lv[DRFE_MAX_LEVELS];
+};
+
+struct FastCell {   /* one cv::FAST call of reference src/ORBextractor.cc:789-816 */
+    uint16_t x0, y0;        /* window origin in interior coordinates */
+    uint8_t ww, wh;         /* window size (<= 68) */
+    uint8_t level, pad;
+    uint16_t offX, offY;    /* j*wCell, i*hCell added to the keypoint (:822-823) */
+    uint32_t cellIdx;       /* i*nCols + j: emission order of the cell */
+};
+
+struct BlurTile { uint16_t tx, ty; uint16_t level, pad; };
+
+struct ResizeTap { uint16_t s0, s1; int16_t w0, w1; };
+
+struct drfe_ctx {
+    drfe_config cfg;
+    int device;
+    hipStream_t stream;       /* context-owned stream (used when caller passes NULL) */
+    std::string err;
+
+    /* host tables */
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> quota;
+    int umax[DRFE_HALF_PATCH + 1];
+    DevGeom geom;             /* current geometry (imgW/imgH == 0 until first frame) */
+    int maxKp;                /* per-slot keypoint capacity (sum of level caps) for max geometry */
+
+    /* device tables */
+    DevGeom* d_geom;
+    FastCell* d_cells; int cellsCap;
+    BlurTile* d_tiles; int tilesCap;
+    ResizeTap* d_taps; int tapsCap;
+    int8_t* d_pattern;        /* 1024 */
+    int16_t* d_disc;          /* 749 x (u,v) */
+    int discCount;
+
+    /* arenas (sized for max geometry x max_batch) */
+    uint8_t* d_pyr; size_t pyrSlotBytesMax;
+    uint8_t* d_blur; size_t blurSlotBytesMax;
+    uint32_t* d_cand0; uint32_t* d_cand1; uint16_t* d_node; size_t candSlotElemsMax;
+    int* d_candCount;         /* [slot][level] */
+    uint32_t* d_sel;          /* [slot][kpSlotElems] packed x|y<<12|resp<<24 */
+    int* d_selCount;          /* [slot][level] */
+    drfe_keypoint* d_kps;     /* [slot][maxKp] */
+    uint8_t* d_desc;          /* [slot][maxKp][32] */
+    int* d_kpCount;           /* [slot] */
+    int* d_status;            /* device-side error flags (overflow) */
+
+    /* frame glue + match */
+    float* d_uRight; float* d_depth;      /* [slot][maxKp] */
+    int* d_gridOff; int* d_gridIdx;       /* [slot][3073], [slot][maxKp] */
+    int* d_match; int* d_matchCount;      /* [slot][maxKp], [slot] */
+    float* d_poses;                       /* per-batch Tcw/Twc staging: [2][max_batch][16] */
+    uint8_t* d_stage;                     /* staging for single-frame host API */
+    size_t stageBytes;
+
+    int lastBatch;            /* frames in the most recent batch */
+    bool glueValid;
+    drfe_camera cam;          /* camera of the most recent glue call */
+
+    struct MatchBuffers* mb;  /* lazily allocated matcher scratch (match_internal.h) */
+
+    /* profiling */
+    bool profile;
+    hipEvent_t ev[DRFE_STAGE_COUNT][2];
+    bool evUsed[DRFE_STAGE_COUNT];
+};
+
+/* orb_geometry.cpp */
+int drfe_build_tables(drfe_ctx* c);                       /* scale tables, quotas, umax */
+int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastCell>* cells,
+                        std::vector<BlurTile>* tiles, std::vector<ResizeTap>* taps);
+
+/* orb_kernels.hip */
+hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStride, size_t rowStride, int nframes,
+                           hipStream_t s);
+/* match_kernels.hip */
+hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameStride, size_t rowStride,
+                            const drfe_camera& cam, int nframes, hipStream_t s);
+hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, float th, int mono, int checkOri,
+                                         int nframes, hipStream_t s);
+
+#define DRFE_BLUR_TW 64
+#define DRFE_BLUR_TH 16
+
+#endif

@@ -1,0 +1,51 @@
+/* match_internal.h — device records shared by match_kernels.hip and capi_match.cpp */
+#ifndef DRFE_MATCH_INTERNAL_H
+#define DRFE_MATCH_INTERNAL_H
+#include "drfe_internal.h"
+
+/* one matcher invocation: queries (map points) against the keypoints of slot `curSlot` */
+struct MatchPair {
+    int curSlot, lastSlot;
+    int mpSlot;      /* >= 0: one query per keypoint of lastSlot (count read on device); < 0: nQueries */
+    int nQueries;
+    int queryBase;   /* element offset into the query / candidate-count arrays */
+    int mpBase;      /* element offset into the map-point array */
+    int forward, backward;   /* bForward / bBackward, reference src/ORBmatcher.cc:1413-1414 */
+    float Tcw[16];   /* CurrentFrame.mTcw */
+};
+
+/* one search window: what the candidate loop of the reference reads per map point */
+struct MatchQuery {
+    float u, v, radius;   /* GetFeaturesInArea(u, v, radius, minLevel, maxLevel) */
+    float ur, thrR;       /* stereo gate: skip if |ur - mvuRight[i2]| > thrR when mvuRight[i2] > 0 */
+    int minLevel, maxLevel;
+    int valid;
+    int obs;              /* Observations() > 0 of this map point (claims by it are permanent) */
+    uint32_t desc[8];
+};
+
+struct MatchBuffers {
+    MatchPair* d_pairs;
+    MatchQuery* d_queries;
+    drfe_map_point* d_mps;
+    float* d_scale;           /* mvScaleFactors */
+    uint32_t* d_candIdx;      /* [query][DRFE_MATCH_MAX_CAND]: keypoint index | octave << 24 */
+    uint32_t* d_candKey;      /* distance << 22 | visit position */
+    int* d_candCnt;
+    uint16_t* d_hist;         /* rotation histogram entries per pair: (bin, idx) */
+    uint8_t* d_initObs;       /* [maxKp] staging of caller-supplied claim flags */
+    int32_t* d_bfIdx; int32_t* d_bfDist; uint8_t* d_bfQ; uint8_t* d_bfT; size_t bfCap; /* elements / bytes */
+    size_t queryCap;          /* queries the buffers hold */
+};
+
+hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,
+                                    int maxQueries, int mode, float th, float nnratio, int checkOri,
+                                    const uint8_t* d_initObs, hipStream_t s);
+hipError_t drfe_launch_mappoints_last(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, const float* d_Twc,
+                                      int nframes, hipStream_t s);
+hipError_t drfe_launch_bf_knn(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, int k, int* dIdx, int* dDist,
+                              hipStream_t s);
+
+MatchBuffers* drfe_match_buffers(drfe_ctx* c);   /* lazily allocated, owned by the context */
+void drfe_match_buffers_free(drfe_ctx* c);
+#endif

@@ -1,0 +1,560 @@
+/* match_kernels.hip — gfx950 kernels of the Frame glue and the windowed Hamming matchers
+ *  and the brute-force matcher (a-11/a-14).
+ *
+ *   k_stereo            Frame::ComputeStereoFromRGBD                  (reference src/Frame.cc:893-911)
+ *   k_grid              Frame::AssignFeaturesToGrid / PosInGrid       (:224-237, 816-825) -> CSR
+ *   k_mappoints_last    Frame::UnprojectStereo of the last frame      (:913-923)
+ *   k_queries_last      projection part of SearchByProjection(F,F)    (src/ORBmatcher.cc:1417-1455)
+ *   k_window_candidates Frame::GetFeaturesInArea + DescriptorDistance (src/Frame.cc:730-779, ORBmatcher.cc:1712)
+ *   k_resolve_last      claim / best / rotation histogram             (src/ORBmatcher.cc:1459-1531)
+ *   k_resolve_map       claim / best+second / ratio                   (:75-127)
+ *   k_bf_knn            cv::BFMatcher(NORM_HAMMING) 1-NN / 2-NN
+ *
+ * The reference's matchers are sequential in the map-point index (a keypoint claimed by an earlier
+ * map point is skipped by later ones).  The split used here: an order-free, fully parallel kernel
+ * computes for every query the Hamming distance to every keypoint of its search window, tagged with
+ * the position the reference's cell scan would visit it at; a one-wavefront-per-frame kernel then
+ * replays the claims in map-point order, picking min(distance, visit position) among unclaimed
+ * candidates — the same winner as the reference's strict `dist < bestDist` scan.
+ */
+#include "drfe_internal.h"
+#include "match_internal.h"
+#include "../../include/drfe_math.h"
+
+#define WAVE 64
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Frame glue                                                                                        */
+
+__global__ __launch_bounds__(256) void k_stereo(const drfe_keypoint* __restrict__ kps, const int* __restrict__ kpCount,
+                                                int maxKp, const uint16_t* __restrict__ depth, size_t frameStride,
+                                                size_t rowStride, int w, int h, drfe_camera cam,
+                                                float* __restrict__ uRight, float* __restrict__ zDepth)
+{
+    const int slot = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kpCount[slot]) return;
+    const drfe_keypoint kp = kps[(size_t)slot * maxKp + i];
+    /* imDepth.at<float>(v,u) with float indices: truncation; depth = raw * factor in
+     * float32 (imDepth.convertTo(CV_32F, factor), src/Frame.cc:113-115) */
+    const int v = (int)kp.y, u = (int)kp.x;
+    float d = 0.f;
+    if (u >= 0 && u < w && v >= 0 && v < h)
+        d = (float)depth[(size_t)slot * frameStride + (size_t)v * rowStride + u] * cam.depth_factor;
+    float ur = -1.f, z = -1.f;
+    if (d > 0) { z = d; ur = kp.x - cam.bf / d; }
+    uRight[(size_t)slot * maxKp + i] = ur;
+    zDepth[(size_t)slot * maxKp + i] = z;
+}
+
+__device__ __forceinline__ int grid_cell(const drfe_keypoint& kp, const drfe_camera& cam, float invW, float invH)
+{
+    const int px = (int)roundf((kp.x - cam.min_x) * invW);
+    const int py = (int)roundf((kp.y - cam.min_y) * invH);
+    if (px < 0 || px >= DRFE_GRID_COLS || py < 0 || py >= DRFE_GRID_ROWS) return -1;
+    return px * DRFE_GRID_ROWS + py;   /* mGrid[px][py] */
+}
+
+/* one workgroup per slot: count -> scan -> fill -> per-cell ascending sort (== insertion order) */
+__global__ __launch_bounds__(256) void k_grid(const drfe_keypoint* __restrict__ kps, const int* __restrict__ kpCount,
+                                              int maxKp, drfe_camera cam, float invW, float invH,
+                                              int* __restrict__ gridOff, int* __restrict__ gridIdx)
+{
+    __shared__ int cnt[DRFE_GRID_CELLS];
+    __shared__ int off[DRFE_GRID_CELLS + 1];
+    __shared__ int part[256];
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int n = kpCount[slot];
+    const drfe_keypoint* K = kps + (size_t)slot * maxKp;
+    int* gIdx = gridIdx + (size_t)slot * maxKp;
+    int* gOff = gridOff + (size_t)slot * (DRFE_GRID_CELLS + 1);
+    for (int c = tid; c < DRFE_GRID_CELLS; c += 256) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = grid_cell(K[i], cam, invW, invH);
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    const int per = DRFE_GRID_CELLS / 256; /* 12 */
+    int s = 0;
+    for (int k = 0; k < per; k++) s += cnt[tid * per + k];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (tid >= o) ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int k = 0; k < per; k++) { off[tid * per + k] = run; run += cnt[tid * per + k]; }
+    if (tid == 255) off[DRFE_GRID_CELLS] = run;
+    __syncthreads();
+    for (int c = tid; c <= DRFE_GRID_CELLS; c += 256) gOff[c] = off[c];
+    for (int c = tid; c < DRFE_GRID_CELLS; c += 256) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = grid_cell(K[i], cam, invW, invH);
+        if (c >= 0) gIdx[off[c] + atomicAdd(&cnt[c], 1)] = i;
+    }
+    __syncthreads();
+    for (int c = tid; c < DRFE_GRID_CELLS; c += 256) {
+        const int b = off[c], e = off[c + 1];
+        for (int a = b + 1; a < e; a++) {
+            const int v = gIdx[a];
+            int j = a - 1;
+            while (j >= b && gIdx[j] > v) { gIdx[j + 1] = gIdx[j]; j--; }
+            gIdx[j + 1] = v;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* queries for SearchByProjection(CurrentFrame, LastFrame)                                           */
+
+/* (3x3)*(3x1)+(3x1) in float32 exactly as OpenCV's small-matrix gemm path evaluates
+ * `Rcw*x3Dw+tcw`: float dot product left to right, then one add (SURVEY.md §10 / oracle). */
+__device__ __forceinline__ void mat3_mul_add(const float* T /* 4x4 row-major */, const float x[3], float out[3])
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float d = T[r * 4 + 0] * x[0] + T[r * 4 + 1] * x[1] + T[r * 4 + 2] * x[2];
+        out[r] = d + T[r * 4 + 3];
+    }
+}
+
+/* map points of the last frame = its keypoints with depth, unprojected with Twc (UnprojectStereo) */
+__global__ __launch_bounds__(256) void k_mappoints_last(const drfe_keypoint* __restrict__ kps,
+                                                        const uint8_t* __restrict__ desc,
+                                                        const int* __restrict__ kpCount, int maxKp,
+                                                        const float* __restrict__ zDepth, drfe_camera cam,
+                                                        const float* __restrict__ Twc /* [slot][16] */,
+                                                        drfe_map_point* __restrict__ mps)
+{
+    const int slot = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kpCount[slot]) return;
+    const size_t o = (size_t)slot * maxKp + i;
+    drfe_map_point mp;
+    const float z = zDepth[o];
+    mp.valid = z > 0 ? 1 : 0;
+    mp.obs_positive = 1;
+    mp.pad[0] = mp.pad[1] = 0;
+    mp.world[0] = mp.world[1] = mp.world[2] = 0.f;
+    if (z > 0) {
+        const float invfx = 1.0f / cam.fx, invfy = 1.0f / cam.fy;
+        const drfe_keypoint kp = kps[o];
+        float p[3];
+        p[0] = (kp.x - cam.cx) * z * invfx;
+        p[1] = (kp.y - cam.cy) * z * invfy;
+        p[2] = z;
+        mat3_mul_add(Twc + (size_t)slot * 16, p, mp.world);
+    }
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(desc + o * 32);
+    uint32_t* md = reinterpret_cast<uint32_t*>(mp.desc);
+#pragma unroll
+    for (int k = 0; k < 8; k++) md[k] = d[k];
+    mps[o] = mp;
+}
+
+/* one thread per last-frame map point: project into the current frame, emit the window query */
+__global__ __launch_bounds__(256) void k_queries_last(const MatchPair* __restrict__ pairs,
+                                                      const drfe_keypoint* __restrict__ kps,
+                                                      const int* __restrict__ kpCount, int maxKp,
+                                                      const drfe_map_point* __restrict__ mps, drfe_camera cam,
+                                                      const float* __restrict__ scaleFactors, float th,
+                                                      MatchQuery* __restrict__ queries)
+{
+    const MatchPair P = pairs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nLast = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
+    if (i >= nLast) return;
+    MatchQuery q;
+    q.valid = 0;
+    q.u = q.v = q.radius = q.ur = q.thrR = 0.f;
+    q.minLevel = q.maxLevel = -1;
+    q.obs = 0;
+    const drfe_map_point mp = mps[(size_t)P.mpBase + i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) q.desc[k] = reinterpret_cast<const uint32_t*>(mp.desc)[k];
+    q.obs = mp.obs_positive;
+    if (mp.valid) {
+        float xc[3];
+        mat3_mul_add(P.Tcw, mp.world, xc);
+        const float invzc = (float)(1.0 / (double)xc[2]);
+        if (!(invzc < 0)) {
+            const float u = cam.fx * xc[0] * invzc + cam.cx;
+            const float v = cam.fy * xc[1] * invzc + cam.cy;
+            if (!(u < cam.min_x || u > cam.max_x) && !(v < cam.min_y || v > cam.max_y)) {
+                const int oct = kps[(size_t)P.lastSlot * maxKp + i].octave;
+                const float radius = th * scaleFactors[oct];
+                q.u = u; q.v = v; q.radius = radius; q.thrR = radius;
+                q.ur = u - cam.bf * invzc;
+                if (P.forward) { q.minLevel = oct; q.maxLevel = -1; }
+                else if (P.backward) { q.minLevel = 0; q.maxLevel = oct; }
+                else { q.minLevel = oct - 1; q.maxLevel = oct + 1; }
+                q.valid = 1;
+            }
+        }
+    }
+    queries[(size_t)P.queryBase + i] = q;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* window gather + Hamming: one wavefront per query                                                  */
+
+__global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __restrict__ pairs,
+                                                           const MatchQuery* __restrict__ queries,
+                                                           const drfe_keypoint* __restrict__ kps,
+                                                           const uint8_t* __restrict__ desc,
+                                                           const float* __restrict__ uRight,
+                                                           const int* __restrict__ kpCount, int maxKp,
+                                                           const int* __restrict__ gridOff,
+                                                           const int* __restrict__ gridIdx, drfe_camera cam,
+                                                           float invW, float invH,
+                                                           uint32_t* __restrict__ candIdx,
+                                                           uint32_t* __restrict__ candKey,
+                                                           int* __restrict__ candCnt, int* __restrict__ status)
+{
+    __shared__ int sCnt[256 / WAVE];
+    const MatchPair P = pairs[blockIdx.y];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * (256 / WAVE) + wv;
+    const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
+    if (qi >= nQ) return;                       /* wave-uniform */
+    const size_t qo = (size_t)P.queryBase + qi;
+    const MatchQuery q = queries[qo];
+    if (lane == 0) sCnt[wv] = 0;
+    if (!q.valid) { if (lane == 0) candCnt[qo] = 0; return; }
+    const float x = q.u, y = q.v, r = q.radius;
+    /* Frame::GetFeaturesInArea cell range, src/Frame.cc:735-749 */
+    const int nMinCellX = max(0, (int)floorf((x - cam.min_x - r) * invW));
+    const int nMaxCellX = min(DRFE_GRID_COLS - 1, (int)ceilf((x - cam.min_x + r) * invW));
+    const int nMinCellY = max(0, (int)floorf((y - cam.min_y - r) * invH));
+    const int nMaxCellY = min(DRFE_GRID_ROWS - 1, (int)ceilf((y - cam.min_y + r) * invH));
+    if (nMinCellX >= DRFE_GRID_COLS || nMaxCellX < 0 || nMinCellY >= DRFE_GRID_ROWS || nMaxCellY < 0) {
+        if (lane == 0) candCnt[qo] = 0;
+        return;
+    }
+    const int ny = nMaxCellY - nMinCellY + 1;
+    const int ncell = (nMaxCellX - nMinCellX + 1) * ny;
+    const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+    const int cur = P.curSlot;
+    const drfe_keypoint* K = kps + (size_t)cur * maxKp;
+    const uint8_t* D = desc + (size_t)cur * maxKp * 32;
+    const float* UR = uRight + (size_t)cur * maxKp;
+    const int* gOff = gridOff + (size_t)cur * (DRFE_GRID_CELLS + 1);
+    const int* gIdx = gridIdx + (size_t)cur * maxKp;
+    uint32_t* oIdx = candIdx + qo * DRFE_MATCH_MAX_CAND;
+    uint32_t* oKey = candKey + qo * DRFE_MATCH_MAX_CAND;
+    const uint64_t q0 = (uint64_t)q.desc[0] | ((uint64_t)q.desc[1] << 32), q1 = (uint64_t)q.desc[2] | ((uint64_t)q.desc[3] << 32),
+                   q2 = (uint64_t)q.desc[4] | ((uint64_t)q.desc[5] << 32), q3 = (uint64_t)q.desc[6] | ((uint64_t)q.desc[7] << 32);
+    bool overflow = false;
+    for (int c = lane; c < ncell; c += WAVE) {
+        const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;   /* ix outer, iy inner */
+        const int cell = ix * DRFE_GRID_ROWS + iy;
+        const int b = gOff[cell], e = gOff[cell + 1];
+        for (int j = b; j < e; j++) {
+            const int idx = gIdx[j];
+            const drfe_keypoint kp = K[idx];
+            if (bCheckLevels) {
+                if (kp.octave < q.minLevel) continue;
+                if (q.maxLevel >= 0 && kp.octave > q.maxLevel) continue;
+            }
+            const float dx = kp.x - x, dy = kp.y - y;
+            if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+            const float ur = UR[idx];
+            if (ur > 0) {
+                const float er = fabsf(q.ur - ur);
+                if (er > q.thrR) continue;
+            }
+            const uint64_t* d = reinterpret_cast<const uint64_t*>(D + (size_t)idx * 32);
+            const int dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
+            const int pos = atomicAdd(&sCnt[wv], 1);
+            if (pos < DRFE_MATCH_MAX_CAND) {
+                oIdx[pos] = (uint32_t)idx | ((uint32_t)kp.octave << 24);
+                /* visit position: cell sequence number, then position inside the cell */
+                oKey[pos] = ((uint32_t)dist << 22) | ((uint32_t)min(c, 16383) << 8) | (uint32_t)min(j - b, 255);
+            } else overflow = true;
+        }
+    }
+    if (__any(overflow) && lane == 0) atomicOr(status, 4);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) candCnt[qo] = min(sCnt[wv], DRFE_MATCH_MAX_CAND);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* sequential claim replay: one wavefront per frame pair                                             */
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+
+/* SearchByProjection(CurrentFrame, LastFrame, th, bMono): best unclaimed candidate per map point in
+ * index order, TH_HIGH gate, rotation histogram with the reference's 1/HISTO_LENGTH factor quirk
+ * (SURVEY.md §9.6), ComputeThreeMaxima, un-assignment of the other bins. */
+__global__ __launch_bounds__(WAVE) void k_resolve_last(const MatchPair* __restrict__ pairs,
+                                                       const MatchQuery* __restrict__ queries,
+                                                       const drfe_keypoint* __restrict__ kps,
+                                                       const int* __restrict__ kpCount, int maxKp,
+                                                       const uint32_t* __restrict__ candIdx,
+                                                       const uint32_t* __restrict__ candKey,
+                                                       const int* __restrict__ candCnt, int checkOri,
+                                                       int* __restrict__ match /* [curSlot][maxKp] in/out */,
+                                                       const uint8_t* __restrict__ initObs,
+                                                       int* __restrict__ matchCount,
+                                                       uint16_t* __restrict__ histScratch /* [pair][2*maxKp] */)
+{
+    extern __shared__ unsigned char claim[];   /* per cur keypoint: bit0 claimed, bit1 obs>0 */
+    __shared__ int hist[30];
+    const MatchPair P = pairs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
+    const int nCur = kpCount[P.curSlot];
+    int* M = match + (size_t)P.curSlot * maxKp;
+    const drfe_keypoint* Kc = kps + (size_t)P.curSlot * maxKp;
+    const drfe_keypoint* Kl = kps + (size_t)P.lastSlot * maxKp;
+    uint16_t* hs = histScratch + (size_t)blockIdx.x * 2 * maxKp;
+    for (int i = lane; i < nCur; i += WAVE) {
+        unsigned char c = 0;
+        if (M[i] >= 0) c = 1 | ((initObs ? initObs[i] : 1) ? 2 : 0);
+        claim[i] = c;
+    }
+    if (lane < 30) hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0, nEntries = 0;
+    const float factor = 1.0f / 30;
+    for (int i = 0; i < nQ; i++) {
+        const size_t qo = (size_t)P.queryBase + i;
+        const int cnt = candCnt[qo];
+        if (cnt == 0) continue;
+        uint32_t bestKey = 0xFFFFFFFFu, bestIdx = 0;
+        for (int c0 = 0; c0 < cnt; c0 += WAVE) {
+            uint32_t key = 0xFFFFFFFFu, idx = 0;
+            if (c0 + lane < cnt) {
+                idx = candIdx[qo * DRFE_MATCH_MAX_CAND + c0 + lane];
+                key = candKey[qo * DRFE_MATCH_MAX_CAND + c0 + lane];
+                if ((claim[idx & 0xFFFFFF] & 3) == 3) key = 0xFFFFFFFFu;  /* holds a point with Observations()>0 */
+            }
+            const uint32_t mn = wave_min_u32(key);
+            if (mn < bestKey) {
+                const unsigned long long who = __ballot(key == mn);
+                const int src = __ffsll((long long)who) - 1;
+                bestIdx = (uint32_t)__shfl((int)idx, src);
+                bestKey = mn;
+            }
+        }
+        if (bestKey == 0xFFFFFFFFu) continue;
+        const int bestDist = (int)(bestKey >> 22);
+        if (bestDist <= 100) {                                   /* TH_HIGH */
+            const int i2 = (int)(bestIdx & 0xFFFFFF);
+            nmatches++;
+            if (lane == 0) {
+                M[i2] = i;
+                claim[i2] = 1 | (queries[qo].obs ? 2 : 0);
+                if (checkOri) {
+                    float rot = Kl[i].angle - Kc[i2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == 30) bin = 0;
+                    hs[2 * nEntries] = (uint16_t)bin;
+                    hs[2 * nEntries + 1] = (uint16_t)i2;
+                    hist[bin]++;
+                }
+            }
+            nEntries++;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (checkOri && lane == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < 30; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int e = 0; e < nEntries; e++) {
+            const int bin = hs[2 * e];
+            if (bin != ind1 && bin != ind2 && bin != ind3) { M[hs[2 * e + 1]] = -1; nmatches--; }
+        }
+    }
+    if (lane == 0) matchCount[P.curSlot] = nmatches;
+}
+
+/* SearchByProjection(Frame&, vector<MapPoint*>&, th): best and second best with their octaves, ratio
+ * test only when both are on the same level (src/ORBmatcher.cc:99-125). */
+__global__ __launch_bounds__(WAVE) void k_resolve_map(const MatchPair* __restrict__ pairs,
+                                                      const MatchQuery* __restrict__ queries,
+                                                      const int* __restrict__ kpCount, int maxKp,
+                                                      const uint32_t* __restrict__ candIdx,
+                                                      const uint32_t* __restrict__ candKey,
+                                                      const int* __restrict__ candCnt, float nnratio,
+                                                      int* __restrict__ match, const uint8_t* __restrict__ initObs,
+                                                      int* __restrict__ matchCount)
+{
+    extern __shared__ unsigned char claim[];
+    const MatchPair P = pairs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int nQ = P.nQueries;
+    const int nCur = kpCount[P.curSlot];
+    int* M = match + (size_t)P.curSlot * maxKp;
+    for (int i = lane; i < nCur; i += WAVE) {
+        unsigned char c = 0;
+        if (M[i] >= 0) c = 1 | ((initObs ? initObs[i] : 1) ? 2 : 0);
+        claim[i] = c;
+    }
+    __syncthreads();
+    int nmatches = 0;
+    for (int i = 0; i < nQ; i++) {
+        const size_t qo = (size_t)P.queryBase + i;
+        const int cnt = candCnt[qo];
+        if (cnt == 0) continue;
+        /* the reference's scan keeps (best, second) with strict '<' in visit order: best = min by
+         * (dist, visit); second = min by (dist, visit) of the rest */
+        uint32_t k1 = 0xFFFFFFFFu, i1 = 0, k2 = 0xFFFFFFFFu, i2 = 0;
+        for (int c0 = 0; c0 < cnt; c0 += WAVE) {
+            uint32_t key = 0xFFFFFFFFu, idx = 0;
+            if (c0 + lane < cnt) {
+                idx = candIdx[qo * DRFE_MATCH_MAX_CAND + c0 + lane];
+                key = candKey[qo * DRFE_MATCH_MAX_CAND + c0 + lane];
+                if ((claim[idx & 0xFFFFFF] & 3) == 3) key = 0xFFFFFFFFu;
+            }
+            for (int pass = 0; pass < 2; pass++) {
+                const uint32_t mn = wave_min_u32(key);
+                if (mn == 0xFFFFFFFFu) break;
+                const unsigned long long who = __ballot(key == mn);
+                const int src = __ffsll((long long)who) - 1;
+                const uint32_t ix = (uint32_t)__shfl((int)idx, src);
+                if (mn < k1) { k2 = k1; i2 = i1; k1 = mn; i1 = ix; }
+                else if (mn < k2) { k2 = mn; i2 = ix; }
+                if (lane == src) key = 0xFFFFFFFFu;
+            }
+        }
+        if (k1 == 0xFFFFFFFFu) continue;
+        const int bestDist = (int)(k1 >> 22);
+        const int bestDist2 = (k2 == 0xFFFFFFFFu) ? 256 : (int)(k2 >> 22);
+        const int bestLevel = (int)(i1 >> 24);
+        const int bestLevel2 = (k2 == 0xFFFFFFFFu) ? -1 : (int)(i2 >> 24);
+        if (bestDist <= 100) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            const int bi = (int)(i1 & 0xFFFFFF);
+            if (lane == 0) { M[bi] = i; claim[bi] = 1 | (queries[qo].obs ? 2 : 0); }
+            nmatches++;
+            __syncthreads();
+        }
+    }
+    if (lane == 0) matchCount[P.curSlot] = nmatches;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* brute-force Hamming k-NN (k <= 2): 64 queries per workgroup, train tiles of 64 descriptors in LDS  */
+
+__global__ __launch_bounds__(64) void k_bf_knn(const uint8_t* __restrict__ Q, int nq, const uint8_t* __restrict__ T,
+                                               int nt, int k, int* __restrict__ outIdx, int* __restrict__ outDist)
+{
+    __shared__ uint64_t tile[64 * 4];
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x * 64 + lane;
+    uint64_t q[4] = {0, 0, 0, 0};
+    if (qi < nq) {
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(Q + (size_t)qi * 32);
+        q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+    }
+    int d1 = 1 << 30, i1 = -1, d2 = 1 << 30, i2 = -1;
+    for (int t0 = 0; t0 < nt; t0 += 64) {
+        __syncthreads();
+        if (t0 + lane < nt) {
+            const uint64_t* p = reinterpret_cast<const uint64_t*>(T + (size_t)(t0 + lane) * 32);
+            tile[lane * 4 + 0] = p[0]; tile[lane * 4 + 1] = p[1]; tile[lane * 4 + 2] = p[2]; tile[lane * 4 + 3] = p[3];
+        }
+        __syncthreads();
+        const int m = min(64, nt - t0);
+        for (int j = 0; j < m; j++) {   /* ascending train index: strict '<' keeps the first minimum */
+            const int d = __popcll(q[0] ^ tile[j * 4]) + __popcll(q[1] ^ tile[j * 4 + 1]) +
+                          __popcll(q[2] ^ tile[j * 4 + 2]) + __popcll(q[3] ^ tile[j * 4 + 3]);
+            if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = t0 + j; }
+            else if (d < d2) { d2 = d; i2 = t0 + j; }
+        }
+    }
+    if (qi < nq) {
+        outIdx[(size_t)qi * k] = i1;
+        outDist[(size_t)qi * k] = i1 >= 0 ? d1 : -1;
+        if (k > 1) {
+            outIdx[(size_t)qi * k + 1] = i2;
+            outDist[(size_t)qi * k + 1] = i2 >= 0 ? d2 : -1;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* launchers                                                                                         */
+
+static inline void prof_begin(drfe_ctx* c, int stage, hipStream_t s)
+{
+    if (c->profile) { (void)hipEventRecord(c->ev[stage][0], s); c->evUsed[stage] = true; }
+}
+static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
+{
+    if (c->profile) (void)hipEventRecord(c->ev[stage][1], s);
+}
+
+hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameStride, size_t rowStride,
+                            const drfe_camera& cam, int nframes, hipStream_t s)
+{
+    const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
+    const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
+    prof_begin(c, DRFE_STAGE_GLUE, s);
+    hipLaunchKernelGGL(k_stereo, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, c->d_kps, c->d_kpCount,
+                       c->maxKp, d_depth, frameStride, rowStride, c->geom.imgW, c->geom.imgH, cam, c->d_uRight,
+                       c->d_depth);
+    hipLaunchKernelGGL(k_grid, dim3(nframes), dim3(256), 0, s, c->d_kps, c->d_kpCount, c->maxKp, cam, invW, invH,
+                       c->d_gridOff, c->d_gridIdx);
+    prof_end(c, DRFE_STAGE_GLUE, s);
+    return hipGetLastError();
+}
+
+hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,
+                                    int maxQueries, int mode, float th, float nnratio, int checkOri,
+                                    const uint8_t* d_initObs, hipStream_t s)
+{
+    const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
+    const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
+                           c->d_kps, c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
+    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 3) / 4, npairs), dim3(256), 0, s, mb.d_pairs,
+                       mb.d_queries, c->d_kps, c->d_desc, c->d_uRight, c->d_kpCount, c->maxKp, c->d_gridOff,
+                       c->d_gridIdx, cam, invW, invH, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, c->d_status);
+    const size_t lds = (size_t)c->maxKp;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_resolve_last, dim3(npairs), dim3(WAVE), lds, s, mb.d_pairs, mb.d_queries, c->d_kps,
+                           c->d_kpCount, c->maxKp, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, checkOri, c->d_match,
+                           d_initObs, c->d_matchCount, mb.d_hist);
+    else
+        hipLaunchKernelGGL(k_resolve_map, dim3(npairs), dim3(WAVE), lds, s, mb.d_pairs, mb.d_queries, c->d_kpCount,
+                           c->maxKp, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, nnratio, c->d_match, d_initObs,
+                           c->d_matchCount);
+    return hipGetLastError();
+}
+
+hipError_t drfe_launch_mappoints_last(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, const float* d_Twc,
+                                      int nframes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mappoints_last, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, c->d_kps, c->d_desc,
+                       c->d_kpCount, c->maxKp, c->d_depth, cam, d_Twc, mb.d_mps);
+    return hipGetLastError();
+}
+
+hipError_t drfe_launch_bf_knn(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, int k, int* dIdx, int* dDist,
+                              hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bf_knn, dim3((nq + 63) / 64), dim3(64), 0, s, dQ, nq, dT, nt, k, dIdx, dDist);
+    return hipGetLastError();
+}

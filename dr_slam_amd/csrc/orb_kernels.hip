@@ -1,0 +1,613 @@
+/* orb_kernels.hip — gfx950 kernels of the ORB extraction path.
+ *
+ * Every kernel is batch-wide: blockIdx.y (or .z) is the frame slot, so one launch covers all frames
+ * of a batch and the grid is >> 256 workgroups even though a single 640x480 frame is only ~7 MB of
+ * traffic.  All arithmetic that decides an output bit is integer, or float32 without FMA contraction
+ * (-ffp-contract=off) through include/drfe_math.h.
+ *
+ *   k_pyr_level0   copyMakeBorder(REFLECT_101) of the input           (reference src/ORBextractor.cc:1127)
+ *   k_pyr_resize   cv::resize(INTER_LINEAR) cascade + border          (:1120-1123)
+ *   k_fast_cells   per-cell cv::FAST(20) -> NMS -> fallback cv::FAST(7) (:789-829)
+ *   k_quadtree     DistributeOctTree                                   (:539-763)
+ *   k_blur         GaussianBlur 7x7 sigma 2 on the interior            (:1085-1086)
+ *   k_orient_desc  IC_Angle + computeOrbDescriptor + keypoint finishing (:77-147, :837-847, :1095-1101)
+ */
+#include "drfe_internal.h"
+#include "../../include/drfe_math.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    /* single reflection: callers guarantee |overshoot| < n */
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+    return p;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* pyramid                                                                                          */
+
+__global__ __launch_bounds__(256) void k_pyr_level0(const DevGeom* __restrict__ G, const uint8_t* __restrict__ gray,
+                                                    size_t frameStride, size_t rowStride,
+                                                    uint8_t* __restrict__ pyr)
+{
+    const DevLevel& L = G->lv[0];
+    const int slot = blockIdx.z;
+    const int y = blockIdx.y;                                   /* bordered row */
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;        /* bordered column of 4 px */
+    if (x4 >= L.pyrPitch) return;
+    const int bw = L.w + 2 * DRFE_EDGE;
+    const uint8_t* src = gray + (size_t)slot * frameStride + (size_t)reflect101(y - DRFE_EDGE, L.h) * rowStride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        uint32_t v = 0;
+        if (x < bw) v = src[reflect101(x - DRFE_EDGE, L.w)];
+        out |= v << (8 * k);
+    }
+    uint8_t* dst = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)y * L.pyrPitch + x4;
+    *reinterpret_cast<uint32_t*>(dst) = out;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize(const DevGeom* __restrict__ G, int level,
+                                                    const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr)
+{
+    const DevLevel& L = G->lv[level];
+    const DevLevel& P = G->lv[level - 1];
+    const int slot = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= L.pyrPitch) return;
+    const int bw = L.w + 2 * DRFE_EDGE;
+    uint8_t* base = pyr + (size_t)slot * G->pyrSlotBytes;
+    const uint8_t* src = base + P.pyrOff + (size_t)DRFE_EDGE * P.pyrPitch + DRFE_EDGE; /* interior of l-1 */
+    const ResizeTap ty = taps[L.ytabOff + reflect101(y - DRFE_EDGE, L.h)];
+    const uint8_t* S0 = src + (size_t)ty.s0 * P.pyrPitch;
+    const uint8_t* S1 = src + (size_t)ty.s1 * P.pyrPitch;
+    const int b0 = ty.w0, b1 = ty.w1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        uint32_t v = 0;
+        if (x < bw) {
+            const ResizeTap tx = taps[L.xtabOff + reflect101(x - DRFE_EDGE, L.w)];
+            const int h0 = S0[tx.s0] * tx.w0 + S0[tx.s1] * tx.w1;
+            const int h1 = S1[tx.s0] * tx.w0 + S1[tx.s1] * tx.w1;
+            int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            r = min(255, max(0, r));
+            v = (uint32_t)r;
+        }
+        out |= v << (8 * k);
+    }
+    uint8_t* dst = base + L.pyrOff + (size_t)y * L.pyrPitch + x4;
+    *reinterpret_cast<uint32_t*>(dst) = out;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* FAST-9/16 per cell                                                                               */
+
+/* Threshold-free corner strength: cornerScore<16>(p, 0) = max(0, S_dark, S_bright) - 1 where
+ * S = max over the 16 nine-pixel arcs of the min |difference|.  "Corner at t" is
+ * exactly "strength >= t", so one strength map serves both FAST thresholds. Returned clamped to >= 0
+ * (values below minThFAST never take part in a decision). */
+__device__ __forceinline__ int fast_strength(const uint8_t* c, const int P)
+{
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * P];          d[1] = v - c[3 * P + 1];     d[2] = v - c[2 * P + 2];    d[3] = v - c[P + 3];
+    d[4] = v - c[3];              d[5] = v - c[-P + 3];        d[6] = v - c[-2 * P + 2];   d[7] = v - c[-3 * P + 1];
+    d[8] = v - c[-3 * P];         d[9] = v - c[-3 * P - 1];    d[10] = v - c[-2 * P - 2];  d[11] = v - c[-P - 3];
+    d[12] = v - c[-3];            d[13] = v - c[P - 3];        d[14] = v - c[2 * P - 2];   d[15] = v - c[3 * P - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int a = -256, b = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        a = max(a, lo9);
+        b = min(b, hi9);
+    }
+    return max(max(a, -b) - 1, 0);
+}
+
+#define FAST_MAX_EVAL 62
+#define FAST_SC_PITCH 64
+#define FAST_MAX_CAND (((FAST_MAX_EVAL + 1) / 2) * ((FAST_MAX_EVAL + 1) / 2))
+
+__global__ __launch_bounds__(256) void k_fast_cells(const DevGeom* __restrict__ G, const FastCell* __restrict__ cells,
+                                                    const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
+                                                    uint32_t* __restrict__ cand1, int* __restrict__ candCount,
+                                                    int* __restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[DRFE_FAST_MAX_WIN * DRFE_FAST_TILE_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[(FAST_MAX_EVAL + 2) * FAST_SC_PITCH];
+    __shared__ uint32_t st0[FAST_MAX_CAND], st1[FAST_MAX_CAND];
+    __shared__ int sCount, sBase;
+
+    const FastCell fc = cells[blockIdx.x];
+    const int slot = blockIdx.y;
+    const DevLevel& L = G->lv[fc.level];
+    const int tid = threadIdx.x;
+    const int ww = fc.ww, wh = fc.wh;
+    const int ew = ww - 6, eh = wh - 6;           /* evaluated area */
+    const uint8_t* src = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff +
+                         (size_t)(fc.y0 + DRFE_EDGE) * L.pyrPitch + (fc.x0 + DRFE_EDGE);
+    for (int i = tid; i < ww * wh; i += 256) {
+        const int y = i / ww, x = i - y * ww;
+        tile[y * DRFE_FAST_TILE_PITCH + x] = src[(size_t)y * L.pyrPitch + x];
+    }
+    for (int i = tid; i < (FAST_MAX_EVAL + 2) * FAST_SC_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    for (int i = tid; i < ew * eh; i += 256) {
+        const int y = i / ew, x = i - y * ew;
+        const int s = fast_strength(&tile[(y + 3) * DRFE_FAST_TILE_PITCH + (x + 3)], DRFE_FAST_TILE_PITCH);
+        sc[(y + 1) * FAST_SC_PITCH + (x + 1)] = (uint8_t)s;
+    }
+    __syncthreads();
+    /* strict 3x3 maximum (neighbours outside the evaluated area read 0) */
+    int has20 = 0;
+    for (int i = tid; i < ew * eh; i += 256) {
+        const int y = i / ew, x = i - y * ew;
+        const uint8_t* p = &sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
+        const int s = p[0];
+        const bool mx = s > p[-1] && s > p[1] && s > p[-FAST_SC_PITCH - 1] && s > p[-FAST_SC_PITCH] &&
+                        s > p[-FAST_SC_PITCH + 1] && s > p[FAST_SC_PITCH - 1] && s > p[FAST_SC_PITCH] &&
+                        s > p[FAST_SC_PITCH + 1];
+        if (mx && s >= G->iniTh) has20 = 1;
+    }
+    has20 = __syncthreads_or(has20);
+    const int thr = has20 ? G->iniTh : G->minTh;
+    for (int i = tid; i < ew * eh; i += 256) {
+        const int y = i / ew, x = i - y * ew;
+        const uint8_t* p = &sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
+        const int s = p[0];
+        const bool mx = s > p[-1] && s > p[1] && s > p[-FAST_SC_PITCH - 1] && s > p[-FAST_SC_PITCH] &&
+                        s > p[-FAST_SC_PITCH + 1] && s > p[FAST_SC_PITCH - 1] && s > p[FAST_SC_PITCH] &&
+                        s > p[FAST_SC_PITCH + 1];
+        if (mx && s >= thr) {
+            const int pos = atomicAdd(&sCount, 1);
+            /* keypoint coordinates as the reference leaves them in vToDistributeKeys (:822-823):
+             * cv::FAST coordinate inside the window + (j*wCell, i*hCell) */
+            const uint32_t kx = (uint32_t)(x + 3 + fc.offX), ky = (uint32_t)(y + 3 + fc.offY);
+            st0[pos] = kx | (ky << 12) | ((uint32_t)s << 24);
+            st1[pos] = (fc.cellIdx << 12) | ((uint32_t)y << 6) | (uint32_t)x;   /* emission order */
+        }
+    }
+    __syncthreads();
+    const int n = sCount;
+    if (n == 0) return;
+    if (tid == 0) sBase = atomicAdd(&candCount[slot * G->nlevels + fc.level], n);
+    __syncthreads();
+    const int base = sBase;
+    if (base + n > L.candCap) { if (tid == 0) atomicOr(status, 1); return; }
+    const size_t off = (size_t)slot * G->candSlotElems + L.candOff + base;
+    for (int i = tid; i < n; i += 256) { cand0[off + i] = st0[i]; cand1[off + i] = st1[i]; }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* quadtree                                                                                          */
+
+#define QT_THREADS 512
+#define QT_MAXN DRFE_QT_MAX_NODES
+
+struct QtShared {
+    short x0[2][QT_MAXN], x1[2][QT_MAXN], y0[2][QT_MAXN], y1[2][QT_MAXN]; /* UL.x, UR.x, UL.y, BR.y */
+    int cnt[2][QT_MAXN];
+    unsigned char isNew[2][QT_MAXN];      /* created in the previous round (phase-2 candidates) */
+    int ccnt[QT_MAXN * 4];                /* child key counts of this round; reused as child positions */
+    int newPos[QT_MAXN];                  /* list position of a surviving node in the next list */
+    unsigned char proc[QT_MAXN];          /* node is divided this round */
+    unsigned short order[QT_MAXN];        /* processing order of divided nodes */
+    int len, phase, finish, nProc, err;
+};
+
+/* One workgroup runs DistributeOctTree for one (slot, level).  The reference's std::list is kept as
+ * an array in list order, rebuilt every round:
+ *   new list = children of the LAST divided node (n4,n3,n2,n1), ..., children of the FIRST divided
+ *              node, followed by the undivided nodes in their old order
+ * which is what push_front + erase produce (src/ORBextractor.cc:612-660).  Sweep rounds (:597-666)
+ * divide every multi-key node in list order; once a sweep could overshoot N (:673) the rounds divide
+ * the previous round's children largest-first (sort at :684, ties by creation order — the canonical
+ * rule of SURVEY.md §9.1) and stop as soon as the list holds N nodes (:730).  Keys never move: each
+ * carries the list position of its node. */
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restrict__ G,
+                                                         const uint32_t* __restrict__ cand0,
+                                                         const uint32_t* __restrict__ cand1,
+                                                         uint16_t* __restrict__ node,
+                                                         const int* __restrict__ candCount,
+                                                         uint32_t* __restrict__ sel, int* __restrict__ selCount,
+                                                         int* __restrict__ status)
+{
+    __shared__ QtShared S;
+    const int level = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
+    const DevLevel& L = G->lv[level];
+    const int n = min(candCount[slot * G->nlevels + level], L.candCap);
+    const size_t coff = (size_t)slot * G->candSlotElems + L.candOff;
+    const uint32_t* k0 = cand0 + coff;
+    const uint32_t* k1 = cand1 + coff;
+    uint16_t* nd = node + coff;
+    const int N = L.quota;
+    const int maxNodes = L.kpCap;
+    if (n == 0) { if (tid == 0) selCount[slot * G->nlevels + level] = 0; return; }
+
+    /* root nodes, :543-566 */
+    const int nIni = L.nIni;
+    for (int i = tid; i < nIni; i += QT_THREADS) {
+        S.x0[0][i] = (short)(int)(L.hX * (float)i);
+        S.x1[0][i] = (short)(int)(L.hX * (float)(i + 1));
+        S.y0[0][i] = 0;
+        S.y1[0][i] = (short)(L.maxBY - L.minBY);
+        S.cnt[0][i] = 0;
+        S.isNew[0][i] = 0;
+    }
+    if (tid == 0) { S.err = 0; S.finish = 0; S.phase = 1; }
+    __syncthreads();
+    for (int k = tid; k < n; k += QT_THREADS) {
+        const int x = (int)(k0[k] & 0xFFF);
+        int r = (int)((float)x / L.hX);
+        r = min(r, nIni - 1);
+        nd[k] = (uint16_t)r;
+        atomicAdd(&S.cnt[0][r], 1);
+    }
+    __syncthreads();
+    /* erase empty roots, :577-590 */
+    if (tid == 0) {
+        int m = 0;
+        for (int i = 0; i < nIni; i++) {
+            S.newPos[i] = m;
+            if (S.cnt[0][i] > 0) {
+                S.x0[0][m] = S.x0[0][i]; S.x1[0][m] = S.x1[0][i]; S.y0[0][m] = S.y0[0][i]; S.y1[0][m] = S.y1[0][i];
+                S.cnt[0][m] = S.cnt[0][i];
+                m++;
+            }
+        }
+        S.len = m;
+    }
+    __syncthreads();
+    if (S.len != nIni)
+        for (int k = tid; k < n; k += QT_THREADS) nd[k] = (uint16_t)S.newPos[nd[k]];
+    __syncthreads();
+
+    int cur = 0;
+    while (true) {
+        const int len = S.len;
+        const int phase = S.phase;
+        /* A. candidates of this round */
+        for (int i = tid; i < len; i += QT_THREADS) {
+            const bool c = S.cnt[cur][i] > 1 && (phase == 1 || S.isNew[cur][i]);
+            S.proc[i] = c ? 1 : 0;
+            S.ccnt[4 * i] = 0; S.ccnt[4 * i + 1] = 0; S.ccnt[4 * i + 2] = 0; S.ccnt[4 * i + 3] = 0;
+        }
+        __syncthreads();
+        /* B. DivideNode key association (:512-526) for every candidate node */
+        for (int k = tid; k < n; k += QT_THREADS) {
+            const int i = nd[k];
+            if (!S.proc[i]) continue;
+            const uint32_t key = k0[k];
+            const int x = (int)(key & 0xFFF), y = (int)((key >> 12) & 0xFFF);
+            const int mx = S.x0[cur][i] + ((S.x1[cur][i] - S.x0[cur][i] + 1) >> 1);
+            const int my = S.y0[cur][i] + ((S.y1[cur][i] - S.y0[cur][i] + 1) >> 1);
+            const int q = (x < mx) ? ((y < my) ? 0 : 2) : ((y < my) ? 1 : 3);
+            atomicAdd(&S.ccnt[4 * i + q], 1);
+        }
+        __syncthreads();
+        /* C. which candidates are divided, in which order */
+        if (phase == 1) {
+            if (tid == 0) {
+                int m = 0;
+                for (int i = 0; i < len; i++)
+                    if (S.proc[i]) S.order[m++] = (unsigned short)i;
+                S.nProc = m;
+            }
+        } else {
+            /* rank sort: larger size first, equal sizes -> later created first == smaller list position
+             * (children sit reversed at the list front) */
+            for (int i = tid; i < len; i += QT_THREADS) {
+                if (!S.proc[i]) continue;
+                const int ci = S.cnt[cur][i];
+                int rank = 0;
+                for (int j = 0; j < len; j++) {
+                    if (!S.proc[j]) continue;
+                    const int cj = S.cnt[cur][j];
+                    if (cj > ci || (cj == ci && j < i)) rank++;
+                }
+                S.order[rank] = (unsigned short)i;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int m = 0;
+                for (int i = 0; i < len; i++) m += S.proc[i];
+                int size = len, take = 0;
+                for (int r = 0; r < m; r++) {
+                    const int i = S.order[r];
+                    const int nch = (S.ccnt[4 * i] > 0) + (S.ccnt[4 * i + 1] > 0) + (S.ccnt[4 * i + 2] > 0) +
+                                    (S.ccnt[4 * i + 3] > 0);
+                    size += nch - 1;
+                    take = r + 1;
+                    if (size >= N) break;
+                }
+                for (int r = take; r < m; r++) S.proc[S.order[r]] = 0;
+                S.nProc = take;
+            }
+        }
+        __syncthreads();
+        /* D/E. next list (thread 0: <= ~N nodes) */
+        const int nxt = cur ^ 1;
+        if (tid == 0) {
+            const int m = S.nProc;
+            int total = 0;
+            for (int r = 0; r < m; r++) {
+                const int i = S.order[r];
+                total += (S.ccnt[4 * i] > 0) + (S.ccnt[4 * i + 1] > 0) + (S.ccnt[4 * i + 2] > 0) + (S.ccnt[4 * i + 3] > 0);
+            }
+            int survivors = 0;
+            for (int i = 0; i < len; i++) survivors += S.proc[i] ? 0 : 1;
+            const int newLen = total + survivors;
+            if (newLen > maxNodes || newLen > QT_MAXN) {
+                S.err = 1; S.finish = 1;
+            } else {
+                int nToExpand = 0;
+                int pos = total; /* children of order[0] end the children block */
+                for (int r = 0; r < m; r++) {
+                    const int i = S.order[r];
+                    const int X0 = S.x0[cur][i], X1 = S.x1[cur][i], Y0 = S.y0[cur][i], Y1 = S.y1[cur][i];
+                    const int mx = X0 + ((X1 - X0 + 1) >> 1), my = Y0 + ((Y1 - Y0 + 1) >> 1);
+                    for (int q = 0; q < 4; q++) {      /* n1..n4 pushed front in this order */
+                        const int c = S.ccnt[4 * i + q];
+                        if (c == 0) { S.ccnt[4 * i + q] = -1; continue; }
+                        pos--;
+                        S.x0[nxt][pos] = (short)((q & 1) ? mx : X0);
+                        S.x1[nxt][pos] = (short)((q & 1) ? X1 : mx);
+                        S.y0[nxt][pos] = (short)((q & 2) ? my : Y0);
+                        S.y1[nxt][pos] = (short)((q & 2) ? Y1 : my);
+                        S.cnt[nxt][pos] = c;
+                        S.isNew[nxt][pos] = 1;
+                        if (c > 1) nToExpand++;
+                        S.ccnt[4 * i + q] = pos;
+                    }
+                }
+                int p2 = total;
+                for (int i = 0; i < len; i++) {
+                    if (S.proc[i]) continue;
+                    S.x0[nxt][p2] = S.x0[cur][i]; S.x1[nxt][p2] = S.x1[cur][i];
+                    S.y0[nxt][p2] = S.y0[cur][i]; S.y1[nxt][p2] = S.y1[cur][i];
+                    S.cnt[nxt][p2] = S.cnt[cur][i];
+                    S.isNew[nxt][p2] = 0;
+                    S.newPos[i] = p2++;
+                }
+                /* termination, :662-666 / :733-734, and the switch to largest-first rounds, :668 */
+                if (newLen >= N || newLen == len) S.finish = 1;
+                else if (phase == 1 && newLen + nToExpand * 3 > N) S.phase = 2;
+                S.len = newLen;
+            }
+        }
+        __syncthreads();
+        if (S.err) break;
+        /* F. keys follow their node */
+        for (int k = tid; k < n; k += QT_THREADS) {
+            const int i = nd[k];
+            if (S.proc[i]) {
+                const uint32_t key = k0[k];
+                const int x = (int)(key & 0xFFF), y = (int)((key >> 12) & 0xFFF);
+                const int mx = S.x0[cur][i] + ((S.x1[cur][i] - S.x0[cur][i] + 1) >> 1);
+                const int my = S.y0[cur][i] + ((S.y1[cur][i] - S.y0[cur][i] + 1) >> 1);
+                const int q = (x < mx) ? ((y < my) ? 0 : 2) : ((y < my) ? 1 : 3);
+                nd[k] = (uint16_t)S.ccnt[4 * i + q];
+            } else {
+                nd[k] = (uint16_t)S.newPos[i];
+            }
+        }
+        cur = nxt;
+        __syncthreads();
+        if (S.finish) break;
+    }
+    if (S.err) {
+        if (tid == 0) { atomicOr(status, 2); selCount[slot * G->nlevels + level] = 0; }
+        return;
+    }
+    /* retain the best key per node, first maximum in emission order wins (:744-760) */
+    const int len = S.len;
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(S.ccnt);
+    for (int i = tid; i < len; i += QT_THREADS) best[i] = 0ull;
+    __syncthreads();
+    for (int k = tid; k < n; k += QT_THREADS) {
+        const unsigned long long p = ((unsigned long long)(k0[k] >> 24) << 32) | (unsigned long long)(~k1[k]);
+        atomicMax(&best[nd[k]], p);
+    }
+    __syncthreads();
+    uint32_t* out = sel + (size_t)slot * G->kpSlotElems + L.kpOff;
+    for (int k = tid; k < n; k += QT_THREADS) {
+        const unsigned long long p = ((unsigned long long)(k0[k] >> 24) << 32) | (unsigned long long)(~k1[k]);
+        if (best[nd[k]] == p) out[nd[k]] = k0[k];
+    }
+    if (tid == 0) selCount[slot * G->nlevels + level] = len;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Gaussian blur 7x7, sigma 2, 8.8 fixed point                                     */
+
+#define BLUR_SRC_PITCH 72
+__global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, const BlurTile* __restrict__ tiles,
+                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t src[(DRFE_BLUR_TH + 6) * BLUR_SRC_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t hb[(DRFE_BLUR_TH + 6) * DRFE_BLUR_TW];
+    const BlurTile t = tiles[blockIdx.x];
+    const int slot = blockIdx.y, tid = threadIdx.x;
+    const DevLevel& L = G->lv[t.level];
+    const uint8_t* in = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)DRFE_EDGE * L.pyrPitch + DRFE_EDGE;
+    const int x0 = t.tx * DRFE_BLUR_TW, y0 = t.ty * DRFE_BLUR_TH;
+    /* the reference blurs a clone of the interior ROI: borders are reflections of the interior */
+    for (int i = tid; i < (DRFE_BLUR_TH + 6) * (DRFE_BLUR_TW + 6); i += 256) {
+        const int r = i / (DRFE_BLUR_TW + 6), c = i - r * (DRFE_BLUR_TW + 6);
+        const int sy = reflect101(min(y0 + r - 3, L.h + 2), L.h);
+        const int sx = reflect101(min(x0 + c - 3, L.w + 2), L.w);
+        src[r * BLUR_SRC_PITCH + c] = in[(size_t)sy * L.pyrPitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (DRFE_BLUR_TH + 6) * DRFE_BLUR_TW; i += 256) {
+        const int r = i / DRFE_BLUR_TW, c = i - r * DRFE_BLUR_TW;
+        const uint8_t* p = &src[r * BLUR_SRC_PITCH + c];
+        const uint32_t acc = 18u * (p[0] + p[6]) + 34u * (p[1] + p[5]) + 49u * (p[2] + p[4]) + 55u * p[3];
+        hb[i] = (uint16_t)acc; /* <= 255*257 */
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+        const int y = y0 + r, x = x0 + c4;
+        if (y < L.h && x < L.blurPitch) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint16_t* p = &hb[r * DRFE_BLUR_TW + c4 + k];
+                const uint32_t acc = 18u * (p[0] + p[6 * DRFE_BLUR_TW]) + 34u * (p[DRFE_BLUR_TW] + p[5 * DRFE_BLUR_TW]) +
+                                     49u * (p[2 * DRFE_BLUR_TW] + p[4 * DRFE_BLUR_TW]) + 55u * p[3 * DRFE_BLUR_TW];
+                const uint32_t v = min(255u, (acc + 32768u) >> 16);
+                out |= v << (8 * k);
+            }
+            uint8_t* dst = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)y * L.blurPitch + x;
+            *reinterpret_cast<uint32_t*>(dst) = out;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* orientation + rBRIEF + keypoint finishing: one wavefront per keypoint                             */
+
+__global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
+                                                     const uint8_t* __restrict__ blur,
+                                                     const uint32_t* __restrict__ sel,
+                                                     const int* __restrict__ selCount,
+                                                     const int8_t* __restrict__ pattern,
+                                                     const int16_t* __restrict__ disc, int discCount,
+                                                     drfe_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                     int* __restrict__ kpCount, int maxKp)
+{
+    const int slot = blockIdx.y;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int g = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); /* output index within the slot */
+    const int nl = G->nlevels;
+    int level = -1, first = 0, total = 0;
+    for (int l = 0; l < nl; l++) {
+        const int c = selCount[slot * nl + l];
+        if (level < 0 && g < total + c) { level = l; first = total; }
+        total += c;
+    }
+    if (g == 0 && lane == 0) kpCount[slot] = min(total, maxKp);
+    if (level < 0 || g >= maxKp) return;
+    const DevLevel& L = G->lv[level];
+    const uint32_t key = sel[(size_t)slot * G->kpSlotElems + L.kpOff + (g - first)];
+    const int xi = (int)(key & 0xFFF) + L.minBX, yi = (int)((key >> 12) & 0xFFF) + L.minBY;
+    const int resp = (int)(key >> 24);
+    /* IC_Angle on the unblurred level: integer moments over the radius-15 disc (749 px) */
+    const uint8_t* c = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(yi + DRFE_EDGE) * L.pyrPitch +
+                       (xi + DRFE_EDGE);
+    int m10 = 0, m01 = 0;
+    for (int j = lane; j < discCount; j += WAVE) {
+        const int u = disc[2 * j], v = disc[2 * j + 1];
+        const int I = c[v * L.pyrPitch + u];
+        m10 += u * I;
+        m01 += v * I;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle = drfe_fast_atan2((float)m01, (float)m10);
+    /* steered BRIEF on the blurred level */
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    drfe_sincos(angle * factorPI, &b, &a);
+    const uint8_t* cb = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)yi * L.blurPitch + xi;
+    uint8_t* drow = desc + ((size_t)slot * maxKp + g) * 32;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int8_t* q = pattern + (r * 64 + lane) * 4;
+        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const int t0 = cb[drfe_round_half_even(x0 * b + y0 * a) * L.blurPitch + drfe_round_half_even(x0 * a - y0 * b)];
+        const int t1 = cb[drfe_round_half_even(x1 * b + y1 * a) * L.blurPitch + drfe_round_half_even(x1 * a - y1 * b)];
+        const unsigned long long m = __ballot(t0 < t1);
+        if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + 8 * r) = m;
+    }
+    if (lane == 0) {
+        drfe_keypoint kp;
+        kp.x = (float)xi; kp.y = (float)yi;
+        if (level != 0) { kp.x *= L.scale; kp.y *= L.scale; }
+        kp.size = L.kpSize;
+        kp.angle = angle;
+        kp.response = (float)resp;
+        kp.octave = level;
+        kp.class_id = -1;
+        kps[(size_t)slot * maxKp + g] = kp;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* host launcher                                                                                     */
+
+static inline void prof_begin(drfe_ctx* c, int stage, hipStream_t s)
+{
+    if (c->profile) { (void)hipEventRecord(c->ev[stage][0], s); c->evUsed[stage] = true; }
+}
+static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
+{
+    if (c->profile) (void)hipEventRecord(c->ev[stage][1], s);
+}
+
+hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStride, size_t rowStride, int nframes,
+                           hipStream_t s)
+{
+    const DevGeom& g = c->geom;
+    const int nl = g.nlevels;
+    hipError_t e;
+    e = hipMemsetAsync(c->d_candCount, 0, sizeof(int) * (size_t)nframes * nl, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(c->d_status, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+
+    prof_begin(c, DRFE_STAGE_PYRAMID, s);
+    {
+        const DevLevel& L = g.lv[0];
+        dim3 grid((L.pyrPitch / 4 + 255) / 256, L.h + 2 * DRFE_EDGE, nframes);
+        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, c->d_geom, d_gray, frameStride, rowStride, c->d_pyr);
+    }
+    for (int l = 1; l < nl; l++) {
+        const DevLevel& L = g.lv[l];
+        dim3 grid((L.pyrPitch / 4 + 255) / 256, L.h + 2 * DRFE_EDGE, nframes);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, c->d_geom, l, c->d_taps, c->d_pyr);
+    }
+    prof_end(c, DRFE_STAGE_PYRAMID, s);
+
+    prof_begin(c, DRFE_STAGE_FAST, s);
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(256), 0, s, c->d_geom, c->d_cells, c->d_pyr,
+                       c->d_cand0, c->d_cand1, c->d_candCount, c->d_status);
+    prof_end(c, DRFE_STAGE_FAST, s);
+
+    prof_begin(c, DRFE_STAGE_QUADTREE, s);
+    hipLaunchKernelGGL(k_quadtree, dim3(nl, nframes), dim3(QT_THREADS), 0, s, c->d_geom, c->d_cand0,
+                       c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_status);
+    prof_end(c, DRFE_STAGE_QUADTREE, s);
+
+    prof_begin(c, DRFE_STAGE_BLUR, s);
+    hipLaunchKernelGGL(k_blur, dim3(g.totalTiles, nframes), dim3(256), 0, s, c->d_geom, c->d_tiles, c->d_pyr,
+                       c->d_blur);
+    prof_end(c, DRFE_STAGE_BLUR, s);
+
+    prof_begin(c, DRFE_STAGE_DESC, s);
+    hipLaunchKernelGGL(k_orient_desc, dim3((c->maxKp + 3) / 4, nframes), dim3(256), 0, s, c->d_geom, c->d_pyr,
+                       c->d_blur, c->d_sel, c->d_selCount, c->d_pattern, c->d_disc, c->discCount, c->d_kps,
+                       c->d_desc, c->d_kpCount, c->maxKp);
+    prof_end(c, DRFE_STAGE_DESC, s);
+    return hipGetLastError();
+}
+
+size_t drfe_quadtree_lds_bytes() { return sizeof(QtShared); }

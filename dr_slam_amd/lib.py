@@ -1,0 +1,273 @@
+"""ctypes binding of libdrfe.so (include/drfe.h) — the only way Python reaches the HIP kernels.
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is present the import /
+context creation raises.  PyTorch is used by callers only for device buffers and streams; nothing
+here depends on it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdrfe.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+MAPPOINT_DTYPE = np.dtype([("valid", "u1"), ("obs_positive", "u1"), ("pad", "u1", (2,)), ("world", "<f4", (3,)),
+                           ("desc", "u1", (32,))])
+TRACKED_DTYPE = np.dtype([("track_in_view", "u1"), ("bad", "u1"), ("obs_positive", "u1"), ("pad", "u1"),
+                          ("level", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
+                          ("view_cos", "<f4"), ("desc", "u1", (32,))])
+
+STAGES = ("pyramid", "fast", "quadtree", "blur", "desc", "glue", "match")
+
+# every symbol include/drfe.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "drfe_create", "drfe_destroy", "drfe_last_error", "drfe_version", "drfe_orb_scale_tables",
+    "drfe_orb_max_keypoints", "drfe_orb_extract", "drfe_orb_extract_batch", "drfe_orb_download", "drfe_orb_counts",
+    "drfe_orb_pyramid_level", "drfe_orb_blurred_level", "drfe_orb_candidates", "drfe_frame_stereo_grid_batch",
+    "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
+    "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
+    "drfe_profile_stage_ms", "drfe_stream_sync",
+)
+
+
+class DrfeError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32),
+                ("max_batch", C.c_int32), ("nfeatures", C.c_int32), ("scale_factor", C.c_float),
+                ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("depth_factor", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libdrfe.so; raises if it was not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DrfeError(f"{LIB_PATH} not found: build it with `make -C dr_slam_amd/csrc` "
+                        "(there is no CPU fallback for the feature path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.drfe_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.drfe_destroy.argtypes = [vp]
+    L.drfe_destroy.restype = None
+    L.drfe_last_error.argtypes = [vp]
+    L.drfe_last_error.restype = C.c_char_p
+    L.drfe_version.restype = C.c_char_p
+    L.drfe_orb_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.drfe_orb_max_keypoints.argtypes = [vp]
+    L.drfe_orb_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, C.POINTER(i32)]
+    L.drfe_orb_extract_batch.argtypes = [vp, vp, sz, sz, i32, i32, i32, vp]
+    L.drfe_orb_download.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
+    L.drfe_orb_counts.argtypes = [vp, i32, vp]
+    L.drfe_orb_pyramid_level.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.drfe_orb_blurred_level.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.drfe_orb_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_frame_stereo_grid_batch.argtypes = [vp, vp, sz, sz, C.POINTER(Camera), i32, vp]
+    L.drfe_frame_download_stereo.argtypes = [vp, i32, vp, vp, i32]
+    L.drfe_frame_download_grid.argtypes = [vp, i32, vp, vp, i32]
+    L.drfe_match_consecutive_batch.argtypes = [vp, vp, vp, C.POINTER(Camera), f32, i32, i32, i32, vp]
+    L.drfe_match_download.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_search_by_projection_last.argtypes = [vp, i32, i32, vp, vp, C.POINTER(Camera), vp, i32, f32, i32, i32,
+                                                 vp, vp, i32, C.POINTER(i32)]
+    L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
+    L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
+    L.drfe_profile_enable.argtypes = [vp, i32]
+    L.drfe_profile_stage_ms.argtypes = [vp, vp]
+    L.drfe_stream_sync.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_camera(fx, fy, cx, cy, bf, depth_map_factor, width, height) -> Camera:
+    """Frame constants for the no-distortion path (bounds = image, reference src/Frame.cc:884-889).
+    depth_map_factor is the yaml DepthMapFactor; the reference inverts it (src/Tracking.cc:144-148)."""
+    inv = np.float32(1.0) if abs(depth_map_factor) < 1e-5 else np.float32(1.0) / np.float32(depth_map_factor)
+    return Camera(fx, fy, cx, cy, bf, float(inv), 0.0, float(width), 0.0, float(height))
+
+
+class Context:
+    """Owns one drfe_ctx (one HIP device, one batch arena)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7,
+                 max_width=640, max_height=480, max_batch=1, device=0):
+        self.L = load()
+        self.cfg = Config(device, max_width, max_height, max_batch, nfeatures, scale_factor, nlevels, ini_th_fast,
+                          min_th_fast)
+        h = C.c_void_p()
+        rc = self.L.drfe_create(C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise DrfeError(f"drfe_create failed ({rc}): {self.L.drfe_last_error(None).decode()}")
+        self.h = h
+        self.nlevels = nlevels
+        self.max_kp = self.L.drfe_orb_max_keypoints(self.h)
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.drfe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise DrfeError(f"{what} failed ({rc}): {self.L.drfe_last_error(self.h).decode()}")
+
+    # --- ORB ---------------------------------------------------------------------------------------
+    def scale_tables(self):
+        t = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        self._chk(self.L.drfe_orb_scale_tables(self.h, *[_p(a) for a in t]), "drfe_orb_scale_tables")
+        return t
+
+    def orb_extract(self, gray: np.ndarray):
+        """Single host frame -> (keypoints structured array, descriptors [N,32] uint8)."""
+        if gray is None or gray.size == 0:
+            n = C.c_int(0)
+            self._chk(self.L.drfe_orb_extract(self.h, None, 0, 0, 0, None, None, 0, C.byref(n)), "drfe_orb_extract")
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert gray.dtype == np.uint8 and gray.ndim == 2 and gray.strides[1] == 1
+        kps = np.zeros(self.max_kp, KP_DTYPE)
+        desc = np.zeros((self.max_kp, 32), np.uint8)
+        n = C.c_int(0)
+        self._chk(self.L.drfe_orb_extract(self.h, _p(gray), gray.shape[1], gray.shape[0], gray.strides[0], _p(kps),
+                                          _p(desc), self.max_kp, C.byref(n)), "drfe_orb_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def orb_extract_batch_ptr(self, d_gray: int, frame_stride: int, row_stride: int, w: int, h: int, nframes: int,
+                              stream: int = 0):
+        self._chk(self.L.drfe_orb_extract_batch(self.h, C.c_void_p(d_gray), frame_stride, row_stride, w, h, nframes,
+                                                C.c_void_p(stream)), "drfe_orb_extract_batch")
+
+    def orb_download(self, slot: int):
+        kps = np.zeros(self.max_kp, KP_DTYPE)
+        desc = np.zeros((self.max_kp, 32), np.uint8)
+        n = C.c_int(0)
+        self._chk(self.L.drfe_orb_download(self.h, slot, _p(kps), _p(desc), self.max_kp, C.byref(n)), "drfe_orb_download")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def orb_counts(self, nframes: int):
+        c = np.zeros(nframes, np.int32)
+        self._chk(self.L.drfe_orb_counts(self.h, nframes, _p(c)), "drfe_orb_counts")
+        return c
+
+    def pyramid_level(self, slot, level):
+        w, h = C.c_int(), C.c_int()
+        self._chk(self.L.drfe_orb_pyramid_level(self.h, slot, level, None, C.byref(w), C.byref(h)), "pyramid_level")
+        out = np.zeros((h.value, w.value), np.uint8)
+        self._chk(self.L.drfe_orb_pyramid_level(self.h, slot, level, _p(out), C.byref(w), C.byref(h)), "pyramid_level")
+        return out
+
+    def blurred_level(self, slot, level):
+        w, h = C.c_int(), C.c_int()
+        self._chk(self.L.drfe_orb_blurred_level(self.h, slot, level, None, C.byref(w), C.byref(h)), "blurred_level")
+        out = np.zeros((h.value, w.value), np.uint8)
+        self._chk(self.L.drfe_orb_blurred_level(self.h, slot, level, _p(out), C.byref(w), C.byref(h)), "blurred_level")
+        return out
+
+    def candidates(self, slot, level):
+        n = C.c_int()
+        self._chk(self.L.drfe_orb_candidates(self.h, slot, level, None, 0, C.byref(n)), "candidates")
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        self._chk(self.L.drfe_orb_candidates(self.h, slot, level, _p(out), len(out), C.byref(n)), "candidates")
+        return out[:n.value]
+
+    # --- Frame glue --------------------------------------------------------------------------------
+    def stereo_grid_batch_ptr(self, d_depth: int, frame_stride_elems: int, row_stride_elems: int, cam: Camera,
+                              nframes: int, stream: int = 0):
+        self._chk(self.L.drfe_frame_stereo_grid_batch(self.h, C.c_void_p(d_depth), frame_stride_elems,
+                                                      row_stride_elems, C.byref(cam), nframes, C.c_void_p(stream)),
+                  "drfe_frame_stereo_grid_batch")
+
+    def download_stereo(self, slot):
+        ur = np.zeros(self.max_kp, np.float32)
+        z = np.zeros(self.max_kp, np.float32)
+        self._chk(self.L.drfe_frame_download_stereo(self.h, slot, _p(ur), _p(z), self.max_kp), "download_stereo")
+        return ur, z
+
+    def download_grid(self, slot):
+        off = np.zeros(64 * 48 + 1, np.int32)
+        idx = np.zeros(self.max_kp, np.int32)
+        self._chk(self.L.drfe_frame_download_grid(self.h, slot, _p(off), _p(idx), self.max_kp), "download_grid")
+        return off, idx[:off[-1]].copy()
+
+    # --- matchers ----------------------------------------------------------------------------------
+    def match_consecutive_batch(self, Tcw: np.ndarray, Twc: np.ndarray, cam: Camera, th=15.0, mono=False,
+                                check_ori=True, nframes=None, stream: int = 0):
+        Tcw = np.ascontiguousarray(Tcw, np.float32)
+        Twc = np.ascontiguousarray(Twc, np.float32)
+        nframes = len(Tcw) if nframes is None else nframes
+        self._chk(self.L.drfe_match_consecutive_batch(self.h, _p(Tcw), _p(Twc), C.byref(cam), th, int(mono),
+                                                      int(check_ori), nframes, C.c_void_p(stream)),
+                  "drfe_match_consecutive_batch")
+
+    def match_download(self, slot):
+        m = np.zeros(self.max_kp, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_match_download(self.h, slot, _p(m), self.max_kp, C.byref(n)), "drfe_match_download")
+        return m, n.value
+
+    def search_by_projection_last(self, cur_slot, last_slot, Tcw_cur, Tcw_last, cam, last_mp, n_cur, th=15.0,
+                                  mono=False, check_ori=True, cur_mp=None, cur_obs=None):
+        last_mp = np.ascontiguousarray(last_mp, MAPPOINT_DTYPE)
+        out = np.full(n_cur, -1, np.int32) if cur_mp is None else np.ascontiguousarray(cur_mp, np.int32).copy()
+        obs = None if cur_obs is None else np.ascontiguousarray(cur_obs, np.uint8)
+        n = C.c_int()
+        self._chk(self.L.drfe_search_by_projection_last(
+            self.h, cur_slot, last_slot, _p(np.ascontiguousarray(Tcw_cur, np.float32)),
+            _p(np.ascontiguousarray(Tcw_last, np.float32)), C.byref(cam), _p(last_mp), len(last_mp), th, int(mono),
+            int(check_ori), _p(obs), _p(out), n_cur, C.byref(n)), "drfe_search_by_projection_last")
+        return n.value, out
+
+    def search_by_projection_map(self, slot, mps, n, th, nnratio, frame_mp=None, claim_obs=None):
+        mps = np.ascontiguousarray(mps, TRACKED_DTYPE)
+        out = np.full(n, -1, np.int32) if frame_mp is None else np.ascontiguousarray(frame_mp, np.int32).copy()
+        obs = None if claim_obs is None else np.ascontiguousarray(claim_obs, np.uint8)
+        nm = C.c_int()
+        self._chk(self.L.drfe_search_by_projection_map(self.h, slot, _p(mps), len(mps), th, nnratio, _p(obs), _p(out),
+                                                       n, C.byref(nm)), "drfe_search_by_projection_map")
+        return nm.value, out
+
+    def bf_knn(self, Q, T, k):
+        Q = np.ascontiguousarray(Q, np.uint8)
+        T = np.ascontiguousarray(T, np.uint8)
+        idx = np.zeros((len(Q), k), np.int32)
+        dist = np.zeros((len(Q), k), np.int32)
+        self._chk(self.L.drfe_match_bf_knn(self.h, _p(Q), len(Q), _p(T), len(T), k, _p(idx), _p(dist)), "drfe_match_bf_knn")
+        return idx, dist
+
+    # --- measurement -------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.L.drfe_profile_enable(self.h, int(on)), "drfe_profile_enable")
+
+    def profile_stage_ms(self):
+        ms = np.zeros(len(STAGES), np.float32)
+        self._chk(self.L.drfe_profile_stage_ms(self.h, _p(ms)), "drfe_profile_stage_ms")
+        return dict(zip(STAGES, ms.tolist()))
+
+    def sync(self):
+        self._chk(self.L.drfe_stream_sync(self.h), "drfe_stream_sync")

@@ -1,0 +1,185 @@
+/* drfe.h — C-ABI of the MI355X-native DR-SLAM feature front-end (libdrfe.so).
+ *
+ * The reference (WangWen-Believer/DR-SLAM) has no FFI: its per-frame feature path is reached through
+ * C++ classes.  Each entry point below names the reference interface it replaces; INTEGRATION.md
+ * shows the adaptor a maintainer would drop into DR-SLAM (`ORBextractor::operator()` etc. calling
+ * these functions).  Plain C: opaque context, caller-owned buffers with capacities, int status
+ * (0 = ok, <0 = drfe_status), no exceptions and no OpenCV/torch types cross this boundary.
+ *
+ * Threading: a drfe_ctx is bound to one HIP device and is NOT re-entrant (like the reference's
+ * ORBextractor instance, include/ORBextractor.h:85 public pyramid member); use one context per calling
+ * thread (Tracking / LocalMapping / LoopClosing).
+ *
+ * Pointers named d_* are device (HBM) pointers; all others are host pointers.
+ */
+#ifndef DRFE_H
+#define DRFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum drfe_status {
+    DRFE_OK = 0,
+    DRFE_ERR_INVALID = -1,    /* bad argument (null pointer, size mismatch, unsupported geometry) */
+    DRFE_ERR_HIP = -2,        /* HIP runtime failure; see drfe_last_error */
+    DRFE_ERR_CAPACITY = -3,   /* caller buffer or internal pool too small; nothing partial is returned */
+    DRFE_ERR_STATE = -4       /* call order violated (e.g. match before extract) */
+} drfe_status;
+
+/* cv::KeyPoint binary layout (7 x 4 bytes) so an adaptor can memcpy into std::vector<cv::KeyPoint>. */
+typedef struct drfe_keypoint {
+    float x, y;       /* pt, level-0 pixel units (already multiplied by the level scale) */
+    float size;       /* 31 * scale[octave] truncated to int, src/ORBextractor.cc:837,846 */
+    float angle;      /* degrees [0,360), IC_Angle */
+    float response;   /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* -1 */
+} drfe_keypoint;
+
+/* ORBextractor constructor arguments (include/ORBextractor.h:56-57; yaml keys ORBextractor.*,
+ * src/Tracking.cc:120-126) plus the capacities the device buffers are sized for. */
+typedef struct drfe_config {
+    int32_t device;        /* HIP device ordinal */
+    int32_t max_width;     /* largest frame the context will see (e.g. 640) */
+    int32_t max_height;    /* (e.g. 480) */
+    int32_t max_batch;     /* frames processed per batched call (>=1) */
+    int32_t nfeatures;     /* 1000 */
+    float scale_factor;    /* 1.2f */
+    int32_t nlevels;       /* 8 */
+    int32_t ini_th_fast;   /* 20 */
+    int32_t min_th_fast;   /* 7 */
+} drfe_config;
+
+typedef struct drfe_ctx drfe_ctx;
+
+/* Camera / Frame constants the glue and matchers read (Frame::Frame, src/Frame.cc:104-196). */
+typedef struct drfe_camera {
+    float fx, fy, cx, cy;
+    float bf;            /* Camera.bf */
+    float depth_factor;  /* 1/DepthMapFactor: metres per raw depth unit (src/Tracking.cc:144-148) */
+    float min_x, max_x, min_y, max_y; /* mnMinX.. (image bounds when k1 == 0, src/Frame.cc:884-889) */
+} drfe_camera;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* lifetime                                                                                          */
+int drfe_create(const drfe_config* cfg, drfe_ctx** out);
+void drfe_destroy(drfe_ctx* ctx);
+const char* drfe_last_error(const drfe_ctx* ctx); /* ctx may be NULL: last create() failure */
+const char* drfe_version(void);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* ORBextractor (replaces src/ORBextractor.cc)                                                       */
+
+/* Getters of include/ORBextractor.h:63-83: arrays of nlevels floats. */
+int drfe_orb_scale_tables(const drfe_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
+/* Capacity a caller needs for keypoint/descriptor buffers of one frame (>= any N the path can emit). */
+int drfe_orb_max_keypoints(const drfe_ctx* ctx);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors), src/ORBextractor.cc:1043-1105.
+ * gray: CV_8UC1 host image with row stride `stride` bytes.  Writes N keypoints and N x 32 descriptor
+ * bytes (level-major order exactly as the reference concatenates them).  Empty image (w==0||h==0 or
+ * gray NULL) -> *n_out = 0, DRFE_OK (reference returns silently, :1046-1047). */
+int drfe_orb_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t stride, drfe_keypoint* kps,
+                     uint8_t* desc, int cap, int* n_out);
+
+/* Batched, device-resident form: nframes (<= max_batch) CV_8UC1 frames already in HBM, frame f at
+ * d_gray + f*frame_stride, rows `row_stride` bytes apart.  Asynchronous on `stream` (a hipStream_t;
+ * NULL = the context's own stream).  Results stay in the context's frame slots 0..nframes-1. */
+int drfe_orb_extract_batch(drfe_ctx* ctx, const uint8_t* d_gray, size_t frame_stride, size_t row_stride, int w,
+                           int h, int nframes, void* stream);
+/* Copy slot results to host (synchronises the batch stream). */
+int drfe_orb_download(drfe_ctx* ctx, int slot, drfe_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* Per-slot keypoint counts (host array of nframes ints; synchronises). */
+int drfe_orb_counts(drfe_ctx* ctx, int nframes, int* counts);
+
+/* mvImagePyramid parity (public member, include/ORBextractor.h:85): copy the bordered level
+ * ((w_l+38) x (h_l+38), tightly packed) of a slot to host.  out may be NULL to query sizes. */
+int drfe_orb_pyramid_level(drfe_ctx* ctx, int slot, int level, uint8_t* out, int* bordered_w, int* bordered_h);
+/* Debug/parity taps (tests): blurred interior level, FAST candidates (x,y,response relative to the
+ * 16-px detection border, unordered). */
+int drfe_orb_blurred_level(drfe_ctx* ctx, int slot, int level, uint8_t* out, int* w, int* h);
+int drfe_orb_candidates(drfe_ctx* ctx, int slot, int level, int32_t* xyr, int cap, int* n_out);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Frame glue (replaces Frame::ComputeStereoFromRGBD + AssignFeaturesToGrid, src/Frame.cc:224-237,
+ * 893-911; no-distortion path of UndistortKeyPoints :836-838).                                      */
+
+/* d_depth: raw CV_16U depth frames in HBM (same indexing as d_gray).  For every slot computes
+ * mvDepth/mvuRight and the 64x48 feature grid, all kept on device for the matchers. */
+int drfe_frame_stereo_grid_batch(drfe_ctx* ctx, const uint16_t* d_depth, size_t frame_stride_elems,
+                                 size_t row_stride_elems, const drfe_camera* cam, int nframes, void* stream);
+int drfe_frame_download_stereo(drfe_ctx* ctx, int slot, float* u_right, float* depth, int cap);
+/* grid as CSR in the reference's iteration order (cell = ix*48 + iy): offsets[64*48+1], indices[N] */
+int drfe_frame_download_grid(drfe_ctx* ctx, int slot, int32_t* offsets, int32_t* indices, int cap);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* ORBmatcher (replaces src/ORBmatcher.cc hot paths)                                                 */
+
+/* What the matcher reads through LastFrame.mvpMapPoints[i] (MapPoint::GetWorldPos/GetDescriptor/
+ * Observations, src/ORBmatcher.cc:1419-1423,1468-1470). */
+typedef struct drfe_map_point {
+    uint8_t valid;        /* pMP != NULL && !mvbOutlier[i] */
+    uint8_t obs_positive; /* Observations() > 0 */
+    uint8_t pad[2];
+    float world[3];
+    uint8_t desc[32];
+} drfe_map_point;
+
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), src/ORBmatcher.cc:1396-1535,
+ * for every consecutive slot pair of a batch: cur = slot s, last = slot s-1 (s = 1..nframes-1).
+ * Map points of `last` are its own keypoints with valid depth, unprojected with Twc[last]
+ * (Frame::UnprojectStereo, src/Frame.cc:913-923) — the state Tracking::UpdateLastFrame leaves for an
+ * RGB-D stream.  Tcw/Twc: nframes row-major 4x4 float matrices (host).  d_matches (device, may be
+ * NULL) / results kept in ctx: per slot s, int32[max_keypoints]: index of the last-frame keypoint
+ * matched to current keypoint i, or -1.  nnratio unused by this overload (no ratio test in the
+ * reference); check_ori = mbCheckOrientation. */
+int drfe_match_consecutive_batch(drfe_ctx* ctx, const float* Tcw, const float* Twc, const drfe_camera* cam,
+                                 float th, int mono, int check_ori, int nframes, void* stream);
+int drfe_match_download(drfe_ctx* ctx, int slot, int32_t* cur_to_last, int cap, int* nmatches);
+
+/* General form of the same overload with caller-supplied map points for `last` slot and initial
+ * CurrentFrame.mvpMapPoints claims (cur_mp in/out: -1 = NULL; cur_obs: Observations()>0 of the
+ * initial claims, may be NULL = all 1). Synchronous. */
+int drfe_search_by_projection_last(drfe_ctx* ctx, int cur_slot, int last_slot, const float* Tcw_cur,
+                                   const float* Tcw_last, const drfe_camera* cam, const drfe_map_point* last_mp,
+                                   int n_last, float th, int mono, int check_ori, const uint8_t* cur_obs,
+                                   int32_t* cur_mp, int n_cur, int* nmatches);
+
+/* What SearchByProjection(Frame&, vector<MapPoint*>&, th) reads (fields written by
+ * Frame::isInFrustum, src/Frame.cc:602-657). */
+typedef struct drfe_tracked_point {
+    uint8_t track_in_view, bad, obs_positive, pad;
+    int32_t level;   /* mnTrackScaleLevel */
+    float proj_x, proj_y, proj_xr, view_cos;
+    uint8_t desc[32];
+} drfe_tracked_point;
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:46-130.
+ * frame_mp in/out: per frame keypoint the index into mps or -1. Synchronous. */
+int drfe_search_by_projection_map(drfe_ctx* ctx, int slot, const drfe_tracked_point* mps, int m, float th,
+                                  float nnratio, const uint8_t* claim_obs, int32_t* frame_mp, int n,
+                                  int* nmatches);
+
+/* cv::BFMatcher(NORM_HAMMING).match / knnMatch(k<=2) on 256-bit descriptors (src/ORBmatcher.cc:1346,
+ * src/LSDmatcher.cpp:222,254): ascending distance, ties -> lower train index. idx/dist: nq x k. */
+int drfe_match_bf_knn(drfe_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx,
+                      int32_t* dist);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* measurement                                                                                       */
+enum { DRFE_STAGE_PYRAMID = 0, DRFE_STAGE_FAST, DRFE_STAGE_QUADTREE, DRFE_STAGE_BLUR, DRFE_STAGE_DESC,
+       DRFE_STAGE_GLUE, DRFE_STAGE_MATCH, DRFE_STAGE_COUNT };
+/* When enabled, batched calls bracket every stage with HIP events on the launch stream. */
+int drfe_profile_enable(drfe_ctx* ctx, int on);
+/* Milliseconds per stage of the most recent batched calls (synchronises). */
+int drfe_profile_stage_ms(drfe_ctx* ctx, float* ms /* DRFE_STAGE_COUNT */);
+int drfe_stream_sync(drfe_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRFE_H */
