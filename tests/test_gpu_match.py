@@ -1,0 +1,144 @@
+"""-m gpu parity tests of the Frame glue and the matchers: HIP (through the C-ABI) vs the CPU oracle.
+Bar: bit-exact match index arrays and counts; uRight/depth float bit patterns; identical grid CSR."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _poses(frames):
+    Twc = np.stack([f[2] for f in frames]).astype(np.float64)
+    Tcw = np.linalg.inv(Twc)
+    return Tcw.astype(np.float32), Twc.astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def setup(frames_room, oracle_mod):
+    import torch
+    from dr_slam_amd import synth
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = synth.TUM3
+    fe = FrontEnd(cam, max_batch=8)
+    gray = torch.from_numpy(np.stack([f[0] for f in frames_room])).cuda()
+    depth = torch.from_numpy(np.stack([f[1] for f in frames_room]).view(np.int16)).cuda()
+    Tcw, Twc = _poses(frames_room)
+    fe.process(gray, depth, Tcw, Twc, th=15.0, check_ori=True, stream=torch.cuda.current_stream().cuda_stream)
+    o = oracle_mod.OrbOracle()
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    oframes = []
+    for g, d, _ in frames_room:
+        kps, desc = o(g)
+        df = oracle_mod.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+        oframes.append(oracle_mod.FrameOracle(kps, desc, df, K4, cam.bf, cam.w, cam.h, o.scale))
+    yield fe, oframes, Tcw, Twc, cam
+    fe.ctx.close()
+
+
+def test_stereo_and_grid(setup):
+    fe, oframes, *_ = setup
+    for s, fo in enumerate(oframes):
+        ur, z = fe.ctx.download_stereo(s)
+        assert np.array_equal(ur[:fo.N].view(np.uint32), fo.uRight.view(np.uint32))
+        assert np.array_equal(z[:fo.N].view(np.uint32), fo.depth.view(np.uint32))
+        off, idx = fe.ctx.download_grid(s)
+        ooff, oidx = fo.grid_csr()
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        assert (z[:fo.N] > 0).mean() > 0.9
+
+
+def _last_mp(oracle_mod, fo, Twc):
+    world, valid = fo.unproject(Twc)
+    mp = np.zeros(fo.N, oracle_mod.MAPPOINT_DTYPE)
+    mp["valid"] = valid
+    mp["obsPositive"] = 1
+    mp["world"] = world
+    mp["desc"] = fo.desc
+    return mp
+
+
+def test_consecutive_search_by_projection(setup, oracle_mod):
+    """ORBmatcher(0.9,true).SearchByProjection(Cur, Last, 15, false) for every consecutive pair."""
+    fe, oframes, Tcw, Twc, cam = setup
+    for s in range(1, len(oframes)):
+        mp = _last_mp(oracle_mod, oframes[s - 1], Twc[s - 1])
+        n_o, m_o = oracle_mod.search_by_projection_last(oframes[s], oframes[s - 1], Tcw[s], Tcw[s - 1], mp, 15.0,
+                                                        False, True)
+        m_g, n_g = fe.matches(s)
+        assert n_g == n_o, (s, n_g, n_o)
+        assert np.array_equal(m_g[:oframes[s].N], m_o)
+        assert n_o > 300   # the synthetic sequence is matchable
+
+
+def test_search_by_projection_last_general(setup, oracle_mod):
+    """Caller-supplied map points, pre-existing claims with and without observations, no orientation check,
+    forward-motion level rule (pose moved 0.5 m along the optical axis)."""
+    from dr_slam_amd import lib
+    fe, oframes, Tcw, Twc, cam = setup
+    cur, last = oframes[2], oframes[1]
+    mp = _last_mp(oracle_mod, last, Twc[1])
+    rng = np.random.default_rng(5)
+    mp["valid"] &= rng.random(last.N) > 0.2
+    mp["obsPositive"] = rng.random(last.N) > 0.3
+    pre = np.full(cur.N, -1, np.int32)
+    pre[rng.choice(cur.N, 120, replace=False)] = 7
+    obs = (rng.random(cur.N) > 0.5).astype(np.uint8)
+    gmp = np.zeros(last.N, lib.MAPPOINT_DTYPE)
+    gmp["valid"], gmp["obs_positive"], gmp["world"], gmp["desc"] = mp["valid"], mp["obsPositive"], mp["world"], mp["desc"]
+    for check_ori, dz in ((False, 0.0), (True, 0.5), (True, -0.5)):
+        Tc = Tcw[2].copy()
+        Tc[2, 3] -= dz
+        n_o, m_o = oracle_mod.search_by_projection_last(cur, last, Tc, Tcw[1], mp, 15.0, False, check_ori, pre, obs)
+        n_g, m_g = fe.ctx.search_by_projection_last(2, 1, Tc, Tcw[1], fe.cam, gmp, cur.N, 15.0, False, check_ori, pre, obs)
+        assert n_g == n_o, (check_ori, dz, n_g, n_o)
+        assert np.array_equal(m_g, m_o)
+
+
+def test_search_by_projection_map(setup, oracle_mod):
+    """ORBmatcher(0.8).SearchByProjection(F, vpMapPoints, th=3): local-map points = last frame's points."""
+    from dr_slam_amd import lib
+    fe, oframes, Tcw, Twc, cam = setup
+    cur, last = oframes[3], oframes[2]
+    world, valid = last.unproject(Twc[2])
+    Pc = (Tcw[3][:3, :3].astype(np.float64) @ world.T.astype(np.float64)).T + Tcw[3][:3, 3]
+    z = np.where(Pc[:, 2] > 0.05, Pc[:, 2], 1.0)
+    u = cam.fx * Pc[:, 0] / z + cam.cx
+    v = cam.fy * Pc[:, 1] / z + cam.cy
+    rng = np.random.default_rng(9)
+    tp = np.zeros(last.N, oracle_mod.TRACKED_DTYPE)
+    tp["trackInView"] = valid & (Pc[:, 2] > 0.05) & (u > 0) & (u < cam.w) & (v > 0) & (v < cam.h)
+    tp["bad"] = rng.random(last.N) < 0.05
+    tp["obsPositive"] = rng.random(last.N) > 0.2
+    tp["level"] = last.kps["octave"]
+    tp["projX"], tp["projY"] = u.astype(np.float32), v.astype(np.float32)
+    tp["projXR"] = (u - cam.bf / z).astype(np.float32)
+    tp["viewCos"] = np.where(rng.random(last.N) > 0.5, 0.9995, 0.9).astype(np.float32)
+    tp["desc"] = last.desc
+    gtp = np.zeros(last.N, lib.TRACKED_DTYPE)
+    for a, b in (("track_in_view", "trackInView"), ("bad", "bad"), ("obs_positive", "obsPositive"), ("level", "level"),
+                 ("proj_x", "projX"), ("proj_y", "projY"), ("proj_xr", "projXR"), ("view_cos", "viewCos"), ("desc", "desc")):
+        gtp[a] = tp[b]
+    for th, ratio in ((3.0, 0.8), (1.0, 0.8), (5.0, 0.6)):
+        n_o, m_o = oracle_mod.search_by_projection_map(cur, tp, th, ratio)
+        n_g, m_g = fe.ctx.search_by_projection_map(3, gtp, cur.N, th, ratio)
+        assert n_g == n_o, (th, ratio, n_g, n_o)
+        assert np.array_equal(m_g, m_o)
+    assert n_o > 100
+
+
+def test_bf_knn(setup, oracle_mod):
+    """cv::BFMatcher(NORM_HAMMING) 1-NN (MatchORBPoints) and 2-NN (LSDmatcher) incl. exact ties."""
+    fe, oframes, *_ = setup
+    rng = np.random.default_rng(3)
+    Q = np.concatenate([oframes[1].desc, oframes[0].desc[:50]])
+    T = np.concatenate([oframes[0].desc, oframes[0].desc[:30]])      # duplicated rows: equal distances
+    for k in (1, 2):
+        gi, gd = fe.ctx.bf_knn(Q, T, k)
+        oi, od = oracle_mod.bf_knn(Q, T, k)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    # ragged: 40x40 line-descriptor-sized problem, single train row, empty query set
+    A = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    gi, gd = fe.ctx.bf_knn(A, A[:1], 2)
+    oi, od = oracle_mod.bf_knn(A, A[:1], 2)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    gi, gd = fe.ctx.bf_knn(A[:0], A, 1)
+    assert gi.shape == (0, 1)
