@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — RGB-D frames/sec (extract+match) at 640x480 on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of `--batch` synthetic frames of one sequence,
+already resident in HBM: ORB extraction (pyramid, FAST, quadtree, blur, rBRIEF) -> stereo/grid glue ->
+SearchByProjection(frame k, frame k-1) for every consecutive pair of the batch (BASELINE config 2).
+N>1: one process per GPU (torch.distributed, backend nccl == RCCL), every rank runs its own sequence —
+no data-path collective; timing is barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, HIP-event
+timed) and `cpu_baseline` (the CPU oracle timed on this host, single thread, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+
+# SURVEY.md §8(d) algorithmic bytes per 640x480 frame, by stage (N = 1000 keypoints)
+ALGO_BYTES = {
+    "pyramid": 307200 + 1158012 + 926546,     # read gray + write bordered pyramid + read for resize
+    "fast": 950532,                           # FAST read of every level interior
+    "blur": 1901064,                          # blur read + write
+    "desc": 1922000 + 60000,                  # orientation + descriptor patches + outputs
+    "match": 676000,                          # window match (a-10)
+}
+
+
+def make_batch(seed: int, batch: int, n_distinct: int):
+    """Ping-pong over n_distinct consecutive frames so every adjacent pair of the batch is a real
+    frame-to-frame motion: 0,1,..,n-1,n-2,..,1,0,1,.."""
+    from dr_slam_amd import synth
+    base = list(synth.sequence(seed, n_distinct, cam=synth.TUM3))
+    order, k, d = [], 0, 1
+    for _ in range(batch):
+        order.append(k)
+        if n_distinct > 1:
+            if k + d < 0 or k + d >= n_distinct:
+                d = -d
+            k += d
+    gray = np.stack([base[i][0] for i in order])
+    depth = np.stack([base[i][1] for i in order])
+    Twc = np.stack([base[i][2] for i in order]).astype(np.float64)
+    Tcw = np.linalg.inv(Twc)
+    return gray, depth, Tcw.astype(np.float32), Twc.astype(np.float32), base
+
+
+def cpu_baseline(base, budget_s: float = 12.0):
+    """Oracle (kind 'port', 1 thread): extract + SearchByProjection against the previous frame."""
+    from dr_slam_amd import synth
+    from oracle import oracle as orc
+    cam = synth.TUM3
+    o = orc.OrbOracle()
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = np.float32(1.0) / np.float32(cam.depth_factor)
+    prev = None
+    n, t0 = 0, time.perf_counter()
+    i = 0
+    while True:
+        g, d, Twc = base[i % len(base)]
+        kps, desc = o(g)
+        fo = orc.FrameOracle(kps, desc, orc.depth_to_float(d, inv), K4, cam.bf, cam.w, cam.h, o.scale)
+        Tcw = np.linalg.inv(Twc).astype(np.float32)
+        if prev is not None:
+            pf, pTwc, pTcw = prev
+            world, valid = pf.unproject(pTwc.astype(np.float32))
+            mp = np.zeros(pf.N, orc.MAPPOINT_DTYPE)
+            mp["valid"], mp["obsPositive"], mp["world"], mp["desc"] = valid, 1, world, pf.desc
+            orc.search_by_projection_last(fo, pf, Tcw, pTcw, mp, 15.0, False, True)
+        prev = (fo, Twc, Tcw)
+        n += 1
+        i += 1
+        el = time.perf_counter() - t0
+        if el > budget_s and n >= 8:
+            break
+    return {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames 640x480 (extract + SearchByProjection vs previous frame), CPU oracle "
+                      f"-O3 -march=x86-64-v3 -ffp-contract=off, 1 thread, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames rendered per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from dr_slam_amd import synth
+    from dr_slam_amd.pipeline import FrontEnd
+
+    B = args.batch
+    gray, depth, Tcw, Twc, base = make_batch(10 + rank, B, args.distinct)
+    fe = FrontEnd(synth.TUM3, max_batch=B, device=local_rank)
+    gray_t = torch.from_numpy(gray).to(dev)
+    depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if world > 1:
+        # the one initial exchange of the sharded mode: rank 0's constant tables travel over RCCL/xGMI
+        # (stands in for the ORB vocabulary broadcast of SURVEY.md §8e until the BoW row lands)
+        tab = torch.from_numpy(np.concatenate(fe.ctx.scale_tables())).to(dev)
+        dist.broadcast(tab, 0)
+
+    def step():
+        fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # sanity: the batch really produced keypoints and matches
+    counts = fe.ctx.orb_counts(B)
+    _, nm = fe.matches(B - 1)
+    assert counts.min() > 500 and nm > 100, (counts.min(), nm)
+
+    out = None
+    if rank == 0:
+        # per-stage kernel time: same steps again with HIP events around every stage on the launch stream
+        fe.ctx.profile_enable(True)
+        acc = {}
+        reps = max(3, min(args.steps, 10))
+        for _ in range(reps):
+            step()
+            ms = fe.ctx.profile_stage_ms()
+            for k, v in ms.items():
+                acc[k] = acc.get(k, 0.0) + v
+        fe.ctx.profile_enable(False)
+        stage_ms = {k: v / reps for k, v in acc.items()}
+        cand = {k: stage_ms[k] for k in ALGO_BYTES}
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        roof_stage = dom if dom in ALGO_BYTES else max(cand, key=lambda k: cand[k])
+        algo = ALGO_BYTES[roof_stage] * B
+        achieved = algo / (stage_ms[roof_stage] * 1e-3) / 1e9
+        fps = world * B * args.steps / el
+        out = {
+            "metric": "RGB-D frames/sec (extract+match) at 640x480",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "640x480 synthetic RGB-D (TUM3 intrinsics), ORB extract 1000/1.2/8/20/7 + "
+                                   "SearchByProjection(frame k, frame k-1, th=15) on consecutive frames; "
+                                   "BASELINE config 2", "batch_per_gpu": B, "frames_per_step": world * B,
+                       "sharding": "one sequence per GPU, no data-path collective"},
+            "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel_stage": roof_stage, "dominant_stage": dom,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": algo},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(base)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

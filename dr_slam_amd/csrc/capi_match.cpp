@@ -26,7 +26,7 @@ void drfe_match_buffers_free(drfe_ctx* c)
 {
     MatchBuffers* m = c->mb;
     if (!m) return;
-    void* ptrs[] = {m->d_pairs, m->d_queries, m->d_mps, m->d_scale, m->d_candIdx, m->d_candKey, m->d_candCnt,
+    void* ptrs[] = {m->d_pairs, m->d_queries, m->d_mps, m->d_scale, m->d_candIdx, m->d_candKey, m->d_candCnt, m->d_candBest,
                     m->d_hist, m->d_initObs, m->d_bfIdx, m->d_bfDist, m->d_bfQ, m->d_bfT};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -47,7 +47,7 @@ MatchBuffers* drfe_match_buffers(drfe_ctx* c)
     bool ok = dalloc(&m->d_pairs, B) == hipSuccess && dalloc(&m->d_queries, Q) == hipSuccess &&
               dalloc(&m->d_mps, Q) == hipSuccess && dalloc(&m->d_scale, DRFE_MAX_LEVELS) == hipSuccess &&
               dalloc(&m->d_candIdx, Q * DRFE_MATCH_MAX_CAND) == hipSuccess &&
-              dalloc(&m->d_candKey, Q * DRFE_MATCH_MAX_CAND) == hipSuccess && dalloc(&m->d_candCnt, Q) == hipSuccess &&
+              dalloc(&m->d_candKey, Q * DRFE_MATCH_MAX_CAND) == hipSuccess && dalloc(&m->d_candCnt, Q) == hipSuccess && dalloc(&m->d_candBest, Q) == hipSuccess &&
               dalloc(&m->d_hist, B * 2 * (size_t)c->maxKp) == hipSuccess &&
               dalloc(&m->d_initObs, (size_t)c->maxKp) == hipSuccess && dalloc(&m->d_bfIdx, m->bfCap * 2) == hipSuccess &&
               dalloc(&m->d_bfDist, m->bfCap * 2) == hipSuccess && dalloc(&m->d_bfQ, m->bfCap * 32) == hipSuccess &&

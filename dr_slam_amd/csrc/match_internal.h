@@ -32,6 +32,7 @@ struct MatchBuffers {
     uint32_t* d_candIdx;      /* [query][DRFE_MATCH_MAX_CAND]: keypoint index | octave << 24 */
     uint32_t* d_candKey;      /* distance << 22 | visit position */
     int* d_candCnt;
+    uint2* d_candBest;        /* per query: (min key, its keypoint index | octave << 24) */
     uint16_t* d_hist;         /* rotation histogram entries per pair: (bin, idx) */
     uint8_t* d_initObs;       /* [maxKp] staging of caller-supplied claim flags */
     int32_t* d_bfIdx; int32_t* d_bfDist; uint8_t* d_bfQ; uint8_t* d_bfT; size_t bfCap; /* elements / bytes */

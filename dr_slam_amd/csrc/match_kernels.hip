@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
                                                            float invW, float invH,
                                                            uint32_t* __restrict__ candIdx,
                                                            uint32_t* __restrict__ candKey,
-                                                           int* __restrict__ candCnt, int* __restrict__ status)
+                                                           int* __restrict__ candCnt, uint2* __restrict__ candBest,
+                                                           int* __restrict__ status)
 {
     __shared__ int sCnt[256 / WAVE];
     const MatchPair P = pairs[blockIdx.y];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
     const size_t qo = (size_t)P.queryBase + qi;
     const MatchQuery q = queries[qo];
     if (lane == 0) sCnt[wv] = 0;
-    if (!q.valid) { if (lane == 0) candCnt[qo] = 0; return; }
+    if (!q.valid) { if (lane == 0) { candCnt[qo] = 0; candBest[qo] = make_uint2(0xFFFFFFFFu, 0u); } return; }
     const float x = q.u, y = q.v, r = q.radius;
     /* Frame::GetFeaturesInArea cell range, src/Frame.cc:735-749 */
     const int nMinCellX = max(0, (int)floorf((x - cam.min_x - r) * invW));
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
     const int nMinCellY = max(0, (int)floorf((y - cam.min_y - r) * invH));
     const int nMaxCellY = min(DRFE_GRID_ROWS - 1, (int)ceilf((y - cam.min_y + r) * invH));
     if (nMinCellX >= DRFE_GRID_COLS || nMaxCellX < 0 || nMinCellY >= DRFE_GRID_ROWS || nMaxCellY < 0) {
-        if (lane == 0) candCnt[qo] = 0;
+        if (lane == 0) { candCnt[qo] = 0; candBest[qo] = make_uint2(0xFFFFFFFFu, 0u); }
         return;
     }
     const int ny = nMaxCellY - nMinCellY + 1;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
     const uint64_t q0 = (uint64_t)q.desc[0] | ((uint64_t)q.desc[1] << 32), q1 = (uint64_t)q.desc[2] | ((uint64_t)q.desc[3] << 32),
                    q2 = (uint64_t)q.desc[4] | ((uint64_t)q.desc[5] << 32), q3 = (uint64_t)q.desc[6] | ((uint64_t)q.desc[7] << 32);
     bool overflow = false;
+    uint32_t myKey = 0xFFFFFFFFu, myIdx = 0;
     for (int c = lane; c < ncell; c += WAVE) {
         const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;   /* ix outer, iy inner */
         const int cell = ix * DRFE_GRID_ROWS + iy;
@@ -274,13 +276,25 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
             if (pos < DRFE_MATCH_MAX_CAND) {
                 oIdx[pos] = (uint32_t)idx | ((uint32_t)kp.octave << 24);
                 /* visit position: cell sequence number, then position inside the cell */
-                oKey[pos] = ((uint32_t)dist << 22) | ((uint32_t)min(c, 16383) << 8) | (uint32_t)min(j - b, 255);
+                const uint32_t key = ((uint32_t)dist << 22) | ((uint32_t)min(c, 16383) << 8) | (uint32_t)min(j - b, 255);
+                oKey[pos] = key;
+                if (key < myKey) { myKey = key; myIdx = (uint32_t)idx | ((uint32_t)kp.octave << 24); }
             } else overflow = true;
         }
     }
     if (__any(overflow) && lane == 0) atomicOr(status, 4);
+    /* the query's overall best (min distance, then earliest visit): what the claim replay takes when
+     * nobody claimed it first */
+    uint32_t mn = myKey;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    const unsigned long long who = __ballot(myKey == mn);
+    const uint32_t bIdx = (uint32_t)__shfl((int)myIdx, __ffsll((long long)who) - 1);
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) candCnt[qo] = min(sCnt[wv], DRFE_MATCH_MAX_CAND);
+    if (lane == 0) {
+        candCnt[qo] = min(sCnt[wv], DRFE_MATCH_MAX_CAND);
+        candBest[qo] = make_uint2(mn, bIdx);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -295,97 +309,130 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 
 /* SearchByProjection(CurrentFrame, LastFrame, th, bMono): best unclaimed candidate per map point in
  * index order, TH_HIGH gate, rotation histogram with the reference's 1/HISTO_LENGTH factor quirk
- * (SURVEY.md §9.6), ComputeThreeMaxima, un-assignment of the other bins. */
-__global__ __launch_bounds__(WAVE) void k_resolve_last(const MatchPair* __restrict__ pairs,
-                                                       const MatchQuery* __restrict__ queries,
-                                                       const drfe_keypoint* __restrict__ kps,
-                                                       const int* __restrict__ kpCount, int maxKp,
-                                                       const uint32_t* __restrict__ candIdx,
-                                                       const uint32_t* __restrict__ candKey,
-                                                       const int* __restrict__ candCnt, int checkOri,
-                                                       int* __restrict__ match /* [curSlot][maxKp] in/out */,
-                                                       const uint8_t* __restrict__ initObs,
-                                                       int* __restrict__ matchCount,
-                                                       uint16_t* __restrict__ histScratch /* [pair][2*maxKp] */)
+ * (SURVEY.md §9.6), ComputeThreeMaxima, un-assignment of the other bins.
+ *
+ * One workgroup per frame pair replays the claims 256 map points at a time, speculatively: every
+ * thread picks the best candidate of its map point that no *committed* earlier point holds (normally
+ * the precomputed overall best — no list scan).  If the picks of threads [start, t) are pairwise
+ * distinct, they are exactly what the sequential loop would have chosen (by induction: no earlier
+ * pick removes a later thread's best), so they commit together; the first thread whose pick collides
+ * with an earlier one restarts the speculation from there with the new claims visible. */
+#define RS_THREADS 256
+__global__ __launch_bounds__(RS_THREADS) void k_resolve_last(const MatchPair* __restrict__ pairs,
+                                                             const MatchQuery* __restrict__ queries,
+                                                             const drfe_keypoint* __restrict__ kps,
+                                                             const int* __restrict__ kpCount, int maxKp,
+                                                             const uint32_t* __restrict__ candIdx,
+                                                             const uint32_t* __restrict__ candKey,
+                                                             const int* __restrict__ candCnt,
+                                                             const uint2* __restrict__ candBest, int checkOri,
+                                                             int* __restrict__ match /* [curSlot][maxKp] in/out */,
+                                                             const uint8_t* __restrict__ initObs,
+                                                             int* __restrict__ matchCount,
+                                                             uint16_t* __restrict__ histScratch /* [pair][2*maxKp] */)
 {
-    extern __shared__ unsigned char claim[];   /* per cur keypoint: bit0 claimed, bit1 obs>0 */
+    extern __shared__ int rs_smem[];
+    int* owner = rs_smem;                                             /* [maxKp] lowest thread picking a keypoint */
+    unsigned char* claim = reinterpret_cast<unsigned char*>(rs_smem + maxKp); /* bit0 claimed, bit1 obs>0 */
     __shared__ int hist[30];
+    __shared__ int sFirst, sNm, sEnt, sInd[3];
     const MatchPair P = pairs[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
     const int nCur = kpCount[P.curSlot];
     int* M = match + (size_t)P.curSlot * maxKp;
     const drfe_keypoint* Kc = kps + (size_t)P.curSlot * maxKp;
     const drfe_keypoint* Kl = kps + (size_t)P.lastSlot * maxKp;
     uint16_t* hs = histScratch + (size_t)blockIdx.x * 2 * maxKp;
-    for (int i = lane; i < nCur; i += WAVE) {
+    for (int i = tid; i < nCur; i += RS_THREADS) {
         unsigned char c = 0;
         if (M[i] >= 0) c = 1 | ((initObs ? initObs[i] : 1) ? 2 : 0);
         claim[i] = c;
+        owner[i] = 0x7FFFFFFF;
     }
-    if (lane < 30) hist[lane] = 0;
+    if (tid < 30) hist[tid] = 0;
+    if (tid == 0) { sNm = 0; sEnt = 0; }
     __syncthreads();
-    int nmatches = 0, nEntries = 0;
     const float factor = 1.0f / 30;
-    for (int i = 0; i < nQ; i++) {
+    for (int chunk = 0; chunk < nQ; chunk += RS_THREADS) {
+        const int i = chunk + tid;
         const size_t qo = (size_t)P.queryBase + i;
-        const int cnt = candCnt[qo];
-        if (cnt == 0) continue;
-        uint32_t bestKey = 0xFFFFFFFFu, bestIdx = 0;
-        for (int c0 = 0; c0 < cnt; c0 += WAVE) {
-            uint32_t key = 0xFFFFFFFFu, idx = 0;
-            if (c0 + lane < cnt) {
-                idx = candIdx[qo * DRFE_MATCH_MAX_CAND + c0 + lane];
-                key = candKey[qo * DRFE_MATCH_MAX_CAND + c0 + lane];
-                if ((claim[idx & 0xFFFFFF] & 3) == 3) key = 0xFFFFFFFFu;  /* holds a point with Observations()>0 */
-            }
-            const uint32_t mn = wave_min_u32(key);
-            if (mn < bestKey) {
-                const unsigned long long who = __ballot(key == mn);
-                const int src = __ffsll((long long)who) - 1;
-                bestIdx = (uint32_t)__shfl((int)idx, src);
-                bestKey = mn;
-            }
+        int cnt = 0, obs = 0;
+        uint32_t bKey = 0xFFFFFFFFu, bIdx = 0;
+        if (i < nQ) {
+            cnt = candCnt[qo];
+            if (cnt > 0) { const uint2 b = candBest[qo]; bKey = b.x; bIdx = b.y; obs = queries[qo].obs; }
         }
-        if (bestKey == 0xFFFFFFFFu) continue;
-        const int bestDist = (int)(bestKey >> 22);
-        if (bestDist <= 100) {                                   /* TH_HIGH */
-            const int i2 = (int)(bestIdx & 0xFFFFFF);
-            nmatches++;
-            if (lane == 0) {
-                M[i2] = i;
-                claim[i2] = 1 | (queries[qo].obs ? 2 : 0);
-                if (checkOri) {
-                    float rot = Kl[i].angle - Kc[i2].angle;
-                    if (rot < 0.0f) rot += 360.0f;
-                    int bin = (int)roundf(rot * factor);
-                    if (bin == 30) bin = 0;
-                    hs[2 * nEntries] = (uint16_t)bin;
-                    hs[2 * nEntries + 1] = (uint16_t)i2;
-                    hist[bin]++;
+        bool done = cnt == 0;
+        int start = 0;
+        while (true) {
+            uint32_t key = 0xFFFFFFFFu, idx = 0;
+            if (!done && tid >= start) {
+                if ((claim[bIdx & 0xFFFFFF] & 3) != 3) { key = bKey; idx = bIdx; }
+                else {
+                    for (int j = 0; j < cnt; j++) {
+                        const uint32_t k = candKey[qo * DRFE_MATCH_MAX_CAND + j];
+                        const uint32_t id = candIdx[qo * DRFE_MATCH_MAX_CAND + j];
+                        if (k < key && (claim[id & 0xFFFFFF] & 3) != 3) { key = k; idx = id; }
+                    }
                 }
             }
-            nEntries++;
+            const bool success = key != 0xFFFFFFFFu && (int)(key >> 22) <= 100;   /* TH_HIGH */
+            const int i2 = (int)(idx & 0xFFFFFF);
+            if (tid == 0) sFirst = RS_THREADS;
             __syncthreads();
+            if (success) atomicMin(&owner[i2], tid);
+            __syncthreads();
+            if (success && owner[i2] != tid) atomicMin(&sFirst, tid);
+            __syncthreads();
+            const int first = sFirst;
+            if (!done && tid >= start && tid < first) {
+                if (success) {
+                    M[i2] = i;
+                    claim[i2] = (unsigned char)(1 | (obs ? 2 : 0));
+                    atomicAdd(&sNm, 1);
+                    if (checkOri) {
+                        float rot = Kl[i].angle - Kc[i2].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == 30) bin = 0;
+                        const int e = atomicAdd(&sEnt, 1);
+                        hs[2 * e] = (uint16_t)bin;
+                        hs[2 * e + 1] = (uint16_t)i2;
+                        atomicAdd(&hist[bin], 1);
+                    }
+                }
+                done = true;
+            }
+            if (success) owner[i2] = 0x7FFFFFFF;
+            __syncthreads();
+            if (first >= RS_THREADS) break;
+            start = first;
         }
     }
     __syncthreads();
-    if (checkOri && lane == 0) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < 30; i++) {
-            const int s = hist[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
+    if (checkOri) {
+        if (tid == 0) {   /* ComputeThreeMaxima, src/ORBmatcher.cc:1666-1707 */
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < 30; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
         }
-        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
-        for (int e = 0; e < nEntries; e++) {
+        __syncthreads();
+        const int nEnt = sEnt;
+        for (int e = tid; e < nEnt; e += RS_THREADS) {
             const int bin = hs[2 * e];
-            if (bin != ind1 && bin != ind2 && bin != ind3) { M[hs[2 * e + 1]] = -1; nmatches--; }
+            if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) { M[hs[2 * e + 1]] = -1; atomicSub(&sNm, 1); }
         }
+        __syncthreads();
     }
-    if (lane == 0) matchCount[P.curSlot] = nmatches;
+    if (tid == 0) matchCount[P.curSlot] = sNm;
 }
 
 /* SearchByProjection(Frame&, vector<MapPoint*>&, th): best and second best with their octaves, ratio
@@ -531,12 +578,13 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
                            c->d_kps, c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
     hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 3) / 4, npairs), dim3(256), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kps, c->d_desc, c->d_uRight, c->d_kpCount, c->maxKp, c->d_gridOff,
-                       c->d_gridIdx, cam, invW, invH, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, c->d_status);
+                       c->d_gridIdx, cam, invW, invH, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest,
+                       c->d_status);
     const size_t lds = (size_t)c->maxKp;
     if (mode == 0)
-        hipLaunchKernelGGL(k_resolve_last, dim3(npairs), dim3(WAVE), lds, s, mb.d_pairs, mb.d_queries, c->d_kps,
-                           c->d_kpCount, c->maxKp, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, checkOri, c->d_match,
-                           d_initObs, c->d_matchCount, mb.d_hist);
+        hipLaunchKernelGGL(k_resolve_last, dim3(npairs), dim3(RS_THREADS), (size_t)c->maxKp * 5 + 16, s, mb.d_pairs,
+                           mb.d_queries, c->d_kps, c->d_kpCount, c->maxKp, mb.d_candIdx, mb.d_candKey, mb.d_candCnt,
+                           mb.d_candBest, checkOri, c->d_match, d_initObs, c->d_matchCount, mb.d_hist);
     else
         hipLaunchKernelGGL(k_resolve_map, dim3(npairs), dim3(WAVE), lds, s, mb.d_pairs, mb.d_queries, c->d_kpCount,
                            c->maxKp, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, nnratio, c->d_match, d_initObs,

@@ -62,6 +62,12 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise DrfeError(f"{LIB_PATH} not found: build it with `make -C dr_slam_amd/csrc` "
                         "(there is no CPU fallback for the feature path)")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64; if libdrfe pulled in the system
+    # copy first, a later `import torch` would bring a second runtime that cannot see the device.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.drfe_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
