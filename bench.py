@@ -39,14 +39,9 @@ def make_batch(seed: int, batch: int, n_distinct: int):
     """Ping-pong over n_distinct consecutive frames so every adjacent pair of the batch is a real
     frame-to-frame motion: 0,1,..,n-1,n-2,..,1,0,1,.."""
     from dr_slam_amd import synth
+    from dr_slam_amd.sharding import pingpong_order
     base = list(synth.sequence(seed, n_distinct, cam=synth.TUM3))
-    order, k, d = [], 0, 1
-    for _ in range(batch):
-        order.append(k)
-        if n_distinct > 1:
-            if k + d < 0 or k + d >= n_distinct:
-                d = -d
-            k += d
+    order = pingpong_order(batch, n_distinct)
     gray = np.stack([base[i][0] for i in order])
     depth = np.stack([base[i][1] for i in order])
     Twc = np.stack([base[i][2] for i in order]).astype(np.float64)
@@ -113,7 +108,8 @@ def main():
     from dr_slam_amd.pipeline import FrontEnd
 
     B = args.batch
-    gray, depth, Tcw, Twc, base = make_batch(10 + rank, B, args.distinct)
+    from dr_slam_amd import sharding
+    gray, depth, Tcw, Twc, base = make_batch(sharding.rank_seed(10, rank), B, args.distinct)
     fe = FrontEnd(synth.TUM3, max_batch=B, device=local_rank)
     gray_t = torch.from_numpy(gray).to(dev)
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
@@ -122,8 +118,7 @@ def main():
     if world > 1:
         # the one initial exchange of the sharded mode: rank 0's constant tables travel over RCCL/xGMI
         # (stands in for the ORB vocabulary broadcast of SURVEY.md §8e until the BoW row lands)
-        tab = torch.from_numpy(np.concatenate(fe.ctx.scale_tables())).to(dev)
-        dist.broadcast(tab, 0)
+        sharding.broadcast_tables(np.concatenate(fe.ctx.scale_tables()), dev, dist)
 
     def step():
         fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
@@ -142,10 +137,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el, total_frames = sharding.reduce_elapsed_and_frames(el, B * args.steps, dev, dist if world > 1 else None)
 
     # sanity: the batch really produced keypoints and matches
     counts = fe.ctx.orb_counts(B)
@@ -170,7 +162,7 @@ def main():
         roof_stage = dom if dom in ALGO_BYTES else max(cand, key=lambda k: cand[k])
         algo = ALGO_BYTES[roof_stage] * B
         achieved = algo / (stage_ms[roof_stage] * 1e-3) / 1e9
-        fps = world * B * args.steps / el
+        fps = total_frames / el
         out = {
             "metric": "RGB-D frames/sec (extract+match) at 640x480",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

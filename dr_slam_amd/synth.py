@@ -90,7 +90,7 @@ def pose_twc(k: int, step_m: float = 0.01, yaw_deg: float = 0.2) -> np.ndarray:
 def _texture(scene: Scene, face: np.ndarray, s: np.ndarray, t: np.ndarray) -> np.ndarray:
     low = scene.kind == "planar_lowtexture"
     out = np.full(s.shape, 100.0)
-    scales = ((0.5, 50), (0.12, 60), (0.035, 50)) if not low else ((0.9, 14), (0.3, 8))
+    scales = ((0.5, 50), (0.12, 60), (0.035, 50)) if not low else ((0.9, 34), (0.3, 14))
     for lvl, (cell, amp) in enumerate(scales):
         a = np.floor(s / cell).astype(np.int64)
         b = np.floor(t / cell).astype(np.int64)
