@@ -26,8 +26,7 @@
 #define DRFE_GRID_COLS 64     /* FRAME_GRID_COLS, reference include/Frame.h:40 */
 #define DRFE_GRID_ROWS 48     /* FRAME_GRID_ROWS, :39 */
 #define DRFE_GRID_CELLS (DRFE_GRID_COLS * DRFE_GRID_ROWS)
-#define DRFE_FAST_TILE_PITCH 72   /* LDS pitch of a FAST cell window (<= 68 px wide) */
-#define DRFE_FAST_MAX_WIN 68
+#define DRFE_FAST_MAX_WIN 60       /* largest FAST cell window (wCell+6): fits 64-byte LDS rows at any alignment */
 #define DRFE_QT_MAX_NODES 1024    /* quadtree list capacity per level (>= quota + 4) */
 #define DRFE_MATCH_MAX_CAND 256   /* candidates kept per query by the window gather */
 
@@ -141,6 +140,6 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
                                          int nframes, hipStream_t s);
 
 #define DRFE_BLUR_TW 64
-#define DRFE_BLUR_TH 16
+#define DRFE_BLUR_TH 32
 
 #endif

@@ -92,104 +92,149 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const DevGeom* __restrict__ 
 /* Threshold-free corner strength: cornerScore<16>(p, 0) = max(0, S_dark, S_bright) - 1 where
  * S = max over the 16 nine-pixel arcs of the min |difference|.  "Corner at t" is
  * exactly "strength >= t", so one strength map serves both FAST thresholds. Returned clamped to >= 0
- * (values below minThFAST never take part in a decision). */
-__device__ __forceinline__ int fast_strength(const uint8_t* c, const int P)
+ * (values below minThFAST never take part in a decision).
+ *
+ * Two vertically adjacent pixels A=(x,y), B=(x,y+1) ride in the two 16-bit halves of every register
+ * (v_pk_sub/min/max_i16).  The eight 8-pixel windows that start at odd ring positions are shared by
+ * two 9-arcs each (arc j-1..j+7 and arc j..j+8), and max(min(w,a), min(w,b)) == min(w, max(a,b)):
+ *   dark:   S = max_j min(w8lo[j], max(d[j-1], d[j+8]))      bright: -min_j max(w8hi[j], min(d[j-1], d[j+8]))
+ * = 16 sub + 2*(8+8+8) + 16 + 16 + 14 packed ops for two pixels. */
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk2(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(s16x2, lo | (hi << 16)); }
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
+/* returns strength(A) | strength(B) << 16 */
+__device__ __forceinline__ uint32_t fast_strength2(const uint8_t* cA, const uint8_t* cB, const int P)
 {
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * P];          d[1] = v - c[3 * P + 1];     d[2] = v - c[2 * P + 2];    d[3] = v - c[P + 3];
-    d[4] = v - c[3];              d[5] = v - c[-P + 3];        d[6] = v - c[-2 * P + 2];   d[7] = v - c[-3 * P + 1];
-    d[8] = v - c[-3 * P];         d[9] = v - c[-3 * P - 1];    d[10] = v - c[-2 * P - 2];  d[11] = v - c[-P - 3];
-    d[12] = v - c[-3];            d[13] = v - c[P - 3];        d[14] = v - c[2 * P - 2];   d[15] = v - c[3 * P - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    const s16x2 v = pk2(cA[0], cB[0]);
+    s16x2 d[16];
+#define RING(k, o) d[k] = v - pk2(cA[o], cB[o])
+    RING(0, 3 * P);       RING(1, 3 * P + 1);   RING(2, 2 * P + 2);    RING(3, P + 3);
+    RING(4, 3);           RING(5, -P + 3);      RING(6, -2 * P + 2);   RING(7, -3 * P + 1);
+    RING(8, -3 * P);      RING(9, -3 * P - 1);  RING(10, -2 * P - 2);  RING(11, -P - 3);
+    RING(12, -3);         RING(13, P - 3);      RING(14, 2 * P - 2);   RING(15, 3 * P - 1);
+#undef RING
+    s16x2 lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int a = -256, b = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        a = max(a, lo9);
-        b = min(b, hi9);
+    for (int m = 0; m < 8; m++) {           /* j = 2m+1: pairs (1,2) (3,4) ... (15,0) */
+        lo2[m] = pmin(d[2 * m + 1], d[(2 * m + 2) & 15]);
+        hi2[m] = pmax(d[2 * m + 1], d[(2 * m + 2) & 15]);
     }
-    return max(max(a, -b) - 1, 0);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { lo4[m] = pmin(lo2[m], lo2[(m + 1) & 7]); hi4[m] = pmax(hi2[m], hi2[(m + 1) & 7]); }
+    s16x2 a = {-256, -256}, b = {256, 256};
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const s16x2 lo8 = pmin(lo4[m], lo4[(m + 2) & 7]);      /* min d[j .. j+7], j = 2m+1 */
+        const s16x2 hi8 = pmax(hi4[m], hi4[(m + 2) & 7]);
+        const s16x2 e0 = d[2 * m], e1 = d[(2 * m + 9) & 15];   /* d[j-1], d[j+8] */
+        a = pmax(a, pmin(lo8, pmax(e0, e1)));
+        b = pmin(b, pmax(hi8, pmin(e0, e1)));
+    }
+    const s16x2 zero = {0, 0}, one = {1, 1};
+    const s16x2 r = pmax(pmax(a, zero - b) - one, zero);
+    return __builtin_bit_cast(uint32_t, r);
 }
 
-#define FAST_MAX_EVAL 62
+#define FAST_TILE_PITCH 64                       /* LDS bytes per window row (16 dwords) */
+#define FAST_MAX_EVAL (DRFE_FAST_MAX_WIN - 6)    /* 54 */
 #define FAST_SC_PITCH 64
-#define FAST_MAX_CAND (((FAST_MAX_EVAL + 1) / 2) * ((FAST_MAX_EVAL + 1) / 2))
 
-__global__ __launch_bounds__(256) void k_fast_cells(const DevGeom* __restrict__ G, const FastCell* __restrict__ cells,
-                                                    const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
-                                                    uint32_t* __restrict__ cand1, int* __restrict__ candCount,
-                                                    int* __restrict__ status)
+/* One wavefront per FAST cell (one cv::FAST call of the reference).  Window rows arrive as aligned
+ * dwords; each lane scores ~16 pixels; the strict-3x3-maximum flags stay in two 64-bit lane masks
+ * (>= iniThFAST / >= minThFAST); `__any` decides the per-cell fallback; a wave prefix sum gives every
+ * lane its slots behind ONE global atomic per cell. */
+__global__ __launch_bounds__(64) void k_fast_cells(const DevGeom* __restrict__ G, const FastCell* __restrict__ cells,
+                                                   const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
+                                                   uint32_t* __restrict__ cand1, int* __restrict__ candCount,
+                                                   int* __restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[DRFE_FAST_MAX_WIN * DRFE_FAST_TILE_PITCH];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[DRFE_FAST_MAX_WIN * (FAST_TILE_PITCH / 4)];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(FAST_MAX_EVAL + 2) * FAST_SC_PITCH];
-    __shared__ uint32_t st0[FAST_MAX_CAND], st1[FAST_MAX_CAND];
-    __shared__ int sCount, sBase;
 
     const FastCell fc = cells[blockIdx.x];
     const int slot = blockIdx.y;
     const DevLevel& L = G->lv[fc.level];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int ww = fc.ww, wh = fc.wh;
     const int ew = ww - 6, eh = wh - 6;           /* evaluated area */
-    const uint8_t* src = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff +
-                         (size_t)(fc.y0 + DRFE_EDGE) * L.pyrPitch + (fc.x0 + DRFE_EDGE);
-    for (int i = tid; i < ww * wh; i += 256) {
-        const int y = i / ww, x = i - y * ww;
-        tile[y * DRFE_FAST_TILE_PITCH + x] = src[(size_t)y * L.pyrPitch + x];
+    const int bx = fc.x0 + DRFE_EDGE, off = bx & 3;
+    const uint8_t* src = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(fc.y0 + DRFE_EDGE) * L.pyrPitch +
+                         (bx - off);
+    const int wpr = (ww + off + 3) >> 2;          /* dwords per window row (<= 16) */
+    {
+        const int c = lane & 15;
+        if (c < wpr)
+            for (int r = lane >> 4; r < wh; r += 4)
+                tile[r * (FAST_TILE_PITCH / 4) + c] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * L.pyrPitch + c * 4);
     }
-    for (int i = tid; i < (FAST_MAX_EVAL + 2) * FAST_SC_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
-    if (tid == 0) sCount = 0;
+    /* zero apron of the score tile (rows 0 / eh+1, columns 0 / ew+1): NMS neighbours outside the cell */
+    if (lane < ew + 2) { sc[lane] = 0; sc[(eh + 1) * FAST_SC_PITCH + lane] = 0; }
+    if (lane < eh + 2) { sc[lane * FAST_SC_PITCH] = 0; sc[lane * FAST_SC_PITCH + ew + 1] = 0; }
     __syncthreads();
-    for (int i = tid; i < ew * eh; i += 256) {
-        const int y = i / ew, x = i - y * ew;
-        const int s = fast_strength(&tile[(y + 3) * DRFE_FAST_TILE_PITCH + (x + 3)], DRFE_FAST_TILE_PITCH);
-        sc[(y + 1) * FAST_SC_PITCH + (x + 1)] = (uint8_t)s;
-    }
-    __syncthreads();
-    /* strict 3x3 maximum (neighbours outside the evaluated area read 0) */
-    int has20 = 0;
-    for (int i = tid; i < ew * eh; i += 256) {
-        const int y = i / ew, x = i - y * ew;
-        const uint8_t* p = &sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
-        const int s = p[0];
-        const bool mx = s > p[-1] && s > p[1] && s > p[-FAST_SC_PITCH - 1] && s > p[-FAST_SC_PITCH] &&
-                        s > p[-FAST_SC_PITCH + 1] && s > p[FAST_SC_PITCH - 1] && s > p[FAST_SC_PITCH] &&
-                        s > p[FAST_SC_PITCH + 1];
-        if (mx && s >= G->iniTh) has20 = 1;
-    }
-    has20 = __syncthreads_or(has20);
-    const int thr = has20 ? G->iniTh : G->minTh;
-    for (int i = tid; i < ew * eh; i += 256) {
-        const int y = i / ew, x = i - y * ew;
-        const uint8_t* p = &sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
-        const int s = p[0];
-        const bool mx = s > p[-1] && s > p[1] && s > p[-FAST_SC_PITCH - 1] && s > p[-FAST_SC_PITCH] &&
-                        s > p[-FAST_SC_PITCH + 1] && s > p[FAST_SC_PITCH - 1] && s > p[FAST_SC_PITCH] &&
-                        s > p[FAST_SC_PITCH + 1];
-        if (mx && s >= thr) {
-            const int pos = atomicAdd(&sCount, 1);
-            /* keypoint coordinates as the reference leaves them in vToDistributeKeys (:822-823):
-             * cv::FAST coordinate inside the window + (j*wCell, i*hCell) */
-            const uint32_t kx = (uint32_t)(x + 3 + fc.offX), ky = (uint32_t)(y + 3 + fc.offY);
-            st0[pos] = kx | (ky << 12) | ((uint32_t)s << 24);
-            st1[pos] = (fc.cellIdx << 12) | ((uint32_t)y << 6) | (uint32_t)x;   /* emission order */
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile) + off;   /* tb[y*64 + x] = window pixel (x, y) */
+    const int npx = ew * eh;
+    const uint32_t magic = 0xFFFFFFFFu / (uint32_t)ew + 1u;             /* i / ew == umulhi(i, magic) for i < 2^16 */
+    {   /* score pass: item = two vertically adjacent pixels (rows 2r, 2r+1) of one column */
+        const int nrp = (eh + 1) >> 1, nitem = nrp * ew;
+        for (int i = lane; i < nitem; i += 64) {
+            const int rp = (int)__umulhi((uint32_t)i, magic), x = i - rp * ew;
+            const int yA = 2 * rp, yB = min(2 * rp + 1, eh - 1);       /* odd eh: B repeats A, not stored */
+            const uint32_t s2 = fast_strength2(&tb[(yA + 3) * FAST_TILE_PITCH + (x + 3)],
+                                               &tb[(yB + 3) * FAST_TILE_PITCH + (x + 3)], FAST_TILE_PITCH);
+            sc[(yA + 1) * FAST_SC_PITCH + (x + 1)] = (uint8_t)(s2 & 0xFF);
+            if (2 * rp + 1 < eh) sc[(yA + 2) * FAST_SC_PITCH + (x + 1)] = (uint8_t)(s2 >> 16);
         }
     }
     __syncthreads();
-    const int n = sCount;
-    if (n == 0) return;
-    if (tid == 0) sBase = atomicAdd(&candCount[slot * G->nlevels + fc.level], n);
-    __syncthreads();
-    const int base = sBase;
-    if (base + n > L.candCap) { if (tid == 0) atomicOr(status, 1); return; }
-    const size_t off = (size_t)slot * G->candSlotElems + L.candOff + base;
-    for (int i = tid; i < n; i += 256) { cand0[off + i] = st0[i]; cand1[off + i] = st1[i]; }
+    /* strict 3x3 maximum (neighbours outside the evaluated area read 0) */
+    unsigned long long m20 = 0, m7 = 0;
+    {
+        int k = 0;
+        for (int i = lane; i < npx; i += 64, k++) {
+            const int y = (int)__umulhi((uint32_t)i, magic), x = i - y * ew;
+            const uint8_t* p = &sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
+            const int s = p[0];
+            if (s < G->minTh) continue;
+            const bool mx = s > p[-1] && s > p[1] && s > p[-FAST_SC_PITCH - 1] && s > p[-FAST_SC_PITCH] &&
+                            s > p[-FAST_SC_PITCH + 1] && s > p[FAST_SC_PITCH - 1] && s > p[FAST_SC_PITCH] &&
+                            s > p[FAST_SC_PITCH + 1];
+            if (mx) {
+                m7 |= 1ull << k;
+                if (s >= G->iniTh) m20 |= 1ull << k;
+            }
+        }
+    }
+    const unsigned long long emit = __any(m20 != 0) ? m20 : m7;   /* fallback decided per cell after NMS@ini */
+    const int cnt = __popcll(emit);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&candCount[slot * G->nlevels + fc.level], total);
+    base = __shfl(base, 0);
+    if (base + total > L.candCap) { if (lane == 0) atomicOr(status, 1); return; }
+    size_t pos = (size_t)slot * G->candSlotElems + L.candOff + base + (incl - cnt);
+    {
+        int k = 0;
+        for (int i = lane; i < npx; i += 64, k++) {
+            if (!((emit >> k) & 1ull)) continue;
+            const int y = (int)__umulhi((uint32_t)i, magic), x = i - y * ew;
+            const uint32_t s = sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
+            /* keypoint coordinates as the reference leaves them in vToDistributeKeys (:822-823):
+             * cv::FAST coordinate inside the window + (j*wCell, i*hCell) */
+            const uint32_t kx = (uint32_t)(x + 3 + fc.offX), ky = (uint32_t)(y + 3 + fc.offY);
+            cand0[pos] = kx | (ky << 12) | (s << 24);
+            cand1[pos] = (fc.cellIdx << 12) | ((uint32_t)y << 6) | (uint32_t)x;   /* emission order */
+            pos++;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -434,48 +479,60 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
 /* ------------------------------------------------------------------------------------------------ */
 /* Gaussian blur 7x7, sigma 2, 8.8 fixed point                                     */
 
-#define BLUR_SRC_PITCH 72
+#define BLUR_ROWS (DRFE_BLUR_TH + 6)
+/* Tile = 64 x DRFE_BLUR_TH output pixels, thread = 4 horizontally adjacent pixels.  The source is the
+ * BORDERED pyramid level: its 19-px frame already holds the REFLECT_101 image of the interior, which is
+ * exactly what GaussianBlur(BORDER_REFLECT_101) of the cloned interior ROI reads (3 px needed), so no
+ * reflection logic runs here.  Horizontal pass straight from three aligned dword loads into 8.8 sums
+ * in LDS; vertical pass from LDS. */
 __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, const BlurTile* __restrict__ tiles,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t src[(DRFE_BLUR_TH + 6) * BLUR_SRC_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t hb[(DRFE_BLUR_TH + 6) * DRFE_BLUR_TW];
+    __shared__ __attribute__((aligned(16))) uint16_t hb[BLUR_ROWS * DRFE_BLUR_TW];
     const BlurTile t = tiles[blockIdx.x];
     const int slot = blockIdx.y, tid = threadIdx.x;
     const DevLevel& L = G->lv[t.level];
-    const uint8_t* in = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)DRFE_EDGE * L.pyrPitch + DRFE_EDGE;
+    const uint8_t* img = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff;
     const int x0 = t.tx * DRFE_BLUR_TW, y0 = t.ty * DRFE_BLUR_TH;
-    /* the reference blurs a clone of the interior ROI: borders are reflections of the interior */
-    for (int i = tid; i < (DRFE_BLUR_TH + 6) * (DRFE_BLUR_TW + 6); i += 256) {
-        const int r = i / (DRFE_BLUR_TW + 6), c = i - r * (DRFE_BLUR_TW + 6);
-        const int sy = reflect101(min(y0 + r - 3, L.h + 2), L.h);
-        const int sx = reflect101(min(x0 + c - 3, L.w + 2), L.w);
-        src[r * BLUR_SRC_PITCH + c] = in[(size_t)sy * L.pyrPitch + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (DRFE_BLUR_TH + 6) * DRFE_BLUR_TW; i += 256) {
-        const int r = i / DRFE_BLUR_TW, c = i - r * DRFE_BLUR_TW;
-        const uint8_t* p = &src[r * BLUR_SRC_PITCH + c];
-        const uint32_t acc = 18u * (p[0] + p[6]) + 34u * (p[1] + p[5]) + 49u * (p[2] + p[4]) + 55u * p[3];
-        hb[i] = (uint16_t)acc; /* <= 255*257 */
-    }
-    __syncthreads();
-    {
-        const int r = tid >> 4, c4 = (tid & 15) * 4;
-        const int y = y0 + r, x = x0 + c4;
-        if (y < L.h && x < L.blurPitch) {
-            uint32_t out = 0;
+    const int cg = tid & 15, rr = tid >> 4;
+    /* interior x maps to bordered column x+19; the window of pixels x..x+3 starts at x+16 (4-aligned) */
+    const int maxWord = L.pyrPitch - 4;
+    const int c0 = min(x0 + cg * 4 + 16, maxWord), c1 = min(x0 + cg * 4 + 20, maxWord), c2 = min(x0 + cg * 4 + 24, maxWord);
+    const int lastRow = L.h + 2 * DRFE_EDGE - 1;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint16_t* p = &hb[r * DRFE_BLUR_TW + c4 + k];
-                const uint32_t acc = 18u * (p[0] + p[6 * DRFE_BLUR_TW]) + 34u * (p[DRFE_BLUR_TW] + p[5 * DRFE_BLUR_TW]) +
-                                     49u * (p[2 * DRFE_BLUR_TW] + p[4 * DRFE_BLUR_TW]) + 55u * p[3 * DRFE_BLUR_TW];
-                const uint32_t v = min(255u, (acc + 32768u) >> 16);
-                out |= v << (8 * k);
-            }
-            uint8_t* dst = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)y * L.blurPitch + x;
-            *reinterpret_cast<uint32_t*>(dst) = out;
+    for (int r = rr; r < BLUR_ROWS; r += 16) {
+        const uint8_t* row = img + (size_t)min(y0 + r - 3 + DRFE_EDGE, lastRow) * L.pyrPitch;
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + c0);
+        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + c1);
+        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + c2);
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; b[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        /* b[k] is interior column x-3+k (bordered column x+16+k); pixel x+j uses b[j..j+6] */
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            h[j] = 18u * (b[j] + b[j + 6]) + 34u * (b[j + 1] + b[j + 5]) + 49u * (b[j + 2] + b[j + 4]) + 55u * b[j + 3];
+        *reinterpret_cast<uint2*>(&hb[r * DRFE_BLUR_TW + cg * 4]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = rr; r < DRFE_BLUR_TH; r += 16) {
+        const int y = y0 + r;
+        if (y >= L.h) continue;
+        uint32_t acc[4] = {0, 0, 0, 0};
+        const uint32_t tap[7] = {18u, 34u, 49u, 55u, 49u, 34u, 18u};
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const uint2 p = *reinterpret_cast<const uint2*>(&hb[(r + k) * DRFE_BLUR_TW + cg * 4]);
+            acc[0] += tap[k] * (p.x & 0xFFFF); acc[1] += tap[k] * (p.x >> 16);
+            acc[2] += tap[k] * (p.y & 0xFFFF); acc[3] += tap[k] * (p.y >> 16);
         }
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) out |= min(255u, (acc[k] + 32768u) >> 16) << (8 * k);
+        uint8_t* dst = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)y * L.blurPitch + x0 + cg * 4;
+        *reinterpret_cast<uint32_t*>(dst) = out;
     }
 }
 
@@ -588,7 +645,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_PYRAMID, s);
 
     prof_begin(c, DRFE_STAGE_FAST, s);
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(256), 0, s, c->d_geom, c->d_cells, c->d_pyr,
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), 0, s, c->d_geom, c->d_cells, c->d_pyr,
                        c->d_cand0, c->d_cand1, c->d_candCount, c->d_status);
     prof_end(c, DRFE_STAGE_FAST, s);
 
