@@ -162,6 +162,19 @@ def main():
         roof_stage = dom if dom in ALGO_BYTES else max(cand, key=lambda k: cand[k])
         algo = ALGO_BYTES[roof_stage] * B
         achieved = algo / (stage_ms[roof_stage] * 1e-3) / 1e9
+        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs; cannot be collected from inside this process). Only valid for the same batch size.
+        traffic, traffic_src = None, None
+        kname = {"pyramid": "k_pyr_resize", "fast": "k_fast_cells", "blur": "k_blur", "desc": "k_orient_desc",
+                 "match": "k_window_candidates"}[roof_stage]
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
+                k = pmc["kernels"][kname]
+                traffic = (k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
+                traffic_src = "profiles/r01_pmc_traffic.json (raw FETCH_SIZE+WRITE_SIZE, see its _about)"
+        except Exception:
+            pass
         fps = total_frames / el
         out = {
             "metric": "RGB-D frames/sec (extract+match) at 640x480",
@@ -173,9 +186,10 @@ def main():
                                    "BASELINE config 2", "batch_per_gpu": B, "frames_per_step": world * B,
                        "sharding": "one sequence per GPU, no data-path collective"},
             "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel_stage": roof_stage, "dominant_stage": dom,
+            "roofline": {"bound": "hbm", "kernel": kname, "kernel_stage": roof_stage, "dominant_stage": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms": stage_ms[roof_stage],
                          "algorithmic_bytes_per_launch": algo},
         }
         if not args.no_cpu_baseline:

@@ -167,9 +167,22 @@ void fast_detect(const uint8_t* img, int w, int h, size_t stride, int threshold,
     if (w < 7 || h < 7) return;
     std::vector<int> sc((size_t)w * h, 0);
     std::vector<char> corner((size_t)w * h, 0);
+    ptrdiff_t o[16];
+    for (int k = 0; k < 16; k++) o[k] = (ptrdiff_t)kRing[k][1] * (ptrdiff_t)stride + kRing[k][0];
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {
             const uint8_t* p = img + (size_t)y * stride + x;
+            /* cv::FAST's early rejection: every 9-arc holds one pixel of each antipodal pair, so each
+             * pair must have a darker (bit 1) / brighter (bit 2) member — a necessary condition only */
+            const int v = p[0], lo = v - threshold, hi = v + threshold;
+#define CLS(k) ((p[o[k]] < lo ? 1 : 0) | (p[o[k]] > hi ? 2 : 0))
+            int d = CLS(0) | CLS(8);
+            if (!d) continue;
+            d &= CLS(2) | CLS(10); d &= CLS(4) | CLS(12); d &= CLS(6) | CLS(14);
+            if (!d) continue;
+            d &= CLS(1) | CLS(9); d &= CLS(3) | CLS(11); d &= CLS(5) | CLS(13); d &= CLS(7) | CLS(15);
+#undef CLS
+            if (!d) continue;
             if (is_fast_corner(p, stride, threshold)) {
                 corner[(size_t)y * w + x] = 1;
                 sc[(size_t)y * w + x] = corner_score16(p, stride, threshold);
@@ -194,20 +207,29 @@ static const int kGauss7[7] = {18, 34, 49, 55, 49, 34, 18};
 
 void gaussian_blur_7x7_s2_u8(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride)
 {
-    std::vector<uint32_t> hbuf((size_t)w * h);
-    for (int y = 0; y < h; y++)
+    /* same arithmetic as the direct double loop; rows are padded once so the inner loops vectorise */
+    std::vector<uint16_t> hbuf((size_t)w * h); /* 8.8 fixed point, <= 255*257 = 65535 */
+    std::vector<uint8_t> pad((size_t)w + 6);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        for (int x = -3; x < w + 3; x++) pad[x + 3] = s[reflect101(x, w)];
+        uint16_t* hrow = &hbuf[(size_t)y * w];
+        const uint8_t* p = pad.data();
+        for (int x = 0; x < w; x++)
+            hrow[x] = (uint16_t)(18u * (p[x] + p[x + 6]) + 34u * (p[x + 1] + p[x + 5]) + 49u * (p[x + 2] + p[x + 4]) +
+                                 55u * p[x + 3]);
+    }
+    for (int y = 0; y < h; y++) {
+        const uint16_t* r[7];
+        for (int k = -3; k <= 3; k++) r[k + 3] = &hbuf[(size_t)reflect101(y + k, h) * w];
+        uint8_t* d = dst + (size_t)y * dstride;
         for (int x = 0; x < w; x++) {
-            uint32_t acc = 0;
-            for (int k = -3; k <= 3; k++) acc += kGauss7[k + 3] * src[(size_t)y * sstride + reflect101(x + k, w)];
-            hbuf[(size_t)y * w + x] = acc; /* 8.8 fixed point, <= 255*257 = 65535 */
+            const uint32_t acc = 18u * ((uint32_t)r[0][x] + r[6][x]) + 34u * ((uint32_t)r[1][x] + r[5][x]) +
+                                 49u * ((uint32_t)r[2][x] + r[4][x]) + 55u * (uint32_t)r[3][x];
+            const uint32_t v = (acc + 32768u) >> 16;
+            d[x] = (uint8_t)std::min<uint32_t>(255u, v);
         }
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-            uint32_t acc = 0;
-            for (int k = -3; k <= 3; k++) acc += kGauss7[k + 3] * hbuf[(size_t)reflect101(y + k, h) * w + x];
-            uint32_t v = (acc + 32768u) >> 16;
-            dst[(size_t)y * dstride + x] = (uint8_t)std::min<uint32_t>(255u, v);
-        }
+    }
 }
 
 /* ---------------------------------------------------------------------------------------------- */
