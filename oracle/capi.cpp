@@ -1,6 +1,7 @@
 /* oracle/capi.cpp — TEST INFRASTRUCTURE: flat C entry points (ctypes) over the CPU oracle. */
 #include "oracle.h"
 #include "match_oracle.h"
+#include "ahc_oracle.h"
 #include "../include/drfe_math.h"
 
 #include <chrono>
@@ -215,6 +216,52 @@ int orc_match_orb_points(const uint8_t* cd, int cn, const uint8_t* ld, int ln, c
                          const uint8_t* lastOutlier, int32_t* curMP)
 {
     return match_orb_points(cd, cn, ld, ln, lastMP, lastOutlier, curMP);
+}
+
+/* AHC planes. Returns an opaque result; accessors copy out. */
+struct AhcHandle { AhcResult r; std::vector<AhcBlock> blocks; };
+void* orc_ahc_run(const uint16_t* depth, int w, int h, const float* K4, float depthfactor)
+{
+    AhcHandle* H = new AhcHandle();
+    try { H->r = ahc_run(depth, w, h, K4, depthfactor, &H->blocks); }
+    catch (const std::exception& e) { g_err = e.what(); delete H; return nullptr; }
+    return H;
+}
+void orc_ahc_free(void* h) { delete (AhcHandle*)h; }
+int orc_ahc_num_planes(void* h) { return (int)((AhcHandle*)h)->r.planes.size(); }
+int orc_ahc_num_blocks(void* h) { return (int)((AhcHandle*)h)->blocks.size(); }
+void orc_ahc_get_planes(void* h, double* out /* n x 8: normal3 center3 mse curvature */, int32_t* nrid /* n x 2 */)
+{
+    const auto& P = ((AhcHandle*)h)->r.planes;
+    for (size_t i = 0; i < P.size(); i++) {
+        for (int k = 0; k < 3; k++) { out[8 * i + k] = P[i].normal[k]; out[8 * i + 3 + k] = P[i].center[k]; }
+        out[8 * i + 6] = P[i].mse; out[8 * i + 7] = P[i].curvature;
+        nrid[2 * i] = P[i].N; nrid[2 * i + 1] = P[i].rid;
+    }
+}
+void orc_ahc_get_seg(void* h, uint8_t* out) { const auto& s = ((AhcHandle*)h)->r.seg; std::memcpy(out, s.data(), s.size()); }
+int orc_ahc_member_count(void* h, int i) { return (int)((AhcHandle*)h)->r.membership[i].size(); }
+void orc_ahc_get_members(void* h, int i, int32_t* out)
+{
+    const auto& m = ((AhcHandle*)h)->r.membership[i];
+    for (size_t k = 0; k < m.size(); k++) out[k] = m[k];
+}
+void orc_ahc_get_blocks(void* h, double* out /* n x 17: sums9 center3 normal3 mse curvature */, int32_t* vn /* n x 2 */)
+{
+    const auto& B = ((AhcHandle*)h)->blocks;
+    for (size_t i = 0; i < B.size(); i++) {
+        for (int k = 0; k < 9; k++) out[17 * i + k] = B[i].sums[k];
+        for (int k = 0; k < 3; k++) { out[17 * i + 9 + k] = B[i].center[k]; out[17 * i + 12 + k] = B[i].normal[k]; }
+        out[17 * i + 15] = B[i].mse; out[17 * i + 16] = B[i].curvature;
+        vn[2 * i] = B[i].valid; vn[2 * i + 1] = B[i].N;
+    }
+}
+void orc_eig33sym(const double* K9, double* s3, double* V9)
+{
+    double K[3][3], V[3][3];
+    for (int i = 0; i < 9; i++) K[i / 3][i % 3] = K9[i];
+    eig33sym(K, s3, V);
+    for (int i = 0; i < 9; i++) V9[i] = V[i / 3][i % 3];
 }
 
 int orc_sizeof_keypoint() { return (int)sizeof(KeyPoint); }

@@ -76,6 +76,17 @@ def lib() -> C.CDLL:
                                                    C.c_void_p, C.c_void_p]
         L.orc_bf_knn_hamming.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_match_orb_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ahc_run.restype = C.c_void_p
+        L.orc_ahc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float]
+        L.orc_ahc_free.argtypes = [C.c_void_p]
+        for n in ("orc_ahc_num_planes", "orc_ahc_num_blocks"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.orc_ahc_get_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ahc_get_seg.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_ahc_member_count.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ahc_get_members.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_ahc_get_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_eig33sym.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.orc_sizeof_keypoint() == KP_DTYPE.itemsize
         assert L.orc_sizeof_mappointrec() == MAPPOINT_DTYPE.itemsize
         assert L.orc_sizeof_trackedpointrec() == TRACKED_DTYPE.itemsize
@@ -292,3 +303,43 @@ def match_orb_points(cur_desc, last_desc, last_mp, last_outlier):
     n = lib().orc_match_orb_points(_p(cd), len(cd), _p(ld), len(ld), _p(_c(last_mp, np.int32)),
                                    _p(_c(last_outlier, np.uint8)), _p(out))
     return n, out
+
+
+def eig33sym(K):
+    """LA::eig33sym (Eigen SelfAdjointEigenSolver<Matrix3d>): ascending eigenvalues, eigenvectors in columns."""
+    K = _c(K, np.float64)
+    s = np.zeros(3)
+    V = np.zeros((3, 3))
+    lib().orc_eig33sym(_p(K), _p(s), _p(V))
+    return s, V
+
+
+def ahc_planes(depth16, K4, depthfactor):
+    """PlaneDetection::readDepthImage + runPlaneDetection (reference src/PlaneExtractor.cpp:28-63).
+    Returns dict(planes=[n,8] normal|center|mse|curvature, N, rid, seg=[h,w] uint8, members=[...],
+    blocks=[nb,17], block_valid, block_N)."""
+    d = _c(depth16, np.uint16)
+    h, w = d.shape
+    L = lib()
+    H = L.orc_ahc_run(_p(d), w, h, _p(_c(K4, np.float32)), np.float32(depthfactor))
+    if not H:
+        raise RuntimeError(L.orc_last_error().decode())
+    try:
+        n, nb = L.orc_ahc_num_planes(H), L.orc_ahc_num_blocks(H)
+        planes = np.zeros((n, 8))
+        nrid = np.zeros((n, 2), np.int32)
+        L.orc_ahc_get_planes(H, _p(planes), _p(nrid))
+        seg = np.zeros((h, w), np.uint8)
+        L.orc_ahc_get_seg(H, _p(seg))
+        members = []
+        for i in range(n):
+            m = np.zeros(L.orc_ahc_member_count(H, i), np.int32)
+            L.orc_ahc_get_members(H, i, _p(m))
+            members.append(m)
+        blocks = np.zeros((nb, 17))
+        vn = np.zeros((nb, 2), np.int32)
+        L.orc_ahc_get_blocks(H, _p(blocks), _p(vn))
+    finally:
+        L.orc_ahc_free(H)
+    return dict(planes=planes, N=nrid[:, 0], rid=nrid[:, 1], seg=seg, members=members, blocks=blocks,
+                block_valid=vn[:, 0], block_N=vn[:, 1])
