@@ -279,6 +279,49 @@ int drfe_search_by_projection_map(drfe_ctx* c, int slot, const drfe_tracked_poin
     return DRFE_OK;
 }
 
+int drfe_match_orb_points(drfe_ctx* c, int cur_slot, int last_slot, const int32_t* last_mp, const uint8_t* last_outlier,
+                          int n_last, int32_t* cur_mp, int n_cur, int* n_pairs)
+{
+    if (!c || !last_mp || !last_outlier || !cur_mp || !n_pairs) return DRFE_ERR_INVALID;
+    if (cur_slot < 0 || cur_slot >= c->lastBatch || last_slot < 0 || last_slot >= c->lastBatch) {
+        c->err = "match_orb_points: slots not ready";
+        return DRFE_ERR_STATE;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int counts[2];
+    HIPCHK(c, hipMemcpy(&counts[0], c->d_kpCount + cur_slot, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&counts[1], c->d_kpCount + last_slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_cur != counts[0] || n_last != counts[1]) { c->err = "match_orb_points: N mismatch"; return DRFE_ERR_INVALID; }
+    *n_pairs = 0;
+    if (n_cur == 0 || n_last == 0) return DRFE_OK;
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    /* matcher.match(descriptor1 = Current, descriptor2 = Last): 1-NN on the device-resident rows */
+    hipStream_t s = c->stream;
+    HIPCHK(c, drfe_launch_bf_knn(c->d_desc + (size_t)cur_slot * c->maxKp * 32, n_cur,
+                                 c->d_desc + (size_t)last_slot * c->maxKp * 32, n_last, 1, m->d_bfIdx, m->d_bfDist, s));
+    std::vector<int32_t> idx(n_cur), dist(n_cur);
+    HIPCHK(c, hipMemcpyAsync(idx.data(), m->d_bfIdx, sizeof(int) * n_cur, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(dist.data(), m->d_bfDist, sizeof(int) * n_cur, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    /* min distance, `dist < max(2*min_dist, 15)` filter, and the pointer copy with the reference's
+     * mvbOutlier[i] indexing by match counter (src/ORBmatcher.cc:1350-1389) */
+    double min_dist = 1000;
+    for (int i = 0; i < n_cur; i++)
+        if ((float)dist[i] < min_dist) min_dist = (float)dist[i];
+    int npair = 0;
+    for (int i = 0; i < n_cur; i++) {
+        if (!((float)dist[i] < std::max(2 * min_dist, 15.0))) continue;
+        const int mp = last_mp[idx[i]];
+        if (mp >= 0 && npair < n_last && !last_outlier[npair]) cur_mp[i] = mp;
+        npair++;
+    }
+    *n_pairs = npair;
+    return DRFE_OK;
+}
+
 int drfe_match_bf_knn(drfe_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, int32_t* dist)
 {
     if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || k < 1 || k > 2) return DRFE_ERR_INVALID;

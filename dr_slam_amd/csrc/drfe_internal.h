@@ -118,6 +118,7 @@ struct drfe_ctx {
     drfe_camera cam;          /* camera of the most recent glue call */
 
     struct MatchBuffers* mb;  /* lazily allocated matcher scratch (match_internal.h) */
+    struct PlanesScratch* ps; /* lazily allocated plane-path scratch (planes_internal.h) */
 
     /* profiling */
     bool profile;

@@ -1,0 +1,465 @@
+/* planes_ahc.cpp — AHC depth-plane extraction behind drfe_planes_ahc (include/drfe.h).
+ *
+ * Split of the reference's ahc::PlaneFitter::run (include/peac/AHCPlaneFitter.hpp:211-260):
+ *   device  k_ahc_blocks: cloud + 3072 init-block plane fits (the only image-sized pass)
+ *   host    graph edges (initGraph :896-975), agglomerative clustering (ahCluster :986-1192),
+ *           block erosion + seed collection (findBlockMembership :488-590), region growing
+ *           (floodFill :431-479), final re-merge and relabel (refineDetails :299-382)
+ * The host part is the round-1 placement ("clustering on host first"): it is a
+ * sequential min-heap / FIFO walk over <= 3072 nodes.  It is written index-based (node ids = creation
+ * order, sorted-vector adjacency) so it can move into a one-workgroup-per-frame kernel later.
+ *
+ * Canonical tie rules where the reference depends on heap addresses: neighbours
+ * iterate in creation order, equal-MSE queue entries pop in creation order, the final sort by N is
+ * stable.
+ */
+#include "drfe_internal.h"
+#include "planes_internal.h"
+#include "ahc_math.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <new>
+#include <queue>
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return DRFE_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+struct Node {
+    double S[9];
+    int N, rid;
+    AhcFit fit;
+    bool nouse;
+    std::vector<int> nbs;   /* sorted node ids */
+};
+
+struct Graph {
+    std::vector<Node> nodes;
+    std::vector<int> dsParent, dsSize;
+
+    int dsFind(int x) { while (dsParent[x] != x) { dsParent[x] = dsParent[dsParent[x]]; x = dsParent[x]; } return x; }
+    void dsUnion(int x, int y)
+    {
+        const int xr = dsFind(x), yr = dsFind(y);
+        if (xr == yr) return;
+        if (dsSize[xr] < dsSize[yr]) { dsParent[xr] = yr; dsSize[yr] += dsSize[xr]; }
+        else { dsParent[yr] = xr; dsSize[xr] += dsSize[yr]; }
+    }
+    static void insertSorted(std::vector<int>& v, int id)
+    {
+        auto it = std::lower_bound(v.begin(), v.end(), id);
+        if (it == v.end() || *it != id) v.insert(it, id);
+    }
+    static void eraseSorted(std::vector<int>& v, int id)
+    {
+        auto it = std::lower_bound(v.begin(), v.end(), id);
+        if (it != v.end() && *it == id) v.erase(it);
+    }
+    void connect(int a, int b) { insertSorted(nodes[a].nbs, b); insertSorted(nodes[b].nbs, a); }
+    void disconnectAll(int a)
+    {
+        for (int nb : nodes[a].nbs) eraseSorted(nodes[nb].nbs, a);
+        nodes[a].nbs.clear();
+    }
+    double similarity(int a, int b) const
+    {
+        const double* n = nodes[a].fit.normal;
+        const double* m = nodes[b].fit.normal;
+        return std::fabs(n[0] * m[0] + n[1] * m[1] + n[2] * m[2]);
+    }
+};
+
+struct QEntry { double mse; int id; };
+struct QCmp {
+    bool operator()(const QEntry& a, const QEntry& b) const
+    {
+        if (b.mse < a.mse) return true;
+        if (a.mse < b.mse) return false;
+        return b.id < a.id;
+    }
+};
+typedef std::priority_queue<QEntry, std::vector<QEntry>, QCmp> MinQ;
+
+const double kCos60 = std::cos(60.0 * M_PI / 180.0);   /* similarityTh_merge */
+const double kCos30 = std::cos(30.0 * M_PI / 180.0);   /* similarityTh_refine */
+
+static double tMseMerge(double z) { const double t = 1.6e-6 * z * z + 8.0; return t * t; }
+static double tAngInit(double z)
+{   /* ParamSet::T_ang(P_INIT, z) with the never-overridden millimetre defaults */
+    const double z_near = 500, z_far = 4000, a_near = 15.0 * M_PI / 180.0, a_far = 90.0 * M_PI / 180.0;
+    double cz = std::max(z, z_near);
+    cz = std::min(cz, z_far);
+    const double factor = (a_far - a_near) / (z_far - z_near);
+    return std::cos(factor * cz + a_near - factor * z_near);
+}
+
+/* ahCluster: pops min-MSE nodes, merges with the neighbour giving the least merged MSE */
+static void cluster(Graph& g, MinQ& q, std::vector<int>& extracted)
+{
+    const int maxStep = 100000;
+    int step = 0;
+    while (!q.empty() && step <= maxStep) {
+        const int p = q.top().id;
+        q.pop();
+        if (g.nodes[p].nouse) continue;
+        int candNb = -1;
+        Node cand;
+        bool have = false;
+        const std::vector<int> nbs = g.nodes[p].nbs;
+        for (int nb : nbs) {
+            if (g.similarity(p, nb) < kCos60) continue;
+            Node m;
+            const Node &a = g.nodes[p], &b = g.nodes[nb];
+            for (int k = 0; k < 9; k++) m.S[k] = a.S[k] + b.S[k];
+            m.N = a.N + b.N;
+            m.rid = a.N >= b.N ? a.rid : b.rid;
+            m.nouse = false;
+            ahc_plane_from_sums(m.S, m.N, &m.fit);
+            if (!have || cand.fit.mse > m.fit.mse || (cand.fit.mse == m.fit.mse && cand.N < m.fit.mse)) {
+                cand = m;
+                candNb = nb;
+                have = true;
+            }
+        }
+        if (have && cand.fit.mse < tMseMerge(cand.fit.center[2])) {
+            const int id = (int)g.nodes.size();
+            g.nodes.push_back(cand);
+            q.push({cand.fit.mse, id});
+            /* mergeNbsFrom */
+            g.dsUnion(g.nodes[p].rid, g.nodes[candNb].rid);
+            std::vector<int> u;
+            std::set_union(g.nodes[p].nbs.begin(), g.nodes[p].nbs.end(), g.nodes[candNb].nbs.begin(),
+                           g.nodes[candNb].nbs.end(), std::back_inserter(u));
+            Graph::eraseSorted(u, p);
+            Graph::eraseSorted(u, candNb);
+            g.disconnectAll(p);
+            g.disconnectAll(candNb);
+            g.nodes[id].nbs = u;
+            for (int nb : u) Graph::insertSorted(g.nodes[nb].nbs, id);
+            g.nodes[p].nouse = g.nodes[candNb].nouse = true;
+        } else {
+            if (g.nodes[p].N >= AHC_MIN_SUPPORT) extracted.push_back(p);
+            g.disconnectAll(p);
+        }
+        ++step;
+    }
+    while (!q.empty()) {
+        const int p = q.top().id;
+        q.pop();
+        if (g.nodes[p].N >= AHC_MIN_SUPPORT) extracted.push_back(p);
+        g.disconnectAll(p);
+    }
+    std::stable_sort(extracted.begin(), extracted.end(), [&](int a, int b) { return g.nodes[b].N < g.nodes[a].N; });
+}
+
+static int valid4(int i, int j, int H, int W, int nbs[4])
+{
+    const int id = i * W + j;
+    int cnt = 0;
+    if (j > 0) nbs[cnt++] = id - 1;
+    if (j < W - 1) nbs[cnt++] = id + 1;
+    if (i > 0) nbs[cnt++] = id - W;
+    if (i < H - 1) nbs[cnt++] = id + W;
+    return cnt;
+}
+
+struct DepthView {
+    const uint16_t* d; size_t stride; int w, h; double factor, fx, fy, cx, cy;
+    bool get(int row, int col, double pt[3]) const
+    {
+        double z = (double)d[(size_t)row * stride + col] * factor;
+        if (z > 5.0) z = 0.0;
+        if (z == 0.0) return false;
+        pt[0] = ((double)col - cx) * z / fx;
+        pt[1] = ((double)row - cy) * z / fy;
+        pt[2] = z;
+        return true;
+    }
+};
+
+} // namespace
+
+void drfe_planes_free(drfe_ctx* c)
+{
+    PlanesScratch* p = c->ps;
+    if (!p) return;
+    if (p->d_blocks) (void)hipFree(p->d_blocks);
+    if (p->d_depth) (void)hipFree(p->d_depth);
+    delete p;
+    c->ps = nullptr;
+}
+
+static int ensure_scratch(drfe_ctx* c, int w, int h)
+{
+    if (!c->ps) {
+        c->ps = new (std::nothrow) PlanesScratch();
+        if (!c->ps) return DRFE_ERR_INVALID;
+        std::memset(c->ps, 0, sizeof(PlanesScratch));
+    }
+    PlanesScratch* p = c->ps;
+    const size_t nb = (size_t)(w / AHC_WIN) * (h / AHC_WIN), px = (size_t)w * h;
+    if (p->blocksCap < nb) {
+        if (p->d_blocks) (void)hipFree(p->d_blocks);
+        p->d_blocks = nullptr; p->blocksCap = 0;
+        HIPCHK(c, hipMalloc((void**)&p->d_blocks, nb * sizeof(AhcBlockRec)));
+        p->blocksCap = nb;
+    }
+    if (p->depthCap < px) {
+        if (p->d_depth) (void)hipFree(p->d_depth);
+        p->d_depth = nullptr; p->depthCap = 0;
+        HIPCHK(c, hipMalloc((void**)&p->d_depth, px * sizeof(uint16_t)));
+        p->depthCap = px;
+    }
+    return DRFE_OK;
+}
+
+static int run_blocks(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float K4[4],
+                      float depth_factor, std::vector<AhcBlockRec>& blocks)
+{
+    if (!c || !depth || !K4 || w < AHC_WIN || h < AHC_WIN || stride < (size_t)w) {
+        if (c) c->err = "planes_ahc: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, w, h);
+    if (rc != DRFE_OK) return rc;
+    PlanesScratch* p = c->ps;
+    HIPCHK(c, hipMemcpy2DAsync(p->d_depth, (size_t)w * 2, depth, stride * 2, (size_t)w * 2, (size_t)h, hipMemcpyHostToDevice,
+                               c->stream));
+    HIPCHK(c, drfe_launch_ahc_blocks(p->d_depth, (size_t)w * h, (size_t)w, w, h, K4, depth_factor, 1, p->d_blocks, c->stream));
+    const size_t nb = (size_t)(w / AHC_WIN) * (h / AHC_WIN);
+    blocks.resize(nb);
+    HIPCHK(c, hipMemcpyAsync(blocks.data(), p->d_blocks, nb * sizeof(AhcBlockRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DRFE_OK;
+}
+
+extern "C" {
+
+int drfe_planes_ahc_blocks(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
+                           float depth_factor, double* blocks17, int32_t* valid_n, int cap)
+{
+    std::vector<AhcBlockRec> blocks;
+    int rc = run_blocks(c, depth, w, h, stride, K4, depth_factor, blocks);
+    if (rc != DRFE_OK) return rc;
+    if ((int)blocks.size() > cap) return DRFE_ERR_CAPACITY;
+    for (size_t i = 0; i < blocks.size(); i++) {
+        const AhcBlockRec& b = blocks[i];
+        for (int k = 0; k < 9; k++) blocks17[17 * i + k] = b.sums[k];
+        for (int k = 0; k < 3; k++) { blocks17[17 * i + 9 + k] = b.center[k]; blocks17[17 * i + 12 + k] = b.normal[k]; }
+        blocks17[17 * i + 15] = b.mse; blocks17[17 * i + 16] = b.curvature;
+        valid_n[2 * i] = b.valid; valid_n[2 * i + 1] = b.N;
+    }
+    return DRFE_OK;
+}
+
+int drfe_planes_ahc(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
+                    drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, int32_t* member_offsets,
+                    int32_t* member_idx)
+{
+    if (!n_planes) return DRFE_ERR_INVALID;
+    *n_planes = 0;
+    std::vector<AhcBlockRec> blocks;
+    int rc = run_blocks(c, depth, w, h, stride, K4, depth_factor, blocks);
+    if (rc != DRFE_OK) return rc;
+    const int Nw = w / AHC_WIN, Nh = h / AHC_WIN, NB = Nw * Nh;
+
+    /* --- initGraph: nodes + 4-neighbour edges with the reference's skip pattern ------------------- */
+    Graph g;
+    g.dsParent.resize(NB); g.dsSize.assign(NB, 1);
+    for (int i = 0; i < NB; i++) g.dsParent[i] = i;
+    g.nodes.reserve(2 * NB);
+    std::vector<int> G(NB, -1);
+    MinQ q;
+    for (int b = 0; b < NB; b++) {
+        if (!blocks[b].valid) continue;
+        Node n;
+        std::memcpy(n.S, blocks[b].sums, sizeof(n.S));
+        n.N = blocks[b].N; n.rid = b; n.nouse = false;
+        std::memcpy(n.fit.center, blocks[b].center, 24);
+        std::memcpy(n.fit.normal, blocks[b].normal, 24);
+        n.fit.mse = blocks[b].mse; n.fit.curvature = blocks[b].curvature;
+        G[b] = (int)g.nodes.size();
+        g.nodes.push_back(n);
+        q.push({n.fit.mse, G[b]});
+    }
+    for (int i = 0; i < Nh; ++i)
+        for (int j = 1; j < Nw; j += 2) {
+            const int cidx = i * Nw + j;
+            if (G[cidx - 1] < 0) { --j; continue; }
+            if (G[cidx] < 0) continue;
+            if (j < Nw - 1 && G[cidx + 1] < 0) { ++j; continue; }
+            const double th = tAngInit(g.nodes[G[cidx]].fit.center[2]);
+            if ((j < Nw - 1 && g.similarity(G[cidx - 1], G[cidx + 1]) >= th) ||
+                (j == Nw - 1 && g.similarity(G[cidx], G[cidx - 1]) >= th)) {
+                g.connect(G[cidx], G[cidx - 1]);
+                if (j < Nw - 1) g.connect(G[cidx], G[cidx + 1]);
+            } else --j;
+        }
+    for (int j = 0; j < Nw; ++j)
+        for (int i = 1; i < Nh; i += 2) {
+            const int cidx = i * Nw + j;
+            if (G[cidx - Nw] < 0) { --i; continue; }
+            if (G[cidx] < 0) continue;
+            if (i < Nh - 1 && G[cidx + Nw] < 0) { ++i; continue; }
+            const double th = tAngInit(g.nodes[G[cidx]].fit.center[2]);
+            if ((i < Nh - 1 && g.similarity(G[cidx - Nw], G[cidx + Nw]) >= th) ||
+                (i == Nh - 1 && g.similarity(G[cidx], G[cidx - Nw]) >= th)) {
+                g.connect(G[cidx], G[cidx - Nw]);
+                if (i < Nh - 1) g.connect(G[cidx], G[cidx + Nw]);
+            } else --i;
+        }
+
+    /* --- ahCluster ------------------------------------------------------------------------------- */
+    std::vector<int> extracted;
+    cluster(g, q, extracted);
+
+    /* --- refineDetails: findBlockMembership ------------------------------------------------------- */
+    std::map<int, int> rid2plid;
+    for (int plid = 0; plid < (int)extracted.size(); ++plid) rid2plid.insert({g.nodes[extracted[plid]].rid, plid});
+    std::vector<int> membership((size_t)w * h, -1), blkMap(NB, 0);
+    std::vector<char> isValid(extracted.size(), 0);
+    std::vector<std::pair<int, int>> rf;
+    const int NptsPerBlk = AHC_WIN * AHC_WIN;
+    for (int i = 0, blkid = 0; i < Nh; ++i)
+        for (int j = 0; j < Nw; ++j, ++blkid) {
+            const int setid = g.dsFind(blkid);
+            const int setSize = g.dsSize[setid] * NptsPerBlk;
+            if (setSize >= AHC_MIN_SUPPORT) {
+                int nbs[4] = {-1};
+                const int nNbs = valid4(i, j, Nh, Nw, nbs);
+                bool same = true;
+                for (int k = 0; k < nNbs; ++k)
+                    if (g.dsFind(nbs[k]) != setid) { same = false; break; }      /* ERODE_ALL_BORDER */
+                const int plid = rid2plid[setid];      /* std::map::operator[] as in the reference */
+                if (same) {
+                    blkMap[blkid] = plid;
+                    for (int y = i * AHC_WIN; y < (i + 1) * AHC_WIN; y++)
+                        for (int x = j * AHC_WIN; x < (j + 1) * AHC_WIN; x++) membership[(size_t)y * w + x] = plid;
+                    isValid[plid] = 1;
+                } else blkMap[blkid] = -1;
+            } else blkMap[blkid] = -1;
+            if (blkMap[blkid] < 0) {
+                if (i > 0 && blkMap[blkid - Nw] >= 0) {
+                    const int spix = (i * AHC_WIN - 1) * w + j * AHC_WIN;
+                    for (int k = 1; k < AHC_WIN; ++k) rf.push_back({spix + k, blkMap[blkid - Nw]});
+                }
+                if (j > 0 && blkMap[blkid - 1] >= 0) {
+                    const int spix = (i * AHC_WIN) * w + j * AHC_WIN - 1;
+                    for (int k = 0; k < AHC_WIN - 1; ++k) rf.push_back({spix + k * w, blkMap[blkid - 1]});
+                }
+            } else {
+                const int plid = blkMap[blkid];
+                if (i > 0 && blkMap[blkid - Nw] != plid) {
+                    const int spix = (i * AHC_WIN) * w + j * AHC_WIN;
+                    for (int k = 0; k < AHC_WIN - 1; ++k) rf.push_back({spix + k, plid});
+                }
+                if (j > 0 && blkMap[blkid - 1] != plid) {
+                    const int spix = (i * AHC_WIN) * w + j * AHC_WIN;
+                    for (int k = 1; k < AHC_WIN; ++k) rf.push_back({spix + k * w, plid});
+                }
+            }
+        }
+
+    /* --- floodFill -------------------------------------------------------------------------------- */
+    DepthView dv = {depth, stride, w, h, (double)depth_factor, (double)K4[0], (double)K4[1], (double)K4[2], (double)K4[3]};
+    {
+        std::vector<float> distMap((size_t)w * h, std::numeric_limits<float>::max());
+        for (size_t k = 0; k < rf.size(); ++k) {
+            const int sIdx = rf[k].first, plid = rf[k].second;
+            const int seedy = sIdx / w, seedx = sIdx - seedy * w;
+            const Node& pl = g.nodes[extracted[plid]];
+            int nbs[4] = {-1};
+            const int Nn = valid4(seedy, seedx, h, w, nbs);
+            for (int t = 0; t < Nn; ++t) {
+                const int cIdx = nbs[t];
+                int& trail = membership[cIdx];
+                if (trail <= -6) continue;
+                if (trail >= 0 && trail == plid) continue;
+                const int cy = cIdx / w, cx = cIdx - cy * w;
+                const int by = cy / AHC_WIN, bx = cx / AHC_WIN;
+                const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
+                if (blkid >= 0 && blkMap[blkid] >= 0) continue;
+                double pt[3] = {0, 0, 0};
+                float cdist = -1;
+                bool in = false;
+                if (dv.get(cy, cx, pt)) {
+                    const double sd = pl.fit.normal[0] * (pt[0] - pl.fit.center[0]) + pl.fit.normal[1] * (pt[1] - pl.fit.center[1]) +
+                                      pl.fit.normal[2] * (pt[2] - pl.fit.center[2]);
+                    cdist = (float)std::fabs(sd);
+                    const double cd = (double)cdist;
+                    in = cd * cd < 9 * pl.fit.mse + 1e-5;       /* std::pow(float -> double, 2) */
+                }
+                if (in) {
+                    if (trail >= 0) {
+                        const int other = extracted[trail];
+                        if (g.similarity(extracted[plid], other) >= kCos30) g.connect(other, extracted[plid]);
+                    }
+                    float& old = distMap[cIdx];
+                    if (cdist < old) {
+                        trail = plid;
+                        old = cdist;
+                        rf.push_back({cIdx, plid});
+                    } else if (trail < 0) trail -= 1;
+                } else if (trail < 0) trail -= 1;
+            }
+        }
+    }
+
+    /* --- re-merge the grown planes and relabel ----------------------------------------------------- */
+    std::vector<int> old;
+    old.swap(extracted);
+    MinQ q2;
+    for (size_t i = 0; i < old.size(); ++i)
+        if (isValid[i]) q2.push({g.nodes[old[i]].fit.mse, old[i]});
+    cluster(g, q2, extracted);
+    std::vector<int> plidmap(old.size(), -1);
+    for (size_t i = 0; i < old.size(); ++i) {
+        if (!isValid[i]) continue;
+        const int np_rid = g.dsFind(g.nodes[old[i]].rid);
+        for (size_t j = 0; j < extracted.size(); ++j)
+            if (np_rid == g.nodes[extracted[j]].rid) { plidmap[i] = (int)j; break; }
+    }
+    const int nFinal = (int)extracted.size();
+    *n_planes = nFinal;
+    if (nFinal > cap) { c->err = "planes_ahc: plane buffer too small"; return DRFE_ERR_CAPACITY; }
+    if (nFinal > 254) { c->err = "planes_ahc: more planes than a CV_8U label image holds"; return DRFE_ERR_CAPACITY; }
+    for (int i = 0; i < nFinal && planes; i++) {
+        const Node& n = g.nodes[extracted[i]];
+        std::memcpy(planes[i].normal, n.fit.normal, 24);
+        std::memcpy(planes[i].center, n.fit.center, 24);
+        planes[i].mse = n.fit.mse; planes[i].curvature = n.fit.curvature;
+        planes[i].n_points = n.N; planes[i].rid = n.rid;
+    }
+    std::vector<int> counts(nFinal + 1, 0);
+    for (size_t i = 0; i < membership.size(); ++i) {
+        int& plid = membership[i];
+        if (plid >= 0 && plidmap[plid] >= 0) { plid = plidmap[plid]; counts[plid + 1]++; }
+        else plid = -1;
+    }
+    if (seg)
+        for (size_t i = 0; i < membership.size(); ++i) seg[i] = membership[i] >= 0 ? (uint8_t)(membership[i] + 1) : 0;
+    if (member_offsets) {
+        for (int i = 0; i < nFinal; i++) counts[i + 1] += counts[i];
+        for (int i = 0; i <= nFinal; i++) member_offsets[i] = counts[i];
+        if (member_idx) {
+            std::vector<int> fill(counts.begin(), counts.end() - 1);
+            for (size_t i = 0; i < membership.size(); ++i)
+                if (membership[i] >= 0) member_idx[fill[membership[i]]++] = (int32_t)i;
+        }
+    }
+    return DRFE_OK;
+}
+
+} /* extern "C" */

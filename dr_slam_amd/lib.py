@@ -31,8 +31,12 @@ SYMBOLS = (
     "drfe_orb_pyramid_level", "drfe_orb_blurred_level", "drfe_orb_candidates", "drfe_frame_stereo_grid_batch",
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
-    "drfe_profile_stage_ms", "drfe_stream_sync",
+    "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
+    "drfe_match_orb_points",
 )
+
+PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("center", "<f8", (3,)), ("mse", "<f8"), ("curvature", "<f8"),
+                        ("n_points", "<i4"), ("rid", "<i4")])
 
 
 class DrfeError(RuntimeError):
@@ -94,6 +98,9 @@ def load() -> C.CDLL:
                                                  vp, vp, i32, C.POINTER(i32)]
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
+    L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_planes_ahc.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
+    L.drfe_planes_ahc_blocks.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, vp, i32]
     L.drfe_profile_enable.argtypes = [vp, i32]
     L.drfe_profile_stage_ms.argtypes = [vp, vp]
     L.drfe_stream_sync.argtypes = [vp]
@@ -258,6 +265,15 @@ class Context:
                                                        n, C.byref(nm)), "drfe_search_by_projection_map")
         return nm.value, out
 
+    def match_orb_points(self, cur_slot, last_slot, last_mp, last_outlier, n_cur, cur_mp=None):
+        last_mp = np.ascontiguousarray(last_mp, np.int32)
+        last_outlier = np.ascontiguousarray(last_outlier, np.uint8)
+        out = np.full(n_cur, -1, np.int32) if cur_mp is None else np.ascontiguousarray(cur_mp, np.int32).copy()
+        n = C.c_int()
+        self._chk(self.L.drfe_match_orb_points(self.h, cur_slot, last_slot, _p(last_mp), _p(last_outlier), len(last_mp),
+                                               _p(out), n_cur, C.byref(n)), "drfe_match_orb_points")
+        return n.value, out
+
     def bf_knn(self, Q, T, k):
         Q = np.ascontiguousarray(Q, np.uint8)
         T = np.ascontiguousarray(T, np.uint8)
@@ -265,6 +281,32 @@ class Context:
         dist = np.zeros((len(Q), k), np.int32)
         self._chk(self.L.drfe_match_bf_knn(self.h, _p(Q), len(Q), _p(T), len(T), k, _p(idx), _p(dist)), "drfe_match_bf_knn")
         return idx, dist
+
+    # --- planes ------------------------------------------------------------------------------------
+    def planes_ahc(self, depth16: np.ndarray, K4, depth_factor, cap=64):
+        """PlaneDetection::readDepthImage + runPlaneDetection -> dict(planes, seg, members)."""
+        d = np.ascontiguousarray(depth16, np.uint16)
+        h, w = d.shape
+        K4 = np.ascontiguousarray(K4, np.float32)
+        planes = np.zeros(cap, PLANE_DTYPE)
+        n = C.c_int()
+        seg = np.zeros((h, w), np.uint8)
+        off = np.zeros(cap + 1, np.int32)
+        idx = np.zeros(h * w, np.int32)
+        self._chk(self.L.drfe_planes_ahc(self.h, _p(d), w, h, w, _p(K4), np.float32(depth_factor), _p(planes), cap,
+                                         C.byref(n), _p(seg), _p(off), _p(idx)), "drfe_planes_ahc")
+        n = n.value
+        return dict(planes=planes[:n].copy(), seg=seg, members=[idx[off[i]:off[i + 1]].copy() for i in range(n)])
+
+    def planes_ahc_blocks(self, depth16: np.ndarray, K4, depth_factor):
+        d = np.ascontiguousarray(depth16, np.uint16)
+        h, w = d.shape
+        nb = (w // 10) * (h // 10)
+        blocks = np.zeros((nb, 17))
+        vn = np.zeros((nb, 2), np.int32)
+        self._chk(self.L.drfe_planes_ahc_blocks(self.h, _p(d), w, h, w, _p(np.ascontiguousarray(K4, np.float32)),
+                                                np.float32(depth_factor), _p(blocks), _p(vn), nb), "drfe_planes_ahc_blocks")
+        return blocks, vn[:, 0], vn[:, 1]
 
     # --- measurement -------------------------------------------------------------------------------
     def profile_enable(self, on=True):

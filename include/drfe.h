@@ -164,10 +164,46 @@ int drfe_search_by_projection_map(drfe_ctx* ctx, int slot, const drfe_tracked_po
                                   float nnratio, const uint8_t* claim_obs, int32_t* frame_mp, int n,
                                   int* nmatches);
 
+/* ORBmatcher::MatchORBPoints(CurrentFrame, LastFrame), src/ORBmatcher.cc:1332-1394 — the fallback
+ * Tracking uses when SearchByProjection finds < 40 matches (src/Tracking.cc:2195-2200): brute-force
+ * 1-NN of the current slot's descriptors against the last slot's (both device-resident), keep
+ * dist < max(2*min_dist, 15), copy map points with the reference's mvbOutlier[match counter] quirk.
+ * last_mp: per last-frame keypoint the map point id or -1; cur_mp (in/out): ids written for matched
+ * current keypoints; *n_pairs = the function's return value (NPair). */
+int drfe_match_orb_points(drfe_ctx* ctx, int cur_slot, int last_slot, const int32_t* last_mp,
+                          const uint8_t* last_outlier, int n_last, int32_t* cur_mp, int n_cur, int* n_pairs);
+
 /* cv::BFMatcher(NORM_HAMMING).match / knnMatch(k<=2) on 256-bit descriptors (src/ORBmatcher.cc:1346,
  * src/LSDmatcher.cpp:222,254): ascending distance, ties -> lower train index. idx/dist: nq x k. */
 int drfe_match_bf_knn(drfe_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx,
                       int32_t* dist);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* PlaneDetection (replaces src/PlaneExtractor.cpp:7-63 + include/peac/ : the live AHC extractor)   */
+
+/* One extracted plane: ahc::PlaneSeg fields Frame::ComputePlanes reads (src/Frame.cc:952-979:
+ * plane_filter.extractedPlanes[i]->normal / center), plus mse, curvature, N, rid. */
+typedef struct drfe_plane {
+    double normal[3];   /* unit normal pointing towards the camera (dot(normal, center) <= 0) */
+    double center[3];   /* centre of mass, metres */
+    double mse, curvature;
+    int32_t n_points;   /* PlaneSeg::N (points of the merged init blocks) */
+    int32_t rid;        /* root block id */
+} drfe_plane;
+
+/* PlaneDetection::readDepthImage(depth16, K, depthfactor) + runPlaneDetection().
+ * depth: host CV_16U image, `stride` elements per row; K4 = {fx, fy, cx, cy} (the float K entries the
+ * reference promotes to double); depth_factor = the float passed as `depthfactor` (1/DepthMapFactor).
+ * Outputs: planes[0..n) sorted by N descending (extractedPlanes); seg (w*h, may be NULL) = seg_output
+ * (plane index + 1, 0 = none); member_offsets[n+1] / member_idx (may be NULL) = plane_vertices_ as CSR,
+ * pixel indices ascending. */
+int drfe_planes_ahc(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
+                    float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
+                    int32_t* member_offsets, int32_t* member_idx);
+/* Parity tap of the device stage: per 10x10 init block 17 doubles (9 sums, center, normal, mse,
+ * curvature) and (enters-graph flag, N). cap = number of blocks the buffers hold. */
+int drfe_planes_ahc_blocks(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
+                           float depth_factor, double* blocks17, int32_t* valid_n, int cap);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* measurement                                                                                       */

@@ -125,6 +125,20 @@ def test_search_by_projection_map(setup, oracle_mod):
     assert n_o > 100
 
 
+def test_match_orb_points(setup, oracle_mod):
+    """ORBmatcher::MatchORBPoints(Cur, Last): BFMatcher 1-NN on the device-resident descriptors + the
+    reference's filter and mvbOutlier[match counter] quirk."""
+    fe, oframes, *_ = setup
+    cur, last = oframes[1], oframes[0]
+    rng = np.random.default_rng(11)
+    last_mp = np.where(rng.random(last.N) > 0.3, np.arange(last.N) + 1000, -1).astype(np.int32)
+    outl = (rng.random(last.N) > 0.8).astype(np.uint8)
+    n_o, m_o = oracle_mod.match_orb_points(cur.desc, last.desc, last_mp, outl)
+    n_g, m_g = fe.ctx.match_orb_points(1, 0, last_mp, outl, cur.N)
+    assert n_g == n_o and n_o > 50
+    assert np.array_equal(m_g, m_o)
+
+
 def test_bf_knn(setup, oracle_mod):
     """cv::BFMatcher(NORM_HAMMING) 1-NN (MatchORBPoints) and 2-NN (LSDmatcher) incl. exact ties."""
     fe, oframes, *_ = setup

@@ -1,0 +1,65 @@
+"""-m gpu parity tests of the AHC depth-plane path (PlaneDetection): device block fits + product
+clustering (through the C-ABI) vs the CPU oracle.  Bar: identical float64 bit patterns for the block
+sums / plane fits, identical plane lists, label image and per-plane pixel lists."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dr_slam_amd import lib
+    c = lib.Context(max_batch=1)
+    yield c
+    c.close()
+
+
+CASES = [(2, "room_boxes", "TUM3"), (3, "living_room", "ICL"), (5, "corridor", "TUM3"), (1, "planar_lowtexture", "TUM3")]
+
+
+def _case(seed, kind, camname):
+    from dr_slam_amd import synth
+    cam = getattr(synth, camname)
+    _, d, _ = next(synth.sequence(seed, 1, cam=cam, kind=kind))
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    return d, K4, np.float32(1.0) / np.float32(cam.depth_factor)
+
+
+@pytest.mark.parametrize("seed,kind,camname", CASES)
+def test_block_fits_bit_exact(ctx, oracle_mod, seed, kind, camname):
+    """depth -> cloud -> 10x10 block statistics -> Eigen 3x3 solve, all on the device."""
+    d, K4, f = _case(seed, kind, camname)
+    blocks, valid, n = ctx.planes_ahc_blocks(d, K4, f)
+    o = oracle_mod.ahc_planes(d, K4, f)
+    assert np.array_equal(valid, o["block_valid"]) and np.array_equal(n, o["block_N"])
+    assert valid.sum() > 500
+    a, b = blocks.view(np.uint64), o["blocks"].view(np.uint64)
+    nan = np.isnan(o["blocks"])
+    assert np.array_equal(np.isnan(blocks), nan)
+    assert np.array_equal(a[~nan], b[~nan])
+
+
+@pytest.mark.parametrize("seed,kind,camname", CASES)
+def test_planes_bit_exact(ctx, oracle_mod, seed, kind, camname):
+    d, K4, f = _case(seed, kind, camname)
+    g = ctx.planes_ahc(d, K4, f)
+    o = oracle_mod.ahc_planes(d, K4, f)
+    assert len(g["planes"]) == len(o["planes"]) >= 3
+    for k, col in (("normal", slice(0, 3)), ("center", slice(3, 6))):
+        assert np.array_equal(g["planes"][k].view(np.uint64), o["planes"][:, col].view(np.uint64)), k
+    assert np.array_equal(g["planes"]["mse"].view(np.uint64), o["planes"][:, 6].view(np.uint64))
+    assert np.array_equal(g["planes"]["curvature"].view(np.uint64), o["planes"][:, 7].view(np.uint64))
+    assert np.array_equal(g["planes"]["n_points"], o["N"]) and np.array_equal(g["planes"]["rid"], o["rid"])
+    assert np.array_equal(g["seg"], o["seg"])
+    for a, b in zip(g["members"], o["members"]):
+        assert np.array_equal(a, b)
+
+
+def test_no_depth_gives_no_planes(ctx, oracle_mod):
+    d = np.zeros((480, 640), np.uint16)
+    K4 = np.array([500, 500, 320, 240], np.float32)
+    g = ctx.planes_ahc(d, K4, 0.0002)
+    assert len(g["planes"]) == 0 and not g["seg"].any()
+    far = np.full((480, 640), 40000, np.uint16)        # 8 m: beyond the 5 m clamp (src/PlaneExtractor.cpp:44)
+    assert len(ctx.planes_ahc(far, K4, 0.0002)["planes"]) == 0
