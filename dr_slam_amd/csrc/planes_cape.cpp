@@ -1,0 +1,289 @@
+/* planes_cape.cpp — CAPE depth-plane extraction behind drfe_planes_cape (include/drfe.h).
+ *
+ * Split of PlaneDetection_CAPE::runPlaneDetection + CAPE::process (reference
+ * src/PlaneExtractor.cpp:111-191, src/CAPE/CAPE.cpp:47-457):
+ *   device  k_cape_cells: cloud, cell-major gather, per-cell validity / jump tests, the nine float32
+ *           sums, PlaneSeg::fitPlane (f64 Eigen 3x3 solve) and the cell's merge tolerance
+ *   host    20x20 normal histogram + seeding, recursive 4-neighbour cell growing, plane merging,
+ *           3x3 erode/dilate on the <= 64x48 cell mask, per-pixel refinement in boundary cells and the
+ *           label image — all on a grid of at most 3072 cells
+ * Reference bugs are kept and the two canonicalisations of oracle/cape_oracle.cpp apply here as well
+ * (sequential float32 cell sums; fit fields of non-planar cells read as 0).
+ */
+#include "drfe_internal.h"
+#include "planes_internal.h"
+#include "ahc_math.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return DRFE_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+struct PSeg {
+    double acc[9];        /* x y z xx yy zz xy xz yz */
+    int nr_pts;
+    double mean[3], normal[3], d;
+    float MSE, score;
+    void expand(const double* a, int n) { for (int k = 0; k < 9; k++) acc[k] += a[k]; nr_pts += n; }
+    void fit()
+    {
+        const double n = nr_pts;
+        mean[0] = acc[0] / n; mean[1] = acc[1] / n; mean[2] = acc[2] / n;
+        double ev[3], Q[9];
+        ahc_eig3(acc[3] - acc[0] * acc[0] / n, acc[6] - acc[0] * acc[1] / n, acc[7] - acc[0] * acc[2] / n,
+                 acc[4] - acc[1] * acc[1] / n, acc[8] - acc[1] * acc[2] / n, acc[5] - acc[2] * acc[2] / n, ev, Q);
+        d = -(Q[0] * mean[0] + Q[1] * mean[1] + Q[2] * mean[2]);
+        if (d > 0) { normal[0] = Q[0]; normal[1] = Q[1]; normal[2] = Q[2]; }
+        else { normal[0] = -Q[0]; normal[1] = -Q[1]; normal[2] = -Q[2]; d = -d; }
+        MSE = (float)(ev[0] / n);
+        score = (float)(ev[1] / ev[0]);
+    }
+};
+
+struct Grow {
+    int W, H;
+    const std::vector<char>* in;
+    std::vector<char>* out;
+    const std::vector<CapeCellRec>* cells;
+    float minCos;
+    void run(int x, int y, const double* n1, double d)
+    {
+        const int idx = x + W * y;
+        if (!(*in)[idx] || (*out)[idx]) return;
+        const CapeCellRec& c = (*cells)[idx];
+        const double v = n1[0] * c.mean[0] + n1[1] * c.mean[1] + n1[2] * c.mean[2] + d;
+        if (n1[0] * c.normal[0] + n1[1] * c.normal[1] + n1[2] * c.normal[2] < minCos || v * v > c.tol) return;
+        (*out)[idx] = 1;
+        if (x > 0) run(x - 1, y, c.normal, c.d);
+        if (x < W - 1) run(x + 1, y, c.normal, c.d);
+        if (y > 0) run(x, y - 1, c.normal, c.d);
+        if (y < H - 1) run(x, y + 1, c.normal, c.d);
+    }
+};
+
+} // namespace
+
+hipError_t drfe_launch_cape_cells(const float* d_depth, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                  float sinCos, float maxMergeDist, CapeCellRec* d_out, hipStream_t s);
+
+extern "C" {
+
+int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
+                     float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
+                     uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn)
+{
+    if (!c || !depth_m || !K4 || !n_planes || !seg) return DRFE_ERR_INVALID;
+    *n_planes = 0;
+    if (patch < 4 || patch > 64 || w % patch || h % patch || stride < (size_t)w) {
+        c->err = "planes_cape: width/height must be multiples of PATCH_SIZE (4..64)";
+        return DRFE_ERR_INVALID;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nh = w / patch, nv = h / patch, ncell = nh * nv, ppc = patch * patch, npx = w * h;
+    /* device stage */
+    float* d_depth = nullptr;
+    CapeCellRec* d_cells = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_depth, (size_t)npx * sizeof(float)));
+    if (hipMalloc((void**)&d_cells, (size_t)ncell * sizeof(CapeCellRec)) != hipSuccess) {
+        (void)hipFree(d_depth);
+        c->err = "planes_cape: hipMalloc failed";
+        return DRFE_ERR_HIP;
+    }
+    const float sinCos = (float)std::sqrt(1 - (double)cos_angle_max * (double)cos_angle_max);
+    std::vector<CapeCellRec> cells(ncell);
+    hipError_t e = hipMemcpy2DAsync(d_depth, (size_t)w * 4, depth_m, stride * 4, (size_t)w * 4, (size_t)h,
+                                    hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = drfe_launch_cape_cells(d_depth, (size_t)w, w, h, K4, patch, sinCos, max_merge_dist, d_cells, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cells.data(), d_cells, (size_t)ncell * sizeof(CapeCellRec), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_depth);
+    (void)hipFree(d_cells);
+    if (e != hipSuccess) { c->err = std::string("planes_cape: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    for (int i = 0; i < ncell && cells16; i++) {
+        const CapeCellRec& r = cells[i];
+        for (int k = 0; k < 9; k++) cells16[16 * i + k] = r.acc[k];
+        for (int k = 0; k < 3; k++) { cells16[16 * i + 9 + k] = r.mean[k]; cells16[16 * i + 12 + k] = r.normal[k]; }
+        cells16[16 * i + 15] = r.d;
+        if (cells_mst) { cells_mst[3 * i] = r.MSE; cells_mst[3 * i + 1] = r.score; cells_mst[3 * i + 2] = r.tol; }
+        if (cells_pn) { cells_pn[2 * i] = r.planar; cells_pn[2 * i + 1] = r.nr_pts; }
+    }
+
+    /* histogram of cell normals in spherical coordinates, src/CAPE/CAPE.cpp:81-104, Histogram.cpp */
+    const int NB = 20;
+    std::vector<int> Hh(NB * NB, 0), Bq(ncell, -1);
+    std::vector<char> unassigned(ncell, 0), act(ncell, 0);
+    int remaining = 0;
+    for (int i = 0; i < ncell; i++) {
+        if (!cells[i].planar) continue;
+        const double nx = cells[i].normal[0], ny = cells[i].normal[1], nz = cells[i].normal[2];
+        const double npn = std::sqrt(nx * nx + ny * ny);
+        const double p0 = std::acos(-nz), p1 = std::atan2(nx / npn, ny / npn);
+        const int Xq = (int)((NB - 1) * (p0 - 0.0) / (3.14 - 0.0));
+        int Yq = 0;
+        if (Xq > 0) Yq = (int)((NB - 1) * (p1 - (-3.14)) / (3.14 - (-3.14)));
+        Bq[i] = Yq * NB + Xq;
+        Hh[Bq[i]]++;
+        unassigned[i] = 1;
+        remaining++;
+    }
+    std::vector<PSeg> segs;
+    std::vector<int> gridMap(ncell, 0);
+    while (remaining > 0) {
+        int best = -1, mx = 0;
+        for (int b = 0; b < NB * NB; b++)
+            if (Hh[b] > mx) { best = b; mx = Hh[b]; }
+        std::vector<int> cand;
+        if (mx > 0)
+            for (int i = 0; i < ncell; i++)
+                if (Bq[i] == best) cand.push_back(i);
+        if (cand.size() < 5) break;
+        int seed = cand[0];
+        float minMSE = (float)INT_MAX;
+        for (size_t i = 0; i < cand.size(); i++)
+            if (cells[cand[i]].MSE < minMSE) { seed = cand[i]; minMSE = cells[i].MSE; }   /* sic: Grid[i], CAPE.cpp:130 */
+        PSeg ps;
+        std::memcpy(ps.acc, cells[seed].acc, sizeof(ps.acc));
+        ps.nr_pts = cells[seed].nr_pts;
+        std::memcpy(ps.mean, cells[seed].mean, 24);
+        std::memcpy(ps.normal, cells[seed].normal, 24);
+        ps.d = cells[seed].d; ps.MSE = cells[seed].MSE; ps.score = cells[seed].score;
+        std::fill(act.begin(), act.end(), 0);
+        Grow g{nh, nv, &unassigned, &act, &cells, cos_angle_max};
+        const double sn[3] = {ps.normal[0], ps.normal[1], ps.normal[2]};
+        g.run(seed % nh, seed / nh, sn, ps.d);
+        int nact = 0;
+        for (int i = 0; i < ncell; i++)
+            if (act[i]) {
+                ps.expand(cells[i].acc, cells[i].nr_pts);
+                nact++;
+                Hh[Bq[i]]--; Bq[i] = -1;
+                unassigned[i] = 0;
+                remaining--;
+            }
+        if (nact < 4) continue;
+        ps.fit();
+        if (ps.score > 100) {
+            segs.push_back(ps);
+            const int nr = (int)segs.size();
+            for (int i = 0; i < ncell; i++)
+                if (act[i]) gridMap[i] = nr;
+        }
+    }
+
+    /* plane merging, CAPE.cpp:208-245 */
+    const int np = (int)segs.size();
+    std::vector<char> assoc((size_t)np * np, 0);
+    for (int r = 0; r < nv - 1; r++)
+        for (int cc = 0; cc < nh - 1; cc++) {
+            const int px = gridMap[r * nh + cc];
+            if (px <= 0) continue;
+            const int right = gridMap[r * nh + cc + 1], below = gridMap[(r + 1) * nh + cc];
+            if (right > 0 && px != right) assoc[(size_t)(px - 1) * np + right - 1] = 1;
+            if (below > 0 && px != below) assoc[(size_t)(px - 1) * np + below - 1] = 1;
+        }
+    for (int r = 0; r < np; r++)
+        for (int k = r + 1; k < np; k++) assoc[(size_t)r * np + k] = assoc[(size_t)r * np + k] || assoc[(size_t)k * np + r];
+    std::vector<int> label(np);
+    for (int i = 0; i < np; i++) label[i] = i;
+    for (int r = 0; r < np; r++) {
+        const int pid = label[r];
+        bool expanded = false;
+        for (int k = r + 1; k < np; k++) {
+            if (!assoc[(size_t)r * np + k]) continue;
+            const PSeg &P = segs[pid], &Q = segs[k];
+            const double cosA = P.normal[0] * Q.normal[0] + P.normal[1] * Q.normal[1] + P.normal[2] * Q.normal[2];
+            const double dv = segs[r].normal[0] * Q.mean[0] + P.normal[1] * Q.mean[1] + P.normal[2] * Q.mean[2] + P.d;   /* sic */
+            if (cosA > cos_angle_max && dv * dv < max_merge_dist) {
+                segs[pid].expand(Q.acc, Q.nr_pts);
+                label[k] = pid;
+                expanded = true;
+            } else assoc[(size_t)r * np + k] = 0;
+        }
+        if (expanded) segs[pid].fit();
+    }
+
+    /* boundary refinement + label image, CAPE.cpp:247-319, 395-431 */
+    std::vector<uint8_t> mask(ncell), er(ncell), di(ncell), gridEroded(ncell, 0), segStacked(npx, 0);
+    float hugeF;
+    { const uint32_t bits = 0x64646464u; std::memcpy(&hugeF, &bits, 4); }
+    std::vector<float> distStacked(npx, hugeF);
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    int nFinal = 0;
+    for (int i = 0; i < np; i++) {
+        if (i != label[i]) continue;
+        std::fill(mask.begin(), mask.end(), 0);
+        for (int j = i; j < np; j++)
+            if (label[j] == label[i])
+                for (int k = 0; k < ncell; k++)
+                    if (gridMap[k] == j + 1) mask[k] = 1;
+        int mx = 0;
+        for (int r = 0; r < nv; r++)
+            for (int k = 0; k < nh; k++) {
+                int e2 = mask[r * nh + k];
+                if (k > 0) e2 = std::min<int>(e2, mask[r * nh + k - 1]);
+                if (k < nh - 1) e2 = std::min<int>(e2, mask[r * nh + k + 1]);
+                if (r > 0) e2 = std::min<int>(e2, mask[(r - 1) * nh + k]);
+                if (r < nv - 1) e2 = std::min<int>(e2, mask[(r + 1) * nh + k]);
+                er[r * nh + k] = (uint8_t)e2;
+                mx = std::max(mx, e2);
+                int dl = 0;
+                for (int dr = -1; dr <= 1; dr++)
+                    for (int dc = -1; dc <= 1; dc++) {
+                        const int rr = r + dr, kk = k + dc;
+                        if (rr >= 0 && rr < nv && kk >= 0 && kk < nh) dl = std::max<int>(dl, mask[rr * nh + kk]);
+                    }
+                di[r * nh + k] = (uint8_t)dl;
+            }
+        if (mx == 0) continue;
+        if (nFinal >= cap || nFinal >= 254) { c->err = "planes_cape: plane buffer too small"; *n_planes = nFinal; return DRFE_ERR_CAPACITY; }
+        if (planes) {
+            drfe_cape_plane& o = planes[nFinal];
+            std::memcpy(o.normal, segs[i].normal, 24);
+            std::memcpy(o.mean, segs[i].mean, 24);
+            o.d = segs[i].d; o.mse = segs[i].MSE; o.score = segs[i].score; o.n_points = segs[i].nr_pts;
+        }
+        nFinal++;
+        const uint8_t nr = (uint8_t)nFinal;
+        const float nx = (float)segs[i].normal[0], ny = (float)segs[i].normal[1], nz = (float)segs[i].normal[2];
+        const float dd = (float)segs[i].d;
+        const float maxDist = 9 * segs[i].MSE;
+        for (int cell = 0; cell < ncell; cell++) {
+            if (er[cell] > 0) gridEroded[cell] = nr;
+            if ((int)di[cell] - (int)er[cell] <= 0) continue;
+            const int r0 = (cell / nh) * patch, c0 = (cell % nh) * patch;
+            for (int lr = 0; lr < patch; lr++)
+                for (int lc = 0; lc < patch; lc++) {
+                    const int pr = r0 + lr, pc = c0 + lc, pt = cell * ppc + lr * patch + lc;
+                    const double z = (double)depth_m[(size_t)pr * stride + pc];
+                    const float X = (float)(((double)pc - cx) * z / fx), Y = (float)(((double)pr - cy) * z / fy), Z = (float)z;
+                    const float dv = X * nx + Y * ny + Z * nz + dd;
+                    const float dist = (float)((double)dv * (double)dv);
+                    if (dist < maxDist && dist < distStacked[pt]) { distStacked[pt] = dist; segStacked[pt] = nr; }
+                }
+        }
+    }
+    *n_planes = nFinal;
+    std::memset(seg, 0, (size_t)npx);
+    for (int cell = 0; cell < ncell; cell++) {
+        const int r0 = (cell / nh) * patch, c0 = (cell % nh) * patch;
+        for (int lr = 0; lr < patch; lr++)
+            for (int lc = 0; lc < patch; lc++) {
+                const uint8_t v = gridEroded[cell] > 0 ? gridEroded[cell] : segStacked[cell * ppc + lr * patch + lc];
+                if (v > 0) seg[(size_t)(r0 + lr) * w + c0 + lc] = v;
+            }
+    }
+    return DRFE_OK;
+}
+
+} /* extern "C" */

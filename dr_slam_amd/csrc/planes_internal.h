@@ -13,6 +13,13 @@ struct AhcBlockRec {          /* result of one PlaneSeg init block */
     int N;                    /* 100 for a valid window, else 0 */
 };
 
+struct CapeCellRec {          /* CAPE PlaneSeg of one PATCH x PATCH cell (src/CAPE/PlaneSeg.cpp:8-94) */
+    double acc[9];            /* x y z xx yy zz xy xz yz (float32 sums widened) */
+    double mean[3], normal[3], d;
+    float MSE, score, tol;    /* tol = cell_distance_tols[cell] (src/CAPE/CAPE.cpp:73) */
+    int planar, nr_pts;
+};
+
 struct PlanesScratch {
     AhcBlockRec* d_blocks; size_t blocksCap;   /* device, [slot][Nw*Nh] */
     uint16_t* d_depth; size_t depthCap;        /* staging for the host-buffer API */

@@ -77,6 +77,121 @@ __global__ __launch_bounds__(128) void k_ahc_blocks(const uint16_t* __restrict__
     out[(size_t)slot * Nw * Nh + b] = rec;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* CAPE: one lane per PATCH x PATCH cell.
+ *   PlaneDetection_CAPE::runPlaneDetection cloud + cell-major layout   src/PlaneExtractor.cpp:117-152
+ *   PlaneSeg::PlaneSeg (validity, cross-search jump test, float32 sums) src/CAPE/PlaneSeg.cpp:8-94
+ *   PlaneSeg::fitPlane                                                  src/CAPE/PlaneSeg.cpp:110-142
+ *   cell_distance_tols                                                  src/CAPE/CAPE.cpp:70-75
+ * The cell-major copy of the cloud is never built: cell-local index k = lr*PATCH + lc addresses pixel
+ * (r0+lr, c0+lc) directly.  The float32 sums run sequentially in k (the canonical order of
+ * oracle/cape_oracle.cpp; Eigen's own order is SIMD-width dependent). */
+__device__ __forceinline__ float cape_z(const float* d, size_t rowStride, int r0, int c0, int patch, int k)
+{
+    const int lr = k / patch, lc = k - lr * patch;
+    return d[(size_t)(r0 + lr) * rowStride + c0 + lc];
+}
+
+__global__ __launch_bounds__(64) void k_cape_cells(const float* __restrict__ depth, size_t rowStride, int w, int h,
+                                                   float fx, float fy, float cx, float cy, int patch, float sinCos,
+                                                   float maxMergeDist, CapeCellRec* __restrict__ out)
+{
+    const int nh = w / patch, nv = h / patch;
+    const int cell = blockIdx.x * 64 + threadIdx.x;
+    if (cell >= nh * nv) return;
+    const int r0 = (cell / nh) * patch, c0 = (cell % nh) * patch;
+    const int n = patch * patch;
+    CapeCellRec rec;
+    for (int k = 0; k < 9; k++) rec.acc[k] = 0.0;
+    for (int k = 0; k < 3; k++) { rec.mean[k] = 0.0; rec.normal[k] = 0.0; }
+    rec.d = 0.0; rec.MSE = 0.f; rec.score = 0.f; rec.tol = 0.f;
+    rec.planar = 1;
+    int cnt = 0;
+    for (int k = 0; k < n; k++) cnt += cape_z(depth, rowStride, r0, c0, patch, k) > 0 ? 1 : 0;
+    rec.nr_pts = cnt;
+    if (cnt < n / 2) rec.planar = 0;
+    if (rec.planar) {   /* horizontal scan through the middle row */
+        int jumps = 0;
+        int i = patch * (patch / 2);
+        const int j = i + patch;
+        float zl = fmaxf(cape_z(depth, rowStride, r0, c0, patch, i), cape_z(depth, rowStride, r0, c0, patch, i + 1));
+        i++;
+        while (i < j) {
+            const float z = cape_z(depth, rowStride, r0, c0, patch, i);
+            if (z > 0 && (double)fabsf(z - zl) < 100.0) zl = z;
+            else if (z > 0) jumps++;
+            i++;
+        }
+        if (jumps > 1) rec.planar = 0;
+    }
+    if (rec.planar) {   /* vertical scan through the middle column */
+        int jumps = 0;
+        int i = patch / 2;
+        const int j = n - i;
+        float zl = fmaxf(cape_z(depth, rowStride, r0, c0, patch, i), cape_z(depth, rowStride, r0, c0, patch, i + patch));
+        i += patch;
+        while (i < j) {
+            const float z = cape_z(depth, rowStride, r0, c0, patch, i);
+            if (z > 0 && (double)fabsf(z - zl) < 100.0) zl = z;
+            else if (z > 0) jumps++;
+            i += patch;
+        }
+        if (jumps > 1) rec.planar = 0;
+    }
+    if (rec.planar) {
+        const double dfx = (double)fx, dfy = (double)fy, dcx = (double)cx, dcy = (double)cy;
+        float sx = 0, sy = 0, sz = 0, sxx = 0, syy = 0, szz = 0, sxy = 0, sxz = 0, syz = 0;
+        float X0 = 0, Y0 = 0, Z0 = 0, X1 = 0, Y1 = 0, Z1 = 0;
+        for (int lr = 0; lr < patch; lr++)
+            for (int lc = 0; lc < patch; lc++) {
+                const double z = (double)depth[(size_t)(r0 + lr) * rowStride + c0 + lc];
+                const float X = (float)(((double)(c0 + lc) - dcx) * z / dfx);
+                const float Y = (float)(((double)(r0 + lr) - dcy) * z / dfy);
+                const float Z = (float)z;
+                sx += X; sy += Y; sz += Z;
+                sxx += X * X; syy += Y * Y; szz += Z * Z;
+                sxy += X * Y; sxz += X * Z; syz += Y * Z;
+                if (lr == 0 && lc == 0) { X0 = X; Y0 = Y; Z0 = Z; }
+                X1 = X; Y1 = Y; Z1 = Z;
+            }
+        rec.acc[0] = sx; rec.acc[1] = sy; rec.acc[2] = sz; rec.acc[3] = sxx; rec.acc[4] = syy; rec.acc[5] = szz;
+        rec.acc[6] = sxy; rec.acc[7] = sxz; rec.acc[8] = syz;
+        const double np = (double)cnt;
+        rec.mean[0] = rec.acc[0] / np; rec.mean[1] = rec.acc[1] / np; rec.mean[2] = rec.acc[2] / np;
+        double ev[3], Q[9];
+        ahc_eig3(rec.acc[3] - rec.acc[0] * rec.acc[0] / np, rec.acc[6] - rec.acc[0] * rec.acc[1] / np,
+                 rec.acc[7] - rec.acc[0] * rec.acc[2] / np, rec.acc[4] - rec.acc[1] * rec.acc[1] / np,
+                 rec.acc[8] - rec.acc[1] * rec.acc[2] / np, rec.acc[5] - rec.acc[2] * rec.acc[2] / np, ev, Q);
+        double dd = -(Q[0] * rec.mean[0] + Q[1] * rec.mean[1] + Q[2] * rec.mean[2]);
+        if (dd > 0) { rec.normal[0] = Q[0]; rec.normal[1] = Q[1]; rec.normal[2] = Q[2]; }
+        else { rec.normal[0] = -Q[0]; rec.normal[1] = -Q[1]; rec.normal[2] = -Q[2]; dd = -dd; }
+        rec.d = dd;
+        rec.MSE = (float)(ev[0] / np);
+        rec.score = (float)(ev[1] / ev[0]);
+        const double t = 0.000001425 * rec.mean[2] * rec.mean[2] + 10;
+        if ((double)rec.MSE > t * t) rec.planar = 0;
+        if (rec.planar) {
+            const float dx = X1 - X0, dy = Y1 - Y0, dz = Z1 - Z0;
+            float sq = dx * dx;
+            sq += dy * dy;
+            sq += dz * dz;
+            const float diameter = sqrtf(sq);
+            const float tt = fminf(fmaxf(diameter * sinCos, 20.0f), maxMergeDist);
+            rec.tol = (float)((double)tt * (double)tt);
+        }
+    }
+    out[cell] = rec;
+}
+
+hipError_t drfe_launch_cape_cells(const float* d_depth, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                  float sinCos, float maxMergeDist, CapeCellRec* d_out, hipStream_t s)
+{
+    const int ncell = (w / patch) * (h / patch);
+    hipLaunchKernelGGL(k_cape_cells, dim3((ncell + 63) / 64), dim3(64), 0, s, d_depth, rowStride, w, h, K4[0], K4[1],
+                       K4[2], K4[3], patch, sinCos, maxMergeDist, d_out);
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_ahc_blocks(const uint16_t* d_depth, size_t frameStride, size_t rowStride, int w, int h,
                                   const float K4[4], float depthFactor, int nframes, AhcBlockRec* d_out, hipStream_t s)
 {

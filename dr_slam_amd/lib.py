@@ -32,8 +32,11 @@ SYMBOLS = (
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
-    "drfe_match_orb_points",
+    "drfe_match_orb_points", "drfe_planes_cape",
 )
+
+CAPE_PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("mean", "<f8", (3,)), ("d", "<f8"), ("mse", "<f4"),
+                             ("score", "<f4"), ("n_points", "<i4"), ("pad", "<i4")])
 
 PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("center", "<f8", (3,)), ("mse", "<f8"), ("curvature", "<f8"),
                         ("n_points", "<i4"), ("rid", "<i4")])
@@ -101,6 +104,7 @@ def load() -> C.CDLL:
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
     L.drfe_planes_ahc.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
     L.drfe_planes_ahc_blocks.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, vp, i32]
+    L.drfe_planes_cape.argtypes = [vp, vp, i32, i32, sz, vp, i32, f32, f32, vp, i32, C.POINTER(i32), vp, vp, vp, vp]
     L.drfe_profile_enable.argtypes = [vp, i32]
     L.drfe_profile_stage_ms.argtypes = [vp, vp]
     L.drfe_stream_sync.argtypes = [vp]
@@ -297,6 +301,25 @@ class Context:
                                          C.byref(n), _p(seg), _p(off), _p(idx)), "drfe_planes_ahc")
         n = n.value
         return dict(planes=planes[:n].copy(), seg=seg, members=[idx[off[i]:off[i + 1]].copy() for i in range(n)])
+
+    def planes_cape(self, depth_m: np.ndarray, K4, patch=20, cos_angle_max=None, max_merge_dist=50.0, cap=64):
+        """PlaneDetection_CAPE::readDepthImage + runPlaneDetection -> dict(planes, seg, cell taps)."""
+        d = np.ascontiguousarray(depth_m, np.float32)
+        h, w = d.shape
+        if cos_angle_max is None:
+            cos_angle_max = np.float32(np.cos(np.pi / 12))
+        nc = (w // patch) * (h // patch)
+        planes = np.zeros(cap, CAPE_PLANE_DTYPE)
+        n = C.c_int()
+        seg = np.zeros((h, w), np.uint8)
+        cells = np.zeros((nc, 16))
+        mst = np.zeros((nc, 3), np.float32)
+        pn = np.zeros((nc, 2), np.int32)
+        self._chk(self.L.drfe_planes_cape(self.h, _p(d), w, h, w, _p(np.ascontiguousarray(K4, np.float32)), patch,
+                                          np.float32(cos_angle_max), np.float32(max_merge_dist), _p(planes), cap,
+                                          C.byref(n), _p(seg), _p(cells), _p(mst), _p(pn)), "drfe_planes_cape")
+        return dict(planes=planes[:n.value].copy(), seg=seg, cells=cells, cell_mst=mst, cell_planar=pn[:, 0],
+                    cell_npts=pn[:, 1])
 
     def planes_ahc_blocks(self, depth16: np.ndarray, K4, depth_factor):
         d = np.ascontiguousarray(depth16, np.uint16)

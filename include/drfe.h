@@ -205,6 +205,28 @@ int drfe_planes_ahc(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t s
 int drfe_planes_ahc_blocks(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
                            float depth_factor, double* blocks17, int32_t* valid_n, int cap);
 
+/* PlaneDetection_CAPE (replaces src/PlaneExtractor.cpp:65-191 + src/CAPE/{CAPE,PlaneSeg,Histogram}.cpp;
+ * its thread launch is commented out in the reference, src/Frame.cc:129, but the class is public API).
+ * One entry of plane_params (CAPE PlaneSeg: normal, d, mean, MSE, score, nr_pts). */
+typedef struct drfe_cape_plane {
+    double normal[3];
+    double mean[3];
+    double d;           /* plane equation normal . p + d = 0, d > 0 */
+    float mse, score;
+    int32_t n_points;
+    int32_t pad;
+} drfe_cape_plane;
+
+/* PlaneDetection_CAPE::readDepthImage(depth32f, K) + runPlaneDetection().  depth_m: host CV_32F depth in
+ * metres (`stride` elements per row); patch = PATCH_SIZE (Plane.PATCH_SIZE: 20 or 10); cos_angle_max =
+ * COS_ANGLE_MAX (cos(pi/12)); max_merge_dist = MAX_MERGE_DIST (Plane.MAX_MERGE_DIST: 50).  w and h must
+ * be multiples of patch.  Outputs: planes[0..n), seg (w*h) = seg_output (plane number, 0 = none).
+ * Parity taps (may be NULL): per cell 16 doubles (9 sums, mean, normal, d), 3 floats (MSE, score,
+ * merge tolerance), 2 ints (planar, nr_pts). */
+int drfe_planes_cape(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
+                     float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
+                     uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* measurement                                                                                       */
 enum { DRFE_STAGE_PYRAMID = 0, DRFE_STAGE_FAST, DRFE_STAGE_QUADTREE, DRFE_STAGE_BLUR, DRFE_STAGE_DESC,

@@ -2,6 +2,7 @@
 #include "oracle.h"
 #include "match_oracle.h"
 #include "ahc_oracle.h"
+#include "cape_oracle.h"
 #include "../include/drfe_math.h"
 
 #include <chrono>
@@ -262,6 +263,40 @@ void orc_eig33sym(const double* K9, double* s3, double* V9)
     for (int i = 0; i < 9; i++) K[i / 3][i % 3] = K9[i];
     eig33sym(K, s3, V);
     for (int i = 0; i < 9; i++) V9[i] = V[i / 3][i % 3];
+}
+
+/* CAPE planes */
+void* orc_cape_run(const float* depth, int w, int h, const float* K4, int patch, float cos_angle_max, float max_merge_dist)
+{
+    CapeResult* R = new CapeResult();
+    try { *R = cape_run(depth, w, h, K4, patch, cos_angle_max, max_merge_dist); }
+    catch (const std::exception& e) { g_err = e.what(); delete R; return nullptr; }
+    return R;
+}
+void orc_cape_free(void* h) { delete (CapeResult*)h; }
+int orc_cape_num_planes(void* h) { return (int)((CapeResult*)h)->planes.size(); }
+int orc_cape_num_cells(void* h) { return (int)((CapeResult*)h)->cells.size(); }
+void orc_cape_get_planes(void* h, double* out /* n x 7: normal3 mean3 d */, float* ms /* n x 2 */, int32_t* npts)
+{
+    const auto& P = ((CapeResult*)h)->planes;
+    for (size_t i = 0; i < P.size(); i++) {
+        for (int k = 0; k < 3; k++) { out[7 * i + k] = P[i].normal[k]; out[7 * i + 3 + k] = P[i].mean[k]; }
+        out[7 * i + 6] = P[i].d;
+        ms[2 * i] = P[i].MSE; ms[2 * i + 1] = P[i].score;
+        npts[i] = P[i].nr_pts;
+    }
+}
+void orc_cape_get_seg(void* h, uint8_t* out) { const auto& s = ((CapeResult*)h)->seg; std::memcpy(out, s.data(), s.size()); }
+void orc_cape_get_cells(void* h, double* out /* n x 16: sums9 mean3 normal3 d */, float* mst /* n x 3 */, int32_t* pn /* n x 2 */)
+{
+    const auto& C = ((CapeResult*)h)->cells;
+    for (size_t i = 0; i < C.size(); i++) {
+        for (int k = 0; k < 9; k++) out[16 * i + k] = C[i].sums[k];
+        for (int k = 0; k < 3; k++) { out[16 * i + 9 + k] = C[i].mean[k]; out[16 * i + 12 + k] = C[i].normal[k]; }
+        out[16 * i + 15] = C[i].d;
+        mst[3 * i] = C[i].MSE; mst[3 * i + 1] = C[i].score; mst[3 * i + 2] = C[i].tol;
+        pn[2 * i] = C[i].planar; pn[2 * i + 1] = C[i].nr_pts;
+    }
 }
 
 int orc_sizeof_keypoint() { return (int)sizeof(KeyPoint); }

@@ -87,6 +87,14 @@ def lib() -> C.CDLL:
         L.orc_ahc_get_members.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_ahc_get_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_eig33sym.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_cape_run.restype = C.c_void_p
+        L.orc_cape_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.orc_cape_free.argtypes = [C.c_void_p]
+        for n in ("orc_cape_num_planes", "orc_cape_num_cells"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.orc_cape_get_planes.argtypes = [C.c_void_p] * 4
+        L.orc_cape_get_seg.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_cape_get_cells.argtypes = [C.c_void_p] * 4
         assert L.orc_sizeof_keypoint() == KP_DTYPE.itemsize
         assert L.orc_sizeof_mappointrec() == MAPPOINT_DTYPE.itemsize
         assert L.orc_sizeof_trackedpointrec() == TRACKED_DTYPE.itemsize
@@ -343,3 +351,33 @@ def ahc_planes(depth16, K4, depthfactor):
         L.orc_ahc_free(H)
     return dict(planes=planes, N=nrid[:, 0], rid=nrid[:, 1], seg=seg, members=members, blocks=blocks,
                 block_valid=vn[:, 0], block_N=vn[:, 1])
+
+
+def cape_planes(depth_m, K4, patch=20, cos_angle_max=None, max_merge_dist=50.0):
+    """PlaneDetection_CAPE::readDepthImage + runPlaneDetection (reference src/PlaneExtractor.cpp:102-191).
+    depth_m: float32 metres (what Frame::ComputePlanes_CAPE passes).  Returns dict(planes=[n,7]
+    normal|mean|d, MSE, score, nr_pts, seg, cells=[nc,16], cell_mst=[nc,3], cell_planar, cell_npts)."""
+    d = _c(depth_m, np.float32)
+    h, w = d.shape
+    if cos_angle_max is None:
+        cos_angle_max = np.float32(np.cos(np.pi / 12))     # include/PlaneExtractor.h:111
+    L = lib()
+    H = L.orc_cape_run(_p(d), w, h, _p(_c(K4, np.float32)), patch, np.float32(cos_angle_max), np.float32(max_merge_dist))
+    if not H:
+        raise RuntimeError(L.orc_last_error().decode())
+    try:
+        n, nc = L.orc_cape_num_planes(H), L.orc_cape_num_cells(H)
+        planes = np.zeros((n, 7))
+        ms = np.zeros((n, 2), np.float32)
+        npts = np.zeros(n, np.int32)
+        L.orc_cape_get_planes(H, _p(planes), _p(ms), _p(npts))
+        seg = np.zeros((h, w), np.uint8)
+        L.orc_cape_get_seg(H, _p(seg))
+        cells = np.zeros((nc, 16))
+        mst = np.zeros((nc, 3), np.float32)
+        pn = np.zeros((nc, 2), np.int32)
+        L.orc_cape_get_cells(H, _p(cells), _p(mst), _p(pn))
+    finally:
+        L.orc_cape_free(H)
+    return dict(planes=planes, MSE=ms[:, 0], score=ms[:, 1], nr_pts=npts, seg=seg, cells=cells, cell_mst=mst,
+                cell_planar=pn[:, 0], cell_npts=pn[:, 1])

@@ -56,6 +56,31 @@ def test_planes_bit_exact(ctx, oracle_mod, seed, kind, camname):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("seed,kind,camname,patch", [(2, "room_boxes", "TUM3", 20), (3, "living_room", "ICL", 20),
+                                                      (5, "corridor", "TUM3", 10), (1, "planar_lowtexture", "TUM3", 10)])
+def test_cape_bit_exact(ctx, oracle_mod, seed, kind, camname, patch):
+    """PlaneDetection_CAPE: device cell fits + product region growing / merging / refinement vs oracle.
+    ICL intrinsics have fy < 0 (Examples/RGB-D/ICL.yaml:9)."""
+    from dr_slam_amd import synth
+    cam = getattr(synth, camname)
+    _, d, _ = next(synth.sequence(seed, 1, cam=cam, kind=kind))
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    dm = oracle_mod.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+    g = ctx.planes_cape(dm, K4, patch)
+    o = oracle_mod.cape_planes(dm, K4, patch)
+    assert np.array_equal(g["cell_planar"], o["cell_planar"]) and np.array_equal(g["cell_npts"], o["cell_npts"])
+    assert np.array_equal(g["cells"].view(np.uint64), o["cells"].view(np.uint64))
+    assert np.array_equal(g["cell_mst"].view(np.uint32), o["cell_mst"].view(np.uint32))
+    assert len(g["planes"]) == len(o["planes"]) >= 3
+    assert np.array_equal(g["planes"]["normal"].view(np.uint64), o["planes"][:, 0:3].view(np.uint64))
+    assert np.array_equal(g["planes"]["mean"].view(np.uint64), o["planes"][:, 3:6].view(np.uint64))
+    assert np.array_equal(g["planes"]["d"].view(np.uint64), o["planes"][:, 6].view(np.uint64))
+    assert np.array_equal(g["planes"]["mse"].view(np.uint32), o["MSE"].view(np.uint32))
+    assert np.array_equal(g["planes"]["score"].view(np.uint32), o["score"].view(np.uint32))
+    assert np.array_equal(g["planes"]["n_points"], o["nr_pts"])
+    assert np.array_equal(g["seg"], o["seg"])
+
+
 def test_no_depth_gives_no_planes(ctx, oracle_mod):
     d = np.zeros((480, 640), np.uint16)
     K4 = np.array([500, 500, 320, 240], np.float32)
