@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames rendered per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
     args = ap.parse_args()
 
     import torch
@@ -115,13 +116,26 @@ def main():
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    if world > 1:
-        # the one initial exchange of the sharded mode: rank 0's constant tables travel over RCCL/xGMI
-        # (stands in for the ORB vocabulary broadcast of SURVEY.md §8e until the BoW row lands)
-        sharding.broadcast_tables(np.concatenate(fe.ctx.scale_tables()), dev, dist)
+    if world > 1 or args.bow:
+        # the one initial exchange of the sharded mode: rank 0 owns the ORB vocabulary
+        # (k=10, L=6, ~50 MB flattened; synthetic because the reference's ORBvoc blob is missing) and
+        # broadcasts it over RCCL/xGMI; every rank uploads its copy into its own context.
+        from dr_slam_amd import vocabulary as V
+        if rank == 0:
+            blob = V.make_synthetic(10, 6, seed=1).pack()
+            size = np.array([blob.size], np.int64)
+        else:
+            size = np.zeros(1, np.int64)
+        size = sharding.broadcast_tables(size, dev, dist if world > 1 else None)
+        if rank != 0:
+            blob = np.zeros(int(size[0]), np.uint8)
+        blob = sharding.broadcast_tables(blob, dev, dist if world > 1 else None)
+        V.Vocabulary.unpack(blob).upload(fe.ctx)
 
     def step():
         fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
+        if args.bow:   # Frame::ComputeBoW tree descent for every frame of the batch (not part of the metric)
+            fe.ctx.bow_transform_batch(4, B, stream)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,185 @@
+/* capi_bow.cpp — C-ABI of the bag-of-words step (include/drfe.h): vocabulary upload, Frame::ComputeBoW
+ * device part, ORBmatcher::SearchByBoW. */
+#include "drfe_internal.h"
+#include "bow_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <new>
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return DRFE_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+void drfe_bow_free(drfe_ctx* c)
+{
+    BowState* b = c->bow;
+    if (!b) return;
+    for (void* p : b->d_vocBlob)
+        if (p) (void)hipFree(p);
+    void* ptrs[] = {b->d_word, b->d_weight, b->d_nid, b->d_groups, b->d_kfIdx, b->d_fIdx, b->d_kfMP, b->d_match,
+                    b->d_counters, b->d_hist, b->d_entries};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete b;
+    c->bow = nullptr;
+}
+
+extern "C" {
+
+int drfe_voc_upload(drfe_ctx* c, int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                    const uint8_t* desc, const double* weight, const uint8_t* is_leaf)
+{
+    if (!c || !parent || !desc || !weight || !is_leaf || n_nodes < 2) return DRFE_ERR_INVALID;
+    /* the limits TemplatedVocabulary::loadFromTextFile enforces (:1359) */
+    if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3) {
+        c->err = "voc_upload: not a valid vocabulary header";
+        return DRFE_ERR_INVALID;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    drfe_bow_free(c);
+    BowState* b = new (std::nothrow) BowState();
+    if (!b) return DRFE_ERR_INVALID;
+    std::memset(b, 0, sizeof(*b));
+    c->bow = b;
+    /* children lists in node-id order, as the loader's m_nodes[pid].children.push_back(nid) builds them */
+    std::vector<int> cnt(n_nodes + 1, 0), children(n_nodes - 1), wordId(n_nodes, -1);
+    for (int i = 1; i < n_nodes; i++) {
+        if (parent[i] < 0 || parent[i] >= n_nodes) { c->err = "voc_upload: bad parent id"; return DRFE_ERR_INVALID; }
+        cnt[parent[i] + 1]++;
+    }
+    for (int i = 0; i < n_nodes; i++) {
+        if (cnt[i + 1] > 32) { c->err = "voc_upload: more than 32 children per node"; return DRFE_ERR_INVALID; }
+        cnt[i + 1] += cnt[i];
+    }
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    int nwords = 0;
+    for (int i = 1; i < n_nodes; i++) {
+        children[fill[parent[i]]++] = i;
+        if (is_leaf[i]) wordId[i] = nwords++;
+    }
+    const size_t n = (size_t)n_nodes;
+    uint8_t* d_desc; double* d_w; int *d_word, *d_cb, *d_ch;
+    HIPCHK(c, hipMalloc((void**)&d_desc, n * 32)); b->d_vocBlob[0] = d_desc;
+    HIPCHK(c, hipMalloc((void**)&d_w, n * 8)); b->d_vocBlob[1] = d_w;
+    HIPCHK(c, hipMalloc((void**)&d_word, n * 4)); b->d_vocBlob[2] = d_word;
+    HIPCHK(c, hipMalloc((void**)&d_cb, (n + 1) * 4)); b->d_vocBlob[3] = d_cb;
+    HIPCHK(c, hipMalloc((void**)&d_ch, n * 4)); b->d_vocBlob[4] = d_ch;
+    HIPCHK(c, hipMemcpy(d_desc, desc, n * 32, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_w, weight, n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_word, wordId.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_cb, cnt.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_ch, children.data(), (n - 1) * 4, hipMemcpyHostToDevice));
+    b->voc.k = k; b->voc.L = L; b->voc.nNodes = n_nodes;
+    b->voc.desc = d_desc; b->voc.weight = d_w; b->voc.wordId = d_word; b->voc.childBegin = d_cb; b->voc.children = d_ch;
+    b->scoring = scoring; b->weighting = weighting;
+    const size_t B = (size_t)c->cfg.max_batch, M = (size_t)c->maxKp;
+    HIPCHK(c, hipMalloc((void**)&b->d_word, B * M * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_weight, B * M * 8));
+    HIPCHK(c, hipMalloc((void**)&b->d_nid, B * M * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_groups, M * sizeof(BowGroup)));
+    HIPCHK(c, hipMalloc((void**)&b->d_kfIdx, M * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_fIdx, M * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_kfMP, M * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_match, M * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_counters, 8));
+    HIPCHK(c, hipMalloc((void**)&b->d_hist, 30 * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_entries, M * 4));
+    return DRFE_OK;
+}
+
+int drfe_bow_transform_batch(drfe_ctx* c, int levelsup, int nframes, void* stream)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    if (!c->bow) { c->err = "bow_transform: upload a vocabulary first"; return DRFE_ERR_STATE; }
+    if (nframes < 1 || nframes > c->lastBatch) { c->err = "bow_transform: extract the batch first"; return DRFE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    BowState* b = c->bow;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, drfe_launch_bow_transform(c, b->voc, levelsup, nframes, b->d_word, b->d_weight, b->d_nid, s));
+    b->levelsup = levelsup;
+    b->transformedFrames = nframes;
+    return DRFE_OK;
+}
+
+int drfe_bow_download(drfe_ctx* c, int slot, int32_t* word, double* weight, int32_t* nid, int cap)
+{
+    if (!c || !c->bow || slot < 0 || slot >= c->bow->transformedFrames) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) return DRFE_ERR_CAPACITY;
+    const size_t o = (size_t)slot * c->maxKp;
+    if (n && word) HIPCHK(c, hipMemcpy(word, c->bow->d_word + o, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (n && weight) HIPCHK(c, hipMemcpy(weight, c->bow->d_weight + o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (n && nid) HIPCHK(c, hipMemcpy(nid, c->bow->d_nid + o, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+int drfe_search_by_bow(drfe_ctx* c, int kf_slot, int f_slot, const int32_t* kf_mp, int n_kf, float nnratio, int check_ori,
+                       int32_t* f_match, int n_f, int* nmatches)
+{
+    if (!c || !kf_mp || !f_match || !nmatches) return DRFE_ERR_INVALID;
+    BowState* b = c->bow;
+    if (!b || kf_slot < 0 || f_slot < 0 || kf_slot >= b->transformedFrames || f_slot >= b->transformedFrames) {
+        c->err = "search_by_bow: both slots need drfe_bow_transform_batch first";
+        return DRFE_ERR_STATE;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int counts[2];
+    HIPCHK(c, hipMemcpy(&counts[0], c->d_kpCount + kf_slot, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&counts[1], c->d_kpCount + f_slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_kf != counts[0] || n_f != counts[1]) { c->err = "search_by_bow: N mismatch"; return DRFE_ERR_INVALID; }
+    *nmatches = 0;
+    for (int i = 0; i < n_f; i++) f_match[i] = -1;
+    if (n_kf == 0 || n_f == 0) return DRFE_OK;
+    /* FeatureVectors of both frames: node -> feature indices in feature order, stopped words skipped
+     * (FeatureVector::addFeature is called only when w > 0, TemplatedVocabulary.h:1158-1162) */
+    std::vector<int> nidKF(n_kf), nidF(n_f);
+    std::vector<double> wKF(n_kf), wF(n_f);
+    const size_t ok = (size_t)kf_slot * c->maxKp, of = (size_t)f_slot * c->maxKp;
+    HIPCHK(c, hipMemcpy(nidKF.data(), b->d_nid + ok, sizeof(int) * n_kf, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(wKF.data(), b->d_weight + ok, sizeof(double) * n_kf, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nidF.data(), b->d_nid + of, sizeof(int) * n_f, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(wF.data(), b->d_weight + of, sizeof(double) * n_f, hipMemcpyDeviceToHost));
+    std::map<int, std::vector<int>> fvKF, fvF;
+    for (int i = 0; i < n_kf; i++) if (wKF[i] > 0) fvKF[nidKF[i]].push_back(i);
+    for (int i = 0; i < n_f; i++) if (wF[i] > 0) fvF[nidF[i]].push_back(i);
+    std::vector<BowGroup> groups;
+    std::vector<int> kfIdx, fIdx;
+    for (auto& kv : fvKF) {                                   /* ascending node id == the merge walk of :181-265 */
+        auto it = fvF.find(kv.first);
+        if (it == fvF.end()) continue;
+        BowGroup g;
+        g.kfBegin = (int)kfIdx.size(); kfIdx.insert(kfIdx.end(), kv.second.begin(), kv.second.end()); g.kfEnd = (int)kfIdx.size();
+        g.fBegin = (int)fIdx.size(); fIdx.insert(fIdx.end(), it->second.begin(), it->second.end()); g.fEnd = (int)fIdx.size();
+        groups.push_back(g);
+    }
+    hipStream_t s = c->stream;
+    if (!groups.empty()) {
+        HIPCHK(c, hipMemcpy(b->d_groups, groups.data(), groups.size() * sizeof(BowGroup), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b->d_kfIdx, kfIdx.data(), kfIdx.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b->d_fIdx, fIdx.data(), fIdx.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMemcpy(b->d_kfMP, kf_mp, sizeof(int) * n_kf, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemsetAsync(b->d_match, 0xFF, sizeof(int) * n_f, s));
+    HIPCHK(c, hipMemsetAsync(b->d_counters, 0, 8, s));
+    HIPCHK(c, hipMemsetAsync(b->d_hist, 0, 30 * 4, s));
+    HIPCHK(c, drfe_launch_bow_match(c, kf_slot, f_slot, b->d_groups, (int)groups.size(), b->d_kfIdx, b->d_fIdx, b->d_kfMP,
+                                    nnratio, check_ori, b->d_match, b->d_counters, b->d_hist, b->d_entries, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpy(f_match, b->d_match, sizeof(int) * n_f, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nmatches, b->d_counters, sizeof(int), hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+} /* extern "C" */

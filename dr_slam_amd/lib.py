@@ -32,7 +32,8 @@ SYMBOLS = (
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
-    "drfe_match_orb_points", "drfe_planes_cape",
+    "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
+    "drfe_search_by_bow",
 )
 
 CAPE_PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("mean", "<f8", (3,)), ("d", "<f8"), ("mse", "<f4"),
@@ -102,6 +103,10 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_voc_upload.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.drfe_bow_transform_batch.argtypes = [vp, i32, i32, vp]
+    L.drfe_bow_download.argtypes = [vp, i32, vp, vp, vp, i32]
+    L.drfe_search_by_bow.argtypes = [vp, i32, i32, vp, i32, f32, i32, vp, i32, C.POINTER(i32)]
     L.drfe_planes_ahc.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
     L.drfe_planes_ahc_blocks.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, vp, i32]
     L.drfe_planes_cape.argtypes = [vp, vp, i32, i32, sz, vp, i32, f32, f32, vp, i32, C.POINTER(i32), vp, vp, vp, vp]
@@ -285,6 +290,33 @@ class Context:
         dist = np.zeros((len(Q), k), np.int32)
         self._chk(self.L.drfe_match_bf_knn(self.h, _p(Q), len(Q), _p(T), len(T), k, _p(idx), _p(dist)), "drfe_match_bf_knn")
         return idx, dist
+
+    # --- bag of words ------------------------------------------------------------------------------
+    def voc_upload(self, k, L, scoring, weighting, parent, desc, weight, is_leaf):
+        parent = np.ascontiguousarray(parent, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        self._chk(self.L.drfe_voc_upload(self.h, k, L, scoring, weighting, len(parent), _p(parent), _p(desc), _p(weight),
+                                         _p(is_leaf)), "drfe_voc_upload")
+
+    def bow_transform_batch(self, levelsup, nframes, stream: int = 0):
+        self._chk(self.L.drfe_bow_transform_batch(self.h, levelsup, nframes, C.c_void_p(stream)), "drfe_bow_transform_batch")
+
+    def bow_download(self, slot):
+        word = np.zeros(self.max_kp, np.int32)
+        weight = np.zeros(self.max_kp, np.float64)
+        nid = np.zeros(self.max_kp, np.int32)
+        self._chk(self.L.drfe_bow_download(self.h, slot, _p(word), _p(weight), _p(nid), self.max_kp), "drfe_bow_download")
+        return word, weight, nid
+
+    def search_by_bow(self, kf_slot, f_slot, kf_mp, n_f, nnratio, check_ori=True):
+        kf_mp = np.ascontiguousarray(kf_mp, np.int32)
+        out = np.full(n_f, -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_search_by_bow(self.h, kf_slot, f_slot, _p(kf_mp), len(kf_mp), nnratio, int(check_ori),
+                                            _p(out), n_f, C.byref(n)), "drfe_search_by_bow")
+        return n.value, out
 
     # --- planes ------------------------------------------------------------------------------------
     def planes_ahc(self, depth16: np.ndarray, K4, depth_factor, cap=64):

@@ -179,6 +179,29 @@ int drfe_match_bf_knn(drfe_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t,
                       int32_t* dist);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
+ * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */
+
+/* Upload a vocabulary in the node format of TemplatedVocabulary::loadFromTextFile
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424): node 0 is the root; for node i >= 1
+ * parent[i], is_leaf[i], 32 descriptor bytes, weight.  Children of a node are ordered by node id and
+ * word ids are assigned to leaves in node order, exactly as the loader does.  k <= 20, L <= 10. */
+int drfe_voc_upload(drfe_ctx* ctx, int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                    const uint8_t* desc, const double* weight, const uint8_t* is_leaf);
+/* Device part of TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) for the
+ * descriptors of slots 0..nframes-1: per feature the word id, the word weight and the node id at level
+ * L-levelsup.  Asynchronous on `stream`. */
+int drfe_bow_transform_batch(drfe_ctx* ctx, int levelsup, int nframes, void* stream);
+/* Per-feature results of a slot.  The caller folds them into BowVector / FeatureVector (std::map) in
+ * feature order — addWeight's float64 sums depend on that order (BowVector.cpp). */
+int drfe_bow_download(drfe_ctx* ctx, int slot, int32_t* word, double* weight, int32_t* nid, int cap);
+/* ORBmatcher(nnratio, checkOri).SearchByBoW(pKF = kf_slot, F = f_slot, vpMapPointMatches).
+ * kf_mp[i] >= 0 iff keyframe keypoint i holds a non-bad MapPoint.  f_match[j] = keyframe keypoint index
+ * matched to frame keypoint j, or -1; *nmatches = return value. */
+int drfe_search_by_bow(drfe_ctx* ctx, int kf_slot, int f_slot, const int32_t* kf_mp, int n_kf, float nnratio,
+                       int check_ori, int32_t* f_match, int n_f, int* nmatches);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* PlaneDetection (replaces src/PlaneExtractor.cpp:7-63 + include/peac/ : the live AHC extractor)   */
 
 /* One extracted plane: ahc::PlaneSeg fields Frame::ComputePlanes reads (src/Frame.cc:952-979:

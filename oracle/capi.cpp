@@ -3,6 +3,7 @@
 #include "match_oracle.h"
 #include "ahc_oracle.h"
 #include "cape_oracle.h"
+#include "bow_oracle.h"
 #include "../include/drfe_math.h"
 
 #include <chrono>
@@ -297,6 +298,54 @@ void orc_cape_get_cells(void* h, double* out /* n x 16: sums9 mean3 normal3 d */
         mst[3 * i] = C[i].MSE; mst[3 * i + 1] = C[i].score; mst[3 * i + 2] = C[i].tol;
         pn[2 * i] = C[i].planar; pn[2 * i + 1] = C[i].nr_pts;
     }
+}
+
+/* DBoW2 vocabulary / transform / SearchByBoW */
+void* orc_voc_create(const char* text)
+{
+    Vocabulary* v = new Vocabulary();
+    try { v->loadFromText(text); }
+    catch (const std::exception& e) { g_err = e.what(); delete v; return nullptr; }
+    return v;
+}
+void orc_voc_free(void* h) { delete (Vocabulary*)h; }
+void orc_voc_info(void* h, int32_t* out5)
+{
+    Vocabulary* v = (Vocabulary*)h;
+    out5[0] = v->k; out5[1] = v->L; out5[2] = v->scoring; out5[3] = v->weighting; out5[4] = (int)v->nodes.size();
+}
+void orc_voc_get_nodes(void* h, int32_t* parent, int32_t* word_id, uint8_t* desc, double* weight)
+{
+    Vocabulary* v = (Vocabulary*)h;
+    for (size_t i = 0; i < v->nodes.size(); i++) {
+        parent[i] = v->nodes[i].parent; word_id[i] = v->nodes[i].word_id; weight[i] = v->nodes[i].weight;
+        std::memcpy(desc + 32 * i, v->nodes[i].desc, 32);
+    }
+}
+void orc_voc_transform_each(void* h, const uint8_t* desc, int n, int levelsup, int32_t* word, double* weight, int32_t* nid)
+{
+    Vocabulary* v = (Vocabulary*)h;
+    for (int i = 0; i < n; i++) v->transformOne(desc + (size_t)i * 32, levelsup, word[i], weight[i], nid[i]);
+}
+/* BowVector as (ids, values) in key order; returns its size */
+int orc_voc_transform_bow(void* h, const uint8_t* desc, int n, int levelsup, int32_t* ids, double* vals, int cap)
+{
+    std::map<int, double> bow;
+    std::map<int, std::vector<unsigned>> fv;
+    ((Vocabulary*)h)->transform(desc, n, levelsup, bow, fv);
+    int i = 0;
+    for (auto& kv : bow) { if (i < cap) { ids[i] = kv.first; vals[i] = kv.second; } i++; }
+    return i;
+}
+/* nid arrays: node id at the FeatureVector level per feature, -1 when the word is stopped (weight <= 0) */
+int orc_search_by_bow(const int32_t* nidKF, int nKF, const int32_t* nidF, int nF, const uint8_t* descKF,
+                      const float* angleKF, const int32_t* kfMP, const uint8_t* descF, const float* angleF,
+                      float nnratio, int checkOri, int32_t* out)
+{
+    std::map<int, std::vector<unsigned>> fvKF, fvF;
+    for (int i = 0; i < nKF; i++) if (nidKF[i] >= 0) fvKF[nidKF[i]].push_back((unsigned)i);
+    for (int i = 0; i < nF; i++) if (nidF[i] >= 0) fvF[nidF[i]].push_back((unsigned)i);
+    return search_by_bow(fvKF, fvF, descKF, angleKF, kfMP, descF, angleF, nF, nnratio, checkOri != 0, out);
 }
 
 int orc_sizeof_keypoint() { return (int)sizeof(KeyPoint); }

@@ -95,6 +95,15 @@ def lib() -> C.CDLL:
         L.orc_cape_get_planes.argtypes = [C.c_void_p] * 4
         L.orc_cape_get_seg.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_cape_get_cells.argtypes = [C.c_void_p] * 4
+        L.orc_voc_create.restype = C.c_void_p
+        L.orc_voc_create.argtypes = [C.c_char_p]
+        L.orc_voc_free.argtypes = [C.c_void_p]
+        L.orc_voc_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_voc_get_nodes.argtypes = [C.c_void_p] * 5
+        L.orc_voc_transform_each.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_voc_transform_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         assert L.orc_sizeof_keypoint() == KP_DTYPE.itemsize
         assert L.orc_sizeof_mappointrec() == MAPPOINT_DTYPE.itemsize
         assert L.orc_sizeof_trackedpointrec() == TRACKED_DTYPE.itemsize
@@ -351,6 +360,56 @@ def ahc_planes(depth16, K4, depthfactor):
         L.orc_ahc_free(H)
     return dict(planes=planes, N=nrid[:, 0], rid=nrid[:, 1], seg=seg, members=members, blocks=blocks,
                 block_valid=vn[:, 0], block_N=vn[:, 1])
+
+
+class VocabularyOracle:
+    """DBoW2 TemplatedVocabulary<FORB>: text loader + transform (reference Thirdparty/DBoW2)."""
+
+    def __init__(self, text: str):
+        self.L_ = lib()
+        self.h = self.L_.orc_voc_create(text.encode())
+        if not self.h:
+            raise RuntimeError(self.L_.orc_last_error().decode())
+        info = np.zeros(5, np.int32)
+        self.L_.orc_voc_info(self.h, _p(info))
+        self.k, self.L, self.scoring, self.weighting, self.n_nodes = (int(v) for v in info)
+
+    def __del__(self):
+        try:
+            self.L_.orc_voc_free(self.h)
+        except Exception:
+            pass
+
+    def nodes(self):
+        n = self.n_nodes
+        parent, word = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        desc, weight = np.zeros((n, 32), np.uint8), np.zeros(n)
+        self.L_.orc_voc_get_nodes(self.h, _p(parent), _p(word), _p(desc), _p(weight))
+        return parent, word, desc, weight
+
+    def transform_each(self, desc, levelsup=4):
+        desc = _c(desc, np.uint8)
+        n = len(desc)
+        word, nid, weight = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n)
+        self.L_.orc_voc_transform_each(self.h, _p(desc), n, levelsup, _p(word), _p(weight), _p(nid))
+        return word, weight, nid
+
+    def bow_vector(self, desc, levelsup=4):
+        desc = _c(desc, np.uint8)
+        cap = max(len(desc), 1)
+        ids, vals = np.zeros(cap, np.int32), np.zeros(cap)
+        n = self.L_.orc_voc_transform_bow(self.h, _p(desc), len(desc), levelsup, _p(ids), _p(vals), cap)
+        return ids[:n], vals[:n]
+
+
+def search_by_bow(nid_kf, nid_f, desc_kf, angle_kf, kf_mp, desc_f, angle_f, nnratio, check_ori=True):
+    """ORBmatcher::SearchByBoW(pKF, F, matches). nid_*: FeatureVector node per feature (-1 = stopped word)."""
+    nid_kf, nid_f = _c(nid_kf, np.int32), _c(nid_f, np.int32)
+    out = np.full(len(nid_f), -1, np.int32)
+    n = lib().orc_search_by_bow(_p(nid_kf), len(nid_kf), _p(nid_f), len(nid_f), _p(_c(desc_kf, np.uint8)),
+                                _p(_c(angle_kf, np.float32)), _p(_c(kf_mp, np.int32)), _p(_c(desc_f, np.uint8)),
+                                _p(_c(angle_f, np.float32)), np.float32(nnratio), int(check_ori), _p(out))
+    return n, out
 
 
 def cape_planes(depth_m, K4, patch=20, cos_angle_max=None, max_merge_dist=50.0):

@@ -87,6 +87,12 @@ def _worker(rank, world, port, q):
     tab = np.arange(8, dtype=np.float32) * (1.0 if rank == 0 else -1.0)
     got = sharding.broadcast_tables(tab, dev, dist)
     el, n = sharding.reduce_elapsed_and_frames(1.0 + rank, 64 * (rank + 1), dev, dist)
+    # the vocabulary travels as one flat blob from rank 0 (bench.py does the same over RCCL)
+    from dr_slam_amd import vocabulary as V
+    ref = V.make_synthetic(5, 3, seed=9)
+    blob = ref.pack() if rank == 0 else np.zeros(ref.pack().size, np.uint8)
+    voc = V.Vocabulary.unpack(sharding.broadcast_tables(blob, dev, dist))
+    assert np.array_equal(voc.desc, ref.desc) and np.array_equal(voc.weight, ref.weight) and voc.k == 5 and voc.L == 3
     q.put((rank, got.tolist(), el, n, sharding.rank_seed(10, rank)))
     dist.barrier()
     dist.destroy_process_group()
