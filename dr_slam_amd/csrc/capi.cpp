@@ -5,6 +5,7 @@
 #include "match_internal.h"
 #include "planes_internal.h"
 #include "bow_internal.h"
+#include "lines_internal.h"
 
 #include <algorithm>
 #include <cstring>
@@ -79,6 +80,7 @@ void drfe_destroy(drfe_ctx* c)
     drfe_match_buffers_free(c);
     drfe_planes_free(c);
     drfe_bow_free(c);
+    drfe_lines_free(c);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
                     c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_desc,
                     c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_match,
@@ -119,6 +121,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->mb = nullptr;
     c->ps = nullptr;
     c->bow = nullptr;
+    c->ls = nullptr;
     std::memset(&c->cam, 0, sizeof(c->cam));
     std::memset(&c->geom, 0, sizeof(c->geom));
     std::memset(c->ev, 0, sizeof(c->ev));

@@ -120,6 +120,7 @@ struct drfe_ctx {
     struct MatchBuffers* mb;  /* lazily allocated matcher scratch (match_internal.h) */
     struct PlanesScratch* ps; /* lazily allocated plane-path scratch (planes_internal.h) */
     struct BowState* bow;     /* vocabulary + BoW scratch (bow_internal.h), set by drfe_voc_upload */
+    struct LinesScratch* ls;  /* line-path scratch (lines_internal.h) */
 
     /* profiling */
     bool profile;

@@ -1,0 +1,20 @@
+/* lines_internal.h — scratch of the line-feature path */
+#ifndef DRFE_LINES_INTERNAL_H
+#define DRFE_LINES_INTERNAL_H
+#include "drfe_internal.h"
+
+struct LineTaps { int n; int t[9]; };   /* 8.8 fixed-point Gaussian taps */
+
+struct LinesScratch {
+    int w, h, sw, sh;               /* input and 0.8-scaled sizes */
+    uint8_t* d_img; uint8_t* d_blur; uint8_t* d_scaled;
+    uint16_t* d_tmp16;
+    double* d_modgrad; double* d_angles;
+    unsigned long long* d_maxGrad;
+    int16_t* d_gx; int16_t* d_gy;
+};
+
+hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,
+                                    LinesScratch* sc, double threshold, hipStream_t s);
+void drfe_lines_free(drfe_ctx* c);
+#endif

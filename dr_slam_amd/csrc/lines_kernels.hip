@@ -1,0 +1,126 @@
+/* lines_kernels.hip — device image passes of the line-feature path.
+ *
+ * The arithmetic of LineSegment::ExtractLineSegment (reference src/LSDextractor.cpp:12-43) lives in
+ * OpenCV 3.4 imgproc/lsd.cpp and opencv_contrib line_descriptor (not vendored; see DESIGN.md §5 for the
+ * parity status).  Its image-sized, order-free passes run here; region growing, rectangle fitting and
+ * the NFA test are sequential and stay on the host (lines_lsd.cpp):
+ *   k_gauss_h / k_gauss_v   cv::GaussianBlur CV_8U fixed-point path (8.8 taps), BORDER_REFLECT_101
+ *   k_resize_exact08        cv::resize(..., 0.8, 0.8, INTER_LINEAR_EXACT)
+ *   k_ll_angle              LineSegmentDetectorImpl::ll_angle: gradient magnitude (f64), level-line
+ *                           angle (fastAtan2 in f32, widened), running maximum of the magnitude
+ *   k_sobel3                cv::Sobel 3x3 CV_16S (dx and dy) for the LBD descriptor
+ */
+#include "drfe_internal.h"
+#include "lines_internal.h"
+#include "../../include/drfe_math.h"
+
+__device__ __forceinline__ int refl(int p, int n)
+{
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_gauss_h(const uint8_t* __restrict__ src, int w, int h, LineTaps taps,
+                                                 uint16_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* row = src + (size_t)y * w;
+    uint32_t acc = 0;
+    const int r = taps.n / 2;
+    for (int k = 0; k < taps.n; k++) acc += (uint32_t)taps.t[k] * row[refl(x + k - r, w)];
+    dst[(size_t)y * w + x] = (uint16_t)min(acc, 65535u);
+}
+
+__global__ __launch_bounds__(256) void k_gauss_v(const uint16_t* __restrict__ src, int w, int h, LineTaps taps,
+                                                 uint8_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    uint32_t acc = 0;
+    const int r = taps.n / 2;
+    for (int k = 0; k < taps.n; k++) acc += (uint32_t)taps.t[k] * src[(size_t)refl(y + k - r, h) * w + x];
+    dst[(size_t)y * w + x] = (uint8_t)min(255u, (acc + 32768u) >> 16);
+}
+
+/* source position (d + 0.5) * 1.25 - 0.5: offset = floor, 8.8 weight of the next sample = frac * 256
+ * (exactly 32, 96, 160 or 224 for this ratio) */
+__device__ __forceinline__ void exact_tap(int d, int srcN, int* o, int* c1)
+{
+    const double v = (d + 0.5) * (1.0 / 0.8) - 0.5;
+    int oo = (int)floor(v);
+    int cc = (int)rint((v - oo) * 256.0);
+    if (oo < 0) { oo = 0; cc = 0; }
+    if (oo >= srcN - 1) { oo = srcN - 1; cc = 0; }
+    *o = oo; *c1 = cc;
+}
+
+__global__ __launch_bounds__(256) void k_resize_exact08(const uint8_t* __restrict__ src, int sw, int sh,
+                                                        uint8_t* __restrict__ dst, int dw, int dh)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    int xo, xc1, yo, yc1;
+    exact_tap(dx, sw, &xo, &xc1);
+    exact_tap(dy, sh, &yo, &yc1);
+    const int xb = min(xo + 1, sw - 1), yb = min(yo + 1, sh - 1);
+    const uint32_t xc0 = 256 - xc1, yc0 = 256 - yc1;
+    const uint32_t h0 = xc0 * src[(size_t)yo * sw + xo] + (uint32_t)xc1 * src[(size_t)yo * sw + xb];
+    const uint32_t h1 = xc0 * src[(size_t)yb * sw + xo] + (uint32_t)xc1 * src[(size_t)yb * sw + xb];
+    const uint32_t acc = yc0 * h0 + (uint32_t)yc1 * h1;
+    dst[(size_t)dy * dw + dx] = (uint8_t)min(255u, (acc + 32768u) >> 16);
+}
+
+__global__ __launch_bounds__(256) void k_ll_angle(const uint8_t* __restrict__ img, int W, int H, double threshold,
+                                                  double* __restrict__ modgrad, double* __restrict__ angles,
+                                                  unsigned long long* __restrict__ maxGradBits)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t o = (size_t)y * W + x;
+    if (x == W - 1 || y == H - 1) { angles[o] = -1024.0; modgrad[o] = 0.0; return; }   /* NOTDEF border */
+    const int DA = img[o + W + 1] - img[o];
+    const int BC = img[o + 1] - img[o + W];
+    const int gx = DA + BC, gy = DA - BC;
+    const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+    modgrad[o] = norm;
+    if (norm <= threshold) angles[o] = -1024.0;
+    else {
+        angles[o] = (double)drfe_fast_atan2((float)gx, (float)(-gy)) * (3.14159265358979323846 / 180.0);
+        atomicMax(maxGradBits, (unsigned long long)__double_as_longlong(norm));   /* positive doubles order as integers */
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src, int w, int h, int16_t* __restrict__ gx,
+                                                int16_t* __restrict__ gy)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int xm = refl(x - 1, w), xp = refl(x + 1, w);
+    const uint8_t* r0 = src + (size_t)refl(y - 1, h) * w;
+    const uint8_t* r1 = src + (size_t)y * w;
+    const uint8_t* r2 = src + (size_t)refl(y + 1, h) * w;
+    const int a = r0[xm], b = r0[x], c = r0[xp], d = r1[xm], f = r1[xp], g = r2[xm], hh = r2[x], i = r2[xp];
+    gx[(size_t)y * w + x] = (int16_t)((c + 2 * f + i) - (a + 2 * d + g));
+    gy[(size_t)y * w + x] = (int16_t)((g + 2 * hh + i) - (a + 2 * b + c));
+}
+
+hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,
+                                    LinesScratch* sc, double threshold, hipStream_t s)
+{
+    const dim3 g((w + 255) / 256, h), b(256);
+    const int W = sc->sw, H = sc->sh;
+    /* LSD input: Gaussian(7x7, sigma 0.75) then exact 0.8 downscale */
+    hipLaunchKernelGGL(k_gauss_h, g, b, 0, s, d_img, w, h, lsdTaps, sc->d_tmp16);
+    hipLaunchKernelGGL(k_gauss_v, g, b, 0, s, sc->d_tmp16, w, h, lsdTaps, sc->d_blur);
+    hipLaunchKernelGGL(k_resize_exact08, dim3((W + 255) / 256, H), b, 0, s, sc->d_blur, w, h, sc->d_scaled, W, H);
+    (void)hipMemsetAsync(sc->d_maxGrad, 0, 8, s);
+    hipLaunchKernelGGL(k_ll_angle, dim3((W + 255) / 256, H), b, 0, s, sc->d_scaled, W, H, threshold, sc->d_modgrad,
+                       sc->d_angles, sc->d_maxGrad);
+    /* LBD input: Gaussian(5x5, sigma 1) then Sobel */
+    hipLaunchKernelGGL(k_gauss_h, g, b, 0, s, d_img, w, h, lbdTaps, sc->d_tmp16);
+    hipLaunchKernelGGL(k_gauss_v, g, b, 0, s, sc->d_tmp16, w, h, lbdTaps, sc->d_blur);
+    hipLaunchKernelGGL(k_sobel3, g, b, 0, s, sc->d_blur, w, h, sc->d_gx, sc->d_gy);
+    return hipGetLastError();
+}

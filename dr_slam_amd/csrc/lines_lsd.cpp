@@ -1,0 +1,556 @@
+/* lines_lsd.cpp — LineSegment::ExtractLineSegment behind drfe_lsd_extract (include/drfe.h).
+ *
+ * reference src/LSDextractor.cpp:12-43 = LSDDetector::detect (octave 0, LSD_REFINE_ADV) -> keep the 40
+ * highest-response lines -> BinaryDescriptor::compute (LBD, 256 bit) -> normalised line equation.
+ * Split: the image passes run on the device (lines_kernels.hip); this file holds the sequential
+ * parts of OpenCV's LineSegmentDetectorImpl (pseudo-ordering, region growing, rectangle fit,
+ * refinement, NFA validation), the KeyLine bookkeeping of LSDDetector::detect, the response sort and
+ * cut of the reference, and computeLBD's band accumulation + binarisation.  Parity status: unpinned
+ * (the OpenCV sources are not in the reference), see DESIGN.md §5.
+ */
+#include "drfe_internal.h"
+#include "lines_internal.h"
+#include "../../include/drfe_math.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return DRFE_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+const double kNotDef = -1024.0, kTwoPi = 2.0 * M_PI, kThreeHalfPi = 3.0 * M_PI / 2.0, kDeg2Rad = M_PI / 180.0;
+
+struct RPt { int x, y; double angle, modgrad; };
+struct OPt { int x, y, norm; };
+struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+
+/* sequential half of cv::LineSegmentDetectorImpl, fed with the device-computed gradient fields */
+class SegmentFinder {
+public:
+    SegmentFinder(int W, int H, const double* modgrad, const double* angles, double maxGrad)
+        : W_(W), H_(H), mod_(modgrad), ang_(angles), used_((size_t)W * H, 0)
+    {
+        const double binCoef = (maxGrad > 0) ? double(1024 - 1) / maxGrad : 0;
+        order_.reserve((size_t)(W - 1) * (H - 1));
+        for (int y = 0; y < H - 1; ++y)
+            for (int x = 0; x < W - 1; ++x) order_.push_back({x, y, int(mod_[(size_t)y * W + x] * binCoef)});
+        std::sort(order_.begin(), order_.end(), [](const OPt& a, const OPt& b) { return a.norm > b.norm; });
+        logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
+    }
+
+    void run(std::vector<float>& lines)
+    {
+        const double angTh = 22.5, scale = 0.8, densityTh = 0.7, logEps = 0;
+        const double prec = M_PI * angTh / 180, p = angTh / 180;
+        const size_t minReg = size_t(-logNT_ / std::log10(p));
+        std::vector<RPt> reg;
+        for (const OPt& s : order_) {
+            if (used_[(size_t)s.y * W_ + s.x] || ang_[(size_t)s.y * W_ + s.x] == kNotDef) continue;
+            double regAngle;
+            grow(s.x, s.y, reg, regAngle, prec);
+            if (reg.size() < minReg) continue;
+            RectD rec;
+            toRect(reg, regAngle, prec, p, rec);
+            if (!refine(reg, regAngle, prec, p, rec, densityTh)) continue;
+            const double logNfa = improve(rec);
+            if (logNfa <= logEps) continue;
+            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+            rec.x1 /= scale; rec.y1 /= scale; rec.x2 /= scale; rec.y2 /= scale;
+            lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1));
+            lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
+        }
+    }
+
+private:
+    int W_, H_;
+    const double *mod_, *ang_;
+    std::vector<uint8_t> used_;
+    std::vector<OPt> order_;
+    double logNT_;
+
+    static double sq(double v) { return v * v; }
+    static double dist(double x1, double y1, double x2, double y2) { return std::sqrt(sq(x2 - x1) + sq(y2 - y1)); }
+    static double diffSigned(double a, double b)
+    {
+        double d = a - b;
+        while (d <= -M_PI) d += kTwoPi;
+        while (d > M_PI) d -= kTwoPi;
+        return d;
+    }
+    bool aligned(int x, int y, double theta, double prec) const
+    {
+        if (x < 0 || y < 0 || x >= W_ || y >= H_) return false;
+        const double a = ang_[(size_t)y * W_ + x];
+        if (a == kNotDef) return false;
+        double n = theta - a;
+        if (n < 0) n = -n;
+        if (n > kThreeHalfPi) { n -= kTwoPi; if (n < 0) n = -n; }
+        return n <= prec;
+    }
+    void grow(int sx, int sy, std::vector<RPt>& reg, double& regAngle, double prec)
+    {
+        reg.clear();
+        regAngle = ang_[(size_t)sy * W_ + sx];
+        reg.push_back({sx, sy, regAngle, mod_[(size_t)sy * W_ + sx]});
+        float sumdx = float(std::cos(regAngle)), sumdy = float(std::sin(regAngle));
+        used_[(size_t)sy * W_ + sx] = 1;
+        for (size_t i = 0; i < reg.size(); i++) {
+            const int px = reg[i].x, py = reg[i].y;
+            for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H_ - 1); ++yy)
+                for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W_ - 1); ++xx) {
+                    uint8_t& u = used_[(size_t)yy * W_ + xx];
+                    if (u != 1 && aligned(xx, yy, regAngle, prec)) {
+                        const double a = ang_[(size_t)yy * W_ + xx];
+                        u = 1;
+                        reg.push_back({xx, yy, a, mod_[(size_t)yy * W_ + xx]});
+                        sumdx += std::cos(float(a));
+                        sumdy += std::sin(float(a));
+                        regAngle = drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
+                    }
+                }
+        }
+    }
+    double thetaOf(const std::vector<RPt>& reg, double x, double y, double regAngle, double prec) const
+    {
+        double Ixx = 0, Iyy = 0, Ixy = 0;
+        for (const RPt& r : reg) {
+            const double dx = double(r.x) - x, dy = double(r.y) - y;
+            Ixx += dy * dy * r.modgrad;
+            Iyy += dx * dx * r.modgrad;
+            Ixy -= dx * dy * r.modgrad;
+        }
+        const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+        double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(drfe_fast_atan2(float(lambda - Ixx), float(Ixy)))
+                                                         : double(drfe_fast_atan2(float(Ixy), float(lambda - Iyy)));
+        theta *= kDeg2Rad;
+        if (std::fabs(diffSigned(theta, regAngle)) > prec) theta += M_PI;
+        return theta;
+    }
+    void toRect(const std::vector<RPt>& reg, double regAngle, double prec, double p, RectD& rec) const
+    {
+        double x = 0, y = 0, sum = 0;
+        for (const RPt& r : reg) { x += double(r.x) * r.modgrad; y += double(r.y) * r.modgrad; sum += r.modgrad; }
+        x /= sum; y /= sum;
+        const double theta = thetaOf(reg, x, y, regAngle, prec);
+        const double dx = std::cos(theta), dy = std::sin(theta);
+        double lmin = 0, lmax = 0, wmin = 0, wmax = 0;
+        for (const RPt& r : reg) {
+            const double rx = double(r.x) - x, ry = double(r.y) - y;
+            const double l = rx * dx + ry * dy, w = -rx * dy + ry * dx;
+            if (l > lmax) lmax = l; else if (l < lmin) lmin = l;
+            if (w > wmax) wmax = w; else if (w < wmin) wmin = w;
+        }
+        rec = {x + lmin * dx, y + lmin * dy, x + lmax * dx, y + lmax * dy, wmax - wmin, x, y, theta, dx, dy, prec, p};
+        if (rec.width < 1.0) rec.width = 1.0;
+    }
+    bool shrink(std::vector<RPt>& reg, double regAngle, double prec, double p, RectD& rec, double density, double densityTh)
+    {
+        const double xc = double(reg[0].x), yc = double(reg[0].y);
+        const double r1 = sq(rec.x1 - xc) + sq(rec.y1 - yc), r2 = sq(rec.x2 - xc) + sq(rec.y2 - yc);
+        double radSq = r1 > r2 ? r1 : r2;
+        while (density < densityTh) {
+            radSq *= 0.75 * 0.75;
+            for (size_t i = 0; i < reg.size(); ++i)
+                if (sq(double(reg[i].x) - xc) + sq(double(reg[i].y) - yc) > radSq) {
+                    used_[(size_t)reg[i].y * W_ + reg[i].x] = 0;
+                    std::swap(reg[i], reg[reg.size() - 1]);
+                    reg.pop_back();
+                    --i;
+                }
+            if (reg.size() < 2) return false;
+            toRect(reg, regAngle, prec, p, rec);
+            density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        }
+        return true;
+    }
+    bool refine(std::vector<RPt>& reg, double regAngle, double prec, double p, RectD& rec, double densityTh)
+    {
+        double density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        if (density >= densityTh) return true;
+        const double xc = double(reg[0].x), yc = double(reg[0].y), angC = reg[0].angle;
+        double sum = 0, ssum = 0;
+        int n = 0;
+        for (const RPt& r : reg) {
+            used_[(size_t)r.y * W_ + r.x] = 0;
+            if (dist(xc, yc, r.x, r.y) < rec.width) {
+                const double d = diffSigned(r.angle, angC);
+                sum += d; ssum += d * d; ++n;
+            }
+        }
+        const double mean = sum / double(n);
+        const double tau = 2.0 * std::sqrt((ssum - 2.0 * mean * sum) / double(n) + mean * mean);
+        const int sx = reg[0].x, sy = reg[0].y;
+        grow(sx, sy, reg, regAngle, tau);
+        if (reg.size() < 2) return false;
+        toRect(reg, regAngle, prec, p, rec);
+        density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        if (density < densityTh) return shrink(reg, regAngle, prec, p, rec, density, densityTh);
+        return true;
+    }
+    static double logGamma(double x)
+    {
+        if (x > 15.0)
+            return 0.918938533204673 + (x - 0.5) * std::log(x) - x +
+                   0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+        static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+        double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), b = 0;
+        for (int n = 0; n < 7; ++n) { a -= std::log(x + double(n)); b += q[n] * std::pow(x, double(n)); }
+        return a + std::log(b);
+    }
+    static bool nearlyEqual(double a, double b)
+    {
+        if (a == b) return true;
+        const double aa = std::fabs(a), bb = std::fabs(b);
+        double m = aa > bb ? aa : bb;
+        if (m < DBL_MIN) m = DBL_MIN;
+        return (std::fabs(a - b) / m) <= (100.0 * DBL_EPSILON);
+    }
+    double nfa(int n, int k, double p) const
+    {
+        if (n == 0 || k == 0) return -logNT_;
+        if (n == k) return -logNT_ - double(n) * std::log10(p);
+        const double pTerm = p / (1 - p);
+        const double log1 = logGamma(double(n) + 1) - logGamma(double(k) + 1) - logGamma(double(n - k) + 1) +
+                            double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
+        double term = std::exp(log1);
+        if (nearlyEqual(term, 0)) return (k > n * p) ? -log1 / M_LN10 - logNT_ : -logNT_;
+        double tail = term;
+        for (int i = k + 1; i <= n; ++i) {
+            const double binTerm = double(n - i + 1) / double(i), mult = binTerm * pTerm;
+            term *= mult;
+            tail += term;
+            if (binTerm < 1) {
+                const double err = term * ((1 - std::pow(mult, double(n - i + 1))) / (1 - mult) - 1);
+                if (err < 0.1 * std::fabs(-std::log10(tail) - logNT_) * tail) break;
+            }
+        }
+        return -std::log10(tail) - logNT_;
+    }
+    double rectNfa(const RectD& rec) const
+    {
+        struct Corner { int x, y; bool taken; };
+        const double hw = rec.width / 2.0, dyhw = rec.dy * hw, dxhw = rec.dx * hw;
+        Corner c[4] = {{int(rec.x1 - dyhw), int(rec.y1 + dxhw), false}, {int(rec.x2 - dyhw), int(rec.y2 + dxhw), false},
+                       {int(rec.x2 + dyhw), int(rec.y2 - dxhw), false}, {int(rec.x1 + dyhw), int(rec.y1 - dxhw), false}};
+        std::sort(c, c + 4, [](const Corner& a, const Corner& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
+        Corner *lo = &c[0], *hi = &c[0];
+        for (int i = 1; i < 4; ++i) { if (lo->y > c[i].y) lo = &c[i]; if (hi->y < c[i].y) hi = &c[i]; }
+        lo->taken = true;
+        Corner *left = 0, *right = 0, *tail = 0;
+        for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!left || left->x > c[i].x) left = &c[i]; }
+        left->taken = true;
+        for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!right || right->x < c[i].x) right = &c[i]; }
+        right->taken = true;
+        for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!tail || tail->x > c[i].x) tail = &c[i]; }
+        /* integer divisions and the x-for-y comparisons below are OpenCV's (imgproc/lsd.cpp rect_nfa) */
+        const double fl = (lo->y != left->y) ? (lo->x - left->x) / (lo->y - left->y) : 0;
+        const double sl = (left->y != tail->x) ? (left->x - tail->x) / (left->y - tail->x) : 0;
+        const double fr = (lo->y != right->y) ? (lo->x - right->x) / (lo->y - right->y) : 0;
+        const double sr = (right->y != tail->x) ? (right->x - tail->x) / (right->y - tail->x) : 0;
+        double lstep = fl, rstep = fr, lx = lo->x, rx = lo->x;
+        int total = 0, alg = 0;
+        for (int y = lo->y; y <= hi->y; ++y) {
+            if (y < 0 || y >= H_) continue;
+            for (int x = int(lx); x <= int(rx); ++x) {
+                if (x < 0 || x >= W_) continue;
+                ++total;
+                if (aligned(x, y, rec.theta, rec.prec)) ++alg;
+            }
+            if (y >= left->y) lstep = sl;
+            if (y >= right->y) rstep = sr;
+            lx += lstep;
+            rx += rstep;
+        }
+        return nfa(total, alg, rec.p);
+    }
+    double improve(RectD& rec) const
+    {
+        const double delta = 0.5, d2 = delta / 2.0, logEps = 0;
+        double best = rectNfa(rec);
+        if (best > logEps) return best;
+        RectD r = rec;
+        for (int n = 0; n < 5; ++n) {
+            r.p /= 2; r.prec = r.p * M_PI;
+            const double v = rectNfa(r);
+            if (v > best) { best = v; rec = r; }
+        }
+        if (best > logEps) return best;
+        for (int mode = 0; mode < 4; mode++) {   /* width, one side, other side, finer precision */
+            r = rec;
+            for (int n = 0; n < 5; ++n) {
+                if (!((r.width - delta) >= 0.5)) continue;
+                if (mode == 0) r.width -= delta;
+                else if (mode == 1) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; r.width -= delta; }
+                else if (mode == 2) { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; r.width -= delta; }
+                else { r.p /= 2; r.prec = r.p * M_PI; }
+                const double v = rectNfa(r);
+                if (v > best) { rec = r; best = v; }
+            }
+            if (mode < 3 && best > logEps) return best;
+        }
+        return best;
+    }
+};
+
+const int kPairs[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
+                           {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
+                           {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+
+/* BinaryDescriptor::computeLBD (one line, octave 0) + binaryConversion */
+static void lbd(const int16_t* gx, const int16_t* gy, int realW, int realH, const drfe_keyline& kl, float* des, uint8_t* out)
+{
+    const int NB = 9, WB = 7;
+    static double coefL[21], coefG[63];
+    static bool ready = false;
+    if (!ready) {
+        double u = (WB * 3 - 1) / 2, sigma = (WB * 2 + 1) / 2, inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < WB * 3; i++) coefL[i] = std::exp((i - u) * (i - u) * inv);
+        u = (NB * WB - 1) / 2; sigma = u; inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < NB * WB; i++) coefG[i] = std::exp((i - u) * (i - u) * inv);
+        ready = true;
+    }
+    float acc[8][9];
+    std::memset(acc, 0, sizeof(acc));
+    const short maxX = (short)(realW - 1), maxY = (short)(realH - 1);
+    const short len = (short)kl.num_of_pixels, height = (short)(WB * NB);
+    const short halfH = (height - 1) / 2, halfW = (len - 1) / 2;
+    const float midX = (float)(0.5 * (kl.s_point_in_octave_x + kl.e_point_in_octave_x));
+    const float midY = (float)(0.5 * (kl.s_point_in_octave_y + kl.e_point_in_octave_y));
+    const float dL0 = (float)std::cos((double)kl.angle), dL1 = (float)std::sin((double)kl.angle);
+    const float dO0 = -dL1, dO1 = dL0;
+    float x0 = -dL0 * halfW + dL1 * halfH + midX;
+    float y0 = -dL1 * halfW - dL0 * halfH + midY;
+    for (short hID = 0; hID < height; hID++) {
+        float sx = x0, sy = y0, pL = 0, nL = 0, pO = 0, nO = 0;
+        for (short wID = 0; wID < len; wID++) {
+            short t = (short)std::round(sx);
+            const short xc = (t < 0) ? 0 : (t > maxX) ? maxX : t;
+            t = (short)std::round(sy);
+            const short yc = (t < 0) ? 0 : (t > maxY) ? maxY : t;
+            const short dx = gx[yc * realW + xc], dy = gy[yc * realW + xc];
+            const float gDL = dx * dL0 + dy * dL1, gDO = dx * dO0 + dy * dO1;
+            if (gDL > 0) pL += gDL; else nL -= gDL;
+            if (gDO > 0) pO += gDO; else nO -= gDO;
+            sx += dL0;
+            sy += dL1;
+        }
+        x0 -= dL1;
+        y0 += dL0;
+        const float cg = (float)coefG[hID];
+        pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
+        const float row[8] = {pL, nL, pL * pL, nL * nL, pO, nO, pO * pO, nO * nO};
+        short band = (short)(hID / WB);
+        float cl = (float)coefL[hID % WB + WB];
+        for (int q = 0; q < 8; q++) acc[q][band] += ((q & 2) ? cl * cl : cl) * row[q];
+        band--;
+        if (band >= 0) {
+            cl = (float)coefL[hID % WB + 2 * WB];
+            for (int q = 0; q < 8; q++) acc[q][band] += ((q & 2) ? cl * cl : cl) * row[q];
+        }
+        band = band + 2;
+        if (band < NB) {
+            cl = (float)coefL[hID % WB];
+            for (int q = 0; q < 8; q++) acc[q][band] += ((q & 2) ? cl * cl : cl) * row[q];
+        }
+    }
+    const float invN2 = (float)(1.0 / (WB * 2.0)), invN3 = (float)(1.0 / (WB * 3.0));
+    for (short b = 0; b < NB; b++) {
+        const float invN = (b == 0 || b == NB - 1) ? invN2 : invN3;
+        float* d = des + 8 * b;
+        float m = acc[0][b] * invN; d[0] = m; d[4] = std::sqrt(acc[2][b] * invN - m * m);
+        m = acc[1][b] * invN; d[1] = m; d[5] = std::sqrt(acc[3][b] * invN - m * m);
+        m = acc[4][b] * invN; d[2] = m; d[6] = std::sqrt(acc[6][b] * invN - m * m);
+        m = acc[5][b] * invN; d[3] = m; d[7] = std::sqrt(acc[7][b] * invN - m * m);
+    }
+    float tm = 0, ts = 0;
+    for (int b = 0; b < NB; b++) {
+        const float* d = des + 8 * b;
+        tm += d[0] * d[0]; tm += d[1] * d[1]; tm += d[2] * d[2]; tm += d[3] * d[3];
+        ts += d[4] * d[4]; ts += d[5] * d[5]; ts += d[6] * d[6]; ts += d[7] * d[7];
+    }
+    tm = 1 / std::sqrt(tm);
+    ts = 1 / std::sqrt(ts);
+    for (int b = 0; b < NB; b++) {
+        float* d = des + 8 * b;
+        d[0] *= tm; d[1] *= tm; d[2] *= tm; d[3] *= tm; d[4] *= ts; d[5] *= ts; d[6] *= ts; d[7] *= ts;
+    }
+    for (int i = 0; i < 72; i++) if (des[i] > 0.4) des[i] = (float)0.4;
+    float nrm = 0;
+    for (int i = 0; i < 72; i++) nrm += des[i] * des[i];
+    nrm = 1 / std::sqrt(nrm);
+    for (int i = 0; i < 72; i++) des[i] = des[i] * nrm;
+    for (int cb = 0; cb < 32; cb++) {
+        const float *a = des + 8 * kPairs[cb][0], *b = des + 8 * kPairs[cb][1];
+        uint8_t v = 0;
+        for (int i = 0; i < 8; i++) if (a[i] > b[i]) v += (uint8_t)(1 << i);
+        out[cb] = v;
+    }
+}
+
+static LineTaps gaussTaps(int n, double sigma)
+{
+    LineTaps t;
+    t.n = n;
+    double v[9], sum = 0;
+    const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; i++) { const double x = i - (n - 1) * 0.5; v[i] = std::exp(s2 * x * x); sum += v[i]; }
+    sum = 1.0 / sum;
+    for (int i = 0; i < 9; i++) t.t[i] = i < n ? (int)std::rint(v[i] * sum * 256.0) : 0;
+    return t;
+}
+
+} // namespace
+
+void drfe_lines_free(drfe_ctx* c)
+{
+    LinesScratch* s = c->ls;
+    if (!s) return;
+    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_maxGrad, s->d_gx, s->d_gy};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete s;
+    c->ls = nullptr;
+}
+
+static int ensure_lines(drfe_ctx* c, int w, int h)
+{
+    if (c->ls && c->ls->w == w && c->ls->h == h) return DRFE_OK;
+    drfe_lines_free(c);
+    LinesScratch* s = new (std::nothrow) LinesScratch();
+    if (!s) return DRFE_ERR_INVALID;
+    std::memset(s, 0, sizeof(*s));
+    c->ls = s;
+    s->w = w; s->h = h;
+    s->sw = (int)std::rint(w * 0.8); s->sh = (int)std::rint(h * 0.8);   /* saturate_cast<int>(size * inv_scale) */
+    const size_t n = (size_t)w * h, ns = (size_t)s->sw * s->sh;
+    HIPCHK(c, hipMalloc((void**)&s->d_img, n));
+    HIPCHK(c, hipMalloc((void**)&s->d_blur, n));
+    HIPCHK(c, hipMalloc((void**)&s->d_scaled, ns));
+    HIPCHK(c, hipMalloc((void**)&s->d_tmp16, n * 2));
+    HIPCHK(c, hipMalloc((void**)&s->d_modgrad, ns * 8));
+    HIPCHK(c, hipMalloc((void**)&s->d_angles, ns * 8));
+    HIPCHK(c, hipMalloc((void**)&s->d_maxGrad, 8));
+    HIPCHK(c, hipMalloc((void**)&s->d_gx, n * 2));
+    HIPCHK(c, hipMalloc((void**)&s->d_gy, n * 2));
+    return DRFE_OK;
+}
+
+extern "C" {
+
+int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stride, int max_lines, drfe_keyline* lines,
+                     uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected)
+{
+    if (!c || !gray || !n_lines || w < 16 || h < 16 || stride < (size_t)w || max_lines < 1) {
+        if (c) c->err = "lsd_extract: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    *n_lines = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_lines(c, w, h);
+    if (rc != DRFE_OK) return rc;
+    LinesScratch* s = c->ls;
+    /* LineSegmentDetector defaults: scale 0.8, sigma_scale 0.6 -> sigma 0.75, 7x7 kernel; quant 2, ang_th 22.5 */
+    const double sigma = 0.6 / 0.8;
+    const int hk = (int)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
+    const LineTaps lsdTaps = gaussTaps(1 + 2 * hk, sigma), lbdTaps = gaussTaps(5, 1.0);
+    const double rho = 2.0 / std::sin(M_PI * 22.5 / 180);
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpy2DAsync(s->d_img, (size_t)w, gray, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
+    HIPCHK(c, drfe_launch_lines_passes(s->d_img, w, h, lsdTaps, lbdTaps, s, rho, st));
+    const size_t ns = (size_t)s->sw * s->sh, n = (size_t)w * h;
+    std::vector<double> modgrad(ns), angles(ns);
+    std::vector<int16_t> gx(n), gy(n);
+    unsigned long long maxBits = 0;
+    HIPCHK(c, hipMemcpyAsync(modgrad.data(), s->d_modgrad, ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(angles.data(), s->d_angles, ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(gx.data(), s->d_gx, n * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(gy.data(), s->d_gy, n * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&maxBits, s->d_maxGrad, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    double maxGrad = -1;
+    if (maxBits) std::memcpy(&maxGrad, &maxBits, 8);
+
+    std::vector<float> segs;
+    SegmentFinder finder(s->sw, s->sh, modgrad.data(), angles.data(), maxGrad);
+    finder.run(segs);
+
+    /* LSDDetector::detect: KeyLine fields for octave 0 (octaveScale = 1) */
+    std::vector<drfe_keyline> kls;
+    int classCounter = -1;
+    for (size_t k = 0; k + 3 < segs.size(); k += 4) {
+        float e[4] = {segs[k], segs[k + 1], segs[k + 2], segs[k + 3]};
+        if (e[0] < 0) e[0] = 0;
+        if (e[0] >= w) e[0] = (float)w - 1.0f;
+        if (e[2] < 0) e[2] = 0;
+        if (e[2] >= w) e[2] = (float)w - 1.0f;
+        if (e[1] < 0) e[1] = 0;
+        if (e[1] >= h) e[1] = (float)h - 1.0f;
+        if (e[3] < 0) e[3] = 0;
+        if (e[3] >= h) e[3] = (float)h - 1.0f;
+        drfe_keyline kl;
+        kl.start_point_x = e[0]; kl.start_point_y = e[1]; kl.end_point_x = e[2]; kl.end_point_y = e[3];
+        kl.s_point_in_octave_x = e[0]; kl.s_point_in_octave_y = e[1]; kl.e_point_in_octave_x = e[2]; kl.e_point_in_octave_y = e[3];
+        kl.line_length = (float)std::sqrt(std::pow(e[0] - e[2], 2) + std::pow(e[1] - e[3], 2));
+        const int x0 = drfe_round_half_even(e[0]), y0 = drfe_round_half_even(e[1]);
+        const int x1 = drfe_round_half_even(e[2]), y1 = drfe_round_half_even(e[3]);
+        kl.num_of_pixels = std::max(std::abs(x1 - x0), std::abs(y1 - y0)) + 1;   /* LineIterator(...).count */
+        kl.angle = (float)std::atan2((double)(e[3] - e[1]), (double)(e[2] - e[0]));
+        kl.class_id = ++classCounter;
+        kl.octave = 0;
+        kl.size = (e[2] - e[0]) * (e[3] - e[1]);
+        kl.response = kl.line_length / std::max(w, h);
+        kl.pt_x = (e[2] + e[0]) / 2; kl.pt_y = (e[3] + e[1]) / 2;
+        kls.push_back(kl);
+    }
+    if (n_detected) *n_detected = (int)kls.size();
+    if ((int)kls.size() > max_lines) {   /* src/LSDextractor.cpp:23-28 */
+        std::sort(kls.begin(), kls.end(), [](const drfe_keyline& a, const drfe_keyline& b) { return a.response > b.response; });
+        kls.resize(max_lines);
+        for (int i = 0; i < max_lines; i++) kls[i].class_id = i;
+    }
+    const int nl = (int)kls.size();
+    *n_lines = nl;
+    if (nl > cap) { c->err = "lsd_extract: line buffer too small"; return DRFE_ERR_CAPACITY; }
+    float des[72];
+    for (int i = 0; i < nl; i++) {
+        if (lines) lines[i] = kls[i];
+        uint8_t bits[32];
+        lbd(gx.data(), gy.data(), w, h, kls[i], des, bits);
+        if (ldesc) std::memcpy(ldesc + (size_t)i * 32, bits, 32);
+        if (line_f) {   /* normalised cross product of the homogeneous end points, :32-42 */
+            const double sx = kls[i].start_point_x, sy = kls[i].start_point_y, ex = kls[i].end_point_x, ey = kls[i].end_point_y;
+            const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
+            const double nrm = std::sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+            line_f[3 * i] = l0 / nrm; line_f[3 * i + 1] = l1 / nrm; line_f[3 * i + 2] = l2 / nrm;
+        }
+    }
+    return DRFE_OK;
+}
+
+/* parity taps of the device passes (tests) */
+int drfe_lsd_stages(drfe_ctx* c, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy, int* sw, int* sh)
+{
+    if (!c || !c->ls) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    LinesScratch* s = c->ls;
+    if (sw) *sw = s->sw;
+    if (sh) *sh = s->sh;
+    const size_t ns = (size_t)s->sw * s->sh, n = (size_t)s->w * s->h;
+    if (scaled) HIPCHK(c, hipMemcpy(scaled, s->d_scaled, ns, hipMemcpyDeviceToHost));
+    if (modgrad) HIPCHK(c, hipMemcpy(modgrad, s->d_modgrad, ns * 8, hipMemcpyDeviceToHost));
+    if (angles) HIPCHK(c, hipMemcpy(angles, s->d_angles, ns * 8, hipMemcpyDeviceToHost));
+    if (gx) HIPCHK(c, hipMemcpy(gx, s->d_gx, n * 2, hipMemcpyDeviceToHost));
+    if (gy) HIPCHK(c, hipMemcpy(gy, s->d_gy, n * 2, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+} /* extern "C" */

@@ -33,8 +33,14 @@ SYMBOLS = (
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
-    "drfe_search_by_bow",
+    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages",
 )
+
+KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"),
+                          ("response", "<f4"), ("size", "<f4"), ("start_point_x", "<f4"), ("start_point_y", "<f4"),
+                          ("end_point_x", "<f4"), ("end_point_y", "<f4"), ("s_point_in_octave_x", "<f4"),
+                          ("s_point_in_octave_y", "<f4"), ("e_point_in_octave_x", "<f4"), ("e_point_in_octave_y", "<f4"),
+                          ("line_length", "<f4"), ("num_of_pixels", "<i4")])
 
 CAPE_PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("mean", "<f8", (3,)), ("d", "<f8"), ("mse", "<f4"),
                              ("score", "<f4"), ("n_points", "<i4"), ("pad", "<i4")])
@@ -103,6 +109,8 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_lsd_extract.argtypes = [vp, vp, i32, i32, sz, i32, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.drfe_lsd_stages.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_voc_upload.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.drfe_bow_transform_batch.argtypes = [vp, i32, i32, vp]
     L.drfe_bow_download.argtypes = [vp, i32, vp, vp, vp, i32]
@@ -290,6 +298,30 @@ class Context:
         dist = np.zeros((len(Q), k), np.int32)
         self._chk(self.L.drfe_match_bf_knn(self.h, _p(Q), len(Q), _p(T), len(T), k, _p(idx), _p(dist)), "drfe_match_bf_knn")
         return idx, dist
+
+    # --- lines -------------------------------------------------------------------------------------
+    def lsd_extract(self, gray: np.ndarray, max_lines=40, stages=False):
+        """LineSegment::ExtractLineSegment -> dict(lines, desc, lineF, detected[, stage images])."""
+        g = np.ascontiguousarray(gray, np.uint8)
+        h, w = g.shape
+        cap = max_lines
+        lines = np.zeros(cap, KEYLINE_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        lf = np.zeros((cap, 3))
+        n, nd = C.c_int(), C.c_int()
+        self._chk(self.L.drfe_lsd_extract(self.h, _p(g), w, h, w, max_lines, _p(lines), _p(desc), _p(lf), cap,
+                                          C.byref(n), C.byref(nd)), "drfe_lsd_extract")
+        out = dict(lines=lines[:n.value].copy(), desc=desc[:n.value].copy(), lineF=lf[:n.value].copy(), detected=nd.value)
+        if stages:
+            sw, sh = C.c_int(), C.c_int()
+            self._chk(self.L.drfe_lsd_stages(self.h, None, None, None, None, None, C.byref(sw), C.byref(sh)), "lsd_stages")
+            scaled = np.zeros((sh.value, sw.value), np.uint8)
+            modgrad, angles = np.zeros((sh.value, sw.value)), np.zeros((sh.value, sw.value))
+            gx, gy = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+            self._chk(self.L.drfe_lsd_stages(self.h, _p(scaled), _p(modgrad), _p(angles), _p(gx), _p(gy), C.byref(sw),
+                                             C.byref(sh)), "lsd_stages")
+            out.update(scaled=scaled, modgrad=modgrad, angles=angles, gx=gx, gy=gy)
+        return out
 
     # --- bag of words ------------------------------------------------------------------------------
     def voc_upload(self, k, L, scoring, weighting, parent, desc, weight, is_leaf):

@@ -179,6 +179,32 @@ int drfe_match_bf_knn(drfe_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t,
                       int32_t* dist);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* LineSegment (replaces src/LSDextractor.cpp: LSDDetector::detect + BinaryDescriptor::compute)      */
+
+/* cv::line_descriptor::KeyLine fields (angle, class_id, octave, pt, response, size, start/end point,
+ * start/end point in octave, lineLength, numOfPixels). */
+typedef struct drfe_keyline {
+    float angle;
+    int32_t class_id, octave;
+    float pt_x, pt_y, response, size;
+    float start_point_x, start_point_y, end_point_x, end_point_y;
+    float s_point_in_octave_x, s_point_in_octave_y, e_point_in_octave_x, e_point_in_octave_y;
+    float line_length;
+    int32_t num_of_pixels;
+} drfe_keyline;
+
+/* LineSegment::ExtractLineSegment(img, keylines, ldesc, keylineFunctions, scale = 1.2f, numOctaves = 1),
+ * src/LSDextractor.cpp:12-43.  gray: host CV_8UC1.  max_lines = lsdNFeatures (40).  Outputs: up to
+ * max_lines key lines (the highest-response ones, class_id renumbered, :23-28), ldesc = NL x 32 LBD
+ * bytes, line_f = NL x 3 normalised line equations; *n_detected = lines found before the cut. */
+int drfe_lsd_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t stride, int max_lines,
+                     drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected);
+/* Parity taps of the device image passes of the last drfe_lsd_extract call (any pointer may be NULL):
+ * 0.8-scaled image, gradient magnitude and level-line angle (sw x sh), Sobel dx/dy of the LBD image. */
+int drfe_lsd_stages(drfe_ctx* ctx, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy,
+                    int* sw, int* sh);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */
 

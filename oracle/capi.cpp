@@ -4,6 +4,7 @@
 #include "ahc_oracle.h"
 #include "cape_oracle.h"
 #include "bow_oracle.h"
+#include "lsd_oracle.h"
 #include "../include/drfe_math.h"
 
 #include <chrono>
@@ -346,6 +347,43 @@ int orc_search_by_bow(const int32_t* nidKF, int nKF, const int32_t* nidF, int nF
     for (int i = 0; i < nKF; i++) if (nidKF[i] >= 0) fvKF[nidKF[i]].push_back((unsigned)i);
     for (int i = 0; i < nF; i++) if (nidF[i] >= 0) fvF[nidF[i]].push_back((unsigned)i);
     return search_by_bow(fvKF, fvF, descKF, angleKF, kfMP, descF, angleF, nF, nnratio, checkOri != 0, out);
+}
+
+/* LSD + LBD lines */
+struct LineHandle { LineResult r; LsdStages st; };
+void* orc_lines_run(const uint8_t* img, int w, int h, int maxLines)
+{
+    LineHandle* H = new LineHandle();
+    try { H->r = extract_lines(img, w, h, maxLines, &H->st); }
+    catch (const std::exception& e) { g_err = e.what(); delete H; return nullptr; }
+    return H;
+}
+void orc_lines_free(void* h) { delete (LineHandle*)h; }
+void orc_lines_info(void* h, int32_t* out4)
+{
+    LineHandle* H = (LineHandle*)h;
+    out4[0] = (int)H->r.lines.size(); out4[1] = H->r.detected; out4[2] = H->st.sw; out4[3] = H->st.sh;
+}
+int orc_sizeof_keyline() { return (int)sizeof(KeyLine); }
+void orc_lines_get(void* h, KeyLine* kl, uint8_t* desc, float* descf, double* lineF)
+{
+    LineHandle* H = (LineHandle*)h;
+    const size_t n = H->r.lines.size();
+    if (n) {
+        std::memcpy(kl, H->r.lines.data(), n * sizeof(KeyLine));
+        std::memcpy(desc, H->r.desc.data(), n * 32);
+        std::memcpy(descf, H->r.descf.data(), n * 72 * sizeof(float));
+        std::memcpy(lineF, H->r.lineF.data(), n * 3 * sizeof(double));
+    }
+}
+void orc_lines_get_stages(void* h, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy)
+{
+    LineHandle* H = (LineHandle*)h;
+    if (scaled) std::memcpy(scaled, H->st.scaled.data(), H->st.scaled.size());
+    if (modgrad) std::memcpy(modgrad, H->st.modgrad.data(), H->st.modgrad.size() * 8);
+    if (angles) std::memcpy(angles, H->st.angles.data(), H->st.angles.size() * 8);
+    if (gx && !H->st.gx.empty()) std::memcpy(gx, H->st.gx.data(), H->st.gx.size() * 2);
+    if (gy && !H->st.gy.empty()) std::memcpy(gy, H->st.gy.data(), H->st.gy.size() * 2);
 }
 
 int orc_sizeof_keypoint() { return (int)sizeof(KeyPoint); }

@@ -362,6 +362,51 @@ def ahc_planes(depth16, K4, depthfactor):
                 block_valid=vn[:, 0], block_N=vn[:, 1])
 
 
+KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("ptX", "<f4"), ("ptY", "<f4"),
+                          ("response", "<f4"), ("size", "<f4"), ("startPointX", "<f4"), ("startPointY", "<f4"),
+                          ("endPointX", "<f4"), ("endPointY", "<f4"), ("sPointInOctaveX", "<f4"),
+                          ("sPointInOctaveY", "<f4"), ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                          ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+
+
+def extract_lines(gray, max_lines=40, stages=False):
+    """LineSegment::ExtractLineSegment (reference src/LSDextractor.cpp:12-43): LSD detect, keep the 40
+    highest-response lines, LBD descriptors, normalised line equations.
+    Returns dict(lines (KEYLINE_DTYPE), desc [n,32], descf [n,72], lineF [n,3], detected[, stage images])."""
+    g = _c(gray, np.uint8)
+    h, w = g.shape
+    L = lib()
+    L.orc_lines_run.restype = C.c_void_p
+    L.orc_lines_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_lines_free.argtypes = [C.c_void_p]
+    L.orc_lines_info.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_lines_get.argtypes = [C.c_void_p] * 5
+    L.orc_lines_get_stages.argtypes = [C.c_void_p] * 6
+    assert L.orc_sizeof_keyline() == KEYLINE_DTYPE.itemsize
+    H = L.orc_lines_run(_p(g), w, h, max_lines)
+    if not H:
+        raise RuntimeError(L.orc_last_error().decode())
+    try:
+        info = np.zeros(4, np.int32)
+        L.orc_lines_info(H, _p(info))
+        n, detected, sw, sh = (int(v) for v in info)
+        kl = np.zeros(n, KEYLINE_DTYPE)
+        desc = np.zeros((n, 32), np.uint8)
+        descf = np.zeros((n, 72), np.float32)
+        lineF = np.zeros((n, 3))
+        L.orc_lines_get(H, _p(kl), _p(desc), _p(descf), _p(lineF))
+        out = dict(lines=kl, desc=desc, descf=descf, lineF=lineF, detected=detected)
+        if stages:
+            scaled = np.zeros((sh, sw), np.uint8)
+            modgrad, angles = np.zeros((sh, sw)), np.zeros((sh, sw))
+            gx, gy = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+            L.orc_lines_get_stages(H, _p(scaled), _p(modgrad), _p(angles), _p(gx), _p(gy))
+            out.update(scaled=scaled, modgrad=modgrad, angles=angles, gx=gx, gy=gy)
+    finally:
+        L.orc_lines_free(H)
+    return out
+
+
 class VocabularyOracle:
     """DBoW2 TemplatedVocabulary<FORB>: text loader + transform (reference Thirdparty/DBoW2)."""
 
