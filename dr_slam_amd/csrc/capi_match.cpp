@@ -322,6 +322,57 @@ int drfe_match_orb_points(drfe_ctx* c, int cur_slot, int last_slot, const int32_
     return DRFE_OK;
 }
 
+/* 1.4826 * median absolute deviation of the NN1 distance and of the NN2-NN1 gap (Frame::lineDescriptorMAD,
+ * reference src/Frame.cc:560-584); DMatch::distance is float, the medians are widened to double. */
+static void line_mad(const int32_t* dist, int nq, double* nnMad, double* nn12Mad)
+{
+    std::vector<float> d0(nq), gap(nq), s(nq);
+    for (int i = 0; i < nq; i++) { d0[i] = (float)dist[2 * i]; gap[i] = (float)dist[2 * i + 1] - (float)dist[2 * i]; }
+    s = d0;
+    std::nth_element(s.begin(), s.begin() + nq / 2, s.end());
+    const double med = s[nq / 2];
+    for (int i = 0; i < nq; i++) s[i] = std::fabs((float)(d0[i] - med));
+    std::nth_element(s.begin(), s.begin() + nq / 2, s.end());
+    *nnMad = 1.4826 * s[nq / 2];
+    s = gap;
+    std::nth_element(s.begin(), s.begin() + nq / 2, s.end(), [](float a, float b) { return a > b; });
+    const double med12 = s[nq / 2];
+    for (int i = 0; i < nq; i++) s[i] = std::fabs((float)(gap[i] - med12));
+    std::nth_element(s.begin(), s.begin() + nq / 2, s.end());
+    *nn12Mad = 1.4826 * s[nq / 2];
+}
+
+int drfe_lsd_search_by_descriptor(drfe_ctx* c, const uint8_t* desc_q, int n_q, const uint8_t* desc_t, int n_t,
+                                  const uint8_t* has_line, int mode, int32_t* out, int* nmatches)
+{
+    if (!c || !desc_q || !desc_t || !out || !nmatches || n_q < 0 || n_t < 0 || mode < 0 || mode > 1) return DRFE_ERR_INVALID;
+    *nmatches = 0;
+    const int n_out = mode == 0 ? n_t : n_q;
+    for (int i = 0; i < n_out; i++) out[i] = -1;
+    if (n_q == 0 || n_t < 2) return DRFE_OK;     /* knnMatch(k=2) needs two train rows */
+    std::vector<int32_t> idx((size_t)n_q * 2), dist((size_t)n_q * 2);
+    int rc = drfe_match_bf_knn(c, desc_q, n_q, desc_t, n_t, 2, idx.data(), dist.data());
+    if (rc != DRFE_OK) return rc;
+    double nnTh, nn12Th;
+    line_mad(dist.data(), n_q, &nnTh, &nn12Th);
+    int n = 0;
+    if (mode == 0) {          /* SearchByDescriptor(KeyFrame*, Frame&): ratio d0/d1 < 1/1.5, src/LSDmatcher.cpp:255-277 */
+        const float minRatio = 1.0f / 1.5f;
+        for (int q = 0; q < n_q; q++) {
+            const double r = (float)dist[2 * q] / (float)dist[2 * q + 1];
+            if (r < minRatio && (!has_line || has_line[q])) { out[idx[2 * q]] = q; n++; }
+        }
+    } else {                  /* (KeyFrame*, KeyFrame*) / SerachForInitialize: gap > MAD12/2, :225-238, :294-311 */
+        const double th = nn12Th * 0.5;
+        for (int q = 0; q < n_q; q++) {
+            const double gap = (float)dist[2 * q + 1] - (float)dist[2 * q];
+            if (gap > th && (!has_line || has_line[idx[2 * q]])) { out[q] = idx[2 * q]; n++; }
+        }
+    }
+    *nmatches = n;
+    return DRFE_OK;
+}
+
 int drfe_match_bf_knn(drfe_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, int32_t* dist)
 {
     if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || k < 1 || k > 2) return DRFE_ERR_INVALID;

@@ -33,7 +33,7 @@ SYMBOLS = (
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
-    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages",
+    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages", "drfe_lsd_search_by_descriptor",
 )
 
 KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"),
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_lsd_search_by_descriptor.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.POINTER(i32)]
     L.drfe_lsd_extract.argtypes = [vp, vp, i32, i32, sz, i32, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_lsd_stages.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_voc_upload.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
@@ -289,6 +290,16 @@ class Context:
         n = C.c_int()
         self._chk(self.L.drfe_match_orb_points(self.h, cur_slot, last_slot, _p(last_mp), _p(last_outlier), len(last_mp),
                                                _p(out), n_cur, C.byref(n)), "drfe_match_orb_points")
+        return n.value, out
+
+    def lsd_search_by_descriptor(self, desc_q, desc_t, has_line=None, mode=0):
+        dq = np.ascontiguousarray(desc_q, np.uint8)
+        dt = np.ascontiguousarray(desc_t, np.uint8)
+        has = None if has_line is None else np.ascontiguousarray(has_line, np.uint8)
+        out = np.full(len(dt) if mode == 0 else len(dq), -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_lsd_search_by_descriptor(self.h, _p(dq), len(dq), _p(dt), len(dt), _p(has), mode, _p(out),
+                                                       C.byref(n)), "drfe_lsd_search_by_descriptor")
         return n.value, out
 
     def bf_knn(self, Q, T, k):

@@ -173,6 +173,17 @@ int drfe_search_by_projection_map(drfe_ctx* ctx, int slot, const drfe_tracked_po
 int drfe_match_orb_points(drfe_ctx* ctx, int cur_slot, int last_slot, const int32_t* last_mp,
                           const uint8_t* last_outlier, int n_last, int32_t* cur_mp, int n_cur, int* n_pairs);
 
+/* LSDmatcher descriptor matching (src/LSDmatcher.cpp): BFMatcher::knnMatch(k=2) of LBD descriptors on the
+ * device + Frame::lineDescriptorMAD (src/Frame.cc:560-584) + the accept rule.
+ *   mode 0  SearchByDescriptor(KeyFrame*, Frame&, ...), :242-279: query = keyframe lines, train = frame
+ *           lines, accept d0/d1 < 1/1.5 when the keyframe line has a MapLine (has_line[q]);
+ *           out[train idx] = query idx (later queries overwrite earlier ones), out has n_t entries.
+ *   mode 1  SearchByDescriptor(KeyFrame*, KeyFrame*, ...), :281-314 and SerachForInitialize, :213-240:
+ *           accept when d1 - d0 > 0.5 * MAD of that gap and has_line[train idx] (NULL = all);
+ *           out[query idx] = train idx, out has n_q entries. */
+int drfe_lsd_search_by_descriptor(drfe_ctx* ctx, const uint8_t* desc_q, int n_q, const uint8_t* desc_t, int n_t,
+                                  const uint8_t* has_line, int mode, int32_t* out, int* nmatches);
+
 /* cv::BFMatcher(NORM_HAMMING).match / knnMatch(k<=2) on 256-bit descriptors (src/ORBmatcher.cc:1346,
  * src/LSDmatcher.cpp:222,254): ascending distance, ties -> lower train index. idx/dist: nq x k. */
 int drfe_match_bf_knn(drfe_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx,

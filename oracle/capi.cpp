@@ -386,6 +386,17 @@ void orc_lines_get_stages(void* h, uint8_t* scaled, double* modgrad, double* ang
     if (gy && !H->st.gy.empty()) std::memcpy(gy, H->st.gy.data(), H->st.gy.size() * 2);
 }
 
+/* LSDmatcher */
+void orc_line_descriptor_mad(const int32_t* dist, int nq, double* out2) { line_descriptor_mad(dist, nq, out2[0], out2[1]); }
+int orc_lsd_search_by_descriptor(const uint8_t* dk, int nk, const uint8_t* has, const uint8_t* df, int nf, int32_t* out)
+{
+    return lsd_search_by_descriptor(dk, nk, has, df, nf, out);
+}
+int orc_lsd_search_by_gap(const uint8_t* dq, int nq, const uint8_t* dt, int nt, const uint8_t* has, int32_t* out)
+{
+    return lsd_search_by_gap(dq, nq, dt, nt, has, out);
+}
+
 int orc_sizeof_keypoint() { return (int)sizeof(KeyPoint); }
 int orc_sizeof_mappointrec() { return (int)sizeof(MapPointRec); }
 int orc_sizeof_trackedpointrec() { return (int)sizeof(TrackedPointRec); }

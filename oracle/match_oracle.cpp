@@ -263,4 +263,64 @@ int match_orb_points(const uint8_t* curDesc, int curN, const uint8_t* lastDesc, 
     return NPair;
 }
 
+/* Frame::lineDescriptorMAD, src/Frame.cc:560-584: 1.4826 * median absolute deviation of the NN distance
+ * and of the NN2-NN1 gap.  dist: nq x 2 knn distances (DMatch::distance is float). */
+void line_descriptor_mad(const int32_t* dist, int nq, double& nn_mad, double& nn12_mad)
+{
+    std::vector<float> d0(nq), gap(nq);
+    for (int i = 0; i < nq; i++) { d0[i] = (float)dist[2 * i]; gap[i] = (float)dist[2 * i + 1] - (float)dist[2 * i]; }
+    std::vector<float> s = d0;
+    std::sort(s.begin(), s.end());
+    const double nn_median = s[nq / 2];
+    for (int i = 0; i < nq; i++) s[i] = std::fabs((float)(d0[i] - nn_median));   /* fabsf(float - double) */
+    std::sort(s.begin(), s.end());
+    nn_mad = 1.4826 * s[nq / 2];
+    std::vector<float> g = gap;
+    std::sort(g.begin(), g.end(), [](float a, float b) { return a > b; });
+    const double nn12_median = g[nq / 2];
+    for (int i = 0; i < nq; i++) s[i] = std::fabs((float)(gap[i] - nn12_median));
+    std::sort(s.begin(), s.end());
+    nn12_mad = 1.4826 * s[nq / 2];
+}
+
+/* LSDmatcher::SearchByDescriptor(KeyFrame*, Frame&, vpMapLineMatches), src/LSDmatcher.cpp:242-279:
+ * knnMatch(k=2) KF lines -> frame lines, accept d0/d1 < 1/1.5, later queries overwrite earlier ones.
+ * out[tdx] = KF line index or -1. */
+int lsd_search_by_descriptor(const uint8_t* descKF, int nKF, const uint8_t* kfHasLine, const uint8_t* descF, int nF,
+                             int32_t* out)
+{
+    for (int i = 0; i < nF; i++) out[i] = -1;
+    if (nKF == 0 || nF < 2) return 0;
+    std::vector<int32_t> idx((size_t)nKF * 2), dist((size_t)nKF * 2);
+    bf_knn_hamming(descKF, nKF, descF, nF, 2, idx.data(), dist.data());
+    double nn_th, nn12_th;
+    line_descriptor_mad(dist.data(), nKF, nn_th, nn12_th);   /* computed and unused by this overload */
+    const float minRatio = 1.0f / 1.5f;
+    int nmatches = 0;
+    for (int q = 0; q < nKF; q++) {
+        const double r = (float)dist[2 * q] / (float)dist[2 * q + 1];
+        if (r < minRatio && kfHasLine[q]) { out[idx[2 * q]] = q; nmatches++; }
+    }
+    return nmatches;
+}
+
+/* LSDmatcher::SearchByDescriptor(KeyFrame*, KeyFrame*, ...), :281-314, and SerachForInitialize, :213-240:
+ * accept when the NN2-NN1 gap exceeds half its MAD.  out[qdx] = train index or -1. */
+int lsd_search_by_gap(const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, const uint8_t* trainHasLine, int32_t* out)
+{
+    for (int i = 0; i < nQ; i++) out[i] = -1;
+    if (nQ == 0 || nT < 2) return 0;
+    std::vector<int32_t> idx((size_t)nQ * 2), dist((size_t)nQ * 2);
+    bf_knn_hamming(descQ, nQ, descT, nT, 2, idx.data(), dist.data());
+    double nn_th, nn12_th;
+    line_descriptor_mad(dist.data(), nQ, nn_th, nn12_th);
+    nn12_th = nn12_th * 0.5;
+    int nmatches = 0;
+    for (int q = 0; q < nQ; q++) {
+        const double gap = (float)dist[2 * q + 1] - (float)dist[2 * q];
+        if (gap > nn12_th && (!trainHasLine || trainHasLine[idx[2 * q]])) { out[q] = idx[2 * q]; nmatches++; }
+    }
+    return nmatches;
+}
+
 } // namespace orc

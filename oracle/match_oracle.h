@@ -48,6 +48,10 @@ int search_by_projection_map(const Frame& F, const TrackedPointRec* mps, int M, 
 void bf_knn_hamming(const uint8_t* Q, int nq, const uint8_t* T, int nt, int k, int32_t* idx, int32_t* dist);
 int match_orb_points(const uint8_t* curDesc, int curN, const uint8_t* lastDesc, int lastN, const int32_t* lastMP,
                      const uint8_t* lastOutlier, int32_t* curMP);
+void line_descriptor_mad(const int32_t* dist, int nq, double& nn_mad, double& nn12_mad);
+int lsd_search_by_descriptor(const uint8_t* descKF, int nKF, const uint8_t* kfHasLine, const uint8_t* descF, int nF,
+                             int32_t* out);
+int lsd_search_by_gap(const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, const uint8_t* trainHasLine, int32_t* out);
 
 } // namespace orc
 #endif

@@ -314,6 +314,27 @@ def bf_knn(Q, T, k):
     return idx, dist
 
 
+def lsd_search_by_descriptor(desc_kf, kf_has_line, desc_f):
+    """LSDmatcher::SearchByDescriptor(pKF, currentF, matches): out[frame line] = KF line or -1."""
+    dk, df = _c(desc_kf, np.uint8), _c(desc_f, np.uint8)
+    out = np.full(len(df), -1, np.int32)
+    L = lib()
+    L.orc_lsd_search_by_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    n = L.orc_lsd_search_by_descriptor(_p(dk), len(dk), _p(_c(kf_has_line, np.uint8)), _p(df), len(df), _p(out))
+    return n, out
+
+
+def lsd_search_by_gap(desc_q, desc_t, train_has_line=None):
+    """LSDmatcher::SearchByDescriptor(pKF, pKF2, ...) / SerachForInitialize: out[query line] = train line or -1."""
+    dq, dt = _c(desc_q, np.uint8), _c(desc_t, np.uint8)
+    out = np.full(len(dq), -1, np.int32)
+    L = lib()
+    L.orc_lsd_search_by_gap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    has = None if train_has_line is None else _c(train_has_line, np.uint8)
+    n = L.orc_lsd_search_by_gap(_p(dq), len(dq), _p(dt), len(dt), _p(has), _p(out))
+    return n, out
+
+
 def match_orb_points(cur_desc, last_desc, last_mp, last_outlier):
     cd, ld = _c(cur_desc, np.uint8), _c(last_desc, np.uint8)
     out = np.full(len(cd), -1, np.int32)

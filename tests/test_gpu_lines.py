@@ -47,6 +47,24 @@ def test_lines_bit_exact(ctx, oracle_mod, seed, kind):
     assert (np.unpackbits(a["desc"], axis=1).sum(1) > 20).all()
 
 
+def test_lsd_matcher(ctx, oracle_mod, frames_room):
+    """LSDmatcher::SearchByDescriptor(KF, Frame) (ratio rule) and the KF-KF / initialisation variant
+    (MAD-gap rule) on the LBD descriptors of two consecutive frames."""
+    a = ctx.lsd_extract(frames_room[0][0])
+    b = ctx.lsd_extract(frames_room[1][0])
+    rng = np.random.default_rng(2)
+    has = (rng.random(len(a["desc"])) > 0.2).astype(np.uint8)
+    n_o, m_o = oracle_mod.lsd_search_by_descriptor(a["desc"], has, b["desc"])
+    n_g, m_g = ctx.lsd_search_by_descriptor(a["desc"], b["desc"], has, mode=0)
+    assert n_g == n_o and np.array_equal(m_g, m_o) and n_o >= 5
+    has_t = (rng.random(len(b["desc"])) > 0.2).astype(np.uint8)
+    n_o, m_o = oracle_mod.lsd_search_by_gap(a["desc"], b["desc"], has_t)
+    n_g, m_g = ctx.lsd_search_by_descriptor(a["desc"], b["desc"], has_t, mode=1)
+    assert n_g == n_o and np.array_equal(m_g, m_o) and n_o >= 5
+    n_g, m_g = ctx.lsd_search_by_descriptor(a["desc"], b["desc"][:1], None, mode=0)     # knn k=2 needs 2 train rows
+    assert n_g == 0 and (m_g == -1).all()
+
+
 def test_flat_image_has_no_lines(ctx, oracle_mod):
     g = np.full((480, 640), 99, np.uint8)
     a = ctx.lsd_extract(g)
