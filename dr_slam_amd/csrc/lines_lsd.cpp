@@ -239,10 +239,12 @@ private:
     }
     double rectNfa(const RectD& rec) const
     {
-        struct Corner { int x, y; bool taken; };
+        struct Corner { double x, y; bool taken; };   /* integer-valued corners stored as doubles (cv::Point2d) */
         const double hw = rec.width / 2.0, dyhw = rec.dy * hw, dxhw = rec.dx * hw;
-        Corner c[4] = {{int(rec.x1 - dyhw), int(rec.y1 + dxhw), false}, {int(rec.x2 - dyhw), int(rec.y2 + dxhw), false},
-                       {int(rec.x2 + dyhw), int(rec.y2 - dxhw), false}, {int(rec.x1 + dyhw), int(rec.y1 - dxhw), false}};
+        Corner c[4] = {{double(int(rec.x1 - dyhw)), double(int(rec.y1 + dxhw)), false},
+                       {double(int(rec.x2 - dyhw)), double(int(rec.y2 + dxhw)), false},
+                       {double(int(rec.x2 + dyhw)), double(int(rec.y2 - dxhw)), false},
+                       {double(int(rec.x1 + dyhw)), double(int(rec.y1 - dxhw)), false}};
         std::sort(c, c + 4, [](const Corner& a, const Corner& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
         Corner *lo = &c[0], *hi = &c[0];
         for (int i = 1; i < 4; ++i) { if (lo->y > c[i].y) lo = &c[i]; if (hi->y < c[i].y) hi = &c[i]; }
@@ -253,14 +255,17 @@ private:
         for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!right || right->x < c[i].x) right = &c[i]; }
         right->taken = true;
         for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!tail || tail->x > c[i].x) tail = &c[i]; }
-        /* integer divisions and the x-for-y comparisons below are OpenCV's (imgproc/lsd.cpp rect_nfa) */
+        /* edge slopes dx/dy; the guards of the second steps compare y against tail->x as OpenCV's rect_nfa
+         * does; a guard that misses would divide by zero and such a step counts as 0 */
         const double fl = (lo->y != left->y) ? (lo->x - left->x) / (lo->y - left->y) : 0;
-        const double sl = (left->y != tail->x) ? (left->x - tail->x) / (left->y - tail->x) : 0;
+        double sl = (left->y != tail->x) ? (left->x - tail->x) / (left->y - tail->y) : 0;
         const double fr = (lo->y != right->y) ? (lo->x - right->x) / (lo->y - right->y) : 0;
-        const double sr = (right->y != tail->x) ? (right->x - tail->x) / (right->y - tail->x) : 0;
+        double sr = (right->y != tail->x) ? (right->x - tail->x) / (right->y - tail->y) : 0;
+        if (!std::isfinite(sl)) sl = 0;
+        if (!std::isfinite(sr)) sr = 0;
         double lstep = fl, rstep = fr, lx = lo->x, rx = lo->x;
         int total = 0, alg = 0;
-        for (int y = lo->y; y <= hi->y; ++y) {
+        for (int y = (int)lo->y; y <= (int)hi->y; ++y) {
             if (y < 0 || y >= H_) continue;
             for (int x = int(lx); x <= int(rx); ++x) {
                 if (x < 0 || x >= W_) continue;

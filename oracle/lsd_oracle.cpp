@@ -362,14 +362,14 @@ struct Lsd {
 
     double rect_nfa(const Rect& rec) const
     {
-        struct Edge { int x, y; bool taken; };
+        struct Edge { double x, y; bool taken; };   /* cv::Point2d holding truncated integer coordinates */
         int total_pts = 0, alg_pts = 0;
         const double half_width = rec.width / 2.0, dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
         Edge e[4];
-        e[0] = {int(rec.x1 - dyhw), int(rec.y1 + dxhw), false};
-        e[1] = {int(rec.x2 - dyhw), int(rec.y2 + dxhw), false};
-        e[2] = {int(rec.x2 + dyhw), int(rec.y2 - dxhw), false};
-        e[3] = {int(rec.x1 + dyhw), int(rec.y1 - dxhw), false};
+        e[0] = {double(int(rec.x1 - dyhw)), double(int(rec.y1 + dxhw)), false};
+        e[1] = {double(int(rec.x2 - dyhw)), double(int(rec.y2 + dxhw)), false};
+        e[2] = {double(int(rec.x2 + dyhw)), double(int(rec.y2 - dxhw)), false};
+        e[3] = {double(int(rec.x1 + dyhw)), double(int(rec.y1 - dxhw)), false};
         std::sort(e, e + 4, [](const Edge& a, const Edge& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
         Edge *min_y = &e[0], *max_y = &e[0];
         for (unsigned i = 1; i < 4; ++i) {
@@ -389,14 +389,16 @@ struct Lsd {
         for (unsigned i = 0; i < 4; ++i)
             if (!e[i].taken) { if (!tailp) tailp = &e[i]; else if (tailp->x > e[i].x) tailp = &e[i]; }
         tailp->taken = true;
-        /* integer divisions and the p.x/p.y mix are in the OpenCV source */
+        /* edge slopes dx/dy; the second-step guards compare against tailp->p.x as the OpenCV source does */
         const double flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
-        const double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->x) : 0;
+        const double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->y) : 0;
         const double frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
-        const double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->x) : 0;
+        const double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->y) : 0;
         double lstep = flstep, rstep = frstep;
         double left_x = min_y->x, right_x = min_y->x;
-        const int min_iter = min_y->y, max_iter = max_y->y;
+        const int min_iter = (int)min_y->y, max_iter = (int)max_y->y;
+        /* a guard that misses (equal y, different x) would divide by zero; such a step is taken as 0 */
+        const double slstepF = std::isfinite(slstep) ? slstep : 0, srstepF = std::isfinite(srstep) ? srstep : 0;
         for (int y = min_iter; y <= max_iter; ++y) {
             if (y < 0 || y >= H) continue;
             for (int x = int(left_x); x <= int(right_x); ++x) {
@@ -404,8 +406,8 @@ struct Lsd {
                 ++total_pts;
                 if (isAligned(x, y, rec.theta, rec.prec)) ++alg_pts;
             }
-            if (y >= leftmost->y) lstep = slstep;
-            if (y >= rightmost->y) rstep = srstep;
+            if (y >= leftmost->y) lstep = slstepF;
+            if (y >= rightmost->y) rstep = srstepF;
             left_x += lstep;
             right_x += rstep;
         }

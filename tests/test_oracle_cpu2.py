@@ -1,0 +1,252 @@
+"""CPU (-m "not gpu") pins of the plane / bag-of-words / line oracles: independent numeric definitions
+(numpy eigh, plane geometry of the synthetic scenes, DBoW2 container semantics, LSD geometry on clean
+edges), structural properties and golden fixtures (tests/golden/planes_lines_bow.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "planes_lines_bow.npz")
+
+
+def _case(seed=2, kind="room_boxes", camname="TUM3"):
+    from dr_slam_amd import synth
+    cam = getattr(synth, camname)
+    g, d, T = next(synth.sequence(seed, 1, cam=cam, kind=kind))
+    return cam, g, d, np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# Eigen 3x3 solver restatement vs numpy
+
+def test_eig33sym_matches_numpy(oracle_mod):
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        A = rng.normal(size=(3, 3)) * 10 ** rng.uniform(-3, 3)
+        A = A @ A.T
+        if trial % 10 == 0:
+            A[0, 2] = A[2, 0] = 0.0          # tridiagonal input: the v1norm2 <= tol branch
+        s, V = oracle_mod.eig33sym(A)
+        w = np.linalg.eigvalsh(A)
+        assert np.all(np.diff(s) >= 0)
+        assert np.allclose(s, w, rtol=1e-9, atol=1e-12 * abs(w).max())
+        assert np.allclose(A @ V, V * s, atol=1e-9 * abs(w).max())
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-12)
+    s, V = oracle_mod.eig33sym(np.zeros((3, 3)))
+    assert (s == 0).all() and np.array_equal(V, np.eye(3))
+
+
+# ------------------------------------------------------------------------------------------------
+# AHC / CAPE on a scene whose planes are known
+
+def test_ahc_finds_the_room_planes(oracle_mod):
+    cam, g, d, K4 = _case()
+    r = oracle_mod.ahc_planes(d, K4, np.float32(1.0) / np.float32(cam.depth_factor))
+    P = r["planes"]
+    assert 5 <= len(P) <= 12
+    assert (np.diff(r["N"]) <= 0).all() and r["N"].min() >= 3000          # sorted by N, minSupport
+    n, c = P[:, 0:3], P[:, 3:6]
+    assert np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-12)
+    assert ((n * c).sum(1) <= 0).all()                                     # normals face the camera
+    assert np.abs(np.abs(n).max(1) - 1).max() < 2e-3                       # axis-aligned room (yaw 0 at frame 0)
+    # floor / ceiling at y = +-1.4 m in camera coordinates
+    horiz = np.abs(n[:, 1]) > 0.99
+    assert horiz.sum() >= 2 and np.allclose(np.abs(c[horiz, 1]), 1.4, atol=0.01)
+    assert (P[:, 6] < 1e-4).all()                                          # mse of a noise-only plane (m^2)
+    # label image and membership agree; planes beyond 5 m are absent
+    for i, m in enumerate(r["members"]):
+        assert (r["seg"].ravel()[m] == i + 1).all() and len(m) == (r["seg"] == i + 1).sum()
+    z = d.astype(np.float64) / cam.depth_factor
+    assert (r["seg"][z > 5.0] == 0).all() and (r["seg"][d == 0] == 0).all()
+    assert (r["seg"] > 0).mean() > 0.4
+
+
+def test_ahc_block_statistics_definition(oracle_mod):
+    """The nine sums of a valid 10x10 block are the row-major sequential float64 sums of its cloud points."""
+    cam, g, d, K4 = _case()
+    f = np.float32(1.0) / np.float32(cam.depth_factor)
+    r = oracle_mod.ahc_planes(d, K4, f)
+    b = int(np.nonzero(r["block_valid"])[0][7])
+    i0, j0 = (b // 64) * 10, (b % 64) * 10
+    S = np.zeros(9)
+    for i in range(i0, i0 + 10):
+        for j in range(j0, j0 + 10):
+            z = float(d[i, j]) * float(f)
+            x = (j - float(K4[2])) * z / float(K4[0])
+            y = (i - float(K4[3])) * z / float(K4[1])
+            S += np.array([x, y, z, x * x, y * y, z * z, x * y, y * z, x * z])
+    assert np.array_equal(S, r["blocks"][b, :9])
+    assert r["block_N"][b] == 100
+    # a block with a hole is rejected (INIT_STRICT)
+    hy, hx = np.nonzero(d == 0)
+    hb = (hy[0] // 10) * 64 + hx[0] // 10
+    assert r["block_valid"][hb] == 0 and r["block_N"][hb] == 0
+
+
+def test_cape_planes_and_labels(oracle_mod):
+    cam, g, d, K4 = _case(3, "living_room", "ICL")
+    dm = oracle_mod.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+    for patch in (20, 10):
+        r = oracle_mod.cape_planes(dm, K4, patch)
+        P = r["planes"]
+        assert 4 <= len(P) <= 14
+        n, m, dd = P[:, 0:3], P[:, 3:6], P[:, 6]
+        assert np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-12) and (dd > 0).all()
+        assert np.allclose((n * m).sum(1) + dd, 0, atol=1e-9)              # the mean lies on the plane
+        assert r["seg"].max() == len(P) and (r["score"] > 100).all()
+        assert len(r["cell_planar"]) == (640 // patch) * (480 // patch)
+
+
+# ------------------------------------------------------------------------------------------------
+# DBoW2 containers
+
+def test_vocabulary_text_roundtrip_and_transform(oracle_mod):
+    from dr_slam_amd import vocabulary as V
+    voc = V.make_synthetic(8, 3, seed=4, stop_fraction=0.1)
+    ov = oracle_mod.VocabularyOracle(voc.to_text())
+    parent, word, desc, weight = ov.nodes()
+    assert np.array_equal(parent[1:], voc.parent[1:]) and np.array_equal(desc[1:], voc.desc[1:])
+    assert np.array_equal(weight[1:], voc.weight[1:])
+    assert (word[voc.is_leaf > 0] == np.arange(voc.is_leaf.sum())).all()   # word ids in leaf order
+    v2 = V.Vocabulary.unpack(V.Vocabulary.from_text(voc.to_text()).pack())
+    assert np.array_equal(v2.desc, voc.desc) and np.array_equal(v2.weight, voc.weight)
+    # a leaf's own descriptor descends to that leaf when it is the unique nearest child at every level
+    rng = np.random.default_rng(0)
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    w_id, w_val, nid = ov.transform_each(q, 1)
+    leaf_nodes = np.nonzero(voc.is_leaf)[0]
+    node_of_word = leaf_nodes[w_id]
+    assert np.array_equal(voc.parent[node_of_word], nid)                   # levelsup=1 -> the leaf's parent
+    assert np.array_equal(w_val, voc.weight[node_of_word])
+    # brute force descent
+    for i in range(20):
+        node = 0
+        while True:
+            ch = np.nonzero(voc.parent[1:] == node)[0] + 1
+            if len(ch) == 0:
+                break
+            dist = [int(np.unpackbits(q[i] ^ voc.desc[c]).sum()) for c in ch]
+            node = int(ch[int(np.argmin(dist))])                            # argmin = first minimum
+        assert node == node_of_word[i]
+    ids, vals = ov.bow_vector(q, 1)
+    i2, v2b, fv = V.bow_and_feature_vectors(voc, w_id, w_val, nid)
+    assert np.array_equal(ids, i2) and np.array_equal(vals.view(np.uint64), v2b.view(np.uint64))
+    assert abs(np.abs(vals).sum() - 1.0) < 1e-12                           # L1 scoring normalises
+    with pytest.raises(RuntimeError):
+        oracle_mod.VocabularyOracle("30 3 0 0\n")                           # k > 20 rejected like DBoW2
+
+
+def test_search_by_bow_semantics(oracle_mod):
+    """Claims are per node group, ratio test is strict, TH_LOW = 50."""
+    z = np.zeros((4, 32), np.uint8)
+    f = np.zeros((3, 32), np.uint8)
+    f[1, 0] = 0b111                     # distance 3 from zero
+    f[2, :3] = 0xFF                     # distance 24
+    kf_mp = np.array([1, 1, -1, 1], np.int32)
+    nid_kf = np.array([5, 5, 5, 9], np.int32)
+    nid_f = np.array([5, 5, 9], np.int32)
+    ang = np.zeros(4, np.float32)
+    n, m = oracle_mod.search_by_bow(nid_kf, nid_f, z, ang, kf_mp, f, ang[:3], 0.9, False)
+    # KF0 takes F0 (0 < 0.9*3); KF1 sees only F1 left: best 3, second 256 -> match; KF2 has no map point;
+    # KF3 (node 9) vs F2: 24 <= 50 and 24 < 0.9*256
+    assert n == 3 and m.tolist() == [0, 1, 3]
+    f[2, :] = 0xFF                      # distance 256 > TH_LOW
+    n, m = oracle_mod.search_by_bow(nid_kf, nid_f, z, ang, kf_mp, f, ang[:3], 0.9, False)
+    assert n == 2 and m.tolist() == [0, 1, -1]
+
+
+# ------------------------------------------------------------------------------------------------
+# LSD / LBD
+
+def test_lsd_stage_definitions(oracle_mod):
+    cam, g, d, K4 = _case(5, "corridor")
+    r = oracle_mod.extract_lines(g, stages=True)
+    assert r["scaled"].shape == (384, 512)
+    # 0.8 downscale of a Gaussian-smoothed image: close to a float reference
+    import scipy.ndimage as ndi
+    blur = ndi.gaussian_filter(g.astype(np.float64), 0.75, mode="mirror", truncate=4.0)
+    ys = (np.arange(384) + 0.5) * 1.25 - 0.5
+    xs = (np.arange(512) + 0.5) * 1.25 - 0.5
+    ref = ndi.map_coordinates(blur, np.meshgrid(ys, xs, indexing="ij"), order=1, mode="nearest")
+    assert np.abs(r["scaled"].astype(np.float64) - ref).max() <= 2.0
+    # gradient magnitude / angle definitions on the scaled image
+    s = r["scaled"].astype(np.int64)
+    DA, BC = s[1:, 1:] - s[:-1, :-1], s[:-1, 1:] - s[1:, :-1]
+    gx, gy = DA + BC, DA - BC
+    assert np.array_equal(r["modgrad"][:-1, :-1], np.sqrt((gx * gx + gy * gy) / 4.0))
+    defined = r["angles"][:-1, :-1] != -1024.0
+    rho = 2.0 / np.sin(np.pi * 22.5 / 180)
+    assert np.array_equal(defined, r["modgrad"][:-1, :-1] > rho)
+    ang = np.arctan2(gx, -gy) % (2 * np.pi)
+    diff = np.abs(((r["angles"][:-1, :-1] - ang + np.pi) % (2 * np.pi)) - np.pi)
+    assert diff[defined].max() < 0.01                                      # fastAtan2 accuracy (~0.3 deg)
+    assert (r["angles"][-1] == -1024.0).all() and (r["angles"][:, -1] == -1024.0).all()
+    # Sobel of the 5x5-blurred image
+    b5 = oracle_mod  # noqa
+    assert np.abs(r["gx"]).max() <= 4 * 255 and r["gx"].dtype == np.int16
+
+
+def test_lsd_lines_on_clean_edges(oracle_mod):
+    g = np.full((480, 640), 50, np.uint8)
+    yy, xx = np.mgrid[0:480, 0:640]
+    g[(yy - 0.6 * xx) > 40] = 200                     # one oblique edge: y = 0.6 x + 40
+    r = oracle_mod.extract_lines(g)
+    assert 1 <= r["detected"] <= 4
+    k = r["lines"][int(np.argmax(r["lines"]["lineLength"]))]
+    slope = (k["endPointY"] - k["startPointY"]) / (k["endPointX"] - k["startPointX"])
+    assert abs(slope - 0.6) < 0.01 and k["lineLength"] > 400
+    assert abs(k["startPointY"] - (0.6 * k["startPointX"] + 40)) < 2.0
+    lf = r["lineF"][int(np.argmax(r["lines"]["lineLength"]))]
+    assert abs(np.linalg.norm(lf) - 1) < 1e-12
+    assert abs(lf @ np.array([k["startPointX"], k["startPointY"], 1.0])) < 1e-9
+    assert abs(k["response"] - k["lineLength"] / 640) < 1e-6
+    assert k["numOfPixels"] == max(abs(round(float(k["endPointX"])) - round(float(k["startPointX"]))),
+                                   abs(round(float(k["endPointY"])) - round(float(k["startPointY"])))) + 1
+
+
+def test_lines_are_cut_to_forty_by_response(oracle_mod):
+    cam, g, d, K4 = _case()
+    r = oracle_mod.extract_lines(g)
+    assert r["detected"] > 40 and len(r["lines"]) == 40
+    assert (r["lines"]["class_id"] == np.arange(40)).all()
+    assert (np.diff(r["lines"]["response"]) <= 0).all()
+    assert r["desc"].shape == (40, 32) and np.allclose(np.linalg.norm(r["descf"], axis=1), 1, atol=1e-5)
+    assert r["descf"].max() <= 0.4 / np.linalg.norm(np.minimum(r["descf"], 1), axis=1).min() + 1e-3
+
+
+def test_line_descriptor_mad_is_order_free(oracle_mod):
+    import ctypes as C
+    L = oracle_mod.lib()
+    L.orc_line_descriptor_mad.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(3)
+    d0 = rng.integers(0, 60, 41)
+    dist = np.stack([d0, d0 + rng.integers(0, 80, 41)], 1).astype(np.int32)
+    out = np.zeros(2)
+    L.orc_line_descriptor_mad(dist.ctypes.data_as(C.c_void_p), 41, out.ctypes.data_as(C.c_void_p))
+    s = np.sort(dist[:, 0].astype(np.float32))
+    med = float(s[20])
+    mad = 1.4826 * float(np.sort(np.abs(dist[:, 0].astype(np.float32) - np.float32(med)))[20])
+    assert out[0] == mad
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures
+
+def test_golden_planes_lines_bow(oracle_mod):
+    from dr_slam_amd import vocabulary as V
+    z = np.load(GOLD)
+    d, g, K4, f = z["depth"], z["gray"], z["K4"], np.float32(z["factor"])
+    r = oracle_mod.ahc_planes(d, K4, f)
+    assert np.array_equal(r["planes"].view(np.uint64), z["ahc_planes"].view(np.uint64))
+    assert np.array_equal(r["N"], z["ahc_N"]) and np.array_equal(r["seg"], z["ahc_seg"])
+    dm = oracle_mod.depth_to_float(d, f)
+    c = oracle_mod.cape_planes(dm, K4, 20)
+    assert np.array_equal(c["planes"].view(np.uint64), z["cape_planes"].view(np.uint64))
+    assert np.array_equal(c["seg"], z["cape_seg"])
+    ln = oracle_mod.extract_lines(g)
+    assert np.array_equal(ln["lines"].view(np.uint8), z["lines"].view(np.uint8))
+    assert np.array_equal(ln["desc"], z["ldesc"])
+    voc = V.make_synthetic(6, 3, seed=2)
+    ov = oracle_mod.VocabularyOracle(voc.to_text())
+    w, wt, nid = ov.transform_each(z["orb_desc"], 2)
+    assert np.array_equal(w, z["bow_word"]) and np.array_equal(nid, z["bow_nid"])
