@@ -103,13 +103,19 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk2(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(s16x2, lo | (hi << 16)); }
 __device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 umax2(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u16x2 umin2(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
 
 /* returns strength(A) | strength(B) << 16 */
 __device__ __forceinline__ uint32_t fast_strength2(const uint8_t* cA, const uint8_t* cB, const int P)
 {
-    const s16x2 v = pk2(cA[0], cB[0]);
+    /* cA / cB point at the top-left corner of the 7x7 patch, so every ring offset is a non-negative
+     * immediate of the LDS load */
+    const int C = 3 * P + 3;
+    const s16x2 v = pk2(cA[C], cB[C]);
     s16x2 d[16];
-#define RING(k, o) d[k] = v - pk2(cA[o], cB[o])
+#define RING(k, o) d[k] = v - pk2(cA[C + (o)], cB[C + (o)])
     RING(0, 3 * P);       RING(1, 3 * P + 1);   RING(2, 2 * P + 2);    RING(3, P + 3);
     RING(4, 3);           RING(5, -P + 3);      RING(6, -2 * P + 2);   RING(7, -3 * P + 1);
     RING(8, -3 * P);      RING(9, -3 * P - 1);  RING(10, -2 * P - 2);  RING(11, -P - 3);
@@ -137,7 +143,8 @@ __device__ __forceinline__ uint32_t fast_strength2(const uint8_t* cA, const uint
     return __builtin_bit_cast(uint32_t, r);
 }
 
-#define FAST_TILE_PITCH 64                       /* LDS bytes per window row (16 dwords) */
+#define FAST_TILE_PITCH 68                       /* LDS bytes per window row: 16 data dwords + 1 pad dword so that
+                                                    lanes two rows apart (the packed A/B pixels) hit different banks */
 #define FAST_MAX_EVAL (DRFE_FAST_MAX_WIN - 6)    /* 54 */
 #define FAST_SC_PITCH 64
 
@@ -169,44 +176,67 @@ __global__ __launch_bounds__(64) void k_fast_cells(const DevGeom* __restrict__ G
             for (int r = lane >> 4; r < wh; r += 4)
                 tile[r * (FAST_TILE_PITCH / 4) + c] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * L.pyrPitch + c * 4);
     }
-    /* zero apron of the score tile (rows 0 / eh+1, columns 0 / ew+1): NMS neighbours outside the cell */
-    if (lane < ew + 2) { sc[lane] = 0; sc[(eh + 1) * FAST_SC_PITCH + lane] = 0; }
-    if (lane < eh + 2) { sc[lane * FAST_SC_PITCH] = 0; sc[lane * FAST_SC_PITCH + ew + 1] = 0; }
+    /* score tile: pixel (x, y) of the evaluated area lives at byte (y+1)*64 + (x+4); everything else
+     * (apron rows 0 / eh+1, bytes left of 4 and right of ew+3) stays 0 = "neighbour outside the cell" */
+    for (int i = lane; i < (eh + 2) * (FAST_SC_PITCH / 16); i += 64) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile) + off;   /* tb[y*64 + x] = window pixel (x, y) */
-    const int npx = ew * eh;
-    const uint32_t magic = 0xFFFFFFFFu / (uint32_t)ew + 1u;             /* i / ew == umulhi(i, magic) for i < 2^16 */
-    {   /* score pass: item = two vertically adjacent pixels (rows 2r, 2r+1) of one column */
-        const int nrp = (eh + 1) >> 1, nitem = nrp * ew;
-        for (int i = lane; i < nitem; i += 64) {
-            const int rp = (int)__umulhi((uint32_t)i, magic), x = i - rp * ew;
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile) + off;   /* tb[y*PITCH + x] = window pixel (x, y) */
+    {   /* score pass: item = two vertically adjacent pixels (rows 2r, 2r+1) of one column; (rp, x) of item
+           lane + 64k is carried incrementally (no integer division in the loop) */
+        const int nrp = (eh + 1) >> 1;
+        const int q64 = 64 / ew, r64 = 64 - q64 * ew;
+        int rp = lane / ew, x = lane - rp * ew;
+        while (rp < nrp) {
             const int yA = 2 * rp, yB = min(2 * rp + 1, eh - 1);       /* odd eh: B repeats A, not stored */
-            const uint32_t s2 = fast_strength2(&tb[(yA + 3) * FAST_TILE_PITCH + (x + 3)],
-                                               &tb[(yB + 3) * FAST_TILE_PITCH + (x + 3)], FAST_TILE_PITCH);
-            sc[(yA + 1) * FAST_SC_PITCH + (x + 1)] = (uint8_t)(s2 & 0xFF);
-            if (2 * rp + 1 < eh) sc[(yA + 2) * FAST_SC_PITCH + (x + 1)] = (uint8_t)(s2 >> 16);
+            const uint32_t s2 = fast_strength2(&tb[__mul24(yA, FAST_TILE_PITCH) + x],
+                                               &tb[__mul24(yB, FAST_TILE_PITCH) + x], FAST_TILE_PITCH);
+            sc[(yA + 1) * FAST_SC_PITCH + (x + 4)] = (uint8_t)(s2 & 0xFF);
+            if (2 * rp + 1 < eh) sc[(yA + 2) * FAST_SC_PITCH + (x + 4)] = (uint8_t)(s2 >> 16);
+            rp += q64; x += r64;
+            if (x >= ew) { x -= ew; rp++; }
         }
     }
     __syncthreads();
-    /* strict 3x3 maximum (neighbours outside the evaluated area read 0) */
+    /* strict 3x3 maximum, four horizontally adjacent pixels per item, branch-free: the nine score dwords
+     * around the quad are split into even / odd byte lanes (u16x2) so that v_pk_max_u16 reduces the eight
+     * neighbours of two pixels at a time.  Bit 4k+j of a lane's mask = pixel j of its k-th quad. */
+    const int nq = (ew + 3) >> 2;                 /* quads per row (<= 14) */
+                                                  /* nq * eh <= 756 items -> <= 12 quads per lane */
+    const uint32_t* scw = reinterpret_cast<const uint32_t*>(sc);
     unsigned long long m20 = 0, m7 = 0;
     {
-        int k = 0;
-        for (int i = lane; i < npx; i += 64, k++) {
-            const int y = (int)__umulhi((uint32_t)i, magic), x = i - y * ew;
-            const uint8_t* p = &sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
-            const int s = p[0];
-            if (s < G->minTh) continue;
-            const bool mx = s > p[-1] && s > p[1] && s > p[-FAST_SC_PITCH - 1] && s > p[-FAST_SC_PITCH] &&
-                            s > p[-FAST_SC_PITCH + 1] && s > p[FAST_SC_PITCH - 1] && s > p[FAST_SC_PITCH] &&
-                            s > p[FAST_SC_PITCH + 1];
-            if (mx) {
-                m7 |= 1ull << k;
-                if (s >= G->iniTh) m20 |= 1ull << k;
+        const int q64 = 64 / nq, r64 = 64 - q64 * nq;
+        int y = lane / nq, q = lane - y * nq;
+        const u16x2 thMin = {(unsigned short)(G->minTh - 1), (unsigned short)(G->minTh - 1)};
+        const u16x2 thIni = {(unsigned short)(G->iniTh - 1), (unsigned short)(G->iniTh - 1)};
+        const u16x2 one = {1, 1};
+        for (int k = 0; y < eh; k += 4) {
+            const uint32_t* w = scw + y * (FAST_SC_PITCH / 4) + q;          /* dword left of the quad, row above */
+            u16x2 E[3], O[3], LE[3], RO[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint32_t a = w[r * 16], b = w[r * 16 + 1], c = w[r * 16 + 2];
+                E[r] = __builtin_bit_cast(u16x2, b & 0x00FF00FFu);                          /* px 0, 2 */
+                O[r] = __builtin_bit_cast(u16x2, (b >> 8) & 0x00FF00FFu);                   /* px 1, 3 */
+                LE[r] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0C050C03u)); /* px -1, 1 */
+                RO[r] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(c, b, 0x0C040C02u)); /* px 2, 4 */
             }
+            const u16x2 H = umax2(umax2(E[0], O[0]), umax2(E[2], O[2]));
+            const u16x2 mE = umax2(umax2(umax2(H, LE[0]), umax2(LE[2], LE[1])), O[1]);
+            const u16x2 mO = umax2(umax2(umax2(H, RO[0]), umax2(RO[2], RO[1])), E[1]);
+            const u16x2 fE = __builtin_elementwise_sub_sat(E[1], mE), fO = __builtin_elementwise_sub_sat(O[1], mO);
+            const uint32_t e7 = __builtin_bit_cast(uint32_t, umin2(umin2(fE, __builtin_elementwise_sub_sat(E[1], thMin)), one));
+            const uint32_t o7 = __builtin_bit_cast(uint32_t, umin2(umin2(fO, __builtin_elementwise_sub_sat(O[1], thMin)), one));
+            const uint32_t e20 = __builtin_bit_cast(uint32_t, umin2(umin2(fE, __builtin_elementwise_sub_sat(E[1], thIni)), one));
+            const uint32_t o20 = __builtin_bit_cast(uint32_t, umin2(umin2(fO, __builtin_elementwise_sub_sat(O[1], thIni)), one));
+            const uint32_t t7 = e7 | (o7 << 1), t20 = e20 | (o20 << 1);    /* bits 0,1 = px 0,1; bits 16,17 = px 2,3 */
+            m7 |= (unsigned long long)((t7 | (t7 >> 14)) & 0xFu) << k;
+            m20 |= (unsigned long long)((t20 | (t20 >> 14)) & 0xFu) << k;
+            y += q64; q += r64;
+            if (q >= nq) { q -= nq; y++; }
         }
     }
-    const unsigned long long emit = __any(m20 != 0) ? m20 : m7;   /* fallback decided per cell after NMS@ini */
+    unsigned long long emit = __any(m20 != 0) ? m20 : m7;         /* fallback decided per cell after NMS@ini */
     const int cnt = __popcll(emit);
     int incl = cnt;
 #pragma unroll
@@ -221,19 +251,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(const DevGeom* __restrict__ G
     base = __shfl(base, 0);
     if (base + total > L.candCap) { if (lane == 0) atomicOr(status, 1); return; }
     size_t pos = (size_t)slot * G->candSlotElems + L.candOff + base + (incl - cnt);
-    {
-        int k = 0;
-        for (int i = lane; i < npx; i += 64, k++) {
-            if (!((emit >> k) & 1ull)) continue;
-            const int y = (int)__umulhi((uint32_t)i, magic), x = i - y * ew;
-            const uint32_t s = sc[(y + 1) * FAST_SC_PITCH + (x + 1)];
-            /* keypoint coordinates as the reference leaves them in vToDistributeKeys (:822-823):
-             * cv::FAST coordinate inside the window + (j*wCell, i*hCell) */
-            const uint32_t kx = (uint32_t)(x + 3 + fc.offX), ky = (uint32_t)(y + 3 + fc.offY);
-            cand0[pos] = kx | (ky << 12) | (s << 24);
-            cand1[pos] = (fc.cellIdx << 12) | ((uint32_t)y << 6) | (uint32_t)x;   /* emission order */
-            pos++;
-        }
+    const uint32_t magic = 0xFFFFFFFFu / (uint32_t)nq + 1u;     /* i / nq == umulhi(i, magic) for i < 2^16, nq > 1 */
+    while (emit) {
+        const int k = __builtin_ctzll(emit);
+        emit &= emit - 1;
+        const int i = lane + 64 * (k >> 2);
+        const int y = nq == 1 ? i : (int)__umulhi((uint32_t)i, magic), x = 4 * (i - y * nq) + (k & 3);
+        const uint32_t s = sc[(y + 1) * FAST_SC_PITCH + (x + 4)];
+        /* keypoint coordinates as the reference leaves them in vToDistributeKeys (:822-823):
+         * cv::FAST coordinate inside the window + (j*wCell, i*hCell) */
+        const uint32_t kx = (uint32_t)(x + 3 + fc.offX), ky = (uint32_t)(y + 3 + fc.offY);
+        cand0[pos] = kx | (ky << 12) | (s << 24);
+        cand1[pos] = (fc.cellIdx << 12) | ((uint32_t)y << 6) | (uint32_t)x;   /* emission order */
+        pos++;
     }
 }
 
