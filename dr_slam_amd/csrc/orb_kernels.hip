@@ -281,8 +281,35 @@ struct QtShared {
     int newPos[QT_MAXN];                  /* list position of a surviving node in the next list */
     unsigned char proc[QT_MAXN];          /* node is divided this round */
     unsigned short order[QT_MAXN];        /* processing order of divided nodes */
-    int len, phase, finish, nProc, err;
+    int wtot[3][QT_THREADS / 64];         /* wave totals of the three block scans of a round */
+    int len, phase, finish, err, take, total, nExp;
 };
+
+/* Exclusive block scan over 2*QT_THREADS values, thread t holding elements 2t (a) and 2t+1 (b);
+ * returns the grand total.  `wtot` must not be reused before the next barrier after the call. */
+__device__ __forceinline__ int qt_scan2(int a, int b, int* wtot, int& exA, int& exB)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = a + b;
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < QT_THREADS / 64; k++) {
+        const int t = wtot[k];
+        if (k < w) before += t;
+        total += t;
+    }
+    exA = before + incl - s;
+    exB = exA + a;
+    return total;
+}
 
 /* One workgroup runs DistributeOctTree for one (slot, level).  The reference's std::list is kept as
  * an array in list order, rebuilt every round:
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
         S.cnt[0][i] = 0;
         S.isNew[0][i] = 0;
     }
-    if (tid == 0) { S.err = 0; S.finish = 0; S.phase = 1; }
+    if (tid == 0) { S.err = 0; S.finish = 0; S.phase = 1; S.nExp = 0; S.take = 0x7FFFFFFF; }
     __syncthreads();
     for (int k = tid; k < n; k += QT_THREADS) {
         const int x = (int)(k0[k] & 0xFFF);
@@ -374,15 +401,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
             atomicAdd(&S.ccnt[4 * i + q], 1);
         }
         __syncthreads();
-        /* C. which candidates are divided, in which order */
-        if (phase == 1) {
-            if (tid == 0) {
-                int m = 0;
-                for (int i = 0; i < len; i++)
-                    if (S.proc[i]) S.order[m++] = (unsigned short)i;
-                S.nProc = m;
+        /* C. which candidates are divided, in which order.  Thread t owns list positions / ranks 2t, 2t+1
+         * in the three block scans of a round. */
+        const int e0 = 2 * tid, e1 = 2 * tid + 1;
+        int m;
+        {
+            const int p0 = e0 < len ? S.proc[e0] : 0, p1 = e1 < len ? S.proc[e1] : 0;
+            int x0, x1;
+            m = qt_scan2(p0, p1, S.wtot[0], x0, x1);
+            if (phase == 1) {                                  /* sweep: list order */
+                if (p0) S.order[x0] = (unsigned short)e0;
+                if (p1) S.order[x1] = (unsigned short)e1;
             }
-        } else {
+        }
+        if (phase != 1) {
             /* rank sort: larger size first, equal sizes -> later created first == smaller list position
              * (children sit reversed at the list front) */
             for (int i = tid; i < len; i += QT_THREADS) {
@@ -396,73 +428,79 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
                 }
                 S.order[rank] = (unsigned short)i;
             }
+        }
+        __syncthreads();
+        /* children per divided node in processing order; in the largest-first rounds the division stops
+         * with the node that brings the list to N (:730) */
+        int nch0 = 0, nch1 = 0, i0 = 0, i1 = 0;
+        if (e0 < m) { i0 = S.order[e0]; nch0 = (S.ccnt[4 * i0] > 0) + (S.ccnt[4 * i0 + 1] > 0) + (S.ccnt[4 * i0 + 2] > 0) + (S.ccnt[4 * i0 + 3] > 0); }
+        if (e1 < m) { i1 = S.order[e1]; nch1 = (S.ccnt[4 * i1] > 0) + (S.ccnt[4 * i1 + 1] > 0) + (S.ccnt[4 * i1 + 2] > 0) + (S.ccnt[4 * i1 + 3] > 0); }
+        int c0, c1;                                            /* children created before rank e0 / e1 */
+        int total = qt_scan2(nch0, nch1, S.wtot[1], c0, c1);
+        int take = m;
+        if (phase != 1) {
+            if (e0 < m && len + (c0 + nch0) - (e0 + 1) >= N) atomicMin(&S.take, e0 + 1);
+            if (e1 < m && len + (c1 + nch1) - (e1 + 1) >= N) atomicMin(&S.take, e1 + 1);
             __syncthreads();
-            if (tid == 0) {
-                int m = 0;
-                for (int i = 0; i < len; i++) m += S.proc[i];
-                int size = len, take = 0;
-                for (int r = 0; r < m; r++) {
-                    const int i = S.order[r];
-                    const int nch = (S.ccnt[4 * i] > 0) + (S.ccnt[4 * i + 1] > 0) + (S.ccnt[4 * i + 2] > 0) +
-                                    (S.ccnt[4 * i + 3] > 0);
-                    size += nch - 1;
-                    take = r + 1;
-                    if (size >= N) break;
+            take = min(S.take, m);
+            if (e0 >= take && e0 < m) S.proc[i0] = 0;
+            if (e1 >= take && e1 < m) S.proc[i1] = 0;
+            if (e0 == take - 1) S.total = c0 + nch0;
+            if (e1 == take - 1) S.total = c1 + nch1;
+            __syncthreads();
+            total = take > 0 ? S.total : 0;
+        }
+        /* D/E. next list: children of order[0] END the children block, survivors follow in old order */
+        const int nxt = cur ^ 1;
+        int s0 = e0 < len ? (S.proc[e0] ? 0 : 1) : 0, s1 = e1 < len ? (S.proc[e1] ? 0 : 1) : 0;
+        int ps0, ps1;
+        const int survivors = qt_scan2(s0, s1, S.wtot[2], ps0, ps1);
+        const int newLen = total + survivors;
+        if (newLen > maxNodes || newLen > QT_MAXN) {
+            if (tid == 0) { S.err = 1; S.finish = 1; }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int r = h ? e1 : e0, i = h ? i1 : i0;
+                if (r >= take) continue;
+                const int X0 = S.x0[cur][i], X1 = S.x1[cur][i], Y0 = S.y0[cur][i], Y1 = S.y1[cur][i];
+                const int mx = X0 + ((X1 - X0 + 1) >> 1), my = Y0 + ((Y1 - Y0 + 1) >> 1);
+                int pos = total - (h ? c1 : c0);
+                int nExp = 0;
+                for (int q = 0; q < 4; q++) {                  /* n1..n4 pushed front in this order */
+                    const int c = S.ccnt[4 * i + q];
+                    if (c == 0) { S.ccnt[4 * i + q] = -1; continue; }
+                    pos--;
+                    S.x0[nxt][pos] = (short)((q & 1) ? mx : X0);
+                    S.x1[nxt][pos] = (short)((q & 1) ? X1 : mx);
+                    S.y0[nxt][pos] = (short)((q & 2) ? my : Y0);
+                    S.y1[nxt][pos] = (short)((q & 2) ? Y1 : my);
+                    S.cnt[nxt][pos] = c;
+                    S.isNew[nxt][pos] = 1;
+                    if (c > 1) nExp++;
+                    S.ccnt[4 * i + q] = pos;
                 }
-                for (int r = take; r < m; r++) S.proc[S.order[r]] = 0;
-                S.nProc = take;
+                if (nExp) atomicAdd(&S.nExp, nExp);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = h ? e1 : e0;
+                if (!(h ? s1 : s0)) continue;
+                const int p2 = total + (h ? ps1 : ps0);
+                S.x0[nxt][p2] = S.x0[cur][i]; S.x1[nxt][p2] = S.x1[cur][i];
+                S.y0[nxt][p2] = S.y0[cur][i]; S.y1[nxt][p2] = S.y1[cur][i];
+                S.cnt[nxt][p2] = S.cnt[cur][i];
+                S.isNew[nxt][p2] = 0;
+                S.newPos[i] = p2;
             }
         }
         __syncthreads();
-        /* D/E. next list (thread 0: <= ~N nodes) */
-        const int nxt = cur ^ 1;
-        if (tid == 0) {
-            const int m = S.nProc;
-            int total = 0;
-            for (int r = 0; r < m; r++) {
-                const int i = S.order[r];
-                total += (S.ccnt[4 * i] > 0) + (S.ccnt[4 * i + 1] > 0) + (S.ccnt[4 * i + 2] > 0) + (S.ccnt[4 * i + 3] > 0);
-            }
-            int survivors = 0;
-            for (int i = 0; i < len; i++) survivors += S.proc[i] ? 0 : 1;
-            const int newLen = total + survivors;
-            if (newLen > maxNodes || newLen > QT_MAXN) {
-                S.err = 1; S.finish = 1;
-            } else {
-                int nToExpand = 0;
-                int pos = total; /* children of order[0] end the children block */
-                for (int r = 0; r < m; r++) {
-                    const int i = S.order[r];
-                    const int X0 = S.x0[cur][i], X1 = S.x1[cur][i], Y0 = S.y0[cur][i], Y1 = S.y1[cur][i];
-                    const int mx = X0 + ((X1 - X0 + 1) >> 1), my = Y0 + ((Y1 - Y0 + 1) >> 1);
-                    for (int q = 0; q < 4; q++) {      /* n1..n4 pushed front in this order */
-                        const int c = S.ccnt[4 * i + q];
-                        if (c == 0) { S.ccnt[4 * i + q] = -1; continue; }
-                        pos--;
-                        S.x0[nxt][pos] = (short)((q & 1) ? mx : X0);
-                        S.x1[nxt][pos] = (short)((q & 1) ? X1 : mx);
-                        S.y0[nxt][pos] = (short)((q & 2) ? my : Y0);
-                        S.y1[nxt][pos] = (short)((q & 2) ? Y1 : my);
-                        S.cnt[nxt][pos] = c;
-                        S.isNew[nxt][pos] = 1;
-                        if (c > 1) nToExpand++;
-                        S.ccnt[4 * i + q] = pos;
-                    }
-                }
-                int p2 = total;
-                for (int i = 0; i < len; i++) {
-                    if (S.proc[i]) continue;
-                    S.x0[nxt][p2] = S.x0[cur][i]; S.x1[nxt][p2] = S.x1[cur][i];
-                    S.y0[nxt][p2] = S.y0[cur][i]; S.y1[nxt][p2] = S.y1[cur][i];
-                    S.cnt[nxt][p2] = S.cnt[cur][i];
-                    S.isNew[nxt][p2] = 0;
-                    S.newPos[i] = p2++;
-                }
-                /* termination, :662-666 / :733-734, and the switch to largest-first rounds, :668 */
-                if (newLen >= N || newLen == len) S.finish = 1;
-                else if (phase == 1 && newLen + nToExpand * 3 > N) S.phase = 2;
-                S.len = newLen;
-            }
+        if (tid == 0 && !S.err) {
+            /* termination, :662-666 / :733-734, and the switch to largest-first rounds, :668 */
+            if (newLen >= N || newLen == len) S.finish = 1;
+            else if (phase == 1 && newLen + S.nExp * 3 > N) S.phase = 2;
+            S.len = newLen;
+            S.nExp = 0; S.take = 0x7FFFFFFF;
         }
         __syncthreads();
         if (S.err) break;
