@@ -311,13 +311,16 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
  * index order, TH_HIGH gate, rotation histogram with the reference's 1/HISTO_LENGTH factor quirk
  * (SURVEY.md §9.6), ComputeThreeMaxima, un-assignment of the other bins.
  *
- * One workgroup per frame pair replays the claims 256 map points at a time, speculatively: every
- * thread picks the best candidate of its map point that no *committed* earlier point holds (normally
- * the precomputed overall best — no list scan).  If the picks of threads [start, t) are pairwise
- * distinct, they are exactly what the sequential loop would have chosen (by induction: no earlier
- * pick removes a later thread's best), so they commit together; the first thread whose pick collides
- * with an earlier one restarts the speculation from there with the new claims visible. */
-#define RS_THREADS 256
+ * One workgroup per frame pair, all map points at once, as a fixed-point iteration instead of a
+ * sequential replay.  State: pick[i] = the candidate map point i takes.  One sweep computes
+ *   owner[k]  = lowest i with obs(i) > 0 whose pick is keypoint k (the claim that blocks later points),
+ *   pick'[i]  = best (distance, visit position) candidate k with k not claimed on entry and owner[k] >= i.
+ * pick[i] depends only on picks of points j < i, so the sequential loop's result is the unique fixed
+ * point and sweep t has points 0..t right; real frames settle in a handful of sweeps because
+ * displacement chains are short.  A point whose overall best candidate is free (the common case) never
+ * touches its candidate list. */
+#define RS_THREADS 1024
+#define RS_MAX_T 4                                /* map points per thread: nQ <= 4096 */
 __global__ __launch_bounds__(RS_THREADS) void k_resolve_last(const MatchPair* __restrict__ pairs,
                                                              const MatchQuery* __restrict__ queries,
                                                              const drfe_keypoint* __restrict__ kps,
@@ -332,10 +335,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_resolve_last(const MatchPair* __
                                                              uint16_t* __restrict__ histScratch /* [pair][2*maxKp] */)
 {
     extern __shared__ int rs_smem[];
-    int* owner = rs_smem;                                             /* [maxKp] lowest thread picking a keypoint */
-    unsigned char* claim = reinterpret_cast<unsigned char*>(rs_smem + maxKp); /* bit0 claimed, bit1 obs>0 */
+    int* owner = rs_smem;                                             /* [maxKp] */
+    unsigned char* claim = reinterpret_cast<unsigned char*>(rs_smem + maxKp); /* bit0 claimed, bit1 obs>0 (on entry) */
     __shared__ int hist[30];
-    __shared__ int sFirst, sNm, sEnt, sInd[3];
+    __shared__ int sNm, sEnt, sInd[3], sChanged[3];
     const MatchPair P = pairs[blockIdx.x];
     const int tid = threadIdx.x;
     const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
@@ -348,68 +351,80 @@ __global__ __launch_bounds__(RS_THREADS) void k_resolve_last(const MatchPair* __
         unsigned char c = 0;
         if (M[i] >= 0) c = 1 | ((initObs ? initObs[i] : 1) ? 2 : 0);
         claim[i] = c;
-        owner[i] = 0x7FFFFFFF;
     }
     if (tid < 30) hist[tid] = 0;
-    if (tid == 0) { sNm = 0; sEnt = 0; }
-    __syncthreads();
+    if (tid == 0) { sNm = 0; sEnt = 0; sChanged[0] = 0; }
     const float factor = 1.0f / 30;
-    for (int chunk = 0; chunk < nQ; chunk += RS_THREADS) {
-        const int i = chunk + tid;
-        const size_t qo = (size_t)P.queryBase + i;
-        int cnt = 0, obs = 0;
-        uint32_t bKey = 0xFFFFFFFFu, bIdx = 0;
+    int cnt[RS_MAX_T], obs[RS_MAX_T];
+    uint32_t bKey[RS_MAX_T], bIdx[RS_MAX_T], pKey[RS_MAX_T], pIdx[RS_MAX_T];
+#pragma unroll
+    for (int t = 0; t < RS_MAX_T; t++) {
+        const int i = tid + t * RS_THREADS;
+        cnt[t] = 0; obs[t] = 0; bKey[t] = 0xFFFFFFFFu; bIdx[t] = 0; pKey[t] = 0xFFFFFFFFu; pIdx[t] = 0;
         if (i < nQ) {
-            cnt = candCnt[qo];
-            if (cnt > 0) { const uint2 b = candBest[qo]; bKey = b.x; bIdx = b.y; obs = queries[qo].obs; }
-        }
-        bool done = cnt == 0;
-        int start = 0;
-        while (true) {
-            uint32_t key = 0xFFFFFFFFu, idx = 0;
-            if (!done && tid >= start) {
-                if ((claim[bIdx & 0xFFFFFF] & 3) != 3) { key = bKey; idx = bIdx; }
-                else {
-                    for (int j = 0; j < cnt; j++) {
-                        const uint32_t k = candKey[qo * DRFE_MATCH_MAX_CAND + j];
-                        const uint32_t id = candIdx[qo * DRFE_MATCH_MAX_CAND + j];
-                        if (k < key && (claim[id & 0xFFFFFF] & 3) != 3) { key = k; idx = id; }
-                    }
-                }
-            }
-            const bool success = key != 0xFFFFFFFFu && (int)(key >> 22) <= 100;   /* TH_HIGH */
-            const int i2 = (int)(idx & 0xFFFFFF);
-            if (tid == 0) sFirst = RS_THREADS;
-            __syncthreads();
-            if (success) atomicMin(&owner[i2], tid);
-            __syncthreads();
-            if (success && owner[i2] != tid) atomicMin(&sFirst, tid);
-            __syncthreads();
-            const int first = sFirst;
-            if (!done && tid >= start && tid < first) {
-                if (success) {
-                    M[i2] = i;
-                    claim[i2] = (unsigned char)(1 | (obs ? 2 : 0));
-                    atomicAdd(&sNm, 1);
-                    if (checkOri) {
-                        float rot = Kl[i].angle - Kc[i2].angle;
-                        if (rot < 0.0f) rot += 360.0f;
-                        int bin = (int)roundf(rot * factor);
-                        if (bin == 30) bin = 0;
-                        const int e = atomicAdd(&sEnt, 1);
-                        hs[2 * e] = (uint16_t)bin;
-                        hs[2 * e + 1] = (uint16_t)i2;
-                        atomicAdd(&hist[bin], 1);
-                    }
-                }
-                done = true;
-            }
-            if (success) owner[i2] = 0x7FFFFFFF;
-            __syncthreads();
-            if (first >= RS_THREADS) break;
-            start = first;
+            const size_t qo = (size_t)P.queryBase + i;
+            cnt[t] = candCnt[qo];
+            if (cnt[t] > 0) { const uint2 b = candBest[qo]; bKey[t] = b.x; bIdx[t] = b.y; obs[t] = queries[qo].obs; }
         }
     }
+    for (int sweep = 0;; sweep++) {
+        for (int k = tid; k < nCur; k += RS_THREADS) owner[k] = 0x7FFFFFFF;
+        if (tid == 0) sChanged[(sweep + 1) % 3] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RS_MAX_T; t++)
+            if (obs[t] && pKey[t] != 0xFFFFFFFFu && (int)(pKey[t] >> 22) <= 100)       /* TH_HIGH */
+                atomicMin(&owner[pIdx[t] & 0xFFFFFF], tid + t * RS_THREADS);
+        __syncthreads();
+        bool changed = false;
+#pragma unroll
+        for (int t = 0; t < RS_MAX_T; t++) {
+            if (cnt[t] == 0) continue;
+            const int i = tid + t * RS_THREADS;
+            uint32_t key = 0xFFFFFFFFu, idx = 0;
+            const int kb = (int)(bIdx[t] & 0xFFFFFF);
+            if ((claim[kb] & 3) != 3 && owner[kb] >= i) { key = bKey[t]; idx = bIdx[t]; }
+            else {
+                const size_t qo = ((size_t)P.queryBase + i) * DRFE_MATCH_MAX_CAND;
+                for (int j = 0; j < cnt[t]; j++) {
+                    const uint32_t k = candKey[qo + j];
+                    if (k >= key) continue;
+                    const uint32_t id = candIdx[qo + j];
+                    const int kk = (int)(id & 0xFFFFFF);
+                    if ((claim[kk] & 3) != 3 && owner[kk] >= i) { key = k; idx = id; }
+                }
+            }
+            if (key != pKey[t] || idx != pIdx[t]) { changed = true; pKey[t] = key; pIdx[t] = idx; }
+        }
+        if (changed) sChanged[sweep % 3] = 1;
+        __syncthreads();
+        if (!sChanged[sweep % 3]) break;
+    }
+    /* commit: M[k] = the LAST point that took k (an obs == 0 claim does not block, a later point overwrites
+     * it, :1507-1510 / :1518); every success counts and enters the rotation histogram */
+    for (int k = tid; k < nCur; k += RS_THREADS) owner[k] = -1;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RS_MAX_T; t++) {
+        if (pKey[t] == 0xFFFFFFFFu || (int)(pKey[t] >> 22) > 100) continue;
+        const int i = tid + t * RS_THREADS;
+        const int i2 = (int)(pIdx[t] & 0xFFFFFF);
+        atomicMax(&owner[i2], i);
+        atomicAdd(&sNm, 1);
+        if (checkOri) {
+            float rot = Kl[i].angle - Kc[i2].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == 30) bin = 0;
+            const int e = atomicAdd(&sEnt, 1);
+            hs[2 * e] = (uint16_t)bin;
+            hs[2 * e + 1] = (uint16_t)i2;
+            atomicAdd(&hist[bin], 1);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < nCur; k += RS_THREADS)
+        if (owner[k] >= 0) M[k] = owner[k];
     __syncthreads();
     if (checkOri) {
         if (tid == 0) {   /* ComputeThreeMaxima, src/ORBmatcher.cc:1666-1707 */
@@ -573,6 +588,7 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
 {
     const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
     const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
+    if (mode == 0 && maxQueries > RS_THREADS * RS_MAX_T) return hipErrorInvalidValue;
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            c->d_kps, c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
