@@ -386,12 +386,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_resolve_last(const MatchPair* __
             if ((claim[kb] & 3) != 3 && owner[kb] >= i) { key = bKey[t]; idx = bIdx[t]; }
             else {
                 const size_t qo = ((size_t)P.queryBase + i) * DRFE_MATCH_MAX_CAND;
-                for (int j = 0; j < cnt[t]; j++) {
-                    const uint32_t k = candKey[qo + j];
-                    if (k >= key) continue;
-                    const uint32_t id = candIdx[qo + j];
-                    const int kk = (int)(id & 0xFFFFFF);
-                    if ((claim[kk] & 3) != 3 && owner[kk] >= i) { key = k; idx = id; }
+                /* eight candidates per trip: four independent 16-byte loads in flight instead of a chain
+                 * of dependent dword loads (the list rows are 1 KB aligned) */
+                for (int j0 = 0; j0 < cnt[t]; j0 += 8) {
+                    const uint4 ka = *reinterpret_cast<const uint4*>(candKey + qo + j0);
+                    const uint4 kb2 = *reinterpret_cast<const uint4*>(candKey + qo + j0 + 4);
+                    const uint4 ia = *reinterpret_cast<const uint4*>(candIdx + qo + j0);
+                    const uint4 ib = *reinterpret_cast<const uint4*>(candIdx + qo + j0 + 4);
+                    const uint32_t kv[8] = {ka.x, ka.y, ka.z, ka.w, kb2.x, kb2.y, kb2.z, kb2.w};
+                    const uint32_t iv[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (j0 + u >= cnt[t] || kv[u] >= key) continue;
+                        const int kk = (int)(iv[u] & 0xFFFFFF);
+                        if ((claim[kk] & 3) != 3 && owner[kk] >= i) { key = kv[u]; idx = iv[u]; }
+                    }
                 }
             }
             if (key != pKey[t] || idx != pIdx[t]) { changed = true; pKey[t] = key; pIdx[t] = idx; }
