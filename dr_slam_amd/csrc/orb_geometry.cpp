@@ -54,7 +54,7 @@ int drfe_build_tables(drfe_ctx* c)
 
 /* cv::resize(INTER_LINEAR) coefficient generation for one axis: source index pair
  * and the two 11-bit weights per destination index. */
-static void build_taps(int src, int dst, std::vector<ResizeTap>* out)
+static void build_taps_axis(int src, int dst, std::vector<ResizeTap>* out)
 {
     const double inv = (double)dst / src;
     const double scale = 1. / inv;
@@ -71,6 +71,25 @@ static void build_taps(int src, int dst, std::vector<ResizeTap>* out)
         t.w0 = (int16_t)std::min(32767, std::max(-32768, w0));
         t.w1 = (int16_t)std::min(32767, std::max(-32768, w1));
         out->push_back(t);
+    }
+}
+
+/* The table the kernel reads is indexed by the BORDERED destination coordinate (copyMakeBorder
+ * REFLECT_101 of the resized interior, :1122-1123, folded into the lookup), starts 16-byte aligned and
+ * is padded to `padded` entries with zero-weight taps (-> output 0 in the pitch padding) that keep the
+ * last source position, so the source window of a thread's four taps stays <= 9 pixels wide. */
+static void build_taps(int src, int dst, int padded, std::vector<ResizeTap>* out)
+{
+    std::vector<ResizeTap> axis;
+    build_taps_axis(src, dst, &axis);
+    if (out->size() & 1) out->push_back(ResizeTap{0, 0, 0, 0});
+    const int bordered = dst + 2 * DRFE_EDGE;
+    for (int b = 0; b < padded; b++) {
+        if (b >= bordered) { ResizeTap z = out->back(); z.w0 = z.w1 = 0; out->push_back(z); continue; }
+        int p = b - DRFE_EDGE;
+        if (p < 0) p = -p;
+        if (p >= dst) p = 2 * (dst - 1) - p;
+        out->push_back(axis[p]);
     }
 }
 
@@ -169,10 +188,12 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
         /* resize taps from level l-1 (cascade, :1120) */
         L.xtabOff = L.ytabOff = 0;
         if (l > 0 && taps) {
+            if (taps->size() & 1) taps->push_back(ResizeTap{0, 0, 0, 0});
             L.xtabOff = (int)taps->size();
-            build_taps(g->lv[l - 1].w, L.w, taps);
+            build_taps(g->lv[l - 1].w, L.w, L.pyrPitch, taps);
+            if (taps->size() & 1) taps->push_back(ResizeTap{0, 0, 0, 0});
             L.ytabOff = (int)taps->size();
-            build_taps(g->lv[l - 1].h, L.h, taps);
+            build_taps(g->lv[l - 1].h, L.h, L.h + 2 * DRFE_EDGE, taps);
         }
     }
     g->pyrSlotBytes = pyrOff;

@@ -51,39 +51,53 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const DevGeom* __restrict__ 
     *reinterpret_cast<uint32_t*>(dst) = out;
 }
 
-__global__ __launch_bounds__(256) void k_pyr_resize(const DevGeom* __restrict__ G, int level,
+/* One thread = 4 horizontally adjacent pixels of the BORDERED level; block = 64 x 4 threads, so a wave
+ * is 256 contiguous pixels of one row.  The tap tables are indexed by bordered coordinates (reflection
+ * folded in on the host), so a thread needs one 8-byte row tap, two 16-byte column-tap loads and, per
+ * source row, three aligned dwords that cover the <= 9 source pixels its four outputs read; the bytes
+ * are picked out of registers.  Level descriptors travel as kernel arguments (no dependent load). */
+__device__ __forceinline__ uint32_t pick_byte(uint32_t d0, uint32_t d1, uint32_t d2, int o)
+{
+    const uint32_t w = o < 4 ? d0 : (o < 8 ? d1 : d2);
+    return (w >> (8 * (o & 3))) & 0xFFu;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize(const DevLevel L, const DevLevel P, int pyrSlotBytes,
                                                     const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr)
 {
-    const DevLevel& L = G->lv[level];
-    const DevLevel& P = G->lv[level - 1];
     const int slot = blockIdx.z;
-    const int y = blockIdx.y;
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x4 >= L.pyrPitch) return;
-    const int bw = L.w + 2 * DRFE_EDGE;
-    uint8_t* base = pyr + (size_t)slot * G->pyrSlotBytes;
-    const uint8_t* src = base + P.pyrOff + (size_t)DRFE_EDGE * P.pyrPitch + DRFE_EDGE; /* interior of l-1 */
-    const ResizeTap ty = taps[L.ytabOff + reflect101(y - DRFE_EDGE, L.h)];
-    const uint8_t* S0 = src + (size_t)ty.s0 * P.pyrPitch;
-    const uint8_t* S1 = src + (size_t)ty.s1 * P.pyrPitch;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (y >= L.h + 2 * DRFE_EDGE || x4 >= L.pyrPitch) return;
+    uint8_t* base = pyr + (size_t)slot * pyrSlotBytes;
+    const ResizeTap ty = taps[L.ytabOff + y];
+    const uint4 ta = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4);       /* taps of x4, x4+1 */
+    const uint4 tb = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4 + 2);   /* x4+2, x4+3 */
+    const uint32_t sp[4] = {ta.x, ta.z, tb.x, tb.z};      /* s0 | s1 << 16 */
+    const uint32_t wp[4] = {ta.y, ta.w, tb.y, tb.w};      /* w0 | w1 << 16 (int16) */
+    int lo = 0xFFFF;
+#pragma unroll
+    for (int k = 0; k < 4; k++) lo = min(lo, (int)(sp[k] & 0xFFFF));
+    const int ws = (lo + DRFE_EDGE) & ~3;                 /* bordered source column of the window, dword aligned */
+    const uint8_t* R0 = base + P.pyrOff + (size_t)(ty.s0 + DRFE_EDGE) * P.pyrPitch + ws;
+    const uint8_t* R1 = base + P.pyrOff + (size_t)(ty.s1 + DRFE_EDGE) * P.pyrPitch + ws;
+    const uint32_t a0 = reinterpret_cast<const uint32_t*>(R0)[0], a1 = reinterpret_cast<const uint32_t*>(R0)[1],
+                   a2 = reinterpret_cast<const uint32_t*>(R0)[2];
+    const uint32_t c0 = reinterpret_cast<const uint32_t*>(R1)[0], c1 = reinterpret_cast<const uint32_t*>(R1)[1],
+                   c2 = reinterpret_cast<const uint32_t*>(R1)[2];
     const int b0 = ty.w0, b1 = ty.w1;
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int x = x4 + k;
-        uint32_t v = 0;
-        if (x < bw) {
-            const ResizeTap tx = taps[L.xtabOff + reflect101(x - DRFE_EDGE, L.w)];
-            const int h0 = S0[tx.s0] * tx.w0 + S0[tx.s1] * tx.w1;
-            const int h1 = S1[tx.s0] * tx.w0 + S1[tx.s1] * tx.w1;
-            int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            r = min(255, max(0, r));
-            v = (uint32_t)r;
-        }
-        out |= v << (8 * k);
+        const int o0 = (int)(sp[k] & 0xFFFF) + DRFE_EDGE - ws, o1 = (int)(sp[k] >> 16) + DRFE_EDGE - ws;
+        const int w0 = (int)(short)(wp[k] & 0xFFFF), w1 = (int)(short)(wp[k] >> 16);
+        const int h0 = (int)pick_byte(a0, a1, a2, o0) * w0 + (int)pick_byte(a0, a1, a2, o1) * w1;
+        const int h1 = (int)pick_byte(c0, c1, c2, o0) * w0 + (int)pick_byte(c0, c1, c2, o1) * w1;
+        int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        r = min(255, max(0, r));
+        out |= (uint32_t)r << (8 * k);
     }
-    uint8_t* dst = base + L.pyrOff + (size_t)y * L.pyrPitch + x4;
-    *reinterpret_cast<uint32_t*>(dst) = out;
+    *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)y * L.pyrPitch + x4) = out;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -707,8 +721,8 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     }
     for (int l = 1; l < nl; l++) {
         const DevLevel& L = g.lv[l];
-        dim3 grid((L.pyrPitch / 4 + 255) / 256, L.h + 2 * DRFE_EDGE, nframes);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, c->d_geom, l, c->d_taps, c->d_pyr);
+        dim3 grid((L.pyrPitch / 4 + 63) / 64, (L.h + 2 * DRFE_EDGE + 3) / 4, nframes);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr);
     }
     prof_end(c, DRFE_STAGE_PYRAMID, s);
 
