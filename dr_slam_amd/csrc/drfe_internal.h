@@ -62,9 +62,13 @@ struct DevGeom {
 struct FastCell {   /* one cv::FAST call of reference src/ORBextractor.cc:789-816 */
     uint16_t x0, y0;        /* window origin in interior coordinates */
     uint8_t ww, wh;         /* window size (<= 68) */
-    uint8_t level, pad;
+    uint8_t level, off;     /* off = (x0 + EDGE) & 3: window start inside its first aligned dword */
     uint16_t offX, offY;    /* j*wCell, i*hCell added to the keypoint (:822-823) */
     uint32_t cellIdx;       /* i*nCols + j: emission order of the cell */
+    /* copies of the level's layout so that the kernel's loads depend on this record only */
+    uint32_t srcOff;        /* byte offset of the window's first aligned dword inside the slot's pyramid block */
+    uint32_t pitch;         /* bordered row pitch of the level */
+    uint32_t candOff, candCap;
 };
 
 struct BlurTile { uint16_t tx, ty; uint16_t level, pad; };

@@ -158,7 +158,11 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
                 const int ww = (int)maxX - (int)iniX, wh = (int)maxY - (int)iniY;
                 if (ww < 7 || wh < 7) continue; /* cv::FAST evaluates nothing */
                 fc.ww = (uint8_t)ww; fc.wh = (uint8_t)wh;
-                fc.level = (uint8_t)l; fc.pad = 0;
+                fc.level = (uint8_t)l;
+                fc.off = (uint8_t)((fc.x0 + DRFE_EDGE) & 3);
+                fc.srcOff = (uint32_t)(L.pyrOff + (fc.y0 + DRFE_EDGE) * L.pyrPitch + (fc.x0 + DRFE_EDGE - fc.off));
+                fc.pitch = (uint32_t)L.pyrPitch;
+                fc.candOff = 0; fc.candCap = 0;   /* filled once the level's capacity is known */
                 fc.offX = (uint16_t)(j * L.wCell); fc.offY = (uint16_t)(i * L.hCell);
                 fc.cellIdx = (uint32_t)(i * L.nCols + j);
                 if (cells) cells->push_back(fc);
@@ -169,6 +173,8 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
         L.cellEnd = cells ? (int)cells->size() : 0;
         L.candCap = align_up(std::max(candCap, 64), 64);
         L.candOff = candOff;
+        if (cells)
+            for (int k = L.cellBegin; k < L.cellEnd; k++) { (*cells)[k].candOff = (uint32_t)L.candOff; (*cells)[k].candCap = (uint32_t)L.candCap; }
         candOff += L.candCap;
         L.kpCap = std::max(L.quota, 4 * L.nIni) + 4;
         if (L.kpCap > DRFE_QT_MAX_NODES) {

@@ -166,7 +166,8 @@ __device__ __forceinline__ uint32_t fast_strength2(const uint8_t* cA, const uint
  * dwords; each lane scores ~16 pixels; the strict-3x3-maximum flags stay in two 64-bit lane masks
  * (>= iniThFAST / >= minThFAST); `__any` decides the per-cell fallback; a wave prefix sum gives every
  * lane its slots behind ONE global atomic per cell. */
-__global__ __launch_bounds__(64) void k_fast_cells(const DevGeom* __restrict__ G, const FastCell* __restrict__ cells,
+__global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ cells, int nlevels, int pyrSlotBytes,
+                                                   int candSlotElems, int iniTh, int minTh,
                                                    const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
                                                    uint32_t* __restrict__ cand1, int* __restrict__ candCount,
                                                    int* __restrict__ status)
@@ -174,21 +175,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(const DevGeom* __restrict__ G
     __shared__ __attribute__((aligned(16))) uint32_t tile[DRFE_FAST_MAX_WIN * (FAST_TILE_PITCH / 4)];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(FAST_MAX_EVAL + 2) * FAST_SC_PITCH];
 
-    const FastCell fc = cells[blockIdx.x];
+    const FastCell fc = cells[blockIdx.x];        /* everything below depends on this one record only */
     const int slot = blockIdx.y;
-    const DevLevel& L = G->lv[fc.level];
     const int lane = threadIdx.x;
     const int ww = fc.ww, wh = fc.wh;
     const int ew = ww - 6, eh = wh - 6;           /* evaluated area */
-    const int bx = fc.x0 + DRFE_EDGE, off = bx & 3;
-    const uint8_t* src = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(fc.y0 + DRFE_EDGE) * L.pyrPitch +
-                         (bx - off);
+    const int off = fc.off;
+    const uint8_t* src = pyr + (size_t)slot * pyrSlotBytes + fc.srcOff;
     const int wpr = (ww + off + 3) >> 2;          /* dwords per window row (<= 16) */
     {
         const int c = lane & 15;
         if (c < wpr)
             for (int r = lane >> 4; r < wh; r += 4)
-                tile[r * (FAST_TILE_PITCH / 4) + c] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * L.pyrPitch + c * 4);
+                tile[r * (FAST_TILE_PITCH / 4) + c] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * fc.pitch + c * 4);
     }
     /* score tile: pixel (x, y) of the evaluated area lives at byte (y+1)*64 + (x+4); everything else
      * (apron rows 0 / eh+1, bytes left of 4 and right of ew+3) stays 0 = "neighbour outside the cell" */
@@ -221,8 +220,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const DevGeom* __restrict__ G
     {
         const int q64 = 64 / nq, r64 = 64 - q64 * nq;
         int y = lane / nq, q = lane - y * nq;
-        const u16x2 thMin = {(unsigned short)(G->minTh - 1), (unsigned short)(G->minTh - 1)};
-        const u16x2 thIni = {(unsigned short)(G->iniTh - 1), (unsigned short)(G->iniTh - 1)};
+        const u16x2 thMin = {(unsigned short)(minTh - 1), (unsigned short)(minTh - 1)};
+        const u16x2 thIni = {(unsigned short)(iniTh - 1), (unsigned short)(iniTh - 1)};
         const u16x2 one = {1, 1};
         for (int k = 0; y < eh; k += 4) {
             const uint32_t* w = scw + y * (FAST_SC_PITCH / 4) + q;          /* dword left of the quad, row above */
@@ -261,10 +260,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const DevGeom* __restrict__ G
     const int total = __shfl(incl, 63);
     if (total == 0) return;
     int base = 0;
-    if (lane == 0) base = atomicAdd(&candCount[slot * G->nlevels + fc.level], total);
+    if (lane == 0) base = atomicAdd(&candCount[slot * nlevels + fc.level], total);
     base = __shfl(base, 0);
-    if (base + total > L.candCap) { if (lane == 0) atomicOr(status, 1); return; }
-    size_t pos = (size_t)slot * G->candSlotElems + L.candOff + base + (incl - cnt);
+    if (base + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
+    size_t pos = (size_t)slot * candSlotElems + fc.candOff + base + (incl - cnt);
     const uint32_t magic = 0xFFFFFFFFu / (uint32_t)nq + 1u;     /* i / nq == umulhi(i, magic) for i < 2^16, nq > 1 */
     while (emit) {
         const int k = __builtin_ctzll(emit);
@@ -727,7 +726,8 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_PYRAMID, s);
 
     prof_begin(c, DRFE_STAGE_FAST, s);
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), 0, s, c->d_geom, c->d_cells, c->d_pyr,
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), 0, s, c->d_cells, g.nlevels, g.pyrSlotBytes,
+                       g.candSlotElems, g.iniTh, g.minTh, c->d_pyr,
                        c->d_cand0, c->d_cand1, c->d_candCount, c->d_status);
     prof_end(c, DRFE_STAGE_FAST, s);
 
