@@ -285,13 +285,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
 
 #define QT_THREADS 512
 #define QT_MAXN DRFE_QT_MAX_NODES
+#define QT_KPT 16                      /* candidate keys a thread keeps in registers */
 
 struct QtShared {
     short x0[2][QT_MAXN], x1[2][QT_MAXN], y0[2][QT_MAXN], y1[2][QT_MAXN]; /* UL.x, UR.x, UL.y, BR.y */
     int cnt[2][QT_MAXN];
     unsigned char isNew[2][QT_MAXN];      /* created in the previous round (phase-2 candidates) */
     int ccnt[QT_MAXN * 4];                /* child key counts of this round; reused as child positions */
-    int newPos[QT_MAXN];                  /* list position of a surviving node in the next list */
+    int newPos[QT_MAXN];                  /* list position of a surviving node in the next list (steps E-F);
+                                             before that (steps A-C) the node's largest-first sort key */
+    uint32_t mid[QT_MAXN];                /* candidate of this round: 1<<31 | split y << 12 | split x */
     unsigned char proc[QT_MAXN];          /* node is divided this round */
     unsigned short order[QT_MAXN];        /* processing order of divided nodes */
     int wtot[3][QT_THREADS / 64];         /* wave totals of the three block scans of a round */
@@ -324,6 +327,33 @@ __device__ __forceinline__ int qt_scan2(int a, int b, int* wtot, int& exA, int& 
     return total;
 }
 
+/* arr[tgt] += 1 for every lane with tgt >= 0, one LDS atomic per distinct counter in the wave.
+ * Must be reached by all lanes of the wave. */
+__device__ __forceinline__ void qt_wave_add(int* arr, int tgt)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(tgt >= 0);
+    while (active) {
+        const int leader = __ffsll((long long)active) - 1;
+        const int t = __shfl(tgt, leader);
+        const unsigned long long m = __ballot(tgt == t);
+        if (lane == leader) atomicAdd(&arr[t], __popcll(m));
+        active &= ~m;
+    }
+}
+
+/* DivideNode key association (:512-526): child counter 4*i+q the key falls in, or -1 if node i is not
+ * divided this round */
+__device__ __forceinline__ int qt_child_slot(const QtShared& S, int cur, int i, uint32_t key)
+{
+    const uint32_t m = S.mid[i];
+    if (!(m >> 31)) return -1;
+    const int x = (int)(key & 0xFFF), y = (int)((key >> 12) & 0xFFF);
+    const int mx = (int)(m & 0xFFF), my = (int)((m >> 12) & 0xFFF);
+    (void)cur;
+    return 4 * i + ((x < mx) ? ((y < my) ? 0 : 2) : ((y < my) ? 1 : 3));
+}
+
 /* One workgroup runs DistributeOctTree for one (slot, level).  The reference's std::list is kept as
  * an array in list order, rebuilt every round:
  *   new list = children of the LAST divided node (n4,n3,n2,n1), ..., children of the FIRST divided
@@ -333,7 +363,7 @@ __device__ __forceinline__ int qt_scan2(int a, int b, int* wtot, int& exA, int& 
  * the previous round's children largest-first (sort at :684, ties by creation order — the canonical
  * rule of SURVEY.md §9.1) and stop as soon as the list holds N nodes (:730).  Keys never move: each
  * carries the list position of its node. */
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restrict__ G,
+__global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __restrict__ G,
                                                          const uint32_t* __restrict__ cand0,
                                                          const uint32_t* __restrict__ cand1,
                                                          uint16_t* __restrict__ node,
@@ -365,12 +395,31 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
     }
     if (tid == 0) { S.err = 0; S.finish = 0; S.phase = 1; S.nExp = 0; S.take = 0x7FFFFFFF; }
     __syncthreads();
-    for (int k = tid; k < n; k += QT_THREADS) {
-        const int x = (int)(k0[k] & 0xFFF);
-        int r = (int)((float)x / L.hX);
-        r = min(r, nIni - 1);
-        nd[k] = (uint16_t)r;
-        atomicAdd(&S.cnt[0][r], 1);
+    /* keys (x | y << 12 | score << 24) and their node positions live in registers: QT_KPT per thread;
+     * only a level with more than QT_KPT * QT_THREADS candidates spills the rest to the global arrays */
+    uint32_t rk[QT_KPT], rn2[QT_KPT / 2];     /* node positions: two 16-bit fields per register */
+#define RN_GET(t) ((rn2[(t) >> 1] >> (((t) & 1) * 16)) & 0xFFFFu)
+#define RN_SET(t, v) (rn2[(t) >> 1] = (rn2[(t) >> 1] & ~(0xFFFFu << (((t) & 1) * 16))) | ((uint32_t)(v) << (((t) & 1) * 16)))
+#pragma unroll
+    for (int t = 0; t < QT_KPT; t++) { const int k = tid + t * QT_THREADS; rk[t] = k < n ? k0[k] : 0u; rn2[t >> 1] = 0; }
+#define QT_FOR_KEYS(...)                                                                               \
+    _Pragma("unroll") for (int t = 0; t < QT_KPT; t++) {                                               \
+        if (tid + t * QT_THREADS < n) { const uint32_t KEY = rk[t]; uint32_t NODE = RN_GET(t); (void)KEY; __VA_ARGS__; RN_SET(t, NODE); } \
+    }                                                                                                  \
+    for (int k = tid + QT_KPT * QT_THREADS; k < n; k += QT_THREADS) {                                  \
+        const uint32_t KEY = k0[k]; uint32_t NODE = nd[k]; (void)KEY; __VA_ARGS__; nd[k] = (uint16_t)NODE;               \
+    }
+#pragma unroll
+    for (int t = 0; t < QT_KPT; t++) {
+        if (t * QT_THREADS >= n) break;
+        int r = -1;
+        if (tid + t * QT_THREADS < n) { r = min((int)((float)(int)(rk[t] & 0xFFF) / L.hX), nIni - 1); RN_SET(t, r); }
+        qt_wave_add(S.cnt[0], r);
+    }
+    for (int kb = QT_KPT * QT_THREADS; kb < n; kb += QT_THREADS) {
+        int r = -1;
+        if (kb + tid < n) { r = min((int)((float)(int)(k0[kb + tid] & 0xFFF) / L.hX), nIni - 1); nd[kb + tid] = (uint16_t)r; }
+        qt_wave_add(S.cnt[0], r);
     }
     __syncthreads();
     /* erase empty roots, :577-590 */
@@ -388,7 +437,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
     }
     __syncthreads();
     if (S.len != nIni)
-        for (int k = tid; k < n; k += QT_THREADS) nd[k] = (uint16_t)S.newPos[nd[k]];
+        QT_FOR_KEYS({ NODE = (uint32_t)S.newPos[NODE]; })
     __syncthreads();
 
     int cur = 0;
@@ -397,21 +446,35 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
         const int phase = S.phase;
         /* A. candidates of this round */
         for (int i = tid; i < len; i += QT_THREADS) {
-            const bool c = S.cnt[cur][i] > 1 && (phase == 1 || S.isNew[cur][i]);
+            const int ci = S.cnt[cur][i];
+            const bool c = ci > 1 && (phase == 1 || S.isNew[cur][i]);
             S.proc[i] = c ? 1 : 0;
+            const int mx = S.x0[cur][i] + ((S.x1[cur][i] - S.x0[cur][i] + 1) >> 1);
+            const int my = S.y0[cur][i] + ((S.y1[cur][i] - S.y0[cur][i] + 1) >> 1);
+            S.mid[i] = c ? (0x80000000u | (uint32_t)mx | ((uint32_t)my << 12)) : 0u;
+            /* largest-first order of the second phase (:684): bigger size first, equal sizes -> later
+             * created first == smaller list position (children sit reversed at the list front) */
+            S.newPos[i] = c ? (int)(((uint32_t)ci << 10) | (uint32_t)(QT_MAXN - 1 - i)) : 0;
             S.ccnt[4 * i] = 0; S.ccnt[4 * i + 1] = 0; S.ccnt[4 * i + 2] = 0; S.ccnt[4 * i + 3] = 0;
         }
         __syncthreads();
         /* B. DivideNode key association (:512-526) for every candidate node */
-        for (int k = tid; k < n; k += QT_THREADS) {
-            const int i = nd[k];
-            if (!S.proc[i]) continue;
-            const uint32_t key = k0[k];
-            const int x = (int)(key & 0xFFF), y = (int)((key >> 12) & 0xFFF);
-            const int mx = S.x0[cur][i] + ((S.x1[cur][i] - S.x0[cur][i] + 1) >> 1);
-            const int my = S.y0[cur][i] + ((S.y1[cur][i] - S.y0[cur][i] + 1) >> 1);
-            const int q = (x < mx) ? ((y < my) ? 0 : 2) : ((y < my) ? 1 : 3);
-            atomicAdd(&S.ccnt[4 * i + q], 1);
+        {
+            /* while the list is short thousands of keys fall on a handful of counters: same-address LDS
+             * atomics serialise lane by lane, so a wave first merges its lanes per counter */
+            const bool agg = len <= 4;
+#pragma unroll
+            for (int t = 0; t < QT_KPT; t++) {
+                if (t * QT_THREADS >= n) break;                       /* block-uniform */
+                int tgt = -1;
+                if (tid + t * QT_THREADS < n) tgt = qt_child_slot(S, cur, (int)RN_GET(t), rk[t]);
+                if (agg) qt_wave_add(S.ccnt, tgt); else if (tgt >= 0) atomicAdd(&S.ccnt[tgt], 1);
+            }
+            for (int kb = QT_KPT * QT_THREADS; kb < n; kb += QT_THREADS) {
+                int tgt = -1;
+                if (kb + tid < n) tgt = qt_child_slot(S, cur, (int)nd[kb + tid], k0[kb + tid]);
+                if (agg) qt_wave_add(S.ccnt, tgt); else if (tgt >= 0) atomicAdd(&S.ccnt[tgt], 1);
+            }
         }
         __syncthreads();
         /* C. which candidates are divided, in which order.  Thread t owns list positions / ranks 2t, 2t+1
@@ -428,17 +491,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
             }
         }
         if (phase != 1) {
-            /* rank sort: larger size first, equal sizes -> later created first == smaller list position
-             * (children sit reversed at the list front) */
+            /* rank sort on the keys step A left in newPos[] (0 for nodes that are not candidates) */
             for (int i = tid; i < len; i += QT_THREADS) {
-                if (!S.proc[i]) continue;
-                const int ci = S.cnt[cur][i];
+                const uint32_t ki = (uint32_t)S.newPos[i];
+                if (ki == 0) continue;
                 int rank = 0;
-                for (int j = 0; j < len; j++) {
-                    if (!S.proc[j]) continue;
-                    const int cj = S.cnt[cur][j];
-                    if (cj > ci || (cj == ci && j < i)) rank++;
-                }
+                for (int j = 0; j < len; j++) rank += ((uint32_t)S.newPos[j] > ki) ? 1 : 0;
                 S.order[rank] = (unsigned short)i;
             }
         }
@@ -518,19 +576,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
         __syncthreads();
         if (S.err) break;
         /* F. keys follow their node */
-        for (int k = tid; k < n; k += QT_THREADS) {
-            const int i = nd[k];
-            if (S.proc[i]) {
-                const uint32_t key = k0[k];
-                const int x = (int)(key & 0xFFF), y = (int)((key >> 12) & 0xFFF);
-                const int mx = S.x0[cur][i] + ((S.x1[cur][i] - S.x0[cur][i] + 1) >> 1);
-                const int my = S.y0[cur][i] + ((S.y1[cur][i] - S.y0[cur][i] + 1) >> 1);
-                const int q = (x < mx) ? ((y < my) ? 0 : 2) : ((y < my) ? 1 : 3);
-                nd[k] = (uint16_t)S.ccnt[4 * i + q];
-            } else {
-                nd[k] = (uint16_t)S.newPos[i];
-            }
-        }
+        QT_FOR_KEYS({
+            const int i = (int)NODE;
+            /* a candidate the largest-first round did not reach keeps proc == 0 but still has mid set */
+            const int slot4 = S.proc[i] ? qt_child_slot(S, cur, i, KEY) : -1;
+            NODE = (uint32_t)(slot4 >= 0 ? S.ccnt[slot4] : S.newPos[i]);
+        })
         cur = nxt;
         __syncthreads();
         if (S.finish) break;
@@ -544,16 +595,26 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const DevGeom* __restri
     unsigned long long* best = reinterpret_cast<unsigned long long*>(S.ccnt);
     for (int i = tid; i < len; i += QT_THREADS) best[i] = 0ull;
     __syncthreads();
-    for (int k = tid; k < n; k += QT_THREADS) {
-        const unsigned long long p = ((unsigned long long)(k0[k] >> 24) << 32) | (unsigned long long)(~k1[k]);
-        atomicMax(&best[nd[k]], p);
-    }
+    uint32_t ord[QT_KPT];                                   /* ~emission order: larger = earlier */
+#pragma unroll
+    for (int t = 0; t < QT_KPT; t++) { const int k = tid + t * QT_THREADS; ord[t] = k < n ? ~k1[k] : 0u; }
+#pragma unroll
+    for (int t = 0; t < QT_KPT; t++)
+        if (tid + t * QT_THREADS < n) atomicMax(&best[RN_GET(t)], ((unsigned long long)(rk[t] >> 24) << 32) | ord[t]);
+    for (int k = tid + QT_KPT * QT_THREADS; k < n; k += QT_THREADS)
+        atomicMax(&best[nd[k]], ((unsigned long long)(k0[k] >> 24) << 32) | (unsigned long long)(~k1[k]));
     __syncthreads();
     uint32_t* out = sel + (size_t)slot * G->kpSlotElems + L.kpOff;
-    for (int k = tid; k < n; k += QT_THREADS) {
+#pragma unroll
+    for (int t = 0; t < QT_KPT; t++)
+        if (tid + t * QT_THREADS < n && best[RN_GET(t)] == (((unsigned long long)(rk[t] >> 24) << 32) | ord[t])) out[RN_GET(t)] = rk[t];
+    for (int k = tid + QT_KPT * QT_THREADS; k < n; k += QT_THREADS) {
         const unsigned long long p = ((unsigned long long)(k0[k] >> 24) << 32) | (unsigned long long)(~k1[k]);
         if (best[nd[k]] == p) out[nd[k]] = k0[k];
     }
+#undef QT_FOR_KEYS
+#undef RN_GET
+#undef RN_SET
     if (tid == 0) selCount[slot * G->nlevels + level] = len;
 }
 
