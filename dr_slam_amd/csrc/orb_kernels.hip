@@ -477,20 +477,32 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
             }
         }
         __syncthreads();
-        /* C. which candidates are divided, in which order.  Thread t owns list positions / ranks 2t, 2t+1
-         * in the three block scans of a round. */
+        /* C. which candidates are divided, in which order.  Thread t owns list positions (sweep rounds) or
+         * ranks (largest-first rounds) 2t, 2t+1.  Outputs: for each of its two elements whether that node
+         * is divided (dv), which node it is (i), how many children earlier-processed nodes create (c);
+         * for its two list positions whether the node survives undivided (s) and how many survivors
+         * precede it (ps). */
         const int e0 = 2 * tid, e1 = 2 * tid + 1;
-        int m;
-        {
-            const int p0 = e0 < len ? S.proc[e0] : 0, p1 = e1 < len ? S.proc[e1] : 0;
+        int i0 = e0, i1 = e1, c0, c1, ps0, ps1, total, survivors;
+        bool dv0, dv1, s0, s1;
+#define QT_NCH(i) ((S.ccnt[4 * (i)] > 0) + (S.ccnt[4 * (i) + 1] > 0) + (S.ccnt[4 * (i) + 2] > 0) + (S.ccnt[4 * (i) + 3] > 0))
+        if (phase == 1) {
+            /* sweep (:597-666): every candidate is divided, in list order -> one scan of the packed pair
+             * (children | survivors << 16) over the list */
+            dv0 = e0 < len && S.proc[e0]; dv1 = e1 < len && S.proc[e1];
+            s0 = e0 < len && !dv0; s1 = e1 < len && !dv1;
+            const int v0 = (dv0 ? QT_NCH(e0) : 0) | ((s0 ? 1 : 0) << 16), v1 = (dv1 ? QT_NCH(e1) : 0) | ((s1 ? 1 : 0) << 16);
             int x0, x1;
-            m = qt_scan2(p0, p1, S.wtot[0], x0, x1);
-            if (phase == 1) {                                  /* sweep: list order */
-                if (p0) S.order[x0] = (unsigned short)e0;
-                if (p1) S.order[x1] = (unsigned short)e1;
+            const int tot = qt_scan2(v0, v1, S.wtot[0], x0, x1);
+            c0 = x0 & 0xFFFF; c1 = x1 & 0xFFFF; ps0 = x0 >> 16; ps1 = x1 >> 16;
+            total = tot & 0xFFFF; survivors = tot >> 16;
+        } else {
+            int m;
+            {
+                const int p0 = e0 < len ? S.proc[e0] : 0, p1 = e1 < len ? S.proc[e1] : 0;
+                int x0, x1;
+                m = qt_scan2(p0, p1, S.wtot[0], x0, x1);
             }
-        }
-        if (phase != 1) {
             /* rank sort on the keys step A left in newPos[] (0 for nodes that are not candidates) */
             for (int i = tid; i < len; i += QT_THREADS) {
                 const uint32_t ki = (uint32_t)S.newPos[i];
@@ -499,41 +511,40 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
                 for (int j = 0; j < len; j++) rank += ((uint32_t)S.newPos[j] > ki) ? 1 : 0;
                 S.order[rank] = (unsigned short)i;
             }
-        }
-        __syncthreads();
-        /* children per divided node in processing order; in the largest-first rounds the division stops
-         * with the node that brings the list to N (:730) */
-        int nch0 = 0, nch1 = 0, i0 = 0, i1 = 0;
-        if (e0 < m) { i0 = S.order[e0]; nch0 = (S.ccnt[4 * i0] > 0) + (S.ccnt[4 * i0 + 1] > 0) + (S.ccnt[4 * i0 + 2] > 0) + (S.ccnt[4 * i0 + 3] > 0); }
-        if (e1 < m) { i1 = S.order[e1]; nch1 = (S.ccnt[4 * i1] > 0) + (S.ccnt[4 * i1 + 1] > 0) + (S.ccnt[4 * i1 + 2] > 0) + (S.ccnt[4 * i1 + 3] > 0); }
-        int c0, c1;                                            /* children created before rank e0 / e1 */
-        int total = qt_scan2(nch0, nch1, S.wtot[1], c0, c1);
-        int take = m;
-        if (phase != 1) {
+            __syncthreads();
+            /* children per candidate in processing order; the division stops with the node that brings the
+             * list to N (:730) */
+            int nch0 = 0, nch1 = 0;
+            i0 = 0; i1 = 0;
+            if (e0 < m) { i0 = S.order[e0]; nch0 = QT_NCH(i0); }
+            if (e1 < m) { i1 = S.order[e1]; nch1 = QT_NCH(i1); }
+            qt_scan2(nch0, nch1, S.wtot[1], c0, c1);
             if (e0 < m && len + (c0 + nch0) - (e0 + 1) >= N) atomicMin(&S.take, e0 + 1);
             if (e1 < m && len + (c1 + nch1) - (e1 + 1) >= N) atomicMin(&S.take, e1 + 1);
             __syncthreads();
-            take = min(S.take, m);
+            const int take = min(S.take, m);
             if (e0 >= take && e0 < m) S.proc[i0] = 0;
             if (e1 >= take && e1 < m) S.proc[i1] = 0;
             if (e0 == take - 1) S.total = c0 + nch0;
             if (e1 == take - 1) S.total = c1 + nch1;
             __syncthreads();
             total = take > 0 ? S.total : 0;
+            dv0 = e0 < take; dv1 = e1 < take;
+            s0 = e0 < len && !S.proc[e0]; s1 = e1 < len && !S.proc[e1];
+            survivors = qt_scan2(s0 ? 1 : 0, s1 ? 1 : 0, S.wtot[2], ps0, ps1);
         }
-        /* D/E. next list: children of order[0] END the children block, survivors follow in old order */
+#undef QT_NCH
+        /* D/E. next list: children of the first processed node END the children block, survivors follow in
+         * old order */
         const int nxt = cur ^ 1;
-        int s0 = e0 < len ? (S.proc[e0] ? 0 : 1) : 0, s1 = e1 < len ? (S.proc[e1] ? 0 : 1) : 0;
-        int ps0, ps1;
-        const int survivors = qt_scan2(s0, s1, S.wtot[2], ps0, ps1);
         const int newLen = total + survivors;
         if (newLen > maxNodes || newLen > QT_MAXN) {
             if (tid == 0) { S.err = 1; S.finish = 1; }
         } else {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int r = h ? e1 : e0, i = h ? i1 : i0;
-                if (r >= take) continue;
+                const int i = h ? i1 : i0;
+                if (!(h ? dv1 : dv0)) continue;
                 const int X0 = S.x0[cur][i], X1 = S.x1[cur][i], Y0 = S.y0[cur][i], Y1 = S.y1[cur][i];
                 const int mx = X0 + ((X1 - X0 + 1) >> 1), my = Y0 + ((Y1 - Y0 + 1) >> 1);
                 int pos = total - (h ? c1 : c0);
