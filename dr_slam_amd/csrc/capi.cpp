@@ -185,6 +185,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
             for (int u = -d; u <= d; u++) { disc.push_back((int16_t)u); disc.push_back((int16_t)v); }
         }
         c->discCount = (int)disc.size() / 2;
+        if (c->discCount > 12 * 64) { c->err = "IC_Angle disc exceeds 12 offsets per lane"; return DRFE_ERR_INVALID; }
         CHIP(dalloc(&c->d_disc, disc.size()));
         CHIP(hipMemcpy(c->d_disc, disc.data(), disc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     }

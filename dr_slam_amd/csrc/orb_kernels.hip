@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
 /* ------------------------------------------------------------------------------------------------ */
 /* orientation + rBRIEF + keypoint finishing: one wavefront per keypoint                             */
 
+#define DESC_DISC_PER_LANE 12                     /* ceil(749 / 64) */
 __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel,
@@ -721,11 +722,28 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
     const uint8_t* c = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(yi + DRFE_EDGE) * L.pyrPitch +
                        (xi + DRFE_EDGE);
     int m10 = 0, m01 = 0;
-    for (int j = lane; j < discCount; j += WAVE) {
-        const int u = disc[2 * j], v = disc[2 * j + 1];
-        const int I = c[v * L.pyrPitch + u];
-        m10 += u * I;
-        m01 += v * I;
+    {
+        /* 749 disc offsets = 12 per lane: all offset loads, then all pixel gathers, in flight together
+         * (two memory round trips per keypoint instead of twenty-four) */
+        const uint32_t* disc32 = reinterpret_cast<const uint32_t*>(disc);     /* u | v << 16, int16 each */
+        uint32_t uv[DESC_DISC_PER_LANE];
+#pragma unroll
+        for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
+            const int j = lane + k * WAVE;
+            uv[k] = j < discCount ? disc32[j] : 0u;
+        }
+        int I[DESC_DISC_PER_LANE];
+#pragma unroll
+        for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
+            const int u = (int)(short)(uv[k] & 0xFFFF), v = (int)(short)(uv[k] >> 16);
+            I[k] = c[v * L.pyrPitch + u];                 /* padding entries read the centre pixel, weight 0 */
+        }
+#pragma unroll
+        for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
+            const int u = (int)(short)(uv[k] & 0xFFFF), v = (int)(short)(uv[k] >> 16);
+            m10 += u * I[k];
+            m01 += v * I[k];
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -739,14 +757,21 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
     drfe_sincos(angle * factorPI, &b, &a);
     const uint8_t* cb = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)yi * L.blurPitch + xi;
     uint8_t* drow = desc + ((size_t)slot * maxKp + g) * 32;
+    int t0[4], t1[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int8_t* q = pattern + (r * 64 + lane) * 4;
-        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
-        const int t0 = cb[drfe_round_half_even(x0 * b + y0 * a) * L.blurPitch + drfe_round_half_even(x0 * a - y0 * b)];
-        const int t1 = cb[drfe_round_half_even(x1 * b + y1 * a) * L.blurPitch + drfe_round_half_even(x1 * a - y1 * b)];
-        const unsigned long long m = __ballot(t0 < t1);
-        if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + 8 * r) = m;
+    for (int r = 0; r < 4; r++) {                 /* lane owns bit `lane` of each of the four 64-bit words */
+        const uint32_t q4 = reinterpret_cast<const uint32_t*>(pattern)[r * 64 + lane];
+        const float x0 = (float)(int8_t)(q4 & 0xFF), y0 = (float)(int8_t)((q4 >> 8) & 0xFF);
+        const float x1 = (float)(int8_t)((q4 >> 16) & 0xFF), y1 = (float)(int8_t)(q4 >> 24);
+        t0[r] = cb[drfe_round_half_even(x0 * b + y0 * a) * L.blurPitch + drfe_round_half_even(x0 * a - y0 * b)];
+        t1[r] = cb[drfe_round_half_even(x1 * b + y1 * a) * L.blurPitch + drfe_round_half_even(x1 * a - y1 * b)];
+    }
+    unsigned long long w4[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) w4[r] = __ballot(t0[r] < t1[r]);
+    if (lane == 0) {
+        reinterpret_cast<ulonglong2*>(drow)[0] = make_ulonglong2(w4[0], w4[1]);
+        reinterpret_cast<ulonglong2*>(drow)[1] = make_ulonglong2(w4[2], w4[3]);
     }
     if (lane == 0) {
         drfe_keypoint kp;
