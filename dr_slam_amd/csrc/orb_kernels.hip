@@ -121,39 +121,50 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 umax2(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ u16x2 umin2(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
 
+/* The arithmetic runs on the packed HALF-FLOAT pipe: an integer n in [-1023, 1023] written into a 16-bit
+ * lane as sign|magnitude IS the f16 subnormal n * 2^-24, subnormal add/sub/min/max are exact (f16
+ * denormals are never flushed in this code object: .amdhsa_float_denorm_mode_16_64 3), and gfx950 has
+ * three-input packed min/max (v_pk_minimum3_f16 / v_pk_maximum3_f16) which the integer pipe lacks:
+ * 17 sub + 2*(8+8+8+8+4) + 3 = 92 packed ops for two pixels instead of 120. */
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h16x2 hpk(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(h16x2, lo | (hi << 16)); }
+__device__ __forceinline__ h16x2 hmin(h16x2 a, h16x2 b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ h16x2 hmax(h16x2 a, h16x2 b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ h16x2 hmin3(h16x2 a, h16x2 b, h16x2 c) { return hmin(hmin(a, b), c); }
+__device__ __forceinline__ h16x2 hmax3(h16x2 a, h16x2 b, h16x2 c) { return hmax(hmax(a, b), c); }
+
 /* returns strength(A) | strength(B) << 16 */
 __device__ __forceinline__ uint32_t fast_strength2(const uint8_t* cA, const uint8_t* cB, const int P)
 {
     /* cA / cB point at the top-left corner of the 7x7 patch, so every ring offset is a non-negative
      * immediate of the LDS load */
     const int C = 3 * P + 3;
-    const s16x2 v = pk2(cA[C], cB[C]);
-    s16x2 d[16];
-#define RING(k, o) d[k] = v - pk2(cA[C + (o)], cB[C + (o)])
+    const h16x2 v = hpk(cA[C], cB[C]);
+    h16x2 d[16];
+#define RING(k, o) d[k] = v - hpk(cA[C + (o)], cB[C + (o)])
     RING(0, 3 * P);       RING(1, 3 * P + 1);   RING(2, 2 * P + 2);    RING(3, P + 3);
     RING(4, 3);           RING(5, -P + 3);      RING(6, -2 * P + 2);   RING(7, -3 * P + 1);
     RING(8, -3 * P);      RING(9, -3 * P - 1);  RING(10, -2 * P - 2);  RING(11, -P - 3);
     RING(12, -3);         RING(13, P - 3);      RING(14, 2 * P - 2);   RING(15, 3 * P - 1);
 #undef RING
-    s16x2 lo2[8], hi2[8], lo4[8], hi4[8];
+    h16x2 lo2[8], hi2[8], lo4[8], hi4[8], t[8], u[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) {           /* j = 2m+1: pairs (1,2) (3,4) ... (15,0) */
-        lo2[m] = pmin(d[2 * m + 1], d[(2 * m + 2) & 15]);
-        hi2[m] = pmax(d[2 * m + 1], d[(2 * m + 2) & 15]);
+        lo2[m] = hmin(d[2 * m + 1], d[(2 * m + 2) & 15]);
+        hi2[m] = hmax(d[2 * m + 1], d[(2 * m + 2) & 15]);
     }
 #pragma unroll
-    for (int m = 0; m < 8; m++) { lo4[m] = pmin(lo2[m], lo2[(m + 1) & 7]); hi4[m] = pmax(hi2[m], hi2[(m + 1) & 7]); }
-    s16x2 a = {-256, -256}, b = {256, 256};
+    for (int m = 0; m < 8; m++) { lo4[m] = hmin(lo2[m], lo2[(m + 1) & 7]); hi4[m] = hmax(hi2[m], hi2[(m + 1) & 7]); }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-        const s16x2 lo8 = pmin(lo4[m], lo4[(m + 2) & 7]);      /* min d[j .. j+7], j = 2m+1 */
-        const s16x2 hi8 = pmax(hi4[m], hi4[(m + 2) & 7]);
-        const s16x2 e0 = d[2 * m], e1 = d[(2 * m + 9) & 15];   /* d[j-1], d[j+8] */
-        a = pmax(a, pmin(lo8, pmax(e0, e1)));
-        b = pmin(b, pmax(hi8, pmin(e0, e1)));
+        const h16x2 e0 = d[2 * m], e1 = d[(2 * m + 9) & 15];   /* d[j-1], d[j+8] */
+        t[m] = hmin3(lo4[m], lo4[(m + 2) & 7], hmax(e0, e1));  /* min(d[j..j+7], max(d[j-1], d[j+8])) */
+        u[m] = hmax3(hi4[m], hi4[(m + 2) & 7], hmin(e0, e1));
     }
-    const s16x2 zero = {0, 0}, one = {1, 1};
-    const s16x2 r = pmax(pmax(a, zero - b) - one, zero);
+    const h16x2 a = hmax(hmax3(hmax3(t[0], t[1], t[2]), t[3], t[4]), hmax3(t[5], t[6], t[7]));
+    const h16x2 b = hmin(hmin3(hmin3(u[0], u[1], u[2]), u[3], u[4]), hmin3(u[5], u[6], u[7]));
+    const h16x2 one = __builtin_bit_cast(h16x2, 0x00010001u), zero = __builtin_bit_cast(h16x2, 0u);
+    const h16x2 r = hmax(hmax(a, -b) - one, zero);
     return __builtin_bit_cast(uint32_t, r);
 }
 
