@@ -199,7 +199,7 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
             build_taps(g->lv[l - 1].w, L.w, L.pyrPitch, taps);
             if (taps->size() & 1) taps->push_back(ResizeTap{0, 0, 0, 0});
             L.ytabOff = (int)taps->size();
-            build_taps(g->lv[l - 1].h, L.h, L.h + 2 * DRFE_EDGE, taps);
+            build_taps(g->lv[l - 1].h, L.h, align_up(L.h + 2 * DRFE_EDGE, 4), taps);   /* 4 rows per thread */
         }
     }
     g->pyrSlotBytes = pyrOff;

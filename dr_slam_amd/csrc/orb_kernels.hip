@@ -28,27 +28,45 @@ __device__ __forceinline__ int reflect101(int p, int n)
 /* ------------------------------------------------------------------------------------------------ */
 /* pyramid                                                                                          */
 
-__global__ __launch_bounds__(256) void k_pyr_level0(const DevGeom* __restrict__ G, const uint8_t* __restrict__ gray,
-                                                    size_t frameStride, size_t rowStride,
+/* thread = 4 bordered pixels x PYR0_ROWS rows; block = 64 x 4 threads.  Interior quads of a 4-byte
+ * aligned source come from two aligned dwords (bordered x4 maps to source column x4 - 19 = 1 mod 4). */
+#define PYR0_ROWS 4
+__global__ __launch_bounds__(256) void k_pyr_level0(const DevLevel L, int pyrSlotBytes, const uint8_t* __restrict__ gray,
+                                                    size_t frameStride, size_t rowStride, int aligned4,
                                                     uint8_t* __restrict__ pyr)
 {
-    const DevLevel& L = G->lv[0];
     const int slot = blockIdx.z;
-    const int y = blockIdx.y;                                   /* bordered row */
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;        /* bordered column of 4 px */
-    if (x4 >= L.pyrPitch) return;
-    const int bw = L.w + 2 * DRFE_EDGE;
-    const uint8_t* src = gray + (size_t)slot * frameStride + (size_t)reflect101(y - DRFE_EDGE, L.h) * rowStride;
-    uint32_t out = 0;
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR0_ROWS; /* bordered row */
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;         /* bordered column of 4 px */
+    const int bw = L.w + 2 * DRFE_EDGE, bh = L.h + 2 * DRFE_EDGE;
+    if (y0 >= bh || x4 >= L.pyrPitch) return;
+    const int sx = x4 - DRFE_EDGE;
+    const bool fast = aligned4 && sx >= 1 && sx + 7 <= L.w;
+    const uint8_t* frame = gray + (size_t)slot * frameStride;
+    uint32_t out[PYR0_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int x = x4 + k;
-        uint32_t v = 0;
-        if (x < bw) v = src[reflect101(x - DRFE_EDGE, L.w)];
-        out |= v << (8 * k);
+    for (int r = 0; r < PYR0_ROWS; r++) {
+        const int y = min(y0 + r, bh - 1);
+        const uint8_t* src = frame + (size_t)reflect101(y - DRFE_EDGE, L.h) * rowStride;
+        if (fast) {
+            const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src + (sx - 1));
+            out[r] = __builtin_amdgcn_alignbyte(s32[1], s32[0], 1);
+        } else {
+            uint32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = x4 + k;
+                uint32_t v = 0;
+                if (x < bw) v = src[reflect101(x - DRFE_EDGE, L.w)];
+                o |= v << (8 * k);
+            }
+            out[r] = o;
+        }
     }
-    uint8_t* dst = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)y * L.pyrPitch + x4;
-    *reinterpret_cast<uint32_t*>(dst) = out;
+    uint8_t* dst = pyr + (size_t)slot * pyrSlotBytes + L.pyrOff + x4;
+#pragma unroll
+    for (int r = 0; r < PYR0_ROWS; r++)
+        if (y0 + r < bh) *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + r) * L.pyrPitch) = out[r];
 }
 
 /* One thread = 4 horizontally adjacent pixels of the BORDERED level; block = 64 x 4 threads, so a wave
@@ -62,42 +80,58 @@ __device__ __forceinline__ uint32_t pick_byte(uint32_t d0, uint32_t d1, uint32_t
     return (w >> (8 * (o & 3))) & 0xFFu;
 }
 
+#define PYR_ROWS 4                                /* output rows per thread */
 __global__ __launch_bounds__(256) void k_pyr_resize(const DevLevel L, const DevLevel P, int pyrSlotBytes,
                                                     const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr)
 {
     const int slot = blockIdx.z;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (y >= L.h + 2 * DRFE_EDGE || x4 >= L.pyrPitch) return;
+    const int bh = L.h + 2 * DRFE_EDGE;
+    if (y0 >= bh || x4 >= L.pyrPitch) return;
     uint8_t* base = pyr + (size_t)slot * pyrSlotBytes;
-    const ResizeTap ty = taps[L.ytabOff + y];
+    /* the row-tap table is padded to a multiple of PYR_ROWS entries, 16-byte aligned */
+    const uint4 tya = *reinterpret_cast<const uint4*>(taps + L.ytabOff + y0);
+    const uint4 tyb = *reinterpret_cast<const uint4*>(taps + L.ytabOff + y0 + 2);
     const uint4 ta = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4);       /* taps of x4, x4+1 */
     const uint4 tb = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4 + 2);   /* x4+2, x4+3 */
+    const uint32_t syp[PYR_ROWS] = {tya.x, tya.z, tyb.x, tyb.z}, wyp[PYR_ROWS] = {tya.y, tya.w, tyb.y, tyb.w};
     const uint32_t sp[4] = {ta.x, ta.z, tb.x, tb.z};      /* s0 | s1 << 16 */
     const uint32_t wp[4] = {ta.y, ta.w, tb.y, tb.w};      /* w0 | w1 << 16 (int16) */
     int lo = 0xFFFF;
 #pragma unroll
     for (int k = 0; k < 4; k++) lo = min(lo, (int)(sp[k] & 0xFFFF));
     const int ws = (lo + DRFE_EDGE) & ~3;                 /* bordered source column of the window, dword aligned */
-    const uint8_t* R0 = base + P.pyrOff + (size_t)(ty.s0 + DRFE_EDGE) * P.pyrPitch + ws;
-    const uint8_t* R1 = base + P.pyrOff + (size_t)(ty.s1 + DRFE_EDGE) * P.pyrPitch + ws;
-    const uint32_t a0 = reinterpret_cast<const uint32_t*>(R0)[0], a1 = reinterpret_cast<const uint32_t*>(R0)[1],
-                   a2 = reinterpret_cast<const uint32_t*>(R0)[2];
-    const uint32_t c0 = reinterpret_cast<const uint32_t*>(R1)[0], c1 = reinterpret_cast<const uint32_t*>(R1)[1],
-                   c2 = reinterpret_cast<const uint32_t*>(R1)[2];
-    const int b0 = ty.w0, b1 = ty.w1;
-    uint32_t out = 0;
+    const uint8_t* srcw = base + P.pyrOff + (size_t)DRFE_EDGE * P.pyrPitch + ws;
+    uint32_t a[PYR_ROWS][3], c[PYR_ROWS][3];
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; r++) {                  /* 6 * PYR_ROWS independent dword loads in flight */
+        const uint32_t* R0 = reinterpret_cast<const uint32_t*>(srcw + (size_t)(syp[r] & 0xFFFF) * P.pyrPitch);
+        const uint32_t* R1 = reinterpret_cast<const uint32_t*>(srcw + (size_t)(syp[r] >> 16) * P.pyrPitch);
+        a[r][0] = R0[0]; a[r][1] = R0[1]; a[r][2] = R0[2];
+        c[r][0] = R1[0]; c[r][1] = R1[1]; c[r][2] = R1[2];
+    }
+    int o0[4], o1[4], w0[4], w1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int o0 = (int)(sp[k] & 0xFFFF) + DRFE_EDGE - ws, o1 = (int)(sp[k] >> 16) + DRFE_EDGE - ws;
-        const int w0 = (int)(short)(wp[k] & 0xFFFF), w1 = (int)(short)(wp[k] >> 16);
-        const int h0 = (int)pick_byte(a0, a1, a2, o0) * w0 + (int)pick_byte(a0, a1, a2, o1) * w1;
-        const int h1 = (int)pick_byte(c0, c1, c2, o0) * w0 + (int)pick_byte(c0, c1, c2, o1) * w1;
-        int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        r = min(255, max(0, r));
-        out |= (uint32_t)r << (8 * k);
+        o0[k] = (int)(sp[k] & 0xFFFF) + DRFE_EDGE - ws; o1[k] = (int)(sp[k] >> 16) + DRFE_EDGE - ws;
+        w0[k] = (int)(short)(wp[k] & 0xFFFF); w1[k] = (int)(short)(wp[k] >> 16);
     }
-    *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)y * L.pyrPitch + x4) = out;
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; r++) {
+        if (y0 + r >= bh) break;
+        const int b0 = (int)(short)(wyp[r] & 0xFFFF), b1 = (int)(short)(wyp[r] >> 16);
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int h0 = (int)pick_byte(a[r][0], a[r][1], a[r][2], o0[k]) * w0[k] + (int)pick_byte(a[r][0], a[r][1], a[r][2], o1[k]) * w1[k];
+            const int h1 = (int)pick_byte(c[r][0], c[r][1], c[r][2], o0[k]) * w0[k] + (int)pick_byte(c[r][0], c[r][1], c[r][2], o1[k]) * w1[k];
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(255, max(0, v));
+            out |= (uint32_t)v << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)(y0 + r) * L.pyrPitch + x4) = out;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -823,12 +857,14 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_begin(c, DRFE_STAGE_PYRAMID, s);
     {
         const DevLevel& L = g.lv[0];
-        dim3 grid((L.pyrPitch / 4 + 255) / 256, L.h + 2 * DRFE_EDGE, nframes);
-        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, c->d_geom, d_gray, frameStride, rowStride, c->d_pyr);
+        dim3 grid((L.pyrPitch / 4 + 63) / 64, (L.h + 2 * DRFE_EDGE + 4 * PYR0_ROWS - 1) / (4 * PYR0_ROWS), nframes);
+        const int aligned4 = (((uintptr_t)d_gray | frameStride | rowStride) & 3) == 0;
+        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(64, 4), 0, s, L, g.pyrSlotBytes, d_gray, frameStride, rowStride, aligned4,
+                           c->d_pyr);
     }
     for (int l = 1; l < nl; l++) {
         const DevLevel& L = g.lv[l];
-        dim3 grid((L.pyrPitch / 4 + 63) / 64, (L.h + 2 * DRFE_EDGE + 3) / 4, nframes);
+        dim3 grid((L.pyrPitch / 4 + 63) / 64, (L.h + 2 * DRFE_EDGE + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), nframes);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr);
     }
     prof_end(c, DRFE_STAGE_PYRAMID, s);
