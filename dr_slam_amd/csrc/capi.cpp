@@ -83,7 +83,7 @@ void drfe_destroy(drfe_ctx* c)
     drfe_lines_free(c);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
                     c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_desc,
-                    c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_match,
+                    c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc, c->d_match,
                     c->d_matchCount, c->d_poses, c->d_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -130,7 +130,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->d_disc = nullptr; c->d_pyr = nullptr; c->d_blur = nullptr; c->d_cand0 = nullptr; c->d_cand1 = nullptr;
     c->d_node = nullptr; c->d_candCount = nullptr; c->d_sel = nullptr; c->d_selCount = nullptr; c->d_kps = nullptr;
     c->d_desc = nullptr; c->d_kpCount = nullptr; c->d_status = nullptr; c->d_uRight = nullptr; c->d_depth = nullptr;
-    c->d_gridOff = nullptr; c->d_gridIdx = nullptr; c->d_match = nullptr; c->d_matchCount = nullptr;
+    c->d_gridOff = nullptr; c->d_gridIdx = nullptr; c->d_cellKp = nullptr; c->d_cellDesc = nullptr; c->d_match = nullptr; c->d_matchCount = nullptr;
     c->d_poses = nullptr; c->d_stage = nullptr;
 
 #define CREATE_FAIL(code)                 \
@@ -205,6 +205,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     CHIP(dalloc(&c->d_depth, B * (size_t)c->maxKp));
     CHIP(dalloc(&c->d_gridOff, B * (DRFE_GRID_CELLS + 1)));
     CHIP(dalloc(&c->d_gridIdx, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_cellKp, B * (size_t)c->maxKp));
+    CHIP(dalloc(&c->d_cellDesc, B * (size_t)c->maxKp * 2));
     CHIP(dalloc(&c->d_match, B * (size_t)c->maxKp));
     CHIP(dalloc(&c->d_matchCount, B));
     CHIP(dalloc(&c->d_poses, 2 * B * 16));

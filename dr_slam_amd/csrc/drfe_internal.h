@@ -112,6 +112,7 @@ struct drfe_ctx {
     /* frame glue + match */
     float* d_uRight; float* d_depth;      /* [slot][maxKp] */
     int* d_gridOff; int* d_gridIdx;       /* [slot][3073], [slot][maxKp] */
+    uint4* d_cellKp; uint4* d_cellDesc;   /* keypoints in grid-cell order: [slot][maxKp] records, [slot][maxKp][2] descriptors */
     int* d_match; int* d_matchCount;      /* [slot][maxKp], [slot] */
     float* d_poses;                       /* per-batch Tcw/Twc staging: [2][max_batch][16] */
     uint8_t* d_stage;                     /* staging for single-frame host API */

@@ -58,7 +58,9 @@ __device__ __forceinline__ int grid_cell(const drfe_keypoint& kp, const drfe_cam
 /* one workgroup per slot: count -> scan -> fill -> per-cell ascending sort (== insertion order) */
 __global__ __launch_bounds__(256) void k_grid(const drfe_keypoint* __restrict__ kps, const int* __restrict__ kpCount,
                                               int maxKp, drfe_camera cam, float invW, float invH,
-                                              int* __restrict__ gridOff, int* __restrict__ gridIdx)
+                                              const float* __restrict__ uRight, const uint8_t* __restrict__ desc,
+                                              int* __restrict__ gridOff, int* __restrict__ gridIdx,
+                                              uint4* __restrict__ cellKp, uint4* __restrict__ cellDesc)
 {
     __shared__ int cnt[DRFE_GRID_CELLS];
     __shared__ int off[DRFE_GRID_CELLS + 1];
@@ -106,6 +108,22 @@ __global__ __launch_bounds__(256) void k_grid(const drfe_keypoint* __restrict__ 
             while (j >= b && gIdx[j] > v) { gIdx[j + 1] = gIdx[j]; j--; }
             gIdx[j + 1] = v;
         }
+    }
+    __syncthreads();
+    /* the same keypoints once more in cell order, packed for the window search: a window column is one
+     * contiguous run of (x, y, uRight, index | octave << 24) records and of descriptors */
+    const int nIn = off[DRFE_GRID_CELLS];
+    uint4* cK = cellKp + (size_t)slot * maxKp;
+    uint4* cD = cellDesc + (size_t)slot * maxKp * 2;
+    const uint4* D4 = reinterpret_cast<const uint4*>(desc + (size_t)slot * maxKp * 32);
+    const float* UR = uRight + (size_t)slot * maxKp;
+    for (int p = tid; p < nIn; p += 256) {
+        const int idx = gIdx[p];
+        const drfe_keypoint kp = K[idx];
+        cK[p] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), __float_as_uint(UR[idx]),
+                           (uint32_t)idx | ((uint32_t)kp.octave << 24));
+        cD[2 * p] = D4[2 * idx];
+        cD[2 * p + 1] = D4[2 * idx + 1];
     }
 }
 
@@ -205,19 +223,16 @@ __global__ __launch_bounds__(256) void k_queries_last(const MatchPair* __restric
 
 __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __restrict__ pairs,
                                                            const MatchQuery* __restrict__ queries,
-                                                           const drfe_keypoint* __restrict__ kps,
-                                                           const uint8_t* __restrict__ desc,
-                                                           const float* __restrict__ uRight,
                                                            const int* __restrict__ kpCount, int maxKp,
                                                            const int* __restrict__ gridOff,
-                                                           const int* __restrict__ gridIdx, drfe_camera cam,
+                                                           const uint4* __restrict__ cellKp,
+                                                           const uint4* __restrict__ cellDesc, drfe_camera cam,
                                                            float invW, float invH,
                                                            uint32_t* __restrict__ candIdx,
                                                            uint32_t* __restrict__ candKey,
                                                            int* __restrict__ candCnt, uint2* __restrict__ candBest,
                                                            int* __restrict__ status)
 {
-    __shared__ int sCnt[256 / WAVE];
     const MatchPair P = pairs[blockIdx.y];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = blockIdx.x * (256 / WAVE) + wv;
@@ -225,7 +240,6 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
     if (qi >= nQ) return;                       /* wave-uniform */
     const size_t qo = (size_t)P.queryBase + qi;
     const MatchQuery q = queries[qo];
-    if (lane == 0) sCnt[wv] = 0;
     if (!q.valid) { if (lane == 0) { candCnt[qo] = 0; candBest[qo] = make_uint2(0xFFFFFFFFu, 0u); } return; }
     const float x = q.u, y = q.v, r = q.radius;
     /* Frame::GetFeaturesInArea cell range, src/Frame.cc:735-749 */
@@ -237,50 +251,81 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
         if (lane == 0) { candCnt[qo] = 0; candBest[qo] = make_uint2(0xFFFFFFFFu, 0u); }
         return;
     }
-    const int ny = nMaxCellY - nMinCellY + 1;
-    const int ncell = (nMaxCellX - nMinCellX + 1) * ny;
     const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
     const int cur = P.curSlot;
-    const drfe_keypoint* K = kps + (size_t)cur * maxKp;
-    const uint8_t* D = desc + (size_t)cur * maxKp * 32;
-    const float* UR = uRight + (size_t)cur * maxKp;
     const int* gOff = gridOff + (size_t)cur * (DRFE_GRID_CELLS + 1);
-    const int* gIdx = gridIdx + (size_t)cur * maxKp;
+    const uint4* cK = cellKp + (size_t)cur * maxKp;
+    const uint4* cD = cellDesc + (size_t)cur * maxKp * 2;
     uint32_t* oIdx = candIdx + qo * DRFE_MATCH_MAX_CAND;
     uint32_t* oKey = candKey + qo * DRFE_MATCH_MAX_CAND;
     const uint64_t q0 = (uint64_t)q.desc[0] | ((uint64_t)q.desc[1] << 32), q1 = (uint64_t)q.desc[2] | ((uint64_t)q.desc[3] << 32),
                    q2 = (uint64_t)q.desc[4] | ((uint64_t)q.desc[5] << 32), q3 = (uint64_t)q.desc[6] | ((uint64_t)q.desc[7] << 32);
+    /* The reference scans cells ix-outer / iy-inner and each cell in insertion order: in the cell-sorted
+     * arrays that is, per window column, ONE contiguous run [gOff[ix][minY], gOff[ix][maxY+1]).  Lane c
+     * owns column c (<= 64 columns); a wave scan turns the run lengths into visit positions, and from
+     * then on lanes work on candidates, not cells. */
+    const int ncol = nMaxCellX - nMinCellX + 1;
+    int runB = 0, runN = 0;
+    if (lane < ncol) {
+        const int cb = (nMinCellX + lane) * DRFE_GRID_ROWS;
+        runB = gOff[cb + nMinCellY];
+        runN = gOff[cb + nMaxCellY + 1] - runB;
+    }
+    int incl = runN;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const int T = __shfl(incl, 63);
+    int nOut = 0;
     bool overflow = false;
     uint32_t myKey = 0xFFFFFFFFu, myIdx = 0;
-    for (int c = lane; c < ncell; c += WAVE) {
-        const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;   /* ix outer, iy inner */
-        const int cell = ix * DRFE_GRID_ROWS + iy;
-        const int b = gOff[cell], e = gOff[cell + 1];
-        for (int j = b; j < e; j++) {
-            const int idx = gIdx[j];
-            const drfe_keypoint kp = K[idx];
+    for (int s0 = 0; s0 < T; s0 += WAVE) {
+        const int sq = s0 + lane;                /* visit position of this lane's candidate */
+        bool pass = false;
+        uint32_t key = 0xFFFFFFFFu, id = 0;
+        /* record position = runB[col] + (sq - exclusive[col]); the column walk uses wave-uniform lane reads */
+        int base = __builtin_amdgcn_readfirstlane(runB);
+        for (int j = 0; j + 1 < ncol; j++) {
+            const int inclJ = __builtin_amdgcn_readlane(incl, j), nextB = __builtin_amdgcn_readlane(runB, j + 1);
+            if (inclJ <= sq) base = nextB - inclJ;
+        }
+        if (sq < T) {
+            const int p = base + sq;
+            const uint4 k4 = cK[p];
+            const uint4 da = cD[2 * p], db = cD[2 * p + 1];
+            const float kx = __uint_as_float(k4.x), ky = __uint_as_float(k4.y), ur = __uint_as_float(k4.z);
+            const int oct = (int)(k4.w >> 24);
+            bool ok = true;
             if (bCheckLevels) {
-                if (kp.octave < q.minLevel) continue;
-                if (q.maxLevel >= 0 && kp.octave > q.maxLevel) continue;
+                if (oct < q.minLevel) ok = false;
+                if (q.maxLevel >= 0 && oct > q.maxLevel) ok = false;
             }
-            const float dx = kp.x - x, dy = kp.y - y;
-            if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
-            const float ur = UR[idx];
+            const float dx = kx - x, dy = ky - y;
+            if (!(fabsf(dx) < r && fabsf(dy) < r)) ok = false;
             if (ur > 0) {
                 const float er = fabsf(q.ur - ur);
-                if (er > q.thrR) continue;
+                if (er > q.thrR) ok = false;
             }
-            const uint64_t* d = reinterpret_cast<const uint64_t*>(D + (size_t)idx * 32);
-            const int dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
-            const int pos = atomicAdd(&sCnt[wv], 1);
+            if (ok) {
+                const int dist = __popcll(q0 ^ ((uint64_t)da.x | ((uint64_t)da.y << 32))) + __popcll(q1 ^ ((uint64_t)da.z | ((uint64_t)da.w << 32))) +
+                                 __popcll(q2 ^ ((uint64_t)db.x | ((uint64_t)db.y << 32))) + __popcll(q3 ^ ((uint64_t)db.z | ((uint64_t)db.w << 32)));
+                key = ((uint32_t)dist << 22) | (uint32_t)min(sq, (1 << 22) - 1);
+                id = k4.w;
+                pass = true;
+            }
+        }
+        const unsigned long long m = __ballot(pass);
+        const int pos = nOut + __popcll(m & ((1ull << lane) - 1ull));
+        if (pass) {
             if (pos < DRFE_MATCH_MAX_CAND) {
-                oIdx[pos] = (uint32_t)idx | ((uint32_t)kp.octave << 24);
-                /* visit position: cell sequence number, then position inside the cell */
-                const uint32_t key = ((uint32_t)dist << 22) | ((uint32_t)min(c, 16383) << 8) | (uint32_t)min(j - b, 255);
+                oIdx[pos] = id;
                 oKey[pos] = key;
-                if (key < myKey) { myKey = key; myIdx = (uint32_t)idx | ((uint32_t)kp.octave << 24); }
+                if (key < myKey) { myKey = key; myIdx = id; }
             } else overflow = true;
         }
+        nOut += __popcll(m);
     }
     if (__any(overflow) && lane == 0) atomicOr(status, 4);
     /* the query's overall best (min distance, then earliest visit): what the claim replay takes when
@@ -290,9 +335,8 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
     for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
     const unsigned long long who = __ballot(myKey == mn);
     const uint32_t bIdx = (uint32_t)__shfl((int)myIdx, __ffsll((long long)who) - 1);
-    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        candCnt[qo] = min(sCnt[wv], DRFE_MATCH_MAX_CAND);
+        candCnt[qo] = min(nOut, DRFE_MATCH_MAX_CAND);
         candBest[qo] = make_uint2(mn, bIdx);
     }
 }
@@ -586,7 +630,7 @@ hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameSt
                        c->maxKp, d_depth, frameStride, rowStride, c->geom.imgW, c->geom.imgH, cam, c->d_uRight,
                        c->d_depth);
     hipLaunchKernelGGL(k_grid, dim3(nframes), dim3(256), 0, s, c->d_kps, c->d_kpCount, c->maxKp, cam, invW, invH,
-                       c->d_gridOff, c->d_gridIdx);
+                       c->d_uRight, c->d_desc, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc);
     prof_end(c, DRFE_STAGE_GLUE, s);
     return hipGetLastError();
 }
@@ -602,9 +646,8 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            c->d_kps, c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
     hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 3) / 4, npairs), dim3(256), 0, s, mb.d_pairs,
-                       mb.d_queries, c->d_kps, c->d_desc, c->d_uRight, c->d_kpCount, c->maxKp, c->d_gridOff,
-                       c->d_gridIdx, cam, invW, invH, mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest,
-                       c->d_status);
+                       mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
+                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status);
     const size_t lds = (size_t)c->maxKp;
     if (mode == 0)
         hipLaunchKernelGGL(k_resolve_last, dim3(npairs), dim3(RS_THREADS), (size_t)c->maxKp * 5 + 16, s, mb.d_pairs,
