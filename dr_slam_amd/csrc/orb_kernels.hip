@@ -328,11 +328,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
 /* ------------------------------------------------------------------------------------------------ */
 /* quadtree                                                                                          */
 
-#define QT_THREADS 512
-#define QT_MAXN DRFE_QT_MAX_NODES
-#define QT_KPT 16                      /* candidate keys a thread keeps in registers */
+/* k_quadtree<QT_THREADS, QT_KPT, QT_MAXN>: workgroup size, candidate keys a thread keeps in registers,
+ * node-list capacity.  The host picks <512,16,*> for the large levels and <256,8,256> for the small ones
+ * (less LDS and fewer registers -> more workgroups per CU). */
 
-struct QtShared {
+template <int QT_THREADS, int QT_MAXN> struct QtShared {
     short x0[2][QT_MAXN], x1[2][QT_MAXN], y0[2][QT_MAXN], y1[2][QT_MAXN]; /* UL.x, UR.x, UL.y, BR.y */
     int cnt[2][QT_MAXN];
     unsigned char isNew[2][QT_MAXN];      /* created in the previous round (phase-2 candidates) */
@@ -348,7 +348,7 @@ struct QtShared {
 
 /* Exclusive block scan over 2*QT_THREADS values, thread t holding elements 2t (a) and 2t+1 (b);
  * returns the grand total.  `wtot` must not be reused before the next barrier after the call. */
-__device__ __forceinline__ int qt_scan2(int a, int b, int* wtot, int& exA, int& exB)
+template <int QT_THREADS> __device__ __forceinline__ int qt_scan2(int a, int b, int* wtot, int& exA, int& exB)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = a + b;
@@ -389,7 +389,7 @@ __device__ __forceinline__ void qt_wave_add(int* arr, int tgt)
 
 /* DivideNode key association (:512-526): child counter 4*i+q the key falls in, or -1 if node i is not
  * divided this round */
-__device__ __forceinline__ int qt_child_slot(const QtShared& S, int cur, int i, uint32_t key)
+template <class SH> __device__ __forceinline__ int qt_child_slot(const SH& S, int cur, int i, uint32_t key)
 {
     const uint32_t m = S.mid[i];
     if (!(m >> 31)) return -1;
@@ -408,7 +408,8 @@ __device__ __forceinline__ int qt_child_slot(const QtShared& S, int cur, int i, 
  * the previous round's children largest-first (sort at :684, ties by creation order — the canonical
  * rule of SURVEY.md §9.1) and stop as soon as the list holds N nodes (:730).  Keys never move: each
  * carries the list position of its node. */
-__global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __restrict__ G,
+template <int QT_THREADS, int QT_KPT, int QT_MAXN>
+__global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __restrict__ G, int levelBase,
                                                          const uint32_t* __restrict__ cand0,
                                                          const uint32_t* __restrict__ cand1,
                                                          uint16_t* __restrict__ node,
@@ -416,8 +417,8 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
                                                          uint32_t* __restrict__ sel, int* __restrict__ selCount,
                                                          int* __restrict__ status)
 {
-    __shared__ QtShared S;
-    const int level = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
+    __shared__ QtShared<QT_THREADS, QT_MAXN> S;
+    const int level = levelBase + blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
     const DevLevel& L = G->lv[level];
     const int n = min(candCount[slot * G->nlevels + level], L.candCap);
     const size_t coff = (size_t)slot * G->candSlotElems + L.candOff;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
             s0 = e0 < len && !dv0; s1 = e1 < len && !dv1;
             const int v0 = (dv0 ? QT_NCH(e0) : 0) | ((s0 ? 1 : 0) << 16), v1 = (dv1 ? QT_NCH(e1) : 0) | ((s1 ? 1 : 0) << 16);
             int x0, x1;
-            const int tot = qt_scan2(v0, v1, S.wtot[0], x0, x1);
+            const int tot = qt_scan2<QT_THREADS>(v0, v1, S.wtot[0], x0, x1);
             c0 = x0 & 0xFFFF; c1 = x1 & 0xFFFF; ps0 = x0 >> 16; ps1 = x1 >> 16;
             total = tot & 0xFFFF; survivors = tot >> 16;
         } else {
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
             {
                 const int p0 = e0 < len ? S.proc[e0] : 0, p1 = e1 < len ? S.proc[e1] : 0;
                 int x0, x1;
-                m = qt_scan2(p0, p1, S.wtot[0], x0, x1);
+                m = qt_scan2<QT_THREADS>(p0, p1, S.wtot[0], x0, x1);
             }
             /* rank sort on the keys step A left in newPos[] (0 for nodes that are not candidates) */
             for (int i = tid; i < len; i += QT_THREADS) {
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
             i0 = 0; i1 = 0;
             if (e0 < m) { i0 = S.order[e0]; nch0 = QT_NCH(i0); }
             if (e1 < m) { i1 = S.order[e1]; nch1 = QT_NCH(i1); }
-            qt_scan2(nch0, nch1, S.wtot[1], c0, c1);
+            qt_scan2<QT_THREADS>(nch0, nch1, S.wtot[1], c0, c1);
             if (e0 < m && len + (c0 + nch0) - (e0 + 1) >= N) atomicMin(&S.take, e0 + 1);
             if (e1 < m && len + (c1 + nch1) - (e1 + 1) >= N) atomicMin(&S.take, e1 + 1);
             __syncthreads();
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
             total = take > 0 ? S.total : 0;
             dv0 = e0 < take; dv1 = e1 < take;
             s0 = e0 < len && !S.proc[e0]; s1 = e1 < len && !S.proc[e1];
-            survivors = qt_scan2(s0 ? 1 : 0, s1 ? 1 : 0, S.wtot[2], ps0, ps1);
+            survivors = qt_scan2<QT_THREADS>(s0 ? 1 : 0, s1 ? 1 : 0, S.wtot[2], ps0, ps1);
         }
 #undef QT_NCH
         /* D/E. next list: children of the first processed node END the children block, survivors follow in
@@ -876,8 +877,28 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_FAST, s);
 
     prof_begin(c, DRFE_STAGE_QUADTREE, s);
-    hipLaunchKernelGGL(k_quadtree, dim3(nl, nframes), dim3(QT_THREADS), 0, s, c->d_geom, c->d_cand0,
-                       c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_status);
+    {
+        /* levels are ordered large -> small: [0, nBig) take the 512-thread variant, the rest the 256-thread one */
+        int nBig = 0, capMax = 0;
+        for (int l = 0; l < nl; l++) {
+            if (g.lv[l].w * g.lv[l].h > (1 << 17) || g.lv[l].kpCap > 256) nBig = l + 1;
+            capMax = std::max(capMax, g.lv[l].kpCap);
+        }
+        /* a batch whose workgroups are all resident at once (2 x 512 threads per CU) finishes soonest as ONE
+         * launch: the kernel is latency-bound and a second launch would only queue behind the first */
+        if (nl * nframes <= 2 * 256) nBig = nl;
+        if (nBig > 0) {
+            if (capMax > 256)
+                hipLaunchKernelGGL((k_quadtree<512, 16, DRFE_QT_MAX_NODES>), dim3(nBig, nframes), dim3(512), 0, s, c->d_geom, 0,
+                                   c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_status);
+            else
+                hipLaunchKernelGGL((k_quadtree<512, 16, 256>), dim3(nBig, nframes), dim3(512), 0, s, c->d_geom, 0, c->d_cand0,
+                                   c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_status);
+        }
+        if (nBig < nl)
+            hipLaunchKernelGGL((k_quadtree<256, 8, 256>), dim3(nl - nBig, nframes), dim3(256), 0, s, c->d_geom, nBig, c->d_cand0,
+                               c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_status);
+    }
     prof_end(c, DRFE_STAGE_QUADTREE, s);
 
     prof_begin(c, DRFE_STAGE_BLUR, s);
@@ -893,4 +914,4 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     return hipGetLastError();
 }
 
-size_t drfe_quadtree_lds_bytes() { return sizeof(QtShared); }
+size_t drfe_quadtree_lds_bytes() { return sizeof(QtShared<512, DRFE_QT_MAX_NODES>); }
