@@ -704,15 +704,19 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
         const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + c0);
         const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + c1);
         const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + c2);
-        uint32_t b[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; b[8 + k] = (w2 >> (8 * k)) & 0xFF; }
-        /* b[k] is interior column x-3+k (bordered column x+16+k); pixel x+j uses b[j..j+6] */
-        uint32_t h[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            h[j] = 18u * (b[j] + b[j + 6]) + 34u * (b[j + 1] + b[j + 5]) + 49u * (b[j + 2] + b[j + 4]) + 55u * b[j + 3];
-        *reinterpret_cast<uint2*>(&hb[r * DRFE_BLUR_TW + cg * 4]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        /* byte k of (w0,w1,w2) is interior column x-3+k; A[k] = (byte k, byte k+1) as a u16 pair, so the
+         * packed sums below are pixels (x, x+1) and (x+2, x+3): 257 * 255 = 65535 still fits a u16 lane */
+        u16x2 A[9];
+#define BLUR_PAIR(k, hi, lo, i) A[k] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (uint32_t)(i) | ((uint32_t)((i) + 1) << 16)))
+        BLUR_PAIR(0, w1, w0, 0); BLUR_PAIR(1, w1, w0, 1); BLUR_PAIR(2, w1, w0, 2); BLUR_PAIR(3, w1, w0, 3);
+        BLUR_PAIR(4, w2, w1, 0); BLUR_PAIR(5, w2, w1, 1); BLUR_PAIR(6, w2, w1, 2); BLUR_PAIR(7, w2, w1, 3);
+        BLUR_PAIR(8, w2, w1, 4);
+#undef BLUR_PAIR
+        const u16x2 t18 = {18, 18}, t34 = {34, 34}, t49 = {49, 49}, t55 = {55, 55};
+        const u16x2 h01 = t18 * (A[0] + A[6]) + t34 * (A[1] + A[5]) + t49 * (A[2] + A[4]) + t55 * A[3];
+        const u16x2 h23 = t18 * (A[2] + A[8]) + t34 * (A[3] + A[7]) + t49 * (A[4] + A[6]) + t55 * A[5];
+        *reinterpret_cast<uint2*>(&hb[r * DRFE_BLUR_TW + cg * 4]) =
+            make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
     }
     __syncthreads();
 #pragma unroll
@@ -724,8 +728,11 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             const uint2 p = *reinterpret_cast<const uint2*>(&hb[(r + k) * DRFE_BLUR_TW + cg * 4]);
-            acc[0] += tap[k] * (p.x & 0xFFFF); acc[1] += tap[k] * (p.x >> 16);
-            acc[2] += tap[k] * (p.y & 0xFFFF); acc[3] += tap[k] * (p.y >> 16);
+            /* acc += tap * (16-bit half of p): one VOP3 each, the half picked by op_sel (no unpacking) */
+            asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(p.x), "s"(tap[k]));
+            asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(acc[1]) : "v"(p.x), "s"(tap[k]));
+            asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(acc[2]) : "v"(p.y), "s"(tap[k]));
+            asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(acc[3]) : "v"(p.y), "s"(tap[k]));
         }
         uint32_t out = 0;
 #pragma unroll
