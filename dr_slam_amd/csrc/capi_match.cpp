@@ -391,4 +391,99 @@ int drfe_match_bf_knn(drfe_ctx* c, const uint8_t* q, int nq, const uint8_t* t, i
     return DRFE_OK;
 }
 
+
+/* ---- LSDmatcher::SearchByProjection (row a-15) ---------------------------------------------------- */
+
+static int line_search_run(drfe_ctx* c, const std::vector<LineQuery>* hostQ, const drfe_map_line* last, int n,
+                           const float* TcwCur, const drfe_camera* cam, int fwd, int bwd, float th,
+                           const drfe_keyline* cur_lines, const uint8_t* cur_desc, int n_cur, float nnratio,
+                           const uint8_t* cur_obs, int32_t* cur_ml, int* nmatches)
+{
+    *nmatches = 0;
+    if (n == 0 || n_cur == 0) return DRFE_OK;
+    if (n_cur > 4096 || n > 65536) { c->err = "lsd_search_by_projection: too many lines"; return DRFE_ERR_CAPACITY; }
+    HIPCHK(c, hipSetDevice(c->device));
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    std::vector<LineCur> lc(n_cur);
+    std::vector<uint8_t> claim(n_cur);
+    for (int i = 0; i < n_cur; i++) {
+        lc[i].ptX = cur_lines[i].pt_x; lc[i].ptY = cur_lines[i].pt_y; lc[i].angle = cur_lines[i].angle;
+        lc[i].octave = cur_lines[i].octave;
+        claim[i] = cur_ml[i] >= 0 ? (uint8_t)(1 | ((cur_obs ? cur_obs[i] : 1) ? 2 : 0)) : 0;
+    }
+    /* one scratch block: queries | map lines | Tcw | current lines | descriptors | claims | cur_ml | count */
+    const size_t oQ = 0, oL = oQ + sizeof(LineQuery) * n, oT = oL + (last ? sizeof(drfe_map_line) * n : 0),
+                 oC = oT + 64, oD = oC + sizeof(LineCur) * n_cur, oK = oD + (size_t)n_cur * 32,
+                 oM = (oK + n_cur + 15) & ~(size_t)15, oN = oM + sizeof(int) * n_cur, total = oN + 16;
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, total));
+    hipStream_t s = c->stream;
+    hipError_t e = hipSuccess;
+    auto up = [&](size_t off, const void* src, size_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s); };
+    if (hostQ) up(oQ, hostQ->data(), sizeof(LineQuery) * n);
+    else { up(oL, last, sizeof(drfe_map_line) * n); up(oT, TcwCur, 64); }
+    up(oC, lc.data(), sizeof(LineCur) * n_cur);
+    up(oD, cur_desc, (size_t)n_cur * 32);
+    up(oK, claim.data(), n_cur);
+    up(oM, cur_ml, sizeof(int) * n_cur);
+    if (e == hipSuccess && !hostQ)
+        e = drfe_launch_line_projection(reinterpret_cast<const drfe_map_line*>(d + oL), n, reinterpret_cast<const float*>(d + oT),
+                                        *cam, fwd, bwd, m->d_scale, th, reinterpret_cast<LineQuery*>(d + oQ), s);
+    if (e == hipSuccess)
+        e = drfe_launch_line_search(reinterpret_cast<const LineQuery*>(d + oQ), n, reinterpret_cast<const LineCur*>(d + oC), d + oD,
+                                    n_cur, nnratio, d + oK, reinterpret_cast<int*>(d + oM), reinterpret_cast<int*>(d + oN), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(cur_ml, d + oM, sizeof(int) * n_cur, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(nmatches, d + oN, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("lsd_search_by_projection: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    return DRFE_OK;
+}
+
+int drfe_lsd_search_by_projection_last(drfe_ctx* c, const float* Tcw_cur, const float* Tcw_last, const drfe_camera* cam,
+                                       const drfe_map_line* last_lines, int n_last, const drfe_keyline* cur_lines,
+                                       const uint8_t* cur_desc, int n_cur, float th, int mono, float nnratio,
+                                       const uint8_t* cur_obs, int32_t* cur_ml, int* nmatches)
+{
+    if (!c || !Tcw_cur || !Tcw_last || !cam || !nmatches || n_last < 0 || n_cur < 0) return DRFE_ERR_INVALID;
+    if ((n_last && !last_lines) || (n_cur && (!cur_lines || !cur_desc || !cur_ml))) return DRFE_ERR_INVALID;
+    for (int i = 0; i < n_last; i++)
+        if (last_lines[i].valid && (last_lines[i].octave < 0 || last_lines[i].octave >= c->cfg.nlevels)) {
+            c->err = "lsd_search_by_projection_last: key line octave outside the scale table";
+            return DRFE_ERR_INVALID;
+        }
+    int fwd = 0, bwd = 0;
+    motion_flags(Tcw_cur, Tcw_last, cam->bf / cam->fx, mono, &fwd, &bwd);
+    return line_search_run(c, nullptr, last_lines, n_last, Tcw_cur, cam, fwd, bwd, th, cur_lines, cur_desc, n_cur, nnratio,
+                           cur_obs, cur_ml, nmatches);
+}
+
+int drfe_lsd_search_by_projection_map(drfe_ctx* c, const drfe_tracked_line* lines, int n, const drfe_keyline* cur_lines,
+                                      const uint8_t* cur_desc, int n_cur, float th, float nnratio, const uint8_t* cur_obs,
+                                      int32_t* cur_ml, int* nmatches)
+{
+    if (!c || !nmatches || n < 0 || n_cur < 0) return DRFE_ERR_INVALID;
+    if ((n && !lines) || (n_cur && (!cur_lines || !cur_desc || !cur_ml))) return DRFE_ERR_INVALID;
+    /* window per map line, src/LSDmatcher.cpp:152-161 (RadiusByViewingCos 5 / 8, r *= th, levels l-1..l) */
+    std::vector<LineQuery> q(n);
+    const bool bFactor = th != 1.0;
+    for (int i = 0; i < n; i++) {
+        const drfe_tracked_line& t = lines[i];
+        LineQuery& Q = q[i];
+        std::memset(&Q, 0, sizeof(Q));
+        Q.valid = t.in_view ? 1 : 0;
+        if (Q.valid && (t.level < 0 || t.level >= c->cfg.nlevels)) { c->err = "tracked line level out of range"; return DRFE_ERR_INVALID; }
+        float r = ((double)t.view_cos > 0.998) ? 5.0f : 8.0f;
+        if (bFactor) r *= th;
+        Q.obs = t.obs_positive ? 1 : 0;
+        Q.minLevel = t.level - 1; Q.maxLevel = t.level;
+        Q.x1 = t.x1; Q.y1 = t.y1; Q.x2 = t.x2; Q.y2 = t.y2;
+        Q.r = Q.valid ? r * c->scale[t.level] : 0.f;
+        std::memcpy(Q.desc, t.desc, 32);
+    }
+    return line_search_run(c, &q, nullptr, n, nullptr, nullptr, 0, 0, th, cur_lines, cur_desc, n_cur, nnratio, cur_obs,
+                           cur_ml, nmatches);
+}
+
 } /* extern "C" */

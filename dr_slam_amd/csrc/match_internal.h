@@ -47,6 +47,21 @@ hipError_t drfe_launch_mappoints_last(drfe_ctx* c, const MatchBuffers& mb, const
 hipError_t drfe_launch_bf_knn(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, int k, int* dIdx, int* dDist,
                               hipStream_t s);
 
+/* one GetLinesInArea + best/second scan of LSDmatcher::SearchByProjection (src/LSDmatcher.cpp:76-136) */
+struct LineQuery {
+    int valid, obs;               /* obs: Observations() > 0 of the map line (its claim blocks later lines) */
+    int minLevel, maxLevel;
+    float x1, y1, x2, y2, r;
+    uint32_t desc[8];
+};
+struct LineCur { float ptX, ptY, angle; int octave; };   /* the KeyLine fields the search reads */
+
+hipError_t drfe_launch_line_projection(const drfe_map_line* d_lines, int n, const float* d_TcwCur, const drfe_camera& cam,
+                                       int forward, int backward, const float* d_scale, float th, LineQuery* d_q,
+                                       hipStream_t s);
+hipError_t drfe_launch_line_search(const LineQuery* d_q, int n, const LineCur* d_cur, const uint8_t* d_desc, int nCur,
+                                   float nnratio, uint8_t* d_claim, int* d_curMl, int* d_nmatches, hipStream_t s);
+
 MatchBuffers* drfe_match_buffers(drfe_ctx* c);   /* lazily allocated, owned by the context */
 void drfe_match_buffers_free(drfe_ctx* c);
 #endif

@@ -674,3 +674,130 @@ hipError_t drfe_launch_bf_knn(const uint8_t* dQ, int nq, const uint8_t* dT, int 
     hipLaunchKernelGGL(k_bf_knn, dim3((nq + 63) / 64), dim3(64), 0, s, dQ, nq, dT, nt, k, dIdx, dDist);
     return hipGetLastError();
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* LSDmatcher::SearchByProjection                                               */
+
+/* projection part of the (Frame, Frame) overload, src/LSDmatcher.cpp:39-85 */
+__global__ __launch_bounds__(64) void k_line_queries_last(const drfe_map_line* __restrict__ lines, int n,
+                                                          const float* __restrict__ TcwCur, drfe_camera cam, int forward,
+                                                          int backward, const float* __restrict__ scale, float th,
+                                                          LineQuery* __restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const drfe_map_line ml = lines[i];
+    LineQuery q;
+    q.valid = 0; q.obs = ml.obs_positive ? 1 : 0; q.minLevel = 0; q.maxLevel = 0;
+    q.x1 = q.y1 = q.x2 = q.y2 = q.r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) q.desc[k] = reinterpret_cast<const uint32_t*>(ml.desc)[k];
+    if (ml.valid) {
+        const float SP[3] = {(float)ml.world[0], (float)ml.world[1], (float)ml.world[2]};
+        const float EP[3] = {(float)ml.world[3], (float)ml.world[4], (float)ml.world[5]};
+        float T[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) T[k] = TcwCur[k];
+        float SPc[3], EPc[3];
+        mat3_mul_add(T, SP, SPc);
+        mat3_mul_add(T, EP, EPc);
+        bool ok = !(SPc[2] < 0.0f || EPc[2] < 0.0f);
+        const float invz1 = 1.0f / SPc[2];
+        const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+        if (u1 < cam.min_x || u1 > cam.max_x || v1 < cam.min_y || v1 > cam.max_y) ok = false;
+        const float invz2 = 1.0f / EPc[2];
+        const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+        if (u2 < cam.min_x || u2 > cam.max_x || v2 < cam.min_y || v2 > cam.max_y) ok = false;
+        if (ok) {
+            const int oct = ml.octave;
+            q.valid = 1;
+            q.x1 = u1; q.y1 = v1; q.x2 = u2; q.y2 = v2;
+            q.r = th * scale[oct];
+            if (forward) { q.minLevel = oct; q.maxLevel = -1; }
+            else if (backward) { q.minLevel = 0; q.maxLevel = oct; }
+            else { q.minLevel = oct - 1; q.maxLevel = oct + 1; }
+        }
+    }
+    out[i] = q;
+}
+
+/* One wavefront replays the map-line loop: lanes over the current key lines (Frame::GetLinesInArea test,
+ * claim check, LBD Hamming distance), wave reductions for best = min (distance, index) and second = the
+ * same over the rest — what the reference's strict-< scan in index order leaves in bestDist/bestLevel and
+ * bestDist2/bestLevel2 (src/LSDmatcher.cpp:95-136). */
+__global__ __launch_bounds__(64) void k_line_search(const LineQuery* __restrict__ queries, int n,
+                                                    const LineCur* __restrict__ cur, const uint8_t* __restrict__ desc,
+                                                    int nCur, float nnratio, const uint8_t* __restrict__ claimIn /* bit0 held, bit1 obs */,
+                                                    int* __restrict__ curMl, int* __restrict__ nmatchesOut)
+{
+    extern __shared__ unsigned char claim[];               /* [nCur] */
+    const int lane = threadIdx.x;
+    for (int k = lane; k < nCur; k += WAVE) claim[k] = claimIn[k];
+    __syncthreads();
+    int nmatches = 0;
+    for (int i = 0; i < n; i++) {
+        const LineQuery q = queries[i];
+        if (!q.valid) continue;
+        const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel > 0);
+        const float r2 = q.r * q.r;
+        const double rs = (double)q.r * 0.01;
+        const float sl0 = (q.y1 - q.y2) / (q.x1 - q.x2);
+        const double mxq = 0.5 * (double)(q.x1 + q.x2), myq = 0.5 * (double)(q.y1 + q.y2);
+        const uint64_t q0 = (uint64_t)q.desc[0] | ((uint64_t)q.desc[1] << 32), q1 = (uint64_t)q.desc[2] | ((uint64_t)q.desc[3] << 32),
+                       q2 = (uint64_t)q.desc[4] | ((uint64_t)q.desc[5] << 32), q3 = (uint64_t)q.desc[6] | ((uint64_t)q.desc[7] << 32);
+        /* per-lane best and second over its stride of lines; key = distance << 16 | index */
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        for (int idx = lane; idx < nCur; idx += WAVE) {
+            const LineCur kl = cur[idx];
+            const double mx = mxq - (double)kl.ptX, my = myq - (double)kl.ptY;
+            const float distance = (float)(mx * mx + my * my);
+            if (distance > r2) continue;
+            const float slope = sl0 - kl.angle;
+            if ((double)slope > rs) continue;
+            if (bCheckLevels) {
+                if (kl.octave < q.minLevel) continue;
+                if (q.maxLevel >= 0 && kl.octave > q.maxLevel) continue;
+            }
+            if ((claim[idx] & 3) == 3) continue;
+            const uint64_t* d = reinterpret_cast<const uint64_t*>(desc + (size_t)idx * 32);
+            const int dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
+            const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)idx;
+            if (key < k1) { k2 = k1; k1 = key; }
+            else if (key < k2) k2 = key;
+        }
+        const uint32_t b1 = wave_min_u32(k1);
+        if (b1 == 0xFFFFFFFFu) continue;                   /* vIndices empty or every candidate claimed */
+        const uint32_t b2 = wave_min_u32(k1 == b1 ? k2 : k1);
+        const int bestDist = (int)(b1 >> 16), bestIdx = (int)(b1 & 0xFFFF);
+        int bestDist2 = 256, bestLevel2 = -1;
+        if (b2 != 0xFFFFFFFFu) { bestDist2 = (int)(b2 >> 16); bestLevel2 = cur[b2 & 0xFFFF].octave; }
+        const int bestLevel = cur[bestIdx].octave;
+        if (bestDist <= 100) {                             /* TH_HIGH */
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            if (lane == 0) {
+                curMl[bestIdx] = i;
+                claim[bestIdx] = (uint8_t)(1 | (q.obs ? 2 : 0));
+            }
+            __syncthreads();                               /* one wave: orders the LDS claim write */
+            nmatches++;
+        }
+    }
+    if (lane == 0) *nmatchesOut = nmatches;
+}
+
+hipError_t drfe_launch_line_projection(const drfe_map_line* d_lines, int n, const float* d_TcwCur, const drfe_camera& cam,
+                                       int forward, int backward, const float* d_scale, float th, LineQuery* d_q,
+                                       hipStream_t s)
+{
+    hipLaunchKernelGGL(k_line_queries_last, dim3((n + 63) / 64), dim3(64), 0, s, d_lines, n, d_TcwCur, cam, forward,
+                       backward, d_scale, th, d_q);
+    return hipGetLastError();
+}
+
+hipError_t drfe_launch_line_search(const LineQuery* d_q, int n, const LineCur* d_cur, const uint8_t* d_desc, int nCur,
+                                   float nnratio, uint8_t* d_claim, int* d_curMl, int* d_nmatches, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_line_search, dim3(1), dim3(64), (size_t)((nCur + 15) & ~15), s, d_q, n, d_cur, d_desc, nCur, nnratio, d_claim, d_curMl,
+                       d_nmatches);
+    return hipGetLastError();
+}

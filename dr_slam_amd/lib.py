@@ -33,9 +33,15 @@ SYMBOLS = (
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
-    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages", "drfe_lsd_search_by_descriptor",
+    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_by_projection_last",
+    "drfe_lsd_search_by_projection_map",
 )
 
+MAPLINE_DTYPE = np.dtype([("valid", "<i4"), ("octave", "<i4"), ("obs_positive", "<i4"), ("pad", "<i4"),
+                          ("world", "<f8", (6,)), ("desc", "u1", (32,))])            # drfe_map_line, 96 B
+TRACKED_LINE_DTYPE = np.dtype([("in_view", "<i4"), ("level", "<i4"), ("obs_positive", "<i4"), ("x1", "<f4"),
+                               ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("view_cos", "<f4"),
+                               ("desc", "u1", (32,))])                                # drfe_tracked_line, 64 B
 KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"),
                           ("response", "<f4"), ("size", "<f4"), ("start_point_x", "<f4"), ("start_point_y", "<f4"),
                           ("end_point_x", "<f4"), ("end_point_y", "<f4"), ("s_point_in_octave_x", "<f4"),
@@ -110,6 +116,9 @@ def load() -> C.CDLL:
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_search_by_descriptor.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.POINTER(i32)]
+    L.drfe_lsd_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, i32, C.c_float, vp, vp,
+                                                     C.POINTER(i32)]
+    L.drfe_lsd_search_by_projection_map.argtypes = [vp, vp, i32, vp, vp, i32, C.c_float, C.c_float, vp, vp, C.POINTER(i32)]
     L.drfe_lsd_extract.argtypes = [vp, vp, i32, i32, sz, i32, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_lsd_stages.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_voc_upload.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
@@ -300,6 +309,36 @@ class Context:
         n = C.c_int()
         self._chk(self.L.drfe_lsd_search_by_descriptor(self.h, _p(dq), len(dq), _p(dt), len(dt), _p(has), mode, _p(out),
                                                        C.byref(n)), "drfe_lsd_search_by_descriptor")
+        return n.value, out
+
+    def lsd_search_by_projection_last(self, Tcw_cur, Tcw_last, cam, last_lines, cur_lines, cur_desc, th, mono, nnratio,
+                                      cur_ml, cur_obs=None):
+        """LSDmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono); returns (nmatches, cur_ml)."""
+        tc = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
+        tl = np.ascontiguousarray(Tcw_last, np.float32).reshape(16)
+        ll = np.ascontiguousarray(last_lines, MAPLINE_DTYPE)
+        kl = np.ascontiguousarray(cur_lines, KEYLINE_DTYPE)
+        cd = np.ascontiguousarray(cur_desc, np.uint8)
+        out = np.ascontiguousarray(cur_ml, np.int32).copy()
+        obs = None if cur_obs is None else np.ascontiguousarray(cur_obs, np.uint8)
+        n = C.c_int()
+        self._chk(self.L.drfe_lsd_search_by_projection_last(self.h, _p(tc), _p(tl), C.byref(cam), _p(ll), len(ll), _p(kl),
+                                                            _p(cd), len(kl), C.c_float(th), int(mono), C.c_float(nnratio),
+                                                            _p(obs), _p(out), C.byref(n)),
+                  "drfe_lsd_search_by_projection_last")
+        return n.value, out
+
+    def lsd_search_by_projection_map(self, lines, cur_lines, cur_desc, th, nnratio, cur_ml, cur_obs=None):
+        """LSDmatcher::SearchByProjection(F, vpMapLines, th); returns (nmatches, cur_ml)."""
+        tl = np.ascontiguousarray(lines, TRACKED_LINE_DTYPE)
+        kl = np.ascontiguousarray(cur_lines, KEYLINE_DTYPE)
+        cd = np.ascontiguousarray(cur_desc, np.uint8)
+        out = np.ascontiguousarray(cur_ml, np.int32).copy()
+        obs = None if cur_obs is None else np.ascontiguousarray(cur_obs, np.uint8)
+        n = C.c_int()
+        self._chk(self.L.drfe_lsd_search_by_projection_map(self.h, _p(tl), len(tl), _p(kl), _p(cd), len(kl), C.c_float(th),
+                                                           C.c_float(nnratio), _p(obs), _p(out), C.byref(n)),
+                  "drfe_lsd_search_by_projection_map")
         return n.value, out
 
     def bf_knn(self, Q, T, k):

@@ -215,6 +215,39 @@ int drfe_lsd_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t st
 int drfe_lsd_stages(drfe_ctx* ctx, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy,
                     int* sw, int* sh);
 
+/* LSDmatcher::SearchByProjection, src/LSDmatcher.cpp:20-139 (Frame, Frame) and :141-211 (Frame,
+ * vector<MapLine*>), with Frame::GetLinesInArea (src/Frame.cc:781-813): project the 3-D end points with
+ * Tcw (float cv::Mat path), collect the current key lines whose midpoint lies within the radius and
+ * whose slope difference passes, best / second-best LBD Hamming distance in index order, TH_HIGH = 100
+ * and the same-octave ratio test, sequential claims (a line already holding a MapLine with
+ * Observations() > 0 is skipped).  One wavefront replays the loop on the device. */
+typedef struct drfe_map_line {      /* read through LastFrame.mvpMapLines[i] / mvKeylinesUn[i] */
+    int32_t valid;                  /* pML && !pML->isBad() && !mvbLineOutlier[i] */
+    int32_t octave;                 /* LastFrame.mvKeylinesUn[i].octave */
+    int32_t obs_positive;           /* pML->Observations() > 0 */
+    int32_t pad;
+    double world[6];                /* MapLine::GetWorldPos(): start xyz, end xyz */
+    uint8_t desc[32];
+} drfe_map_line;
+typedef struct drfe_tracked_line {  /* fields Frame::isInFrustum(MapLine*) leaves on the map line */
+    int32_t in_view;                /* pML && !isBad() && mbTrackInView */
+    int32_t level;                  /* mnTrackScaleLevel */
+    int32_t obs_positive;
+    float x1, y1, x2, y2;           /* mTrackProjX1 / Y1 / X2 / Y2 */
+    float view_cos;
+    uint8_t desc[32];
+} drfe_tracked_line;
+/* cur_lines / cur_desc: the current frame's key lines (pt, angle, octave are read) and LBD rows.
+ * cur_ml in/out, n_cur entries: -1 = no MapLine, >= 0 = holds one (cur_obs[i] = its Observations() > 0,
+ * NULL = all); a new match writes the index of the matched last/tracked record.  Synchronous. */
+int drfe_lsd_search_by_projection_last(drfe_ctx* ctx, const float* Tcw_cur, const float* Tcw_last,
+                                       const drfe_camera* cam, const drfe_map_line* last_lines, int n_last,
+                                       const drfe_keyline* cur_lines, const uint8_t* cur_desc, int n_cur, float th,
+                                       int mono, float nnratio, const uint8_t* cur_obs, int32_t* cur_ml, int* nmatches);
+int drfe_lsd_search_by_projection_map(drfe_ctx* ctx, const drfe_tracked_line* lines, int n,
+                                      const drfe_keyline* cur_lines, const uint8_t* cur_desc, int n_cur, float th,
+                                      float nnratio, const uint8_t* cur_obs, int32_t* cur_ml, int* nmatches);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */

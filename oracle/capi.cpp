@@ -397,6 +397,23 @@ int orc_lsd_search_by_gap(const uint8_t* dq, int nq, const uint8_t* dt, int nt, 
     return lsd_search_by_gap(dq, nq, dt, nt, has, out);
 }
 
+int orc_lsd_search_by_projection_last(const float* cam9, const float* TcwCur, const float* TcwLast, const float* scale,
+                                      const MapLineRec* last, int nLast, const LineRec* cur, const uint8_t* curDesc,
+                                      int nCur, float th, int mono, float nnratio, const uint8_t* curObs, int32_t* curML)
+{
+    const LineCamera cam = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    return lsd_search_by_projection_last(cam, TcwCur, TcwLast, scale, last, nLast, cur, curDesc, nCur, th, mono != 0,
+                                         nnratio, curObs, curML);
+}
+int orc_lsd_search_by_projection_map(const float* scale, const TrackedLineRec* lines, int n, const LineRec* cur,
+                                     const uint8_t* curDesc, int nCur, float th, float nnratio, const uint8_t* curObs,
+                                     int32_t* curML)
+{
+    return lsd_search_by_projection_map(scale, lines, n, cur, curDesc, nCur, th, nnratio, curObs, curML);
+}
+int orc_sizeof_maplinerec() { return (int)sizeof(MapLineRec); }
+int orc_sizeof_trackedlinerec() { return (int)sizeof(TrackedLineRec); }
+
 int orc_sizeof_keypoint() { return (int)sizeof(KeyPoint); }
 int orc_sizeof_mappointrec() { return (int)sizeof(MapPointRec); }
 int orc_sizeof_trackedpointrec() { return (int)sizeof(TrackedPointRec); }

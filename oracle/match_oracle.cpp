@@ -323,4 +323,139 @@ int lsd_search_by_gap(const uint8_t* descQ, int nQ, const uint8_t* descT, int nT
     return nmatches;
 }
 
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* LSDmatcher::SearchByProjection (row a-15)                                                            */
+
+/* Frame::GetLinesInArea, src/Frame.cc:781-813.  `0.5 * (x1 + x2)`: float sum, the rest of the distance in
+ * double, stored to a float; slope in float, compared against the double `r * 0.01`; the level test
+ * switches on with maxLevel > 0 (not >= 0 as in GetFeaturesInArea). */
+void get_lines_in_area(const LineRec* lines, int n, float x1, float y1, float x2, float y2, float r, int minLevel,
+                       int maxLevel, std::vector<int>& out)
+{
+    out.clear();
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel > 0);
+    for (int i = 0; i < n; i++) {
+        const LineRec& kl = lines[i];
+        const double mx = 0.5 * (double)(x1 + x2) - (double)kl.ptX, my = 0.5 * (double)(y1 + y2) - (double)kl.ptY;
+        const float distance = (float)(mx * mx + my * my);
+        if (distance > r * r) continue;
+        const float slope = (y1 - y2) / (x1 - x2) - kl.angle;
+        if ((double)slope > (double)r * 0.01) continue;
+        if (bCheckLevels) {
+            if (kl.octave < minLevel) continue;
+            if (maxLevel >= 0 && kl.octave > maxLevel) continue;
+        }
+        out.push_back(i);
+    }
+}
+
+/* the candidate scan shared by both variants, src/LSDmatcher.cpp:95-136 / :168-209 */
+static bool best_line(const std::vector<int>& cand, const LineRec* cur, const uint8_t* curDesc, const uint8_t* desc,
+                      const int32_t* curML, const std::vector<uint8_t>& claimObs, float nnratio, int& bestIdx)
+{
+    const int TH_HIGH = 100;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
+    bestIdx = -1;
+    for (int idx : cand) {
+        if (curML[idx] >= 0 && claimObs[idx]) continue;
+        const int dist = descriptor_distance_swar(desc, curDesc + (size_t)idx * 32);
+        if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = cur[idx].octave; bestIdx = idx;
+        } else if (dist < bestDist2) {
+            bestLevel2 = cur[idx].octave; bestDist2 = dist;
+        }
+    }
+    if (bestDist <= TH_HIGH) {
+        if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) return false;
+        return true;
+    }
+    return false;
+}
+
+int lsd_search_by_projection_last(const LineCamera& cam, const float TcwCur[16], const float TcwLast[16],
+                                  const float* scaleFactors, const MapLineRec* last, int nLast, const LineRec* cur,
+                                  const uint8_t* curDesc, int nCur, float th, bool bMono, float nnratio,
+                                  const uint8_t* curObs, int32_t* curML)
+{
+    int nmatches = 0;
+    float Rcw[9], tcw[3], Rlw[9], tlw[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) { Rcw[r * 3 + c] = TcwCur[r * 4 + c]; Rlw[r * 3 + c] = TcwLast[r * 4 + c]; }
+        tcw[r] = TcwCur[r * 4 + 3];
+        tlw[r] = TcwLast[r * 4 + 3];
+    }
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {   /* -Rcw.t()*tcw: general gemm path, double accumulation (as for points) */
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Rcw[k * 3 + i] * (double)tcw[k];
+        twc[i] = (float)(s * -1.0);
+    }
+    mat3_mul_add(Rlw, twc, tlw, tlc);
+    const bool bForward = tlc[2] > cam.mb && !bMono;
+    const bool bBackward = -tlc[2] > cam.mb && !bMono;
+    std::vector<uint8_t> claimObs(nCur, 0);
+    for (int i = 0; i < nCur; i++)
+        if (curML[i] >= 0) claimObs[i] = curObs ? curObs[i] : 1;
+    std::vector<int> cand;
+    for (int i = 0; i < nLast; i++) {
+        const MapLineRec& ml = last[i];
+        if (!ml.valid) continue;
+        const float SP[3] = {(float)ml.world[0], (float)ml.world[1], (float)ml.world[2]};
+        const float EP[3] = {(float)ml.world[3], (float)ml.world[4], (float)ml.world[5]};
+        float SPc[3], EPc[3];
+        mat3_mul_add(Rcw, SP, tcw, SPc);
+        mat3_mul_add(Rcw, EP, tcw, EPc);
+        if (SPc[2] < 0.0f || EPc[2] < 0.0f) continue;
+        const float invz1 = 1.0f / SPc[2];
+        const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+        if (u1 < cam.minX || u1 > cam.maxX) continue;
+        if (v1 < cam.minY || v1 > cam.maxY) continue;
+        const float invz2 = 1.0f / EPc[2];
+        const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+        if (u2 < cam.minX || u2 > cam.maxX) continue;
+        if (v2 < cam.minY || v2 > cam.maxY) continue;
+        const int oct = ml.octave;
+        const float radius = th * scaleFactors[oct];
+        if (bForward) get_lines_in_area(cur, nCur, u1, v1, u2, v2, radius, oct, -1, cand);
+        else if (bBackward) get_lines_in_area(cur, nCur, u1, v1, u2, v2, radius, 0, oct, cand);
+        else get_lines_in_area(cur, nCur, u1, v1, u2, v2, radius, oct - 1, oct + 1, cand);
+        if (cand.empty()) continue;
+        int bestIdx;
+        if (best_line(cand, cur, curDesc, ml.desc, curML, claimObs, nnratio, bestIdx)) {
+            curML[bestIdx] = i;
+            claimObs[bestIdx] = ml.obsPositive ? 1 : 0;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+int lsd_search_by_projection_map(const float* scaleFactors, const TrackedLineRec* lines, int n, const LineRec* cur,
+                                 const uint8_t* curDesc, int nCur, float th, float nnratio, const uint8_t* curObs,
+                                 int32_t* curML)
+{
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<uint8_t> claimObs(nCur, 0);
+    for (int i = 0; i < nCur; i++)
+        if (curML[i] >= 0) claimObs[i] = curObs ? curObs[i] : 1;
+    std::vector<int> cand;
+    for (int i = 0; i < n; i++) {
+        const TrackedLineRec& tl = lines[i];
+        if (!tl.inView) continue;
+        float r = tl.viewCos > 0.998 ? 5.0f : 8.0f;   /* RadiusByViewingCos, :369-375 (double compare) */
+        if (bFactor) r *= th;
+        get_lines_in_area(cur, nCur, tl.x1, tl.y1, tl.x2, tl.y2, r * scaleFactors[tl.level], tl.level - 1, tl.level, cand);
+        if (cand.empty()) continue;
+        int bestIdx;
+        if (best_line(cand, cur, curDesc, tl.desc, curML, claimObs, nnratio, bestIdx)) {
+            curML[bestIdx] = i;
+            claimObs[bestIdx] = tl.obsPositive ? 1 : 0;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
 } // namespace orc

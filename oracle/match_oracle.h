@@ -53,5 +53,41 @@ int lsd_search_by_descriptor(const uint8_t* descKF, int nKF, const uint8_t* kfHa
                              int32_t* out);
 int lsd_search_by_gap(const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, const uint8_t* trainHasLine, int32_t* out);
 
+
+/* --- LSDmatcher::SearchByProjection, src/LSDmatcher.cpp:20-211 --------------- */
+/* the KeyLine fields Frame::GetLinesInArea and the matcher read (src/Frame.cc:781-813) */
+struct LineRec { float ptX, ptY, angle; int32_t octave; };
+/* what the (Frame, Frame) variant reads through LastFrame.mvpMapLines[i] / mvKeylinesUn[i] */
+struct MapLineRec {
+    int32_t valid;        /* pML && !pML->isBad() && !mvbLineOutlier[i] */
+    int32_t octave;       /* LastFrame.mvKeylinesUn[i].octave */
+    int32_t obsPositive;  /* pML->Observations() > 0 (a claim by it blocks later lines, :101-103) */
+    int32_t pad;
+    double world[6];      /* GetWorldPos(): start xyz, end xyz */
+    uint8_t desc[32];
+};
+/* what the (Frame, vector<MapLine*>) variant reads (fields set by Frame::isInFrustum for lines) */
+struct TrackedLineRec {
+    int32_t inView;       /* pML && !isBad() && mbTrackInView */
+    int32_t level;        /* mnTrackScaleLevel */
+    int32_t obsPositive;
+    float x1, y1, x2, y2; /* mTrackProjX1/Y1/X2/Y2 */
+    float viewCos;
+    uint8_t desc[32];
+};
+struct LineCamera { float fx, fy, cx, cy, mb, minX, maxX, minY, maxY; };
+
+void get_lines_in_area(const LineRec* lines, int n, float x1, float y1, float x2, float y2, float r, int minLevel,
+                       int maxLevel, std::vector<int>& out);
+/* curML in/out: >= 0 = holds a map line (curObs[i] says whether Observations() > 0; NULL = all positive);
+ * new matches are written as the index i of the matched record.  Returns nmatches. */
+int lsd_search_by_projection_last(const LineCamera& cam, const float TcwCur[16], const float TcwLast[16],
+                                  const float* scaleFactors, const MapLineRec* last, int nLast, const LineRec* cur,
+                                  const uint8_t* curDesc, int nCur, float th, bool bMono, float nnratio,
+                                  const uint8_t* curObs, int32_t* curML);
+int lsd_search_by_projection_map(const float* scaleFactors, const TrackedLineRec* lines, int n, const LineRec* cur,
+                                 const uint8_t* curDesc, int nCur, float th, float nnratio, const uint8_t* curObs,
+                                 int32_t* curML);
+
 } // namespace orc
 #endif

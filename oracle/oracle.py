@@ -335,6 +335,58 @@ def lsd_search_by_gap(desc_q, desc_t, train_has_line=None):
     return n, out
 
 
+LINE_DTYPE = np.dtype([("pt_x", "<f4"), ("pt_y", "<f4"), ("angle", "<f4"), ("octave", "<i4")])          # orc::LineRec
+MAPLINE_DTYPE = np.dtype([("valid", "<i4"), ("octave", "<i4"), ("obs_positive", "<i4"), ("pad", "<i4"),
+                          ("world", "<f8", (6,)), ("desc", "u1", (32,))])                                 # orc::MapLineRec
+TRACKED_LINE_DTYPE = np.dtype([("in_view", "<i4"), ("level", "<i4"), ("obs_positive", "<i4"), ("x1", "<f4"),
+                               ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("view_cos", "<f4"),
+                               ("desc", "u1", (32,))])                                                     # orc::TrackedLineRec
+
+
+def _line_recs(keylines):
+    out = np.zeros(len(keylines), LINE_DTYPE)
+    for f in ("pt_x", "pt_y", "angle", "octave"):
+        out[f] = keylines[f]
+    return out
+
+
+def lsd_search_by_projection_last(cam9, Tcw_cur, Tcw_last, scale, last_lines, cur_keylines, cur_desc, th, mono, nnratio,
+                                  cur_ml, cur_obs=None):
+    """LSDmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), src/LSDmatcher.cpp:20-139.
+    cam9 = (fx, fy, cx, cy, mb, minX, maxX, minY, maxY)."""
+    L = lib()
+    assert L.orc_sizeof_maplinerec() == MAPLINE_DTYPE.itemsize
+    cam = _c(cam9, np.float32)
+    tc, tl = _c(Tcw_cur, np.float32).reshape(16), _c(Tcw_last, np.float32).reshape(16)
+    sc = _c(scale, np.float32)
+    ll = np.ascontiguousarray(last_lines, MAPLINE_DTYPE)
+    cur = _line_recs(cur_keylines)
+    cd = _c(cur_desc, np.uint8)
+    out = _c(cur_ml, np.int32).copy()
+    obs = None if cur_obs is None else _c(cur_obs, np.uint8)
+    L.orc_lsd_search_by_projection_last.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                                                       C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    n = L.orc_lsd_search_by_projection_last(_p(cam), _p(tc), _p(tl), _p(sc), _p(ll), len(ll), _p(cur), _p(cd), len(cur),
+                                            th, int(mono), nnratio, _p(obs), _p(out))
+    return n, out
+
+
+def lsd_search_by_projection_map(scale, lines, cur_keylines, cur_desc, th, nnratio, cur_ml, cur_obs=None):
+    """LSDmatcher::SearchByProjection(F, vpMapLines, th), src/LSDmatcher.cpp:141-211."""
+    L = lib()
+    assert L.orc_sizeof_trackedlinerec() == TRACKED_LINE_DTYPE.itemsize
+    sc = _c(scale, np.float32)
+    tl = np.ascontiguousarray(lines, TRACKED_LINE_DTYPE)
+    cur = _line_recs(cur_keylines)
+    cd = _c(cur_desc, np.uint8)
+    out = _c(cur_ml, np.int32).copy()
+    obs = None if cur_obs is None else _c(cur_obs, np.uint8)
+    L.orc_lsd_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                                   C.c_float, C.c_void_p, C.c_void_p]
+    n = L.orc_lsd_search_by_projection_map(_p(sc), _p(tl), len(tl), _p(cur), _p(cd), len(cur), th, nnratio, _p(obs), _p(out))
+    return n, out
+
+
 def match_orb_points(cur_desc, last_desc, last_mp, last_outlier):
     cd, ld = _c(cur_desc, np.uint8), _c(last_desc, np.uint8)
     out = np.full(len(cd), -1, np.int32)

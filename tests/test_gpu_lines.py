@@ -82,3 +82,40 @@ def test_rectangle_edges(ctx, oracle_mod):
     xs = sorted(float(v) for v in a["lines"]["start_point_x"])
     assert abs(xs[0] - 149.4) < 1.0 and abs(xs[-1] - 449.4) < 1.0
     assert np.array_equal(a["desc"], o["desc"])
+
+
+@pytest.mark.parametrize("seed,motion,th", [(1, 0.0, 15.0), (2, 0.5, 15.0), (3, -0.5, 15.0), (4, 0.0, 7.0), (5, 0.0, 30.0),
+                                            (11, 0.0, 15.0), (12, 0.2, 20.0)])
+def test_lsd_search_by_projection(ctx, oracle_mod, seed, motion, th):
+    """LSDmatcher::SearchByProjection, both overloads (row a-15): device replay vs the oracle, identical claims."""
+    import os
+    import line_scenarios as LS
+    from dr_slam_amd import lib
+    O = oracle_mod
+    sc = LS.make(seed, lib.KEYLINE_DTYPE, lib.MAPLINE_DTYPE, lib.TRACKED_LINE_DTYPE, n_cur=40 if seed < 10 else 150,
+                 n_last=48 if seed < 10 else 200, motion=motion)
+    cam = lib.Camera(**LS.CAM) if hasattr(lib, "Camera") else None
+    assert cam is not None
+    n, ml = ctx.lsd_search_by_projection_last(sc["Tcw_cur"], sc["Tcw_last"], cam, sc["last"], sc["cur"], sc["cur_desc"], th,
+                                              False, 0.9, sc["cur_ml"], sc["cur_obs"])
+    no, mlo = O.lsd_search_by_projection_last(LS.cam9(), sc["Tcw_cur"], sc["Tcw_last"], LS.SCALE, sc["last"], sc["cur"],
+                                              sc["cur_desc"], th, False, 0.9, sc["cur_ml"], sc["cur_obs"])
+    assert n == no and np.array_equal(ml, mlo)
+    assert n > 5
+    n, ml = ctx.lsd_search_by_projection_map(sc["tracked"], sc["cur"], sc["cur_desc"], th / 15.0, 0.9, sc["cur_ml"], sc["cur_obs"])
+    no, mlo = O.lsd_search_by_projection_map(LS.SCALE, sc["tracked"], sc["cur"], sc["cur_desc"], th / 15.0, 0.9, sc["cur_ml"],
+                                             sc["cur_obs"])
+    assert n == no and np.array_equal(ml, mlo)
+    if seed < 10:
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lsd_projection.npz"))
+        assert np.array_equal(np.concatenate([[n], ml]), g[f"map_{seed}"])
+
+
+def test_lsd_search_by_projection_empty(ctx):
+    from dr_slam_amd import lib
+    import line_scenarios as LS
+    cam = lib.Camera(**LS.CAM)
+    T = np.eye(4, dtype=np.float32)
+    n, ml = ctx.lsd_search_by_projection_last(T, T, cam, np.zeros(0, lib.MAPLINE_DTYPE), np.zeros(0, lib.KEYLINE_DTYPE),
+                                              np.zeros((0, 32), np.uint8), 15.0, False, 0.9, np.zeros(0, np.int32))
+    assert n == 0 and len(ml) == 0

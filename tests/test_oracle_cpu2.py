@@ -250,3 +250,69 @@ def test_golden_planes_lines_bow(oracle_mod):
     ov = oracle_mod.VocabularyOracle(voc.to_text())
     w, wt, nid = ov.transform_each(z["orb_desc"], 2)
     assert np.array_equal(w, z["bow_word"]) and np.array_equal(nid, z["bow_nid"])
+
+
+# ---- LSDmatcher::SearchByProjection (row a-15) ---------------------------------------------------------------------
+
+_KL = np.dtype([("pt_x", "<f4"), ("pt_y", "<f4"), ("angle", "<f4"), ("octave", "<i4")])
+
+
+def _tracked(oracle_mod, x1, y1, x2, y2, desc, level=0, obs=1, view_cos=1.0):
+    t = np.zeros(1, oracle_mod.TRACKED_LINE_DTYPE)
+    t["in_view"], t["level"], t["obs_positive"] = 1, level, obs
+    t["x1"], t["y1"], t["x2"], t["y2"], t["view_cos"] = x1, y1, x2, y2, view_cos
+    t["desc"][0] = desc
+    return t
+
+
+def test_lines_in_area_gates_and_claims(oracle_mod):
+    """Hand cases of Frame::GetLinesInArea + the best/second scan: midpoint radius, the slope-vs-angle quirk, the
+    same-octave ratio test, a claim held by a line with observations."""
+    O = oracle_mod
+    rng = np.random.RandomState(0)
+    d = rng.randint(0, 256, 32).astype(np.uint8)
+    far = d ^ np.uint8(0xFF)
+    cur = np.zeros(3, _KL)
+    cur["pt_x"], cur["pt_y"] = [100, 104, 300], [100, 100, 300]
+    cur["angle"] = [0.5, 0.5, 0.5]
+    scale = (1.2 ** np.arange(8)).astype(np.float32)
+    free = np.full(3, -1, np.int32)
+    # window radius 5 (viewCos > 0.998, th = 1, level 0); query midpoint (100, 100), dy/dx = 0.5 -> slope 0 passes
+    q = _tracked(O, 90, 95, 110, 105, d)
+    n, ml = O.lsd_search_by_projection_map(scale, q, cur, np.stack([d, far, d]), 1.0, 0.9, free)
+    assert n == 1 and list(ml) == [0, -1, -1]                 # line 2 is outside the radius, line 1 is a poor second
+    # two equally good candidates in the same octave: best (0) > 0.9 * second (0) is false -> accepted, first index wins
+    n, ml = O.lsd_search_by_projection_map(scale, q, cur, np.stack([d, d, d]), 1.0, 0.9, free)
+    assert n == 1 and list(ml) == [0, -1, -1]
+    d1 = d.copy(); d1[0] ^= 0x0F                              # distance 4 vs second 4: 4 > 0.9 * 4 -> ratio test rejects
+    n, ml = O.lsd_search_by_projection_map(scale, _tracked(O, 90, 95, 110, 105, d), cur, np.stack([d1, d1, d]), 1.0, 0.9, free)
+    assert n == 0
+    # steeper query: dy/dx - angle = 0.6 > r * 0.01 = 0.05 -> no candidates at all
+    n, ml = O.lsd_search_by_projection_map(scale, _tracked(O, 95, 89.5, 105, 110.5, d), cur, np.stack([d, far, d]), 1.0, 0.9, free)
+    assert n == 0
+    # a shallower query passes (the test is one-sided): dy/dx - angle = -0.4
+    n, ml = O.lsd_search_by_projection_map(scale, _tracked(O, 90, 99, 110, 101, d), cur, np.stack([d, far, d]), 1.0, 0.9, free)
+    assert n == 1 and ml[0] == 0
+    # line 0 already holds a map line with observations -> skipped, the (poor but < TH_HIGH?) second is line 1
+    held = np.array([7, -1, -1], np.int32)
+    near = d.copy(); near[:5] ^= 0xFF                         # distance 40
+    n, ml = O.lsd_search_by_projection_map(scale, q, cur, np.stack([d, near, d]), 1.0, 0.9, held, np.array([1, 0, 0], np.uint8))
+    assert n == 1 and list(ml) == [7, 0, -1]
+    n, ml = O.lsd_search_by_projection_map(scale, q, cur, np.stack([d, near, d]), 1.0, 0.9, held, np.array([0, 0, 0], np.uint8))
+    assert n == 1 and list(ml) == [0, -1, -1]                 # a claim without observations is overwritten
+
+
+def test_golden_lsd_projection(oracle_mod):
+    import line_scenarios as LS
+    O = oracle_mod
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lsd_projection.npz"))
+    for seed, motion, th in g["cases"]:
+        seed = int(seed)
+        sc = LS.make(seed, _KL, O.MAPLINE_DTYPE, O.TRACKED_LINE_DTYPE, motion=float(motion))
+        n, ml = O.lsd_search_by_projection_last(LS.cam9(), sc["Tcw_cur"], sc["Tcw_last"], LS.SCALE, sc["last"], sc["cur"],
+                                                sc["cur_desc"], float(th), False, 0.9, sc["cur_ml"], sc["cur_obs"])
+        assert np.array_equal(np.concatenate([[n], ml]), g[f"last_{seed}"])
+        n, ml = O.lsd_search_by_projection_map(LS.SCALE, sc["tracked"], sc["cur"], sc["cur_desc"], float(th) / 15.0, 0.9,
+                                               sc["cur_ml"], sc["cur_obs"])
+        assert np.array_equal(np.concatenate([[n], ml]), g[f"map_{seed}"])
+        assert n > 5
