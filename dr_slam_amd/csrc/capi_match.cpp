@@ -104,6 +104,63 @@ int drfe_frame_stereo_grid_batch(drfe_ctx* c, const uint16_t* d_depth, size_t fr
     return DRFE_OK;
 }
 
+/* Frame::UndistortKeyPoints model: (k1, k2, p1, p2[, k3]) with mK = (fx, fy, cx, cy); k1 == 0 switches it off
+ * exactly as src/Frame.cc:836 does */
+int drfe_frame_set_distortion(drfe_ctx* c, const drfe_camera* cam, const float* dist, int n)
+{
+    if (!c || (n > 0 && (!dist || !cam)) || n < 0 || n > 5) return DRFE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    std::memset(&c->dist, 0, sizeof(c->dist));
+    c->glueValid = false;
+    if (n == 0 || dist[0] == 0.0f) return DRFE_OK;
+    if (n < 4) { c->err = "set_distortion: need k1, k2, p1, p2[, k3]"; return DRFE_ERR_INVALID; }
+    if (!c->d_kpsUn) {
+        void* p = nullptr;
+        HIPCHK(c, hipMalloc(&p, sizeof(drfe_keypoint) * (size_t)c->cfg.max_batch * c->maxKp));
+        c->d_kpsUn = (drfe_keypoint*)p;
+    }
+    c->dist.fx = cam->fx; c->dist.fy = cam->fy; c->dist.cx = cam->cx; c->dist.cy = cam->cy;
+    for (int i = 0; i < n; i++) c->dist.k[i] = (double)dist[i];
+    c->dist.enabled = 1;
+    return DRFE_OK;
+}
+
+/* Frame::ComputeImageBounds, src/Frame.cc:862-891 (four corners through the same undistortPoints) */
+int drfe_frame_image_bounds(const drfe_camera* cam, const float* dist, int n, int cols, int rows, float* bounds)
+{
+    if (!cam || !bounds || n < 0 || n > 5 || (n > 0 && !dist)) return DRFE_ERR_INVALID;
+    if (n >= 4 && dist[0] != 0.0f) {
+        DrfeDistortion D;
+        std::memset(&D, 0, sizeof(D));
+        D.fx = cam->fx; D.fy = cam->fy; D.cx = cam->cx; D.cy = cam->cy; D.enabled = 1;
+        for (int i = 0; i < n; i++) D.k[i] = (double)dist[i];
+        const float cx[4] = {0.f, (float)cols, 0.f, (float)cols}, cy[4] = {0.f, 0.f, (float)rows, (float)rows};
+        float ux[4], uy[4];
+        for (int i = 0; i < 4; i++) drfe_undistort_point(D, cx[i], cy[i], &ux[i], &uy[i]);
+        bounds[0] = std::min(ux[0], ux[2]); bounds[1] = std::max(ux[1], ux[3]);
+        bounds[2] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
+    } else {
+        bounds[0] = 0.f; bounds[1] = (float)cols; bounds[2] = 0.f; bounds[3] = (float)rows;
+    }
+    return DRFE_OK;
+}
+
+int drfe_frame_download_keys_un(drfe_ctx* c, int slot, drfe_keypoint* kps, int cap)
+{
+    if (!c || !kps) return DRFE_ERR_INVALID;
+    if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = "download_keys_un: run the glue first"; return DRFE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) { c->err = "keypoint buffer too small"; return DRFE_ERR_CAPACITY; }
+    if (n) HIPCHK(c, hipMemcpy(kps, drfe_kps_un(c) + (size_t)slot * c->maxKp, sizeof(drfe_keypoint) * n, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
 int drfe_frame_download_stereo(drfe_ctx* c, int slot, float* u_right, float* depth, int cap)
 {
     if (!c || slot < 0 || slot >= c->lastBatch || !c->glueValid) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;

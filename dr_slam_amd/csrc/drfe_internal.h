@@ -75,6 +75,8 @@ struct BlurTile { uint16_t tx, ty; uint16_t level, pad; };
 
 struct ResizeTap { uint16_t s0, s1; int16_t w0, w1; };
 
+#include "undistort_math.h"
+
 struct drfe_ctx {
     drfe_config cfg;
     int device;
@@ -104,7 +106,9 @@ struct drfe_ctx {
     int* d_candCount;         /* [slot][level] */
     uint32_t* d_sel;          /* [slot][kpSlotElems] packed x|y<<12|resp<<24 */
     int* d_selCount;          /* [slot][level] */
-    drfe_keypoint* d_kps;     /* [slot][maxKp] */
+    drfe_keypoint* d_kps;     /* [slot][maxKp] mvKeys */
+    drfe_keypoint* d_kpsUn;   /* [slot][maxKp] mvKeysUn; allocated only when a distortion model is set */
+    DrfeDistortion dist;      /* Frame::UndistortKeyPoints model (enabled == 0: mvKeysUn = mvKeys) */
     uint8_t* d_desc;          /* [slot][maxKp][32] */
     int* d_kpCount;           /* [slot] */
     int* d_status;            /* device-side error flags (overflow) */
@@ -132,6 +136,9 @@ struct drfe_ctx {
     hipEvent_t ev[DRFE_STAGE_COUNT][2];
     bool evUsed[DRFE_STAGE_COUNT];
 };
+
+/* what the matchers and the grid read: mvKeysUn (== mvKeys without distortion) */
+static inline drfe_keypoint* drfe_kps_un(const drfe_ctx* c) { return c->dist.enabled ? c->d_kpsUn : c->d_kps; }
 
 /* orb_geometry.cpp */
 int drfe_build_tables(drfe_ctx* c);                       /* scale tables, quotas, umax */

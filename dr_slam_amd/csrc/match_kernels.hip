@@ -26,7 +26,23 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* Frame glue                                                                                        */
 
-__global__ __launch_bounds__(256) void k_stereo(const drfe_keypoint* __restrict__ kps, const int* __restrict__ kpCount,
+/* Frame::UndistortKeyPoints, src/Frame.cc:835-860: mvKeysUn[i] = mvKeys[i] with pt replaced by
+ * cv::undistortPoints (undistort_math.h) */
+__global__ __launch_bounds__(256) void k_undistort(const drfe_keypoint* __restrict__ kps, const int* __restrict__ kpCount,
+                                                   int maxKp, DrfeDistortion D, drfe_keypoint* __restrict__ kpsUn)
+{
+    const int slot = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kpCount[slot]) return;
+    drfe_keypoint kp = kps[(size_t)slot * maxKp + i];
+    float ux, uy;
+    drfe_undistort_point(D, kp.x, kp.y, &ux, &uy);
+    kp.x = ux; kp.y = uy;
+    kpsUn[(size_t)slot * maxKp + i] = kp;
+}
+
+__global__ __launch_bounds__(256) void k_stereo(const drfe_keypoint* __restrict__ kps, const drfe_keypoint* __restrict__ kpsUn,
+                                                const int* __restrict__ kpCount,
                                                 int maxKp, const uint16_t* __restrict__ depth, size_t frameStride,
                                                 size_t rowStride, int w, int h, drfe_camera cam,
                                                 float* __restrict__ uRight, float* __restrict__ zDepth)
@@ -42,7 +58,7 @@ __global__ __launch_bounds__(256) void k_stereo(const drfe_keypoint* __restrict_
     if (u >= 0 && u < w && v >= 0 && v < h)
         d = (float)depth[(size_t)slot * frameStride + (size_t)v * rowStride + u] * cam.depth_factor;
     float ur = -1.f, z = -1.f;
-    if (d > 0) { z = d; ur = kp.x - cam.bf / d; }
+    if (d > 0) { z = d; ur = kpsUn[(size_t)slot * maxKp + i].x - cam.bf / d; }   /* kpU.pt.x - mbf/d, :906 */
     uRight[(size_t)slot * maxKp + i] = ur;
     zDepth[(size_t)slot * maxKp + i] = z;
 }
@@ -626,10 +642,13 @@ hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameSt
     const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
     const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
     prof_begin(c, DRFE_STAGE_GLUE, s);
-    hipLaunchKernelGGL(k_stereo, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, c->d_kps, c->d_kpCount,
+    if (c->dist.enabled)
+        hipLaunchKernelGGL(k_undistort, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, c->d_kps, c->d_kpCount,
+                           c->maxKp, c->dist, c->d_kpsUn);
+    hipLaunchKernelGGL(k_stereo, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, c->d_kps, drfe_kps_un(c), c->d_kpCount,
                        c->maxKp, d_depth, frameStride, rowStride, c->geom.imgW, c->geom.imgH, cam, c->d_uRight,
                        c->d_depth);
-    hipLaunchKernelGGL(k_grid, dim3(nframes), dim3(256), 0, s, c->d_kps, c->d_kpCount, c->maxKp, cam, invW, invH,
+    hipLaunchKernelGGL(k_grid, dim3(nframes), dim3(256), 0, s, drfe_kps_un(c), c->d_kpCount, c->maxKp, cam, invW, invH,
                        c->d_uRight, c->d_desc, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc);
     prof_end(c, DRFE_STAGE_GLUE, s);
     return hipGetLastError();
@@ -644,14 +663,14 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
     if (mode == 0 && maxQueries > RS_THREADS * RS_MAX_T) return hipErrorInvalidValue;
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
-                           c->d_kps, c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
+                           drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
     hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 3) / 4, npairs), dim3(256), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
                        mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status);
     const size_t lds = (size_t)c->maxKp;
     if (mode == 0)
         hipLaunchKernelGGL(k_resolve_last, dim3(npairs), dim3(RS_THREADS), (size_t)c->maxKp * 5 + 16, s, mb.d_pairs,
-                           mb.d_queries, c->d_kps, c->d_kpCount, c->maxKp, mb.d_candIdx, mb.d_candKey, mb.d_candCnt,
+                           mb.d_queries, drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_candIdx, mb.d_candKey, mb.d_candCnt,
                            mb.d_candBest, checkOri, c->d_match, d_initObs, c->d_matchCount, mb.d_hist);
     else
         hipLaunchKernelGGL(k_resolve_map, dim3(npairs), dim3(WAVE), lds, s, mb.d_pairs, mb.d_queries, c->d_kpCount,
@@ -663,7 +682,7 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
 hipError_t drfe_launch_mappoints_last(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, const float* d_Twc,
                                       int nframes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mappoints_last, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, c->d_kps, c->d_desc,
+    hipLaunchKernelGGL(k_mappoints_last, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, drfe_kps_un(c), c->d_desc,
                        c->d_kpCount, c->maxKp, c->d_depth, cam, d_Twc, mb.d_mps);
     return hipGetLastError();
 }

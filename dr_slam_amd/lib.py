@@ -29,6 +29,7 @@ SYMBOLS = (
     "drfe_create", "drfe_destroy", "drfe_last_error", "drfe_version", "drfe_orb_scale_tables",
     "drfe_orb_max_keypoints", "drfe_orb_extract", "drfe_orb_extract_batch", "drfe_orb_download", "drfe_orb_counts",
     "drfe_orb_pyramid_level", "drfe_orb_blurred_level", "drfe_orb_candidates", "drfe_frame_stereo_grid_batch",
+    "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
@@ -115,6 +116,9 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_frame_set_distortion.argtypes = [vp, vp, vp, i32]
+    L.drfe_frame_image_bounds.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.drfe_frame_download_keys_un.argtypes = [vp, i32, vp, i32]
     L.drfe_lsd_search_by_descriptor.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.POINTER(i32)]
     L.drfe_lsd_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, i32, C.c_float, vp, vp,
                                                      C.POINTER(i32)]
@@ -300,6 +304,23 @@ class Context:
         self._chk(self.L.drfe_match_orb_points(self.h, cur_slot, last_slot, _p(last_mp), _p(last_outlier), len(last_mp),
                                                _p(out), n_cur, C.byref(n)), "drfe_match_orb_points")
         return n.value, out
+
+    def set_distortion(self, cam, dist):
+        """Frame::UndistortKeyPoints model (k1, k2, p1, p2[, k3]); None / k1 == 0 switches it off."""
+        d = np.zeros(0, np.float32) if dist is None else np.ascontiguousarray(dist, np.float32)
+        self._chk(self.L.drfe_frame_set_distortion(self.h, C.byref(cam), _p(d), len(d)), "drfe_frame_set_distortion")
+
+    def image_bounds(self, cam, dist, cols, rows):
+        d = np.zeros(0, np.float32) if dist is None else np.ascontiguousarray(dist, np.float32)
+        out = np.zeros(4, np.float32)
+        self._chk(self.L.drfe_frame_image_bounds(C.byref(cam), _p(d), len(d), int(cols), int(rows), _p(out)),
+                  "drfe_frame_image_bounds")
+        return out
+
+    def download_keys_un(self, slot, n):
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self._chk(self.L.drfe_frame_download_keys_un(self.h, slot, _p(out), len(out)), "drfe_frame_download_keys_un")
+        return out[:n]
 
     def lsd_search_by_descriptor(self, desc_q, desc_t, has_line=None, mode=0):
         dq = np.ascontiguousarray(desc_q, np.uint8)

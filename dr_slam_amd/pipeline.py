@@ -87,6 +87,13 @@ class FrontEnd:
                  device=0):
         self.ctx = lib.Context(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, cam.w, cam.h, max_batch, device)
         self.cam = lib.make_camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.depth_factor, cam.w, cam.h)
+        dist = tuple(getattr(cam, "dist", ()) or ())
+        if dist and dist[0] != 0.0:
+            # Frame::ComputeImageBounds + UndistortKeyPoints (src/Frame.cc:835-891): bounds of the undistorted
+            # corners, mvKeysUn built on the device by every glue call
+            b = self.ctx.image_bounds(self.cam, dist, cam.w, cam.h)
+            self.cam.min_x, self.cam.max_x, self.cam.min_y, self.cam.max_y = (float(v) for v in b)
+            self.ctx.set_distortion(self.cam, dist)
         self.w, self.h = cam.w, cam.h
         self.max_batch = max_batch
 

@@ -46,14 +46,20 @@ class Camera:
     depth_factor: float = 5000.0  # DepthMapFactor (raw units per metre)
     w: int = 640
     h: int = 480
+    dist: tuple = ()              # Camera.k1, k2, p1, p2, k3 (mDistCoef); empty / k1 == 0: no undistortion
 
     def scaled(self, s: float) -> "Camera":
         return Camera(self.fx * s, self.fy * s, self.cx * s, self.cy * s, self.bf * s, self.depth_factor,
-                      int(round(self.w * s)), int(round(self.h * s)))
+                      int(round(self.w * s)), int(round(self.h * s)), self.dist)
 
 
 # intrinsics of reference Examples/RGB-D/*.yaml (TUM3.yaml:8-34, ICL.yaml:8-11, Realsense.yaml:8-17)
 TUM3 = Camera(535.4, 539.2, 320.1, 247.6, 40.0, 5000.0)
+# the two settings with lens distortion (TUM1.yaml:8-35, TUM2.yaml:8-35): Frame::UndistortKeyPoints is live
+TUM1 = Camera(517.306408, 516.469215, 318.643040, 255.313989, 40.0, 5000.0, 640, 480,
+              (0.262383, -0.953104, -0.005358, 0.002628, 1.163314))
+TUM2 = Camera(520.908620, 521.007327, 325.141442, 249.701764, 40.0, 5208.0, 640, 480,
+              (0.231222, -0.784899, -0.003257, -0.000105, 0.917205))
 ICL = Camera(481.2, -480.0, 319.5, 239.5, 40.0, 5000.0)
 REALSENSE = Camera(615.9, 616.1, 323.0, 241.5, 30.8, 1000.0)
 

@@ -112,6 +112,16 @@ int drfe_orb_candidates(drfe_ctx* ctx, int slot, int level, int32_t* xyr, int ca
  * mvDepth/mvuRight and the 64x48 feature grid, all kept on device for the matchers. */
 int drfe_frame_stereo_grid_batch(drfe_ctx* ctx, const uint16_t* d_depth, size_t frame_stride_elems,
                                  size_t row_stride_elems, const drfe_camera* cam, int nframes, void* stream);
+/* Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:835-891) for cameras with k1 != 0 (TUM1/TUM2
+ * settings): dist = (k1, k2, p1, p2[, k3]) as Tracking reads Camera.k1.. into mDistCoef, cam supplies mK.  With a
+ * model set, drfe_frame_stereo_grid_batch first builds mvKeysUn on the device (cv::undistortPoints(pts, K, dist,
+ * Mat(), K): five fixed-point iterations in double) and the depth association, the grid and every matcher read
+ * mvKeysUn, exactly as the reference does; n = 0 or k1 == 0 restores mvKeysUn = mvKeys.  The image bounds
+ * (min_x, max_x, min_y, max_y of drfe_camera) come from drfe_frame_image_bounds. */
+int drfe_frame_set_distortion(drfe_ctx* ctx, const drfe_camera* cam, const float* dist, int n);
+int drfe_frame_image_bounds(const drfe_camera* cam, const float* dist, int n, int cols, int rows,
+                            float* bounds /* min_x, max_x, min_y, max_y */);
+int drfe_frame_download_keys_un(drfe_ctx* ctx, int slot, drfe_keypoint* kps, int cap);
 int drfe_frame_download_stereo(drfe_ctx* ctx, int slot, float* u_right, float* depth, int cap);
 /* grid as CSR in the reference's iteration order (cell = ix*48 + iy): offsets[64*48+1], indices[N] */
 int drfe_frame_download_grid(drfe_ctx* ctx, int slot, int32_t* offsets, int32_t* indices, int cap);

@@ -153,6 +153,46 @@ void* orc_frame_create(const KeyPoint* kps, const uint8_t* desc, int N, const fl
     f->assignFeaturesToGrid();
     return f;
 }
+/* Frame with radial/tangential distortion: mvKeysUn through cv::undistortPoints, bounds through
+ * ComputeImageBounds (src/Frame.cc:835-891); everything downstream reads mvKeysUn and the bounds */
+void* orc_frame_create_dist(const KeyPoint* kps, const uint8_t* desc, int N, const float* depth, int dw, int dh,
+                            const float K[4], float bf, int imw, int imh, const float* scaleFactors, int nlevels,
+                            const float* dist, int nd)
+{
+    Frame* f = new Frame();
+    f->N = N;
+    f->keys.assign(kps, kps + N);
+    f->keysUn = f->keys;
+    if (nd > 0 && dist[0] != 0.0f && N > 0) {
+        std::vector<float> xy(2 * (size_t)N), un(2 * (size_t)N);
+        for (int i = 0; i < N; i++) { xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y; }
+        undistort_points(xy.data(), N, K, dist, nd, un.data());
+        for (int i = 0; i < N; i++) { f->keysUn[i].x = un[2 * i]; f->keysUn[i].y = un[2 * i + 1]; }
+    }
+    f->desc.assign(desc, desc + (size_t)N * 32);
+    f->scaleFactors.assign(scaleFactors, scaleFactors + nlevels);
+    f->fx = K[0]; f->fy = K[1]; f->cx = K[2]; f->cy = K[3];
+    f->bf = bf; f->mb = bf / f->fx;
+    float b[4];
+    image_bounds(imw, imh, K, dist, nd, b);
+    f->minX = b[0]; f->maxX = b[1]; f->minY = b[2]; f->maxY = b[3];
+    f->gridInvW = (float)kGridCols / (float)(f->maxX - f->minX);
+    f->gridInvH = (float)kGridRows / (float)(f->maxY - f->minY);
+    f->computeStereoFromRGBD(depth, dw, dh);
+    f->assignFeaturesToGrid();
+    return f;
+}
+void orc_frame_get_keys_un(void* h, KeyPoint* out)
+{
+    Frame* f = (Frame*)h;
+    if (f->N) std::memcpy(out, f->keysUn.data(), sizeof(KeyPoint) * f->N);
+}
+void orc_frame_get_bounds(void* h, float* out) { Frame* f = (Frame*)h; out[0] = f->minX; out[1] = f->maxX; out[2] = f->minY; out[3] = f->maxY; }
+void orc_undistort_points(const float* xy, int n, const float* K, const float* dist, int nd, float* out)
+{
+    undistort_points(xy, n, K, dist, nd, out);
+}
+void orc_image_bounds(int cols, int rows, const float* K, const float* dist, int nd, float* out) { image_bounds(cols, rows, K, dist, nd, out); }
 void orc_frame_destroy(void* h) { delete (Frame*)h; }
 void orc_frame_get_stereo(void* h, float* uRight, float* depth)
 {

@@ -29,6 +29,58 @@ void Frame::computeStereoFromRGBD(const float* depth, int dw, int dh)
     }
 }
 
+/* cvUndistortPointsInternal, OpenCV 3.4 modules/imgproc/src/undistort.cpp (R = identity, P = K, no tilt
+ * terms, TermCriteria(MAX_ITER, 5, 0.01) -> exactly five iterations): K and the coefficients are converted
+ * to double, the point is normalised, the distortion is inverted by fixed-point iteration
+ *   r2 = x^2+y^2; icdist = (1 + ((k7 r2 + k6) r2 + k5) r2) / (1 + ((k4 r2 + k1) r2 + k0) r2)
+ *   dX = 2 k2 x y + k3 (r2 + 2 x^2) + k8 r2 + k9 r2^2;  dY = k2 (r2 + 2 y^2) + 2 k3 x y + k10 r2 + k11 r2^2
+ *   x = (x0 - dX) icdist; y = (y0 - dY) icdist
+ * and re-projected with P: xx = P00 x + P01 y + P02, ..., x = xx * (1 / ww); stored as float.  Terms whose
+ * coefficient is zero are kept (they add exact zeros), so the rounding sequence is the library's. */
+void undistort_points(const float* xy, int n, const float K[4], const float* dist, int nd, float* out)
+{
+    double k[14] = {0};
+    for (int i = 0; i < nd && i < 14; i++) k[i] = (double)dist[i];
+    const double fx = (double)K[0], fy = (double)K[1], cx = (double)K[2], cy = (double)K[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};
+    for (int i = 0; i < n; i++) {
+        double x = (double)xy[2 * i], y = (double)xy[2 * i + 1];
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        out[2 * i] = (float)(xx * ww);
+        out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+/* Frame::ComputeImageBounds, src/Frame.cc:862-891 */
+void image_bounds(int cols, int rows, const float K[4], const float* dist, int nd, float out[4])
+{
+    if (nd > 0 && dist[0] != 0.0f) {
+        const float c[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+        float u[8];
+        undistort_points(c, 4, K, dist, nd, u);
+        out[0] = std::min(u[0], u[4]);
+        out[1] = std::max(u[2], u[6]);
+        out[2] = std::min(u[1], u[3]);
+        out[3] = std::max(u[5], u[7]);
+    } else {
+        out[0] = 0.f; out[1] = (float)cols; out[2] = 0.f; out[3] = (float)rows;
+    }
+}
+
 /* Frame::PosInGrid + AssignFeaturesToGrid, src/Frame.cc:224-237, 816-825 (C round(), §9.19) */
 void Frame::assignFeaturesToGrid()
 {

@@ -40,6 +40,13 @@ struct Frame {
     void getFeaturesInArea(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const;
 };
 
+/* cv::undistortPoints(src, dst, K, distCoef, Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call
+ * it (src/Frame.cc:835-888): OpenCV 3.4 cvUndistortPointsInternal, 5 fixed-point iterations in double.
+ * dist = (k1, k2, p1, p2[, k3]). */
+void undistort_points(const float* xy, int n, const float K[4], const float* dist, int nd, float* out);
+/* Frame::ComputeImageBounds: out = (mnMinX, mnMaxX, mnMinY, mnMaxY) */
+void image_bounds(int cols, int rows, const float K[4], const float* dist, int nd, float out[4]);
+
 int search_by_projection_last(const Frame& Cur, const Frame& Last, const float TcwCur[16], const float TcwLast[16],
                               const MapPointRec* lastMP, float th, bool bMono, bool checkOri,
                               const uint8_t* curClaimObsPositive, int* curMP);

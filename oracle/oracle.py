@@ -249,7 +249,7 @@ def depth_to_float(d16, factor):
 class FrameOracle:
     """Restatement of the parts of Frame the matchers read (reference include/Frame.h:183-299)."""
 
-    def __init__(self, kps, desc, depth_f32, K4, bf, imw, imh, scale_factors):
+    def __init__(self, kps, desc, depth_f32, K4, bf, imw, imh, scale_factors, dist=None):
         self.L = lib()
         self.kps = _c(kps, KP_DTYPE)
         self.desc = _c(desc, np.uint8)
@@ -257,8 +257,17 @@ class FrameOracle:
         depth_f32 = _c(depth_f32, np.float32)
         K4 = _c(K4, np.float32)
         sf = _c(scale_factors, np.float32)
-        self.h = self.L.orc_frame_create(_p(self.kps), _p(self.desc), self.N, _p(depth_f32), depth_f32.shape[1],
-                                         depth_f32.shape[0], _p(K4), np.float32(bf), imw, imh, _p(sf), len(sf))
+        if dist is None:
+            self.h = self.L.orc_frame_create(_p(self.kps), _p(self.desc), self.N, _p(depth_f32), depth_f32.shape[1],
+                                             depth_f32.shape[0], _p(K4), np.float32(bf), imw, imh, _p(sf), len(sf))
+        else:   # Frame::UndistortKeyPoints + ComputeImageBounds with (k1, k2, p1, p2[, k3])
+            d = _c(dist, np.float32)
+            self.L.orc_frame_create_dist.restype = C.c_void_p
+            self.L.orc_frame_create_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                     C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            self.h = self.L.orc_frame_create_dist(_p(self.kps), _p(self.desc), self.N, _p(depth_f32), depth_f32.shape[1],
+                                                  depth_f32.shape[0], _p(K4), np.float32(bf), imw, imh, _p(sf), len(sf),
+                                                  _p(d), len(d))
         self.uRight = np.zeros(self.N, np.float32)
         self.depth = np.zeros(self.N, np.float32)
         self.L.orc_frame_get_stereo(self.h, _p(self.uRight), _p(self.depth))
@@ -268,6 +277,18 @@ class FrameOracle:
             self.L.orc_frame_destroy(self.h)
         except Exception:
             pass
+
+    def keys_un(self):
+        out = np.zeros(max(self.N, 1), KP_DTYPE)
+        self.L.orc_frame_get_keys_un.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_frame_get_keys_un(self.h, _p(out))
+        return out[:self.N]
+
+    def bounds(self):
+        out = np.zeros(4, np.float32)
+        self.L.orc_frame_get_bounds.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_frame_get_bounds(self.h, _p(out))
+        return out
 
     def grid_csr(self):
         off = np.zeros(64 * 48 + 1, np.int32)
@@ -286,6 +307,22 @@ class FrameOracle:
         v = np.zeros(self.N, np.uint8)
         self.L.orc_frame_unproject(self.h, _p(Twc), _p(w), _p(v))
         return w, v
+
+
+def undistort_points(xy, K4, dist):
+    """cv::undistortPoints(xy, K, dist, Mat(), K), float32 in/out (N x 2)."""
+    xy = _c(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    d = _c(dist, np.float32)
+    lib().orc_undistort_points(_p(xy), len(xy), _p(_c(K4, np.float32)), _p(d), len(d), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, K4, dist):
+    out = np.zeros(4, np.float32)
+    d = _c(dist, np.float32)
+    lib().orc_image_bounds(int(cols), int(rows), _p(_c(K4, np.float32)), _p(d), len(d), _p(out))
+    return out
 
 
 def search_by_projection_last(cur: FrameOracle, last: FrameOracle, Tcw_cur, Tcw_last, last_mp, th=15.0,

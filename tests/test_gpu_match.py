@@ -156,3 +156,52 @@ def test_bf_knn(setup, oracle_mod):
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
     gi, gd = fe.ctx.bf_knn(A[:0], A, 1)
     assert gi.shape == (0, 1)
+
+
+def test_distorted_camera_undistort_glue_and_match(frames_room, oracle_mod):
+    """TUM1 settings (k1 != 0): Frame::UndistortKeyPoints + ComputeImageBounds feed the depth association, the grid
+    and SearchByProjection — mvKeysUn float bit patterns, bounds, uRight, grid CSR and matches equal the oracle's."""
+    import torch
+    from dr_slam_amd import synth
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = synth.TUM1
+    fe = FrontEnd(cam, max_batch=8)
+    try:
+        frames = frames_room[:4]
+        gray = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+        depth = torch.from_numpy(np.stack([f[1] for f in frames]).view(np.int16)).cuda()
+        Tcw, Twc = _poses(frames)
+        fe.process(gray, depth, Tcw, Twc, th=15.0, check_ori=True, stream=torch.cuda.current_stream().cuda_stream)
+        o = oracle_mod.OrbOracle()
+        K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        ob = oracle_mod.image_bounds(cam.w, cam.h, K4, cam.dist)
+        assert np.array_equal(np.array([fe.cam.min_x, fe.cam.max_x, fe.cam.min_y, fe.cam.max_y], np.float32).view(np.uint32),
+                              ob.view(np.uint32))
+        assert ob[0] > 5 and ob[1] < cam.w - 5            # the undistorted bounds really differ from the image
+        oframes = []
+        for g, d, _ in frames:
+            kps, desc = o(g)
+            df = oracle_mod.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+            oframes.append(oracle_mod.FrameOracle(kps, desc, df, K4, cam.bf, cam.w, cam.h, o.scale, dist=cam.dist))
+        moved = 0.0
+        for s, fo in enumerate(oframes):
+            un = fe.ctx.download_keys_un(s, fo.N)
+            oun = fo.keys_un()
+            for f in ("x", "y", "angle", "size", "response"):
+                assert np.array_equal(un[f].view(np.uint32), oun[f].view(np.uint32)), f
+            assert np.array_equal(un["octave"], oun["octave"])
+            moved = max(moved, float(np.abs(un["x"] - fo.kps["x"]).max()))
+            ur, z = fe.ctx.download_stereo(s)
+            assert np.array_equal(ur[:fo.N].view(np.uint32), fo.uRight.view(np.uint32))
+            off, idx = fe.ctx.download_grid(s)
+            ooff, oidx = fo.grid_csr()
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        assert moved > 2.0                                  # keypoints near the border move by pixels
+        for s in range(1, len(oframes)):
+            m, n = fe.matches(s)
+            mp = _last_mp(oracle_mod, oframes[s - 1], Twc[s - 1])
+            no, mo = oracle_mod.search_by_projection_last(oframes[s], oframes[s - 1], Tcw[s], Tcw[s - 1], mp, 15.0, False, True)
+            assert n == no and np.array_equal(m[:oframes[s].N], mo)
+            assert n > 100
+    finally:
+        fe.ctx.close()

@@ -114,3 +114,20 @@ def test_two_rank_gloo_sharding():
         assert tab == list(np.arange(8, dtype=np.float32))   # rank 0's tables everywhere
         assert el == 2.0 and n == 64 + 128                   # MAX of time, SUM of frames
         assert seed == 10 + rank                             # one independent sequence per rank
+
+
+def test_image_bounds_host_entry_matches_oracle(oracle_mod):
+    """drfe_frame_image_bounds is pure host code (Frame::ComputeImageBounds): callable without a GPU, bit-equal to
+    the oracle's restatement of cv::undistortPoints on the four corners."""
+    import ctypes as C
+    from dr_slam_amd import lib, synth
+    L = lib.load()
+    for cam in (synth.TUM1, synth.TUM2, synth.TUM3):
+        c = lib.make_camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.depth_factor, cam.w, cam.h)
+        d = np.ascontiguousarray(cam.dist, np.float32)
+        out = np.zeros(4, np.float32)
+        rc = L.drfe_frame_image_bounds(C.byref(c), d.ctypes.data_as(C.c_void_p), len(d), cam.w, cam.h, out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        K = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        ref = oracle_mod.image_bounds(cam.w, cam.h, K, d if len(d) else [0.0])
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (out, ref)

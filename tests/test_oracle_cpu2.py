@@ -316,3 +316,31 @@ def test_golden_lsd_projection(oracle_mod):
                                                sc["cur_ml"], sc["cur_obs"])
         assert np.array_equal(np.concatenate([[n], ml]), g[f"map_{seed}"])
         assert n > 5
+
+
+# ---- Frame::UndistortKeyPoints / ComputeImageBounds (row a-21, k1 != 0) -------------------------------------------
+
+def test_undistort_points_inverts_the_distortion_model(oracle_mod):
+    """cv::undistortPoints restatement: re-applying the forward radial/tangential model to the output returns the
+    input (five iterations: ~1e-5 px in the image centre, ~0.1 px in the far corners, as OpenCV's)."""
+    from dr_slam_amd import synth
+    for cam in (synth.TUM1, synth.TUM2):
+        K = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        k1, k2, p1, p2, k3 = cam.dist
+        rng = np.random.RandomState(3)
+        pts = np.stack([rng.uniform(0, 640, 500), rng.uniform(0, 480, 500)], 1).astype(np.float32)
+        un = oracle_mod.undistort_points(pts, K, cam.dist).astype(np.float64)
+        x, y = (un[:, 0] - K[2]) / K[0], (un[:, 1] - K[3]) / K[1]
+        r2 = x * x + y * y
+        c = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+        xd = x * c + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * c + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        back = np.stack([xd * K[0] + K[2], yd * K[1] + K[3]], 1)
+        err = np.abs(back - pts).max(1)
+        central = np.hypot(pts[:, 0] - 320, pts[:, 1] - 240) < 150
+        assert err[central].max() < 1e-3 and err.max() < 0.2
+        assert np.abs(un - pts).max() > 3.0                    # the model really moves border points
+    # k1 == 0 -> bounds are the image, as src/Frame.cc:884-889
+    assert list(oracle_mod.image_bounds(640, 480, K, [0.0, 0.1, 0, 0])) == [0.0, 640.0, 0.0, 480.0]
+    b = oracle_mod.image_bounds(640, 480, np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32), synth.TUM1.dist)
+    assert 5 < b[0] < 20 and 620 < b[1] < 635 and 5 < b[2] < 20 and 465 < b[3] < 478
