@@ -34,7 +34,7 @@ SYMBOLS = (
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
-    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_by_projection_last",
+    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map",
 )
 
@@ -116,6 +116,8 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_uint32, vp, vp, vp, C.POINTER(i32)]
     L.drfe_frame_set_distortion.argtypes = [vp, vp, vp, i32]
     L.drfe_frame_image_bounds.argtypes = [vp, vp, i32, i32, i32, vp]
     L.drfe_frame_download_keys_un.argtypes = [vp, i32, vp, i32]
@@ -148,6 +150,26 @@ def make_camera(fx, fy, cx, cy, bf, depth_map_factor, width, height) -> Camera:
     depth_map_factor is the yaml DepthMapFactor; the reference inverts it (src/Tracking.cc:144-148)."""
     inv = np.float32(1.0) if abs(depth_map_factor) < 1e-5 else np.float32(1.0) / np.float32(depth_map_factor)
     return Camera(fx, fy, cx, cy, bf, float(inv), 0.0, float(width), 0.0, float(height))
+
+
+def lines_is_good(lines, depth_f32, K9, cx, cy, invfx, invfy, k_as_f64=False, seed=1):
+    """Frame::isLineGood (host entry, no context / GPU needed): returns (mvDepthLine, mvLines3D[n,6], inliers, n_good).
+    k_as_f64=False is the reference as shipped (CV_32F mK read as double -> nothing is accepted)."""
+    L = load()
+    kl = np.ascontiguousarray(lines, KEYLINE_DTYPE)
+    d = np.ascontiguousarray(depth_f32, np.float32)
+    K = np.ascontiguousarray(K9, np.float32).reshape(9)
+    n = len(kl)
+    dl = np.zeros(max(n, 1), np.float32)
+    l3 = np.zeros((max(n, 1), 6), np.float64)
+    ni = np.zeros(max(n, 1), np.int32)
+    good = C.c_int()
+    rc = L.drfe_lines_is_good(_p(kl), n, _p(d), d.shape[1], d.shape[0], d.shape[1], _p(K), int(bool(k_as_f64)),
+                              C.c_float(cx), C.c_float(cy), C.c_float(invfx), C.c_float(invfy), int(seed), _p(dl), _p(l3),
+                              _p(ni), C.byref(good))
+    if rc != 0:
+        raise RuntimeError(f"drfe_lines_is_good failed ({rc})")
+    return dl[:n], l3[:n], ni[:n], good.value
 
 
 class Context:

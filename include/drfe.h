@@ -225,6 +225,19 @@ int drfe_lsd_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t st
 int drfe_lsd_stages(drfe_ctx* ctx, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy,
                     int* sw, int* sh);
 
+/* Frame::isLineGood, src/Frame.cc:481-558, with the 3-D line lifting of src/LineExtractor.cpp:1157-1470: up to 51
+ * nearest-pixel depth samples per key line, per-sample covariance, Mahalanobis RANSAC driven by rand(), refit,
+ * accept if inliers / length > 0.4 and |A - B| > 0.02.  Host code (40 lines x 51 samples of double arithmetic), no
+ * context needed.  depth: the CV_32F depth image in metres; K: the nine floats of mK exactly as the reference passes
+ * them.  k_as_f64 = 0 reproduces the shipped behaviour — compPt3dCov reads that CV_32F matrix with at<double>, the
+ * focal length becomes a subnormal, every covariance is NaN and NO line is accepted (depth_line = -1, lines3d = 0
+ * for all) — by doing the same arithmetic on the same bytes; k_as_f64 = 1 runs the algorithm with f = fx as it was
+ * meant (agrees with an OpenCV build to rounding, endpoint order not pinned; see lines_3d.cpp).  seed: srand() state
+ * (1 = a fresh process).  Outputs per line: mvDepthLine, mvLines3D (A xyz, B xyz), optional inlier counts. */
+int drfe_lines_is_good(const drfe_keyline* lines, int n, const float* depth, int w, int h, size_t stride,
+                       const float* K, int k_as_f64, float cx, float cy, float invfx, float invfy, uint32_t seed,
+                       float* depth_line, double* lines3d, int32_t* n_inliers, int* n_good);
+
 /* LSDmatcher::SearchByProjection, src/LSDmatcher.cpp:20-139 (Frame, Frame) and :141-211 (Frame,
  * vector<MapLine*>), with Frame::GetLinesInArea (src/Frame.cc:781-813): project the 3-D end points with
  * Tcw (float cv::Mat path), collect the current key lines whose midpoint lies within the radius and

@@ -131,3 +131,70 @@ def test_image_bounds_host_entry_matches_oracle(oracle_mod):
         K = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
         ref = oracle_mod.image_bounds(cam.w, cam.h, K, d if len(d) else [0.0])
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (out, ref)
+
+
+# ---- Frame::isLineGood (row a-8): host entry of libdrfe.so vs the numpy oracle, no GPU involved -----------------
+
+def _lines_and_depth(oracle_mod, seed=2, kind="room_boxes"):
+    from dr_slam_amd import lib, synth
+    g, d16, _ = next(synth.sequence(seed, 1, kind=kind))
+    o = oracle_mod.extract_lines(g)
+    kl = np.zeros(len(o["lines"]), lib.KEYLINE_DTYPE)
+    for a, b in (("start_point_x", "startPointX"), ("start_point_y", "startPointY"), ("end_point_x", "endPointX"),
+                 ("end_point_y", "endPointY"), ("pt_x", "ptX"), ("pt_y", "ptY"), ("angle", "angle"), ("octave", "octave")):
+        kl[a] = o["lines"][b]
+    depth = oracle_mod.depth_to_float(d16, np.float32(1.0) / np.float32(synth.TUM3.depth_factor))
+    return kl, depth
+
+
+def test_glibc_rand_restatement_matches_libc():
+    import ctypes
+    from oracle.line3d_oracle import GlibcRand
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (1, 7, 20240101):
+        libc.srand(seed)
+        g = GlibcRand(seed)
+        assert [libc.rand() for _ in range(500)] == [g() for _ in range(500)]
+
+
+def test_is_line_good_as_shipped_rejects_every_line(oracle_mod):
+    """mK is CV_32F but compPt3dCov reads K.at<double>(0,0): f is subnormal, z/f = inf, the covariance is NaN and no
+    sample is ever an inlier — the reference leaves mvDepthLine = -1 and mvLines3D = 0; product and oracle agree."""
+    from dr_slam_amd import lib, synth
+    from oracle import line3d_oracle as L3
+    cam = synth.TUM3
+    K = np.array([cam.fx, 0, cam.cx, 0, cam.fy, cam.cy, 0, 0, 1], np.float32)
+    f = L3.focal_as_reference_reads_it(K)
+    with np.errstate(over="ignore"):
+        assert 0 < f < 1e-300 and np.isinf(np.float64(0.5) / f)
+    kl, depth = _lines_and_depth(oracle_mod)
+    assert len(kl) >= 20
+    inv = (np.float32(1) / np.float32(cam.fx), np.float32(1) / np.float32(cam.fy))
+    dl, l3, ni, good = lib.lines_is_good(kl, depth, K, cam.cx, cam.cy, inv[0], inv[1], k_as_f64=False)
+    odl, ol3, oni = L3.is_line_good(kl, depth, K, False, cam.cx, cam.cy, inv[0], inv[1])
+    assert good == 0 and (dl == -1).all() and (l3 == 0).all() and (ni == 0).all()
+    assert np.array_equal(dl, odl) and np.array_equal(l3, ol3) and np.array_equal(ni, oni)
+
+
+def test_is_line_good_as_intended_matches_numpy_oracle(oracle_mod):
+    """k_as_f64: f = fx.  Same accept decisions, inlier counts and depth; 3-D end points equal up to the A/B swap the
+    singular-vector sign allows (the oracle uses LAPACK SVD, the product a symmetric eigen-solve)."""
+    from dr_slam_amd import lib, synth
+    from oracle import line3d_oracle as L3
+    cam = synth.TUM3
+    K = np.array([cam.fx, 0, cam.cx, 0, cam.fy, cam.cy, 0, 0, 1], np.float32)
+    inv = (np.float32(1) / np.float32(cam.fx), np.float32(1) / np.float32(cam.fy))
+    total = 0
+    for seed, kind in ((2, "room_boxes"), (5, "corridor")):
+        kl, depth = _lines_and_depth(oracle_mod, seed, kind)
+        dl, l3, ni, good = lib.lines_is_good(kl, depth, K, cam.cx, cam.cy, inv[0], inv[1], k_as_f64=True, seed=1)
+        odl, ol3, oni = L3.is_line_good(kl, depth, K, True, cam.cx, cam.cy, inv[0], inv[1], seed=1)
+        assert np.array_equal(ni, oni), (ni, oni)
+        assert np.array_equal(dl.view(np.uint32), odl.view(np.uint32))
+        for a, b in zip(l3, ol3):
+            same = np.allclose(a, b, atol=1e-9)
+            swapped = np.allclose(a, np.concatenate([b[3:], b[:3]]), atol=1e-9)
+            assert same or swapped
+        assert good == int((dl >= 0).sum())
+        total += good
+    assert total >= 10          # most synthetic wall/box edges carry depth and lift to 3-D
