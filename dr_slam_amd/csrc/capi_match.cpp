@@ -1,6 +1,7 @@
 /* capi_match.cpp — C-ABI entry points of the Frame glue and the matchers (include/drfe.h). */
 #include "drfe_internal.h"
 #include "match_internal.h"
+#include "../../include/drfe_math.h"
 
 #include <algorithm>
 #include <cstring>
@@ -87,6 +88,40 @@ static int match_status(drfe_ctx* c)
     if (st & 4) { c->err = "match candidate list overflow (DRFE_MATCH_MAX_CAND)"; return DRFE_ERR_CAPACITY; }
     return DRFE_OK;
 }
+
+static void frustum_pose(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, float limit, FrustumPose* P)
+{
+    std::memcpy(P->T, Tcw, 64);
+    for (int i = 0; i < 3; i++) {   /* mOw = -mRcw.t()*mtcw: general gemm path, double accumulation (src/Frame.cc:592-600) */
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tcw[k * 4 + i] * (double)Tcw[k * 4 + 3];
+        P->Ow[i] = (float)(s * -1.0);
+    }
+    P->bf = cam->bf;
+    P->logScale = drfe_logf(c->cfg.scale_factor);     /* Frame::mfLogScaleFactor = log(mfScaleFactor) */
+    P->nLevels = c->cfg.nlevels;
+    P->limit = limit;
+}
+
+template <class In, class Out, class Launch>
+static int frustum_run(drfe_ctx* c, const In* in, int n, Out* out, Launch launch)
+{
+    if (n == 0) return DRFE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t oIn = 0, oOut = (sizeof(In) * (size_t)n + 63) & ~(size_t)63, total = oOut + sizeof(Out) * (size_t)n;
+    HIPCHK(c, hipMalloc(&d, total));
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(d + oIn, in, sizeof(In) * (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oOut, out, sizeof(Out) * (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch(reinterpret_cast<const In*>(d + oIn), reinterpret_cast<Out*>(d + oOut), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + oOut, sizeof(Out) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("is_in_frustum: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    return DRFE_OK;
+}
+
 
 extern "C" {
 
@@ -541,6 +576,33 @@ int drfe_lsd_search_by_projection_map(drfe_ctx* c, const drfe_tracked_line* line
     }
     return line_search_run(c, &q, nullptr, n, nullptr, nullptr, 0, 0, th, cur_lines, cur_desc, n_cur, nnratio, cur_obs,
                            cur_ml, nmatches);
+}
+
+
+/* ---- Frame::isInFrustum ---------------------------------------------------------------------------- */
+
+int drfe_frame_is_in_frustum(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, const drfe_frustum_point* pts, int n,
+                             float viewing_cos_limit, drfe_tracked_point* out)
+{
+    if (!c || !Tcw || !cam || n < 0 || (n && (!pts || !out))) return DRFE_ERR_INVALID;
+    FrustumPose P;
+    frustum_pose(c, Tcw, cam, viewing_cos_limit, &P);
+    const drfe_camera cm = *cam;
+    return frustum_run(c, pts, n, out, [&](const drfe_frustum_point* di, drfe_tracked_point* dout, hipStream_t s) {
+        return drfe_launch_frustum_points(di, n, P, cm, dout, s);
+    });
+}
+
+int drfe_frame_is_in_frustum_lines(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines, int n,
+                                   float viewing_cos_limit, drfe_tracked_line* out)
+{
+    if (!c || !Tcw || !cam || n < 0 || (n && (!lines || !out))) return DRFE_ERR_INVALID;
+    FrustumPose P;
+    frustum_pose(c, Tcw, cam, viewing_cos_limit, &P);
+    const drfe_camera cm = *cam;
+    return frustum_run(c, lines, n, out, [&](const drfe_frustum_line* di, drfe_tracked_line* dout, hipStream_t s) {
+        return drfe_launch_frustum_lines(di, n, P, cm, dout, s);
+    });
 }
 
 } /* extern "C" */

@@ -62,6 +62,12 @@ hipError_t drfe_launch_line_projection(const drfe_map_line* d_lines, int n, cons
 hipError_t drfe_launch_line_search(const LineQuery* d_q, int n, const LineCur* d_cur, const uint8_t* d_desc, int nCur,
                                    float nnratio, uint8_t* d_claim, int* d_curMl, int* d_nmatches, hipStream_t s);
 
+struct FrustumPose { float T[16]; float Ow[3]; float bf; float logScale; int nLevels; float limit; };
+hipError_t drfe_launch_frustum_points(const drfe_frustum_point* d_pts, int n, const FrustumPose& P, const drfe_camera& cam,
+                                      drfe_tracked_point* d_out, hipStream_t s);
+hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, const FrustumPose& P, const drfe_camera& cam,
+                                     drfe_tracked_line* d_out, hipStream_t s);
+
 MatchBuffers* drfe_match_buffers(drfe_ctx* c);   /* lazily allocated, owned by the context */
 void drfe_match_buffers_free(drfe_ctx* c);
 #endif

@@ -820,3 +820,90 @@ hipError_t drfe_launch_line_search(const LineQuery* d_q, int n, const LineCur* d
                        d_nmatches);
     return hipGetLastError();
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Frame::isInFrustum (src/Frame.cc:602-727)                                                          */
+
+/* cv::norm / Mat::dot of 3x1 CV_32F: double accumulation */
+__device__ __forceinline__ float norm3_f(const float v[3]) { return (float)sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }
+__device__ __forceinline__ double dot3_d(const float a[3], const float b[3]) { return (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]; }
+
+__global__ __launch_bounds__(256) void k_frustum_points(const drfe_frustum_point* __restrict__ pts, int n, FrustumPose P,
+                                                        drfe_camera cam, drfe_tracked_point* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const drfe_frustum_point p = pts[i];
+    drfe_tracked_point o = out[i];
+    o.track_in_view = 0; o.level = 0; o.proj_x = o.proj_y = o.proj_xr = o.view_cos = 0.f;
+    float Pc[3];
+    mat3_mul_add(P.T, p.world, Pc);
+    bool ok = !(Pc[2] < 0.0f);
+    const float invz = 1.0f / Pc[2];
+    const float u = cam.fx * Pc[0] * invz + cam.cx, v = cam.fy * Pc[1] * invz + cam.cy;
+    if (u < cam.min_x || u > cam.max_x || v < cam.min_y || v > cam.max_y) ok = false;
+    const float maxDistance = 1.2f * p.max_distance, minDistance = 0.8f * p.min_distance;
+    const float PO[3] = {p.world[0] - P.Ow[0], p.world[1] - P.Ow[1], p.world[2] - P.Ow[2]};
+    const float dist = norm3_f(PO);
+    if (dist < minDistance || dist > maxDistance) ok = false;
+    const float viewCos = (float)(dot3_d(PO, p.normal) / (double)dist);
+    if (viewCos < P.limit) ok = false;
+    if (ok) {
+        const float ratio = p.max_distance / dist;
+        int nScale = (int)ceilf(drfe_logf(ratio) / P.logScale);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= P.nLevels) nScale = P.nLevels - 1;
+        o.track_in_view = 1; o.proj_x = u; o.proj_xr = u - P.bf * invz; o.proj_y = v; o.level = nScale; o.view_cos = viewCos;
+    }
+    out[i] = o;
+}
+
+__global__ __launch_bounds__(256) void k_frustum_lines(const drfe_frustum_line* __restrict__ lines, int n, FrustumPose P,
+                                                       drfe_camera cam, drfe_tracked_line* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const drfe_frustum_line l = lines[i];
+    drfe_tracked_line o = out[i];
+    o.in_view = 0; o.level = 0; o.x1 = o.y1 = o.x2 = o.y2 = o.view_cos = 0.f;
+    const float SP[3] = {(float)l.world[0], (float)l.world[1], (float)l.world[2]};
+    const float EP[3] = {(float)l.world[3], (float)l.world[4], (float)l.world[5]};
+    float SPc[3], EPc[3];
+    mat3_mul_add(P.T, SP, SPc);
+    mat3_mul_add(P.T, EP, EPc);
+    bool ok = !(SPc[2] < 0.0f || EPc[2] < 0.0f);
+    const float invz1 = 1.0f / SPc[2];
+    const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+    if (u1 < cam.min_x || u1 > cam.max_x || v1 < cam.min_y || v1 > cam.max_y) ok = false;
+    const float invz2 = 1.0f / EPc[2];
+    const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+    if (u2 < cam.min_x || u2 > cam.max_x || v2 < cam.min_y || v2 > cam.max_y) ok = false;
+    const float maxDistance = 1.2f * l.max_distance, minDistance = 0.8f * l.min_distance;
+    float OM[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) OM[k] = (SP[k] + EP[k]) * 0.5f - P.Ow[k];
+    const float dist = norm3_f(OM);
+    if (dist < minDistance || dist > maxDistance) ok = false;
+    const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
+    const float viewCos = (float)(dot3_d(OM, pn) / (double)dist);
+    if (viewCos < P.limit) ok = false;
+    if (ok) {
+        const float ratio = l.max_distance / dist;
+        o.in_view = 1; o.x1 = u1; o.y1 = v1; o.x2 = u2; o.y2 = v2; o.view_cos = viewCos;
+        o.level = (int)ceilf(drfe_logf(ratio) / P.logScale);       /* MapLine::PredictScale does not clamp */
+    }
+    out[i] = o;
+}
+
+hipError_t drfe_launch_frustum_points(const drfe_frustum_point* d_pts, int n, const FrustumPose& P, const drfe_camera& cam,
+                                      drfe_tracked_point* d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_frustum_points, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, P, cam, d_out);
+    return hipGetLastError();
+}
+hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, const FrustumPose& P, const drfe_camera& cam,
+                                     drfe_tracked_line* d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_frustum_lines, dim3((n + 255) / 256), dim3(256), 0, s, d_lines, n, P, cam, d_out);
+    return hipGetLastError();
+}

@@ -29,7 +29,7 @@ SYMBOLS = (
     "drfe_create", "drfe_destroy", "drfe_last_error", "drfe_version", "drfe_orb_scale_tables",
     "drfe_orb_max_keypoints", "drfe_orb_extract", "drfe_orb_extract_batch", "drfe_orb_download", "drfe_orb_counts",
     "drfe_orb_pyramid_level", "drfe_orb_blurred_level", "drfe_orb_candidates", "drfe_frame_stereo_grid_batch",
-    "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
+    "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
@@ -38,6 +38,10 @@ SYMBOLS = (
     "drfe_lsd_search_by_projection_map",
 )
 
+FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
+                                ("max_distance", "<f4")])                            # drfe_frustum_point, 32 B
+FRUSTUM_LINE_DTYPE = np.dtype([("world", "<f8", (6,)), ("normal", "<f8", (3,)), ("min_distance", "<f4"),
+                               ("max_distance", "<f4")])                             # drfe_frustum_line, 80 B
 MAPLINE_DTYPE = np.dtype([("valid", "<i4"), ("octave", "<i4"), ("obs_positive", "<i4"), ("pad", "<i4"),
                           ("world", "<f8", (6,)), ("desc", "u1", (32,))])            # drfe_map_line, 96 B
 TRACKED_LINE_DTYPE = np.dtype([("in_view", "<i4"), ("level", "<i4"), ("obs_positive", "<i4"), ("x1", "<f4"),
@@ -118,6 +122,8 @@ def load() -> C.CDLL:
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
     L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
+    L.drfe_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, i32, C.c_float, vp]
+    L.drfe_frame_is_in_frustum_lines.argtypes = [vp, vp, vp, vp, i32, C.c_float, vp]
     L.drfe_frame_set_distortion.argtypes = [vp, vp, vp, i32]
     L.drfe_frame_image_bounds.argtypes = [vp, vp, i32, i32, i32, vp]
     L.drfe_frame_download_keys_un.argtypes = [vp, i32, vp, i32]
@@ -326,6 +332,24 @@ class Context:
         self._chk(self.L.drfe_match_orb_points(self.h, cur_slot, last_slot, _p(last_mp), _p(last_outlier), len(last_mp),
                                                _p(out), n_cur, C.byref(n)), "drfe_match_orb_points")
         return n.value, out
+
+    def is_in_frustum(self, Tcw, cam, pts, viewing_cos_limit, out=None):
+        """Frame::isInFrustum(MapPoint*, limit) for an array of map points; returns the drfe_tracked_point array with
+        the tracking fields filled (bad / obs_positive / desc of `out` are preserved)."""
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        p = np.ascontiguousarray(pts, FRUSTUM_POINT_DTYPE)
+        o = np.zeros(len(p), TRACKED_DTYPE) if out is None else np.ascontiguousarray(out, TRACKED_DTYPE).copy()
+        self._chk(self.L.drfe_frame_is_in_frustum(self.h, _p(T), C.byref(cam), _p(p), len(p), C.c_float(viewing_cos_limit),
+                                                  _p(o)), "drfe_frame_is_in_frustum")
+        return o
+
+    def is_in_frustum_lines(self, Tcw, cam, lines, viewing_cos_limit, out=None):
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+        o = np.zeros(len(l), TRACKED_LINE_DTYPE) if out is None else np.ascontiguousarray(out, TRACKED_LINE_DTYPE).copy()
+        self._chk(self.L.drfe_frame_is_in_frustum_lines(self.h, _p(T), C.byref(cam), _p(l), len(l),
+                                                        C.c_float(viewing_cos_limit), _p(o)), "drfe_frame_is_in_frustum_lines")
+        return o
 
     def set_distortion(self, cam, dist):
         """Frame::UndistortKeyPoints model (k1, k2, p1, p2[, k3]); None / k1 == 0 switches it off."""

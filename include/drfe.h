@@ -271,6 +271,20 @@ int drfe_lsd_search_by_projection_map(drfe_ctx* ctx, const drfe_tracked_line* li
                                       const drfe_keyline* cur_lines, const uint8_t* cur_desc, int n_cur, float th,
                                       float nnratio, const uint8_t* cur_obs, int32_t* cur_ml, int* nmatches);
 
+/* Frame::isInFrustum, src/Frame.cc:602-657 (MapPoint*) and :659-727 (MapLine*), the step Tracking::SearchLocalPoints
+ * runs over the local map before SearchByProjection(F, MapPoints): project with Tcw, image bounds, scale-invariance
+ * distance band (0.8 * min, 1.2 * max), viewing-angle cosine against the mean normal, MapPoint::PredictScale
+ * (ceil(log(max / dist) / log scaleFactor), clamped to the pyramid; MapLine::PredictScale does not clamp).  One thread
+ * per map point.  log() is the shared routine drfe_logf (include/drfe_math.h) because glibc's logf is not pinned.
+ * out: only the tracking fields are written (track_in_view / in_view, level, projections, view_cos): fill bad /
+ * obs_positive / desc yourself and hand the array to drfe_search_by_projection_map / drfe_lsd_search_by_projection_map. */
+typedef struct drfe_frustum_point { float world[3], normal[3], min_distance, max_distance; } drfe_frustum_point;
+typedef struct drfe_frustum_line { double world[6], normal[3]; float min_distance, max_distance; } drfe_frustum_line;
+int drfe_frame_is_in_frustum(drfe_ctx* ctx, const float* Tcw, const drfe_camera* cam, const drfe_frustum_point* pts, int n,
+                             float viewing_cos_limit, drfe_tracked_point* out);
+int drfe_frame_is_in_frustum_lines(drfe_ctx* ctx, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines,
+                                   int n, float viewing_cos_limit, drfe_tracked_line* out);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */

@@ -10,12 +10,15 @@
  *   drfe_sincos           <- cos(float)/sin(float) (reference src/ORBextractor.cc:113-114); the
  *                            reference calls glibc cosf/sinf whose last bit is host dependent, so the
  *                            build canonicalises on this routine.
+ *   drfe_logf             <- log(float) of MapPoint::PredictScale / MapLine::PredictScale (reference
+ *                            src/MapPoint.cc:456, src/MapLine.cpp:389) — same libm caveat, same remedy.
  */
 #ifndef DRFE_MATH_H
 #define DRFE_MATH_H
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define DRFE_HD __host__ __device__ static inline
@@ -102,6 +105,29 @@ DRFE_HD void drfe_sincos(float rad, float* s_out, float* c_out)
 
 /* 256-bit Hamming distance: the reference's 8x32-bit SWAR popcount (src/ORBmatcher.cc:1712-1728,
  * src/LSDmatcher.cpp:316-332) equals popcount(xor) over 4x u64. */
+/* log of a positive finite float32, evaluated in float64 and rounded once to float32:
+ * x = m * 2^e with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) as an odd series to t^25
+ * (|t| <= 0.1716: truncation < 1e-20), plus e * ln 2.  Zero, negative, inf and NaN follow logf(). */
+DRFE_HD float drfe_logf(float xf)
+{
+    if (!(xf > 0.0f)) return xf == 0.0f ? -INFINITY : NAN;
+    if (xf == INFINITY) return xf;
+    double x = (double)xf;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7FF) - 1023;          /* floats promoted to double are never subnormal */
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    memcpy(&m, &bits, 8);                                 /* [1, 2) */
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double p = 1.0 / 25.0;
+    p = p * t2 + 1.0 / 23.0; p = p * t2 + 1.0 / 21.0; p = p * t2 + 1.0 / 19.0; p = p * t2 + 1.0 / 17.0;
+    p = p * t2 + 1.0 / 15.0; p = p * t2 + 1.0 / 13.0; p = p * t2 + 1.0 / 11.0; p = p * t2 + 1.0 / 9.0;
+    p = p * t2 + 1.0 / 7.0;  p = p * t2 + 1.0 / 5.0;  p = p * t2 + 1.0 / 3.0;  p = p * t2 + 1.0;
+    return (float)(2.0 * t * p + (double)e * 0.6931471805599453);
+}
+
 DRFE_HD int drfe_hamming256(const uint64_t* a, const uint64_t* b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

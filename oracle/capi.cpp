@@ -451,6 +451,19 @@ int orc_lsd_search_by_projection_map(const float* scale, const TrackedLineRec* l
 {
     return lsd_search_by_projection_map(scale, lines, n, cur, curDesc, nCur, th, nnratio, curObs, curML);
 }
+void orc_is_in_frustum(const float* cam9, float bf, const float* Tcw, float logScale, int nLevels, const FrustumPointRec* pts,
+                       int n, float limit, FrustumOut* out)
+{
+    const LineCamera cam = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    is_in_frustum(cam, bf, Tcw, logScale, nLevels, pts, n, limit, out);
+}
+void orc_is_in_frustum_lines(const float* cam9, const float* Tcw, float logScale, const FrustumLineRec* lines, int n,
+                             float limit, FrustumLineOut* out)
+{
+    const LineCamera cam = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    is_in_frustum_lines(cam, Tcw, logScale, lines, n, limit, out);
+}
+float orc_logf(float x) { return drfe_logf(x); }
 int orc_sizeof_maplinerec() { return (int)sizeof(MapLineRec); }
 int orc_sizeof_trackedlinerec() { return (int)sizeof(TrackedLineRec); }
 

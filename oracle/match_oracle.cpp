@@ -6,6 +6,7 @@
  */
 #include "oracle.h"
 #include "match_oracle.h"
+#include "../include/drfe_math.h"
 
 #include <algorithm>
 #include <cmath>
@@ -508,6 +509,96 @@ int lsd_search_by_projection_map(const float* scaleFactors, const TrackedLineRec
         }
     }
     return nmatches;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* Frame::isInFrustum                                                                                   */
+
+/* mOw = -mRcw.t()*mtcw (Frame::UpdatePoseMatrices, src/Frame.cc:592-600): general gemm path, double
+ * accumulation, alpha = -1 */
+static void camera_centre(const float Rcw[9], const float tcw[3], float Ow[3])
+{
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Rcw[k * 3 + i] * (double)tcw[k];
+        Ow[i] = (float)(s * -1.0);
+    }
+}
+/* cv::norm(3x1 CV_32F): double accumulation, sqrt, stored to float; Mat::dot likewise accumulates in double */
+static float norm3(const float v[3]) { return (float)std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }
+static double dot3(const float a[3], const float b[3]) { return (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]; }
+
+void is_in_frustum(const LineCamera& cam, float bf, const float Tcw[16], float logScaleFactor, int nLevels,
+                   const FrustumPointRec* pts, int n, float viewingCosLimit, FrustumOut* out)
+{
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+    camera_centre(Rcw, tcw, Ow);
+    for (int i = 0; i < n; i++) {
+        FrustumOut& o = out[i];
+        o.inView = 0; o.level = 0; o.projX = o.projY = o.projXR = o.viewCos = 0.f;
+        const FrustumPointRec& p = pts[i];
+        float Pc[3];
+        mat3_mul_add(Rcw, p.world, tcw, Pc);
+        if (Pc[2] < 0.0f) continue;
+        const float invz = 1.0f / Pc[2];
+        const float u = cam.fx * Pc[0] * invz + cam.cx, v = cam.fy * Pc[1] * invz + cam.cy;
+        if (u < cam.minX || u > cam.maxX) continue;
+        if (v < cam.minY || v > cam.maxY) continue;
+        const float maxDistance = 1.2f * p.maxDistance, minDistance = 0.8f * p.minDistance;
+        const float PO[3] = {p.world[0] - Ow[0], p.world[1] - Ow[1], p.world[2] - Ow[2]};
+        const float dist = norm3(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float viewCos = (float)(dot3(PO, p.normal) / (double)dist);
+        if (viewCos < viewingCosLimit) continue;
+        /* MapPoint::PredictScale(dist, Frame*), src/MapPoint.cc:448-463 */
+        const float ratio = p.maxDistance / dist;
+        int nScale = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= nLevels) nScale = nLevels - 1;
+        o.inView = 1; o.projX = u; o.projXR = u - bf * invz; o.projY = v; o.level = nScale; o.viewCos = viewCos;
+    }
+}
+
+void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logScaleFactor, const FrustumLineRec* lines,
+                         int n, float viewingCosLimit, FrustumLineOut* out)
+{
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+    camera_centre(Rcw, tcw, Ow);
+    for (int i = 0; i < n; i++) {
+        FrustumLineOut& o = out[i];
+        o.inView = 0; o.level = 0; o.x1 = o.y1 = o.x2 = o.y2 = o.viewCos = 0.f;
+        const FrustumLineRec& l = lines[i];
+        const float SP[3] = {(float)l.world[0], (float)l.world[1], (float)l.world[2]};
+        const float EP[3] = {(float)l.world[3], (float)l.world[4], (float)l.world[5]};
+        float SPc[3], EPc[3];
+        mat3_mul_add(Rcw, SP, tcw, SPc);
+        mat3_mul_add(Rcw, EP, tcw, EPc);
+        if (SPc[2] < 0.0f || EPc[2] < 0.0f) continue;
+        const float invz1 = 1.0f / SPc[2];
+        const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+        if (u1 < cam.minX || u1 > cam.maxX) continue;
+        if (v1 < cam.minY || v1 > cam.maxY) continue;
+        const float invz2 = 1.0f / EPc[2];
+        const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+        if (u2 < cam.minX || u2 > cam.maxX) continue;
+        if (v2 < cam.minY || v2 > cam.maxY) continue;
+        const float maxDistance = 1.2f * l.maxDistance, minDistance = 0.8f * l.minDistance;
+        /* OM = 0.5*(SP+EP) - mOw: float sum, exact halving, float difference (cv::addWeighted in float) */
+        float OM[3];
+        for (int k = 0; k < 3; k++) OM[k] = (SP[k] + EP[k]) * 0.5f - Ow[k];
+        const float dist = norm3(OM);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
+        const float viewCos = (float)(dot3(OM, pn) / (double)dist);
+        if (viewCos < viewingCosLimit) continue;
+        /* MapLine::PredictScale, src/MapLine.cpp:381-390: no clamping */
+        const float ratio = l.maxDistance / dist;
+        o.inView = 1; o.x1 = u1; o.y1 = v1; o.x2 = u2; o.y2 = v2; o.viewCos = viewCos;
+        o.level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+    }
 }
 
 } // namespace orc

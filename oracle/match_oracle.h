@@ -96,5 +96,17 @@ int lsd_search_by_projection_map(const float* scaleFactors, const TrackedLineRec
                                  const uint8_t* curDesc, int nCur, float th, float nnratio, const uint8_t* curObs,
                                  int32_t* curML);
 
+
+/* --- Frame::isInFrustum, src/Frame.cc:602-657 (MapPoint) and :659-727 (MapLine) -------------------- */
+struct FrustumPointRec { float world[3], normal[3], minDistance, maxDistance; };      /* mfMinDistance / mfMaxDistance raw */
+struct FrustumLineRec { double world[6], normal[3]; float minDistance, maxDistance; };
+struct FrustumOut { int32_t inView, level; float projX, projY, projXR, viewCos; };    /* mbTrackInView ... mTrackViewCos */
+struct FrustumLineOut { int32_t inView, level; float x1, y1, x2, y2, viewCos; };
+/* logScaleFactor = Frame::mfLogScaleFactor; nLevels = mnScaleLevels.  log() is the canonical drfe_logf. */
+void is_in_frustum(const LineCamera& cam, float bf, const float Tcw[16], float logScaleFactor, int nLevels,
+                   const FrustumPointRec* pts, int n, float viewingCosLimit, FrustumOut* out);
+void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logScaleFactor, const FrustumLineRec* lines,
+                         int n, float viewingCosLimit, FrustumLineOut* out);
+
 } // namespace orc
 #endif

@@ -309,6 +309,45 @@ class FrameOracle:
         return w, v
 
 
+FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
+                                ("max_distance", "<f4")])
+FRUSTUM_LINE_DTYPE = np.dtype([("world", "<f8", (6,)), ("normal", "<f8", (3,)), ("min_distance", "<f4"),
+                               ("max_distance", "<f4")])
+FRUSTUM_OUT_DTYPE = np.dtype([("in_view", "<i4"), ("level", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
+                              ("view_cos", "<f4")])
+FRUSTUM_LINE_OUT_DTYPE = np.dtype([("in_view", "<i4"), ("level", "<i4"), ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"),
+                                   ("y2", "<f4"), ("view_cos", "<f4")])
+
+
+def logf(x):
+    L = lib()
+    L.orc_logf.restype = C.c_float
+    L.orc_logf.argtypes = [C.c_float]
+    return L.orc_logf(float(x))
+
+
+def is_in_frustum(cam9, bf, Tcw, scale_factor, nlevels, pts, limit):
+    """Frame::isInFrustum(MapPoint*, viewingCosLimit), src/Frame.cc:602-657, for an array of map points."""
+    L = lib()
+    p = np.ascontiguousarray(pts, FRUSTUM_POINT_DTYPE)
+    out = np.zeros(len(p), FRUSTUM_OUT_DTYPE)
+    L.orc_is_in_frustum.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                    C.c_void_p]
+    L.orc_is_in_frustum(_p(_c(cam9, np.float32)), float(bf), _p(_c(Tcw, np.float32).reshape(16)),
+                        logf(np.float32(scale_factor)), int(nlevels), _p(p), len(p), float(limit), _p(out))
+    return out
+
+
+def is_in_frustum_lines(cam9, Tcw, scale_factor, lines, limit):
+    L = lib()
+    l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+    out = np.zeros(len(l), FRUSTUM_LINE_OUT_DTYPE)
+    L.orc_is_in_frustum_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.orc_is_in_frustum_lines(_p(_c(cam9, np.float32)), _p(_c(Tcw, np.float32).reshape(16)), logf(np.float32(scale_factor)),
+                              _p(l), len(l), float(limit), _p(out))
+    return out
+
+
 def undistort_points(xy, K4, dist):
     """cv::undistortPoints(xy, K, dist, Mat(), K), float32 in/out (N x 2)."""
     xy = _c(xy, np.float32).reshape(-1, 2)

@@ -205,3 +205,54 @@ def test_distorted_camera_undistort_glue_and_match(frames_room, oracle_mod):
             assert n > 100
     finally:
         fe.ctx.close()
+
+
+def _frustum_scene(seed, n, lib_mod):
+    import line_scenarios as LS
+    rng = np.random.RandomState(seed)
+    Tcw = LS._pose(rng, 0.3)
+    pts = np.zeros(n, lib_mod.FRUSTUM_POINT_DTYPE)
+    # points in a box around the camera: in front and behind, inside and outside the image, near and far
+    pts["world"] = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(-2, 8, n)], 1).astype(np.float32)
+    nrm = rng.normal(size=(n, 3))
+    nrm[:, 2] += 1.5                      # mostly facing the camera direction, some not
+    pts["normal"] = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    d = np.linalg.norm(pts["world"], axis=1)
+    pts["min_distance"] = (d * rng.uniform(0.3, 1.3, n)).astype(np.float32)
+    pts["max_distance"] = (pts["min_distance"] * rng.uniform(1.0, 4.0, n)).astype(np.float32)
+    lines = np.zeros(n, lib_mod.FRUSTUM_LINE_DTYPE)
+    a = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(-1, 7, n)], 1)
+    lines["world"] = np.concatenate([a, a + rng.normal(0, 0.5, (n, 3))], 1)
+    lines["normal"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    dl = np.linalg.norm(a, axis=1)
+    lines["min_distance"] = (dl * rng.uniform(0.3, 1.3, n)).astype(np.float32)
+    lines["max_distance"] = (lines["min_distance"] * rng.uniform(1.0, 4.0, n)).astype(np.float32)
+    return Tcw, pts, lines
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_is_in_frustum_points_and_lines(oracle_mod, seed):
+    """Frame::isInFrustum for map points and map lines: every tracking field bit-equal to the oracle, including the
+    float64-accumulated norm / dot and the canonical log of PredictScale."""
+    import line_scenarios as LS
+    from dr_slam_amd import lib
+    ctx = lib.Context(max_batch=1)
+    try:
+        cam = lib.Camera(**LS.CAM)
+        Tcw, pts, lines = _frustum_scene(seed, 5000, lib)
+        o = ctx.is_in_frustum(Tcw, cam, pts, 0.5)
+        ref = oracle_mod.is_in_frustum(LS.cam9(), LS.CAM["bf"], Tcw, 1.2, 8, pts, 0.5)
+        assert np.array_equal(o["track_in_view"], ref["in_view"].astype(np.uint8))
+        assert np.array_equal(o["level"], ref["level"])
+        for a, b in (("proj_x", "proj_x"), ("proj_y", "proj_y"), ("proj_xr", "proj_xr"), ("view_cos", "view_cos")):
+            assert np.array_equal(o[a].view(np.uint32), ref[b].view(np.uint32)), a
+        frac = ref["in_view"].mean()
+        assert 0.02 < frac < 0.6 and len(set(ref["level"][ref["in_view"] == 1])) >= 4
+        ol = ctx.is_in_frustum_lines(Tcw, cam, lines, 0.5)
+        rl = oracle_mod.is_in_frustum_lines(LS.cam9(), Tcw, 1.2, lines, 0.5)
+        assert np.array_equal(ol["in_view"], rl["in_view"]) and np.array_equal(ol["level"], rl["level"])
+        for f in ("x1", "y1", "x2", "y2", "view_cos"):
+            assert np.array_equal(ol[f].view(np.uint32), rl[f].view(np.uint32)), f
+        assert rl["in_view"].sum() > 50
+    finally:
+        ctx.close()

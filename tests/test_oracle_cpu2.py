@@ -344,3 +344,44 @@ def test_undistort_points_inverts_the_distortion_model(oracle_mod):
     assert list(oracle_mod.image_bounds(640, 480, K, [0.0, 0.1, 0, 0])) == [0.0, 640.0, 0.0, 480.0]
     b = oracle_mod.image_bounds(640, 480, np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32), synth.TUM1.dist)
     assert 5 < b[0] < 20 and 620 < b[1] < 635 and 5 < b[2] < 20 and 465 < b[3] < 478
+
+
+# ---- Frame::isInFrustum (f-3) ---------------------------------------------------------------------------------------
+
+def test_canonical_logf_is_correctly_rounded(oracle_mod):
+    rng = np.random.RandomState(5)
+    x = np.exp(rng.uniform(-20, 20, 5000)).astype(np.float32)
+    got = np.array([oracle_mod.logf(v) for v in x], np.float32)
+    ref = np.log(x.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert oracle_mod.logf(1.0) == 0.0 and np.isinf(oracle_mod.logf(0.0)) and np.isnan(oracle_mod.logf(-1.0))
+
+
+def test_is_in_frustum_hand_cases(oracle_mod):
+    """Identity pose, TUM3-like camera: the gates of src/Frame.cc:602-657 one by one and MapPoint::PredictScale."""
+    O = oracle_mod
+    cam9 = np.array([500, 500, 320, 240, 0.08, 0, 640, 0, 480], np.float32)
+    T = np.eye(4, dtype=np.float32)
+
+    def pt(world, normal=(0, 0, 1), dmin=1.0, dmax=10.0):
+        p = np.zeros(1, O.FRUSTUM_POINT_DTYPE)
+        p["world"], p["normal"], p["min_distance"], p["max_distance"] = world, normal, dmin, dmax
+        return p
+
+    r = O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((0, 0, 4)), 0.5)[0]
+    assert r["in_view"] == 1 and r["proj_x"] == 320 and r["proj_y"] == 240 and r["view_cos"] == 1.0
+    assert r["proj_xr"] == np.float32(320) - np.float32(40.0) * np.float32(0.25)
+    # PredictScale: ceil(log(10/4) / log(1.2)) = ceil(5.03) = 6
+    assert r["level"] == 6
+    assert O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((0, 0, -1)), 0.5)[0]["in_view"] == 0          # behind the camera
+    assert O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((4, 0, 4)), 0.5)[0]["in_view"] == 0           # u = 820 > maxX
+    assert O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((0, 0, 0.7)), 0.5)[0]["in_view"] == 0         # closer than 0.8 * min
+    assert O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((0, 0, 12.5)), 0.5)[0]["in_view"] == 0        # farther than 1.2 * max
+    assert O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((0, 0, 11.9)), 0.5)[0]["level"] == 0          # ratio < 1 -> clamped to 0
+    assert O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((0, 0, 1.0), dmin=0.5, dmax=9.0), 0.5)[0]["level"] == 7   # clamped to nLevels-1
+    assert O.is_in_frustum(cam9, 40.0, T, 1.2, 8, pt((0, 0, 4), normal=(1, 0, 0.2)), 0.5)[0]["in_view"] == 0   # viewing angle
+    # map lines: no clamping of the predicted level (src/MapLine.cpp:381-390)
+    ln = np.zeros(1, O.FRUSTUM_LINE_DTYPE)
+    ln["world"], ln["normal"], ln["min_distance"], ln["max_distance"] = (-0.5, 0, 1.0, 0.5, 0, 1.0), (0, 0, 1), 0.5, 9.0
+    r = O.is_in_frustum_lines(cam9, T, 1.2, ln, 0.5)[0]
+    assert r["in_view"] == 1 and r["level"] == 13 and r["x1"] == 70 and r["x2"] == 570
