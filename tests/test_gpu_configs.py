@@ -1,0 +1,98 @@
+"""-m gpu parity tests at the level of BASELINE.json's configs: the whole front-end of one configuration through the
+C-ABI vs the CPU oracle (bit-exact), on top of the per-stage files.
+  config 2 (index 2): ICL-NUIM living-room style scene, ICL intrinsics (fy < 0): ORB + glue + SearchByProjection on a
+                      short sequence, LSD + LBD lines, CAPE and AHC planes of its first frame;
+  config 5 (index 4): 1280x960 RealSense-style frame: LSD + LBD lines and CAPE planes at 4x the pixels (the ORB part
+                      of this configuration is tests/test_gpu_orb.py::test_1280x960_config5)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_kps(kps, okps):
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "angle", "response"):
+        assert np.array_equal(kps[f].view(np.uint32), okps[f].view(np.uint32)), f
+    assert np.array_equal(kps["octave"], okps["octave"])
+
+
+def test_config2_icl_living_room_full_front_end(oracle_mod):
+    import torch
+    from dr_slam_amd import synth
+    from dr_slam_amd.pipeline import FrontEnd
+    O = oracle_mod
+    cam = synth.ICL
+    frames = list(synth.sequence(3, 3, cam=cam, kind="living_room"))
+    fe = FrontEnd(cam, max_batch=4)
+    try:
+        gray = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+        depth = torch.from_numpy(np.stack([f[1] for f in frames]).view(np.int16)).cuda()
+        Twc = np.stack([f[2] for f in frames]).astype(np.float64)
+        Tcw = np.linalg.inv(Twc).astype(np.float32)
+        Twc = Twc.astype(np.float32)
+        fe.process(gray, depth, Tcw, Twc, th=15.0, check_ori=True, stream=torch.cuda.current_stream().cuda_stream)
+        o = O.OrbOracle()
+        K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        inv = np.float32(1.0) / np.float32(cam.depth_factor)
+        of = []
+        for s, (g, d, _) in enumerate(frames):
+            okps, odesc = o(g)
+            kps, desc = fe.keypoints(s)
+            _same_kps(kps, okps)
+            assert np.array_equal(desc, odesc)
+            of.append(O.FrameOracle(okps, odesc, O.depth_to_float(d, inv), K4, cam.bf, cam.w, cam.h, o.scale))
+            ur, z = fe.ctx.download_stereo(s)
+            assert np.array_equal(ur[:of[s].N].view(np.uint32), of[s].uRight.view(np.uint32))
+        total = 0
+        for s in range(1, 3):
+            world, valid = of[s - 1].unproject(Twc[s - 1])
+            mp = np.zeros(of[s - 1].N, O.MAPPOINT_DTYPE)
+            mp["valid"], mp["obsPositive"], mp["world"], mp["desc"] = valid, 1, world, of[s - 1].desc
+            no, mo = O.search_by_projection_last(of[s], of[s - 1], Tcw[s], Tcw[s - 1], mp, 15.0, False, True)
+            m, n = fe.matches(s)
+            assert n == no and np.array_equal(m[:of[s].N], mo)
+            total += n
+        assert total > 200
+        # lines and planes of the first frame
+        g0, d0, _ = frames[0]
+        a, b = fe.ctx.lsd_extract(g0), O.extract_lines(g0)
+        assert len(a["lines"]) == len(b["lines"]) >= 10
+        assert np.array_equal(a["desc"], b["desc"])
+        assert np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
+        for pa, pb in (("start_point_x", "startPointX"), ("end_point_y", "endPointY"), ("angle", "angle"), ("response", "response")):
+            assert np.array_equal(a["lines"][pa].view(np.uint32), b["lines"][pb].view(np.uint32)), pa
+        dm = O.depth_to_float(d0, inv)
+        gp, op = fe.ctx.planes_cape(dm, K4, 20), O.cape_planes(dm, K4, 20)
+        assert len(gp["planes"]) == len(op["planes"]) >= 3 and np.array_equal(gp["seg"], op["seg"])
+        assert np.array_equal(gp["planes"]["normal"].view(np.uint64), op["planes"][:, 0:3].view(np.uint64))
+        ga, oa = fe.ctx.planes_ahc(d0, K4, float(inv)), O.ahc_planes(d0, K4, float(inv))
+        assert len(ga["planes"]) == len(oa["planes"]) >= 2 and np.array_equal(ga["seg"], oa["seg"])
+    finally:
+        fe.ctx.close()
+
+
+def test_config5_1280x960_lines_and_cape_planes(oracle_mod):
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = synth.REALSENSE.scaled(2.0)
+    g, d, _ = next(synth.sequence(5, 1, cam=cam, kind="corridor"))
+    assert g.shape == (960, 1280)
+    c = lib.Context(nfeatures=800, max_width=1280, max_height=960)
+    try:
+        a, b = c.lsd_extract(g), O.extract_lines(g)
+        assert b["detected"] >= 40 and len(a["lines"]) == len(b["lines"]) == 40 and a["detected"] == b["detected"]
+        assert np.array_equal(a["desc"], b["desc"])
+        assert np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
+        for pa, pb in (("start_point_x", "startPointX"), ("start_point_y", "startPointY"), ("end_point_x", "endPointX"),
+                       ("end_point_y", "endPointY"), ("line_length", "lineLength"), ("response", "response")):
+            assert np.array_equal(a["lines"][pa].view(np.uint32), b["lines"][pb].view(np.uint32)), pa
+        K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        dm = O.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+        gp, op = c.planes_cape(dm, K4, 20), O.cape_planes(dm, K4, 20)
+        assert len(gp["planes"]) == len(op["planes"]) >= 2
+        assert np.array_equal(gp["seg"], op["seg"])
+        assert np.array_equal(gp["planes"]["normal"].view(np.uint64), op["planes"][:, 0:3].view(np.uint64))
+        assert np.array_equal(gp["planes"]["d"].view(np.uint64), op["planes"][:, 6].view(np.uint64))
+    finally:
+        c.close()
