@@ -122,6 +122,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->ps = nullptr;
     c->bow = nullptr;
     c->ls = nullptr;
+    c->lineWorkers = nullptr;
+    c->lineHost = nullptr;
     std::memset(&c->cam, 0, sizeof(c->cam));
     std::memset(&c->geom, 0, sizeof(c->geom));
     std::memset(c->ev, 0, sizeof(c->ev));

@@ -130,6 +130,8 @@ struct drfe_ctx {
     struct PlanesScratch* ps; /* lazily allocated plane-path scratch (planes_internal.h) */
     struct BowState* bow;     /* vocabulary + BoW scratch (bow_internal.h), set by drfe_voc_upload */
     struct LinesScratch* ls;  /* line-path scratch (lines_internal.h) */
+    void* lineHost;           /* LineHost*: host buffers of the single-frame line entry */
+    void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */
 
     /* profiling */
     bool profile;

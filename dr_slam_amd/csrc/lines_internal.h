@@ -10,6 +10,7 @@ struct LinesScratch {
     uint8_t* d_img; uint8_t* d_blur; uint8_t* d_scaled;
     uint16_t* d_tmp16;
     double* d_modgrad; double* d_angles;
+    float2* d_cs;                   /* (cos, sin) of float(angle) per scaled pixel, 0 where the angle is undefined */
     unsigned long long* d_maxGrad;
     int16_t* d_gx; int16_t* d_gy;
 };

@@ -14,7 +14,12 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -38,13 +43,19 @@ struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 /* sequential half of cv::LineSegmentDetectorImpl, fed with the device-computed gradient fields */
 class SegmentFinder {
 public:
-    SegmentFinder(int W, int H, const double* modgrad, const double* angles, double maxGrad)
-        : W_(W), H_(H), mod_(modgrad), ang_(angles), used_((size_t)W * H, 0)
+    /* used / order: caller-owned buffers that survive between frames (a lane reuses them: no multi-megabyte
+     * allocation, hence no mmap/page-fault traffic, per frame) */
+    SegmentFinder(int W, int H, const double* modgrad, const double* angles, const float* cs, double maxGrad,
+                  std::vector<uint8_t>& used, std::vector<OPt>& order)
+        : W_(W), H_(H), mod_(modgrad), ang_(angles), cs_(cs), used_(used), order_(order)
     {
+        used_.assign((size_t)W * H, 0);
         const double binCoef = (maxGrad > 0) ? double(1024 - 1) / maxGrad : 0;
+        order_.clear();
         order_.reserve((size_t)(W - 1) * (H - 1));
         for (int y = 0; y < H - 1; ++y)
             for (int x = 0; x < W - 1; ++x) order_.push_back({x, y, int(mod_[(size_t)y * W + x] * binCoef)});
+        /* std::sort, as OpenCV: the order of equal bins is whatever libstdc++'s introsort leaves */
         std::sort(order_.begin(), order_.end(), [](const OPt& a, const OPt& b) { return a.norm > b.norm; });
         logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     }
@@ -58,12 +69,25 @@ public:
         for (const OPt& s : order_) {
             if (used_[(size_t)s.y * W_ + s.x] || ang_[(size_t)s.y * W_ + s.x] == kNotDef) continue;
             double regAngle;
-            grow(s.x, s.y, reg, regAngle, prec);
-            if (reg.size() < minReg) continue;
+            if (!timed_) {
+                grow(s.x, s.y, reg, regAngle, prec);
+                if (reg.size() < minReg) continue;
+            } else {   /* DRFE_TRACE_LINES: the same steps with wall-clock accounting */
+                const auto t0 = std::chrono::steady_clock::now();
+                grow(s.x, s.y, reg, regAngle, prec);
+                tGrow_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                nGrow_++;
+                if (reg.size() < minReg) continue;
+            }
             RectD rec;
+            const auto t1 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             toRect(reg, regAngle, prec, p, rec);
-            if (!refine(reg, regAngle, prec, p, rec, densityTh)) continue;
+            const bool okr = refine(reg, regAngle, prec, p, rec, densityTh);
+            const auto t2 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+            if (timed_) { tRefine_ += std::chrono::duration<double, std::milli>(t2 - t1).count(); nRect_++; }
+            if (!okr) continue;
             const double logNfa = improve(rec);
+            if (timed_) tImprove_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
             if (logNfa <= logEps) continue;
             rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
             rec.x1 /= scale; rec.y1 /= scale; rec.x2 /= scale; rec.y2 /= scale;
@@ -72,11 +96,13 @@ public:
         }
     }
 
+    double tGrow_ = 0, tRefine_ = 0, tImprove_ = 0; long nGrow_ = 0, nRect_ = 0; bool timed_ = false;
 private:
     int W_, H_;
     const double *mod_, *ang_;
-    std::vector<uint8_t> used_;
-    std::vector<OPt> order_;
+    const float* cs_;                /* device-computed (cos, sin) of float(angle) per pixel */
+    std::vector<uint8_t>& used_;
+    std::vector<OPt>& order_;
     double logNT_;
 
     static double sq(double v) { return v * v; }
@@ -114,8 +140,8 @@ private:
                         const double a = ang_[(size_t)yy * W_ + xx];
                         u = 1;
                         reg.push_back({xx, yy, a, mod_[(size_t)yy * W_ + xx]});
-                        sumdx += std::cos(float(a));
-                        sumdy += std::sin(float(a));
+                        sumdx += cs_[2 * ((size_t)yy * W_ + xx)];        /* cos(float(angle)), shared routine (device) */
+                        sumdy += cs_[2 * ((size_t)yy * W_ + xx) + 1];    /* sin(float(angle)) */
                         regAngle = drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
                     }
                 }
@@ -417,20 +443,53 @@ static LineTaps gaussTaps(int n, double sigma)
 
 } // namespace
 
-void drfe_lines_free(drfe_ctx* c)
+/* One line-extraction lane: device scratch + stream + its own error string.  The context owns one (the
+ * single-frame entry) and, for drfe_lsd_extract_batch, a pool of them, one per host thread. */
+struct LineHost {                     /* per-lane host buffers reused across frames */
+    std::vector<double> modgrad, angles;
+    std::vector<float> cs;
+    std::vector<int16_t> gx, gy;
+    std::vector<uint8_t> used;
+    std::vector<OPt> order;
+};
+struct LineWorker {
+    std::string err;
+    LinesScratch* ls = nullptr;
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    LineHost* host = nullptr;
+};
+
+static void scratch_free(LinesScratch*& s)
 {
-    LinesScratch* s = c->ls;
     if (!s) return;
-    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_maxGrad, s->d_gx, s->d_gy};
+    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_maxGrad, s->d_gx, s->d_gy};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete s;
-    c->ls = nullptr;
+    s = nullptr;
 }
 
-static int ensure_lines(drfe_ctx* c, int w, int h)
+void drfe_lines_free(drfe_ctx* c)
+{
+    scratch_free(c->ls);
+    delete static_cast<LineHost*>(c->lineHost);
+    c->lineHost = nullptr;
+    auto* pool = static_cast<std::vector<LineWorker>*>(c->lineWorkers);
+    if (pool) {
+        for (LineWorker& w : *pool) {
+            scratch_free(w.ls);
+            delete w.host;
+            if (w.ownsStream && w.stream) (void)hipStreamDestroy(w.stream);
+        }
+        delete pool;
+        c->lineWorkers = nullptr;
+    }
+}
+
+static int ensure_lines(LineWorker* c, int w, int h)
 {
     if (c->ls && c->ls->w == w && c->ls->h == h) return DRFE_OK;
-    drfe_lines_free(c);
+    scratch_free(c->ls);
     LinesScratch* s = new (std::nothrow) LinesScratch();
     if (!s) return DRFE_ERR_INVALID;
     std::memset(s, 0, sizeof(*s));
@@ -444,23 +503,19 @@ static int ensure_lines(drfe_ctx* c, int w, int h)
     HIPCHK(c, hipMalloc((void**)&s->d_tmp16, n * 2));
     HIPCHK(c, hipMalloc((void**)&s->d_modgrad, ns * 8));
     HIPCHK(c, hipMalloc((void**)&s->d_angles, ns * 8));
+    HIPCHK(c, hipMalloc((void**)&s->d_cs, ns * 8));
     HIPCHK(c, hipMalloc((void**)&s->d_maxGrad, 8));
     HIPCHK(c, hipMalloc((void**)&s->d_gx, n * 2));
     HIPCHK(c, hipMalloc((void**)&s->d_gy, n * 2));
     return DRFE_OK;
 }
 
-extern "C" {
-
-int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stride, int max_lines, drfe_keyline* lines,
-                     uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected)
+/* LineSegment::ExtractLineSegment for one frame on one lane */
+static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int w, int h, size_t stride, int max_lines,
+                            drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected)
 {
-    if (!c || !gray || !n_lines || w < 16 || h < 16 || stride < (size_t)w || max_lines < 1) {
-        if (c) c->err = "lsd_extract: invalid argument";
-        return DRFE_ERR_INVALID;
-    }
     *n_lines = 0;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipSetDevice(device));
     int rc = ensure_lines(c, w, h);
     if (rc != DRFE_OK) return rc;
     LinesScratch* s = c->ls;
@@ -470,14 +525,20 @@ int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
     const LineTaps lsdTaps = gaussTaps(1 + 2 * hk, sigma), lbdTaps = gaussTaps(5, 1.0);
     const double rho = 2.0 / std::sin(M_PI * 22.5 / 180);
     hipStream_t st = c->stream;
+    const bool trace = std::getenv("DRFE_TRACE_LINES") != nullptr;
+    const auto tStart = std::chrono::steady_clock::now();
     HIPCHK(c, hipMemcpy2DAsync(s->d_img, (size_t)w, gray, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
     HIPCHK(c, drfe_launch_lines_passes(s->d_img, w, h, lsdTaps, lbdTaps, s, rho, st));
     const size_t ns = (size_t)s->sw * s->sh, n = (size_t)w * h;
-    std::vector<double> modgrad(ns), angles(ns);
-    std::vector<int16_t> gx(n), gy(n);
+    if (!c->host) c->host = new LineHost();
+    LineHost& H = *c->host;
+    std::vector<double>&modgrad = H.modgrad, &angles = H.angles;
+    std::vector<int16_t>&gx = H.gx, &gy = H.gy;
+    modgrad.resize(ns); angles.resize(ns); gx.resize(n); gy.resize(n); H.cs.resize(2 * ns);
     unsigned long long maxBits = 0;
     HIPCHK(c, hipMemcpyAsync(modgrad.data(), s->d_modgrad, ns * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(angles.data(), s->d_angles, ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(H.cs.data(), s->d_cs, ns * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(gx.data(), s->d_gx, n * 2, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(gy.data(), s->d_gy, n * 2, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(&maxBits, s->d_maxGrad, 8, hipMemcpyDeviceToHost, st));
@@ -485,9 +546,15 @@ int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
     double maxGrad = -1;
     if (maxBits) std::memcpy(&maxGrad, &maxBits, 8);
 
+    const auto tDev = std::chrono::steady_clock::now();
     std::vector<float> segs;
-    SegmentFinder finder(s->sw, s->sh, modgrad.data(), angles.data(), maxGrad);
+    SegmentFinder finder(s->sw, s->sh, modgrad.data(), angles.data(), H.cs.data(), maxGrad, H.used, H.order);
+    const auto tSort = std::chrono::steady_clock::now();
+    finder.timed_ = trace;
     finder.run(segs);
+    const auto tSeg = std::chrono::steady_clock::now();
+    if (trace) std::fprintf(stderr, "drfe_lsd_extract: pixel ordering (bins + std::sort) %.2f ms; grow %.2f ms (%ld regions); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
+                            std::chrono::duration<double, std::milli>(tSort - tDev).count(), finder.tGrow_, finder.nGrow_, finder.tRefine_, finder.nRect_, finder.tImprove_);
 
     /* LSDDetector::detect: KeyLine fields for octave 0 (octaveScale = 1) */
     std::vector<drfe_keyline> kls;
@@ -526,6 +593,15 @@ int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
     const int nl = (int)kls.size();
     *n_lines = nl;
     if (nl > cap) { c->err = "lsd_extract: line buffer too small"; return DRFE_ERR_CAPACITY; }
+    struct TraceAtExit {   /* DRFE_TRACE_LINES=1: where a call spends its time (device passes + copies | LSD host | LBD host) */
+        bool on; std::chrono::steady_clock::time_point a, b, cc;
+        ~TraceAtExit() {
+            if (!on) return;
+            const auto e = std::chrono::steady_clock::now();
+            auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+            std::fprintf(stderr, "drfe_lsd_extract: device+copies %.2f ms, LSD host %.2f ms, keylines+LBD host %.2f ms\n", ms(a, b), ms(b, cc), ms(cc, e));
+        }
+    } traceAtExit{trace, tStart, tDev, tSeg};
     float des[72];
     for (int i = 0; i < nl; i++) {
         if (lines) lines[i] = kls[i];
@@ -539,6 +615,75 @@ int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
             line_f[3 * i] = l0 / nrm; line_f[3 * i + 1] = l1 / nrm; line_f[3 * i + 2] = l2 / nrm;
         }
     }
+    return DRFE_OK;
+}
+
+extern "C" {
+
+int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stride, int max_lines, drfe_keyline* lines,
+                     uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected)
+{
+    if (!c || !gray || !n_lines || w < 16 || h < 16 || stride < (size_t)w || max_lines < 1) {
+        if (c) c->err = "lsd_extract: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    LineWorker lw;
+    lw.ls = c->ls;
+    lw.stream = c->stream;
+    lw.host = static_cast<LineHost*>(c->lineHost);
+    const int rc = lsd_extract_core(&lw, c->device, gray, w, h, stride, max_lines, lines, ldesc, line_f, cap, n_lines, n_detected);
+    c->ls = lw.ls;
+    c->lineHost = lw.host;
+    if (rc != DRFE_OK) c->err = lw.err;
+    return rc;
+}
+
+/* LineSegment::ExtractLineSegment for nframes host images at once.  The device passes are microseconds; the
+ * sequential host stages (region growing, rectangle refinement, NFA: ~25 ms per 640x480 frame) are what a frame
+ * costs, and they are independent between frames — so the batch runs on a pool of host threads, one lane (device
+ * scratch + stream) per thread, the way the reference spreads its four extractors over four threads
+ * (src/Frame.cc:116-126).  Outputs are per frame: lines[f * cap ..], ldesc[f * cap * 32 ..], line_f[f * cap * 3 ..],
+ * n_lines[f], n_detected[f].  n_threads <= 0: one thread per frame up to the hardware concurrency. */
+int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                           int max_lines, drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines,
+                           int* n_detected, int n_threads)
+{
+    if (!c || !gray || !n_lines || nframes < 0 || w < 16 || h < 16 || stride < (size_t)w || max_lines < 1 || cap < 1 ||
+        frame_stride < stride * (size_t)h) {
+        if (c) c->err = "lsd_extract_batch: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    if (nframes == 0) return DRFE_OK;
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    T = std::max(1, std::min(T, nframes));
+    HIPCHK(c, hipSetDevice(c->device));
+    auto* pool = static_cast<std::vector<LineWorker>*>(c->lineWorkers);
+    if (!pool) { pool = new std::vector<LineWorker>(); c->lineWorkers = pool; }
+    while ((int)pool->size() < T) {
+        LineWorker lw;
+        HIPCHK(c, hipStreamCreateWithFlags(&lw.stream, hipStreamNonBlocking));
+        lw.ownsStream = true;
+        pool->push_back(lw);
+    }
+    std::vector<int> rcs(T, DRFE_OK);
+    std::vector<std::thread> th;
+    th.reserve(T);
+    std::atomic<int> next(0);
+    for (int k = 0; k < T; k++)
+        th.emplace_back([&, k]() {
+            LineWorker* lw = &(*pool)[k];
+            for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {
+                int nd = 0;
+                const int rc = lsd_extract_core(lw, c->device, gray + (size_t)f * frame_stride, w, h, stride, max_lines,
+                                                lines ? lines + (size_t)f * cap : nullptr, ldesc ? ldesc + (size_t)f * cap * 32 : nullptr,
+                                                line_f ? line_f + (size_t)f * cap * 3 : nullptr, cap, &n_lines[f], &nd);
+                if (n_detected) n_detected[f] = nd;
+                if (rc != DRFE_OK) { rcs[k] = rc; return; }
+            }
+        });
+    for (std::thread& t : th) t.join();
+    for (int k = 0; k < T; k++)
+        if (rcs[k] != DRFE_OK) { c->err = (*pool)[k].err; return rcs[k]; }
     return DRFE_OK;
 }
 

@@ -34,7 +34,7 @@ SYMBOLS = (
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
-    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_by_projection_last",
+    "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map",
 )
 
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_lsd_extract_batch.argtypes = [vp, vp, C.c_size_t, i32, i32, C.c_size_t, i32, i32, vp, vp, vp, i32, vp, vp, i32]
     L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
     L.drfe_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, i32, C.c_float, vp]
@@ -439,6 +440,22 @@ class Context:
                                              C.byref(sh)), "lsd_stages")
             out.update(scaled=scaled, modgrad=modgrad, angles=angles, gx=gx, gy=gy)
         return out
+
+    def lsd_extract_batch(self, gray_batch: np.ndarray, max_lines=40, n_threads=0):
+        """LineSegment::ExtractLineSegment for a [B, H, W] uint8 host array on a pool of host threads (one device lane
+        each); returns a list of dicts like lsd_extract."""
+        g = np.ascontiguousarray(gray_batch, np.uint8)
+        B, h, w = g.shape
+        cap = max_lines
+        lines = np.zeros((B, cap), KEYLINE_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        lf = np.zeros((B, cap, 3))
+        n = np.zeros(B, np.int32)
+        nd = np.zeros(B, np.int32)
+        self._chk(self.L.drfe_lsd_extract_batch(self.h, _p(g), w * h, w, h, w, B, max_lines, _p(lines), _p(desc), _p(lf), cap,
+                                                _p(n), _p(nd), int(n_threads)), "drfe_lsd_extract_batch")
+        return [dict(lines=lines[f, :n[f]].copy(), desc=desc[f, :n[f]].copy(), lineF=lf[f, :n[f]].copy(), detected=int(nd[f]))
+                for f in range(B)]
 
     # --- bag of words ------------------------------------------------------------------------------
     def voc_upload(self, k, L, scoring, weighting, parent, desc, weight, is_leaf):

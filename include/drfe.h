@@ -220,6 +220,14 @@ typedef struct drfe_keyline {
  * bytes, line_f = NL x 3 normalised line equations; *n_detected = lines found before the cut. */
 int drfe_lsd_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t stride, int max_lines,
                      drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected);
+/* The same for nframes host images (gray + f * frame_stride): the sequential host stages of LSD (~25 ms per 640x480
+ * frame) are independent between frames and run on a pool of n_threads host threads, one device lane (scratch +
+ * stream) each — frames instead of the reference's four extractors across threads (src/Frame.cc:116-126).  Outputs per
+ * frame f at lines[f * cap], ldesc[f * cap * 32], line_f[f * cap * 3], n_lines[f], n_detected[f]; results are identical
+ * to nframes calls of drfe_lsd_extract.  n_threads <= 0: hardware concurrency. */
+int drfe_lsd_extract_batch(drfe_ctx* ctx, const uint8_t* gray, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                           int max_lines, drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines,
+                           int* n_detected, int n_threads);
 /* Parity taps of the device image passes of the last drfe_lsd_extract call (any pointer may be NULL):
  * 0.8-scaled image, gradient magnitude and level-line angle (sw x sh), Sobel dx/dy of the LBD image. */
 int drfe_lsd_stages(drfe_ctx* ctx, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy,

@@ -231,8 +231,12 @@ struct Lsd {
                         const double angle = angles[(size_t)yy * W + xx];
                         is_used = 1;
                         reg.push_back({xx, yy, angle, modgrad[(size_t)yy * W + xx]});
-                        sumdx += std::cos(float(angle));
-                        sumdy += std::sin(float(angle));
+                        /* cos(float)/sin(float) of lsd.cpp resolve to cosf/sinf, whose last bit is libm dependent:
+                         * canonicalised on the shared float routine, as for the ORB steering (oracle.h, §9.4) */
+                        float sn, cn;
+                        drfe_sincos(float(angle), &sn, &cn);
+                        sumdx += cn;
+                        sumdy += sn;
                         reg_angle = drfe_fast_atan2(sumdy, sumdx) * DEG_TO_RADS;
                     }
                 }

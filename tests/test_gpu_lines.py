@@ -119,3 +119,18 @@ def test_lsd_search_by_projection_empty(ctx):
     n, ml = ctx.lsd_search_by_projection_last(T, T, cam, np.zeros(0, lib.MAPLINE_DTYPE), np.zeros(0, lib.KEYLINE_DTYPE),
                                               np.zeros((0, 32), np.uint8), 15.0, False, 0.9, np.zeros(0, np.int32))
     assert n == 0 and len(ml) == 0
+
+
+def test_lsd_extract_batch_equals_single(ctx):
+    """drfe_lsd_extract_batch (host thread pool, one device lane per thread) == per-frame calls, any thread count."""
+    from dr_slam_amd import synth
+    frames = [f[0] for f in synth.sequence(2, 6, kind="room_boxes")] + [_frame(5, "corridor")]
+    single = [ctx.lsd_extract(g) for g in frames]
+    for threads in (1, 3, 16):
+        batch = ctx.lsd_extract_batch(np.stack(frames), n_threads=threads)
+        assert len(batch) == len(frames)
+        for a, b in zip(batch, single):
+            assert a["detected"] == b["detected"] and len(a["lines"]) == len(b["lines"]) > 5
+            assert np.array_equal(a["lines"].view(np.uint8), b["lines"].view(np.uint8))
+            assert np.array_equal(a["desc"], b["desc"])
+            assert np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
