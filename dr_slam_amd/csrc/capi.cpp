@@ -120,6 +120,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->glueValid = false;
     c->mb = nullptr;
     c->ps = nullptr;
+    c->planeLanes = nullptr;
     c->bow = nullptr;
     c->ls = nullptr;
     c->lineWorkers = nullptr;

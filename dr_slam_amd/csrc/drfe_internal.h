@@ -128,6 +128,7 @@ struct drfe_ctx {
 
     struct MatchBuffers* mb;  /* lazily allocated matcher scratch (match_internal.h) */
     struct PlanesScratch* ps; /* lazily allocated plane-path scratch (planes_internal.h) */
+    void* planeLanes;         /* std::vector<PlaneLane>*: lanes of drfe_planes_ahc_batch (planes_ahc.cpp) */
     struct BowState* bow;     /* vocabulary + BoW scratch (bow_internal.h), set by drfe_voc_upload */
     struct LinesScratch* ls;  /* line-path scratch (lines_internal.h) */
     void* lineHost;           /* LineHost*: host buffers of the single-frame line entry */

@@ -24,6 +24,9 @@
 #include <map>
 #include <new>
 #include <queue>
+#include <atomic>
+#include <thread>
+#include <string>
 
 #define HIPCHK(c, call)                                                                         \
     do {                                                                                        \
@@ -190,17 +193,39 @@ struct DepthView {
 
 } // namespace
 
-void drfe_planes_free(drfe_ctx* c)
+/* One plane-extraction lane of drfe_planes_ahc_batch: device scratch + stream + its own error string (the
+ * templates below only touch these members, which drfe_ctx has under the same names). */
+struct PlaneLane {
+    std::string err;
+    int device = 0;
+    PlanesScratch* ps = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+static void scratch_free(PlanesScratch*& p)
 {
-    PlanesScratch* p = c->ps;
     if (!p) return;
     if (p->d_blocks) (void)hipFree(p->d_blocks);
     if (p->d_depth) (void)hipFree(p->d_depth);
     delete p;
-    c->ps = nullptr;
+    p = nullptr;
 }
 
-static int ensure_scratch(drfe_ctx* c, int w, int h)
+void drfe_planes_free(drfe_ctx* c)
+{
+    scratch_free(c->ps);
+    auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);
+    if (pool) {
+        for (PlaneLane& l : *pool) {
+            scratch_free(l.ps);
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+        }
+        delete pool;
+        c->planeLanes = nullptr;
+    }
+}
+
+template <class Ctx> static int ensure_scratch(Ctx* c, int w, int h)
 {
     if (!c->ps) {
         c->ps = new (std::nothrow) PlanesScratch();
@@ -224,7 +249,7 @@ static int ensure_scratch(drfe_ctx* c, int w, int h)
     return DRFE_OK;
 }
 
-static int run_blocks(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float K4[4],
+template <class Ctx> static int run_blocks(Ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float K4[4],
                       float depth_factor, std::vector<AhcBlockRec>& blocks)
 {
     if (!c || !depth || !K4 || w < AHC_WIN || h < AHC_WIN || stride < (size_t)w) {
@@ -245,28 +270,11 @@ static int run_blocks(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t s
     return DRFE_OK;
 }
 
-extern "C" {
-
-int drfe_planes_ahc_blocks(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
-                           float depth_factor, double* blocks17, int32_t* valid_n, int cap)
-{
-    std::vector<AhcBlockRec> blocks;
-    int rc = run_blocks(c, depth, w, h, stride, K4, depth_factor, blocks);
-    if (rc != DRFE_OK) return rc;
-    if ((int)blocks.size() > cap) return DRFE_ERR_CAPACITY;
-    for (size_t i = 0; i < blocks.size(); i++) {
-        const AhcBlockRec& b = blocks[i];
-        for (int k = 0; k < 9; k++) blocks17[17 * i + k] = b.sums[k];
-        for (int k = 0; k < 3; k++) { blocks17[17 * i + 9 + k] = b.center[k]; blocks17[17 * i + 12 + k] = b.normal[k]; }
-        blocks17[17 * i + 15] = b.mse; blocks17[17 * i + 16] = b.curvature;
-        valid_n[2 * i] = b.valid; valid_n[2 * i + 1] = b.N;
-    }
-    return DRFE_OK;
-}
-
-int drfe_planes_ahc(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
-                    drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, int32_t* member_offsets,
-                    int32_t* member_idx)
+/* PlaneDetection::readDepthImage + runPlaneDetection for one frame on one lane (Ctx: drfe_ctx or PlaneLane) */
+template <class Ctx>
+static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
+                           drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, int32_t* member_offsets,
+                           int32_t* member_idx)
 {
     if (!n_planes) return DRFE_ERR_INVALID;
     *n_planes = 0;
@@ -459,6 +467,79 @@ int drfe_planes_ahc(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t str
                 if (membership[i] >= 0) member_idx[fill[membership[i]]++] = (int32_t)i;
         }
     }
+    return DRFE_OK;
+}
+
+extern "C" {
+
+int drfe_planes_ahc_blocks(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
+                           float depth_factor, double* blocks17, int32_t* valid_n, int cap)
+{
+    std::vector<AhcBlockRec> blocks;
+    int rc = run_blocks(c, depth, w, h, stride, K4, depth_factor, blocks);
+    if (rc != DRFE_OK) return rc;
+    if ((int)blocks.size() > cap) return DRFE_ERR_CAPACITY;
+    for (size_t i = 0; i < blocks.size(); i++) {
+        const AhcBlockRec& b = blocks[i];
+        for (int k = 0; k < 9; k++) blocks17[17 * i + k] = b.sums[k];
+        for (int k = 0; k < 3; k++) { blocks17[17 * i + 9 + k] = b.center[k]; blocks17[17 * i + 12 + k] = b.normal[k]; }
+        blocks17[17 * i + 15] = b.mse; blocks17[17 * i + 16] = b.curvature;
+        valid_n[2 * i] = b.valid; valid_n[2 * i + 1] = b.N;
+    }
+    return DRFE_OK;
+}
+
+int drfe_planes_ahc(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
+                    drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, int32_t* member_offsets,
+                    int32_t* member_idx)
+{
+    return planes_ahc_core(c, depth, w, h, stride, K4, depth_factor, planes, cap, n_planes, seg, member_offsets, member_idx);
+}
+
+/* The same for nframes host depth images (depth + f * frame_stride elements).  The block fits are microseconds on
+ * the device; the clustering / erosion / flood fill of a frame (~7 ms) is sequential host code, independent between
+ * frames, so the batch runs on n_threads host threads with one device lane each.  Outputs per frame f:
+ * planes[f * cap], n_planes[f], seg + f * w * h, member_offsets[f * (cap + 1)], member_idx + f * w * h (any of the
+ * last three may be NULL).  Results equal nframes calls of drfe_planes_ahc. */
+int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                          const float* K4, float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
+                          int32_t* member_offsets, int32_t* member_idx, int n_threads)
+{
+    if (!c || !depth || !K4 || !planes || !n_planes || nframes < 0 || cap < 1 || frame_stride < stride * (size_t)h) {
+        if (c) c->err = "planes_ahc_batch: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    if (nframes == 0) return DRFE_OK;
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    T = std::max(1, std::min(T, nframes));
+    HIPCHK(c, hipSetDevice(c->device));
+    auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);
+    if (!pool) { pool = new std::vector<PlaneLane>(); c->planeLanes = pool; }
+    while ((int)pool->size() < T) {
+        PlaneLane l;
+        l.device = c->device;
+        HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        pool->push_back(l);
+    }
+    std::vector<int> rcs(T, DRFE_OK);
+    std::vector<std::thread> th;
+    th.reserve(T);
+    std::atomic<int> next(0);
+    const size_t px = (size_t)w * h;
+    for (int k = 0; k < T; k++)
+        th.emplace_back([&, k]() {
+            PlaneLane* l = &(*pool)[k];
+            for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {
+                const int rc = planes_ahc_core(l, depth + (size_t)f * frame_stride, w, h, stride, K4, depth_factor,
+                                               planes + (size_t)f * cap, cap, &n_planes[f], seg ? seg + f * px : nullptr,
+                                               member_offsets ? member_offsets + (size_t)f * (cap + 1) : nullptr,
+                                               member_idx ? member_idx + f * px : nullptr);
+                if (rc != DRFE_OK) { rcs[k] = rc; return; }
+            }
+        });
+    for (std::thread& t : th) t.join();
+    for (int k = 0; k < T; k++)
+        if (rcs[k] != DRFE_OK) { c->err = (*pool)[k].err; return rcs[k]; }
     return DRFE_OK;
 }
 

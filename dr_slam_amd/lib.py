@@ -32,7 +32,7 @@ SYMBOLS = (
     "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
-    "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_blocks",
+    "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_batch", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
     "drfe_search_by_bow", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map",
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_planes_ahc_batch.argtypes = [vp, vp, C.c_size_t, i32, i32, C.c_size_t, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32]
     L.drfe_lsd_extract_batch.argtypes = [vp, vp, C.c_size_t, i32, i32, C.c_size_t, i32, i32, vp, vp, vp, i32, vp, vp, i32]
     L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
@@ -499,6 +500,26 @@ class Context:
                                          C.byref(n), _p(seg), _p(off), _p(idx)), "drfe_planes_ahc")
         n = n.value
         return dict(planes=planes[:n].copy(), seg=seg, members=[idx[off[i]:off[i + 1]].copy() for i in range(n)])
+
+    def planes_ahc_batch(self, depth16_batch: np.ndarray, K4, depth_factor, cap=64, n_threads=0, members=True):
+        """drfe_planes_ahc for a [B, H, W] uint16 host array on a pool of host threads; list of dicts like planes_ahc."""
+        d = np.ascontiguousarray(depth16_batch, np.uint16)
+        B, h, w = d.shape
+        K4 = np.ascontiguousarray(K4, np.float32)
+        planes = np.zeros((B, cap), PLANE_DTYPE)
+        n = np.zeros(B, np.int32)
+        seg = np.zeros((B, h, w), np.uint8)
+        off = np.zeros((B, cap + 1), np.int32) if members else None
+        idx = np.zeros((B, h * w), np.int32) if members else None
+        self._chk(self.L.drfe_planes_ahc_batch(self.h, _p(d), w * h, w, h, w, B, _p(K4), np.float32(depth_factor), _p(planes),
+                                               cap, _p(n), _p(seg), _p(off), _p(idx), int(n_threads)), "drfe_planes_ahc_batch")
+        out = []
+        for f in range(B):
+            r = dict(planes=planes[f, :n[f]].copy(), seg=seg[f])
+            if members:
+                r["members"] = [idx[f, off[f, i]:off[f, i + 1]].copy() for i in range(n[f])]
+            out.append(r)
+        return out
 
     def planes_cape(self, depth_m: np.ndarray, K4, patch=20, cos_angle_max=None, max_merge_dist=50.0, cap=64):
         """PlaneDetection_CAPE::readDepthImage + runPlaneDetection -> dict(planes, seg, cell taps)."""

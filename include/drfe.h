@@ -338,6 +338,14 @@ typedef struct drfe_plane {
 int drfe_planes_ahc(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
                     float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
                     int32_t* member_offsets, int32_t* member_idx);
+/* drfe_planes_ahc for nframes host depth images (depth + f * frame_stride elements): the block fits take
+ * microseconds on the device, the per-frame clustering / erosion / flood fill (~7 ms) is sequential host code that is
+ * independent between frames and runs on n_threads host threads, one device lane each.  Outputs per frame f at
+ * planes[f * cap], n_planes[f], seg + f * w * h, member_offsets[f * (cap + 1)], member_idx + f * w * h (the last three
+ * may be NULL); identical to nframes single calls.  n_threads <= 0: hardware concurrency. */
+int drfe_planes_ahc_batch(drfe_ctx* ctx, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                          const float* K4, float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
+                          int32_t* member_offsets, int32_t* member_idx, int n_threads);
 /* Parity tap of the device stage: per 10x10 init block 17 doubles (9 sums, center, normal, mse,
  * curvature) and (enters-graph flag, N). cap = number of blocks the buffers hold. */
 int drfe_planes_ahc_blocks(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,

@@ -88,3 +88,21 @@ def test_no_depth_gives_no_planes(ctx, oracle_mod):
     assert len(g["planes"]) == 0 and not g["seg"].any()
     far = np.full((480, 640), 40000, np.uint16)        # 8 m: beyond the 5 m clamp (src/PlaneExtractor.cpp:44)
     assert len(ctx.planes_ahc(far, K4, 0.0002)["planes"]) == 0
+
+
+def test_ahc_batch_equals_single(ctx):
+    """drfe_planes_ahc_batch (host thread pool, one device lane per thread) == per-frame calls, any thread count."""
+    from dr_slam_amd import synth
+    cam = synth.TUM3
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    depth = np.stack([f[1] for f in synth.sequence(2, 5, kind="room_boxes")] + [next(synth.sequence(5, 1, kind="corridor"))[1]])
+    single = [ctx.planes_ahc(d, K4, inv) for d in depth]
+    for threads in (1, 4, 16):
+        batch = ctx.planes_ahc_batch(depth, K4, inv, n_threads=threads)
+        for a, b in zip(batch, single):
+            assert len(a["planes"]) == len(b["planes"]) >= 2
+            assert np.array_equal(a["planes"].view(np.uint8), b["planes"].view(np.uint8))
+            assert np.array_equal(a["seg"], b["seg"])
+            for ma, mb in zip(a["members"], b["members"]):
+                assert np.array_equal(ma, mb)
