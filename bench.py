@@ -206,7 +206,7 @@ def main():
                          "kernel_ms": stage_ms[roof_stage],
                          "algorithmic_bytes_per_launch": algo},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported by the N=1 run only
             out["cpu_baseline"] = cpu_baseline(base)
     if world > 1:
         dist.barrier()
