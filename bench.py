@@ -99,9 +99,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Rehearsal hooks for a 1-GPU box (the driver never sets them): DRFE_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and DRFE_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
+    if os.environ.get("DRFE_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("DRFE_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
