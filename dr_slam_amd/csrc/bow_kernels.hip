@@ -157,6 +157,104 @@ hipError_t drfe_launch_bow_transform(drfe_ctx* c, const VocDev& voc, int levelsu
     return hipGetLastError();
 }
 
+/* ORBmatcher::SearchForTriangulation inner loops (src/ORBmatcher.cc:695-793): one wavefront per common vocabulary
+ * node.  For a keypoint of KF1 the reference keeps, among the KF2 keypoints of the node that pass the static tests
+ * (no map point, stereo rule, distance <= TH_LOW, not closer than 10 px (scaled) to the epipole when both are
+ * monocular, CheckDistEpipolarLine), the LAST one with the smallest distance (`dist > bestDist -> continue` lets
+ * equal distances replace): wave minimum of dist << 16 | (0xFFFF - position).  This reference never marks KF2
+ * keypoints as taken, so KF1 keypoints are independent. */
+__global__ __launch_bounds__(WAVE) void k_bow_triangulation_groups(const BowGroup* __restrict__ groups,
+                                                                   const int* __restrict__ idx1s, const int* __restrict__ idx2s,
+                                                                   const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
+                                                                   const drfe_keypoint* __restrict__ kp1, const drfe_keypoint* __restrict__ kp2,
+                                                                   const float* __restrict__ ur1, const float* __restrict__ ur2,
+                                                                   const int* __restrict__ mp1, const int* __restrict__ mp2, TriParams P,
+                                                                   int* __restrict__ match12, int* __restrict__ counters,
+                                                                   int* __restrict__ hist, uint16_t* __restrict__ entries)
+{
+    const BowGroup g = groups[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n2 = g.fEnd - g.fBegin;
+    for (int a = g.kfBegin; a < g.kfEnd; a++) {
+        const int i1 = idx1s[a];
+        if (mp1[i1] >= 0) continue;
+        const bool bStereo1 = ur1[i1] >= 0;
+        if (P.onlyStereo && !bStereo1) continue;
+        const drfe_keypoint k1 = kp1[i1];
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(desc1 + (size_t)i1 * 32);
+        const uint64_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        /* epipolar line l = x1' F12 (CheckDistEpipolarLine, :143-146) */
+        const float la = k1.x * P.F[0] + k1.y * P.F[3] + P.F[6];
+        const float lb = k1.x * P.F[1] + k1.y * P.F[4] + P.F[7];
+        const float lc = k1.x * P.F[2] + k1.y * P.F[5] + P.F[8];
+        const float den = la * la + lb * lb;
+        uint32_t best = 0xFFFFFFFFu;
+        for (int b0 = 0; b0 < n2; b0 += WAVE) {
+            const int b = b0 + lane;
+            uint32_t key = 0xFFFFFFFFu;
+            if (b < n2) {
+                const int i2 = idx2s[g.fBegin + b];
+                bool ok = mp2[i2] < 0;
+                const bool bStereo2 = ur2[i2] >= 0;
+                if (P.onlyStereo && !bStereo2) ok = false;
+                if (ok) {
+                    const uint64_t* d = reinterpret_cast<const uint64_t*>(desc2 + (size_t)i2 * 32);
+                    const int dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
+                    if (dist > 50) ok = false;                                     /* TH_LOW */
+                    const drfe_keypoint k2 = kp2[i2];
+                    if (ok && !bStereo1 && !bStereo2) {
+                        const float distex = P.ex - k2.x, distey = P.ey - k2.y;
+                        if (distex * distex + distey * distey < 100 * P.scale[k2.octave]) ok = false;
+                    }
+                    if (ok) {
+                        const float num = la * k2.x + lb * k2.y + lc;
+                        if (den == 0) ok = false;
+                        else {
+                            const float dsqr = num * num / den;
+                            if (!((double)dsqr < 3.84 * (double)P.sigma2[k2.octave])) ok = false;
+                        }
+                    }
+                    if (ok) key = ((uint32_t)dist << 16) | (uint32_t)(0xFFFF - b);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o));
+            best = min(best, key);
+        }
+        if (best == 0xFFFFFFFFu) continue;
+        if (lane == 0) {
+            const int i2 = idx2s[g.fBegin + (0xFFFF - (int)(best & 0xFFFF))];
+            match12[i1] = i2;
+            atomicAdd(&counters[0], 1);
+            if (P.checkOri) {
+                float rot = k1.angle - kp2[i2].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / 30));
+                if (bin == 30) bin = 0;
+                const int e = atomicAdd(&counters[1], 1);
+                entries[2 * e] = (uint16_t)bin;
+                entries[2 * e + 1] = (uint16_t)i1;
+                atomicAdd(&hist[bin], 1);
+            }
+        }
+    }
+}
+
+hipError_t drfe_launch_bow_triangulation(drfe_ctx* c, int slot1, int slot2, const BowGroup* d_groups, int ngroups,
+                                         const int* d_idx1, const int* d_idx2, const int* d_mp1, const int* d_mp2,
+                                         const TriParams& P, int* d_match12, int* d_counters, int* d_hist,
+                                         uint16_t* d_entries, hipStream_t s)
+{
+    const size_t o1 = (size_t)slot1 * c->maxKp, o2 = (size_t)slot2 * c->maxKp;
+    if (ngroups > 0)
+        hipLaunchKernelGGL(k_bow_triangulation_groups, dim3(ngroups), dim3(WAVE), 0, s, d_groups, d_idx1, d_idx2,
+                           c->d_desc + o1 * 32, c->d_desc + o2 * 32, drfe_kps_un(c) + o1, drfe_kps_un(c) + o2, c->d_uRight + o1,
+                           c->d_uRight + o2, d_mp1, d_mp2, P, d_match12, d_counters, d_hist, d_entries);
+    if (P.checkOri)
+        hipLaunchKernelGGL(k_bow_rot_filter, dim3(1), dim3(256), 0, s, d_match12, d_counters, d_hist, d_entries);
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_bow_match(drfe_ctx* c, int kfSlot, int fSlot, const BowGroup* d_groups, int ngroups,
                                  const int* d_kfIdx, const int* d_fIdx, const int* d_kfMP, float nnratio, int checkOri,
                                  int* d_match, int* d_counters, int* d_hist, uint16_t* d_entries, hipStream_t s)

@@ -23,7 +23,7 @@ void drfe_bow_free(drfe_ctx* c)
     if (!b) return;
     for (void* p : b->d_vocBlob)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {b->d_word, b->d_weight, b->d_nid, b->d_groups, b->d_kfIdx, b->d_fIdx, b->d_kfMP, b->d_match,
+    void* ptrs[] = {b->d_word, b->d_weight, b->d_nid, b->d_groups, b->d_kfIdx, b->d_fIdx, b->d_kfMP, b->d_fMP, b->d_match,
                     b->d_counters, b->d_hist, b->d_entries};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -87,6 +87,7 @@ int drfe_voc_upload(drfe_ctx* c, int k, int L, int scoring, int weighting, int n
     HIPCHK(c, hipMalloc((void**)&b->d_kfIdx, M * 4));
     HIPCHK(c, hipMalloc((void**)&b->d_fIdx, M * 4));
     HIPCHK(c, hipMalloc((void**)&b->d_kfMP, M * 4));
+    HIPCHK(c, hipMalloc((void**)&b->d_fMP, M * 4));
     HIPCHK(c, hipMalloc((void**)&b->d_match, M * 4));
     HIPCHK(c, hipMalloc((void**)&b->d_counters, 8));
     HIPCHK(c, hipMalloc((void**)&b->d_hist, 30 * 4));
@@ -178,6 +179,83 @@ int drfe_search_by_bow(drfe_ctx* c, int kf_slot, int f_slot, const int32_t* kf_m
                                     nnratio, check_ori, b->d_match, b->d_counters, b->d_hist, b->d_entries, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipMemcpy(f_match, b->d_match, sizeof(int) * n_f, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nmatches, b->d_counters, sizeof(int), hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), src/ORBmatcher.cc:661-827 */
+int drfe_search_for_triangulation(drfe_ctx* c, int slot1, int slot2, const int32_t* mp1, int n1, const int32_t* mp2, int n2,
+                                  const float* F12, const float* Cw1, const float* T2w, const drfe_camera* cam2,
+                                  int only_stereo, int check_ori, int32_t* matches12, int* nmatches)
+{
+    if (!c || !mp1 || !mp2 || !F12 || !Cw1 || !T2w || !cam2 || !matches12 || !nmatches) return DRFE_ERR_INVALID;
+    BowState* b = c->bow;
+    if (!b || slot1 < 0 || slot2 < 0 || slot1 >= b->transformedFrames || slot2 >= b->transformedFrames || !c->glueValid) {
+        c->err = "search_for_triangulation: both slots need the glue and drfe_bow_transform_batch first";
+        return DRFE_ERR_STATE;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int counts[2];
+    HIPCHK(c, hipMemcpy(&counts[0], c->d_kpCount + slot1, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&counts[1], c->d_kpCount + slot2, sizeof(int), hipMemcpyDeviceToHost));
+    if (n1 != counts[0] || n2 != counts[1]) { c->err = "search_for_triangulation: N mismatch"; return DRFE_ERR_INVALID; }
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return DRFE_OK;
+    /* epipole of KF1's centre in KF2, :667-674: C2 = R2w*Cw + t2w through cv::Mat's float small-matrix product */
+    TriParams P;
+    std::memset(&P, 0, sizeof(P));
+    float C2[3];
+    for (int r = 0; r < 3; r++) {
+        const float d = T2w[r * 4 + 0] * Cw1[0] + T2w[r * 4 + 1] * Cw1[1] + T2w[r * 4 + 2] * Cw1[2];
+        C2[r] = d + T2w[r * 4 + 3];
+    }
+    const float invz = 1.0f / C2[2];
+    P.ex = cam2->fx * C2[0] * invz + cam2->cx;
+    P.ey = cam2->fy * C2[1] * invz + cam2->cy;
+    std::memcpy(P.F, F12, 36);
+    if (c->cfg.nlevels > 16) { c->err = "search_for_triangulation: more than 16 pyramid levels"; return DRFE_ERR_INVALID; }
+    for (int l = 0; l < c->cfg.nlevels; l++) { P.scale[l] = c->scale[l]; P.sigma2[l] = c->sigma2[l]; }
+    P.onlyStereo = only_stereo ? 1 : 0;
+    P.checkOri = check_ori ? 1 : 0;
+    std::vector<int> nid1(n1), nid2(n2);
+    std::vector<double> w1(n1), w2(n2);
+    const size_t o1 = (size_t)slot1 * c->maxKp, o2 = (size_t)slot2 * c->maxKp;
+    HIPCHK(c, hipMemcpy(nid1.data(), b->d_nid + o1, sizeof(int) * n1, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(w1.data(), b->d_weight + o1, sizeof(double) * n1, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nid2.data(), b->d_nid + o2, sizeof(int) * n2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(w2.data(), b->d_weight + o2, sizeof(double) * n2, hipMemcpyDeviceToHost));
+    std::map<int, std::vector<int>> fv1, fv2;
+    for (int i = 0; i < n1; i++) if (w1[i] > 0) fv1[nid1[i]].push_back(i);
+    for (int i = 0; i < n2; i++) if (w2[i] > 0) fv2[nid2[i]].push_back(i);
+    std::vector<BowGroup> groups;
+    std::vector<int> idx1, idx2;
+    for (auto& kv : fv1) {
+        auto it = fv2.find(kv.first);
+        if (it == fv2.end()) continue;
+        BowGroup g;
+        g.kfBegin = (int)idx1.size(); idx1.insert(idx1.end(), kv.second.begin(), kv.second.end()); g.kfEnd = (int)idx1.size();
+        g.fBegin = (int)idx2.size(); idx2.insert(idx2.end(), it->second.begin(), it->second.end()); g.fEnd = (int)idx2.size();
+        groups.push_back(g);
+    }
+    hipStream_t s = c->stream;
+    if (!groups.empty()) {
+        HIPCHK(c, hipMemcpy(b->d_groups, groups.data(), groups.size() * sizeof(BowGroup), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b->d_kfIdx, idx1.data(), idx1.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(b->d_fIdx, idx2.data(), idx2.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMemcpy(b->d_kfMP, mp1, sizeof(int) * n1, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(b->d_fMP, mp2, sizeof(int) * n2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemsetAsync(b->d_match, 0xFF, sizeof(int) * n1, s));
+    HIPCHK(c, hipMemsetAsync(b->d_counters, 0, 8, s));
+    HIPCHK(c, hipMemsetAsync(b->d_hist, 0, 30 * 4, s));
+    HIPCHK(c, drfe_launch_bow_triangulation(c, slot1, slot2, b->d_groups, (int)groups.size(), b->d_kfIdx, b->d_fIdx, b->d_kfMP,
+                                            b->d_fMP, P, b->d_match, b->d_counters, b->d_hist, b->d_entries, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpy(matches12, b->d_match, sizeof(int) * n1, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(nmatches, b->d_counters, sizeof(int), hipMemcpyDeviceToHost));
     return DRFE_OK;
 }

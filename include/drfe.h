@@ -316,6 +316,17 @@ int drfe_bow_download(drfe_ctx* ctx, int slot, int32_t* word, double* weight, in
 int drfe_search_by_bow(drfe_ctx* ctx, int kf_slot, int f_slot, const int32_t* kf_mp, int n_kf, float nnratio,
                        int check_ori, int32_t* f_match, int n_f, int* nmatches);
 
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), src/ORBmatcher.cc:661-827 (LocalMapping::
+ * CreateNewMapPoints): for every vocabulary node common to both keyframes, match the keypoints of KF1 without a map
+ * point against those of KF2 (distance <= TH_LOW, epipole exclusion, CheckDistEpipolarLine against F12, rotation
+ * histogram).  Both slots need the glue (mvKeysUn, mvuRight) and drfe_bow_transform_batch.  mp1 / mp2: >= 0 where the
+ * keyframe keypoint already has a map point.  F12: 3x3 row-major; Cw1: KF1 camera centre (GetCameraCenter); T2w: KF2
+ * pose (4x4 row-major); cam2: KF2 intrinsics.  matches12[i1] = keypoint of KF2 or -1 (vMatchedPairs = the pairs with
+ * a match, ascending i1). */
+int drfe_search_for_triangulation(drfe_ctx* ctx, int slot1, int slot2, const int32_t* mp1, int n1, const int32_t* mp2, int n2,
+                                  const float* F12, const float* Cw1, const float* T2w, const drfe_camera* cam2,
+                                  int only_stereo, int check_ori, int32_t* matches12, int* nmatches);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* PlaneDetection (replaces src/PlaneExtractor.cpp:7-63 + include/peac/ : the live AHC extractor)   */
 

@@ -175,4 +175,86 @@ int search_by_bow(const std::map<int, std::vector<unsigned>>& fvKF, const std::m
     return nmatches;
 }
 
+
+/* ORBmatcher::CheckDistEpipolarLine, src/ORBmatcher.cc:141-158 (float32 throughout; the threshold compares in double) */
+static bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float F[9], float sigma2)
+{
+    const float a = x1 * F[0] + y1 * F[3] + F[6];
+    const float b = x1 * F[1] + y1 * F[4] + F[7];
+    const float c = x1 * F[2] + y1 * F[5] + F[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)sigma2;
+}
+
+int search_for_triangulation(const TriKeyFrame& k1, const TriKeyFrame& k2, const float F12[9], float ex, float ey,
+                             const float* scaleFactors, const float* levelSigma2, bool onlyStereo, bool checkOri,
+                             int32_t* out12)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    int nmatches = 0;
+    for (int i = 0; i < k1.N; i++) out12[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto f1it = k1.fv->begin(), f1end = k1.fv->end();
+    auto f2it = k2.fv->begin(), f2end = k2.fv->end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            for (unsigned idx1 : f1it->second) {
+                if (k1.mp[idx1] >= 0) continue;                    /* already a MapPoint */
+                const bool bStereo1 = k1.uRight[idx1] >= 0;
+                if (onlyStereo && !bStereo1) continue;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (unsigned idx2 : f2it->second) {
+                    if (k2.mp[idx2] >= 0) continue;                /* vbMatched2 is never set in this reference */
+                    const bool bStereo2 = k2.uRight[idx2] >= 0;
+                    if (onlyStereo && !bStereo2) continue;
+                    const int dist = descriptor_distance_swar(k1.desc + (size_t)idx1 * 32, k2.desc + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - k2.x[idx2], distey = ey - k2.y[idx2];
+                        if (distex * distex + distey * distey < 100 * scaleFactors[k2.octave[idx2]]) continue;
+                    }
+                    if (check_dist_epipolar_line(k1.x[idx1], k1.y[idx1], k2.x[idx2], k2.y[idx2], F12, levelSigma2[k2.octave[idx2]])) {
+                        bestIdx2 = (int)idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    out12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) {
+                        float rot = k1.angle[idx1] - k2.angle[bestIdx2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back((int)idx1);
+                    }
+                }
+            }
+            ++f1it;
+            ++f2it;
+        } else if (f1it->first < f2it->first) f1it = k1.fv->lower_bound(f2it->first);
+        else f2it = k2.fv->lower_bound(f1it->first);
+    }
+    if (checkOri) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = (int)rotHist[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { out12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 } // namespace orc

@@ -28,5 +28,21 @@ int search_by_bow(const std::map<int, std::vector<unsigned>>& fvKF, const std::m
                   const uint8_t* descKF, const float* angleKF, const int32_t* kfMP, const uint8_t* descF,
                   const float* angleF, int nF, float nnratio, bool checkOri, int32_t* out);
 
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), src/ORBmatcher.cc:661-827, with
+ * CheckDistEpipolarLine (:141-158).  Per-keypoint inputs of both keyframes: undistorted position (x, y), octave,
+ * angle, uRight (>= 0 = stereo), map-point flag (>= 0 = has one).  epipole = projection of KF1's centre into KF2
+ * (:667-674).  out12[i1] = matched keypoint of KF2 or -1.  Note: this reference never sets vbMatched2, so keypoints
+ * of KF2 can be matched more than once and the loop has no order dependence between KF1 keypoints. */
+struct TriKeyFrame {
+    const std::map<int, std::vector<unsigned>>* fv;
+    const float *x, *y, *angle, *uRight;
+    const int32_t *octave, *mp;
+    const uint8_t* desc;
+    int N;
+};
+int search_for_triangulation(const TriKeyFrame& k1, const TriKeyFrame& k2, const float F12[9], float ex, float ey,
+                             const float* scaleFactors, const float* levelSigma2, bool onlyStereo, bool checkOri,
+                             int32_t* out12);
+
 } // namespace orc
 #endif

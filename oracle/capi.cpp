@@ -389,6 +389,30 @@ int orc_search_by_bow(const int32_t* nidKF, int nKF, const int32_t* nidF, int nF
     return search_by_bow(fvKF, fvF, descKF, angleKF, kfMP, descF, angleF, nF, nnratio, checkOri != 0, out);
 }
 
+/* per keyframe: kp = N x (x, y, angle, uRight) floats, io = N x (octave, mp, nid) ints (nid < 0: stopped word) */
+int orc_search_for_triangulation(const float* kp1, const int32_t* io1, const uint8_t* desc1, int n1, const float* kp2,
+                                 const int32_t* io2, const uint8_t* desc2, int n2, const float* F12, float ex, float ey,
+                                 const float* scaleFactors, const float* levelSigma2, int onlyStereo, int checkOri,
+                                 int32_t* out12)
+{
+    std::map<int, std::vector<unsigned>> fv1, fv2;
+    std::vector<float> x1(n1), y1(n1), a1(n1), u1(n1), x2(n2), y2(n2), a2(n2), u2(n2);
+    std::vector<int32_t> o1(n1), m1(n1), o2(n2), m2(n2);
+    for (int i = 0; i < n1; i++) {
+        x1[i] = kp1[4 * i]; y1[i] = kp1[4 * i + 1]; a1[i] = kp1[4 * i + 2]; u1[i] = kp1[4 * i + 3];
+        o1[i] = io1[3 * i]; m1[i] = io1[3 * i + 1];
+        if (io1[3 * i + 2] >= 0) fv1[io1[3 * i + 2]].push_back((unsigned)i);
+    }
+    for (int i = 0; i < n2; i++) {
+        x2[i] = kp2[4 * i]; y2[i] = kp2[4 * i + 1]; a2[i] = kp2[4 * i + 2]; u2[i] = kp2[4 * i + 3];
+        o2[i] = io2[3 * i]; m2[i] = io2[3 * i + 1];
+        if (io2[3 * i + 2] >= 0) fv2[io2[3 * i + 2]].push_back((unsigned)i);
+    }
+    const TriKeyFrame k1 = {&fv1, x1.data(), y1.data(), a1.data(), u1.data(), o1.data(), m1.data(), desc1, n1};
+    const TriKeyFrame k2 = {&fv2, x2.data(), y2.data(), a2.data(), u2.data(), o2.data(), m2.data(), desc2, n2};
+    return search_for_triangulation(k1, k2, F12, ex, ey, scaleFactors, levelSigma2, onlyStereo != 0, checkOri != 0, out12);
+}
+
 /* LSD + LBD lines */
 struct LineHandle { LineResult r; LsdStages st; };
 void* orc_lines_run(const uint8_t* img, int w, int h, int maxLines)

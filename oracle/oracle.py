@@ -606,6 +606,27 @@ def search_by_bow(nid_kf, nid_f, desc_kf, angle_kf, kf_mp, desc_f, angle_f, nnra
     return n, out
 
 
+def search_for_triangulation(kf1, kf2, F12, ex, ey, scale_factors, level_sigma2, only_stereo=False, check_ori=True):
+    """ORBmatcher::SearchForTriangulation.  kf = dict(x, y, angle, u_right, octave, mp, nid, desc) per keypoint
+    (mp >= 0: has a map point; nid < 0: stopped word).  Returns (nmatches, matches12)."""
+    def pack(k):
+        kp = np.stack([_c(k["x"], np.float32), _c(k["y"], np.float32), _c(k["angle"], np.float32),
+                       _c(k["u_right"], np.float32)], 1).astype(np.float32)
+        io = np.stack([_c(k["octave"], np.int32), _c(k["mp"], np.int32), _c(k["nid"], np.int32)], 1).astype(np.int32)
+        return np.ascontiguousarray(kp), np.ascontiguousarray(io), _c(k["desc"], np.uint8)
+    kp1, io1, d1 = pack(kf1)
+    kp2, io2, d2 = pack(kf2)
+    out = np.full(len(kp1), -1, np.int32)
+    L = lib()
+    L.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int, C.c_void_p]
+    n = L.orc_search_for_triangulation(_p(kp1), _p(io1), _p(d1), len(kp1), _p(kp2), _p(io2), _p(d2), len(kp2),
+                                       _p(_c(F12, np.float32).reshape(9)), float(ex), float(ey), _p(_c(scale_factors, np.float32)),
+                                       _p(_c(level_sigma2, np.float32)), int(only_stereo), int(check_ori), _p(out))
+    return n, out
+
+
 def cape_planes(depth_m, K4, patch=20, cos_angle_max=None, max_merge_dist=50.0):
     """PlaneDetection_CAPE::readDepthImage + runPlaneDetection (reference src/PlaneExtractor.cpp:102-191).
     depth_m: float32 metres (what Frame::ComputePlanes_CAPE passes).  Returns dict(planes=[n,7]

@@ -70,3 +70,66 @@ def test_vocabulary_limits(env):
     voc = V.make_synthetic(4, 2)
     with pytest.raises(lib.DrfeError):
         c.voc_upload(25, 2, 0, 0, voc.parent, voc.desc, voc.weight, voc.is_leaf)     # k > 20 rejected like the loader
+
+
+def _skew(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]], np.float64)
+
+
+def test_search_for_triangulation(frames_room, oracle_mod):
+    """ORBmatcher(0.6, false/true).SearchForTriangulation(KF1, KF2, F12, pairs, bOnlyStereo) as LocalMapping::
+    CreateNewMapPoints calls it: vocabulary-node groups, epipole exclusion, epipolar-line gate, rotation histogram."""
+    import torch
+    from dr_slam_amd import lib, synth, vocabulary as V
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = synth.TUM3
+    fe = FrontEnd(cam, max_batch=4)
+    try:
+        gray = torch.from_numpy(np.stack([f[0] for f in frames_room])).cuda()
+        depth = torch.from_numpy(np.stack([f[1] for f in frames_room]).view(np.int16)).cuda()
+        fe.process(gray, depth, None, None, stream=torch.cuda.current_stream().cuda_stream)
+        c = fe.ctx
+        voc = V.make_synthetic(10, 4, seed=5, stop_fraction=0.02)
+        ov = oracle_mod.VocabularyOracle(voc.to_text())
+        voc.upload(c)
+        c.bow_transform_batch(2, 4)
+        scale, _, sigma2, _ = c.scale_tables()
+        K = np.array([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], np.float64)
+        rng = np.random.default_rng(7)
+        total = 0
+        for s1, s2, only_stereo, ori in ((0, 2, False, True), (3, 1, False, False), (1, 3, True, True)):
+            Twc1, Twc2 = frames_room[s1][2].astype(np.float64), frames_room[s2][2].astype(np.float64)
+            T1w, T2w = np.linalg.inv(Twc1), np.linalg.inv(Twc2)
+            R12 = T1w[:3, :3] @ T2w[:3, :3].T                       # LocalMapping::ComputeF12
+            t12 = -R12 @ T2w[:3, 3] + T1w[:3, 3]
+            F12 = (np.linalg.inv(K).T @ _skew(t12) @ R12 @ np.linalg.inv(K)).astype(np.float32)
+            Cw1 = Twc1[:3, 3].astype(np.float32)
+            T2w32 = T2w.astype(np.float32)
+            kf = []
+            for s in (s1, s2):
+                kps, desc = c.orb_download(s)
+                n = len(kps)
+                un = c.download_keys_un(s, n)
+                ur, _ = c.download_stereo(s)
+                ur = ur[:n].copy()
+                ur[rng.random(n) < 0.3] = -1.0                      # mix of monocular and stereo keypoints ...
+                mp = np.where(rng.random(n) < 0.4, 5, -1).astype(np.int32)
+                _, w, nid = ov.transform_each(desc, 2)
+                kf.append(dict(x=un["x"], y=un["y"], angle=un["angle"], u_right=ur, octave=un["octave"], mp=mp,
+                               nid=np.where(w > 0, nid, -1), desc=desc, n=n))
+            # ... the product reads mvuRight of its slots: make the device copy agree with the edited arrays
+            # (only_stereo / epipole rules are exercised through the map-point mask instead when unedited)
+            for k, s in zip(kf, (s1, s2)):
+                ur_dev, _ = c.download_stereo(s)
+                k["u_right"] = ur_dev[:k["n"]]
+            C2 = T2w32[:3, :3] @ Cw1 + T2w32[:3, 3]
+            ex = np.float32(cam.fx) * C2[0] * (np.float32(1.0) / C2[2]) + np.float32(cam.cx)
+            ey = np.float32(cam.fy) * C2[1] * (np.float32(1.0) / C2[2]) + np.float32(cam.cy)
+            no, mo = oracle_mod.search_for_triangulation(kf[0], kf[1], F12, ex, ey, scale, sigma2, only_stereo, ori)
+            ng, mg = c.search_for_triangulation(s1, s2, kf[0]["mp"], kf[1]["mp"], F12, Cw1, T2w32, fe.cam, only_stereo, ori)
+            assert ng == no, (s1, s2, ng, no)
+            assert np.array_equal(mg, mo)
+            total += no
+        assert total > 60
+    finally:
+        fe.ctx.close()

@@ -385,3 +385,44 @@ def test_is_in_frustum_hand_cases(oracle_mod):
     ln["world"], ln["normal"], ln["min_distance"], ln["max_distance"] = (-0.5, 0, 1.0, 0.5, 0, 1.0), (0, 0, 1), 0.5, 9.0
     r = O.is_in_frustum_lines(cam9, T, 1.2, ln, 0.5)[0]
     assert r["in_view"] == 1 and r["level"] == 13 and r["x1"] == 70 and r["x2"] == 570
+
+
+# ---- ORBmatcher::SearchForTriangulation (f-4) -------------------------------------------------------------------------
+
+def test_search_for_triangulation_hand_cases(oracle_mod):
+    """One vocabulary node, pure x-translation (epipolar lines are image rows: F12 = [t]x with t = (1,0,0) in pixel
+    units): the LAST of equally good candidates wins, the epipolar gate uses sigma2 of the KF2 octave, keypoints that
+    already have a map point are skipped on both sides."""
+    O = oracle_mod
+    rng = np.random.RandomState(4)
+    d = rng.randint(0, 256, 32).astype(np.uint8)
+    far = d ^ np.uint8(0xFF)
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)       # l = x1' F = (0, -1, y1): distance = |y2 - y1|
+    scale = (1.2 ** np.arange(8)).astype(np.float32)
+    sigma2 = scale * scale
+
+    def kf(x, y, desc, octave=None, mp=None, ur=None):
+        n = len(x)
+        return dict(x=np.array(x, np.float32), y=np.array(y, np.float32), angle=np.zeros(n, np.float32),
+                    u_right=np.full(n, 10.0, np.float32) if ur is None else np.array(ur, np.float32),
+                    octave=np.zeros(n, np.int32) if octave is None else np.array(octave, np.int32),
+                    mp=np.full(n, -1, np.int32) if mp is None else np.array(mp, np.int32), nid=np.zeros(n, np.int32),
+                    desc=np.stack(desc))
+
+    k1 = kf([100], [50], [d])
+    n, m = O.search_for_triangulation(k1, kf([90, 80, 70], [50, 50.5, 49.5], [d, d, d]), F, -1e4, -1e4, scale, sigma2, False, False)
+    assert n == 1 and m[0] == 2                                      # equal distances: the last candidate replaces
+    n, m = O.search_for_triangulation(k1, kf([90, 80], [50, 53], [far, d]), F, -1e4, -1e4, scale, sigma2, False, False)
+    assert n == 0                                                    # 3 px off the line: 9 > 3.84 at octave 0
+    n, m = O.search_for_triangulation(k1, kf([90, 80], [50, 53], [far, d], octave=[0, 6]), F, -1e4, -1e4, scale, sigma2, False, False)
+    assert n == 1 and m[0] == 1                                      # sigma2(6) = 8.9: 9 < 3.84 * 8.9
+    n, m = O.search_for_triangulation(k1, kf([90], [50], [d], mp=[3]), F, -1e4, -1e4, scale, sigma2, False, False)
+    assert n == 0                                                    # KF2 keypoint already has a map point
+    n, m = O.search_for_triangulation(kf([100], [50], [d], mp=[1]), kf([90], [50], [d]), F, -1e4, -1e4, scale, sigma2, False, False)
+    assert n == 0
+    # both monocular and within 10 px (scaled) of the epipole -> excluded; stereo keypoints are not
+    mono1, mono2 = kf([100], [50], [d], ur=[-1]), kf([90], [50], [d], ur=[-1])
+    assert O.search_for_triangulation(mono1, mono2, F, 95.0, 50.0, scale, sigma2, False, False)[0] == 0
+    assert O.search_for_triangulation(mono1, mono2, F, 500.0, 50.0, scale, sigma2, False, False)[0] == 1
+    assert O.search_for_triangulation(mono1, mono2, F, 500.0, 50.0, scale, sigma2, True, False)[0] == 0      # bOnlyStereo
+    assert O.search_for_triangulation(k1, kf([90], [50], [d]), F, 95.0, 50.0, scale, sigma2, True, False)[0] == 1
