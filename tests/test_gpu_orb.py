@@ -138,3 +138,44 @@ def test_1280x960_config5(oracle_mod):
     assert (x0 >= 18.99).all() and (k1["y"] / sc[lvl] >= 18.99).all()
     assert (np.unpackbits(d1, axis=1).sum(1) > 40).all()
     c.close()
+
+
+def test_large_batch_uses_both_quadtree_variants(frames_room, oracle_mod):
+    """72 frames in one batch: nlevels * nframes exceeds what is resident at once, so the launcher splits the quadtree
+    into the 512-thread variant (large levels) and the 256-thread / small-LDS variant (small levels).  Every slot must
+    still equal the oracle of its source frame."""
+    import torch
+    from dr_slam_amd import lib
+    B = 72
+    c = lib.Context(max_batch=B)
+    try:
+        order = [i % 4 for i in range(B)]
+        gray = torch.from_numpy(np.stack([frames_room[i][0] for i in order])).cuda()
+        c.orb_extract_batch_ptr(gray.data_ptr(), 640 * 480, 640, 640, 480, B, torch.cuda.current_stream().cuda_stream)
+        o = oracle_mod.OrbOracle()
+        ref = [o(frames_room[i][0]) for i in range(4)]
+        counts = c.orb_counts(B)
+        for s in range(B):
+            kps, desc = c.orb_download(s)
+            okps, odesc = ref[order[s]]
+            assert counts[s] == len(okps)
+            _same_kps(kps, okps)
+            assert np.array_equal(desc, odesc)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("nfeatures", [500, 2000])
+def test_other_feature_budgets(frames_room, oracle_mod, nfeatures):
+    """nfeatures = 2000 (per-level quotas above 256 nodes: the 1024-node quadtree variant) and 500."""
+    from dr_slam_amd import lib
+    c = lib.Context(nfeatures=nfeatures)
+    try:
+        g = frames_room[1][0]
+        kps, desc = c.orb_extract(g)
+        okps, odesc = oracle_mod.OrbOracle(nfeatures, 1.2, 8, 20, 7)(g)
+        _same_kps(kps, okps)
+        assert np.array_equal(desc, odesc)
+        assert abs(len(kps) - nfeatures) < 0.1 * nfeatures
+    finally:
+        c.close()
