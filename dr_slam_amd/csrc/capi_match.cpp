@@ -605,4 +605,44 @@ int drfe_frame_is_in_frustum_lines(drfe_ctx* c, const float* Tcw, const drfe_cam
     });
 }
 
+
+/* ---- ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th): search part -------------------------------- */
+int drfe_fuse_search(drfe_ctx* c, int slot, const float* Tcw, const drfe_frustum_point* pts, const uint8_t* descs,
+                     const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c || !Tcw || n < 0 || (n && (!pts || !descs || !best_idx || !best_dist))) return DRFE_ERR_INVALID;
+    if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = "fuse_search: slot needs extract + glue first"; return DRFE_ERR_STATE; }
+    if (c->cfg.nlevels > 16) { c->err = "fuse_search: more than 16 pyramid levels"; return DRFE_ERR_INVALID; }
+    if (n == 0) return DRFE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    const drfe_camera cam = c->cam;                       /* the glue call's camera: bounds and grid of this slot */
+    FrustumPose fp;
+    frustum_pose(c, Tcw, &cam, 0.f, &fp);
+    FuseParams P;
+    std::memset(&P, 0, sizeof(P));
+    std::memcpy(P.T, fp.T, 64);
+    std::memcpy(P.Ow, fp.Ow, 12);
+    P.bf = cam.bf; P.logScale = fp.logScale; P.th = th; P.nLevels = c->cfg.nlevels;
+    for (int l = 0; l < c->cfg.nlevels; l++) { P.scale[l] = c->scale[l]; P.invSigma2[l] = c->invSigma2[l]; }
+    uint8_t* d = nullptr;
+    const size_t oP = 0, oD = (sizeof(drfe_frustum_point) * (size_t)n + 63) & ~(size_t)63, oS = oD + (((size_t)n * 32 + 63) & ~(size_t)63),
+                 oI = oS + (((size_t)n + 63) & ~(size_t)63), oB = oI + sizeof(int) * (size_t)n, total = oB + sizeof(int) * (size_t)n;
+    HIPCHK(c, hipMalloc(&d, total));
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(d + oP, pts, sizeof(drfe_frustum_point) * (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oD, descs, (size_t)n * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && skip) e = hipMemcpyAsync(d + oS, skip, (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = drfe_launch_fuse_search(c, slot, reinterpret_cast<const drfe_frustum_point*>(d + oP), d + oD, skip ? d + oS : nullptr, n, P,
+                                    cam, reinterpret_cast<int*>(d + oI), reinterpret_cast<int*>(d + oB), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(best_idx, d + oI, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(best_dist, d + oB, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("fuse_search: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    return DRFE_OK;
+}
+
 } /* extern "C" */

@@ -907,3 +907,119 @@ hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, co
     hipLaunchKernelGGL(k_frustum_lines, dim3((n + 255) / 256), dim3(256), 0, s, d_lines, n, P, cam, d_out);
     return hipGetLastError();
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th): the search (src/ORBmatcher.cc:846-953)          */
+
+/* One wavefront per map point.  Projection, KeyFrame::IsInImage, distance band, 60-degree cone and PredictScale are
+ * wave-uniform; the window is gathered exactly like k_window_candidates (one contiguous run of cell-sorted records per
+ * grid column, lanes on candidates) with KeyFrame::GetFeaturesInArea's rules (no level filter), then the octave
+ * window, the chi-square reprojection gate and a wave minimum of distance << 22 | visit position (first minimum). */
+__global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* __restrict__ pts, const uint8_t* __restrict__ descs,
+                                                     const uint8_t* __restrict__ skip, int n, FuseParams P, drfe_camera cam,
+                                                     float invW, float invH, const int* __restrict__ gridOff,
+                                                     const uint4* __restrict__ cellKp, const uint4* __restrict__ cellDesc,
+                                                     int* __restrict__ bestIdx, int* __restrict__ bestDist)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    if (i >= n) return;                          /* wave-uniform */
+    int outIdx = -1, outDist = 256;
+    bool ok = !(skip && skip[i]);
+    const drfe_frustum_point p = pts[i];
+    float Pc[3];
+    mat3_mul_add(P.T, p.world, Pc);
+    if (Pc[2] < 0.0f) ok = false;
+    const float invz = 1 / Pc[2];
+    const float x = Pc[0] * invz, y = Pc[1] * invz;
+    const float u = cam.fx * x + cam.cx, v = cam.fy * y + cam.cy;
+    if (!(u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y)) ok = false;
+    const float ur = u - P.bf * invz;
+    const float maxDistance = 1.2f * p.max_distance, minDistance = 0.8f * p.min_distance;
+    const float PO[3] = {p.world[0] - P.Ow[0], p.world[1] - P.Ow[1], p.world[2] - P.Ow[2]};
+    const float dist3D = norm3_f(PO);
+    if (dist3D < minDistance || dist3D > maxDistance) ok = false;
+    if (dot3_d(PO, p.normal) < 0.5 * (double)dist3D) ok = false;
+    if (ok) {
+        const float ratio = p.max_distance / dist3D;
+        int level = (int)ceilf(drfe_logf(ratio) / P.logScale);
+        if (level < 0) level = 0;
+        else if (level >= P.nLevels) level = P.nLevels - 1;
+        const float r = P.th * P.scale[level];
+        const int nMinCellX = max(0, (int)floorf((u - cam.min_x - r) * invW));
+        const int nMaxCellX = min(DRFE_GRID_COLS - 1, (int)ceilf((u - cam.min_x + r) * invW));
+        const int nMinCellY = max(0, (int)floorf((v - cam.min_y - r) * invH));
+        const int nMaxCellY = min(DRFE_GRID_ROWS - 1, (int)ceilf((v - cam.min_y + r) * invH));
+        if (!(nMinCellX >= DRFE_GRID_COLS || nMaxCellX < 0 || nMinCellY >= DRFE_GRID_ROWS || nMaxCellY < 0)) {
+            const uint64_t* q = reinterpret_cast<const uint64_t*>(descs + (size_t)i * 32);
+            const uint64_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const int ncol = nMaxCellX - nMinCellX + 1;
+            int runB = 0, runN = 0;
+            if (lane < ncol) {
+                const int cb = (nMinCellX + lane) * DRFE_GRID_ROWS;
+                runB = gridOff[cb + nMinCellY];
+                runN = gridOff[cb + nMaxCellY + 1] - runB;
+            }
+            int incl = runN;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const int T = __shfl(incl, 63);
+            uint32_t myKey = 0xFFFFFFFFu, myIdx = 0;
+            for (int s0 = 0; s0 < T; s0 += WAVE) {
+                const int sq = s0 + lane;
+                int base = __builtin_amdgcn_readfirstlane(runB);
+                for (int j = 0; j + 1 < ncol; j++) {
+                    const int inclJ = __builtin_amdgcn_readlane(incl, j), nextB = __builtin_amdgcn_readlane(runB, j + 1);
+                    if (inclJ <= sq) base = nextB - inclJ;
+                }
+                if (sq < T) {
+                    const int pp = base + sq;
+                    const uint4 k4 = cellKp[pp];
+                    const float kx = __uint_as_float(k4.x), ky = __uint_as_float(k4.y), kr = __uint_as_float(k4.z);
+                    const int oct = (int)(k4.w >> 24);
+                    const float dx = kx - u, dy = ky - v;
+                    bool c = fabsf(dx) < r && fabsf(dy) < r;                /* KeyFrame::GetFeaturesInArea */
+                    if (oct < level - 1 || oct > level) c = false;
+                    const float ex = u - kx, ey = v - ky;
+                    if (kr >= 0) {
+                        const float er = ur - kr;
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * P.invSigma2[oct & 15]) > 7.8) c = false;
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * P.invSigma2[oct & 15]) > 5.99) c = false;
+                    }
+                    if (c) {
+                        const uint4 da = cellDesc[2 * pp], db = cellDesc[2 * pp + 1];
+                        const int dist = __popcll(q0 ^ ((uint64_t)da.x | ((uint64_t)da.y << 32))) + __popcll(q1 ^ ((uint64_t)da.z | ((uint64_t)da.w << 32))) +
+                                         __popcll(q2 ^ ((uint64_t)db.x | ((uint64_t)db.y << 32))) + __popcll(q3 ^ ((uint64_t)db.z | ((uint64_t)db.w << 32)));
+                        const uint32_t key = ((uint32_t)dist << 22) | (uint32_t)min(sq, (1 << 22) - 1);
+                        if (key < myKey) { myKey = key; myIdx = k4.w & 0xFFFFFF; }
+                    }
+                }
+            }
+            const uint32_t mn = wave_min_u32(myKey);
+            if (mn != 0xFFFFFFFFu) {
+                const unsigned long long who = __ballot(myKey == mn);
+                outIdx = __shfl((int)myIdx, __ffsll((long long)who) - 1);
+                outDist = (int)(mn >> 22);
+            }
+        }
+    }
+    if (lane == 0) { bestIdx[i] = outIdx; bestDist[i] = outDist; }
+}
+
+hipError_t drfe_launch_fuse_search(drfe_ctx* c, int slot, const drfe_frustum_point* d_pts, const uint8_t* d_descs,
+                                   const uint8_t* d_skip, int n, const FuseParams& P, const drfe_camera& cam, int* d_bestIdx,
+                                   int* d_bestDist, hipStream_t s)
+{
+    const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
+    const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
+    hipLaunchKernelGGL(k_fuse_search, dim3((n + 3) / 4), dim3(256), 0, s, d_pts, d_descs, d_skip, n, P, cam, invW, invH,
+                       c->d_gridOff + (size_t)slot * (DRFE_GRID_CELLS + 1), c->d_cellKp + (size_t)slot * c->maxKp,
+                       c->d_cellDesc + (size_t)slot * c->maxKp * 2, d_bestIdx, d_bestDist);
+    return hipGetLastError();
+}

@@ -293,6 +293,16 @@ int drfe_frame_is_in_frustum(drfe_ctx* ctx, const float* Tcw, const drfe_camera*
 int drfe_frame_is_in_frustum_lines(drfe_ctx* ctx, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines,
                                    int n, float viewing_cos_limit, drfe_tracked_line* out);
 
+/* ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th), src/ORBmatcher.cc:829-985 (LocalMapping::SearchInNeighbors): the
+ * search.  The keyframe is a slot with extract + glue done; per map point (skip[i] = !pMP || isBad() ||
+ * IsInKeyFrame(pKF), may be NULL): projection with Tcw, KeyFrame::IsInImage, distance band, 60-degree viewing cone,
+ * PredictScale, KeyFrame::GetFeaturesInArea(u, v, th * scale[level]), octave in [level-1, level], chi-square
+ * reprojection gate (7.8 with a right coordinate, 5.99 without), first minimum of the Hamming distance.
+ * best_idx[i] = keyframe keypoint or -1, best_dist[i] = its distance (256 if none).  Applying the result
+ * (bestDist <= TH_LOW: Replace / AddObservation / AddMapPoint) mutates the map graph and is the caller's loop. */
+int drfe_fuse_search(drfe_ctx* ctx, int slot, const float* Tcw, const drfe_frustum_point* pts, const uint8_t* descs,
+                     const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */

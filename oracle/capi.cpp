@@ -488,6 +488,12 @@ void orc_is_in_frustum_lines(const float* cam9, const float* Tcw, float logScale
     is_in_frustum_lines(cam, Tcw, logScale, lines, n, limit, out);
 }
 float orc_logf(float x) { return drfe_logf(x); }
+void orc_fuse_search(void* frame, const float* Tcw, const float* invSigma2, float logScale, int nLevels,
+                     const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* bestIdx,
+                     int32_t* bestDist)
+{
+    fuse_search(*(Frame*)frame, Tcw, invSigma2, logScale, nLevels, pts, descs, skip, n, th, bestIdx, bestDist);
+}
 int orc_sizeof_maplinerec() { return (int)sizeof(MapLineRec); }
 int orc_sizeof_trackedlinerec() { return (int)sizeof(TrackedLineRec); }
 

@@ -601,4 +601,58 @@ void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logSc
     }
 }
 
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* ORBmatcher::Fuse (search part)                                                                       */
+
+void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigma2, float logScaleFactor, int nLevels,
+                 const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* bestIdx,
+                 int32_t* bestDist)
+{
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+    camera_centre(Rcw, tcw, Ow);
+    std::vector<int> cand;
+    for (int i = 0; i < n; i++) {
+        bestIdx[i] = -1; bestDist[i] = 256;
+        if (skip && skip[i]) continue;
+        const FrustumPointRec& p = pts[i];
+        float p3Dc[3];
+        mat3_mul_add(Rcw, p.world, tcw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = KF.fx * x + KF.cx, v = KF.fy * y + KF.cy;
+        if (!(u >= KF.minX && u < KF.maxX && v >= KF.minY && v < KF.maxY)) continue;     /* KeyFrame::IsInImage */
+        const float ur = u - KF.bf * invz;
+        const float maxDistance = 1.2f * p.maxDistance, minDistance = 0.8f * p.minDistance;
+        const float PO[3] = {p.world[0] - Ow[0], p.world[1] - Ow[1], p.world[2] - Ow[2]};
+        const float dist3D = norm3(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        if (dot3(PO, p.normal) < 0.5 * (double)dist3D) continue;
+        const float ratio = p.maxDistance / dist3D;
+        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        if (level < 0) level = 0;
+        else if (level >= nLevels) level = nLevels - 1;
+        const float radius = th * KF.scaleFactors[level];
+        KF.getFeaturesInArea(u, v, radius, -1, -1, cand);          /* the KeyFrame version has no level filter */
+        for (int idx : cand) {
+            const KeyPoint& kp = KF.keysUn[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < level - 1 || kpLevel > level) continue;
+            const float ex = u - kp.x, ey = v - kp.y;
+            if (KF.uRight[idx] >= 0) {
+                const float er = ur - KF.uRight[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if ((double)(e2 * invLevelSigma2[kpLevel]) > 7.8) continue;
+            } else {
+                const float e2 = ex * ex + ey * ey;
+                if ((double)(e2 * invLevelSigma2[kpLevel]) > 5.99) continue;
+            }
+            const int dist = descriptor_distance_swar(descs + (size_t)i * 32, KF.desc.data() + (size_t)idx * 32);
+            if (dist < bestDist[i]) { bestDist[i] = dist; bestIdx[i] = idx; }
+        }
+    }
+}
+
 } // namespace orc

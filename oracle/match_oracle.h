@@ -108,5 +108,17 @@ void is_in_frustum(const LineCamera& cam, float bf, const float Tcw[16], float l
 void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logScaleFactor, const FrustumLineRec* lines,
                          int n, float viewingCosLimit, FrustumLineOut* out);
 
+
+/* --- ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th), src/ORBmatcher.cc:829-985: the search part ------------ */
+/* For every map point (skip[i] = !pMP || isBad() || IsInKeyFrame(pKF)): projection, KeyFrame::IsInImage, distance band,
+ * 60-degree viewing cone, PredictScale, KeyFrame::GetFeaturesInArea(u, v, th * scale[level]) (no level filter, src/
+ * KeyFrame.cc:707-746), octave in [level-1, level], chi-square reprojection gate (7.8 stereo / 5.99 mono), first
+ * minimum of the Hamming distance.  bestIdx[i] = keyframe keypoint or -1, bestDist[i] = its distance (256 if none);
+ * what the caller does with it (Replace / AddObservation when bestDist <= TH_LOW) touches the map graph and stays on
+ * the host. */
+void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigma2, float logScaleFactor, int nLevels,
+                 const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* bestIdx,
+                 int32_t* bestDist);
+
 } // namespace orc
 #endif

@@ -256,3 +256,36 @@ def test_is_in_frustum_points_and_lines(oracle_mod, seed):
         assert rl["in_view"].sum() > 50
     finally:
         ctx.close()
+
+
+def test_fuse_search(setup, oracle_mod):
+    """Search part of ORBmatcher::Fuse(pKF, vpMapPoints, 3.0) as LocalMapping::SearchInNeighbors calls it: the map
+    points are another frame's keypoints unprojected with their depth, viewed from the target keyframe."""
+    from dr_slam_amd import lib
+    fe, oframes, Tcw, Twc, cam = setup
+    o = oracle_mod.OrbOracle()
+    inv_sigma2 = fe.ctx.scale_tables()[3]
+    rng = np.random.RandomState(11)
+    found = 0
+    for kf_slot, src in ((1, 0), (2, 3), (0, 2)):
+        world, valid = oframes[src].unproject(Twc[src])
+        keep = np.flatnonzero(valid)
+        n = len(keep)
+        pts = np.zeros(n, lib.FRUSTUM_POINT_DTYPE)
+        pts["world"] = world[keep]
+        Ow = Twc[src][:3, 3]
+        v = Ow[None, :] - world[keep]                       # mean viewing direction = towards the observing camera
+        d = np.linalg.norm(v, axis=1)
+        pts["normal"] = (-(v / d[:, None])).astype(np.float32)     # PO.dot(Pn) > 0 when seen from the same side
+        lvl = oframes[src].kps["octave"][keep]
+        pts["max_distance"] = (d * o.scale[lvl] * rng.uniform(0.9, 1.3, n)).astype(np.float32)
+        pts["min_distance"] = (pts["max_distance"] / o.scale[-1] * rng.uniform(0.5, 1.0, n)).astype(np.float32)
+        descs = oframes[src].desc[keep]
+        skip = (rng.uniform(size=n) < 0.1).astype(np.uint8)
+        for th in (3.0, 6.0):
+            bi, bd = fe.ctx.fuse_search(kf_slot, Tcw[kf_slot], pts, descs, skip, th)
+            obi, obd = oracle_mod.fuse_search(oframes[kf_slot], Tcw[kf_slot], 1.2, inv_sigma2, pts, descs, skip, th)
+            assert np.array_equal(bi, obi) and np.array_equal(bd, obd), (kf_slot, src, th)
+            found += int(((obi >= 0) & (obd <= 50)).sum())
+        assert (obi[skip == 1] == -1).all()
+    assert found > 500
