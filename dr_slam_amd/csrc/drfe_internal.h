@@ -45,6 +45,10 @@ struct DevLevel {
     float scale;              /* mvScaleFactor[l] */
     float kpSize;             /* (float)(int)(31*scale) */
     int xtabOff, ytabOff;     /* resize coefficient tables (level >= 1), element offsets */
+    int xwinOff, ywinOff;     /* per 256-column / 16-row block of the bordered level: (lowest, highest) source index its
+                                 taps touch, stored as ResizeTap{s0 = lo, s1 = hi}; resizeLds = 0 if a window exceeds the
+                                 LDS tile of k_pyr_resize_lds */
+    int resizeLds;
     int cellBegin, cellEnd;   /* range in the FAST cell table */
     int tileBegin, tileEnd;   /* range in the blur tile table */
 };
@@ -157,6 +161,8 @@ hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameSt
 hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, float th, int mono, int checkOri,
                                          int nframes, hipStream_t s);
 
+#define DRFE_RESIZE_LDS_WD 88     /* dwords per source row of the k_pyr_resize_lds tile (256 output columns * 1.25 + slack) */
+#define DRFE_RESIZE_LDS_ROWS 24   /* source rows of the tile (16 output rows * 1.25 + slack) */
 #define DRFE_BLUR_TW 64
 #define DRFE_BLUR_TH 32
 

@@ -193,6 +193,8 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
         L.tileEnd = tiles ? (int)tiles->size() : 0;
         /* resize taps from level l-1 (cascade, :1120) */
         L.xtabOff = L.ytabOff = 0;
+        L.xwinOff = L.ywinOff = 0;
+        L.resizeLds = 0;
         if (l > 0 && taps) {
             if (taps->size() & 1) taps->push_back(ResizeTap{0, 0, 0, 0});
             L.xtabOff = (int)taps->size();
@@ -200,6 +202,31 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
             if (taps->size() & 1) taps->push_back(ResizeTap{0, 0, 0, 0});
             L.ytabOff = (int)taps->size();
             build_taps(g->lv[l - 1].h, L.h, align_up(L.h + 2 * DRFE_EDGE, 4), taps);   /* 4 rows per thread */
+            /* source windows of the 256 x 16 output blocks of k_pyr_resize_lds */
+            const int bh = L.h + 2 * DRFE_EDGE;
+            const int nbx = (L.pyrPitch + 255) / 256, nby = (bh + 15) / 16;
+            L.resizeLds = 1;
+            L.xwinOff = (int)taps->size();
+            for (int b = 0; b < nbx; b++) {
+                int lo = 1 << 30, hi = -1;
+                for (int x = b * 256; x < std::min(b * 256 + 256, L.pyrPitch); x++) {
+                    const ResizeTap& t = (*taps)[L.xtabOff + x];
+                    lo = std::min(lo, (int)t.s0); hi = std::max(hi, (int)t.s1);
+                }
+                const int ws = (lo + DRFE_EDGE) & ~3;
+                if ((hi + DRFE_EDGE - ws) / 4 + 1 > DRFE_RESIZE_LDS_WD) L.resizeLds = 0;
+                taps->push_back(ResizeTap{(uint16_t)lo, (uint16_t)hi, 0, 0});
+            }
+            L.ywinOff = (int)taps->size();
+            for (int b = 0; b < nby; b++) {
+                int lo = 1 << 30, hi = -1;
+                for (int y = b * 16; y < std::min(b * 16 + 16, bh); y++) {
+                    const ResizeTap& t = (*taps)[L.ytabOff + y];
+                    lo = std::min(lo, (int)t.s0); hi = std::max(hi, (int)t.s1);
+                }
+                if (hi - lo + 1 > DRFE_RESIZE_LDS_ROWS) L.resizeLds = 0;
+                taps->push_back(ResizeTap{(uint16_t)lo, (uint16_t)hi, 0, 0});
+            }
         }
     }
     g->pyrSlotBytes = pyrOff;

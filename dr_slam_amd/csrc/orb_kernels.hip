@@ -28,45 +28,63 @@ __device__ __forceinline__ int reflect101(int p, int n)
 /* ------------------------------------------------------------------------------------------------ */
 /* pyramid                                                                                          */
 
-/* thread = 4 bordered pixels x PYR0_ROWS rows; block = 64 x 4 threads.  Interior quads of a 4-byte
- * aligned source come from two aligned dwords (bordered x4 maps to source column x4 - 19 = 1 mod 4). */
-#define PYR0_ROWS 4
-__global__ __launch_bounds__(256) void k_pyr_level0(const DevLevel L, int pyrSlotBytes, const uint8_t* __restrict__ gray,
-                                                    size_t frameStride, size_t rowStride, int aligned4,
-                                                    uint8_t* __restrict__ pyr)
+/* copyMakeBorder(REFLECT_101) of the input into level 0.  Streaming kernels on this part want 16 bytes per lane
+ * (tools/ubench_copy.hip: 16 B/lane copies run at 6-7 TB/s, 4 B/lane at 4-5).
+ *   k_pyr_level0_wide   thread = 16 bordered pixels of one row whose sources are plain interior bytes: bordered column
+ *                       x16 maps to source column x16 - 19 = 13 (mod 16), so two aligned 16-byte loads and a 13-byte
+ *                       shift (v_alignbyte) per row, no divergence; needs a 16-byte aligned source
+ *   k_pyr_level0_edge   thread = 4 bordered pixels, byte by byte with reflection: the left and right column bands the
+ *                       wide kernel leaves out (or everything, for unaligned sources) */
+#define PYR0_ROWS 2
+__global__ __launch_bounds__(256) void k_pyr_level0_wide(const DevLevel L, int pyrSlotBytes, const uint8_t* __restrict__ gray,
+                                                         size_t frameStride, size_t rowStride, int x16First, int x16Last,
+                                                         uint8_t* __restrict__ pyr)
 {
     const int slot = blockIdx.z;
-    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR0_ROWS; /* bordered row */
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;         /* bordered column of 4 px */
-    const int bw = L.w + 2 * DRFE_EDGE, bh = L.h + 2 * DRFE_EDGE;
-    if (y0 >= bh || x4 >= L.pyrPitch) return;
-    const int sx = x4 - DRFE_EDGE;
-    const bool fast = aligned4 && sx >= 1 && sx + 7 <= L.w;
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR0_ROWS;     /* bordered row */
+    const int x16 = x16First + (blockIdx.x * 64 + threadIdx.x) * 16;
+    const int bh = L.h + 2 * DRFE_EDGE;
+    if (y0 >= bh || x16 > x16Last) return;
+    const int sx = x16 - DRFE_EDGE;
     const uint8_t* frame = gray + (size_t)slot * frameStride;
-    uint32_t out[PYR0_ROWS];
+    uint4 out[PYR0_ROWS];
 #pragma unroll
     for (int r = 0; r < PYR0_ROWS; r++) {
         const int y = min(y0 + r, bh - 1);
         const uint8_t* src = frame + (size_t)reflect101(y - DRFE_EDGE, L.h) * rowStride;
-        if (fast) {
-            const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src + (sx - 1));
-            out[r] = __builtin_amdgcn_alignbyte(s32[1], s32[0], 1);
-        } else {
-            uint32_t o = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int x = x4 + k;
-                uint32_t v = 0;
-                if (x < bw) v = src[reflect101(x - DRFE_EDGE, L.w)];
-                o |= v << (8 * k);
-            }
-            out[r] = o;
-        }
+        const uint4 A = *reinterpret_cast<const uint4*>(src + (sx - 13));
+        const uint4 B = *reinterpret_cast<const uint4*>(src + (sx + 3));
+        out[r] = make_uint4(__builtin_amdgcn_alignbyte(B.x, A.w, 1), __builtin_amdgcn_alignbyte(B.y, B.x, 1),
+                            __builtin_amdgcn_alignbyte(B.z, B.y, 1), __builtin_amdgcn_alignbyte(B.w, B.z, 1));
     }
-    uint8_t* dst = pyr + (size_t)slot * pyrSlotBytes + L.pyrOff + x4;
+    uint8_t* dst = pyr + (size_t)slot * pyrSlotBytes + L.pyrOff + x16;
 #pragma unroll
     for (int r = 0; r < PYR0_ROWS; r++)
-        if (y0 + r < bh) *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + r) * L.pyrPitch) = out[r];
+        if (y0 + r < bh) *reinterpret_cast<uint4*>(dst + (size_t)(y0 + r) * L.pyrPitch) = out[r];
+}
+
+/* columns [0, leftEnd) and [rightBegin, pitch) of every bordered row; thread = one dword of one row */
+__global__ __launch_bounds__(256) void k_pyr_level0_edge(const DevLevel L, int pyrSlotBytes, const uint8_t* __restrict__ gray,
+                                                         size_t frameStride, size_t rowStride, int leftEnd, int rightBegin,
+                                                         uint8_t* __restrict__ pyr)
+{
+    const int slot = blockIdx.z;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int nLeft = leftEnd / 4, nRight = (L.pyrPitch - rightBegin) / 4;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int bw = L.w + 2 * DRFE_EDGE, bh = L.h + 2 * DRFE_EDGE;
+    if (y >= bh || t >= nLeft + nRight) return;
+    const int x4 = t < nLeft ? t * 4 : rightBegin + (t - nLeft) * 4;
+    const uint8_t* src = gray + (size_t)slot * frameStride + (size_t)reflect101(y - DRFE_EDGE, L.h) * rowStride;
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        uint32_t v = 0;
+        if (x < bw) v = src[reflect101(x - DRFE_EDGE, L.w)];
+        o |= v << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(pyr + (size_t)slot * pyrSlotBytes + L.pyrOff + (size_t)y * L.pyrPitch + x4) = o;
 }
 
 /* One thread = 4 horizontally adjacent pixels of the BORDERED level; block = 64 x 4 threads, so a wave
@@ -126,6 +144,66 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const DevLevel L, const DevL
         for (int k = 0; k < 4; k++) {
             const int h0 = (int)pick_byte(a[r][0], a[r][1], a[r][2], o0[k]) * w0[k] + (int)pick_byte(a[r][0], a[r][1], a[r][2], o1[k]) * w1[k];
             const int h1 = (int)pick_byte(c[r][0], c[r][1], c[r][2], o0[k]) * w0[k] + (int)pick_byte(c[r][0], c[r][1], c[r][2], o1[k]) * w1[k];
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(255, max(0, v));
+            out |= (uint32_t)v << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)(y0 + r) * L.pyrPitch + x4) = out;
+    }
+}
+
+/* The same resize with the source staged in LDS: a 64 x 4 block (256 output columns x 16 rows) first copies the
+ * source window its taps touch — host-computed per block, <= 24 rows x 88 dwords — into LDS with coalesced dword loads
+ * (6-7 per thread instead of 24), and every tap becomes one ds_read_u8 instead of a byte picked out of registers.
+ * Arithmetic and results are identical to k_pyr_resize; measured speed is the same (~2.3 TB/s: neither version is
+ * VALU- or issue-bound), so this is the default only because it is the simpler inner loop.  (Tried: 16 pixels per
+ * thread with 16-byte loads and stores — slower, the strided LDS byte reads conflict.) */
+#define RES_PITCH (DRFE_RESIZE_LDS_WD * 4 + 4)      /* bytes per LDS row: odd dword count, no bank aliasing between rows */
+__global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const DevLevel P, int pyrSlotBytes,
+                                                        const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[DRFE_RESIZE_LDS_ROWS * RES_PITCH];
+    const int slot = blockIdx.z;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    uint8_t* base = pyr + (size_t)slot * pyrSlotBytes;
+    const ResizeTap wx = taps[L.xwinOff + blockIdx.x], wy = taps[L.ywinOff + blockIdx.y];
+    const int ws = ((int)wx.s0 + DRFE_EDGE) & ~3;                       /* bordered source column of tile byte 0 */
+    const int wd = (((int)wx.s1 + DRFE_EDGE - ws) >> 2) + 1;           /* dwords per tile row */
+    const int nr = (int)wy.s1 - (int)wy.s0 + 1;
+    const uint8_t* srcw = base + P.pyrOff + (size_t)((int)wy.s0 + DRFE_EDGE) * P.pyrPitch + ws;
+    for (int e = tid; e < nr * wd; e += 256) {
+        const int r = e / wd, cdw = e - r * wd;
+        *reinterpret_cast<uint32_t*>(&tile[r * RES_PITCH + cdw * 4]) =
+            *reinterpret_cast<const uint32_t*>(srcw + (size_t)r * P.pyrPitch + cdw * 4);
+    }
+    __syncthreads();
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int bh = L.h + 2 * DRFE_EDGE;
+    if (y0 >= bh || x4 >= L.pyrPitch) return;
+    const uint4 tya = *reinterpret_cast<const uint4*>(taps + L.ytabOff + y0);
+    const uint4 tyb = *reinterpret_cast<const uint4*>(taps + L.ytabOff + y0 + 2);
+    const uint4 ta = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4);
+    const uint4 tb = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4 + 2);
+    const uint32_t syp[PYR_ROWS] = {tya.x, tya.z, tyb.x, tyb.z}, wyp[PYR_ROWS] = {tya.y, tya.w, tyb.y, tyb.w};
+    const uint32_t sp[4] = {ta.x, ta.z, tb.x, tb.z}, wp[4] = {ta.y, ta.w, tb.y, tb.w};
+    int o0[4], o1[4], w0[4], w1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        o0[k] = (int)(sp[k] & 0xFFFF) + DRFE_EDGE - ws; o1[k] = (int)(sp[k] >> 16) + DRFE_EDGE - ws;
+        w0[k] = (int)(short)(wp[k] & 0xFFFF); w1[k] = (int)(short)(wp[k] >> 16);
+    }
+#pragma unroll
+    for (int r = 0; r < PYR_ROWS; r++) {
+        if (y0 + r >= bh) break;
+        const uint8_t* R0 = &tile[((int)(syp[r] & 0xFFFF) - (int)wy.s0) * RES_PITCH];
+        const uint8_t* R1 = &tile[((int)(syp[r] >> 16) - (int)wy.s0) * RES_PITCH];
+        const int b0 = (int)(short)(wyp[r] & 0xFFFF), b1 = (int)(short)(wyp[r] >> 16);
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int h0 = (int)R0[o0[k]] * w0[k] + (int)R0[o1[k]] * w1[k];
+            const int h1 = (int)R1[o0[k]] * w0[k] + (int)R1[o1[k]] * w1[k];
             int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
             v = min(255, max(0, v));
             out |= (uint32_t)v << (8 * k);
@@ -865,15 +943,27 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_begin(c, DRFE_STAGE_PYRAMID, s);
     {
         const DevLevel& L = g.lv[0];
-        dim3 grid((L.pyrPitch / 4 + 63) / 64, (L.h + 2 * DRFE_EDGE + 4 * PYR0_ROWS - 1) / (4 * PYR0_ROWS), nframes);
-        const int aligned4 = (((uintptr_t)d_gray | frameStride | rowStride) & 3) == 0;
-        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(64, 4), 0, s, L, g.pyrSlotBytes, d_gray, frameStride, rowStride, aligned4,
-                           c->d_pyr);
+        const int bh = L.h + 2 * DRFE_EDGE;
+        const bool aligned16 = (((uintptr_t)d_gray | frameStride | rowStride) & 15) == 0;
+        /* wide kernel: 16-px groups whose two aligned source words lie inside the row: x16 - 19 >= 13, x16 <= w */
+        int x16First = 32, x16Last = (L.w / 16) * 16, leftEnd = 0, rightBegin = 0;
+        if (aligned16 && x16Last >= x16First) {
+            const int nWide = (x16Last - x16First) / 16 + 1;
+            hipLaunchKernelGGL(k_pyr_level0_wide, dim3((nWide + 63) / 64, (bh + 4 * PYR0_ROWS - 1) / (4 * PYR0_ROWS), nframes),
+                               dim3(64, 4), 0, s, L, g.pyrSlotBytes, d_gray, frameStride, rowStride, x16First, x16Last, c->d_pyr);
+            leftEnd = x16First; rightBegin = x16Last + 16;
+        }
+        const int nEdge = leftEnd / 4 + (L.pyrPitch - rightBegin) / 4;      /* leftEnd == rightBegin == 0: every dword */
+        hipLaunchKernelGGL(k_pyr_level0_edge, dim3((nEdge + 63) / 64, (bh + 3) / 4, nframes), dim3(64, 4), 0, s, L,
+                           g.pyrSlotBytes, d_gray, frameStride, rowStride, leftEnd, rightBegin, c->d_pyr);
     }
     for (int l = 1; l < nl; l++) {
         const DevLevel& L = g.lv[l];
         dim3 grid((L.pyrPitch / 4 + 63) / 64, (L.h + 2 * DRFE_EDGE + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), nframes);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr);
+        if (L.resizeLds)
+            hipLaunchKernelGGL(k_pyr_resize_lds, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr);
+        else
+            hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr);
     }
     prof_end(c, DRFE_STAGE_PYRAMID, s);
 
