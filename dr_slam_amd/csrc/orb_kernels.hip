@@ -824,6 +824,12 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
 /* orientation + rBRIEF + keypoint finishing: one wavefront per keypoint                             */
 
 #define DESC_DISC_PER_LANE 12                     /* ceil(749 / 64) */
+#define DESC_KPW 4                                /* keypoints a wavefront carries at once */
+#define DESC_REACH 19                             /* ceil(13 * sqrt(2)): how far the rotated pattern reaches */
+/* The kernel is latency-bound (key -> pixel gathers -> angle -> pattern gathers -> store: five dependent round trips,
+ * ~10 us per wavefront under load), so a wavefront carries DESC_KPW keypoints through the phases together: their
+ * loads of one phase are all in flight at once, and the lane-constant tables (disc offsets, pattern) are loaded once
+ * per wavefront. */
 __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel,
@@ -835,85 +841,136 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
 {
     const int slot = blockIdx.y;
     const int lane = threadIdx.x & (WAVE - 1);
-    const int g = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); /* output index within the slot */
+    /* first output index of this wave; readfirstlane makes it (and every level / pointer derived from it) wave-uniform
+     * for the compiler: scalar ALU and SGPR base addresses instead of 64-bit vector address arithmetic per gather */
+    const int g0 = (blockIdx.x * (256 / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * DESC_KPW;
     const int nl = G->nlevels;
-    int level = -1, first = 0, total = 0;
-    for (int l = 0; l < nl; l++) {
-        const int c = selCount[slot * nl + l];
-        if (level < 0 && g < total + c) { level = l; first = total; }
-        total += c;
+    /* level of every output index: prefix sums of the per-level counts (level-major concatenation, :1103) */
+    int cnt[DRFE_MAX_LEVELS], total = 0;
+#pragma unroll
+    for (int l = 0; l < DRFE_MAX_LEVELS; l++) { cnt[l] = l < nl ? selCount[slot * nl + l] : 0; total += cnt[l]; }
+    if (g0 == 0 && lane == 0) kpCount[slot] = min(total, maxKp);
+    if (g0 >= total || g0 >= maxKp) return;                   /* wave-uniform */
+    int level[DESC_KPW], xi[DESC_KPW], yi[DESC_KPW], resp[DESC_KPW], pitchP[DESC_KPW], pitchB[DESC_KPW];
+    bool live[DESC_KPW];
+    const uint8_t* cP[DESC_KPW];
+    const uint8_t* cB[DESC_KPW];
+    uint32_t key[DESC_KPW];
+#pragma unroll
+    for (int j = 0; j < DESC_KPW; j++) {
+        const int g = g0 + j;
+        live[j] = g < total && g < maxKp;
+        int lv = 0, first = 0, run = 0;
+#pragma unroll
+        for (int l = 0; l < DRFE_MAX_LEVELS; l++) {
+            if (g >= run && g < run + cnt[l]) { lv = l; first = run; }
+            run += cnt[l];
+        }
+        level[j] = lv;
+        key[j] = live[j] ? sel[(size_t)slot * G->kpSlotElems + G->lv[lv].kpOff + (g - first)] : 0u;
     }
-    if (g == 0 && lane == 0) kpCount[slot] = min(total, maxKp);
-    if (level < 0 || g >= maxKp) return;
-    const DevLevel& L = G->lv[level];
-    const uint32_t key = sel[(size_t)slot * G->kpSlotElems + L.kpOff + (g - first)];
-    const int xi = (int)(key & 0xFFF) + L.minBX, yi = (int)((key >> 12) & 0xFFF) + L.minBY;
-    const int resp = (int)(key >> 24);
-    /* IC_Angle on the unblurred level: integer moments over the radius-15 disc (749 px) */
-    const uint8_t* c = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(yi + DRFE_EDGE) * L.pyrPitch +
-                       (xi + DRFE_EDGE);
-    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int j = 0; j < DESC_KPW; j++) {
+        const DevLevel& L = G->lv[level[j]];
+        xi[j] = (int)(key[j] & 0xFFF) + L.minBX; yi[j] = (int)((key[j] >> 12) & 0xFFF) + L.minBY;
+        resp[j] = (int)(key[j] >> 24);
+        pitchP[j] = L.pyrPitch; pitchB[j] = L.blurPitch;
+        if (!live[j]) { xi[j] = L.minBX + 16; yi[j] = L.minBY + 16; }      /* a harmless in-bounds position */
+        /* top-left corners of the patches, so that every gather offset below is a non-negative 32-bit number the
+         * hardware adds to a scalar base: the disc reaches 15 px, the rotated pattern (|x|, |y| <= 13) 19 px */
+        cP[j] = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(yi[j] + DRFE_EDGE - 15) * L.pyrPitch + (xi[j] + DRFE_EDGE - 15);
+        cB[j] = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (ptrdiff_t)(yi[j] - DESC_REACH) * L.blurPitch + (xi[j] - DESC_REACH);
+    }
+    /* IC_Angle on the unblurred level: integer moments over the radius-15 disc (749 px = 12 offsets per lane) */
+    const uint32_t* disc32 = reinterpret_cast<const uint32_t*>(disc);         /* u | v << 16, int16 each */
+    uint32_t uv[DESC_DISC_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
+        const int t = lane + k * WAVE;
+        uv[k] = t < discCount ? disc32[t] : 0u;               /* padding entries read the centre pixel, weight 0 */
+    }
+    int m10[DESC_KPW], m01[DESC_KPW];
     {
-        /* 749 disc offsets = 12 per lane: all offset loads, then all pixel gathers, in flight together
-         * (two memory round trips per keypoint instead of twenty-four) */
-        const uint32_t* disc32 = reinterpret_cast<const uint32_t*>(disc);     /* u | v << 16, int16 each */
-        uint32_t uv[DESC_DISC_PER_LANE];
+        int I[DESC_KPW][DESC_DISC_PER_LANE];
+        int du[DESC_DISC_PER_LANE], dv[DESC_DISC_PER_LANE];
 #pragma unroll
-        for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
-            const int j = lane + k * WAVE;
-            uv[k] = j < discCount ? disc32[j] : 0u;
-        }
-        int I[DESC_DISC_PER_LANE];
+        for (int k = 0; k < DESC_DISC_PER_LANE; k++) { du[k] = (int)(short)(uv[k] & 0xFFFF); dv[k] = (int)(short)(uv[k] >> 16); }
 #pragma unroll
-        for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
-            const int u = (int)(short)(uv[k] & 0xFFFF), v = (int)(short)(uv[k] >> 16);
-            I[k] = c[v * L.pyrPitch + u];                 /* padding entries read the centre pixel, weight 0 */
-        }
+        for (int j = 0; j < DESC_KPW; j++)
 #pragma unroll
-        for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
-            const int u = (int)(short)(uv[k] & 0xFFFF), v = (int)(short)(uv[k] >> 16);
-            m10 += u * I[k];
-            m01 += v * I[k];
+            for (int k = 0; k < DESC_DISC_PER_LANE; k++) I[j][k] = cP[j][(uint32_t)((dv[k] + 15) * pitchP[j] + (du[k] + 15))];
+#pragma unroll
+        for (int j = 0; j < DESC_KPW; j++) {
+            m10[j] = 0; m01[j] = 0;
+#pragma unroll
+            for (int k = 0; k < DESC_DISC_PER_LANE; k++) {
+                m10[j] += du[k] * I[j][k];
+                m01[j] += dv[k] * I[j][k];
+            }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
-    const float angle = drfe_fast_atan2((float)m01, (float)m10);
-    /* steered BRIEF on the blurred level */
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < DESC_KPW; j++) {
+            m10[j] += __shfl_xor(m10[j], o);
+            m01[j] += __shfl_xor(m01[j], o);
+        }
+    /* steered BRIEF on the blurred level: lane owns bit `lane` of each of the four 64-bit words */
+    uint32_t pat[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pat[r] = reinterpret_cast<const uint32_t*>(pattern)[r * 64 + lane];
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    float a, b;
-    drfe_sincos(angle * factorPI, &b, &a);
-    const uint8_t* cb = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)yi * L.blurPitch + xi;
-    uint8_t* drow = desc + ((size_t)slot * maxKp + g) * 32;
-    int t0[4], t1[4];
+    float angle[DESC_KPW], cosA[DESC_KPW], sinA[DESC_KPW];
+    {   /* fastAtan2 and the float64 sin/cos once per wave: lane j evaluates keypoint j, the results are broadcast */
+        int my01 = 0, my10 = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {                 /* lane owns bit `lane` of each of the four 64-bit words */
-        const uint32_t q4 = reinterpret_cast<const uint32_t*>(pattern)[r * 64 + lane];
-        const float x0 = (float)(int8_t)(q4 & 0xFF), y0 = (float)(int8_t)((q4 >> 8) & 0xFF);
-        const float x1 = (float)(int8_t)((q4 >> 16) & 0xFF), y1 = (float)(int8_t)(q4 >> 24);
-        t0[r] = cb[drfe_round_half_even(x0 * b + y0 * a) * L.blurPitch + drfe_round_half_even(x0 * a - y0 * b)];
-        t1[r] = cb[drfe_round_half_even(x1 * b + y1 * a) * L.blurPitch + drfe_round_half_even(x1 * a - y1 * b)];
-    }
-    unsigned long long w4[4];
+        for (int j = 0; j < DESC_KPW; j++)
+            if (lane == j) { my01 = m01[j]; my10 = m10[j]; }
+        const float ang = drfe_fast_atan2((float)my01, (float)my10);
+        float sn, cs;
+        drfe_sincos(ang * factorPI, &sn, &cs);
 #pragma unroll
-    for (int r = 0; r < 4; r++) w4[r] = __ballot(t0[r] < t1[r]);
-    if (lane == 0) {
-        reinterpret_cast<ulonglong2*>(drow)[0] = make_ulonglong2(w4[0], w4[1]);
-        reinterpret_cast<ulonglong2*>(drow)[1] = make_ulonglong2(w4[2], w4[3]);
+        for (int j = 0; j < DESC_KPW; j++) {
+            angle[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang), j));
+            cosA[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cs), j));
+            sinA[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sn), j));
+        }
     }
-    if (lane == 0) {
-        drfe_keypoint kp;
-        kp.x = (float)xi; kp.y = (float)yi;
-        if (level != 0) { kp.x *= L.scale; kp.y *= L.scale; }
-        kp.size = L.kpSize;
-        kp.angle = angle;
-        kp.response = (float)resp;
-        kp.octave = level;
-        kp.class_id = -1;
-        kps[(size_t)slot * maxKp + g] = kp;
+    int t0[DESC_KPW][4], t1[DESC_KPW][4];
+#pragma unroll
+    for (int j = 0; j < DESC_KPW; j++) {
+        const float a = cosA[j], b = sinA[j];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t q4 = pat[r];
+            const float x0 = (float)(int8_t)(q4 & 0xFF), y0 = (float)(int8_t)((q4 >> 8) & 0xFF);
+            const float x1 = (float)(int8_t)((q4 >> 16) & 0xFF), y1 = (float)(int8_t)(q4 >> 24);
+            t0[j][r] = cB[j][(uint32_t)((drfe_round_half_even(x0 * b + y0 * a) + DESC_REACH) * pitchB[j] + (drfe_round_half_even(x0 * a - y0 * b) + DESC_REACH))];
+            t1[j][r] = cB[j][(uint32_t)((drfe_round_half_even(x1 * b + y1 * a) + DESC_REACH) * pitchB[j] + (drfe_round_half_even(x1 * a - y1 * b) + DESC_REACH))];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DESC_KPW; j++) {
+        unsigned long long w4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) w4[r] = __ballot(t0[j][r] < t1[j][r]);
+        if (lane == 0 && live[j]) {
+            const int g = g0 + j;
+            uint8_t* drow = desc + ((size_t)slot * maxKp + g) * 32;
+            reinterpret_cast<ulonglong2*>(drow)[0] = make_ulonglong2(w4[0], w4[1]);
+            reinterpret_cast<ulonglong2*>(drow)[1] = make_ulonglong2(w4[2], w4[3]);
+            const DevLevel& L = G->lv[level[j]];
+            drfe_keypoint kp;
+            kp.x = (float)xi[j]; kp.y = (float)yi[j];
+            if (level[j] != 0) { kp.x *= L.scale; kp.y *= L.scale; }
+            kp.size = L.kpSize;
+            kp.angle = angle[j];
+            kp.response = (float)resp[j];
+            kp.octave = level[j];
+            kp.class_id = -1;
+            kps[(size_t)slot * maxKp + g] = kp;
+        }
     }
 }
 
@@ -1004,7 +1061,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_BLUR, s);
 
     prof_begin(c, DRFE_STAGE_DESC, s);
-    hipLaunchKernelGGL(k_orient_desc, dim3((c->maxKp + 3) / 4, nframes), dim3(256), 0, s, c->d_geom, c->d_pyr,
+    hipLaunchKernelGGL(k_orient_desc, dim3((c->maxKp + 4 * DESC_KPW - 1) / (4 * DESC_KPW), nframes), dim3(256), 0, s, c->d_geom, c->d_pyr,
                        c->d_blur, c->d_sel, c->d_selCount, c->d_pattern, c->d_disc, c->discCount, c->d_kps,
                        c->d_desc, c->d_kpCount, c->maxKp);
     prof_end(c, DRFE_STAGE_DESC, s);
