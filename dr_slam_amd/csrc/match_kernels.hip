@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
                                                            int* __restrict__ status)
 {
     const MatchPair P = pairs[blockIdx.y];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   /* wave-uniform for the compiler */
     const int qi = blockIdx.x * (256 / WAVE) + wv;
     const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
     if (qi >= nQ) return;                       /* wave-uniform */
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
                                                      int* __restrict__ bestIdx, int* __restrict__ bestDist)
 {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    const int i = blockIdx.x * (256 / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (i >= n) return;                          /* wave-uniform */
     int outIdx = -1, outDist = 256;
     bool ok = !(skip && skip[i]);
