@@ -164,6 +164,6 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
 #define DRFE_RESIZE_LDS_WD 88     /* dwords per source row of the k_pyr_resize_lds tile (256 output columns * 1.25 + slack) */
 #define DRFE_RESIZE_LDS_ROWS 24   /* source rows of the tile (16 output rows * 1.25 + slack) */
 #define DRFE_BLUR_TW 64
-#define DRFE_BLUR_TH 32
+#define DRFE_BLUR_TH 128
 
 #endif

@@ -776,7 +776,6 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
     const int maxWord = L.pyrPitch - 4;
     const int c0 = min(x0 + cg * 4 + 16, maxWord), c1 = min(x0 + cg * 4 + 20, maxWord), c2 = min(x0 + cg * 4 + 24, maxWord);
     const int lastRow = L.h + 2 * DRFE_EDGE - 1;
-#pragma unroll
     for (int r = rr; r < BLUR_ROWS; r += 16) {
         const uint8_t* row = img + (size_t)min(y0 + r - 3 + DRFE_EDGE, lastRow) * L.pyrPitch;
         const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + c0);
@@ -797,7 +796,6 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
             make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
     }
     __syncthreads();
-#pragma unroll
     for (int r = rr; r < DRFE_BLUR_TH; r += 16) {
         const int y = y0 + r;
         if (y >= L.h) continue;
