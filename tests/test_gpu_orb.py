@@ -179,3 +179,20 @@ def test_other_feature_budgets(frames_room, oracle_mod, nfeatures):
         assert abs(len(kps) - nfeatures) < 0.1 * nfeatures
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("w,h", [(641, 479), (752, 480), (333, 250)])
+def test_odd_image_sizes(oracle_mod, w, h):
+    """Widths that are not multiples of 16 (unaligned source rows take the byte-wise border kernel, EuRoC's 752x480,
+    a small image with few cells per level): same keypoints and descriptors as the oracle."""
+    from dr_slam_amd import lib, synth
+    g = synth.noise_frame(7, w, h)
+    c = lib.Context(nfeatures=600, max_width=w, max_height=h)
+    try:
+        kps, desc = c.orb_extract(g)
+        okps, odesc = oracle_mod.OrbOracle(600, 1.2, 8, 20, 7)(g)
+        _same_kps(kps, okps)
+        assert np.array_equal(desc, odesc)
+        assert len(kps) > 300
+    finally:
+        c.close()
