@@ -63,17 +63,18 @@ __global__ __launch_bounds__(256) void k_pyr_level0_wide(const DevLevel L, int p
         if (y0 + r < bh) *reinterpret_cast<uint4*>(dst + (size_t)(y0 + r) * L.pyrPitch) = out[r];
 }
 
-/* columns [0, leftEnd) and [rightBegin, pitch) of every bordered row; thread = one dword of one row */
+/* columns [0, leftEnd) and [rightBegin, pitch) of every bordered row; thread = one dword, items numbered densely
+ * (row-major over the nLeft + nRight dwords of a row) so that no lane idles */
 __global__ __launch_bounds__(256) void k_pyr_level0_edge(const DevLevel L, int pyrSlotBytes, const uint8_t* __restrict__ gray,
                                                          size_t frameStride, size_t rowStride, int leftEnd, int rightBegin,
                                                          uint8_t* __restrict__ pyr)
 {
-    const int slot = blockIdx.z;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int nLeft = leftEnd / 4, nRight = (L.pyrPitch - rightBegin) / 4;
-    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int slot = blockIdx.y;
+    const int nLeft = leftEnd / 4, nPer = nLeft + (L.pyrPitch - rightBegin) / 4;
     const int bw = L.w + 2 * DRFE_EDGE, bh = L.h + 2 * DRFE_EDGE;
-    if (y >= bh || t >= nLeft + nRight) return;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= nPer * bh) return;
+    const int y = item / nPer, t = item - y * nPer;
     const int x4 = t < nLeft ? t * 4 : rightBegin + (t - nLeft) * 4;
     const uint8_t* src = gray + (size_t)slot * frameStride + (size_t)reflect101(y - DRFE_EDGE, L.h) * rowStride;
     uint32_t o = 0;
@@ -1009,7 +1010,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
             leftEnd = x16First; rightBegin = x16Last + 16;
         }
         const int nEdge = leftEnd / 4 + (L.pyrPitch - rightBegin) / 4;      /* leftEnd == rightBegin == 0: every dword */
-        hipLaunchKernelGGL(k_pyr_level0_edge, dim3((nEdge + 63) / 64, (bh + 3) / 4, nframes), dim3(64, 4), 0, s, L,
+        hipLaunchKernelGGL(k_pyr_level0_edge, dim3((nEdge * bh + 255) / 256, nframes), dim3(256), 0, s, L,
                            g.pyrSlotBytes, d_gray, frameStride, rowStride, leftEnd, rightBegin, c->d_pyr);
     }
     for (int l = 1; l < nl; l++) {
