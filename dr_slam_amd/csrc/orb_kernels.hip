@@ -168,24 +168,32 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
     const int tid = threadIdx.y * 64 + threadIdx.x;
     uint8_t* base = pyr + (size_t)slot * pyrSlotBytes;
     const ResizeTap wx = taps[L.xwinOff + blockIdx.x], wy = taps[L.ywinOff + blockIdx.y];
+    /* this thread's taps first: their latency overlaps the tile fill instead of following the barrier */
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int bh = L.h + 2 * DRFE_EDGE;
+    const bool active = y0 < bh && x4 < L.pyrPitch;
+    const int yT = active ? y0 : 0, xT = active ? x4 : 0;
+    const uint4 tya = *reinterpret_cast<const uint4*>(taps + L.ytabOff + yT);
+    const uint4 tyb = *reinterpret_cast<const uint4*>(taps + L.ytabOff + yT + 2);
+    const uint4 ta = *reinterpret_cast<const uint4*>(taps + L.xtabOff + xT);
+    const uint4 tb = *reinterpret_cast<const uint4*>(taps + L.xtabOff + xT + 2);
     const int ws = ((int)wx.s0 + DRFE_EDGE) & ~3;                       /* bordered source column of tile byte 0 */
     const int wd = (((int)wx.s1 + DRFE_EDGE - ws) >> 2) + 1;           /* dwords per tile row */
     const int nr = (int)wy.s1 - (int)wy.s0 + 1;
     const uint8_t* srcw = base + P.pyrOff + (size_t)((int)wy.s0 + DRFE_EDGE) * P.pyrPitch + ws;
-    for (int e = tid; e < nr * wd; e += 256) {
-        const int r = e / wd, cdw = e - r * wd;
-        *reinterpret_cast<uint32_t*>(&tile[r * RES_PITCH + cdw * 4]) =
-            *reinterpret_cast<const uint32_t*>(srcw + (size_t)r * P.pyrPitch + cdw * 4);
+    {   /* (row, dword) of element tid + 256 k, carried incrementally: one division per thread, none in the loop */
+        const int q256 = 256 / wd, r256 = 256 - q256 * wd;
+        int r = tid / wd, cdw = tid - r * wd;
+        while (r < nr) {
+            *reinterpret_cast<uint32_t*>(&tile[r * RES_PITCH + cdw * 4]) =
+                *reinterpret_cast<const uint32_t*>(srcw + (size_t)r * P.pyrPitch + cdw * 4);
+            r += q256; cdw += r256;
+            if (cdw >= wd) { cdw -= wd; r++; }
+        }
     }
     __syncthreads();
-    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int bh = L.h + 2 * DRFE_EDGE;
-    if (y0 >= bh || x4 >= L.pyrPitch) return;
-    const uint4 tya = *reinterpret_cast<const uint4*>(taps + L.ytabOff + y0);
-    const uint4 tyb = *reinterpret_cast<const uint4*>(taps + L.ytabOff + y0 + 2);
-    const uint4 ta = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4);
-    const uint4 tb = *reinterpret_cast<const uint4*>(taps + L.xtabOff + x4 + 2);
+    if (!active) return;
     const uint32_t syp[PYR_ROWS] = {tya.x, tya.z, tyb.x, tyb.z}, wyp[PYR_ROWS] = {tya.y, tya.w, tyb.y, tyb.w};
     const uint32_t sp[4] = {ta.x, ta.z, tb.x, tb.z}, wp[4] = {ta.y, ta.w, tb.y, tb.w};
     int o0[4], o1[4], w0[4], w1[4];
