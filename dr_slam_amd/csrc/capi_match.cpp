@@ -465,6 +465,31 @@ int drfe_lsd_search_by_descriptor(drfe_ctx* c, const uint8_t* desc_q, int n_q, c
     return DRFE_OK;
 }
 
+/* LSDmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs), src/LSDmatcher.cpp:334-367 */
+int drfe_lsd_search_for_triangulation(drfe_ctx* c, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2,
+                                      const uint8_t* has1, const uint8_t* has2, int32_t* out12, int* nmatches)
+{
+    if (!c || !desc1 || !desc2 || !has1 || !has2 || !out12 || !nmatches || n1 < 0 || n2 < 0) return DRFE_ERR_INVALID;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) out12[i] = -1;
+    if (n1 == 0 || n2 < 2) return DRFE_OK;
+    std::vector<int32_t> idx((size_t)n1 * 2), dist((size_t)n1 * 2);
+    int rc = drfe_match_bf_knn(c, desc1, n1, desc2, n2, 2, idx.data(), dist.data());
+    if (rc != DRFE_OK) return rc;
+    double nnTh, nn12Th;
+    line_mad(dist.data(), n1, &nnTh, &nn12Th);
+    const double th = nn12Th * 0.1;
+    int n = 0;
+    for (int q = 0; q < n1; q++) {
+        const int t = idx[2 * q];
+        if (has1[q] || has2[t]) continue;
+        const double gap = (float)dist[2 * q + 1] - (float)dist[2 * q];
+        if (gap > th) { out12[q] = t; n++; }
+    }
+    *nmatches = n;
+    return DRFE_OK;
+}
+
 int drfe_match_bf_knn(drfe_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, int32_t* dist)
 {
     if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || k < 1 || k > 2) return DRFE_ERR_INVALID;

@@ -24,6 +24,9 @@
 #include <map>
 #include <new>
 #include <queue>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <thread>
 #include <string>
@@ -270,6 +273,24 @@ template <class Ctx> static int run_blocks(Ctx* c, const uint16_t* depth, int w,
     return DRFE_OK;
 }
 
+struct AhcTrace {
+    bool on = std::getenv("DRFE_TRACE_PLANES") != nullptr;
+    std::chrono::steady_clock::time_point t[8];
+    int n = 0;
+    AhcTrace() { if (on) t[n++] = std::chrono::steady_clock::now(); }
+    void mark(int) { if (on && n < 8) t[n++] = std::chrono::steady_clock::now(); }
+    ~AhcTrace()
+    {
+        if (!on) return;
+        t[n++] = std::chrono::steady_clock::now();
+        static const char* names[] = {"device blocks + copies", "initGraph", "ahCluster", "findBlockMembership", "floodFill", "re-merge + relabel"};
+        std::fprintf(stderr, "drfe_planes_ahc:");
+        for (int i = 0; i + 1 < n && i < 6; i++)
+            std::fprintf(stderr, " %s %.2f ms;", names[i], std::chrono::duration<double, std::milli>(t[i + 1] - t[i]).count());
+        std::fprintf(stderr, "\n");
+    }
+};
+
 /* PlaneDetection::readDepthImage + runPlaneDetection for one frame on one lane (Ctx: drfe_ctx or PlaneLane) */
 template <class Ctx>
 static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
@@ -279,10 +300,12 @@ static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t s
     if (!n_planes) return DRFE_ERR_INVALID;
     *n_planes = 0;
     std::vector<AhcBlockRec> blocks;
+    AhcTrace tr;               /* DRFE_TRACE_PLANES=1: wall time per stage on stderr */
     int rc = run_blocks(c, depth, w, h, stride, K4, depth_factor, blocks);
     if (rc != DRFE_OK) return rc;
     const int Nw = w / AHC_WIN, Nh = h / AHC_WIN, NB = Nw * Nh;
 
+    tr.mark(0);
     /* --- initGraph: nodes + 4-neighbour edges with the reference's skip pattern ------------------- */
     Graph g;
     g.dsParent.resize(NB); g.dsSize.assign(NB, 1);
@@ -329,10 +352,12 @@ static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t s
             } else --i;
         }
 
+    tr.mark(1);
     /* --- ahCluster ------------------------------------------------------------------------------- */
     std::vector<int> extracted;
     cluster(g, q, extracted);
 
+    tr.mark(2);
     /* --- refineDetails: findBlockMembership ------------------------------------------------------- */
     std::map<int, int> rid2plid;
     for (int plid = 0; plid < (int)extracted.size(); ++plid) rid2plid.insert({g.nodes[extracted[plid]].rid, plid});
@@ -380,6 +405,7 @@ static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t s
             }
         }
 
+    tr.mark(3);
     /* --- floodFill -------------------------------------------------------------------------------- */
     DepthView dv = {depth, stride, w, h, (double)depth_factor, (double)K4[0], (double)K4[1], (double)K4[2], (double)K4[3]};
     {
@@ -425,6 +451,7 @@ static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t s
         }
     }
 
+    tr.mark(4);
     /* --- re-merge the grown planes and relabel ----------------------------------------------------- */
     std::vector<int> old;
     old.swap(extracted);

@@ -34,7 +34,7 @@ SYMBOLS = (
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_batch", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
-    "drfe_search_by_bow", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_by_projection_last",
+    "drfe_search_by_bow", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map",
 )
 
@@ -131,6 +131,7 @@ def load() -> C.CDLL:
     L.drfe_frame_set_distortion.argtypes = [vp, vp, vp, i32]
     L.drfe_frame_image_bounds.argtypes = [vp, vp, i32, i32, i32, vp]
     L.drfe_frame_download_keys_un.argtypes = [vp, i32, vp, i32]
+    L.drfe_lsd_search_for_triangulation.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, C.POINTER(i32)]
     L.drfe_lsd_search_by_descriptor.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.POINTER(i32)]
     L.drfe_lsd_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, i32, C.c_float, vp, vp,
                                                      C.POINTER(i32)]
@@ -422,6 +423,17 @@ class Context:
         self._chk(self.L.drfe_lsd_search_by_projection_map(self.h, _p(tl), len(tl), _p(kl), _p(cd), len(kl), C.c_float(th),
                                                            C.c_float(nnratio), _p(obs), _p(out), C.byref(n)),
                   "drfe_lsd_search_by_projection_map")
+        return n.value, out
+
+    def lsd_search_for_triangulation(self, desc1, desc2, has1, has2):
+        d1 = np.ascontiguousarray(desc1, np.uint8)
+        d2 = np.ascontiguousarray(desc2, np.uint8)
+        out = np.full(len(d1), -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_lsd_search_for_triangulation(self.h, _p(d1), len(d1), _p(d2), len(d2),
+                                                           _p(np.ascontiguousarray(has1, np.uint8)),
+                                                           _p(np.ascontiguousarray(has2, np.uint8)), _p(out), C.byref(n)),
+                  "drfe_lsd_search_for_triangulation")
         return n.value, out
 
     def bf_knn(self, Q, T, k):

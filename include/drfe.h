@@ -193,6 +193,11 @@ int drfe_match_orb_points(drfe_ctx* ctx, int cur_slot, int last_slot, const int3
  *           out[query idx] = train idx, out has n_q entries. */
 int drfe_lsd_search_by_descriptor(drfe_ctx* ctx, const uint8_t* desc_q, int n_q, const uint8_t* desc_t, int n_t,
                                   const uint8_t* has_line, int mode, int32_t* out, int* nmatches);
+/* LSDmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs), src/LSDmatcher.cpp:334-367 (LocalMapping::
+ * CreateNewMapLines): knnMatch(k = 2) on the device, accept the nearest neighbour when the NN2-NN1 gap exceeds a tenth
+ * of its MAD and neither line has a MapLine (has1 / has2).  out12[line of KF1] = line of KF2 or -1. */
+int drfe_lsd_search_for_triangulation(drfe_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2,
+                                      const uint8_t* has1, const uint8_t* has2, int32_t* out12, int* nmatches);
 
 /* cv::BFMatcher(NORM_HAMMING).match / knnMatch(k<=2) on 256-bit descriptors (src/ORBmatcher.cc:1346,
  * src/LSDmatcher.cpp:222,254): ascending distance, ties -> lower train index. idx/dist: nq x k. */

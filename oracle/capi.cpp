@@ -456,6 +456,11 @@ int orc_lsd_search_by_descriptor(const uint8_t* dk, int nk, const uint8_t* has, 
 {
     return lsd_search_by_descriptor(dk, nk, has, df, nf, out);
 }
+int orc_lsd_search_for_triangulation(const uint8_t* d1, int n1, const uint8_t* d2, int n2, const uint8_t* h1, const uint8_t* h2,
+                                     int32_t* out)
+{
+    return lsd_search_for_triangulation(d1, n1, d2, n2, h1, h2, out);
+}
 int orc_lsd_search_by_gap(const uint8_t* dq, int nq, const uint8_t* dt, int nt, const uint8_t* has, int32_t* out)
 {
     return lsd_search_by_gap(dq, nq, dt, nt, has, out);

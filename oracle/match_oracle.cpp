@@ -377,6 +377,28 @@ int lsd_search_by_gap(const uint8_t* descQ, int nQ, const uint8_t* descT, int nT
 }
 
 
+/* LSDmatcher::SearchForTriangulation, :334-367 (LocalMapping::CreateNewMapLines): knnMatch(k = 2), accept the nearest
+ * neighbour when the NN2-NN1 gap exceeds a TENTH of its MAD and neither line has a MapLine yet */
+int lsd_search_for_triangulation(const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, const uint8_t* has1,
+                                 const uint8_t* has2, int32_t* out12)
+{
+    for (int i = 0; i < n1; i++) out12[i] = -1;
+    if (n1 == 0 || n2 < 2) return 0;
+    std::vector<int32_t> idx((size_t)n1 * 2), dist((size_t)n1 * 2);
+    bf_knn_hamming(desc1, n1, desc2, n2, 2, idx.data(), dist.data());
+    double nn_th, nn12_th;
+    line_descriptor_mad(dist.data(), n1, nn_th, nn12_th);
+    nn12_th = nn12_th * 0.1;
+    int nmatches = 0;
+    for (int q = 0; q < n1; q++) {            /* sorted by queryIdx: knnMatch already returns that order */
+        const int t = idx[2 * q];
+        if (has1[q] || has2[t]) continue;
+        const double gap = (float)dist[2 * q + 1] - (float)dist[2 * q];
+        if (gap > nn12_th) { out12[q] = t; nmatches++; }
+    }
+    return nmatches;
+}
+
 /* ---------------------------------------------------------------------------------------------------- */
 /* LSDmatcher::SearchByProjection (row a-15)                                                            */
 

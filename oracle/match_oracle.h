@@ -59,6 +59,9 @@ void line_descriptor_mad(const int32_t* dist, int nq, double& nn_mad, double& nn
 int lsd_search_by_descriptor(const uint8_t* descKF, int nKF, const uint8_t* kfHasLine, const uint8_t* descF, int nF,
                              int32_t* out);
 int lsd_search_by_gap(const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, const uint8_t* trainHasLine, int32_t* out);
+/* LSDmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs), src/LSDmatcher.cpp:334-367: out12[q] = t or -1 */
+int lsd_search_for_triangulation(const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, const uint8_t* has1,
+                                 const uint8_t* has2, int32_t* out12);
 
 
 /* --- LSDmatcher::SearchByProjection, src/LSDmatcher.cpp:20-211 --------------- */

@@ -414,6 +414,16 @@ def lsd_search_by_descriptor(desc_kf, kf_has_line, desc_f):
     return n, out
 
 
+def lsd_search_for_triangulation(desc1, desc2, has1, has2):
+    """LSDmatcher::SearchForTriangulation(pKF1, pKF2, pairs): out12[line of KF1] = line of KF2 or -1."""
+    d1, d2 = _c(desc1, np.uint8), _c(desc2, np.uint8)
+    out = np.full(len(d1), -1, np.int32)
+    L = lib()
+    L.orc_lsd_search_for_triangulation.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.orc_lsd_search_for_triangulation(_p(d1), len(d1), _p(d2), len(d2), _p(_c(has1, np.uint8)), _p(_c(has2, np.uint8)), _p(out))
+    return n, out
+
+
 def lsd_search_by_gap(desc_q, desc_t, train_has_line=None):
     """LSDmatcher::SearchByDescriptor(pKF, pKF2, ...) / SerachForInitialize: out[query line] = train line or -1."""
     dq, dt = _c(desc_q, np.uint8), _c(desc_t, np.uint8)

@@ -63,6 +63,13 @@ def test_lsd_matcher(ctx, oracle_mod, frames_room):
     assert n_g == n_o and np.array_equal(m_g, m_o) and n_o >= 5
     n_g, m_g = ctx.lsd_search_by_descriptor(a["desc"], b["desc"][:1], None, mode=0)     # knn k=2 needs 2 train rows
     assert n_g == 0 and (m_g == -1).all()
+    # LSDmatcher::SearchForTriangulation (LocalMapping::CreateNewMapLines): tenth-of-MAD gap, neither side has a MapLine
+    h1 = (rng.random(len(a["desc"])) < 0.3).astype(np.uint8)
+    h2 = (rng.random(len(b["desc"])) < 0.3).astype(np.uint8)
+    n_o, m_o = oracle_mod.lsd_search_for_triangulation(a["desc"], b["desc"], h1, h2)
+    n_g, m_g = ctx.lsd_search_for_triangulation(a["desc"], b["desc"], h1, h2)
+    assert n_g == n_o and np.array_equal(m_g, m_o) and n_o >= 5
+    assert (m_o[h1 == 1] == -1).all() and not h2[m_o[m_o >= 0]].any()
 
 
 def test_flat_image_has_no_lines(ctx, oracle_mod):
