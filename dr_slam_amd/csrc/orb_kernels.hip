@@ -1042,7 +1042,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
         /* levels are ordered large -> small: [0, nBig) take the 512-thread variant, the rest the 256-thread one */
         int nBig = 0, capMax = 0;
         for (int l = 0; l < nl; l++) {
-            if (g.lv[l].w * g.lv[l].h > (1 << 17) || g.lv[l].kpCap > 256) nBig = l + 1;
+            if (g.lv[l].w * g.lv[l].h > 160000 || g.lv[l].kpCap > 256) nBig = l + 1;
             capMax = std::max(capMax, g.lv[l].kpCap);
         }
         /* a batch whose workgroups are all resident at once (2 x 512 threads per CU) finishes soonest as ONE
