@@ -227,6 +227,20 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
                 if (hi - lo + 1 > DRFE_RESIZE_LDS_ROWS) L.resizeLds = 0;
                 taps->push_back(ResizeTap{(uint16_t)lo, (uint16_t)hi, 0, 0});
             }
+            if (!L.resizeLds) {
+                /* the register-only kernel reads a 12-byte window per four output columns: make sure it is enough */
+                for (int x = 0; x + 3 < L.pyrPitch; x += 4) {
+                    int lo = 1 << 30, hi = -1;
+                    for (int k = 0; k < 4; k++) {
+                        const ResizeTap& t = (*taps)[L.xtabOff + x + k];
+                        lo = std::min(lo, (int)t.s0); hi = std::max(hi, (int)t.s1);
+                    }
+                    if (hi + DRFE_EDGE - ((lo + DRFE_EDGE) & ~3) > 11) {
+                        c->err = "pyramid scale factor too large for the resize kernels (supported: up to 2.0)";
+                        return DRFE_ERR_INVALID;
+                    }
+                }
+            }
         }
     }
     g->pyrSlotBytes = pyrOff;

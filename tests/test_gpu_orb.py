@@ -196,3 +196,23 @@ def test_odd_image_sizes(oracle_mod, w, h):
         assert len(kps) > 300
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("scale,nlevels", [(1.5, 5), (2.0, 3), (1.1, 12)])
+def test_other_scale_factors(frames_room, oracle_mod, scale, nlevels):
+    """Scale factors whose source windows no longer fit the LDS tile take the register-only resize kernel; 1.1 has twelve
+    closely spaced levels.  Pyramid bytes and keypoints / descriptors equal the oracle."""
+    from dr_slam_amd import lib
+    g = frames_room[2][0]
+    c = lib.Context(nfeatures=700, scale_factor=scale, nlevels=nlevels)
+    try:
+        kps, desc = c.orb_extract(g)
+        o = oracle_mod.OrbOracle(700, scale, nlevels, 20, 7)
+        okps, odesc = o(g)
+        _same_kps(kps, okps)
+        assert np.array_equal(desc, odesc)
+        assert len(kps) > 400
+    finally:
+        c.close()
+    with pytest.raises(lib.DrfeError):
+        lib.Context(scale_factor=3.0, nlevels=3).orb_extract(g)
