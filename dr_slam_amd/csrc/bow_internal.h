@@ -28,8 +28,9 @@ struct BowState {
 hipError_t drfe_launch_bow_transform(drfe_ctx* c, const VocDev& voc, int levelsup, int nframes, int* d_word,
                                      double* d_weight, int* d_nid, hipStream_t s);
 hipError_t drfe_launch_bow_match(drfe_ctx* c, int kfSlot, int fSlot, const BowGroup* d_groups, int ngroups,
-                                 const int* d_kfIdx, const int* d_fIdx, const int* d_kfMP, float nnratio, int checkOri,
-                                 int* d_match, int* d_counters, int* d_hist, uint16_t* d_entries, hipStream_t s);
+                                 const int* d_kfIdx, const int* d_fIdx, const int* d_kfMP, const int* d_fMP, int thLow,
+                                 float nnratio, int checkOri, int* d_match, int* d_counters, int* d_hist,
+                                 uint16_t* d_entries, hipStream_t s);
 struct TriParams { float F[9]; float ex, ey; float scale[16], sigma2[16]; int onlyStereo, checkOri; };
 hipError_t drfe_launch_bow_triangulation(drfe_ctx* c, int slot1, int slot2, const BowGroup* d_groups, int ngroups,
                                          const int* d_idx1, const int* d_idx2, const int* d_mp1, const int* d_mp2,

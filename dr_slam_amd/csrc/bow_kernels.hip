@@ -60,7 +60,9 @@ __global__ __launch_bounds__(WAVE) void k_bow_match_groups(const BowGroup* __res
                                                            const uint8_t* __restrict__ descF,
                                                            const drfe_keypoint* __restrict__ kpKF,
                                                            const drfe_keypoint* __restrict__ kpF,
-                                                           const int* __restrict__ kfMP, float nnratio, int checkOri,
+                                                           const int* __restrict__ kfMP, const int* __restrict__ fMP /* NULL: frame */,
+                                                           int thLow /* 50: <=, 49: the keyframe overload's < 50 */,
+                                                           float nnratio, int checkOri,
                                                            int* __restrict__ match /* per F keypoint, -1 init */,
                                                            int* __restrict__ counters /* [0]=nmatches [1]=entries */,
                                                            int* __restrict__ hist /* 30 */,
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(WAVE) void k_bow_match_groups(const BowGroup* __res
                 const int iF = fIdx[g.fBegin + b];
                 /* claims are written by lane 0 of this very wavefront; agent-scope accesses keep the
                  * vector L1 out of the picture */
-                if (__hip_atomic_load(&match[iF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
+                if (__hip_atomic_load(&match[iF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0 && (!fMP || fMP[iF] >= 0)) {
                     const uint64_t* d = reinterpret_cast<const uint64_t*>(descF + (size_t)iF * 32);
                     const int dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
                     key = ((uint32_t)dist << 16) | (uint32_t)b;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(WAVE) void k_bow_match_groups(const BowGroup* __res
         if (k1 == 0xFFFFFFFFu) continue;
         const int bestDist1 = (int)(k1 >> 16);
         const int bestDist2 = (k2 == 0xFFFFFFFFu) ? 256 : (int)(k2 >> 16);
-        if (bestDist1 <= 50 && (float)bestDist1 < nnratio * (float)bestDist2) {      /* TH_LOW, ratio */
+        if (bestDist1 <= thLow && (float)bestDist1 < nnratio * (float)bestDist2) {   /* TH_LOW, ratio */
             const int iF = fIdx[g.fBegin + (int)(k1 & 0xFFFF)];
             if (lane == 0) {
                 __hip_atomic_store(&match[iF], iKF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -256,14 +258,15 @@ hipError_t drfe_launch_bow_triangulation(drfe_ctx* c, int slot1, int slot2, cons
 }
 
 hipError_t drfe_launch_bow_match(drfe_ctx* c, int kfSlot, int fSlot, const BowGroup* d_groups, int ngroups,
-                                 const int* d_kfIdx, const int* d_fIdx, const int* d_kfMP, float nnratio, int checkOri,
-                                 int* d_match, int* d_counters, int* d_hist, uint16_t* d_entries, hipStream_t s)
+                                 const int* d_kfIdx, const int* d_fIdx, const int* d_kfMP, const int* d_fMP, int thLow,
+                                 float nnratio, int checkOri, int* d_match, int* d_counters, int* d_hist,
+                                 uint16_t* d_entries, hipStream_t s)
 {
     if (ngroups > 0)
         hipLaunchKernelGGL(k_bow_match_groups, dim3(ngroups), dim3(WAVE), 0, s, d_groups, d_kfIdx, d_fIdx,
                            c->d_desc + (size_t)kfSlot * c->maxKp * 32, c->d_desc + (size_t)fSlot * c->maxKp * 32,
-                           c->d_kps + (size_t)kfSlot * c->maxKp, c->d_kps + (size_t)fSlot * c->maxKp, d_kfMP, nnratio,
-                           checkOri, d_match, d_counters, d_hist, d_entries);
+                           c->d_kps + (size_t)kfSlot * c->maxKp, c->d_kps + (size_t)fSlot * c->maxKp, d_kfMP, d_fMP, thLow,
+                           nnratio, checkOri, d_match, d_counters, d_hist, d_entries);
     if (checkOri)
         hipLaunchKernelGGL(k_bow_rot_filter, dim3(1), dim3(256), 0, s, d_match, d_counters, d_hist, d_entries);
     return hipGetLastError();

@@ -124,8 +124,9 @@ int drfe_bow_download(drfe_ctx* c, int slot, int32_t* word, double* weight, int3
     return DRFE_OK;
 }
 
-int drfe_search_by_bow(drfe_ctx* c, int kf_slot, int f_slot, const int32_t* kf_mp, int n_kf, float nnratio, int check_ori,
-                       int32_t* f_match, int n_f, int* nmatches)
+/* shared body of SearchByBoW(KF, Frame) (f_mp == NULL, `<= TH_LOW`) and SearchByBoW(KF1, KF2) (f_mp given, `< TH_LOW`) */
+static int search_by_bow_impl(drfe_ctx* c, int kf_slot, int f_slot, const int32_t* kf_mp, int n_kf, const int32_t* f_mp,
+                              int th_low, float nnratio, int check_ori, int32_t* f_match, int n_f, int* nmatches)
 {
     if (!c || !kf_mp || !f_match || !nmatches) return DRFE_ERR_INVALID;
     BowState* b = c->bow;
@@ -172,15 +173,32 @@ int drfe_search_by_bow(drfe_ctx* c, int kf_slot, int f_slot, const int32_t* kf_m
         HIPCHK(c, hipMemcpy(b->d_fIdx, fIdx.data(), fIdx.size() * 4, hipMemcpyHostToDevice));
     }
     HIPCHK(c, hipMemcpy(b->d_kfMP, kf_mp, sizeof(int) * n_kf, hipMemcpyHostToDevice));
+    if (f_mp) HIPCHK(c, hipMemcpy(b->d_fMP, f_mp, sizeof(int) * n_f, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(b->d_match, 0xFF, sizeof(int) * n_f, s));
     HIPCHK(c, hipMemsetAsync(b->d_counters, 0, 8, s));
     HIPCHK(c, hipMemsetAsync(b->d_hist, 0, 30 * 4, s));
     HIPCHK(c, drfe_launch_bow_match(c, kf_slot, f_slot, b->d_groups, (int)groups.size(), b->d_kfIdx, b->d_fIdx, b->d_kfMP,
-                                    nnratio, check_ori, b->d_match, b->d_counters, b->d_hist, b->d_entries, s));
+                                    f_mp ? b->d_fMP : nullptr, th_low, nnratio, check_ori, b->d_match, b->d_counters, b->d_hist,
+                                    b->d_entries, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipMemcpy(f_match, b->d_match, sizeof(int) * n_f, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(nmatches, b->d_counters, sizeof(int), hipMemcpyDeviceToHost));
     return DRFE_OK;
+}
+
+int drfe_search_by_bow(drfe_ctx* c, int kf_slot, int f_slot, const int32_t* kf_mp, int n_kf, float nnratio, int check_ori,
+                       int32_t* f_match, int n_f, int* nmatches)
+{
+    return search_by_bow_impl(c, kf_slot, f_slot, kf_mp, n_kf, nullptr, 50, nnratio, check_ori, f_match, n_f, nmatches);
+}
+
+/* ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12), src/ORBmatcher.cc:526-660 (LoopClosing::ComputeSim3): both sides need
+ * a good map point, `bestDist1 < TH_LOW`.  match2[keypoint of KF2] = keypoint of KF1 (vpMatches12[idx1] = vpMapPoints2[idx2]). */
+int drfe_search_by_bow_kf(drfe_ctx* c, int slot1, int slot2, const int32_t* mp1, int n1, const int32_t* mp2, int n2,
+                          float nnratio, int check_ori, int32_t* match2, int* nmatches)
+{
+    if (!mp2) return DRFE_ERR_INVALID;
+    return search_by_bow_impl(c, slot1, slot2, mp1, n1, mp2, 49, nnratio, check_ori, match2, n2, nmatches);
 }
 
 

@@ -34,7 +34,7 @@ SYMBOLS = (
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_batch", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
-    "drfe_search_by_bow", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
+    "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map",
 )
 
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     L.drfe_search_by_projection_map.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_match_bf_knn.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.drfe_match_orb_points.argtypes = [vp, i32, i32, vp, vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_search_by_bow_kf.argtypes = [vp, i32, i32, vp, i32, vp, i32, C.c_float, i32, vp, C.POINTER(i32)]
     L.drfe_search_for_triangulation.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, C.POINTER(i32)]
     L.drfe_planes_ahc_batch.argtypes = [vp, vp, C.c_size_t, i32, i32, C.c_size_t, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32]
     L.drfe_lsd_extract_batch.argtypes = [vp, vp, C.c_size_t, i32, i32, C.c_size_t, i32, i32, vp, vp, vp, i32, vp, vp, i32]
@@ -509,6 +510,16 @@ class Context:
         n = C.c_int()
         self._chk(self.L.drfe_search_by_bow(self.h, kf_slot, f_slot, _p(kf_mp), len(kf_mp), nnratio, int(check_ori),
                                             _p(out), n_f, C.byref(n)), "drfe_search_by_bow")
+        return n.value, out
+
+    def search_by_bow_kf(self, slot1, slot2, mp1, mp2, nnratio, check_ori=True):
+        """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12); returns (nmatches, match2) with match2[i2] = i1 or -1."""
+        mp1 = np.ascontiguousarray(mp1, np.int32)
+        mp2 = np.ascontiguousarray(mp2, np.int32)
+        out = np.full(len(mp2), -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_search_by_bow_kf(self.h, slot1, slot2, _p(mp1), len(mp1), _p(mp2), len(mp2), C.c_float(nnratio),
+                                               int(check_ori), _p(out), C.byref(n)), "drfe_search_by_bow_kf")
         return n.value, out
 
     def search_for_triangulation(self, slot1, slot2, mp1, mp2, F12, Cw1, T2w, cam2, only_stereo=False, check_ori=True):

@@ -330,6 +330,11 @@ int drfe_bow_download(drfe_ctx* ctx, int slot, int32_t* word, double* weight, in
  * matched to frame keypoint j, or -1; *nmatches = return value. */
 int drfe_search_by_bow(drfe_ctx* ctx, int kf_slot, int f_slot, const int32_t* kf_mp, int n_kf, float nnratio,
                        int check_ori, int32_t* f_match, int n_f, int* nmatches);
+/* ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12), src/ORBmatcher.cc:526-660 (LoopClosing::ComputeSim3): the keyframe-
+ * keyframe overload — keypoints of BOTH keyframes need a good map point (mp >= 0) and the test is bestDist1 < TH_LOW.
+ * match2[keypoint of KF2] = keypoint of KF1 or -1, i.e. vpMatches12[match2[i2]] = vpMapPoints2[i2]. */
+int drfe_search_by_bow_kf(drfe_ctx* ctx, int slot1, int slot2, const int32_t* mp1, int n1, const int32_t* mp2, int n2,
+                          float nnratio, int check_ori, int32_t* match2, int* nmatches);
 
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), src/ORBmatcher.cc:661-827 (LocalMapping::
  * CreateNewMapPoints): for every vocabulary node common to both keyframes, match the keypoints of KF1 without a map

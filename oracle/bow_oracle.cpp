@@ -113,7 +113,7 @@ void Vocabulary::transform(const uint8_t* desc, int n, int levelsup, std::map<in
  * kfMP[i] >= 0: pKF has a good (non-bad) map point at keypoint i.  out[f] = KF keypoint index or -1. */
 int search_by_bow(const std::map<int, std::vector<unsigned>>& fvKF, const std::map<int, std::vector<unsigned>>& fvF,
                   const uint8_t* descKF, const float* angleKF, const int32_t* kfMP, const uint8_t* descF,
-                  const float* angleF, int nF, float nnratio, bool checkOri, int32_t* out)
+                  const float* angleF, int nF, float nnratio, bool checkOri, int32_t* out, const int32_t* fMP, bool strictLow)
 {
     const int TH_LOW = 50, HISTO_LENGTH = 30;
     for (int i = 0; i < nF; i++) out[i] = -1;
@@ -134,11 +134,12 @@ int search_by_bow(const std::map<int, std::vector<unsigned>>& fvKF, const std::m
                 for (size_t b = 0; b < iFs.size(); b++) {
                     const unsigned realIdxF = iFs[b];
                     if (out[realIdxF] >= 0) continue;
+                    if (fMP && fMP[realIdxF] < 0) continue;          /* KF-KF overload: !pMP2 || pMP2->isBad() */
                     const int dist = descriptor_distance_swar(dKF, descF + (size_t)realIdxF * 32);
                     if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
                     else if (dist < bestDist2) bestDist2 = dist;
                 }
-                if (bestDist1 <= TH_LOW) {
+                if (strictLow ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) {
                     if ((float)bestDist1 < nnratio * (float)bestDist2) {
                         out[bestIdxF] = (int32_t)realIdxKF;
                         if (checkOri) {

@@ -24,9 +24,13 @@ struct Vocabulary {
                    std::map<int, std::vector<unsigned>>& fv) const;
 };
 
+/* fMP / strictLow select the keyframe-keyframe overload (src/ORBmatcher.cc:526-660, LoopClosing::ComputeSim3): only
+ * keypoints of the second keyframe that HAVE a good map point take part (fMP[i] >= 0) and the distance test is
+ * `bestDist1 < TH_LOW` instead of `<=`. */
 int search_by_bow(const std::map<int, std::vector<unsigned>>& fvKF, const std::map<int, std::vector<unsigned>>& fvF,
                   const uint8_t* descKF, const float* angleKF, const int32_t* kfMP, const uint8_t* descF,
-                  const float* angleF, int nF, float nnratio, bool checkOri, int32_t* out);
+                  const float* angleF, int nF, float nnratio, bool checkOri, int32_t* out, const int32_t* fMP = nullptr,
+                  bool strictLow = false);
 
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), src/ORBmatcher.cc:661-827, with
  * CheckDistEpipolarLine (:141-158).  Per-keypoint inputs of both keyframes: undistorted position (x, y), octave,

@@ -389,6 +389,17 @@ int orc_search_by_bow(const int32_t* nidKF, int nKF, const int32_t* nidF, int nF
     return search_by_bow(fvKF, fvF, descKF, angleKF, kfMP, descF, angleF, nF, nnratio, checkOri != 0, out);
 }
 
+/* ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12): out2[idx2] = idx1 (vpMatches12[idx1] = map point of idx2) */
+int orc_search_by_bow_kf(const int32_t* nid1, int n1, const int32_t* nid2, int n2, const uint8_t* desc1, const float* angle1,
+                         const int32_t* mp1, const uint8_t* desc2, const float* angle2, const int32_t* mp2, float nnratio,
+                         int checkOri, int32_t* out2)
+{
+    std::map<int, std::vector<unsigned>> fv1, fv2;
+    for (int i = 0; i < n1; i++) if (nid1[i] >= 0) fv1[nid1[i]].push_back((unsigned)i);
+    for (int i = 0; i < n2; i++) if (nid2[i] >= 0) fv2[nid2[i]].push_back((unsigned)i);
+    return search_by_bow(fv1, fv2, desc1, angle1, mp1, desc2, angle2, n2, nnratio, checkOri != 0, out2, mp2, true);
+}
+
 /* per keyframe: kp = N x (x, y, angle, uRight) floats, io = N x (octave, mp, nid) ints (nid < 0: stopped word) */
 int orc_search_for_triangulation(const float* kp1, const int32_t* io1, const uint8_t* desc1, int n1, const float* kp2,
                                  const int32_t* io2, const uint8_t* desc2, int n2, const float* F12, float ex, float ey,

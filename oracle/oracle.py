@@ -630,6 +630,20 @@ def search_by_bow(nid_kf, nid_f, desc_kf, angle_kf, kf_mp, desc_f, angle_f, nnra
     return n, out
 
 
+def search_by_bow_kf(nid1, nid2, desc1, angle1, mp1, desc2, angle2, mp2, nnratio, check_ori=True):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12): returns (nmatches, out2) with out2[keypoint of KF2] = keypoint
+    of KF1 or -1 (vpMatches12[idx1] = vpMapPoints2[idx2])."""
+    nid1, nid2 = _c(nid1, np.int32), _c(nid2, np.int32)
+    out = np.full(len(nid2), -1, np.int32)
+    L = lib()
+    L.orc_search_by_bow_kf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    n = L.orc_search_by_bow_kf(_p(nid1), len(nid1), _p(nid2), len(nid2), _p(_c(desc1, np.uint8)), _p(_c(angle1, np.float32)),
+                               _p(_c(mp1, np.int32)), _p(_c(desc2, np.uint8)), _p(_c(angle2, np.float32)), _p(_c(mp2, np.int32)),
+                               float(nnratio), int(check_ori), _p(out))
+    return n, out
+
+
 def search_for_triangulation(kf1, kf2, F12, ex, ey, scale_factors, level_sigma2, only_stereo=False, check_ori=True):
     """ORBmatcher::SearchForTriangulation.  kf = dict(x, y, angle, u_right, octave, mp, nid, desc) per keypoint
     (mp >= 0: has a map point; nid < 0: stopped word).  Returns (nmatches, matches12)."""

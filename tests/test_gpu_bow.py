@@ -64,6 +64,29 @@ def test_search_by_bow(env, oracle_mod):
         assert n_o > 30
 
 
+def test_search_by_bow_keyframes(env, oracle_mod):
+    """ORBmatcher(0.75, true).SearchByBoW(pKF1, pKF2, vpMatches12) — LoopClosing::ComputeSim3's call: map points on both
+    sides, strict `< TH_LOW`."""
+    from dr_slam_amd import vocabulary as V
+    c, frames = env
+    voc = V.make_synthetic(10, 4, seed=5, stop_fraction=0.02)
+    ov = oracle_mod.VocabularyOracle(voc.to_text())
+    voc.upload(c)
+    c.bow_transform_batch(2, 4)
+    rng = np.random.default_rng(3)
+    for s1, s2, ratio, ori in ((0, 1, 0.75, True), (2, 0, 0.9, True), (1, 3, 0.75, False)):
+        (k1, d1), (k2, d2) = frames[s1], frames[s2]
+        mp1 = np.where(rng.random(len(k1)) > 0.3, 1, -1).astype(np.int32)
+        mp2 = np.where(rng.random(len(k2)) > 0.3, 1, -1).astype(np.int32)
+        _, w1, n1 = ov.transform_each(d1, 2)
+        _, w2, n2 = ov.transform_each(d2, 2)
+        no, mo = oracle_mod.search_by_bow_kf(np.where(w1 > 0, n1, -1), np.where(w2 > 0, n2, -1), d1, k1["angle"], mp1, d2,
+                                             k2["angle"], mp2, ratio, ori)
+        ng, mg = c.search_by_bow_kf(s1, s2, mp1, mp2, ratio, ori)
+        assert ng == no and np.array_equal(mg, mo), (s1, s2, ng, no)
+        assert no > 20 and (mo[mp2 < 0] == -1).all()
+
+
 def test_vocabulary_limits(env):
     from dr_slam_amd import lib, vocabulary as V
     c, _ = env
