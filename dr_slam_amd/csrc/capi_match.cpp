@@ -632,8 +632,8 @@ int drfe_frame_is_in_frustum_lines(drfe_ctx* c, const float* Tcw, const drfe_cam
 
 
 /* ---- ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th): search part -------------------------------- */
-int drfe_fuse_search(drfe_ctx* c, int slot, const float* Tcw, const drfe_frustum_point* pts, const uint8_t* descs,
-                     const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist)
+static int fuse_search_impl(drfe_ctx* c, int slot, const float* Tcw, int sim3, const drfe_frustum_point* pts,
+                            const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist)
 {
     if (!c || !Tcw || n < 0 || (n && (!pts || !descs || !best_idx || !best_dist))) return DRFE_ERR_INVALID;
     if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = "fuse_search: slot needs extract + glue first"; return DRFE_ERR_STATE; }
@@ -650,6 +650,7 @@ int drfe_fuse_search(drfe_ctx* c, int slot, const float* Tcw, const drfe_frustum
     std::memcpy(P.T, fp.T, 64);
     std::memcpy(P.Ow, fp.Ow, 12);
     P.bf = cam.bf; P.logScale = fp.logScale; P.th = th; P.nLevels = c->cfg.nlevels;
+    P.sim3 = sim3;
     for (int l = 0; l < c->cfg.nlevels; l++) { P.scale[l] = c->scale[l]; P.invSigma2[l] = c->invSigma2[l]; }
     uint8_t* d = nullptr;
     const size_t oP = 0, oD = (sizeof(drfe_frustum_point) * (size_t)n + 63) & ~(size_t)63, oS = oD + (((size_t)n * 32 + 63) & ~(size_t)63),
@@ -668,6 +669,30 @@ int drfe_fuse_search(drfe_ctx* c, int slot, const float* Tcw, const drfe_frustum
     (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string("fuse_search: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
+}
+
+int drfe_fuse_search(drfe_ctx* c, int slot, const float* Tcw, const drfe_frustum_point* pts, const uint8_t* descs,
+                     const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist)
+{
+    return fuse_search_impl(c, slot, Tcw, 0, pts, descs, skip, n, th, best_idx, best_dist);
+}
+
+/* ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, points, th, vpReplacePoint), src/ORBmatcher.cc:981-1107: Scw decomposed as
+ * at :989-993 (double-accumulated row norm, float scale 1/s through convertTo) */
+int drfe_fuse_search_sim3(drfe_ctx* c, int slot, const float* Scw, const drfe_frustum_point* pts, const uint8_t* descs,
+                          const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!Scw) return DRFE_ERR_INVALID;
+    const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    float T[16];
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) T[r * 4 + k] = Scw[r * 4 + k] * inv;
+        T[r * 4 + 3] = Scw[r * 4 + 3] * inv;
+    }
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    return fuse_search_impl(c, slot, T, 1, pts, descs, skip, n, th, best_idx, best_dist);
 }
 
 } /* extern "C" */

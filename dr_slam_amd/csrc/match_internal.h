@@ -68,7 +68,8 @@ hipError_t drfe_launch_frustum_points(const drfe_frustum_point* d_pts, int n, co
 hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, const FrustumPose& P, const drfe_camera& cam,
                                      drfe_tracked_line* d_out, hipStream_t s);
 
-struct FuseParams { float T[16]; float Ow[3]; float bf, logScale, th; int nLevels; float scale[16], invSigma2[16]; };
+struct FuseParams { float T[16]; float Ow[3]; float bf, logScale, th; int nLevels; float scale[16], invSigma2[16];
+                    int sim3; /* the Scw overload: no chi-square gate, invz = (float)(1.0 / z) */ };
 hipError_t drfe_launch_fuse_search(drfe_ctx* c, int slot, const drfe_frustum_point* d_pts, const uint8_t* d_descs,
                                    const uint8_t* d_skip, int n, const FuseParams& P, const drfe_camera& cam, int* d_bestIdx,
                                    int* d_bestDist, hipStream_t s);

@@ -930,7 +930,7 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
     float Pc[3];
     mat3_mul_add(P.T, p.world, Pc);
     if (Pc[2] < 0.0f) ok = false;
-    const float invz = 1 / Pc[2];
+    const float invz = P.sim3 ? (float)(1.0 / (double)Pc[2]) : 1 / Pc[2];
     const float x = Pc[0] * invz, y = Pc[1] * invz;
     const float u = cam.fx * x + cam.cx, v = cam.fy * y + cam.cy;
     if (!(u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y)) ok = false;
@@ -984,7 +984,8 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
                     bool c = fabsf(dx) < r && fabsf(dy) < r;                /* KeyFrame::GetFeaturesInArea */
                     if (oct < level - 1 || oct > level) c = false;
                     const float ex = u - kx, ey = v - ky;
-                    if (kr >= 0) {
+                    if (P.sim3) {
+                    } else if (kr >= 0) {
                         const float er = ur - kr;
                         const float e2 = ex * ex + ey * ey + er * er;
                         if ((double)(e2 * P.invSigma2[oct & 15]) > 7.8) c = false;

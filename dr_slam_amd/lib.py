@@ -29,7 +29,7 @@ SYMBOLS = (
     "drfe_create", "drfe_destroy", "drfe_last_error", "drfe_version", "drfe_orb_scale_tables",
     "drfe_orb_max_keypoints", "drfe_orb_extract", "drfe_orb_extract_batch", "drfe_orb_download", "drfe_orb_counts",
     "drfe_orb_pyramid_level", "drfe_orb_blurred_level", "drfe_orb_candidates", "drfe_frame_stereo_grid_batch",
-    "drfe_fuse_search", "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
+    "drfe_fuse_search", "drfe_fuse_search_sim3", "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_batch", "drfe_planes_ahc_blocks",
@@ -126,6 +126,7 @@ def load() -> C.CDLL:
     L.drfe_lsd_extract_batch.argtypes = [vp, vp, C.c_size_t, i32, i32, C.c_size_t, i32, i32, vp, vp, vp, i32, vp, vp, i32]
     L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
+    L.drfe_fuse_search_sim3.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.c_float, vp, vp]
     L.drfe_fuse_search.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.c_float, vp, vp]
     L.drfe_frame_is_in_frustum.argtypes = [vp, vp, vp, vp, i32, C.c_float, vp]
     L.drfe_frame_is_in_frustum_lines.argtypes = [vp, vp, vp, vp, i32, C.c_float, vp]
@@ -359,6 +360,18 @@ class Context:
         bd = np.zeros(len(p), np.int32)
         self._chk(self.L.drfe_fuse_search(self.h, slot, _p(T), _p(p), _p(d), _p(sk), len(p), C.c_float(th), _p(bi), _p(bd)),
                   "drfe_fuse_search")
+        return bi, bd
+
+    def fuse_search_sim3(self, slot, Scw, pts, descs, skip, th):
+        """Search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)."""
+        T = np.ascontiguousarray(Scw, np.float32).reshape(16)
+        p = np.ascontiguousarray(pts, FRUSTUM_POINT_DTYPE)
+        d = np.ascontiguousarray(descs, np.uint8)
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+        bi = np.zeros(len(p), np.int32)
+        bd = np.zeros(len(p), np.int32)
+        self._chk(self.L.drfe_fuse_search_sim3(self.h, slot, _p(T), _p(p), _p(d), _p(sk), len(p), C.c_float(th), _p(bi), _p(bd)),
+                  "drfe_fuse_search_sim3")
         return bi, bd
 
     def is_in_frustum_lines(self, Tcw, cam, lines, viewing_cos_limit, out=None):

@@ -307,6 +307,11 @@ int drfe_frame_is_in_frustum_lines(drfe_ctx* ctx, const float* Tcw, const drfe_c
  * (bestDist <= TH_LOW: Replace / AddObservation / AddMapPoint) mutates the map graph and is the caller's loop. */
 int drfe_fuse_search(drfe_ctx* ctx, int slot, const float* Tcw, const drfe_frustum_point* pts, const uint8_t* descs,
                      const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist);
+/* ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, points, th, vpReplacePoint), src/ORBmatcher.cc:981-1107 (LoopClosing::
+ * SearchAndFuse): the same search under a similarity pose — Scw is decomposed as the reference does (:989-993), invz is
+ * 1.0 / z evaluated in double, and there is no chi-square gate. */
+int drfe_fuse_search_sim3(drfe_ctx* ctx, int slot, const float* Scw, const drfe_frustum_point* pts, const uint8_t* descs,
+                          const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and

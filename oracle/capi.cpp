@@ -510,6 +510,14 @@ void orc_fuse_search(void* frame, const float* Tcw, const float* invSigma2, floa
 {
     fuse_search(*(Frame*)frame, Tcw, invSigma2, logScale, nLevels, pts, descs, skip, n, th, bestIdx, bestDist);
 }
+void orc_fuse_search_sim3(void* frame, const float* Scw, const float* invSigma2, float logScale, int nLevels,
+                          const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th,
+                          int32_t* bestIdx, int32_t* bestDist)
+{
+    float Tcw[16];
+    decompose_sim3(Scw, Tcw);
+    fuse_search(*(Frame*)frame, Tcw, invSigma2, logScale, nLevels, pts, descs, skip, n, th, bestIdx, bestDist, true);
+}
 int orc_sizeof_maplinerec() { return (int)sizeof(MapLineRec); }
 int orc_sizeof_trackedlinerec() { return (int)sizeof(TrackedLineRec); }
 

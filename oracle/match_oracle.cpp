@@ -624,12 +624,26 @@ void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logSc
 }
 
 
+/* Scw -> [Rcw | tcw], src/ORBmatcher.cc:989-993: Mat::dot accumulates in double, sqrt in double, stored to float;
+ * Mat / float goes through convertTo with the float scale (float)(1.0 / s) */
+void decompose_sim3(const float Scw[16], float Tcw[16])
+{
+    const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Tcw[r * 4 + c] = Scw[r * 4 + c] * inv;
+        Tcw[r * 4 + 3] = Scw[r * 4 + 3] * inv;
+    }
+    Tcw[12] = Tcw[13] = Tcw[14] = 0.f; Tcw[15] = 1.f;
+}
+
 /* ---------------------------------------------------------------------------------------------------- */
 /* ORBmatcher::Fuse (search part)                                                                       */
 
 void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigma2, float logScaleFactor, int nLevels,
                  const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* bestIdx,
-                 int32_t* bestDist)
+                 int32_t* bestDist, bool sim3)
 {
     float Rcw[9], tcw[3], Ow[3];
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
@@ -642,7 +656,7 @@ void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigm
         float p3Dc[3];
         mat3_mul_add(Rcw, p.world, tcw, p3Dc);
         if (p3Dc[2] < 0.0f) continue;
-        const float invz = 1 / p3Dc[2];
+        const float invz = sim3 ? (float)(1.0 / (double)p3Dc[2]) : 1 / p3Dc[2];     /* `1.0/z` at :1023, `1/z` at :863 */
         const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
         const float u = KF.fx * x + KF.cx, v = KF.fy * y + KF.cy;
         if (!(u >= KF.minX && u < KF.maxX && v >= KF.minY && v < KF.maxY)) continue;     /* KeyFrame::IsInImage */
@@ -663,7 +677,9 @@ void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigm
             const int kpLevel = kp.octave;
             if (kpLevel < level - 1 || kpLevel > level) continue;
             const float ex = u - kp.x, ey = v - kp.y;
-            if (KF.uRight[idx] >= 0) {
+            if (sim3) {
+                /* the Sim3 overload has no reprojection gate */
+            } else if (KF.uRight[idx] >= 0) {
                 const float er = ur - KF.uRight[idx];
                 const float e2 = ex * ex + ey * ey + er * er;
                 if ((double)(e2 * invLevelSigma2[kpLevel]) > 7.8) continue;

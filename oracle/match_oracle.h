@@ -121,7 +121,11 @@ void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logSc
  * the host. */
 void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigma2, float logScaleFactor, int nLevels,
                  const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* bestIdx,
-                 int32_t* bestDist);
+                 int32_t* bestDist, bool sim3 = false);
+/* Fuse(KeyFrame*, cv::Mat Scw, points, th, vpReplacePoint), :981-1107 (LoopClosing::SearchAndFuse): the pose is the
+ * similarity Scw decomposed as in :989-994 (scale = |first row|, Rcw = sRcw / s, tcw = t / s), there is no chi-square
+ * gate, and invz is computed as 1.0 / z in double.  Tcw receives the decomposed [Rcw | tcw]. */
+void decompose_sim3(const float Scw[16], float Tcw[16]);
 
 } // namespace orc
 #endif

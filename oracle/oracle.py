@@ -362,6 +362,20 @@ def fuse_search(kf: "FrameOracle", Tcw, scale_factor, inv_level_sigma2, pts, des
     return bi, bd
 
 
+def fuse_search_sim3(kf: "FrameOracle", Scw, scale_factor, inv_level_sigma2, pts, descs, skip, th):
+    """Search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (similarity pose, no chi-square gate)."""
+    L = lib()
+    p = np.ascontiguousarray(pts, FRUSTUM_POINT_DTYPE)
+    bi = np.zeros(len(p), np.int32)
+    bd = np.zeros(len(p), np.int32)
+    inv = _c(inv_level_sigma2, np.float32)
+    L.orc_fuse_search_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_fuse_search_sim3(kf.h, _p(_c(Scw, np.float32).reshape(16)), _p(inv), logf(np.float32(scale_factor)), len(inv), _p(p),
+                           _p(_c(descs, np.uint8)), _p(_c(skip, np.uint8)), len(p), float(th), _p(bi), _p(bd))
+    return bi, bd
+
+
 def undistort_points(xy, K4, dist):
     """cv::undistortPoints(xy, K, dist, Mat(), K), float32 in/out (N x 2)."""
     xy = _c(xy, np.float32).reshape(-1, 2)

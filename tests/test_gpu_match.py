@@ -288,4 +288,11 @@ def test_fuse_search(setup, oracle_mod):
             assert np.array_equal(bi, obi) and np.array_equal(bd, obd), (kf_slot, src, th)
             found += int(((obi >= 0) & (obd <= 50)).sum())
         assert (obi[skip == 1] == -1).all()
+        # LoopClosing's overload: the pose as a similarity (scale 1.7 here), no chi-square gate
+        Scw = Tcw[kf_slot].copy()
+        Scw[:3, :] *= np.float32(1.7)
+        bi, bd = fe.ctx.fuse_search_sim3(kf_slot, Scw, pts, descs, skip, 4.0)
+        obi, obd = oracle_mod.fuse_search_sim3(oframes[kf_slot], Scw, 1.2, inv_sigma2, pts, descs, skip, 4.0)
+        assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+        assert ((obi >= 0) & (obd <= 50)).sum() > 100
     assert found > 500
