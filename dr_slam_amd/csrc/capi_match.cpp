@@ -4,6 +4,7 @@
 #include "../../include/drfe_math.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -633,7 +634,8 @@ int drfe_frame_is_in_frustum_lines(drfe_ctx* c, const float* Tcw, const drfe_cam
 
 /* ---- ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th): search part -------------------------------- */
 static int fuse_search_impl(drfe_ctx* c, int slot, const float* Tcw, int sim3, const drfe_frustum_point* pts,
-                            const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist)
+                            const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist,
+                            const float* sR2 = nullptr, const float* t2 = nullptr)
 {
     if (!c || !Tcw || n < 0 || (n && (!pts || !descs || !best_idx || !best_dist))) return DRFE_ERR_INVALID;
     if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = "fuse_search: slot needs extract + glue first"; return DRFE_ERR_STATE; }
@@ -651,6 +653,7 @@ static int fuse_search_impl(drfe_ctx* c, int slot, const float* Tcw, int sim3, c
     std::memcpy(P.Ow, fp.Ow, 12);
     P.bf = cam.bf; P.logScale = fp.logScale; P.th = th; P.nLevels = c->cfg.nlevels;
     P.sim3 = sim3;
+    if (sR2) { std::memcpy(P.sR2, sR2, 36); std::memcpy(P.t2, t2, 12); }
     for (int l = 0; l < c->cfg.nlevels; l++) { P.scale[l] = c->scale[l]; P.invSigma2[l] = c->invSigma2[l]; }
     uint8_t* d = nullptr;
     const size_t oP = 0, oD = (sizeof(drfe_frustum_point) * (size_t)n + 63) & ~(size_t)63, oS = oD + (((size_t)n * 32 + 63) & ~(size_t)63),
@@ -693,6 +696,136 @@ int drfe_fuse_search_sim3(drfe_ctx* c, int slot, const float* Scw, const drfe_fr
     }
     T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
     return fuse_search_impl(c, slot, T, 1, pts, descs, skip, n, th, best_idx, best_dist);
+}
+
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1106-1330 */
+int drfe_search_by_sim3(drfe_ctx* c, int slot1, int slot2, const float* T1w, const float* T2w, float s12, const float* R12,
+                        const float* t12, const drfe_frustum_point* pts1, const uint8_t* descs1, const uint8_t* skip1, int n1,
+                        const drfe_frustum_point* pts2, const uint8_t* descs2, const uint8_t* skip2, int n2, float th,
+                        int32_t* matches12, int* n_found)
+{
+    if (!c || !T1w || !T2w || !R12 || !t12 || !skip1 || !skip2 || !matches12 || !n_found || n1 < 0 || n2 < 0) return DRFE_ERR_INVALID;
+    *n_found = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return DRFE_OK;
+    /* sR12 = s12*R12, sR21 = (1.0/s12)*R12.t(), t21 = -sR21*t12 (:1121-1123) as cv::Mat evaluates them */
+    float sR12[9], sR21[9], t21[3];
+    const float a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) { sR12[r * 3 + k] = R12[r * 3 + k] * s12; sR21[r * 3 + k] = R12[k * 3 + r] * a21; }
+    for (int r = 0; r < 3; r++) {
+        const float d = sR21[r * 3] * t12[0] + sR21[r * 3 + 1] * t12[1] + sR21[r * 3 + 2] * t12[2];
+        t21[r] = (float)((double)d * -1.0);
+    }
+    std::vector<int32_t> m1(n1), d1(n1), m2(n2), d2(n2);
+    int rc = fuse_search_impl(c, slot2, T1w, 2, pts1, descs1, skip1, n1, th, m1.data(), d1.data(), sR21, t21);
+    if (rc != DRFE_OK) return rc;
+    rc = fuse_search_impl(c, slot1, T2w, 2, pts2, descs2, skip2, n2, th, m2.data(), d2.data(), sR12, t12);
+    if (rc != DRFE_OK) return rc;
+    int found = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int idx2 = (m1[i1] >= 0 && d1[i1] <= 100) ? m1[i1] : -1;                /* TH_HIGH */
+        if (idx2 < 0 || idx2 >= n2) continue;
+        const int idx1 = (m2[idx2] >= 0 && d2[idx2] <= 100) ? m2[idx2] : -1;
+        if (idx1 == i1) { matches12[i1] = idx2; found++; }
+    }
+    *n_found = found;
+    return DRFE_OK;
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:294-407.
+ * The loop over points is sequential in the reference (a keypoint claimed by an earlier point stops being a candidate), so
+ * the device lists, per point, its FUSE_LIST_K best candidates within TH_LOW among the keypoints free on entry, in the
+ * reference's comparison order; the host then walks the points in order and takes the first listed candidate that is
+ * still free.  A point whose list ran out while the device counted more candidates than it listed is asked again, alone,
+ * against the current claims (the device search, not a host one). */
+int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const drfe_frustum_point* pts, const uint8_t* descs,
+                                 const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th, int32_t* new_match,
+                                 int* n_matches)
+{
+    if (!c || !Scw || !matched || !new_match || !n_matches || n < 0 || n_kp < 0 || (n && (!pts || !descs))) return DRFE_ERR_INVALID;
+    if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = "search_by_projection_kf: slot needs extract + glue first"; return DRFE_ERR_STATE; }
+    if (c->cfg.nlevels > 16) { c->err = "search_by_projection_kf: more than 16 pyramid levels"; return DRFE_ERR_INVALID; }
+    *n_matches = 0;
+    for (int k = 0; k < n_kp; k++) new_match[k] = -1;
+    if (n == 0 || n_kp == 0) return DRFE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int slotCount = 0;
+    HIPCHK(c, hipMemcpy(&slotCount, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_kp != slotCount) { c->err = "search_by_projection_kf: n_kp is not the slot's keypoint count"; return DRFE_ERR_INVALID; }
+    const double dd = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)std::sqrt(dd);
+    const float inv = (float)(1.0 / (double)scw);
+    float T[16];
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) T[r * 4 + k] = Scw[r * 4 + k] * inv;
+        T[r * 4 + 3] = Scw[r * 4 + 3] * inv;
+    }
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    const drfe_camera cam = c->cam;
+    FrustumPose fp;
+    frustum_pose(c, T, &cam, 0.f, &fp);
+    FuseParams P;
+    std::memset(&P, 0, sizeof(P));
+    std::memcpy(P.T, fp.T, 64);
+    std::memcpy(P.Ow, fp.Ow, 12);
+    P.bf = cam.bf; P.logScale = fp.logScale; P.th = th; P.nLevels = c->cfg.nlevels;
+    P.sim3 = 3; P.listTh = 50;                                                          /* TH_LOW */
+    for (int l = 0; l < c->cfg.nlevels; l++) { P.scale[l] = c->scale[l]; P.invSigma2[l] = c->invSigma2[l]; }
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t oP = 0, oD = up(sizeof(drfe_frustum_point) * (size_t)n), oS = oD + up((size_t)n * 32), oT = oS + up((size_t)n),
+                 oI = oT + up((size_t)n_kp), oB = oI + up(sizeof(int) * (size_t)n), oC = oB + up(sizeof(int) * (size_t)n),
+                 oL = oC + up(sizeof(int) * (size_t)n), total = oL + sizeof(int2) * (size_t)n * FUSE_LIST_K;
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, total));
+    hipStream_t s = c->stream;
+    std::vector<uint8_t> taken(matched, matched + n_kp);
+    std::vector<int2> list((size_t)n * FUSE_LIST_K);
+    std::vector<int> count(n);
+    auto P_ = [&](size_t o) { return d + o; };
+    hipError_t e = hipMemcpyAsync(P_(oP), pts, sizeof(drfe_frustum_point) * (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(P_(oD), descs, (size_t)n * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && skip) e = hipMemcpyAsync(P_(oS), skip, (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(P_(oT), taken.data(), (size_t)n_kp, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = drfe_launch_fuse_search(c, slot, reinterpret_cast<const drfe_frustum_point*>(P_(oP)), P_(oD), skip ? P_(oS) : nullptr, n, P, cam,
+                                    reinterpret_cast<int*>(P_(oI)), reinterpret_cast<int*>(P_(oB)), s, P_(oT),
+                                    reinterpret_cast<int2*>(P_(oL)), reinterpret_cast<int*>(P_(oC)));
+    if (e == hipSuccess) e = hipMemcpyAsync(list.data(), P_(oL), sizeof(int2) * list.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(count.data(), P_(oC), sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int nm = 0;
+    /* DRFE_TEST_LIST_K=1..FUSE_LIST_K shortens the lists the host trusts so that tests reach the ask-again path */
+    int listK = FUSE_LIST_K;
+    if (const char* ev = std::getenv("DRFE_TEST_LIST_K")) { const int v = std::atoi(ev); if (v >= 1 && v < FUSE_LIST_K) listK = v; }
+    for (int i = 0; i < n && e == hipSuccess; i++) {
+        const int2* L = &list[(size_t)i * FUSE_LIST_K];
+        /* entries the list really holds in order: all of them up to listK unless more than 64 candidates folded */
+        const int held = count[i] > 64 ? 1 : (count[i] < listK ? count[i] : listK);
+        int pick = -1;
+        for (int r = 0; r < held; r++)
+            if (!taken[L[r].x]) { pick = L[r].x; break; }
+        if (pick < 0 && count[i] > held) {
+            /* every listed candidate was claimed and there were more: search this point again with today's claims */
+            int one[2] = {-1, 256};
+            e = hipMemcpyAsync(P_(oT), taken.data(), (size_t)n_kp, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess)
+                e = drfe_launch_fuse_search(c, slot, reinterpret_cast<const drfe_frustum_point*>(P_(oP)) + i, P_(oD) + (size_t)i * 32,
+                                            skip ? P_(oS) + i : nullptr, 1, P, cam, reinterpret_cast<int*>(P_(oI)),
+                                            reinterpret_cast<int*>(P_(oB)), s, P_(oT), nullptr, nullptr);
+            if (e == hipSuccess) e = hipMemcpyAsync(&one[0], P_(oI), sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(&one[1], P_(oB), sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess && one[0] >= 0 && one[1] <= 50) pick = one[0];
+        }
+        if (pick >= 0) { taken[pick] = 1; new_match[pick] = i; nm++; }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("search_by_projection_kf: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    *n_matches = nm;
+    return DRFE_OK;
 }
 
 } /* extern "C" */

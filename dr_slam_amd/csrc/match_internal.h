@@ -69,10 +69,21 @@ hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, co
                                      drfe_tracked_line* d_out, hipStream_t s);
 
 struct FuseParams { float T[16]; float Ow[3]; float bf, logScale, th; int nLevels; float scale[16], invSigma2[16];
-                    int sim3; /* the Scw overload: no chi-square gate, invz = (float)(1.0 / z) */ };
+                    int sim3; /* 1: the Scw overload of Fuse: no chi-square gate, invz = (float)(1.0 / z);
+                                 2: one direction of SearchBySim3: the point goes through T and then (sR2 | t2), the
+                                    distance is the norm of the result, no viewing-cone test, no chi-square gate;
+                                 3: SearchByProjection(KeyFrame*, Scw, ...): float 1/z, viewing cone kept, no chi-square
+                                    gate; keypoints with taken[idx] != 0 are not candidates and the FUSE_LIST_K best
+                                    candidates within listTh are listed in (distance, visit order) */
+                    float sR2[9], t2[3];
+                    int listTh; };
+#define FUSE_LIST_K 8
+/* d_taken / d_list / d_listCount are the mode-3 extras (nullptr otherwise): taken[keypoint], list[n][FUSE_LIST_K] =
+ * (keypoint, distance), listCount[n] = how many candidates were within listTh (may exceed what the list holds) */
 hipError_t drfe_launch_fuse_search(drfe_ctx* c, int slot, const drfe_frustum_point* d_pts, const uint8_t* d_descs,
                                    const uint8_t* d_skip, int n, const FuseParams& P, const drfe_camera& cam, int* d_bestIdx,
-                                   int* d_bestDist, hipStream_t s);
+                                   int* d_bestDist, hipStream_t s, const uint8_t* d_taken = nullptr, int2* d_list = nullptr,
+                                   int* d_listCount = nullptr);
 
 MatchBuffers* drfe_match_buffers(drfe_ctx* c);   /* lazily allocated, owned by the context */
 void drfe_match_buffers_free(drfe_ctx* c);

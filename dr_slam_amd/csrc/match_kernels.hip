@@ -919,27 +919,42 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
                                                      const uint8_t* __restrict__ skip, int n, FuseParams P, drfe_camera cam,
                                                      float invW, float invH, const int* __restrict__ gridOff,
                                                      const uint4* __restrict__ cellKp, const uint4* __restrict__ cellDesc,
-                                                     int* __restrict__ bestIdx, int* __restrict__ bestDist)
+                                                     int* __restrict__ bestIdx, int* __restrict__ bestDist,
+                                                     const uint8_t* __restrict__ taken, int2* __restrict__ list,
+                                                     int* __restrict__ listCount)
 {
+    __shared__ uint32_t sKey[256 / WAVE][WAVE];
+    __shared__ uint32_t sIdx[256 / WAVE][WAVE];
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (256 / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = blockIdx.x * (256 / WAVE) + w;
     if (i >= n) return;                          /* wave-uniform */
     int outIdx = -1, outDist = 256;
+    int nListed = 0;                             /* candidates within listTh, wave-uniform */
+    if (list) sKey[w][lane] = 0xFFFFFFFFu;
     bool ok = !(skip && skip[i]);
     const drfe_frustum_point p = pts[i];
     float Pc[3];
     mat3_mul_add(P.T, p.world, Pc);
+    if (P.sim3 == 2) {                                      /* p3Dc2 = sR21 * p3Dc1 + t21 */
+        const float q[3] = {Pc[0], Pc[1], Pc[2]};
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float d = P.sR2[r * 3] * q[0] + P.sR2[r * 3 + 1] * q[1] + P.sR2[r * 3 + 2] * q[2];
+            Pc[r] = d + P.t2[r];
+        }
+    }
     if (Pc[2] < 0.0f) ok = false;
-    const float invz = P.sim3 ? (float)(1.0 / (double)Pc[2]) : 1 / Pc[2];
+    const float invz = (P.sim3 == 1 || P.sim3 == 2) ? (float)(1.0 / (double)Pc[2]) : 1 / Pc[2];
     const float x = Pc[0] * invz, y = Pc[1] * invz;
     const float u = cam.fx * x + cam.cx, v = cam.fy * y + cam.cy;
     if (!(u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y)) ok = false;
     const float ur = u - P.bf * invz;
     const float maxDistance = 1.2f * p.max_distance, minDistance = 0.8f * p.min_distance;
     const float PO[3] = {p.world[0] - P.Ow[0], p.world[1] - P.Ow[1], p.world[2] - P.Ow[2]};
-    const float dist3D = norm3_f(PO);
+    const float dist3D = P.sim3 == 2 ? norm3_f(Pc) : norm3_f(PO);
     if (dist3D < minDistance || dist3D > maxDistance) ok = false;
-    if (dot3_d(PO, p.normal) < 0.5 * (double)dist3D) ok = false;
+    if (P.sim3 != 2 && dot3_d(PO, p.normal) < 0.5 * (double)dist3D) ok = false;
     if (ok) {
         const float ratio = p.max_distance / dist3D;
         int level = (int)ceilf(drfe_logf(ratio) / P.logScale);
@@ -970,6 +985,7 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
             uint32_t myKey = 0xFFFFFFFFu, myIdx = 0;
             for (int s0 = 0; s0 < T; s0 += WAVE) {
                 const int sq = s0 + lane;
+                uint32_t lKey = 0xFFFFFFFFu, lIdx = 0;
                 int base = __builtin_amdgcn_readfirstlane(runB);
                 for (int j = 0; j + 1 < ncol; j++) {
                     const int inclJ = __builtin_amdgcn_readlane(incl, j), nextB = __builtin_amdgcn_readlane(runB, j + 1);
@@ -993,13 +1009,26 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
                         const float e2 = ex * ex + ey * ey;
                         if ((double)(e2 * P.invSigma2[oct & 15]) > 5.99) c = false;
                     }
+                    if (c && taken && taken[k4.w & 0xFFFFFF]) c = false;    /* vpMatched[idx] */
                     if (c) {
                         const uint4 da = cellDesc[2 * pp], db = cellDesc[2 * pp + 1];
                         const int dist = __popcll(q0 ^ ((uint64_t)da.x | ((uint64_t)da.y << 32))) + __popcll(q1 ^ ((uint64_t)da.z | ((uint64_t)da.w << 32))) +
                                          __popcll(q2 ^ ((uint64_t)db.x | ((uint64_t)db.y << 32))) + __popcll(q3 ^ ((uint64_t)db.z | ((uint64_t)db.w << 32)));
                         const uint32_t key = ((uint32_t)dist << 22) | (uint32_t)min(sq, (1 << 22) - 1);
                         if (key < myKey) { myKey = key; myIdx = k4.w & 0xFFFFFF; }
+                        if (dist <= P.listTh) { lKey = key; lIdx = k4.w & 0xFFFFFF; }
                     }
+                }
+                if (list) {
+                    /* append this step's candidates within listTh: slot = running count + rank in the ballot, folded
+                     * onto the 64 slots with a minimum (a fold only happens past 64 such candidates; the overall
+                     * minimum survives it and listCount tells the host the list is incomplete) */
+                    const unsigned long long bal = __ballot(lKey != 0xFFFFFFFFu);
+                    if (lKey != 0xFFFFFFFFu) {
+                        const int slot = (nListed + __popcll(bal & ((1ull << lane) - 1))) & 63;
+                        if (lKey < sKey[w][slot]) { sKey[w][slot] = lKey; sIdx[w][slot] = lIdx; }
+                    }
+                    nListed += __popcll(bal);
                 }
             }
             const uint32_t mn = wave_min_u32(myKey);
@@ -1011,16 +1040,32 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
         }
     }
     if (lane == 0) { bestIdx[i] = outIdx; bestDist[i] = outDist; }
+    if (list) {
+        /* the FUSE_LIST_K smallest keys of the 64 slots, in order (same-wave LDS traffic: no barrier needed) */
+        uint32_t k = sKey[w][lane];
+        const uint32_t id = sIdx[w][lane];
+        for (int r = 0; r < FUSE_LIST_K; r++) {
+            const uint32_t mn = wave_min_u32(k);
+            int2 e = make_int2(-1, 256);
+            if (mn != 0xFFFFFFFFu) {
+                const int src = __ffsll((long long)__ballot(k == mn)) - 1;
+                e = make_int2(__shfl((int)id, src), (int)(mn >> 22));
+                if (lane == src) k = 0xFFFFFFFFu;
+            }
+            if (lane == 0) list[(size_t)i * FUSE_LIST_K + r] = e;
+        }
+        if (lane == 0) listCount[i] = nListed;
+    }
 }
 
 hipError_t drfe_launch_fuse_search(drfe_ctx* c, int slot, const drfe_frustum_point* d_pts, const uint8_t* d_descs,
                                    const uint8_t* d_skip, int n, const FuseParams& P, const drfe_camera& cam, int* d_bestIdx,
-                                   int* d_bestDist, hipStream_t s)
+                                   int* d_bestDist, hipStream_t s, const uint8_t* d_taken, int2* d_list, int* d_listCount)
 {
     const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
     const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
     hipLaunchKernelGGL(k_fuse_search, dim3((n + 3) / 4), dim3(256), 0, s, d_pts, d_descs, d_skip, n, P, cam, invW, invH,
                        c->d_gridOff + (size_t)slot * (DRFE_GRID_CELLS + 1), c->d_cellKp + (size_t)slot * c->maxKp,
-                       c->d_cellDesc + (size_t)slot * c->maxKp * 2, d_bestIdx, d_bestDist);
+                       c->d_cellDesc + (size_t)slot * c->maxKp * 2, d_bestIdx, d_bestDist, d_taken, d_list, d_listCount);
     return hipGetLastError();
 }

@@ -313,6 +313,28 @@ int drfe_fuse_search(drfe_ctx* ctx, int slot, const float* Tcw, const drfe_frust
 int drfe_fuse_search_sim3(drfe_ctx* ctx, int slot, const float* Scw, const drfe_frustum_point* pts, const uint8_t* descs,
                           const uint8_t* skip, int n, float th, int32_t* best_idx, int32_t* best_dist);
 
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1106-1330 (LoopClosing::ComputeSim3):
+ * both keyframes are slots with extract + glue done; pts / descs / skip are per KEYPOINT of the keyframe (skip[i] = no good
+ * map point there or already matched, :1131-1142).  Every remaining map point of KF1 is carried into KF2 by
+ * (sR21, t21) — and those of KF2 into KF1 by (sR12, t12) — and searched in a th * scale[level] window (octave
+ * level-1..level, distance <= TH_HIGH, first minimum) on the device; a pair is kept when both directions agree.
+ * matches12[i1] = keypoint of KF2 or -1 (vpMatches12[i1] = vpMapPoints2[matches12[i1]]); *n_found = the return value. */
+int drfe_search_by_sim3(drfe_ctx* ctx, int slot1, int slot2, const float* T1w, const float* T2w, float s12, const float* R12,
+                        const float* t12, const drfe_frustum_point* pts1, const uint8_t* descs1, const uint8_t* skip1, int n1,
+                        const drfe_frustum_point* pts2, const uint8_t* descs2, const uint8_t* skip2, int n2, float th,
+                        int32_t* matches12, int* n_found);
+
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched,
+ * int th), src/ORBmatcher.cc:294-407 (LoopClosing::ComputeSim3, th = 10): the n candidate map points are projected with
+ * the similarity and matched, IN ORDER, to the slot's keypoints that have no match yet: matched[k] != 0 means
+ * vpMatched[k] != NULL on entry (n_kp = the slot's keypoint count), skip[i] != 0 means the point is bad or already in
+ * vpMatched (:321).  new_match[k] = the point this call assigned to keypoint k (vpMatched[k] = vpPoints[new_match[k]]) or
+ * -1; *n_matches = the return value.  Windows, octave gate and Hamming distances run on the device, the first-come
+ * claim order is replayed on the host from the device's per-point candidate lists. */
+int drfe_search_by_projection_kf(drfe_ctx* ctx, int slot, const float* Scw, const drfe_frustum_point* pts, const uint8_t* descs,
+                                 const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th, int32_t* new_match,
+                                 int* n_matches);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */

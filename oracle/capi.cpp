@@ -510,6 +510,18 @@ void orc_fuse_search(void* frame, const float* Tcw, const float* invSigma2, floa
 {
     fuse_search(*(Frame*)frame, Tcw, invSigma2, logScale, nLevels, pts, descs, skip, n, th, bestIdx, bestDist);
 }
+int orc_search_by_projection_kf(void* kf, const float* Scw, float logScale, int nLevels, const FrustumPointRec* pts,
+                                const uint8_t* descs, const uint8_t* skip, int n, const uint8_t* matched, float th, int32_t* newMatch)
+{
+    return search_by_projection_kf(*(Frame*)kf, Scw, logScale, nLevels, pts, descs, skip, n, matched, th, newMatch);
+}
+int orc_search_by_sim3(void* kf1, void* kf2, const float* T1w, const float* T2w, float s12, const float* R12, const float* t12,
+                       float logScale, int nLevels, const FrustumPointRec* pts1, const uint8_t* descs1, const uint8_t* skip1,
+                       const FrustumPointRec* pts2, const uint8_t* descs2, const uint8_t* skip2, float th, int32_t* out12)
+{
+    return search_by_sim3(*(Frame*)kf1, *(Frame*)kf2, T1w, T2w, s12, R12, t12, logScale, nLevels, pts1, descs1, skip1, pts2,
+                          descs2, skip2, th, out12);
+}
 void orc_fuse_search_sim3(void* frame, const float* Scw, const float* invSigma2, float logScale, int nLevels,
                           const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th,
                           int32_t* bestIdx, int32_t* bestDist)

@@ -9,6 +9,7 @@
 #include "../include/drfe_math.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 
@@ -691,6 +692,128 @@ void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigm
             if (dist < bestDist[i]) { bestDist[i] = dist; bestIdx[i] = idx; }
         }
     }
+}
+
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* ORBmatcher::SearchBySim3                                                                             */
+
+/* one direction (:1147-1203 / :1206-1262): points of `src` (camera pose Tsw) carried by (sR, t) into `dst` */
+static void sim3_direction(const Frame& dst, const float Tsw[16], const float sR[9], const float t[3], float logScaleFactor,
+                           int nLevels, const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th,
+                           std::vector<int>& match)
+{
+    const int TH_HIGH = 100;
+    float Rsw[9], tsw[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rsw[r * 3 + c] = Tsw[r * 4 + c]; tsw[r] = Tsw[r * 4 + 3]; }
+    match.assign(n, -1);
+    std::vector<int> cand;
+    for (int i = 0; i < n; i++) {
+        if (skip[i]) continue;
+        const FrustumPointRec& p = pts[i];
+        float pa[3], pb[3];
+        mat3_mul_add(Rsw, p.world, tsw, pa);
+        mat3_mul_add(sR, pa, t, pb);
+        if (pb[2] < 0.0) continue;
+        const float invz = (float)(1.0 / (double)pb[2]);
+        const float x = pb[0] * invz, y = pb[1] * invz;
+        const float u = dst.fx * x + dst.cx, v = dst.fy * y + dst.cy;
+        if (!(u >= dst.minX && u < dst.maxX && v >= dst.minY && v < dst.maxY)) continue;
+        const float maxDistance = 1.2f * p.maxDistance, minDistance = 0.8f * p.minDistance;
+        const float dist3D = norm3(pb);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float ratio = p.maxDistance / dist3D;
+        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        if (level < 0) level = 0;
+        else if (level >= nLevels) level = nLevels - 1;
+        const float radius = th * dst.scaleFactors[level];
+        dst.getFeaturesInArea(u, v, radius, -1, -1, cand);
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : cand) {
+            const int oct = dst.keysUn[idx].octave;
+            if (oct < level - 1 || oct > level) continue;
+            const int dist = descriptor_distance_swar(descs + (size_t)i * 32, dst.desc.data() + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) match[i] = bestIdx;
+    }
+}
+
+int search_by_sim3(const Frame& KF1, const Frame& KF2, const float T1w[16], const float T2w[16], float s12,
+                   const float R12[9], const float t12[3], float logScaleFactor, int nLevels, const FrustumPointRec* pts1,
+                   const uint8_t* descs1, const uint8_t* skip1, const FrustumPointRec* pts2, const uint8_t* descs2,
+                   const uint8_t* skip2, float th, int32_t* out12)
+{
+    /* sR12 = s12*R12; sR21 = (1.0/s12)*R12.t(); t21 = -sR21*t12 (:1121-1123): scaling through convertTo with a float
+     * factor, the product through the float small-matrix path with alpha = -1 */
+    float sR12[9], sR21[9], t21[3];
+    const float a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { sR12[r * 3 + c] = R12[r * 3 + c] * s12; sR21[r * 3 + c] = R12[c * 3 + r] * a21; }
+    for (int r = 0; r < 3; r++) {
+        const float d = sR21[r * 3] * t12[0] + sR21[r * 3 + 1] * t12[1] + sR21[r * 3 + 2] * t12[2];
+        t21[r] = (float)((double)d * -1.0);
+    }
+    std::vector<int> m1, m2;
+    sim3_direction(KF2, T1w, sR21, t21, logScaleFactor, nLevels, pts1, descs1, skip1, KF1.N, th, m1);
+    sim3_direction(KF1, T2w, sR12, t12, logScaleFactor, nLevels, pts2, descs2, skip2, KF2.N, th, m2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < KF1.N; i1++) {
+        out12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { out12[i1] = idx2; nFound++; }
+    }
+    return nFound;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, ...)                                                   */
+
+int search_by_projection_kf(const Frame& KF, const float Scw[16], float logScaleFactor, int nLevels, const FrustumPointRec* pts,
+                            const uint8_t* descs, const uint8_t* skip, int n, const uint8_t* matched, float th, int32_t* newMatch)
+{
+    const int TH_LOW = 50;
+    float Tcw[16], Rcw[9], tcw[3], Ow[3];
+    decompose_sim3(Scw, Tcw);                                                      /* :303-307 */
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+    camera_centre(Rcw, tcw, Ow);
+    std::vector<uint8_t> taken(matched, matched + KF.N);
+    for (int k = 0; k < KF.N; k++) newMatch[k] = -1;
+    std::vector<int> cand;
+    int nmatches = 0;
+    for (int i = 0; i < n; i++) {
+        if (skip && skip[i]) continue;                                             /* isBad() || spAlreadyFound.count(pMP) */
+        const FrustumPointRec& p = pts[i];
+        float p3Dc[3];
+        mat3_mul_add(Rcw, p.world, tcw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = 1 / p3Dc[2];                                            /* :335 */
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = KF.fx * x + KF.cx, v = KF.fy * y + KF.cy;
+        if (!(u >= KF.minX && u < KF.maxX && v >= KF.minY && v < KF.maxY)) continue;
+        const float maxDistance = 1.2f * p.maxDistance, minDistance = 0.8f * p.minDistance;
+        const float PO[3] = {p.world[0] - Ow[0], p.world[1] - Ow[1], p.world[2] - Ow[2]};
+        const float dist = norm3(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        if (dot3(PO, p.normal) < 0.5 * (double)dist) continue;
+        const float ratio = p.maxDistance / dist;
+        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        if (level < 0) level = 0;
+        else if (level >= nLevels) level = nLevels - 1;
+        const float radius = th * KF.scaleFactors[level];
+        KF.getFeaturesInArea(u, v, radius, -1, -1, cand);
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : cand) {
+            if (taken[idx]) continue;                                              /* vpMatched[idx] */
+            const int kpLevel = KF.keysUn[idx].octave;
+            if (kpLevel < level - 1 || kpLevel > level) continue;
+            const int d = descriptor_distance_swar(descs + (size_t)i * 32, KF.desc.data() + (size_t)idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { taken[bestIdx] = 1; newMatch[bestIdx] = i; nmatches++; }
+    }
+    return nmatches;
 }
 
 } // namespace orc

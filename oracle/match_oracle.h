@@ -126,6 +126,21 @@ void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigm
  * similarity Scw decomposed as in :989-994 (scale = |first row|, Rcw = sRcw / s, tcw = t / s), there is no chi-square
  * gate, and invz is computed as 1.0 / z in double.  Tcw receives the decomposed [Rcw | tcw]. */
 void decompose_sim3(const float Scw[16], float Tcw[16]);
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:294-407
+ * (LoopClosing::ComputeSim3 after the Sim3 optimisation, th = 10): the points are visited in order, a keypoint whose
+ * vpMatched entry is set (on entry, or by an earlier point of this call) is not a candidate, a point is accepted when its
+ * best remaining candidate is within TH_LOW.  matched[idx] != 0 on entry = vpMatched[idx] != NULL; newMatch[idx] = the
+ * point that claimed keypoint idx in this call or -1.  Returns nmatches. */
+int search_by_projection_kf(const Frame& KF, const float Scw[16], float logScaleFactor, int nLevels, const FrustumPointRec* pts,
+                            const uint8_t* descs, const uint8_t* skip, int n, const uint8_t* matched, float th, int32_t* newMatch);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1106-1330 (LoopClosing::ComputeSim3):
+ * every unmatched map point of KF1 is moved into KF2 with the similarity (and vice versa), searched in a th * scale
+ * window (octave level-1..level, distance <= TH_HIGH, first minimum), and a pair is accepted when both directions agree.
+ * pts / descs / skip are per keypoint of the keyframe (skip = !pMP || isBad() || already matched).  out12[i1] = i2 or -1. */
+int search_by_sim3(const Frame& KF1, const Frame& KF2, const float T1w[16], const float T2w[16], float s12,
+                   const float R12[9], const float t12[3], float logScaleFactor, int nLevels, const FrustumPointRec* pts1,
+                   const uint8_t* descs1, const uint8_t* skip1, const FrustumPointRec* pts2, const uint8_t* descs2,
+                   const uint8_t* skip2, float th, int32_t* out12);
 
 } // namespace orc
 #endif

@@ -362,6 +362,35 @@ def fuse_search(kf: "FrameOracle", Tcw, scale_factor, inv_level_sigma2, pts, des
     return bi, bd
 
 
+def search_by_projection_kf(kf: "FrameOracle", Scw, scale_factor, nlevels, pts, descs, skip, matched, th):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): returns (nmatches, new_match per keypoint)."""
+    L = lib()
+    p = np.ascontiguousarray(pts, FRUSTUM_POINT_DTYPE)
+    m = _c(matched, np.uint8)
+    out = np.full(len(m), -1, np.int32)
+    L.orc_search_by_projection_kf.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_float, C.c_void_p]
+    n = L.orc_search_by_projection_kf(kf.h, _p(_c(Scw, np.float32).reshape(16)), logf(np.float32(scale_factor)), int(nlevels), _p(p),
+                                      _p(_c(descs, np.uint8)), _p(_c(skip, np.uint8)), len(p), _p(m), float(th), _p(out))
+    return n, out
+
+
+def search_by_sim3(kf1: "FrameOracle", kf2: "FrameOracle", T1w, T2w, s12, R12, t12, scale_factor, nlevels, pts1, descs1, skip1,
+                   pts2, descs2, skip2, th):
+    """ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): returns (nFound, out12[i1] = i2 or -1)."""
+    L = lib()
+    p1, p2 = np.ascontiguousarray(pts1, FRUSTUM_POINT_DTYPE), np.ascontiguousarray(pts2, FRUSTUM_POINT_DTYPE)
+    out = np.full(len(p1), -1, np.int32)
+    L.orc_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                     C.c_void_p]
+    n = L.orc_search_by_sim3(kf1.h, kf2.h, _p(_c(T1w, np.float32).reshape(16)), _p(_c(T2w, np.float32).reshape(16)), float(s12),
+                             _p(_c(R12, np.float32).reshape(9)), _p(_c(t12, np.float32).reshape(3)), logf(np.float32(scale_factor)),
+                             int(nlevels), _p(p1), _p(_c(descs1, np.uint8)), _p(_c(skip1, np.uint8)), _p(p2), _p(_c(descs2, np.uint8)),
+                             _p(_c(skip2, np.uint8)), float(th), _p(out))
+    return n, out
+
+
 def fuse_search_sim3(kf: "FrameOracle", Scw, scale_factor, inv_level_sigma2, pts, descs, skip, th):
     """Search part of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (similarity pose, no chi-square gate)."""
     L = lib()

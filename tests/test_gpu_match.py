@@ -296,3 +296,86 @@ def test_fuse_search(setup, oracle_mod):
         assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
         assert ((obi >= 0) & (obd <= 50)).sum() > 100
     assert found > 500
+
+
+def test_search_by_sim3(setup, oracle_mod):
+    """ORBmatcher::SearchBySim3 as LoopClosing::ComputeSim3 calls it (th = 7.5): both directions searched on the device,
+    agreement on the host; the similarity is the true relative pose with a perturbed scale / translation."""
+    from dr_slam_amd import lib
+    fe, oframes, Tcw, Twc, cam = setup
+    o = oracle_mod.OrbOracle()
+    rng = np.random.RandomState(21)
+
+    def kf_points(slot):
+        world, valid = oframes[slot].unproject(Twc[slot])
+        valid = valid.astype(bool)
+        n = len(world)
+        pts = np.zeros(n, lib.FRUSTUM_POINT_DTYPE)
+        pts["world"] = np.where(valid[:, None], world, 0)
+        d = np.linalg.norm(Twc[slot][:3, 3][None, :] - pts["world"], axis=1)
+        lvl = oframes[slot].kps["octave"]
+        pts["max_distance"] = (d * o.scale[lvl] * rng.uniform(0.9, 1.3, n)).astype(np.float32)
+        pts["min_distance"] = (pts["max_distance"] / o.scale[-1] * rng.uniform(0.5, 1.0, n)).astype(np.float32)
+        skip = ((~valid) | (rng.uniform(size=n) < 0.15)).astype(np.uint8)
+        return pts, oframes[slot].desc, skip
+
+    total = 0
+    for s1, s2, s12 in ((0, 1, 1.0), (2, 1, 1.03), (3, 0, 0.97)):
+        p1, d1, k1 = kf_points(s1)
+        p2, d2, k2 = kf_points(s2)
+        T12 = (Tcw[s1].astype(np.float64) @ Twc[s2].astype(np.float64))
+        R12 = T12[:3, :3].astype(np.float32)
+        t12 = (T12[:3, 3] + rng.normal(0, 0.002, 3)).astype(np.float32)
+        for th in (7.5, 3.0):
+            n, m12 = fe.ctx.search_by_sim3(s1, s2, Tcw[s1], Tcw[s2], s12, R12, t12, p1, d1, k1, p2, d2, k2, th)
+            on, om12 = oracle_mod.search_by_sim3(oframes[s1], oframes[s2], Tcw[s1], Tcw[s2], s12, R12, t12, 1.2, 8, p1, d1, k1,
+                                                 p2, d2, k2, th)
+            assert n == on and np.array_equal(m12, om12), (s1, s2, th)
+            assert (m12[k1 == 1] == -1).all()
+            total += n
+    assert total > 300
+    # nothing to search: every point already matched
+    n, m12 = fe.ctx.search_by_sim3(0, 1, Tcw[0], Tcw[1], 1.0, R12, t12, p1[:5], d1[:5], np.ones(5, np.uint8), p2[:5], d2[:5],
+                                   np.ones(5, np.uint8), 7.5)
+    assert n == 0 and (m12 == -1).all()
+
+
+@pytest.mark.parametrize("list_k", [None, "1"])
+def test_search_by_projection_kf(setup, oracle_mod, list_k, monkeypatch):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): first-come claims.  Every point appears three
+    times so later copies must fall back to their next-best free keypoint; with DRFE_TEST_LIST_K=1 the host trusts only
+    the first list entry and the ask-again path carries the rest."""
+    from dr_slam_amd import lib
+    fe, oframes, Tcw, Twc, cam = setup
+    if list_k:
+        monkeypatch.setenv("DRFE_TEST_LIST_K", list_k)
+    o = oracle_mod.OrbOracle()
+    rng = np.random.RandomState(31)
+    total = 0
+    for kf_slot, src, s in ((1, 0, 1.0), (2, 3, 1.4), (0, 2, 0.8)):
+        world, valid = oframes[src].unproject(Twc[src])
+        keep = np.repeat(np.flatnonzero(valid), 3)
+        rng.shuffle(keep[: len(keep) // 2])                 # first half in random order, second half in runs of three
+        n = len(keep)
+        pts = np.zeros(n, lib.FRUSTUM_POINT_DTYPE)
+        pts["world"] = world[keep]
+        v = Twc[src][:3, 3][None, :] - world[keep]
+        d = np.linalg.norm(v, axis=1)
+        pts["normal"] = (-(v / d[:, None])).astype(np.float32)
+        lvl = oframes[src].kps["octave"][keep]
+        pts["max_distance"] = (d * o.scale[lvl] * rng.uniform(0.9, 1.3, n)).astype(np.float32)
+        pts["min_distance"] = (pts["max_distance"] / o.scale[-1] * rng.uniform(0.5, 1.0, n)).astype(np.float32)
+        descs = oframes[src].desc[keep]
+        skip = (rng.uniform(size=n) < 0.1).astype(np.uint8)
+        matched = (rng.uniform(size=oframes[kf_slot].N) < 0.2).astype(np.uint8)
+        Scw = Tcw[kf_slot].copy()
+        Scw[:3, :] *= np.float32(s)
+        for th in (10.0, 25.0):
+            nm, new = fe.ctx.search_by_projection_kf(kf_slot, Scw, pts, descs, skip, matched, th)
+            onm, onew = oracle_mod.search_by_projection_kf(oframes[kf_slot], Scw, 1.2, 8, pts, descs, skip, matched, th)
+            assert nm == onm and np.array_equal(new, onew), (kf_slot, src, th)
+            assert (new[matched == 1] == -1).all() and (new >= 0).sum() == nm
+            total += nm
+    assert total > 600
+    with pytest.raises(lib.DrfeError):
+        fe.ctx.search_by_projection_kf(0, Scw, pts, descs, skip, matched[:-1], 10.0)
