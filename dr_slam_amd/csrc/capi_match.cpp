@@ -104,6 +104,16 @@ static void frustum_pose(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, 
     P->limit = limit;
 }
 
+/* KeyFrame::GetCameraCenter(): Ow = -Rwc*tcw with Rwc = Rcw.t() stored first (KeyFrame::SetPose, src/KeyFrame.cc:153-154), so
+ * the product has no transpose flag and cv::gemm takes its small-matrix float path: float dot, then * alpha = -1 */
+static void camera_centre_kf(const float* Tcw, float Ow[3])
+{
+    for (int i = 0; i < 3; i++) {
+        const float d = Tcw[0 * 4 + i] * Tcw[3] + Tcw[1 * 4 + i] * Tcw[7] + Tcw[2 * 4 + i] * Tcw[11];
+        Ow[i] = (float)((double)d * -1.0);
+    }
+}
+
 template <class In, class Out, class Launch>
 static int frustum_run(drfe_ctx* c, const In* in, int n, Out* out, Launch launch)
 {
@@ -650,7 +660,8 @@ static int fuse_search_impl(drfe_ctx* c, int slot, const float* Tcw, int sim3, c
     FuseParams P;
     std::memset(&P, 0, sizeof(P));
     std::memcpy(P.T, fp.T, 64);
-    std::memcpy(P.Ow, fp.Ow, 12);
+    std::memcpy(P.Ow, fp.Ow, 12);                         /* `-Rcw.t()*tcw` of the Scw overloads: double accumulation */
+    if (sim3 == 0) camera_centre_kf(Tcw, P.Ow);           /* pKF->GetCameraCenter(), src/ORBmatcher.cc:840 */
     P.bf = cam.bf; P.logScale = fp.logScale; P.th = th; P.nLevels = c->cfg.nlevels;
     P.sim3 = sim3;
     if (sR2) { std::memcpy(P.sR2, sR2, 36); std::memcpy(P.t2, t2, 12); }
@@ -825,6 +836,49 @@ int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const 
     (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string("search_by_projection_kf: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     *n_matches = nm;
+    return DRFE_OK;
+}
+
+/* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, th), src/LSDmatcher.cpp:884-1010: the search */
+int drfe_lsd_fuse_search(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
+                         const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,
+                         int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c || !Tcw || !cam || n < 0 || n_kf < 0 || (n && (!lines || !descs || !best_idx || !best_dist)) || (n_kf && (!kf_lines || !kf_desc)))
+        return DRFE_ERR_INVALID;
+    if (n == 0) return DRFE_OK;
+    if (n_kf > 65535) { c->err = "lsd_fuse_search: too many key lines"; return DRFE_ERR_CAPACITY; }
+    HIPCHK(c, hipSetDevice(c->device));
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    FrustumPose P;
+    frustum_pose(c, Tcw, cam, 0.f, &P);
+    camera_centre_kf(Tcw, P.Ow);
+    std::vector<LineCur> lc(n_kf);
+    for (int i = 0; i < n_kf; i++) {
+        lc[i].ptX = kf_lines[i].pt_x; lc[i].ptY = kf_lines[i].pt_y; lc[i].angle = kf_lines[i].angle; lc[i].octave = kf_lines[i].octave;
+    }
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t oL = 0, oD = up(sizeof(drfe_frustum_line) * (size_t)n), oS = oD + up((size_t)n * 32), oK = oS + up((size_t)n),
+                 oKD = oK + up(sizeof(LineCur) * (size_t)n_kf), oI = oKD + up((size_t)n_kf * 32), oB = oI + up(sizeof(int) * (size_t)n),
+                 total = oB + sizeof(int) * (size_t)n;
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, total));
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(d + oL, lines, sizeof(drfe_frustum_line) * (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oD, descs, (size_t)n * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && skip) e = hipMemcpyAsync(d + oS, skip, (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && n_kf) e = hipMemcpyAsync(d + oK, lc.data(), sizeof(LineCur) * (size_t)n_kf, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && n_kf) e = hipMemcpyAsync(d + oKD, kf_desc, (size_t)n_kf * 32, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = drfe_launch_line_fuse_search(reinterpret_cast<const drfe_frustum_line*>(d + oL), d + oD, skip ? d + oS : nullptr, n, P, *cam,
+                                         m->d_scale, th, reinterpret_cast<const LineCur*>(d + oK), d + oKD, n_kf,
+                                         reinterpret_cast<int*>(d + oI), reinterpret_cast<int*>(d + oB), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(best_idx, d + oI, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(best_dist, d + oB, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("lsd_fuse_search: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
 }
 

@@ -68,6 +68,13 @@ hipError_t drfe_launch_frustum_points(const drfe_frustum_point* d_pts, int n, co
 hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, const FrustumPose& P, const drfe_camera& cam,
                                      drfe_tracked_line* d_out, hipStream_t s);
 
+/* LSDmatcher::Fuse search: one wavefront per map line over the keyframe's key lines; bestIdx -2 = predicted level outside
+ * the pyramid */
+hipError_t drfe_launch_line_fuse_search(const drfe_frustum_line* d_lines, const uint8_t* d_descs, const uint8_t* d_skip, int n,
+                                        const FrustumPose& P, const drfe_camera& cam, const float* d_scale, float th,
+                                        const LineCur* d_kf, const uint8_t* d_kfDesc, int nKF, int* d_bestIdx, int* d_bestDist,
+                                        hipStream_t s);
+
 struct FuseParams { float T[16]; float Ow[3]; float bf, logScale, th; int nLevels; float scale[16], invSigma2[16];
                     int sim3; /* 1: the Scw overload of Fuse: no chi-square gate, invz = (float)(1.0 / z);
                                  2: one direction of SearchBySim3: the point goes through T and then (sR2 | t2), the

@@ -909,6 +909,89 @@ hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, co
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* LSDmatcher::Fuse(KeyFrame*, vector<MapLine*>, th): the search (src/LSDmatcher.cpp:901-991)          */
+
+/* One wavefront per map line.  The projection of both end points, the image-bound tests, the distance band, the
+ * 60-degree cone and MapLine::PredictScale are wave-uniform (every lane evaluates them); the lanes then stride over the
+ * keyframe's key lines with KeyFrame::GetLinesInArea's midpoint / slope test and the octave window, and the wave
+ * minimum of distance << 16 | index is the reference's first strict minimum in index order. */
+__global__ __launch_bounds__(256) void k_line_fuse_search(const drfe_frustum_line* __restrict__ lines, const uint8_t* __restrict__ descs,
+                                                          const uint8_t* __restrict__ skip, int n, FrustumPose P, drfe_camera cam,
+                                                          const float* __restrict__ scale, float th,
+                                                          const LineCur* __restrict__ kf, const uint8_t* __restrict__ kfDesc, int nKF,
+                                                          int* __restrict__ bestIdx, int* __restrict__ bestDist)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (256 / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (i >= n) return;                          /* wave-uniform */
+    int outIdx = -1, outDist = 0x7FFFFFFF;
+    bool ok = !(skip && skip[i]);
+    const drfe_frustum_line l = lines[i];
+    const float SP[3] = {(float)l.world[0], (float)l.world[1], (float)l.world[2]};
+    const float EP[3] = {(float)l.world[3], (float)l.world[4], (float)l.world[5]};
+    float SPc[3], EPc[3];
+    mat3_mul_add(P.T, SP, SPc);
+    mat3_mul_add(P.T, EP, EPc);
+    if (SPc[2] < 0.0f || EPc[2] < 0.0f) ok = false;
+    const float invz1 = 1.0f / SPc[2];
+    const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+    if (u1 < cam.min_x || u1 > cam.max_x || v1 < cam.min_y || v1 > cam.max_y) ok = false;
+    const float invz2 = 1.0f / EPc[2];
+    const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+    if (u2 < cam.min_x || u2 > cam.max_x || v2 < cam.min_y || v2 > cam.max_y) ok = false;
+    const float maxDistance = 1.2f * l.max_distance, minDistance = 0.8f * l.min_distance;
+    float OM[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) OM[k] = (SP[k] + EP[k]) * 0.5f - P.Ow[k];
+    const float dist = norm3_f(OM);
+    if (dist < minDistance || dist > maxDistance) ok = false;
+    const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
+    if (dot3_d(OM, pn) < 0.5 * (double)dist) ok = false;
+    if (ok) {
+        const float ratio = l.max_distance / dist;
+        const int level = (int)ceilf(drfe_logf(ratio) / P.logScale);
+        if (level < 0 || level >= P.nLevels) {
+            outIdx = -2;
+        } else {
+            const float r = th * scale[level];
+            const float r2 = r * r;
+            const double rs = (double)r * 0.01;
+            const float sl0 = (v1 - v2) / (u1 - u2);
+            const double mxq = 0.5 * (double)(u1 + u2), myq = 0.5 * (double)(v1 + v2);
+            const uint64_t* q = reinterpret_cast<const uint64_t*>(descs + (size_t)i * 32);
+            const uint64_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            uint32_t best = 0xFFFFFFFFu;
+            for (int idx = lane; idx < nKF; idx += WAVE) {
+                const LineCur kl = kf[idx];
+                const double mx = mxq - (double)kl.ptX, my = myq - (double)kl.ptY;
+                const float distance = (float)(mx * mx + my * my);
+                if (distance > r2) continue;
+                const float slope = sl0 - kl.angle;
+                if ((double)slope > rs) continue;
+                if (kl.octave < level - 1 || kl.octave > level) continue;
+                const uint64_t* d = reinterpret_cast<const uint64_t*>(kfDesc + (size_t)idx * 32);
+                const int hd = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
+                const uint32_t key = ((uint32_t)hd << 16) | (uint32_t)idx;
+                if (key < best) best = key;
+            }
+            const uint32_t mn = wave_min_u32(best);
+            if (mn != 0xFFFFFFFFu) { outIdx = (int)(mn & 0xFFFF); outDist = (int)(mn >> 16); }
+        }
+    }
+    if (lane == 0) { bestIdx[i] = outIdx; bestDist[i] = outDist; }
+}
+
+hipError_t drfe_launch_line_fuse_search(const drfe_frustum_line* d_lines, const uint8_t* d_descs, const uint8_t* d_skip, int n,
+                                        const FrustumPose& P, const drfe_camera& cam, const float* d_scale, float th,
+                                        const LineCur* d_kf, const uint8_t* d_kfDesc, int nKF, int* d_bestIdx, int* d_bestDist,
+                                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_line_fuse_search, dim3((n + 3) / 4), dim3(256), 0, s, d_lines, d_descs, d_skip, n, P, cam, d_scale, th,
+                       d_kf, d_kfDesc, nKF, d_bestIdx, d_bestDist);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th): the search (src/ORBmatcher.cc:846-953)          */
 
 /* One wavefront per map point.  Projection, KeyFrame::IsInImage, distance band, 60-degree cone and PredictScale are

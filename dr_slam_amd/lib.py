@@ -29,7 +29,7 @@ SYMBOLS = (
     "drfe_create", "drfe_destroy", "drfe_last_error", "drfe_version", "drfe_orb_scale_tables",
     "drfe_orb_max_keypoints", "drfe_orb_extract", "drfe_orb_extract_batch", "drfe_orb_download", "drfe_orb_counts",
     "drfe_orb_pyramid_level", "drfe_orb_blurred_level", "drfe_orb_candidates", "drfe_frame_stereo_grid_batch",
-    "drfe_fuse_search", "drfe_fuse_search_sim3", "drfe_search_by_sim3", "drfe_search_by_projection_kf", "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
+    "drfe_fuse_search", "drfe_fuse_search_sim3", "drfe_search_by_sim3", "drfe_search_by_projection_kf", "drfe_lsd_fuse_search", "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_batch", "drfe_planes_ahc_blocks",
@@ -126,6 +126,7 @@ def load() -> C.CDLL:
     L.drfe_lsd_extract_batch.argtypes = [vp, vp, C.c_size_t, i32, i32, C.c_size_t, i32, i32, vp, vp, vp, i32, vp, vp, i32]
     L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
+    L.drfe_lsd_fuse_search.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp]
     L.drfe_search_by_projection_kf.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, C.c_float, vp, C.POINTER(i32)]
     L.drfe_search_by_sim3.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_float, vp,
                                       C.POINTER(i32)]
@@ -375,6 +376,18 @@ class Context:
         bd = np.zeros(len(p), np.int32)
         self._chk(self.L.drfe_fuse_search_sim3(self.h, slot, _p(T), _p(p), _p(d), _p(sk), len(p), C.c_float(th), _p(bi), _p(bd)),
                   "drfe_fuse_search_sim3")
+        return bi, bd
+
+    def lsd_fuse_search(self, Tcw, cam, lines, descs, skip, kf_lines, kf_desc, th):
+        """Search part of LSDmatcher::Fuse(pKF, vpMapLines, th); returns (best_idx, best_dist) per map line."""
+        l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+        kl = np.ascontiguousarray(kf_lines, KEYLINE_DTYPE)
+        bi = np.zeros(len(l), np.int32)
+        bd = np.zeros(len(l), np.int32)
+        self._chk(self.L.drfe_lsd_fuse_search(self.h, _p(np.ascontiguousarray(Tcw, np.float32).reshape(16)), C.byref(cam), _p(l),
+                                              _p(np.ascontiguousarray(descs, np.uint8)), _p(np.ascontiguousarray(skip, np.uint8)),
+                                              len(l), _p(kl), _p(np.ascontiguousarray(kf_desc, np.uint8)), len(kl), C.c_float(th),
+                                              _p(bi), _p(bd)), "drfe_lsd_fuse_search")
         return bi, bd
 
     def search_by_projection_kf(self, slot, Scw, pts, descs, skip, matched, th):

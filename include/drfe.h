@@ -335,6 +335,18 @@ int drfe_search_by_projection_kf(drfe_ctx* ctx, int slot, const float* Scw, cons
                                  const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th, int32_t* new_match,
                                  int* n_matches);
 
+/* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, const float th = 3.0), src/LSDmatcher.cpp:884-1010
+ * (LocalMapping::SearchInNeighbors, src/LocalMapping.cc:1103 / :1124): the search per map line — both end points projected
+ * with the keyframe pose (camera centre as KeyFrame::SetPose builds it), image bounds, distance band, 60-degree cone,
+ * MapLine::PredictScale, KeyFrame::GetLinesInArea (src/KeyFrame.cc:749-781) over the keyframe's key lines, octave window
+ * level-1..level, first minimum of the LBD Hamming distance.  skip[i] = !pML || pML->isBad().  best_idx[i] = key line
+ * or -1; -2 when the predicted level is outside the pyramid (MapLine::PredictScale does not clamp and the reference then
+ * reads mvScaleFactors out of bounds: undefined there, reported here).  best_dist[i] = the distance (INT_MAX when none);
+ * the caller applies `<= TH_LOW` (50) and the Replace / AddObservation / AddMapLine surgery (:993-1008). */
+int drfe_lsd_fuse_search(drfe_ctx* ctx, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
+                         const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,
+                         int32_t* best_idx, int32_t* best_dist);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */

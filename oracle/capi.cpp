@@ -510,6 +510,14 @@ void orc_fuse_search(void* frame, const float* Tcw, const float* invSigma2, floa
 {
     fuse_search(*(Frame*)frame, Tcw, invSigma2, logScale, nLevels, pts, descs, skip, n, th, bestIdx, bestDist);
 }
+void orc_lsd_fuse_search(const float* cam9, const float* Tcw, float logScale, const float* scaleFactors, int nLevels,
+                         const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                         const uint8_t* kfDesc, int nKF, float th, int32_t* bestIdx, int32_t* bestDist)
+{
+    LineCamera cam;
+    std::memcpy(&cam, cam9, sizeof(cam));
+    lsd_fuse_search(cam, Tcw, logScale, scaleFactors, nLevels, lines, descs, skip, n, kf, kfDesc, nKF, th, bestIdx, bestDist);
+}
 int orc_search_by_projection_kf(void* kf, const float* Scw, float logScale, int nLevels, const FrustumPointRec* pts,
                                 const uint8_t* descs, const uint8_t* skip, int n, const uint8_t* matched, float th, int32_t* newMatch)
 {

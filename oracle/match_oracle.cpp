@@ -548,6 +548,15 @@ static void camera_centre(const float Rcw[9], const float tcw[3], float Ow[3])
         Ow[i] = (float)(s * -1.0);
     }
 }
+/* KeyFrame::GetCameraCenter(): Ow = -Rwc*tcw with Rwc = Rcw.t() materialised first (KeyFrame::SetPose, src/KeyFrame.cc:153-154):
+ * no transpose flag on the product, so cv::gemm takes its small-matrix float path (float dot, then * alpha = -1) */
+static void camera_centre_kf(const float Rcw[9], const float tcw[3], float Ow[3])
+{
+    for (int i = 0; i < 3; i++) {
+        const float d = Rcw[0 * 3 + i] * tcw[0] + Rcw[1 * 3 + i] * tcw[1] + Rcw[2 * 3 + i] * tcw[2];
+        Ow[i] = (float)((double)d * -1.0);
+    }
+}
 /* cv::norm(3x1 CV_32F): double accumulation, sqrt, stored to float; Mat::dot likewise accumulates in double */
 static float norm3(const float v[3]) { return (float)std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }
 static double dot3(const float a[3], const float b[3]) { return (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]; }
@@ -648,7 +657,8 @@ void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigm
 {
     float Rcw[9], tcw[3], Ow[3];
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
-    camera_centre(Rcw, tcw, Ow);
+    if (sim3) camera_centre(Rcw, tcw, Ow);          /* `-Rcw.t()*tcw` at :993 */
+    else camera_centre_kf(Rcw, tcw, Ow);            /* pKF->GetCameraCenter() at :840 */
     std::vector<int> cand;
     for (int i = 0; i < n; i++) {
         bestIdx[i] = -1; bestDist[i] = 256;
@@ -814,6 +824,57 @@ int search_by_projection_kf(const Frame& KF, const float Scw[16], float logScale
         if (bestDist <= TH_LOW) { taken[bestIdx] = 1; newMatch[bestIdx] = i; nmatches++; }
     }
     return nmatches;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* LSDmatcher::Fuse(KeyFrame*, vector<MapLine*>, th): the search, src/LSDmatcher.cpp:884-993               */
+
+void lsd_fuse_search(const LineCamera& cam, const float Tcw[16], float logScaleFactor, const float* scaleFactors, int nLevels,
+                     const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                     const uint8_t* kfDesc, int nKF, float th, int32_t* bestIdx, int32_t* bestDist)
+{
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+    camera_centre_kf(Rcw, tcw, Ow);
+    std::vector<int> cand;
+    for (int i = 0; i < n; i++) {
+        bestIdx[i] = -1; bestDist[i] = INT_MAX;
+        if (skip && skip[i]) continue;                                            /* !pML || pML->isBad() */
+        const FrustumLineRec& l = lines[i];
+        const float SP[3] = {(float)l.world[0], (float)l.world[1], (float)l.world[2]};
+        const float EP[3] = {(float)l.world[3], (float)l.world[4], (float)l.world[5]};
+        float SPc[3], EPc[3];
+        mat3_mul_add(Rcw, SP, tcw, SPc);
+        mat3_mul_add(Rcw, EP, tcw, EPc);
+        if (SPc[2] < 0.0f || EPc[2] < 0.0f) continue;
+        const float invz1 = 1.0f / SPc[2];
+        const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+        if (u1 < cam.minX || u1 > cam.maxX) continue;
+        if (v1 < cam.minY || v1 > cam.maxY) continue;
+        const float invz2 = 1.0f / EPc[2];
+        const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+        if (u2 < cam.minX || u2 > cam.maxX) continue;
+        if (v2 < cam.minY || v2 > cam.maxY) continue;
+        const float maxDistance = 1.2f * l.maxDistance, minDistance = 0.8f * l.minDistance;
+        float OM[3];
+        for (int k = 0; k < 3; k++) OM[k] = (SP[k] + EP[k]) * 0.5f - Ow[k];
+        const float dist = norm3(OM);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
+        if (dot3(OM, pn) < 0.5 * (double)dist) continue;                          /* :956 */
+        const float ratio = l.maxDistance / dist;
+        const int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);      /* MapLine::PredictScale: no clamp */
+        if (level < 0 || level >= nLevels) { bestIdx[i] = -2; continue; }         /* mvScaleFactors[level] is out of bounds there */
+        const float radius = th * scaleFactors[level];
+        get_lines_in_area(kf, nKF, u1, v1, u2, v2, radius, -1, -1, cand);         /* KeyFrame::GetLinesInArea, src/KeyFrame.cc:749 */
+        for (int idx : cand) {
+            const int klLevel = kf[idx].octave;
+            if (klLevel < level - 1 || klLevel > level) continue;
+            const int d = descriptor_distance_swar(descs + (size_t)i * 32, kfDesc + (size_t)idx * 32);
+            if (d < bestDist[i]) { bestDist[i] = d; bestIdx[i] = idx; }
+        }
+    }
 }
 
 } // namespace orc

@@ -126,6 +126,14 @@ void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigm
  * similarity Scw decomposed as in :989-994 (scale = |first row|, Rcw = sRcw / s, tcw = t / s), there is no chi-square
  * gate, and invz is computed as 1.0 / z in double.  Tcw receives the decomposed [Rcw | tcw]. */
 void decompose_sim3(const float Scw[16], float Tcw[16]);
+/* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, th), src/LSDmatcher.cpp:884-1010 (LocalMapping::
+ * SearchInNeighbors): the search per map line (projection of both end points, distance band, 60-degree cone, unclamped
+ * PredictScale, KeyFrame::GetLinesInArea, octave window, first minimum of the LBD distance).  bestIdx = -1: nothing,
+ * -2: the predicted level is outside the pyramid (the reference indexes mvScaleFactors out of bounds there).
+ * The caller applies TH_LOW and does the Replace / AddObservation surgery. */
+void lsd_fuse_search(const LineCamera& cam, const float Tcw[16], float logScaleFactor, const float* scaleFactors, int nLevels,
+                     const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                     const uint8_t* kfDesc, int nKF, float th, int32_t* bestIdx, int32_t* bestDist);
 /* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:294-407
  * (LoopClosing::ComputeSim3 after the Sim3 optimisation, th = 10): the points are visited in order, a keypoint whose
  * vpMatched entry is set (on entry, or by an earlier point of this call) is not a candidate, a point is accepted when its

@@ -362,6 +362,22 @@ def fuse_search(kf: "FrameOracle", Tcw, scale_factor, inv_level_sigma2, pts, des
     return bi, bd
 
 
+def lsd_fuse_search(cam9, Tcw, scale_factor, scale, lines, descs, skip, kf_keylines, kf_desc, th):
+    """Search part of LSDmatcher::Fuse(pKF, vpMapLines, th): returns (best_idx, best_dist) per map line."""
+    L = lib()
+    l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+    sc = _c(scale, np.float32)
+    kf = _line_recs(kf_keylines)
+    bi = np.zeros(len(l), np.int32)
+    bd = np.zeros(len(l), np.int32)
+    L.orc_lsd_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_lsd_fuse_search(_p(_c(cam9, np.float32)), _p(_c(Tcw, np.float32).reshape(16)), logf(np.float32(scale_factor)), _p(sc), len(sc),
+                          _p(l), _p(_c(descs, np.uint8)), _p(_c(skip, np.uint8)), len(l), _p(kf), _p(_c(kf_desc, np.uint8)), len(kf),
+                          float(th), _p(bi), _p(bd))
+    return bi, bd
+
+
 def search_by_projection_kf(kf: "FrameOracle", Scw, scale_factor, nlevels, pts, descs, skip, matched, th):
     """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): returns (nmatches, new_match per keypoint)."""
     L = lib()

@@ -141,3 +141,44 @@ def test_lsd_extract_batch_equals_single(ctx):
             assert np.array_equal(a["lines"].view(np.uint8), b["lines"].view(np.uint8))
             assert np.array_equal(a["desc"], b["desc"])
             assert np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 11])
+def test_lsd_fuse_search(oracle_mod, seed):
+    """Search part of LSDmatcher::Fuse(pKF, vpMapLines, 3.0) (LocalMapping::SearchInNeighbors): projection gates, cone test,
+    unclamped PredictScale (levels outside the pyramid are reported as -2), KeyFrame::GetLinesInArea, octave window, first
+    minimum.  Bit-equal best index and distance per map line."""
+    import line_scenarios as LS
+    from dr_slam_amd import lib
+    n_kf, n = (40, 64) if seed < 10 else (300, 2000)
+    sc = LS.make(seed, lib.KEYLINE_DTYPE, lib.MAPLINE_DTYPE, lib.TRACKED_LINE_DTYPE, n_cur=n_kf, n_last=n)
+    rng = np.random.RandomState(100 + seed)
+    Tcw = sc["Tcw_cur"]
+    Twc = np.linalg.inv(Tcw.astype(np.float64))
+    lines = np.zeros(n, lib.FRUSTUM_LINE_DTYPE)
+    lines["world"] = sc["last"]["world"]
+    mid = 0.5 * (lines["world"][:, :3] + lines["world"][:, 3:])
+    om = mid - Twc[:3, 3][None, :]
+    dist = np.linalg.norm(om, axis=1)
+    nrm = om / dist[:, None] + rng.normal(0, 0.5, (n, 3))            # some outside the 60-degree cone
+    lines["normal"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    lvl = rng.choice([-1, 0, 1, 2, 9], size=n, p=[0.04, 0.4, 0.4, 0.12, 0.04])
+    lines["max_distance"] = (dist * 1.2 ** (lvl - rng.uniform(0.1, 0.9, n))).astype(np.float32)
+    lines["min_distance"] = (dist * rng.uniform(0.3, 1.3, n)).astype(np.float32)
+    descs = sc["last"]["desc"]
+    skip = (rng.uniform(size=n) < 0.1).astype(np.uint8)
+    ctx = lib.Context(max_batch=1)
+    try:
+        cam = lib.Camera(**LS.CAM)
+        for th in (3.0, 12.0):
+            bi, bd = ctx.lsd_fuse_search(Tcw, cam, lines, descs, skip, sc["cur"], sc["cur_desc"], th)
+            obi, obd = oracle_mod.lsd_fuse_search(LS.cam9(), Tcw, 1.2, LS.SCALE, lines, descs, skip, sc["cur"], sc["cur_desc"], th)
+            assert np.array_equal(bi, obi) and np.array_equal(bd, obd), th
+        assert (obi[skip == 1] == -1).all()
+        assert (obi >= 0).sum() > n // 8 and ((obi >= 0) & (obd <= 50)).sum() > n // 20
+        assert seed < 10 or (obi == -2).sum() > 10
+        # a keyframe without key lines
+        bi, bd = ctx.lsd_fuse_search(Tcw, cam, lines, descs, skip, sc["cur"][:0], sc["cur_desc"][:0], 3.0)
+        assert (bi < 0).all()
+    finally:
+        ctx.close()
