@@ -4,6 +4,7 @@
 #include "../../include/drfe_math.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -744,46 +745,37 @@ int drfe_search_by_sim3(drfe_ctx* c, int slot1, int slot2, const float* T1w, con
     return DRFE_OK;
 }
 
-/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:294-407.
- * The loop over points is sequential in the reference (a keypoint claimed by an earlier point stops being a candidate), so
- * the device lists, per point, its FUSE_LIST_K best candidates within TH_LOW among the keypoints free on entry, in the
- * reference's comparison order; the host then walks the points in order and takes the first listed candidate that is
- * still free.  A point whose list ran out while the device counted more candidates than it listed is asked again, alone,
- * against the current claims (the device search, not a host one). */
-int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const drfe_frustum_point* pts, const uint8_t* descs,
-                                 const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th, int32_t* new_match,
-                                 int* n_matches)
+/* The two matchers whose loop over the map points is first come, first served in the reference (a keypoint claimed by an
+ * earlier point stops being a candidate): SearchByProjection(KeyFrame*, Scw, ...) (mode 3) and the relocalisation
+ * SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (mode 4).  The device lists, per point, its
+ * FUSE_LIST_K best candidates within listTh among the keypoints free on entry, in the reference's comparison order; the
+ * host then walks the points in order and takes the first listed candidate that is still free.  A point whose list ran
+ * out while the device counted more candidates than it listed is asked again, alone, against the current claims (the
+ * device search, not a host one).  pick[i] = the keypoint point i claimed or -1; taken[] is updated. */
+static int first_come_search(drfe_ctx* c, const char* who, int slot, const float* T, int mode, int listTh,
+                             const drfe_frustum_point* pts, const uint8_t* descs, const uint8_t* skip, int n,
+                             std::vector<uint8_t>& taken, float th, std::vector<int>& pick)
 {
-    if (!c || !Scw || !matched || !new_match || !n_matches || n < 0 || n_kp < 0 || (n && (!pts || !descs))) return DRFE_ERR_INVALID;
-    if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = "search_by_projection_kf: slot needs extract + glue first"; return DRFE_ERR_STATE; }
-    if (c->cfg.nlevels > 16) { c->err = "search_by_projection_kf: more than 16 pyramid levels"; return DRFE_ERR_INVALID; }
-    *n_matches = 0;
-    for (int k = 0; k < n_kp; k++) new_match[k] = -1;
-    if (n == 0 || n_kp == 0) return DRFE_OK;
+    const int n_kp = (int)taken.size();
+    pick.assign(n, -1);
+    if (slot < 0 || slot >= c->lastBatch || !c->glueValid) { c->err = std::string(who) + ": slot needs extract + glue first"; return DRFE_ERR_STATE; }
+    if (c->cfg.nlevels > 16) { c->err = std::string(who) + ": more than 16 pyramid levels"; return DRFE_ERR_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     int rc = drfe_stream_sync(c);
     if (rc != DRFE_OK) return rc;
     int slotCount = 0;
     HIPCHK(c, hipMemcpy(&slotCount, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
-    if (n_kp != slotCount) { c->err = "search_by_projection_kf: n_kp is not the slot's keypoint count"; return DRFE_ERR_INVALID; }
-    const double dd = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
-    const float scw = (float)std::sqrt(dd);
-    const float inv = (float)(1.0 / (double)scw);
-    float T[16];
-    for (int r = 0; r < 3; r++) {
-        for (int k = 0; k < 3; k++) T[r * 4 + k] = Scw[r * 4 + k] * inv;
-        T[r * 4 + 3] = Scw[r * 4 + 3] * inv;
-    }
-    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    if (n_kp != slotCount) { c->err = std::string(who) + ": n_kp is not the slot's keypoint count"; return DRFE_ERR_INVALID; }
+    if (n == 0 || n_kp == 0) return DRFE_OK;
     const drfe_camera cam = c->cam;
     FrustumPose fp;
-    frustum_pose(c, T, &cam, 0.f, &fp);
+    frustum_pose(c, T, &cam, 0.f, &fp);                                                 /* Ow = -Rcw.t()*tcw in both callers */
     FuseParams P;
     std::memset(&P, 0, sizeof(P));
     std::memcpy(P.T, fp.T, 64);
     std::memcpy(P.Ow, fp.Ow, 12);
     P.bf = cam.bf; P.logScale = fp.logScale; P.th = th; P.nLevels = c->cfg.nlevels;
-    P.sim3 = 3; P.listTh = 50;                                                          /* TH_LOW */
+    P.sim3 = mode; P.listTh = listTh;
     for (int l = 0; l < c->cfg.nlevels; l++) { P.scale[l] = c->scale[l]; P.invSigma2[l] = c->invSigma2[l]; }
     auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
     const size_t oP = 0, oD = up(sizeof(drfe_frustum_point) * (size_t)n), oS = oD + up((size_t)n * 32), oT = oS + up((size_t)n),
@@ -792,7 +784,6 @@ int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const 
     uint8_t* d = nullptr;
     HIPCHK(c, hipMalloc(&d, total));
     hipStream_t s = c->stream;
-    std::vector<uint8_t> taken(matched, matched + n_kp);
     std::vector<int2> list((size_t)n * FUSE_LIST_K);
     std::vector<int> count(n);
     auto P_ = [&](size_t o) { return d + o; };
@@ -807,7 +798,6 @@ int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const 
     if (e == hipSuccess) e = hipMemcpyAsync(list.data(), P_(oL), sizeof(int2) * list.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(count.data(), P_(oC), sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    int nm = 0;
     /* DRFE_TEST_LIST_K=1..FUSE_LIST_K shortens the lists the host trusts so that tests reach the ask-again path */
     int listK = FUSE_LIST_K;
     if (const char* ev = std::getenv("DRFE_TEST_LIST_K")) { const int v = std::atoi(ev); if (v >= 1 && v < FUSE_LIST_K) listK = v; }
@@ -815,10 +805,10 @@ int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const 
         const int2* L = &list[(size_t)i * FUSE_LIST_K];
         /* entries the list really holds in order: all of them up to listK unless more than 64 candidates folded */
         const int held = count[i] > 64 ? 1 : (count[i] < listK ? count[i] : listK);
-        int pick = -1;
+        int pk = -1;
         for (int r = 0; r < held; r++)
-            if (!taken[L[r].x]) { pick = L[r].x; break; }
-        if (pick < 0 && count[i] > held) {
+            if (!taken[L[r].x]) { pk = L[r].x; break; }
+        if (pk < 0 && count[i] > held) {
             /* every listed candidate was claimed and there were more: search this point again with today's claims */
             int one[2] = {-1, 256};
             e = hipMemcpyAsync(P_(oT), taken.data(), (size_t)n_kp, hipMemcpyHostToDevice, s);
@@ -829,12 +819,93 @@ int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const 
             if (e == hipSuccess) e = hipMemcpyAsync(&one[0], P_(oI), sizeof(int), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipMemcpyAsync(&one[1], P_(oB), sizeof(int), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e == hipSuccess && one[0] >= 0 && one[1] <= 50) pick = one[0];
+            if (e == hipSuccess && one[0] >= 0 && one[1] <= listTh) pk = one[0];
         }
-        if (pick >= 0) { taken[pick] = 1; new_match[pick] = i; nm++; }
+        if (pk >= 0) { taken[pk] = 1; pick[i] = pk; }
     }
     (void)hipFree(d);
-    if (e != hipSuccess) { c->err = std::string("search_by_projection_kf: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    if (e != hipSuccess) { c->err = std::string(who) + ": " + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    return DRFE_OK;
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:294-407 */
+int drfe_search_by_projection_kf(drfe_ctx* c, int slot, const float* Scw, const drfe_frustum_point* pts, const uint8_t* descs,
+                                 const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th, int32_t* new_match,
+                                 int* n_matches)
+{
+    if (!c || !Scw || !matched || !new_match || !n_matches || n < 0 || n_kp < 0 || (n && (!pts || !descs))) return DRFE_ERR_INVALID;
+    *n_matches = 0;
+    for (int k = 0; k < n_kp; k++) new_match[k] = -1;
+    const double dd = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)std::sqrt(dd);
+    const float inv = (float)(1.0 / (double)scw);
+    float T[16];
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) T[r * 4 + k] = Scw[r * 4 + k] * inv;
+        T[r * 4 + 3] = Scw[r * 4 + 3] * inv;
+    }
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    std::vector<uint8_t> taken(matched, matched + n_kp);
+    std::vector<int> pick;
+    const int rc = first_come_search(c, "search_by_projection_kf", slot, T, 3, 50 /* TH_LOW */, pts, descs, skip, n, taken, th, pick);
+    if (rc != DRFE_OK) return rc;
+    int nm = 0;
+    for (int i = 0; i < n; i++)
+        if (pick[i] >= 0) { new_match[pick[i]] = i; nm++; }
+    *n_matches = nm;
+    return DRFE_OK;
+}
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist),
+ * src/ORBmatcher.cc:1537-1664 (Tracking::Relocalization) */
+int drfe_search_by_projection_reloc(drfe_ctx* c, int slot, const float* Tcw, const drfe_frustum_point* pts, const uint8_t* descs,
+                                    const float* kf_angles, const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th,
+                                    int orb_dist, int check_orientation, int32_t* new_match, int* n_matches)
+{
+    if (!c || !Tcw || !matched || !new_match || !n_matches || n < 0 || n_kp < 0 || (n && (!pts || !descs)) || orb_dist < 0 || orb_dist > 256)
+        return DRFE_ERR_INVALID;
+    if (check_orientation && n && !kf_angles) return DRFE_ERR_INVALID;
+    *n_matches = 0;
+    for (int k = 0; k < n_kp; k++) new_match[k] = -1;
+    std::vector<uint8_t> taken(matched, matched + n_kp);
+    std::vector<int> pick;
+    const int rc = first_come_search(c, "search_by_projection_reloc", slot, Tcw, 4, orb_dist, pts, descs, skip, n, taken, th, pick);
+    if (rc != DRFE_OK) return rc;
+    std::vector<drfe_keypoint> kp;
+    if (check_orientation && n && n_kp) {
+        kp.resize(n_kp);
+        HIPCHK(c, hipMemcpy(kp.data(), drfe_kps_un(c) + (size_t)slot * c->maxKp, sizeof(drfe_keypoint) * (size_t)n_kp, hipMemcpyDeviceToHost));
+    }
+    int nm = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / 30;
+    for (int i = 0; i < n; i++) {
+        if (pick[i] < 0) continue;
+        new_match[pick[i]] = i;
+        nm++;
+        if (check_orientation) {
+            float rot = kf_angles[i] - kp[pick[i]].angle;                               /* :1623-1630 */
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == 30) bin = 0;
+            if (bin < 0 || bin >= 30) { c->err = "search_by_projection_reloc: keypoint angle outside [0, 360)"; return DRFE_ERR_INVALID; }
+            rotHist[bin].push_back(pick[i]);
+        }
+    }
+    if (check_orientation) {                                                            /* ComputeThreeMaxima, :1666-1707 */
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < 30; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < 30; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int k : rotHist[i]) { new_match[k] = -1; nm--; }
+    }
     *n_matches = nm;
     return DRFE_OK;
 }

@@ -81,7 +81,10 @@ struct FuseParams { float T[16]; float Ow[3]; float bf, logScale, th; int nLevel
                                     distance is the norm of the result, no viewing-cone test, no chi-square gate;
                                  3: SearchByProjection(KeyFrame*, Scw, ...): float 1/z, viewing cone kept, no chi-square
                                     gate; keypoints with taken[idx] != 0 are not candidates and the FUSE_LIST_K best
-                                    candidates within listTh are listed in (distance, visit order) */
+                                    candidates within listTh are listed in (distance, visit order);
+                                 4: the relocalisation SearchByProjection(Frame&, KeyFrame*, ...): no depth test,
+                                    double 1/z, inclusive image bounds, no viewing cone, octave window level-1..level+1,
+                                    taken[] and candidate lists like mode 3 */
                     float sR2[9], t2[3];
                     int listTh; };
 #define FUSE_LIST_K 8

@@ -1027,17 +1027,23 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
             Pc[r] = d + P.t2[r];
         }
     }
-    if (Pc[2] < 0.0f) ok = false;
-    const float invz = (P.sim3 == 1 || P.sim3 == 2) ? (float)(1.0 / (double)Pc[2]) : 1 / Pc[2];
+    const bool reloc = P.sim3 == 4;
+    if (!reloc && Pc[2] < 0.0f) ok = false;                 /* the relocalisation search has no depth test */
+    const float invz = (P.sim3 == 1 || P.sim3 == 2 || reloc) ? (float)(1.0 / (double)Pc[2]) : 1 / Pc[2];
     const float x = Pc[0] * invz, y = Pc[1] * invz;
-    const float u = cam.fx * x + cam.cx, v = cam.fy * y + cam.cy;
-    if (!(u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y)) ok = false;
+    /* `fx*xc*invzc+cx` at :1568 associates the other way round */
+    const float u = reloc ? cam.fx * Pc[0] * invz + cam.cx : cam.fx * x + cam.cx;
+    const float v = reloc ? cam.fy * Pc[1] * invz + cam.cy : cam.fy * y + cam.cy;
+    if (reloc) {
+        if (u < cam.min_x || u > cam.max_x || v < cam.min_y || v > cam.max_y) ok = false;
+        if (!(Pc[2] != 0.0f)) ok = false;                   /* z = 0 (or NaN): the reference projects to infinity */
+    } else if (!(u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y)) ok = false;
     const float ur = u - P.bf * invz;
     const float maxDistance = 1.2f * p.max_distance, minDistance = 0.8f * p.min_distance;
     const float PO[3] = {p.world[0] - P.Ow[0], p.world[1] - P.Ow[1], p.world[2] - P.Ow[2]};
     const float dist3D = P.sim3 == 2 ? norm3_f(Pc) : norm3_f(PO);
     if (dist3D < minDistance || dist3D > maxDistance) ok = false;
-    if (P.sim3 != 2 && dot3_d(PO, p.normal) < 0.5 * (double)dist3D) ok = false;
+    if (P.sim3 != 2 && !reloc && dot3_d(PO, p.normal) < 0.5 * (double)dist3D) ok = false;
     if (ok) {
         const float ratio = p.max_distance / dist3D;
         int level = (int)ceilf(drfe_logf(ratio) / P.logScale);
@@ -1081,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
                     const int oct = (int)(k4.w >> 24);
                     const float dx = kx - u, dy = ky - v;
                     bool c = fabsf(dx) < r && fabsf(dy) < r;                /* KeyFrame::GetFeaturesInArea */
-                    if (oct < level - 1 || oct > level) c = false;
+                    if (oct < level - 1 || oct > level + (reloc ? 1 : 0)) c = false;  /* reloc: Frame::GetFeaturesInArea(level-1, level+1) */
                     const float ex = u - kx, ey = v - ky;
                     if (P.sim3) {
                     } else if (kr >= 0) {

@@ -29,7 +29,7 @@ SYMBOLS = (
     "drfe_create", "drfe_destroy", "drfe_last_error", "drfe_version", "drfe_orb_scale_tables",
     "drfe_orb_max_keypoints", "drfe_orb_extract", "drfe_orb_extract_batch", "drfe_orb_download", "drfe_orb_counts",
     "drfe_orb_pyramid_level", "drfe_orb_blurred_level", "drfe_orb_candidates", "drfe_frame_stereo_grid_batch",
-    "drfe_fuse_search", "drfe_fuse_search_sim3", "drfe_search_by_sim3", "drfe_search_by_projection_kf", "drfe_lsd_fuse_search", "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
+    "drfe_fuse_search", "drfe_fuse_search_sim3", "drfe_search_by_sim3", "drfe_search_by_projection_kf", "drfe_search_by_projection_reloc", "drfe_lsd_fuse_search", "drfe_frame_is_in_frustum", "drfe_frame_is_in_frustum_lines", "drfe_frame_set_distortion", "drfe_frame_image_bounds", "drfe_frame_download_keys_un",
     "drfe_frame_download_stereo", "drfe_frame_download_grid", "drfe_match_consecutive_batch", "drfe_match_download",
     "drfe_search_by_projection_last", "drfe_search_by_projection_map", "drfe_match_bf_knn", "drfe_profile_enable",
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_batch", "drfe_planes_ahc_blocks",
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
     L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
     L.drfe_lsd_fuse_search.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp]
+    L.drfe_search_by_projection_reloc.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, C.c_float, i32, i32, vp, C.POINTER(i32)]
     L.drfe_search_by_projection_kf.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, C.c_float, vp, C.POINTER(i32)]
     L.drfe_search_by_sim3.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_float, vp,
                                       C.POINTER(i32)]
@@ -400,6 +401,20 @@ class Context:
                                                       _p(np.ascontiguousarray(descs, np.uint8)),
                                                       _p(np.ascontiguousarray(skip, np.uint8)), len(p), _p(m), len(m),
                                                       C.c_float(th), _p(out), C.byref(n)), "drfe_search_by_projection_kf")
+        return n.value, out
+
+    def search_by_projection_reloc(self, slot, Tcw, pts, descs, kf_angles, skip, matched, th, orb_dist, check_orientation=True):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist); returns (nmatches, new_match)."""
+        p = np.ascontiguousarray(pts, FRUSTUM_POINT_DTYPE)
+        m = np.ascontiguousarray(matched, np.uint8)
+        out = np.full(len(m), -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_search_by_projection_reloc(self.h, slot, _p(np.ascontiguousarray(Tcw, np.float32).reshape(16)), _p(p),
+                                                         _p(np.ascontiguousarray(descs, np.uint8)),
+                                                         _p(np.ascontiguousarray(kf_angles, np.float32)),
+                                                         _p(np.ascontiguousarray(skip, np.uint8)), len(p), _p(m), len(m),
+                                                         C.c_float(th), int(orb_dist), int(bool(check_orientation)), _p(out),
+                                                         C.byref(n)), "drfe_search_by_projection_reloc")
         return n.value, out
 
     def search_by_sim3(self, slot1, slot2, T1w, T2w, s12, R12, t12, pts1, descs1, skip1, pts2, descs2, skip2, th):

@@ -335,6 +335,19 @@ int drfe_search_by_projection_kf(drfe_ctx* ctx, int slot, const float* Scw, cons
                                  const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th, int32_t* new_match,
                                  int* n_matches);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, const float th,
+ * const int ORBdist), src/ORBmatcher.cc:1537-1664 (Tracking::Relocalization, src/Tracking.cc:3638 / :3651): the keyframe's
+ * map points (pts / descs per entry of pKF->GetMapPointMatches(), skip[i] = !pMP || isBad() || sAlreadyFound.count(pMP),
+ * kf_angles[i] = pKF->mvKeysUn[i].angle) are projected into the current frame (slot) with Tcw = CurrentFrame.mTcw — no
+ * depth test, double 1/z, inclusive image bounds, 0.8 / 1.2 distance band, MapPoint::PredictScale — and matched IN ORDER
+ * to the frame's keypoints without a map point (matched[k] = CurrentFrame.mvpMapPoints[k] != NULL), octaves
+ * level-1..level+1, first minimum, accepted when <= orb_dist; then the rotation-histogram filter when check_orientation.
+ * new_match[k] = index i of the point assigned to keypoint k (CurrentFrame.mvpMapPoints[k] = vpMPs[i]) or -1;
+ * *n_matches = the return value.  A point with camera-space z == 0 is skipped (the reference projects it to infinity). */
+int drfe_search_by_projection_reloc(drfe_ctx* ctx, int slot, const float* Tcw, const drfe_frustum_point* pts, const uint8_t* descs,
+                                    const float* kf_angles, const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th,
+                                    int orb_dist, int check_orientation, int32_t* new_match, int* n_matches);
+
 /* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, const float th = 3.0), src/LSDmatcher.cpp:884-1010
  * (LocalMapping::SearchInNeighbors, src/LocalMapping.cc:1103 / :1124): the search per map line — both end points projected
  * with the keyframe pose (camera centre as KeyFrame::SetPose builds it), image bounds, distance band, 60-degree cone,

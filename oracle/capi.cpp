@@ -523,6 +523,13 @@ int orc_search_by_projection_kf(void* kf, const float* Scw, float logScale, int 
 {
     return search_by_projection_kf(*(Frame*)kf, Scw, logScale, nLevels, pts, descs, skip, n, matched, th, newMatch);
 }
+int orc_search_by_projection_reloc(void* cur, const float* Tcw, float logScale, int nLevels, const FrustumPointRec* pts,
+                                   const uint8_t* descs, const float* kfAngles, const uint8_t* skip, int n, const uint8_t* matched,
+                                   float th, int orbDist, int checkOri, int32_t* newMatch)
+{
+    return search_by_projection_reloc(*(Frame*)cur, Tcw, logScale, nLevels, pts, descs, kfAngles, skip, n, matched, th, orbDist,
+                                      checkOri != 0, newMatch);
+}
 int orc_search_by_sim3(void* kf1, void* kf2, const float* T1w, const float* T2w, float s12, const float* R12, const float* t12,
                        float logScale, int nLevels, const FrustumPointRec* pts1, const uint8_t* descs1, const uint8_t* skip1,
                        const FrustumPointRec* pts2, const uint8_t* descs2, const uint8_t* skip2, float th, int32_t* out12)

@@ -877,4 +877,74 @@ void lsd_fuse_search(const LineCamera& cam, const float Tcw[16], float logScaleF
     }
 }
 
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)                          */
+
+int search_by_projection_reloc(const Frame& Cur, const float Tcw[16], float logScaleFactor, int nLevels, const FrustumPointRec* pts,
+                               const uint8_t* descs, const float* kfAngles, const uint8_t* skip, int n, const uint8_t* matched,
+                               float th, int orbDist, bool checkOri, int32_t* newMatch)
+{
+    const int HISTO_LENGTH = 30;
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+    camera_centre(Rcw, tcw, Ow);                                                  /* -Rcw.t()*tcw, :1543 */
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<uint8_t> taken(matched, matched + Cur.N);
+    for (int k = 0; k < Cur.N; k++) newMatch[k] = -1;
+    std::vector<int> cand;
+    int nmatches = 0;
+    for (int i = 0; i < n; i++) {
+        if (skip && skip[i]) continue;
+        const FrustumPointRec& p = pts[i];
+        float x3Dc[3];
+        mat3_mul_add(Rcw, p.world, tcw, x3Dc);
+        if (!(x3Dc[2] != 0.0f)) continue;                                         /* documented deviation: z == 0 is skipped */
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / (double)x3Dc[2]);
+        const float u = Cur.fx * xc * invzc + Cur.cx;
+        const float v = Cur.fy * yc * invzc + Cur.cy;
+        if (u < Cur.minX || u > Cur.maxX) continue;
+        if (v < Cur.minY || v > Cur.maxY) continue;
+        const float PO[3] = {p.world[0] - Ow[0], p.world[1] - Ow[1], p.world[2] - Ow[2]};
+        const float dist3D = norm3(PO);
+        const float maxDistance = 1.2f * p.maxDistance, minDistance = 0.8f * p.minDistance;
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float ratio = p.maxDistance / dist3D;
+        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);            /* MapPoint::PredictScale(dist, Frame*) */
+        if (level < 0) level = 0;
+        else if (level >= nLevels) level = nLevels - 1;
+        const float radius = th * Cur.scaleFactors[level];
+        Cur.getFeaturesInArea(u, v, radius, level - 1, level + 1, cand);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : cand) {
+            if (taken[i2]) continue;
+            const int d = descriptor_distance_swar(descs + (size_t)i * 32, &Cur.desc[(size_t)i2 * 32]);
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= orbDist) {
+            taken[bestIdx2] = 1;
+            newMatch[bestIdx2] = i;
+            nmatches++;
+            if (checkOri) {
+                float rot = kfAngles[i] - Cur.keysUn[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { newMatch[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
 } // namespace orc

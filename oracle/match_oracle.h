@@ -141,6 +141,12 @@ void lsd_fuse_search(const LineCamera& cam, const float Tcw[16], float logScaleF
  * point that claimed keypoint idx in this call or -1.  Returns nmatches. */
 int search_by_projection_kf(const Frame& KF, const float Scw[16], float logScaleFactor, int nLevels, const FrustumPointRec* pts,
                             const uint8_t* descs, const uint8_t* skip, int n, const uint8_t* matched, float th, int32_t* newMatch);
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1537-1664
+ * (Tracking::Relocalization).  pts / descs / kfAngles / skip per keyframe keypoint; matched[k] = CurrentFrame.mvpMapPoints[k]
+ * != NULL; newMatch[k] = keyframe index or -1.  Returns nmatches. */
+int search_by_projection_reloc(const Frame& Cur, const float Tcw[16], float logScaleFactor, int nLevels, const FrustumPointRec* pts,
+                               const uint8_t* descs, const float* kfAngles, const uint8_t* skip, int n, const uint8_t* matched,
+                               float th, int orbDist, bool checkOri, int32_t* newMatch);
 /* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1106-1330 (LoopClosing::ComputeSim3):
  * every unmatched map point of KF1 is moved into KF2 with the similarity (and vice versa), searched in a th * scale
  * window (octave level-1..level, distance <= TH_HIGH, first minimum), and a pair is accepted when both directions agree.

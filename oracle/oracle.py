@@ -391,6 +391,21 @@ def search_by_projection_kf(kf: "FrameOracle", Scw, scale_factor, nlevels, pts, 
     return n, out
 
 
+def search_by_projection_reloc(cur: "FrameOracle", Tcw, scale_factor, nlevels, pts, descs, kf_angles, skip, matched, th, orb_dist,
+                               check_ori=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): (nmatches, new_match per keypoint)."""
+    L = lib()
+    p = np.ascontiguousarray(pts, FRUSTUM_POINT_DTYPE)
+    m = _c(matched, np.uint8)
+    out = np.full(len(m), -1, np.int32)
+    L.orc_search_by_projection_reloc.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    n = L.orc_search_by_projection_reloc(cur.h, _p(_c(Tcw, np.float32).reshape(16)), logf(np.float32(scale_factor)), int(nlevels), _p(p),
+                                         _p(_c(descs, np.uint8)), _p(_c(kf_angles, np.float32)), _p(_c(skip, np.uint8)), len(p), _p(m),
+                                         float(th), int(orb_dist), int(bool(check_ori)), _p(out))
+    return n, out
+
+
 def search_by_sim3(kf1: "FrameOracle", kf2: "FrameOracle", T1w, T2w, s12, R12, t12, scale_factor, nlevels, pts1, descs1, skip1,
                    pts2, descs2, skip2, th):
     """ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): returns (nFound, out12[i1] = i2 or -1)."""

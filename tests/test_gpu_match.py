@@ -379,3 +379,41 @@ def test_search_by_projection_kf(setup, oracle_mod, list_k, monkeypatch):
     assert total > 600
     with pytest.raises(lib.DrfeError):
         fe.ctx.search_by_projection_kf(0, Scw, pts, descs, skip, matched[:-1], 10.0)
+
+
+@pytest.mark.parametrize("list_k", [None, "1"])
+def test_search_by_projection_reloc(setup, oracle_mod, list_k, monkeypatch):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) as Tracking::Relocalization calls it
+    (th 10 / ORBdist 100, then th 3 / ORBdist 64), with and without the rotation histogram; every point twice so that
+    the first-come claims matter; a few points behind the camera (the reference has no depth test here)."""
+    from dr_slam_amd import lib
+    fe, oframes, Tcw, Twc, cam = setup
+    if list_k:
+        monkeypatch.setenv("DRFE_TEST_LIST_K", list_k)
+    o = oracle_mod.OrbOracle()
+    rng = np.random.RandomState(41)
+    total = 0
+    for cur_slot, kf in ((1, 0), (2, 3), (0, 3)):
+        world, valid = oframes[kf].unproject(Twc[kf])
+        keep = np.repeat(np.flatnonzero(valid), 2)
+        n = len(keep)
+        pts = np.zeros(n, lib.FRUSTUM_POINT_DTYPE)
+        pts["world"] = world[keep]
+        behind = rng.choice(n, 20, replace=False)
+        pts["world"][behind] = (Twc[cur_slot][:3, :3] @ np.array([0.1, 0.05, -1.5], np.float32) + Twc[cur_slot][:3, 3])[None, :]
+        d = np.linalg.norm(Twc[kf][:3, 3][None, :] - pts["world"], axis=1)
+        lvl = oframes[kf].kps["octave"][keep]
+        pts["max_distance"] = (d * o.scale[lvl] * rng.uniform(0.9, 1.3, n)).astype(np.float32)
+        pts["min_distance"] = (pts["max_distance"] / o.scale[-1] * rng.uniform(0.5, 1.0, n)).astype(np.float32)
+        descs = oframes[kf].desc[keep]
+        angles = oframes[kf].kps["angle"][keep]
+        skip = (rng.uniform(size=n) < 0.1).astype(np.uint8)
+        matched = (rng.uniform(size=oframes[cur_slot].N) < 0.2).astype(np.uint8)
+        for th, orb_dist, ori in ((10.0, 100, True), (3.0, 64, True), (10.0, 100, False)):
+            nm, new = fe.ctx.search_by_projection_reloc(cur_slot, Tcw[cur_slot], pts, descs, angles, skip, matched, th, orb_dist, ori)
+            onm, onew = oracle_mod.search_by_projection_reloc(oframes[cur_slot], Tcw[cur_slot], 1.2, 8, pts, descs, angles, skip,
+                                                              matched, th, orb_dist, ori)
+            assert nm == onm and np.array_equal(new, onew), (cur_slot, kf, th, ori)
+            assert (new[matched == 1] == -1).all() and (new >= 0).sum() == nm
+            total += nm
+    assert total > 1500
