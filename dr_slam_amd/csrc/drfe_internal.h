@@ -60,6 +60,7 @@ struct DevGeom {
     int pyrSlotBytes, blurSlotBytes;
     int candSlotElems, kpSlotElems; /* per-slot element counts */
     int totalCells, totalTiles;
+    int fastMaxWh;                  /* tallest FAST cell window of this geometry: sizes the kernel's dynamic LDS */
     DevLevel lv[DRFE_MAX_LEVELS];
 };
 

@@ -101,6 +101,7 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
     g->iniTh = c->cfg.ini_th_fast;
     g->minTh = c->cfg.min_th_fast;
     g->imgW = w; g->imgH = h;
+    g->fastMaxWh = 7;
     int pyrOff = 0, blurOff = 0, candOff = 0, kpOff = 0;
     if (cells) cells->clear();
     if (tiles) tiles->clear();
@@ -166,6 +167,7 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
                 fc.offX = (uint16_t)(j * L.wCell); fc.offY = (uint16_t)(i * L.hCell);
                 fc.cellIdx = (uint32_t)(i * L.nCols + j);
                 if (cells) cells->push_back(fc);
+                if (wh > g->fastMaxWh) g->fastMaxWh = wh;
                 /* strict 3x3 maxima: at most one per 2x2 block of the evaluated area */
                 candCap += ((ww - 6 + 1) / 2) * ((wh - 6 + 1) / 2);
             }

@@ -245,8 +245,10 @@ __device__ __forceinline__ u16x2 umin2(u16x2 a, u16x2 b) { return __builtin_elem
 /* The arithmetic runs on the packed HALF-FLOAT pipe: an integer n in [-1023, 1023] written into a 16-bit
  * lane as sign|magnitude IS the f16 subnormal n * 2^-24, subnormal add/sub/min/max are exact (f16
  * denormals are never flushed in this code object: .amdhsa_float_denorm_mode_16_64 3), and gfx950 has
- * three-input packed min/max (v_pk_minimum3_f16 / v_pk_maximum3_f16) which the integer pipe lacks:
- * 17 sub + 2*(8+8+8+8+4) + 3 = 92 packed ops for two pixels instead of 120. */
+ * three-input packed min/max (v_pk_minimum3_f16 / v_pk_maximum3_f16) which the integer pipe lacks.
+ * The trees run on the ring pixels themselves, not on the 16 differences: min over an arc of (v - p) is v - max over
+ * the arc of p, so the centre is subtracted twice at the end instead of 16 times at the start:
+ * 2*(8+8+8+8+4) + 5 = 77 packed ops for two pixels instead of 120 (integer pipe) or 92 (differences first). */
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h16x2 hpk(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(h16x2, lo | (hi << 16)); }
 __device__ __forceinline__ h16x2 hmin(h16x2 a, h16x2 b) { return __builtin_elementwise_minimum(a, b); }
@@ -254,15 +256,30 @@ __device__ __forceinline__ h16x2 hmax(h16x2 a, h16x2 b) { return __builtin_eleme
 __device__ __forceinline__ h16x2 hmin3(h16x2 a, h16x2 b, h16x2 c) { return hmin(hmin(a, b), c); }
 __device__ __forceinline__ h16x2 hmax3(h16x2 a, h16x2 b, h16x2 c) { return hmax(hmax(a, b), c); }
 
-/* returns strength(A) | strength(B) << 16 */
-__device__ __forceinline__ uint32_t fast_strength2(const uint8_t* cA, const uint8_t* cB, const int P)
+/* returns strength(A) | strength(B) << 16.
+ * FAST_ROWPAIR = 1 (experiment, slower so far): the window tile is row-interleaved — element (x, y) is the 16-bit word
+ * pixel(x, y) | pixel(x, y + 1) << 8 — so ONE ds_read_u16 brings the same ring position of A = (x, y) and of
+ * B = (x, y + 1) and one v_perm spreads the two bytes into the packed halves (an LDS read costs ~2.3 cycles per CU
+ * whatever its width, tools/ubench_lds.hip).  FAST_ROWPAIR = 0: byte tile, two ds_read_u8 and a v_lshl_or per ring
+ * position. */
+#ifndef FAST_ROWPAIR
+#define FAST_ROWPAIR 0
+#endif
+#if FAST_ROWPAIR
+typedef uint16_t fast_px;
+__device__ __forceinline__ h16x2 hpair(const fast_px* c, int i, int) { return __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0u, (uint32_t)c[i], 0x0C010C00u)); }
+#else
+typedef uint8_t fast_px;
+__device__ __forceinline__ h16x2 hpair(const fast_px* c, int i, int P) { return hpk(c[i], c[i + P]); }
+#endif
+__device__ __forceinline__ uint32_t fast_strength2(const fast_px* c, const int P)
 {
-    /* cA / cB point at the top-left corner of the 7x7 patch, so every ring offset is a non-negative
-     * immediate of the LDS load */
+    /* c points at the top-left corner of A's 7x7 patch (B = the pixel below A), so every ring offset is a
+     * non-negative immediate of the LDS load */
     const int C = 3 * P + 3;
-    const h16x2 v = hpk(cA[C], cB[C]);
-    h16x2 d[16];
-#define RING(k, o) d[k] = v - hpk(cA[C + (o)], cB[C + (o)])
+    const h16x2 v = hpair(c, C, P);
+    h16x2 d[16];                            /* the ring pixels p[k] (as exact f16 subnormals) */
+#define RING(k, o) d[k] = hpair(c, C + (o), P)
     RING(0, 3 * P);       RING(1, 3 * P + 1);   RING(2, 2 * P + 2);    RING(3, P + 3);
     RING(4, 3);           RING(5, -P + 3);      RING(6, -2 * P + 2);   RING(7, -3 * P + 1);
     RING(8, -3 * P);      RING(9, -3 * P - 1);  RING(10, -2 * P - 2);  RING(11, -P - 3);
@@ -279,20 +296,31 @@ __device__ __forceinline__ uint32_t fast_strength2(const uint8_t* cA, const uint
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         const h16x2 e0 = d[2 * m], e1 = d[(2 * m + 9) & 15];   /* d[j-1], d[j+8] */
-        t[m] = hmin3(lo4[m], lo4[(m + 2) & 7], hmax(e0, e1));  /* min(d[j..j+7], max(d[j-1], d[j+8])) */
+        t[m] = hmin3(lo4[m], lo4[(m + 2) & 7], hmax(e0, e1));  /* min(p[j..j+7], max(p[j-1], p[j+8])) */
         u[m] = hmax3(hi4[m], hi4[(m + 2) & 7], hmin(e0, e1));
     }
+    /* a = the brightest arc floor, b = the darkest arc ceiling: S_bright = a - v, S_dark = v - b */
     const h16x2 a = hmax(hmax3(hmax3(t[0], t[1], t[2]), t[3], t[4]), hmax3(t[5], t[6], t[7]));
     const h16x2 b = hmin(hmin3(hmin3(u[0], u[1], u[2]), u[3], u[4]), hmin3(u[5], u[6], u[7]));
     const h16x2 one = __builtin_bit_cast(h16x2, 0x00010001u), zero = __builtin_bit_cast(h16x2, 0u);
-    const h16x2 r = hmax(hmax(a, -b) - one, zero);
+    const h16x2 r = hmax(hmax(a - v, v - b) - one, zero);
     return __builtin_bit_cast(uint32_t, r);
 }
 
-#define FAST_TILE_PITCH 68                       /* LDS bytes per window row: 16 data dwords + 1 pad dword so that
-                                                    lanes two rows apart (the packed A/B pixels) hit different banks */
+#define FAST_TILE_PITCH 68                       /* pixels per window-tile row: 16 data dwords + 1 pad dword so that lanes two
+                                                    rows apart hit different banks */
 #define FAST_MAX_EVAL (DRFE_FAST_MAX_WIN - 6)    /* 54 */
 #define FAST_SC_PITCH 64
+
+/* LDS bytes of k_fast_cells for windows up to maxWh rows: tile rows (one spare row in the byte layout: the unstored B pixel
+ * of an odd-height area reads it), then (maxWh - 6 + 2) score rows */
+#if FAST_ROWPAIR
+#define FAST_TILE_ROW_BYTES (FAST_TILE_PITCH * 2)
+#else
+#define FAST_TILE_ROW_BYTES FAST_TILE_PITCH
+#endif
+static inline int fast_sc_off(int maxWh) { return ((maxWh + 1) * FAST_TILE_ROW_BYTES + 15) & ~15; }
+static inline int fast_lds_bytes(int maxWh) { return fast_sc_off(maxWh) + (maxWh - 6 + 2) * FAST_SC_PITCH; }
 
 /* One wavefront per FAST cell (one cv::FAST call of the reference).  Window rows arrive as aligned
  * dwords; each lane scores ~16 pixels; the strict-3x3-maximum flags stay in two 64-bit lane masks
@@ -302,10 +330,17 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
                                                    int candSlotElems, int iniTh, int minTh,
                                                    const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
                                                    uint32_t* __restrict__ cand1, int* __restrict__ candCount,
-                                                   int* __restrict__ status)
+                                                   int* __restrict__ status, int scOff)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[DRFE_FAST_MAX_WIN * (FAST_TILE_PITCH / 4)];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[(FAST_MAX_EVAL + 2) * FAST_SC_PITCH];
+    /* dynamic LDS sized for the tallest cell window of this geometry (36 rows for 30-px cells, not the 60-row worst
+     * case): window tile, then the score tile at byte scOff (fast_lds_bytes below) */
+    extern __shared__ __attribute__((aligned(16))) unsigned char fastLds[];
+#if FAST_ROWPAIR
+    uint2* tile = reinterpret_cast<uint2*>(fastLds);                 /* 4 words each */
+#else
+    uint32_t* tile = reinterpret_cast<uint32_t*>(fastLds);
+#endif
+    uint8_t* sc = fastLds + scOff;
 
     const FastCell fc = cells[blockIdx.x];        /* everything below depends on this one record only */
     const int slot = blockIdx.y;
@@ -316,25 +351,33 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
     const uint8_t* src = pyr + (size_t)slot * pyrSlotBytes + fc.srcOff;
     const int wpr = (ww + off + 3) >> 2;          /* dwords per window row (<= 16) */
     {
+        /* row r interleaved with row r + 1 (the last row with itself: only an unstored B pixel reads it) */
         const int c = lane & 15;
         if (c < wpr)
-            for (int r = lane >> 4; r < wh; r += 4)
-                tile[r * (FAST_TILE_PITCH / 4) + c] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * fc.pitch + c * 4);
+            for (int r = lane >> 4; r < wh; r += 4) {
+                const uint32_t g0 = *reinterpret_cast<const uint32_t*>(src + (size_t)r * fc.pitch + c * 4);
+#if FAST_ROWPAIR
+                const uint32_t g1 = *reinterpret_cast<const uint32_t*>(src + (size_t)min(r + 1, wh - 1) * fc.pitch + c * 4);
+                tile[r * (FAST_TILE_PITCH / 4) + c] = make_uint2(__builtin_amdgcn_perm(g1, g0, 0x05010400u),
+                                                                 __builtin_amdgcn_perm(g1, g0, 0x07030602u));
+#else
+                tile[r * (FAST_TILE_PITCH / 4) + c] = g0;
+#endif
+            }
     }
     /* score tile: pixel (x, y) of the evaluated area lives at byte (y+1)*64 + (x+4); everything else
      * (apron rows 0 / eh+1, bytes left of 4 and right of ew+3) stays 0 = "neighbour outside the cell" */
     for (int i = lane; i < (eh + 2) * (FAST_SC_PITCH / 16); i += 64) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile) + off;   /* tb[y*PITCH + x] = window pixel (x, y) */
+    const fast_px* tb = reinterpret_cast<const fast_px*>(tile) + off;   /* tb[y*PITCH + x] = window pixel (x, y) [| (x, y+1) << 8] */
     {   /* score pass: item = two vertically adjacent pixels (rows 2r, 2r+1) of one column; (rp, x) of item
            lane + 64k is carried incrementally (no integer division in the loop) */
         const int nrp = (eh + 1) >> 1;
         const int q64 = 64 / ew, r64 = 64 - q64 * ew;
         int rp = lane / ew, x = lane - rp * ew;
         while (rp < nrp) {
-            const int yA = 2 * rp, yB = min(2 * rp + 1, eh - 1);       /* odd eh: B repeats A, not stored */
-            const uint32_t s2 = fast_strength2(&tb[__mul24(yA, FAST_TILE_PITCH) + x],
-                                               &tb[__mul24(yB, FAST_TILE_PITCH) + x], FAST_TILE_PITCH);
+            const int yA = 2 * rp;                                    /* odd eh: the last B is scored but not stored */
+            const uint32_t s2 = fast_strength2(&tb[__mul24(yA, FAST_TILE_PITCH) + x], FAST_TILE_PITCH);
             sc[(yA + 1) * FAST_SC_PITCH + (x + 4)] = (uint8_t)(s2 & 0xFF);
             if (2 * rp + 1 < eh) sc[(yA + 2) * FAST_SC_PITCH + (x + 4)] = (uint8_t)(s2 >> 16);
             rp += q64; x += r64;
@@ -831,12 +874,26 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
 /* orientation + rBRIEF + keypoint finishing: one wavefront per keypoint                             */
 
 #define DESC_DISC_PER_LANE 12                     /* ceil(749 / 64) */
+#ifndef DESC_KPW
 #define DESC_KPW 4                                /* keypoints a wavefront carries at once */
-#define DESC_REACH 19                             /* ceil(13 * sqrt(2)): how far the rotated pattern reaches */
-/* The kernel is latency-bound (key -> pixel gathers -> angle -> pattern gathers -> store: five dependent round trips,
- * ~10 us per wavefront under load), so a wavefront carries DESC_KPW keypoints through the phases together: their
- * loads of one phase are all in flight at once, and the lane-constant tables (disc offsets, pattern) are loaded once
- * per wavefront. */
+#endif
+#define DESC_REACH 18                             /* round(13 * sqrt(2)): how far the rotated pattern reaches; keypoints
+                                                     sit >= 19 px inside their level (16-px region + FAST's 3-px margin) */
+#define DESC_RAW_ROWS 31                          /* disc patch: rows y-15..y+15, 9 aligned dwords cover x-15..x+15 */
+#define DESC_RAW_DW 9
+#define DESC_BLUR_ROWS (2 * DESC_REACH + 1)       /* pattern patch: rows y-18..y+18, 10 aligned dwords cover x-18..x+18 */
+#define DESC_BLUR_DW 10
+#define DESC_RAW_N (DESC_RAW_ROWS * DESC_RAW_DW)      /* 279 dwords = 5 loads per lane */
+#define DESC_BLUR_N (DESC_BLUR_ROWS * DESC_BLUR_DW)   /* 370 dwords = 6 loads per lane */
+#define DESC_RAW_LD 5
+#define DESC_BLUR_LD 6
+#define DESC_LDS_DW 372
+/* A byte gather with 64 scattered addresses costs the texture path ~30 cycles per instruction, and a keypoint needs 20
+ * of them (12 for the moments, 8 for the pattern).  So each keypoint's two patches are fetched as aligned dwords along
+ * rows instead (11 coalesced loads), parked in a wave-private LDS region, and the 20 gathers become ds_read_u8.  A
+ * wavefront carries DESC_KPW keypoints through the phases together: every global load of the wave is issued up front,
+ * and the lane-constant tables (disc offsets, pattern) are loaded once per wavefront.  The raw patch and the blurred
+ * patch share the LDS region (LDS operations of one wave execute in order). */
 __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel,
@@ -846,19 +903,30 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
                                                      drfe_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                      int* __restrict__ kpCount, int maxKp)
 {
+    __shared__ uint32_t sPatch[256 / WAVE][DESC_KPW][DESC_LDS_DW];
     const int slot = blockIdx.y;
     const int lane = threadIdx.x & (WAVE - 1);
     /* first output index of this wave; readfirstlane makes it (and every level / pointer derived from it) wave-uniform
      * for the compiler: scalar ALU and SGPR base addresses instead of 64-bit vector address arithmetic per gather */
-    const int g0 = (blockIdx.x * (256 / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * DESC_KPW;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g0 = (blockIdx.x * (256 / WAVE) + wv) * DESC_KPW;
     const int nl = G->nlevels;
-    /* level of every output index: prefix sums of the per-level counts (level-major concatenation, :1103) */
-    int cnt[DRFE_MAX_LEVELS], total = 0;
-#pragma unroll
-    for (int l = 0; l < DRFE_MAX_LEVELS; l++) { cnt[l] = l < nl ? selCount[slot * nl + l] : 0; total += cnt[l]; }
+    /* level of every output index: prefix sums of the per-level counts (level-major concatenation, :1103), kept
+     * across lanes (lane l = level l) so that the lookup per keypoint is a compare, a ballot and a readlane instead of a
+     * 16-deep scalar select chain (the scalar unit was the busiest one in this kernel) */
+    const int cntL = lane < nl ? selCount[slot * nl + lane] : 0;
+    int incl = cntL;                              /* inclusive prefix inside the first row of 16 lanes: four DPP adds */
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);      /* row_shr:1, 0 shifted in */
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);      /* row_shr:2 */
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);      /* row_shr:4 */
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);      /* row_shr:8 */
+    static_assert(DRFE_MAX_LEVELS == 16, "the level prefix assumes one DPP row");
+    const int excl = incl - cntL;
+    const int total = __builtin_amdgcn_readlane(incl, DRFE_MAX_LEVELS - 1);
     if (g0 == 0 && lane == 0) kpCount[slot] = min(total, maxKp);
     if (g0 >= total || g0 >= maxKp) return;                   /* wave-uniform */
     int level[DESC_KPW], xi[DESC_KPW], yi[DESC_KPW], resp[DESC_KPW], pitchP[DESC_KPW], pitchB[DESC_KPW];
+    int shP[DESC_KPW], shB[DESC_KPW];             /* byte position of the patch's first column inside its first dword */
     bool live[DESC_KPW];
     const uint8_t* cP[DESC_KPW];
     const uint8_t* cB[DESC_KPW];
@@ -867,12 +935,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
     for (int j = 0; j < DESC_KPW; j++) {
         const int g = g0 + j;
         live[j] = g < total && g < maxKp;
-        int lv = 0, first = 0, run = 0;
-#pragma unroll
-        for (int l = 0; l < DRFE_MAX_LEVELS; l++) {
-            if (g >= run && g < run + cnt[l]) { lv = l; first = run; }
-            run += cnt[l];
-        }
+        /* levels whose run ends at or before g; empty levels share their end with the previous one and are skipped */
+        const int lv = live[j] ? __popcll(__ballot(lane < DRFE_MAX_LEVELS && g >= incl)) : 0;
+        const int first = __builtin_amdgcn_readlane(excl, lv);
         level[j] = lv;
         key[j] = live[j] ? sel[(size_t)slot * G->kpSlotElems + G->lv[lv].kpOff + (g - first)] : 0u;
     }
@@ -883,10 +948,38 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
         resp[j] = (int)(key[j] >> 24);
         pitchP[j] = L.pyrPitch; pitchB[j] = L.blurPitch;
         if (!live[j]) { xi[j] = L.minBX + 16; yi[j] = L.minBY + 16; }      /* a harmless in-bounds position */
-        /* top-left corners of the patches, so that every gather offset below is a non-negative 32-bit number the
-         * hardware adds to a scalar base: the disc reaches 15 px, the rotated pattern (|x|, |y| <= 13) 19 px */
-        cP[j] = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(yi[j] + DRFE_EDGE - 15) * L.pyrPitch + (xi[j] + DRFE_EDGE - 15);
-        cB[j] = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (ptrdiff_t)(yi[j] - DESC_REACH) * L.blurPitch + (xi[j] - DESC_REACH);
+        /* top-left corners of the patches, moved left to a dword boundary (slot and level offsets are multiples of
+         * 256, pitches of 64, the arenas come from hipMalloc): the disc reaches 15 px, the rotated pattern 18 px */
+        const size_t oP = (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(yi[j] + DRFE_EDGE - 15) * L.pyrPitch + (xi[j] + DRFE_EDGE - 15);
+        const size_t oB = (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)(yi[j] - DESC_REACH) * L.blurPitch + (xi[j] - DESC_REACH);
+        shP[j] = (int)(oP & 3); shB[j] = (int)(oB & 3);
+        cP[j] = pyr + (oP & ~(size_t)3);
+        cB[j] = blur + (oB & ~(size_t)3);
+    }
+    /* every global load of the wave: lane t of load k fetches dword (t / 9, t % 9) of the raw patch and (t / 10, t % 10)
+     * of the blurred one (t = lane + 64 k) */
+    uint32_t rw[DESC_KPW][DESC_RAW_LD], bw[DESC_KPW][DESC_BLUR_LD];
+    {
+        int rRow[DESC_RAW_LD], rCol[DESC_RAW_LD], bRow[DESC_BLUR_LD], bCol[DESC_BLUR_LD];
+#pragma unroll
+        for (int k = 0; k < DESC_RAW_LD; k++) {
+            const int t = min(lane + k * WAVE, DESC_RAW_N - 1);               /* the tail repeats the last dword */
+            rRow[k] = (int)(__umul24(t, 7282) >> 16); rCol[k] = (t - __mul24(rRow[k], DESC_RAW_DW)) * 4;
+        }
+#pragma unroll
+        for (int k = 0; k < DESC_BLUR_LD; k++) {
+            const int t = min(lane + k * WAVE, DESC_BLUR_N - 1);
+            bRow[k] = (int)(__umul24(t, 6554) >> 16); bCol[k] = (t - __mul24(bRow[k], DESC_BLUR_DW)) * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < DESC_KPW; j++) {
+#pragma unroll
+            for (int k = 0; k < DESC_RAW_LD; k++)
+                rw[j][k] = *reinterpret_cast<const uint32_t*>(cP[j] + (uint32_t)(__mul24(rRow[k], pitchP[j]) + rCol[k]));   /* 24-bit multiply: full rate */
+#pragma unroll
+            for (int k = 0; k < DESC_BLUR_LD; k++)
+                bw[j][k] = *reinterpret_cast<const uint32_t*>(cB[j] + (uint32_t)(__mul24(bRow[k], pitchB[j]) + bCol[k]));
+        }
     }
     /* IC_Angle on the unblurred level: integer moments over the radius-15 disc (749 px = 12 offsets per lane) */
     const uint32_t* disc32 = reinterpret_cast<const uint32_t*>(disc);         /* u | v << 16, int16 each */
@@ -905,7 +998,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
 #pragma unroll
         for (int j = 0; j < DESC_KPW; j++)
 #pragma unroll
-            for (int k = 0; k < DESC_DISC_PER_LANE; k++) I[j][k] = cP[j][(uint32_t)((dv[k] + 15) * pitchP[j] + (du[k] + 15))];
+            for (int k = 0; k < DESC_RAW_LD; k++) {
+                const int t = lane + k * WAVE;
+                if (t < DESC_RAW_N) sPatch[wv][j][t] = rw[j][k];
+            }
+#pragma unroll
+        for (int j = 0; j < DESC_KPW; j++) {
+            const uint8_t* pb = reinterpret_cast<const uint8_t*>(sPatch[wv][j]) + shP[j];
+#pragma unroll
+            for (int k = 0; k < DESC_DISC_PER_LANE; k++) I[j][k] = pb[__mul24(dv[k] + 15, DESC_RAW_DW * 4) + (du[k] + 15)];
+        }
 #pragma unroll
         for (int j = 0; j < DESC_KPW; j++) {
             m10[j] = 0; m01[j] = 0;
@@ -944,17 +1046,26 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
             sinA[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sn), j));
         }
     }
+    /* the blurred patches take over the LDS regions (the moment reads above are done: same wave, in order) */
+#pragma unroll
+    for (int j = 0; j < DESC_KPW; j++)
+#pragma unroll
+        for (int k = 0; k < DESC_BLUR_LD; k++) {
+            const int t = lane + k * WAVE;
+            if (t < DESC_BLUR_N) sPatch[wv][j][t] = bw[j][k];
+        }
     int t0[DESC_KPW][4], t1[DESC_KPW][4];
 #pragma unroll
     for (int j = 0; j < DESC_KPW; j++) {
         const float a = cosA[j], b = sinA[j];
+        const uint8_t* pb = reinterpret_cast<const uint8_t*>(sPatch[wv][j]) + shB[j];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint32_t q4 = pat[r];
             const float x0 = (float)(int8_t)(q4 & 0xFF), y0 = (float)(int8_t)((q4 >> 8) & 0xFF);
             const float x1 = (float)(int8_t)((q4 >> 16) & 0xFF), y1 = (float)(int8_t)(q4 >> 24);
-            t0[j][r] = cB[j][(uint32_t)((drfe_round_half_even(x0 * b + y0 * a) + DESC_REACH) * pitchB[j] + (drfe_round_half_even(x0 * a - y0 * b) + DESC_REACH))];
-            t1[j][r] = cB[j][(uint32_t)((drfe_round_half_even(x1 * b + y1 * a) + DESC_REACH) * pitchB[j] + (drfe_round_half_even(x1 * a - y1 * b) + DESC_REACH))];
+            t0[j][r] = pb[__mul24(drfe_round_half_even(x0 * b + y0 * a) + DESC_REACH, DESC_BLUR_DW * 4) + (drfe_round_half_even(x0 * a - y0 * b) + DESC_REACH)];
+            t1[j][r] = pb[__mul24(drfe_round_half_even(x1 * b + y1 * a) + DESC_REACH, DESC_BLUR_DW * 4) + (drfe_round_half_even(x1 * a - y1 * b) + DESC_REACH)];
         }
     }
 #pragma unroll
@@ -1032,9 +1143,9 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_PYRAMID, s);
 
     prof_begin(c, DRFE_STAGE_FAST, s);
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), 0, s, c->d_cells, g.nlevels, g.pyrSlotBytes,
-                       g.candSlotElems, g.iniTh, g.minTh, c->d_pyr,
-                       c->d_cand0, c->d_cand1, c->d_candCount, c->d_status);
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), (size_t)fast_lds_bytes(g.fastMaxWh), s, c->d_cells,
+                       g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr,
+                       c->d_cand0, c->d_cand1, c->d_candCount, c->d_status, fast_sc_off(g.fastMaxWh));
     prof_end(c, DRFE_STAGE_FAST, s);
 
     prof_begin(c, DRFE_STAGE_QUADTREE, s);
