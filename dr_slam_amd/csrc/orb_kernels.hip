@@ -1054,18 +1054,37 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
             const int t = lane + k * WAVE;
             if (t < DESC_BLUR_N) sPatch[wv][j][t] = bw[j][k];
         }
+    /* The rotated pattern on the packed-f32 pipe: points 0 and 1 of a pair ride in one 64-bit register pair, so every
+     * product and sum is one v_pk_*_f32 for both (each product and each sum still rounds on its own: no fused
+     * multiply-add).  cvRound is the float add of 1.5 * 2^23: the sum's ulp is 1 there, round-to-nearest-even, and the
+     * integer sits in the mantissa (0x4B400000 + n); v_mad_u32_u24 takes the low 24 bits of the row word (0x400000 + ry)
+     * times the LDS row pitch plus the whole column word, and the constant excess is subtracted once. */
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 PX[4], PY[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t q4 = pat[r];
+        PX[r] = f32x2{(float)(int8_t)(q4 & 0xFF), (float)(int8_t)((q4 >> 16) & 0xFF)};
+        PY[r] = f32x2{(float)(int8_t)((q4 >> 8) & 0xFF), (float)(int8_t)(q4 >> 24)};
+    }
+    const f32x2 magic = {12582912.0f, 12582912.0f};
+    const uint32_t excess = 0x400000u * (DESC_BLUR_DW * 4) + 0x4B400000u;       /* what the two biased words add */
     int t0[DESC_KPW][4], t1[DESC_KPW][4];
 #pragma unroll
     for (int j = 0; j < DESC_KPW; j++) {
-        const float a = cosA[j], b = sinA[j];
-        const uint8_t* pb = reinterpret_cast<const uint8_t*>(sPatch[wv][j]) + shB[j];
+        const f32x2 a = {cosA[j], cosA[j]}, b = {sinA[j], sinA[j]};
+        /* the patch centre: (DESC_REACH, DESC_REACH) of the staged rows, plus the dword-alignment shift */
+        const uint8_t* pc = reinterpret_cast<const uint8_t*>(sPatch[wv][j]) + shB[j] + DESC_REACH * (DESC_BLUR_DW * 4) + DESC_REACH;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const uint32_t q4 = pat[r];
-            const float x0 = (float)(int8_t)(q4 & 0xFF), y0 = (float)(int8_t)((q4 >> 8) & 0xFF);
-            const float x1 = (float)(int8_t)((q4 >> 16) & 0xFF), y1 = (float)(int8_t)(q4 >> 24);
-            t0[j][r] = pb[__mul24(drfe_round_half_even(x0 * b + y0 * a) + DESC_REACH, DESC_BLUR_DW * 4) + (drfe_round_half_even(x0 * a - y0 * b) + DESC_REACH)];
-            t1[j][r] = pb[__mul24(drfe_round_half_even(x1 * b + y1 * a) + DESC_REACH, DESC_BLUR_DW * 4) + (drfe_round_half_even(x1 * a - y1 * b) + DESC_REACH)];
+            const f32x2 ry = (PX[r] * b + PY[r] * a) + magic;      /* cvRound(x*b + y*a) */
+            const f32x2 rx = (PX[r] * a - PY[r] * b) + magic;      /* cvRound(x*a - y*b) */
+            /* elements copied to scalars first: __builtin_bit_cast applied to `v.y` directly reads element 0 (clang) */
+            const float ry0 = ry.x, ry1 = ry.y, rx0 = rx.x, rx1 = rx.y;
+            const uint32_t i0 = __umul24(__float_as_uint(ry0), DESC_BLUR_DW * 4) + __float_as_uint(rx0) - excess;
+            const uint32_t i1 = __umul24(__float_as_uint(ry1), DESC_BLUR_DW * 4) + __float_as_uint(rx1) - excess;
+            t0[j][r] = pc[(int)i0];
+            t1[j][r] = pc[(int)i1];
         }
     }
 #pragma unroll
