@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames rendered per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
@@ -190,11 +190,12 @@ def main():
         kname = {"pyramid": "k_pyr_resize", "fast": "k_fast_cells", "blur": "k_blur", "desc": "k_orient_desc",
                  "match": "k_window_candidates"}[roof_stage]
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_b256.json")))
+            pmc_name = "r01_pmc_traffic_b%d.json" % B
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
                 k = pmc["kernels"][kname]
                 traffic = (k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
-                traffic_src = "profiles/r01_pmc_traffic_b256.json (raw FETCH_SIZE+WRITE_SIZE, see its _about)"
+                traffic_src = "profiles/%s (raw FETCH_SIZE+WRITE_SIZE, see its _about)" % pmc_name
         except Exception:
             pass
         fps = total_frames / el
