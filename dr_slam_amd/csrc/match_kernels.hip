@@ -235,51 +235,63 @@ __global__ __launch_bounds__(256) void k_queries_last(const MatchPair* __restric
 }
 
 /* ------------------------------------------------------------------------------------------------ */
-/* window gather + Hamming: one wavefront per query                                                  */
+/* window gather + Hamming: a quarter wavefront per query, a whole one for the rare wide window       */
 
-__global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __restrict__ pairs,
-                                                           const MatchQuery* __restrict__ queries,
-                                                           const int* __restrict__ kpCount, int maxKp,
-                                                           const int* __restrict__ gridOff,
-                                                           const uint4* __restrict__ cellKp,
-                                                           const uint4* __restrict__ cellDesc, drfe_camera cam,
-                                                           float invW, float invH,
-                                                           uint32_t* __restrict__ candIdx,
-                                                           uint32_t* __restrict__ candKey,
-                                                           int* __restrict__ candCnt, uint2* __restrict__ candBest,
-                                                           int* __restrict__ status)
+/* Frame::GetFeaturesInArea cell range, src/Frame.cc:735-749; false when the window misses the grid */
+__device__ __forceinline__ bool window_cells(const MatchQuery& q, const drfe_camera& cam, float invW, float invH, int& minX,
+                                             int& maxX, int& minY, int& maxY)
 {
-    const MatchPair P = pairs[blockIdx.y];
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   /* wave-uniform for the compiler */
-    const int qi = blockIdx.x * (256 / WAVE) + wv;
-    const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
-    if (qi >= nQ) return;                       /* wave-uniform */
-    const size_t qo = (size_t)P.queryBase + qi;
-    const MatchQuery q = queries[qo];
-    if (!q.valid) { if (lane == 0) { candCnt[qo] = 0; candBest[qo] = make_uint2(0xFFFFFFFFu, 0u); } return; }
     const float x = q.u, y = q.v, r = q.radius;
-    /* Frame::GetFeaturesInArea cell range, src/Frame.cc:735-749 */
-    const int nMinCellX = max(0, (int)floorf((x - cam.min_x - r) * invW));
-    const int nMaxCellX = min(DRFE_GRID_COLS - 1, (int)ceilf((x - cam.min_x + r) * invW));
-    const int nMinCellY = max(0, (int)floorf((y - cam.min_y - r) * invH));
-    const int nMaxCellY = min(DRFE_GRID_ROWS - 1, (int)ceilf((y - cam.min_y + r) * invH));
-    if (nMinCellX >= DRFE_GRID_COLS || nMaxCellX < 0 || nMinCellY >= DRFE_GRID_ROWS || nMaxCellY < 0) {
-        if (lane == 0) { candCnt[qo] = 0; candBest[qo] = make_uint2(0xFFFFFFFFu, 0u); }
-        return;
+    minX = max(0, (int)floorf((x - cam.min_x - r) * invW));
+    maxX = min(DRFE_GRID_COLS - 1, (int)ceilf((x - cam.min_x + r) * invW));
+    minY = max(0, (int)floorf((y - cam.min_y - r) * invH));
+    maxY = min(DRFE_GRID_ROWS - 1, (int)ceilf((y - cam.min_y + r) * invH));
+    return !(minX >= DRFE_GRID_COLS || maxX < 0 || minY >= DRFE_GRID_ROWS || maxY < 0);
+}
+
+/* one candidate record against one query: the level, window and stereo gates of the reference's inner loop, then
+ * the Hamming distance; returns false when the record is skipped */
+__device__ __forceinline__ bool window_candidate(const MatchQuery& q, bool bCheckLevels, const uint4* __restrict__ cK,
+                                                 const uint4* __restrict__ cD, int p, int sq, uint64_t q0, uint64_t q1,
+                                                 uint64_t q2, uint64_t q3, uint32_t& key, uint32_t& id)
+{
+    const uint4 k4 = cK[p];
+    const uint4 da = cD[2 * p], db = cD[2 * p + 1];
+    const float kx = __uint_as_float(k4.x), ky = __uint_as_float(k4.y), ur = __uint_as_float(k4.z);
+    const int oct = (int)(k4.w >> 24);
+    bool ok = true;
+    if (bCheckLevels) {
+        if (oct < q.minLevel) ok = false;
+        if (q.maxLevel >= 0 && oct > q.maxLevel) ok = false;
     }
+    const float dx = kx - q.u, dy = ky - q.v;
+    if (!(fabsf(dx) < q.radius && fabsf(dy) < q.radius)) ok = false;
+    if (ur > 0) {
+        const float er = fabsf(q.ur - ur);
+        if (er > q.thrR) ok = false;
+    }
+    if (!ok) return false;
+    const int dist = __popcll(q0 ^ ((uint64_t)da.x | ((uint64_t)da.y << 32))) + __popcll(q1 ^ ((uint64_t)da.z | ((uint64_t)da.w << 32))) +
+                     __popcll(q2 ^ ((uint64_t)db.x | ((uint64_t)db.y << 32))) + __popcll(q3 ^ ((uint64_t)db.z | ((uint64_t)db.w << 32)));
+    key = ((uint32_t)dist << 22) | (uint32_t)min(sq, (1 << 22) - 1);
+    id = k4.w;
+    return true;
+}
+
+/* A whole wavefront on one query (windows wider than 16 grid columns or with more than WQ_TAB records).
+ * The reference scans cells ix-outer / iy-inner and each cell in insertion order: in the cell-sorted arrays that is,
+ * per window column, ONE contiguous run [gOff[ix][minY], gOff[ix][maxY+1]).  Lane c owns column c (<= 64 columns); a
+ * wave scan turns the run lengths into visit positions, and from then on lanes work on candidates, not cells. */
+__device__ void window_query_wave(const MatchQuery& q, size_t qo, int lane, int nMinCellX, int nMaxCellX, int nMinCellY, int nMaxCellY,
+                                  const int* __restrict__ gOff, const uint4* __restrict__ cK, const uint4* __restrict__ cD,
+                                  uint32_t* __restrict__ candIdx, uint32_t* __restrict__ candKey, int* __restrict__ candCnt,
+                                  uint2* __restrict__ candBest, int* __restrict__ status)
+{
     const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
-    const int cur = P.curSlot;
-    const int* gOff = gridOff + (size_t)cur * (DRFE_GRID_CELLS + 1);
-    const uint4* cK = cellKp + (size_t)cur * maxKp;
-    const uint4* cD = cellDesc + (size_t)cur * maxKp * 2;
     uint32_t* oIdx = candIdx + qo * DRFE_MATCH_MAX_CAND;
     uint32_t* oKey = candKey + qo * DRFE_MATCH_MAX_CAND;
     const uint64_t q0 = (uint64_t)q.desc[0] | ((uint64_t)q.desc[1] << 32), q1 = (uint64_t)q.desc[2] | ((uint64_t)q.desc[3] << 32),
                    q2 = (uint64_t)q.desc[4] | ((uint64_t)q.desc[5] << 32), q3 = (uint64_t)q.desc[6] | ((uint64_t)q.desc[7] << 32);
-    /* The reference scans cells ix-outer / iy-inner and each cell in insertion order: in the cell-sorted
-     * arrays that is, per window column, ONE contiguous run [gOff[ix][minY], gOff[ix][maxY+1]).  Lane c
-     * owns column c (<= 64 columns); a wave scan turns the run lengths into visit positions, and from
-     * then on lanes work on candidates, not cells. */
     const int ncol = nMaxCellX - nMinCellX + 1;
     int runB = 0, runN = 0;
     if (lane < ncol) {
@@ -307,31 +319,7 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
             const int inclJ = __builtin_amdgcn_readlane(incl, j), nextB = __builtin_amdgcn_readlane(runB, j + 1);
             if (inclJ <= sq) base = nextB - inclJ;
         }
-        if (sq < T) {
-            const int p = base + sq;
-            const uint4 k4 = cK[p];
-            const uint4 da = cD[2 * p], db = cD[2 * p + 1];
-            const float kx = __uint_as_float(k4.x), ky = __uint_as_float(k4.y), ur = __uint_as_float(k4.z);
-            const int oct = (int)(k4.w >> 24);
-            bool ok = true;
-            if (bCheckLevels) {
-                if (oct < q.minLevel) ok = false;
-                if (q.maxLevel >= 0 && oct > q.maxLevel) ok = false;
-            }
-            const float dx = kx - x, dy = ky - y;
-            if (!(fabsf(dx) < r && fabsf(dy) < r)) ok = false;
-            if (ur > 0) {
-                const float er = fabsf(q.ur - ur);
-                if (er > q.thrR) ok = false;
-            }
-            if (ok) {
-                const int dist = __popcll(q0 ^ ((uint64_t)da.x | ((uint64_t)da.y << 32))) + __popcll(q1 ^ ((uint64_t)da.z | ((uint64_t)da.w << 32))) +
-                                 __popcll(q2 ^ ((uint64_t)db.x | ((uint64_t)db.y << 32))) + __popcll(q3 ^ ((uint64_t)db.z | ((uint64_t)db.w << 32)));
-                key = ((uint32_t)dist << 22) | (uint32_t)min(sq, (1 << 22) - 1);
-                id = k4.w;
-                pass = true;
-            }
-        }
+        if (sq < T) pass = window_candidate(q, bCheckLevels, cK, cD, base + sq, sq, q0, q1, q2, q3, key, id);
         const unsigned long long m = __ballot(pass);
         const int pos = nOut + __popcll(m & ((1ull << lane) - 1ull));
         if (pass) {
@@ -354,6 +342,111 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
     if (lane == 0) {
         candCnt[qo] = min(nOut, DRFE_MATCH_MAX_CAND);
         candBest[qo] = make_uint2(mn, bIdx);
+    }
+}
+
+#define WQ_TAB 64                                /* visit positions a quarter wave handles; longer windows take a whole wave */
+/* Typical windows hold 5-40 records in 4-12 grid columns, so a whole wavefront per query idles most of its lanes and the
+ * kernel is bound by instruction issue.  Here a wavefront takes FOUR queries, 16 lanes each: lane = column for the
+ * run lengths (DPP row prefix), the column owners scatter the record positions of their runs into a 64-entry LDS table
+ * in visit order, then lane = candidate, 16 at a time; compaction positions come from the query's 16-bit slice of the
+ * ballot, the minimum from a DPP row reduction.  Output is identical to the whole-wave routine, which still handles the
+ * queries whose window is wider than 16 columns or longer than WQ_TAB records. */
+__global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __restrict__ pairs,
+                                                           const MatchQuery* __restrict__ queries,
+                                                           const int* __restrict__ kpCount, int maxKp,
+                                                           const int* __restrict__ gridOff,
+                                                           const uint4* __restrict__ cellKp,
+                                                           const uint4* __restrict__ cellDesc, drfe_camera cam,
+                                                           float invW, float invH,
+                                                           uint32_t* __restrict__ candIdx,
+                                                           uint32_t* __restrict__ candKey,
+                                                           int* __restrict__ candCnt, uint2* __restrict__ candBest,
+                                                           int* __restrict__ status)
+{
+    __shared__ int sTab[256 / WAVE][4][WQ_TAB];
+    const MatchPair P = pairs[blockIdx.y];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   /* wave-uniform for the compiler */
+    const int g = lane >> 4, l = lane & 15;
+    const int qbase = (blockIdx.x * (256 / WAVE) + wv) * 4;
+    const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
+    if (qbase >= nQ) return;                     /* wave-uniform */
+    const int cur = P.curSlot;
+    const int* gOff = gridOff + (size_t)cur * (DRFE_GRID_CELLS + 1);
+    const uint4* cK = cellKp + (size_t)cur * maxKp;
+    const uint4* cD = cellDesc + (size_t)cur * maxKp * 2;
+    const bool have = qbase + g < nQ;
+    const size_t qo = (size_t)P.queryBase + (have ? qbase + g : qbase);
+    const MatchQuery q = queries[qo];
+    int nMinCellX = 0, nMaxCellX = 0, nMinCellY = 0, nMaxCellY = 0;
+    const bool inRange = have && q.valid && window_cells(q, cam, invW, invH, nMinCellX, nMaxCellX, nMinCellY, nMaxCellY);
+    const int ncol = nMaxCellX - nMinCellX + 1;
+    /* lane = column: run of records per window column, inclusive prefix inside the row of 16 lanes */
+    int runB = 0, runN = 0;
+    const bool narrow = inRange && ncol <= 16;
+    if (narrow && l < ncol) {
+        const int cb = (nMinCellX + l) * DRFE_GRID_ROWS;
+        runB = gOff[cb + nMinCellY];
+        runN = gOff[cb + nMaxCellY + 1] - runB;
+    }
+    int incl = runN;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);      /* row_shr:1, 0 shifted in */
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+    const int T = __shfl(incl, 15, 16);
+    const bool small = narrow && T <= WQ_TAB;    /* uniform inside the group */
+    /* column owners write the record position of every visit position of their run */
+    {
+        const int excl = incl - runN;
+        const int n = small ? runN : 0;
+        for (int k = 0; __any(k < n); k++)
+            if (k < n) sTab[wv][g][excl + k] = runB + k;
+    }
+    const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+    const uint64_t q0 = (uint64_t)q.desc[0] | ((uint64_t)q.desc[1] << 32), q1 = (uint64_t)q.desc[2] | ((uint64_t)q.desc[3] << 32),
+                   q2 = (uint64_t)q.desc[4] | ((uint64_t)q.desc[5] << 32), q3 = (uint64_t)q.desc[6] | ((uint64_t)q.desc[7] << 32);
+    uint32_t* oIdx = candIdx + qo * DRFE_MATCH_MAX_CAND;
+    uint32_t* oKey = candKey + qo * DRFE_MATCH_MAX_CAND;
+    const int Tg = small ? T : 0;
+    int nOut = 0;
+    uint32_t myKey = 0xFFFFFFFFu, myIdx = 0;
+    for (int s0 = 0; __any(s0 < Tg); s0 += 16) {
+        const int sq = s0 + l;
+        bool pass = false;
+        uint32_t key = 0xFFFFFFFFu, id = 0;
+        if (sq < Tg) pass = window_candidate(q, bCheckLevels, cK, cD, sTab[wv][g][sq], sq, q0, q1, q2, q3, key, id);
+        const uint32_t m16 = (uint32_t)(__ballot(pass) >> (g * 16)) & 0xFFFFu;
+        const int pos = nOut + __popc(m16 & ((1u << l) - 1u));
+        if (pass) {                              /* Tg <= WQ_TAB < DRFE_MATCH_MAX_CAND: no overflow on this path */
+            oIdx[pos] = id;
+            oKey[pos] = key;
+            if (key < myKey) { myKey = key; myIdx = id; }
+        }
+        nOut += __popc(m16);
+    }
+    /* group minimum of (key, lane): xor butterflies inside the row of 16 lanes */
+    uint32_t mn = myKey;
+    mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0xB1, 0xf, 0xf, false));     /* quad_perm [1,0,3,2] */
+    mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0x4E, 0xf, 0xf, false));     /* quad_perm [2,3,0,1] */
+    mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0x141, 0xf, 0xf, false));    /* row_half_mirror */
+    mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0x140, 0xf, 0xf, false));    /* row_mirror */
+    const uint32_t who16 = (uint32_t)(__ballot(myKey == mn) >> (g * 16)) & 0xFFFFu;
+    const uint32_t bIdx = (uint32_t)__shfl((int)myIdx, __ffs((int)who16) - 1, 16);
+    if (have && l == 0 && (small || !inRange)) {
+        candCnt[qo] = nOut;                                     /* 0 for an invalid query or a window off the grid */
+        candBest[qo] = small ? make_uint2(mn, bIdx) : make_uint2(0xFFFFFFFFu, 0u);
+    }
+    /* the wide or long windows of this quartet: the whole wavefront, one query at a time */
+    unsigned long long wide = __ballot(inRange && !small && l == 0);
+    while (wide) {
+        const int gg = (__ffsll((long long)wide) - 1) >> 4;
+        wide &= wide - 1;
+        const size_t qw = (size_t)P.queryBase + qbase + gg;
+        const MatchQuery qq = queries[qw];
+        int x0, x1, y0, y1;
+        window_cells(qq, cam, invW, invH, x0, x1, y0, y1);
+        window_query_wave(qq, qw, lane, x0, x1, y0, y1, gOff, cK, cD, candIdx, candKey, candCnt, candBest, status);
     }
 }
 
@@ -664,7 +757,7 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
-    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 3) / 4, npairs), dim3(256), 0, s, mb.d_pairs,
+    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 15) / 16, npairs), dim3(256), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
                        mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status);
     const size_t lds = (size_t)c->maxKp;

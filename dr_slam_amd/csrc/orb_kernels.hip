@@ -256,23 +256,10 @@ __device__ __forceinline__ h16x2 hmax(h16x2 a, h16x2 b) { return __builtin_eleme
 __device__ __forceinline__ h16x2 hmin3(h16x2 a, h16x2 b, h16x2 c) { return hmin(hmin(a, b), c); }
 __device__ __forceinline__ h16x2 hmax3(h16x2 a, h16x2 b, h16x2 c) { return hmax(hmax(a, b), c); }
 
-/* returns strength(A) | strength(B) << 16.
- * FAST_ROWPAIR = 1 (experiment, slower so far): the window tile is row-interleaved — element (x, y) is the 16-bit word
- * pixel(x, y) | pixel(x, y + 1) << 8 — so ONE ds_read_u16 brings the same ring position of A = (x, y) and of
- * B = (x, y + 1) and one v_perm spreads the two bytes into the packed halves (an LDS read costs ~2.3 cycles per CU
- * whatever its width, tools/ubench_lds.hip).  FAST_ROWPAIR = 0: byte tile, two ds_read_u8 and a v_lshl_or per ring
- * position. */
-#ifndef FAST_ROWPAIR
-#define FAST_ROWPAIR 0
-#endif
-#if FAST_ROWPAIR
-typedef uint16_t fast_px;
-__device__ __forceinline__ h16x2 hpair(const fast_px* c, int i, int) { return __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0u, (uint32_t)c[i], 0x0C010C00u)); }
-#else
-typedef uint8_t fast_px;
-__device__ __forceinline__ h16x2 hpair(const fast_px* c, int i, int P) { return hpk(c[i], c[i + P]); }
-#endif
-__device__ __forceinline__ uint32_t fast_strength2(const fast_px* c, const int P)
+/* returns strength(A) | strength(B) << 16: two ds_read_u8 and one v_lshl_or per ring position (DESIGN.md section 4 lists
+ * the alternatives that were measured: a row-interleaved 16-bit tile, d16 / d16_hi LDS loads) */
+__device__ __forceinline__ h16x2 hpair(const uint8_t* c, int i, int P) { return hpk(c[i], c[i + P]); }
+__device__ __forceinline__ uint32_t fast_strength2(const uint8_t* c, const int P)
 {
     /* c points at the top-left corner of A's 7x7 patch (B = the pixel below A), so every ring offset is a
      * non-negative immediate of the LDS load */
@@ -314,11 +301,7 @@ __device__ __forceinline__ uint32_t fast_strength2(const fast_px* c, const int P
 
 /* LDS bytes of k_fast_cells for windows up to maxWh rows: tile rows (one spare row in the byte layout: the unstored B pixel
  * of an odd-height area reads it), then (maxWh - 6 + 2) score rows */
-#if FAST_ROWPAIR
-#define FAST_TILE_ROW_BYTES (FAST_TILE_PITCH * 2)
-#else
 #define FAST_TILE_ROW_BYTES FAST_TILE_PITCH
-#endif
 static inline int fast_sc_off(int maxWh) { return ((maxWh + 1) * FAST_TILE_ROW_BYTES + 15) & ~15; }
 static inline int fast_lds_bytes(int maxWh) { return fast_sc_off(maxWh) + (maxWh - 6 + 2) * FAST_SC_PITCH; }
 
@@ -335,11 +318,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
     /* dynamic LDS sized for the tallest cell window of this geometry (36 rows for 30-px cells, not the 60-row worst
      * case): window tile, then the score tile at byte scOff (fast_lds_bytes below) */
     extern __shared__ __attribute__((aligned(16))) unsigned char fastLds[];
-#if FAST_ROWPAIR
-    uint2* tile = reinterpret_cast<uint2*>(fastLds);                 /* 4 words each */
-#else
     uint32_t* tile = reinterpret_cast<uint32_t*>(fastLds);
-#endif
     uint8_t* sc = fastLds + scOff;
 
     const FastCell fc = cells[blockIdx.x];        /* everything below depends on this one record only */
@@ -356,20 +335,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
         if (c < wpr)
             for (int r = lane >> 4; r < wh; r += 4) {
                 const uint32_t g0 = *reinterpret_cast<const uint32_t*>(src + (size_t)r * fc.pitch + c * 4);
-#if FAST_ROWPAIR
-                const uint32_t g1 = *reinterpret_cast<const uint32_t*>(src + (size_t)min(r + 1, wh - 1) * fc.pitch + c * 4);
-                tile[r * (FAST_TILE_PITCH / 4) + c] = make_uint2(__builtin_amdgcn_perm(g1, g0, 0x05010400u),
-                                                                 __builtin_amdgcn_perm(g1, g0, 0x07030602u));
-#else
                 tile[r * (FAST_TILE_PITCH / 4) + c] = g0;
-#endif
             }
     }
     /* score tile: pixel (x, y) of the evaluated area lives at byte (y+1)*64 + (x+4); everything else
      * (apron rows 0 / eh+1, bytes left of 4 and right of ew+3) stays 0 = "neighbour outside the cell" */
     for (int i = lane; i < (eh + 2) * (FAST_SC_PITCH / 16); i += 64) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const fast_px* tb = reinterpret_cast<const fast_px*>(tile) + off;   /* tb[y*PITCH + x] = window pixel (x, y) [| (x, y+1) << 8] */
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile) + off;   /* tb[y*PITCH + x] = window pixel (x, y) */
     {   /* score pass: item = two vertically adjacent pixels (rows 2r, 2r+1) of one column; (rp, x) of item
            lane + 64k is carried incrementally (no integer division in the loop) */
         const int nrp = (eh + 1) >> 1;
