@@ -169,11 +169,13 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
     uint8_t* base = pyr + (size_t)slot * pyrSlotBytes;
     const ResizeTap wx = taps[L.xwinOff + blockIdx.x], wy = taps[L.ywinOff + blockIdx.y];
     /* this thread's taps first: their latency overlaps the tile fill instead of following the barrier */
-    const int y0 = (blockIdx.y * 4 + threadIdx.y) * PYR_ROWS;
+    /* a wavefront is one row of the 64 x 4 block: its four output rows, their source rows and vertical weights are
+     * wave-uniform, and readfirstlane tells the compiler so (scalar row bases, scalar branches below) */
+    const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * PYR_ROWS;
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int bh = L.h + 2 * DRFE_EDGE;
     const bool active = y0 < bh && x4 < L.pyrPitch;
-    const int yT = active ? y0 : 0, xT = active ? x4 : 0;
+    const int yT = y0 < bh ? y0 : 0, xT = active ? x4 : 0;
     const uint4 tya = *reinterpret_cast<const uint4*>(taps + L.ytabOff + yT);
     const uint4 tyb = *reinterpret_cast<const uint4*>(taps + L.ytabOff + yT + 2);
     const uint4 ta = *reinterpret_cast<const uint4*>(taps + L.xtabOff + xT);
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
         }
     }
     __syncthreads();
-    if (!active) return;
+    if (y0 >= bh) return;                        /* wave-uniform; columns past the pitch compute on column 0 and store nothing */
     const uint32_t syp[PYR_ROWS] = {tya.x, tya.z, tyb.x, tyb.z}, wyp[PYR_ROWS] = {tya.y, tya.w, tyb.y, tyb.w};
     const uint32_t sp[4] = {ta.x, ta.z, tb.x, tb.z}, wp[4] = {ta.y, ta.w, tb.y, tb.w};
     int o0[4], o1[4], w0[4], w1[4];
@@ -202,22 +204,44 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
         o0[k] = (int)(sp[k] & 0xFFFF) + DRFE_EDGE - ws; o1[k] = (int)(sp[k] >> 16) + DRFE_EDGE - ws;
         w0[k] = (int)(short)(wp[k] & 0xFFFF); w1[k] = (int)(short)(wp[k] >> 16);
     }
+    /* horizontal pass of one source row for this thread's four columns, already shifted (the vertical pass only ever
+     * uses h >> 4) */
+    auto hrow = [&](int srow, uint32_t (&H)[4]) {
+        const uint8_t* R = &tile[srow * RES_PITCH];
+#pragma unroll
+        for (int k = 0; k < 4; k++) H[k] = (uint32_t)(((int)R[o0[k]] * w0[k] + (int)R[o1[k]] * w1[k]) >> 4);
+    };
+    /* Consecutive output rows mostly share a source row (scale 1.2: rows (s, s+1), (s+1, s+2), ...): the lower row's
+     * horizontal pass is kept for the next output row, 5 instead of 8 row passes per thread.  (b * h) >> 16 is the high
+     * half of h * (b << 16): one v_mul_hi_u32 instead of a multiply and a shift (weights and sums are non-negative). */
+    int prevB = -1;
+    uint32_t Hp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; r++) {
         if (y0 + r >= bh) break;
-        const uint8_t* R0 = &tile[((int)(syp[r] & 0xFFFF) - (int)wy.s0) * RES_PITCH];
-        const uint8_t* R1 = &tile[((int)(syp[r] >> 16) - (int)wy.s0) * RES_PITCH];
-        const int b0 = (int)(short)(wyp[r] & 0xFFFF), b1 = (int)(short)(wyp[r] >> 16);
+        const uint32_t sy = (uint32_t)__builtin_amdgcn_readfirstlane((int)syp[r]), wy2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wyp[r]);
+        const int a = (int)(sy & 0xFFFF) - (int)wy.s0, b = (int)(sy >> 16) - (int)wy.s0;
+        uint32_t Ha[4], Hb[4];
+        if (a == prevB) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) Ha[k] = Hp[k];
+        } else hrow(a, Ha);
+        if (b == a) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) Hb[k] = Ha[k];
+        } else hrow(b, Hb);
+        const uint32_t b0s = wy2 << 16, b1s = wy2 & 0xFFFF0000u;
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int h0 = (int)R0[o0[k]] * w0[k] + (int)R0[o1[k]] * w1[k];
-            const int h1 = (int)R1[o0[k]] * w0[k] + (int)R1[o1[k]] * w1[k];
-            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            int v = (int)(__umulhi(Ha[k], b0s) + __umulhi(Hb[k], b1s) + 2u) >> 2;
             v = min(255, max(0, v));
             out |= (uint32_t)v << (8 * k);
         }
-        *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)(y0 + r) * L.pyrPitch + x4) = out;
+        if (active) *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)(y0 + r) * L.pyrPitch + x4) = out;
+        prevB = b;
+#pragma unroll
+        for (int k = 0; k < 4; k++) Hp[k] = Hb[k];
     }
 }
 
