@@ -164,7 +164,9 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
 
 #define DRFE_RESIZE_LDS_WD 88     /* dwords per source row of the k_pyr_resize_lds tile (256 output columns * 1.25 + slack) */
 #define DRFE_RESIZE_LDS_ROWS 24   /* source rows of the tile (16 output rows * 1.25 + slack) */
-#define DRFE_BLUR_TW 64
-#define DRFE_BLUR_TH 128
+#ifndef DRFE_BLUR_TW
+#define DRFE_BLUR_TW 128      /* blur tile: 128 x 64 output pixels (full 128-byte lines per stored row, 9 % halo rows) */
+#define DRFE_BLUR_TH 64
+#endif
 
 #endif

@@ -806,11 +806,13 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
 /* Gaussian blur 7x7, sigma 2, 8.8 fixed point                                     */
 
 #define BLUR_ROWS (DRFE_BLUR_TH + 6)
-/* Tile = 64 x DRFE_BLUR_TH output pixels, thread = 4 horizontally adjacent pixels.  The source is the
+#define BLUR_COLG (DRFE_BLUR_TW / 4)             /* threads across a tile row (4 px each) */
+#define BLUR_ROWL (256 / BLUR_COLG)               /* tile rows a pass of the block covers */
+/* Tile = DRFE_BLUR_TW x DRFE_BLUR_TH output pixels, thread = 4 horizontally adjacent pixels.  The source is the
  * BORDERED pyramid level: its 19-px frame already holds the REFLECT_101 image of the interior, which is
  * exactly what GaussianBlur(BORDER_REFLECT_101) of the cloned interior ROI reads (3 px needed), so no
  * reflection logic runs here.  Horizontal pass straight from three aligned dword loads into 8.8 sums
- * in LDS; vertical pass from LDS. */
+ * in LDS (v_dot4_u32_u8); vertical pass from LDS (v_mad_u32_u16). */
 __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, const BlurTile* __restrict__ tiles,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
 {
@@ -820,12 +822,12 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
     const DevLevel& L = G->lv[t.level];
     const uint8_t* img = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff;
     const int x0 = t.tx * DRFE_BLUR_TW, y0 = t.ty * DRFE_BLUR_TH;
-    const int cg = tid & 15, rr = tid >> 4;
+    const int cg = tid & (BLUR_COLG - 1), rr = tid / BLUR_COLG;
     /* interior x maps to bordered column x+19; the window of pixels x..x+3 starts at x+16 (4-aligned) */
     const int maxWord = L.pyrPitch - 4;
     const int c0 = min(x0 + cg * 4 + 16, maxWord), c1 = min(x0 + cg * 4 + 20, maxWord), c2 = min(x0 + cg * 4 + 24, maxWord);
     const int lastRow = L.h + 2 * DRFE_EDGE - 1;
-    for (int r = rr; r < BLUR_ROWS; r += 16) {
+    for (int r = rr; r < BLUR_ROWS; r += BLUR_ROWL) {
         const uint8_t* row = img + (size_t)min(y0 + r - 3 + DRFE_EDGE, lastRow) * L.pyrPitch;
         const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + c0);
         const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + c1);
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
             make_uint2(h01, h23);
     }
     __syncthreads();
-    for (int r = rr; r < DRFE_BLUR_TH; r += 16) {
+    for (int r = rr; r < DRFE_BLUR_TH; r += BLUR_ROWL) {
         const int y = y0 + r;
         if (y >= L.h) continue;
         uint32_t acc[4] = {0, 0, 0, 0};
@@ -862,6 +864,7 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) out |= min(255u, (acc[k] + 32768u) >> 16) << (8 * k);
+        if (x0 + cg * 4 >= L.blurPitch) continue;            /* tiles wider than the pitch granule may overhang it */
         uint8_t* dst = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)y * L.blurPitch + x0 + cg * 4;
         *reinterpret_cast<uint32_t*>(dst) = out;
     }

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # DRFE_TEST_LIB=<path>: run the suite against a variant build of libdrfe.so (kernel experiments)
+    if os.environ.get("DRFE_TEST_LIB"):
+        import dr_slam_amd.lib as _L
+        _L.LIB_PATH = os.path.abspath(os.environ["DRFE_TEST_LIB"])
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
