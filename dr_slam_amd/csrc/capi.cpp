@@ -347,8 +347,12 @@ int drfe_orb_blurred_level(drfe_ctx* c, int slot, int level, uint8_t* out, int* 
     if (!out) return DRFE_OK;
     int rc = drfe_stream_sync(c);
     if (rc != DRFE_OK) return rc;
-    HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, c->d_blur + (size_t)slot * c->geom.blurSlotBytes + L.blurOff,
-                          (size_t)L.blurPitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+    /* the level is tiled on the device (drfe_blur_offset): fetch it whole, untile on the host */
+    const size_t bytes = (size_t)L.blurPitch * ((L.h + DRFE_BTILE_H - 1) / DRFE_BTILE_H) * 128;
+    std::vector<uint8_t> tiled(bytes);
+    HIPCHK(c, hipMemcpy(tiled.data(), c->d_blur + (size_t)slot * c->geom.blurSlotBytes + L.blurOff, bytes, hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; y++)
+        for (int x = 0; x < L.w; x++) out[(size_t)y * L.w + x] = tiled[drfe_blur_offset(x, y, L.blurPitch)];
     return DRFE_OK;
 }
 

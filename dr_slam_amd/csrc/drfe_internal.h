@@ -164,6 +164,20 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
 
 #define DRFE_RESIZE_LDS_WD 88     /* dwords per source row of the k_pyr_resize_lds tile (256 output columns * 1.25 + slack) */
 #define DRFE_RESIZE_LDS_ROWS 24   /* source rows of the tile (16 output rows * 1.25 + slack) */
+/* layout of a blurred level in HBM: tiles of DRFE_BTILE_W x DRFE_BTILE_H pixels = one 128-byte line each, row-major inside
+ * the tile, tiles row-major over the level; DevLevel::blurPitch = tiles per tile row */
+#define DRFE_BTILE_W 32
+#define DRFE_BTILE_H 4
+#if defined(__HIPCC__) || defined(__cplusplus)
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+unsigned drfe_blur_offset(int x, int y, int tilesX)
+{
+    return (unsigned)(((y >> 2) * tilesX + (x >> 5)) * 128 + (y & 3) * 32 + (x & 31));
+}
+#endif
 #ifndef DRFE_BLUR_TW
 #define DRFE_BLUR_TW 128      /* blur tile: 128 x 64 output pixels (full 128-byte lines per stored row, 9 % halo rows) */
 #define DRFE_BLUR_TH 64

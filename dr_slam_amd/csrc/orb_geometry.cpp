@@ -138,9 +138,11 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
         L.pyrPitch = align_up(L.w + 2 * DRFE_EDGE, 64);
         L.pyrOff = pyrOff;
         pyrOff += align_up(L.pyrPitch * (L.h + 2 * DRFE_EDGE), 256);
-        L.blurPitch = align_up(L.w, 64);
+        /* blurred level: 32 x 4-pixel tiles of 128 bytes (DRFE_BLUR_TILE_*), blurPitch = tiles per tile row.  Its only
+         * reader gathers 37 x 37 patches: ~23 lines per patch instead of ~48 with row-major rows. */
+        L.blurPitch = (L.w + DRFE_BTILE_W - 1) / DRFE_BTILE_W;
         L.blurOff = blurOff;
-        blurOff += align_up(L.blurPitch * L.h, 256);
+        blurOff += align_up(L.blurPitch * ((L.h + DRFE_BTILE_H - 1) / DRFE_BTILE_H) * 128, 256);
         /* FAST cells in the reference's loop order with its skip rules, :789-806 */
         L.cellBegin = cells ? (int)cells->size() : 0;
         int candCap = 0;

@@ -864,8 +864,8 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) out |= min(255u, (acc[k] + 32768u) >> 16) << (8 * k);
-        if (x0 + cg * 4 >= L.blurPitch) continue;            /* tiles wider than the pitch granule may overhang it */
-        uint8_t* dst = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)y * L.blurPitch + x0 + cg * 4;
+        if (x0 + cg * 4 >= L.blurPitch * DRFE_BTILE_W) continue;   /* the block tile may overhang the last layout tile */
+        uint8_t* dst = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + drfe_blur_offset(x0 + cg * 4, y, L.blurPitch);
         *reinterpret_cast<uint32_t*>(dst) = out;
     }
 }
@@ -927,6 +927,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
     if (g0 >= total || g0 >= maxKp) return;                   /* wave-uniform */
     int level[DESC_KPW], xi[DESC_KPW], yi[DESC_KPW], resp[DESC_KPW], pitchP[DESC_KPW], pitchB[DESC_KPW];
     int shP[DESC_KPW], shB[DESC_KPW];             /* byte position of the patch's first column inside its first dword */
+    int bx0[DESC_KPW], by0[DESC_KPW];             /* blurred patch: first (dword-aligned) column and first row */
     bool live[DESC_KPW];
     const uint8_t* cP[DESC_KPW];
     const uint8_t* cB[DESC_KPW];
@@ -951,10 +952,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
         /* top-left corners of the patches, moved left to a dword boundary (slot and level offsets are multiples of
          * 256, pitches of 64, the arenas come from hipMalloc): the disc reaches 15 px, the rotated pattern 18 px */
         const size_t oP = (size_t)slot * G->pyrSlotBytes + L.pyrOff + (size_t)(yi[j] + DRFE_EDGE - 15) * L.pyrPitch + (xi[j] + DRFE_EDGE - 15);
-        const size_t oB = (size_t)slot * G->blurSlotBytes + L.blurOff + (size_t)(yi[j] - DESC_REACH) * L.blurPitch + (xi[j] - DESC_REACH);
-        shP[j] = (int)(oP & 3); shB[j] = (int)(oB & 3);
+        /* blurred level: tiled (drfe_blur_offset); cB = the level, (bx0, by0) = the patch corner moved left to a dword */
+        shP[j] = (int)(oP & 3); shB[j] = (xi[j] - DESC_REACH) & 3;
         cP[j] = pyr + (oP & ~(size_t)3);
-        cB[j] = blur + (oB & ~(size_t)3);
+        cB[j] = blur + (size_t)slot * G->blurSlotBytes + L.blurOff;
+        bx0[j] = (xi[j] - DESC_REACH) & ~3; by0[j] = yi[j] - DESC_REACH;
     }
     /* every global load of the wave: lane t of load k fetches dword (t / 9, t % 9) of the raw patch and (t / 10, t % 10)
      * of the blurred one (t = lane + 64 k) */
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
                 rw[j][k] = *reinterpret_cast<const uint32_t*>(cP[j] + (uint32_t)(__mul24(rRow[k], pitchP[j]) + rCol[k]));   /* 24-bit multiply: full rate */
 #pragma unroll
             for (int k = 0; k < DESC_BLUR_LD; k++)
-                bw[j][k] = *reinterpret_cast<const uint32_t*>(cB[j] + (uint32_t)(__mul24(bRow[k], pitchB[j]) + bCol[k]));
+                bw[j][k] = *reinterpret_cast<const uint32_t*>(cB[j] + drfe_blur_offset(bx0[j] + bCol[k], by0[j] + bRow[k], pitchB[j]));
         }
     }
     /* IC_Angle on the unblurred level: integer moments over the radius-15 disc (749 px = 12 offsets per lane) */
