@@ -166,8 +166,10 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
 #define DRFE_RESIZE_LDS_ROWS 24   /* source rows of the tile (16 output rows * 1.25 + slack) */
 /* layout of a blurred level in HBM: tiles of DRFE_BTILE_W x DRFE_BTILE_H pixels = one 128-byte line each, row-major inside
  * the tile, tiles row-major over the level; DevLevel::blurPitch = tiles per tile row */
+#ifndef DRFE_BTILE_W
 #define DRFE_BTILE_W 32
 #define DRFE_BTILE_H 4
+#endif
 #if defined(__HIPCC__) || defined(__cplusplus)
 static inline
 #if defined(__HIPCC__)
@@ -175,7 +177,8 @@ __host__ __device__
 #endif
 unsigned drfe_blur_offset(int x, int y, int tilesX)
 {
-    return (unsigned)(((y >> 2) * tilesX + (x >> 5)) * 128 + (y & 3) * 32 + (x & 31));
+    const unsigned ux = (unsigned)x, uy = (unsigned)y;      /* non-negative by construction: powers of two become shifts */
+    return ((uy / DRFE_BTILE_H) * (unsigned)tilesX + ux / DRFE_BTILE_W) * 128u + (uy % DRFE_BTILE_H) * DRFE_BTILE_W + ux % DRFE_BTILE_W;
 }
 #endif
 #ifndef DRFE_BLUR_TW
