@@ -84,13 +84,16 @@ def test_search_by_projection_last_general(setup, oracle_mod):
     obs = (rng.random(cur.N) > 0.5).astype(np.uint8)
     gmp = np.zeros(last.N, lib.MAPPOINT_DTYPE)
     gmp["valid"], gmp["obs_positive"], gmp["world"], gmp["desc"] = mp["valid"], mp["obsPositive"], mp["world"], mp["desc"]
-    for check_ori, dz in ((False, 0.0), (True, 0.5), (True, -0.5)):
+    # th = 30 is Tracking's retry (2 * th): on the upper levels the window is wider than 16 grid columns and longer than
+    # 64 records, which takes the whole-wavefront routine of the window kernel instead of the quarter-wave one
+    for check_ori, dz, th in ((False, 0.0, 15.0), (True, 0.5, 15.0), (True, -0.5, 15.0), (True, 0.0, 30.0), (False, 0.5, 30.0),
+                              (True, 0.0, 4.0)):
         Tc = Tcw[2].copy()
         Tc[2, 3] -= dz
-        n_o, m_o = oracle_mod.search_by_projection_last(cur, last, Tc, Tcw[1], mp, 15.0, False, check_ori, pre, obs)
-        n_g, m_g = fe.ctx.search_by_projection_last(2, 1, Tc, Tcw[1], fe.cam, gmp, cur.N, 15.0, False, check_ori, pre, obs)
-        assert n_g == n_o, (check_ori, dz, n_g, n_o)
-        assert np.array_equal(m_g, m_o)
+        n_o, m_o = oracle_mod.search_by_projection_last(cur, last, Tc, Tcw[1], mp, th, False, check_ori, pre, obs)
+        n_g, m_g = fe.ctx.search_by_projection_last(2, 1, Tc, Tcw[1], fe.cam, gmp, cur.N, th, False, check_ori, pre, obs)
+        assert n_g == n_o, (check_ori, dz, th, n_g, n_o)
+        assert np.array_equal(m_g, m_o), (check_ori, dz, th)
 
 
 def test_search_by_projection_map(setup, oracle_mod):
