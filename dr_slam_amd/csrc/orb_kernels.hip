@@ -352,14 +352,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
     const int ew = ww - 6, eh = wh - 6;           /* evaluated area */
     const int off = fc.off;
     const uint8_t* src = pyr + (size_t)slot * pyrSlotBytes + fc.srcOff;
-    const int wpr = (ww + off + 3) >> 2;          /* dwords per window row (<= 16) */
     {
-        /* row r interleaved with row r + 1 (the last row with itself: only an unstored B pixel reads it) */
-        const int c = lane & 15;
-        if (c < wpr)
-            for (int r = lane >> 4; r < wh; r += 4) {
-                const uint32_t g0 = *reinterpret_cast<const uint32_t*>(src + (size_t)r * fc.pitch + c * 4);
-                tile[r * (FAST_TILE_PITCH / 4) + c] = g0;
+        /* window rows as 16-byte chunks (dword-aligned addresses): lane = (row, chunk), 16 rows per trip, so a 36-row
+         * window fills in 3 trips instead of 9 with single dwords; a chunk is loaded only if the window needs its first
+         * byte, which keeps the over-read inside the level's bordered row */
+        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        const int nch = (ww + off + 15) >> 4;     /* chunks per window row (<= 4) */
+        const int c = lane & 3;
+        if (c < nch)
+            for (int r = lane >> 2; r < wh; r += 16) {
+                const u32x4_a4 g = *reinterpret_cast<const u32x4_a4*>(src + (size_t)r * fc.pitch + c * 16);
+                uint32_t* t = &tile[r * (FAST_TILE_PITCH / 4) + c * 4];
+                t[0] = g.x; t[1] = g.y; t[2] = g.z; t[3] = g.w;
             }
     }
     /* score tile: pixel (x, y) of the evaluated area lives at byte (y+1)*64 + (x+4); everything else
