@@ -84,7 +84,7 @@ void drfe_destroy(drfe_ctx* c)
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
                     c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_kpsUn, c->d_desc,
                     c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc, c->d_match,
-                    c->d_matchCount, c->d_poses, c->d_stage};
+                    c->d_matchCount, c->d_poses, c->d_stage, c->d_callScratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < DRFE_STAGE_COUNT; i++)
@@ -130,6 +130,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     std::memset(c->ev, 0, sizeof(c->ev));
     std::memset(c->evUsed, 0, sizeof(c->evUsed));
     c->d_geom = nullptr; c->d_cells = nullptr; c->d_tiles = nullptr; c->d_taps = nullptr; c->d_pattern = nullptr;
+    c->d_callScratch = nullptr; c->callScratchBytes = 0;
     c->d_disc = nullptr; c->d_pyr = nullptr; c->d_blur = nullptr; c->d_cand0 = nullptr; c->d_cand1 = nullptr;
     c->d_node = nullptr; c->d_candCount = nullptr; c->d_sel = nullptr; c->d_selCount = nullptr; c->d_kps = nullptr; c->d_kpsUn = nullptr; std::memset(&c->dist, 0, sizeof(c->dist));
     c->d_desc = nullptr; c->d_kpCount = nullptr; c->d_status = nullptr; c->d_uRight = nullptr; c->d_depth = nullptr;

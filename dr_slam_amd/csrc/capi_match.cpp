@@ -105,6 +105,23 @@ static void frustum_pose(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, 
     P->limit = limit;
 }
 
+/* Device scratch of a host-buffer matcher call: one grow-only block per context instead of hipMalloc + hipFree around
+ * every call (both synchronise the device and cost tens of microseconds, most of such a call's latency).  Calls on a
+ * context are sequential, and each one ends with a stream synchronisation before it returns. */
+static hipError_t call_scratch(drfe_ctx* c, size_t bytes, uint8_t** out)
+{
+    if (bytes > c->callScratchBytes) {
+        if (c->d_callScratch) (void)hipFree(c->d_callScratch);
+        c->d_callScratch = nullptr; c->callScratchBytes = 0;
+        const size_t want = (bytes + (bytes >> 1) + 65535) & ~(size_t)65535;
+        const hipError_t e = hipMalloc((void**)&c->d_callScratch, want);
+        if (e != hipSuccess) return e;
+        c->callScratchBytes = want;
+    }
+    *out = c->d_callScratch;
+    return hipSuccess;
+}
+
 /* KeyFrame::GetCameraCenter(): Ow = -Rwc*tcw with Rwc = Rcw.t() stored first (KeyFrame::SetPose, src/KeyFrame.cc:153-154), so
  * the product has no transpose flag and cv::gemm takes its small-matrix float path: float dot, then * alpha = -1 */
 static void camera_centre_kf(const float* Tcw, float Ow[3])
@@ -122,14 +139,13 @@ static int frustum_run(drfe_ctx* c, const In* in, int n, Out* out, Launch launch
     HIPCHK(c, hipSetDevice(c->device));
     uint8_t* d = nullptr;
     const size_t oIn = 0, oOut = (sizeof(In) * (size_t)n + 63) & ~(size_t)63, total = oOut + sizeof(Out) * (size_t)n;
-    HIPCHK(c, hipMalloc(&d, total));
+    HIPCHK(c, call_scratch(c, total, &d));
     hipStream_t s = c->stream;
     hipError_t e = hipMemcpyAsync(d + oIn, in, sizeof(In) * (size_t)n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d + oOut, out, sizeof(Out) * (size_t)n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = launch(reinterpret_cast<const In*>(d + oIn), reinterpret_cast<Out*>(d + oOut), s);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d + oOut, sizeof(Out) * (size_t)n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string("is_in_frustum: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
 }
@@ -546,7 +562,7 @@ static int line_search_run(drfe_ctx* c, const std::vector<LineQuery>* hostQ, con
                  oC = oT + 64, oD = oC + sizeof(LineCur) * n_cur, oK = oD + (size_t)n_cur * 32,
                  oM = (oK + n_cur + 15) & ~(size_t)15, oN = oM + sizeof(int) * n_cur, total = oN + 16;
     uint8_t* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, total));
+    HIPCHK(c, call_scratch(c, total, &d));
     hipStream_t s = c->stream;
     hipError_t e = hipSuccess;
     auto up = [&](size_t off, const void* src, size_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s); };
@@ -565,7 +581,6 @@ static int line_search_run(drfe_ctx* c, const std::vector<LineQuery>* hostQ, con
     if (e == hipSuccess) e = hipMemcpyAsync(cur_ml, d + oM, sizeof(int) * n_cur, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(nmatches, d + oN, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string("lsd_search_by_projection: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
 }
@@ -670,7 +685,7 @@ static int fuse_search_impl(drfe_ctx* c, int slot, const float* Tcw, int sim3, c
     uint8_t* d = nullptr;
     const size_t oP = 0, oD = (sizeof(drfe_frustum_point) * (size_t)n + 63) & ~(size_t)63, oS = oD + (((size_t)n * 32 + 63) & ~(size_t)63),
                  oI = oS + (((size_t)n + 63) & ~(size_t)63), oB = oI + sizeof(int) * (size_t)n, total = oB + sizeof(int) * (size_t)n;
-    HIPCHK(c, hipMalloc(&d, total));
+    HIPCHK(c, call_scratch(c, total, &d));
     hipStream_t s = c->stream;
     hipError_t e = hipMemcpyAsync(d + oP, pts, sizeof(drfe_frustum_point) * (size_t)n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d + oD, descs, (size_t)n * 32, hipMemcpyHostToDevice, s);
@@ -681,7 +696,6 @@ static int fuse_search_impl(drfe_ctx* c, int slot, const float* Tcw, int sim3, c
     if (e == hipSuccess) e = hipMemcpyAsync(best_idx, d + oI, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(best_dist, d + oB, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string("fuse_search: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
 }
@@ -782,7 +796,7 @@ static int first_come_search(drfe_ctx* c, const char* who, int slot, const float
                  oI = oT + up((size_t)n_kp), oB = oI + up(sizeof(int) * (size_t)n), oC = oB + up(sizeof(int) * (size_t)n),
                  oL = oC + up(sizeof(int) * (size_t)n), total = oL + sizeof(int2) * (size_t)n * FUSE_LIST_K;
     uint8_t* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, total));
+    HIPCHK(c, call_scratch(c, total, &d));
     hipStream_t s = c->stream;
     std::vector<int2> list((size_t)n * FUSE_LIST_K);
     std::vector<int> count(n);
@@ -823,7 +837,6 @@ static int first_come_search(drfe_ctx* c, const char* who, int slot, const float
         }
         if (pk >= 0) { taken[pk] = 1; pick[i] = pk; }
     }
-    (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string(who) + ": " + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
 }
@@ -934,7 +947,7 @@ int drfe_lsd_fuse_search(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, 
                  oKD = oK + up(sizeof(LineCur) * (size_t)n_kf), oI = oKD + up((size_t)n_kf * 32), oB = oI + up(sizeof(int) * (size_t)n),
                  total = oB + sizeof(int) * (size_t)n;
     uint8_t* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, total));
+    HIPCHK(c, call_scratch(c, total, &d));
     hipStream_t s = c->stream;
     hipError_t e = hipMemcpyAsync(d + oL, lines, sizeof(drfe_frustum_line) * (size_t)n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d + oD, descs, (size_t)n * 32, hipMemcpyHostToDevice, s);
@@ -948,7 +961,6 @@ int drfe_lsd_fuse_search(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, 
     if (e == hipSuccess) e = hipMemcpyAsync(best_idx, d + oI, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(best_dist, d + oB, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string("lsd_fuse_search: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
 }

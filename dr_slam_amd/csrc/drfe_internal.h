@@ -126,6 +126,8 @@ struct drfe_ctx {
     float* d_poses;                       /* per-batch Tcw/Twc staging: [2][max_batch][16] */
     uint8_t* d_stage;                     /* staging for single-frame host API */
     size_t stageBytes;
+    uint8_t* d_callScratch;               /* grow-only device scratch of the host-buffer matcher calls (one call at a time) */
+    size_t callScratchBytes;
 
     int lastBatch;            /* frames in the most recent batch */
     bool glueValid;
