@@ -166,6 +166,26 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
 
 #define DRFE_RESIZE_LDS_WD 88     /* dwords per source row of the k_pyr_resize_lds tile (256 output columns * 1.25 + slack) */
 #define DRFE_RESIZE_LDS_ROWS 24   /* source rows of the tile (16 output rows * 1.25 + slack) */
+/* XCD-aware block numbering for the batch-wide 2-D grids (x = item inside a frame, y = frame slot).  Workgroups are dealt
+ * round-robin over the 8 XCDs in dispatch order (x fastest), so consecutive cells / tiles / keypoint groups of one frame -
+ * which share pyramid lines - would land on eight different private L2s and every line would cross the fabric several
+ * times.  The swizzle gives each XCD a contiguous eighth of the flattened grid, i.e. whole frames: the blocks that share
+ * lines share an L2.  Bijective for any grid size (cdna_hip_programming.md, T1); placement is a speed matter only.
+ * `magic` = drfe_div_magic(gridDim.x) from the host: swz / gx as one multiply-high (exact while swz * gx < 2^32). */
+static inline uint32_t drfe_div_magic(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
+#if defined(__HIPCC__)
+__device__ __forceinline__ void drfe_xcd_swizzle_2d(uint32_t magic, int& lx, int& ly)
+{
+    const uint32_t gx = gridDim.x, nwg = gx * gridDim.y;
+    const uint32_t orig = blockIdx.y * gx + blockIdx.x;
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7, j = orig >> 3;
+    const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const uint32_t y = __umulhi(swz, magic);
+    lx = (int)(swz - y * gx);
+    ly = (int)y;
+}
+#endif
+
 /* layout of a blurred level in HBM: tiles of DRFE_BTILE_W x DRFE_BTILE_H pixels = one 128-byte line each, row-major inside
  * the tile, tiles row-major over the level; DevLevel::blurPitch = tiles per tile row */
 #ifndef DRFE_BTILE_W

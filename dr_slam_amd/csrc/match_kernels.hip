@@ -362,13 +362,15 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
                                                            uint32_t* __restrict__ candIdx,
                                                            uint32_t* __restrict__ candKey,
                                                            int* __restrict__ candCnt, uint2* __restrict__ candBest,
-                                                           int* __restrict__ status)
+                                                           int* __restrict__ status, uint32_t gxMagic)
 {
     __shared__ int sTab[256 / WAVE][4][WQ_TAB];
-    const MatchPair P = pairs[blockIdx.y];
+    int bx, by;
+    drfe_xcd_swizzle_2d(gxMagic, bx, by);        /* a frame pair's queries on one XCD: they gather the same cell-sorted records */
+    const MatchPair P = pairs[by];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   /* wave-uniform for the compiler */
     const int g = lane >> 4, l = lane & 15;
-    const int qbase = (blockIdx.x * (256 / WAVE) + wv) * 4;
+    const int qbase = (bx * (256 / WAVE) + wv) * 4;
     const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
     if (qbase >= nQ) return;                     /* wave-uniform */
     const int cur = P.curSlot;
@@ -759,7 +761,8 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
                            drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
     hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 15) / 16, npairs), dim3(256), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
-                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status);
+                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status,
+                       drfe_div_magic((uint32_t)((maxQueries + 15) / 16)));
     const size_t lds = (size_t)c->maxKp;
     if (mode == 0)
         hipLaunchKernelGGL(k_resolve_last, dim3(npairs), dim3(RS_THREADS), (size_t)c->maxKp * 5 + 16, s, mb.d_pairs,
