@@ -194,8 +194,8 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
                 k = pmc["kernels"][kname]
-                traffic = (k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
-                traffic_src = "profiles/%s (raw FETCH_SIZE+WRITE_SIZE, see its _about)" % pmc_name
+                traffic = float(k["HBM_BYTES_per_launch"])
+                traffic_src = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 half-count correction, calibrated, see its _about)" % pmc_name
         except Exception:
             pass
         fps = total_frames / el
