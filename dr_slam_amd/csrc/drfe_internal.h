@@ -172,7 +172,7 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
  * times.  The swizzle gives each XCD a contiguous eighth of the flattened grid, i.e. whole frames: the blocks that share
  * lines share an L2.  Bijective for any grid size (cdna_hip_programming.md, T1); placement is a speed matter only.
  * `magic` = drfe_div_magic(gridDim.x) from the host: swz / gx as one multiply-high (exact while swz * gx < 2^32). */
-static inline uint32_t drfe_div_magic(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
+static inline uint32_t drfe_div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); }   /* 0 = divide by one */
 #if defined(__HIPCC__)
 __device__ __forceinline__ void drfe_xcd_swizzle_2d(uint32_t magic, int& lx, int& ly)
 {
@@ -180,9 +180,20 @@ __device__ __forceinline__ void drfe_xcd_swizzle_2d(uint32_t magic, int& lx, int
     const uint32_t orig = blockIdx.y * gx + blockIdx.x;
     const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7, j = orig >> 3;
     const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    const uint32_t y = __umulhi(swz, magic);
+    const uint32_t y = magic ? __umulhi(swz, magic) : swz;
     lx = (int)(swz - y * gx);
     ly = (int)y;
+}
+/* the same for 3-D grids (x, y = tile, z = frame slot): magicXY = drfe_div_magic(gridDim.x * gridDim.y), magicX = drfe_div_magic(gridDim.x) */
+__device__ __forceinline__ void drfe_xcd_swizzle_3d(uint32_t magicXY, uint32_t magicX, int& lx, int& ly, int& lz)
+{
+    const uint32_t gx = gridDim.x, gxy = gx * gridDim.y, nwg = gxy * gridDim.z;
+    const uint32_t orig = blockIdx.z * gxy + blockIdx.y * gx + blockIdx.x;
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7, j = orig >> 3;
+    const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const uint32_t z = magicXY ? __umulhi(swz, magicXY) : swz, rem = swz - z * gxy;
+    const uint32_t y = magicX ? __umulhi(rem, magicX) : rem;
+    lx = (int)(rem - y * gx); ly = (int)y; lz = (int)z;
 }
 #endif
 

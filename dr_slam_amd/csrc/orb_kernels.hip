@@ -161,18 +161,21 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const DevLevel L, const DevL
  * thread with 16-byte loads and stores — slower, the strided LDS byte reads conflict.) */
 #define RES_PITCH (DRFE_RESIZE_LDS_WD * 4 + 4)      /* bytes per LDS row: odd dword count, no bank aliasing between rows */
 __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const DevLevel P, int pyrSlotBytes,
-                                                        const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr)
+                                                        const ResizeTap* __restrict__ taps, uint8_t* __restrict__ pyr,
+                                                        uint32_t magicXY, uint32_t magicX)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[DRFE_RESIZE_LDS_ROWS * RES_PITCH];
-    const int slot = blockIdx.z;
+    int bx, by, bz;
+    drfe_xcd_swizzle_3d(magicXY, magicX, bx, by, bz);   /* a frame's tiles on one XCD: neighbouring source windows overlap */
+    const int slot = bz;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     uint8_t* base = pyr + (size_t)slot * pyrSlotBytes;
-    const ResizeTap wx = taps[L.xwinOff + blockIdx.x], wy = taps[L.ywinOff + blockIdx.y];
+    const ResizeTap wx = taps[L.xwinOff + bx], wy = taps[L.ywinOff + by];
     /* this thread's taps first: their latency overlaps the tile fill instead of following the barrier */
     /* a wavefront is one row of the 64 x 4 block: its four output rows, their source rows and vertical weights are
      * wave-uniform, and readfirstlane tells the compiler so (scalar row bases, scalar branches below) */
-    const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * PYR_ROWS;
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = (by * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * PYR_ROWS;
+    const int x4 = (bx * 64 + threadIdx.x) * 4;
     const int bh = L.h + 2 * DRFE_EDGE;
     const bool active = y0 < bh && x4 < L.pyrPitch;
     const int yT = y0 < bh ? y0 : 0, xT = active ? x4 : 0;
@@ -1168,7 +1171,8 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
         const DevLevel& L = g.lv[l];
         dim3 grid((L.pyrPitch / 4 + 63) / 64, (L.h + 2 * DRFE_EDGE + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), nframes);
         if (L.resizeLds)
-            hipLaunchKernelGGL(k_pyr_resize_lds, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr);
+            hipLaunchKernelGGL(k_pyr_resize_lds, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr,
+                               drfe_div_magic(grid.x * grid.y), drfe_div_magic(grid.x));
         else
             hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, L, g.lv[l - 1], g.pyrSlotBytes, c->d_taps, c->d_pyr);
     }

@@ -126,6 +126,11 @@ def test_search_by_projection_map(setup, oracle_mod):
         assert n_g == n_o, (th, ratio, n_g, n_o)
         assert np.array_equal(m_g, m_o)
     assert n_o > 100
+    # a handful of map points: one block column in the window kernel's grid (the XCD numbering divides by the grid width)
+    for n_small in (1, 5, 16, 17):
+        n_o, m_o = oracle_mod.search_by_projection_map(cur, tp[:n_small], 3.0, 0.8)
+        n_g, m_g = fe.ctx.search_by_projection_map(3, gtp[:n_small], cur.N, 3.0, 0.8)
+        assert n_g == n_o and np.array_equal(m_g, m_o), n_small
 
 
 def test_match_orb_points(setup, oracle_mod):
