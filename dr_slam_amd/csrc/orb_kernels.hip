@@ -828,7 +828,10 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
     /* no XCD swizzle here: it halves this kernel's fetch traffic too, but measured 1.4 % slower (the stores of eight
      * XCDs then crowd into a few frames' worth of addresses) */
     const int bx = blockIdx.x, by = blockIdx.y; (void)gxMagic;
-    __shared__ __attribute__((aligned(16))) uint16_t hb[BLUR_ROWS * DRFE_BLUR_TW];
+    /* horizontal sums of rows 2p and 2p+1 interleaved per pixel: hb2[p][x] = H[2p][x] | H[2p+1][x] << 16, so that the
+     * vertical pass multiplies two rows per instruction (v_dot2_u32_u16) */
+    __shared__ __attribute__((aligned(16))) uint32_t hb2[(BLUR_ROWS / 2) * DRFE_BLUR_TW];
+    static_assert(BLUR_ROWS % 2 == 0 && DRFE_BLUR_TH % 2 == 0, "row pairs");
     const BlurTile t = tiles[bx];
     const int slot = by, tid = threadIdx.x;
     const DevLevel& L = G->lv[t.level];
@@ -839,46 +842,59 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
     const int maxWord = L.pyrPitch - 4;
     const int c0 = min(x0 + cg * 4 + 16, maxWord), c1 = min(x0 + cg * 4 + 20, maxWord), c2 = min(x0 + cg * 4 + 24, maxWord);
     const int lastRow = L.h + 2 * DRFE_EDGE - 1;
-    for (int r = rr; r < BLUR_ROWS; r += BLUR_ROWL) {
-        const uint8_t* row = img + (size_t)min(y0 + r - 3 + DRFE_EDGE, lastRow) * L.pyrPitch;
+    /* byte k of (w0,w1,w2) is interior column x-3+k.  Pixel x+j needs bytes j..j+6: the dword starting at byte j
+     * (v_alignbyte) against taps (18,34,49,55) and the dword starting at byte j+4 against (49,34,18,0), two
+     * v_dot4_u32_u8 per pixel; 257 * 255 = 65535 still fits 16 bits */
+    const uint32_t tA = 18u | (34u << 8) | (49u << 16) | (55u << 24), tB = 49u | (34u << 8) | (18u << 16);
+    auto hsum4 = [&](const uint8_t* row, uint32_t (&h)[4]) {
         const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + c0);
         const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + c1);
         const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + c2);
-        /* byte k of (w0,w1,w2) is interior column x-3+k.  Pixel x+j needs bytes j..j+6: the dword starting at byte j
-         * (v_alignbyte) against taps (18,34,49,55) and the dword starting at byte j+4 against (49,34,18,0), two
-         * v_dot4_u32_u8 per pixel instead of 5.75 packed-u16 ops; 257 * 255 = 65535 still fits 16 bits */
-        const uint32_t tA = 18u | (34u << 8) | (49u << 16) | (55u << 24), tB = 49u | (34u << 8) | (18u << 16);
         const uint32_t a1 = __builtin_amdgcn_alignbyte(w1, w0, 1), a2 = __builtin_amdgcn_alignbyte(w1, w0, 2), a3 = __builtin_amdgcn_alignbyte(w1, w0, 3);
         const uint32_t b1 = __builtin_amdgcn_alignbyte(w2, w1, 1), b2 = __builtin_amdgcn_alignbyte(w2, w1, 2), b3 = __builtin_amdgcn_alignbyte(w2, w1, 3);
-        const uint32_t h0 = __builtin_amdgcn_udot4(w0, tA, __builtin_amdgcn_udot4(w1, tB, 0u, false), false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(a1, tA, __builtin_amdgcn_udot4(b1, tB, 0u, false), false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(a2, tA, __builtin_amdgcn_udot4(b2, tB, 0u, false), false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(a3, tA, __builtin_amdgcn_udot4(b3, tB, 0u, false), false);
-        const uint32_t h01 = h0 | (h1 << 16), h23 = h2 | (h3 << 16);
-        *reinterpret_cast<uint2*>(&hb[r * DRFE_BLUR_TW + cg * 4]) =
-            make_uint2(h01, h23);
+        h[0] = __builtin_amdgcn_udot4(w0, tA, __builtin_amdgcn_udot4(w1, tB, 0u, false), false);
+        h[1] = __builtin_amdgcn_udot4(a1, tA, __builtin_amdgcn_udot4(b1, tB, 0u, false), false);
+        h[2] = __builtin_amdgcn_udot4(a2, tA, __builtin_amdgcn_udot4(b2, tB, 0u, false), false);
+        h[3] = __builtin_amdgcn_udot4(a3, tA, __builtin_amdgcn_udot4(b3, tB, 0u, false), false);
+    };
+    for (int p = rr; p < BLUR_ROWS / 2; p += BLUR_ROWL) {
+        uint32_t ha[4], hc[4];
+        hsum4(img + (size_t)min(y0 + 2 * p - 3 + DRFE_EDGE, lastRow) * L.pyrPitch, ha);
+        hsum4(img + (size_t)min(y0 + 2 * p - 2 + DRFE_EDGE, lastRow) * L.pyrPitch, hc);
+        *reinterpret_cast<uint4*>(&hb2[p * DRFE_BLUR_TW + cg * 4]) =
+            make_uint4(ha[0] | (hc[0] << 16), ha[1] | (hc[1] << 16), ha[2] | (hc[2] << 16), ha[3] | (hc[3] << 16));
     }
     __syncthreads();
-    for (int r = rr; r < DRFE_BLUR_TH; r += BLUR_ROWL) {
-        const int y = y0 + r;
+    /* vertical pass, two output rows (2q, 2q+1) per thread from the four row pairs q..q+3:
+     *   row 2q   = (18,34).P[q] + (49,55).P[q+1] + (49,34).P[q+2] + 18 * lo(P[q+3])
+     *   row 2q+1 = 18 * hi(P[q]) + (34,49).P[q+1] + (55,49).P[q+2] + (34,18).P[q+3] */
+    typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+    const u16x2v t1834 = {18, 34}, t4955 = {49, 55}, t4934 = {49, 34}, t3449 = {34, 49}, t5549 = {55, 49}, t3418 = {34, 18};
+    if (x0 + cg * 4 >= L.blurPitch * DRFE_BTILE_W) return;      /* the block tile may overhang the last layout tile */
+    for (int q = rr; q < DRFE_BLUR_TH / 2; q += BLUR_ROWL) {
+        const int y = y0 + 2 * q;
         if (y >= L.h) continue;
-        uint32_t acc[4] = {0, 0, 0, 0};
-        const uint32_t tap[7] = {18u, 34u, 49u, 55u, 49u, 34u, 18u};
+        uint4 P[4];
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            const uint2 p = *reinterpret_cast<const uint2*>(&hb[(r + k) * DRFE_BLUR_TW + cg * 4]);
-            /* acc += tap * (16-bit half of p): one VOP3 each, the half picked by op_sel (no unpacking) */
-            asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(p.x), "s"(tap[k]));
-            asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(acc[1]) : "v"(p.x), "s"(tap[k]));
-            asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(acc[2]) : "v"(p.y), "s"(tap[k]));
-            asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(acc[3]) : "v"(p.y), "s"(tap[k]));
+        for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4*>(&hb2[(q + k) * DRFE_BLUR_TW + cg * 4]);
+        uint32_t outA = 0, outB = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t p0 = (&P[0].x)[j], p1 = (&P[1].x)[j], p2 = (&P[2].x)[j], p3 = (&P[3].x)[j];
+            uint32_t a = (p3 & 0xFFFFu) * 18u;
+            a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p0), t1834, a, false);
+            a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), t4955, a, false);
+            a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), t4934, a, false);
+            uint32_t c2v = (p0 >> 16) * 18u;
+            c2v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), t3449, c2v, false);
+            c2v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), t5549, c2v, false);
+            c2v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p3), t3418, c2v, false);
+            outA |= min(255u, (a + 32768u) >> 16) << (8 * j);
+            outB |= min(255u, (c2v + 32768u) >> 16) << (8 * j);
         }
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) out |= min(255u, (acc[k] + 32768u) >> 16) << (8 * k);
-        if (x0 + cg * 4 >= L.blurPitch * DRFE_BTILE_W) continue;   /* the block tile may overhang the last layout tile */
-        uint8_t* dst = blur + (size_t)slot * G->blurSlotBytes + L.blurOff + drfe_blur_offset(x0 + cg * 4, y, L.blurPitch);
-        *reinterpret_cast<uint32_t*>(dst) = out;
+        uint8_t* base = blur + (size_t)slot * G->blurSlotBytes + L.blurOff;
+        *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y, L.blurPitch)) = outA;
+        if (y + 1 < L.h) *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y + 1, L.blurPitch)) = outB;
     }
 }
 
