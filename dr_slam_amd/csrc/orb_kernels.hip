@@ -877,21 +877,25 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
         uint4 P[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4*>(&hb2[(q + k) * DRFE_BLUR_TW + cg * 4]);
-        uint32_t outA = 0, outB = 0;
+        /* the single-row term opens the sum together with the rounding constant (v_mad_u32_u16 picks the 16-bit half by
+         * op_sel); (sum >> 16) saturated to a byte, two pixels at a time, is one v_ashr_pk_u8_i32 */
+        uint32_t a[4], c2v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t p0 = (&P[0].x)[j], p1 = (&P[1].x)[j], p2 = (&P[2].x)[j], p3 = (&P[3].x)[j];
-            uint32_t a = (p3 & 0xFFFFu) * 18u;
-            a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p0), t1834, a, false);
-            a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), t4955, a, false);
-            a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), t4934, a, false);
-            uint32_t c2v = (p0 >> 16) * 18u;
-            c2v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), t3449, c2v, false);
-            c2v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), t5549, c2v, false);
-            c2v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p3), t3418, c2v, false);
-            outA |= min(255u, (a + 32768u) >> 16) << (8 * j);
-            outB |= min(255u, (c2v + 32768u) >> 16) << (8 * j);
+            asm("v_mad_u32_u16 %0, %1, 18, %2" : "=v"(a[j]) : "v"(p3), "s"(32768u));
+            a[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p0), t1834, a[j], false);
+            a[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), t4955, a[j], false);
+            a[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), t4934, a[j], false);
+            asm("v_mad_u32_u16 %0, %1, 18, %2 op_sel:[1,0,0,0]" : "=v"(c2v[j]) : "v"(p0), "s"(32768u));
+            c2v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), t3449, c2v[j], false);
+            c2v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), t5549, c2v[j], false);
+            c2v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p3), t3418, c2v[j], false);
         }
+        const uint32_t outA = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a[0], (int)a[1], 16) |
+                              ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a[2], (int)a[3], 16) << 16);
+        const uint32_t outB = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)c2v[0], (int)c2v[1], 16) |
+                              ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)c2v[2], (int)c2v[3], 16) << 16);
         uint8_t* base = blur + (size_t)slot * G->blurSlotBytes + L.blurOff;
         *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y, L.blurPitch)) = outA;
         if (y + 1 < L.h) *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y + 1, L.blurPitch)) = outB;
