@@ -171,16 +171,24 @@ hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, fl
  * which share pyramid lines - would land on eight different private L2s and every line would cross the fabric several
  * times.  The swizzle gives each XCD a contiguous eighth of the flattened grid, i.e. whole frames: the blocks that share
  * lines share an L2.  Bijective for any grid size (cdna_hip_programming.md, T1); placement is a speed matter only.
- * `magic` = drfe_div_magic(gridDim.x) from the host: swz / gx as one multiply-high (exact while swz * gx < 2^32). */
+ * `magic` = drfe_div_magic(gridDim.x) from the host: swz / gx as one multiply-high, which is the quotient or the quotient
+ * plus one for any 32-bit swz (M * gx = 2^32 + e, e < gx), hence the one-step correction in drfe_div_by. */
 static inline uint32_t drfe_div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); }   /* 0 = divide by one */
 #if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t drfe_div_by(uint32_t n, uint32_t d, uint32_t magic)
+{
+    if (!magic) return n;                         /* d == 1 */
+    uint32_t q = __umulhi(n, magic);
+    if (q * d > n) q--;
+    return q;
+}
 __device__ __forceinline__ void drfe_xcd_swizzle_2d(uint32_t magic, int& lx, int& ly)
 {
     const uint32_t gx = gridDim.x, nwg = gx * gridDim.y;
     const uint32_t orig = blockIdx.y * gx + blockIdx.x;
     const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7, j = orig >> 3;
     const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    const uint32_t y = magic ? __umulhi(swz, magic) : swz;
+    const uint32_t y = drfe_div_by(swz, gx, magic);
     lx = (int)(swz - y * gx);
     ly = (int)y;
 }
@@ -191,8 +199,8 @@ __device__ __forceinline__ void drfe_xcd_swizzle_3d(uint32_t magicXY, uint32_t m
     const uint32_t orig = blockIdx.z * gxy + blockIdx.y * gx + blockIdx.x;
     const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7, j = orig >> 3;
     const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    const uint32_t z = magicXY ? __umulhi(swz, magicXY) : swz, rem = swz - z * gxy;
-    const uint32_t y = magicX ? __umulhi(rem, magicX) : rem;
+    const uint32_t z = drfe_div_by(swz, gxy, magicXY), rem = swz - z * gxy;
+    const uint32_t y = drfe_div_by(rem, gx, magicX);
     lx = (int)(rem - y * gx); ly = (int)y; lz = (int)z;
 }
 #endif
