@@ -190,10 +190,18 @@ def test_odd_image_sizes(oracle_mod, w, h):
     c = lib.Context(nfeatures=600, max_width=w, max_height=h)
     try:
         kps, desc = c.orb_extract(g)
-        okps, odesc = oracle_mod.OrbOracle(600, 1.2, 8, 20, 7)(g)
+        oo = oracle_mod.OrbOracle(600, 1.2, 8, 20, 7)
+        okps, odesc = oo(g)
         _same_kps(kps, okps)
         assert np.array_equal(desc, odesc)
         assert len(kps) > 300
+        # every level and its blurred copy (the blurred levels are tiled 32 x 4 on the device: widths / heights that are
+        # not multiples of the tile exercise the untiling download and the overhanging blur blocks)
+        for l in range(8):
+            assert np.array_equal(c.pyramid_level(0, l), oo.pyramid(l)), f"pyramid level {l}"
+            ob = oo.blurred(l)
+            if ob is not None:
+                assert np.array_equal(c.blurred_level(0, l), ob), f"blur level {l}"
     finally:
         c.close()
 
