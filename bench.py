@@ -35,25 +35,30 @@ ALGO_BYTES = {
 }
 
 
-def make_batch(seed: int, batch: int, n_distinct: int):
-    """Ping-pong over n_distinct consecutive frames so every adjacent pair of the batch is a real
+WORKLOAD_TEXT = {
+    2: "640x480 synthetic RGB-D (TUM3 intrinsics), ORB extract 1000/1.2/8/20/7 + SearchByProjection(frame k, "
+       "frame k-1, th=15) on consecutive frames; BASELINE config 2",
+    4: "640x480 synthetic RGB-D, one 256-frame sequence per rank (seed 10+rank, intrinsics cycling TUM1/TUM2/TUM3: "
+       "UndistortKeyPoints live on two thirds of the ranks), ORB extract 1000/1.2/8/20/7 + SearchByProjection(frame "
+       "k, frame k-1, th=15); BASELINE config 4",
+}
+
+
+def make_batch(base, batch: int):
+    """Ping-pong over the rendered sequence so every adjacent pair of the batch is a real
     frame-to-frame motion: 0,1,..,n-1,n-2,..,1,0,1,.."""
-    from dr_slam_amd import synth
     from dr_slam_amd.sharding import pingpong_order
-    base = list(synth.sequence(seed, n_distinct, cam=synth.TUM3))
-    order = pingpong_order(batch, n_distinct)
+    order = pingpong_order(batch, len(base))
     gray = np.stack([base[i][0] for i in order])
     depth = np.stack([base[i][1] for i in order])
     Twc = np.stack([base[i][2] for i in order]).astype(np.float64)
     Tcw = np.linalg.inv(Twc)
-    return gray, depth, Tcw.astype(np.float32), Twc.astype(np.float32), base
+    return gray, depth, Tcw.astype(np.float32), Twc.astype(np.float32)
 
 
-def cpu_baseline(base, budget_s: float = 12.0):
+def cpu_baseline(base, cam, budget_s: float = 12.0):
     """Oracle (kind 'port', 1 thread): extract + SearchByProjection against the previous frame."""
-    from dr_slam_amd import synth
     from oracle import oracle as orc
-    cam = synth.TUM3
     o = orc.OrbOracle()
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     inv = np.float32(1.0) / np.float32(cam.depth_factor)
@@ -63,7 +68,8 @@ def cpu_baseline(base, budget_s: float = 12.0):
     while True:
         g, d, Twc = base[i % len(base)]
         kps, desc = o(g)
-        fo = orc.FrameOracle(kps, desc, orc.depth_to_float(d, inv), K4, cam.bf, cam.w, cam.h, o.scale)
+        fo = orc.FrameOracle(kps, desc, orc.depth_to_float(d, inv), K4, cam.bf, cam.w, cam.h, o.scale,
+                             dist=cam.dist)
         Tcw = np.linalg.inv(Twc).astype(np.float32)
         if prev is not None:
             pf, pTwc, pTcw = prev
@@ -82,26 +88,88 @@ def cpu_baseline(base, budget_s: float = 12.0):
                       f"-O3 -march=x86-64-v3 -ffp-contract=off, 1 thread, {el:.1f} s"}
 
 
+def launch(args) -> int:
+    """`--gpus N` without a launcher around us: start N fresh rank processes (one per GPU) BEFORE this process makes
+    any GPU call - the parent never initialises HIP, it only counts devices - and pass rank 0's JSON line through.
+    Non-zero exit if any rank fails.  On a box with fewer than N devices the ranks share device 0 over gloo
+    (rehearsal of the N-rank control path; flagged in the JSON line, not a scaling measurement)."""
+    import socket
+    import subprocess
+    import torch
+    n = args.gpus
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < n:
+        env["DRFE_BENCH_ONE_DEVICE"] = "1"
+        env["DRFE_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].stdout.read().decode()
+    rc = 0
+    deadline = time.time() + 1800
+    for p in procs:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+        rc = rc or p.returncode
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write(out0)
+        return rc or 1
+    sys.stdout.write(out0)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames rendered per rank")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4),
+                    help="BASELINE.json config: 2 = TUM3 single sequence, 4 = TUM1/2/3 mix, one 256-frame sequence "
+                         "per rank; 0 = config 2 at one rank, config 4 at N > 1")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="frames rendered per rank (0 = the config's sequence length: 64 / 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # Rehearsal hooks for a 1-GPU box (the driver never sets them): DRFE_BENCH_ONE_DEVICE=1 puts every rank on
-    # cuda:0 and DRFE_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
-    if os.environ.get("DRFE_BENCH_ONE_DEVICE"):
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size is used\n")
+    config = args.config or (2 if world == 1 else 4)
+
+    # Render this rank's sequence first: the pool forks, so it must run before anything touches the GPU.
+    from dr_slam_amd import sharding
+    seed, cam, kind, seq_len = sharding.rank_workload(config, rank)
+    n_distinct = args.distinct or seq_len
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    base = sharding.render_sequence(seed, n_distinct, cam, kind, workers=max(1, sharding.host_cpus() // local_world))
+
+    import torch
+    import torch.distributed as dist
+
+    # Rehearsal hooks for a box with fewer devices than ranks (set by launch(); the driver never sets them):
+    # DRFE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and DRFE_BENCH_BACKEND=gloo replaces RCCL, which refuses
+    # two ranks on one device.
+    rehearsal = bool(os.environ.get("DRFE_BENCH_ONE_DEVICE"))
+    if rehearsal:
         local_rank = 0
     backend = os.environ.get("DRFE_BENCH_BACKEND", "nccl")
     if world > 1:
@@ -113,13 +181,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from dr_slam_amd import synth
     from dr_slam_amd.pipeline import FrontEnd
 
     B = args.batch
-    from dr_slam_amd import sharding
-    gray, depth, Tcw, Twc, base = make_batch(sharding.rank_seed(10, rank), B, args.distinct)
-    fe = FrontEnd(synth.TUM3, max_batch=B, device=local_rank)
+    gray, depth, Tcw, Twc = make_batch(base, B)
+    fe = FrontEnd(cam, max_batch=B, device=local_rank)
     gray_t = torch.from_numpy(gray).to(dev)
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -204,9 +270,8 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "640x480 synthetic RGB-D (TUM3 intrinsics), ORB extract 1000/1.2/8/20/7 + "
-                                   "SearchByProjection(frame k, frame k-1, th=15) on consecutive frames; "
-                                   "BASELINE config 2", "batch_per_gpu": B, "frames_per_step": world * B,
+            "config": {"workload": WORKLOAD_TEXT[config], "baseline_config": config, "batch_per_gpu": B,
+                       "frames_per_step": world * B, "sequence_frames_per_rank": len(base),
                        "sharding": "one sequence per GPU, no data-path collective"},
             "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": kname, "kernel_stage": roof_stage, "dominant_stage": dom,
@@ -216,11 +281,13 @@ def main():
                          "algorithmic_bytes_per_launch": algo},
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported by the N=1 run only
-            out["cpu_baseline"] = cpu_baseline(base)
+            out["cpu_baseline"] = cpu_baseline(base, cam)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
+        if rehearsal:
+            out["rehearsal"] = "%d ranks share ONE device over gloo: control-path check, not a scaling number" % world
         print(json.dumps(out))
 
 

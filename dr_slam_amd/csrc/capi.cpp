@@ -189,7 +189,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
             for (int u = -d; u <= d; u++) { disc.push_back((int16_t)u); disc.push_back((int16_t)v); }
         }
         c->discCount = (int)disc.size() / 2;
-        if (c->discCount > 12 * 64) { c->err = "IC_Angle disc exceeds 12 offsets per lane"; return DRFE_ERR_INVALID; }
+        if (c->discCount > 12 * 64) { c->err = "IC_Angle disc exceeds 12 offsets per lane"; CREATE_FAIL(DRFE_ERR_INVALID); }
         CHIP(dalloc(&c->d_disc, disc.size()));
         CHIP(hipMemcpy(c->d_disc, disc.data(), disc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     }
@@ -245,7 +245,6 @@ static int check_status(drfe_ctx* c)
     HIPCHK(c, hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st & 1) { c->err = "FAST candidate arena overflow"; return DRFE_ERR_CAPACITY; }
     if (st & 2) { c->err = "quadtree node pool overflow"; return DRFE_ERR_CAPACITY; }
-    if (st & 4) { c->err = "match candidate list overflow"; return DRFE_ERR_CAPACITY; }
     return DRFE_OK;
 }
 

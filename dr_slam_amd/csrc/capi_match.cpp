@@ -86,7 +86,7 @@ static void motion_flags(const float* TcwCur, const float* TcwLast, float mb, in
 static int match_status(drfe_ctx* c)
 {
     int st = 0;
-    HIPCHK(c, hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&st, c->d_status + 1, sizeof(int), hipMemcpyDeviceToHost));
     if (st & 4) { c->err = "match candidate list overflow (DRFE_MATCH_MAX_CAND)"; return DRFE_ERR_CAPACITY; }
     return DRFE_OK;
 }

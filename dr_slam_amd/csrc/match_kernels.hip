@@ -756,12 +756,15 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
     const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
     const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
     if (mode == 0 && maxQueries > RS_THREADS * RS_MAX_T) return hipErrorInvalidValue;
+    /* the matcher's overflow flag is its own word (d_status[1]) and is cleared by every search: an overflowing
+     * window fails THAT call only, the next call on the same extracted batch starts clean */
+    hipMemsetAsync(c->d_status + 1, 0, sizeof(int), s);
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
     hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 15) / 16, npairs), dim3(256), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
-                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status,
+                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status + 1,
                        drfe_div_magic((uint32_t)((maxQueries + 15) / 16)));
     const size_t lds = (size_t)c->maxKp;
     if (mode == 0)

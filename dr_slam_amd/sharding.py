@@ -46,3 +46,56 @@ def pingpong_order(batch: int, n_distinct: int):
                 d = -d
             k += d
     return order
+
+
+# ---------------------------------------------------------------------------------------------------
+# Workloads of BASELINE.json's configs, one rank's share
+
+def rank_workload(config: int, rank: int):
+    """-> (seed, camera, scene kind, frames per sequence) of the sequence rank `rank` owns.
+
+    config 2: the single-GPU headline (TUM3 intrinsics, room_boxes; every rank runs seed 10+rank so N ranks never
+              render the same images);
+    config 4: eight independent 256-frame sequences, seeds 10..17, intrinsics cycling TUM1/TUM2/TUM3 yaml - two
+              thirds of the ranks have lens distortion, so Frame::UndistortKeyPoints (src/Frame.cc:835-871) is live.
+    """
+    from . import synth
+    if config == 4:
+        cam = (synth.TUM1, synth.TUM2, synth.TUM3)[rank % 3]
+        return 10 + (rank % 8), cam, "room_boxes", 256
+    if config == 2:
+        return rank_seed(10, rank), synth.TUM3, "room_boxes", 64
+    raise ValueError(f"no sharded workload for config {config}")
+
+
+def _render_one(args):
+    from . import synth
+    seed, k, cam, kind = args
+    sc = synth.Scene(seed, kind)
+    T = synth.pose_twc(k)
+    g, d = synth.render(sc, cam, T, k)
+    return g, d, T
+
+
+def render_sequence(seed: int, n_frames: int, cam, kind: str = "room_boxes", workers: int = 1):
+    """synth.sequence(seed, n_frames, cam, kind) as a list, rendered on `workers` processes (frames are independent).
+    Call it BEFORE the process touches the GPU: the pool forks."""
+    jobs = [(seed, k, cam, kind) for k in range(n_frames)]
+    if workers <= 1 or n_frames < 4:
+        return [_render_one(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(workers, n_frames)) as pool:
+        return pool.map(_render_one, jobs, chunksize=max(1, n_frames // (workers * 4)))
+
+
+def host_cpus() -> int:
+    """CPUs this process may use: the cgroup quota if there is one, else the affinity mask."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n

@@ -96,3 +96,60 @@ def test_config5_1280x960_lines_and_cape_planes(oracle_mod):
         assert np.array_equal(gp["planes"]["d"].view(np.uint64), op["planes"][:, 6].view(np.uint64))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("rank", [0, 1, 2])
+def test_config4_rank_workload_batched(oracle_mod, rank):
+    """BASELINE config 4 (index 3), one rank's share on one GPU: the sequence bench.py gives rank `rank`
+    (seed 10+rank, intrinsics TUM1 / TUM2 / TUM3 - lens distortion live on ranks 0 and 1), 32 frames through the
+    batched FrontEnd.process; mvKeys, descriptors, mvKeysUn, uRight, the grid and the SearchByProjection match arrays
+    of all 31 consecutive pairs are compared with the oracle."""
+    import torch
+    from dr_slam_amd import sharding
+    from dr_slam_amd.pipeline import FrontEnd
+    O = oracle_mod
+    seed, cam, kind, seq_len = sharding.rank_workload(4, rank)
+    assert seq_len == 256 and seed == 10 + rank
+    assert (len(cam.dist) > 0 and cam.dist[0] != 0.0) == (rank % 3 != 2)
+    n = 32
+    frames = sharding.render_sequence(seed, n, cam, kind, workers=min(8, sharding.host_cpus()))
+    fe = FrontEnd(cam, max_batch=n)
+    try:
+        gray = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+        depth = torch.from_numpy(np.stack([f[1] for f in frames]).view(np.int16)).cuda()
+        Twc = np.stack([f[2] for f in frames]).astype(np.float64)
+        Tcw = np.linalg.inv(Twc).astype(np.float32)
+        Twc = Twc.astype(np.float32)
+        fe.process(gray, depth, Tcw, Twc, th=15.0, check_ori=True, stream=torch.cuda.current_stream().cuda_stream)
+        o = O.OrbOracle()
+        K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        inv = np.float32(1.0) / np.float32(cam.depth_factor)
+        of = []
+        for s, (g, d, _) in enumerate(frames):
+            okps, odesc = o(g)
+            kps, desc = fe.keypoints(s)
+            _same_kps(kps, okps)
+            assert np.array_equal(desc, odesc)
+            fo = O.FrameOracle(okps, odesc, O.depth_to_float(d, inv), K4, cam.bf, cam.w, cam.h, o.scale, dist=cam.dist)
+            of.append(fo)
+            un, oun = fe.ctx.download_keys_un(s, fo.N), fo.keys_un()
+            for f in ("x", "y"):
+                assert np.array_equal(un[f].view(np.uint32), oun[f].view(np.uint32)), (s, f)
+            ur, z = fe.ctx.download_stereo(s)
+            assert np.array_equal(ur[:fo.N].view(np.uint32), fo.uRight.view(np.uint32))
+            assert np.array_equal(z[:fo.N].view(np.uint32), fo.depth.view(np.uint32))
+            off, idx = fe.ctx.download_grid(s)
+            ooff, oidx = fo.grid_csr()
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        total = 0
+        for s in range(1, n):
+            world, valid = of[s - 1].unproject(Twc[s - 1])
+            mp = np.zeros(of[s - 1].N, O.MAPPOINT_DTYPE)
+            mp["valid"], mp["obsPositive"], mp["world"], mp["desc"] = valid, 1, world, of[s - 1].desc
+            no, mo = O.search_by_projection_last(of[s], of[s - 1], Tcw[s], Tcw[s - 1], mp, 15.0, False, True)
+            m, nm = fe.matches(s)
+            assert nm == no and np.array_equal(m[:of[s].N], mo), s
+            total += nm
+        assert total > 100 * (n - 1)
+    finally:
+        fe.ctx.close()

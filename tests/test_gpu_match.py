@@ -131,6 +131,14 @@ def test_search_by_projection_map(setup, oracle_mod):
         n_o, m_o = oracle_mod.search_by_projection_map(cur, tp[:n_small], 3.0, 0.8)
         n_g, m_g = fe.ctx.search_by_projection_map(3, gtp[:n_small], cur.N, 3.0, 0.8)
         assert n_g == n_o and np.array_equal(m_g, m_o), n_small
+    # a window holding more than DRFE_MATCH_MAX_CAND (256) keypoints fails THAT call with DRFE_ERR_CAPACITY (the
+    # reference's GetFeaturesInArea is unbounded); the next call on the same extracted batch starts clean
+    assert (cur.kps["octave"] <= 1).sum() > 256
+    with pytest.raises(lib.DrfeError):
+        fe.ctx.search_by_projection_map(3, gtp, cur.N, 200.0, 0.8)
+    n_o, m_o = oracle_mod.search_by_projection_map(cur, tp, 3.0, 0.8)
+    n_g, m_g = fe.ctx.search_by_projection_map(3, gtp, cur.N, 3.0, 0.8)
+    assert n_g == n_o and np.array_equal(m_g, m_o)
 
 
 def test_match_orb_points(setup, oracle_mod):

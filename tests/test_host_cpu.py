@@ -198,3 +198,46 @@ def test_is_line_good_as_intended_matches_numpy_oracle(oracle_mod):
         assert good == int((dl >= 0).sum())
         total += good
     assert total >= 10          # most synthetic wall/box edges carry depth and lift to 3-D
+
+
+def test_rank_workloads_and_parallel_render():
+    """Config 4's partition (SURVEY.md §8d-4): seeds 10..17, intrinsics cycling TUM1/TUM2/TUM3, 256 frames each;
+    the pooled renderer returns exactly what synth.sequence yields."""
+    from dr_slam_amd import sharding, synth
+    cams = [sharding.rank_workload(4, r)[1] for r in range(8)]
+    assert [sharding.rank_workload(4, r)[0] for r in range(8)] == list(range(10, 18))
+    assert cams[0] is synth.TUM1 and cams[1] is synth.TUM2 and cams[2] is synth.TUM3 and cams[3] is synth.TUM1
+    assert all(sharding.rank_workload(4, r)[3] == 256 for r in range(8))
+    assert sharding.rank_workload(2, 0)[1] is synth.TUM3
+    cam = synth.TUM1.scaled(0.25)
+    a = list(synth.sequence(11, 5, cam=cam))
+    b = sharding.render_sequence(11, 5, cam, workers=2)
+    for (g1, d1, T1), (g2, d2, T2) in zip(a, b):
+        assert np.array_equal(g1, g2) and np.array_equal(d1, d2) and np.array_equal(T1, T2)
+    assert sharding.host_cpus() >= 1
+
+
+def test_bench_launcher_starts_n_fresh_ranks(tmp_path):
+    """`bench.py --gpus 2` without a launcher spawns 2 rank processes with RANK / WORLD_SIZE / MASTER_* set and
+    relays rank 0's stdout; a failing rank makes the launcher exit non-zero.  (The ranks here are a stub script:
+    no GPU in this container.)"""
+    import subprocess
+    import sys
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text("import os,sys\n"
+                    "r=int(os.environ['RANK']); w=int(os.environ['WORLD_SIZE'])\n"
+                    "assert os.environ['MASTER_ADDR']=='127.0.0.1' and int(os.environ['MASTER_PORT'])>0\n"
+                    "assert os.environ['LOCAL_RANK']==str(r)\n"
+                    "if '--fail' in sys.argv and r==1: sys.exit(3)\n"
+                    "print('{\"rank\": %d, \"world\": %d}' % (r, w))\n")
+    code = ("import sys, bench, argparse; bench.__file__=%r; sys.argv=['bench.py']+sys.argv[1:];"
+            "sys.exit(bench.launch(argparse.Namespace(gpus=2)))" % str(stub))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.strip() == '{"rank": 0, "world": 2}'       # rank 0's line only; rank 1 goes to stderr
+    assert '"rank": 1' in p.stderr
+    p = subprocess.run([sys.executable, "-c", code, "--fail"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0
