@@ -758,7 +758,7 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
     if (mode == 0 && maxQueries > RS_THREADS * RS_MAX_T) return hipErrorInvalidValue;
     /* the matcher's overflow flag is its own word (d_status[1]) and is cleared by every search: an overflowing
      * window fails THAT call only, the next call on the same extracted batch starts clean */
-    hipMemsetAsync(c->d_status + 1, 0, sizeof(int), s);
+    (void)hipMemsetAsync(c->d_status + 1, 0, sizeof(int), s);
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
