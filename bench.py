@@ -230,7 +230,8 @@ def main():
     # sanity: the batch really produced keypoints and matches
     counts = fe.ctx.orb_counts(B)
     _, nm = fe.matches(B - 1)
-    assert counts.min() > 500 and nm > 100, (counts.min(), nm)
+    if not os.environ.get("DRFE_BENCH_NO_SANITY"):      # kernel experiments with deliberately wrong results
+        assert counts.min() > 500 and nm > 100, (counts.min(), nm)
 
     out = None
     if rank == 0:

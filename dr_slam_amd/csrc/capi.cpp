@@ -8,6 +8,7 @@
 #include "lines_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -157,6 +158,10 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     for (int i = 0; i < DRFE_STAGE_COUNT; i++)
         for (int j = 0; j < 2; j++) CHIP(hipEventCreate(&c->ev[i][j]));
     drfe_build_tables(c);
+    {
+        const char* e = std::getenv("DRFE_FAST_GENERIC");
+        c->fastGeneric = (e && e[0] == '1') ? 1 : 0;
+    }
 
     /* size the arenas with the geometry of the largest frame */
     DevGeom gmax;

@@ -26,6 +26,8 @@
 #define DRFE_GRID_COLS 64     /* FRAME_GRID_COLS, reference include/Frame.h:40 */
 #define DRFE_GRID_ROWS 48     /* FRAME_GRID_ROWS, :39 */
 #define DRFE_GRID_CELLS (DRFE_GRID_COLS * DRFE_GRID_ROWS)
+#define DRFE_FASTC_MAX_EW 38       /* k_fast_cells_cols: widest evaluated area (window + alignment <= 48 pixels of a 52-pixel LDS row) */
+#define DRFE_FASTC_MAX_RPL 12      /* ... and most rows per lane (its score registers) */
 #define DRFE_FAST_MAX_WIN 60       /* largest FAST cell window (wCell+6): fits 64-byte LDS rows at any alignment */
 #define DRFE_QT_MAX_NODES 1024    /* quadtree list capacity per level (>= quota + 4) */
 #define DRFE_MATCH_MAX_CAND 256   /* candidates kept per query by the window gather */
@@ -61,6 +63,8 @@ struct DevGeom {
     int candSlotElems, kpSlotElems; /* per-slot element counts */
     int totalCells, totalTiles;
     int fastMaxWh;                  /* tallest FAST cell window of this geometry: sizes the kernel's dynamic LDS */
+    int fastCols;                   /* 1: every cell fits k_fast_cells_cols (ew <= 38, rows per lane <= 12) */
+    int fastColsRows;               /* LDS tile rows k_fast_cells_cols touches: max over cells of nrb * rpl + 6 */
     DevLevel lv[DRFE_MAX_LEVELS];
 };
 
@@ -74,6 +78,10 @@ struct FastCell {   /* one cv::FAST call of reference src/ORBextractor.cc:789-81
     uint32_t srcOff;        /* byte offset of the window's first aligned dword inside the slot's pyramid block */
     uint32_t pitch;         /* bordered row pitch of the level */
     uint32_t candOff, candCap;
+    /* column-pair layout of k_fast_cells_cols: lane = (column pair cp, row block rb); ncp = ceil(ew/2) column pairs,
+     * nrb = 64 / ncp row blocks of rpl = ceil(eh/nrb) rows each; ncpMagic = ceil(2^16/ncp): lane / ncp as a multiply */
+    uint8_t ncp, nrb, rpl, pad;
+    uint32_t ncpMagic;
 };
 
 struct BlurTile { uint16_t tx, ty; uint16_t level, pad; };
@@ -117,6 +125,7 @@ struct drfe_ctx {
     uint8_t* d_desc;          /* [slot][maxKp][32] */
     int* d_kpCount;           /* [slot] */
     int* d_status;            /* device-side error flags (overflow) */
+    int fastGeneric;          /* DRFE_FAST_GENERIC=1 in the environment: run k_fast_cells even where k_fast_cells_cols fits (A/B, tests) */
 
     /* frame glue + match */
     float* d_uRight; float* d_depth;      /* [slot][maxKp] */

@@ -102,6 +102,8 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
     g->minTh = c->cfg.min_th_fast;
     g->imgW = w; g->imgH = h;
     g->fastMaxWh = 7;
+    g->fastCols = 1;
+    g->fastColsRows = 7;
     int pyrOff = 0, blurOff = 0, candOff = 0, kpOff = 0;
     if (cells) cells->clear();
     if (tiles) tiles->clear();
@@ -168,6 +170,15 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
                 fc.candOff = 0; fc.candCap = 0;   /* filled once the level's capacity is known */
                 fc.offX = (uint16_t)(j * L.wCell); fc.offY = (uint16_t)(i * L.hCell);
                 fc.cellIdx = (uint32_t)(i * L.nCols + j);
+                {
+                    const int ew = ww - 6, eh = wh - 6;
+                    const int ncp = (ew + 1) / 2, nrb = std::min(64 / ncp, eh);
+                    const int rpl = (eh + nrb - 1) / nrb;
+                    fc.ncp = (uint8_t)ncp; fc.nrb = (uint8_t)nrb; fc.rpl = (uint8_t)rpl; fc.pad = 0;
+                    fc.ncpMagic = (uint32_t)((65536 + ncp - 1) / ncp);
+                    g->fastColsRows = std::max(g->fastColsRows, std::max(nrb * rpl + 6, wh));
+                    if (ew > DRFE_FASTC_MAX_EW || rpl > DRFE_FASTC_MAX_RPL) g->fastCols = 0;
+                }
                 if (cells) cells->push_back(fc);
                 if (wh > g->fastMaxWh) g->fastMaxWh = wh;
                 /* strict 3x3 maxima: at most one per 2x2 block of the evaluated area */

@@ -462,6 +462,211 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* FAST per cell, column-pair layout (the kernel the batch path runs when the geometry fits)          */
+
+/* k_fast_cells_cols: same result as k_fast_cells, a third fewer VALU instructions.
+ *  - the window tile holds one pixel per 16-bit lane, so an aligned ds_read_b32 is the exact f16 pair (x, x+1) of a ring
+ *    position with an even pixel offset (10 of 17) and two dwords + one v_alignbit of the others: 7 packing instructions
+ *    per pixel pair instead of 17, dwords instead of bytes from LDS;
+ *  - lane = (column pair cp, row block rb): a lane scores rpl consecutive rows of its two columns and keeps the scores
+ *    in registers; the strict 3x3 maximum takes vertical neighbours from the lane's own registers (block seams: one
+ *    ds_bpermute each way), horizontal ones through wave_shr:1 / wave_shl:1 DPP moves of the column maxima - there is
+ *    no score tile in LDS and no byte unpacking;
+ *  - two horizontally adjacent pixels cannot both be strict maxima, so a lane emits at most one candidate per row.
+ * Emission order inside a cell differs from k_fast_cells; the order key in cand1 is what the quadtree ties on. */
+#define FASTC_P16 52                              /* pixels per tile row: 26 dwords, so row blocks 8 rows apart start 16 banks apart */
+#define FASTC_PB (FASTC_P16 * 2)
+static inline int fastc_lds_bytes(int rows) { return rows * FASTC_PB + 16; }
+#define FASTC_DPP_SHR 0x138                        /* wave_shr:1 */
+#define FASTC_DPP_SHL 0x130                        /* wave_shl:1 */
+
+/* ring position (DX, DY) of the pixel pair whose 7x7 patch starts at c (a 4-byte-aligned tile address: the fill drops the odd
+ * part of the window's byte alignment).  Even pixel offsets are one aligned ds_read_b32; odd ones take the two aligned dwords
+ * around them and one v_alignbit - misaligned LDS dwords are legal on gfx950 but run ~20x slower (measured: 3.4 ms against
+ * 0.8 ms for this kernel). */
+template <int DX, int DY>
+__device__ __forceinline__ h16x2 fastc_ld(const uint8_t* c)
+{
+    constexpr int k = (DY + 3) * FASTC_P16 + (DX + 3);
+    if constexpr ((k & 1) != 0) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(c + (k - 1) * 2);
+        return __builtin_bit_cast(h16x2, __builtin_amdgcn_alignbit(p[1], p[0], 16));
+    } else {
+        return __builtin_bit_cast(h16x2, *reinterpret_cast<const uint32_t*>(c + k * 2));
+    }
+}
+
+/* c -> the 16-bit tile at the top-left corner of the 7x7 patch of pixel A; returns strength(A) | strength(A+1) << 16 */
+__device__ __forceinline__ uint32_t fastc_strength2(const uint8_t* c)
+{
+#define PX(dx, dy) fastc_ld<dx, dy>(c)
+    const h16x2 v = PX(0, 0);
+    h16x2 d[16];
+    d[0] = PX(0, 3);    d[1] = PX(1, 3);    d[2] = PX(2, 2);    d[3] = PX(3, 1);
+    d[4] = PX(3, 0);    d[5] = PX(3, -1);   d[6] = PX(2, -2);   d[7] = PX(1, -3);
+    d[8] = PX(0, -3);   d[9] = PX(-1, -3);  d[10] = PX(-2, -2); d[11] = PX(-3, -1);
+    d[12] = PX(-3, 0);  d[13] = PX(-3, 1);  d[14] = PX(-2, 2);  d[15] = PX(-1, 3);
+#undef PX
+    h16x2 lo2[8], hi2[8], lo4[8], hi4[8], t[8], u[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        lo2[m] = hmin(d[2 * m + 1], d[(2 * m + 2) & 15]);
+        hi2[m] = hmax(d[2 * m + 1], d[(2 * m + 2) & 15]);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) { lo4[m] = hmin(lo2[m], lo2[(m + 1) & 7]); hi4[m] = hmax(hi2[m], hi2[(m + 1) & 7]); }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const h16x2 e0 = d[2 * m], e1 = d[(2 * m + 9) & 15];
+        t[m] = hmin3(lo4[m], lo4[(m + 2) & 7], hmax(e0, e1));
+        u[m] = hmax3(hi4[m], hi4[(m + 2) & 7], hmin(e0, e1));
+    }
+    const h16x2 a = hmax(hmax3(hmax3(t[0], t[1], t[2]), t[3], t[4]), hmax3(t[5], t[6], t[7]));
+    const h16x2 b = hmin(hmin3(hmin3(u[0], u[1], u[2]), u[3], u[4]), hmin3(u[5], u[6], u[7]));
+    const h16x2 one = __builtin_bit_cast(h16x2, 0x00010001u), zero = __builtin_bit_cast(h16x2, 0u);
+    const h16x2 r = hmax(hmax(a - v, v - b) - one, zero);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+__device__ __forceinline__ uint32_t u2max(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, umax2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t u2min(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, umin2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t u2subs(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+template <int RMAX>
+__global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restrict__ cells, int nlevels, int pyrSlotBytes,
+                                                        int candSlotElems, int iniTh, int minTh,
+                                                        const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
+                                                        uint32_t* __restrict__ cand1, int* __restrict__ candCount,
+                                                        int* __restrict__ status, uint32_t gxMagic)
+{
+    int bx, by;
+    drfe_xcd_swizzle_2d(gxMagic, bx, by);
+    extern __shared__ __attribute__((aligned(16))) unsigned char fastLds[];
+    const FastCell fc = cells[bx];
+    const int slot = by;
+    const int lane = threadIdx.x;
+    const int ww = fc.ww, wh = fc.wh;
+    const int ew = ww - 6, eh = wh - 6;
+    const int off = fc.off;
+    const uint8_t* src = pyr + (size_t)slot * pyrSlotBytes + fc.srcOff;
+    {   /* window rows as 16-byte chunks, widened to one pixel per 16-bit lane.  Tile index k of a row holds byte k + sh of
+           the aligned source row, sh = off & 1: pixel (wx, wy) of the window sits at index (off & 2) + wx, so every pixel
+           pair a lane reads starts at an even index.  A chunk is loaded only if the window needs its first byte (and the
+           dword behind it only if the window reaches it), which keeps the over-read inside the level's bordered row */
+        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        const int need = ww + off;                /* bytes of the aligned row the window covers */
+        const int nch = (need + 15) >> 4;         /* chunks per window row (<= 3) */
+        const int nitems = wh * nch;
+        const int sh = off & 1;
+        const uint32_t selE = sh ? 0x0C020C01u : 0x0C010C00u, selO = sh ? 0x0C040C03u : 0x0C030C02u;
+        for (int i = lane; i < nitems; i += 64) {
+            const int r = nch == 1 ? i : nch == 2 ? (i >> 1) : (int)(((uint32_t)i * 21846u) >> 16);
+            const int c = i - r * nch;
+            const uint8_t* p = src + (size_t)r * fc.pitch + c * 16;
+            const u32x4_a4 g = *reinterpret_cast<const u32x4_a4*>(p);
+            uint32_t g4 = 0;
+            if (sh && c * 16 + 16 < need) g4 = *reinterpret_cast<const uint32_t*>(p + 16);
+            uint2* t = reinterpret_cast<uint2*>(fastLds + r * FASTC_PB + c * 32);
+            t[0] = make_uint2(__builtin_amdgcn_perm(0u, g.x, selE), __builtin_amdgcn_perm(g.y, g.x, selO));
+            t[1] = make_uint2(__builtin_amdgcn_perm(0u, g.y, selE), __builtin_amdgcn_perm(g.z, g.y, selO));
+            t[2] = make_uint2(__builtin_amdgcn_perm(0u, g.z, selE), __builtin_amdgcn_perm(g.w, g.z, selO));
+            t[3] = make_uint2(__builtin_amdgcn_perm(0u, g.w, selE), __builtin_amdgcn_perm(g4, g.w, selO));
+        }
+    }
+    __syncthreads();
+    const int ncp = fc.ncp, R = fc.rpl, nrb = fc.nrb;
+    const int rb = (int)(((uint32_t)lane * fc.ncpMagic) >> 16), cp = lane - rb * ncp;
+    const int x = 2 * cp, y0 = rb * R;
+    const bool laneOn = rb < nrb;
+    /* pixels outside the evaluated area (odd width, rows past the last block's end, idle lanes) score 0 = "neighbour
+       outside the cell"; what the tile holds there is never looked at */
+    const uint32_t mcol = laneOn ? ((x < ew ? 0xFFFFu : 0u) | (x + 1 < ew ? 0xFFFF0000u : 0u)) : 0u;
+    const int nvalid = eh - y0;
+    const uint8_t* base = fastLds + (laneOn ? y0 * FASTC_PB + ((off & 2) + x) * 2 : 0);
+    uint32_t s[RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; i++) {
+        s[i] = 0;
+        if (i < R) {
+            const uint32_t r = fastc_strength2(base + i * FASTC_PB);
+            s[i] = i < nvalid ? (r & mcol) : 0u;
+        }
+    }
+    /* block seams: the row above this lane's first row is the last row of lane - ncp, the row below its last one the
+       first row of lane + ncp */
+    uint32_t last = 0;
+#pragma unroll
+    for (int i = 0; i < RMAX; i++)
+        if (i == R - 1) last = s[i];
+    uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - ncp) << 2, (int)last);
+    uint32_t down = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + ncp) << 2, (int)s[0]);
+    if (rb == 0) up = 0;
+    if (rb + 1 >= nrb) down = 0;
+    /* strict 3x3 maximum: V = the two vertical neighbours, C3 = column maximum incl. the pixel; the left / right column
+       maxima come from the neighbouring lanes (wave shifts; the selectors blank the cell's outer columns) */
+    const uint32_t selA = cp == 0 ? 0x05040C0Cu : 0x05040302u;          /* [own col x   | left lane's col x-1] */
+    const uint32_t selB = cp == ncp - 1 ? 0x0C0C0302u : 0x05040302u;    /* [right lane's col x+2 | own col x+1] */
+    const uint32_t th7 = (uint32_t)(minTh - 1) * 0x00010001u, th20 = (uint32_t)(iniTh - 1) * 0x00010001u;
+    /* rows i >= R hold zero scores: they run through the same instructions (no control flow around register arrays) and
+       come out as "no maximum" */
+    uint32_t dm[RMAX], acc20 = 0;
+#pragma unroll
+    for (int i = 0; i < RMAX; i++) {
+        const uint32_t sup = i == 0 ? up : s[i > 0 ? i - 1 : 0];
+        const uint32_t sdn = (i == R - 1 || i == RMAX - 1) ? down : s[i + 1 < RMAX ? i + 1 : i];
+        const uint32_t V = u2max(sup, sdn), C3 = u2max(V, s[i]);
+        const uint32_t L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHR, 0xF, 0xF, true);   /* wave_shr:1 */
+        const uint32_t Rr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHL, 0xF, 0xF, true);  /* wave_shl:1 */
+        const uint32_t A = __builtin_amdgcn_perm(C3, L, selA), B = __builtin_amdgcn_perm(Rr, C3, selB);
+        const uint32_t N = u2max(u2max(V, A), B);
+        dm[i] = u2subs(s[i], N);                                   /* non-zero: strictly above all eight neighbours */
+        acc20 |= u2min(u2subs(s[i], th20), dm[i]);
+    }
+    const bool any20 = __any(acc20 != 0);                              /* fallback decided per cell after NMS@ini */
+    const uint32_t th = any20 ? th20 : th7;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < RMAX; i++) {
+        dm[i] = u2min(u2subs(s[i], th), dm[i]);
+        cnt += dm[i] != 0 ? 1 : 0;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    int cbase = 0;
+    if (lane == 0) cbase = atomicAdd(&candCount[slot * nlevels + fc.level], total);
+    cbase = __shfl(cbase, 0);
+    if (cbase + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
+    size_t pos = (size_t)slot * candSlotElems + fc.candOff + cbase + (incl - cnt);
+#pragma unroll
+    for (int i = 0; i < RMAX; i++)
+        if (dm[i] != 0) {
+            const uint32_t hi = dm[i] >> 16 ? 1u : 0u;
+            const uint32_t sc = hi ? s[i] >> 16 : s[i] & 0xFFFFu;
+            const uint32_t xx = (uint32_t)x + hi, yy = (uint32_t)(y0 + i);
+            /* keypoint coordinates as the reference leaves them in vToDistributeKeys (:822-823) */
+            const uint32_t kx = xx + 3 + fc.offX, ky = yy + 3 + fc.offY;
+            cand0[pos] = kx | (ky << 12) | (sc << 24);
+            cand1[pos] = (fc.cellIdx << 12) | (yy << 6) | xx;          /* emission order */
+            pos++;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* quadtree                                                                                          */
 
 /* k_quadtree<QT_THREADS, QT_KPT, QT_MAXN>: workgroup size, candidate keys a thread keeps in registers,
@@ -1199,10 +1404,16 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_PYRAMID, s);
 
     prof_begin(c, DRFE_STAGE_FAST, s);
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), (size_t)fast_lds_bytes(g.fastMaxWh), s, c->d_cells,
-                       g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr,
-                       c->d_cand0, c->d_cand1, c->d_candCount, c->d_status, fast_sc_off(g.fastMaxWh),
-                       drfe_div_magic((uint32_t)g.totalCells));
+    if (g.fastCols && !c->fastGeneric)
+        hipLaunchKernelGGL((k_fast_cells_cols<DRFE_FASTC_MAX_RPL>), dim3(g.totalCells, nframes), dim3(64),
+                           (size_t)fastc_lds_bytes(g.fastColsRows), s, c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems,
+                           g.iniTh, g.minTh, c->d_pyr, c->d_cand0, c->d_cand1, c->d_candCount, c->d_status,
+                           drfe_div_magic((uint32_t)g.totalCells));
+    else
+        hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), (size_t)fast_lds_bytes(g.fastMaxWh), s, c->d_cells,
+                           g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr,
+                           c->d_cand0, c->d_cand1, c->d_candCount, c->d_status, fast_sc_off(g.fastMaxWh),
+                           drfe_div_magic((uint32_t)g.totalCells));
     prof_end(c, DRFE_STAGE_FAST, s);
 
     prof_begin(c, DRFE_STAGE_QUADTREE, s);
