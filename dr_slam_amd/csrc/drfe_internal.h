@@ -64,6 +64,7 @@ struct DevGeom {
     int totalCells, totalTiles;
     int fastMaxWh;                  /* tallest FAST cell window of this geometry: sizes the kernel's dynamic LDS */
     int fastCols;                   /* 1: every cell fits k_fast_cells_cols (ew <= 38, rows per lane <= 12) */
+    int fastColsSmall;              /* cells [0, fastColsSmall) of the table have rpl <= 8 */
     int fastColsRows;               /* LDS tile rows k_fast_cells_cols touches: max over cells of nrb * rpl + 6 */
     DevLevel lv[DRFE_MAX_LEVELS];
 };

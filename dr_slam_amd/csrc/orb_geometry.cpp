@@ -172,8 +172,9 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
                 fc.cellIdx = (uint32_t)(i * L.nCols + j);
                 {
                     const int ew = ww - 6, eh = wh - 6;
-                    const int ncp = (ew + 1) / 2, nrb = std::min(64 / ncp, eh);
-                    const int rpl = (eh + nrb - 1) / nrb;
+                    const int ncp = (ew + 1) / 2, nrb0 = std::min(64 / ncp, eh);
+                    const int rpl = (eh + nrb0 - 1) / nrb0;
+                    const int nrb = (eh + rpl - 1) / rpl;      /* every block but the last one is full, the last one not empty */
                     fc.ncp = (uint8_t)ncp; fc.nrb = (uint8_t)nrb; fc.rpl = (uint8_t)rpl; fc.pad = 0;
                     fc.ncpMagic = (uint32_t)((65536 + ncp - 1) / ncp);
                     g->fastColsRows = std::max(g->fastColsRows, std::max(nrb * rpl + 6, wh));
@@ -257,6 +258,14 @@ int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastC
                 }
             }
         }
+    }
+    /* k_fast_cells_cols keeps a lane's row scores in registers: the cells of at most 8 rows per lane (the four large levels
+     * at 640x480) come first and run the 8-row instantiation, the rest the DRFE_FASTC_MAX_RPL one.  The table's order is
+     * free: FastCell::cellIdx carries the emission order. */
+    g->fastColsSmall = 0;
+    if (cells) {
+        std::stable_partition(cells->begin(), cells->end(), [](const FastCell& f) { return f.rpl <= 8; });
+        for (const FastCell& f : *cells) g->fastColsSmall += f.rpl <= 8 ? 1 : 0;
     }
     g->pyrSlotBytes = pyrOff;
     g->blurSlotBytes = blurOff;

@@ -523,8 +523,8 @@ __device__ __forceinline__ uint32_t fastc_strength2(const uint8_t* c)
     }
     const h16x2 a = hmax(hmax3(hmax3(t[0], t[1], t[2]), t[3], t[4]), hmax3(t[5], t[6], t[7]));
     const h16x2 b = hmin(hmin3(hmin3(u[0], u[1], u[2]), u[3], u[4]), hmin3(u[5], u[6], u[7]));
-    const h16x2 one = __builtin_bit_cast(h16x2, 0x00010001u), zero = __builtin_bit_cast(h16x2, 0u);
-    const h16x2 r = hmax(hmax(a - v, v - b) - one, zero);
+    const h16x2 one = __builtin_bit_cast(h16x2, 0x00010001u);
+    const h16x2 r = hmax3(a - v, v - b, one) - one;              /* max(S - 1, 0) */
     return __builtin_bit_cast(uint32_t, r);
 }
 
@@ -546,12 +546,12 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
                                                         int candSlotElems, int iniTh, int minTh,
                                                         const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
                                                         uint32_t* __restrict__ cand1, int* __restrict__ candCount,
-                                                        int* __restrict__ status, uint32_t gxMagic)
+                                                        int* __restrict__ status, uint32_t gxMagic, int cellFirst)
 {
     int bx, by;
     drfe_xcd_swizzle_2d(gxMagic, bx, by);
     extern __shared__ __attribute__((aligned(16))) unsigned char fastLds[];
-    const FastCell fc = cells[bx];
+    const FastCell fc = cells[cellFirst + bx];
     const int slot = by;
     const int lane = threadIdx.x;
     const int ww = fc.ww, wh = fc.wh;
@@ -590,15 +590,18 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     /* pixels outside the evaluated area (odd width, rows past the last block's end, idle lanes) score 0 = "neighbour
        outside the cell"; what the tile holds there is never looked at */
     const uint32_t mcol = laneOn ? ((x < ew ? 0xFFFFu : 0u) | (x + 1 < ew ? 0xFFFF0000u : 0u)) : 0u;
-    const int nvalid = eh - y0;
     const uint8_t* base = fastLds + (laneOn ? y0 * FASTC_PB + ((off & 2) + x) * 2 : 0);
+    /* rows past the area's last one exist only at the end of the last row block: rows i >= iInv of the lanes with
+       rb == nrb - 1 (iInv is wave-uniform) */
+    const int iInv = eh - (nrb - 1) * R;
+    const uint32_t mlast = rb == nrb - 1 ? 0u : mcol;
     uint32_t s[RMAX];
 #pragma unroll
     for (int i = 0; i < RMAX; i++) {
         s[i] = 0;
         if (i < R) {
             const uint32_t r = fastc_strength2(base + i * FASTC_PB);
-            s[i] = i < nvalid ? (r & mcol) : 0u;
+            s[i] = r & (i < iInv ? mcol : mlast);
         }
     }
     /* block seams: the row above this lane's first row is the last row of lane - ncp, the row below its last one the
@@ -611,34 +614,34 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     uint32_t down = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + ncp) << 2, (int)s[0]);
     if (rb == 0) up = 0;
     if (rb + 1 >= nrb) down = 0;
-    /* strict 3x3 maximum: V = the two vertical neighbours, C3 = column maximum incl. the pixel; the left / right column
-       maxima come from the neighbouring lanes (wave shifts; the selectors blank the cell's outer columns) */
+    /* strict 3x3 maximum: C3 = column maximum incl. the pixel; the left / right column maxima come from the neighbouring
+       lanes (wave shifts; the selectors blank the cell's outer columns); N = the eight neighbours' maximum.  A pixel is
+       kept at threshold t iff s > max(N, t - 1).  Rows i >= R hold zero scores: they run through the same instructions
+       (no control flow around register arrays) and come out as "no maximum". */
     const uint32_t selA = cp == 0 ? 0x05040C0Cu : 0x05040302u;          /* [own col x   | left lane's col x-1] */
     const uint32_t selB = cp == ncp - 1 ? 0x0C0C0302u : 0x05040302u;    /* [right lane's col x+2 | own col x+1] */
     const uint32_t th7 = (uint32_t)(minTh - 1) * 0x00010001u, th20 = (uint32_t)(iniTh - 1) * 0x00010001u;
-    /* rows i >= R hold zero scores: they run through the same instructions (no control flow around register arrays) and
-       come out as "no maximum" */
-    uint32_t dm[RMAX], acc20 = 0;
+    uint32_t dm[RMAX], nb[RMAX], acc20 = 0;
 #pragma unroll
     for (int i = 0; i < RMAX; i++) {
         const uint32_t sup = i == 0 ? up : s[i > 0 ? i - 1 : 0];
         const uint32_t sdn = (i == R - 1 || i == RMAX - 1) ? down : s[i + 1 < RMAX ? i + 1 : i];
         const uint32_t V = u2max(sup, sdn), C3 = u2max(V, s[i]);
-        const uint32_t L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHR, 0xF, 0xF, true);   /* wave_shr:1 */
-        const uint32_t Rr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHL, 0xF, 0xF, true);  /* wave_shl:1 */
+        const uint32_t L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHR, 0xF, 0xF, true);
+        const uint32_t Rr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHL, 0xF, 0xF, true);
         const uint32_t A = __builtin_amdgcn_perm(C3, L, selA), B = __builtin_amdgcn_perm(Rr, C3, selB);
-        const uint32_t N = u2max(u2max(V, A), B);
-        dm[i] = u2subs(s[i], N);                                   /* non-zero: strictly above all eight neighbours */
-        acc20 |= u2min(u2subs(s[i], th20), dm[i]);
+        nb[i] = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(h16x2, V), __builtin_bit_cast(h16x2, A),
+                                                   __builtin_bit_cast(h16x2, B)));     /* small integers = exact f16 subnormals */
+        dm[i] = u2subs(s[i], u2max(nb[i], th20));
+        acc20 |= dm[i];
     }
-    const bool any20 = __any(acc20 != 0);                              /* fallback decided per cell after NMS@ini */
-    const uint32_t th = any20 ? th20 : th7;
     int cnt = 0;
+    if (!__any(acc20 != 0)) {                                          /* fallback decided per cell after NMS@ini */
 #pragma unroll
-    for (int i = 0; i < RMAX; i++) {
-        dm[i] = u2min(u2subs(s[i], th), dm[i]);
-        cnt += dm[i] != 0 ? 1 : 0;
+        for (int i = 0; i < RMAX; i++) dm[i] = u2subs(s[i], u2max(nb[i], th7));
     }
+#pragma unroll
+    for (int i = 0; i < RMAX; i++) cnt += dm[i] != 0 ? 1 : 0;
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1404,12 +1407,18 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_PYRAMID, s);
 
     prof_begin(c, DRFE_STAGE_FAST, s);
-    if (g.fastCols && !c->fastGeneric)
-        hipLaunchKernelGGL((k_fast_cells_cols<DRFE_FASTC_MAX_RPL>), dim3(g.totalCells, nframes), dim3(64),
-                           (size_t)fastc_lds_bytes(g.fastColsRows), s, c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems,
-                           g.iniTh, g.minTh, c->d_pyr, c->d_cand0, c->d_cand1, c->d_candCount, c->d_status,
-                           drfe_div_magic((uint32_t)g.totalCells));
-    else
+    if (g.fastCols && !c->fastGeneric) {
+        const int nSmall = g.fastColsSmall, nBig = g.totalCells - nSmall;
+        if (nSmall > 0)
+            hipLaunchKernelGGL((k_fast_cells_cols<8>), dim3(nSmall, nframes), dim3(64), (size_t)fastc_lds_bytes(g.fastColsRows), s,
+                               c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr, c->d_cand0,
+                               c->d_cand1, c->d_candCount, c->d_status, drfe_div_magic((uint32_t)nSmall), 0);
+        if (nBig > 0)
+            hipLaunchKernelGGL((k_fast_cells_cols<DRFE_FASTC_MAX_RPL>), dim3(nBig, nframes), dim3(64),
+                               (size_t)fastc_lds_bytes(g.fastColsRows), s, c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems,
+                               g.iniTh, g.minTh, c->d_pyr, c->d_cand0, c->d_cand1, c->d_candCount, c->d_status,
+                               drfe_div_magic((uint32_t)nBig), nSmall);
+    } else
         hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), (size_t)fast_lds_bytes(g.fastMaxWh), s, c->d_cells,
                            g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr,
                            c->d_cand0, c->d_cand1, c->d_candCount, c->d_status, fast_sc_off(g.fastMaxWh),
