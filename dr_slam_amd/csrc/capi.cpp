@@ -2,6 +2,7 @@
  * staging.  No compute happens on the host: every entry point either launches the HIP kernels or
  * copies their results.  There is no CPU fallback — a missing GPU / HIP failure is DRFE_ERR_HIP. */
 #include "drfe_internal.h"
+#include "post_internal.h"
 #include "match_internal.h"
 #include "planes_internal.h"
 #include "bow_internal.h"
@@ -82,6 +83,7 @@ void drfe_destroy(drfe_ctx* c)
     drfe_planes_free(c);
     drfe_bow_free(c);
     drfe_lines_free(c);
+    drfe_post_free(c);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
                     c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_kpsUn, c->d_desc,
                     c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc, c->d_match,

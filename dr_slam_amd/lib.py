@@ -35,7 +35,8 @@ SYMBOLS = (
     "drfe_profile_stage_ms", "drfe_stream_sync", "drfe_planes_ahc", "drfe_planes_ahc_batch", "drfe_planes_ahc_blocks",
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
-    "drfe_lsd_search_by_projection_map",
+    "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
+    "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -53,8 +54,16 @@ KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4
                           ("s_point_in_octave_y", "<f4"), ("e_point_in_octave_x", "<f4"), ("e_point_in_octave_y", "<f4"),
                           ("line_length", "<f4"), ("num_of_pixels", "<i4")])
 
-CAPE_PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("mean", "<f8", (3,)), ("d", "<f8"), ("mse", "<f4"),
+CAPE_PLANE_POST_DTYPE = np.dtype([("coef", "<f4", (4,)), ("accepted", "<i4"), ("n_voxels", "<i4")])      # drfe_plane_post, 24 B
+SURFACE_NORMAL_DTYPE = np.dtype([("normal", "<f4", (3,)), ("camera_position", "<f4", (3,)), ("frame_x", "<i4"),
+                                 ("frame_y", "<i4")])                                               # drfe_surface_normal, 32 B
+
+PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("mean", "<f8", (3,)), ("d", "<f8"), ("mse", "<f4"),
                              ("score", "<f4"), ("n_points", "<i4"), ("pad", "<i4")])
+
+PLANE_POST_DTYPE = np.dtype([("coef", "<f4", (4,)), ("accepted", "<i4"), ("n_voxels", "<i4")])      # drfe_plane_post, 24 B
+SURFACE_NORMAL_DTYPE = np.dtype([("normal", "<f4", (3,)), ("camera_position", "<f4", (3,)), ("frame_x", "<i4"),
+                                 ("frame_y", "<i4")])                                               # drfe_surface_normal, 32 B
 
 PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("center", "<f8", (3,)), ("mse", "<f8"), ("curvature", "<f8"),
                         ("n_points", "<i4"), ("rid", "<i4")])
@@ -152,6 +161,16 @@ def load() -> C.CDLL:
     L.drfe_planes_ahc.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
     L.drfe_planes_ahc_blocks.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, vp, i32]
     L.drfe_planes_cape.argtypes = [vp, vp, i32, i32, sz, vp, i32, f32, f32, vp, i32, C.POINTER(i32), vp, vp, vp, vp]
+    f64 = C.c_double
+    L.drfe_plane_voxel_grid.argtypes = [vp, i32, f32, vp, i32, C.POINTER(i32)]
+    L.drfe_plane_refit.argtypes = [vp, vp, i32, f64, C.POINTER(i32)]
+    L.drfe_planes_ahc_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, vp, vp, f32, f64, vp, vp, vp, i32,
+                                              C.POINTER(i32), C.POINTER(i32)]
+    L.drfe_planes_cape_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, vp, vp, i32, f32, f64, vp, vp, vp, i32,
+                                               C.POINTER(i32), C.POINTER(i32)]
+    L.drfe_surface_normals.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
+    L.drfe_surface_normals_batch.argtypes = [vp, vp, sz, sz, i32, i32, vp, f32, f32, i32, vp]
+    L.drfe_surface_normals_download.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.drfe_profile_enable.argtypes = [vp, i32]
     L.drfe_profile_stage_ms.argtypes = [vp, vp]
     L.drfe_stream_sync.argtypes = [vp]
@@ -161,6 +180,30 @@ def load() -> C.CDLL:
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def plane_voxel_grid(xyz, leaf=0.05):
+    """pcl::VoxelGrid(leaf) of an [n, 3] float32 point list (inputCloud order) -> [m, 3] centroids. Host code."""
+    L = load()
+    p = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros_like(p)
+    n = C.c_int()
+    rc = L.drfe_plane_voxel_grid(_p(p), len(p), np.float32(leaf), _p(out), len(p), C.byref(n))
+    if rc != 0:
+        raise DrfeError(f"drfe_plane_voxel_grid failed ({rc})")
+    return out[:n.value].copy()
+
+
+def plane_refit(coef4, xyz, dist_threshold):
+    """Frame::MaxPointDistanceFromPlane(coef, cloud) -> (valid, coef after the refit). Host code."""
+    L = load()
+    c = np.ascontiguousarray(coef4, np.float32).copy()
+    p = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    v = C.c_int()
+    rc = L.drfe_plane_refit(_p(c), _p(p), len(p), float(dist_threshold), C.byref(v))
+    if rc != 0:
+        raise DrfeError(f"drfe_plane_refit failed ({rc})")
+    return bool(v.value), c
 
 
 def make_camera(fx, fy, cx, cy, bf, depth_map_factor, width, height) -> Camera:
@@ -669,6 +712,77 @@ class Context:
         self._chk(self.L.drfe_planes_ahc_blocks(self.h, _p(d), w, h, w, _p(np.ascontiguousarray(K4, np.float32)),
                                                 np.float32(depth_factor), _p(blocks), _p(vn), nb), "drfe_planes_ahc_blocks")
         return blocks, vn[:, 0], vn[:, 1]
+
+    # --- plane post-processing + surface normals (Frame::ComputePlanes after the extractor) ------------
+    def planes_ahc_postprocess(self, depth16, K4, depth_factor, ahc, max_point_dist, dist_threshold):
+        """ahc = the dict planes_ahc returned. -> dict(post, voxels=[per plane [m,3]], n_accepted, plane_num)."""
+        d = np.ascontiguousarray(depth16, np.uint16)
+        h, w = d.shape
+        planes = np.ascontiguousarray(ahc["planes"], PLANE_DTYPE)
+        n = len(planes)
+        off = np.zeros(n + 1, np.int32)
+        off[1:] = np.cumsum([len(m) for m in ahc["members"]])
+        idx = np.concatenate([np.asarray(m, np.int32) for m in ahc["members"]]) if n else np.zeros(0, np.int32)
+        idx = np.ascontiguousarray(idx, np.int32)
+        post = np.zeros(n, PLANE_POST_DTYPE)
+        vox = np.zeros((max(len(idx), 1), 3), np.float32)
+        voff = np.zeros(n + 1, np.int32)
+        na, pn = C.c_int(), C.c_int()
+        self._chk(self.L.drfe_planes_ahc_postprocess(self.h, _p(d), w, h, w, _p(np.ascontiguousarray(K4, np.float32)),
+                                                     np.float32(depth_factor), _p(planes), n, _p(off), _p(idx),
+                                                     np.float32(max_point_dist), float(dist_threshold), _p(post), _p(vox),
+                                                     _p(voff), len(vox), C.byref(na), C.byref(pn)),
+                  "drfe_planes_ahc_postprocess")
+        return dict(post=post, voxels=[vox[voff[i]:voff[i + 1]].copy() for i in range(n)], n_accepted=na.value,
+                    plane_num=pn.value)
+
+    def planes_cape_postprocess(self, depth_m, K4, cape, max_point_dist, dist_threshold):
+        """cape = the dict planes_cape returned. -> dict(post, voxels, n_accepted, plane_num)."""
+        d = np.ascontiguousarray(depth_m, np.float32)
+        h, w = d.shape
+        planes = np.ascontiguousarray(cape["planes"], CAPE_PLANE_DTYPE)
+        seg = np.ascontiguousarray(cape["seg"], np.uint8)
+        n = len(planes)
+        post = np.zeros(n, PLANE_POST_DTYPE)
+        vox = np.zeros((h * w, 3), np.float32)
+        voff = np.zeros(n + 1, np.int32)
+        na, pn = C.c_int(), C.c_int()
+        self._chk(self.L.drfe_planes_cape_postprocess(self.h, _p(d), w, h, w, _p(np.ascontiguousarray(K4, np.float32)),
+                                                      _p(seg), _p(planes), n, np.float32(max_point_dist),
+                                                      float(dist_threshold), _p(post), _p(vox), _p(voff), len(vox),
+                                                      C.byref(na), C.byref(pn)), "drfe_planes_cape_postprocess")
+        return dict(post=post, voxels=[vox[voff[i]:voff[i + 1]].copy() for i in range(n)], n_accepted=na.value,
+                    plane_num=pn.value)
+
+    def surface_normals(self, depth_m, K4, max_point_dist, taps=False):
+        """vSurfaceNormal of Frame::ComputePlanes for one CV_32F depth image (metres)."""
+        d = np.ascontiguousarray(depth_m, np.float32)
+        h, w = d.shape
+        W, H = (w + 2) // 3, (h + 2) // 3
+        out = np.zeros((H // 2) * (W // 2), SURFACE_NORMAL_DTYPE)
+        n = C.c_int()
+        cloud = np.zeros((H, W, 3), np.float32) if taps else None
+        nrm = np.zeros((H, W, 3), np.float32) if taps else None
+        dist = np.zeros((H, W), np.float32) if taps else None
+        self._chk(self.L.drfe_surface_normals(self.h, _p(d), w, h, w, _p(np.ascontiguousarray(K4, np.float32)),
+                                              np.float32(max_point_dist), _p(out), len(out), C.byref(n), _p(cloud), _p(nrm),
+                                              _p(dist)), "drfe_surface_normals")
+        return (out[:n.value], cloud, nrm, dist) if taps else out[:n.value]
+
+    def surface_normals_batch_ptr(self, d_depth: int, frame_stride: int, row_stride: int, w: int, h: int, K4, depth_factor,
+                                  max_point_dist, nframes: int, stream: int = 0):
+        self._chk(self.L.drfe_surface_normals_batch(self.h, C.c_void_p(d_depth), frame_stride, row_stride, w, h,
+                                                    _p(np.ascontiguousarray(K4, np.float32)), np.float32(depth_factor),
+                                                    np.float32(max_point_dist), nframes, C.c_void_p(stream)),
+                  "drfe_surface_normals_batch")
+
+    def surface_normals_download(self, slot: int):
+        n = C.c_int()
+        self._chk(self.L.drfe_surface_normals_download(self.h, slot, None, 0, C.byref(n)), "drfe_surface_normals_download")
+        out = np.zeros(n.value, SURFACE_NORMAL_DTYPE)
+        self._chk(self.L.drfe_surface_normals_download(self.h, slot, _p(out), len(out), C.byref(n)),
+                  "drfe_surface_normals_download")
+        return out
 
     # --- measurement -------------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -457,6 +457,61 @@ int drfe_planes_cape(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t s
                      uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Plane post-processing and surface normals (replaces the PCL part of Frame::ComputePlanes / ComputePlanes_CAPE,  */
+/* src/Frame.cc:949-1094, 1096-1213, and Frame::MaxPointDistanceFromPlane, src/Frame.cc:1222-1307)                 */
+
+/* One plane after the per-plane loop of Frame::ComputePlanes (:952-1011): coef = the 4x1 float Mat pushed into
+ * mvPlaneCoefficients when accepted (normal, d AFTER the RANSAC + least-squares refit of MaxPointDistanceFromPlane, sign
+ * kept on the side of the extractor's d), else the extractor's (normal, d); n_voxels = coarseCloud->size(). */
+typedef struct drfe_plane_post {
+    float coef[4];
+    int32_t accepted;   /* 1: coefficients + voxel cloud pushed (mvPlaneCoefficients / mvPlanePoints) */
+    int32_t n_voxels;
+} drfe_plane_post;
+
+/* pcl::VoxelGrid (leaf x leaf x leaf) of a point list in inputCloud order: centroids ordered by leaf index.  Host code. */
+int drfe_plane_voxel_grid(const float* xyz, int n, float leaf, float* out_xyz, int cap, int* n_out);
+/* Frame::MaxPointDistanceFromPlane(plane, cloud) with Plane.DistanceThreshold = dist_threshold: *valid = its return value;
+ * coef4 is overwritten by the refit when valid.  Host code. */
+int drfe_plane_refit(float* coef4, const float* xyz, int n, double dist_threshold, int* valid);
+
+/* The per-plane loop of Frame::ComputePlanes for the planes drfe_planes_ahc returned (same depth image, K4, depth_factor;
+ * planes / member_offsets / member_idx as that call filled them).  max_point_dist = Point.MaxDistance, dist_threshold =
+ * Plane.DistanceThreshold.  Outputs: post[n_planes]; voxel_offsets[n_planes + 1] + voxel_xyz (may be NULL) = mvPlanePoints
+ * of the accepted planes as CSR; *n_accepted = mvPlaneCoefficients.size(); *plane_num (may be NULL) = planeDetector.plane_num_
+ * after `-= fail_planes`. */
+int drfe_planes_ahc_postprocess(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
+                                const drfe_plane* planes, int n_planes, const int32_t* member_offsets, const int32_t* member_idx,
+                                float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz,
+                                int32_t* voxel_offsets, int cap_voxels, int* n_accepted, int* plane_num);
+/* The same loop of Frame::ComputePlanes_CAPE (:1111-1141) for the planes / seg image drfe_planes_cape returned: plane_cloud[i]
+ * = the points of the pixels labelled i + 1 in raster order (src/PlaneExtractor.cpp:171-188). */
+int drfe_planes_cape_postprocess(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, const uint8_t* seg,
+                                 const drfe_cape_plane* planes, int n_planes, float max_point_dist, double dist_threshold,
+                                 drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets, int cap_voxels, int* n_accepted,
+                                 int* plane_num);
+
+/* SurfaceNormal (include/LSDextractor.h:34-41): cv::Point3f normal, cv::Point3f cameraPosition, cv::Point2i FramePosition */
+typedef struct drfe_surface_normal {
+    float normal[3];            /* NaN where PCL leaves the normal undefined (border, depth discontinuity) */
+    float camera_position[3];
+    int32_t frame_x, frame_y;
+} drfe_surface_normal;
+
+/* vSurfaceNormal of Frame::ComputePlanes (:1025-1090): depth_m = the CV_32F depth in metres (`stride` elements per row),
+ * K4 = {fx, fy, cx, cy} (Frame's static floats).  out[(h3/2) * (w3/2)] with w3 = ceil(w/3), h3 = ceil(h/3), rows of odd m,
+ * inside a row odd n, as the reference pushes them.  Parity taps (may be NULL): the organized cloud (w3*h3*3), every normal
+ * (w3*h3*3), the distance map (w3*h3). */
+int drfe_surface_normals(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, float max_point_dist,
+                         drfe_surface_normal* out, int cap, int* n_out, float* cloud_tap, float* normals_tap, float* dist_tap);
+/* The same for nframes device-resident raw depth images (CV_16U; depth = raw * depth_factor in float32, as
+ * imDepth.convertTo does): asynchronous on `stream` (hipStream_t; NULL = the context stream), results stay on the device. */
+int drfe_surface_normals_batch(drfe_ctx* ctx, const uint16_t* d_depth, size_t frame_stride, size_t row_stride, int w, int h,
+                               const float* K4, float depth_factor, float max_point_dist, int nframes, void* stream);
+/* Records of frame `slot` of the most recent drfe_surface_normals_batch (synchronises). */
+int drfe_surface_normals_download(drfe_ctx* ctx, int slot, drfe_surface_normal* out, int cap, int* n_out);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* measurement                                                                                       */
 enum { DRFE_STAGE_PYRAMID = 0, DRFE_STAGE_FAST, DRFE_STAGE_QUADTREE, DRFE_STAGE_BLUR, DRFE_STAGE_DESC,
        DRFE_STAGE_GLUE, DRFE_STAGE_MATCH, DRFE_STAGE_COUNT };

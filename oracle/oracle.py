@@ -767,3 +767,109 @@ def cape_planes(depth_m, K4, patch=20, cos_angle_max=None, max_merge_dist=50.0):
         L.orc_cape_free(H)
     return dict(planes=planes, MSE=ms[:, 0], score=ms[:, 1], nr_pts=npts, seg=seg, cells=cells, cell_mst=mst,
                 cell_planar=pn[:, 0], cell_npts=pn[:, 1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Frame::ComputePlanes after the extractor: voxel grid, RANSAC refit, surface normals (oracle/post_oracle.cpp)
+
+def post_voxel_grid(xyz, leaf=0.05):
+    L = lib()
+    p = _c(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros_like(p)
+    L.orc_post_voxel_grid.restype = C.c_int
+    L.orc_post_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    n = L.orc_post_voxel_grid(_p(p), len(p), np.float32(leaf), _p(out))
+    return out[:n].copy()
+
+
+def post_refit(coef4, xyz, dist_threshold):
+    """Frame::MaxPointDistanceFromPlane -> (valid, coef)."""
+    L = lib()
+    c = _c(coef4, np.float32).copy()
+    p = _c(xyz, np.float32).reshape(-1, 3)
+    L.orc_post_refit.restype = C.c_int
+    L.orc_post_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+    v = L.orc_post_refit(_p(c), _p(p), len(p), float(dist_threshold))
+    return bool(v), c
+
+
+def post_surface_normals(depth_m, K4, max_point_dist):
+    """-> (cloud [H3, W3, 3], normals [H3, W3, 3]) of the 3x-subsampled organized cloud."""
+    L = lib()
+    d = _c(depth_m, np.float32)
+    h, w = d.shape
+    W, H = (w + 2) // 3, (h + 2) // 3
+    cloud = np.zeros((H, W, 3), np.float32)
+    nrm = np.zeros((H, W, 3), np.float32)
+    L.orc_post_surface_normals.restype = None
+    L.orc_post_surface_normals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long] + [C.c_float] * 5 + [C.c_void_p] * 3
+    L.orc_post_surface_normals(_p(d), w, h, w, *(np.float32(v) for v in K4), np.float32(max_point_dist), _p(cloud), _p(nrm), None)
+    return cloud, nrm
+
+
+def post_surface_normal_records(cloud, nrm):
+    """The vSurfaceNormal list (src/Frame.cc:1069-1090): odd rows, odd columns."""
+    H, W, _ = cloud.shape
+    rows, cols = np.arange(1, H, 2), np.arange(1, W, 2)
+    rr, cc = np.meshgrid(rows, cols, indexing="ij")
+    return nrm[rr, cc].reshape(-1, 3), cloud[rr, cc].reshape(-1, 3), (cc * 3).reshape(-1), (rr * 3).reshape(-1)
+
+
+def ahc_post_planes(depth16, K4, depthfactor, ahc, max_point_dist, dist_threshold):
+    """The per-plane loop of Frame::ComputePlanes (src/Frame.cc:952-1011) on the oracle's AHC output `ahc`.
+    Returns list of dict(coef, accepted, voxels) per extracted plane and plane_num."""
+    d = _c(depth16, np.uint16)
+    h, w = d.shape
+    fx, fy, cx, cy = (np.float32(v) for v in K4)
+    out, fail = [], 0
+    for i, mem in enumerate(ahc["members"]):
+        j = np.asarray(mem, np.int64)
+        row, col = j // w, j % w
+        z = d[row, col].astype(np.float64) * np.float64(np.float32(depthfactor))
+        far = z > 5.0
+        x = np.where(far, 0.0, (col.astype(np.float64) - np.float64(cx)) * z / np.float64(fx))
+        y = np.where(far, 0.0, (row.astype(np.float64) - np.float64(cy)) * z / np.float64(fy))
+        z = np.where(far, 0.0, z)
+        pts = np.stack([x, y, z], 1).astype(np.float32)
+        pts = pts[~(pts[:, 2] > np.float32(max_point_dist))]
+        nrm, cen = ahc["planes"][i, 0:3], ahc["planes"][i, 3:6]
+        dd = np.float32(-(nrm[0] * cen[0] + nrm[1] * cen[1] + nrm[2] * cen[2]))
+        coef = np.array([nrm[0], nrm[1], nrm[2], dd], np.float32)
+        vox = post_voxel_grid(pts)
+        rec = dict(coef=coef, accepted=False, voxels=vox)
+        if dd > np.float32(max_point_dist) or len(vox) < 100:
+            fail += 1
+        else:
+            ok, c2 = post_refit(coef, vox, dist_threshold)
+            if ok:
+                rec["coef"], rec["accepted"] = c2, True
+        out.append(rec)
+    return out, len(ahc["members"]) - fail
+
+
+def cape_post_planes(depth_m, K4, cape, max_point_dist, dist_threshold):
+    """The per-plane loop of Frame::ComputePlanes_CAPE (src/Frame.cc:1111-1141) on the oracle's CAPE output."""
+    d = _c(depth_m, np.float32)
+    h, w = d.shape
+    fx, fy, cx, cy = (np.float64(np.float32(v)) for v in K4)
+    seg = cape["seg"]
+    out, fail = [], 0
+    jj, ii = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    z = d.astype(np.float64)
+    cloud = np.stack([(jj - cx) * z / fx, (ii - cy) * z / fy, z], -1).astype(np.float32)
+    for i in range(len(cape["planes"])):
+        pts = cloud[seg == i + 1]
+        P = cape["planes"][i]
+        coef = np.array([P[0], P[1], P[2], P[6]], np.float32)
+        vox = post_voxel_grid(pts)
+        rec = dict(coef=coef, accepted=False, voxels=vox)
+        if P[6] > np.float64(np.float32(max_point_dist)) or len(vox) < 100:
+            fail += 1
+        else:
+            ok, c2 = post_refit(coef, vox, dist_threshold)
+            if ok:
+                rec["coef"], rec["accepted"] = c2, True
+            else:
+                fail += 1
+        out.append(rec)
+    return out, len(cape["planes"]) - fail

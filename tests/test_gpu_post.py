@@ -1,0 +1,137 @@
+"""-m gpu parity tests of rows a-20 / f-2: the surface-normal pass (device) and the per-plane post-processing behind the
+C-ABI vs the CPU oracle (bit-exact: float bit patterns, NaN positions, accepted flags, voxel clouds)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _check_records(rec, cloud, nrm, O):
+    on, oc, fx, fy = O.post_surface_normal_records(cloud, nrm)
+    assert len(rec) == len(on)
+    assert np.array_equal(_bits(rec["normal"]) & 0x7FC00000 == 0x7FC00000, np.isnan(on))     # NaN in the same places
+    m = ~np.isnan(on)
+    assert np.array_equal(_bits(rec["normal"])[m], _bits(on)[m])
+    assert np.array_equal(_bits(rec["camera_position"]), _bits(oc))
+    assert np.array_equal(rec["frame_x"], fx) and np.array_equal(rec["frame_y"], fy)
+    return int(m.all(1).sum())
+
+
+@pytest.mark.parametrize("camname,kind,seed,maxd", [("TUM3", "room_boxes", 2, 9.0), ("ICL", "living_room", 3, 9.0),
+                                                    ("TUM1", "room_boxes", 10, 3.0)])
+def test_surface_normals_single_frame(oracle_mod, camname, kind, seed, maxd):
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = getattr(synth, camname)
+    g, d, _ = next(synth.sequence(seed, 1, cam=cam, kind=kind))
+    dm = O.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+    K4 = (cam.fx, cam.fy, cam.cx, cam.cy)
+    c = lib.Context()
+    try:
+        rec, cloud, nrm, dist = c.surface_normals(dm, K4, maxd, taps=True)
+        ocloud, onrm = O.post_surface_normals(dm, K4, maxd)
+        assert np.array_equal(_bits(cloud), _bits(ocloud))
+        nan = np.isnan(onrm)
+        assert np.array_equal(np.isnan(nrm), nan) and np.array_equal(_bits(nrm)[~nan], _bits(onrm)[~nan])
+        good = _check_records(rec, ocloud, onrm, O)
+        assert good > 2000                                  # a real share of the 8560 records carries a normal
+        assert dist.min() == 0 and dist.max() > 5           # discontinuities exist and so do smooth regions
+    finally:
+        c.close()
+
+
+def test_surface_normals_batch_from_device_depth(oracle_mod):
+    """Device-resident raw depth (CV_16U) of 6 frames in one call: every frame equals the single-frame oracle."""
+    import torch
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = synth.TUM3
+    frames = list(synth.sequence(2, 6, cam=cam))
+    inv = np.float32(1.0) / np.float32(cam.depth_factor)
+    K4 = (cam.fx, cam.fy, cam.cx, cam.cy)
+    depth = torch.from_numpy(np.stack([f[1] for f in frames]).view(np.int16)).cuda()
+    c = lib.Context()
+    try:
+        c.surface_normals_batch_ptr(depth.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, K4, inv, 9.0, len(frames),
+                                    torch.cuda.current_stream().cuda_stream)
+        for s, (_, d, _) in enumerate(frames):
+            ocloud, onrm = O.post_surface_normals(O.depth_to_float(d, inv), K4, 9.0)
+            assert _check_records(c.surface_normals_download(s), ocloud, onrm, O) > 2000
+    finally:
+        c.close()
+
+
+def test_surface_normals_1280x960(oracle_mod):
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = synth.REALSENSE.scaled(2.0)
+    _, d, _ = next(synth.sequence(5, 1, cam=cam, kind="corridor"))
+    dm = O.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+    K4 = (cam.fx, cam.fy, cam.cx, cam.cy)
+    c = lib.Context(max_width=1280, max_height=960)
+    try:
+        rec = c.surface_normals(dm, K4, 9.0)
+        ocloud, onrm = O.post_surface_normals(dm, K4, 9.0)
+        assert ocloud.shape[:2] == (320, 427)
+        assert _check_records(rec, ocloud, onrm, O) > 5000
+    finally:
+        c.close()
+
+
+def _same_post(g, o, n_min_accept):
+    assert len(g["post"]) == len(o[0])
+    acc = 0
+    for i, rec in enumerate(o[0]):
+        assert bool(g["post"]["accepted"][i]) == rec["accepted"], i
+        assert g["post"]["n_voxels"][i] == len(rec["voxels"])
+        assert np.array_equal(_bits(g["post"]["coef"][i]), _bits(rec["coef"])), i
+        if rec["accepted"]:
+            acc += 1
+            assert np.array_equal(_bits(g["voxels"][i]), _bits(rec["voxels"]))
+        else:
+            assert len(g["voxels"][i]) == 0
+    assert g["n_accepted"] == acc >= n_min_accept and g["plane_num"] == o[1]
+
+
+@pytest.mark.parametrize("camname,kind,seed", [("TUM3", "room_boxes", 2), ("ICL", "living_room", 3)])
+def test_ahc_planes_postprocess(oracle_mod, camname, kind, seed):
+    """Frame::ComputePlanes after runPlaneDetection: gates, voxel clouds and the refit coefficients of every AHC plane."""
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = getattr(synth, camname)
+    _, d, _ = next(synth.sequence(seed, 1, cam=cam, kind=kind))
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    c = lib.Context()
+    try:
+        ga, oa = c.planes_ahc(d, K4, inv), O.ahc_planes(d, K4, inv)
+        assert len(ga["planes"]) == len(oa["planes"]) >= 2
+        for maxd, th in ((9.0, 0.10), (9.0, 0.05), (2.0, 0.05)):
+            g = c.planes_ahc_postprocess(d, K4, inv, ga, maxd, th)
+            o = O.ahc_post_planes(d, K4, inv, oa, maxd, th)
+            _same_post(g, o, 1 if (maxd, th) == (9.0, 0.10) else 0)
+    finally:
+        c.close()
+
+
+def test_cape_planes_postprocess(oracle_mod):
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = synth.ICL
+    _, d, _ = next(synth.sequence(3, 1, cam=cam, kind="living_room"))
+    dm = O.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    c = lib.Context()
+    try:
+        gp, op = c.planes_cape(dm, K4, 20), O.cape_planes(dm, K4, 20)
+        assert len(gp["planes"]) == len(op["planes"]) >= 3
+        for maxd, th in ((9.0, 0.10), (9.0, 0.03)):
+            g = c.planes_cape_postprocess(dm, K4, gp, maxd, th)
+            o = O.cape_post_planes(dm, K4, op, maxd, th)
+            _same_post(g, o, 1 if th == 0.10 else 0)
+    finally:
+        c.close()
