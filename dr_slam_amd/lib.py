@@ -54,11 +54,7 @@ KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4
                           ("s_point_in_octave_y", "<f4"), ("e_point_in_octave_x", "<f4"), ("e_point_in_octave_y", "<f4"),
                           ("line_length", "<f4"), ("num_of_pixels", "<i4")])
 
-CAPE_PLANE_POST_DTYPE = np.dtype([("coef", "<f4", (4,)), ("accepted", "<i4"), ("n_voxels", "<i4")])      # drfe_plane_post, 24 B
-SURFACE_NORMAL_DTYPE = np.dtype([("normal", "<f4", (3,)), ("camera_position", "<f4", (3,)), ("frame_x", "<i4"),
-                                 ("frame_y", "<i4")])                                               # drfe_surface_normal, 32 B
-
-PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("mean", "<f8", (3,)), ("d", "<f8"), ("mse", "<f4"),
+CAPE_PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("mean", "<f8", (3,)), ("d", "<f8"), ("mse", "<f4"),
                              ("score", "<f4"), ("n_points", "<i4"), ("pad", "<i4")])
 
 PLANE_POST_DTYPE = np.dtype([("coef", "<f4", (4,)), ("accepted", "<i4"), ("n_voxels", "<i4")])      # drfe_plane_post, 24 B
