@@ -5,7 +5,7 @@
 #include "cape_oracle.h"
 #include "bow_oracle.h"
 #include "lsd_oracle.h"
-#include "../include/drfe_math.h"
+#include "oracle_math.h"
 
 #include <chrono>
 #include <cstring>
@@ -105,8 +105,8 @@ void orc_gaussian_blur(const uint8_t* s, int w, int h, long ss, uint8_t* d, long
 {
     gaussian_blur_7x7_s2_u8(s, w, h, (size_t)ss, d, (size_t)ds);
 }
-float orc_fast_atan2(float y, float x) { return drfe_fast_atan2(y, x); }
-void orc_sincos(float r, float* s, float* c) { drfe_sincos(r, s, c); }
+float orc_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+void orc_sincos(float r, float* s, float* c) { sincos_f(r, s, c); }
 float orc_ic_angle(void* h, const uint8_t* img, long stride, int x, int y)
 {
     return ic_angle(img + (size_t)y * stride + x, (size_t)stride, ((OrbExtractor*)h)->umax);
@@ -503,7 +503,7 @@ void orc_is_in_frustum_lines(const float* cam9, const float* Tcw, float logScale
     const LineCamera cam = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
     is_in_frustum_lines(cam, Tcw, logScale, lines, n, limit, out);
 }
-float orc_logf(float x) { return drfe_logf(x); }
+float orc_logf(float x) { return log_f(x); }
 void orc_fuse_search(void* frame, const float* Tcw, const float* invSigma2, float logScale, int nLevels,
                      const FrustumPointRec* pts, const uint8_t* descs, const uint8_t* skip, int n, float th, int32_t* bestIdx,
                      int32_t* bestDist)

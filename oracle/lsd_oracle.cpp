@@ -17,7 +17,7 @@
  */
 #include "lsd_oracle.h"
 #include "oracle.h"
-#include "../include/drfe_math.h"
+#include "oracle_math.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -186,7 +186,7 @@ struct Lsd {
                 modgrad[(size_t)y * W + x] = norm;
                 if (norm <= threshold) angles[(size_t)y * W + x] = NOTDEF;
                 else {
-                    angles[(size_t)y * W + x] = drfe_fast_atan2(float(gx), float(-gy)) * DEG_TO_RADS;
+                    angles[(size_t)y * W + x] = fast_atan2_deg(float(gx), float(-gy)) * DEG_TO_RADS;
                     if (norm > max_grad) max_grad = norm;
                 }
             }
@@ -234,10 +234,10 @@ struct Lsd {
                         /* cos(float)/sin(float) of lsd.cpp resolve to cosf/sinf, whose last bit is libm dependent:
                          * canonicalised on the shared float routine, as for the ORB steering (oracle.h, §9.4) */
                         float sn, cn;
-                        drfe_sincos(float(angle), &sn, &cn);
+                        sincos_f(float(angle), &sn, &cn);
                         sumdx += cn;
                         sumdy += sn;
-                        reg_angle = drfe_fast_atan2(sumdy, sumdx) * DEG_TO_RADS;
+                        reg_angle = fast_atan2_deg(sumdy, sumdx) * DEG_TO_RADS;
                     }
                 }
         }
@@ -253,8 +253,8 @@ struct Lsd {
             Ixy -= dx * dy * w;
         }
         const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-        double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(drfe_fast_atan2(float(lambda - Ixx), float(Ixy)))
-                                                         : double(drfe_fast_atan2(float(Ixy), float(lambda - Iyy)));
+        double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(fast_atan2_deg(float(lambda - Ixx), float(Ixy)))
+                                                         : double(fast_atan2_deg(float(Ixy), float(lambda - Iyy)));
         theta *= DEG_TO_RADS;
         if (angle_diff(theta, reg_angle) > prec) theta += M_PI;
         return theta;
@@ -652,8 +652,8 @@ LineResult extract_lines(const uint8_t* img, int w, int h, int maxLines, LsdStag
         kl.sPointInOctaveX = e[0]; kl.sPointInOctaveY = e[1]; kl.ePointInOctaveX = e[2]; kl.ePointInOctaveY = e[3];
         kl.lineLength = (float)std::sqrt(std::pow(e[0] - e[2], 2) + std::pow(e[1] - e[3], 2));
         /* LineIterator(img, Point(e0,e1), Point(e2,e3)).count, 8-connected */
-        const int x0 = drfe_round_half_even(e[0]), y0 = drfe_round_half_even(e[1]);
-        const int x1 = drfe_round_half_even(e[2]), y1 = drfe_round_half_even(e[3]);
+        const int x0 = round_he(e[0]), y0 = round_he(e[1]);
+        const int x1 = round_he(e[2]), y1 = round_he(e[3]);
         kl.numOfPixels = std::max(std::abs(x1 - x0), std::abs(y1 - y0)) + 1;
         kl.angle = (float)std::atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
         kl.class_id = ++class_counter;

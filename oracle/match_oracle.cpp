@@ -6,7 +6,7 @@
  */
 #include "oracle.h"
 #include "match_oracle.h"
-#include "../include/drfe_math.h"
+#include "oracle_math.h"
 
 #include <algorithm>
 #include <climits>
@@ -586,7 +586,7 @@ void is_in_frustum(const LineCamera& cam, float bf, const float Tcw[16], float l
         if (viewCos < viewingCosLimit) continue;
         /* MapPoint::PredictScale(dist, Frame*), src/MapPoint.cc:448-463 */
         const float ratio = p.maxDistance / dist;
-        int nScale = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        int nScale = (int)std::ceil(log_f(ratio) / logScaleFactor);
         if (nScale < 0) nScale = 0;
         else if (nScale >= nLevels) nScale = nLevels - 1;
         o.inView = 1; o.projX = u; o.projXR = u - bf * invz; o.projY = v; o.level = nScale; o.viewCos = viewCos;
@@ -629,7 +629,7 @@ void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logSc
         /* MapLine::PredictScale, src/MapLine.cpp:381-390: no clamping */
         const float ratio = l.maxDistance / dist;
         o.inView = 1; o.x1 = u1; o.y1 = v1; o.x2 = u2; o.y2 = v2; o.viewCos = viewCos;
-        o.level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        o.level = (int)std::ceil(log_f(ratio) / logScaleFactor);
     }
 }
 
@@ -678,7 +678,7 @@ void fuse_search(const Frame& KF, const float Tcw[16], const float* invLevelSigm
         if (dist3D < minDistance || dist3D > maxDistance) continue;
         if (dot3(PO, p.normal) < 0.5 * (double)dist3D) continue;
         const float ratio = p.maxDistance / dist3D;
-        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        int level = (int)std::ceil(log_f(ratio) / logScaleFactor);
         if (level < 0) level = 0;
         else if (level >= nLevels) level = nLevels - 1;
         const float radius = th * KF.scaleFactors[level];
@@ -733,7 +733,7 @@ static void sim3_direction(const Frame& dst, const float Tsw[16], const float sR
         const float dist3D = norm3(pb);
         if (dist3D < minDistance || dist3D > maxDistance) continue;
         const float ratio = p.maxDistance / dist3D;
-        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        int level = (int)std::ceil(log_f(ratio) / logScaleFactor);
         if (level < 0) level = 0;
         else if (level >= nLevels) level = nLevels - 1;
         const float radius = th * dst.scaleFactors[level];
@@ -808,7 +808,7 @@ int search_by_projection_kf(const Frame& KF, const float Scw[16], float logScale
         if (dist < minDistance || dist > maxDistance) continue;
         if (dot3(PO, p.normal) < 0.5 * (double)dist) continue;
         const float ratio = p.maxDistance / dist;
-        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);
+        int level = (int)std::ceil(log_f(ratio) / logScaleFactor);
         if (level < 0) level = 0;
         else if (level >= nLevels) level = nLevels - 1;
         const float radius = th * KF.scaleFactors[level];
@@ -864,7 +864,7 @@ void lsd_fuse_search(const LineCamera& cam, const float Tcw[16], float logScaleF
         const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
         if (dot3(OM, pn) < 0.5 * (double)dist) continue;                          /* :956 */
         const float ratio = l.maxDistance / dist;
-        const int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);      /* MapLine::PredictScale: no clamp */
+        const int level = (int)std::ceil(log_f(ratio) / logScaleFactor);      /* MapLine::PredictScale: no clamp */
         if (level < 0 || level >= nLevels) { bestIdx[i] = -2; continue; }         /* mvScaleFactors[level] is out of bounds there */
         const float radius = th * scaleFactors[level];
         get_lines_in_area(kf, nKF, u1, v1, u2, v2, radius, -1, -1, cand);         /* KeyFrame::GetLinesInArea, src/KeyFrame.cc:749 */
@@ -912,7 +912,7 @@ int search_by_projection_reloc(const Frame& Cur, const float Tcw[16], float logS
         const float maxDistance = 1.2f * p.maxDistance, minDistance = 0.8f * p.minDistance;
         if (dist3D < minDistance || dist3D > maxDistance) continue;
         const float ratio = p.maxDistance / dist3D;
-        int level = (int)std::ceil(drfe_logf(ratio) / logScaleFactor);            /* MapPoint::PredictScale(dist, Frame*) */
+        int level = (int)std::ceil(log_f(ratio) / logScaleFactor);            /* MapPoint::PredictScale(dist, Frame*) */
         if (level < 0) level = 0;
         else if (level >= nLevels) level = nLevels - 1;
         const float radius = th * Cur.scaleFactors[level];

@@ -105,7 +105,7 @@ struct FrustumPointRec { float world[3], normal[3], minDistance, maxDistance; };
 struct FrustumLineRec { double world[6], normal[3]; float minDistance, maxDistance; };
 struct FrustumOut { int32_t inView, level; float projX, projY, projXR, viewCos; };    /* mbTrackInView ... mTrackViewCos */
 struct FrustumLineOut { int32_t inView, level; float x1, y1, x2, y2, viewCos; };
-/* logScaleFactor = Frame::mfLogScaleFactor; nLevels = mnScaleLevels.  log() is the canonical drfe_logf. */
+/* logScaleFactor = Frame::mfLogScaleFactor; nLevels = mnScaleLevels.  log() is the canonical log_f. */
 void is_in_frustum(const LineCamera& cam, float bf, const float Tcw[16], float logScaleFactor, int nLevels,
                    const FrustumPointRec* pts, int n, float viewingCosLimit, FrustumOut* out);
 void is_in_frustum_lines(const LineCamera& cam, const float Tcw[16], float logScaleFactor, const FrustumLineRec* lines,

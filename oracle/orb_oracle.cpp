@@ -4,7 +4,7 @@
  * makes.  Each function cites the reference lines it follows.
  */
 #include "oracle.h"
-#include "../include/drfe_math.h"
+#include "oracle_math.h"
 
 #include <algorithm>
 #include <cassert>
@@ -38,7 +38,7 @@ namespace {
 struct LinCoef { int s; short w0, w1; bool edge; };
 static short sat_short_round(float v)
 {
-    int r = drfe_round_half_even(v);
+    int r = round_he(v);
     return (short)std::min(32767, std::max(-32768, r));
 }
 static void build_axis_x(int src, int dst, std::vector<LinCoef>& t)
@@ -251,7 +251,7 @@ float ic_angle(const uint8_t* center, size_t stride, const std::vector<int>& uma
         }
         m_01 += v * v_sum;
     }
-    return drfe_fast_atan2((float)m_01, (float)m_10);
+    return fast_atan2_deg((float)m_01, (float)m_10);
 }
 
 /* computeOrbDescriptor, src/ORBextractor.cc:108-147 (cos/sin canonicalised) */
@@ -260,7 +260,7 @@ void orb_descriptor(const uint8_t* center, size_t stride, float angle_deg, uint8
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float angle = angle_deg * factorPI;
     float a, b;
-    drfe_sincos(angle, &b, &a);
+    sincos_f(angle, &b, &a);
     const ptrdiff_t step = (ptrdiff_t)stride;
     const int8_t* pat = kPattern;
     /* flat table: point j of byte i at pat[(16*i + j)*2 ..]; bit k compares points 2k and 2k+1 */
@@ -268,10 +268,10 @@ void orb_descriptor(const uint8_t* center, size_t stride, float angle_deg, uint8
         int val = 0;
         for (int k = 0; k < 8; k++) {
             const int8_t* q = pat + k * 4;
-            const int t0 = center[drfe_round_half_even(q[0] * b + q[1] * a) * step +
-                                  drfe_round_half_even(q[0] * a - q[1] * b)];
-            const int t1 = center[drfe_round_half_even(q[2] * b + q[3] * a) * step +
-                                  drfe_round_half_even(q[2] * a - q[3] * b)];
+            const int t0 = center[round_he(q[0] * b + q[1] * a) * step +
+                                  round_he(q[0] * a - q[1] * b)];
+            const int t1 = center[round_he(q[2] * b + q[3] * a) * step +
+                                  round_he(q[2] * a - q[3] * b)];
             val |= (t0 < t1) << k;
         }
         desc[i] = (uint8_t)val;
@@ -313,7 +313,7 @@ OrbExtractor::OrbExtractor(int nf, float sf, int nl, int ini, int mn)
     float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
     int sum = 0;
     for (int l = 0; l < nl - 1; l++) {
-        quota[l] = drfe_round_half_even(nDesired);
+        quota[l] = round_he(nDesired);
         sum += quota[l];
         nDesired *= factor;
     }
@@ -323,7 +323,7 @@ OrbExtractor::OrbExtractor(int nf, float sf, int nl, int ini, int mn)
     const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
     const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
     const double hp2 = kHalfPatch * kHalfPatch;
-    for (int v = 0; v <= vmax; ++v) umax[v] = drfe_round_half_even_d(std::sqrt(hp2 - v * v));
+    for (int v = 0; v <= vmax; ++v) umax[v] = round_he_d(std::sqrt(hp2 - v * v));
     for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
         while (umax[v0] == umax[v0 + 1]) ++v0;
         umax[v] = v0;
@@ -337,8 +337,8 @@ void OrbExtractor::computeGeometry(int w, int h)
     geom.resize(nlevels);
     for (int l = 0; l < nlevels; l++) {
         LevelGeom& g = geom[l];
-        g.w = drfe_round_half_even((float)w * invScale[l]);
-        g.h = drfe_round_half_even((float)h * invScale[l]);
+        g.w = round_he((float)w * invScale[l]);
+        g.h = round_he((float)h * invScale[l]);
         g.quota = quota[l];
         g.minBX = kEdge - 3; g.minBY = kEdge - 3;
         g.maxBX = g.w - kEdge + 3; g.maxBY = g.h - kEdge + 3;
@@ -585,7 +585,7 @@ int OrbExtractor::extract(const uint8_t* gray, int w, int h, size_t stride)
         const Image& im = pyramid[l];
         const uint8_t* roi = im.px.data() + (size_t)kEdge * im.w + kEdge;
         for (KeyPoint& kp : all[l]) {
-            const uint8_t* c = roi + (ptrdiff_t)drfe_round_half_even(kp.y) * im.w + drfe_round_half_even(kp.x);
+            const uint8_t* c = roi + (ptrdiff_t)round_he(kp.y) * im.w + round_he(kp.x);
             kp.angle = ic_angle(c, im.w, umax);
         }
     }
@@ -598,7 +598,7 @@ int OrbExtractor::extract(const uint8_t* gray, int w, int h, size_t stride)
         blurLevel(l);
         const Image& b = blurred[l];
         for (KeyPoint& kp : all[l]) {
-            const uint8_t* c = b.px.data() + (ptrdiff_t)drfe_round_half_even(kp.y) * b.w + drfe_round_half_even(kp.x);
+            const uint8_t* c = b.px.data() + (ptrdiff_t)round_he(kp.y) * b.w + round_he(kp.x);
             orb_descriptor(c, b.w, kp.angle, &descriptors[off * 32]);
             off++;
         }
