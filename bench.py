@@ -56,36 +56,220 @@ def make_batch(base, batch: int):
     return gray, depth, Tcw.astype(np.float32), Twc.astype(np.float32)
 
 
-def cpu_baseline(base, cam, budget_s: float = 12.0):
-    """Oracle (kind 'port', 1 thread): extract + SearchByProjection against the previous frame."""
+def _native_oracle():
+    """BASELINE.md section 2 asks for -O3 -march=native -ffp-contract=off: the checked-in oracle build is x86-64-v3 (it has to
+    run in the build container too), so the timing leg compiles its own copy for THIS host into a scratch directory and
+    points oracle.py at it (never into the tree).  Falls back to the shipped build if the compiler is missing."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle")
+    out = os.path.join(tempfile.gettempdir(), "drfe_oracle_native_%d" % os.getuid())
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libdrfe_oracle_native.so")
+    files = sorted(f for f in os.listdir(src) if f.endswith(".cpp"))
+    try:
+        objs = []
+        procs = []
+        for f in files:
+            o = os.path.join(out, f[:-4] + ".o")
+            objs.append(o)
+            procs.append(subprocess.Popen(["g++", "-std=c++17", "-O3", "-march=native", "-ffp-contract=off", "-fPIC", "-c",
+                                           os.path.join(src, f), "-o", o], stderr=subprocess.DEVNULL))
+        if any(p.wait() != 0 for p in procs):
+            return None, "-O3 -march=x86-64-v3 (native rebuild failed)"
+        subprocess.check_call(["g++", "-shared", "-o", so] + objs)
+        return so, "-O3 -march=native"
+    except Exception:
+        return None, "-O3 -march=x86-64-v3 (no compiler on this host)"
+
+
+def _host_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(base, cam, frames: int = 220, discard: int = 20):
+    """The CPU oracle (kind 'port': the reference cannot be built) timed on this host in the three threading shapes of
+    BASELINE.md section 2; steady_clock per frame, first `discard` frames dropped, median and p95:
+      (i)   1 thread: ORB extract + SearchByProjection against the previous frame  (= the metric's path; `value`)
+      (ii)  the reference's own shape: ORB || LSD+LBD || AHC planes on 3 threads per frame (src/Frame.cc:124-134), then
+            the matcher
+      (iii) as many independent sequences x 3 threads as the host has cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dr_slam_amd import sharding
+    so, flags = _native_oracle()
+    if so:
+        os.environ["DRFE_ORACLE_LIB"] = so
     from oracle import oracle as orc
-    o = orc.OrbOracle()
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     inv = np.float32(1.0) / np.float32(cam.depth_factor)
-    prev = None
-    n, t0 = 0, time.perf_counter()
-    i = 0
-    while True:
-        g, d, Twc = base[i % len(base)]
-        kps, desc = o(g)
-        fo = orc.FrameOracle(kps, desc, orc.depth_to_float(d, inv), K4, cam.bf, cam.w, cam.h, o.scale,
-                             dist=cam.dist)
-        Tcw = np.linalg.inv(Twc).astype(np.float32)
-        if prev is not None:
-            pf, pTwc, pTcw = prev
-            world, valid = pf.unproject(pTwc.astype(np.float32))
-            mp = np.zeros(pf.N, orc.MAPPOINT_DTYPE)
-            mp["valid"], mp["obsPositive"], mp["world"], mp["desc"] = valid, 1, world, pf.desc
-            orc.search_by_projection_last(fo, pf, Tcw, pTcw, mp, 15.0, False, True)
-        prev = (fo, Twc, Tcw)
-        n += 1
-        i += 1
-        el = time.perf_counter() - t0
-        if el > budget_s and n >= 8:
-            break
-    return {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames 640x480 (extract + SearchByProjection vs previous frame), CPU oracle "
-                      f"-O3 -march=x86-64-v3 -ffp-contract=off, 1 thread, {el:.1f} s"}
+    ncpu = sharding.host_cpus()
+
+    def run_sequence(n, full, pool):
+        o = orc.OrbOracle()
+        prev, ms = None, []
+        for i in range(n):
+            g, d, Twc = base[i % len(base)]
+            t0 = time.perf_counter()
+            if full:
+                fl = pool.submit(orc.extract_lines, g)
+                fp = pool.submit(orc.ahc_planes, d, K4, float(inv))
+            kps, desc = o(g)
+            fo = orc.FrameOracle(kps, desc, orc.depth_to_float(d, inv), K4, cam.bf, cam.w, cam.h, o.scale, dist=cam.dist)
+            if full:
+                fl.result(); fp.result()
+            Tcw = np.linalg.inv(Twc).astype(np.float32)
+            if prev is not None:
+                pf, pTwc, pTcw = prev
+                world, valid = pf.unproject(pTwc.astype(np.float32))
+                mp = np.zeros(pf.N, orc.MAPPOINT_DTYPE)
+                mp["valid"], mp["obsPositive"], mp["world"], mp["desc"] = valid, 1, world, pf.desc
+                orc.search_by_projection_last(fo, pf, Tcw, pTcw, mp, 15.0, False, True)
+            prev = (fo, Twc, Tcw)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        return np.array(ms[discard:])
+
+    def stats(ms, nseq=1):
+        med = float(np.median(ms))
+        return {"frames_per_s": nseq * 1e3 / med, "median_ms": med, "p95_ms": float(np.percentile(ms, 95)), "frames": int(len(ms))}
+
+    shapes = {}
+    shapes["i_orb_match_1thread"] = dict(stats(run_sequence(frames, False, None)), threads=1)
+    n2 = max(discard + 40, frames // 2)                 # the full front-end costs ~3x per frame: bounded sample
+    with ThreadPoolExecutor(2) as pool:
+        shapes["ii_orb_lsd_ahc_3threads"] = dict(stats(run_sequence(n2, True, pool)), threads=3)
+    nseq = max(1, ncpu // 3)
+    if nseq > 1:
+        pools = [ThreadPoolExecutor(2) for _ in range(nseq)]
+        with ThreadPoolExecutor(nseq) as outer:
+            res = list(outer.map(lambda p: run_sequence(n2, True, p), pools))
+        for p in pools:
+            p.shutdown()
+        shapes["iii_all_cores"] = dict(stats(np.concatenate(res), nseq), threads=3 * nseq, sequences=nseq)
+    one = shapes["i_orb_match_1thread"]
+    return {"value": one["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{one['frames']} frames 640x480 after {discard} discarded (ORB extract + SearchByProjection vs the previous "
+                      f"frame), CPU oracle {flags} -ffp-contract=off, 1 thread; 1 / median frame time",
+            "host": {"model": _host_model(), "cpus_available": ncpu}, "shapes": shapes}
+
+
+def host_fed_rate(fe, gray, depth, Tcw, Twc, B, steps, dev):
+    """The same step fed from HOST memory: pinned gray + depth copied H2D on a copy stream while the previous batch
+    computes (double-buffered inputs), keypoints / descriptors / matches of every batch copied back D2H.  The link, not the
+    kernels, bounds this number (472 MB in + 34 MB out per 512 frames)."""
+    import torch
+    K = fe.ctx.max_kp
+    gh, dh = torch.from_numpy(gray).pin_memory(), torch.from_numpy(depth.view(np.int16)).pin_memory()
+    gd = [torch.empty_like(gh, device=dev) for _ in range(2)]
+    dd = [torch.empty_like(dh, device=dev) for _ in range(2)]
+    res = dict(kps=torch.empty((B, K, 28), dtype=torch.uint8).pin_memory(), desc=torch.empty((B, K, 32), dtype=torch.uint8).pin_memory(),
+               kc=torch.empty(B, dtype=torch.int32).pin_memory(), m=torch.empty((B, K), dtype=torch.int32).pin_memory(),
+               mc=torch.empty(B, dtype=torch.int32).pin_memory())
+    s_copy, s_comp = torch.cuda.Stream(), torch.cuda.Stream()
+    ev_in = [torch.cuda.Event() for _ in range(2)]        # inputs of buffer k are on the device
+    ev_done = [torch.cuda.Event() for _ in range(2)]      # the batch computed from buffer k has been downloaded
+
+    def h2d(k):
+        with torch.cuda.stream(s_copy):
+            s_copy.wait_event(ev_done[k])
+            gd[k].copy_(gh, non_blocking=True)
+            dd[k].copy_(dh, non_blocking=True)
+            ev_in[k].record(s_copy)
+
+    def run(n):
+        for k in range(2):
+            ev_done[k].record(s_comp)
+        h2d(0)
+        for i in range(n):
+            k = i & 1
+            if i + 1 < n:
+                h2d(k ^ 1)
+            s_comp.wait_event(ev_in[k])
+            fe.process(gd[k], dd[k], Tcw, Twc, th=15.0, check_ori=True, stream=s_comp.cuda_stream)
+            fe.ctx.batch_download_async_ptr(B, res["kps"].data_ptr(), res["desc"].data_ptr(), res["kc"].data_ptr(),
+                                            res["m"].data_ptr(), res["mc"].data_ptr(), s_comp.cuda_stream)
+            ev_done[k].record(s_comp)
+        torch.cuda.synchronize()
+
+    run(2)
+    t0 = time.perf_counter()
+    run(steps)
+    el = time.perf_counter() - t0
+    assert int(res["kc"].min()) > 500 and int(res["mc"][1:].min()) > 50
+    return B * steps / el, el / steps * 1e3
+
+
+def full_frontend(cam_name, n_frames: int = 48, reps: int = 2):
+    """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
+    SearchByProjection and the surface normals batched on the device; LSD + LBD lines, AHC planes with their PCL-style
+    post-processing and CAPE planes per frame (device passes + the sequential host stages on a pool of host threads)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from dr_slam_amd import lib, sharding, synth
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = getattr(synth, cam_name)
+    ncpu = sharding.host_cpus()
+    base = sharding.render_sequence(3, 8, cam, "living_room", workers=1)
+    order = sharding.pingpong_order(n_frames, len(base))
+    gray = np.stack([base[i][0] for i in order])
+    depth = np.stack([base[i][1] for i in order])
+    Twc = np.stack([base[i][2] for i in order]).astype(np.float64)
+    Tcw = np.linalg.inv(Twc).astype(np.float32)
+    Twc = Twc.astype(np.float32)
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    depth_m = depth.astype(np.float32) * np.float32(inv)
+    fe = FrontEnd(cam, max_batch=n_frames)
+    gray_t = torch.from_numpy(gray).cuda()
+    depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    line_threads = max(1, (ncpu * 3) // 4 - 1)
+    plane_threads = max(1, ncpu - line_threads - 1)
+    ctx_planes = lib.Context(max_batch=1)
+    ctx_cape = lib.Context(max_batch=1)
+
+    def planes():
+        out = ctx_planes.planes_ahc_batch(depth, K4, inv, n_threads=plane_threads, members=True)
+        acc = 0
+        for f, r in enumerate(out):            # Frame::ComputePlanes after the extractor (host: voxel grid + refit)
+            acc += ctx_planes.planes_ahc_postprocess(depth[f], K4, inv, r, 9.0, 0.10)["n_accepted"]
+        return len(out), acc
+
+    def cape():
+        return sum(len(ctx_cape.planes_cape(depth_m[f], K4, 20)["planes"]) for f in range(n_frames))
+
+    def step(pool):
+        fl = pool.submit(lambda: fe.ctx.lsd_extract_batch(gray, n_threads=line_threads))
+        fp = pool.submit(planes)
+        fc = pool.submit(cape)
+        fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
+        fe.ctx.surface_normals_batch_ptr(depth_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, K4, inv, 9.0, n_frames, stream)
+        torch.cuda.synchronize()
+        nl, (npl, nacc), ncp = len(fl.result()), fp.result(), fc.result()
+        assert nl == n_frames and npl == n_frames and ncp > 0
+        return nacc
+
+    with ThreadPoolExecutor(3) as pool:
+        step(pool)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            nacc = step(pool)
+        el = (time.perf_counter() - t0) / reps
+    for c in (ctx_planes, ctx_cape):
+        c.close()
+    fe.ctx.close()
+    return {"workload": "BASELINE config 3: living_room scene, ICL intrinsics, 640x480: ORB + glue + SearchByProjection + surface "
+                        "normals batched on the device; LSD+LBD lines, AHC planes + post-processing, CAPE planes for every frame",
+            "value": n_frames / el, "unit": "frames/s", "frames_per_step": n_frames, "ms_per_step": el * 1e3,
+            "host_threads": {"lines": line_threads, "ahc_planes": plane_threads, "cape": 1}, "host_cpus_available": ncpu,
+            "planes_accepted_per_step": int(nacc),
+            "note": "bound by the sequential host stages of LSD (pixel ordering + region growing) and AHC (clustering): "
+                    "scales with host threads, not with the GPU"}
 
 
 def launch(args) -> int:
@@ -142,6 +326,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=0,
                     help="frames rendered per rank (0 = the config's sequence length: 64 / 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-fed rate and the config-3 full front-end block")
     ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
     args = ap.parse_args()
 
@@ -246,23 +431,32 @@ def main():
                 acc[k] = acc.get(k, 0.0) + v
         fe.ctx.profile_enable(False)
         stage_ms = {k: v / reps for k, v in acc.items()}
-        cand = {k: stage_ms[k] for k in ALGO_BYTES}
+        # FAST runs as two launches (k_fast_cells_cols<8> over the cells of <= 8 rows per lane, <12> over the rest): each has its
+        # own event pair and its share of the FAST read (every pixel of the detection region belongs to exactly one cell)
+        cells, px = fe.ctx.fast_partition(cam.w, cam.h)
+        algo_bytes = dict(ALGO_BYTES)
+        tot = float(px.sum())
+        algo_bytes["fast"] = ALGO_BYTES["fast"] * float(px[0]) / tot
+        algo_bytes["fast_b"] = ALGO_BYTES["fast"] * float(px[1]) / tot
+        cand = {k: stage_ms[k] for k in algo_bytes if stage_ms.get(k, 0.0) > 0}
         dom = max(stage_ms, key=lambda k: stage_ms[k])
-        roof_stage = dom if dom in ALGO_BYTES else max(cand, key=lambda k: cand[k])
-        algo = ALGO_BYTES[roof_stage] * B
+        roof_stage = dom if dom in cand else max(cand, key=lambda k: cand[k])
+        algo = algo_bytes[roof_stage] * B
         achieved = algo / (stage_ms[roof_stage] * 1e-3) / 1e9
-        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # separate runs; cannot be collected from inside this process). Only valid for the same batch size.
-        traffic, traffic_src = None, None
-        kname = {"pyramid": "k_pyr_resize", "fast": "k_fast_cells", "blur": "k_blur", "desc": "k_orient_desc",
+        # HBM traffic and VALU utilisation of that kernel from the committed PMC passes (rocprofv3 --pmc, separate runs;
+        # cannot be collected from inside this process). Only valid for the same batch size.
+        traffic, traffic_src, valu = None, None, None
+        kname = {"pyramid": "k_pyr_resize_lds", "fast": "k_fast_cells_cols<8>" if cells[1] else "k_fast_cells",
+                 "fast_b": "k_fast_cells_cols<12>", "blur": "k_blur", "desc": "k_orient_desc",
                  "match": "k_window_candidates"}[roof_stage]
         try:
-            pmc_name = "r01_pmc_traffic_b%d.json" % B
+            pmc_name = "r02_pmc_traffic_b%d.json" % B
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
                 k = pmc["kernels"][kname]
                 traffic = float(k["HBM_BYTES_per_launch"])
                 traffic_src = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 half-count correction, calibrated, see its _about)" % pmc_name
+                valu = k.get("valu_issue_utilisation")
         except Exception:
             pass
         fps = total_frames / el
@@ -275,14 +469,29 @@ def main():
                        "frames_per_step": world * B, "sequence_frames_per_rank": len(base),
                        "sharding": "one sequence per GPU, no data-path collective"},
             "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": kname, "kernel_stage": roof_stage, "dominant_stage": dom,
+            "roofline": {"bound": "hbm", "limited_by": "valu issue (byte-wise image work: %s of the kernel's cycles issue VALU "
+                                                       "instructions; see profiles/)" % ("%.0f %%" % (100 * valu) if valu else "most"),
+                         "kernel": kname, "kernel_stage": roof_stage, "dominant_stage": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": stage_ms[roof_stage],
                          "algorithmic_bytes_per_launch": algo},
         }
+        out["parity"] = "bit-exact vs the in-repo CPU oracle; the oracle restates OpenCV 3.4 / Eigen 3.3.7 / PCL 1.9 and is UNPINNED " \
+                        "against the real libraries (none can be built here)"
+        if world == 1 and not args.no_extras:
+            fps_hf, ms_hf = host_fed_rate(fe, gray, depth, Tcw, Twc, B, max(4, min(args.steps, 10)), dev)
+            out["value_host_fed"] = fps_hf
+            out["host_fed"] = {"ms_per_step": ms_hf, "h2d_bytes_per_step": int(gray.nbytes + depth.nbytes),
+                               "d2h_bytes_per_step": int(B * fe.ctx.max_kp * (28 + 32 + 4) + 8 * B),
+                               "note": "pinned gray + depth H2D on a copy stream overlapped with the previous batch, keypoints / "
+                                       "descriptors / matches D2H; link-bound"}
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported by the N=1 run only
             out["cpu_baseline"] = cpu_baseline(base, cam)
+        if world == 1 and not args.no_extras:
+            fe.ctx.close()
+            del gray_t, depth_t
+            out["full_frontend"] = full_frontend("ICL")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

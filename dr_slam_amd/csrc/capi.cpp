@@ -312,6 +312,43 @@ int drfe_orb_download(drfe_ctx* c, int slot, drfe_keypoint* kps, uint8_t* desc, 
     return DRFE_OK;
 }
 
+int drfe_orb_fast_partition(drfe_ctx* c, int w, int h, int32_t* ncells, int64_t* pixels)
+{
+    if (!c || !ncells || !pixels) return DRFE_ERR_INVALID;
+    DevGeom g;
+    std::memset(&g, 0, sizeof(g));
+    std::vector<FastCell> cells;
+    const int rc = drfe_build_geometry(c, w, h, &g, &cells, nullptr, nullptr);
+    if (rc != DRFE_OK) return rc;
+    ncells[0] = ncells[1] = 0;
+    pixels[0] = pixels[1] = 0;
+    const bool cols = g.fastCols && !c->fastGeneric;
+    for (size_t i = 0; i < cells.size(); i++) {
+        const int k = (cols && (int)i >= g.fastColsSmall) ? 1 : 0;
+        ncells[k]++;
+        pixels[k] += (int64_t)(cells[i].ww - 6) * (cells[i].wh - 6);
+    }
+    return DRFE_OK;
+}
+
+int drfe_batch_download_async(drfe_ctx* c, int nframes, drfe_keypoint* kps, uint8_t* desc, int32_t* kp_counts, int32_t* matches,
+                              int32_t* match_counts, void* stream)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    if (nframes < 1 || nframes > c->lastBatch || !kps || !desc || !kp_counts) {
+        c->err = "drfe_batch_download_async: invalid argument";
+        return nframes > c->lastBatch ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t F = (size_t)nframes, K = (size_t)c->maxKp;
+    HIPCHK(c, hipMemcpyAsync(kps, c->d_kps, F * K * sizeof(drfe_keypoint), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(desc, c->d_desc, F * K * 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(kp_counts, c->d_kpCount, F * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (matches) HIPCHK(c, hipMemcpyAsync(matches, c->d_match, F * K * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (match_counts) HIPCHK(c, hipMemcpyAsync(match_counts, c->d_matchCount, F * sizeof(int), hipMemcpyDeviceToHost, s));
+    return DRFE_OK;
+}
+
 int drfe_orb_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stride, drfe_keypoint* kps, uint8_t* desc,
                      int cap, int* n_out)
 {

@@ -33,6 +33,10 @@ void drfe_match_buffers_free(drfe_ctx* c)
                     m->d_hist, m->d_initObs, m->d_bfIdx, m->d_bfDist, m->d_bfQ, m->d_bfT};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) {
+        if (m->h_stage[k]) (void)hipHostFree(m->h_stage[k]);
+        if (m->stageEv[k]) (void)hipEventDestroy(m->stageEv[k]);
+    }
     delete m;
     c->mb = nullptr;
 }
@@ -263,7 +267,22 @@ int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc
     if (!m) return DRFE_ERR_HIP;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int np = nframes - 1;
-    std::vector<MatchPair> pairs(np);
+    /* pairs + poses staged in pinned memory the context owns: the call returns without waiting for the stream */
+    const size_t pairBytes = sizeof(MatchPair) * (size_t)c->cfg.max_batch, poseBytes = sizeof(float) * 16 * (size_t)c->cfg.max_batch;
+    if (!m->h_stage[0]) {
+        m->stageBytes = pairBytes + poseBytes;
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(c, hipHostMalloc(&m->h_stage[k], m->stageBytes, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&m->stageEv[k], hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(m->stageEv[k], s));
+        }
+    }
+    const int slotK = m->stageNext;
+    m->stageNext ^= 1;
+    HIPCHK(c, hipEventSynchronize(m->stageEv[slotK]));          /* the copies of two calls ago have left this buffer */
+    MatchPair* pairs = static_cast<MatchPair*>(m->h_stage[slotK]);
+    float* poses = reinterpret_cast<float*>(static_cast<uint8_t*>(m->h_stage[slotK]) + pairBytes);
+    std::memcpy(poses, Twc, sizeof(float) * 16 * (size_t)nframes);
     const float mb = cam->bf / cam->fx;
     for (int p = 0; p < np; p++) {
         MatchPair& P = pairs[p];
@@ -273,10 +292,9 @@ int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc
         std::memcpy(P.Tcw, Tcw + (size_t)(p + 1) * 16, sizeof(float) * 16);
         motion_flags(Tcw + (size_t)(p + 1) * 16, Tcw + (size_t)p * 16, mb, mono, &P.forward, &P.backward);
     }
-    /* the launch stream must not overtake these host staging copies */
-    HIPCHK(c, hipMemcpyAsync(m->d_pairs, pairs.data(), sizeof(MatchPair) * np, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->d_poses, Twc, sizeof(float) * 16 * nframes, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpyAsync(m->d_pairs, pairs, sizeof(MatchPair) * np, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 16 * nframes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(m->stageEv[slotK], s));
     if (c->profile) { (void)hipEventRecord(c->ev[DRFE_STAGE_MATCH][0], s); c->evUsed[DRFE_STAGE_MATCH] = true; }
     HIPCHK(c, hipMemsetAsync(c->d_match, 0xFF, sizeof(int) * (size_t)nframes * c->maxKp, s));
     HIPCHK(c, hipMemsetAsync(c->d_matchCount, 0, sizeof(int) * nframes, s));

@@ -113,6 +113,84 @@ __global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src,
     gy[(size_t)y * w + x] = (int16_t)((g + 2 * hh + i) - (a + 2 * b + c));
 }
 
+/* The pixel loop of cv::LineSegmentDetectorImpl::rect_nfa (OpenCV 3.4 imgproc/src/lsd.cpp) for one rectangle per wavefront.
+ * The corner bookkeeping and the scan-line walk are order-defined double arithmetic (lx += step per row) and run
+ * wave-uniformly; the pixels of a row are spread over the lanes (coalesced reads of the angle row), the two counters meet
+ * in a wave reduction.  Only integers leave the kernel: the NFA itself (lgamma, log, exp of the counts) stays with the
+ * caller's libm so that the host decides with exactly the values the CPU path would compute. */
+__global__ __launch_bounds__(64) void k_rect_counts(const RectCand* __restrict__ cands, int n, const double* __restrict__ ang, int W,
+                                                    int H, int2* __restrict__ out)
+{
+    const int id = blockIdx.x, lane = threadIdx.x;
+    if (id >= n) return;
+    const RectCand rc = cands[id];
+    const double kNotDef = -1024.0, kTwoPi = 2.0 * 3.14159265358979323846, kThreeHalfPi = 3.0 * 3.14159265358979323846 / 2.0;
+    const double hw = rc.width / 2.0, dyhw = rc.dy * hw, dxhw = rc.dx * hw;
+    /* integer-valued corners kept as doubles (cv::Point2d built from ints) */
+    double cx[4] = {(double)(int)(rc.x1 - dyhw), (double)(int)(rc.x2 - dyhw), (double)(int)(rc.x2 + dyhw), (double)(int)(rc.x1 + dyhw)};
+    double cy[4] = {(double)(int)(rc.y1 + dxhw), (double)(int)(rc.y2 + dxhw), (double)(int)(rc.y2 - dxhw), (double)(int)(rc.y1 - dxhw)};
+    /* ascending (x, y): five compare-exchanges */
+#define CSWAP(a, b)                                                                     \
+    if (cx[a] > cx[b] || (cx[a] == cx[b] && cy[a] > cy[b])) {                           \
+        const double tx = cx[a], ty = cy[a]; cx[a] = cx[b]; cy[a] = cy[b]; cx[b] = tx; cy[b] = ty; \
+    }
+    CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+    int lo = 0, hi = 0;
+    for (int i = 1; i < 4; i++) { if (cy[lo] > cy[i]) lo = i; if (cy[hi] < cy[i]) hi = i; }
+    bool taken[4] = {false, false, false, false};
+    taken[lo] = true;
+    int left = -1, right = -1, tail = -1;
+    for (int i = 0; i < 4; i++) if (!taken[i] && (left < 0 || cx[left] > cx[i])) left = i;
+    taken[left] = true;
+    for (int i = 0; i < 4; i++) if (!taken[i] && (right < 0 || cx[right] < cx[i])) right = i;
+    taken[right] = true;
+    for (int i = 0; i < 4; i++) if (!taken[i] && (tail < 0 || cx[tail] > cx[i])) tail = i;
+    const double loX = cx[lo], loY = cy[lo], hiY = cy[hi], leftX = cx[left], leftY = cy[left], rightX = cx[right], rightY = cy[right],
+                 tailX = cx[tail], tailY = cy[tail];
+    /* edge steps dx/dy; the second-step guards compare y against tail.x as rect_nfa does, a step that would divide by zero
+     * counts as 0 */
+    const double fl = (loY != leftY) ? (loX - leftX) / (loY - leftY) : 0;
+    double sl = (leftY != tailX) ? (leftX - tailX) / (leftY - tailY) : 0;
+    const double fr = (loY != rightY) ? (loX - rightX) / (loY - rightY) : 0;
+    double sr = (rightY != tailX) ? (rightX - tailX) / (rightY - tailY) : 0;
+    if (!isfinite(sl)) sl = 0;
+    if (!isfinite(sr)) sr = 0;
+    double lstep = fl, rstep = fr, lx = loX, rx = loX;
+    int total = 0, alg = 0;
+    for (int y = (int)loY; y <= (int)hiY; ++y) {
+        if (y < 0 || y >= H) continue;
+        const int xs = (int)lx, xe = (int)rx;
+        const double* row = ang + (size_t)y * W;
+        for (int x = xs + lane; x <= xe; x += 64) {
+            if (x < 0 || x >= W) continue;
+            ++total;
+            const double a = row[x];
+            if (a != kNotDef) {
+                double d = rc.theta - a;
+                if (d < 0) d = -d;
+                if (d > kThreeHalfPi) { d -= kTwoPi; if (d < 0) d = -d; }
+                if (d <= rc.prec) ++alg;
+            }
+        }
+        if ((double)y >= leftY) lstep = sl;
+        if ((double)y >= rightY) rstep = sr;
+        lx += lstep;
+        rx += rstep;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { total += __shfl_xor(total, o); alg += __shfl_xor(alg, o); }
+    if (lane == 0) out[id] = make_int2(total, alg);
+}
+
+hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double* d_angles, int W, int H, int2* d_counts,
+                                   hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rect_counts, dim3(n), dim3(64), 0, s, d_cands, n, d_angles, W, H, d_counts);
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,
                                     LinesScratch* sc, double threshold, hipStream_t s)
 {

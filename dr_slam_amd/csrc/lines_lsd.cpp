@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <functional>
+#include <mutex>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -60,12 +62,18 @@ public:
         logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     }
 
-    void run(std::vector<float>& lines)
+    /* counts(cands, out): (pixels, aligned pixels) of every rectangle - the device kernel k_rect_counts */
+    typedef std::function<bool(const std::vector<RectCand>&, std::vector<int2>&)> CountFn;
+
+    bool run(std::vector<float>& lines, const CountFn& counts)
     {
         const double angTh = 22.5, scale = 0.8, densityTh = 0.7, logEps = 0;
         const double prec = M_PI * angTh / 180, p = angTh / 180;
         const size_t minReg = size_t(-logNT_ / std::log10(p));
         std::vector<RPt> reg;
+        /* rect_improve only READS the angle field and decides whether the segment is kept: it is taken out of the seed loop
+         * (whose `used` bookkeeping is the sequential part) and evaluated for all rectangles of the frame at once */
+        std::vector<RectD> pending;
         for (const OPt& s : order_) {
             if (used_[(size_t)s.y * W_ + s.x] || ang_[(size_t)s.y * W_ + s.x] == kNotDef) continue;
             double regAngle;
@@ -83,17 +91,23 @@ public:
             const auto t1 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             toRect(reg, regAngle, prec, p, rec);
             const bool okr = refine(reg, regAngle, prec, p, rec, densityTh);
-            const auto t2 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            if (timed_) { tRefine_ += std::chrono::duration<double, std::milli>(t2 - t1).count(); nRect_++; }
+            if (timed_) { tRefine_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(); nRect_++; }
             if (!okr) continue;
-            const double logNfa = improve(rec);
-            if (timed_) tImprove_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
-            if (logNfa <= logEps) continue;
+            pending.push_back(rec);
+        }
+        const auto t2 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        std::vector<double> logNfa;
+        if (!improveAll(pending, logNfa, counts)) return false;
+        if (timed_) tImprove_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+        for (size_t i = 0; i < pending.size(); i++) {
+            if (logNfa[i] <= logEps) continue;
+            RectD rec = pending[i];
             rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
             rec.x1 /= scale; rec.y1 /= scale; rec.x2 /= scale; rec.y2 /= scale;
             lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1));
             lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
         }
+        return true;
     }
 
     double tGrow_ = 0, tRefine_ = 0, tImprove_ = 0; long nGrow_ = 0, nRect_ = 0; bool timed_ = false;
@@ -234,6 +248,19 @@ private:
         for (int n = 0; n < 7; ++n) { a -= std::log(x + double(n)); b += q[n] * std::pow(x, double(n)); }
         return a + std::log(b);
     }
+    /* logGamma at the integer arguments nfa() asks for, from a table filled once by logGamma itself (identical values; the
+     * seven log + seven pow per call were most of the NFA stage's host time) */
+    static double logGammaInt(int x)
+    {
+        static const int kTable = 1 << 16;
+        static std::vector<double> table;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            table.resize(kTable);
+            for (int i = 0; i < kTable; i++) table[i] = logGamma(double(i));
+        });
+        return (x >= 0 && x < kTable) ? table[x] : logGamma(double(x));
+    }
     static bool nearlyEqual(double a, double b)
     {
         if (a == b) return true;
@@ -247,7 +274,7 @@ private:
         if (n == 0 || k == 0) return -logNT_;
         if (n == k) return -logNT_ - double(n) * std::log10(p);
         const double pTerm = p / (1 - p);
-        const double log1 = logGamma(double(n) + 1) - logGamma(double(k) + 1) - logGamma(double(n - k) + 1) +
+        const double log1 = logGammaInt(n + 1) - logGammaInt(k + 1) - logGammaInt(n - k + 1) +
                             double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
         double term = std::exp(log1);
         if (nearlyEqual(term, 0)) return (k > n * p) ? -log1 / M_LN10 - logNT_ : -logNT_;
@@ -263,9 +290,11 @@ private:
         }
         return -std::log10(tail) - logNT_;
     }
-    double rectNfa(const RectD& rec) const
+public:
+    /* DRFE_LSD_CHECK=1: the same pixel loop on the host, to cross-check k_rect_counts (debug only) */
+    void countHost(const RectCand& rec, int& total, int& alg) const
     {
-        struct Corner { double x, y; bool taken; };   /* integer-valued corners stored as doubles (cv::Point2d) */
+        struct Corner { double x, y; bool taken; };
         const double hw = rec.width / 2.0, dyhw = rec.dy * hw, dxhw = rec.dx * hw;
         Corner c[4] = {{double(int(rec.x1 - dyhw)), double(int(rec.y1 + dxhw)), false},
                        {double(int(rec.x2 - dyhw)), double(int(rec.y2 + dxhw)), false},
@@ -281,8 +310,6 @@ private:
         for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!right || right->x < c[i].x) right = &c[i]; }
         right->taken = true;
         for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!tail || tail->x > c[i].x) tail = &c[i]; }
-        /* edge slopes dx/dy; the guards of the second steps compare y against tail->x as OpenCV's rect_nfa
-         * does; a guard that misses would divide by zero and such a step counts as 0 */
         const double fl = (lo->y != left->y) ? (lo->x - left->x) / (lo->y - left->y) : 0;
         double sl = (left->y != tail->x) ? (left->x - tail->x) / (left->y - tail->y) : 0;
         const double fr = (lo->y != right->y) ? (lo->x - right->x) / (lo->y - right->y) : 0;
@@ -290,7 +317,7 @@ private:
         if (!std::isfinite(sl)) sl = 0;
         if (!std::isfinite(sr)) sr = 0;
         double lstep = fl, rstep = fr, lx = lo->x, rx = lo->x;
-        int total = 0, alg = 0;
+        total = 0; alg = 0;
         for (int y = (int)lo->y; y <= (int)hi->y; ++y) {
             if (y < 0 || y >= H_) continue;
             for (int x = int(lx); x <= int(rx); ++x) {
@@ -303,34 +330,57 @@ private:
             lx += lstep;
             rx += rstep;
         }
-        return nfa(total, alg, rec.p);
     }
-    double improve(RectD& rec) const
+private:
+    static RectCand cand(const RectD& r) { return RectCand{r.x1, r.y1, r.x2, r.y2, r.width, r.dx, r.dy, r.theta, r.prec}; }
+
+    /* cv::LineSegmentDetectorImpl::rect_improve for every rectangle of the frame, level-synchronous: the five candidates of
+     * a refinement stage depend only on the rectangle the stage starts from, so a stage is ONE counting launch over all
+     * live rectangles (device) followed by the NFA comparisons in the reference's order (host, the caller's libm).
+     * Stages: the rectangle itself; 5 x precision halved; 5 x width reduced; 5 x one side; 5 x the other side; 5 x precision. */
+    bool improveAll(std::vector<RectD>& rects, std::vector<double>& best, const CountFn& counts) const
     {
         const double delta = 0.5, d2 = delta / 2.0, logEps = 0;
-        double best = rectNfa(rec);
-        if (best > logEps) return best;
-        RectD r = rec;
-        for (int n = 0; n < 5; ++n) {
-            r.p /= 2; r.prec = r.p * M_PI;
-            const double v = rectNfa(r);
-            if (v > best) { best = v; rec = r; }
-        }
-        if (best > logEps) return best;
-        for (int mode = 0; mode < 4; mode++) {   /* width, one side, other side, finer precision */
-            r = rec;
-            for (int n = 0; n < 5; ++n) {
-                if (!((r.width - delta) >= 0.5)) continue;
-                if (mode == 0) r.width -= delta;
-                else if (mode == 1) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; r.width -= delta; }
-                else if (mode == 2) { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; r.width -= delta; }
-                else { r.p /= 2; r.prec = r.p * M_PI; }
-                const double v = rectNfa(r);
-                if (v > best) { rec = r; best = v; }
+        const size_t R = rects.size();
+        best.assign(R, 0.0);
+        std::vector<char> done(R, 0);
+        std::vector<RectCand> cands;
+        std::vector<RectD> trial;              /* the candidate rectangles of the current stage */
+        std::vector<int> owner;                /* rectangle a candidate belongs to */
+        std::vector<int2> cnt;
+        for (int stage = 0; stage < 6; stage++) {
+            cands.clear(); trial.clear(); owner.clear();
+            for (size_t i = 0; i < R; i++) {
+                if (done[i]) continue;
+                RectD r = rects[i];
+                if (stage == 0) { trial.push_back(r); owner.push_back((int)i); continue; }
+                for (int n = 0; n < 5; ++n) {
+                    if (stage == 1) { r.p /= 2; r.prec = r.p * M_PI; }
+                    else {
+                        if (!((r.width - delta) >= 0.5)) continue;        /* guards the last precision stage too */
+                        if (stage == 5) { r.p /= 2; r.prec = r.p * M_PI; }
+                        else if (stage == 2) r.width -= delta;
+                        else if (stage == 3) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; r.width -= delta; }
+                        else { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; r.width -= delta; }
+                    }
+                    trial.push_back(r); owner.push_back((int)i);
+                }
             }
-            if (mode < 3 && best > logEps) return best;
+            if (trial.empty()) continue;
+            cands.reserve(trial.size());
+            for (const RectD& r : trial) cands.push_back(cand(r));
+            if (!counts(cands, cnt)) return false;
+            for (size_t k = 0; k < trial.size(); k++) {
+                const int i = owner[k];
+                const double v = nfa(cnt[k].x, cnt[k].y, trial[k].p);
+                if (stage == 0) best[i] = v;
+                else if (v > best[i]) { best[i] = v; rects[i] = trial[k]; }
+            }
+            if (stage < 5)
+                for (size_t i = 0; i < R; i++)
+                    if (!done[i] && best[i] > logEps) done[i] = 1;
         }
-        return best;
+        return true;
     }
 };
 
@@ -463,7 +513,7 @@ struct LineWorker {
 static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
-    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_maxGrad, s->d_gx, s->d_gy};
+    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_maxGrad, s->d_gx, s->d_gy, s->d_cands, s->d_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete s;
     s = nullptr;
@@ -551,7 +601,37 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
     SegmentFinder finder(s->sw, s->sh, modgrad.data(), angles.data(), H.cs.data(), maxGrad, H.used, H.order);
     const auto tSort = std::chrono::steady_clock::now();
     finder.timed_ = trace;
-    finder.run(segs);
+    int countRc = DRFE_OK;
+    const bool checkCounts = std::getenv("DRFE_LSD_CHECK") != nullptr;
+    auto counts = [&](const std::vector<RectCand>& cands, std::vector<int2>& out) -> bool {
+        const size_t nc = cands.size();
+        out.resize(nc);
+        if (nc > s->candCap) {
+            if (s->d_cands) (void)hipFree(s->d_cands);
+            if (s->d_counts) (void)hipFree(s->d_counts);
+            s->d_cands = nullptr; s->d_counts = nullptr;
+            s->candCap = std::max<size_t>(nc * 2, 4096);
+            if (hipMalloc((void**)&s->d_cands, s->candCap * sizeof(RectCand)) != hipSuccess ||
+                hipMalloc((void**)&s->d_counts, s->candCap * sizeof(int2)) != hipSuccess) {
+                s->candCap = 0; c->err = "lsd_extract: hipMalloc of the NFA scratch failed"; countRc = DRFE_ERR_HIP; return false;
+            }
+        }
+        hipError_t e = hipMemcpyAsync(s->d_cands, cands.data(), nc * sizeof(RectCand), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, s->d_angles, s->sw, s->sh, s->d_counts, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(out.data(), s->d_counts, nc * sizeof(int2), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { c->err = std::string("lsd_extract: rectangle counting: ") + hipGetErrorString(e); countRc = DRFE_ERR_HIP; return false; }
+        if (checkCounts)
+            for (size_t k = 0; k < nc; k++) {
+                int t = 0, a = 0;
+                finder.countHost(cands[k], t, a);
+                if (t != out[k].x || a != out[k].y)
+                    std::fprintf(stderr, "k_rect_counts mismatch: cand %zu device (%d, %d) host (%d, %d)  x1 %.17g y1 %.17g x2 %.17g y2 %.17g w %.17g dx %.17g dy %.17g theta %.17g prec %.17g\n",
+                                 k, out[k].x, out[k].y, t, a, cands[k].x1, cands[k].y1, cands[k].x2, cands[k].y2, cands[k].width, cands[k].dx, cands[k].dy, cands[k].theta, cands[k].prec);
+            }
+        return true;
+    };
+    if (!finder.run(segs, counts)) return countRc;
     const auto tSeg = std::chrono::steady_clock::now();
     if (trace) std::fprintf(stderr, "drfe_lsd_extract: pixel ordering (bins + std::sort) %.2f ms; grow %.2f ms (%ld regions); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
                             std::chrono::duration<double, std::milli>(tSort - tDev).count(), finder.tGrow_, finder.nGrow_, finder.tRefine_, finder.nRect_, finder.tImprove_);

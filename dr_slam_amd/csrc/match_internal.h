@@ -37,6 +37,9 @@ struct MatchBuffers {
     uint8_t* d_initObs;       /* [maxKp] staging of caller-supplied claim flags */
     int32_t* d_bfIdx; int32_t* d_bfDist; uint8_t* d_bfQ; uint8_t* d_bfT; size_t bfCap; /* elements / bytes */
     size_t queryCap;          /* queries the buffers hold */
+    /* pinned staging ring of drfe_match_consecutive_batch: pairs + poses of a batch travel from here, so the call needs
+     * no stream synchronisation; an event per slot guards its reuse two calls later */
+    void* h_stage[2]; hipEvent_t stageEv[2]; size_t stageBytes; int stageNext;
 };
 
 hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,

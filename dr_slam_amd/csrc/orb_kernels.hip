@@ -1413,17 +1413,24 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
             hipLaunchKernelGGL((k_fast_cells_cols<8>), dim3(nSmall, nframes), dim3(64), (size_t)fastc_lds_bytes(g.fastColsRows), s,
                                c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr, c->d_cand0,
                                c->d_cand1, c->d_candCount, c->d_status, drfe_div_magic((uint32_t)nSmall), 0);
+        if (nBig > 0) {
+            prof_end(c, DRFE_STAGE_FAST, s);
+            prof_begin(c, DRFE_STAGE_FAST_B, s);
+        }
         if (nBig > 0)
             hipLaunchKernelGGL((k_fast_cells_cols<DRFE_FASTC_MAX_RPL>), dim3(nBig, nframes), dim3(64),
                                (size_t)fastc_lds_bytes(g.fastColsRows), s, c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems,
                                g.iniTh, g.minTh, c->d_pyr, c->d_cand0, c->d_cand1, c->d_candCount, c->d_status,
                                drfe_div_magic((uint32_t)nBig), nSmall);
-    } else
+        if (nBig > 0) prof_end(c, DRFE_STAGE_FAST_B, s);
+        else prof_end(c, DRFE_STAGE_FAST, s);
+    } else {
         hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, nframes), dim3(64), (size_t)fast_lds_bytes(g.fastMaxWh), s, c->d_cells,
                            g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr,
                            c->d_cand0, c->d_cand1, c->d_candCount, c->d_status, fast_sc_off(g.fastMaxWh),
                            drfe_div_magic((uint32_t)g.totalCells));
-    prof_end(c, DRFE_STAGE_FAST, s);
+        prof_end(c, DRFE_STAGE_FAST, s);
+    }
 
     prof_begin(c, DRFE_STAGE_QUADTREE, s);
     {

@@ -22,7 +22,7 @@ TRACKED_DTYPE = np.dtype([("track_in_view", "u1"), ("bad", "u1"), ("obs_positive
                           ("level", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
                           ("view_cos", "<f4"), ("desc", "u1", (32,))])
 
-STAGES = ("pyramid", "fast", "quadtree", "blur", "desc", "glue", "match")
+STAGES = ("pyramid", "fast", "quadtree", "blur", "desc", "glue", "match", "fast_b")
 
 # every symbol include/drfe.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -36,7 +36,7 @@ SYMBOLS = (
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
-    "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download",
+    "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -112,6 +112,8 @@ def load() -> C.CDLL:
     L.drfe_orb_extract_batch.argtypes = [vp, vp, sz, sz, i32, i32, i32, vp]
     L.drfe_orb_download.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_counts.argtypes = [vp, i32, vp]
+    L.drfe_orb_fast_partition.argtypes = [vp, i32, i32, vp, vp]
+    L.drfe_batch_download_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.drfe_orb_pyramid_level.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_orb_blurred_level.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_orb_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
@@ -292,6 +294,20 @@ class Context:
         n = C.c_int(0)
         self._chk(self.L.drfe_orb_download(self.h, slot, _p(kps), _p(desc), self.max_kp, C.byref(n)), "drfe_orb_download")
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def batch_download_async_ptr(self, nframes: int, kps: int, desc: int, kp_counts: int, matches: int, match_counts: int,
+                                 stream: int = 0):
+        """Raw host pointers (pinned torch tensors): see drfe_batch_download_async."""
+        self._chk(self.L.drfe_batch_download_async(self.h, nframes, C.c_void_p(kps), C.c_void_p(desc), C.c_void_p(kp_counts),
+                                                   C.c_void_p(matches), C.c_void_p(match_counts), C.c_void_p(stream)),
+                  "drfe_batch_download_async")
+
+    def fast_partition(self, w: int, h: int):
+        """-> (cells[2], evaluated pixels[2]) of the two FAST launches for a w x h frame."""
+        cells = np.zeros(2, np.int32)
+        px = np.zeros(2, np.int64)
+        self._chk(self.L.drfe_orb_fast_partition(self.h, w, h, _p(cells), _p(px)), "drfe_orb_fast_partition")
+        return cells, px
 
     def orb_counts(self, nframes: int):
         c = np.zeros(nframes, np.int32)

@@ -93,6 +93,13 @@ int drfe_orb_extract_batch(drfe_ctx* ctx, const uint8_t* d_gray, size_t frame_st
                            int h, int nframes, void* stream);
 /* Copy slot results to host (synchronises the batch stream). */
 int drfe_orb_download(drfe_ctx* ctx, int slot, drfe_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* The whole batch to host memory in five copies, asynchronous on `stream` (hipStream_t; NULL = the context stream): for a
+ * pipeline that overlaps the results of batch i with the kernels of batch i+1 (pinned host buffers).  kps
+ * [nframes][max_keypoints], desc [nframes][max_keypoints][32], kp_counts [nframes]; matches [nframes][max_keypoints] and
+ * match_counts [nframes] (both may be NULL) as drfe_match_download returns them.  Rows past a frame's count are
+ * unspecified.  The caller synchronises the stream before reading. */
+int drfe_batch_download_async(drfe_ctx* ctx, int nframes, drfe_keypoint* kps, uint8_t* desc, int32_t* kp_counts,
+                              int32_t* matches, int32_t* match_counts, void* stream);
 /* Per-slot keypoint counts (host array of nframes ints; synchronises). */
 int drfe_orb_counts(drfe_ctx* ctx, int nframes, int* counts);
 
@@ -513,8 +520,13 @@ int drfe_surface_normals_download(drfe_ctx* ctx, int slot, drfe_surface_normal* 
 
 /* ------------------------------------------------------------------------------------------------ */
 /* measurement                                                                                       */
+/* DRFE_STAGE_FAST = the first FAST launch (k_fast_cells_cols<8>: the cells of at most 8 rows per lane - the four large levels at
+ * 640x480 - or the generic k_fast_cells over all cells); DRFE_STAGE_FAST_B = the second one (k_fast_cells_cols<12>, the rest). */
 enum { DRFE_STAGE_PYRAMID = 0, DRFE_STAGE_FAST, DRFE_STAGE_QUADTREE, DRFE_STAGE_BLUR, DRFE_STAGE_DESC,
-       DRFE_STAGE_GLUE, DRFE_STAGE_MATCH, DRFE_STAGE_COUNT };
+       DRFE_STAGE_GLUE, DRFE_STAGE_MATCH, DRFE_STAGE_FAST_B, DRFE_STAGE_COUNT };
+/* How the FAST cells of a w x h frame split over the two launches: cells[2] and evaluated pixels[2] (sum of the cells'
+ * (window - 6)^2 areas: every pixel of the detection region belongs to exactly one cell).  Host code. */
+int drfe_orb_fast_partition(drfe_ctx* ctx, int w, int h, int32_t* cells, int64_t* pixels);
 /* When enabled, batched calls bracket every stage with HIP events on the launch stream. */
 int drfe_profile_enable(drfe_ctx* ctx, int on);
 /* Milliseconds per stage of the most recent batched calls (synchronises). */

@@ -1,0 +1,275 @@
+/* drfe_adaptor.hpp — header-only C++ adaptor: the reference's class interfaces over the C-ABI of drfe.h.
+ *
+ * What a DR-SLAM maintainer drops in place of src/ORBextractor.cc, src/LSDextractor.cpp and src/PlaneExtractor.cpp
+ * (INTEGRATION.md): same class names, constructor arguments, methods and public members as
+ *   Planar_SLAM::ORBextractor          include/ORBextractor.h:51-85
+ *   LineSegment::ExtractLineSegment    include/LSDextractor.h:342-350
+ *   Planar_SLAM::PlaneDetection        include/PlaneExtractor.h:61-82
+ *   Planar_SLAM::PlaneDetection_CAPE   include/PlaneExtractor.h:84-115
+ *   Planar_SLAM::ORBmatcher (DescriptorDistance + the index-level SearchByProjection the MapPoint* overloads wrap)
+ * With -DDRFE_WITH_OPENCV the container types are OpenCV's (cv::Mat, cv::KeyPoint, cv::line_descriptor::KeyLine);
+ * without it (this image has no OpenCV) minimal stand-ins with the same member names and memory layout are used, so the
+ * header is compiled and exercised here (tests/native/adaptor_caller.cpp, run by tests/test_gpu_native.py).
+ * Compiled against nothing but drfe.h; link with -ldrfe.  Errors of the C-ABI become std::runtime_error, as the
+ * reference's constructors would throw; operator() keeps the reference's silent return on an empty image. */
+#ifndef DRFE_ADAPTOR_HPP
+#define DRFE_ADAPTOR_HPP
+
+#include "drfe.h"
+
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifdef DRFE_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+#include <opencv2/line_descriptor/descriptor.hpp>
+namespace drfe_cv {
+using Mat = cv::Mat;
+using KeyPoint = cv::KeyPoint;
+using KeyLine = cv::line_descriptor::KeyLine;
+inline const uint8_t* mat_data(const Mat& m) { return m.data; }
+inline size_t mat_step(const Mat& m) { return m.step; }
+inline Mat mat_u8(int rows, int cols) { return Mat(rows, cols, CV_8U); }
+}  // namespace drfe_cv
+#else
+namespace drfe_cv {
+struct Point2f { float x, y; };
+/* cv::KeyPoint: pt, size, angle, response, octave, class_id (7 x 4 bytes) */
+struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id; };
+/* the fields of cv::line_descriptor::KeyLine, in its declaration order */
+struct KeyLine {
+    float angle; int class_id, octave; Point2f pt; float response, size;
+    float startPointX, startPointY, endPointX, endPointY, sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength; int numOfPixels;
+};
+/* continuous single-channel 8-bit matrix: the subset of cv::Mat the adaptor touches */
+struct Mat {
+    int rows = 0, cols = 0; size_t step = 0; uint8_t* data = nullptr; int elem = 1;
+    std::shared_ptr<std::vector<uint8_t>> own;
+    Mat() {}
+    Mat(int r, int c, int elemSize = 1) : rows(r), cols(c), step((size_t)c * elemSize), elem(elemSize),
+                                          own(std::make_shared<std::vector<uint8_t>>((size_t)r * c * elemSize)) { data = own->data(); }
+    Mat(int r, int c, uint8_t* external, size_t stepBytes, int elemSize = 1) : rows(r), cols(c), step(stepBytes), data(external), elem(elemSize) {}
+    bool empty() const { return rows == 0 || cols == 0 || !data; }
+    void release() { rows = cols = 0; step = 0; data = nullptr; own.reset(); }
+    template <class T> T* ptr(int r) { return reinterpret_cast<T*>(data + (size_t)r * step); }
+    template <class T> const T* ptr(int r) const { return reinterpret_cast<const T*>(data + (size_t)r * step); }
+};
+inline const uint8_t* mat_data(const Mat& m) { return m.data; }
+inline size_t mat_step(const Mat& m) { return m.step; }
+inline Mat mat_u8(int rows, int cols) { return Mat(rows, cols); }
+}  // namespace drfe_cv
+#endif
+
+static_assert(sizeof(drfe_cv::KeyPoint) == sizeof(drfe_keypoint), "cv::KeyPoint and drfe_keypoint must share one layout");
+#ifndef DRFE_WITH_OPENCV
+static_assert(sizeof(drfe_cv::KeyLine) == sizeof(drfe_keyline), "KeyLine stand-in and drfe_keyline must share one layout");
+#endif
+
+namespace Planar_SLAM {
+
+namespace drfe_detail {
+inline void check(int rc, drfe_ctx* c, const char* what)
+{
+    if (rc != DRFE_OK) throw std::runtime_error(std::string(what) + ": " + drfe_last_error(c));
+}
+struct CtxDeleter { void operator()(drfe_ctx* c) const { drfe_destroy(c); } };
+using CtxPtr = std::shared_ptr<drfe_ctx>;
+inline CtxPtr make_ctx(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int maxW, int maxH, int maxBatch,
+                       int device)
+{
+    drfe_config cfg = {device, maxW, maxH, maxBatch, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
+    drfe_ctx* c = nullptr;
+    if (drfe_create(&cfg, &c) != DRFE_OK) throw std::runtime_error(std::string("drfe_create: ") + drfe_last_error(nullptr));
+    return CtxPtr(c, CtxDeleter());
+}
+}  // namespace drfe_detail
+
+/* include/ORBextractor.h:51-85 */
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int maxWidth = 640, int maxHeight = 480,
+                 int device = 0)
+        : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST),
+          mCtx(drfe_detail::make_ctx(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, maxWidth, maxHeight, 1, device))
+    {
+        mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+        drfe_detail::check(drfe_orb_scale_tables(mCtx.get(), mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                                                 mvInvLevelSigma2.data()), mCtx.get(), "drfe_orb_scale_tables");
+        mvImagePyramid.resize(nlevels);
+    }
+    ~ORBextractor() {}
+
+    /* Compute the ORB features and descriptors on an image; the mask is ignored (include/ORBextractor.h:60-65) */
+    void operator()(const drfe_cv::Mat& image, const drfe_cv::Mat& /*mask*/, std::vector<drfe_cv::KeyPoint>& keypoints,
+                    drfe_cv::Mat& descriptors)
+    {
+        if (image.empty()) return;                                       /* src/ORBextractor.cc:1046-1047 */
+        const int cap = drfe_orb_max_keypoints(mCtx.get());
+        keypoints.resize(cap);
+        drfe_cv::Mat desc = drfe_cv::mat_u8(cap, 32);
+        int n = 0;
+        drfe_detail::check(drfe_orb_extract(mCtx.get(), drfe_cv::mat_data(image), image.cols, image.rows, drfe_cv::mat_step(image),
+                                            reinterpret_cast<drfe_keypoint*>(keypoints.data()), desc.data, cap, &n),
+                           mCtx.get(), "drfe_orb_extract");
+        keypoints.resize(n);
+        if (n == 0) { descriptors.release(); return; }                   /* :1064-1065 */
+        descriptors = drfe_cv::mat_u8(n, 32);
+        std::memcpy(descriptors.data, desc.data, (size_t)n * 32);
+        /* public member mvImagePyramid (include/ORBextractor.h:85): interior ROI views of the bordered levels */
+        mvPyramidStore.resize(nlevels);
+        for (int l = 0; l < nlevels; ++l) {
+            int bw = 0, bh = 0;
+            drfe_detail::check(drfe_orb_pyramid_level(mCtx.get(), 0, l, nullptr, &bw, &bh), mCtx.get(), "drfe_orb_pyramid_level");
+            mvPyramidStore[l] = drfe_cv::mat_u8(bh, bw);
+            drfe_detail::check(drfe_orb_pyramid_level(mCtx.get(), 0, l, mvPyramidStore[l].data, &bw, &bh), mCtx.get(),
+                               "drfe_orb_pyramid_level");
+#ifdef DRFE_WITH_OPENCV
+            mvImagePyramid[l] = mvPyramidStore[l](cv::Rect(19, 19, bw - 38, bh - 38));
+#else
+            mvImagePyramid[l] = drfe_cv::Mat(bh - 38, bw - 38, mvPyramidStore[l].data + 19 * (size_t)bw + 19, (size_t)bw);
+#endif
+        }
+    }
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    std::vector<drfe_cv::Mat> mvImagePyramid;
+
+    drfe_ctx* context() { return mCtx.get(); }        /* for the Frame glue / matcher adaptors that share the device state */
+
+protected:
+    int nfeatures; double scaleFactor; int nlevels; int iniThFAST; int minThFAST;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<drfe_cv::Mat> mvPyramidStore;
+    drfe_detail::CtxPtr mCtx;
+};
+
+/* include/ORBmatcher.h:41-84: the parts that do not touch the MapPoint graph.  The MapPoint* overloads of the reference
+ * flatten what their loops read into drfe_map_point / drfe_tracked_point records and call these. */
+class ORBmatcher {
+public:
+    static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    /* src/ORBmatcher.cc:1712-1728 */
+    static int DescriptorDistance(const uint8_t* a, const uint8_t* b)
+    {
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t pa, pb;
+            std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+            uint32_t v = pa ^ pb;
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+        }
+        return dist;
+    }
+    /* SearchByProjection(CurrentFrame, LastFrame, th, bMono) on the slots `cur` / `last` of ctx (extract + glue done):
+     * lastPoints[i] = what the loop reads of LastFrame.mvpMapPoints[i]; curClaims in/out = index into lastPoints or -1 */
+    int SearchByProjection(drfe_ctx* ctx, int cur, int last, const float* TcwCur, const float* TcwLast, const drfe_camera& cam,
+                           const std::vector<drfe_map_point>& lastPoints, std::vector<int32_t>& curClaims, float th, bool bMono)
+    {
+        int n = 0;
+        drfe_detail::check(drfe_search_by_projection_last(ctx, cur, last, TcwCur, TcwLast, &cam, lastPoints.data(), (int)lastPoints.size(),
+                                                          th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, nullptr, curClaims.data(),
+                                                          (int)curClaims.size(), &n), ctx, "drfe_search_by_projection_last");
+        return n;
+    }
+protected:
+    float mfNNratio; bool mbCheckOrientation;
+};
+
+/* include/PlaneExtractor.h:61-82 (the live AHC extractor).  extractedPlanes[i]->normal / center are what Frame::ComputePlanes reads */
+class PlaneDetection {
+public:
+    struct ExtractedPlane { double normal[3], center[3], mse, curvature; int N; };
+    static const int kDepthWidth = 640, kDepthHeight = 480;
+    std::vector<std::vector<int>> plane_vertices_;     /* vertex indices each plane contains */
+    std::vector<std::shared_ptr<ExtractedPlane>> extractedPlanes;   /* plane_filter.extractedPlanes */
+    drfe_cv::Mat seg_output;
+    int plane_num_ = 0;
+
+    explicit PlaneDetection(drfe_ctx* ctx) : mCtx(ctx) {}
+
+    bool readDepthImage(const drfe_cv::Mat& depthImg, const float K[9] /* mK row-major */, float depthfactor)
+    {
+        if (depthImg.empty() || depthImg.elem != 2) return false;       /* "cannot read depth image": CV_16U only */
+        mDepth = depthImg; mFactor = depthfactor;
+        mK4[0] = K[0]; mK4[1] = K[4]; mK4[2] = K[2]; mK4[3] = K[5];
+        return true;
+    }
+    void runPlaneDetection()
+    {
+        std::vector<drfe_plane> pl(64);
+        std::vector<int32_t> off(65), idx((size_t)mDepth.cols * mDepth.rows);
+        seg_output = drfe_cv::mat_u8(mDepth.rows, mDepth.cols);
+        int np = 0;
+        drfe_detail::check(drfe_planes_ahc(mCtx, mDepth.ptr<uint16_t>(0), mDepth.cols, mDepth.rows, mDepth.step / 2, mK4, mFactor,
+                                           pl.data(), 64, &np, seg_output.data, off.data(), idx.data()), mCtx, "drfe_planes_ahc");
+        plane_num_ = np;
+        plane_vertices_.assign(np, std::vector<int>());
+        extractedPlanes.clear();
+        for (int i = 0; i < np; i++) {
+            plane_vertices_[i].assign(idx.begin() + off[i], idx.begin() + off[i + 1]);
+            auto e = std::make_shared<ExtractedPlane>();
+            std::memcpy(e->normal, pl[i].normal, 24); std::memcpy(e->center, pl[i].center, 24);
+            e->mse = pl[i].mse; e->curvature = pl[i].curvature; e->N = pl[i].n_points;
+            extractedPlanes.push_back(e);
+        }
+    }
+private:
+    drfe_ctx* mCtx; drfe_cv::Mat mDepth; float mFactor = 0; float mK4[4] = {0, 0, 0, 0};
+};
+
+}  // namespace Planar_SLAM
+
+/* include/LSDextractor.h:342-350 (global namespace in the reference) */
+class LineSegment {
+public:
+    explicit LineSegment(drfe_ctx* ctx) : mCtx(ctx) {}
+    /* lineF[i] = normalised sp x ep (Eigen::Vector3d in the reference: three doubles) */
+    void ExtractLineSegment(const drfe_cv::Mat& img, std::vector<drfe_cv::KeyLine>& keylines, drfe_cv::Mat& ldesc,
+                            std::vector<std::vector<double>>& keylineFunctions, float /*scale*/ = 1.2f, int /*numOctaves*/ = 1)
+    {
+        const int cap = 40;                                            /* lsdNFeatures, src/LSDextractor.cpp:20-28 */
+        std::vector<drfe_keyline> kl(cap);
+        drfe_cv::Mat desc = drfe_cv::mat_u8(cap, 32);
+        std::vector<double> lf(3 * cap);
+        int n = 0, found = 0;
+        Planar_SLAM::drfe_detail::check(drfe_lsd_extract(mCtx, drfe_cv::mat_data(img), img.cols, img.rows, drfe_cv::mat_step(img), cap,
+                                                         kl.data(), desc.data, lf.data(), cap, &n, &found), mCtx, "drfe_lsd_extract");
+        keylines.resize(n);
+        keylineFunctions.clear();
+        for (int i = 0; i < n; i++) {
+            drfe_cv::KeyLine& k = keylines[i];
+            k.angle = kl[i].angle; k.class_id = kl[i].class_id; k.octave = kl[i].octave;
+            k.pt.x = kl[i].pt_x; k.pt.y = kl[i].pt_y; k.response = kl[i].response; k.size = kl[i].size;
+            k.startPointX = kl[i].start_point_x; k.startPointY = kl[i].start_point_y; k.endPointX = kl[i].end_point_x; k.endPointY = kl[i].end_point_y;
+            k.sPointInOctaveX = kl[i].s_point_in_octave_x; k.sPointInOctaveY = kl[i].s_point_in_octave_y;
+            k.ePointInOctaveX = kl[i].e_point_in_octave_x; k.ePointInOctaveY = kl[i].e_point_in_octave_y;
+            k.lineLength = kl[i].line_length; k.numOfPixels = kl[i].num_of_pixels;
+            keylineFunctions.push_back({lf[3 * i], lf[3 * i + 1], lf[3 * i + 2]});
+        }
+        ldesc = drfe_cv::mat_u8(n, 32);
+        if (n) std::memcpy(ldesc.data, desc.data, (size_t)n * 32);
+    }
+private:
+    drfe_ctx* mCtx;
+};
+
+#endif /* DRFE_ADAPTOR_HPP */

@@ -32,7 +32,8 @@ def build(force: bool = False) -> str:
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # DRFE_ORACLE_LIB: bench.py's timing leg loads its own -march=native build (kept outside the tree)
+        _LIB = C.CDLL(os.environ.get("DRFE_ORACLE_LIB") or build())
         L = _LIB
         L.orc_last_error.restype = C.c_char_p
         L.orc_orb_create.restype = C.c_void_p

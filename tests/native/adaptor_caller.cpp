@@ -1,0 +1,59 @@
+/* adaptor_caller.cpp — compiles include/drfe_adaptor.hpp (no OpenCV: the stand-in container types) and drives one frame
+ * through the reference's class interfaces: ORBextractor(...)(image, mask, keypoints, descriptors), the getters, the public
+ * pyramid member, LineSegment::ExtractLineSegment, PlaneDetection::readDepthImage + runPlaneDetection.
+ * usage: adaptor_caller <gray.raw> <depth16.raw> <w> <h> <out.bin>; tests/test_gpu_native.py compares out.bin with the ctypes path. */
+#include "drfe_adaptor.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+static std::vector<uint8_t> slurp(const char* path, size_t n)
+{
+    std::vector<uint8_t> b(n);
+    FILE* f = std::fopen(path, "rb");
+    if (!f || std::fread(b.data(), 1, n, f) != n) { std::fprintf(stderr, "cannot read %s\n", path); std::exit(2); }
+    std::fclose(f);
+    return b;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 6) return 2;
+    const int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
+    std::vector<uint8_t> gray = slurp(argv[1], (size_t)w * h), depth = slurp(argv[2], (size_t)w * h * 2);
+    try {
+        Planar_SLAM::ORBextractor ex(1000, 1.2f, 8, 20, 7, w, h);
+        drfe_cv::Mat image(h, w, gray.data(), (size_t)w), mask, desc;
+        std::vector<drfe_cv::KeyPoint> kps;
+        ex(image, mask, kps, desc);
+        drfe_cv::Mat empty;
+        std::vector<drfe_cv::KeyPoint> none;
+        ex(empty, mask, none, desc);                                      /* empty image: silent return, outputs untouched */
+        if (!none.empty() || desc.rows != (int)kps.size()) return 3;
+        if (ex.GetLevels() != 8 || ex.GetScaleFactors().size() != 8 || ex.mvImagePyramid[0].cols != w) return 4;
+        LineSegment ls(ex.context());
+        std::vector<drfe_cv::KeyLine> kl; drfe_cv::Mat ldesc; std::vector<std::vector<double>> lf;
+        ls.ExtractLineSegment(image, kl, ldesc, lf);
+        Planar_SLAM::PlaneDetection pd(ex.context());
+        const float K[9] = {535.4f, 0, 320.1f, 0, 539.2f, 247.6f, 0, 0, 1};
+        drfe_cv::Mat dimg(h, w, depth.data(), (size_t)w * 2, 2);
+        if (!pd.readDepthImage(dimg, K, 1.0f / 5000.0f)) return 5;
+        pd.runPlaneDetection();
+        FILE* f = std::fopen(argv[5], "wb");
+        const int32_t hdr[4] = {(int32_t)kps.size(), (int32_t)kl.size(), pd.plane_num_, Planar_SLAM::ORBmatcher::DescriptorDistance(desc.data, desc.data + 32)};
+        std::fwrite(hdr, 4, 4, f);
+        std::fwrite(kps.data(), sizeof(drfe_cv::KeyPoint), kps.size(), f);
+        std::fwrite(desc.data, 32, kps.size(), f);
+        std::fwrite(kl.data(), sizeof(drfe_cv::KeyLine), kl.size(), f);
+        std::fwrite(ldesc.data, 32, kl.size(), f);
+        for (int i = 0; i < pd.plane_num_; i++) { std::fwrite(pd.extractedPlanes[i]->normal, 8, 3, f); std::fwrite(pd.extractedPlanes[i]->center, 8, 3, f); }
+        std::fwrite(pd.seg_output.data, 1, (size_t)w * h, f);
+        std::fwrite(ex.mvImagePyramid[1].ptr<uint8_t>(7), 1, ex.mvImagePyramid[1].cols, f);   /* one interior row of level 1 */
+        std::fclose(f);
+        std::printf("adaptor ok: %zu keypoints, %zu lines, %d planes\n", kps.size(), kl.size(), pd.plane_num_);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "adaptor_caller: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

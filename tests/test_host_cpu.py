@@ -241,3 +241,15 @@ def test_bench_launcher_starts_n_fresh_ranks(tmp_path):
     assert '"rank": 1' in p.stderr
     p = subprocess.run([sys.executable, "-c", code, "--fail"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0
+
+
+def test_native_callers_build_and_link():
+    """The C99 caller and the C++ adaptor caller compile against include/ alone and link libdrfe.so (no compute here)."""
+    import subprocess
+    nat = os.path.join(ROOT, "tests", "native")
+    subprocess.check_call(["make", "-C", nat], stdout=subprocess.DEVNULL)
+    for exe in ("c_caller", "adaptor_caller"):
+        out = subprocess.run(["ldd", os.path.join(nat, exe)], capture_output=True, text=True).stdout
+        assert "libdrfe.so" in out and "not found" not in out.split("libdrfe.so")[1].split("\n")[0], out
+    # without arguments both print nothing and exit 2 before touching the device
+    assert subprocess.run([os.path.join(nat, "c_caller")]).returncode == 2
