@@ -104,7 +104,20 @@ def cpu_baseline(base, cam, frames: int = 220, discard: int = 20):
     from dr_slam_amd import sharding
     so, flags = _native_oracle()
     if so:
-        os.environ["DRFE_ORACLE_LIB"] = so
+        # take whichever build extracts faster on this host (gcc's -march=native is not always the quicker one)
+        import subprocess
+        probe = ("import sys,time,numpy as np; sys.path.insert(0, %r); from oracle import oracle as orc; o = orc.OrbOracle(); "
+                 "g = (np.arange(640*480, dtype=np.uint32) * 2654435761 >> 13).astype(np.uint8).reshape(480, 640); o(g); "
+                 "t = time.perf_counter(); [o(g) for _ in range(8)]; print(time.perf_counter() - t)" % ROOT)
+        t_native = float(subprocess.run([sys.executable, "-c", probe], env=dict(os.environ, DRFE_ORACLE_LIB=so),
+                                        capture_output=True, text=True).stdout or 1e9)
+        t_ship = float(subprocess.run([sys.executable, "-c", probe], env={k: v for k, v in os.environ.items() if k != "DRFE_ORACLE_LIB"},
+                                      capture_output=True, text=True).stdout or 1e9)
+        if t_native < t_ship:
+            os.environ["DRFE_ORACLE_LIB"] = so
+            flags += " (%.0f %% faster than the shipped x86-64-v3 build here)" % (100 * (t_ship / t_native - 1))
+        else:
+            flags = "-O3 -march=x86-64-v3 (the -march=native build is %.0f %% slower on this host)" % (100 * (t_native / t_ship - 1))
     from oracle import oracle as orc
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     inv = np.float32(1.0) / np.float32(cam.depth_factor)
@@ -204,7 +217,7 @@ def host_fed_rate(fe, gray, depth, Tcw, Twc, B, steps, dev):
     return B * steps / el, el / steps * 1e3
 
 
-def full_frontend(cam_name, n_frames: int = 48, reps: int = 2):
+def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines, AHC planes with their PCL-style
     post-processing and CAPE planes per frame (device passes + the sequential host stages on a pool of host threads)."""
@@ -228,16 +241,18 @@ def full_frontend(cam_name, n_frames: int = 48, reps: int = 2):
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    line_threads = max(1, (ncpu * 3) // 4 - 1)
+    line_threads = max(1, (ncpu * 5) // 8)
     plane_threads = max(1, ncpu - line_threads - 1)
     ctx_planes = lib.Context(max_batch=1)
     ctx_cape = lib.Context(max_batch=1)
 
+    post_pool = ThreadPoolExecutor(plane_threads)
+
     def planes():
         out = ctx_planes.planes_ahc_batch(depth, K4, inv, n_threads=plane_threads, members=True)
-        acc = 0
-        for f, r in enumerate(out):            # Frame::ComputePlanes after the extractor (host: voxel grid + refit)
-            acc += ctx_planes.planes_ahc_postprocess(depth[f], K4, inv, r, 9.0, 0.10)["n_accepted"]
+        # Frame::ComputePlanes after the extractor (host: voxel grid + refit), frames across the same threads
+        acc = sum(post_pool.map(lambda f: ctx_planes.planes_ahc_postprocess(depth[f], K4, inv, out[f], 9.0, 0.10)["n_accepted"],
+                                range(n_frames)))
         return len(out), acc
 
     def cape():
@@ -260,6 +275,7 @@ def full_frontend(cam_name, n_frames: int = 48, reps: int = 2):
         for _ in range(reps):
             nacc = step(pool)
         el = (time.perf_counter() - t0) / reps
+    post_pool.shutdown()
     for c in (ctx_planes, ctx_cape):
         c.close()
     fe.ctx.close()
