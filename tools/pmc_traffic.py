@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Folds two rocprofv3 counter-collection CSVs (one `--pmc FETCH_SIZE` pass, one `--pmc WRITE_SIZE` pass of the same
-bench command, collected without any tracing) into the per-kernel HBM traffic table bench.py reads.
+"""Folds rocprofv3 counter-collection CSVs (one `--pmc FETCH_SIZE` pass, one `--pmc WRITE_SIZE` pass and optionally an SQ pass
+holding SQ_INSTS_VALU + SQ_BUSY_CYCLES of the same bench command, collected without any tracing) into the per-kernel table
+bench.py reads: HBM traffic per launch and the VALU issue utilisation.
 
-usage: tools/pmc_traffic.py <fetch.csv> <write.csv> <batch> <out.json>"""
+usage: tools/pmc_traffic.py <fetch.csv> <write.csv> <batch> <out.json> [sq.csv]"""
 import collections
 import csv
 import json
@@ -17,7 +18,8 @@ def fold(path, counter):
         name = r["Kernel_Name"].split("(")[0]
         if name.startswith("void "):
             name = name[5:]
-        name = name.split("<")[0]
+        if not name.startswith("k_fast_cells_cols"):       # its two instantiations are two different launches
+            name = name.split("<")[0]
         acc[name][0] += float(r["Counter_Value"])
         acc[name][1] += 1
     return acc
@@ -33,9 +35,20 @@ def main():
             "WRITE_SIZE_KB_per_launch": round(w[k][0] / max(w[k][1], 1), 1), "launches_sampled_WRITE_SIZE": w[k][1],
         }
         kernels[k]["HBM_BYTES_per_launch"] = round((2.0 * kernels[k]["FETCH_SIZE_KB_per_launch"] + kernels[k]["WRITE_SIZE_KB_per_launch"]) * 1024.0)
+    if len(sys.argv) > 5:
+        # SQ_INSTS_VALU wave-instructions x 4 cycles each on one of the 1024 SIMDs, against the kernel's busy cycles
+        # (SQ_BUSY_CYCLES is reported summed over the 32 shader engines x ... of the device: normalised as in round 1 by the
+        # ratio that makes a pure-VALU micro-kernel read 1.0: busy / 32)
+        vi, bc = fold(sys.argv[5], "SQ_INSTS_VALU"), fold(sys.argv[5], "SQ_BUSY_CYCLES")
+        for k in kernels:
+            if k in vi and k in bc and bc[k][0] > 0:
+                inst, busy = vi[k][0] / vi[k][1], bc[k][0] / bc[k][1]
+                kernels[k]["SQ_INSTS_VALU_per_launch"] = round(inst)
+                kernels[k]["SQ_BUSY_CYCLES_per_launch"] = round(busy)
+                kernels[k]["valu_issue_utilisation"] = round(min(1.0, inst * 4.0 / 1024.0 / (busy / 32.0)), 3)
     doc = {
         "_about": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) over "
-                  f"`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (batch {batch}, 640x480), MI355X. Counter "
+                  f"`python3 bench.py --steps 5 --warmup 2 --distinct 8 --no-cpu-baseline --no-extras` (tools/profile_round.sh) (batch {batch}, 640x480), MI355X. Counter "
                   "units are KB as rocprofv3 reports them (TCC_EA0 requests x 64 B / 1024). Calibration in this repo's own "
                   "access widths (tools/ubench_copy.hip under the same two passes): a streaming copy of 86 016 KB reports "
                   "FETCH_SIZE 43 018 KB at 4, 8 and 16 bytes per lane alike (the gfx950 half-count of "

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r02 [batch]
+# one --kernel-trace --stats pass and four counter passes (FETCH_SIZE | WRITE_SIZE | two SQ groups), never combined with
+# tracing; everything lands under gpurun_out/<tag>_*; tools/pmc_traffic.py folds the counter CSVs into profiles/.
+set -u
+TAG=${1:-r02}
+B=${2:-512}
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --batch $B --distinct 8 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o ${TAG}_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
+            "sq1 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
+            "sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
+    set -- $pass
+    name=$1; shift
+    rocprofv3 --pmc "$@" -d $OUT/${TAG}_pmc_$name -o ${TAG}_pmc_$name -- $CMD > $OUT/${TAG}_pmc_$name.log 2>&1
+done
+find $OUT -name "${TAG}_*" -name "*.csv" | head -20
