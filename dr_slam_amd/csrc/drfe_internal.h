@@ -149,6 +149,7 @@ struct drfe_ctx {
     struct BowState* bow;     /* vocabulary + BoW scratch (bow_internal.h), set by drfe_voc_upload */
     struct LinesScratch* ls;  /* line-path scratch (lines_internal.h) */
     void* lineHost;           /* LineHost*: host buffers of the single-frame line entry */
+    void* cape;               /* CapeScratch*: device buffers of drfe_planes_cape (planes_internal.h) */
     void* sn;                 /* SnBuffers*: surface-normal scratch (post_internal.h) */
     void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */
 

@@ -14,6 +14,7 @@ struct LinesScratch {
     unsigned long long* d_maxGrad;
     int16_t* d_gx; int16_t* d_gy;
     struct RectCand* d_cands; int2* d_counts; size_t candCap;   /* grow-only scratch of the NFA rounds */
+    struct LbdLine* d_lbdLines; uint8_t* d_lbdOut; size_t lbdCap;
 };
 
 /* one rectangle whose aligned pixels are to be counted: the fields cv::LineSegmentDetectorImpl::rect_nfa reads */
@@ -23,6 +24,14 @@ struct RectCand { double x1, y1, x2, y2, width, dx, dy, theta, prec; };
  * rect_nfa, one wavefront per rectangle.  d_angles = the level-line angle field k_ll_angle left on the device. */
 hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double* d_angles, int W, int H, int2* d_counts,
                                    hipStream_t s);
+
+/* one key line as BinaryDescriptor::computeLBD reads it (octave 0); dL = (cos, sin) of the line angle from the host's libm */
+struct LbdLine { float midX, midY, dL0, dL1; int len, pad; };
+struct LbdTables { float coefG[63], coefL[21]; };      /* the Gaussian band weights, float(double exp(..)) */
+/* LBD descriptors (32 bytes each) of n lines from the Sobel images of the LBD input: one wavefront per line, lane = one of
+ * the 63 band rows for the row sums, lane = (moment, band) for the band accumulation; every float sum in the reference's order */
+hipError_t drfe_launch_lbd(const LbdLine* d_lines, int n, const int16_t* d_gx, const int16_t* d_gy, int w, int h,
+                           const LbdTables& tab, uint8_t* d_out, hipStream_t s);
 
 hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,
                                     LinesScratch* sc, double threshold, hipStream_t s);

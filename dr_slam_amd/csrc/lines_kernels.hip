@@ -191,6 +191,109 @@ hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double*
     return hipGetLastError();
 }
 
+/* BinaryDescriptor::computeLBD + binaryConversion (opencv_contrib 3.4 line_descriptor/src/binary_descriptor.cpp) for one key
+ * line per wavefront.  The sample positions walk by repeated float addition (sx += dL0; x0 -= dL1), so a lane that owns band
+ * row hID replays the hID row steps and then the len pixel steps in order; the 8 x 9 band moments are sums over at most 21 rows
+ * in row order (lane = one moment of one band); the normalisation chain is a single lane. */
+__global__ __launch_bounds__(64) void k_lbd(const LbdLine* __restrict__ lines, int n, const int16_t* __restrict__ gx,
+                                            const int16_t* __restrict__ gy, int realW, int realH, LbdTables tab,
+                                            uint8_t* __restrict__ out)
+{
+    const int NB = 9, WB = 7, height = 63;
+    __shared__ float rowv[63][8];
+    __shared__ float acc[8][9];
+    __shared__ float des[72];
+    const int id = blockIdx.x, lane = threadIdx.x;
+    if (id >= n) return;
+    const LbdLine L = lines[id];
+    const short maxX = (short)(realW - 1), maxY = (short)(realH - 1);
+    const short len = (short)L.len;
+    const short halfH = (height - 1) / 2, halfW = (short)((len - 1) / 2);
+    const float dL0 = L.dL0, dL1 = L.dL1, dO0 = -dL1, dO1 = dL0;
+    if (lane < height) {
+        float x0 = -dL0 * halfW + dL1 * halfH + L.midX;
+        float y0 = -dL1 * halfW - dL0 * halfH + L.midY;
+        for (int r = 0; r < lane; r++) { x0 -= dL1; y0 += dL0; }
+        float sx = x0, sy = y0, pL = 0, nL = 0, pO = 0, nO = 0;
+        for (short wID = 0; wID < len; wID++) {
+            short t = (short)roundf(sx);
+            const short xc = (t < 0) ? (short)0 : (t > maxX) ? maxX : t;
+            t = (short)roundf(sy);
+            const short yc = (t < 0) ? (short)0 : (t > maxY) ? maxY : t;
+            const short dx = gx[yc * realW + xc], dy = gy[yc * realW + xc];
+            const float gDL = dx * dL0 + dy * dL1, gDO = dx * dO0 + dy * dO1;
+            if (gDL > 0) pL += gDL; else nL -= gDL;
+            if (gDO > 0) pO += gDO; else nO -= gDO;
+            sx += dL0;
+            sy += dL1;
+        }
+        const float cg = tab.coefG[lane];
+        pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
+        rowv[lane][0] = pL; rowv[lane][1] = nL; rowv[lane][2] = pL * pL; rowv[lane][3] = nL * nL;
+        rowv[lane][4] = pO; rowv[lane][5] = nO; rowv[lane][6] = pO * pO; rowv[lane][7] = nO * nO;
+    }
+    __syncthreads();
+    for (int item = lane; item < 72; item += 64) {
+        const int q = item / NB, b = item - q * NB;
+        float a = 0.f;
+        /* rows of band b-1 reach b as their "next" band (coefL[i]), rows of b as their own (coefL[i + 7]), rows of b+1 as their
+         * "previous" band (coefL[i + 14]): ascending row order */
+        for (int hID = max(0, (b - 1) * WB); hID < min(height, (b + 2) * WB); hID++) {
+            const int own = hID / WB, i = hID - own * WB;
+            const float cl = tab.coefL[own == b ? i + WB : own == b + 1 ? i + 2 * WB : i];
+            a += ((q & 2) ? cl * cl : cl) * rowv[hID][q];
+        }
+        acc[q][b] = a;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        const float invN2 = (float)(1.0 / (WB * 2.0)), invN3 = (float)(1.0 / (WB * 3.0));
+        for (int b = 0; b < NB; b++) {
+            const float invN = (b == 0 || b == NB - 1) ? invN2 : invN3;
+            float* d = des + 8 * b;
+            float m = acc[0][b] * invN; d[0] = m; d[4] = sqrtf(acc[2][b] * invN - m * m);
+            m = acc[1][b] * invN; d[1] = m; d[5] = sqrtf(acc[3][b] * invN - m * m);
+            m = acc[4][b] * invN; d[2] = m; d[6] = sqrtf(acc[6][b] * invN - m * m);
+            m = acc[5][b] * invN; d[3] = m; d[7] = sqrtf(acc[7][b] * invN - m * m);
+        }
+        float tm = 0, ts = 0;
+        for (int b = 0; b < NB; b++) {
+            const float* d = des + 8 * b;
+            tm += d[0] * d[0]; tm += d[1] * d[1]; tm += d[2] * d[2]; tm += d[3] * d[3];
+            ts += d[4] * d[4]; ts += d[5] * d[5]; ts += d[6] * d[6]; ts += d[7] * d[7];
+        }
+        tm = 1 / sqrtf(tm);
+        ts = 1 / sqrtf(ts);
+        for (int b = 0; b < NB; b++) {
+            float* d = des + 8 * b;
+            d[0] *= tm; d[1] *= tm; d[2] *= tm; d[3] *= tm; d[4] *= ts; d[5] *= ts; d[6] *= ts; d[7] *= ts;
+        }
+        for (int i = 0; i < 72; i++) if ((double)des[i] > 0.4) des[i] = (float)0.4;
+        float nrm = 0;
+        for (int i = 0; i < 72; i++) nrm += des[i] * des[i];
+        nrm = 1 / sqrtf(nrm);
+        for (int i = 0; i < 72; i++) des[i] = des[i] * nrm;
+    }
+    __syncthreads();
+    if (lane < 32) {
+        /* binaryConversion: 32 band pairs x 8 comparisons */
+        const unsigned char pa[32] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
+        const unsigned char pb[32] = {1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8};
+        const float *a = des + 8 * pa[lane], *b = des + 8 * pb[lane];
+        unsigned v = 0;
+        for (int i = 0; i < 8; i++) if (a[i] > b[i]) v += 1u << i;
+        out[(size_t)id * 32 + lane] = (uint8_t)v;
+    }
+}
+
+hipError_t drfe_launch_lbd(const LbdLine* d_lines, int n, const int16_t* d_gx, const int16_t* d_gy, int w, int h,
+                           const LbdTables& tab, uint8_t* d_out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lbd, dim3(n), dim3(64), 0, s, d_lines, n, d_gx, d_gy, w, h, tab, d_out);
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,
                                     LinesScratch* sc, double threshold, hipStream_t s)
 {

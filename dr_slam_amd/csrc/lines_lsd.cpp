@@ -39,7 +39,12 @@ namespace {
 const double kNotDef = -1024.0, kTwoPi = 2.0 * M_PI, kThreeHalfPi = 3.0 * M_PI / 2.0, kDeg2Rad = M_PI / 180.0;
 
 struct RPt { int x, y; double angle, modgrad; };
-struct OPt { int x, y, norm; };
+/* one pixel of the pseudo-ordering: gradient bin << 32 | y << 16 | x.  std::sort's permutation depends on the comparator's
+ * answers only (it looks at the bin), so sorting these 8-byte keys orders the pixels exactly as sorting OpenCV's 12-byte
+ * normPoint records does, with a third less memory traffic */
+typedef uint64_t OPt;
+static inline int opt_x(OPt k) { return (int)(k & 0xFFFF); }
+static inline int opt_y(OPt k) { return (int)((k >> 16) & 0xFFFF); }
 struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
 /* sequential half of cv::LineSegmentDetectorImpl, fed with the device-computed gradient fields */
@@ -56,9 +61,10 @@ public:
         order_.clear();
         order_.reserve((size_t)(W - 1) * (H - 1));
         for (int y = 0; y < H - 1; ++y)
-            for (int x = 0; x < W - 1; ++x) order_.push_back({x, y, int(mod_[(size_t)y * W + x] * binCoef)});
+            for (int x = 0; x < W - 1; ++x)
+                order_.push_back(((uint64_t)(uint32_t)int(mod_[(size_t)y * W + x] * binCoef) << 32) | ((uint64_t)y << 16) | (uint64_t)x);
         /* std::sort, as OpenCV: the order of equal bins is whatever libstdc++'s introsort leaves */
-        std::sort(order_.begin(), order_.end(), [](const OPt& a, const OPt& b) { return a.norm > b.norm; });
+        std::sort(order_.begin(), order_.end(), [](const OPt& a, const OPt& b) { return (int)(a >> 32) > (int)(b >> 32); });
         logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     }
 
@@ -74,7 +80,8 @@ public:
         /* rect_improve only READS the angle field and decides whether the segment is kept: it is taken out of the seed loop
          * (whose `used` bookkeeping is the sequential part) and evaluated for all rectangles of the frame at once */
         std::vector<RectD> pending;
-        for (const OPt& s : order_) {
+        for (const OPt& key : order_) {
+            const struct { int x, y; } s = {opt_x(key), opt_y(key)};
             if (used_[(size_t)s.y * W_ + s.x] || ang_[(size_t)s.y * W_ + s.x] == kNotDef) continue;
             double regAngle;
             if (!timed_) {
@@ -143,7 +150,11 @@ private:
         reg.clear();
         regAngle = ang_[(size_t)sy * W_ + sx];
         reg.push_back({sx, sy, regAngle, mod_[(size_t)sy * W_ + sx]});
-        float sumdx = float(std::cos(regAngle)), sumdy = float(std::sin(regAngle));
+        /* the seed's own direction enters the running sums when the first neighbour joins: most of the ~35 000 seeds of a
+         * frame never get one, and these are the only two libm calls of the loop */
+        float sumdx = 0.f, sumdy = 0.f;
+        bool seeded = false;
+        const double seedAngle = regAngle;
         used_[(size_t)sy * W_ + sx] = 1;
         for (size_t i = 0; i < reg.size(); i++) {
             const int px = reg[i].x, py = reg[i].y;
@@ -154,6 +165,7 @@ private:
                         const double a = ang_[(size_t)yy * W_ + xx];
                         u = 1;
                         reg.push_back({xx, yy, a, mod_[(size_t)yy * W_ + xx]});
+                        if (!seeded) { sumdx = float(std::cos(seedAngle)); sumdy = float(std::sin(seedAngle)); seeded = true; }
                         sumdx += cs_[2 * ((size_t)yy * W_ + xx)];        /* cos(float(angle)), shared routine (device) */
                         sumdy += cs_[2 * ((size_t)yy * W_ + xx) + 1];    /* sin(float(angle)) */
                         regAngle = drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
@@ -384,99 +396,20 @@ private:
     }
 };
 
-const int kPairs[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
-                           {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
-                           {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
-
-/* BinaryDescriptor::computeLBD (one line, octave 0) + binaryConversion */
-static void lbd(const int16_t* gx, const int16_t* gy, int realW, int realH, const drfe_keyline& kl, float* des, uint8_t* out)
+/* the Gaussian weights of BinaryDescriptor::computeLBD: local (3 x 7 rows, sigma 7) and global (63 rows, sigma 31), cast to
+ * float where the reference casts them */
+static const LbdTables& lbdTables()
 {
-    const int NB = 9, WB = 7;
-    static double coefL[21], coefG[63];
-    static bool ready = false;
-    if (!ready) {
+    static LbdTables t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const int NB = 9, WB = 7;
         double u = (WB * 3 - 1) / 2, sigma = (WB * 2 + 1) / 2, inv = -1 / (2 * sigma * sigma);
-        for (int i = 0; i < WB * 3; i++) coefL[i] = std::exp((i - u) * (i - u) * inv);
+        for (int i = 0; i < WB * 3; i++) t.coefL[i] = (float)std::exp((i - u) * (i - u) * inv);
         u = (NB * WB - 1) / 2; sigma = u; inv = -1 / (2 * sigma * sigma);
-        for (int i = 0; i < NB * WB; i++) coefG[i] = std::exp((i - u) * (i - u) * inv);
-        ready = true;
-    }
-    float acc[8][9];
-    std::memset(acc, 0, sizeof(acc));
-    const short maxX = (short)(realW - 1), maxY = (short)(realH - 1);
-    const short len = (short)kl.num_of_pixels, height = (short)(WB * NB);
-    const short halfH = (height - 1) / 2, halfW = (len - 1) / 2;
-    const float midX = (float)(0.5 * (kl.s_point_in_octave_x + kl.e_point_in_octave_x));
-    const float midY = (float)(0.5 * (kl.s_point_in_octave_y + kl.e_point_in_octave_y));
-    const float dL0 = (float)std::cos((double)kl.angle), dL1 = (float)std::sin((double)kl.angle);
-    const float dO0 = -dL1, dO1 = dL0;
-    float x0 = -dL0 * halfW + dL1 * halfH + midX;
-    float y0 = -dL1 * halfW - dL0 * halfH + midY;
-    for (short hID = 0; hID < height; hID++) {
-        float sx = x0, sy = y0, pL = 0, nL = 0, pO = 0, nO = 0;
-        for (short wID = 0; wID < len; wID++) {
-            short t = (short)std::round(sx);
-            const short xc = (t < 0) ? 0 : (t > maxX) ? maxX : t;
-            t = (short)std::round(sy);
-            const short yc = (t < 0) ? 0 : (t > maxY) ? maxY : t;
-            const short dx = gx[yc * realW + xc], dy = gy[yc * realW + xc];
-            const float gDL = dx * dL0 + dy * dL1, gDO = dx * dO0 + dy * dO1;
-            if (gDL > 0) pL += gDL; else nL -= gDL;
-            if (gDO > 0) pO += gDO; else nO -= gDO;
-            sx += dL0;
-            sy += dL1;
-        }
-        x0 -= dL1;
-        y0 += dL0;
-        const float cg = (float)coefG[hID];
-        pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
-        const float row[8] = {pL, nL, pL * pL, nL * nL, pO, nO, pO * pO, nO * nO};
-        short band = (short)(hID / WB);
-        float cl = (float)coefL[hID % WB + WB];
-        for (int q = 0; q < 8; q++) acc[q][band] += ((q & 2) ? cl * cl : cl) * row[q];
-        band--;
-        if (band >= 0) {
-            cl = (float)coefL[hID % WB + 2 * WB];
-            for (int q = 0; q < 8; q++) acc[q][band] += ((q & 2) ? cl * cl : cl) * row[q];
-        }
-        band = band + 2;
-        if (band < NB) {
-            cl = (float)coefL[hID % WB];
-            for (int q = 0; q < 8; q++) acc[q][band] += ((q & 2) ? cl * cl : cl) * row[q];
-        }
-    }
-    const float invN2 = (float)(1.0 / (WB * 2.0)), invN3 = (float)(1.0 / (WB * 3.0));
-    for (short b = 0; b < NB; b++) {
-        const float invN = (b == 0 || b == NB - 1) ? invN2 : invN3;
-        float* d = des + 8 * b;
-        float m = acc[0][b] * invN; d[0] = m; d[4] = std::sqrt(acc[2][b] * invN - m * m);
-        m = acc[1][b] * invN; d[1] = m; d[5] = std::sqrt(acc[3][b] * invN - m * m);
-        m = acc[4][b] * invN; d[2] = m; d[6] = std::sqrt(acc[6][b] * invN - m * m);
-        m = acc[5][b] * invN; d[3] = m; d[7] = std::sqrt(acc[7][b] * invN - m * m);
-    }
-    float tm = 0, ts = 0;
-    for (int b = 0; b < NB; b++) {
-        const float* d = des + 8 * b;
-        tm += d[0] * d[0]; tm += d[1] * d[1]; tm += d[2] * d[2]; tm += d[3] * d[3];
-        ts += d[4] * d[4]; ts += d[5] * d[5]; ts += d[6] * d[6]; ts += d[7] * d[7];
-    }
-    tm = 1 / std::sqrt(tm);
-    ts = 1 / std::sqrt(ts);
-    for (int b = 0; b < NB; b++) {
-        float* d = des + 8 * b;
-        d[0] *= tm; d[1] *= tm; d[2] *= tm; d[3] *= tm; d[4] *= ts; d[5] *= ts; d[6] *= ts; d[7] *= ts;
-    }
-    for (int i = 0; i < 72; i++) if (des[i] > 0.4) des[i] = (float)0.4;
-    float nrm = 0;
-    for (int i = 0; i < 72; i++) nrm += des[i] * des[i];
-    nrm = 1 / std::sqrt(nrm);
-    for (int i = 0; i < 72; i++) des[i] = des[i] * nrm;
-    for (int cb = 0; cb < 32; cb++) {
-        const float *a = des + 8 * kPairs[cb][0], *b = des + 8 * kPairs[cb][1];
-        uint8_t v = 0;
-        for (int i = 0; i < 8; i++) if (a[i] > b[i]) v += (uint8_t)(1 << i);
-        out[cb] = v;
-    }
+        for (int i = 0; i < NB * WB; i++) t.coefG[i] = (float)std::exp((i - u) * (i - u) * inv);
+    });
+    return t;
 }
 
 static LineTaps gaussTaps(int n, double sigma)
@@ -498,7 +431,6 @@ static LineTaps gaussTaps(int n, double sigma)
 struct LineHost {                     /* per-lane host buffers reused across frames */
     std::vector<double> modgrad, angles;
     std::vector<float> cs;
-    std::vector<int16_t> gx, gy;
     std::vector<uint8_t> used;
     std::vector<OPt> order;
 };
@@ -513,7 +445,8 @@ struct LineWorker {
 static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
-    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_maxGrad, s->d_gx, s->d_gy, s->d_cands, s->d_counts};
+    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_maxGrad, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
+                    s->d_lbdLines, s->d_lbdOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete s;
     s = nullptr;
@@ -579,18 +512,15 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
     const auto tStart = std::chrono::steady_clock::now();
     HIPCHK(c, hipMemcpy2DAsync(s->d_img, (size_t)w, gray, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
     HIPCHK(c, drfe_launch_lines_passes(s->d_img, w, h, lsdTaps, lbdTaps, s, rho, st));
-    const size_t ns = (size_t)s->sw * s->sh, n = (size_t)w * h;
+    const size_t ns = (size_t)s->sw * s->sh;
     if (!c->host) c->host = new LineHost();
     LineHost& H = *c->host;
     std::vector<double>&modgrad = H.modgrad, &angles = H.angles;
-    std::vector<int16_t>&gx = H.gx, &gy = H.gy;
-    modgrad.resize(ns); angles.resize(ns); gx.resize(n); gy.resize(n); H.cs.resize(2 * ns);
+    modgrad.resize(ns); angles.resize(ns); H.cs.resize(2 * ns);
     unsigned long long maxBits = 0;
     HIPCHK(c, hipMemcpyAsync(modgrad.data(), s->d_modgrad, ns * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(angles.data(), s->d_angles, ns * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(H.cs.data(), s->d_cs, ns * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(gx.data(), s->d_gx, n * 2, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(gy.data(), s->d_gy, n * 2, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(&maxBits, s->d_maxGrad, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     double maxGrad = -1;
@@ -682,12 +612,33 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
             std::fprintf(stderr, "drfe_lsd_extract: device+copies %.2f ms, LSD host %.2f ms, keylines+LBD host %.2f ms\n", ms(a, b), ms(b, cc), ms(cc, e));
         }
     } traceAtExit{trace, tStart, tDev, tSeg};
-    float des[72];
+    /* LBD descriptors of the kept lines on the device (k_lbd); the direction cosines come from this host's libm, as the
+     * reference's do */
+    if (nl > 0 && ldesc) {
+        if ((size_t)nl > s->lbdCap) {
+            if (s->d_lbdLines) (void)hipFree(s->d_lbdLines);
+            if (s->d_lbdOut) (void)hipFree(s->d_lbdOut);
+            s->d_lbdLines = nullptr; s->d_lbdOut = nullptr;
+            s->lbdCap = std::max<size_t>((size_t)nl, 64);
+            HIPCHK(c, hipMalloc((void**)&s->d_lbdLines, s->lbdCap * sizeof(LbdLine)));
+            HIPCHK(c, hipMalloc((void**)&s->d_lbdOut, s->lbdCap * 32));
+        }
+        std::vector<LbdLine> ll(nl);
+        for (int i = 0; i < nl; i++) {
+            const drfe_keyline& kl = kls[i];
+            ll[i].midX = (float)(0.5 * (kl.s_point_in_octave_x + kl.e_point_in_octave_x));
+            ll[i].midY = (float)(0.5 * (kl.s_point_in_octave_y + kl.e_point_in_octave_y));
+            ll[i].dL0 = (float)std::cos((double)kl.angle);
+            ll[i].dL1 = (float)std::sin((double)kl.angle);
+            ll[i].len = kl.num_of_pixels; ll[i].pad = 0;
+        }
+        HIPCHK(c, hipMemcpyAsync(s->d_lbdLines, ll.data(), nl * sizeof(LbdLine), hipMemcpyHostToDevice, st));
+        HIPCHK(c, drfe_launch_lbd(s->d_lbdLines, nl, s->d_gx, s->d_gy, w, h, lbdTables(), s->d_lbdOut, st));
+        HIPCHK(c, hipMemcpyAsync(ldesc, s->d_lbdOut, (size_t)nl * 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     for (int i = 0; i < nl; i++) {
         if (lines) lines[i] = kls[i];
-        uint8_t bits[32];
-        lbd(gx.data(), gy.data(), w, h, kls[i], des, bits);
-        if (ldesc) std::memcpy(ldesc + (size_t)i * 32, bits, 32);
         if (line_f) {   /* normalised cross product of the homogeneous end points, :32-42 */
             const double sx = kls[i].start_point_x, sy = kls[i].start_point_y, ex = kls[i].end_point_x, ey = kls[i].end_point_y;
             const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;

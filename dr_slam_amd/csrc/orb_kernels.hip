@@ -1033,9 +1033,16 @@ __global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __res
 __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, const BlurTile* __restrict__ tiles,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, uint32_t gxMagic)
 {
-    /* no XCD swizzle here: it halves this kernel's fetch traffic too, but measured 1.4 % slower (the stores of eight
-     * XCDs then crowd into a few frames' worth of addresses) */
+    /* XCD-aware numbering (whole frames per XCD): neighbouring tiles share the 128-byte lines their 136-byte rows straddle and
+     * the halo rows; dealt round-robin over eight private L2s every such line was fetched twice (2 x FETCH_SIZE = 2.4 x the
+     * algorithmic bytes in round 1).  DRFE_BLUR_NOSWIZZLE=1 (compile time) restores the plain numbering: it measured 1.4 %
+     * faster on this VALU-bound kernel, at twice the fabric traffic. */
+#if defined(DRFE_BLUR_NOSWIZZLE)
     const int bx = blockIdx.x, by = blockIdx.y; (void)gxMagic;
+#else
+    int bx, by;
+    drfe_xcd_swizzle_2d(gxMagic, bx, by);
+#endif
     /* horizontal sums of rows 2p and 2p+1 interleaved per pixel: hb2[p][x] = H[2p][x] | H[2p+1][x] << 16, so that the
      * vertical pass multiplies two rows per instruction (v_dot2_u32_u16) */
     __shared__ __attribute__((aligned(16))) uint32_t hb2[(BLUR_ROWS / 2) * DRFE_BLUR_TW];

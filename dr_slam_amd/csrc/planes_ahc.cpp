@@ -225,6 +225,13 @@ static void scratch_free(PlanesScratch*& p)
 void drfe_planes_free(drfe_ctx* c)
 {
     scratch_free(c->ps);
+    if (CapeScratch* cs = static_cast<CapeScratch*>(c->cape)) {
+        void* ptrs[] = {cs->d_depth, cs->d_cells, cs->d_seg, cs->d_tab};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        delete cs;
+        c->cape = nullptr;
+    }
     auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);
     if (pool) {
         for (PlaneLane& l : *pool) {

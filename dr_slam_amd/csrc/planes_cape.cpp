@@ -90,16 +90,26 @@ int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t str
         return DRFE_ERR_INVALID;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    const int nh = w / patch, nv = h / patch, ncell = nh * nv, ppc = patch * patch, npx = w * h;
-    /* device stage */
-    float* d_depth = nullptr;
-    CapeCellRec* d_cells = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_depth, (size_t)npx * sizeof(float)));
-    if (hipMalloc((void**)&d_cells, (size_t)ncell * sizeof(CapeCellRec)) != hipSuccess) {
-        (void)hipFree(d_depth);
-        c->err = "planes_cape: hipMalloc failed";
-        return DRFE_ERR_HIP;
+    const int nh = w / patch, nv = h / patch, ncell = nh * nv, npx = w * h;
+    /* device stage: buffers owned by the context (no allocation per frame) */
+    CapeScratch* cs = static_cast<CapeScratch*>(c->cape);
+    if (!cs) { cs = new (std::nothrow) CapeScratch(); if (!cs) return DRFE_ERR_INVALID; std::memset(cs, 0, sizeof(*cs)); c->cape = cs; }
+    if (cs->depthCap < (size_t)npx) {
+        if (cs->d_depth) (void)hipFree(cs->d_depth);
+        if (cs->d_seg) (void)hipFree(cs->d_seg);
+        cs->d_depth = nullptr; cs->d_seg = nullptr; cs->depthCap = cs->segCap = 0;
+        HIPCHK(c, hipMalloc((void**)&cs->d_depth, (size_t)npx * sizeof(float)));
+        HIPCHK(c, hipMalloc((void**)&cs->d_seg, (size_t)npx));
+        cs->depthCap = cs->segCap = (size_t)npx;
     }
+    if (cs->cellCap < (size_t)ncell) {
+        if (cs->d_cells) (void)hipFree(cs->d_cells);
+        cs->d_cells = nullptr; cs->cellCap = 0;
+        HIPCHK(c, hipMalloc((void**)&cs->d_cells, (size_t)ncell * sizeof(CapeCellRec)));
+        cs->cellCap = (size_t)ncell;
+    }
+    float* d_depth = cs->d_depth;
+    CapeCellRec* d_cells = cs->d_cells;
     const float sinCos = (float)std::sqrt(1 - (double)cos_angle_max * (double)cos_angle_max);
     std::vector<CapeCellRec> cells(ncell);
     hipError_t e = hipMemcpy2DAsync(d_depth, (size_t)w * 4, depth_m, stride * 4, (size_t)w * 4, (size_t)h,
@@ -107,8 +117,6 @@ int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t str
     if (e == hipSuccess) e = drfe_launch_cape_cells(d_depth, (size_t)w, w, h, K4, patch, sinCos, max_merge_dist, d_cells, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(cells.data(), d_cells, (size_t)ncell * sizeof(CapeCellRec), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_depth);
-    (void)hipFree(d_cells);
     if (e != hipSuccess) { c->err = std::string("planes_cape: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     for (int i = 0; i < ncell && cells16; i++) {
         const CapeCellRec& r = cells[i];
@@ -213,12 +221,10 @@ int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t str
         if (expanded) segs[pid].fit();
     }
 
-    /* boundary refinement + label image, CAPE.cpp:247-319, 395-431 */
-    std::vector<uint8_t> mask(ncell), er(ncell), di(ncell), gridEroded(ncell, 0), segStacked(npx, 0);
-    float hugeF;
-    { const uint32_t bits = 0x64646464u; std::memcpy(&hugeF, &bits, 4); }
-    std::vector<float> distStacked(npx, hugeF);
-    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    /* boundary refinement + label image, CAPE.cpp:247-319, 395-431: the cell masks (<= 64 x 48 cells) are erode / dilate work
+     * on the host; the per-pixel assignment runs on the device (k_cape_refine) from the depth image already there */
+    std::vector<uint8_t> mask(ncell), er(ncell), di(ncell), gridEroded(ncell, 0), boundary;
+    std::vector<CapeRefinePlane> rp;
     int nFinal = 0;
     for (int i = 0; i < np; i++) {
         if (i != label[i]) continue;
@@ -255,34 +261,31 @@ int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t str
         }
         nFinal++;
         const uint8_t nr = (uint8_t)nFinal;
-        const float nx = (float)segs[i].normal[0], ny = (float)segs[i].normal[1], nz = (float)segs[i].normal[2];
-        const float dd = (float)segs[i].d;
-        const float maxDist = 9 * segs[i].MSE;
+        rp.push_back(CapeRefinePlane{(float)segs[i].normal[0], (float)segs[i].normal[1], (float)segs[i].normal[2], (float)segs[i].d,
+                                     9 * segs[i].MSE});
+        boundary.resize((size_t)nFinal * ncell);
+        uint8_t* bnd = boundary.data() + (size_t)(nFinal - 1) * ncell;
         for (int cell = 0; cell < ncell; cell++) {
             if (er[cell] > 0) gridEroded[cell] = nr;
-            if ((int)di[cell] - (int)er[cell] <= 0) continue;
-            const int r0 = (cell / nh) * patch, c0 = (cell % nh) * patch;
-            for (int lr = 0; lr < patch; lr++)
-                for (int lc = 0; lc < patch; lc++) {
-                    const int pr = r0 + lr, pc = c0 + lc, pt = cell * ppc + lr * patch + lc;
-                    const double z = (double)depth_m[(size_t)pr * stride + pc];
-                    const float X = (float)(((double)pc - cx) * z / fx), Y = (float)(((double)pr - cy) * z / fy), Z = (float)z;
-                    const float dv = X * nx + Y * ny + Z * nz + dd;
-                    const float dist = (float)((double)dv * (double)dv);
-                    if (dist < maxDist && dist < distStacked[pt]) { distStacked[pt] = dist; segStacked[pt] = nr; }
-                }
+            bnd[cell] = ((int)di[cell] - (int)er[cell] > 0) ? 1 : 0;
         }
     }
     *n_planes = nFinal;
-    std::memset(seg, 0, (size_t)npx);
-    for (int cell = 0; cell < ncell; cell++) {
-        const int r0 = (cell / nh) * patch, c0 = (cell % nh) * patch;
-        for (int lr = 0; lr < patch; lr++)
-            for (int lc = 0; lc < patch; lc++) {
-                const uint8_t v = gridEroded[cell] > 0 ? gridEroded[cell] : segStacked[cell * ppc + lr * patch + lc];
-                if (v > 0) seg[(size_t)(r0 + lr) * w + c0 + lc] = v;
-            }
+    const size_t tabBytes = ((rp.size() * sizeof(CapeRefinePlane) + 15) & ~(size_t)15) + (size_t)ncell + boundary.size() + 16;
+    if (cs->tabCap < tabBytes) {
+        if (cs->d_tab) (void)hipFree(cs->d_tab);
+        cs->d_tab = nullptr; cs->tabCap = 0;
+        HIPCHK(c, hipMalloc((void**)&cs->d_tab, tabBytes * 2));
+        cs->tabCap = tabBytes * 2;
     }
+    const size_t offGrid = (rp.size() * sizeof(CapeRefinePlane) + 15) & ~(size_t)15, offBnd = offGrid + (size_t)ncell;
+    if (!rp.empty()) HIPCHK(c, hipMemcpyAsync(cs->d_tab, rp.data(), rp.size() * sizeof(CapeRefinePlane), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cs->d_tab + offGrid, gridEroded.data(), (size_t)ncell, hipMemcpyHostToDevice, c->stream));
+    if (!boundary.empty()) HIPCHK(c, hipMemcpyAsync(cs->d_tab + offBnd, boundary.data(), boundary.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, drfe_launch_cape_refine(cs->d_depth, (size_t)w, w, h, K4, patch, reinterpret_cast<const CapeRefinePlane*>(cs->d_tab), nFinal,
+                                      cs->d_tab + offGrid, cs->d_tab + offBnd, cs->d_seg, c->stream));
+    HIPCHK(c, hipMemcpyAsync(seg, cs->d_seg, (size_t)npx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return DRFE_OK;
 }
 

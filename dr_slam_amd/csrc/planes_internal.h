@@ -25,6 +25,24 @@ struct PlanesScratch {
     uint16_t* d_depth; size_t depthCap;        /* staging for the host-buffer API */
 };
 
+/* device scratch of drfe_planes_cape, kept by the context between frames (grow-only) */
+struct CapeScratch {
+    float* d_depth; size_t depthCap;           /* w*h metres */
+    CapeCellRec* d_cells; size_t cellCap;
+    uint8_t* d_seg; size_t segCap;             /* w*h labels */
+    uint8_t* d_tab; size_t tabCap;             /* CapeRefinePlane[n] | gridEroded[ncell] | boundary[n][ncell] */
+};
+
+/* one final plane of the boundary refinement (src/CAPE/CAPE.cpp:294-319): float copies of normal and d, 9 * MSE */
+struct CapeRefinePlane { float nx, ny, nz, d, maxDist; };
+
+/* seg_output of CAPE: cells of a plane's eroded mask take its number; every pixel of a boundary cell (dilated minus eroded
+ * mask of plane p) goes to the plane with the least squared distance below 9 * MSE, planes in extraction order, strict <
+ * (first plane wins ties).  One thread per pixel. */
+hipError_t drfe_launch_cape_refine(const float* d_depth, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                   const CapeRefinePlane* d_planes, int nplanes, const uint8_t* d_gridEroded,
+                                   const uint8_t* d_boundary, uint8_t* d_seg, hipStream_t s);
+
 hipError_t drfe_launch_ahc_blocks(const uint16_t* d_depth, size_t frameStride, size_t rowStride, int w, int h,
                                   const float K4[4], float depthFactor, int nframes, AhcBlockRec* d_out, hipStream_t s);
 void drfe_planes_free(drfe_ctx* c);

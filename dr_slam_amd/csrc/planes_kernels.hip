@@ -192,6 +192,46 @@ hipError_t drfe_launch_cape_cells(const float* d_depth, size_t rowStride, int w,
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_cape_refine(const float* __restrict__ depth, size_t rowStride, int w, int h, float fx,
+                                                     float fy, float cx, float cy, int patch, const CapeRefinePlane* __restrict__ planes,
+                                                     int nplanes, const uint8_t* __restrict__ gridEroded,
+                                                     const uint8_t* __restrict__ boundary, uint8_t* __restrict__ seg)
+{
+    const int pc = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
+    if (pc >= w) return;
+    const int nh = w / patch, ncell = nh * (h / patch);
+    const int cell = (pr / patch) * nh + pc / patch;
+    uint8_t v = gridEroded[cell];
+    if (v == 0) {
+        /* distances_stacked starts as memset(.., 100, ..): every float is 0x64646464 */
+        float best = __uint_as_float(0x64646464u);
+        float X = 0.f, Y = 0.f, Z = 0.f;
+        bool have = false;
+        for (int p = 0; p < nplanes; p++) {
+            if (!boundary[(size_t)p * ncell + cell]) continue;
+            if (!have) {
+                const double z = (double)depth[(size_t)pr * rowStride + pc];
+                X = (float)(((double)pc - cx) * z / fx); Y = (float)(((double)pr - cy) * z / fy); Z = (float)z;
+                have = true;
+            }
+            const CapeRefinePlane P = planes[p];
+            const float dv = X * P.nx + Y * P.ny + Z * P.nz + P.d;
+            const float dist = (float)((double)dv * (double)dv);
+            if (dist < P.maxDist && dist < best) { best = dist; v = (uint8_t)(p + 1); }
+        }
+    }
+    seg[(size_t)pr * w + pc] = v;
+}
+
+hipError_t drfe_launch_cape_refine(const float* d_depth, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                   const CapeRefinePlane* d_planes, int nplanes, const uint8_t* d_gridEroded,
+                                   const uint8_t* d_boundary, uint8_t* d_seg, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cape_refine, dim3((w + 255) / 256, h), dim3(256), 0, s, d_depth, rowStride, w, h, K4[0], K4[1], K4[2],
+                       K4[3], patch, d_planes, nplanes, d_gridEroded, d_boundary, d_seg);
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_ahc_blocks(const uint16_t* d_depth, size_t frameStride, size_t rowStride, int w, int h,
                                   const float K4[4], float depthFactor, int nframes, AhcBlockRec* d_out, hipStream_t s)
 {

@@ -135,3 +135,19 @@ def test_cape_planes_postprocess(oracle_mod):
             _same_post(g, o, 1 if th == 0.6 else 0)
     finally:
         c.close()
+
+
+def test_golden_post_normals_on_device():
+    """The committed fixture (tests/golden/post_room_320x240.npz) through the device path, without the oracle."""
+    import os
+    from dr_slam_amd import lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post_room_320x240.npz"))
+    dm = (g["depth"].astype(np.float32) * (np.float32(1.0) / g["depth_factor"])).astype(np.float32)
+    c = lib.Context(max_width=320, max_height=240)
+    try:
+        rec, cloud, nrm, _ = c.surface_normals(dm, g["K4"], float(g["max_point_dist"]), taps=True)
+    finally:
+        c.close()
+    nan = np.isnan(g["normals"])
+    assert np.array_equal(np.isnan(nrm), nan) and np.array_equal(_bits(nrm)[~nan], _bits(g["normals"])[~nan])
+    assert len(rec) == (nrm.shape[0] // 2) * (nrm.shape[1] // 2)

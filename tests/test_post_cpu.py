@@ -110,3 +110,24 @@ def test_surface_normals_on_a_tilted_plane(oracle_mod):
     assert (cloud2[z[::3, ::3] > 2.5] == 0).all()
     recs = oracle_mod.post_surface_normal_records(cloud, nrm)
     assert len(recs[0]) == 80 * 107 and recs[2][0] == 3 and recs[3][0] == 3
+
+
+GOLD_POST = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "post_room_320x240.npz")
+
+
+def test_golden_post(oracle_mod):
+    """Committed fixture of the post-processing path (tests/golden/make_golden_post.py): oracle and the product's host entry
+    points reproduce it bit for bit."""
+    import zlib
+    from dr_slam_amd import lib
+    g = np.load(GOLD_POST)
+    dm = oracle_mod.depth_to_float(g["depth"], np.float32(1.0) / g["depth_factor"])
+    cloud, nrm = oracle_mod.post_surface_normals(dm, g["K4"], float(g["max_point_dist"]))
+    assert zlib.crc32(cloud.tobytes()) == int(g["cloud_crc"])
+    nan = np.isnan(g["normals"])
+    assert np.array_equal(np.isnan(nrm), nan) and np.array_equal(nrm.view(np.uint32)[~nan], g["normals"].view(np.uint32)[~nan])
+    for vg in (oracle_mod.post_voxel_grid, lib.plane_voxel_grid):
+        assert np.array_equal(vg(g["plane_points"], 0.05).view(np.uint32), g["voxels"].view(np.uint32))
+    for rf in (oracle_mod.post_refit, lib.plane_refit):
+        ok, coef = rf(g["coef0"], g["voxels"], float(g["refit_threshold"]))
+        assert ok == bool(g["refit_valid"]) and np.array_equal(coef.view(np.uint32), g["refit_coef"].view(np.uint32))
