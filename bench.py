@@ -341,6 +341,9 @@ def main():
                          "per rank; 0 = config 2 at one rank, config 4 at N > 1")
     ap.add_argument("--distinct", type=int, default=0,
                     help="frames rendered per rank (0 = the config's sequence length: 64 / 256)")
+    ap.add_argument("--render-workers", type=int, default=0,
+                    help="processes that render the synthetic sequence (0 = the CPUs this rank may use; forced to 1 under a "
+                         "profiler, whose preloaded runtime must not be forked)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-fed rate and the config-3 full front-end block")
     ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
@@ -361,7 +364,10 @@ def main():
     seed, cam, kind, seq_len = sharding.rank_workload(config, rank)
     n_distinct = args.distinct or seq_len
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    base = sharding.render_sequence(seed, n_distinct, cam, kind, workers=max(1, sharding.host_cpus() // local_world))
+    profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) \
+        or any(k.startswith("ROCPROF") for k in os.environ)
+    workers = 1 if profiled else (args.render_workers or max(1, sharding.host_cpus() // local_world))
+    base = sharding.render_sequence(seed, n_distinct, cam, kind, workers=workers)
 
     import torch
     import torch.distributed as dist
