@@ -11,6 +11,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
+#include <cstdio>
+#include <thread>
 #include <new>
 
 static std::string g_create_err;
@@ -66,6 +69,28 @@ static int upload_geometry(drfe_ctx* c, int w, int h)
     c->lastBatch = 0;
     c->glueValid = false;
     return DRFE_OK;
+}
+
+int drfe_default_host_threads()
+{
+    int n = 0;
+#if defined(__linux__)
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = std::atoll(q);
+            const int lim = (int)std::max<long long>(1, quota / period);
+            if (n <= 0 || lim < n) n = lim;
+        }
+        std::fclose(f);
+    }
+#endif
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    return std::max(1, n);
 }
 
 extern "C" {

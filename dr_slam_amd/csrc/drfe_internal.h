@@ -162,6 +162,10 @@ struct drfe_ctx {
 /* what the matchers and the grid read: mvKeysUn (== mvKeys without distortion) */
 static inline drfe_keypoint* drfe_kps_un(const drfe_ctx* c) { return c->dist.enabled ? c->d_kpsUn : c->d_kps; }
 
+/* capi.cpp: host threads a batch entry point may start by default - the affinity mask clipped by the cgroup CPU quota
+ * (std::thread::hardware_concurrency() reports the machine, which oversubscribes a quota-limited container) */
+int drfe_default_host_threads();
+
 /* orb_geometry.cpp */
 int drfe_build_tables(drfe_ctx* c);                       /* scale tables, quotas, umax */
 int drfe_build_geometry(drfe_ctx* c, int w, int h, DevGeom* g, std::vector<FastCell>* cells,

@@ -685,7 +685,7 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
         return DRFE_ERR_INVALID;
     }
     if (nframes == 0) return DRFE_OK;
-    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int T = n_threads > 0 ? n_threads : drfe_default_host_threads();
     T = std::max(1, std::min(T, nframes));
     HIPCHK(c, hipSetDevice(c->device));
     auto* pool = static_cast<std::vector<LineWorker>*>(c->lineWorkers);

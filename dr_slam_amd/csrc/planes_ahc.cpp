@@ -552,7 +552,7 @@ int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_strid
         return DRFE_ERR_INVALID;
     }
     if (nframes == 0) return DRFE_OK;
-    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int T = n_threads > 0 ? n_threads : drfe_default_host_threads();
     T = std::max(1, std::min(T, nframes));
     HIPCHK(c, hipSetDevice(c->device));
     auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);

@@ -143,7 +143,7 @@ def test_golden_post_normals_on_device():
     from dr_slam_amd import lib
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post_room_320x240.npz"))
     dm = (g["depth"].astype(np.float32) * (np.float32(1.0) / g["depth_factor"])).astype(np.float32)
-    c = lib.Context(max_width=320, max_height=240)
+    c = lib.Context()
     try:
         rec, cloud, nrm, _ = c.surface_normals(dm, g["K4"], float(g["max_point_dist"]), taps=True)
     finally:

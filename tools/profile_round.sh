@@ -10,12 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 CMD="python3 $R/bench.py --steps 5 --warmup 2 --batch $B --distinct 8 --render-workers 1 --no-cpu-baseline --no-extras"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o ${TAG}_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
             "sq1 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
             "sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
     set -- $pass
     name=$1; shift
-    timeout 300 rocprofv3 --pmc "$@" -d $OUT/${TAG}_pmc_$name -o ${TAG}_pmc_$name -- $CMD > $OUT/${TAG}_pmc_$name.log 2>&1
+    timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $CMD > $OUT/${TAG}_pmc_$name.log 2>&1
 done
 find $OUT -name "${TAG}_*" -name "*.csv" | head -20
