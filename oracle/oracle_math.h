@@ -15,17 +15,14 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <emmintrin.h>
 
 namespace orc {
 
-inline int round_he_d(double v)
-{
-    const double f = std::floor(v), d = v - f;
-    long long r = (long long)f;
-    if (d > 0.5 || (d == 0.5 && (r & 1))) r++;
-    return (int)r;
-}
-inline int round_he(float v) { return round_he_d((double)v); }   /* float -> double is exact; ties are preserved */
+/* cvRound as OpenCV 3.4 defines it on x86-64 (core/include/opencv2/core/fast_math.hpp): the SSE conversion instruction,
+ * round-half-to-even under the default MXCSR mode */
+inline int round_he_d(double v) { return _mm_cvtsd_si32(_mm_set_sd(v)); }
+inline int round_he(float v) { return _mm_cvtss_si32(_mm_set_ss(v)); }
 
 inline float fast_atan2_deg(float y, float x)
 {
