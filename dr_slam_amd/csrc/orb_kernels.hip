@@ -237,9 +237,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int v = (int)(__umulhi(Ha[k], b0s) + __umulhi(Hb[k], b1s) + 2u) >> 2;
-            v = min(255, max(0, v));
-            out |= (uint32_t)v << (8 * k);
+            /* no saturation needed: H <= (255 * 2049) >> 4 = 32655 and b0 + b1 <= 2049 (two independently rounded 11-bit
+             * weights), so the two floored products sum to at most 1020 and (1020 + 2) >> 2 = 255 */
+            const uint32_t v = (__umulhi(Ha[k], b0s) + __umulhi(Hb[k], b1s) + 2u) >> 2;
+            out |= v << (8 * k);
         }
         if (active) *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)(y0 + r) * L.pyrPitch + x4) = out;
         prevB = b;
