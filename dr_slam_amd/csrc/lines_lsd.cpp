@@ -718,6 +718,33 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
     return DRFE_OK;
 }
 
+/* The sequential half of LSD on caller-supplied gradient fields, rectangle counting on the host as well: the host logic of
+ * drfe_lsd_extract without a device (CPU tests and profiling of the ordering / region growing / fitting code).  modgrad,
+ * angles: W x H doubles; cs: (cos, sin) of float(angle) per pixel; segs: up to cap x 4 floats (x1, y1, x2, y2 at input scale). */
+int drfe_lsd_segments_host(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad, float* segs,
+                           int cap, int* n_segs)
+{
+    if (!modgrad || !angles || !cs || !n_segs || W < 4 || H < 4) return DRFE_ERR_INVALID;
+    std::vector<uint8_t> used;
+    std::vector<OPt> order;
+    SegmentFinder finder(W, H, modgrad, angles, cs, max_grad, used, order);
+    std::vector<float> out;
+    auto counts = [&](const std::vector<RectCand>& cands, std::vector<int2>& res) -> bool {
+        res.resize(cands.size());
+        for (size_t k = 0; k < cands.size(); k++) finder.countHost(cands[k], res[k].x, res[k].y);
+        return true;
+    };
+    finder.timed_ = std::getenv("DRFE_TRACE_LINES") != nullptr;
+    finder.run(out, counts);
+    if (finder.timed_)
+        std::fprintf(stderr, "drfe_lsd_segments_host: grow %.2f ms (%ld regions); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
+                     finder.tGrow_, finder.nGrow_, finder.tRefine_, finder.nRect_, finder.tImprove_);
+    *n_segs = (int)(out.size() / 4);
+    if (*n_segs > cap) return DRFE_ERR_CAPACITY;
+    if (segs && !out.empty()) std::memcpy(segs, out.data(), out.size() * sizeof(float));
+    return DRFE_OK;
+}
+
 /* parity taps of the device passes (tests) */
 int drfe_lsd_stages(drfe_ctx* c, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy, int* sw, int* sh)
 {

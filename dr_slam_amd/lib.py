@@ -36,7 +36,7 @@ SYMBOLS = (
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
-    "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition",
+    "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -169,6 +169,7 @@ def load() -> C.CDLL:
     L.drfe_surface_normals.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
     L.drfe_surface_normals_batch.argtypes = [vp, vp, sz, sz, i32, i32, vp, f32, f32, i32, vp]
     L.drfe_surface_normals_download.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.drfe_lsd_segments_host.argtypes = [vp, vp, vp, i32, i32, f64, vp, i32, C.POINTER(i32)]
     L.drfe_profile_enable.argtypes = [vp, i32]
     L.drfe_profile_stage_ms.argtypes = [vp, vp]
     L.drfe_stream_sync.argtypes = [vp]
@@ -178,6 +179,21 @@ def load() -> C.CDLL:
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def lsd_segments_host(modgrad, angles, cs, max_grad):
+    """The sequential half of LSD on given level-line fields (host code, no device): [n, 4] float32 segments."""
+    L = load()
+    m = np.ascontiguousarray(modgrad, np.float64)
+    a = np.ascontiguousarray(angles, np.float64)
+    c = np.ascontiguousarray(cs, np.float32)
+    H, W = m.shape
+    out = np.zeros((20000, 4), np.float32)
+    n = C.c_int()
+    rc = L.drfe_lsd_segments_host(_p(m), _p(a), _p(c), W, H, float(max_grad), _p(out), len(out), C.byref(n))
+    if rc != 0:
+        raise DrfeError(f"drfe_lsd_segments_host failed ({rc})")
+    return out[:n.value].copy()
 
 
 def plane_voxel_grid(xyz, leaf=0.05):

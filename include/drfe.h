@@ -232,6 +232,13 @@ typedef struct drfe_keyline {
  * bytes, line_f = NL x 3 normalised line equations; *n_detected = lines found before the cut. */
 int drfe_lsd_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t stride, int max_lines,
                      drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected);
+/* The sequential half of cv::LineSegmentDetector (pixel ordering, region growing, rectangle fit + refinement, NFA validation)
+ * on caller-supplied level-line fields, without a device: what drfe_lsd_extract runs on the host between its device passes,
+ * with the rectangle pixel counts taken on the host too.  modgrad / angles: W x H doubles of the 0.8-scaled image (angle
+ * -1024 = undefined); cs: W x H x 2 floats, (cos, sin) of float(angle); max_grad: the largest modgrad.  segs: up to cap x 4
+ * floats (x1, y1, x2, y2 in input-image coordinates).  Host code: CPU tests and profiling. */
+int drfe_lsd_segments_host(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad, float* segs,
+                           int cap, int* n_segs);
 /* The same for nframes host images (gray + f * frame_stride): the sequential host stages of LSD (~25 ms per 640x480
  * frame) are independent between frames and run on a pool of n_threads host threads, one device lane (scratch +
  * stream) each — frames instead of the reference's four extractors across threads (src/Frame.cc:116-126).  Outputs per

@@ -253,3 +253,29 @@ def test_native_callers_build_and_link():
         assert "libdrfe.so" in out and "not found" not in out.split("libdrfe.so")[1].split("\n")[0], out
     # without arguments both print nothing and exit 2 before touching the device
     assert subprocess.run([os.path.join(nat, "c_caller")]).returncode == 2
+
+
+def test_lsd_host_stages_without_a_device(oracle_mod):
+    """The sequential half of the product's LSD (pixel ordering, region growing, rectangle fit, deferred level-synchronous
+    rect_improve with host pixel counts, NFA) on the oracle's level-line fields: same segments as the oracle's own
+    sequential implementation.  No device involved (drfe_lsd_segments_host)."""
+    from dr_slam_amd import lib, synth
+    for seed, kind in ((2, "room_boxes"), (5, "corridor")):
+        g, _, _ = next(synth.sequence(seed, 1, kind=kind))
+        o = oracle_mod.extract_lines(g, max_lines=100000, stages=True)
+        ang = o["angles"]
+        cs = np.zeros(ang.shape + (2,), np.float32)
+        defined = ang != -1024.0
+        a32 = ang.astype(np.float32)
+        # canonical cos/sin of float(angle): the exactly rounded value (oracle_math.h / drfe_math.h agree on it)
+        cs[..., 0] = np.where(defined, np.cos(a32.astype(np.float64)).astype(np.float32), 0)
+        cs[..., 1] = np.where(defined, np.sin(a32.astype(np.float64)).astype(np.float32), 0)
+        segs = lib.lsd_segments_host(o["modgrad"], ang, cs, float(o["modgrad"].max()))
+        assert len(segs) == o["detected"] > 40
+        h, w = g.shape
+        e = segs.copy()
+        e[:, 0] = np.clip(e[:, 0], 0, np.float32(w) - np.float32(1)); e[:, 2] = np.clip(e[:, 2], 0, np.float32(w) - np.float32(1))
+        e[:, 1] = np.clip(e[:, 1], 0, np.float32(h) - np.float32(1)); e[:, 3] = np.clip(e[:, 3], 0, np.float32(h) - np.float32(1))
+        L = o["lines"]
+        ref = np.stack([L["startPointX"], L["startPointY"], L["endPointX"], L["endPointY"]], 1)
+        assert np.array_equal(e.view(np.uint32), ref.view(np.uint32))
