@@ -109,6 +109,7 @@ void drfe_destroy(drfe_ctx* c)
     drfe_bow_free(c);
     drfe_lines_free(c);
     drfe_post_free(c);
+    drfe_one_shot_free(c);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
                     c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_kpsUn, c->d_desc,
                     c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc, c->d_match,
@@ -374,6 +375,84 @@ int drfe_batch_download_async(drfe_ctx* c, int nframes, drfe_keypoint* kps, uint
     return DRFE_OK;
 }
 
+} /* extern "C" */
+
+/* The single-frame entry as ONE graph launch: pinned input -> H2D -> the 20-odd kernels of drfe_launch_orb -> status, count,
+ * keypoints and descriptors D2H into pinned memory.  Tracking calls this once per frame; at one frame the kernels are
+ * launch-latency bound, so replaying a captured hipGraph replaces ~25 enqueues, four blocking copies and two
+ * synchronisations by one launch and one synchronisation.  Captured per (w, h); DRFE_NO_GRAPH=1 keeps the plain path. */
+struct OrbOneShot {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int w = 0, h = 0;
+    uint8_t* h_in = nullptr;      /* pinned, w * h */
+    uint8_t* h_out = nullptr;     /* pinned: int status | int count | kps[maxKp] | desc[maxKp][32] */
+    size_t inBytes = 0;
+    bool disabled = false;
+};
+
+static void one_shot_release(OrbOneShot* o)
+{
+    if (o->exec) (void)hipGraphExecDestroy(o->exec);
+    if (o->graph) (void)hipGraphDestroy(o->graph);
+    o->exec = nullptr; o->graph = nullptr; o->w = o->h = 0;
+}
+
+void drfe_one_shot_free(drfe_ctx* c)
+{
+    if (!c->oneShot) return;
+    one_shot_release(c->oneShot);
+    if (c->oneShot->h_in) (void)hipHostFree(c->oneShot->h_in);
+    if (c->oneShot->h_out) (void)hipHostFree(c->oneShot->h_out);
+    delete c->oneShot;
+    c->oneShot = nullptr;
+}
+
+static int one_shot_prepare(drfe_ctx* c, int w, int h)
+{
+    if (!c->oneShot) {
+        c->oneShot = new (std::nothrow) OrbOneShot();
+        if (!c->oneShot) return DRFE_ERR_INVALID;
+        const char* e = std::getenv("DRFE_NO_GRAPH");
+        c->oneShot->disabled = e && e[0] == '1';
+    }
+    OrbOneShot* o = c->oneShot;
+    if (o->disabled) return DRFE_OK;
+    if (o->exec && o->w == w && o->h == h) return DRFE_OK;
+    one_shot_release(o);
+    int rc = upload_geometry(c, w, h);        /* table uploads are not capturable: before the capture */
+    if (rc != DRFE_OK) return rc;
+    const size_t K = (size_t)c->maxKp, outBytes = 8 + K * sizeof(drfe_keypoint) + K * 32;
+    if (o->inBytes < (size_t)w * h) {
+        if (o->h_in) (void)hipHostFree(o->h_in);
+        o->h_in = nullptr;
+        HIPCHK(c, hipHostMalloc((void**)&o->h_in, (size_t)w * h, hipHostMallocDefault));
+        o->inBytes = (size_t)w * h;
+    }
+    if (!o->h_out) HIPCHK(c, hipHostMalloc((void**)&o->h_out, outBytes, hipHostMallocDefault));
+    hipStream_t s = c->stream;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { o->disabled = true; (void)hipGetLastError(); return DRFE_OK; }
+    hipError_t e = hipMemcpyAsync(c->d_stage, o->h_in, (size_t)w * h, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = drfe_launch_orb(c, c->d_stage, (size_t)w * h, (size_t)w, 1, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out, c->d_status, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out + 4, c->d_kpCount, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out + 8, c->d_kps, K * sizeof(drfe_keypoint), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out + 8 + K * sizeof(drfe_keypoint), c->d_desc, K * 32, hipMemcpyDeviceToHost, s);
+    hipGraph_t g = nullptr;
+    const hipError_t ee = hipStreamEndCapture(s, &g);
+    if (e != hipSuccess || ee != hipSuccess || !g || hipGraphInstantiate(&o->exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        o->exec = nullptr;
+        o->disabled = true;                   /* graphs unavailable: the plain path stays correct */
+        (void)hipGetLastError();
+        return DRFE_OK;
+    }
+    o->graph = g; o->w = w; o->h = h;
+    return DRFE_OK;
+}
+
+extern "C" {
+
 int drfe_orb_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stride, drfe_keypoint* kps, uint8_t* desc,
                      int cap, int* n_out)
 {
@@ -385,6 +464,28 @@ int drfe_orb_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
         return DRFE_ERR_INVALID;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->profile) {
+        const int rcp = one_shot_prepare(c, w, h);
+        if (rcp != DRFE_OK) return rcp;
+    }
+    OrbOneShot* o = c->oneShot;
+    if (o && o->exec && !o->disabled && !c->profile && o->w == w && o->h == h) {
+        for (int y = 0; y < h; y++) std::memcpy(o->h_in + (size_t)y * w, gray + (size_t)y * stride, (size_t)w);
+        HIPCHK(c, hipGraphLaunch(o->exec, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->lastBatch = 1;
+        c->glueValid = false;
+        int st = 0, n = 0;
+        std::memcpy(&st, o->h_out, 4);
+        std::memcpy(&n, o->h_out + 4, 4);
+        if (st & 1) { c->err = "FAST candidate arena overflow"; return DRFE_ERR_CAPACITY; }
+        if (st & 2) { c->err = "quadtree node pool overflow"; return DRFE_ERR_CAPACITY; }
+        *n_out = n;
+        if (n > cap) { c->err = "keypoint buffer too small"; return DRFE_ERR_CAPACITY; }
+        if (n > 0 && kps) std::memcpy(kps, o->h_out + 8, sizeof(drfe_keypoint) * (size_t)n);
+        if (n > 0 && desc) std::memcpy(desc, o->h_out + 8 + (size_t)c->maxKp * sizeof(drfe_keypoint), (size_t)n * 32);
+        return DRFE_OK;
+    }
     HIPCHK(c, hipMemcpy2DAsync(c->d_stage, (size_t)w, gray, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice,
                                c->stream));
     int rc = drfe_orb_extract_batch(c, c->d_stage, (size_t)w * h, (size_t)w, w, h, 1, c->stream);

@@ -149,6 +149,7 @@ struct drfe_ctx {
     struct BowState* bow;     /* vocabulary + BoW scratch (bow_internal.h), set by drfe_voc_upload */
     struct LinesScratch* ls;  /* line-path scratch (lines_internal.h) */
     void* lineHost;           /* LineHost*: host buffers of the single-frame line entry */
+    struct OrbOneShot* oneShot; /* captured hipGraph of the single-frame ORB entry (capi.cpp) */
     void* cape;               /* CapeScratch*: device buffers of drfe_planes_cape (planes_internal.h) */
     void* sn;                 /* SnBuffers*: surface-normal scratch (post_internal.h) */
     void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */
@@ -165,6 +166,7 @@ static inline drfe_keypoint* drfe_kps_un(const drfe_ctx* c) { return c->dist.ena
 /* capi.cpp: host threads a batch entry point may start by default - the affinity mask clipped by the cgroup CPU quota
  * (std::thread::hardware_concurrency() reports the machine, which oversubscribes a quota-limited container) */
 int drfe_default_host_threads();
+void drfe_one_shot_free(drfe_ctx* c);                    /* capi.cpp: the captured single-frame ORB graph */
 
 /* orb_geometry.cpp */
 int drfe_build_tables(drfe_ctx* c);                       /* scale tables, quotas, umax */

@@ -1375,15 +1375,23 @@ static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
     if (c->profile) (void)hipEventRecord(c->ev[stage][1], s);
 }
 
+__global__ void k_clear_counts(int* __restrict__ candCount, int n, int* __restrict__ status)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) candCount[i] = 0;
+    if (i == 0) status[0] = 0;
+}
+
 hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStride, size_t rowStride, int nframes,
                            hipStream_t s)
 {
     const DevGeom& g = c->geom;
     const int nl = g.nlevels;
     hipError_t e;
-    e = hipMemsetAsync(c->d_candCount, 0, sizeof(int) * (size_t)nframes * nl, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(c->d_status, 0, sizeof(int), s);
+    /* a kernel, not two hipMemsetAsync: memset nodes of a captured graph (the single-frame entry replays one) did not run
+     * on this ROCm, and one launch is cheaper than two anyway */
+    hipLaunchKernelGGL(k_clear_counts, dim3((nframes * nl + 255) / 256), dim3(256), 0, s, c->d_candCount, nframes * nl, c->d_status);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
 
     prof_begin(c, DRFE_STAGE_PYRAMID, s);
