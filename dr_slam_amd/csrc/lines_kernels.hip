@@ -158,12 +158,13 @@ __global__ __launch_bounds__(64) void k_rect_counts(const RectCand* __restrict__
     if (!isfinite(sr)) sr = 0;
     double lstep = fl, rstep = fr, lx = loX, rx = loX;
     int total = 0, alg = 0;
-    for (int y = (int)loY; y <= (int)hiY; ++y) {
-        if (y < 0 || y >= H) continue;
-        const int xs = (int)lx, xe = (int)rx;
+    /* rows outside the image change nothing in rect_nfa (its `continue` comes before the edge steps) and pixels outside are
+     * not counted: both loops are clamped to the image, which also bounds the work of a degenerate rectangle */
+    const int yBeg = max((int)loY, 0), yEnd = min((int)hiY, H - 1);
+    for (int y = yBeg; y <= yEnd; ++y) {
+        const int xs = max((int)lx, 0), xe = min((int)rx, W - 1);
         const double* row = ang + (size_t)y * W;
         for (int x = xs + lane; x <= xe; x += 64) {
-            if (x < 0 || x >= W) continue;
             ++total;
             const double a = row[x];
             if (a != kNotDef) {

@@ -151,3 +151,31 @@ def test_golden_post_normals_on_device():
     nan = np.isnan(g["normals"])
     assert np.array_equal(np.isnan(nrm), nan) and np.array_equal(_bits(nrm)[~nan], _bits(g["normals"])[~nan])
     assert len(rec) == (nrm.shape[0] // 2) * (nrm.shape[1] // 2)
+
+
+def test_post_edge_cases(oracle_mod):
+    """Empty and degenerate inputs: a depth image of zeros (every normal undefined), depth beyond Point.MaxDistance only, an
+    image too small for the 10-point border, no planes at all."""
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = synth.TUM3
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    c = lib.Context()
+    try:
+        for dm in (np.zeros((cam.h, cam.w), np.float32), np.full((cam.h, cam.w), 12.0, np.float32)):
+            rec = c.surface_normals(dm, K4, 9.0)
+            ocl, onr = O.post_surface_normals(dm, K4, 9.0)
+            assert np.isnan(onr).all() and np.isnan(rec["normal"]).all() and len(rec) == 80 * 107
+            assert np.array_equal(_bits(rec["camera_position"]), _bits(O.post_surface_normal_records(ocl, onr)[1]))
+        small = np.full((48, 60), 2.0, np.float32)               # 16 x 20 cloud: nothing inside the 10-point border
+        rec = c.surface_normals(small, K4, 9.0)
+        assert len(rec) == 8 * 10 and np.isnan(rec["normal"]).all()
+        with pytest.raises(lib.DrfeError):
+            c.surface_normals(np.zeros((2, 2), np.float32), K4, 9.0)
+        d = np.zeros((cam.h, cam.w), np.uint16)                   # no depth: AHC finds nothing, the post-processing loop is empty
+        ga = c.planes_ahc(d, K4, 1.0 / 5000.0)
+        assert len(ga["planes"]) == 0
+        g = c.planes_ahc_postprocess(d, K4, 1.0 / 5000.0, ga, 9.0, 0.05)
+        assert g["n_accepted"] == 0 and g["plane_num"] == 0 and len(g["post"]) == 0
+    finally:
+        c.close()
