@@ -217,6 +217,66 @@ def host_fed_rate(fe, gray, depth, Tcw, Twc, B, steps, dev):
     return B * steps / el, el / steps * 1e3
 
 
+def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev):
+    """Host-fed with HALF the bytes: only the gray frames cross the link (157 MB per 512 frames); the depth images stay on the
+    host, which gathers the one raw value per keypoint the glue reads (drfe_orb_keypoint_pixels_async ->
+    drfe_gather_keypoint_depth -> drfe_frame_stereo_grid_batch_kpdepth: 2 MB up, 1 MB down per batch).  Two contexts
+    alternate so that the host gather of batch i runs while the device extracts batch i + 1."""
+    import torch
+    K = fes[0].ctx.max_kp
+    gh = torch.from_numpy(gray).pin_memory()
+    gd = [torch.empty_like(gh, device=dev) for _ in range(2)]
+    uv = [torch.empty((B, K), dtype=torch.int32).pin_memory() for _ in range(2)]
+    kc = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(2)]
+    kpd = [torch.zeros((B, K), dtype=torch.int16).pin_memory() for _ in range(2)]
+    res = [dict(kps=torch.empty((B, K, 28), dtype=torch.uint8).pin_memory(), desc=torch.empty((B, K, 32), dtype=torch.uint8).pin_memory(),
+                kc=torch.empty(B, dtype=torch.int32).pin_memory(), m=torch.empty((B, K), dtype=torch.int32).pin_memory(),
+                mc=torch.empty(B, dtype=torch.int32).pin_memory()) for _ in range(2)]
+    s_copy, s_comp = torch.cuda.Stream(), torch.cuda.Stream()
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_uv = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    w, h = gray.shape[2], gray.shape[1]
+    threads = max(1, __import__("dr_slam_amd.sharding", fromlist=["host_cpus"]).host_cpus() // 2)
+
+    def front(k):        # H2D + extraction + the keypoint pixels of the batch in buffer k
+        with torch.cuda.stream(s_copy):
+            s_copy.wait_event(ev_done[k])
+            gd[k].copy_(gh, non_blocking=True)
+            ev_in[k].record(s_copy)
+        s_comp.wait_event(ev_in[k])
+        fes[k].ctx.orb_extract_batch_ptr(gd[k].data_ptr(), w * h, w, w, h, B, s_comp.cuda_stream)
+        fes[k].ctx.keypoint_pixels_async_ptr(B, uv[k].data_ptr(), kc[k].data_ptr(), s_comp.cuda_stream)
+        ev_uv[k].record(s_comp)
+
+    def back(k):         # host gather, glue from the gathered values, match, results home
+        ev_uv[k].synchronize()
+        fes[k].ctx.gather_keypoint_depth(depth, uv[k].numpy().view(np.uint32), kc[k].numpy(), kpd[k].numpy().view(np.uint16), threads)
+        fes[k].ctx.stereo_grid_batch_kpdepth_ptr(kpd[k].data_ptr(), True, fes[k].cam, B, s_comp.cuda_stream)
+        fes[k].ctx.match_consecutive_batch(Tcw, Twc, fes[k].cam, 15.0, False, True, B, s_comp.cuda_stream)
+        r = res[k]
+        fes[k].ctx.batch_download_async_ptr(B, r["kps"].data_ptr(), r["desc"].data_ptr(), r["kc"].data_ptr(), r["m"].data_ptr(),
+                                            r["mc"].data_ptr(), s_comp.cuda_stream)
+        ev_done[k].record(s_comp)
+
+    def run(n):
+        for k in range(2):
+            ev_done[k].record(s_comp)
+        front(0)
+        for i in range(n):
+            if i + 1 < n:
+                front((i + 1) & 1)
+            back(i & 1)
+        torch.cuda.synchronize()
+
+    run(2)
+    t0 = time.perf_counter()
+    run(steps)
+    el = time.perf_counter() - t0
+    assert int(res[0]["kc"].min()) > 500 and int(res[0]["mc"][1:].min()) > 50
+    return B * steps / el, el / steps * 1e3, threads
+
+
 def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines, AHC planes with their PCL-style
@@ -508,6 +568,15 @@ def main():
                                "d2h_bytes_per_step": int(B * fe.ctx.max_kp * (28 + 32 + 4) + 8 * B),
                                "note": "pinned gray + depth H2D on a copy stream overlapped with the previous batch, keypoints / "
                                        "descriptors / matches D2H; link-bound"}
+            fe2 = FrontEnd(cam, max_batch=B, device=local_rank)
+            fps_sp, ms_sp, thr = host_fed_sparse_rate([fe, fe2], gray, depth, Tcw, Twc, B, max(4, min(args.steps, 10)), dev)
+            fe2.ctx.close()
+            out["host_fed_sparse_depth"] = {"value": fps_sp, "unit": "frames/s", "ms_per_step": ms_sp,
+                                            "h2d_bytes_per_step": int(gray.nbytes + B * fe.ctx.max_kp * 2),
+                                            "d2h_bytes_per_step": int(B * fe.ctx.max_kp * (28 + 32 + 4 + 4) + 12 * B),
+                                            "gather_threads": thr,
+                                            "note": "gray frames only cross the link; the host gathers one raw depth value per keypoint "
+                                                    "(sparse-depth glue), two contexts alternate"}
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported by the N=1 run only
             out["cpu_baseline"] = cpu_baseline(base, cam)
         if world == 1 and not args.no_extras:

@@ -113,7 +113,7 @@ void drfe_destroy(drfe_ctx* c)
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
                     c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_kpsUn, c->d_desc,
                     c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc, c->d_match,
-                    c->d_matchCount, c->d_poses, c->d_stage, c->d_callScratch};
+                    c->d_matchCount, c->d_poses, c->d_stage, c->d_callScratch, c->d_kpUV, c->d_kpDepth};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < DRFE_STAGE_COUNT; i++)

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #define HIPCHK(c, call)                                                                         \
     do {                                                                                        \
@@ -225,6 +226,64 @@ int drfe_frame_download_keys_un(drfe_ctx* c, int slot, drfe_keypoint* kps, int c
     HIPCHK(c, hipMemcpy(&n, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));
     if (n > cap) { c->err = "keypoint buffer too small"; return DRFE_ERR_CAPACITY; }
     if (n) HIPCHK(c, hipMemcpy(kps, drfe_kps_un(c) + (size_t)slot * c->maxKp, sizeof(drfe_keypoint) * n, hipMemcpyDeviceToHost));
+    return DRFE_OK;
+}
+
+/* ---- sparse depth: the host keeps the depth images and ships one raw value per keypoint -------------------------------- */
+
+int drfe_orb_keypoint_pixels_async(drfe_ctx* c, int nframes, uint32_t* uv, int32_t* counts, void* stream)
+{
+    if (!c || !uv || !counts) return DRFE_ERR_INVALID;
+    if (nframes < 1 || nframes > c->lastBatch) { c->err = "keypoint_pixels: extract the batch first"; return DRFE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_kpUV) HIPCHK(c, hipMalloc((void**)&c->d_kpUV, sizeof(uint32_t) * (size_t)c->cfg.max_batch * c->maxKp));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, drfe_launch_kp_pixels(c, nframes, c->d_kpUV, s));
+    HIPCHK(c, hipMemcpyAsync(uv, c->d_kpUV, sizeof(uint32_t) * (size_t)nframes * c->maxKp, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(counts, c->d_kpCount, sizeof(int) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+    return DRFE_OK;
+}
+
+int drfe_gather_keypoint_depth(const uint16_t* depth, size_t frame_stride, size_t row_stride, int nframes, const uint32_t* uv,
+                               const int32_t* counts, int max_kp, uint16_t* out, int n_threads)
+{
+    if (!depth || !uv || !counts || !out || nframes < 0 || max_kp < 1) return DRFE_ERR_INVALID;
+    int T = n_threads > 0 ? n_threads : drfe_default_host_threads();
+    T = std::max(1, std::min(T, nframes));
+    auto work = [&](int f0, int f1) {
+        for (int f = f0; f < f1; f++) {
+            const uint16_t* img = depth + (size_t)f * frame_stride;
+            const uint32_t* p = uv + (size_t)f * max_kp;
+            uint16_t* o = out + (size_t)f * max_kp;
+            const int n = std::min(counts[f], max_kp);
+            for (int i = 0; i < n; i++)
+                o[i] = p[i] == 0xFFFFFFFFu ? (uint16_t)0 : img[(size_t)(p[i] >> 16) * row_stride + (p[i] & 0xFFFFu)];
+        }
+    };
+    if (T == 1) { work(0, nframes); return DRFE_OK; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; k++) th.emplace_back(work, (int)((int64_t)nframes * k / T), (int)((int64_t)nframes * (k + 1) / T));
+    for (std::thread& t : th) t.join();
+    return DRFE_OK;
+}
+
+int drfe_frame_stereo_grid_batch_kpdepth(drfe_ctx* c, const uint16_t* kp_depth, int kp_depth_on_host, const drfe_camera* cam,
+                                         int nframes, void* stream)
+{
+    if (!c || !kp_depth || !cam) return DRFE_ERR_INVALID;
+    if (nframes < 1 || nframes > c->lastBatch) { c->err = "glue: extract the batch first"; return DRFE_ERR_STATE; }
+    if (!(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { c->err = "glue: empty image bounds"; return DRFE_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const uint16_t* d = kp_depth;
+    if (kp_depth_on_host) {
+        if (!c->d_kpDepth) HIPCHK(c, hipMalloc((void**)&c->d_kpDepth, sizeof(uint16_t) * (size_t)c->cfg.max_batch * c->maxKp));
+        HIPCHK(c, hipMemcpyAsync(c->d_kpDepth, kp_depth, sizeof(uint16_t) * (size_t)nframes * c->maxKp, hipMemcpyHostToDevice, s));
+        d = c->d_kpDepth;
+    }
+    HIPCHK(c, drfe_launch_glue(c, d, (size_t)c->maxKp, 0, *cam, nframes, s));
+    c->glueValid = true;
+    c->cam = *cam;
     return DRFE_OK;
 }
 

@@ -136,6 +136,8 @@ struct drfe_ctx {
     float* d_poses;                       /* per-batch Tcw/Twc staging: [2][max_batch][16] */
     uint8_t* d_stage;                     /* staging for single-frame host API */
     size_t stageBytes;
+    uint32_t* d_kpUV;                     /* [max_batch][maxKp] depth pixel of every keypoint (drfe_orb_keypoint_pixels_async) */
+    uint16_t* d_kpDepth;                  /* [max_batch][maxKp] raw depth per keypoint (drfe_frame_stereo_grid_batch_kpdepth) */
     uint8_t* d_callScratch;               /* grow-only device scratch of the host-buffer matcher calls (one call at a time) */
     size_t callScratchBytes;
 
@@ -179,6 +181,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
 /* match_kernels.hip */
 hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameStride, size_t rowStride,
                             const drfe_camera& cam, int nframes, hipStream_t s);
+hipError_t drfe_launch_kp_pixels(drfe_ctx* c, int nframes, uint32_t* d_uv, hipStream_t s);
 hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, float th, int mono, int checkOri,
                                          int nframes, hipStream_t s);
 

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void k_stereo(const drfe_keypoint* __restrict_
      * float32 (imDepth.convertTo(CV_32F, factor), src/Frame.cc:113-115) */
     const int v = (int)kp.y, u = (int)kp.x;
     float d = 0.f;
-    if (u >= 0 && u < w && v >= 0 && v < h)
-        d = (float)depth[(size_t)slot * frameStride + (size_t)v * rowStride + u] * cam.depth_factor;
+    if (u >= 0 && u < w && v >= 0 && v < h)      /* rowStride == 0: `depth` holds the raw value AT each keypoint ([slot][frameStride]) */
+        d = (float)depth[rowStride ? (size_t)slot * frameStride + (size_t)v * rowStride + u : (size_t)slot * frameStride + i] * cam.depth_factor;
     float ur = -1.f, z = -1.f;
     if (d > 0) { z = d; ur = kpsUn[(size_t)slot * maxKp + i].x - cam.bf / d; }   /* kpU.pt.x - mbf/d, :906 */
     uRight[(size_t)slot * maxKp + i] = ur;
@@ -729,6 +729,30 @@ static inline void prof_begin(drfe_ctx* c, int stage, hipStream_t s)
 static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
 {
     if (c->profile) (void)hipEventRecord(c->ev[stage][1], s);
+}
+
+/* the pixel ComputeStereoFromRGBD reads the depth of keypoint i at (u | v << 16; 0xFFFFFFFF = outside the image): what a host
+ * that keeps the depth images needs to gather one raw value per keypoint instead of shipping whole depth frames */
+__global__ __launch_bounds__(256) void k_kp_pixels(const drfe_keypoint* __restrict__ kps, const int* __restrict__ kpCount, int maxKp,
+                                                   int w, int h, uint32_t* __restrict__ uv)
+{
+    const int slot = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= maxKp) return;
+    uint32_t o = 0xFFFFFFFFu;
+    if (i < kpCount[slot]) {
+        const drfe_keypoint kp = kps[(size_t)slot * maxKp + i];
+        const int v = (int)kp.y, u = (int)kp.x;
+        if (u >= 0 && u < w && v >= 0 && v < h) o = (uint32_t)u | ((uint32_t)v << 16);
+    }
+    uv[(size_t)slot * maxKp + i] = o;
+}
+
+hipError_t drfe_launch_kp_pixels(drfe_ctx* c, int nframes, uint32_t* d_uv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kp_pixels, dim3((c->maxKp + 255) / 256, nframes), dim3(256), 0, s, c->d_kps, c->d_kpCount, c->maxKp,
+                       c->geom.imgW, c->geom.imgH, d_uv);
+    return hipGetLastError();
 }
 
 hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameStride, size_t rowStride,

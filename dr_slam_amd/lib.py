@@ -36,7 +36,8 @@ SYMBOLS = (
     "drfe_match_orb_points", "drfe_planes_cape", "drfe_voc_upload", "drfe_bow_transform_batch", "drfe_bow_download",
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
-    "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host",
+    "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
+    "drfe_frame_stereo_grid_batch_kpdepth",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -113,6 +114,9 @@ def load() -> C.CDLL:
     L.drfe_orb_download.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_counts.argtypes = [vp, i32, vp]
     L.drfe_orb_fast_partition.argtypes = [vp, i32, i32, vp, vp]
+    L.drfe_orb_keypoint_pixels_async.argtypes = [vp, i32, vp, vp, vp]
+    L.drfe_gather_keypoint_depth.argtypes = [vp, sz, sz, i32, vp, vp, i32, vp, i32]
+    L.drfe_frame_stereo_grid_batch_kpdepth.argtypes = [vp, vp, i32, C.POINTER(Camera), i32, vp]
     L.drfe_batch_download_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.drfe_orb_pyramid_level.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
     L.drfe_orb_blurred_level.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
@@ -357,6 +361,22 @@ class Context:
         self._chk(self.L.drfe_frame_stereo_grid_batch(self.h, C.c_void_p(d_depth), frame_stride_elems,
                                                       row_stride_elems, C.byref(cam), nframes, C.c_void_p(stream)),
                   "drfe_frame_stereo_grid_batch")
+
+    def keypoint_pixels_async_ptr(self, nframes: int, uv: int, counts: int, stream: int = 0):
+        """uv / counts: raw host pointers (pinned) of [nframes][max_kp] uint32 and [nframes] int32."""
+        self._chk(self.L.drfe_orb_keypoint_pixels_async(self.h, nframes, C.c_void_p(uv), C.c_void_p(counts), C.c_void_p(stream)),
+                  "drfe_orb_keypoint_pixels_async")
+
+    def gather_keypoint_depth(self, depth16: np.ndarray, uv: np.ndarray, counts: np.ndarray, out: np.ndarray, n_threads=0):
+        """Host gather: out[f, i] = depth16[f, v, u] for the pixels drfe_orb_keypoint_pixels_async reported."""
+        B, h, w = depth16.shape
+        rc = self.L.drfe_gather_keypoint_depth(_p(depth16), w * h, w, B, _p(uv), _p(counts), self.max_kp, _p(out), int(n_threads))
+        if rc != 0:
+            raise DrfeError(f"drfe_gather_keypoint_depth failed ({rc})")
+
+    def stereo_grid_batch_kpdepth_ptr(self, kp_depth: int, on_host: bool, cam: Camera, nframes: int, stream: int = 0):
+        self._chk(self.L.drfe_frame_stereo_grid_batch_kpdepth(self.h, C.c_void_p(kp_depth), int(on_host), C.byref(cam), nframes,
+                                                               C.c_void_p(stream)), "drfe_frame_stereo_grid_batch_kpdepth")
 
     def download_stereo(self, slot):
         ur = np.zeros(self.max_kp, np.float32)

@@ -119,6 +119,19 @@ int drfe_orb_candidates(drfe_ctx* ctx, int slot, int level, int32_t* xyr, int ca
  * mvDepth/mvuRight and the 64x48 feature grid, all kept on device for the matchers. */
 int drfe_frame_stereo_grid_batch(drfe_ctx* ctx, const uint16_t* d_depth, size_t frame_stride_elems,
                                  size_t row_stride_elems, const drfe_camera* cam, int nframes, void* stream);
+/* Sparse-depth form of the glue for a pipeline fed from HOST memory: ComputeStereoFromRGBD reads the depth image at <= max_keypoints
+ * pixels per frame, so a host that keeps its depth images can ship one raw value per keypoint (2 KB per frame) instead of the
+ * frame (614 KB).  Three steps after drfe_orb_extract_batch:
+ *   drfe_orb_keypoint_pixels_async   the pixel of every keypoint (u | v << 16, truncated as the reference truncates kp.pt;
+ *                                    0xFFFFFFFF = outside the image) and the per-frame counts, D2H on `stream`
+ *   drfe_gather_keypoint_depth       HOST code: out[f][i] = depth_f(v, u) on n_threads threads (<= 0: the CPUs this process may use)
+ *   drfe_frame_stereo_grid_batch_kpdepth   the glue from those values ([nframes][max_keypoints], host or device memory)
+ * Results are identical to drfe_frame_stereo_grid_batch on the same depth images (tests/test_gpu_match.py). */
+int drfe_orb_keypoint_pixels_async(drfe_ctx* ctx, int nframes, uint32_t* uv, int32_t* counts, void* stream);
+int drfe_gather_keypoint_depth(const uint16_t* depth, size_t frame_stride_elems, size_t row_stride_elems, int nframes,
+                               const uint32_t* uv, const int32_t* counts, int max_keypoints, uint16_t* out, int n_threads);
+int drfe_frame_stereo_grid_batch_kpdepth(drfe_ctx* ctx, const uint16_t* kp_depth, int kp_depth_on_host, const drfe_camera* cam,
+                                         int nframes, void* stream);
 /* Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:835-891) for cameras with k1 != 0 (TUM1/TUM2
  * settings): dist = (k1, k2, p1, p2[, k3]) as Tracking reads Camera.k1.. into mDistCoef, cam supplies mK.  With a
  * model set, drfe_frame_stereo_grid_batch first builds mvKeysUn on the device (cv::undistortPoints(pts, K, dist,

@@ -433,3 +433,42 @@ def test_search_by_projection_reloc(setup, oracle_mod, list_k, monkeypatch):
             assert (new[matched == 1] == -1).all() and (new >= 0).sum() == nm
             total += nm
     assert total > 1500
+
+
+def test_sparse_depth_glue_equals_image_glue(setup, frames_room):
+    """The host-fed form of the glue (one raw depth value per keypoint, gathered on the host from the pixels
+    drfe_orb_keypoint_pixels_async reports) leaves exactly what the depth-image form leaves: uRight, depth, grid, matches."""
+    import torch
+    fe, oframes, Tcw, Twc, cam = setup
+    n = len(frames_room)
+    ref = [(fe.ctx.download_stereo(s), fe.ctx.download_grid(s), fe.matches(s) if s else None) for s in range(n)]
+    depth = np.stack([f[1] for f in frames_room])
+    K = fe.ctx.max_kp
+    uv = torch.zeros((n, K), dtype=torch.int32).pin_memory()
+    counts = torch.zeros(n, dtype=torch.int32).pin_memory()
+    stream = torch.cuda.current_stream().cuda_stream
+    fe.ctx.keypoint_pixels_async_ptr(n, uv.data_ptr(), counts.data_ptr(), stream)
+    torch.cuda.synchronize()
+    uvn, cn = uv.numpy().view(np.uint32), counts.numpy()
+    assert [int(c) for c in cn] == [fo.N for fo in oframes]
+    kpd = np.zeros((n, K), np.uint16)
+    fe.ctx.gather_keypoint_depth(depth, uvn, cn, kpd, n_threads=2)
+    for s, fo in enumerate(oframes):                     # the gather is the reference's truncating lookup
+        v, u = fo.kps["y"].astype(np.int32), fo.kps["x"].astype(np.int32)
+        assert np.array_equal(kpd[s, :fo.N], depth[s][v, u])
+    for on_host in (True, False):
+        if on_host:
+            fe.ctx.stereo_grid_batch_kpdepth_ptr(kpd.ctypes.data, True, fe.cam, n, stream)
+        else:
+            t = torch.from_numpy(kpd.view(np.int16)).cuda()
+            fe.ctx.stereo_grid_batch_kpdepth_ptr(t.data_ptr(), False, fe.cam, n, stream)
+        fe.ctx.match_consecutive_batch(Tcw, Twc, fe.cam, 15.0, False, True, n, stream)
+        for s in range(n):
+            (ur0, z0), (off0, idx0), m0 = ref[s]
+            ur, z = fe.ctx.download_stereo(s)
+            off, idx = fe.ctx.download_grid(s)
+            assert np.array_equal(ur.view(np.uint32), ur0.view(np.uint32)) and np.array_equal(z.view(np.uint32), z0.view(np.uint32))
+            assert np.array_equal(off, off0) and np.array_equal(idx, idx0)
+            if s:
+                m, nm = fe.matches(s)
+                assert nm == m0[1] and np.array_equal(m, m0[0])
