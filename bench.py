@@ -217,7 +217,7 @@ def host_fed_rate(fe, gray, depth, Tcw, Twc, B, steps, dev):
     return B * steps / el, el / steps * 1e3
 
 
-def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev):
+def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=()):
     """Host-fed with HALF the bytes: only the gray frames cross the link (157 MB per 512 frames); the depth images stay on the
     host, which gathers the one raw value per keypoint the glue reads (drfe_orb_keypoint_pixels_async ->
     drfe_gather_keypoint_depth -> drfe_frame_stereo_grid_batch_kpdepth: 2 MB up, 1 MB down per batch).  Two contexts
@@ -232,36 +232,46 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev):
     res = [dict(kps=torch.empty((B, K, 28), dtype=torch.uint8).pin_memory(), desc=torch.empty((B, K, 32), dtype=torch.uint8).pin_memory(),
                 kc=torch.empty(B, dtype=torch.int32).pin_memory(), m=torch.empty((B, K), dtype=torch.int32).pin_memory(),
                 mc=torch.empty(B, dtype=torch.int32).pin_memory()) for _ in range(2)]
-    s_copy, s_comp = torch.cuda.Stream(), torch.cuda.Stream()
+    s_copy, s_comp, s_d2h = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_uv = [torch.cuda.Event() for _ in range(2)]
-    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_ext = [torch.cuda.Event() for _ in range(2)]       # the extraction has read input buffer k: it may be refilled
+    ev_m = [torch.cuda.Event() for _ in range(2)]         # batch k is matched: its results may leave
+    ev_done = [torch.cuda.Event() for _ in range(2)]      # ... and have left: context k may extract again
     w, h = gray.shape[2], gray.shape[1]
     threads = max(1, __import__("dr_slam_amd.sharding", fromlist=["host_cpus"]).host_cpus() // 2)
 
     def front(k):        # H2D + extraction + the keypoint pixels of the batch in buffer k
         with torch.cuda.stream(s_copy):
-            s_copy.wait_event(ev_done[k])
-            gd[k].copy_(gh, non_blocking=True)
+            s_copy.wait_event(ev_ext[k])
+            if "h2d" not in _skip:
+                gd[k].copy_(gh, non_blocking=True)
             ev_in[k].record(s_copy)
         s_comp.wait_event(ev_in[k])
+        s_comp.wait_event(ev_done[k])
         fes[k].ctx.orb_extract_batch_ptr(gd[k].data_ptr(), w * h, w, w, h, B, s_comp.cuda_stream)
+        ev_ext[k].record(s_comp)
         fes[k].ctx.keypoint_pixels_async_ptr(B, uv[k].data_ptr(), kc[k].data_ptr(), s_comp.cuda_stream)
         ev_uv[k].record(s_comp)
 
-    def back(k):         # host gather, glue from the gathered values, match, results home
+    def back(k):         # host gather, glue from the gathered values, match; the results go home on their own stream
         ev_uv[k].synchronize()
-        fes[k].ctx.gather_keypoint_depth(depth, uv[k].numpy().view(np.uint32), kc[k].numpy(), kpd[k].numpy().view(np.uint16), threads)
+        if "gather" not in _skip:
+            fes[k].ctx.gather_keypoint_depth(depth, uv[k].numpy().view(np.uint32), kc[k].numpy(), kpd[k].numpy().view(np.uint16), threads)
         fes[k].ctx.stereo_grid_batch_kpdepth_ptr(kpd[k].data_ptr(), True, fes[k].cam, B, s_comp.cuda_stream)
         fes[k].ctx.match_consecutive_batch(Tcw, Twc, fes[k].cam, 15.0, False, True, B, s_comp.cuda_stream)
+        ev_m[k].record(s_comp)
+        s_d2h.wait_event(ev_m[k])
         r = res[k]
-        fes[k].ctx.batch_download_async_ptr(B, r["kps"].data_ptr(), r["desc"].data_ptr(), r["kc"].data_ptr(), r["m"].data_ptr(),
-                                            r["mc"].data_ptr(), s_comp.cuda_stream)
-        ev_done[k].record(s_comp)
+        if "d2h" not in _skip:
+            fes[k].ctx.batch_download_async_ptr(B, r["kps"].data_ptr(), r["desc"].data_ptr(), r["kc"].data_ptr(), r["m"].data_ptr(),
+                                                r["mc"].data_ptr(), s_d2h.cuda_stream)
+        ev_done[k].record(s_d2h)
 
     def run(n):
         for k in range(2):
             ev_done[k].record(s_comp)
+            ev_ext[k].record(s_comp)
         front(0)
         for i in range(n):
             if i + 1 < n:
@@ -273,7 +283,8 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev):
     t0 = time.perf_counter()
     run(steps)
     el = time.perf_counter() - t0
-    assert int(res[0]["kc"].min()) > 500 and int(res[0]["mc"][1:].min()) > 50
+    if not _skip:
+        assert int(res[0]["kc"].min()) > 500 and int(res[0]["mc"][1:].min()) > 50
     return B * steps / el, el / steps * 1e3, threads
 
 

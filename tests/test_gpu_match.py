@@ -441,8 +441,12 @@ def test_sparse_depth_glue_equals_image_glue(setup, frames_room):
     import torch
     fe, oframes, Tcw, Twc, cam = setup
     n = len(frames_room)
-    ref = [(fe.ctx.download_stereo(s), fe.ctx.download_grid(s), fe.matches(s) if s else None) for s in range(n)]
     depth = np.stack([f[1] for f in frames_room])
+    # the reference state: the depth-image form, re-run here (earlier tests of this module searched with other parameters)
+    gray_t = torch.from_numpy(np.stack([f[0] for f in frames_room])).cuda()
+    depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
+    fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=torch.cuda.current_stream().cuda_stream)
+    ref = [(fe.ctx.download_stereo(s), fe.ctx.download_grid(s), fe.matches(s) if s else None) for s in range(n)]
     K = fe.ctx.max_kp
     uv = torch.zeros((n, K), dtype=torch.int32).pin_memory()
     counts = torch.zeros(n, dtype=torch.int32).pin_memory()
