@@ -312,19 +312,14 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    line_threads = max(1, (ncpu * 5) // 8)
-    plane_threads = max(1, ncpu - line_threads - 1)
+    line_threads = max(1, (ncpu * 11) // 16)
+    plane_threads = max(1, ncpu - line_threads)
     ctx_planes = lib.Context(max_batch=1)
     ctx_cape = lib.Context(max_batch=1)
 
-    post_pool = ThreadPoolExecutor(plane_threads)
-
-    def planes():
-        out = ctx_planes.planes_ahc_batch(depth, K4, inv, n_threads=plane_threads, members=True)
-        # Frame::ComputePlanes after the extractor (host: voxel grid + refit), frames across the same threads
-        acc = sum(post_pool.map(lambda f: ctx_planes.planes_ahc_postprocess(depth[f], K4, inv, out[f], 9.0, 0.10)["n_accepted"],
-                                range(n_frames)))
-        return len(out), acc
+    def planes():       # AHC planes + Frame::ComputePlanes' per-plane loop, frames across the C++ thread pool
+        _, n, _, na, _ = ctx_planes.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=plane_threads)
+        return len(n), int(na.sum())
 
     def cape():
         return sum(len(ctx_cape.planes_cape(depth_m[f], K4, 20)["planes"]) for f in range(n_frames))
@@ -346,7 +341,6 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
         for _ in range(reps):
             nacc = step(pool)
         el = (time.perf_counter() - t0) / reps
-    post_pool.shutdown()
     for c in (ctx_planes, ctx_cape):
         c.close()
     fe.ctx.close()

@@ -16,6 +16,7 @@
 #include "drfe_internal.h"
 #include "planes_internal.h"
 #include "ahc_math.h"
+#include "post_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -576,6 +577,55 @@ int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_strid
                                                planes + (size_t)f * cap, cap, &n_planes[f], seg ? seg + f * px : nullptr,
                                                member_offsets ? member_offsets + (size_t)f * (cap + 1) : nullptr,
                                                member_idx ? member_idx + f * px : nullptr);
+                if (rc != DRFE_OK) { rcs[k] = rc; return; }
+            }
+        });
+    for (std::thread& t : th) t.join();
+    for (int k = 0; k < T; k++)
+        if (rcs[k] != DRFE_OK) { c->err = (*pool)[k].err; return rcs[k]; }
+    return DRFE_OK;
+}
+
+/* drfe_planes_ahc_batch followed, on the same worker thread and frame, by the per-plane loop of Frame::ComputePlanes
+ * (drfe_planes_ahc_postprocess): what a frame of the plane path costs end to end, nframes at a time.  post: [nframes][cap];
+ * n_accepted / plane_num: [nframes]; the voxel clouds are not returned (use the single-frame call for mvPlanePoints). */
+int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                               const float* K4, float depth_factor, float max_point_dist, double dist_threshold, drfe_plane* planes,
+                               int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num, int n_threads)
+{
+    if (!c || !depth || !K4 || !planes || !n_planes || !post || !n_accepted || nframes < 0 || cap < 1 || frame_stride < stride * (size_t)h) {
+        if (c) c->err = "planes_ahc_post_batch: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    if (nframes == 0) return DRFE_OK;
+    int T = n_threads > 0 ? n_threads : drfe_default_host_threads();
+    T = std::max(1, std::min(T, nframes));
+    HIPCHK(c, hipSetDevice(c->device));
+    auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);
+    if (!pool) { pool = new std::vector<PlaneLane>(); c->planeLanes = pool; }
+    while ((int)pool->size() < T) {
+        PlaneLane l;
+        l.device = c->device;
+        HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        pool->push_back(l);
+    }
+    std::vector<int> rcs(T, DRFE_OK);
+    std::vector<std::thread> th;
+    th.reserve(T);
+    std::atomic<int> next(0);
+    const size_t px = (size_t)w * h;
+    for (int k = 0; k < T; k++)
+        th.emplace_back([&, k]() {
+            PlaneLane* l = &(*pool)[k];
+            std::vector<int32_t> off((size_t)cap + 1), idx(px), voff((size_t)cap + 1);
+            for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {
+                const uint16_t* d = depth + (size_t)f * frame_stride;
+                int rc = planes_ahc_core(l, d, w, h, stride, K4, depth_factor, planes + (size_t)f * cap, cap, &n_planes[f],
+                                         seg ? seg + f * px : nullptr, off.data(), idx.data());
+                if (rc == DRFE_OK)
+                    rc = drfe_ahc_post_core(&l->err, d, w, h, stride, K4, depth_factor, planes + (size_t)f * cap, n_planes[f], off.data(),
+                                            idx.data(), max_point_dist, dist_threshold, post + (size_t)f * cap, nullptr, voff.data(), 0,
+                                            &n_accepted[f], plane_num ? &plane_num[f] : nullptr);
                 if (rc != DRFE_OK) { rcs[k] = rc; return; }
             }
         });

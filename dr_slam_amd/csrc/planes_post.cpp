@@ -270,6 +270,50 @@ void post_one_plane(const std::vector<Pt>& input, const float coefIn[4], bool ga
 
 }  // namespace
 
+/* the per-plane loop of Frame::ComputePlanes without a context (error text to *err): shared by drfe_planes_ahc_postprocess
+ * and the worker threads of drfe_planes_ahc_post_batch */
+int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
+                       const drfe_plane* planes, int n_planes, const int32_t* member_offsets, const int32_t* member_idx,
+                       float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets,
+                       int cap_voxels, int* n_accepted, int* plane_num)
+{
+    if (!depth || !K4 || (!planes && n_planes) || n_planes < 0 || !member_offsets || (!member_idx && n_planes) || (!post && n_planes) ||
+        !voxel_offsets || !n_accepted) {
+        if (err) *err = "planes_ahc_postprocess: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    PostOut o{post, voxel_xyz, voxel_offsets, cap_voxels, 0, 0, 0, false};
+    std::vector<Pt> input;
+    for (int i = 0; i < n_planes; i++) {
+        input.clear();
+        for (int k = member_offsets[i]; k < member_offsets[i + 1]; k++) {
+            const int j = member_idx[k];
+            if (j < 0 || j >= w * h) { if (err) *err = "planes_ahc_postprocess: member index outside the image"; return DRFE_ERR_INVALID; }
+            const int row = j / w, col = j - row * w;
+            /* PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:39-52): doubles, K floats promoted */
+            const double z = (double)depth[(size_t)row * stride + col] * depth_factor;
+            double X = 0, Y = 0, Z = 0;
+            if (!(z > 5.0)) {
+                X = ((double)col - K4[2]) * z / K4[0];
+                Y = ((double)row - K4[3]) * z / K4[1];
+                Z = z;
+            }
+            const Pt p{(float)X, (float)Y, (float)Z};
+            if (p.z > max_point_dist) continue;
+            input.push_back(p);
+        }
+        const drfe_plane& e = planes[i];
+        const float d = (float)-(e.normal[0] * e.center[0] + e.normal[1] * e.center[1] + e.normal[2] * e.center[2]);
+        const float coef[4] = {(float)e.normal[0], (float)e.normal[1], (float)e.normal[2], d};
+        post_one_plane(input, coef, d > max_point_dist, dist_threshold, false, i, &o);
+    }
+    voxel_offsets[n_planes] = o.used;
+    *n_accepted = o.nAccepted;
+    if (plane_num) *plane_num = n_planes - o.failPlanes;     /* planeDetector.plane_num_ -= fail_planes (:1023) */
+    if (o.overflow) { if (err) *err = "planes_ahc_postprocess: voxel buffer too small"; return DRFE_ERR_CAPACITY; }
+    return DRFE_OK;
+}
+
 extern "C" {
 
 int drfe_plane_voxel_grid(const float* xyz, int n, float leaf, float* out_xyz, int cap, int* n_out)
@@ -297,40 +341,8 @@ int drfe_planes_ahc_postprocess(drfe_ctx* c, const uint16_t* depth, int w, int h
                                 int32_t* voxel_offsets, int cap_voxels, int* n_accepted, int* plane_num)
 {
     if (!c) return DRFE_ERR_INVALID;
-    if (!depth || !K4 || !planes || n_planes < 0 || !member_offsets || !member_idx || !post || !voxel_offsets || !n_accepted) {
-        c->err = "planes_ahc_postprocess: invalid argument";
-        return DRFE_ERR_INVALID;
-    }
-    PostOut o{post, voxel_xyz, voxel_offsets, cap_voxels, 0, 0, 0, false};
-    std::vector<Pt> input;
-    for (int i = 0; i < n_planes; i++) {
-        input.clear();
-        for (int k = member_offsets[i]; k < member_offsets[i + 1]; k++) {
-            const int j = member_idx[k];
-            if (j < 0 || j >= w * h) { c->err = "planes_ahc_postprocess: member index outside the image"; return DRFE_ERR_INVALID; }
-            const int row = j / w, col = j - row * w;
-            /* PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:39-52): doubles, K floats promoted */
-            const double z = (double)depth[(size_t)row * stride + col] * depth_factor;
-            double X = 0, Y = 0, Z = 0;
-            if (!(z > 5.0)) {
-                X = ((double)col - K4[2]) * z / K4[0];
-                Y = ((double)row - K4[3]) * z / K4[1];
-                Z = z;
-            }
-            const Pt p{(float)X, (float)Y, (float)Z};
-            if (p.z > max_point_dist) continue;
-            input.push_back(p);
-        }
-        const drfe_plane& e = planes[i];
-        const float d = (float)-(e.normal[0] * e.center[0] + e.normal[1] * e.center[1] + e.normal[2] * e.center[2]);
-        const float coef[4] = {(float)e.normal[0], (float)e.normal[1], (float)e.normal[2], d};
-        post_one_plane(input, coef, d > max_point_dist, dist_threshold, false, i, &o);
-    }
-    voxel_offsets[n_planes] = o.used;
-    *n_accepted = o.nAccepted;
-    if (plane_num) *plane_num = n_planes - o.failPlanes;     /* planeDetector.plane_num_ -= fail_planes (:1023) */
-    if (o.overflow) { c->err = "planes_ahc_postprocess: voxel buffer too small"; return DRFE_ERR_CAPACITY; }
-    return DRFE_OK;
+    return drfe_ahc_post_core(&c->err, depth, w, h, stride, K4, depth_factor, planes, n_planes, member_offsets, member_idx, max_point_dist,
+                              dist_threshold, post, voxel_xyz, voxel_offsets, cap_voxels, n_accepted, plane_num);
 }
 
 int drfe_planes_cape_postprocess(drfe_ctx* c, const float* depth_m, int w, int h, size_t stride, const float* K4, const uint8_t* seg,

@@ -21,4 +21,9 @@ struct SnBuffers {            /* device scratch of the surface-normal pass, [fra
 hipError_t drfe_launch_surface_normals(const void* d_depth, int isU16, float factor, size_t frameStride, size_t rowStride, int w,
                                        int h, const float K4[4], float maxDist, int nframes, const SnBuffers& b, hipStream_t s);
 void drfe_post_free(drfe_ctx* c);
+#include <string>
+int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
+                       const drfe_plane* planes, int n_planes, const int32_t* member_offsets, const int32_t* member_idx,
+                       float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets,
+                       int cap_voxels, int* n_accepted, int* plane_num);
 #endif

@@ -37,7 +37,7 @@ SYMBOLS = (
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
     "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
-    "drfe_frame_stereo_grid_batch_kpdepth",
+    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -168,6 +168,7 @@ def load() -> C.CDLL:
     L.drfe_plane_refit.argtypes = [vp, vp, i32, f64, C.POINTER(i32)]
     L.drfe_planes_ahc_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, vp, vp, f32, f64, vp, vp, vp, i32,
                                               C.POINTER(i32), C.POINTER(i32)]
+    L.drfe_planes_ahc_post_batch.argtypes = [vp, vp, sz, i32, i32, sz, i32, vp, f32, f32, f64, vp, i32, vp, vp, vp, vp, vp, i32]
     L.drfe_planes_cape_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, vp, vp, i32, f32, f64, vp, vp, vp, i32,
                                                C.POINTER(i32), C.POINTER(i32)]
     L.drfe_surface_normals.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
@@ -783,6 +784,21 @@ class Context:
                   "drfe_planes_ahc_postprocess")
         return dict(post=post, voxels=[vox[voff[i]:voff[i + 1]].copy() for i in range(n)], n_accepted=na.value,
                     plane_num=pn.value)
+
+    def planes_ahc_post_batch(self, depth16_batch, K4, depth_factor, max_point_dist, dist_threshold, cap=64, n_threads=0, seg=False):
+        """planes_ahc_batch + planes_ahc_postprocess per frame inside the C++ thread pool -> (planes [B,cap], n_planes [B],
+        post [B,cap], n_accepted [B], plane_num [B][, seg [B,H,W]])."""
+        d = np.ascontiguousarray(depth16_batch, np.uint16)
+        B, h, w = d.shape
+        planes = np.zeros((B, cap), PLANE_DTYPE)
+        post = np.zeros((B, cap), PLANE_POST_DTYPE)
+        n, na, pn = (np.zeros(B, np.int32) for _ in range(3))
+        sg = np.zeros((B, h, w), np.uint8) if seg else None
+        self._chk(self.L.drfe_planes_ahc_post_batch(self.h, _p(d), w * h, w, h, w, B, _p(np.ascontiguousarray(K4, np.float32)),
+                                                    np.float32(depth_factor), np.float32(max_point_dist), float(dist_threshold),
+                                                    _p(planes), cap, _p(n), _p(sg), _p(post), _p(na), _p(pn), int(n_threads)),
+                  "drfe_planes_ahc_post_batch")
+        return (planes, n, post, na, pn, sg) if seg else (planes, n, post, na, pn)
 
     def planes_cape_postprocess(self, depth_m, K4, cape, max_point_dist, dist_threshold):
         """cape = the dict planes_cape returned. -> dict(post, voxels, n_accepted, plane_num)."""

@@ -511,6 +511,12 @@ int drfe_planes_ahc_postprocess(drfe_ctx* ctx, const uint16_t* depth, int w, int
                                 const drfe_plane* planes, int n_planes, const int32_t* member_offsets, const int32_t* member_idx,
                                 float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz,
                                 int32_t* voxel_offsets, int cap_voxels, int* n_accepted, int* plane_num);
+/* drfe_planes_ahc_batch and, on the same worker thread, drfe_planes_ahc_postprocess of every frame: the plane path of nframes host
+ * depth images end to end.  planes / post: [nframes][cap]; n_planes / n_accepted / plane_num (may be NULL): [nframes]; seg (may be
+ * NULL): [nframes][w*h].  The voxel clouds are not returned here.  n_threads <= 0: the CPUs this process may use. */
+int drfe_planes_ahc_post_batch(drfe_ctx* ctx, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                               const float* K4, float depth_factor, float max_point_dist, double dist_threshold, drfe_plane* planes,
+                               int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num, int n_threads);
 /* The same loop of Frame::ComputePlanes_CAPE (:1111-1141) for the planes / seg image drfe_planes_cape returned: plane_cloud[i]
  * = the points of the pixels labelled i + 1 in raster order (src/PlaneExtractor.cpp:171-188). */
 int drfe_planes_cape_postprocess(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, const uint8_t* seg,

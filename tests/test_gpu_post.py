@@ -179,3 +179,26 @@ def test_post_edge_cases(oracle_mod):
         assert g["n_accepted"] == 0 and g["plane_num"] == 0 and len(g["post"]) == 0
     finally:
         c.close()
+
+
+def test_ahc_post_batch_equals_single_frame_calls(oracle_mod):
+    """drfe_planes_ahc_post_batch (AHC + the per-plane loop on a pool of host threads) == per-frame drfe_planes_ahc +
+    drfe_planes_ahc_postprocess."""
+    from dr_slam_amd import lib, synth
+    cam = synth.TUM3
+    frames = list(synth.sequence(2, 5, cam=cam))
+    depth = np.stack([f[1] for f in frames])
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    c = lib.Context()
+    try:
+        planes, n, post, na, pn, seg = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        for f in range(len(frames)):
+            ga = c.planes_ahc(depth[f], K4, inv)
+            g = c.planes_ahc_postprocess(depth[f], K4, inv, ga, 9.0, 0.10)
+            assert n[f] == len(ga["planes"]) and planes[f, :n[f]].tobytes() == ga["planes"].tobytes()
+            assert np.array_equal(seg[f], ga["seg"])
+            assert post[f, :n[f]].tobytes() == g["post"].tobytes() and na[f] == g["n_accepted"] and pn[f] == g["plane_num"]
+        assert na.sum() >= 5
+    finally:
+        c.close()
