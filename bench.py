@@ -217,15 +217,17 @@ def host_fed_rate(fe, gray, depth, Tcw, Twc, B, steps, dev):
     return B * steps / el, el / steps * 1e3
 
 
-def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=()):
+def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _threads=0):
     """Host-fed with HALF the bytes: only the gray frames cross the link (157 MB per 512 frames); the depth images stay on the
     host, which gathers the one raw value per keypoint the glue reads (drfe_orb_keypoint_pixels_async ->
     drfe_gather_keypoint_depth -> drfe_frame_stereo_grid_batch_kpdepth: 2 MB up, 1 MB down per batch).  Two contexts
-    alternate so that the host gather of batch i runs while the device extracts batch i + 1."""
+    alternate so that the host gather of batch i runs while the device extracts batch i + 1, and three input buffers keep the
+    copy of batch i + 2 in flight meanwhile (a copy issued after the gather would add the gather to every step)."""
     import torch
+    from dr_slam_amd import sharding
     K = fes[0].ctx.max_kp
     gh = torch.from_numpy(gray).pin_memory()
-    gd = [torch.empty_like(gh, device=dev) for _ in range(2)]
+    gd = [torch.empty_like(gh, device=dev) for _ in range(3)]
     uv = [torch.empty((B, K), dtype=torch.int32).pin_memory() for _ in range(2)]
     kc = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(2)]
     kpd = [torch.zeros((B, K), dtype=torch.int16).pin_memory() for _ in range(2)]
@@ -233,28 +235,33 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=()):
                 kc=torch.empty(B, dtype=torch.int32).pin_memory(), m=torch.empty((B, K), dtype=torch.int32).pin_memory(),
                 mc=torch.empty(B, dtype=torch.int32).pin_memory()) for _ in range(2)]
     s_copy, s_comp, s_d2h = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-    ev_in = [torch.cuda.Event() for _ in range(2)]
-    ev_uv = [torch.cuda.Event() for _ in range(2)]
-    ev_ext = [torch.cuda.Event() for _ in range(2)]       # the extraction has read input buffer k: it may be refilled
-    ev_m = [torch.cuda.Event() for _ in range(2)]         # batch k is matched: its results may leave
+    ev_in = [torch.cuda.Event() for _ in range(3)]        # input buffer b holds its batch
+    ev_ext = [torch.cuda.Event() for _ in range(3)]       # the extraction has read input buffer b: it may be refilled
+    ev_uv = [torch.cuda.Event() for _ in range(2)]        # context k: keypoint pixels are on the host
+    ev_m = [torch.cuda.Event() for _ in range(2)]         # context k: matched, the results may leave
     ev_done = [torch.cuda.Event() for _ in range(2)]      # ... and have left: context k may extract again
     w, h = gray.shape[2], gray.shape[1]
-    threads = max(1, __import__("dr_slam_amd.sharding", fromlist=["host_cpus"]).host_cpus() // 2)
+    threads = _threads or max(1, min(2, sharding.host_cpus() // 4))
 
-    def front(k):        # H2D + extraction + the keypoint pixels of the batch in buffer k
+    def copy_in(i):      # H2D of batch i into input buffer i % 3
+        b = i % 3
         with torch.cuda.stream(s_copy):
-            s_copy.wait_event(ev_ext[k])
+            s_copy.wait_event(ev_ext[b])
             if "h2d" not in _skip:
-                gd[k].copy_(gh, non_blocking=True)
-            ev_in[k].record(s_copy)
-        s_comp.wait_event(ev_in[k])
+                gd[b].copy_(gh, non_blocking=True)
+            ev_in[b].record(s_copy)
+
+    def extract(i):      # extraction + the keypoint pixels of batch i on context i & 1
+        b, k = i % 3, i & 1
+        s_comp.wait_event(ev_in[b])
         s_comp.wait_event(ev_done[k])
-        fes[k].ctx.orb_extract_batch_ptr(gd[k].data_ptr(), w * h, w, w, h, B, s_comp.cuda_stream)
-        ev_ext[k].record(s_comp)
+        fes[k].ctx.orb_extract_batch_ptr(gd[b].data_ptr(), w * h, w, w, h, B, s_comp.cuda_stream)
+        ev_ext[b].record(s_comp)
         fes[k].ctx.keypoint_pixels_async_ptr(B, uv[k].data_ptr(), kc[k].data_ptr(), s_comp.cuda_stream)
         ev_uv[k].record(s_comp)
 
-    def back(k):         # host gather, glue from the gathered values, match; the results go home on their own stream
+    def finish(i):       # host gather, glue from the gathered values, match; the results go home on their own stream
+        k = i & 1
         ev_uv[k].synchronize()
         if "gather" not in _skip:
             fes[k].ctx.gather_keypoint_depth(depth, uv[k].numpy().view(np.uint32), kc[k].numpy(), kpd[k].numpy().view(np.uint16), threads)
@@ -269,17 +276,21 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=()):
         ev_done[k].record(s_d2h)
 
     def run(n):
-        for k in range(2):
-            ev_done[k].record(s_comp)
-            ev_ext[k].record(s_comp)
-        front(0)
+        for e in ev_ext + ev_done:
+            e.record(s_comp)
+        copy_in(0)
+        if n > 1:
+            copy_in(1)
+        extract(0)
         for i in range(n):
+            if i + 2 < n:
+                copy_in(i + 2)
             if i + 1 < n:
-                front((i + 1) & 1)
-            back(i & 1)
+                extract(i + 1)
+            finish(i)
         torch.cuda.synchronize()
 
-    run(2)
+    run(3)
     t0 = time.perf_counter()
     run(steps)
     el = time.perf_counter() - t0

@@ -21,6 +21,6 @@ for T in (1, 2, 4, 8):
     for _ in range(5): fes[0].ctx.gather_keypoint_depth(depth, uv.numpy().view(np.uint32), kc.numpy(), out, T)
     print("gather", T, "threads", (time.perf_counter() - t) / 5 * 1e3, "ms")
 bench.host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, 4, dev)
-for skip in ((), ("h2d",), ("d2h",), ("gather",), ("h2d", "d2h"), ("h2d", "d2h", "gather")):
-    r = bench.host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, 10, dev, _skip=skip)
-    print("skip", skip, "->", round(r[0]), "frames/s", round(r[1], 2), "ms/step")
+for thr in (1, 2, 4, 8):
+    r = bench.host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, 10, dev, _threads=thr)
+    print("gather threads", thr, "->", round(r[0]), "frames/s", round(r[1], 2), "ms/step")
