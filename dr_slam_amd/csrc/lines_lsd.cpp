@@ -56,7 +56,10 @@ public:
                   std::vector<uint8_t>& used, std::vector<OPt>& order)
         : W_(W), H_(H), mod_(modgrad), ang_(angles), cs_(cs), used_(used), order_(order)
     {
-        used_.assign((size_t)W * H, 0);
+        /* 0 = free, 1 = claimed, 2 = no level-line angle (never joins a region): the probe of a neighbour then reads the
+         * compact byte map only, not the angle field, for the third of the pixels that can never pass */
+        used_.resize((size_t)W * H);
+        for (size_t i = 0; i < used_.size(); i++) used_[i] = angles[i] == kNotDef ? 2 : 0;
         const double binCoef = (maxGrad > 0) ? double(1024 - 1) / maxGrad : 0;
         order_.clear();
         order_.reserve((size_t)(W - 1) * (H - 1));
@@ -82,7 +85,7 @@ public:
         std::vector<RectD> pending;
         for (const OPt& key : order_) {
             const struct { int x, y; } s = {opt_x(key), opt_y(key)};
-            if (used_[(size_t)s.y * W_ + s.x] || ang_[(size_t)s.y * W_ + s.x] == kNotDef) continue;
+            if (used_[(size_t)s.y * W_ + s.x]) continue;          /* claimed, or no angle */
             double regAngle;
             if (!timed_) {
                 grow(s.x, s.y, reg, regAngle, prec);
@@ -161,8 +164,13 @@ private:
             for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H_ - 1); ++yy)
                 for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W_ - 1); ++xx) {
                     uint8_t& u = used_[(size_t)yy * W_ + xx];
-                    if (u != 1 && aligned(xx, yy, regAngle, prec)) {
-                        const double a = ang_[(size_t)yy * W_ + xx];
+                    if (u != 0) continue;
+                    /* isAligned() on a pixel known to be inside the image and to have an angle */
+                    const double a = ang_[(size_t)yy * W_ + xx];
+                    double dn = regAngle - a;
+                    if (dn < 0) dn = -dn;
+                    if (dn > kThreeHalfPi) { dn -= kTwoPi; if (dn < 0) dn = -dn; }
+                    if (dn <= prec) {
                         u = 1;
                         reg.push_back({xx, yy, a, mod_[(size_t)yy * W_ + xx]});
                         if (!seeded) { sumdx = float(std::cos(seedAngle)); sumdy = float(std::sin(seedAngle)); seeded = true; }
