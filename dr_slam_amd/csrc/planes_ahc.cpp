@@ -116,8 +116,12 @@ static double tAngInit(double z)
 /* merged statistics of two nodes (ahc::PlaneSeg(pa, pb): sums added, plane refitted) without the neighbour list */
 struct Merged { double S[9]; int N, rid; AhcFit fit; };
 
-/* ahCluster: pops min-MSE nodes, merges with the neighbour giving the least merged MSE.  (Keeping the trial fits per node
- * pair in a hash map was measured: 7.0 ms against 5.1 ms - the 3x3 solve is cheaper than the lookup.) */
+/* ahCluster: pops min-MSE nodes, merges with the neighbour giving the least merged MSE.
+ * Measured on the host harness (drfe_planes_ahc_from_blocks, room frame: 1525 steps): 31 600 trial solves, ~21 per step - a
+ * grown plane tries every block of its boundary - and they are the cost (9.2 of 9.9 ms there).  An edge dies with the first
+ * of its end points to be popped (merged or extracted), so no trial is ever asked for twice: a per-pair cache cannot hit
+ * (tried: 7.0 ms against 5.1 ms on the box).  Skipping trials by the eigenvalue bound 4 det / tr^2 pruned 1.4 % of them: the
+ * candidates of a step are blocks of the same plane and their merged MSEs differ by percents, not factors. */
 static void cluster(Graph& g, MinQ& q, std::vector<int>& extracted)
 {
     const int maxStep = 100000;
@@ -286,6 +290,19 @@ template <class Ctx> static int run_blocks(Ctx* c, const uint16_t* depth, int w,
     blocks.resize(nb);
     HIPCHK(c, hipMemcpyAsync(blocks.data(), p->d_blocks, nb * sizeof(AhcBlockRec), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DRFE_OK;
+}
+
+/* the host half alone: block fits supplied by the caller (drfe_planes_ahc_from_blocks: CPU tests and profiling) */
+struct HostBlocks { std::string err; const AhcBlockRec* blocks; size_t n; };
+static int run_blocks(HostBlocks* c, const uint16_t* depth, int w, int h, size_t stride, const float K4[4], float, std::vector<AhcBlockRec>& blocks)
+{
+    const size_t nb = (size_t)(w / AHC_WIN) * (h / AHC_WIN);
+    if (!c || !depth || !K4 || w < AHC_WIN || h < AHC_WIN || stride < (size_t)w || c->n != nb) {
+        if (c) c->err = "planes_ahc_from_blocks: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    blocks.assign(c->blocks, c->blocks + nb);
     return DRFE_OK;
 }
 
@@ -584,6 +601,28 @@ int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_strid
     for (int k = 0; k < T; k++)
         if (rcs[k] != DRFE_OK) { c->err = (*pool)[k].err; return rcs[k]; }
     return DRFE_OK;
+}
+
+/* The host half of drfe_planes_ahc (graph, agglomerative clustering, block membership, flood fill, re-merge, labels) on
+ * caller-supplied block fits, without a device: blocks17 = per 10x10 block 9 sums, center, normal, mse, curvature (the layout
+ * drfe_planes_ahc_blocks returns), valid_n = (enters-graph flag, N) per block.  Host code: CPU tests and profiling. */
+int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, const uint16_t* depth, int w, int h, size_t stride,
+                                const float* K4, float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
+                                int32_t* member_offsets, int32_t* member_idx)
+{
+    if (!blocks17 || !valid_n || !n_planes || w < AHC_WIN || h < AHC_WIN) return DRFE_ERR_INVALID;
+    const size_t nb = (size_t)(w / AHC_WIN) * (h / AHC_WIN);
+    std::vector<AhcBlockRec> rec(nb);
+    for (size_t i = 0; i < nb; i++) {
+        const double* b = blocks17 + 17 * i;
+        std::memcpy(rec[i].sums, b, 72);
+        std::memcpy(rec[i].center, b + 9, 24);
+        std::memcpy(rec[i].normal, b + 12, 24);
+        rec[i].mse = b[15]; rec[i].curvature = b[16];
+        rec[i].valid = valid_n[2 * i]; rec[i].N = valid_n[2 * i + 1];
+    }
+    HostBlocks hb{std::string(), rec.data(), nb};
+    return planes_ahc_core(&hb, depth, w, h, stride, K4, depth_factor, planes, cap, n_planes, seg, member_offsets, member_idx);
 }
 
 /* drfe_planes_ahc_batch followed, on the same worker thread and frame, by the per-plane loop of Frame::ComputePlanes

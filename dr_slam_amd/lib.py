@@ -37,7 +37,7 @@ SYMBOLS = (
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
     "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
-    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch",
+    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -169,6 +169,7 @@ def load() -> C.CDLL:
     L.drfe_planes_ahc_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, vp, vp, f32, f64, vp, vp, vp, i32,
                                               C.POINTER(i32), C.POINTER(i32)]
     L.drfe_planes_ahc_post_batch.argtypes = [vp, vp, sz, i32, i32, sz, i32, vp, f32, f32, f64, vp, i32, vp, vp, vp, vp, vp, i32]
+    L.drfe_planes_ahc_from_blocks.argtypes = [vp, vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
     L.drfe_planes_cape_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, vp, vp, i32, f32, f64, vp, vp, vp, i32,
                                                C.POINTER(i32), C.POINTER(i32)]
     L.drfe_surface_normals.argtypes = [vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
@@ -199,6 +200,25 @@ def lsd_segments_host(modgrad, angles, cs, max_grad):
     if rc != 0:
         raise DrfeError(f"drfe_lsd_segments_host failed ({rc})")
     return out[:n.value].copy()
+
+
+def planes_ahc_from_blocks(blocks17, valid, N, depth16, K4, depth_factor, cap=64):
+    """The host half of the AHC extractor on given block fits (no device) -> dict(planes, seg, members)."""
+    L = load()
+    d = np.ascontiguousarray(depth16, np.uint16)
+    h, w = d.shape
+    b = np.ascontiguousarray(blocks17, np.float64)
+    vn = np.ascontiguousarray(np.stack([valid, N], 1), np.int32)
+    planes = np.zeros(cap, PLANE_DTYPE)
+    n = C.c_int()
+    seg = np.zeros((h, w), np.uint8)
+    off = np.zeros(cap + 1, np.int32)
+    idx = np.zeros(h * w, np.int32)
+    rc = L.drfe_planes_ahc_from_blocks(_p(b), _p(vn), _p(d), w, h, w, _p(np.ascontiguousarray(K4, np.float32)), np.float32(depth_factor),
+                                       _p(planes), cap, C.byref(n), _p(seg), _p(off), _p(idx))
+    if rc != 0:
+        raise DrfeError(f"drfe_planes_ahc_from_blocks failed ({rc})")
+    return dict(planes=planes[:n.value].copy(), seg=seg, members=[idx[off[i]:off[i + 1]].copy() for i in range(n.value)])
 
 
 def plane_voxel_grid(xyz, leaf=0.05):

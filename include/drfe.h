@@ -461,6 +461,12 @@ int drfe_planes_ahc_batch(drfe_ctx* ctx, const uint16_t* depth, size_t frame_str
 int drfe_planes_ahc_blocks(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
                            float depth_factor, double* blocks17, int32_t* valid_n, int cap);
 
+/* The host half of drfe_planes_ahc on caller-supplied block fits (the records drfe_planes_ahc_blocks returns), without a device:
+ * graph, agglomerative clustering, block membership, flood fill, re-merge and labels.  Host code: CPU tests and profiling. */
+int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, const uint16_t* depth, int w, int h, size_t stride,
+                                const float* K4, float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
+                                int32_t* member_offsets, int32_t* member_idx);
+
 /* PlaneDetection_CAPE (replaces src/PlaneExtractor.cpp:65-191 + src/CAPE/{CAPE,PlaneSeg,Histogram}.cpp;
  * its thread launch is commented out in the reference, src/Frame.cc:129, but the class is public API).
  * One entry of plane_params (CAPE PlaneSeg: normal, d, mean, MSE, score, nr_pts). */

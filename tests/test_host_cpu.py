@@ -279,3 +279,22 @@ def test_lsd_host_stages_without_a_device(oracle_mod):
         L = o["lines"]
         ref = np.stack([L["startPointX"], L["startPointY"], L["endPointX"], L["endPointY"]], 1)
         assert np.array_equal(e.view(np.uint32), ref.view(np.uint32))
+
+
+def test_ahc_host_stages_without_a_device(oracle_mod):
+    """The host half of the product's AHC extractor (graph, clustering, membership, flood fill, re-merge, labels) on the oracle's
+    block fits: same planes, label image and member lists as the oracle.  No device involved (drfe_planes_ahc_from_blocks)."""
+    from dr_slam_amd import lib, synth
+    for cam, kind, seed in ((synth.TUM3, "room_boxes", 2), (synth.ICL, "living_room", 3)):
+        _, d, _ = next(synth.sequence(seed, 1, cam=cam, kind=kind))
+        K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+        o = oracle_mod.ahc_planes(d, K4, inv)
+        g = lib.planes_ahc_from_blocks(o["blocks"], o["block_valid"], o["block_N"], d, K4, inv)
+        assert len(g["planes"]) == len(o["planes"]) >= 2
+        assert np.array_equal(g["seg"], o["seg"])
+        assert np.array_equal(g["planes"]["normal"].view(np.uint64), o["planes"][:, 0:3].view(np.uint64))
+        assert np.array_equal(g["planes"]["center"].view(np.uint64), o["planes"][:, 3:6].view(np.uint64))
+        assert np.array_equal(g["planes"]["n_points"], o["N"])
+        for a, b in zip(g["members"], o["members"]):
+            assert np.array_equal(a, b)
