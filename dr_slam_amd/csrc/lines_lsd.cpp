@@ -40,11 +40,11 @@ const double kNotDef = -1024.0, kTwoPi = 2.0 * M_PI, kThreeHalfPi = 3.0 * M_PI /
 
 struct RPt { int x, y; double angle, modgrad; };
 /* one pixel of the pseudo-ordering: gradient bin << 32 | y << 16 | x.  std::sort's permutation depends on the comparator's
- * answers only (it looks at the bin), so sorting these 8-byte keys orders the pixels exactly as sorting OpenCV's 12-byte
+ * answers only (it looks at the bin), so sorting these 4-byte keys orders the pixels exactly as sorting OpenCV's 12-byte
  * normPoint records does, with a third less memory traffic */
-typedef uint64_t OPt;
-static inline int opt_x(OPt k) { return (int)(k & 0xFFFF); }
-static inline int opt_y(OPt k) { return (int)((k >> 16) & 0xFFFF); }
+typedef uint32_t OPt;       /* gradient bin (10 bits) << 22 | y (11 bits) << 11 | x (11 bits): 4-byte keys, the array of a 512 x 384
+                               field fits the L2; fields up to 2048 x 2048 (checked by the caller) */
+#define LSD_ORDER_IDX_BITS 22
 struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
 /* sequential half of cv::LineSegmentDetectorImpl, fed with the device-computed gradient fields */
@@ -65,9 +65,9 @@ public:
         order_.reserve((size_t)(W - 1) * (H - 1));
         for (int y = 0; y < H - 1; ++y)
             for (int x = 0; x < W - 1; ++x)
-                order_.push_back(((uint64_t)(uint32_t)int(mod_[(size_t)y * W + x] * binCoef) << 32) | ((uint64_t)y << 16) | (uint64_t)x);
+                order_.push_back(((uint32_t)int(mod_[(size_t)y * W + x] * binCoef) << LSD_ORDER_IDX_BITS) | ((uint32_t)y << 11) | (uint32_t)x);
         /* std::sort, as OpenCV: the order of equal bins is whatever libstdc++'s introsort leaves */
-        std::sort(order_.begin(), order_.end(), [](const OPt& a, const OPt& b) { return (int)(a >> 32) > (int)(b >> 32); });
+        std::sort(order_.begin(), order_.end(), [](const OPt& a, const OPt& b) { return (a >> LSD_ORDER_IDX_BITS) > (b >> LSD_ORDER_IDX_BITS); });
         logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     }
 
@@ -84,7 +84,7 @@ public:
          * (whose `used` bookkeeping is the sequential part) and evaluated for all rectangles of the frame at once */
         std::vector<RectD> pending;
         for (const OPt& key : order_) {
-            const struct { int x, y; } s = {opt_x(key), opt_y(key)};
+            const struct { int x, y; } s = {(int)(key & 0x7FFu), (int)((key >> 11) & 0x7FFu)};
             if (used_[(size_t)s.y * W_ + s.x]) continue;          /* claimed, or no angle */
             double regAngle;
             if (!timed_) {
@@ -510,6 +510,7 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
     int rc = ensure_lines(c, w, h);
     if (rc != DRFE_OK) return rc;
     LinesScratch* s = c->ls;
+    if (s->sw > 2048 || s->sh > 2048) { c->err = "lsd_extract: image larger than 2560 x 2560 (pixel-ordering keys)"; return DRFE_ERR_INVALID; }
     /* LineSegmentDetector defaults: scale 0.8, sigma_scale 0.6 -> sigma 0.75, 7x7 kernel; quant 2, ang_th 22.5 */
     const double sigma = 0.6 / 0.8;
     const int hk = (int)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
@@ -732,7 +733,7 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
 int drfe_lsd_segments_host(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad, float* segs,
                            int cap, int* n_segs)
 {
-    if (!modgrad || !angles || !cs || !n_segs || W < 4 || H < 4) return DRFE_ERR_INVALID;
+    if (!modgrad || !angles || !cs || !n_segs || W < 4 || H < 4 || W > 2048 || H > 2048) return DRFE_ERR_INVALID;
     std::vector<uint8_t> used;
     std::vector<OPt> order;
     SegmentFinder finder(W, H, modgrad, angles, cs, max_grad, used, order);
