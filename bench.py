@@ -411,7 +411,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=384, help="frames per step per GPU")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent batches in flight per GPU: consecutive steps alternate between this many contexts, each on "
+                         "its own stream, so that the latency-bound kernels of one batch (quadtree, claim resolution) run beside "
+                         "the VALU-bound ones of the other (1 = one context, one stream)")
     ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4),
                     help="BASELINE.json config: 2 = TUM3 single sequence, 4 = TUM1/2/3 mix, one 256-frame sequence "
                          "per rank; 0 = config 2 at one rank, config 4 at N > 1")
@@ -468,15 +472,19 @@ def main():
 
     B = args.batch
     gray, depth, Tcw, Twc = make_batch(base, B)
-    fe = FrontEnd(cam, max_batch=B, device=local_rank)
+    nfl = max(1, args.inflight)
+    fes = [FrontEnd(cam, max_batch=B, device=local_rank) for _ in range(nfl)]
+    fe = fes[0]
     gray_t = torch.from_numpy(gray).to(dev)
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
+    streams = [s.cuda_stream for s in tstreams]
+    stream = streams[0]
 
     if world > 1 or args.bow:
         # the one initial exchange of the sharded mode: rank 0 owns the ORB vocabulary
         # (k=10, L=6, ~50 MB flattened; synthetic because the reference's ORBvoc blob is missing) and
-        # broadcasts it over RCCL/xGMI; every rank uploads its copy into its own context.
+        # broadcasts it over RCCL/xGMI; every rank uploads its copy into its own context(s).
         from dr_slam_amd import vocabulary as V
         if rank == 0:
             blob = V.make_synthetic(10, 6, seed=1).pack()
@@ -487,12 +495,20 @@ def main():
         if rank != 0:
             blob = np.zeros(int(size[0]), np.uint8)
         blob = sharding.broadcast_tables(blob, dev, dist if world > 1 else None)
-        V.Vocabulary.unpack(blob).upload(fe.ctx)
+        voc = V.Vocabulary.unpack(blob)
+        for f in (fes if args.bow else fes[:1]):
+            voc.upload(f.ctx)
 
-    def step():
-        fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
+    nstep = [0]
+
+    def step(k=None):
+        """One batch through the hot path on context / stream k (default: round robin over the batches in flight)."""
+        if k is None:
+            k = nstep[0] % nfl
+            nstep[0] += 1
+        fes[k].process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=streams[k])
         if args.bow:   # Frame::ComputeBoW tree descent for every frame of the batch (not part of the metric)
-            fe.ctx.bow_transform_batch(4, B, stream)
+            fes[k].ctx.bow_transform_batch(4, B, streams[k])
 
     for _ in range(args.warmup):
         step()
@@ -511,10 +527,11 @@ def main():
     el, total_frames = sharding.reduce_elapsed_and_frames(el, B * args.steps, dev, dist if world > 1 else None)
 
     # sanity: the batch really produced keypoints and matches
-    counts = fe.ctx.orb_counts(B)
-    _, nm = fe.matches(B - 1)
-    if not os.environ.get("DRFE_BENCH_NO_SANITY"):      # kernel experiments with deliberately wrong results
-        assert counts.min() > 500 and nm > 100, (counts.min(), nm)
+    for f in fes:
+        counts = f.ctx.orb_counts(B)
+        _, nm = f.matches(B - 1)
+        if not os.environ.get("DRFE_BENCH_NO_SANITY"):      # kernel experiments with deliberately wrong results
+            assert counts.min() > 500 and nm > 100, (counts.min(), nm)
 
     out = None
     if rank == 0:
@@ -523,7 +540,7 @@ def main():
         acc = {}
         reps = max(3, min(args.steps, 10))
         for _ in range(reps):
-            step()
+            step(0)                                     # one context, one stream: clean per-kernel times
             ms = fe.ctx.profile_stage_ms()
             for k, v in ms.items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -564,7 +581,7 @@ def main():
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[config], "baseline_config": config, "batch_per_gpu": B,
-                       "frames_per_step": world * B, "sequence_frames_per_rank": len(base),
+                       "frames_per_step": world * B, "batches_in_flight_per_gpu": nfl, "sequence_frames_per_rank": len(base),
                        "sharding": "one sequence per GPU, no data-path collective"},
             "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "limited_by": "valu issue (byte-wise image work: %s of the kernel's cycles issue VALU "
@@ -577,6 +594,8 @@ def main():
         }
         out["parity"] = "bit-exact vs the in-repo CPU oracle; the oracle restates OpenCV 3.4 / Eigen 3.3.7 / PCL 1.9 and is UNPINNED " \
                         "against the real libraries (none can be built here)"
+        for f in fes[1:]:
+            f.ctx.close()
         if world == 1 and not args.no_extras:
             fps_hf, ms_hf = host_fed_rate(fe, gray, depth, Tcw, Twc, B, max(4, min(args.steps, 10)), dev)
             out["value_host_fed"] = fps_hf

@@ -8,18 +8,18 @@ from dr_slam_amd.pipeline import FrontEnd
 cam = synth.TUM3
 base = sharding.render_sequence(10, 8, cam, "room_boxes", workers=8)
 dev = torch.device("cuda", 0)
-for B in (512, 256):
+for B, S in ((512, 1), (384, 2), (256, 2), (192, 3), (128, 4), (512, 1), (384, 2), (256, 2), (192, 3), (128, 4)):
     gray, depth, Tcw, Twc = bench.make_batch(base, B)
     g = torch.from_numpy(gray).to(dev); d = torch.from_numpy(depth.view(np.int16)).to(dev)
-    fes = [FrontEnd(cam, max_batch=B), FrontEnd(cam, max_batch=B)]
-    ss = [torch.cuda.Stream(), torch.cuda.Stream()]
-    def run(n, two):
+    fes = [FrontEnd(cam, max_batch=B) for _ in range(S)]
+    ss = [torch.cuda.Stream() for _ in range(S)]
+    def run(n):
         torch.cuda.synchronize(); t = time.perf_counter()
         for i in range(n):
-            k = (i & 1) if two else 0
+            k = i % S
             fes[k].process(g, d, Tcw, Twc, th=15.0, check_ori=True, stream=ss[k].cuda_stream)
         torch.cuda.synchronize()
         return B * n / (time.perf_counter() - t)
-    run(4, True)
-    print("batch", B, "one stream", round(run(20, False)), "two streams", round(run(20, True)), "frames/s")
+    run(2 * S)
+    print("batch", B, "x", S, "streams:", [round(run(12 * S)) for _ in range(3)], "frames/s")
     for f in fes: f.ctx.close()
