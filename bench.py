@@ -411,11 +411,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=384, help="frames per step per GPU")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--inflight", type=int, default=1,
                     help="independent batches in flight per GPU: consecutive steps alternate between this many contexts, each on "
                          "its own stream, so that the latency-bound kernels of one batch (quadtree, claim resolution) run beside "
-                         "the VALU-bound ones of the other (1 = one context, one stream)")
+                         "the VALU-bound ones of the other.  Measured: --batch 384 --inflight 2 reaches 221-226 k frames/s against "
+                         "203 k for the default, but only after ~50 steps of ramp-up (tools/two_stream_probe.py), so a 20-step run "
+                         "reads lower: not the default")
     ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4),
                     help="BASELINE.json config: 2 = TUM3 single sequence, 4 = TUM1/2/3 mix, one 256-frame sequence "
                          "per rank; 0 = config 2 at one rank, config 4 at N > 1")
@@ -477,7 +479,8 @@ def main():
     fe = fes[0]
     gray_t = torch.from_numpy(gray).to(dev)
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
-    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
+    # own (non-default) streams when batches overlap: work on the null stream does not run beside other streams
+    tstreams = [torch.cuda.current_stream()] if nfl == 1 else [torch.cuda.Stream() for _ in range(nfl)]
     streams = [s.cuda_stream for s in tstreams]
     stream = streams[0]
 

@@ -5,7 +5,7 @@
 # tracing; everything lands under gpurun_out/<tag>_*; tools/pmc_traffic.py folds the counter CSVs into profiles/.
 set -u
 TAG=${1:-r02}
-B=${2:-384}
+B=${2:-512}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
