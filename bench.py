@@ -415,9 +415,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent batches in flight per GPU: consecutive steps alternate between this many contexts, each on "
                          "its own stream, so that the latency-bound kernels of one batch (quadtree, claim resolution) run beside "
-                         "the VALU-bound ones of the other.  Measured: --batch 384 --inflight 2 reaches 221-226 k frames/s against "
-                         "203 k for the default, but only after ~50 steps of ramp-up (tools/two_stream_probe.py), so a 20-step run "
-                         "reads lower: not the default")
+                         "the VALU-bound ones of the other.  Measured: 220-226 k frames/s against 203 k for the default when it works, "
+                         "176-194 k when the two arena sets land badly (tools/two_stream_probe2.py): not the default")
     ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4),
                     help="BASELINE.json config: 2 = TUM3 single sequence, 4 = TUM1/2/3 mix, one 256-frame sequence "
                          "per rank; 0 = config 2 at one rank, config 4 at N > 1")
