@@ -16,6 +16,7 @@
 #include "drfe_internal.h"
 #include "planes_internal.h"
 #include "ahc_math.h"
+#include "ahc_math_simd.h"
 #include "post_internal.h"
 
 #include <algorithm>
@@ -116,36 +117,89 @@ static double tAngInit(double z)
 /* merged statistics of two nodes (ahc::PlaneSeg(pa, pb): sums added, plane refitted) without the neighbour list */
 struct Merged { double S[9]; int N, rid; AhcFit fit; };
 
+/* The plane fits of n trial merges (their sums in m[i].S / m[i].N): W at a time in the lanes of the host's vector unit
+ * (ahc_math_simd.h: bit-identical to the scalar routine), scalar where the CPU has neither AVX2 nor AVX-512F. */
+template <int W>
+static inline __attribute__((always_inline)) void solve_trials_w(Merged* m, int n)
+{
+    for (int i = 0; i < n; i += W) {
+        double S[9][W];
+        int N[W];
+        AhcFit fit[W];
+        for (int l = 0; l < W; l++) {
+            const Merged& t = m[std::min(i + l, n - 1)];         /* idle lanes repeat the last trial */
+            for (int k = 0; k < 9; k++) S[k][l] = t.S[k];
+            N[l] = t.N;
+        }
+        ahc_simd::plane_from_sums<W>(S, N, fit);
+        for (int l = 0; l < W && i + l < n; l++) m[i + l].fit = fit[l];
+    }
+}
+/* AVX2: 8 lanes as two 4-wide registers per value - the two halves' division / square-root chains overlap (1.53 ms against
+ * 1.74 ms with 4 lanes for the 32 000 trials of the room frame on the EPYC 9575F; AVX-512F: 1.10 ms; scalar 4.47 ms) */
+__attribute__((target("avx2"))) static void solve_trials_avx2(Merged* m, int n) { solve_trials_w<8>(m, n); }
+__attribute__((target("avx512f"))) static void solve_trials_avx512(Merged* m, int n) { solve_trials_w<8>(m, n); }
+
+static void solve_trials_scalar(Merged* m, int n)
+{
+    for (int i = 0; i < n; i++) ahc_plane_from_sums(m[i].S, m[i].N, &m[i].fit);
+}
+/* mode: 0 scalar, 1 AVX2 (8 lanes in two registers), 2 AVX-512F (8 lanes); -1: the widest this CPU has (DRFE_AHC_SIMD=0/1/2 overrides) */
+static void solve_trials(Merged* m, int n, int mode = -1)
+{
+    static const int best = [] {
+        int b = 0;
+        if (__builtin_cpu_supports("avx2")) b = 1;
+        if (__builtin_cpu_supports("avx512f")) b = 2;
+        if (const char* e = std::getenv("DRFE_AHC_SIMD")) b = std::min(b, std::max(0, std::atoi(e)));
+        return b;
+    }();
+    if (mode < 0) mode = best;
+    if (mode == 2 && n > 4) solve_trials_avx512(m, n);
+    else if (mode >= 1 && n > 1) solve_trials_avx2(m, n);
+    else solve_trials_scalar(m, n);
+}
+
 /* ahCluster: pops min-MSE nodes, merges with the neighbour giving the least merged MSE.
  * Measured on the host harness (drfe_planes_ahc_from_blocks, room frame: 1525 steps): 31 600 trial solves, ~21 per step - a
  * grown plane tries every block of its boundary - and they are the cost (9.2 of 9.9 ms there).  An edge dies with the first
  * of its end points to be popped (merged or extracted), so no trial is ever asked for twice: a per-pair cache cannot hit
  * (tried: 7.0 ms against 5.1 ms on the box).  Skipping trials by the eigenvalue bound 4 det / tr^2 pruned 1.4 % of them: the
- * candidates of a step are blocks of the same plane and their merged MSEs differ by percents, not factors. */
+ * candidates of a step are blocks of the same plane and their merged MSEs differ by percents, not factors.  What does help:
+ * the trials of one step are independent, so they are solved side by side in vector lanes (solve_trials): 4.47 -> 1.10 ms for
+ * the solves, 5.2 -> 1.8 ms for ahCluster on the EPYC 9575F of the GPU box (profiles/r02_ahc_simd_modes.txt). */
 static void cluster(Graph& g, MinQ& q, std::vector<int>& extracted)
 {
     const int maxStep = 100000;
     int step = 0;
-    std::vector<int> nbs, u;
+    std::vector<int> nbs, u, trialNb;
+    std::vector<Merged> trials;
     while (!q.empty() && step <= maxStep) {
         const int p = q.top().id;
         q.pop();
         if (g.nodes[p].nouse) continue;
         int candNb = -1;
-        Merged best, m;
         const Merged* cand = nullptr;
         nbs = g.nodes[p].nbs;
+        trials.clear();
+        trialNb.clear();
         for (int nb : nbs) {
             if (g.similarity(p, nb) < kCos60) continue;
+            Merged m;
             const Node &a = g.nodes[p], &b = g.nodes[nb];
             for (int k = 0; k < 9; k++) m.S[k] = a.S[k] + b.S[k];
             m.N = a.N + b.N;
             m.rid = a.N >= b.N ? a.rid : b.rid;
-            ahc_plane_from_sums(m.S, m.N, &m.fit);
-            if (!cand || best.fit.mse > m.fit.mse || (best.fit.mse == m.fit.mse && best.N < m.fit.mse)) {
-                best = m;
-                cand = &best;
-                candNb = nb;
+            trials.push_back(m);
+            trialNb.push_back(nb);
+        }
+        /* the ~21 trial fits of a step are independent: solved side by side, then folded in neighbour order */
+        solve_trials(trials.data(), (int)trials.size());
+        for (size_t t = 0; t < trials.size(); t++) {
+            const Merged& m = trials[t];
+            if (!cand || cand->fit.mse > m.fit.mse || (cand->fit.mse == m.fit.mse && cand->N < m.fit.mse)) {
+                cand = &m;
+                candNb = trialNb[t];
             }
         }
         if (cand && cand->fit.mse < tMseMerge(cand->fit.center[2])) {
@@ -600,6 +654,25 @@ int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_strid
     for (std::thread& t : th) t.join();
     for (int k = 0; k < T; k++)
         if (rcs[k] != DRFE_OK) { c->err = (*pool)[k].err; return rcs[k]; }
+    return DRFE_OK;
+}
+
+/* Test hook: the plane fits of n (sums, N) records by the scalar routine (mode 0), the 4-lane (1) or the 8-lane (2) vector
+ * instantiation; out8 = center, normal, mse, curvature per record.  Returns DRFE_ERR_STATE if the CPU lacks the mode. */
+int drfe_debug_ahc_trials(const double* sums9, const int32_t* N, int n, int mode, double* out8)
+{
+    if (!sums9 || !N || !out8 || n < 0 || mode < 0 || mode > 2) return DRFE_ERR_INVALID;
+    if ((mode == 1 && !__builtin_cpu_supports("avx2")) || (mode == 2 && !__builtin_cpu_supports("avx512f"))) return DRFE_ERR_STATE;
+    std::vector<Merged> m((size_t)n);
+    for (int i = 0; i < n; i++) { std::memcpy(m[i].S, sums9 + 9 * (size_t)i, 72); m[i].N = N[i]; m[i].rid = 0; }
+    if (mode == 0) solve_trials_scalar(m.data(), n);
+    else if (mode == 1) solve_trials_avx2(m.data(), n);
+    else solve_trials_avx512(m.data(), n);
+    for (int i = 0; i < n; i++) {
+        double* o = out8 + 8 * (size_t)i;
+        std::memcpy(o, m[i].fit.center, 24); std::memcpy(o + 3, m[i].fit.normal, 24);
+        o[6] = m[i].fit.mse; o[7] = m[i].fit.curvature;
+    }
     return DRFE_OK;
 }
 

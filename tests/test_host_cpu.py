@@ -298,3 +298,56 @@ def test_ahc_host_stages_without_a_device(oracle_mod):
         assert np.array_equal(g["planes"]["n_points"], o["N"])
         for a, b in zip(g["members"], o["members"]):
             assert np.array_equal(a, b)
+
+
+def test_ahc_vector_trial_solver_equals_scalar():
+    """ahc_math_simd.h: the 4-lane (AVX2) and 8-lane (AVX-512F) instantiations of the AHC trial-merge fit against the scalar
+    routine, bit for bit, on point-cloud statistics of every kind the clustering meets and on degenerate ones."""
+    import ctypes as C
+    from dr_slam_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(5)
+    recs, Ns = [], []
+
+    def add(P):
+        P = np.asarray(P, np.float64)
+        x, y, z = P[:, 0], P[:, 1], P[:, 2]
+        recs.append([x.sum(), y.sum(), z.sum(), (x * x).sum(), (y * y).sum(), (z * z).sum(), (x * y).sum(), (y * z).sum(), (x * z).sum()])
+        Ns.append(len(P))
+
+    for _ in range(3000):
+        n = int(rng.integers(100, 30000))
+        m = min(n, 400)
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        a = np.cross(nrm, [1, 0, 0.3]); a /= np.linalg.norm(a); b = np.cross(nrm, a)
+        ext = rng.uniform(0.05, 3.0, 2)
+        P = rng.uniform(0.5, 4.0) * nrm + rng.uniform(-1, 1, (m, 1)) * ext[0] * a + rng.uniform(-1, 1, (m, 1)) * ext[1] * b \
+            + rng.normal(0, rng.choice([0, 1e-4, 3e-3, 0.05]), (m, 1)) * nrm
+        add(P)
+        Ns[-1] = n                                   # sums of m points presented as N = n: exercises odd scalings too
+    add(np.ones((100, 3)))                           # zero covariance
+    add(np.zeros((100, 3)))                          # all-zero sums (scale == 0 branch)
+    add(np.stack([np.linspace(0, 1, 100), np.zeros(100), np.ones(100)], 1))          # a line: two zero eigenvalues
+    add(np.stack([np.linspace(0, 1, 100), np.linspace(0, 2, 100), np.full(100, 2.0)], 1))
+    g = np.stack(np.meshgrid(np.arange(10.0), np.arange(10.0)), -1).reshape(-1, 2)
+    add(np.concatenate([g, np.full((100, 1), 1.5)], 1))                             # exact axis-aligned plane (no Householder step)
+    add(np.concatenate([np.full((100, 1), -2.0), g], 1))
+    S = np.ascontiguousarray(recs, np.float64)
+    N = np.ascontiguousarray(Ns, np.int32)
+    out = {}
+    for mode in (0, 1, 2):
+        o = np.zeros((len(S), 8))
+        rc = L.drfe_debug_ahc_trials(S.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), len(S), mode, o.ctypes.data_as(C.c_void_p))
+        if rc == -4:
+            continue                                  # this CPU lacks the vector width
+        assert rc == 0
+        out[mode] = o
+    assert 0 in out and len(out) >= 2, "no vector instantiation available on this host"
+    for mode, o in out.items():
+        same = (o.view(np.uint64) == out[0].view(np.uint64)) | (np.isnan(o) & np.isnan(out[0]))
+        assert same.all(), (mode, np.argwhere(~same)[:5])
+    for n in (1, 2, 3, 5, 9):                         # ragged tails: fewer records than lanes
+        o1, o0 = np.zeros((n, 8)), np.zeros((n, 8))
+        for mode, o in ((max(k for k in out), o1), (0, o0)):
+            assert L.drfe_debug_ahc_trials(S.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), n, mode, o.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(o1.view(np.uint64), o0.view(np.uint64))
