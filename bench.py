@@ -323,7 +323,7 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    line_threads = max(1, (ncpu * 11) // 16)
+    line_threads = max(1, (ncpu * 12) // 16)      # lines 16 ms, AHC + post-processing ~5 ms per frame: 3 : 1
     plane_threads = max(1, ncpu - line_threads)
     ctx_planes = lib.Context(max_batch=1)
     ctx_cape = lib.Context(max_batch=1)

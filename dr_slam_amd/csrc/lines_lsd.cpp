@@ -11,6 +11,7 @@
 #include "drfe_internal.h"
 #include "lines_internal.h"
 #include "../../include/drfe_math.h"
+#include "lsd_order_sort.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -53,8 +54,8 @@ public:
     /* used / order: caller-owned buffers that survive between frames (a lane reuses them: no multi-megabyte
      * allocation, hence no mmap/page-fault traffic, per frame) */
     SegmentFinder(int W, int H, const double* modgrad, const double* angles, const float* cs, double maxGrad,
-                  std::vector<uint8_t>& used, std::vector<OPt>& order)
-        : W_(W), H_(H), mod_(modgrad), ang_(angles), cs_(cs), used_(used), order_(order)
+                  std::vector<uint8_t>& used, std::vector<OPt>& order, std::vector<OPt>& orderTmp)
+        : W_(W), H_(H), mod_(modgrad), ang_(angles), cs_(cs), used_(used), order_(order), orderTmp_(orderTmp)
     {
         /* 0 = free, 1 = claimed, 2 = no level-line angle (never joins a region): the probe of a neighbour then reads the
          * compact byte map only, not the angle field, for the third of the pixels that can never pass */
@@ -66,8 +67,11 @@ public:
         for (int y = 0; y < H - 1; ++y)
             for (int x = 0; x < W - 1; ++x)
                 order_.push_back(((uint32_t)int(mod_[(size_t)y * W + x] * binCoef) << LSD_ORDER_IDX_BITS) | ((uint32_t)y << 11) | (uint32_t)x);
-        /* std::sort, as OpenCV: the order of equal bins is whatever libstdc++'s introsort leaves */
-        std::sort(order_.begin(), order_.end(), [](const OPt& a, const OPt& b) { return (a >> LSD_ORDER_IDX_BITS) > (b >> LSD_ORDER_IDX_BITS); });
+        /* std::sort, as OpenCV: the order of equal bins is whatever libstdc++'s introsort leaves - reproduced move for move by
+         * lsd_order::sort (lsd_order_sort.h) without the per-element branch mispredictions; DRFE_LSD_STD_SORT=1 calls std::sort */
+        static const bool stdSort = std::getenv("DRFE_LSD_STD_SORT") != nullptr;
+        if (stdSort) std::sort(order_.begin(), order_.end(), lsd_order::Before());
+        else lsd_order::sort(order_.data(), order_.size(), orderTmp_);
         logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     }
 
@@ -127,6 +131,7 @@ private:
     const float* cs_;                /* device-computed (cos, sin) of float(angle) per pixel */
     std::vector<uint8_t>& used_;
     std::vector<OPt>& order_;
+    std::vector<OPt>& orderTmp_;
     double logNT_;
 
     static double sq(double v) { return v * v; }
@@ -440,7 +445,7 @@ struct LineHost {                     /* per-lane host buffers reused across fra
     std::vector<double> modgrad, angles;
     std::vector<float> cs;
     std::vector<uint8_t> used;
-    std::vector<OPt> order;
+    std::vector<OPt> order, orderTmp;
 };
 struct LineWorker {
     std::string err;
@@ -537,7 +542,7 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
 
     const auto tDev = std::chrono::steady_clock::now();
     std::vector<float> segs;
-    SegmentFinder finder(s->sw, s->sh, modgrad.data(), angles.data(), H.cs.data(), maxGrad, H.used, H.order);
+    SegmentFinder finder(s->sw, s->sh, modgrad.data(), angles.data(), H.cs.data(), maxGrad, H.used, H.order, H.orderTmp);
     const auto tSort = std::chrono::steady_clock::now();
     finder.timed_ = trace;
     int countRc = DRFE_OK;
@@ -735,8 +740,8 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
 {
     if (!modgrad || !angles || !cs || !n_segs || W < 4 || H < 4 || W > 2048 || H > 2048) return DRFE_ERR_INVALID;
     std::vector<uint8_t> used;
-    std::vector<OPt> order;
-    SegmentFinder finder(W, H, modgrad, angles, cs, max_grad, used, order);
+    std::vector<OPt> order, orderTmp;
+    SegmentFinder finder(W, H, modgrad, angles, cs, max_grad, used, order, orderTmp);
     std::vector<float> out;
     auto counts = [&](const std::vector<RectCand>& cands, std::vector<int2>& res) -> bool {
         res.resize(cands.size());
@@ -751,6 +756,22 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
     *n_segs = (int)(out.size() / 4);
     if (*n_segs > cap) return DRFE_ERR_CAPACITY;
     if (segs && !out.empty()) std::memcpy(segs, out.data(), out.size() * sizeof(float));
+    return DRFE_OK;
+}
+
+/* Test hook of lsd_order_sort.h: keys[n] (bin << 22 | y << 11 | x) sorted in place.  mode 0: std::sort with LSD's comparator;
+ * 1 / 2: lsd_order::sort with scalar / AVX2 stopper masks; 3: the plain transcription of libstdc++'s introsort.  depth_limit
+ * >= 0 replaces 2 lg n (modes 1-3).  DRFE_ERR_STATE for mode 2 on a CPU without AVX2. */
+int drfe_debug_lsd_order_sort(uint32_t* keys, size_t n, int mode, int depth_limit)
+{
+    if (!keys || mode < 0 || mode > 3) return DRFE_ERR_INVALID;
+    std::vector<uint32_t> tmp;
+    if (mode == 0) std::sort(keys, keys + n, lsd_order::Before());
+    else if (mode == 3) lsd_order::reference_sort(keys, n, depth_limit);
+    else {
+        if (mode == 2 && !__builtin_cpu_supports("avx2")) return DRFE_ERR_STATE;
+        lsd_order::sort(keys, n, tmp, mode - 1, depth_limit);
+    }
     return DRFE_OK;
 }
 

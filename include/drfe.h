@@ -462,9 +462,14 @@ int drfe_planes_ahc_blocks(drfe_ctx* ctx, const uint16_t* depth, int w, int h, s
                            float depth_factor, double* blocks17, int32_t* valid_n, int cap);
 
 /* Test hook of the vectorised trial-merge solver of the AHC clustering (dr_slam_amd/csrc/ahc_math_simd.h): plane fits of n (nine
- * sums, N) records by the scalar routine (mode 0), its 4-lane AVX2 (1) or 8-lane AVX-512F (2) instantiation; out8 = center,
+ * sums, N) records by the scalar routine (mode 0), its 8-lane AVX2 (1) or 8-lane AVX-512F (2) instantiation; out8 = center,
  * normal, mse, curvature per record.  DRFE_ERR_STATE if this CPU lacks the mode.  Host code. */
 int drfe_debug_ahc_trials(const double* sums9, const int32_t* N, int n, int mode, double* out8);
+/* Test hook of LSD's pseudo-ordering (dr_slam_amd/csrc/lsd_order_sort.h): keys[n] = gradient bin << 22 | y << 11 | x sorted in place
+ * by descending bin.  mode 0: std::sort with cv::LineSegmentDetectorImpl's comparator (lsd.cpp, compare_norm); 1 / 2: the
+ * product's restatement with scalar / AVX2 stopper masks; 3: the plain transcription of libstdc++'s introsort.  depth_limit >= 0
+ * replaces the 2 lg n of modes 1-3 (reaches the heap-sort branch).  DRFE_ERR_STATE if this CPU lacks AVX2 (mode 2).  Host code. */
+int drfe_debug_lsd_order_sort(uint32_t* keys, size_t n, int mode, int depth_limit);
 /* The host half of drfe_planes_ahc on caller-supplied block fits (the records drfe_planes_ahc_blocks returns), without a device:
  * graph, agglomerative clustering, block membership, flood fill, re-merge and labels.  Host code: CPU tests and profiling. */
 int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, const uint16_t* depth, int w, int h, size_t stride,

@@ -351,3 +351,51 @@ def test_ahc_vector_trial_solver_equals_scalar():
         for mode, o in ((max(k for k in out), o1), (0, o0)):
             assert L.drfe_debug_ahc_trials(S.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), n, mode, o.ctypes.data_as(C.c_void_p)) == 0
         assert np.array_equal(o1.view(np.uint64), o0.view(np.uint64))
+
+
+def test_lsd_pseudo_ordering_equals_std_sort():
+    """lsd_order_sort.h: the product's restatement of libstdc++'s introsort (mask-driven Hoare partitions + counting sort for the
+    final insertion sort) against std::sort with LSD's comparator itself - the permutation of equal bins included - on key arrays
+    of many sizes and bin distributions; with a forced depth limit (heap-sort branch) against the plain transcription, which is
+    itself compared with std::sort at the natural limit."""
+    import ctypes as C
+    from dr_slam_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(11)
+
+    def run(keys, mode, depth=-1):
+        k = keys.copy()
+        rc = L.drfe_debug_lsd_order_sort(k.ctypes.data_as(C.c_void_p), len(k), mode, depth)
+        if rc == -4:
+            return None                               # no AVX2 on this CPU
+        assert rc == 0
+        return k
+
+    def keys_of(bins):
+        bins = np.asarray(bins)
+        return ((bins.astype(np.uint32) << 22) | (np.arange(len(bins), dtype=np.uint32) & 0x3FFFFF)).astype(np.uint32)
+
+    cases = []
+    for trial in range(600):
+        n = int(rng.integers(0, 6000)) if trial % 3 else int(rng.integers(0, 300))
+        kind = trial % 7
+        if kind == 0: b = rng.integers(0, 1024, n)
+        elif kind == 1: b = rng.integers(0, 4, n)
+        elif kind == 2: b = np.full(n, 7)
+        elif kind == 3: b = np.minimum(1023, rng.exponential(20, n).astype(int))
+        elif kind == 4: b = np.sort(rng.integers(0, 50, n))
+        elif kind == 5: b = np.sort(rng.integers(0, 50, n))[::-1]
+        else: b = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) % 1024     # organ pipe
+        cases.append(keys_of(b))
+    cases.append(keys_of(np.minimum(1023, rng.exponential(30, 511 * 383).astype(int))))          # one 512 x 384 field
+    for k in cases:
+        want = run(k, 0)
+        for mode in (1, 2, 3):
+            got = run(k, mode)
+            assert got is None or np.array_equal(got, want), (len(k), mode)
+        if len(k) < 6000:
+            for depth in (0, 1, 3):
+                want_d = run(k, 3, depth)
+                for mode in (1, 2):
+                    got = run(k, mode, depth)
+                    assert got is None or np.array_equal(got, want_d), (len(k), mode, depth)
