@@ -323,30 +323,44 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    line_threads = max(1, (ncpu * 12) // 16)      # lines 16 ms, AHC + post-processing ~5 ms per frame: 3 : 1
-    plane_threads = max(1, ncpu - line_threads)
+    split = {"lines": max(1, (ncpu * 3) // 4)}
+    split["planes"] = max(1, ncpu - split["lines"])
     ctx_planes = lib.Context(max_batch=1)
     ctx_cape = lib.Context(max_batch=1)
+    wall = {}
+
+    def timed(name, fn):
+        t = time.perf_counter()
+        r = fn()
+        wall[name] = (time.perf_counter() - t) * 1e3
+        return r
 
     def planes():       # AHC planes + Frame::ComputePlanes' per-plane loop, frames across the C++ thread pool
-        _, n, _, na, _ = ctx_planes.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=plane_threads)
+        _, n, _, na, _ = ctx_planes.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=split["planes"])
         return len(n), int(na.sum())
 
     def cape():
         return sum(len(ctx_cape.planes_cape(depth_m[f], K4, 20)["planes"]) for f in range(n_frames))
 
     def step(pool):
-        fl = pool.submit(lambda: fe.ctx.lsd_extract_batch(gray, n_threads=line_threads))
-        fp = pool.submit(planes)
-        fc = pool.submit(cape)
+        fl = pool.submit(timed, "lines", lambda: fe.ctx.lsd_extract_batch(gray, n_threads=split["lines"]))
+        fp = pool.submit(timed, "ahc_planes", planes)
+        fc = pool.submit(timed, "cape", cape)
+        t = time.perf_counter()
         fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
         fe.ctx.surface_normals_batch_ptr(depth_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, K4, inv, 9.0, n_frames, stream)
         torch.cuda.synchronize()
+        wall["orb_match_normals_device"] = (time.perf_counter() - t) * 1e3
         nl, (npl, nacc), ncp = len(fl.result()), fp.result(), fc.result()
         assert nl == n_frames and npl == n_frames and ncp > 0
         return nacc
 
     with ThreadPoolExecutor(3) as pool:
+        step(pool)
+        # the two host pools are balanced from the warm-up step's own timing: thread-ms per frame of lines against planes
+        cl, cp = wall["lines"] * split["lines"], wall["ahc_planes"] * split["planes"]
+        split["lines"] = min(ncpu - 1, max(1, round(ncpu * cl / (cl + cp)))) if ncpu > 1 else 1
+        split["planes"] = max(1, ncpu - split["lines"])
         step(pool)
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -358,7 +372,8 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     return {"workload": "BASELINE config 3: living_room scene, ICL intrinsics, 640x480: ORB + glue + SearchByProjection + surface "
                         "normals batched on the device; LSD+LBD lines, AHC planes + post-processing, CAPE planes for every frame",
             "value": n_frames / el, "unit": "frames/s", "frames_per_step": n_frames, "ms_per_step": el * 1e3,
-            "host_threads": {"lines": line_threads, "ahc_planes": plane_threads, "cape": 1}, "host_cpus_available": ncpu,
+            "host_threads": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": 1}, "host_cpus_available": ncpu,
+            "stage_wall_ms_last_step": {k: round(v, 2) for k, v in wall.items()},
             "planes_accepted_per_step": int(nacc),
             "note": "bound by the sequential host stages of LSD (pixel ordering + region growing) and AHC (clustering): "
                     "scales with host threads, not with the GPU"}

@@ -11,7 +11,7 @@
 #include "drfe_internal.h"
 #include "lines_internal.h"
 #include "../../include/drfe_math.h"
-#include "lsd_order_sort.h"
+#include "introsort_restated.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -68,7 +68,7 @@ public:
             for (int x = 0; x < W - 1; ++x)
                 order_.push_back(((uint32_t)int(mod_[(size_t)y * W + x] * binCoef) << LSD_ORDER_IDX_BITS) | ((uint32_t)y << 11) | (uint32_t)x);
         /* std::sort, as OpenCV: the order of equal bins is whatever libstdc++'s introsort leaves - reproduced move for move by
-         * lsd_order::sort (lsd_order_sort.h) without the per-element branch mispredictions; DRFE_LSD_STD_SORT=1 calls std::sort */
+         * lsd_order::sort (introsort_restated.h) without the per-element branch mispredictions; DRFE_LSD_STD_SORT=1 calls std::sort */
         static const bool stdSort = std::getenv("DRFE_LSD_STD_SORT") != nullptr;
         if (stdSort) std::sort(order_.begin(), order_.end(), lsd_order::Before());
         else lsd_order::sort(order_.data(), order_.size(), orderTmp_);
@@ -759,18 +759,25 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
     return DRFE_OK;
 }
 
-/* Test hook of lsd_order_sort.h: keys[n] (bin << 22 | y << 11 | x) sorted in place.  mode 0: std::sort with LSD's comparator;
- * 1 / 2: lsd_order::sort with scalar / AVX2 stopper masks; 3: the plain transcription of libstdc++'s introsort.  depth_limit
- * >= 0 replaces 2 lg n (modes 1-3).  DRFE_ERR_STATE for mode 2 on a CPU without AVX2. */
-int drfe_debug_lsd_order_sort(uint32_t* keys, size_t n, int mode, int depth_limit)
+/* Test hook of introsort_restated.h: records sorted in place.  kind 0: LSD keys (uint32: bin << 22 | y << 11 | x, larger bins
+ * first); kind 1: VoxelGrid records (uint64: leaf << 32 | point, smaller leaves first).  mode 0: std::sort with the reference's
+ * comparator; 1 / 2: the restatement with scalar / AVX2 stopper masks; 3: the plain transcription of libstdc++'s introsort.
+ * depth_limit >= 0 replaces 2 lg n (modes 1-3).  DRFE_ERR_STATE for mode 2 on a CPU without AVX2. */
+int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_limit)
 {
-    if (!keys || mode < 0 || mode > 3) return DRFE_ERR_INVALID;
-    std::vector<uint32_t> tmp;
-    if (mode == 0) std::sort(keys, keys + n, lsd_order::Before());
-    else if (mode == 3) lsd_order::reference_sort(keys, n, depth_limit);
-    else {
-        if (mode == 2 && !__builtin_cpu_supports("avx2")) return DRFE_ERR_STATE;
-        lsd_order::sort(keys, n, tmp, mode - 1, depth_limit);
+    if (!recs || mode < 0 || mode > 3 || kind < 0 || kind > 1) return DRFE_ERR_INVALID;
+    if (mode == 2 && !isr::have_avx2()) return DRFE_ERR_STATE;
+    if (kind == 0) {
+        uint32_t* keys = static_cast<uint32_t*>(recs);
+        std::vector<uint32_t> tmp;
+        if (mode == 0) std::sort(keys, keys + n, lsd_order::Before());
+        else if (mode == 3) lsd_order::reference_sort(keys, n, depth_limit);
+        else lsd_order::sort(keys, n, tmp, mode - 1, depth_limit);
+    } else {
+        uint64_t* r = static_cast<uint64_t*>(recs);
+        if (mode == 0) std::sort(r, r + n, voxel_order::Before());
+        else if (mode == 3) voxel_order::reference_sort(r, n, depth_limit);
+        else voxel_order::sort(r, n, mode - 1, depth_limit);
     }
     return DRFE_OK;
 }

@@ -6,8 +6,10 @@
  *   per frame: surface normals of the 3x-subsampled cloud (device: normals_kernels.hip).
  * PCL 1.9.1 semantics and the canonical choices are listed in DESIGN.md section 9. */
 #include "post_internal.h"
+#include "introsort_restated.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -28,14 +30,22 @@ namespace {
 
 struct Pt { float x, y, z; };
 
-/* pcl::VoxelGrid<PointXYZRGB>::applyFilter (filters/impl/voxel_grid.hpp), xyz part of the all-fields centroid */
-struct VoxelKey {
-    unsigned leaf, point;
-    bool operator<(const VoxelKey& o) const { return leaf < o.leaf; }     /* cloud_point_index_idx::operator< */
-};
+/* std::floor(float) without the libm call (the build targets baseline x86-64, where floorf is a function): exact for every
+ * finite value - |v| >= 2^23 is integral already, below that the truncation is corrected downwards */
+inline float floor_f(float v)
+{
+    if (!(std::fabs(v) < 8388608.0f)) return v;
+    const float t = (float)(int)v;
+    return t > v ? t - 1.0f : t;
+}
 
+/* pcl::VoxelGrid<PointXYZRGB>::applyFilter (filters/impl/voxel_grid.hpp), xyz part of the all-fields centroid.  Its
+ * std::sort(index_vector) compares leaf indices only (cloud_point_index_idx::operator<), and the unstable sort's order inside
+ * a leaf is the order of the float centroid sums: voxel_order::sort makes libstdc++'s moves (introsort_restated.h) on
+ * leaf << 32 | point records; DRFE_VOXEL_STD_SORT=1 calls std::sort itself. */
 void voxel_downsample(const std::vector<Pt>& src, float leafSize, std::vector<Pt>* dst)
 {
+    static thread_local std::vector<uint64_t> keys;      /* scratch kept per host thread */
     dst->clear();
     if (src.empty()) return;
     const float inv = 1.0f / leafSize;
@@ -47,24 +57,25 @@ void voxel_downsample(const std::vector<Pt>& src, float leafSize, std::vector<Pt
     }
     const int64_t nx = (int64_t)((hi.x - lo.x) * inv) + 1, ny = (int64_t)((hi.y - lo.y) * inv) + 1, nz = (int64_t)((hi.z - lo.z) * inv) + 1;
     if (nx * ny * nz > (int64_t)std::numeric_limits<int32_t>::max()) { *dst = src; return; }
-    const int bx = (int)std::floor(lo.x * inv), by = (int)std::floor(lo.y * inv), bz = (int)std::floor(lo.z * inv);
-    const int ex = (int)std::floor(hi.x * inv), ey = (int)std::floor(hi.y * inv);
+    const int bx = (int)floor_f(lo.x * inv), by = (int)floor_f(lo.y * inv), bz = (int)floor_f(lo.z * inv);
+    const int ex = (int)floor_f(hi.x * inv), ey = (int)floor_f(hi.y * inv);
     const int sx = ex - bx + 1, sxy = sx * (ey - by + 1);
-    std::vector<VoxelKey> keys(src.size());
+    keys.resize(src.size());
     for (size_t i = 0; i < src.size(); i++) {
-        const int a = (int)(std::floor(src[i].x * inv) - (float)bx);
-        const int b = (int)(std::floor(src[i].y * inv) - (float)by);
-        const int c = (int)(std::floor(src[i].z * inv) - (float)bz);
-        keys[i] = VoxelKey{(unsigned)(a + b * sx + c * sxy), (unsigned)i};
+        const int a = (int)(floor_f(src[i].x * inv) - (float)bx);
+        const int b = (int)(floor_f(src[i].y * inv) - (float)by);
+        const int c = (int)(floor_f(src[i].z * inv) - (float)bz);
+        keys[i] = voxel_order::record((unsigned)(a + b * sx + c * sxy), (unsigned)i);
     }
-    /* the unstable std::sort on the leaf index alone decides the float summation order inside a leaf: reproduced by running
-     * the same library routine on the same records */
-    std::sort(keys.begin(), keys.end(), std::less<VoxelKey>());
+    static const bool stdSort = std::getenv("DRFE_VOXEL_STD_SORT") != nullptr;
+    if (stdSort) std::sort(keys.begin(), keys.end(), voxel_order::Before());
+    else voxel_order::sort(keys.data(), keys.size());
     for (size_t first = 0; first < keys.size();) {
         size_t last = first;
+        const uint32_t leaf = voxel_order::leaf_of(keys[first]);
         Pt acc{0.f, 0.f, 0.f};
-        while (last < keys.size() && keys[last].leaf == keys[first].leaf) {
-            const Pt& p = src[keys[last].point];
+        while (last < keys.size() && voxel_order::leaf_of(keys[last]) == leaf) {
+            const Pt& p = src[voxel_order::point_of(keys[last])];
             acc.x += p.x; acc.y += p.y; acc.z += p.z;
             last++;
         }
@@ -239,6 +250,8 @@ bool refit_plane(float coef[4], const std::vector<Pt>& pts, double disTh)
     return true;
 }
 
+thread_local double g_tVoxel = 0;       /* DRFE_TRACE_PLANES accounting */
+
 /* one plane of the per-plane loop: gates + refit; appends the voxel cloud of an accepted plane */
 struct PostOut {
     drfe_plane_post* post; float* vox; int32_t* voxOff; int capVox; int used; int nAccepted; int failPlanes; bool overflow;
@@ -248,7 +261,9 @@ void post_one_plane(const std::vector<Pt>& input, const float coefIn[4], bool ga
                     PostOut* o)
 {
     std::vector<Pt> coarse;
+    const auto tv = std::chrono::steady_clock::now();
     voxel_downsample(input, 0.05f, &coarse);
+    g_tVoxel += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count();
     drfe_plane_post& P = o->post[i];
     std::memcpy(P.coef, coefIn, 16);
     P.n_voxels = (int32_t)coarse.size();
@@ -284,12 +299,19 @@ int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, si
     }
     PostOut o{post, voxel_xyz, voxel_offsets, cap_voxels, 0, 0, 0, false};
     std::vector<Pt> input;
+    const double invW = 1.0 / (double)w;
+    static const bool trace = std::getenv("DRFE_TRACE_PLANES") != nullptr;      /* wall time per stage on stderr */
+    double tGather = 0, tPlane = 0;
+    size_t nPts = 0;
     for (int i = 0; i < n_planes; i++) {
         input.clear();
+        const auto t0 = std::chrono::steady_clock::now();
         for (int k = member_offsets[i]; k < member_offsets[i + 1]; k++) {
             const int j = member_idx[k];
             if (j < 0 || j >= w * h) { if (err) *err = "planes_ahc_postprocess: member index outside the image"; return DRFE_ERR_INVALID; }
-            const int row = j / w, col = j - row * w;
+            /* j / w without the division instruction: (j + 0.5) / w is at least 0.5 / w away from an integer, far more than the
+             * rounding error of the double product */
+            const int row = (int)(((double)j + 0.5) * invW), col = j - row * w;
             /* PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:39-52): doubles, K floats promoted */
             const double z = (double)depth[(size_t)row * stride + col] * depth_factor;
             double X = 0, Y = 0, Z = 0;
@@ -305,8 +327,16 @@ int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, si
         const drfe_plane& e = planes[i];
         const float d = (float)-(e.normal[0] * e.center[0] + e.normal[1] * e.center[1] + e.normal[2] * e.center[2]);
         const float coef[4] = {(float)e.normal[0], (float)e.normal[1], (float)e.normal[2], d};
+        const auto t1 = std::chrono::steady_clock::now();
         post_one_plane(input, coef, d > max_point_dist, dist_threshold, false, i, &o);
+        if (trace) {
+            tGather += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            tPlane += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            nPts += input.size();
+        }
     }
+    if (trace) std::fprintf(stderr, "drfe_ahc_post_core: %d planes, %zu member points; gather %.2f ms; voxel grid %.2f ms; refit %.2f ms\n",
+                            n_planes, nPts, tGather, g_tVoxel, tPlane - g_tVoxel), g_tVoxel = 0;
     voxel_offsets[n_planes] = o.used;
     *n_accepted = o.nAccepted;
     if (plane_num) *plane_num = n_planes - o.failPlanes;     /* planeDetector.plane_num_ -= fail_planes (:1023) */
@@ -340,8 +370,8 @@ int drfe_planes_ahc_postprocess(drfe_ctx* c, const uint16_t* depth, int w, int h
                                 float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz,
                                 int32_t* voxel_offsets, int cap_voxels, int* n_accepted, int* plane_num)
 {
-    if (!c) return DRFE_ERR_INVALID;
-    return drfe_ahc_post_core(&c->err, depth, w, h, stride, K4, depth_factor, planes, n_planes, member_offsets, member_idx, max_point_dist,
+    std::string local;                    /* ctx == NULL: host code, usable without a device (no error text then) */
+    return drfe_ahc_post_core(c ? &c->err : &local, depth, w, h, stride, K4, depth_factor, planes, n_planes, member_offsets, member_idx, max_point_dist,
                               dist_threshold, post, voxel_xyz, voxel_offsets, cap_voxels, n_accepted, plane_num);
 }
 

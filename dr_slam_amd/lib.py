@@ -37,7 +37,7 @@ SYMBOLS = (
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
     "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
-    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_lsd_order_sort",
+    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -170,7 +170,7 @@ def load() -> C.CDLL:
                                               C.POINTER(i32), C.POINTER(i32)]
     L.drfe_planes_ahc_post_batch.argtypes = [vp, vp, sz, i32, i32, sz, i32, vp, f32, f32, f64, vp, i32, vp, vp, vp, vp, vp, i32]
     L.drfe_debug_ahc_trials.argtypes = [vp, vp, i32, i32, vp]
-    L.drfe_debug_lsd_order_sort.argtypes = [vp, sz, i32, i32]
+    L.drfe_debug_order_sort.argtypes = [vp, sz, i32, i32, i32]
     L.drfe_planes_ahc_from_blocks.argtypes = [vp, vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
     L.drfe_planes_cape_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, vp, vp, i32, f32, f64, vp, vp, vp, i32,
                                                C.POINTER(i32), C.POINTER(i32)]

@@ -465,11 +465,13 @@ int drfe_planes_ahc_blocks(drfe_ctx* ctx, const uint16_t* depth, int w, int h, s
  * sums, N) records by the scalar routine (mode 0), its 8-lane AVX2 (1) or 8-lane AVX-512F (2) instantiation; out8 = center,
  * normal, mse, curvature per record.  DRFE_ERR_STATE if this CPU lacks the mode.  Host code. */
 int drfe_debug_ahc_trials(const double* sums9, const int32_t* N, int n, int mode, double* out8);
-/* Test hook of LSD's pseudo-ordering (dr_slam_amd/csrc/lsd_order_sort.h): keys[n] = gradient bin << 22 | y << 11 | x sorted in place
- * by descending bin.  mode 0: std::sort with cv::LineSegmentDetectorImpl's comparator (lsd.cpp, compare_norm); 1 / 2: the
- * product's restatement with scalar / AVX2 stopper masks; 3: the plain transcription of libstdc++'s introsort.  depth_limit >= 0
- * replaces the 2 lg n of modes 1-3 (reaches the heap-sort branch).  DRFE_ERR_STATE if this CPU lacks AVX2 (mode 2).  Host code. */
-int drfe_debug_lsd_order_sort(uint32_t* keys, size_t n, int mode, int depth_limit);
+/* Test hook of dr_slam_amd/csrc/introsort_restated.h, the two std::sort calls whose permutation of equal keys reaches the output:
+ * kind 0 = LSD's pseudo-ordering (uint32 keys: gradient bin << 22 | y << 11 | x, larger bins first: lsd.cpp compare_norm), kind 1 =
+ * pcl::VoxelGrid's index sort (uint64 records: leaf << 32 | point, smaller leaves first).  recs[n] sorted in place.  mode 0:
+ * std::sort with the reference's comparator; 1 / 2: the product's restatement with scalar / AVX2 stopper masks; 3: the plain
+ * transcription of libstdc++'s introsort.  depth_limit >= 0 replaces the 2 lg n of modes 1-3 (reaches the heap-sort branch).
+ * DRFE_ERR_STATE if this CPU lacks AVX2 (mode 2).  Host code. */
+int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_limit);
 /* The host half of drfe_planes_ahc on caller-supplied block fits (the records drfe_planes_ahc_blocks returns), without a device:
  * graph, agglomerative clustering, block membership, flood fill, re-merge and labels.  Host code: CPU tests and profiling. */
 int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, const uint16_t* depth, int w, int h, size_t stride,
@@ -521,7 +523,7 @@ int drfe_plane_refit(float* coef4, const float* xyz, int n, double dist_threshol
  * planes / member_offsets / member_idx as that call filled them).  max_point_dist = Point.MaxDistance, dist_threshold =
  * Plane.DistanceThreshold.  Outputs: post[n_planes]; voxel_offsets[n_planes + 1] + voxel_xyz (may be NULL) = mvPlanePoints
  * of the accepted planes as CSR; *n_accepted = mvPlaneCoefficients.size(); *plane_num (may be NULL) = planeDetector.plane_num_
- * after `-= fail_planes`. */
+ * after `-= fail_planes`.  Host code: ctx may be NULL (no error text then). */
 int drfe_planes_ahc_postprocess(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
                                 const drfe_plane* planes, int n_planes, const int32_t* member_offsets, const int32_t* member_idx,
                                 float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz,

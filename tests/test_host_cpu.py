@@ -353,49 +353,56 @@ def test_ahc_vector_trial_solver_equals_scalar():
         assert np.array_equal(o1.view(np.uint64), o0.view(np.uint64))
 
 
-def test_lsd_pseudo_ordering_equals_std_sort():
-    """lsd_order_sort.h: the product's restatement of libstdc++'s introsort (mask-driven Hoare partitions + counting sort for the
-    final insertion sort) against std::sort with LSD's comparator itself - the permutation of equal bins included - on key arrays
-    of many sizes and bin distributions; with a forced depth limit (heap-sort branch) against the plain transcription, which is
-    itself compared with std::sort at the natural limit."""
+def test_restated_introsort_equals_std_sort():
+    """introsort_restated.h: the product's restatement of libstdc++'s introsort (mask-driven Hoare partitions + a stable final pass)
+    against std::sort with the reference's comparator itself - the permutation of equal keys included - for both users (LSD's
+    pseudo-ordering, VoxelGrid's index sort) on arrays of many sizes and key distributions; with a forced depth limit (heap-sort
+    branch) against the plain transcription, which is itself compared with std::sort at the natural limit."""
     import ctypes as C
     from dr_slam_amd import lib
     L = lib.load()
     rng = np.random.default_rng(11)
 
-    def run(keys, mode, depth=-1):
-        k = keys.copy()
-        rc = L.drfe_debug_lsd_order_sort(k.ctypes.data_as(C.c_void_p), len(k), mode, depth)
+    def run(recs, kind, mode, depth=-1):
+        k = recs.copy()
+        rc = L.drfe_debug_order_sort(k.ctypes.data_as(C.c_void_p), len(k), kind, mode, depth)
         if rc == -4:
             return None                               # no AVX2 on this CPU
         assert rc == 0
         return k
 
-    def keys_of(bins):
-        bins = np.asarray(bins)
-        return ((bins.astype(np.uint32) << 22) | (np.arange(len(bins), dtype=np.uint32) & 0x3FFFFF)).astype(np.uint32)
+    def recs_of(keys, kind):
+        keys = np.asarray(keys)
+        if kind == 0:
+            return ((keys.astype(np.uint32) << 22) | (np.arange(len(keys), dtype=np.uint32) & 0x3FFFFF)).astype(np.uint32)
+        return ((keys.astype(np.uint64) << np.uint64(32)) | np.arange(len(keys), dtype=np.uint64)).astype(np.uint64)
 
-    cases = []
-    for trial in range(600):
-        n = int(rng.integers(0, 6000)) if trial % 3 else int(rng.integers(0, 300))
-        kind = trial % 7
-        if kind == 0: b = rng.integers(0, 1024, n)
-        elif kind == 1: b = rng.integers(0, 4, n)
-        elif kind == 2: b = np.full(n, 7)
-        elif kind == 3: b = np.minimum(1023, rng.exponential(20, n).astype(int))
-        elif kind == 4: b = np.sort(rng.integers(0, 50, n))
-        elif kind == 5: b = np.sort(rng.integers(0, 50, n))[::-1]
-        else: b = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) % 1024     # organ pipe
-        cases.append(keys_of(b))
-    cases.append(keys_of(np.minimum(1023, rng.exponential(30, 511 * 383).astype(int))))          # one 512 x 384 field
-    for k in cases:
-        want = run(k, 0)
-        for mode in (1, 2, 3):
-            got = run(k, mode)
-            assert got is None or np.array_equal(got, want), (len(k), mode)
-        if len(k) < 6000:
-            for depth in (0, 1, 3):
-                want_d = run(k, 3, depth)
-                for mode in (1, 2):
-                    got = run(k, mode, depth)
-                    assert got is None or np.array_equal(got, want_d), (len(k), mode, depth)
+    for kind, top in ((0, 1024), (1, 1 << 21)):
+        cases = []
+        for trial in range(420):
+            n = int(rng.integers(0, 6000)) if trial % 3 else int(rng.integers(0, 300))
+            shape = trial % 7
+            if shape == 0: b = rng.integers(0, top, n)
+            elif shape == 1: b = rng.integers(0, 4, n)
+            elif shape == 2: b = np.full(n, 7)
+            elif shape == 3: b = np.minimum(top - 1, rng.exponential(20, n).astype(int))
+            elif shape == 4: b = np.sort(rng.integers(0, 50, n))
+            elif shape == 5: b = np.sort(rng.integers(0, 50, n))[::-1]
+            else: b = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) % top       # organ pipe
+            cases.append(recs_of(b, kind))
+        if kind == 0:
+            cases.append(recs_of(np.minimum(1023, rng.exponential(30, 511 * 383).astype(int)), 0))    # one 512 x 384 field
+        else:   # a plane's points in scan order: leaf indices locally repetitive, globally increasing with noise
+            t = np.arange(60000)
+            cases.append(recs_of((t // 640) // 12 * 200 + (t % 640) // 12 + rng.integers(0, 2, len(t)) * 40000, 1))
+        for k in cases:
+            want = run(k, kind, 0)
+            for mode in (1, 2, 3):
+                got = run(k, kind, mode)
+                assert got is None or np.array_equal(got, want), (kind, len(k), mode)
+            if len(k) < 6000:
+                for depth in (0, 1, 3):
+                    want_d = run(k, kind, 3, depth)
+                    for mode in (1, 2):
+                        got = run(k, kind, mode, depth)
+                        assert got is None or np.array_equal(got, want_d), (kind, len(k), mode, depth)
