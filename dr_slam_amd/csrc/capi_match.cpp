@@ -1008,6 +1008,122 @@ int drfe_search_by_projection_reloc(drfe_ctx* c, int slot, const float* Tcw, con
     return DRFE_OK;
 }
 
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:409-524 (monocular
+ * initialisation).  The loop over F1's level-0 keypoints is first come, first served with replacement: a candidate whose
+ * recorded match is at least as close is skipped (:448), a new match evicts the older one (:467-471) - so the device gathers
+ * each keypoint's window (GetFeaturesInArea order, level 0 only, Hamming distances) and the host replays the loop on the lists. */
+int drfe_search_for_initialization(drfe_ctx* c, int slot1, int slot2, float* prev_matched, int n1, int window_size, float nnratio,
+                                   int check_orientation, int32_t* matches12, int* n_matches)
+{
+    if (!c || !prev_matched || !matches12 || !n_matches || n1 < 0 || window_size < 0) return DRFE_ERR_INVALID;
+    if (slot1 < 0 || slot1 >= c->lastBatch || slot2 < 0 || slot2 >= c->lastBatch || !c->glueValid) {
+        c->err = "search_for_initialization: slots not ready";
+        return DRFE_ERR_STATE;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    int cnt[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(&cnt[0], c->d_kpCount + slot1, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&cnt[1], c->d_kpCount + slot2, sizeof(int), hipMemcpyDeviceToHost));
+    if (n1 != cnt[0]) { c->err = "search_for_initialization: N mismatch"; return DRFE_ERR_INVALID; }
+    const int n2 = cnt[1];
+    *n_matches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                                   /* :412 */
+    if (n1 == 0 || n2 == 0) return DRFE_OK;
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return DRFE_ERR_HIP;
+    std::vector<drfe_keypoint> k1(n1), k2(n2);
+    std::vector<uint8_t> d1((size_t)n1 * 32);
+    HIPCHK(c, hipMemcpy(k1.data(), drfe_kps_un(c) + (size_t)slot1 * c->maxKp, sizeof(drfe_keypoint) * (size_t)n1, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(k2.data(), drfe_kps_un(c) + (size_t)slot2 * c->maxKp, sizeof(drfe_keypoint) * (size_t)n2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(d1.data(), c->d_desc + (size_t)slot1 * c->maxKp * 32, d1.size(), hipMemcpyDeviceToHost));
+    /* one window query per level-0 keypoint of F1 (:425-429): GetFeaturesInArea(prev.x, prev.y, windowSize, 0, 0), no stereo gate */
+    std::vector<int> owner;
+    std::vector<MatchQuery> q;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (k1[i1].octave > 0) continue;
+        MatchQuery Q;
+        std::memset(&Q, 0, sizeof(Q));
+        Q.valid = 1;
+        Q.u = prev_matched[2 * i1]; Q.v = prev_matched[2 * i1 + 1]; Q.radius = (float)window_size;
+        Q.ur = 0.f; Q.thrR = std::numeric_limits<float>::infinity();
+        Q.minLevel = k1[i1].octave; Q.maxLevel = k1[i1].octave;
+        std::memcpy(Q.desc, &d1[(size_t)i1 * 32], 32);
+        q.push_back(Q);
+        owner.push_back(i1);
+    }
+    const int nq = (int)q.size();
+    if (nq == 0) return DRFE_OK;
+    if ((size_t)nq > m->queryCap) { c->err = "search_for_initialization: too many level-0 keypoints for the scratch"; return DRFE_ERR_CAPACITY; }
+    MatchPair P;
+    std::memset(&P, 0, sizeof(P));
+    P.curSlot = slot2; P.lastSlot = slot2; P.mpSlot = -1; P.nQueries = nq;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpy(m->d_pairs, &P, sizeof(P), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(m->d_queries, q.data(), sizeof(MatchQuery) * (size_t)nq, hipMemcpyHostToDevice));
+    HIPCHK(c, drfe_launch_window_candidates(c, *m, c->cam, 1, nq, s));
+    std::vector<uint32_t> cIdx((size_t)nq * DRFE_MATCH_MAX_CAND), cKey((size_t)nq * DRFE_MATCH_MAX_CAND);
+    std::vector<int> cCnt(nq);
+    HIPCHK(c, hipMemcpyAsync(cIdx.data(), m->d_candIdx, cIdx.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(cKey.data(), m->d_candKey, cKey.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(cCnt.data(), m->d_candCnt, sizeof(int) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    rc = match_status(c);
+    if (rc != DRFE_OK) return rc;
+    /* the loop of :422-491 on the gathered lists */
+    const int TH_LOW = 50;
+    std::vector<int> matchedDistance(n2, std::numeric_limits<int>::max()), matches21(n2, -1);
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / 30;
+    int nm = 0;
+    for (int k = 0; k < nq; k++) {
+        const int i1 = owner[k];
+        int bestDist = std::numeric_limits<int>::max(), bestDist2 = bestDist, bestIdx2 = -1;
+        for (int t = 0; t < cCnt[k]; t++) {
+            const int i2 = (int)(cIdx[(size_t)k * DRFE_MATCH_MAX_CAND + t] & 0xFFFFFFu);
+            const int dist = (int)(cKey[(size_t)k * DRFE_MATCH_MAX_CAND + t] >> 22);
+            if (matchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nm--; }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matchedDistance[bestIdx2] = bestDist;
+            nm++;
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == 30) bin = 0;
+                if (bin < 0 || bin >= 30) { c->err = "search_for_initialization: keypoint angle outside [0, 360)"; return DRFE_ERR_INVALID; }
+                rotHist[bin].push_back(i1);
+            }
+        }
+    }
+    if (check_orientation) {                                                          /* ComputeThreeMaxima, :1666-1707 */
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < 30; i++) {
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < 30; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx1 : rotHist[i])
+                    if (matches12[idx1] >= 0) { matches12[idx1] = -1; nm--; }
+    }
+    for (int i1 = 0; i1 < n1; i1++)                                                   /* :519-521 */
+        if (matches12[i1] >= 0) { prev_matched[2 * i1] = k2[matches12[i1]].x; prev_matched[2 * i1 + 1] = k2[matches12[i1]].y; }
+    *n_matches = nm;
+    return DRFE_OK;
+}
+
 /* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, th), src/LSDmatcher.cpp:884-1010: the search */
 int drfe_lsd_fuse_search(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
                          const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,

@@ -802,6 +802,21 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
     return hipGetLastError();
 }
 
+/* the window gather alone (candidate lists in GetFeaturesInArea order with their distances): for searches whose acceptance
+ * rule is replayed on the host */
+hipError_t drfe_launch_window_candidates(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs, int maxQueries,
+                                         hipStream_t s)
+{
+    const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
+    const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
+    (void)hipMemsetAsync(c->d_status + 1, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 15) / 16, npairs), dim3(256), 0, s, mb.d_pairs,
+                       mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
+                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status + 1,
+                       drfe_div_magic((uint32_t)((maxQueries + 15) / 16)));
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_mappoints_last(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, const float* d_Twc,
                                       int nframes, hipStream_t s)
 {

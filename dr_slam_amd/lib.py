@@ -37,7 +37,7 @@ SYMBOLS = (
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
     "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
-    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort",
+    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -139,6 +139,7 @@ def load() -> C.CDLL:
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
     L.drfe_lsd_fuse_search.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp]
     L.drfe_search_by_projection_reloc.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, C.c_float, i32, i32, vp, C.POINTER(i32)]
+    L.drfe_search_for_initialization.argtypes = [vp, i32, i32, vp, i32, i32, C.c_float, i32, vp, C.POINTER(i32)]
     L.drfe_search_by_projection_kf.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, C.c_float, vp, C.POINTER(i32)]
     L.drfe_search_by_sim3.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_float, vp,
                                       C.POINTER(i32)]
@@ -530,6 +531,17 @@ class Context:
                                                          C.c_float(th), int(orb_dist), int(bool(check_orientation)), _p(out),
                                                          C.byref(n)), "drfe_search_by_projection_reloc")
         return n.value, out
+
+    def search_for_initialization(self, slot1, slot2, prev_matched, window_size=100, nnratio=0.9, check_orientation=True):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize); returns (nmatches, matches12,
+        prev_matched after the update)."""
+        pm = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+        out = np.full(len(pm), -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_search_for_initialization(self.h, slot1, slot2, _p(pm), len(pm), int(window_size), C.c_float(nnratio),
+                                                        int(bool(check_orientation)), _p(out), C.byref(n)),
+                  "drfe_search_for_initialization")
+        return n.value, out, pm
 
     def search_by_sim3(self, slot1, slot2, T1w, T2w, s12, R12, t12, pts1, descs1, skip1, pts2, descs2, skip2, th):
         """ORBmatcher::SearchBySim3; returns (nFound, matches12[i1] = i2 or -1)."""

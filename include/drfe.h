@@ -375,6 +375,14 @@ int drfe_search_by_projection_reloc(drfe_ctx* ctx, int slot, const float* Tcw, c
                                     const float* kf_angles, const uint8_t* skip, int n, const uint8_t* matched, int n_kp, float th,
                                     int orb_dist, int check_orientation, int32_t* new_match, int* n_matches);
 
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:409-524; monocular
+ * initialisation).  F1 / F2 = slots of the last extracted batch (frame glue done).  prev_matched[n1 * 2] = vbPrevMatched (x, y per
+ * F1 keypoint), updated in place as the reference does; matches12[n1] = index into F2's keypoints or -1; *n_matches = the return
+ * value.  nnratio / check_orientation = the ORBmatcher constructor's arguments.  A window holding more than 256 level-0
+ * keypoints fails with DRFE_ERR_CAPACITY. */
+int drfe_search_for_initialization(drfe_ctx* ctx, int slot1, int slot2, float* prev_matched, int n1, int window_size, float nnratio,
+                                   int check_orientation, int32_t* matches12, int* n_matches);
+
 /* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, const float th = 3.0), src/LSDmatcher.cpp:884-1010
  * (LocalMapping::SearchInNeighbors, src/LocalMapping.cc:1103 / :1124): the search per map line — both end points projected
  * with the keyframe pose (camera centre as KeyFrame::SetPose builds it), image bounds, distance band, 60-degree cone,

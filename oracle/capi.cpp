@@ -523,6 +523,11 @@ int orc_search_by_projection_kf(void* kf, const float* Scw, float logScale, int 
 {
     return search_by_projection_kf(*(Frame*)kf, Scw, logScale, nLevels, pts, descs, skip, n, matched, th, newMatch);
 }
+int orc_search_for_initialization(void* f1, void* f2, float* prevMatched, int windowSize, float nnratio, int checkOri, int32_t* matches12)
+{
+    return search_for_initialization(*(Frame*)f1, *(Frame*)f2, prevMatched, windowSize, nnratio, checkOri != 0, matches12);
+}
+
 int orc_search_by_projection_reloc(void* cur, const float* Tcw, float logScale, int nLevels, const FrustumPointRec* pts,
                                    const uint8_t* descs, const float* kfAngles, const uint8_t* skip, int n, const uint8_t* matched,
                                    float th, int orbDist, int checkOri, int32_t* newMatch)

@@ -947,4 +947,61 @@ int search_by_projection_reloc(const Frame& Cur, const float Tcw[16], float logS
     return nmatches;
 }
 
+/* ---------------------------------------------------------------------------------------------------- */
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:409-524 */
+
+int search_for_initialization(const Frame& F1, const Frame& F2, float* prevMatched /* F1.N x 2, in/out */, int windowSize,
+                              float nnratio, bool checkOri, int32_t* matches12)
+{
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    int nmatches = 0;
+    for (int i = 0; i < F1.N; i++) matches12[i] = -1;                             /* :412 */
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> matchedDistance(F2.N, INT_MAX), matches21(F2.N, -1);         /* :419-420 */
+    std::vector<int> cand;
+    for (int i1 = 0; i1 < F1.N; i1++) {
+        const int level1 = F1.keysUn[i1].octave;
+        if (level1 > 0) continue;                                                 /* :426 */
+        F2.getFeaturesInArea(prevMatched[2 * i1], prevMatched[2 * i1 + 1], (float)windowSize, level1, level1, cand);   /* :429 */
+        if (cand.empty()) continue;
+        const uint8_t* d1 = &F1.desc[(size_t)i1 * 32];
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : cand) {
+            const int dist = descriptor_distance_swar(d1, &F2.desc[(size_t)i2 * 32]);
+            if (matchedDistance[i2] <= dist) continue;                            /* :448 */
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if ((float)bestDist < (float)bestDist2 * nnratio) {                   /* :465, int -> float as written */
+                if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                matches21[bestIdx2] = i1;
+                matchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) {
+                    float rot = F1.keysUn[i1].angle - F2.keysUn[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }   /* :508-512: a replaced match is not counted twice */
+        }
+    }
+    for (int i1 = 0; i1 < F1.N; i1++)                                             /* :519-521 */
+        if (matches12[i1] >= 0) { prevMatched[2 * i1] = F2.keysUn[matches12[i1]].x; prevMatched[2 * i1 + 1] = F2.keysUn[matches12[i1]].y; }
+    return nmatches;
+}
+
 } // namespace orc

@@ -156,5 +156,10 @@ int search_by_sim3(const Frame& KF1, const Frame& KF2, const float T1w[16], cons
                    const uint8_t* descs1, const uint8_t* skip1, const FrustumPointRec* pts2, const uint8_t* descs2,
                    const uint8_t* skip2, float th, int32_t* out12);
 
+/* ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:409-524: matches12[F1.N] (index into F2 or -1), prevMatched updated */
+int search_for_initialization(const Frame& F1, const Frame& F2, float* prevMatched, int windowSize, float nnratio, bool checkOri,
+                              int32_t* matches12);
+
 } // namespace orc
+
 #endif

@@ -407,6 +407,17 @@ def search_by_projection_reloc(cur: "FrameOracle", Tcw, scale_factor, nlevels, p
     return n, out
 
 
+def search_for_initialization(f1: "FrameOracle", f2: "FrameOracle", prev_matched, window_size=100, nnratio=0.9, check_ori=True):
+    """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:409-524:
+    returns (nmatches, matches12 [F1.N], prev_matched after the update [F1.N, 2])."""
+    L = lib()
+    pm = _c(prev_matched, np.float32).reshape(-1, 2).copy()
+    out = np.full(len(pm), -1, np.int32)
+    L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    n = L.orc_search_for_initialization(f1.h, f2.h, _p(pm), int(window_size), float(nnratio), int(bool(check_ori)), _p(out))
+    return n, out, pm
+
+
 def search_by_sim3(kf1: "FrameOracle", kf2: "FrameOracle", T1w, T2w, s12, R12, t12, scale_factor, nlevels, pts1, descs1, skip1,
                    pts2, descs2, skip2, th):
     """ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): returns (nFound, out12[i1] = i2 or -1)."""

@@ -435,6 +435,29 @@ def test_search_by_projection_reloc(setup, oracle_mod, list_k, monkeypatch):
     assert total > 1500
 
 
+def test_search_for_initialization(setup, oracle_mod):
+    """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) as Tracking::MonocularInitialization
+    calls it (nnratio 0.9, orientation check, window 100), chained over frames the way the tracker does (vbPrevMatched starts as
+    F1's keypoints and is updated by every call); smaller windows, a stricter ratio and no orientation check too."""
+    fe, oframes, Tcw, Twc, cam = setup
+    total = 0
+    for window, ratio, ori in ((100, 0.9, True), (30, 0.9, False), (60, 0.7, True)):
+        for s1 in (0, 2):
+            prev = np.stack([oframes[s1].keys_un()["x"], oframes[s1].keys_un()["y"]], 1).astype(np.float32)
+            oprev = prev.copy()
+            for s2 in range(len(oframes)):
+                if s2 == s1:
+                    continue
+                n, m12, prev = fe.ctx.search_for_initialization(s1, s2, prev, window, ratio, ori)
+                on, om12, oprev = oracle_mod.search_for_initialization(oframes[s1], oframes[s2], oprev, window, ratio, ori)
+                assert n == on and np.array_equal(m12, om12), (window, s1, s2)
+                assert np.array_equal(prev.view(np.uint32), oprev.view(np.uint32))
+                lvl0 = oframes[s1].keys_un()["octave"] == 0
+                assert (m12[~lvl0] == -1).all() and (m12 >= 0).sum() == n
+                hit = m12[m12 >= 0]
+                assert len(np.unique(hit)) == len(hit)                      # vnMatches21 keeps the map one to one
+                total += n
+    assert total > 400
 def test_sparse_depth_glue_equals_image_glue(setup, frames_room):
     """The host-fed form of the glue (one raw depth value per keypoint, gathered on the host from the pixels
     drfe_orb_keypoint_pixels_async reports) leaves exactly what the depth-image form leaves: uRight, depth, grid, matches."""
