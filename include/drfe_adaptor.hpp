@@ -190,6 +190,18 @@ public:
                                                           (int)curClaims.size(), &n), ctx, "drfe_search_by_projection_last");
         return n;
     }
+    /* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) on the slots f1 / f2 of ctx (src/ORBmatcher.cc:409-524):
+     * vbPrevMatched = (x, y) per F1 keypoint, updated in place; vnMatches12[i1] = index into F2's keypoints or -1 */
+    int SearchForInitialization(drfe_ctx* ctx, int f1, int f2, std::vector<float>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                int windowSize = 10)
+    {
+        int n = 0;
+        vnMatches12.assign(vbPrevMatched.size() / 2, -1);
+        drfe_detail::check(drfe_search_for_initialization(ctx, f1, f2, vbPrevMatched.data(), (int)vnMatches12.size(), windowSize, mfNNratio,
+                                                          mbCheckOrientation ? 1 : 0, vnMatches12.data(), &n), ctx,
+                           "drfe_search_for_initialization");
+        return n;
+    }
 protected:
     float mfNNratio; bool mbCheckOrientation;
 };
