@@ -607,7 +607,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": stage_ms[roof_stage],
-                         "algorithmic_bytes_per_launch": algo},
+                         "algorithmic_bytes_per_launch": algo,
+                         "valu_issue_utilisation": valu, "valu_source": "SQ_INSTS_VALU x 4 / 1024 SIMDs against SQ_BUSY_CYCLES / 32 "
+                                                                         "(profiles/r02_pmc_sq_pass1_b512.csv via tools/pmc_traffic.py)"},
         }
         out["parity"] = "bit-exact vs the in-repo CPU oracle; the oracle restates OpenCV 3.4 / Eigen 3.3.7 / PCL 1.9 and is UNPINNED " \
                         "against the real libraries (none can be built here)"
