@@ -323,8 +323,12 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    split = {"lines": max(1, (ncpu * 3) // 4)}
-    split["planes"] = max(1, ncpu - split["lines"])
+    # a host thread of either pool sleeps in stream synchronisations (six NFA rounds per frame of lines, the block fits of the
+    # planes) for about a fifth of its time: 1.25 threads per CPU fill it (tools/host_pool_scaling.py: 16 CPUs, lines 94 ms with
+    # 16 threads, 76 ms with 20)
+    nthr = max(2, (ncpu * 5) // 4)
+    split = {"lines": max(1, (nthr * 3) // 4)}
+    split["planes"] = max(1, nthr - split["lines"])
     ctx_planes = lib.Context(max_batch=1)
     ctx_cape = lib.Context(max_batch=1)
     wall = {}
@@ -359,8 +363,8 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
         step(pool)
         # the two host pools are balanced from the warm-up step's own timing: thread-ms per frame of lines against planes
         cl, cp = wall["lines"] * split["lines"], wall["ahc_planes"] * split["planes"]
-        split["lines"] = min(ncpu - 1, max(1, round(ncpu * cl / (cl + cp)))) if ncpu > 1 else 1
-        split["planes"] = max(1, ncpu - split["lines"])
+        split["lines"] = min(nthr - 1, max(1, round(nthr * cl / (cl + cp))))
+        split["planes"] = max(1, nthr - split["lines"])
         step(pool)
         t0 = time.perf_counter()
         for _ in range(reps):

@@ -10,11 +10,11 @@ order = sharding.pingpong_order(96, len(base))
 gray = np.stack([base[i][0] for i in order]); depth = np.stack([base[i][1] for i in order])
 K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32); inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
 ctx = lib.Context(max_batch=1)
-for T in (1, 2, 4, 8, 16):
+for T in (1, 2, 4, 8, 16, 20, 24):
     ctx.lsd_extract_batch(gray[:T * 2], n_threads=T)
     t = time.perf_counter(); ctx.lsd_extract_batch(gray, n_threads=T); el = time.perf_counter() - t
     print("lines  threads %2d: wall %7.1f ms, %5.2f thread-ms per frame" % (T, el * 1e3, el * 1e3 * T / len(gray)), flush=True)
-for T in (1, 2, 4, 8, 16):
+for T in (1, 2, 4, 8, 16, 20, 24):
     ctx.planes_ahc_post_batch(depth[:T * 2], K4, inv, 9.0, 0.10, n_threads=T)
     t = time.perf_counter(); ctx.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=T); el = time.perf_counter() - t
     print("planes threads %2d: wall %7.1f ms, %5.2f thread-ms per frame" % (T, el * 1e3, el * 1e3 * T / len(depth)), flush=True)
