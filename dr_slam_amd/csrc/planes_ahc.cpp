@@ -497,18 +497,24 @@ static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t s
     DepthView dv = {depth, stride, w, h, (double)depth_factor, (double)K4[0], (double)K4[1], (double)K4[2], (double)K4[3]};
     {
         std::vector<float> distMap((size_t)w * h, std::numeric_limits<float>::max());
+        const double invW = 1.0 / (double)w;
         for (size_t k = 0; k < rf.size(); ++k) {
             const int sIdx = rf[k].first, plid = rf[k].second;
-            const int seedy = sIdx / w, seedx = sIdx - seedy * w;
+            /* sIdx / w without the division instruction: (sIdx + 0.5) / w is at least 0.5 / w away from an integer */
+            const int seedy = (int)(((double)sIdx + 0.5) * invW), seedx = sIdx - seedy * w;
             const Node& pl = g.nodes[extracted[plid]];
-            int nbs[4] = {-1};
-            const int Nn = valid4(seedy, seedx, h, w, nbs);
+            /* valid4's order - left, right, up, down - with the neighbour's row / column carried along */
+            int nbs[4], nby[4], nbx[4], Nn = 0;
+            if (seedx > 0) { nbs[Nn] = sIdx - 1; nby[Nn] = seedy; nbx[Nn++] = seedx - 1; }
+            if (seedx < w - 1) { nbs[Nn] = sIdx + 1; nby[Nn] = seedy; nbx[Nn++] = seedx + 1; }
+            if (seedy > 0) { nbs[Nn] = sIdx - w; nby[Nn] = seedy - 1; nbx[Nn++] = seedx; }
+            if (seedy < h - 1) { nbs[Nn] = sIdx + w; nby[Nn] = seedy + 1; nbx[Nn++] = seedx; }
             for (int t = 0; t < Nn; ++t) {
                 const int cIdx = nbs[t];
                 int& trail = membership[cIdx];
                 if (trail <= -6) continue;
                 if (trail >= 0 && trail == plid) continue;
-                const int cy = cIdx / w, cx = cIdx - cy * w;
+                const int cy = nby[t], cx = nbx[t];
                 const int by = cy / AHC_WIN, bx = cx / AHC_WIN;
                 const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
                 if (blkid >= 0 && blkMap[blkid] >= 0) continue;
@@ -565,20 +571,39 @@ static int planes_ahc_core(Ctx* c, const uint16_t* depth, int w, int h, size_t s
         planes[i].n_points = n.N; planes[i].rid = n.rid;
     }
     std::vector<int> counts(nFinal + 1, 0);
-    for (size_t i = 0; i < membership.size(); ++i) {
-        int& plid = membership[i];
-        if (plid >= 0 && plidmap[plid] >= 0) { plid = plidmap[plid]; counts[plid + 1]++; }
-        else plid = -1;
+    {   /* final plane number per pixel, the label image and the member counts in one pass over RUNS of equal membership (a
+         * per-pixel `counts[plid]++` serialises on the counter's store-to-load chain: 2.7 ns per pixel against 0.4) */
+        const size_t np = membership.size();
+        int* mem = membership.data();
+        for (size_t i = 0; i < np;) {
+            const int raw = mem[i];
+            size_t j = i + 1;
+            while (j < np && mem[j] == raw) j++;
+            const int plid = raw >= 0 ? plidmap[raw] : -1;
+            if (plid != raw) std::fill(mem + i, mem + j, plid);
+            if (plid >= 0) counts[plid + 1] += (int)(j - i);
+            if (seg) std::memset(seg + i, plid + 1, j - i);
+            i = j;
+        }
     }
-    if (seg)
-        for (size_t i = 0; i < membership.size(); ++i) seg[i] = membership[i] >= 0 ? (uint8_t)(membership[i] + 1) : 0;
     if (member_offsets) {
         for (int i = 0; i < nFinal; i++) counts[i + 1] += counts[i];
         for (int i = 0; i <= nFinal; i++) member_offsets[i] = counts[i];
         if (member_idx) {
             std::vector<int> fill(counts.begin(), counts.end() - 1);
-            for (size_t i = 0; i < membership.size(); ++i)
-                if (membership[i] >= 0) member_idx[fill[membership[i]]++] = (int32_t)i;
+            const size_t np = membership.size();
+            const int* mem = membership.data();
+            for (size_t i = 0; i < np;) {                    /* run by run, as above */
+                const int plid = mem[i];
+                size_t j = i + 1;
+                while (j < np && mem[j] == plid) j++;
+                if (plid >= 0) {
+                    int32_t* dst = member_idx + fill[plid];
+                    for (size_t k = i; k < j; k++) *dst++ = (int32_t)k;
+                    fill[plid] += (int)(j - i);
+                }
+                i = j;
+            }
         }
     }
     return DRFE_OK;
