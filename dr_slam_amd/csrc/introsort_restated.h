@@ -115,13 +115,16 @@ static inline void stable_by_bin(uint32_t* a, size_t n, std::vector<uint32_t>& t
 }
 
 /* a[0..n) into std::sort(a, a + n, Before())'s order.  mode: -1 best for this CPU, 0 scalar masks, 1 AVX2 masks.
- * depthOverride >= 0 replaces the depth limit 2 lg n (tests reach the heap-sort branch with it). */
-static inline void sort(uint32_t* a, size_t n, std::vector<uint32_t>& tmp, int mode = -1, int depthOverride = -1)
+ * depthOverride >= 0 replaces the depth limit 2 lg n (tests reach the heap-sort branch with it).
+ * skipBelow > 0: only the keys with bin >= skipBelow are wanted - they come out in std::sort's order (a prefix of the array,
+ * bins descend); ranges known to hold smaller bins only are not sorted among themselves.  LSD's region growing never seeds from
+ * a pixel without a level-line angle, and those are the small bins: a third of the array. */
+static inline void sort(uint32_t* a, size_t n, std::vector<uint32_t>& tmp, int mode = -1, int depthOverride = -1, uint32_t skipBelow = 0)
 {
     if (n < 2) return;
     if (mode < 0) mode = isr::have_avx2() ? 1 : 0;
-    if (mode == 1 && isr::have_avx2()) lsd_order_avx2::partition_phase(a, n, depthOverride);
-    else lsd_order_scalar::partition_phase(a, n, depthOverride);
+    if (mode == 1 && isr::have_avx2()) lsd_order_avx2::partition_phase(a, n, depthOverride, skipBelow);
+    else lsd_order_scalar::partition_phase(a, n, depthOverride, skipBelow);
     stable_by_bin(a, n, tmp);
 }
 static inline void reference_sort(uint32_t* a, size_t n, int depthOverride) { lsd_order_scalar::reference_sort(a, n, depthOverride); }

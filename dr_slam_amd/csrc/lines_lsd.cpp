@@ -64,14 +64,21 @@ public:
         const double binCoef = (maxGrad > 0) ? double(1024 - 1) / maxGrad : 0;
         order_.clear();
         order_.reserve((size_t)(W - 1) * (H - 1));
+        uint32_t minSeedBin = 1024;               /* smallest bin of a pixel that can seed a region (has an angle) */
         for (int y = 0; y < H - 1; ++y)
-            for (int x = 0; x < W - 1; ++x)
-                order_.push_back(((uint32_t)int(mod_[(size_t)y * W + x] * binCoef) << LSD_ORDER_IDX_BITS) | ((uint32_t)y << 11) | (uint32_t)x);
+            for (int x = 0; x < W - 1; ++x) {
+                const uint32_t bin = (uint32_t)int(mod_[(size_t)y * W + x] * binCoef);
+                if (used_[(size_t)y * W + x] == 0 && bin < minSeedBin) minSeedBin = bin;
+                order_.push_back((bin << LSD_ORDER_IDX_BITS) | ((uint32_t)y << 11) | (uint32_t)x);
+            }
+        minSeedBin_ = minSeedBin;
         /* std::sort, as OpenCV: the order of equal bins is whatever libstdc++'s introsort leaves - reproduced move for move by
          * lsd_order::sort (introsort_restated.h) without the per-element branch mispredictions; DRFE_LSD_STD_SORT=1 calls std::sort */
         static const bool stdSort = std::getenv("DRFE_LSD_STD_SORT") != nullptr;
+        /* pixels without an angle never seed (the loop below skips them): the ranges that hold only bins below the smallest
+         * seed bin are left unsorted and the seed loop stops where they begin */
         if (stdSort) std::sort(order_.begin(), order_.end(), lsd_order::Before());
-        else lsd_order::sort(order_.data(), order_.size(), orderTmp_);
+        else lsd_order::sort(order_.data(), order_.size(), orderTmp_, -1, -1, minSeedBin_);
         logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     }
 
@@ -88,6 +95,7 @@ public:
          * (whose `used` bookkeeping is the sequential part) and evaluated for all rectangles of the frame at once */
         std::vector<RectD> pending;
         for (const OPt& key : order_) {
+            if ((key >> LSD_ORDER_IDX_BITS) < minSeedBin_) break;          /* bins descend: no seed from here on */
             const struct { int x, y; } s = {(int)(key & 0x7FFu), (int)((key >> 11) & 0x7FFu)};
             if (used_[(size_t)s.y * W_ + s.x]) continue;          /* claimed, or no angle */
             double regAngle;
@@ -132,6 +140,7 @@ private:
     std::vector<uint8_t>& used_;
     std::vector<OPt>& order_;
     std::vector<OPt>& orderTmp_;
+    uint32_t minSeedBin_ = 0;
     double logNT_;
 
     static double sq(double v) { return v * v; }
@@ -762,8 +771,9 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
 /* Test hook of introsort_restated.h: records sorted in place.  kind 0: LSD keys (uint32: bin << 22 | y << 11 | x, larger bins
  * first); kind 1: VoxelGrid records (uint64: leaf << 32 | point, smaller leaves first).  mode 0: std::sort with the reference's
  * comparator; 1 / 2: the restatement with scalar / AVX2 stopper masks; 3: the plain transcription of libstdc++'s introsort.
- * depth_limit >= 0 replaces 2 lg n (modes 1-3).  DRFE_ERR_STATE for mode 2 on a CPU without AVX2. */
-int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_limit)
+ * depth_limit >= 0 replaces 2 lg n (modes 1-3).  skip_below (kind 0, modes 1 / 2): only the keys with bin >= skip_below are wanted
+ * (lsd_order::sort).  DRFE_ERR_STATE for mode 2 on a CPU without AVX2. */
+int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_limit, uint32_t skip_below)
 {
     if (!recs || mode < 0 || mode > 3 || kind < 0 || kind > 1) return DRFE_ERR_INVALID;
     if (mode == 2 && !isr::have_avx2()) return DRFE_ERR_STATE;
@@ -772,7 +782,7 @@ int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_li
         std::vector<uint32_t> tmp;
         if (mode == 0) std::sort(keys, keys + n, lsd_order::Before());
         else if (mode == 3) lsd_order::reference_sort(keys, n, depth_limit);
-        else lsd_order::sort(keys, n, tmp, mode - 1, depth_limit);
+        else lsd_order::sort(keys, n, tmp, mode - 1, depth_limit, skip_below);
     } else {
         uint64_t* r = static_cast<uint64_t*>(recs);
         if (mode == 0) std::sort(r, r + n, voxel_order::Before());

@@ -171,7 +171,7 @@ def load() -> C.CDLL:
                                               C.POINTER(i32), C.POINTER(i32)]
     L.drfe_planes_ahc_post_batch.argtypes = [vp, vp, sz, i32, i32, sz, i32, vp, f32, f32, f64, vp, i32, vp, vp, vp, vp, vp, i32]
     L.drfe_debug_ahc_trials.argtypes = [vp, vp, i32, i32, vp]
-    L.drfe_debug_order_sort.argtypes = [vp, sz, i32, i32, i32]
+    L.drfe_debug_order_sort.argtypes = [vp, sz, i32, i32, i32, C.c_uint32]
     L.drfe_planes_ahc_from_blocks.argtypes = [vp, vp, vp, i32, i32, sz, vp, f32, vp, i32, C.POINTER(i32), vp, vp, vp]
     L.drfe_planes_cape_postprocess.argtypes = [vp, vp, i32, i32, sz, vp, vp, vp, i32, f32, f64, vp, vp, vp, i32,
                                                C.POINTER(i32), C.POINTER(i32)]

@@ -478,8 +478,10 @@ int drfe_debug_ahc_trials(const double* sums9, const int32_t* N, int n, int mode
  * pcl::VoxelGrid's index sort (uint64 records: leaf << 32 | point, smaller leaves first).  recs[n] sorted in place.  mode 0:
  * std::sort with the reference's comparator; 1 / 2: the product's restatement with scalar / AVX2 stopper masks; 3: the plain
  * transcription of libstdc++'s introsort.  depth_limit >= 0 replaces the 2 lg n of modes 1-3 (reaches the heap-sort branch).
- * DRFE_ERR_STATE if this CPU lacks AVX2 (mode 2).  Host code. */
-int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_limit);
+ * skip_below > 0 (kind 0, modes 1 / 2): only the keys whose bin is >= skip_below are wanted - they form a prefix of the result
+ * and come out in std::sort's order, the rest follows unsorted within its bins' ranges (what the product asks for: pixels
+ * without a level-line angle never seed a region).  DRFE_ERR_STATE if this CPU lacks AVX2 (mode 2).  Host code. */
+int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_limit, uint32_t skip_below);
 /* The host half of drfe_planes_ahc on caller-supplied block fits (the records drfe_planes_ahc_blocks returns), without a device:
  * graph, agglomerative clustering, block membership, flood fill, re-merge and labels.  Host code: CPU tests and profiling. */
 int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, const uint16_t* depth, int w, int h, size_t stride,

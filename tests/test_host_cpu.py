@@ -363,9 +363,9 @@ def test_restated_introsort_equals_std_sort():
     L = lib.load()
     rng = np.random.default_rng(11)
 
-    def run(recs, kind, mode, depth=-1):
+    def run(recs, kind, mode, depth=-1, skip_below=0):
         k = recs.copy()
-        rc = L.drfe_debug_order_sort(k.ctypes.data_as(C.c_void_p), len(k), kind, mode, depth)
+        rc = L.drfe_debug_order_sort(k.ctypes.data_as(C.c_void_p), len(k), kind, mode, depth, skip_below)
         if rc == -4:
             return None                               # no AVX2 on this CPU
         assert rc == 0
@@ -400,6 +400,17 @@ def test_restated_introsort_equals_std_sort():
             for mode in (1, 2, 3):
                 got = run(k, kind, mode)
                 assert got is None or np.array_equal(got, want), (kind, len(k), mode)
+            if kind == 0 and len(k):
+                # only the bins >= skip_below wanted: that prefix is std::sort's, the rest holds the same keys bin by bin
+                bins = k >> 22
+                for skip in (int(np.median(bins)), int(bins.max()), 1):
+                    keep = int((bins >= skip).sum())
+                    for mode in (1, 2):
+                        got = run(k, 0, mode, -1, skip)
+                        if got is None:
+                            continue
+                        assert np.array_equal(got[:keep], want[:keep]), (len(k), mode, skip)
+                        assert np.array_equal(got >> 22, want >> 22) and np.array_equal(np.sort(got), np.sort(want))
             if len(k) < 6000:
                 for depth in (0, 1, 3):
                     want_d = run(k, kind, 3, depth)
