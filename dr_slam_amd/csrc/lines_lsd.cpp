@@ -708,7 +708,8 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
         return DRFE_ERR_INVALID;
     }
     if (nframes == 0) return DRFE_OK;
-    int T = n_threads > 0 ? n_threads : drfe_default_host_threads();
+    /* default: 1.25 threads per CPU - a lane sleeps in stream synchronisations for about a fifth of a frame's time */
+    int T = n_threads > 0 ? n_threads : std::max(1, drfe_default_host_threads() * 5 / 4);
     T = std::max(1, std::min(T, nframes));
     HIPCHK(c, hipSetDevice(c->device));
     auto* pool = static_cast<std::vector<LineWorker>*>(c->lineWorkers);

@@ -649,7 +649,8 @@ int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_strid
         return DRFE_ERR_INVALID;
     }
     if (nframes == 0) return DRFE_OK;
-    int T = n_threads > 0 ? n_threads : drfe_default_host_threads();
+    /* default: 1.25 threads per CPU - a lane sleeps in stream synchronisations for about a fifth of a frame's time */
+    int T = n_threads > 0 ? n_threads : std::max(1, drfe_default_host_threads() * 5 / 4);
     T = std::max(1, std::min(T, nframes));
     HIPCHK(c, hipSetDevice(c->device));
     auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);
@@ -735,7 +736,8 @@ int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_
         return DRFE_ERR_INVALID;
     }
     if (nframes == 0) return DRFE_OK;
-    int T = n_threads > 0 ? n_threads : drfe_default_host_threads();
+    /* default: 1.25 threads per CPU - a lane sleeps in stream synchronisations for about a fifth of a frame's time */
+    int T = n_threads > 0 ? n_threads : std::max(1, drfe_default_host_threads() * 5 / 4);
     T = std::max(1, std::min(T, nframes));
     HIPCHK(c, hipSetDevice(c->device));
     auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);

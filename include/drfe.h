@@ -256,7 +256,8 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
  * frame) are independent between frames and run on a pool of n_threads host threads, one device lane (scratch +
  * stream) each — frames instead of the reference's four extractors across threads (src/Frame.cc:116-126).  Outputs per
  * frame f at lines[f * cap], ldesc[f * cap * 32], line_f[f * cap * 3], n_lines[f], n_detected[f]; results are identical
- * to nframes calls of drfe_lsd_extract.  n_threads <= 0: the CPUs this process may use (affinity mask clipped by the cgroup quota). */
+ * to nframes calls of drfe_lsd_extract.  n_threads <= 0: 1.25 x the CPUs this process may use (affinity mask clipped by the cgroup
+ * quota; a lane sleeps in stream synchronisations for about a fifth of a frame's time). */
 int drfe_lsd_extract_batch(drfe_ctx* ctx, const uint8_t* gray, size_t frame_stride, int w, int h, size_t stride, int nframes,
                            int max_lines, drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines,
                            int* n_detected, int n_threads);
@@ -460,7 +461,8 @@ int drfe_planes_ahc(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t s
  * microseconds on the device, the per-frame clustering / erosion / flood fill (~7 ms) is sequential host code that is
  * independent between frames and runs on n_threads host threads, one device lane each.  Outputs per frame f at
  * planes[f * cap], n_planes[f], seg + f * w * h, member_offsets[f * (cap + 1)], member_idx + f * w * h (the last three
- * may be NULL); identical to nframes single calls.  n_threads <= 0: the CPUs this process may use (affinity mask clipped by the cgroup quota). */
+ * may be NULL); identical to nframes single calls.  n_threads <= 0: 1.25 x the CPUs this process may use (affinity mask clipped by
+ * the cgroup quota). */
 int drfe_planes_ahc_batch(drfe_ctx* ctx, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
                           const float* K4, float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
                           int32_t* member_offsets, int32_t* member_idx, int n_threads);
