@@ -1124,29 +1124,26 @@ int drfe_search_for_initialization(drfe_ctx* c, int slot1, int slot2, float* pre
     return DRFE_OK;
 }
 
-/* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, th), src/LSDmatcher.cpp:884-1010: the search */
-int drfe_lsd_fuse_search(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
-                         const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,
-                         int32_t* best_idx, int32_t* best_dist)
+/* the device search shared by LSDmatcher::Fuse x2, SearchByProjection(KF, Scw) and both directions of SearchBySim3: pose P
+ * (and, for SearchBySim3, the similarity chained onto it), one wavefront per map line over the keyframe's key lines.
+ * dist_rows != NULL: [n][n_kf] distances of the key lines that passed every gate (-1 otherwise) for a first-come replay. */
+static int lsd_fuse_impl(drfe_ctx* c, const char* who, const FrustumPose& P, const drfe_camera* cam, const drfe_frustum_line* lines,
+                         const uint8_t* descs, const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf,
+                         float th, int32_t* best_idx, int32_t* best_dist, const LineSim3* sim3, std::vector<int32_t>* dist_rows)
 {
-    if (!c || !Tcw || !cam || n < 0 || n_kf < 0 || (n && (!lines || !descs || !best_idx || !best_dist)) || (n_kf && (!kf_lines || !kf_desc)))
-        return DRFE_ERR_INVALID;
-    if (n == 0) return DRFE_OK;
-    if (n_kf > 65535) { c->err = "lsd_fuse_search: too many key lines"; return DRFE_ERR_CAPACITY; }
+    if (n_kf > 65535) { c->err = std::string(who) + ": too many key lines"; return DRFE_ERR_CAPACITY; }
     HIPCHK(c, hipSetDevice(c->device));
     MatchBuffers* m = drfe_match_buffers(c);
     if (!m) return DRFE_ERR_HIP;
-    FrustumPose P;
-    frustum_pose(c, Tcw, cam, 0.f, &P);
-    camera_centre_kf(Tcw, P.Ow);
     std::vector<LineCur> lc(n_kf);
     for (int i = 0; i < n_kf; i++) {
         lc[i].ptX = kf_lines[i].pt_x; lc[i].ptY = kf_lines[i].pt_y; lc[i].angle = kf_lines[i].angle; lc[i].octave = kf_lines[i].octave;
     }
     auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t rows = dist_rows ? sizeof(int) * (size_t)n * (size_t)n_kf : 0;
     const size_t oL = 0, oD = up(sizeof(drfe_frustum_line) * (size_t)n), oS = oD + up((size_t)n * 32), oK = oS + up((size_t)n),
                  oKD = oK + up(sizeof(LineCur) * (size_t)n_kf), oI = oKD + up((size_t)n_kf * 32), oB = oI + up(sizeof(int) * (size_t)n),
-                 total = oB + sizeof(int) * (size_t)n;
+                 oR = oB + up(sizeof(int) * (size_t)n), total = oR + rows;
     uint8_t* d = nullptr;
     HIPCHK(c, call_scratch(c, total, &d));
     hipStream_t s = c->stream;
@@ -1158,11 +1155,142 @@ int drfe_lsd_fuse_search(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, 
     if (e == hipSuccess)
         e = drfe_launch_line_fuse_search(reinterpret_cast<const drfe_frustum_line*>(d + oL), d + oD, skip ? d + oS : nullptr, n, P, *cam,
                                          m->d_scale, th, reinterpret_cast<const LineCur*>(d + oK), d + oKD, n_kf,
-                                         reinterpret_cast<int*>(d + oI), reinterpret_cast<int*>(d + oB), s);
+                                         reinterpret_cast<int*>(d + oI), reinterpret_cast<int*>(d + oB), s, sim3,
+                                         rows ? reinterpret_cast<int*>(d + oR) : nullptr);
     if (e == hipSuccess) e = hipMemcpyAsync(best_idx, d + oI, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(best_dist, d + oB, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rows) {
+        dist_rows->resize((size_t)n * (size_t)n_kf);
+        e = hipMemcpyAsync(dist_rows->data(), d + oR, rows, hipMemcpyDeviceToHost, s);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { c->err = std::string("lsd_fuse_search: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    if (e != hipSuccess) { c->err = std::string(who) + ": " + hipGetErrorString(e); return DRFE_ERR_HIP; }
+    return DRFE_OK;
+}
+
+/* Scw -> [Rcw | tcw] as LSDmatcher.cpp:386-390 / :759-763 evaluate it (Mat::dot in double, Mat / float through convertTo) */
+static void decompose_scw(const float* Scw, float T[16])
+{
+    const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) T[r * 4 + k] = Scw[r * 4 + k] * inv;
+        T[r * 4 + 3] = Scw[r * 4 + 3] * inv;
+    }
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+}
+
+/* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, th), src/LSDmatcher.cpp:884-1010: the search */
+int drfe_lsd_fuse_search(drfe_ctx* c, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
+                         const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,
+                         int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c || !Tcw || !cam || n < 0 || n_kf < 0 || (n && (!lines || !descs || !best_idx || !best_dist)) || (n_kf && (!kf_lines || !kf_desc)))
+        return DRFE_ERR_INVALID;
+    if (n == 0) return DRFE_OK;
+    FrustumPose P;
+    frustum_pose(c, Tcw, cam, 0.f, &P);
+    camera_centre_kf(Tcw, P.Ow);
+    return lsd_fuse_impl(c, "lsd_fuse_search", P, cam, lines, descs, skip, n, kf_lines, kf_desc, n_kf, th, best_idx, best_dist, nullptr, nullptr);
+}
+
+/* LSDmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, vpLines, th, vpReplaceLine), src/LSDmatcher.cpp:750-882: the search.  The pose
+ * is the decomposed similarity, the camera centre -Rcw.t()*tcw (:763) */
+int drfe_lsd_fuse_search_sim3(drfe_ctx* c, const float* Scw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
+                              const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,
+                              int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c || !Scw || !cam || n < 0 || n_kf < 0 || (n && (!lines || !descs || !best_idx || !best_dist)) || (n_kf && (!kf_lines || !kf_desc)))
+        return DRFE_ERR_INVALID;
+    if (n == 0) return DRFE_OK;
+    float T[16];
+    decompose_scw(Scw, T);
+    FrustumPose P;
+    frustum_pose(c, T, cam, 0.f, &P);                 /* Ow = -Rcw.t()*tcw */
+    return lsd_fuse_impl(c, "lsd_fuse_search_sim3", P, cam, lines, descs, skip, n, kf_lines, kf_desc, n_kf, th, best_idx, best_dist, nullptr,
+                         nullptr);
+}
+
+/* LSDmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpLines, vpMatched, th), src/LSDmatcher.cpp:377-502.  The loop over
+ * the map lines is first come, first served (a key line taken by an earlier line is no candidate, :476): the device returns every
+ * line's gated distances, the host replays the claims in order. */
+int drfe_lsd_search_by_projection_kf(drfe_ctx* c, const float* Scw, const drfe_camera* cam, const drfe_frustum_line* lines,
+                                     const uint8_t* descs, const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc,
+                                     int n_kf, const uint8_t* matched, int th, int32_t* new_match, int* n_matches)
+{
+    if (!c || !Scw || !cam || !n_matches || n < 0 || n_kf < 0 || (n && (!lines || !descs)) || (n_kf && (!kf_lines || !kf_desc || !matched || !new_match)))
+        return DRFE_ERR_INVALID;
+    *n_matches = 0;
+    for (int k = 0; k < n_kf; k++) new_match[k] = -1;
+    if (n == 0 || n_kf == 0) return DRFE_OK;
+    float T[16];
+    decompose_scw(Scw, T);
+    FrustumPose P;
+    frustum_pose(c, T, cam, 0.f, &P);
+    std::vector<int32_t> bi(n), bd(n), rows;
+    const int rc = lsd_fuse_impl(c, "lsd_search_by_projection_kf", P, cam, lines, descs, skip, n, kf_lines, kf_desc, n_kf, (float)th, bi.data(),
+                                 bd.data(), nullptr, &rows);
+    if (rc != DRFE_OK) return rc;
+    std::vector<uint8_t> taken(matched, matched + n_kf);
+    int nm = 0;
+    for (int i = 0; i < n; i++) {
+        if (bi[i] < 0) continue;                         /* dropped by a gate, no candidate, or level outside the pyramid (-2) */
+        int bestDist = 256, bestIdx = -1;
+        const int32_t* row = &rows[(size_t)i * n_kf];
+        for (int idx = 0; idx < n_kf; idx++) {
+            if (row[idx] < 0 || taken[idx]) continue;
+            if (row[idx] < bestDist) { bestDist = row[idx]; bestIdx = idx; }
+        }
+        if (bestDist <= 50) { taken[bestIdx] = 1; new_match[bestIdx] = i; nm++; }        /* TH_LOW */
+    }
+    *n_matches = nm;
+    return DRFE_OK;
+}
+
+/* LSDmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/LSDmatcher.cpp:504-748: both directions on the
+ * device, the agreement check on the host.  lines / descs / skip are per key line of the keyframe (skip = no map line, bad, or
+ * already matched); kf1_lines / kf2_lines the key lines themselves. */
+int drfe_lsd_search_by_sim3(drfe_ctx* c, const drfe_camera* cam, const float* T1w, const float* T2w, float s12, const float* R12,
+                            const float* t12, const drfe_frustum_line* lines1, const uint8_t* descs1, const uint8_t* skip1,
+                            const drfe_keyline* kf1_lines, const uint8_t* kf1_desc, int n1, const drfe_frustum_line* lines2,
+                            const uint8_t* descs2, const uint8_t* skip2, const drfe_keyline* kf2_lines, const uint8_t* kf2_desc, int n2,
+                            float th, int32_t* matches12, int* n_found)
+{
+    if (!c || !cam || !T1w || !T2w || !R12 || !t12 || !matches12 || !n_found || n1 < 0 || n2 < 0) return DRFE_ERR_INVALID;
+    if ((n1 && (!lines1 || !descs1 || !skip1 || !kf1_lines || !kf1_desc)) || (n2 && (!lines2 || !descs2 || !skip2 || !kf2_lines || !kf2_desc)))
+        return DRFE_ERR_INVALID;
+    *n_found = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return DRFE_OK;
+    /* sR12 = s12*R12, sR21 = (1.0/s12)*R12.t(), t21 = -sR21*t12 (:521-523) as cv::Mat evaluates them */
+    LineSim3 c21, c12;
+    const float a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) { c12.sR[r * 3 + k] = R12[r * 3 + k] * s12; c21.sR[r * 3 + k] = R12[k * 3 + r] * a21; }
+    for (int r = 0; r < 3; r++) {
+        const float d = c21.sR[r * 3] * t12[0] + c21.sR[r * 3 + 1] * t12[1] + c21.sR[r * 3 + 2] * t12[2];
+        c21.t[r] = (float)((double)d * -1.0);
+        c12.t[r] = t12[r];
+    }
+    std::vector<int32_t> m1(n1), d1(n1), m2(n2), d2(n2);
+    FrustumPose P;
+    frustum_pose(c, T1w, cam, 0.f, &P);
+    int rc = lsd_fuse_impl(c, "lsd_search_by_sim3", P, cam, lines1, descs1, skip1, n1, kf2_lines, kf2_desc, n2, th, m1.data(), d1.data(), &c21,
+                           nullptr);
+    if (rc != DRFE_OK) return rc;
+    frustum_pose(c, T2w, cam, 0.f, &P);
+    rc = lsd_fuse_impl(c, "lsd_search_by_sim3", P, cam, lines2, descs2, skip2, n2, kf1_lines, kf1_desc, n1, th, m2.data(), d2.data(), &c12,
+                       nullptr);
+    if (rc != DRFE_OK) return rc;
+    int found = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int idx2 = (m1[i1] >= 0 && d1[i1] <= 100) ? m1[i1] : -1;                /* TH_HIGH */
+        if (idx2 < 0) continue;
+        const int idx1 = (m2[idx2] >= 0 && d2[idx2] <= 100) ? m2[idx2] : -1;
+        if (idx1 == i1) { matches12[i1] = idx2; found++; }
+    }
+    *n_found = found;
     return DRFE_OK;
 }
 

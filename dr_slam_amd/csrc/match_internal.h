@@ -75,10 +75,14 @@ hipError_t drfe_launch_frustum_lines(const drfe_frustum_line* d_lines, int n, co
 
 /* LSDmatcher::Fuse search: one wavefront per map line over the keyframe's key lines; bestIdx -2 = predicted level outside
  * the pyramid */
+/* the similarity chained onto the source keyframe's pose in LSDmatcher::SearchBySim3: x2 = sR * x1 + t */
+struct LineSim3 { float sR[9], t[3]; };
+/* sim3 != NULL: the SearchBySim3 direction (P.T = pose of the source keyframe); d_distRow != NULL: [n][nKF] Hamming distance of
+ * every key line that passed the gates, -1 otherwise (first-come replay on the host) */
 hipError_t drfe_launch_line_fuse_search(const drfe_frustum_line* d_lines, const uint8_t* d_descs, const uint8_t* d_skip, int n,
                                         const FrustumPose& P, const drfe_camera& cam, const float* d_scale, float th,
                                         const LineCur* d_kf, const uint8_t* d_kfDesc, int nKF, int* d_bestIdx, int* d_bestDist,
-                                        hipStream_t s);
+                                        hipStream_t s, const LineSim3* sim3 = nullptr, int* d_distRow = nullptr);
 
 struct FuseParams { float T[16]; float Ow[3]; float bf, logScale, th; int nLevels; float scale[16], invSigma2[16];
                     int sim3; /* 1: the Scw overload of Fuse: no chi-square gate, invz = (float)(1.0 / z);

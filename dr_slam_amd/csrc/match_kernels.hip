@@ -1057,7 +1057,8 @@ __global__ __launch_bounds__(256) void k_line_fuse_search(const drfe_frustum_lin
                                                           const uint8_t* __restrict__ skip, int n, FrustumPose P, drfe_camera cam,
                                                           const float* __restrict__ scale, float th,
                                                           const LineCur* __restrict__ kf, const uint8_t* __restrict__ kfDesc, int nKF,
-                                                          int* __restrict__ bestIdx, int* __restrict__ bestDist)
+                                                          int* __restrict__ bestIdx, int* __restrict__ bestDist, int sim3,
+                                                          LineSim3 C, int* __restrict__ distRow)
 {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (256 / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1070,21 +1071,43 @@ __global__ __launch_bounds__(256) void k_line_fuse_search(const drfe_frustum_lin
     float SPc[3], EPc[3];
     mat3_mul_add(P.T, SP, SPc);
     mat3_mul_add(P.T, EP, EPc);
+    if (sim3) {                                  /* LSDmatcher::SearchBySim3: SPc2 = sR * (R1w * SP + t1w) + t, :566-574 */
+        float a[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) a[r] = (C.sR[r * 3] * SPc[0] + C.sR[r * 3 + 1] * SPc[1] + C.sR[r * 3 + 2] * SPc[2]) + C.t[r];
+#pragma unroll
+        for (int r = 0; r < 3; r++) SPc[r] = a[r];
+#pragma unroll
+        for (int r = 0; r < 3; r++) a[r] = (C.sR[r * 3] * EPc[0] + C.sR[r * 3 + 1] * EPc[1] + C.sR[r * 3 + 2] * EPc[2]) + C.t[r];
+#pragma unroll
+        for (int r = 0; r < 3; r++) EPc[r] = a[r];
+    }
     if (SPc[2] < 0.0f || EPc[2] < 0.0f) ok = false;
     const float invz1 = 1.0f / SPc[2];
     const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
-    if (u1 < cam.min_x || u1 > cam.max_x || v1 < cam.min_y || v1 > cam.max_y) ok = false;
     const float invz2 = 1.0f / EPc[2];
     const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
-    if (u2 < cam.min_x || u2 > cam.max_x || v2 < cam.min_y || v2 > cam.max_y) ok = false;
     const float maxDistance = 1.2f * l.max_distance, minDistance = 0.8f * l.min_distance;
-    float OM[3];
+    float dist;
+    if (sim3) {                                  /* KeyFrame::IsInImage, distance of the midpoint in the target camera, no cone */
+        if (!(u1 >= cam.min_x && u1 < cam.max_x && v1 >= cam.min_y && v1 < cam.max_y)) ok = false;
+        if (!(u2 >= cam.min_x && u2 < cam.max_x && v2 >= cam.min_y && v2 < cam.max_y)) ok = false;
+        const float mid[3] = {(SPc[0] + EPc[0]) * 0.5f, (SPc[1] + EPc[1]) * 0.5f, (SPc[2] + EPc[2]) * 0.5f};
+        dist = norm3_f(mid);
+        if (dist < minDistance || dist > maxDistance) ok = false;
+    } else {
+        if (u1 < cam.min_x || u1 > cam.max_x || v1 < cam.min_y || v1 > cam.max_y) ok = false;
+        if (u2 < cam.min_x || u2 > cam.max_x || v2 < cam.min_y || v2 > cam.max_y) ok = false;
+        float OM[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) OM[k] = (SP[k] + EP[k]) * 0.5f - P.Ow[k];
-    const float dist = norm3_f(OM);
-    if (dist < minDistance || dist > maxDistance) ok = false;
-    const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
-    if (dot3_d(OM, pn) < 0.5 * (double)dist) ok = false;
+        for (int k = 0; k < 3; k++) OM[k] = (SP[k] + EP[k]) * 0.5f - P.Ow[k];
+        dist = norm3_f(OM);
+        if (dist < minDistance || dist > maxDistance) ok = false;
+        const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
+        if (dot3_d(OM, pn) < 0.5 * (double)dist) ok = false;
+    }
+    if (distRow)                                 /* per-key-line distances for the host's first-come replay: -1 = no candidate */
+        for (int idx = lane; idx < nKF; idx += WAVE) distRow[(size_t)i * nKF + idx] = -1;
     if (ok) {
         const float ratio = l.max_distance / dist;
         const int level = (int)ceilf(drfe_logf(ratio) / P.logScale);
@@ -1111,6 +1134,7 @@ __global__ __launch_bounds__(256) void k_line_fuse_search(const drfe_frustum_lin
                 const int hd = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
                 const uint32_t key = ((uint32_t)hd << 16) | (uint32_t)idx;
                 if (key < best) best = key;
+                if (distRow) distRow[(size_t)i * nKF + idx] = hd;
             }
             const uint32_t mn = wave_min_u32(best);
             if (mn != 0xFFFFFFFFu) { outIdx = (int)(mn & 0xFFFF); outDist = (int)(mn >> 16); }
@@ -1122,10 +1146,13 @@ __global__ __launch_bounds__(256) void k_line_fuse_search(const drfe_frustum_lin
 hipError_t drfe_launch_line_fuse_search(const drfe_frustum_line* d_lines, const uint8_t* d_descs, const uint8_t* d_skip, int n,
                                         const FrustumPose& P, const drfe_camera& cam, const float* d_scale, float th,
                                         const LineCur* d_kf, const uint8_t* d_kfDesc, int nKF, int* d_bestIdx, int* d_bestDist,
-                                        hipStream_t s)
+                                        hipStream_t s, const LineSim3* sim3, int* d_distRow)
 {
+    LineSim3 C;
+    memset(&C, 0, sizeof(C));
+    if (sim3) C = *sim3;
     hipLaunchKernelGGL(k_line_fuse_search, dim3((n + 3) / 4), dim3(256), 0, s, d_lines, d_descs, d_skip, n, P, cam, d_scale, th,
-                       d_kf, d_kfDesc, nKF, d_bestIdx, d_bestDist);
+                       d_kf, d_kfDesc, nKF, d_bestIdx, d_bestDist, sim3 ? 1 : 0, C, d_distRow);
     return hipGetLastError();
 }
 

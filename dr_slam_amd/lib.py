@@ -37,7 +37,8 @@ SYMBOLS = (
     "drfe_search_by_bow", "drfe_search_by_bow_kf", "drfe_search_for_triangulation", "drfe_lsd_extract", "drfe_lsd_extract_batch", "drfe_lsd_stages", "drfe_lines_is_good", "drfe_lsd_search_by_descriptor", "drfe_lsd_search_for_triangulation", "drfe_lsd_search_by_projection_last",
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
     "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
-    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization",
+    "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
+    "drfe_lsd_search_by_sim3",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -138,6 +139,10 @@ def load() -> C.CDLL:
     L.drfe_lines_is_good.argtypes = [vp, i32, vp, i32, i32, C.c_size_t, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_uint32, vp, vp, vp, C.POINTER(i32)]
     L.drfe_lsd_fuse_search.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp]
+    L.drfe_lsd_fuse_search_sim3.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp]
+    L.drfe_lsd_search_by_projection_kf.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, C.POINTER(i32)]
+    L.drfe_lsd_search_by_sim3.argtypes = [vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, C.c_float,
+                                          vp, C.POINTER(i32)]
     L.drfe_search_by_projection_reloc.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, C.c_float, i32, i32, vp, C.POINTER(i32)]
     L.drfe_search_for_initialization.argtypes = [vp, i32, i32, vp, i32, i32, C.c_float, i32, vp, C.POINTER(i32)]
     L.drfe_search_by_projection_kf.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, C.c_float, vp, C.POINTER(i32)]
@@ -505,6 +510,48 @@ class Context:
                                               len(l), _p(kl), _p(np.ascontiguousarray(kf_desc, np.uint8)), len(kl), C.c_float(th),
                                               _p(bi), _p(bd)), "drfe_lsd_fuse_search")
         return bi, bd
+
+    def lsd_fuse_search_sim3(self, Scw, cam, lines, descs, skip, kf_lines, kf_desc, th):
+        """Search part of LSDmatcher::Fuse(pKF, Scw, vpLines, th, vpReplaceLine); returns (best_idx, best_dist) per map line."""
+        l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+        kl = np.ascontiguousarray(kf_lines, KEYLINE_DTYPE)
+        bi = np.zeros(len(l), np.int32)
+        bd = np.zeros(len(l), np.int32)
+        self._chk(self.L.drfe_lsd_fuse_search_sim3(self.h, _p(np.ascontiguousarray(Scw, np.float32).reshape(16)), C.byref(cam), _p(l),
+                                                   _p(np.ascontiguousarray(descs, np.uint8)), _p(np.ascontiguousarray(skip, np.uint8)),
+                                                   len(l), _p(kl), _p(np.ascontiguousarray(kf_desc, np.uint8)), len(kl), C.c_float(th),
+                                                   _p(bi), _p(bd)), "drfe_lsd_fuse_search_sim3")
+        return bi, bd
+
+    def lsd_search_by_projection_kf(self, Scw, cam, lines, descs, skip, kf_lines, kf_desc, matched, th):
+        """LSDmatcher::SearchByProjection(pKF, Scw, vpLines, vpMatched, th); returns (nmatches, new_match per key line)."""
+        l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+        kl = np.ascontiguousarray(kf_lines, KEYLINE_DTYPE)
+        m = np.ascontiguousarray(matched, np.uint8)
+        out = np.full(len(kl), -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_lsd_search_by_projection_kf(self.h, _p(np.ascontiguousarray(Scw, np.float32).reshape(16)), C.byref(cam),
+                                                          _p(l), _p(np.ascontiguousarray(descs, np.uint8)),
+                                                          _p(np.ascontiguousarray(skip, np.uint8)), len(l), _p(kl),
+                                                          _p(np.ascontiguousarray(kf_desc, np.uint8)), len(kl), _p(m), int(th), _p(out),
+                                                          C.byref(n)), "drfe_lsd_search_by_projection_kf")
+        return n.value, out
+
+    def lsd_search_by_sim3(self, cam, T1w, T2w, s12, R12, t12, lines1, descs1, skip1, kf1_lines, kf1_desc, lines2, descs2, skip2,
+                           kf2_lines, kf2_desc, th):
+        """LSDmatcher::SearchBySim3; returns (nFound, matches12[i1] = key line of KF2 or -1)."""
+        f = lambda a, n: _p(np.ascontiguousarray(a, np.float32).reshape(n))
+        u8 = lambda a: _p(np.ascontiguousarray(a, np.uint8))
+        l1, l2 = np.ascontiguousarray(lines1, FRUSTUM_LINE_DTYPE), np.ascontiguousarray(lines2, FRUSTUM_LINE_DTYPE)
+        k1, k2 = np.ascontiguousarray(kf1_lines, KEYLINE_DTYPE), np.ascontiguousarray(kf2_lines, KEYLINE_DTYPE)
+        assert len(l1) == len(k1) and len(l2) == len(k2)
+        out = np.full(len(l1), -1, np.int32)
+        n = C.c_int()
+        self._chk(self.L.drfe_lsd_search_by_sim3(self.h, C.byref(cam), f(T1w, 16), f(T2w, 16), C.c_float(s12), f(R12, 9), f(t12, 3),
+                                                 _p(l1), u8(descs1), u8(skip1), _p(k1), u8(kf1_desc), len(l1), _p(l2), u8(descs2),
+                                                 u8(skip2), _p(k2), u8(kf2_desc), len(l2), C.c_float(th), _p(out), C.byref(n)),
+                  "drfe_lsd_search_by_sim3")
+        return n.value, out
 
     def search_by_projection_kf(self, slot, Scw, pts, descs, skip, matched, th):
         """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th); returns (nmatches, new_match per keypoint)."""

@@ -395,6 +395,27 @@ int drfe_search_for_initialization(drfe_ctx* ctx, int slot1, int slot2, float* p
 int drfe_lsd_fuse_search(drfe_ctx* ctx, const float* Tcw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
                          const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,
                          int32_t* best_idx, int32_t* best_dist);
+/* The search of LSDmatcher::Fuse(pKF, Scw, vpLines, th, vpReplaceLine) (src/LSDmatcher.cpp:750-882; public API without a caller in
+ * the reference): as drfe_lsd_fuse_search with the pose taken from the similarity Scw (4x4 row-major, decomposed as :759-763).
+ * skip[i] = !pML || isBad() || spAlreadyFound.count(pML).  The caller applies TH_LOW and the Replace / AddObservation surgery. */
+int drfe_lsd_fuse_search_sim3(drfe_ctx* ctx, const float* Scw, const drfe_camera* cam, const drfe_frustum_line* lines, const uint8_t* descs,
+                              const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc, int n_kf, float th,
+                              int32_t* best_idx, int32_t* best_dist);
+/* LSDmatcher::SearchByProjection(pKF, Scw, vpLines, vpMatched, th) (src/LSDmatcher.cpp:377-502).  matched[n_kf] = vpMatched[idx] !=
+ * NULL on entry; new_match[n_kf] = the map line that claimed key line idx in this call or -1 (the caller sets vpMatched[idx] =
+ * vpLines[new_match[idx]]); *n_matches = the return value.  First come, first served over the map lines, as the reference. */
+int drfe_lsd_search_by_projection_kf(drfe_ctx* ctx, const float* Scw, const drfe_camera* cam, const drfe_frustum_line* lines,
+                                     const uint8_t* descs, const uint8_t* skip, int n, const drfe_keyline* kf_lines, const uint8_t* kf_desc,
+                                     int n_kf, const uint8_t* matched, int th, int32_t* new_match, int* n_matches);
+/* LSDmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/LSDmatcher.cpp:504-748).  lines / descs / skip: one
+ * entry per key line of the keyframe (its map line; skip = none, bad, or already matched: :534-555), kf*_lines / kf*_desc the key
+ * lines themselves; T1w / T2w = the keyframe poses (4x4 row-major), R12 3x3 row-major.  matches12[n1] = key line of KF2 or -1
+ * (the caller stores vpMapLines2[matches12[i1]]); *n_found = the return value. */
+int drfe_lsd_search_by_sim3(drfe_ctx* ctx, const drfe_camera* cam, const float* T1w, const float* T2w, float s12, const float* R12,
+                            const float* t12, const drfe_frustum_line* lines1, const uint8_t* descs1, const uint8_t* skip1,
+                            const drfe_keyline* kf1_lines, const uint8_t* kf1_desc, int n1, const drfe_frustum_line* lines2,
+                            const uint8_t* descs2, const uint8_t* skip2, const drfe_keyline* kf2_lines, const uint8_t* kf2_desc, int n2,
+                            float th, int32_t* matches12, int* n_found);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and

@@ -518,6 +518,33 @@ void orc_lsd_fuse_search(const float* cam9, const float* Tcw, float logScale, co
     std::memcpy(&cam, cam9, sizeof(cam));
     lsd_fuse_search(cam, Tcw, logScale, scaleFactors, nLevels, lines, descs, skip, n, kf, kfDesc, nKF, th, bestIdx, bestDist);
 }
+void orc_lsd_fuse_search_sim3(const float* cam9, const float* Scw, float logScale, const float* scaleFactors, int nLevels,
+                              const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                              const uint8_t* kfDesc, int nKF, float th, int32_t* bestIdx, int32_t* bestDist)
+{
+    LineCamera cam;
+    std::memcpy(&cam, cam9, sizeof(cam));
+    lsd_fuse_search_sim3(cam, Scw, logScale, scaleFactors, nLevels, lines, descs, skip, n, kf, kfDesc, nKF, th, bestIdx, bestDist);
+}
+int orc_lsd_search_by_projection_kf(const float* cam9, const float* Scw, float logScale, const float* scaleFactors, int nLevels,
+                                    const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                                    const uint8_t* kfDesc, int nKF, const uint8_t* matched, int th, int32_t* newMatch)
+{
+    LineCamera cam;
+    std::memcpy(&cam, cam9, sizeof(cam));
+    return lsd_search_by_projection_kf(cam, Scw, logScale, scaleFactors, nLevels, lines, descs, skip, n, kf, kfDesc, nKF, matched, th, newMatch);
+}
+int orc_lsd_search_by_sim3(const float* cam9, const float* T1w, const float* T2w, float s12, const float* R12, const float* t12,
+                           float logScale, const float* scaleFactors, int nLevels, const FrustumLineRec* lines1, const uint8_t* descs1,
+                           const uint8_t* skip1, const LineRec* kf1, const uint8_t* kf1Desc, int n1, const FrustumLineRec* lines2,
+                           const uint8_t* descs2, const uint8_t* skip2, const LineRec* kf2, const uint8_t* kf2Desc, int n2, float th,
+                           int32_t* out12)
+{
+    LineCamera cam;
+    std::memcpy(&cam, cam9, sizeof(cam));
+    return lsd_search_by_sim3(cam, T1w, T2w, s12, R12, t12, logScale, scaleFactors, nLevels, lines1, descs1, skip1, kf1, kf1Desc, n1,
+                              lines2, descs2, skip2, kf2, kf2Desc, n2, th, out12);
+}
 int orc_search_by_projection_kf(void* kf, const float* Scw, float logScale, int nLevels, const FrustumPointRec* pts,
                                 const uint8_t* descs, const uint8_t* skip, int n, const uint8_t* matched, float th, int32_t* newMatch)
 {

@@ -1004,4 +1004,187 @@ int search_for_initialization(const Frame& F1, const Frame& F2, float* prevMatch
     return nmatches;
 }
 
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* LSDmatcher's loop-closing variants (no caller in the reference; public API, src/LSDmatcher.cpp:377-882)  */
+
+/* the common front of Fuse(KF, Scw, ...) / SearchByProjection(KF, Scw, ...): projection of both end points with the
+ * decomposed similarity, image bounds, distance band, 60-degree cone, PredictScale, KeyFrame::GetLinesInArea and the
+ * octave window (:408-470 / :783-845).  Returns false when the map line is dropped; level == -2 flags a predicted level
+ * outside the pyramid (mvScaleFactors[level] is out of bounds in the reference). */
+static bool lsd_scw_candidates(const LineCamera& cam, const float Rcw[9], const float tcw[3], const float Ow[3], float logScaleFactor,
+                               const float* scaleFactors, int nLevels, const FrustumLineRec& l, const LineRec* kf, int nKF, float th,
+                               int& level, std::vector<int>& cand)
+{
+    cand.clear();
+    level = -1;
+    const float SP[3] = {(float)l.world[0], (float)l.world[1], (float)l.world[2]};
+    const float EP[3] = {(float)l.world[3], (float)l.world[4], (float)l.world[5]};
+    float SPc[3], EPc[3];
+    mat3_mul_add(Rcw, SP, tcw, SPc);
+    mat3_mul_add(Rcw, EP, tcw, EPc);
+    if (SPc[2] < 0.0f || EPc[2] < 0.0f) return false;
+    const float invz1 = 1.0f / SPc[2];
+    const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+    if (u1 < cam.minX || u1 > cam.maxX) return false;
+    if (v1 < cam.minY || v1 > cam.maxY) return false;
+    const float invz2 = 1.0f / EPc[2];
+    const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+    if (u2 < cam.minX || u2 > cam.maxX) return false;
+    if (v2 < cam.minY || v2 > cam.maxY) return false;
+    const float maxDistance = 1.2f * l.maxDistance, minDistance = 0.8f * l.minDistance;
+    float OM[3];
+    for (int k = 0; k < 3; k++) OM[k] = (SP[k] + EP[k]) * 0.5f - Ow[k];
+    const float dist = norm3(OM);
+    if (dist < minDistance || dist > maxDistance) return false;
+    const float pn[3] = {(float)l.normal[0], (float)l.normal[1], (float)l.normal[2]};
+    if (dot3(OM, pn) < 0.5 * (double)dist) return false;
+    const float ratio = l.maxDistance / dist;
+    level = (int)std::ceil(log_f(ratio) / logScaleFactor);                    /* MapLine::PredictScale: no clamp */
+    if (level < 0 || level >= nLevels) { level = -2; return true; }
+    const float radius = th * scaleFactors[level];
+    std::vector<int> area;
+    get_lines_in_area(kf, nKF, u1, v1, u2, v2, radius, -1, -1, area);
+    for (int idx : area) {
+        const int klLevel = kf[idx].octave;
+        if (klLevel < level - 1 || klLevel > level) continue;
+        cand.push_back(idx);
+    }
+    return true;
+}
+
+/* LSDmatcher::Fuse(KeyFrame*, cv::Mat Scw, vpLines, th, vpReplaceLine), :750-882: the search.  bestIdx[i] = key line or -1
+ * (-2: predicted level outside the pyramid), bestDist[i] its distance (INT_MAX if none); the caller applies TH_LOW */
+void lsd_fuse_search_sim3(const LineCamera& cam, const float Scw[16], float logScaleFactor, const float* scaleFactors, int nLevels,
+                          const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                          const uint8_t* kfDesc, int nKF, float th, int32_t* bestIdx, int32_t* bestDist)
+{
+    float T[16], Rcw[9], tcw[3], Ow[3];
+    decompose_sim3(Scw, T);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = T[r * 4 + c]; tcw[r] = T[r * 4 + 3]; }
+    camera_centre(Rcw, tcw, Ow);                                              /* -Rcw.t()*tcw, :763 */
+    std::vector<int> cand;
+    for (int i = 0; i < n; i++) {
+        bestIdx[i] = -1; bestDist[i] = INT_MAX;
+        if (skip && skip[i]) continue;                                        /* !pML || isBad() || spAlreadyFound.count(pML) */
+        int level;
+        if (!lsd_scw_candidates(cam, Rcw, tcw, Ow, logScaleFactor, scaleFactors, nLevels, lines[i], kf, nKF, th, level, cand)) continue;
+        if (level == -2) { bestIdx[i] = -2; continue; }
+        for (int idx : cand) {
+            const int d = descriptor_distance_swar(descs + (size_t)i * 32, kfDesc + (size_t)idx * 32);
+            if (d < bestDist[i]) { bestDist[i] = d; bestIdx[i] = idx; }
+        }
+    }
+}
+
+/* LSDmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, vpLines, vpMatched, th), :377-502: first come, first served over
+ * the map lines - a key line whose vpMatched entry is set (on entry or by an earlier line) is no candidate.  matched[idx] != 0 on
+ * entry = vpMatched[idx] != NULL; newMatch[idx] = the line that claimed key line idx in this call or -1.  A predicted level
+ * outside the pyramid drops the line (the reference reads past mvScaleFactors there).  Returns nmatches. */
+int lsd_search_by_projection_kf(const LineCamera& cam, const float Scw[16], float logScaleFactor, const float* scaleFactors, int nLevels,
+                                const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                                const uint8_t* kfDesc, int nKF, const uint8_t* matched, int th, int32_t* newMatch)
+{
+    const int TH_LOW = 50;
+    float T[16], Rcw[9], tcw[3], Ow[3];
+    decompose_sim3(Scw, T);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r * 3 + c] = T[r * 4 + c]; tcw[r] = T[r * 4 + 3]; }
+    camera_centre(Rcw, tcw, Ow);
+    std::vector<uint8_t> taken(matched, matched + nKF);
+    for (int k = 0; k < nKF; k++) newMatch[k] = -1;
+    std::vector<int> cand;
+    int nmatches = 0;
+    for (int i = 0; i < n; i++) {
+        if (skip && skip[i]) continue;
+        int level;
+        if (!lsd_scw_candidates(cam, Rcw, tcw, Ow, logScaleFactor, scaleFactors, nLevels, lines[i], kf, nKF, (float)th, level, cand)) continue;
+        if (level == -2) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : cand) {
+            if (taken[idx]) continue;                                         /* :476 */
+            const int d = descriptor_distance_swar(descs + (size_t)i * 32, kfDesc + (size_t)idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { taken[bestIdx] = 1; newMatch[bestIdx] = i; nmatches++; }
+    }
+    return nmatches;
+}
+
+/* one direction of LSDmatcher::SearchBySim3 (:549-625 / :628-704): map lines of `src` (camera pose Tsw) carried by (sR, t)
+ * into the other keyframe, whose key lines are kf / kfDesc */
+static void lsd_sim3_direction(const LineCamera& cam, const float Tsw[16], const float sR[9], const float t[3], float logScaleFactor,
+                               const float* scaleFactors, int nLevels, const FrustumLineRec* lines, const uint8_t* descs,
+                               const uint8_t* skip, int n, const LineRec* kf, const uint8_t* kfDesc, int nKF, float th,
+                               std::vector<int>& match)
+{
+    const int TH_HIGH = 100;
+    float Rsw[9], tsw[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rsw[r * 3 + c] = Tsw[r * 4 + c]; tsw[r] = Tsw[r * 4 + 3]; }
+    match.assign(n, -1);
+    std::vector<int> area;
+    for (int i = 0; i < n; i++) {
+        if (skip[i]) continue;
+        const FrustumLineRec& l = lines[i];
+        const float SP[3] = {(float)l.world[0], (float)l.world[1], (float)l.world[2]};
+        const float EP[3] = {(float)l.world[3], (float)l.world[4], (float)l.world[5]};
+        float a[3], SPc[3], EPc[3];
+        mat3_mul_add(Rsw, SP, tsw, a);
+        mat3_mul_add(sR, a, t, SPc);
+        mat3_mul_add(Rsw, EP, tsw, a);
+        mat3_mul_add(sR, a, t, EPc);
+        if (SPc[2] < 0.0f || EPc[2] < 0.0f) continue;
+        const float invz1 = 1.0f / SPc[2];
+        const float u1 = cam.fx * SPc[0] * invz1 + cam.cx, v1 = cam.fy * SPc[1] * invz1 + cam.cy;
+        if (!(u1 >= cam.minX && u1 < cam.maxX && v1 >= cam.minY && v1 < cam.maxY)) continue;          /* KeyFrame::IsInImage */
+        const float invz2 = 1.0f / EPc[2];
+        const float u2 = cam.fx * EPc[0] * invz2 + cam.cx, v2 = cam.fy * EPc[1] * invz2 + cam.cy;
+        if (!(u2 >= cam.minX && u2 < cam.maxX && v2 >= cam.minY && v2 < cam.maxY)) continue;
+        const float maxDistance = 1.2f * l.maxDistance, minDistance = 0.8f * l.minDistance;
+        const float mid[3] = {(SPc[0] + EPc[0]) * 0.5f, (SPc[1] + EPc[1]) * 0.5f, (SPc[2] + EPc[2]) * 0.5f};
+        const float dist3D = norm3(mid);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float ratio = l.maxDistance / dist3D;
+        const int level = (int)std::ceil(log_f(ratio) / logScaleFactor);      /* MapLine::PredictScale: no clamp */
+        if (level < 0 || level >= nLevels) continue;                              /* out-of-bounds read in the reference: dropped */
+        const float radius = th * scaleFactors[level];
+        get_lines_in_area(kf, nKF, u1, v1, u2, v2, radius, -1, -1, area);
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : area) {
+            const int klLevel = kf[idx].octave;
+            if (klLevel < level - 1 || klLevel > level) continue;
+            const int d = descriptor_distance_swar(descs + (size_t)i * 32, kfDesc + (size_t)idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) match[i] = bestIdx;
+    }
+}
+
+/* LSDmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), :504-748.  lines / descs / skip per key line of the
+ * keyframe (skip = !pML || isBad() || already matched); kf1 / kf2 = the key lines themselves.  out12[i1] = i2 or -1. */
+int lsd_search_by_sim3(const LineCamera& cam, const float T1w[16], const float T2w[16], float s12, const float R12[9],
+                       const float t12[3], float logScaleFactor, const float* scaleFactors, int nLevels, const FrustumLineRec* lines1,
+                       const uint8_t* descs1, const uint8_t* skip1, const LineRec* kf1, const uint8_t* kf1Desc, int n1,
+                       const FrustumLineRec* lines2, const uint8_t* descs2, const uint8_t* skip2, const LineRec* kf2,
+                       const uint8_t* kf2Desc, int n2, float th, int32_t* out12)
+{
+    float sR12[9], sR21[9], t21[3];
+    const float a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { sR12[r * 3 + c] = R12[r * 3 + c] * s12; sR21[r * 3 + c] = R12[c * 3 + r] * a21; }
+    for (int r = 0; r < 3; r++) {
+        const float d = sR21[r * 3] * t12[0] + sR21[r * 3 + 1] * t12[1] + sR21[r * 3 + 2] * t12[2];
+        t21[r] = (float)((double)d * -1.0);
+    }
+    std::vector<int> m1, m2;
+    lsd_sim3_direction(cam, T1w, sR21, t21, logScaleFactor, scaleFactors, nLevels, lines1, descs1, skip1, n1, kf2, kf2Desc, n2, th, m1);
+    lsd_sim3_direction(cam, T2w, sR12, t12, logScaleFactor, scaleFactors, nLevels, lines2, descs2, skip2, n2, kf1, kf1Desc, n1, th, m2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        out12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { out12[i1] = idx2; nFound++; }
+    }
+    return nFound;
+}
+
 } // namespace orc

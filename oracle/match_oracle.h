@@ -160,6 +160,20 @@ int search_by_sim3(const Frame& KF1, const Frame& KF2, const float T1w[16], cons
 int search_for_initialization(const Frame& F1, const Frame& F2, float* prevMatched, int windowSize, float nnratio, bool checkOri,
                               int32_t* matches12);
 
+/* LSDmatcher::Fuse(KF, Scw, ...) (search), SearchByProjection(KF, Scw, ...) and SearchBySim3, src/LSDmatcher.cpp:377-882
+ * (public API without a caller in the reference) */
+void lsd_fuse_search_sim3(const LineCamera& cam, const float Scw[16], float logScaleFactor, const float* scaleFactors, int nLevels,
+                          const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                          const uint8_t* kfDesc, int nKF, float th, int32_t* bestIdx, int32_t* bestDist);
+int lsd_search_by_projection_kf(const LineCamera& cam, const float Scw[16], float logScaleFactor, const float* scaleFactors, int nLevels,
+                                const FrustumLineRec* lines, const uint8_t* descs, const uint8_t* skip, int n, const LineRec* kf,
+                                const uint8_t* kfDesc, int nKF, const uint8_t* matched, int th, int32_t* newMatch);
+int lsd_search_by_sim3(const LineCamera& cam, const float T1w[16], const float T2w[16], float s12, const float R12[9],
+                       const float t12[3], float logScaleFactor, const float* scaleFactors, int nLevels, const FrustumLineRec* lines1,
+                       const uint8_t* descs1, const uint8_t* skip1, const LineRec* kf1, const uint8_t* kf1Desc, int n1,
+                       const FrustumLineRec* lines2, const uint8_t* descs2, const uint8_t* skip2, const LineRec* kf2,
+                       const uint8_t* kf2Desc, int n2, float th, int32_t* out12);
+
 } // namespace orc
 
 #endif

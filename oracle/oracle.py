@@ -379,6 +379,58 @@ def lsd_fuse_search(cam9, Tcw, scale_factor, scale, lines, descs, skip, kf_keyli
     return bi, bd
 
 
+def lsd_fuse_search_sim3(cam9, Scw, scale_factor, scale, lines, descs, skip, kf_keylines, kf_desc, th):
+    """Search part of LSDmatcher::Fuse(pKF, Scw, vpLines, th, vpReplaceLine): returns (best_idx, best_dist) per map line."""
+    L = lib()
+    l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+    sc = _c(scale, np.float32)
+    kf = _line_recs(kf_keylines)
+    bi = np.zeros(len(l), np.int32)
+    bd = np.zeros(len(l), np.int32)
+    L.orc_lsd_fuse_search_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_lsd_fuse_search_sim3(_p(_c(cam9, np.float32)), _p(_c(Scw, np.float32).reshape(16)), logf(np.float32(scale_factor)), _p(sc),
+                               len(sc), _p(l), _p(_c(descs, np.uint8)), _p(_c(skip, np.uint8)), len(l), _p(kf),
+                               _p(_c(kf_desc, np.uint8)), len(kf), float(th), _p(bi), _p(bd))
+    return bi, bd
+
+
+def lsd_search_by_projection_kf(cam9, Scw, scale_factor, scale, lines, descs, skip, kf_keylines, kf_desc, matched, th):
+    """LSDmatcher::SearchByProjection(pKF, Scw, vpLines, vpMatched, th): returns (nmatches, new_match per key line)."""
+    L = lib()
+    l = np.ascontiguousarray(lines, FRUSTUM_LINE_DTYPE)
+    sc = _c(scale, np.float32)
+    kf = _line_recs(kf_keylines)
+    out = np.full(len(kf), -1, np.int32)
+    L.orc_lsd_search_by_projection_kf.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    n = L.orc_lsd_search_by_projection_kf(_p(_c(cam9, np.float32)), _p(_c(Scw, np.float32).reshape(16)), logf(np.float32(scale_factor)),
+                                          _p(sc), len(sc), _p(l), _p(_c(descs, np.uint8)), _p(_c(skip, np.uint8)), len(l), _p(kf),
+                                          _p(_c(kf_desc, np.uint8)), len(kf), _p(_c(matched, np.uint8)), int(th), _p(out))
+    return n, out
+
+
+def lsd_search_by_sim3(cam9, T1w, T2w, s12, R12, t12, scale_factor, scale, lines1, descs1, skip1, kf1_keylines, kf1_desc,
+                       lines2, descs2, skip2, kf2_keylines, kf2_desc, th):
+    """LSDmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): returns (nFound, out12[i1] = i2 or -1)."""
+    L = lib()
+    l1, l2 = np.ascontiguousarray(lines1, FRUSTUM_LINE_DTYPE), np.ascontiguousarray(lines2, FRUSTUM_LINE_DTYPE)
+    sc = _c(scale, np.float32)
+    k1, k2 = _line_recs(kf1_keylines), _line_recs(kf2_keylines)
+    assert len(l1) == len(k1) and len(l2) == len(k2)
+    out = np.full(len(l1), -1, np.int32)
+    L.orc_lsd_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    f = lambda a, n: _p(_c(a, np.float32).reshape(n))
+    n = L.orc_lsd_search_by_sim3(_p(_c(cam9, np.float32)), f(T1w, 16), f(T2w, 16), float(s12), f(R12, 9), f(t12, 3),
+                                 logf(np.float32(scale_factor)), _p(sc), len(sc), _p(l1), _p(_c(descs1, np.uint8)),
+                                 _p(_c(skip1, np.uint8)), _p(k1), _p(_c(kf1_desc, np.uint8)), len(l1), _p(l2),
+                                 _p(_c(descs2, np.uint8)), _p(_c(skip2, np.uint8)), _p(k2), _p(_c(kf2_desc, np.uint8)), len(l2),
+                                 float(th), _p(out))
+    return n, out
+
+
 def search_by_projection_kf(kf: "FrameOracle", Scw, scale_factor, nlevels, pts, descs, skip, matched, th):
     """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): returns (nmatches, new_match per keypoint)."""
     L = lib()
