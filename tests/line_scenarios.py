@@ -77,3 +77,89 @@ def make(seed, keyline_dtype, mapline_dtype, tracked_dtype, n_cur=40, n_last=48,
 def cam9():
     return np.array([CAM["fx"], CAM["fy"], CAM["cx"], CAM["cy"], np.float32(CAM["bf"]) / np.float32(CAM["fx"]),
                      CAM["min_x"], CAM["max_x"], CAM["min_y"], CAM["max_y"]], np.float32)
+
+
+def sim3_line_scene(seed, n_kf, n, keyline_dtype, mapline_dtype, tracked_dtype, frustum_line_dtype):
+    """Map lines seen from a keyframe, with normals / distance bands that exercise every gate (as test_lsd_fuse_search)."""
+    sc = make(seed, keyline_dtype, mapline_dtype, tracked_dtype, n_cur=n_kf, n_last=n)
+    rng = np.random.RandomState(300 + seed)
+    Tcw = sc["Tcw_cur"]
+    Twc = np.linalg.inv(Tcw.astype(np.float64))
+    lines = np.zeros(n, frustum_line_dtype)
+    lines["world"] = sc["last"]["world"]
+    mid = 0.5 * (lines["world"][:, :3] + lines["world"][:, 3:])
+    om = mid - Twc[:3, 3][None, :]
+    dist = np.linalg.norm(om, axis=1)
+    nrm = om / dist[:, None] + rng.normal(0, 0.5, (n, 3))
+    lines["normal"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    lvl = rng.choice([-1, 0, 1, 2, 9], size=n, p=[0.04, 0.4, 0.4, 0.12, 0.04])
+    lines["max_distance"] = (dist * 1.2 ** (lvl - rng.uniform(0.1, 0.9, n))).astype(np.float32)
+    lines["min_distance"] = (dist * rng.uniform(0.3, 1.3, n)).astype(np.float32)
+    return sc, lines, rng
+
+
+
+def keyframe_with_own_map_lines(seed, n, keyline_dtype, frustum_line_dtype):
+    """A keyframe whose key line i carries map line i (aimed at it: midpoint, slope and descriptor perturbed), as
+    KeyFrame::GetMapLineMatches() presents them."""
+    rng = np.random.RandomState(700 + seed)
+    kl = np.zeros(n, keyline_dtype)
+    kl["pt_x"] = rng.uniform(80, 560, n).astype(np.float32)
+    kl["pt_y"] = rng.uniform(80, 400, n).astype(np.float32)
+    kl["angle"] = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+    kl["octave"] = (rng.uniform(size=n) < 0.25).astype(np.int32)
+    kdesc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    Tcw = _pose(rng, 0.0)
+    Rcw, tcw = Tcw[:3, :3].astype(np.float64), Tcw[:3, 3].astype(np.float64)
+    lines = np.zeros(n, frustum_line_dtype)
+    descs = np.zeros((n, 32), np.uint8)
+    for i in range(n):
+        mid = np.array([kl["pt_x"][i], kl["pt_y"][i]], np.float64) + rng.normal(0, 3.0, 2)
+        m = float(kl["angle"][i]) + rng.uniform(-0.3, 0.1)
+        d = np.array([1.0, m]) / np.hypot(1.0, m) * rng.uniform(20, 50)
+        pts = []
+        for (u, v), z in ((mid - d, rng.uniform(1, 4)), (mid + d, rng.uniform(1, 4))):
+            Xc = np.array([(u - CAM["cx"]) * z / CAM["fx"], (v - CAM["cy"]) * z / CAM["fy"], z])
+            pts.append(Rcw.T @ (Xc - tcw))
+        lines["world"][i] = np.concatenate(pts)
+        descs[i] = _flip(rng, kdesc[i], int(rng.choice([0, 3, 10, 25, 40, 70, 120])))
+    mid = 0.5 * (lines["world"][:, :3] + lines["world"][:, 3:])
+    dist = np.linalg.norm(mid - np.linalg.inv(Tcw.astype(np.float64))[:3, 3][None, :], axis=1)
+    lvl = np.where(rng.uniform(size=n) < 0.05, 9, kl["octave"] + (rng.uniform(size=n) < 0.3))
+    lines["max_distance"] = (dist * 1.2 ** (lvl - rng.uniform(0.1, 0.9, n))).astype(np.float32)
+    lines["min_distance"] = (dist * rng.uniform(0.3, 1.1, n)).astype(np.float32)
+    lines["normal"] = [0, 0, 1]
+    return Tcw, kl, kdesc, lines, descs, rng
+
+
+
+def keyframe_pair_for_sim3(seed, keyline_dtype, frustum_line_dtype):
+    """Two keyframes that see the same n world lines from nearby poses (key line i of either carries its own map line; KF2 lists
+    them in another order) and the similarity between them: everything LSDmatcher::SearchBySim3 reads."""
+    n = 40 if seed < 10 else 300
+    T1w, kl1, kd1, lines1, descs1, rng = keyframe_with_own_map_lines(seed, n, keyline_dtype, frustum_line_dtype)
+    # keyframe 2: a nearby pose looking at the same world lines; its key lines are where they project (perturbed), in another order
+    ang = np.deg2rad(rng.uniform(-2, 2, 2))
+    Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+    Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+    T21 = np.eye(4); T21[:3, :3] = Rx @ Ry; T21[:3, 3] = rng.uniform(-0.05, 0.05, 3)
+    T2w = (T21 @ T1w.astype(np.float64)).astype(np.float32)
+    perm = rng.permutation(n)                                    # key line k of KF2 shows world line perm[k]
+    W = lines1["world"][perm]
+    kl2 = np.zeros(n, keyline_dtype)
+    R2, t2 = T2w[:3, :3].astype(np.float64), T2w[:3, 3].astype(np.float64)
+    a = (R2 @ W[:, :3].T).T + t2; b = (R2 @ W[:, 3:].T).T + t2
+    ua = CAM["fx"] * a[:, 0] / a[:, 2] + CAM["cx"]; va = CAM["fy"] * a[:, 1] / a[:, 2] + CAM["cy"]
+    ub = CAM["fx"] * b[:, 0] / b[:, 2] + CAM["cx"]; vb = CAM["fy"] * b[:, 1] / b[:, 2] + CAM["cy"]
+    kl2["pt_x"] = (0.5 * (ua + ub) + rng.normal(0, 2.0, n)).astype(np.float32)
+    kl2["pt_y"] = (0.5 * (va + vb) + rng.normal(0, 2.0, n)).astype(np.float32)
+    kl2["angle"] = ((va - vb) / (ua - ub) + rng.uniform(0.0, 0.3, n)).astype(np.float32)
+    kl2["octave"] = kl1["octave"][perm]
+    kd2 = np.stack([_flip(rng, kd1[perm[k]], int(rng.choice([0, 5, 20, 60]))) for k in range(n)])
+    lines2 = lines1[perm].copy(); descs2 = np.stack([_flip(rng, descs1[perm[k]], int(rng.choice([0, 4, 12]))) for k in range(n)])
+    T12 = np.linalg.inv(T21)
+    s12 = float(1.0 + rng.uniform(-0.03, 0.03))
+    R12 = T12[:3, :3].astype(np.float32); t12 = T12[:3, 3].astype(np.float32)
+    skip1 = (rng.uniform(size=n) < 0.15).astype(np.uint8); skip2 = (rng.uniform(size=n) < 0.15).astype(np.uint8)
+    return dict(n=n, T1w=T1w, T2w=T2w, s12=s12, R12=R12, t12=t12, perm=perm, lines1=lines1, descs1=descs1, skip1=skip1, kl1=kl1, kd1=kd1,
+                lines2=lines2, descs2=descs2, skip2=skip2, kl2=kl2, kd2=kd2)

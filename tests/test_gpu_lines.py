@@ -184,27 +184,6 @@ def test_lsd_fuse_search(oracle_mod, seed):
         ctx.close()
 
 
-def _sim3_line_scene(seed, n_kf, n):
-    """Map lines seen from a keyframe, with normals / distance bands that exercise every gate (as test_lsd_fuse_search)."""
-    import line_scenarios as LS
-    from dr_slam_amd import lib
-    sc = LS.make(seed, lib.KEYLINE_DTYPE, lib.MAPLINE_DTYPE, lib.TRACKED_LINE_DTYPE, n_cur=n_kf, n_last=n)
-    rng = np.random.RandomState(300 + seed)
-    Tcw = sc["Tcw_cur"]
-    Twc = np.linalg.inv(Tcw.astype(np.float64))
-    lines = np.zeros(n, lib.FRUSTUM_LINE_DTYPE)
-    lines["world"] = sc["last"]["world"]
-    mid = 0.5 * (lines["world"][:, :3] + lines["world"][:, 3:])
-    om = mid - Twc[:3, 3][None, :]
-    dist = np.linalg.norm(om, axis=1)
-    nrm = om / dist[:, None] + rng.normal(0, 0.5, (n, 3))
-    lines["normal"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
-    lvl = rng.choice([-1, 0, 1, 2, 9], size=n, p=[0.04, 0.4, 0.4, 0.12, 0.04])
-    lines["max_distance"] = (dist * 1.2 ** (lvl - rng.uniform(0.1, 0.9, n))).astype(np.float32)
-    lines["min_distance"] = (dist * rng.uniform(0.3, 1.3, n)).astype(np.float32)
-    return sc, lines, rng
-
-
 @pytest.mark.parametrize("seed", [1, 2, 11])
 def test_lsd_fuse_and_projection_with_similarity(oracle_mod, seed):
     """LSDmatcher::Fuse(pKF, Scw, ...) (the search) and LSDmatcher::SearchByProjection(pKF, Scw, vpLines, vpMatched, th): the pose is
@@ -213,7 +192,7 @@ def test_lsd_fuse_and_projection_with_similarity(oracle_mod, seed):
     import line_scenarios as LS
     from dr_slam_amd import lib
     n_kf, n = (40, 64) if seed < 10 else (300, 1500)
-    sc, lines, rng = _sim3_line_scene(seed, n_kf, n)
+    sc, lines, rng = LS.sim3_line_scene(seed, n_kf, n, lib.KEYLINE_DTYPE, lib.MAPLINE_DTYPE, lib.TRACKED_LINE_DTYPE, lib.FRUSTUM_LINE_DTYPE)
     Tcw = sc["Tcw_cur"]
     descs = sc["last"]["desc"]
     skip = (rng.uniform(size=n) < 0.1).astype(np.uint8)
@@ -247,41 +226,6 @@ def test_lsd_fuse_and_projection_with_similarity(oracle_mod, seed):
         ctx.close()
 
 
-def _keyframe_with_own_map_lines(seed, n):
-    """A keyframe whose key line i carries map line i (aimed at it: midpoint, slope and descriptor perturbed), as
-    KeyFrame::GetMapLineMatches() presents them."""
-    import line_scenarios as LS
-    from dr_slam_amd import lib
-    rng = np.random.RandomState(700 + seed)
-    kl = np.zeros(n, lib.KEYLINE_DTYPE)
-    kl["pt_x"] = rng.uniform(80, 560, n).astype(np.float32)
-    kl["pt_y"] = rng.uniform(80, 400, n).astype(np.float32)
-    kl["angle"] = rng.uniform(-1.2, 1.2, n).astype(np.float32)
-    kl["octave"] = (rng.uniform(size=n) < 0.25).astype(np.int32)
-    kdesc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
-    Tcw = LS._pose(rng, 0.0)
-    Rcw, tcw = Tcw[:3, :3].astype(np.float64), Tcw[:3, 3].astype(np.float64)
-    lines = np.zeros(n, lib.FRUSTUM_LINE_DTYPE)
-    descs = np.zeros((n, 32), np.uint8)
-    for i in range(n):
-        mid = np.array([kl["pt_x"][i], kl["pt_y"][i]], np.float64) + rng.normal(0, 3.0, 2)
-        m = float(kl["angle"][i]) + rng.uniform(-0.3, 0.1)
-        d = np.array([1.0, m]) / np.hypot(1.0, m) * rng.uniform(20, 50)
-        pts = []
-        for (u, v), z in ((mid - d, rng.uniform(1, 4)), (mid + d, rng.uniform(1, 4))):
-            Xc = np.array([(u - LS.CAM["cx"]) * z / LS.CAM["fx"], (v - LS.CAM["cy"]) * z / LS.CAM["fy"], z])
-            pts.append(Rcw.T @ (Xc - tcw))
-        lines["world"][i] = np.concatenate(pts)
-        descs[i] = LS._flip(rng, kdesc[i], int(rng.choice([0, 3, 10, 25, 40, 70, 120])))
-    mid = 0.5 * (lines["world"][:, :3] + lines["world"][:, 3:])
-    dist = np.linalg.norm(mid - np.linalg.inv(Tcw.astype(np.float64))[:3, 3][None, :], axis=1)
-    lvl = np.where(rng.uniform(size=n) < 0.05, 9, kl["octave"] + (rng.uniform(size=n) < 0.3))
-    lines["max_distance"] = (dist * 1.2 ** (lvl - rng.uniform(0.1, 0.9, n))).astype(np.float32)
-    lines["min_distance"] = (dist * rng.uniform(0.3, 1.1, n)).astype(np.float32)
-    lines["normal"] = [0, 0, 1]
-    return Tcw, kl, kdesc, lines, descs, rng
-
-
 @pytest.mark.parametrize("seed", [1, 2, 11])
 def test_lsd_search_by_sim3(oracle_mod, seed):
     """LSDmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): the map lines of each keyframe carried into the other
@@ -290,39 +234,17 @@ def test_lsd_search_by_sim3(oracle_mod, seed):
     n lines from nearby poses (key line i of either carries map line i), a sixth of them skipped on either side."""
     import line_scenarios as LS
     from dr_slam_amd import lib
-    n = 40 if seed < 10 else 300
-    T1w, kl1, kd1, lines1, descs1, rng = _keyframe_with_own_map_lines(seed, n)
-    # keyframe 2: a nearby pose looking at the same world lines; its key lines are where they project (perturbed), in another order
-    ang = np.deg2rad(rng.uniform(-2, 2, 2))
-    Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
-    Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
-    T21 = np.eye(4); T21[:3, :3] = Rx @ Ry; T21[:3, 3] = rng.uniform(-0.05, 0.05, 3)
-    T2w = (T21 @ T1w.astype(np.float64)).astype(np.float32)
-    perm = rng.permutation(n)                                    # key line k of KF2 shows world line perm[k]
-    W = lines1["world"][perm]
-    kl2 = np.zeros(n, lib.KEYLINE_DTYPE)
-    R2, t2 = T2w[:3, :3].astype(np.float64), T2w[:3, 3].astype(np.float64)
-    a = (R2 @ W[:, :3].T).T + t2; b = (R2 @ W[:, 3:].T).T + t2
-    ua = LS.CAM["fx"] * a[:, 0] / a[:, 2] + LS.CAM["cx"]; va = LS.CAM["fy"] * a[:, 1] / a[:, 2] + LS.CAM["cy"]
-    ub = LS.CAM["fx"] * b[:, 0] / b[:, 2] + LS.CAM["cx"]; vb = LS.CAM["fy"] * b[:, 1] / b[:, 2] + LS.CAM["cy"]
-    kl2["pt_x"] = (0.5 * (ua + ub) + rng.normal(0, 2.0, n)).astype(np.float32)
-    kl2["pt_y"] = (0.5 * (va + vb) + rng.normal(0, 2.0, n)).astype(np.float32)
-    kl2["angle"] = ((va - vb) / (ua - ub) + rng.uniform(0.0, 0.3, n)).astype(np.float32)
-    kl2["octave"] = kl1["octave"][perm]
-    kd2 = np.stack([LS._flip(rng, kd1[perm[k]], int(rng.choice([0, 5, 20, 60]))) for k in range(n)])
-    lines2 = lines1[perm].copy(); descs2 = np.stack([LS._flip(rng, descs1[perm[k]], int(rng.choice([0, 4, 12]))) for k in range(n)])
-    T12 = np.linalg.inv(T21)
-    s12 = float(1.0 + rng.uniform(-0.03, 0.03))
-    R12 = T12[:3, :3].astype(np.float32); t12 = T12[:3, 3].astype(np.float32)
-    skip1 = (rng.uniform(size=n) < 0.15).astype(np.uint8); skip2 = (rng.uniform(size=n) < 0.15).astype(np.uint8)
+    K = LS.keyframe_pair_for_sim3(seed, lib.KEYLINE_DTYPE, lib.FRUSTUM_LINE_DTYPE)
+    n, perm, skip1 = K["n"], K["perm"], K["skip1"]
+    args = (K["T1w"], K["T2w"], K["s12"], K["R12"], K["t12"])
+    sides = (K["lines1"], K["descs1"], K["skip1"], K["kl1"], K["kd1"], K["lines2"], K["descs2"], K["skip2"], K["kl2"], K["kd2"])
     ctx = lib.Context(max_batch=1)
     try:
         cam = lib.Camera(**LS.CAM)
         found = 0
         for th in (7.5, 20.0):
-            nf, m12 = ctx.lsd_search_by_sim3(cam, T1w, T2w, s12, R12, t12, lines1, descs1, skip1, kl1, kd1, lines2, descs2, skip2, kl2, kd2, th)
-            onf, om12 = oracle_mod.lsd_search_by_sim3(LS.cam9(), T1w, T2w, s12, R12, t12, 1.2, LS.SCALE, lines1, descs1, skip1, kl1, kd1,
-                                                      lines2, descs2, skip2, kl2, kd2, th)
+            nf, m12 = ctx.lsd_search_by_sim3(cam, *args, *sides, th)
+            onf, om12 = oracle_mod.lsd_search_by_sim3(LS.cam9(), *args, 1.2, LS.SCALE, *sides, th)
             assert nf == onf and np.array_equal(m12, om12), th
             assert (m12 >= 0).sum() == nf and (m12[skip1 == 1] == -1).all()
             ok = m12 >= 0

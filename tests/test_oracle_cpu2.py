@@ -426,3 +426,97 @@ def test_search_for_triangulation_hand_cases(oracle_mod):
     assert O.search_for_triangulation(mono1, mono2, F, 500.0, 50.0, scale, sigma2, False, False)[0] == 1
     assert O.search_for_triangulation(mono1, mono2, F, 500.0, 50.0, scale, sigma2, True, False)[0] == 0      # bOnlyStereo
     assert O.search_for_triangulation(k1, kf([90], [50], [d]), F, 95.0, 50.0, scale, sigma2, True, False)[0] == 1
+
+
+# ---- LSDmatcher's loop-closing variants (src/LSDmatcher.cpp:377-882) and ORBmatcher::SearchForInitialization ------------------
+
+def test_lsd_sim3_agreement_finds_the_true_pairs(oracle_mod):
+    """LSDmatcher::SearchBySim3 on two keyframes that see the same world lines from nearby poses, KF2 listing them in another
+    order: what the two directions agree on must be the true correspondence, skipped lines must stay unmatched, and a wider
+    window cannot lose pairs that the narrow one found with the same partners."""
+    import line_scenarios as LS
+    O = oracle_mod
+    for seed in (1, 2, 11):
+        K = LS.keyframe_pair_for_sim3(seed, _KL, O.FRUSTUM_LINE_DTYPE)
+        args = (K["T1w"], K["T2w"], K["s12"], K["R12"], K["t12"])
+        sides = (K["lines1"], K["descs1"], K["skip1"], K["kl1"], K["kd1"], K["lines2"], K["descs2"], K["skip2"], K["kl2"], K["kd2"])
+        prev = None
+        for th in (7.5, 20.0):
+            nf, m12 = O.lsd_search_by_sim3(LS.cam9(), *args, 1.2, LS.SCALE, *sides, th)
+            ok = m12 >= 0
+            assert nf == ok.sum() > K["n"] // 4
+            assert (K["perm"][m12[ok]] == np.flatnonzero(ok)).all()             # key line m12[i] of KF2 shows world line i
+            assert (m12[K["skip1"] == 1] == -1).all() and (K["skip2"][m12[ok]] == 0).all()
+            if prev is not None:
+                both = (prev >= 0) & ok
+                assert np.array_equal(prev[both], m12[both])
+            prev = m12
+        # everything skipped on one side: nothing can be agreed on
+        nf, m12 = O.lsd_search_by_sim3(LS.cam9(), *args, 1.2, LS.SCALE, K["lines1"], K["descs1"], np.ones(K["n"], np.uint8), K["kl1"],
+                                       K["kd1"], K["lines2"], K["descs2"], K["skip2"], K["kl2"], K["kd2"], 20.0)
+        assert nf == 0 and (m12 == -1).all()
+
+
+def test_lsd_similarity_pose_is_scale_free_and_claims_are_first_come(oracle_mod):
+    """Fuse(KF, Scw) / SearchByProjection(KF, Scw): Scw = s [R | t] decomposes to the same [R | t] for s a power of two (exact in
+    float), so the search must not depend on it and must equal Fuse(KF, MapLines) up to the camera-centre formula; the projection
+    variant gives a key line to the first map line that asks for it, never touches the ones matched on entry, and a line offered
+    twice matches at most twice with different key lines."""
+    import line_scenarios as LS
+    O = oracle_mod
+    sc, lines, rng = LS.sim3_line_scene(11, 300, 1500, _KL, O.MAPLINE_DTYPE, O.TRACKED_LINE_DTYPE, O.FRUSTUM_LINE_DTYPE)
+    Tcw = sc["Tcw_cur"].astype(np.float32)
+    descs = sc["last"]["desc"]
+    skip = (rng.uniform(size=len(lines)) < 0.1).astype(np.uint8)
+    ref = None
+    for s in (1.0, 0.5, 4.0):
+        Scw = Tcw.copy(); Scw[:3, :] *= np.float32(s)
+        bi, bd = O.lsd_fuse_search_sim3(LS.cam9(), Scw, 1.2, LS.SCALE, lines, descs, skip, sc["cur"], sc["cur_desc"], 3.0)
+        if ref is None:
+            ref = (bi, bd)
+        assert np.array_equal(bi, ref[0]) and np.array_equal(bd, ref[1])
+    fi, fd = O.lsd_fuse_search(LS.cam9(), Tcw, 1.2, LS.SCALE, lines, descs, skip, sc["cur"], sc["cur_desc"], 3.0)
+    assert (fi == ref[0]).mean() > 0.99                                          # only the camera centre's rounding differs
+    matched = (rng.uniform(size=len(sc["cur"])) < 0.2).astype(np.uint8)
+    l2 = np.concatenate([lines, lines]); d2 = np.concatenate([descs, descs]); s2 = np.concatenate([skip, skip])
+    nm, new = O.lsd_search_by_projection_kf(LS.cam9(), Tcw, 1.2, LS.SCALE, l2, d2, s2, sc["cur"], sc["cur_desc"], matched, 4)
+    assert nm == (new >= 0).sum() > 100 and (new[matched == 1] == -1).all()
+    n = len(lines)
+    first, second = new[(new >= 0) & (new < n)], new[new >= n] - n
+    assert len(np.intersect1d(first, second)) == len(second)          # a second copy only ever matches where its first one did
+    one, new1 = O.lsd_search_by_projection_kf(LS.cam9(), Tcw, 1.2, LS.SCALE, lines, descs, skip, sc["cur"], sc["cur_desc"], matched, 4)
+    assert one == (new1 >= 0).sum() and np.array_equal(new1[new1 >= 0], new[new1 >= 0])   # the first pass does not see the copies
+
+
+def test_search_for_initialization_semantics(oracle_mod):
+    """ORBmatcher::SearchForInitialization on a frame against a shifted copy of itself: level-0 keypoints find their own copy,
+    keypoints of higher levels are never matched, the map stays one to one (a closer later keypoint evicts the earlier match),
+    vbPrevMatched moves to the matched positions only."""
+    from dr_slam_amd import synth
+    O = oracle_mod
+    cam = synth.TUM3
+    g, d, _ = next(synth.sequence(4, 1, cam=cam, kind="room_boxes"))
+    o = O.OrbOracle()
+    kps, desc = o(g)
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    depth = O.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+    f1 = O.FrameOracle(kps, desc, depth, K4, cam.bf, cam.w, cam.h, o.scale)
+    shifted = kps.copy(); shifted["x"] += np.float32(6.0); shifted["y"] -= np.float32(4.0)
+    keep = np.random.RandomState(3).uniform(size=len(kps)) < 0.9                 # a tenth of the keypoints is missing in F2
+    f2 = O.FrameOracle(shifted[keep], desc[keep], depth, K4, cam.bf, cam.w, cam.h, o.scale)
+    idx2 = np.full(len(kps), -1); idx2[keep] = np.arange(keep.sum())
+    prev = np.stack([f1.keys_un()["x"], f1.keys_un()["y"]], 1).astype(np.float32)
+    n, m12, prev2 = O.search_for_initialization(f1, f2, prev, 100, 0.9, True)
+    lvl0 = f1.keys_un()["octave"] == 0
+    assert n == (m12 >= 0).sum() > 0.6 * (lvl0 & keep).sum()
+    assert (m12[~lvl0] == -1).all()
+    hit = m12[m12 >= 0]
+    assert len(np.unique(hit)) == len(hit)
+    assert (m12[m12 >= 0] == idx2[m12 >= 0]).mean() > 0.95                       # its own copy
+    moved = np.any(prev2 != prev, axis=1)
+    assert np.array_equal(moved, m12 >= 0)
+    k2 = f2.keys_un()
+    assert np.array_equal(prev2[m12 >= 0], np.stack([k2["x"], k2["y"]], 1)[m12[m12 >= 0]])
+    # a window too small to reach the shifted copy: nothing matches, nothing moves
+    n0, m0, p0 = O.search_for_initialization(f1, f2, prev, 3, 0.9, True)
+    assert n0 == 0 and (m0 == -1).all() and np.array_equal(p0, prev)
