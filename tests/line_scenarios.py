@@ -163,3 +163,41 @@ def keyframe_pair_for_sim3(seed, keyline_dtype, frustum_line_dtype):
     skip1 = (rng.uniform(size=n) < 0.15).astype(np.uint8); skip2 = (rng.uniform(size=n) < 0.15).astype(np.uint8)
     return dict(n=n, T1w=T1w, T2w=T2w, s12=s12, R12=R12, t12=t12, perm=perm, lines1=lines1, descs1=descs1, skip1=skip1, kl1=kl1, kd1=kd1,
                 lines2=lines2, descs2=descs2, skip2=skip2, kl2=kl2, kd2=kd2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Analytic line scene: convex polygons of known corners, area-sampled.  Every polygon edge is one step edge of known
+# position, direction and length, so what LSD must report is known in closed form (independent of any LSD code).
+
+def _coverage(h, w, pts, ss=4):
+    """fraction of each pixel covered by the convex polygon `pts` (pixel-centre coordinates), ss x ss supersampling"""
+    ys = (np.arange(h * ss) + 0.5) / ss - 0.5
+    xs = (np.arange(w * ss) + 0.5) / ss - 0.5
+    X, Y = np.meshgrid(xs, ys)
+    P = np.asarray(pts, float)
+    c = P.mean(0)
+    inside = np.ones_like(X, bool)
+    for a, b in zip(P, np.roll(P, -1, 0)):
+        nrm = np.array([-(b - a)[1], (b - a)[0]])
+        s = np.sign(nrm @ (c - a))
+        inside &= s * ((X - a[0]) * nrm[0] + (Y - a[1]) * nrm[1]) >= 0
+    return inside.reshape(h, ss, w, ss).mean((1, 3))
+
+
+def _rot_rect(cx, cy, a, b, deg):
+    t = np.deg2rad(deg)
+    R = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+    return (np.array([[-a, -b], [a, -b], [a, b], [-a, b]], float) @ R.T) + [cx, cy]
+
+
+def analytic_polygons(h=480, w=640):
+    """-> (gray uint8 image, list of edges (a, b) in image coordinates): two rotated rectangles and a triangle on a flat
+    background, 11 edges between 138 and 270 px long"""
+    polys = [_rot_rect(180, 150, 110, 70, 17.0), _rot_rect(450, 300, 120, 90, -31.0),
+             np.array([[330.0, 40.0], [600.0, 70.0], [420.0, 170.0]])]
+    img = np.full((h, w), 60.0)
+    for p, v in zip(polys, (200.0, 150.0, 230.0)):
+        m = _coverage(h, w, p)
+        img = img * (1 - m) + v * m
+    edges = [(a, b) for p in polys for a, b in zip(p, np.roll(p, -1, 0))]
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), edges

@@ -47,6 +47,20 @@ def test_lines_bit_exact(ctx, oracle_mod, seed, kind):
     assert (np.unpackbits(a["desc"], axis=1).sum(1) > 20).all()
 
 
+def test_lines_analytic_polygons_bit_exact(ctx, oracle_mod):
+    """The analytic polygon scene whose segments tests/test_oracle_cpu2.py checks in closed form: the device path reports
+    the same 11 segments as the oracle, bit for bit."""
+    from line_scenarios import analytic_polygons
+    g, edges = analytic_polygons()
+    a = ctx.lsd_extract(g)
+    o = oracle_mod.extract_lines(g)
+    assert a["detected"] == o["detected"] == len(edges) == 11
+    for gk, ok in PAIRS:
+        assert np.array_equal(a["lines"][gk].view(np.uint32), o["lines"][ok].view(np.uint32)), gk
+    assert np.array_equal(a["desc"], o["desc"])
+    assert np.array_equal(a["lineF"].view(np.uint64), o["lineF"].view(np.uint64))
+
+
 def test_lsd_matcher(ctx, oracle_mod, frames_room):
     """LSDmatcher::SearchByDescriptor(KF, Frame) (ratio rule) and the KF-KF / initialisation variant
     (MAD-gap rule) on the LBD descriptors of two consecutive frames."""

@@ -204,6 +204,40 @@ def test_lsd_lines_on_clean_edges(oracle_mod):
                                    abs(round(float(k["endPointY"])) - round(float(k["startPointY"])))) + 1
 
 
+def test_lsd_against_analytic_polygons(oracle_mod):
+    """Independent of any LSD code: an area-sampled scene of convex polygons has one step edge per polygon side, whose
+    position, direction and length are known in closed form.  The detector must report exactly those segments: one per
+    edge, the end points on the analytic line (sub-pixel), reaching the corners to within the 2 px a region of aligned
+    gradient pixels can lose at a corner, the direction to a few hundredths of a degree."""
+    from line_scenarios import analytic_polygons
+    g, edges = analytic_polygons()
+    r = oracle_mod.extract_lines(g)
+    assert r["detected"] == len(edges) == len(r["lines"]) == 11
+    hit = np.zeros(len(edges), int)
+    for k in r["lines"]:
+        s = np.array([k["startPointX"], k["startPointY"]], float)
+        e = np.array([k["endPointX"], k["endPointY"]], float)
+        found = None
+        for i, (a, b) in enumerate(edges):
+            L = np.linalg.norm(b - a)
+            d = (b - a) / L
+            nrm = np.array([-d[1], d[0]])
+            if max(abs((s - a) @ nrm), abs((e - a) @ nrm)) < 0.25:          # both end points on the analytic line
+                found = i
+                ts, te = sorted([(s - a) @ d, (e - a) @ d])
+                assert -0.5 <= ts < 2.0 and -0.5 <= L - te < 2.0, (i, ts, L - te)   # corner to corner
+                ang = np.degrees(np.arctan2(e[1] - s[1], e[0] - s[0]))
+                ref = np.degrees(np.arctan2(d[1], d[0]))
+                assert min(abs((ang - ref + 180) % 360 - 180), abs((ang - ref) % 360 - 180)) < 0.08
+                assert abs(k["lineLength"] - np.linalg.norm(e - s)) < 1e-3 and abs(k["lineLength"] - L) < 3.0
+                assert abs(np.degrees(float(k["angle"])) - ang) < 1e-3      # KeyLine::angle = atan2 of its own end points
+        assert found is not None
+        hit[found] += 1
+    assert (hit == 1).all()
+    # response = length / max(w, h); no ordering below 41 lines (src/LSDextractor.cpp:18-27 sorts only to cut to 40)
+    assert np.allclose(r["lines"]["response"], r["lines"]["lineLength"] / 640.0, rtol=1e-6)
+
+
 def test_lines_are_cut_to_forty_by_response(oracle_mod):
     cam, g, d, K4 = _case()
     r = oracle_mod.extract_lines(g)
