@@ -110,6 +110,7 @@ void drfe_destroy(drfe_ctx* c)
     drfe_lines_free(c);
     drfe_post_free(c);
     drfe_one_shot_free(c);
+    drfe_frame_lanes_free(c);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_taps, c->d_pattern, c->d_disc, c->d_pyr, c->d_blur,
                     c->d_cand0, c->d_cand1, c->d_node, c->d_candCount, c->d_sel, c->d_selCount, c->d_kps, c->d_kpsUn, c->d_desc,
                     c->d_kpCount, c->d_status, c->d_uRight, c->d_depth, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc, c->d_match,
@@ -153,6 +154,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->bow = nullptr;
     c->ls = nullptr;
     c->lineWorkers = nullptr;
+    c->frameLanes = nullptr;
     c->lineHost = nullptr;
     std::memset(&c->cam, 0, sizeof(c->cam));
     std::memset(&c->geom, 0, sizeof(c->geom));
@@ -578,6 +580,196 @@ int drfe_profile_stage_ms(drfe_ctx* c, float* ms)
             if (hipEventElapsedTime(&t, c->ev[i][0], c->ev[i][1]) == hipSuccess) ms[i] = t;
         }
     }
+    return DRFE_OK;
+}
+
+} /* extern "C" */
+
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Per-frame pipelined flow ("async variants take a frame slot id for pipelining").
+ * Tracking::GrabImageRGBD (src/Tracking.cc:191) builds one Frame at a time and matches it against the previous one, so
+ * frame k is extracted into slot k % max_batch while the slot of frame k-1 keeps LastFrame's keypoints, descriptors and
+ * grid on the device for the slot-pair matchers.  A submission is the H2D of the frame, the kernels of drfe_launch_orb
+ * and (with a depth image) drfe_launch_glue on that ONE slot, and the D2H of its results, replayed as one captured
+ * hipGraph per slot; it returns without waiting, so the calling thread can run the host halves of the line / plane
+ * extractors meanwhile (the reference starts three threads for that, src/Frame.cc:124-134). */
+
+struct FrameLane {
+    uint8_t* h_in = nullptr;      /* pinned: gray w*h, then raw depth w*h*2 */
+    uint8_t* h_out = nullptr;     /* pinned: int status | int count | kps[K] | desc[K][32] | uRight[K] | depth[K] */
+    uint8_t* d_in = nullptr;      /* device staging, same layout as h_in */
+    size_t inBytes = 0;
+    hipEvent_t done = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int w = 0, h = 0, withDepth = 0;
+    drfe_camera cam;
+    DrfeDistortion dist;
+    bool pending = false, graphOff = false;
+};
+
+/* The kernels address a slot as base + slot * stride.  One slot of a larger arena is therefore the same launches on
+ * shifted bases: this shifts every per-slot base the ORB and glue launchers read, for the duration of the enqueue. */
+struct SlotShift {
+    drfe_ctx* c; int slot;
+    SlotShift(drfe_ctx* c_, int slot_) : c(c_), slot(slot_) { apply(1); }
+    ~SlotShift() { apply(-1); }
+    void apply(int sgn)
+    {
+        const ptrdiff_t s = (ptrdiff_t)sgn * slot, K = c->maxKp;
+        const DevGeom& g = c->geom;
+        c->d_pyr += s * g.pyrSlotBytes; c->d_blur += s * g.blurSlotBytes;
+        c->d_cand0 += s * g.candSlotElems; c->d_cand1 += s * g.candSlotElems; c->d_node += s * g.candSlotElems;
+        c->d_candCount += s * g.nlevels; c->d_selCount += s * g.nlevels; c->d_sel += s * g.kpSlotElems;
+        c->d_kps += s * K; if (c->d_kpsUn) c->d_kpsUn += s * K;
+        c->d_desc += s * K * 32; c->d_kpCount += s;
+        c->d_uRight += s * K; c->d_depth += s * K;
+        c->d_gridOff += s * (DRFE_GRID_CELLS + 1); c->d_gridIdx += s * K;
+        c->d_cellKp += s * K; c->d_cellDesc += s * K * 2;
+    }
+};
+
+static void frame_lane_release_graph(FrameLane& L)
+{
+    if (L.exec) (void)hipGraphExecDestroy(L.exec);
+    if (L.graph) (void)hipGraphDestroy(L.graph);
+    L.exec = nullptr; L.graph = nullptr;
+}
+
+void drfe_frame_lanes_free(drfe_ctx* c)
+{
+    auto* v = static_cast<std::vector<FrameLane>*>(c->frameLanes);
+    if (!v) return;
+    for (FrameLane& L : *v) {
+        frame_lane_release_graph(L);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.h_in) (void)hipHostFree(L.h_in);
+        if (L.h_out) (void)hipHostFree(L.h_out);
+        if (L.d_in) (void)hipFree(L.d_in);
+    }
+    delete v;
+    c->frameLanes = nullptr;
+}
+
+/* the stream work of one submission (capturable: no table upload, no synchronisation) */
+static hipError_t frame_enqueue(drfe_ctx* c, FrameLane& L, int slot, int w, int h, hipStream_t s)
+{
+    const size_t K = (size_t)c->maxKp, px = (size_t)w * h;
+    hipError_t e = hipMemcpyAsync(L.d_in, L.h_in, L.withDepth ? px * 3 : px, hipMemcpyHostToDevice, s);
+    SlotShift shift(c, slot);
+    if (e == hipSuccess) e = drfe_launch_orb(c, L.d_in, px, (size_t)w, 1, s);
+    if (e == hipSuccess && L.withDepth)
+        e = drfe_launch_glue(c, reinterpret_cast<const uint16_t*>(L.d_in + px), px, (size_t)w, L.cam, 1, s);
+    uint8_t* o = L.h_out;
+    if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_status, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(o + 4, c->d_kpCount, 4, hipMemcpyDeviceToHost, s);
+    o += 8;
+    if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_kps, K * sizeof(drfe_keypoint), hipMemcpyDeviceToHost, s);
+    o += K * sizeof(drfe_keypoint);
+    if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_desc, K * 32, hipMemcpyDeviceToHost, s);
+    o += K * 32;
+    if (L.withDepth) {
+        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_uRight, K * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4, c->d_depth, K * 4, hipMemcpyDeviceToHost, s);
+    }
+    return e;
+}
+
+extern "C" {
+
+int drfe_frame_submit(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, size_t stride, const uint16_t* depth,
+                      size_t depth_stride_elems, const drfe_camera* cam)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    if (slot < 0 || slot >= c->cfg.max_batch || !gray || w < 1 || h < 1 || stride < (size_t)w || (size_t)w * h > c->stageBytes ||
+        (depth && (!cam || depth_stride_elems < (size_t)w))) {
+        c->err = "drfe_frame_submit: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    if (depth && (!(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y))) { c->err = "drfe_frame_submit: empty image bounds"; return DRFE_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->frameLanes) {
+        auto* v = new (std::nothrow) std::vector<FrameLane>((size_t)c->cfg.max_batch);
+        if (!v) return DRFE_ERR_INVALID;
+        c->frameLanes = v;
+    }
+    FrameLane& L = (*static_cast<std::vector<FrameLane>*>(c->frameLanes))[(size_t)slot];
+    if (L.pending) { c->err = "drfe_frame_submit: the slot's previous submission has not been collected"; return DRFE_ERR_STATE; }
+    /* geometry tables first: an upload synchronises the device and invalidates every slot */
+    int rc = upload_geometry(c, w, h);
+    if (rc != DRFE_OK) return rc;
+    const size_t K = (size_t)c->maxKp, px = (size_t)w * h;
+    if (L.inBytes < px * 3) {
+        if (L.h_in) (void)hipHostFree(L.h_in);
+        if (L.d_in) (void)hipFree(L.d_in);
+        L.h_in = nullptr; L.d_in = nullptr; L.inBytes = 0;
+        frame_lane_release_graph(L);
+        HIPCHK(c, hipHostMalloc((void**)&L.h_in, px * 3, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&L.d_in, px * 3));
+        L.inBytes = px * 3;
+    }
+    if (!L.h_out) HIPCHK(c, hipHostMalloc((void**)&L.h_out, 8 + K * (sizeof(drfe_keypoint) + 32 + 8), hipHostMallocDefault));
+    if (!L.done) HIPCHK(c, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    for (int y = 0; y < h; y++) std::memcpy(L.h_in + (size_t)y * w, gray + (size_t)y * stride, (size_t)w);
+    if (depth)
+        for (int y = 0; y < h; y++) std::memcpy(L.h_in + px + (size_t)y * w * 2, depth + (size_t)y * depth_stride_elems, (size_t)w * 2);
+    const int withDepth = depth ? 1 : 0;
+    /* a captured graph holds kernel arguments by value: camera, distortion model and sizes are part of its key */
+    const bool sameKey = L.w == w && L.h == h && L.withDepth == withDepth &&
+                         (!withDepth || (std::memcmp(&L.cam, cam, sizeof(drfe_camera)) == 0 && std::memcmp(&L.dist, &c->dist, sizeof(DrfeDistortion)) == 0));
+    if (!sameKey) frame_lane_release_graph(L);
+    L.w = w; L.h = h; L.withDepth = withDepth;
+    if (withDepth) { L.cam = *cam; L.dist = c->dist; }
+    hipStream_t s = c->stream;
+    static const bool noGraph = [] { const char* e = std::getenv("DRFE_NO_GRAPH"); return e && e[0] == '1'; }();
+    if (!L.exec && !L.graphOff && !noGraph && !c->profile) {
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const hipError_t e = frame_enqueue(c, L, slot, w, h, s);
+            hipGraph_t g = nullptr;
+            const hipError_t ee = hipStreamEndCapture(s, &g);
+            if (e == hipSuccess && ee == hipSuccess && g && hipGraphInstantiate(&L.exec, g, nullptr, nullptr, 0) == hipSuccess) L.graph = g;
+            else { if (g) (void)hipGraphDestroy(g); L.exec = nullptr; L.graphOff = true; (void)hipGetLastError(); }
+        } else { L.graphOff = true; (void)hipGetLastError(); }
+    }
+    if (L.exec && !c->profile) HIPCHK(c, hipGraphLaunch(L.exec, s));
+    else HIPCHK(c, frame_enqueue(c, L, slot, w, h, s));
+    HIPCHK(c, hipEventRecord(L.done, s));
+    L.pending = true;
+    c->lastBatch = std::max(c->lastBatch, slot + 1);
+    if (withDepth) { c->glueValid = true; c->cam = *cam; }
+    return DRFE_OK;
+}
+
+int drfe_frame_collect(drfe_ctx* c, int slot, drfe_keypoint* kps, uint8_t* desc, float* u_right, float* depth_m, int cap, int* n_out)
+{
+    if (!c || !n_out) return DRFE_ERR_INVALID;
+    *n_out = 0;
+    auto* v = static_cast<std::vector<FrameLane>*>(c->frameLanes);
+    if (slot < 0 || slot >= c->cfg.max_batch || !v || !(*v)[(size_t)slot].pending) {
+        c->err = "drfe_frame_collect: nothing submitted to this slot";
+        return DRFE_ERR_STATE;
+    }
+    FrameLane& L = (*v)[(size_t)slot];
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(L.done));
+    L.pending = false;
+    const size_t K = (size_t)c->maxKp;
+    int st = 0, n = 0;
+    std::memcpy(&st, L.h_out, 4);
+    std::memcpy(&n, L.h_out + 4, 4);
+    if (st & 1) { c->err = "FAST candidate arena overflow"; return DRFE_ERR_CAPACITY; }
+    if (st & 2) { c->err = "quadtree node pool overflow"; return DRFE_ERR_CAPACITY; }
+    *n_out = n;
+    if (n > cap) { c->err = "keypoint buffer too small"; return DRFE_ERR_CAPACITY; }
+    if ((u_right || depth_m) && !L.withDepth) { c->err = "drfe_frame_collect: the frame was submitted without a depth image"; return DRFE_ERR_STATE; }
+    const uint8_t* o = L.h_out + 8;
+    if (n > 0 && kps) std::memcpy(kps, o, sizeof(drfe_keypoint) * (size_t)n);
+    o += K * sizeof(drfe_keypoint);
+    if (n > 0 && desc) std::memcpy(desc, o, (size_t)n * 32);
+    o += K * 32;
+    if (n > 0 && u_right) std::memcpy(u_right, o, (size_t)n * 4);
+    if (n > 0 && depth_m) std::memcpy(depth_m, o + K * 4, (size_t)n * 4);
     return DRFE_OK;
 }
 

@@ -155,6 +155,7 @@ struct drfe_ctx {
     void* cape;               /* CapeScratch*: device buffers of drfe_planes_cape (planes_internal.h) */
     void* sn;                 /* SnBuffers*: surface-normal scratch (post_internal.h) */
     void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */
+    void* frameLanes;         /* std::vector<FrameLane>*: per-slot staging of drfe_frame_submit / drfe_frame_collect (capi.cpp) */
 
     /* profiling */
     bool profile;
@@ -169,6 +170,7 @@ static inline drfe_keypoint* drfe_kps_un(const drfe_ctx* c) { return c->dist.ena
  * (std::thread::hardware_concurrency() reports the machine, which oversubscribes a quota-limited container) */
 int drfe_default_host_threads();
 void drfe_one_shot_free(drfe_ctx* c);                    /* capi.cpp: the captured single-frame ORB graph */
+void drfe_frame_lanes_free(drfe_ctx* c);                 /* capi.cpp: staging + graphs of the per-frame pipelined flow */
 
 /* orb_geometry.cpp */
 int drfe_build_tables(drfe_ctx* c);                       /* scale tables, quotas, umax */

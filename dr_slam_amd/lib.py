@@ -38,7 +38,7 @@ SYMBOLS = (
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
     "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
-    "drfe_lsd_search_by_sim3",
+    "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -112,6 +112,8 @@ def load() -> C.CDLL:
     L.drfe_orb_max_keypoints.argtypes = [vp]
     L.drfe_orb_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_extract_batch.argtypes = [vp, vp, sz, sz, i32, i32, i32, vp]
+    L.drfe_frame_submit.argtypes = [vp, i32, vp, i32, i32, sz, vp, sz, C.POINTER(Camera)]
+    L.drfe_frame_collect.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_download.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_counts.argtypes = [vp, i32, vp]
     L.drfe_orb_fast_partition.argtypes = [vp, i32, i32, vp, vp]
@@ -331,6 +333,29 @@ class Context:
         self._chk(self.L.drfe_orb_extract(self.h, _p(gray), gray.shape[1], gray.shape[0], gray.strides[0], _p(kps),
                                           _p(desc), self.max_kp, C.byref(n)), "drfe_orb_extract")
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def frame_submit(self, slot: int, gray: np.ndarray, depth16: np.ndarray = None, cam: Camera = None):
+        """Per-frame pipelined flow: enqueue ORB (+ the Frame glue when a raw depth image is given) of one host frame into
+        `slot` and return without waiting."""
+        assert gray.dtype == np.uint8 and gray.ndim == 2 and gray.strides[1] == 1
+        dp, ds = None, 0
+        if depth16 is not None:
+            assert depth16.dtype == np.uint16 and depth16.shape == gray.shape and depth16.strides[1] == 2
+            dp, ds = _p(depth16), depth16.strides[0] // 2
+        self._chk(self.L.drfe_frame_submit(self.h, slot, _p(gray), gray.shape[1], gray.shape[0], gray.strides[0], dp,
+                                           C.c_size_t(ds), C.byref(cam) if cam is not None else None), "drfe_frame_submit")
+
+    def frame_collect(self, slot: int, stereo=False):
+        """-> (mvKeys, mDescriptors[, mvuRight, mvDepth]) of the slot's outstanding submission."""
+        kps = np.zeros(self.max_kp, KP_DTYPE)
+        desc = np.zeros((self.max_kp, 32), np.uint8)
+        ur = np.zeros(self.max_kp, np.float32) if stereo else None
+        z = np.zeros(self.max_kp, np.float32) if stereo else None
+        n = C.c_int(0)
+        self._chk(self.L.drfe_frame_collect(self.h, slot, _p(kps), _p(desc), _p(ur) if stereo else None,
+                                            _p(z) if stereo else None, self.max_kp, C.byref(n)), "drfe_frame_collect")
+        out = (kps[:n.value].copy(), desc[:n.value].copy())
+        return out + (ur[:n.value].copy(), z[:n.value].copy()) if stereo else out
 
     def orb_extract_batch_ptr(self, d_gray: int, frame_stride: int, row_stride: int, w: int, h: int, nframes: int,
                               stream: int = 0):

@@ -147,6 +147,28 @@ int drfe_frame_download_stereo(drfe_ctx* ctx, int slot, float* u_right, float* d
 int drfe_frame_download_grid(drfe_ctx* ctx, int slot, int32_t* offsets, int32_t* indices, int cap);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Per-frame pipelined flow: what Frame::Frame (src/Frame.cc:74-160) does for ONE frame, without waiting for it.
+ * Tracking::GrabImageRGBD (src/Tracking.cc:191) builds one Frame at a time and matches it against the previous one:
+ * frame k goes to slot k % max_batch, the slot of frame k-1 keeps LastFrame's keypoints, descriptors and grid on the
+ * device for the slot-pair matchers (drfe_search_by_projection_last(cur_slot, last_slot, ...), drfe_match_orb_points,
+ * drfe_search_by_bow, ...).  Other slots are not touched.
+ *   drfe_frame_submit   copies the frame into pinned staging and enqueues, as one captured hipGraph per slot: H2D ->
+ *                       ORBextractor::operator() -> [depth != NULL: UndistortKeyPoints / ComputeStereoFromRGBD /
+ *                       AssignFeaturesToGrid with `cam` and the model of drfe_frame_set_distortion] -> D2H of mvKeys,
+ *                       mDescriptors, mvuRight, mvDepth.  Returns without waiting: the calling thread is free for the host
+ *                       halves of the line / plane extractors (the reference starts threads for ExtractORB / ExtractLSD /
+ *                       ComputePlanes, src/Frame.cc:124-134).  depth: raw CV_16U image, rows depth_stride_elems apart,
+ *                       or NULL (ORB only).  One submission per slot may be outstanding (DRFE_ERR_STATE otherwise).
+ *   drfe_frame_collect  waits for that slot's submission and copies its results out (u_right / depth_m may be NULL; they
+ *                       need a submission with a depth image).  Results are identical to drfe_orb_extract +
+ *                       drfe_frame_stereo_grid_batch on the same frame (tests/test_gpu_match.py).
+ * The batch entry points renumber the slots (a batch fills 0..nframes-1): use one context per flow. */
+int drfe_frame_submit(drfe_ctx* ctx, int slot, const uint8_t* gray, int w, int h, size_t stride, const uint16_t* depth,
+                      size_t depth_stride_elems, const drfe_camera* cam);
+int drfe_frame_collect(drfe_ctx* ctx, int slot, drfe_keypoint* kps, uint8_t* desc, float* u_right, float* depth_m, int cap,
+                       int* n_out);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* ORBmatcher (replaces src/ORBmatcher.cc hot paths)                                                 */
 
 /* What the matcher reads through LastFrame.mvpMapPoints[i] (MapPoint::GetWorldPos/GetDescriptor/

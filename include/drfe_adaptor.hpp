@@ -95,10 +95,12 @@ class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
+    /* slots: frame slots of the context - 1 for the plain operator(), >= 2 for the pipelined Submit / Collect flow in which
+     * LastFrame stays on the device for the slot-pair matchers */
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int maxWidth = 640, int maxHeight = 480,
-                 int device = 0)
+                 int device = 0, int slots = 1)
         : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST),
-          mCtx(drfe_detail::make_ctx(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, maxWidth, maxHeight, 1, device))
+          mCtx(drfe_detail::make_ctx(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, maxWidth, maxHeight, slots, device))
     {
         mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
         mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
@@ -138,6 +140,37 @@ public:
             mvImagePyramid[l] = drfe_cv::Mat(bh - 38, bw - 38, mvPyramidStore[l].data + 19 * (size_t)bw + 19, (size_t)bw);
 #endif
         }
+    }
+
+    /* The same extraction without waiting for it (drfe_frame_submit / drfe_frame_collect): Frame::Frame calls Submit where it
+     * started the ExtractORB thread (src/Frame.cc:124), runs ExtractLSD / ComputePlanes on the calling thread, then Collect where
+     * it joined.  With a depth image (CV_16U, as Tracking hands imDepth before its convertTo) and the camera, the glue
+     * (UndistortKeyPoints, ComputeStereoFromRGBD, AssignFeaturesToGrid) runs in the same submission and mvuRight / mvDepth
+     * come back with the keypoints. */
+    void Submit(int slot, const drfe_cv::Mat& image, const uint16_t* depth16 = nullptr, size_t depthStrideElems = 0,
+                const drfe_camera* cam = nullptr)
+    {
+        drfe_detail::check(drfe_frame_submit(mCtx.get(), slot, drfe_cv::mat_data(image), image.cols, image.rows, drfe_cv::mat_step(image),
+                                             depth16, depthStrideElems, cam), mCtx.get(), "drfe_frame_submit");
+    }
+    void Collect(int slot, std::vector<drfe_cv::KeyPoint>& keypoints, drfe_cv::Mat& descriptors, std::vector<float>* mvuRight = nullptr,
+                 std::vector<float>* mvDepth = nullptr)
+    {
+        const int cap = drfe_orb_max_keypoints(mCtx.get());
+        keypoints.resize(cap);
+        drfe_cv::Mat desc = drfe_cv::mat_u8(cap, 32);
+        if (mvuRight) mvuRight->resize(cap);
+        if (mvDepth) mvDepth->resize(cap);
+        int n = 0;
+        drfe_detail::check(drfe_frame_collect(mCtx.get(), slot, reinterpret_cast<drfe_keypoint*>(keypoints.data()), desc.data,
+                                              mvuRight ? mvuRight->data() : nullptr, mvDepth ? mvDepth->data() : nullptr, cap, &n),
+                           mCtx.get(), "drfe_frame_collect");
+        keypoints.resize(n);
+        if (mvuRight) mvuRight->resize(n);
+        if (mvDepth) mvDepth->resize(n);
+        if (n == 0) { descriptors.release(); return; }
+        descriptors = drfe_cv::mat_u8(n, 32);
+        std::memcpy(descriptors.data, desc.data, (size_t)n * 32);
     }
 
     int inline GetLevels() { return nlevels; }

@@ -39,6 +39,15 @@ int main(int argc, char** argv)
         drfe_cv::Mat dimg(h, w, depth.data(), (size_t)w * 2, 2);
         if (!pd.readDepthImage(dimg, K, 1.0f / 5000.0f)) return 5;
         pd.runPlaneDetection();
+        {   /* the pipelined flow through the adaptor: Submit returns at once, Collect brings the same keypoints + the glue's stereo */
+            Planar_SLAM::ORBextractor ex2(1000, 1.2f, 8, 20, 7, w, h, 0, 2);
+            const drfe_camera cam = {535.4f, 539.2f, 320.1f, 247.6f, 40.0f, 1.0f / 5000.0f, 0.0f, (float)w, 0.0f, (float)h};
+            std::vector<drfe_cv::KeyPoint> k2; drfe_cv::Mat d2; std::vector<float> ur, z;
+            ex2.Submit(1, image, reinterpret_cast<const uint16_t*>(depth.data()), (size_t)w, &cam);
+            ex2.Collect(1, k2, d2, &ur, &z);
+            if (k2.size() != kps.size() || std::memcmp(k2.data(), kps.data(), kps.size() * sizeof(drfe_cv::KeyPoint)) != 0 ||
+                std::memcmp(d2.data, desc.data, kps.size() * 32) != 0 || ur.size() != kps.size() || z.size() != kps.size()) return 6;
+        }
         FILE* f = std::fopen(argv[5], "wb");
         const int32_t hdr[4] = {(int32_t)kps.size(), (int32_t)kl.size(), pd.plane_num_, Planar_SLAM::ORBmatcher::DescriptorDistance(desc.data, desc.data + 32)};
         std::fwrite(hdr, 4, 4, f);

@@ -499,3 +499,73 @@ def test_sparse_depth_glue_equals_image_glue(setup, frames_room):
             if s:
                 m, nm = fe.matches(s)
                 assert nm == m0[1] and np.array_equal(m, m0[0])
+
+
+@pytest.mark.parametrize("camname", ["TUM3", "TUM1"])
+def test_per_frame_pipelined_flow(oracle_mod, camname):
+    """drfe_frame_submit / drfe_frame_collect: Tracking's frame-by-frame flow on a two-slot context.  Frame k + 1 is
+    submitted before frame k is collected (two submissions in flight), frame k goes to slot k % 2, and after collecting it
+    SearchByProjection(cur slot, last slot) runs against the previous frame that still lives in the other slot.  Keypoints,
+    descriptors, mvuRight / mvDepth, the grid and every match array equal the oracle's; TUM1 has lens distortion, so
+    mvKeysUn is live in the glue."""
+    from dr_slam_amd import lib, synth
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = getattr(synth, camname)
+    frames = list(synth.sequence(7, 5, cam=cam))
+    fe = FrontEnd(cam, max_batch=2)            # sets the camera, the image bounds and the distortion model
+    c = fe.ctx
+    Tcw, Twc = _poses(frames)
+    o = oracle_mod.OrbOracle()
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    dist = tuple(getattr(cam, "dist", ()) or ())
+    ofr = []
+    for g, d, _ in frames:
+        kps, desc = o(g)
+        df = oracle_mod.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+        if dist and dist[0] != 0.0:
+            ofr.append(oracle_mod.FrameOracle(kps, desc, df, K4, cam.bf, cam.w, cam.h, o.scale, dist=cam.dist))
+        else:
+            ofr.append(oracle_mod.FrameOracle(kps, desc, df, K4, cam.bf, cam.w, cam.h, o.scale))
+    with pytest.raises(lib.DrfeError):
+        c.frame_collect(0)                                      # nothing submitted yet
+    c.frame_submit(0, frames[0][0], frames[0][1], fe.cam)
+    with pytest.raises(lib.DrfeError):
+        c.frame_submit(0, frames[0][0], frames[0][1], fe.cam)   # one submission per slot
+    for k in range(len(frames)):
+        if k + 1 < len(frames):
+            c.frame_submit((k + 1) % 2, frames[k + 1][0], frames[k + 1][1], fe.cam)     # two in flight
+        kps, desc, ur, z = c.frame_collect(k % 2, stereo=True)
+        fo = ofr[k]
+        assert np.array_equal(kps.view(np.uint8), fo.kps.view(np.uint8)) and np.array_equal(desc, fo.desc)
+        assert np.array_equal(ur.view(np.uint32), fo.uRight.view(np.uint32))
+        assert np.array_equal(z.view(np.uint32), fo.depth.view(np.uint32))
+    c.close()
+    # lock-step variant (frame k - 1 must still be in its slot when the pair is matched): collect frame k, match it against
+    # frame k - 1 in the other slot, then submit frame k + 1
+    fe2 = FrontEnd(cam, max_batch=2)
+    c = fe2.ctx
+    c.frame_submit(0, frames[0][0], frames[0][1], fe2.cam)
+    for k in range(len(frames)):
+        kps, desc = c.frame_collect(k % 2)
+        assert np.array_equal(kps.view(np.uint8), ofr[k].kps.view(np.uint8))
+        off, idx = c.download_grid(k % 2)
+        ooff, oidx = ofr[k].grid_csr()
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        if k >= 1:
+            cur, last = ofr[k], ofr[k - 1]
+            mp = _last_mp(oracle_mod, last, Twc[k - 1])
+            gmp = np.zeros(last.N, lib.MAPPOINT_DTYPE)
+            gmp["valid"], gmp["obs_positive"], gmp["world"], gmp["desc"] = mp["valid"], mp["obsPositive"], mp["world"], mp["desc"]
+            n_o, m_o = oracle_mod.search_by_projection_last(cur, last, Tcw[k], Tcw[k - 1], mp, 15.0, False, True)
+            n_g, m_g = c.search_by_projection_last(k % 2, (k - 1) % 2, Tcw[k], Tcw[k - 1], fe2.cam, gmp, cur.N, 15.0, False, True)
+            assert n_g == n_o and np.array_equal(m_g, m_o) and n_o > 200, (k, n_g, n_o)
+        if k + 1 < len(frames):
+            c.frame_submit((k + 1) % 2, frames[k + 1][0], frames[k + 1][1], fe2.cam)
+    # ORB only (no depth image): keypoints as before, the stereo outputs are refused
+    c.frame_submit(0, frames[2][0])
+    with pytest.raises(lib.DrfeError):
+        c.frame_collect(0, stereo=True)
+    c.frame_submit(0, frames[2][0])
+    kps, desc = c.frame_collect(0)
+    assert np.array_equal(kps.view(np.uint8), ofr[2].kps.view(np.uint8)) and np.array_equal(desc, ofr[2].desc)
+    c.close()
