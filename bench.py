@@ -41,6 +41,9 @@ WORKLOAD_TEXT = {
     4: "640x480 synthetic RGB-D, one 256-frame sequence per rank (seed 10+rank, intrinsics cycling TUM1/TUM2/TUM3: "
        "UndistortKeyPoints live on two thirds of the ranks), ORB extract 1000/1.2/8/20/7 + SearchByProjection(frame "
        "k, frame k-1, th=15); BASELINE config 4",
+    5: "1280x960 synthetic RealSense-style RGB-D stream (D435 intrinsics x 2, depth factor 1000), 8 pyramid levels, ORB extract "
+       "1000/1.2/8/20/7 + SearchByProjection(frame k, frame k-1, th=15), batched on the device; LSD+LBD lines and CAPE planes of "
+       "the same frames timed per frame beside it; BASELINE config 5 (a parity / roofline case, not the headline)",
 }
 
 
@@ -93,7 +96,7 @@ def _host_model():
     return "unknown"
 
 
-def cpu_baseline(base, cam, frames: int = 220, discard: int = 20):
+def cpu_baseline(base, cam, frames: int = 220, discard: int = 20, only_orb: bool = False):
     """The CPU oracle (kind 'port': the reference cannot be built) timed on this host in the three threading shapes of
     BASELINE.md section 2; steady_clock per frame, first `discard` frames dropped, median and p95:
       (i)   1 thread: ORB extract + SearchByProjection against the previous frame  (= the metric's path; `value`)
@@ -154,10 +157,11 @@ def cpu_baseline(base, cam, frames: int = 220, discard: int = 20):
     shapes = {}
     shapes["i_orb_match_1thread"] = dict(stats(run_sequence(frames, False, None)), threads=1)
     n2 = max(discard + 40, frames // 2)                 # the full front-end costs ~3x per frame: bounded sample
-    with ThreadPoolExecutor(2) as pool:
-        shapes["ii_orb_lsd_ahc_3threads"] = dict(stats(run_sequence(n2, True, pool)), threads=3)
+    if not only_orb:                                    # AHC is a 640x480 extractor (the reference hard-codes its block grid)
+        with ThreadPoolExecutor(2) as pool:
+            shapes["ii_orb_lsd_ahc_3threads"] = dict(stats(run_sequence(n2, True, pool)), threads=3)
     nseq = max(1, ncpu // 3)
-    if nseq > 1:
+    if nseq > 1 and not only_orb:
         pools = [ThreadPoolExecutor(2) for _ in range(nseq)]
         with ThreadPoolExecutor(nseq) as outer:
             res = list(outer.map(lambda p: run_sequence(n2, True, p), pools))
@@ -166,9 +170,28 @@ def cpu_baseline(base, cam, frames: int = 220, discard: int = 20):
         shapes["iii_all_cores"] = dict(stats(np.concatenate(res), nseq), threads=3 * nseq, sequences=nseq)
     one = shapes["i_orb_match_1thread"]
     return {"value": one["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{one['frames']} frames 640x480 after {discard} discarded (ORB extract + SearchByProjection vs the previous "
+            "sample": f"{one['frames']} frames {cam.w}x{cam.h} after {discard} discarded (ORB extract + SearchByProjection vs the previous "
                       f"frame), CPU oracle {flags} -ffp-contract=off, 1 thread; 1 / median frame time",
             "host": {"model": _host_model(), "cpus_available": ncpu}, "shapes": shapes}
+
+
+def config5_aux(ctx, base, cam, n: int = 6):
+    """BASELINE config 5 names ORB + LSD + plane: single-frame latency of the line path (device passes + host LSD / LBD) and
+    of the CAPE plane path at this frame size, on the context the ORB batch ran on (AHC is a 640x480 extractor: the
+    reference hard-codes its 10 x 10 block grid for that size)."""
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    out = {}
+    ctx.lsd_extract(base[0][0])
+    t0 = time.perf_counter()
+    nl = [len(ctx.lsd_extract(base[i % len(base)][0])["lines"]) for i in range(n)]
+    out["lsd_lbd_ms"] = (time.perf_counter() - t0) * 1e3 / n
+    dm = [(base[i % len(base)][1].astype(np.float32) * (np.float32(1.0) / np.float32(cam.depth_factor))) for i in range(n)]
+    ctx.planes_cape(dm[0], K4, 20)
+    t0 = time.perf_counter()
+    npl = [len(ctx.planes_cape(d, K4, 20)["planes"]) for d in dm]
+    out["cape_ms"] = (time.perf_counter() - t0) * 1e3 / n
+    out["lines_per_frame"], out["planes_per_frame"] = float(np.mean(nl)), float(np.mean(npl))
+    return out
 
 
 def host_fed_rate(fe, gray, depth, Tcw, Twc, B, steps, dev):
@@ -430,15 +453,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = 512; 128 at config 5, whose frames have 4x the pixels)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent batches in flight per GPU: consecutive steps alternate between this many contexts, each on "
                          "its own stream, so that the latency-bound kernels of one batch (quadtree, claim resolution) run beside "
                          "the VALU-bound ones of the other.  Measured: 220-226 k frames/s against 203 k for the default when it works, "
                          "176-194 k when the two arena sets land badly (tools/two_stream_probe2.py): not the default")
-    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4),
+    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4, 5),
                     help="BASELINE.json config: 2 = TUM3 single sequence, 4 = TUM1/2/3 mix, one 256-frame sequence "
-                         "per rank; 0 = config 2 at one rank, config 4 at N > 1")
+                         "per rank; 5 = 1280x960 RealSense-style stream (roofline report at 4x the pixels); 0 = config 2 at one "
+                         "rank, config 4 at N > 1")
     ap.add_argument("--distinct", type=int, default=0,
                     help="frames rendered per rank (0 = the config's sequence length: 64 / 256)")
     ap.add_argument("--render-workers", type=int, default=0,
@@ -490,7 +514,7 @@ def main():
 
     from dr_slam_amd.pipeline import FrontEnd
 
-    B = args.batch
+    B = args.batch or (128 if config == 5 else 512)
     gray, depth, Tcw, Twc = make_batch(base, B)
     nfl = max(1, args.inflight)
     fes = [FrontEnd(cam, max_batch=B, device=local_rank) for _ in range(nfl)]
@@ -571,9 +595,17 @@ def main():
         # own event pair and its share of the FAST read (every pixel of the detection region belongs to exactly one cell)
         cells, px = fe.ctx.fast_partition(cam.w, cam.h)
         algo_bytes = dict(ALGO_BYTES)
+        if (cam.w, cam.h) != (640, 480):
+            # SURVEY.md section 8(d)'s per-frame figures are functions of the level sizes: the same formulas on this geometry
+            lv = [fe.ctx.pyramid_level(0, l).shape for l in range(fe.ctx.nlevels)]          # bordered (h + 38, w + 38)
+            interior = [(h - 38) * (w - 38) for h, w in lv]
+            algo_bytes["pyramid"] = cam.w * cam.h + sum(h * w for h, w in lv) + sum(interior[:-1])
+            algo_bytes["fast"] = sum(interior)
+            algo_bytes["blur"] = 2 * sum(interior)
         tot = float(px.sum())
-        algo_bytes["fast"] = ALGO_BYTES["fast"] * float(px[0]) / tot
-        algo_bytes["fast_b"] = ALGO_BYTES["fast"] * float(px[1]) / tot
+        fast_all = algo_bytes["fast"]
+        algo_bytes["fast"] = fast_all * float(px[0]) / tot
+        algo_bytes["fast_b"] = fast_all * float(px[1]) / tot
         cand = {k: stage_ms[k] for k in algo_bytes if stage_ms.get(k, 0.0) > 0}
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         roof_stage = dom if dom in cand else max(cand, key=lambda k: cand[k])
@@ -586,7 +618,7 @@ def main():
                  "fast_b": "k_fast_cells_cols<12>", "blur": "k_blur", "desc": "k_orient_desc",
                  "match": "k_window_candidates"}[roof_stage]
         try:
-            pmc_name = "r02_pmc_traffic_b%d.json" % B
+            pmc_name = ("r02_pmc_traffic_c5_b%d.json" if config == 5 else "r02_pmc_traffic_b%d.json") % B
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
                 k = pmc["kernels"][kname]
@@ -597,7 +629,7 @@ def main():
             pass
         fps = total_frames / el
         out = {
-            "metric": "RGB-D frames/sec (extract+match) at 640x480",
+            "metric": "RGB-D frames/sec (extract+match) at %dx%d" % (cam.w, cam.h),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -619,7 +651,11 @@ def main():
                         "against the real libraries (none can be built here)"
         for f in fes[1:]:
             f.ctx.close()
-        if world == 1 and not args.no_extras:
+        if config == 5:
+            out["algorithmic_bytes_per_frame"] = {k: int(v) for k, v in algo_bytes.items()}
+            if not args.no_extras:
+                out["aux_per_frame"] = config5_aux(fe.ctx, base, cam)
+        if world == 1 and not args.no_extras and config != 5:
             fps_hf, ms_hf = host_fed_rate(fe, gray, depth, Tcw, Twc, B, max(4, min(args.steps, 10)), dev)
             out["value_host_fed"] = fps_hf
             out["host_fed"] = {"ms_per_step": ms_hf, "h2d_bytes_per_step": int(gray.nbytes + depth.nbytes),
@@ -636,8 +672,8 @@ def main():
                                             "note": "gray frames only cross the link; the host gathers one raw depth value per keypoint "
                                                     "(sparse-depth glue), two contexts alternate"}
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported by the N=1 run only
-            out["cpu_baseline"] = cpu_baseline(base, cam)
-        if world == 1 and not args.no_extras:
+            out["cpu_baseline"] = cpu_baseline(base, cam, frames=70 if config == 5 else 220, only_orb=config == 5)
+        if world == 1 and not args.no_extras and config != 5:
             fe.ctx.close()
             del gray_t, depth_t
             out["full_frontend"] = full_frontend("ICL")

@@ -56,6 +56,7 @@ def rank_workload(config: int, rank: int):
 
     config 2: the single-GPU headline (TUM3 intrinsics, room_boxes; every rank runs seed 10+rank so N ranks never
               render the same images);
+    config 5: a 1280x960 RealSense-style stream (BASELINE.json configs[4]), 16 distinct frames per rank;
     config 4: eight independent 256-frame sequences, seeds 10..17, intrinsics cycling TUM1/TUM2/TUM3 yaml - two
               thirds of the ranks have lens distortion, so Frame::UndistortKeyPoints (src/Frame.cc:835-871) is live.
     """
@@ -65,6 +66,8 @@ def rank_workload(config: int, rank: int):
         return 10 + (rank % 8), cam, "room_boxes", 256
     if config == 2:
         return rank_seed(10, rank), synth.TUM3, "room_boxes", 64
+    if config == 5:   # 1280x960 RealSense-style stream (a parity / roofline case): D435 intrinsics x 2
+        return rank_seed(20, rank), synth.REALSENSE.scaled(2.0), "corridor", 16
     raise ValueError(f"no sharded workload for config {config}")
 
 

@@ -1,15 +1,16 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r02 [batch]
+#   tools/profile_round.sh r02 [batch] [extra bench.py arguments, e.g. "--config 5"]
 # one --kernel-trace --stats pass and four counter passes (FETCH_SIZE | WRITE_SIZE | two SQ groups), never combined with
 # tracing; everything lands under gpurun_out/<tag>_*; tools/pmc_traffic.py folds the counter CSVs into profiles/.
 set -u
 TAG=${1:-r02}
 B=${2:-512}
+EXTRA=${3:-}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --batch $B --inflight 1 --distinct 8 --render-workers 1 --no-cpu-baseline --no-extras"
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --batch $B --inflight 1 --distinct 8 --render-workers 1 --no-cpu-baseline --no-extras $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
             "sq1 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
