@@ -228,7 +228,9 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
         CHIP(dalloc(&c->d_disc, disc.size()));
         CHIP(hipMemcpy(c->d_disc, disc.data(), disc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     }
-    CHIP(dalloc(&c->d_pyr, B * c->pyrSlotBytesMax));
+    /* + 256: k_blur reads whole dwords up to 24 bytes past a tile's last column without clamping; only the last row of the last
+     * level of the last slot can take that past the arena (the values are never stored) */
+    CHIP(dalloc(&c->d_pyr, B * c->pyrSlotBytesMax + 256));
     CHIP(dalloc(&c->d_blur, B * c->blurSlotBytesMax));
     CHIP(dalloc(&c->d_cand0, B * c->candSlotElemsMax));
     CHIP(dalloc(&c->d_cand1, B * c->candSlotElemsMax));

@@ -754,7 +754,7 @@ template <class SH> __device__ __forceinline__ int qt_child_slot(const SH& S, in
  * rule of SURVEY.md §9.1) and stop as soon as the list holds N nodes (:730).  Keys never move: each
  * carries the list position of its node. */
 template <int QT_THREADS, int QT_KPT, int QT_MAXN>
-__global__ __launch_bounds__(QT_THREADS, 4) void k_quadtree(const DevGeom* __restrict__ G, int levelBase,
+__global__ __launch_bounds__(QT_THREADS, QT_THREADS == 256 ? 8 : 4) void k_quadtree(const DevGeom* __restrict__ G, int levelBase,
                                                          const uint32_t* __restrict__ cand0,
                                                          const uint32_t* __restrict__ cand1,
                                                          uint16_t* __restrict__ node,
@@ -1051,21 +1051,26 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
     const BlurTile t = tiles[bx];
     const int slot = by, tid = threadIdx.x;
     const DevLevel& L = G->lv[t.level];
-    const uint8_t* img = pyr + (size_t)slot * G->pyrSlotBytes + L.pyrOff;
-    const int x0 = t.tx * DRFE_BLUR_TW, y0 = t.ty * DRFE_BLUR_TH;
+    /* block-uniform bases stay in SGPRs (the swizzled bx / by come out of vector arithmetic: readfirstlane says they are
+     * uniform); a thread addresses with ONE 32-bit offset per source row and the three dwords of a row are immediate
+     * offsets 0 / 4 / 8 of the same load (a level is < 2^24 bytes) */
+    const size_t imgOff = (size_t)__builtin_amdgcn_readfirstlane(slot) * (size_t)G->pyrSlotBytes + (size_t)L.pyrOff;
+    const uint8_t* img = pyr + imgOff;
+    const int x0 = __builtin_amdgcn_readfirstlane(t.tx * DRFE_BLUR_TW), y0 = __builtin_amdgcn_readfirstlane(t.ty * DRFE_BLUR_TH);
     const int cg = tid & (BLUR_COLG - 1), rr = tid / BLUR_COLG;
-    /* interior x maps to bordered column x+19; the window of pixels x..x+3 starts at x+16 (4-aligned) */
-    const int maxWord = L.pyrPitch - 4;
-    const int c0 = min(x0 + cg * 4 + 16, maxWord), c1 = min(x0 + cg * 4 + 20, maxWord), c2 = min(x0 + cg * 4 + 24, maxWord);
+    /* interior x maps to bordered column x+19; the window of pixels x..x+3 starts at x+16 (4-aligned).  No column clamp: a
+     * block tile may overhang the row, its threads then read the bytes that follow (the next row; at the very end of the arena
+     * the 256 spare bytes drfe_create allocates) and store nothing */
+    const uint32_t col = (uint32_t)(x0 + cg * 4 + 16);
+    const uint32_t pitch = (uint32_t)L.pyrPitch;
     const int lastRow = L.h + 2 * DRFE_EDGE - 1;
     /* byte k of (w0,w1,w2) is interior column x-3+k.  Pixel x+j needs bytes j..j+6: the dword starting at byte j
      * (v_alignbyte) against taps (18,34,49,55) and the dword starting at byte j+4 against (49,34,18,0), two
      * v_dot4_u32_u8 per pixel; 257 * 255 = 65535 still fits 16 bits */
     const uint32_t tA = 18u | (34u << 8) | (49u << 16) | (55u << 24), tB = 49u | (34u << 8) | (18u << 16);
-    auto hsum4 = [&](const uint8_t* row, uint32_t (&h)[4]) {
-        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + c0);
-        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + c1);
-        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + c2);
+    auto hsum4 = [&](uint32_t off, uint32_t (&h)[4]) {
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(img + off);
+        const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
         const uint32_t a1 = __builtin_amdgcn_alignbyte(w1, w0, 1), a2 = __builtin_amdgcn_alignbyte(w1, w0, 2), a3 = __builtin_amdgcn_alignbyte(w1, w0, 3);
         const uint32_t b1 = __builtin_amdgcn_alignbyte(w2, w1, 1), b2 = __builtin_amdgcn_alignbyte(w2, w1, 2), b3 = __builtin_amdgcn_alignbyte(w2, w1, 3);
         h[0] = __builtin_amdgcn_udot4(w0, tA, __builtin_amdgcn_udot4(w1, tB, 0u, false), false);
@@ -1073,12 +1078,15 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
         h[2] = __builtin_amdgcn_udot4(a2, tA, __builtin_amdgcn_udot4(b2, tB, 0u, false), false);
         h[3] = __builtin_amdgcn_udot4(a3, tA, __builtin_amdgcn_udot4(b3, tB, 0u, false), false);
     };
+    /* low halves of two registers as one dword (the sums fit 16 bits): one v_perm_b32 */
+    auto pack16 = [](uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); };
     for (int p = rr; p < BLUR_ROWS / 2; p += BLUR_ROWL) {
         uint32_t ha[4], hc[4];
-        hsum4(img + (size_t)min(y0 + 2 * p - 3 + DRFE_EDGE, lastRow) * L.pyrPitch, ha);
-        hsum4(img + (size_t)min(y0 + 2 * p - 2 + DRFE_EDGE, lastRow) * L.pyrPitch, hc);
+        const uint32_t ra = (uint32_t)min(y0 + 2 * p - 3 + DRFE_EDGE, lastRow), rc = (uint32_t)min(y0 + 2 * p - 2 + DRFE_EDGE, lastRow);
+        hsum4(__umul24(ra, pitch) + col, ha);
+        hsum4(__umul24(rc, pitch) + col, hc);
         *reinterpret_cast<uint4*>(&hb2[p * DRFE_BLUR_TW + cg * 4]) =
-            make_uint4(ha[0] | (hc[0] << 16), ha[1] | (hc[1] << 16), ha[2] | (hc[2] << 16), ha[3] | (hc[3] << 16));
+            make_uint4(pack16(ha[0], hc[0]), pack16(ha[1], hc[1]), pack16(ha[2], hc[2]), pack16(ha[3], hc[3]));
     }
     __syncthreads();
     /* vertical pass, two output rows (2q, 2q+1) per thread from the four row pairs q..q+3:
@@ -1086,10 +1094,12 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
      *   row 2q+1 = 18 * hi(P[q]) + (34,49).P[q+1] + (55,49).P[q+2] + (34,18).P[q+3] */
     typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
     const u16x2v t1834 = {18, 34}, t4955 = {49, 55}, t4934 = {49, 34}, t3449 = {34, 49}, t5549 = {55, 49}, t3418 = {34, 18};
-    if (x0 + cg * 4 >= L.blurPitch * DRFE_BTILE_W) return;      /* the block tile may overhang the last layout tile */
+    const int blurPitch = L.blurPitch, levelH = L.h;
+    if (x0 + cg * 4 >= blurPitch * DRFE_BTILE_W) return;      /* the block tile may overhang the last layout tile */
+    uint8_t* base = blur + (size_t)__builtin_amdgcn_readfirstlane(slot) * (size_t)G->blurSlotBytes + (size_t)L.blurOff;
     for (int q = rr; q < DRFE_BLUR_TH / 2; q += BLUR_ROWL) {
         const int y = y0 + 2 * q;
-        if (y >= L.h) continue;
+        if (y >= levelH) continue;
         uint4 P[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4*>(&hb2[(q + k) * DRFE_BLUR_TW + cg * 4]);
@@ -1108,13 +1118,12 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
             c2v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), t5549, c2v[j], false);
             c2v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p3), t3418, c2v[j], false);
         }
-        const uint32_t outA = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a[0], (int)a[1], 16) |
-                              ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a[2], (int)a[3], 16) << 16);
-        const uint32_t outB = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)c2v[0], (int)c2v[1], 16) |
-                              ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)c2v[2], (int)c2v[3], 16) << 16);
-        uint8_t* base = blur + (size_t)slot * G->blurSlotBytes + L.blurOff;
-        *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y, L.blurPitch)) = outA;
-        if (y + 1 < L.h) *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y + 1, L.blurPitch)) = outB;
+        const uint32_t outA = pack16((uint32_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a[0], (int)a[1], 16),
+                                     (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a[2], (int)a[3], 16));
+        const uint32_t outB = pack16((uint32_t)__builtin_amdgcn_ashr_pk_u8_i32((int)c2v[0], (int)c2v[1], 16),
+                                     (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32((int)c2v[2], (int)c2v[3], 16));
+        *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y, blurPitch)) = outA;
+        if (y + 1 < levelH) *reinterpret_cast<uint32_t*>(base + drfe_blur_offset(x0 + cg * 4, y + 1, blurPitch)) = outB;
     }
 }
 
