@@ -1080,7 +1080,10 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
     };
     /* low halves of two registers as one dword (the sums fit 16 bits): one v_perm_b32 */
     auto pack16 = [](uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); };
-    for (int p = rr; p < BLUR_ROWS / 2; p += BLUR_ROWL) {
+    /* source rows y0-3 .. min(y0 + TH, h) + 2 are all the stored output rows read: a tile that overhangs the level's last row
+     * (a third of the tile area on the small levels) stops there - whole wavefronts drop out, a wave is two tile rows */
+    const int pEnd = __builtin_amdgcn_readfirstlane(min(BLUR_ROWS / 2, (min(DRFE_BLUR_TH, L.h - y0) + 7) >> 1));
+    for (int p = rr; p < pEnd; p += BLUR_ROWL) {
         uint32_t ha[4], hc[4];
         const uint32_t ra = (uint32_t)min(y0 + 2 * p - 3 + DRFE_EDGE, lastRow), rc = (uint32_t)min(y0 + 2 * p - 2 + DRFE_EDGE, lastRow);
         hsum4(__umul24(ra, pitch) + col, ha);
