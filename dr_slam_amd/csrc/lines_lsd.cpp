@@ -59,8 +59,8 @@ public:
     {
         /* 0 = free, 1 = claimed, 2 = no level-line angle (never joins a region): the probe of a neighbour then reads the
          * compact byte map only, not the angle field, for the third of the pixels that can never pass */
-        used_.resize((size_t)W * H);
-        for (size_t i = 0; i < used_.size(); i++) used_[i] = angles[i] == kNotDef ? 2 : 0;
+        used_.resize((size_t)W * H + 8);             /* + 8: grow() reads the state bytes four at a time */
+        for (size_t i = 0; i < (size_t)W * H; i++) used_[i] = angles[i] == kNotDef ? 2 : 0;
         const double binCoef = (maxGrad > 0) ? double(1024 - 1) / maxGrad : 0;
         order_.clear();
         order_.reserve((size_t)(W - 1) * (H - 1));
@@ -102,12 +102,14 @@ public:
             if (!timed_) {
                 grow(s.x, s.y, reg, regAngle, prec);
                 if (reg.size() < minReg) continue;
+                fillModgrad(reg);
             } else {   /* DRFE_TRACE_LINES: the same steps with wall-clock accounting */
                 const auto t0 = std::chrono::steady_clock::now();
                 grow(s.x, s.y, reg, regAngle, prec);
                 tGrow_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                nGrow_++;
+                nGrow_++; nGrowPx_ += (long)reg.size();
                 if (reg.size() < minReg) continue;
+                fillModgrad(reg);
             }
             RectD rec;
             const auto t1 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
@@ -132,7 +134,7 @@ public:
         return true;
     }
 
-    double tGrow_ = 0, tRefine_ = 0, tImprove_ = 0; long nGrow_ = 0, nRect_ = 0; bool timed_ = false;
+    double tGrow_ = 0, tRefine_ = 0, tImprove_ = 0; long nGrow_ = 0, nRect_ = 0, nGrowPx_ = 0; bool timed_ = false;
 private:
     int W_, H_;
     const double *mod_, *ang_;
@@ -162,38 +164,71 @@ private:
         if (n > kThreeHalfPi) { n -= kTwoPi; if (n < 0) n = -n; }
         return n <= prec;
     }
+    /* region_grow.  The gradient magnitude of a member is filled in by fillModgrad() for the regions that reach the minimum
+     * size only (one in twenty: the rest are dropped without ever reading it). */
     void grow(int sx, int sy, std::vector<RPt>& reg, double& regAngle, double prec)
     {
         reg.clear();
         regAngle = ang_[(size_t)sy * W_ + sx];
-        reg.push_back({sx, sy, regAngle, mod_[(size_t)sy * W_ + sx]});
+        reg.push_back({sx, sy, regAngle, 0.0});
         /* the seed's own direction enters the running sums when the first neighbour joins: most of the ~35 000 seeds of a
          * frame never get one, and these are the only two libm calls of the loop */
         float sumdx = 0.f, sumdy = 0.f;
         bool seeded = false;
         const double seedAngle = regAngle;
-        used_[(size_t)sy * W_ + sx] = 1;
+        uint8_t* const used = used_.data();
+        used[(size_t)sy * W_ + sx] = 1;
+        auto probe = [&](int xx, int yy, uint8_t& u) {
+            /* isAligned() on a pixel known to be inside the image and to have an angle */
+            const size_t at = (size_t)yy * W_ + xx;
+            const double a = ang_[at];
+            double dn = regAngle - a;
+            if (dn < 0) dn = -dn;
+            if (dn > kThreeHalfPi) { dn -= kTwoPi; if (dn < 0) dn = -dn; }
+            if (dn <= prec) {
+                u = 1;
+                reg.push_back({xx, yy, a, 0.0});
+                if (!seeded) { sumdx = float(std::cos(seedAngle)); sumdy = float(std::sin(seedAngle)); seeded = true; }
+                sumdx += cs_[2 * at];        /* cos(float(angle)), shared routine (device) */
+                sumdy += cs_[2 * at + 1];    /* sin(float(angle)) */
+                regAngle = drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
+            }
+        };
+        /* the three state bytes of a row as bits: byte == 0 (free; 1 = claimed, 2 = no angle) -> bit c of the result */
+        auto freeBits = [](const uint8_t* p) {
+            uint32_t r;
+            std::memcpy(&r, p, 4);
+            r &= 0x00FFFFFFu;
+            r = ~(r | (r >> 1)) & 0x00010101u;
+            return (r | (r >> 7) | (r >> 14)) & 7u;
+        };
         for (size_t i = 0; i < reg.size(); i++) {
             const int px = reg[i].x, py = reg[i].y;
+            if (px >= 1 && py >= 1 && px <= W_ - 2 && py <= H_ - 2) {
+                /* interior member: the 3 x 3 neighbourhood's state as nine bits in visiting order (rows, then columns), read
+                 * with three loads; nothing inside it changes behind the scan except the neighbour just claimed, so the bits
+                 * stay valid for the whole visit and only the free neighbours (few) are looked at */
+                uint8_t* u0 = used + (size_t)(py - 1) * W_ + (px - 1);
+                uint32_t f = freeBits(u0) | (freeBits(u0 + W_) << 3) | (freeBits(u0 + 2 * (size_t)W_) << 6);
+                while (f) {
+                    const int k = __builtin_ctz(f);
+                    f &= f - 1;
+                    const int r = (k * 11) >> 5, c = k - 3 * r;          /* k / 3, k % 3 for k < 9 */
+                    probe(px - 1 + c, py - 1 + r, u0[(size_t)r * W_ + c]);
+                }
+                continue;
+            }
             for (int yy = std::max(py - 1, 0); yy <= std::min(py + 1, H_ - 1); ++yy)
                 for (int xx = std::max(px - 1, 0); xx <= std::min(px + 1, W_ - 1); ++xx) {
-                    uint8_t& u = used_[(size_t)yy * W_ + xx];
+                    uint8_t& u = used[(size_t)yy * W_ + xx];
                     if (u != 0) continue;
-                    /* isAligned() on a pixel known to be inside the image and to have an angle */
-                    const double a = ang_[(size_t)yy * W_ + xx];
-                    double dn = regAngle - a;
-                    if (dn < 0) dn = -dn;
-                    if (dn > kThreeHalfPi) { dn -= kTwoPi; if (dn < 0) dn = -dn; }
-                    if (dn <= prec) {
-                        u = 1;
-                        reg.push_back({xx, yy, a, mod_[(size_t)yy * W_ + xx]});
-                        if (!seeded) { sumdx = float(std::cos(seedAngle)); sumdy = float(std::sin(seedAngle)); seeded = true; }
-                        sumdx += cs_[2 * ((size_t)yy * W_ + xx)];        /* cos(float(angle)), shared routine (device) */
-                        sumdy += cs_[2 * ((size_t)yy * W_ + xx) + 1];    /* sin(float(angle)) */
-                        regAngle = drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
-                    }
+                    probe(xx, yy, u);
                 }
         }
+    }
+    void fillModgrad(std::vector<RPt>& reg) const
+    {
+        for (RPt& r : reg) r.modgrad = mod_[(size_t)r.y * W_ + r.x];
     }
     double thetaOf(const std::vector<RPt>& reg, double x, double y, double regAngle, double prec) const
     {
@@ -267,6 +302,7 @@ private:
         const int sx = reg[0].x, sy = reg[0].y;
         grow(sx, sy, reg, regAngle, tau);
         if (reg.size() < 2) return false;
+        fillModgrad(reg);
         toRect(reg, regAngle, prec, p, rec);
         density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
         if (density < densityTh) return shrink(reg, regAngle, prec, p, rec, density, densityTh);
@@ -586,8 +622,8 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
     };
     if (!finder.run(segs, counts)) return countRc;
     const auto tSeg = std::chrono::steady_clock::now();
-    if (trace) std::fprintf(stderr, "drfe_lsd_extract: pixel ordering (bins + std::sort) %.2f ms; grow %.2f ms (%ld regions); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
-                            std::chrono::duration<double, std::milli>(tSort - tDev).count(), finder.tGrow_, finder.nGrow_, finder.tRefine_, finder.nRect_, finder.tImprove_);
+    if (trace) std::fprintf(stderr, "drfe_lsd_extract: pixel ordering (bins + std::sort) %.2f ms; grow %.2f ms (%ld regions, %ld pixels); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
+                            std::chrono::duration<double, std::milli>(tSort - tDev).count(), finder.tGrow_, finder.nGrow_, finder.nGrowPx_, finder.tRefine_, finder.nRect_, finder.tImprove_);
 
     /* LSDDetector::detect: KeyLine fields for octave 0 (octaveScale = 1) */
     std::vector<drfe_keyline> kls;
@@ -761,8 +797,8 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
     finder.timed_ = std::getenv("DRFE_TRACE_LINES") != nullptr;
     finder.run(out, counts);
     if (finder.timed_)
-        std::fprintf(stderr, "drfe_lsd_segments_host: grow %.2f ms (%ld regions); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
-                     finder.tGrow_, finder.nGrow_, finder.tRefine_, finder.nRect_, finder.tImprove_);
+        std::fprintf(stderr, "drfe_lsd_segments_host: grow %.2f ms (%ld regions, %ld pixels); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
+                     finder.tGrow_, finder.nGrow_, finder.nGrowPx_, finder.tRefine_, finder.nRect_, finder.tImprove_);
     *n_segs = (int)(out.size() / 4);
     if (*n_segs > cap) return DRFE_ERR_CAPACITY;
     if (segs && !out.empty()) std::memcpy(segs, out.data(), out.size() * sizeof(float));
