@@ -627,4 +627,20 @@ AhcResult ahc_run(const uint16_t* depth, int w, int h, const float K4[4], float 
     return out;
 }
 
+/* taps for tests/test_ref_pins.py: the thresholds and the disjoint set of this restatement, to be compared with the
+ * reference's own include/peac/AHCParamSet.hpp and DisjointSet.hpp compiled into oracle/_ref */
+void ahc_thresholds(int phase, double z, double out3[3])
+{
+    const Params p;
+    out3[0] = p.T_mse((Params::Phase)phase, z);
+    out3[1] = p.T_ang((Params::Phase)phase, z);
+    out3[2] = p.T_dz(z);
+}
+void ahc_disjoint_set(int n, const int32_t* pairs, int npairs, int32_t* unionRet, int32_t* findOut, int32_t* sizeOut)
+{
+    DisjointSet ds(n);
+    for (int i = 0; i < npairs; i++) unionRet[i] = ds.Union(pairs[2 * i], pairs[2 * i + 1]);
+    for (int i = 0; i < n; i++) { findOut[i] = ds.Find(i); sizeOut[i] = ds.getSetSize(i); }
+}
+
 } // namespace orc

@@ -25,5 +25,8 @@ void eig33sym(const double K[3][3], double s[3], double V[3][3]);
 AhcResult ahc_run(const uint16_t* depth, int w, int h, const float K4[4], float depthfactor,
                   std::vector<AhcBlock>* blocksOut = nullptr);
 
+void ahc_thresholds(int phase, double z, double out3[3]);      /* T_mse, T_ang, T_dz of the default ParamSet */
+void ahc_disjoint_set(int n, const int32_t* pairs, int npairs, int32_t* unionRet, int32_t* findOut, int32_t* sizeOut);
+
 } // namespace orc
 #endif

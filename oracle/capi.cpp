@@ -270,6 +270,11 @@ void* orc_ahc_run(const uint16_t* depth, int w, int h, const float* K4, float de
     catch (const std::exception& e) { g_err = e.what(); delete H; return nullptr; }
     return H;
 }
+void orc_ahc_thresholds(int phase, double z, double* out3) { ahc_thresholds(phase, z, out3); }
+void orc_ahc_disjoint_set(int n, const int32_t* pairs, int npairs, int32_t* unionRet, int32_t* findOut, int32_t* sizeOut)
+{
+    ahc_disjoint_set(n, pairs, npairs, unionRet, findOut, sizeOut);
+}
 void orc_ahc_free(void* h) { delete (AhcHandle*)h; }
 int orc_ahc_num_planes(void* h) { return (int)((AhcHandle*)h)->r.planes.size(); }
 int orc_ahc_num_blocks(void* h) { return (int)((AhcHandle*)h)->blocks.size(); }
