@@ -569,3 +569,52 @@ def test_per_frame_pipelined_flow(oracle_mod, camname):
     kps, desc = c.frame_collect(0)
     assert np.array_equal(kps.view(np.uint8), ofr[2].kps.view(np.uint8)) and np.array_equal(desc, ofr[2].desc)
     c.close()
+
+
+def test_per_frame_flow_survives_reconfiguration(oracle_mod):
+    """The per-slot graphs of drfe_frame_submit are keyed by image size, camera and distortion model: a change of any of
+    them between submissions (another resolution - which also re-uploads the geometry tables -, a distortion model switched
+    on and off, a different depth factor) must give the results of a fresh context, and argument errors must not leave a slot
+    pending."""
+    from dr_slam_amd import lib, synth
+    o = oracle_mod.OrbOracle()
+    cam3 = synth.TUM3
+    f_big = list(synth.sequence(4, 2, cam=cam3))
+    small = synth.TUM3.scaled(0.75)                       # 480 x 360
+    f_small = list(synth.sequence(5, 2, cam=small))
+    c = lib.Context(max_width=640, max_height=480, max_batch=3)
+    mk = lambda cam: lib.make_camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.depth_factor, cam.w, cam.h)
+    K = lambda cam: np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+
+    def check(slot, frame, cam, dist=None):
+        kps, desc, ur, z = c.frame_collect(slot, stereo=True)
+        okps, odesc = o(frame[0])
+        assert np.array_equal(kps.view(np.uint8), okps.view(np.uint8)) and np.array_equal(desc, odesc)
+        df = oracle_mod.depth_to_float(frame[1], np.float32(1.0) / np.float32(cam.depth_factor))
+        fo = oracle_mod.FrameOracle(okps, odesc, df, K(cam), cam.bf, cam.w, cam.h, o.scale, dist=dist)
+        assert np.array_equal(ur.view(np.uint32), fo.uRight.view(np.uint32)) and np.array_equal(z.view(np.uint32), fo.depth.view(np.uint32))
+
+    with pytest.raises(lib.DrfeError):
+        c.frame_submit(3, f_big[0][0], f_big[0][1], mk(cam3))            # slot out of range
+    with pytest.raises(lib.DrfeError):
+        c.frame_collect(0)                                                # the failed call left nothing pending
+    c.frame_submit(0, f_big[0][0], f_big[0][1], mk(cam3)); check(0, f_big[0], cam3)
+    # another resolution on the same slot and on a fresh one (geometry tables re-uploaded, graphs re-captured)
+    c.frame_submit(0, f_small[0][0], f_small[0][1], mk(small)); check(0, f_small[0], small)
+    c.frame_submit(1, f_small[1][0], f_small[1][1], mk(small)); check(1, f_small[1], small)
+    # back, with two submissions in flight across the switch of the distortion model
+    c.frame_submit(2, f_big[1][0], f_big[1][1], mk(cam3))
+    check(2, f_big[1], cam3)
+    cam1 = synth.TUM1
+    cd = mk(cam1)
+    b = c.image_bounds(cd, cam1.dist, cam1.w, cam1.h)
+    cd.min_x, cd.max_x, cd.min_y, cd.max_y = (float(v) for v in b)
+    c.set_distortion(cd, cam1.dist)
+    f1 = list(synth.sequence(6, 1, cam=cam1))
+    c.frame_submit(0, f1[0][0], f1[0][1], cd); check(0, f1[0], cam1, dist=cam1.dist)
+    c.set_distortion(cd, None)                                            # model off again: mvKeysUn = mvKeys
+    c.frame_submit(0, f_big[0][0], f_big[0][1], mk(cam3)); check(0, f_big[0], cam3)
+    # a different depth factor only (kernel argument of the captured glue)
+    rs = synth.Camera(cam3.fx, cam3.fy, cam3.cx, cam3.cy, cam3.bf, 1000.0)
+    c.frame_submit(0, f_big[0][0], f_big[0][1], mk(rs)); check(0, f_big[0], rs)
+    c.close()
