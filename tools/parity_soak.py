@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Parity soak: many seeded synthetic sequences of every scene kind through the batched product path (ORB extract + stereo /
 grid + SearchByProjection against the previous frame) and through the CPU oracle, frame by frame; prints the number of
-frames compared and every mismatch.  Longer than the test-suite cases; run on a GPU box: python tools/parity_soak.py [n_seq]"""
+frames compared and every mismatch.  Longer than the test-suite cases; run on a GPU box:
+    python tools/parity_soak.py [n_seq] [--cam TUM3|TUM1|TUM2|ICL|REALSENSE[xSCALE]] [--flow batch|frame]
+--cam REALSENSEx2 is BASELINE config 5's 1280x960 stream, TUM1 / TUM2 have lens distortion (mvKeysUn live);
+--flow frame pushes the frames one at a time through drfe_frame_submit / drfe_frame_collect on a two-slot context (frame k + 1
+submitted once frame k has been matched against frame k - 1, which must stay in its slot until then) and matches slot pairs with
+drfe_search_by_projection_last."""
 import os
 import sys
 import time
@@ -18,10 +23,23 @@ def main():
     from dr_slam_amd.pipeline import FrontEnd
     from oracle import oracle as O
     O.lib()
-    n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    args = [a for a in sys.argv[1:]]
+    camname, flow = "TUM3", "batch"
+    if "--cam" in args:
+        camname = args[args.index("--cam") + 1]
+        del args[args.index("--cam"):args.index("--cam") + 2]
+    if "--flow" in args:
+        flow = args[args.index("--flow") + 1]
+        del args[args.index("--flow"):args.index("--flow") + 2]
+    n_seq = int(args[0]) if args else 12
     frames_per = 8
-    cam = synth.TUM3
-    fe = FrontEnd(cam, max_batch=frames_per)
+    base, _, sc = camname.partition("x")
+    cam = getattr(synth, base)
+    if sc:
+        cam = cam.scaled(float(sc))
+    dist = cam.dist if (len(cam.dist) > 0 and cam.dist[0] != 0.0) else None
+    from dr_slam_amd import lib
+    fe = FrontEnd(cam, max_batch=frames_per if flow == "batch" else 2)
     o = O.OrbOracle()
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     kinds = ["room_boxes", "planar_lowtexture", "living_room", "corridor"]
@@ -30,33 +48,55 @@ def main():
     t0 = time.time()
     for s in range(n_seq):
         kind = kinds[s % len(kinds)]
-        frames = list(synth.sequence(1000 + s, frames_per, kind=kind, start=(s * 7) % 40))
-        gray = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
-        depth = torch.from_numpy(np.stack([f[1] for f in frames]).view(np.int16)).cuda()
+        frames = list(synth.sequence(1000 + s, frames_per, cam=cam, kind=kind, start=(s * 7) % 40))
         Twc = np.stack([f[2] for f in frames]).astype(np.float64)
         Tcw = np.linalg.inv(Twc).astype(np.float32)
         Twc = Twc.astype(np.float32)
-        fe.process(gray, depth, Tcw, Twc, th=15.0, check_ori=True, stream=torch.cuda.current_stream().cuda_stream)
+        if flow == "batch":
+            gray = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+            depth = torch.from_numpy(np.stack([f[1] for f in frames]).view(np.int16)).cuda()
+            fe.process(gray, depth, Tcw, Twc, th=15.0, check_ori=True, stream=torch.cuda.current_stream().cuda_stream)
         of = []
+        frame_matches = {}
         for i, (g, d, _) in enumerate(frames):
             kps, desc = o(g)
-            gk, gd = fe.keypoints(i)
+            if flow == "batch":
+                gk, gd = fe.keypoints(i)
+            else:
+                if i == 0:
+                    fe.ctx.frame_submit(0, g, d, fe.cam)
+                gk, gd = fe.ctx.frame_collect(i % 2)
             ok = len(gk) == len(kps) and np.array_equal(gd, desc) and gk.tobytes() == kps.tobytes()   # same record layout
             if not ok:
                 bad += 1
                 print(f"MISMATCH extract: seq {s} ({kind}) frame {i}: {len(gk)} vs {len(kps)} keypoints")
-            of.append(O.FrameOracle(kps, desc, O.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor)), K4, cam.bf, cam.w, cam.h, o.scale))
+            of.append(O.FrameOracle(kps, desc, O.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor)), K4, cam.bf, cam.w, cam.h, o.scale,
+                                    dist=dist))
             total += 1
+            if flow != "batch":
+                if i >= 1 and ok:       # match against LastFrame, still resident in the other slot, before that slot is reused
+                    world, valid = of[i - 1].unproject(Twc[i - 1])
+                    gmp = np.zeros(of[i - 1].N, lib.MAPPOINT_DTYPE)
+                    gmp["valid"], gmp["obs_positive"], gmp["world"], gmp["desc"] = valid, 1, world, of[i - 1].desc
+                    n_g, m_g = fe.ctx.search_by_projection_last(i % 2, (i - 1) % 2, Tcw[i], Tcw[i - 1], fe.cam, gmp, of[i].N, 15.0, False, True)
+                    frame_matches[i] = (m_g, n_g)
+                if i + 1 < frames_per:
+                    fe.ctx.frame_submit((i + 1) % 2, frames[i + 1][0], frames[i + 1][1], fe.cam)
         for i in range(1, frames_per):
             world, valid = of[i - 1].unproject(Twc[i - 1])
             mp = np.zeros(of[i - 1].N, O.MAPPOINT_DTYPE)
             mp["valid"], mp["obsPositive"], mp["world"], mp["desc"] = valid, 1, world, of[i - 1].desc
             n_o, m_o = O.search_by_projection_last(of[i], of[i - 1], Tcw[i], Tcw[i - 1], mp, 15.0, False, True)
-            m_g, n_g = fe.matches(i)
+            if flow == "batch":
+                m_g, n_g = fe.matches(i)
+            elif i in frame_matches:
+                m_g, n_g = frame_matches[i]
+            else:
+                continue
             if n_g != n_o or not np.array_equal(m_g[:of[i].N], m_o):
                 bad += 1
                 print(f"MISMATCH match: seq {s} ({kind}) frame {i}: {n_g} vs {n_o}")
-    print(f"{total} frames, {n_seq * (frames_per - 1)} frame pairs compared in {time.time() - t0:.0f} s: {bad} mismatches")
+    print(f"{camname} {cam.w}x{cam.h}, {flow} flow: {total} frames, {n_seq * (frames_per - 1)} frame pairs compared in {time.time() - t0:.0f} s: {bad} mismatches")
     fe.ctx.close()
     sys.exit(1 if bad else 0)
 
