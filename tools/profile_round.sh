@@ -7,6 +7,7 @@ set -u
 TAG=${1:-r02}
 B=${2:-512}
 EXTRA=${3:-}
+rm -rf ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_stats ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_pmc_*      # one run per directory: the fold picks the only CSV
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
