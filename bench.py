@@ -451,14 +451,18 @@ def launch(args) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 1000 timed steps (~2.3 s of device time): the steady rate.  Shorter runs are not wrong, but they sit on a clock transient of
+    # the device - at batch 512 one context does 203 k frames/s over 20 steps, 192 k over 200 and 203-206 k over 1000; three in
+    # flight 220 k / 213 k / 225 k (three fresh processes each, one box)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = 512; 128 at config 5, whose frames have 4x the pixels)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="independent batches in flight per GPU: consecutive steps alternate between this many contexts, each on "
-                         "its own stream, so that the latency-bound kernels of one batch (quadtree, claim resolution) run beside "
-                         "the VALU-bound ones of the other.  Measured: 220-226 k frames/s against 203 k for the default when it works, "
-                         "176-194 k when the two arena sets land badly (tools/two_stream_probe2.py): not the default")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="independent batches in flight per GPU: consecutive steps alternate between this many contexts, each on the "
+                         "stream its context owns, so that the latency-bound kernels of one batch (quadtree, claim resolution, "
+                         "the small glue kernels: 40 %% VALU-busy or less) run beside the VALU-bound ones of the others.  Measured "
+                         "(fresh processes, 120 steps): 1 x 512: 203 k frames/s, 2 x 512: 222 k, 3 x 512: 227-231 k, 4 x 512: 218-223 k "
+                         "(more contexts than hardware queues).  1 = a single context on torch's current stream")
     ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4, 5),
                     help="BASELINE.json config: 2 = TUM3 single sequence, 4 = TUM1/2/3 mix, one 256-frame sequence "
                          "per rank; 5 = 1280x960 RealSense-style stream (roofline report at 4x the pixels); 0 = config 2 at one "
@@ -522,8 +526,10 @@ def main():
     gray_t = torch.from_numpy(gray).to(dev)
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
     # own (non-default) streams when batches overlap: work on the null stream does not run beside other streams
-    tstreams = [torch.cuda.current_stream()] if nfl == 1 else [torch.cuda.Stream() for _ in range(nfl)]
-    streams = [s.cuda_stream for s in tstreams]
+    # Batches in flight run on the streams their contexts OWN (drfe_create makes one per context; 0 = "the context's stream"):
+    # those land on different hardware queues.  Streams handed out by torch's pool did not, in a fresh process - the two
+    # batches then queue behind each other and nothing overlaps (tools/two_stream_probe4.py: 207 k against 227 k frames/s).
+    streams = [torch.cuda.current_stream().cuda_stream] if nfl == 1 else [0] * nfl
     stream = streams[0]
 
     if world > 1 or args.bow:
