@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
     __shared__ __attribute__((aligned(16))) uint8_t tile[DRFE_RESIZE_LDS_ROWS * RES_PITCH];
     int bx, by, bz;
     drfe_xcd_swizzle_3d(magicXY, magicX, bx, by, bz);   /* a frame's tiles on one XCD: neighbouring source windows overlap */
-    const int slot = bz;
+    bx = __builtin_amdgcn_readfirstlane(bx); by = __builtin_amdgcn_readfirstlane(by);    /* block-uniform: scalar bases */
+    const int slot = __builtin_amdgcn_readfirstlane(bz);
     const int tid = threadIdx.y * 64 + threadIdx.x;
     uint8_t* base = pyr + (size_t)slot * pyrSlotBytes;
     const ResizeTap wx = taps[L.xwinOff + bx], wy = taps[L.ywinOff + by];
@@ -199,12 +200,17 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
     }
     __syncthreads();
     if (y0 >= bh) return;                        /* wave-uniform; columns past the pitch compute on column 0 and store nothing */
+    uint8_t* const dstLevel = base + L.pyrOff;   /* block-uniform: the stores address with one 32-bit offset (a level is < 2^24 bytes) */
     const uint32_t syp[PYR_ROWS] = {tya.x, tya.z, tyb.x, tyb.z}, wyp[PYR_ROWS] = {tya.y, tya.w, tyb.y, tyb.w};
     const uint32_t sp[4] = {ta.x, ta.z, tb.x, tb.z}, wp[4] = {ta.y, ta.w, tb.y, tb.w};
-    int o0[4], o1[4], w0[4], w1[4];
+    /* The second tap of a column is the pixel right of the first (s1 == s0 + 1), except at the level's last column where the
+     * table repeats s0 with weight 0: reading s0 + 1 there multiplies whatever the tile holds by zero, so ONE address per
+     * column serves both taps (the second is the +1 immediate of the LDS load; a tile row has a spare dword behind it):
+     * four address adds per source row instead of eight, 22 VGPRs instead of 30 */
+    int o0[4], w0[4], w1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        o0[k] = (int)(sp[k] & 0xFFFF) + DRFE_EDGE - ws; o1[k] = (int)(sp[k] >> 16) + DRFE_EDGE - ws;
+        o0[k] = (int)(sp[k] & 0xFFFF) + DRFE_EDGE - ws;
         w0[k] = (int)(short)(wp[k] & 0xFFFF); w1[k] = (int)(short)(wp[k] >> 16);
     }
     /* horizontal pass of one source row for this thread's four columns, already shifted (the vertical pass only ever
@@ -212,7 +218,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
     auto hrow = [&](int srow, uint32_t (&H)[4]) {
         const uint8_t* R = &tile[srow * RES_PITCH];
 #pragma unroll
-        for (int k = 0; k < 4; k++) H[k] = (uint32_t)(((int)R[o0[k]] * w0[k] + (int)R[o1[k]] * w1[k]) >> 4);
+        for (int k = 0; k < 4; k++) {
+            /* two byte loads on purpose: merged into one 16-bit load (what the compiler does with plain accesses) they are
+             * misaligned for half of the columns, and the LDS serves those at a third of the speed (measured: pyramid stage
+             * 0.50 -> 1.43 ms).  The volatile LDS-address-space pointer keeps them apart. */
+            typedef const volatile __attribute__((address_space(3))) uint8_t* lds_u8p;
+            lds_u8p q = (lds_u8p)(R + o0[k]);
+            H[k] = (uint32_t)(((int)q[0] * w0[k] + (int)q[1] * w1[k]) >> 4);
+        }
     };
     /* Consecutive output rows mostly share a source row (scale 1.2: rows (s, s+1), (s+1, s+2), ...): the lower row's
      * horizontal pass is kept for the next output row, 5 instead of 8 row passes per thread.  (b * h) >> 16 is the high
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
             const uint32_t v = (__umulhi(Ha[k], b0s) + __umulhi(Hb[k], b1s) + 2u) >> 2;
             out |= v << (8 * k);
         }
-        if (active) *reinterpret_cast<uint32_t*>(base + L.pyrOff + (size_t)(y0 + r) * L.pyrPitch + x4) = out;
+        if (active) *reinterpret_cast<uint32_t*>(dstLevel + (uint32_t)(__umul24((uint32_t)(y0 + r), (uint32_t)L.pyrPitch) + (uint32_t)x4)) = out;
         prevB = b;
 #pragma unroll
         for (int k = 0; k < 4; k++) Hp[k] = Hb[k];
