@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     const int ww = fc.ww, wh = fc.wh;
     const int ew = ww - 6, eh = wh - 6;
     const int off = fc.off;
-    const uint8_t* src = pyr + (size_t)slot * pyrSlotBytes + fc.srcOff;
+    const uint8_t* src = pyr + (size_t)__builtin_amdgcn_readfirstlane(slot) * pyrSlotBytes + fc.srcOff;    /* block-uniform: a scalar base */
     {   /* window rows as 16-byte chunks, widened to one pixel per 16-bit lane.  Tile index k of a row holds byte k + sh of
            the aligned source row, sh = off & 1: pixel (wx, wy) of the window sits at index (off & 2) + wx, so every pixel
            pair a lane reads starts at an even index.  A chunk is loaded only if the window needs its first byte (and the
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
         for (int i = lane; i < nitems; i += 64) {
             const int r = nch == 1 ? i : nch == 2 ? (i >> 1) : (int)(((uint32_t)i * 21846u) >> 16);
             const int c = i - r * nch;
-            const uint8_t* p = src + (size_t)r * fc.pitch + c * 16;
+            const uint8_t* p = src + (uint32_t)(__umul24((uint32_t)r, fc.pitch) + (uint32_t)c * 16u);      /* 32-bit offset: a window is a few KB */
             const u32x4_a4 g = *reinterpret_cast<const u32x4_a4*>(p);
             uint32_t g4 = 0;
             if (sh && c * 16 + 16 < need) g4 = *reinterpret_cast<const uint32_t*>(p + 16);
@@ -649,38 +649,44 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
         dm[i] = u2subs(s[i], u2max(nb[i], th20));
         acc20 |= dm[i];
     }
-    int cnt = 0;
     if (!__any(acc20 != 0)) {                                          /* fallback decided per cell after NMS@ini */
 #pragma unroll
         for (int i = 0; i < RMAX; i++) dm[i] = u2subs(s[i], u2max(nb[i], th7));
     }
+    /* where a candidate goes inside the cell's run: row by row, the lanes of a row in lane order - one ballot per row, the
+     * row's start is a scalar popcount sum and a lane's place two v_mbcnt (the order inside a run is free: the quadtree ties on
+     * the order key of cand1, not on the array position) */
+    unsigned long long rowMask[RMAX];
+    int total = 0;
 #pragma unroll
-    for (int i = 0; i < RMAX; i++) cnt += dm[i] != 0 ? 1 : 0;
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    const int total = __shfl(incl, 63);
+    for (int i = 0; i < RMAX; i++) { rowMask[i] = __ballot(dm[i] != 0); total += __popcll(rowMask[i]); }
     if (total == 0) return;
     int cbase = 0;
     if (lane == 0) cbase = atomicAdd(&candCount[slot * nlevels + fc.level], total);
-    cbase = __shfl(cbase, 0);
+    cbase = __builtin_amdgcn_readfirstlane(cbase);
     if (cbase + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
-    size_t pos = (size_t)slot * candSlotElems + fc.candOff + cbase + (incl - cnt);
+    /* the cell's output run starts at a wave-uniform element (scalar base); a lane adds its 32-bit offset */
+    const size_t run = (size_t)__builtin_amdgcn_readfirstlane(slot) * (size_t)candSlotElems + fc.candOff + (size_t)cbase;
+    uint32_t* const out0 = cand0 + run;
+    uint32_t* const out1 = cand1 + run;
+    uint32_t rowStart = 0;                            /* scalar: candidates of the rows before this one */
+    /* the constant parts of the two records: keypoint coordinates as the reference leaves them in vToDistributeKeys
+     * (:822-823), and the emission-order key */
+    const uint32_t k0base = ((uint32_t)x + 3 + fc.offX) | (((uint32_t)y0 + 3 + fc.offY) << 12);
+    const uint32_t k1base = (fc.cellIdx << 12) | ((uint32_t)y0 << 6) | (uint32_t)x;
 #pragma unroll
-    for (int i = 0; i < RMAX; i++)
+    for (int i = 0; i < RMAX; i++) {
         if (dm[i] != 0) {
             const uint32_t hi = dm[i] >> 16 ? 1u : 0u;
             const uint32_t sc = hi ? s[i] >> 16 : s[i] & 0xFFFFu;
-            const uint32_t xx = (uint32_t)x + hi, yy = (uint32_t)(y0 + i);
-            /* keypoint coordinates as the reference leaves them in vToDistributeKeys (:822-823) */
-            const uint32_t kx = xx + 3 + fc.offX, ky = yy + 3 + fc.offY;
-            cand0[pos] = kx | (ky << 12) | (sc << 24);
-            cand1[pos] = (fc.cellIdx << 12) | (yy << 6) | xx;          /* emission order */
-            pos++;
+            /* x + hi and y0 + i never carry out of their fields (x + 1 < 64, y0 + i < 64; kx, ky < 4096) */
+            /* byte offset in 32-bit arithmetic: the store address stays scalar base + VGPR offset */
+            const uint32_t pos = (rowStart + __builtin_amdgcn_mbcnt_hi((uint32_t)(rowMask[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rowMask[i], 0u))) * 4u;
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out0) + pos) = (k0base + hi + ((uint32_t)i << 12)) | (sc << 24);
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out1) + pos) = k1base + hi + ((uint32_t)i << 6);
         }
+        rowStart += (uint32_t)__popcll(rowMask[i]);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ */
