@@ -184,6 +184,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
     const uint4 tyb = *reinterpret_cast<const uint4*>(taps + L.ytabOff + yT + 2);
     const uint4 ta = *reinterpret_cast<const uint4*>(taps + L.xtabOff + xT);
     const uint4 tb = *reinterpret_cast<const uint4*>(taps + L.xtabOff + xT + 2);
+    /* The 19 border rows above and below the level are mirror images of interior rows (copyMakeBorder REFLECT_101 of the resized
+     * interior, :1122-1123): the thread that computes interior row p in [1, 19] or [h - 20, h - 2] stores it a second time at
+     * its mirror row, and nobody computes a border row - 38 of a level's h + 38 rows, a fifth of the small levels.  A block
+     * whose sixteen rows are all border rows has nothing to do (block-uniform: before the tile fill and the barrier). */
+    {
+        const int r0 = by * (4 * PYR_ROWS);
+        if (r0 + 4 * PYR_ROWS <= DRFE_EDGE || r0 >= DRFE_EDGE + L.h) return;
+    }
     const int ws = ((int)wx.s0 + DRFE_EDGE) & ~3;                       /* bordered source column of tile byte 0 */
     const int wd = (((int)wx.s1 + DRFE_EDGE - ws) >> 2) + 1;           /* dwords per tile row */
     const int nr = (int)wy.s1 - (int)wy.s0 + 1;
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
     }
     __syncthreads();
     if (y0 >= bh) return;                        /* wave-uniform; columns past the pitch compute on column 0 and store nothing */
+    if (y0 + PYR_ROWS <= DRFE_EDGE || y0 >= DRFE_EDGE + L.h) return;    /* four border rows: nothing to compute */
     uint8_t* const dstLevel = base + L.pyrOff;   /* block-uniform: the stores address with one 32-bit offset (a level is < 2^24 bytes) */
     const uint32_t syp[PYR_ROWS] = {tya.x, tya.z, tyb.x, tyb.z}, wyp[PYR_ROWS] = {tya.y, tya.w, tyb.y, tyb.w};
     const uint32_t sp[4] = {ta.x, ta.z, tb.x, tb.z}, wp[4] = {ta.y, ta.w, tb.y, tb.w};
@@ -235,6 +244,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
 #pragma unroll
     for (int r = 0; r < PYR_ROWS; r++) {
         if (y0 + r >= bh) break;
+        const int pr = y0 + r - DRFE_EDGE;                               /* interior row; wave-uniform */
+        if (pr < 0 || pr >= L.h) continue;                               /* border row: written with its mirror image below */
         const uint32_t sy = (uint32_t)__builtin_amdgcn_readfirstlane((int)syp[r]), wy2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wyp[r]);
         const int a = (int)(sy & 0xFFFF) - (int)wy.s0, b = (int)(sy >> 16) - (int)wy.s0;
         uint32_t Ha[4], Hb[4];
@@ -255,7 +266,13 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
             const uint32_t v = (__umulhi(Ha[k], b0s) + __umulhi(Hb[k], b1s) + 2u) >> 2;
             out |= v << (8 * k);
         }
-        if (active) *reinterpret_cast<uint32_t*>(dstLevel + (uint32_t)(__umul24((uint32_t)(y0 + r), (uint32_t)L.pyrPitch) + (uint32_t)x4)) = out;
+        if (active) {
+            *reinterpret_cast<uint32_t*>(dstLevel + (uint32_t)(__umul24((uint32_t)(y0 + r), (uint32_t)L.pyrPitch) + (uint32_t)x4)) = out;
+            if (pr >= 1 && pr <= DRFE_EDGE)                              /* mirrors into the top border: bordered row 19 - p */
+                *reinterpret_cast<uint32_t*>(dstLevel + (uint32_t)(__umul24((uint32_t)(DRFE_EDGE - pr), (uint32_t)L.pyrPitch) + (uint32_t)x4)) = out;
+            if (pr >= L.h - 1 - DRFE_EDGE && pr <= L.h - 2)              /* ... into the bottom border: 19 + 2 (h - 1) - p */
+                *reinterpret_cast<uint32_t*>(dstLevel + (uint32_t)(__umul24((uint32_t)(DRFE_EDGE + 2 * (L.h - 1) - pr), (uint32_t)L.pyrPitch) + (uint32_t)x4)) = out;
+        }
         prevB = b;
 #pragma unroll
         for (int k = 0; k < 4; k++) Hp[k] = Hb[k];
