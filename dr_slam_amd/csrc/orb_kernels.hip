@@ -1100,20 +1100,22 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
     const uint32_t col = (uint32_t)(x0 + cg * 4 + 16);
     const uint32_t pitch = (uint32_t)L.pyrPitch;
     const int lastRow = L.h + 2 * DRFE_EDGE - 1;
-    /* byte k of (w0,w1,w2) is interior column x-3+k.  Pixel x+j needs bytes j..j+6: the dword starting at byte j
-     * (v_alignbyte) against taps (18,34,49,55) and the dword starting at byte j+4 against (49,34,18,0), two
-     * v_dot4_u32_u8 per pixel; 257 * 255 = 65535 still fits 16 bits */
-    const uint32_t tA = 18u | (34u << 8) | (49u << 16) | (55u << 24), tB = 49u | (34u << 8) | (18u << 16);
+    /* byte k of (w0,w1,w2) is interior column x-3+k and pixel x+j needs bytes j..j+6 under the taps (18,34,49,55,49,34,18).  The
+     * TAPS are shifted to where the bytes lie instead of the bytes to the taps: every product is a v_dot4_u32_u8 of an aligned
+     * dword with a constant - 2 + 2 + 3 + 3 of them for the four pixels, no v_alignbyte (8 + 6 instructions before);
+     * 257 * 255 = 65535 still fits 16 bits */
+#define TAP4(a, b, c, d) ((uint32_t)(a) | ((uint32_t)(b) << 8) | ((uint32_t)(c) << 16) | ((uint32_t)(d) << 24))
     auto hsum4 = [&](uint32_t off, uint32_t (&h)[4]) {
         const uint32_t* row = reinterpret_cast<const uint32_t*>(img + off);
         const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
-        const uint32_t a1 = __builtin_amdgcn_alignbyte(w1, w0, 1), a2 = __builtin_amdgcn_alignbyte(w1, w0, 2), a3 = __builtin_amdgcn_alignbyte(w1, w0, 3);
-        const uint32_t b1 = __builtin_amdgcn_alignbyte(w2, w1, 1), b2 = __builtin_amdgcn_alignbyte(w2, w1, 2), b3 = __builtin_amdgcn_alignbyte(w2, w1, 3);
-        h[0] = __builtin_amdgcn_udot4(w0, tA, __builtin_amdgcn_udot4(w1, tB, 0u, false), false);
-        h[1] = __builtin_amdgcn_udot4(a1, tA, __builtin_amdgcn_udot4(b1, tB, 0u, false), false);
-        h[2] = __builtin_amdgcn_udot4(a2, tA, __builtin_amdgcn_udot4(b2, tB, 0u, false), false);
-        h[3] = __builtin_amdgcn_udot4(a3, tA, __builtin_amdgcn_udot4(b3, tB, 0u, false), false);
+        h[0] = __builtin_amdgcn_udot4(w0, TAP4(18, 34, 49, 55), __builtin_amdgcn_udot4(w1, TAP4(49, 34, 18, 0), 0u, false), false);
+        h[1] = __builtin_amdgcn_udot4(w0, TAP4(0, 18, 34, 49), __builtin_amdgcn_udot4(w1, TAP4(55, 49, 34, 18), 0u, false), false);
+        h[2] = __builtin_amdgcn_udot4(w0, TAP4(0, 0, 18, 34), __builtin_amdgcn_udot4(w1, TAP4(49, 55, 49, 34),
+                                      __builtin_amdgcn_udot4(w2, TAP4(18, 0, 0, 0), 0u, false), false), false);
+        h[3] = __builtin_amdgcn_udot4(w0, TAP4(0, 0, 0, 18), __builtin_amdgcn_udot4(w1, TAP4(34, 49, 55, 49),
+                                      __builtin_amdgcn_udot4(w2, TAP4(34, 18, 0, 0), 0u, false), false), false);
     };
+#undef TAP4
     /* low halves of two registers as one dword (the sums fit 16 bits): one v_perm_b32 */
     auto pack16 = [](uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); };
     /* source rows y0-3 .. min(y0 + TH, h) + 2 are all the stored output rows read: a tile that overhangs the level's last row
