@@ -258,14 +258,17 @@ __global__ __launch_bounds__(256) void k_pyr_resize_lds(const DevLevel L, const 
             for (int k = 0; k < 4; k++) Hb[k] = Ha[k];
         } else hrow(b, Hb);
         const uint32_t b0s = wy2 << 16, b1s = wy2 & 0xFFFF0000u;
-        uint32_t out = 0;
+        /* no saturation needed: H <= (255 * 2049) >> 4 = 32655 and b0 + b1 <= 2049 (two independently rounded 11-bit
+         * weights), so the two floored products sum to at most 1020 and (1020 + 2) >> 2 = 255.  The four 10-bit sums are
+         * shifted two at a time (v_pk_lshrrev_b16 on 16-bit halves) and their low bytes gathered by one v_perm_b32 */
+        uint32_t sm[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            /* no saturation needed: H <= (255 * 2049) >> 4 = 32655 and b0 + b1 <= 2049 (two independently rounded 11-bit
-             * weights), so the two floored products sum to at most 1020 and (1020 + 2) >> 2 = 255 */
-            const uint32_t v = (__umulhi(Ha[k], b0s) + __umulhi(Hb[k], b1s) + 2u) >> 2;
-            out |= v << (8 * k);
-        }
+        for (int k = 0; k < 4; k++) sm[k] = __umulhi(Ha[k], b0s) + __umulhi(Hb[k], b1s) + 2u;
+        typedef unsigned short u16x2r __attribute__((ext_vector_type(2)));
+        const u16x2r two = {2, 2};
+        const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2r, sm[0] | (sm[1] << 16)) >> two);
+        const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2r, sm[2] | (sm[3] << 16)) >> two);
+        const uint32_t out = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
         if (active) {
             *reinterpret_cast<uint32_t*>(dstLevel + (uint32_t)(__umul24((uint32_t)(y0 + r), (uint32_t)L.pyrPitch) + (uint32_t)x4)) = out;
             if (pr >= 1 && pr <= DRFE_EDGE)                              /* mirrors into the top border: bordered row 19 - p */
