@@ -462,7 +462,7 @@ def main():
                          "stream its context owns, so that the latency-bound kernels of one batch (quadtree, claim resolution, "
                          "the small glue kernels: 40 %% VALU-busy or less) run beside the VALU-bound ones of the others.  Measured "
                          "(fresh processes, 120 steps): 1 x 512: 203 k frames/s, 2 x 512: 222 k, 3 x 512: 227-231 k, 4 x 512: 218-223 k "
-                         "(more contexts than hardware queues).  1 = a single context on torch's current stream")
+                         "(more contexts than hardware queues).  The contexts are a drfe_pipeline object of the C-ABI")
     ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4, 5),
                     help="BASELINE.json config: 2 = TUM3 single sequence, 4 = TUM1/2/3 mix, one 256-frame sequence "
                          "per rank; 5 = 1280x960 RealSense-style stream (roofline report at 4x the pixels); 0 = config 2 at one "
@@ -521,16 +521,16 @@ def main():
     B = args.batch or (128 if config == 5 else 512)
     gray, depth, Tcw, Twc = make_batch(base, B)
     nfl = max(1, args.inflight)
-    fes = [FrontEnd(cam, max_batch=B, device=local_rank) for _ in range(nfl)]
+    # Batches in flight are a library object (include/drfe.h drfe_pipeline_*): nfl contexts used round robin, each on the stream
+    # it owns - those sit on different hardware queues.  (Streams handed out by torch's pool did not, in a fresh process: the
+    # batches then queue behind each other and nothing overlaps - tools/two_stream_probe4.py, 207 k against 227 k frames/s.)
+    from dr_slam_amd import lib as drfe_lib
+    pipe = drfe_lib.Pipeline(nfl, 1000, 1.2, 8, 20, 7, cam.w, cam.h, B, local_rank)
+    fes = [FrontEnd(cam, max_batch=B, device=local_rank, ctx=c) for c in pipe.contexts]
     fe = fes[0]
     gray_t = torch.from_numpy(gray).to(dev)
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
-    # own (non-default) streams when batches overlap: work on the null stream does not run beside other streams
-    # Batches in flight run on the streams their contexts OWN (drfe_create makes one per context; 0 = "the context's stream"):
-    # those land on different hardware queues.  Streams handed out by torch's pool did not, in a fresh process - the two
-    # batches then queue behind each other and nothing overlaps (tools/two_stream_probe4.py: 207 k against 227 k frames/s).
-    streams = [torch.cuda.current_stream().cuda_stream] if nfl == 1 else [0] * nfl
-    stream = streams[0]
+    torch.cuda.synchronize()                           # the inputs are in HBM before any context's stream reads them
 
     if world > 1 or args.bow:
         # the one initial exchange of the sharded mode: rank 0 owns the ORB vocabulary
@@ -550,16 +550,14 @@ def main():
         for f in (fes if args.bow else fes[:1]):
             voc.upload(f.ctx)
 
-    nstep = [0]
-
     def step(k=None):
-        """One batch through the hot path on context / stream k (default: round robin over the batches in flight)."""
+        """One batch through the hot path: on the pipeline's next context (default) or on context k's own stream."""
         if k is None:
-            k = nstep[0] % nfl
-            nstep[0] += 1
-        fes[k].process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=streams[k])
+            k = pipe.submit(gray_t.data_ptr(), depth_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, Tcw, Twc, fe.cam, 15.0, False, True, B)
+        else:
+            fes[k].process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=0)
         if args.bow:   # Frame::ComputeBoW tree descent for every frame of the batch (not part of the metric)
-            fes[k].ctx.bow_transform_batch(4, B, streams[k])
+            fes[k].ctx.bow_transform_batch(4, B, 0)
 
     for _ in range(args.warmup):
         step()
@@ -655,8 +653,6 @@ def main():
         }
         out["parity"] = "bit-exact vs the in-repo CPU oracle; the oracle restates OpenCV 3.4 / Eigen 3.3.7 / PCL 1.9 and is UNPINNED " \
                         "against the real libraries (none can be built here)"
-        for f in fes[1:]:
-            f.ctx.close()
         if config == 5:
             out["algorithmic_bytes_per_frame"] = {k: int(v) for k, v in algo_bytes.items()}
             if not args.no_extras:
@@ -680,7 +676,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported by the N=1 run only
             out["cpu_baseline"] = cpu_baseline(base, cam, frames=70 if config == 5 else 220, only_orb=config == 5)
         if world == 1 and not args.no_extras and config != 5:
-            fe.ctx.close()
+            pipe.close()
             del gray_t, depth_t
             out["full_frontend"] = full_frontend("ICL")
     if world > 1:

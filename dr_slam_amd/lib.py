@@ -38,7 +38,8 @@ SYMBOLS = (
     "drfe_lsd_search_by_projection_map", "drfe_plane_voxel_grid", "drfe_plane_refit", "drfe_planes_ahc_postprocess",
     "drfe_planes_cape_postprocess", "drfe_surface_normals", "drfe_surface_normals_batch", "drfe_surface_normals_download", "drfe_batch_download_async", "drfe_orb_fast_partition", "drfe_lsd_segments_host", "drfe_orb_keypoint_pixels_async", "drfe_gather_keypoint_depth",
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
-    "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect",
+    "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
+    "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -112,6 +113,16 @@ def load() -> C.CDLL:
     L.drfe_orb_max_keypoints.argtypes = [vp]
     L.drfe_orb_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_extract_batch.argtypes = [vp, vp, sz, sz, i32, i32, i32, vp]
+    L.drfe_pipeline_create.argtypes = [C.POINTER(Config), i32, C.POINTER(vp)]
+    L.drfe_pipeline_destroy.argtypes = [vp]
+    L.drfe_pipeline_destroy.restype = None
+    L.drfe_pipeline_depth.argtypes = [vp]
+    L.drfe_pipeline_context.argtypes = [vp, i32]
+    L.drfe_pipeline_context.restype = vp
+    L.drfe_pipeline_last_error.argtypes = [vp]
+    L.drfe_pipeline_last_error.restype = C.c_char_p
+    L.drfe_pipeline_submit.argtypes = [vp, vp, vp, sz, sz, i32, i32, vp, vp, C.POINTER(Camera), C.c_float, i32, i32, i32]
+    L.drfe_pipeline_sync.argtypes = [vp, i32]
     L.drfe_frame_submit.argtypes = [vp, i32, vp, i32, i32, sz, vp, sz, C.POINTER(Camera)]
     L.drfe_frame_collect.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_download.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
@@ -282,6 +293,52 @@ def lines_is_good(lines, depth_f32, K9, cx, cy, invfx, invfy, k_as_f64=False, se
     return dl[:n], l3[:n], ni[:n], good.value
 
 
+class Pipeline:
+    """drfe_pipeline: `depth` contexts used round robin, each on its own stream (batches in flight)."""
+
+    def __init__(self, depth, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, max_width=640, max_height=480,
+                 max_batch=1, device=0):
+        self.L = load()
+        self.cfg = Config(device, max_width, max_height, max_batch, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast)
+        h = C.c_void_p()
+        rc = self.L.drfe_pipeline_create(C.byref(self.cfg), depth, C.byref(h))
+        if rc != 0:
+            raise DrfeError(f"drfe_pipeline_create failed ({rc}): {self.L.drfe_last_error(None).decode()}")
+        self.h = h
+        self.depth = self.L.drfe_pipeline_depth(self.h)
+        self.contexts = [Context.view(self.L.drfe_pipeline_context(self.h, k), nlevels, max_batch) for k in range(self.depth)]
+
+    def submit(self, d_gray: int, d_depth: int, frame_stride: int, row_stride: int, w: int, h: int, Tcw, Twc, cam, th=15.0, mono=False,
+               check_ori=True, nframes=1) -> int:
+        """-> index of the context that holds this batch's results"""
+        t1 = np.ascontiguousarray(Tcw, np.float32) if Tcw is not None else None
+        t2 = np.ascontiguousarray(Twc, np.float32) if Twc is not None else None
+        k = self.L.drfe_pipeline_submit(self.h, C.c_void_p(d_gray), C.c_void_p(d_depth) if d_depth else None, frame_stride, row_stride, w, h,
+                                        _p(t1) if t1 is not None else None, _p(t2) if t2 is not None else None,
+                                        C.byref(cam) if cam is not None else None, th, int(mono), int(check_ori), nframes)
+        if k < 0:
+            raise DrfeError(f"drfe_pipeline_submit failed ({k}): {self.L.drfe_pipeline_last_error(self.h).decode()}")
+        return k
+
+    def sync(self, k=-1):
+        rc = self.L.drfe_pipeline_sync(self.h, k)
+        if rc != 0:
+            raise DrfeError(f"drfe_pipeline_sync failed ({rc}): {self.L.drfe_pipeline_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.contexts:
+                c.close()
+            self.L.drfe_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """Owns one drfe_ctx (one HIP device, one batch arena)."""
 
@@ -299,9 +356,22 @@ class Context:
         self.max_kp = self.L.drfe_orb_max_keypoints(self.h)
         self.max_batch = max_batch
 
+    @classmethod
+    def view(cls, handle, nlevels, max_batch):
+        """A Context over a drfe_ctx somebody else owns (a pipeline's): same methods, close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.h = C.c_void_p(handle)
+        self.owned = False
+        self.nlevels = nlevels
+        self.max_kp = self.L.drfe_orb_max_keypoints(self.h)
+        self.max_batch = max_batch
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.L.drfe_destroy(self.h)
+            if getattr(self, "owned", True):
+                self.L.drfe_destroy(self.h)
             self.h = None
 
     def __del__(self):

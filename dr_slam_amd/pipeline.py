@@ -84,8 +84,10 @@ class FrontEnd:
     """Batched extract + glue + match over device-resident frames of one sequence."""
 
     def __init__(self, cam, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, max_batch=8,
-                 device=0):
-        self.ctx = lib.Context(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, cam.w, cam.h, max_batch, device)
+                 device=0, ctx=None):
+        """ctx: an existing lib.Context to work on (one of a lib.Pipeline's) instead of a new one"""
+        self.ctx = ctx if ctx is not None else lib.Context(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, cam.w, cam.h,
+                                                           max_batch, device)
         self.cam = lib.make_camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.depth_factor, cam.w, cam.h)
         dist = tuple(getattr(cam, "dist", ()) or ())
         if dist and dist[0] != 0.0:

@@ -150,6 +150,29 @@ int drfe_frame_download_stereo(drfe_ctx* ctx, int slot, float* u_right, float* d
 int drfe_frame_download_grid(drfe_ctx* ctx, int slot, int32_t* offsets, int32_t* indices, int cap);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Batches in flight: `depth` contexts used round robin, each on the stream it owns (its own hardware queue), so that the
+ * latency-bound kernels of one batch (quadtree, claim resolution, glue) run beside the VALU-bound ones of the others:
+ * +10-13 % device rate at depth 3, the measured optimum (bench.py uses this object).
+ *   drfe_pipeline_submit   one batch through drfe_orb_extract_batch -> [d_depth != NULL: drfe_frame_stereo_grid_batch ->
+ *                          Tcw && Twc: drfe_match_consecutive_batch] on the next context; asynchronous; returns the index k
+ *                          (>= 0) of the context that holds the batch's results, or a negative DRFE_ERR_* code.  The caller
+ *                          must have consumed the previous results of that context (depth submissions earlier).
+ *                          frame_stride / row_stride count ELEMENTS of each image (bytes of d_gray, 16-bit words of d_depth).
+ *   drfe_pipeline_context  context k: result access (drfe_orb_download, drfe_match_download, drfe_batch_download_async, ...)
+ *                          and per-context setup (drfe_frame_set_distortion, drfe_voc_upload - once per context)
+ *   drfe_pipeline_sync     waits for context k's stream (k < 0: all of them) */
+typedef struct drfe_pipeline drfe_pipeline;
+int drfe_pipeline_create(const drfe_config* cfg, int depth, drfe_pipeline** out);
+void drfe_pipeline_destroy(drfe_pipeline* pipe);
+int drfe_pipeline_depth(const drfe_pipeline* pipe);
+drfe_ctx* drfe_pipeline_context(drfe_pipeline* pipe, int k);
+const char* drfe_pipeline_last_error(const drfe_pipeline* pipe);
+int drfe_pipeline_submit(drfe_pipeline* pipe, const uint8_t* d_gray, const uint16_t* d_depth, size_t frame_stride, size_t row_stride,
+                         int w, int h, const float* Tcw, const float* Twc, const drfe_camera* cam, float th, int mono, int check_ori,
+                         int nframes);
+int drfe_pipeline_sync(drfe_pipeline* pipe, int k);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* Per-frame pipelined flow: what Frame::Frame (src/Frame.cc:74-160) does for ONE frame, without waiting for it.
  * Tracking::GrabImageRGBD (src/Tracking.cc:191) builds one Frame at a time and matches it against the previous one:
  * frame k goes to slot k % max_batch, the slot of frame k-1 keeps LastFrame's keypoints, descriptors and grid on the

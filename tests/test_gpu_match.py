@@ -618,3 +618,59 @@ def test_per_frame_flow_survives_reconfiguration(oracle_mod):
     rs = synth.Camera(cam3.fx, cam3.fy, cam3.cx, cam3.cy, cam3.bf, 1000.0)
     c.frame_submit(0, f_big[0][0], f_big[0][1], mk(rs)); check(0, f_big[0], rs)
     c.close()
+
+
+def test_pipeline_batches_in_flight(oracle_mod):
+    """drfe_pipeline_*: three contexts used round robin, each on its own stream.  Five different batches are submitted back to
+    back (up to three in flight at once); every batch's keypoints, descriptors, stereo values and match arrays equal those of
+    a single context that processed the same batch alone, and the first batch equals the oracle."""
+    import torch
+    from dr_slam_amd import lib, synth
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = synth.TUM3
+    B = 4
+    batches = []
+    for i in range(5):
+        fr = list(synth.sequence(30 + i, B, cam=cam, kind=("room_boxes", "corridor", "living_room")[i % 3]))
+        Tcw, Twc = _poses(fr)
+        batches.append((fr, torch.from_numpy(np.stack([f[0] for f in fr])).cuda(),
+                        torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).cuda(), Tcw, Twc))
+    torch.cuda.synchronize()
+    # reference: one context, one batch at a time
+    ref = []
+    fe = FrontEnd(cam, max_batch=B)
+    for fr, g, d, Tcw, Twc in batches:
+        fe.process(g, d, Tcw, Twc, th=15.0, check_ori=True, stream=0)
+        ref.append([(fe.keypoints(s), fe.ctx.download_stereo(s), fe.matches(s) if s else None) for s in range(B)])
+    fe.ctx.close()
+    pipe = lib.Pipeline(3, max_width=cam.w, max_height=cam.h, max_batch=B)
+    assert pipe.depth == 3
+    views = [FrontEnd(cam, max_batch=B, ctx=c) for c in pipe.contexts]
+    pending = []
+
+    def check(i, k):
+        for s in range(B):
+            (rk, rd), (rur, rz), rm = ref[i][s]
+            kps, desc = views[k].keypoints(s)
+            assert np.array_equal(kps.view(np.uint8), rk.view(np.uint8)) and np.array_equal(desc, rd), (i, s)
+            ur, z = views[k].ctx.download_stereo(s)
+            assert np.array_equal(ur.view(np.uint32), rur.view(np.uint32)) and np.array_equal(z.view(np.uint32), rz.view(np.uint32))
+            if s:
+                m, n = views[k].matches(s)
+                assert n == rm[1] and np.array_equal(m, rm[0]) and n > 100, (i, s, n)
+
+    for i, (fr, g, d, Tcw, Twc) in enumerate(batches):
+        k = pipe.submit(g.data_ptr(), d.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, Tcw, Twc, views[0].cam, 15.0, False, True, B)
+        assert k == i % 3
+        pending.append((i, k))
+        if len(pending) == 3:                    # the oldest batch's context is the next one to be reused: consume it first
+            check(*pending.pop(0))
+    for it in pending:
+        check(*it)
+    pipe.sync()
+    # the first batch against the oracle itself
+    okps, odesc = oracle_mod.OrbOracle()(batches[0][0][0][0])
+    assert np.array_equal(ref[0][0][0][0].view(np.uint8), okps.view(np.uint8)) and np.array_equal(ref[0][0][0][1], odesc)
+    with pytest.raises(lib.DrfeError):
+        pipe.submit(0, 0, cam.w * cam.h, cam.w, cam.w, cam.h, None, None, None)       # NULL image
+    pipe.close()
