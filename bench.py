@@ -584,6 +584,19 @@ def main():
 
     out = None
     if rank == 0:
+        # for comparison with the per-stage times below: the same batch ONE at a time (a single context, nothing overlaps)
+        one_at_a_time = None
+        if nfl > 1 and world == 1:
+            n1 = max(20, min(args.steps, 400))
+            for _ in range(5):
+                step(0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                step(0)
+            torch.cuda.synchronize()
+            one_at_a_time = {"value": B * n1 / (time.perf_counter() - t1), "unit": "frames/s", "steps": n1,
+                             "note": "one context, one batch at a time: what the sum of the per-stage kernel times corresponds to"}
         # per-stage kernel time: same steps again with HIP events around every stage on the launch stream
         fe.ctx.profile_enable(True)
         acc = {}
@@ -651,6 +664,8 @@ def main():
                          "valu_issue_utilisation": valu, "valu_source": "SQ_INSTS_VALU x 4 / 1024 SIMDs against SQ_BUSY_CYCLES / 32 "
                                                                          "(profiles/r02_pmc_sq_pass1_b512.csv via tools/pmc_traffic.py)"},
         }
+        if one_at_a_time:
+            out["one_batch_at_a_time"] = one_at_a_time
         out["parity"] = "bit-exact vs the in-repo CPU oracle; the oracle restates OpenCV 3.4 / Eigen 3.3.7 / PCL 1.9 and is UNPINNED " \
                         "against the real libraries (none can be built here)"
         if config == 5:
