@@ -235,7 +235,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     CHIP(dalloc(&c->d_cand0, B * c->candSlotElemsMax));
     CHIP(dalloc(&c->d_cand1, B * c->candSlotElemsMax));
     CHIP(dalloc(&c->d_node, B * c->candSlotElemsMax));
-    CHIP(dalloc(&c->d_candCount, B * nl));
+    CHIP(dalloc(&c->d_candCount, B * DRFE_CC_SLOT));
     CHIP(dalloc(&c->d_sel, B * (size_t)c->maxKp));
     CHIP(dalloc(&c->d_selCount, B * nl));
     CHIP(dalloc(&c->d_kps, B * (size_t)c->maxKp));
@@ -539,7 +539,7 @@ int drfe_orb_candidates(drfe_ctx* c, int slot, int level, int32_t* xyr, int cap,
     if (rc != DRFE_OK) return rc;
     const DevLevel& L = c->geom.lv[level];
     int n = 0;
-    HIPCHK(c, hipMemcpy(&n, c->d_candCount + (size_t)slot * c->cfg.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&n, c->d_candCount + DRFE_CC_IDX(slot, level), sizeof(int), hipMemcpyDeviceToHost));
     *n_out = n;
     if (!xyr) return DRFE_OK;
     if (n > cap) return DRFE_ERR_CAPACITY;
@@ -623,7 +623,7 @@ struct SlotShift {
         const DevGeom& g = c->geom;
         c->d_pyr += s * g.pyrSlotBytes; c->d_blur += s * g.blurSlotBytes;
         c->d_cand0 += s * g.candSlotElems; c->d_cand1 += s * g.candSlotElems; c->d_node += s * g.candSlotElems;
-        c->d_candCount += s * g.nlevels; c->d_selCount += s * g.nlevels; c->d_sel += s * g.kpSlotElems;
+        c->d_candCount += s * DRFE_CC_SLOT; c->d_selCount += s * g.nlevels; c->d_sel += s * g.kpSlotElems;
         c->d_kps += s * K; if (c->d_kpsUn) c->d_kpsUn += s * K;
         c->d_desc += s * K * 32; c->d_kpCount += s;
         c->d_uRight += s * K; c->d_depth += s * K;

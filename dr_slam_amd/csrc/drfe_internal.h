@@ -69,6 +69,15 @@ struct DevGeom {
     DevLevel lv[DRFE_MAX_LEVELS];
 };
 
+/* FAST's per-(slot, level) candidate counters are bumped by one returning atomic per cell, and every wavefront waits for its
+ * answer: packed as [slot][level] ints, four slots share a 128-byte line and the kernel's time depended on where the 16 KB array
+ * happened to lie (0.59 / 0.66 / 0.69 / 0.71 ms from context to context, tools/fast_mode_probe2.py).  One counter per line. */
+#ifndef DRFE_CC_LINE
+#define DRFE_CC_LINE 32           /* ints between two counters */
+#endif
+#define DRFE_CC_SLOT (DRFE_MAX_LEVELS * DRFE_CC_LINE)
+#define DRFE_CC_IDX(slot, level) ((size_t)(slot) * DRFE_CC_SLOT + (size_t)(level) * DRFE_CC_LINE)
+
 struct FastCell {   /* one cv::FAST call of reference src/ORBextractor.cc:789-816 */
     uint16_t x0, y0;        /* window origin in interior coordinates */
     uint8_t ww, wh;         /* window size (<= 68) */
@@ -117,7 +126,7 @@ struct drfe_ctx {
     uint8_t* d_pyr; size_t pyrSlotBytesMax;
     uint8_t* d_blur; size_t blurSlotBytesMax;
     uint32_t* d_cand0; uint32_t* d_cand1; uint16_t* d_node; size_t candSlotElemsMax;
-    int* d_candCount;         /* [slot][level] */
+    int* d_candCount;         /* [slot][level], one counter per DRFE_CC_LINE ints: DRFE_CC_IDX */
     uint32_t* d_sel;          /* [slot][kpSlotElems] packed x|y<<12|resp<<24 */
     int* d_selCount;          /* [slot][level] */
     drfe_keypoint* d_kps;     /* [slot][maxKp] mvKeys */

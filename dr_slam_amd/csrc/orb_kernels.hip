@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
     const int total = __shfl(incl, 63);
     if (total == 0) return;
     int base = 0;
-    if (lane == 0) base = atomicAdd(&candCount[slot * nlevels + fc.level], total);
+    if (lane == 0) base = atomicAdd(&candCount[DRFE_CC_IDX(slot, fc.level)], total);
     base = __shfl(base, 0);
     if (base + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
     size_t pos = (size_t)slot * candSlotElems + fc.candOff + base + (incl - cnt);
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     for (int i = 0; i < RMAX; i++) { rowMask[i] = __ballot(dm[i] != 0); total += __popcll(rowMask[i]); }
     if (total == 0) return;
     int cbase = 0;
-    if (lane == 0) cbase = atomicAdd(&candCount[slot * nlevels + fc.level], total);
+    if (lane == 0) cbase = atomicAdd(&candCount[DRFE_CC_IDX(slot, fc.level)], total);
     cbase = __builtin_amdgcn_readfirstlane(cbase);
     if (cbase + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
     /* the cell's output run starts at a wave-uniform element (scalar base); a lane adds its 32-bit offset */
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(QT_THREADS, QT_THREADS == 256 ? 8 : 4) void k_quadt
     __shared__ QtShared<QT_THREADS, QT_MAXN> S;
     const int level = levelBase + blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
     const DevLevel& L = G->lv[level];
-    const int n = min(candCount[slot * G->nlevels + level], L.candCap);
+    const int n = min(candCount[DRFE_CC_IDX(slot, level)], L.candCap);
     const size_t coff = (size_t)slot * G->candSlotElems + L.candOff;
     const uint32_t* k0 = cand0 + coff;
     const uint32_t* k1 = cand1 + coff;
@@ -1431,7 +1431,7 @@ static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
 __global__ void k_clear_counts(int* __restrict__ candCount, int n, int* __restrict__ status)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) candCount[i] = 0;
+    if (i < n) candCount[(size_t)i * DRFE_CC_LINE] = 0;
     if (i == 0) status[0] = 0;
 }
 
@@ -1443,7 +1443,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     hipError_t e;
     /* a kernel, not two hipMemsetAsync: memset nodes of a captured graph (the single-frame entry replays one) did not run
      * on this ROCm, and one launch is cheaper than two anyway */
-    hipLaunchKernelGGL(k_clear_counts, dim3((nframes * nl + 255) / 256), dim3(256), 0, s, c->d_candCount, nframes * nl, c->d_status);
+    hipLaunchKernelGGL(k_clear_counts, dim3((nframes * DRFE_CC_SLOT / DRFE_CC_LINE + 255) / 256), dim3(256), 0, s, c->d_candCount, nframes * DRFE_CC_SLOT / DRFE_CC_LINE, c->d_status);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 
