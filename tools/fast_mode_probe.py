@@ -1,5 +1,6 @@
-"""The FAST stage's time depended on the context (0.59 / 0.66 / 0.69 / 0.71 ms for the same batch): contexts alive at once in ONE
-process, the FAST stage of each timed with HIP events."""
+"""Does a stage's time depend on the context, i.e. on where its arenas happen to lie?  (The FAST stage's did: 0.59 / 0.66 / 0.69 /
+0.71 ms for the same batch until its atomic counters got a cache line each.)  Six contexts alive at once in ONE process, every
+stage of each timed with HIP events."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
@@ -15,17 +16,22 @@ g = torch.from_numpy(gray).to(dev); d = torch.from_numpy(depth.view(np.int16)).t
 torch.cuda.synchronize()
 
 
-def fast_ms(fe):
+def stage_ms(fe):
     for _ in range(3):
         fe.process(g, d, Tcw, Twc, th=15.0, check_ori=True, stream=0)
     fe.ctx.profile_enable(True)
-    acc = []
+    acc = {}
     for _ in range(5):
         fe.process(g, d, Tcw, Twc, th=15.0, check_ori=True, stream=0)
-        acc.append(fe.ctx.profile_stage_ms()["fast"])
+        for k, v in fe.ctx.profile_stage_ms().items():
+            acc[k] = acc.get(k, 0.0) + v / 5
     fe.ctx.profile_enable(False)
-    return round(float(np.mean(acc)), 3)
+    return acc
 
 
 fes = [FrontEnd(cam, max_batch=B) for _ in range(6)]
-print("six contexts alive at once, FAST stage ms:", [fast_ms(f) for f in fes])
+stage_ms(fes[0])                                       # clocks up before the first measurement
+res = [stage_ms(f) for f in fes]
+print("six contexts alive at once, stage ms per context:")
+for k in res[0]:
+    print(f"  {k:10s}", [round(r[k], 3) for r in res])
