@@ -474,8 +474,11 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
  * point and sweep t has points 0..t right; real frames settle in a handful of sweeps because
  * displacement chains are short.  A point whose overall best candidate is free (the common case) never
  * touches its candidate list. */
-#define RS_THREADS 1024
-#define RS_MAX_T 4                                /* map points per thread: nQ <= 4096 */
+#define RS_THREADS 512
+#define RS_MAX_T 8                                /* map points per thread: nQ <= 4096.  512 threads: a workgroup of 1024 needs sixteen free wave slots on one CU
+                                                     at once, which it waits for while other batches' kernels fill the device (1.6 ms per launch with three
+                                                     batches in flight against 0.09 alone); 512 x 8 is faster alone too (match stage 0.229 -> 0.209 ms) and
+                                                     gave +3 % on the step, 256 x 16 the same step but 0.239 ms alone */
 __global__ __launch_bounds__(RS_THREADS) void k_resolve_last(const MatchPair* __restrict__ pairs,
                                                              const MatchQuery* __restrict__ queries,
                                                              const drfe_keypoint* __restrict__ kps,
