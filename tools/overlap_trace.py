@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Reads a rocprofv3 --kernel-trace CSV of a bench run with batches in flight and reports, per kernel, how much of its
 run time other streams' kernels were running beside it, and the distribution of the number of kernels in flight.
-    python tools/overlap_trace.py <kernel_trace.csv>"""
+    python tools/overlap_trace.py <kernel_trace.csv> [lo hi]
+lo, hi: the part of the trace to look at, as fractions of its kernel launches (default 0.05 0.45: bench.py's timed in-flight loop
+comes first, its single-context comparison and event-timed steps after it)."""
 import collections
 import csv
 import sys
@@ -14,8 +16,8 @@ for r in rows:
         n = n.split("<")[0]
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r.get("Queue_Id", r.get("Stream_Id", "0"))))
 ev.sort()
-# the middle half of the run: steady state, without the warm-up at the start and the bench's event-timed single-context steps at the end
-t0, t1 = ev[len(ev) // 4][0], ev[3 * len(ev) // 4][0]
+lo, hi = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (0.05, 0.45)
+t0, t1 = ev[int(lo * len(ev))][0], ev[int(hi * len(ev))][0]
 ev = [e for e in ev if t0 <= e[0] < t1]
 pts = []
 for s, e, n, q in ev:
