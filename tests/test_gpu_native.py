@@ -67,3 +67,42 @@ def test_cpp_adaptor_matches_ctypes(frames_room, tmp_path):
     assert raw[o:o + g.size] == planes["seg"].tobytes(); o += g.size
     row = np.frombuffer(raw[o:], np.uint8)
     assert np.array_equal(row, lvl1[19 + 7, 19:-19])                         # mvImagePyramid[1] is the interior ROI
+
+
+def test_cpp_pipeline_caller_matches_ctypes(frames_room, tmp_path):
+    """tests/native/pipeline_caller.cpp: the throughput path without Python - device buffers from the HIP runtime, five batches
+    through drfe_pipeline_submit on three contexts, results through drfe_batch_download_async.  The program itself checks that the
+    five batches come back identical; here its first batch is compared with the ctypes path on the same frames."""
+    import torch
+    from dr_slam_amd import synth
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = synth.TUM3
+    (g0, d0, _), (g1, d1, _) = frames_room[0], frames_room[1]
+    for name, a in (("g0", g0), ("d0", d0), ("g1", g1), ("d1", d1)):
+        (tmp_path / f"{name}.raw").write_bytes(a.tobytes())
+    out = _run("pipeline_caller", tmp_path / "g0.raw", tmp_path / "d0.raw", tmp_path / "g1.raw", tmp_path / "d1.raw", cam.w, cam.h,
+               tmp_path / "o.bin")
+    assert "pipeline_caller ok" in out
+    raw = (tmp_path / "o.bin").read_bytes()
+    cnt = np.frombuffer(raw[:16], np.int32)
+    mc = np.frombuffer(raw[16:32], np.int32)
+    fe = FrontEnd(cam, max_batch=4)
+    try:
+        gray = torch.from_numpy(np.stack([g0, g1, g0, g1])).cuda()
+        depth = torch.from_numpy(np.stack([d0, d1, d0, d1]).view(np.int16)).cuda()
+        T = np.tile(np.eye(4, dtype=np.float32), (4, 1, 1))
+        fe.process(gray, depth, T, T, th=15.0, check_ori=True, stream=0)
+        o = 32
+        for s in range(2):
+            kps, desc = fe.keypoints(s)
+            assert cnt[s] == len(kps) > 500
+            assert raw[o:o + 28 * len(kps)] == kps.tobytes()
+            o += 28 * len(kps)
+            assert raw[o:o + 32 * len(kps)] == desc.tobytes()
+            o += 32 * len(kps)
+        m, n = fe.matches(1)
+        assert n == mc[1] > 100
+        assert raw[o:o + 4 * cnt[1]] == m[:cnt[1]].astype(np.int32).tobytes()
+        assert cnt[2] == cnt[0] and cnt[3] == cnt[1]
+    finally:
+        fe.ctx.close()
