@@ -523,7 +523,7 @@ def main():
     nfl = max(1, args.inflight)
     # Batches in flight are a library object (include/drfe.h drfe_pipeline_*): nfl contexts used round robin, each on the stream
     # it owns - those sit on different hardware queues.  (Streams handed out by torch's pool did not, in a fresh process: the
-    # batches then queue behind each other and nothing overlaps - tools/two_stream_probe4.py, 207 k against 227 k frames/s.)
+    # batches then queue behind each other and nothing overlaps - tools/streams_in_flight_probe.py, 207 k against 227 k frames/s.)
     from dr_slam_amd import lib as drfe_lib
     pipe = drfe_lib.Pipeline(nfl, 1000, 1.2, 8, 20, 7, cam.w, cam.h, B, local_rank)
     fes = [FrontEnd(cam, max_batch=B, device=local_rank, ctx=c) for c in pipe.contexts]

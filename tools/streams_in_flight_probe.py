@@ -1,5 +1,5 @@
 """What makes two batches in flight fast (224 k) or not (206 k)?  Fresh process per variant.
-    python tools/two_stream_probe4.py [VARIANT]"""
+    python tools/streams_in_flight_probe.py [VARIANT]"""
 import os, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
