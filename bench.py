@@ -472,6 +472,9 @@ def main():
     ap.add_argument("--render-workers", type=int, default=0,
                     help="processes that render the synthetic sequence (0 = the CPUs this rank may use; forced to 1 under a "
                          "profiler, whose preloaded runtime must not be forked)")
+    ap.add_argument("--preload", type=int, default=400,
+                    help="single-context steps measured BEFORE the timed loop (reported as one_batch_at_a_time; they also carry the "
+                         "device through its clock transient under load); 0 under a profiler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-fed rate and the config-3 full front-end block")
     ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
@@ -559,6 +562,34 @@ def main():
         if args.bow:   # Frame::ComputeBoW tree descent for every frame of the batch (not part of the metric)
             fes[k].ctx.bow_transform_batch(4, B, 0)
 
+    # Before the timed loop, on every rank: the same batch ONE at a time (a single context, nothing overlaps; 400 steps) and the
+    # per-stage times by HIP events (10 steps).  Both are reported - and they put about a second of load on the device first: its
+    # clocks go through a transient in the first half second under load (one context: 203 k frames/s over 20 steps, 192 k over
+    # 200, 203-206 k over 1000), which a 20-step timed loop straight after start-up may or may not hit (200-236 k measured).
+    one_at_a_time = None
+    n1 = max(0, args.preload)
+    if n1:
+        for _ in range(5):
+            step(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            step(0)
+        torch.cuda.synchronize()
+        one_at_a_time = {"value": B * n1 / (time.perf_counter() - t1), "unit": "frames/s", "steps": n1,
+                         "note": "one context, one batch at a time (measured before the timed loop): what the sum of the per-stage "
+                                 "kernel times corresponds to"}
+    # per-stage kernel time: HIP events around every stage on the launch stream
+    fe.ctx.profile_enable(True)
+    acc = {}
+    reps = max(3, min(args.steps, 10))
+    for _ in range(reps):
+        step(0)                                     # one context, one stream: clean per-kernel times
+        ms = fe.ctx.profile_stage_ms()
+        for k, v in ms.items():
+            acc[k] = acc.get(k, 0.0) + v
+    fe.ctx.profile_enable(False)
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -584,29 +615,6 @@ def main():
 
     out = None
     if rank == 0:
-        # for comparison with the per-stage times below: the same batch ONE at a time (a single context, nothing overlaps)
-        one_at_a_time = None
-        if nfl > 1 and world == 1:
-            n1 = max(20, min(args.steps, 400))
-            for _ in range(5):
-                step(0)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(n1):
-                step(0)
-            torch.cuda.synchronize()
-            one_at_a_time = {"value": B * n1 / (time.perf_counter() - t1), "unit": "frames/s", "steps": n1,
-                             "note": "one context, one batch at a time: what the sum of the per-stage kernel times corresponds to"}
-        # per-stage kernel time: same steps again with HIP events around every stage on the launch stream
-        fe.ctx.profile_enable(True)
-        acc = {}
-        reps = max(3, min(args.steps, 10))
-        for _ in range(reps):
-            step(0)                                     # one context, one stream: clean per-kernel times
-            ms = fe.ctx.profile_stage_ms()
-            for k, v in ms.items():
-                acc[k] = acc.get(k, 0.0) + v
-        fe.ctx.profile_enable(False)
         stage_ms = {k: v / reps for k, v in acc.items()}
         # FAST runs as two launches (k_fast_cells_cols<8> over the cells of <= 8 rows per lane, <12> over the rest): each has its
         # own event pair and its share of the FAST read (every pixel of the detection region belongs to exactly one cell)

@@ -11,7 +11,7 @@ rm -rf ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_stats ${GRAFT_REPO_ROOT:
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --batch $B --inflight 1 --distinct 8 --render-workers 1 --no-cpu-baseline --no-extras $EXTRA"
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --batch $B --inflight 1 --distinct 8 --render-workers 1 --preload 0 --no-cpu-baseline --no-extras $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- $CMD > $OUT/${TAG}_stats.log 2>&1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
             "sq1 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
