@@ -352,7 +352,11 @@ __device__ void window_query_wave(const MatchQuery& q, size_t qo, int lane, int 
  * in visit order, then lane = candidate, 16 at a time; compaction positions come from the query's 16-bit slice of the
  * ballot, the minimum from a DPP row reduction.  Output is identical to the whole-wave routine, which still handles the
  * queries whose window is wider than 16 columns or longer than WQ_TAB records. */
-__global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __restrict__ pairs,
+#ifndef WQ_THREADS
+#define WQ_THREADS 64                 /* wavefronts of this kernel are independent of each other: one per workgroup */
+#endif
+#define WQ_PER_BLOCK (WQ_THREADS / WAVE * 4)
+__global__ __launch_bounds__(WQ_THREADS) void k_window_candidates(const MatchPair* __restrict__ pairs,
                                                            const MatchQuery* __restrict__ queries,
                                                            const int* __restrict__ kpCount, int maxKp,
                                                            const int* __restrict__ gridOff,
@@ -364,13 +368,13 @@ __global__ __launch_bounds__(256) void k_window_candidates(const MatchPair* __re
                                                            int* __restrict__ candCnt, uint2* __restrict__ candBest,
                                                            int* __restrict__ status, uint32_t gxMagic)
 {
-    __shared__ int sTab[256 / WAVE][4][WQ_TAB];
+    __shared__ int sTab[WQ_THREADS / WAVE][4][WQ_TAB];
     int bx, by;
     drfe_xcd_swizzle_2d(gxMagic, bx, by);        /* a frame pair's queries on one XCD: they gather the same cell-sorted records */
     const MatchPair P = pairs[by];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   /* wave-uniform for the compiler */
     const int g = lane >> 4, l = lane & 15;
-    const int qbase = (bx * (256 / WAVE) + wv) * 4;
+    const int qbase = (bx * (WQ_THREADS / WAVE) + wv) * 4;
     const int nQ = P.mpSlot >= 0 ? kpCount[P.lastSlot] : P.nQueries;
     if (qbase >= nQ) return;                     /* wave-uniform */
     const int cur = P.curSlot;
@@ -789,10 +793,10 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
-    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 15) / 16, npairs), dim3(256), 0, s, mb.d_pairs,
+    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + WQ_PER_BLOCK - 1) / WQ_PER_BLOCK, npairs), dim3(WQ_THREADS), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
                        mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status + 1,
-                       drfe_div_magic((uint32_t)((maxQueries + 15) / 16)));
+                       drfe_div_magic((uint32_t)((maxQueries + WQ_PER_BLOCK - 1) / WQ_PER_BLOCK)));
     const size_t lds = (size_t)c->maxKp;
     if (mode == 0)
         hipLaunchKernelGGL(k_resolve_last, dim3(npairs), dim3(RS_THREADS), (size_t)c->maxKp * 5 + 16, s, mb.d_pairs,
@@ -813,10 +817,10 @@ hipError_t drfe_launch_window_candidates(drfe_ctx* c, const MatchBuffers& mb, co
     const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
     const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
     (void)hipMemsetAsync(c->d_status + 1, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + 15) / 16, npairs), dim3(256), 0, s, mb.d_pairs,
+    hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + WQ_PER_BLOCK - 1) / WQ_PER_BLOCK, npairs), dim3(WQ_THREADS), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
                        mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status + 1,
-                       drfe_div_magic((uint32_t)((maxQueries + 15) / 16)));
+                       drfe_div_magic((uint32_t)((maxQueries + WQ_PER_BLOCK - 1) / WQ_PER_BLOCK)));
     return hipGetLastError();
 }
 
