@@ -1195,7 +1195,11 @@ __global__ __launch_bounds__(256) void k_blur(const DevGeom* __restrict__ G, con
  * wavefront carries DESC_KPW keypoints through the phases together: every global load of the wave is issued up front,
  * and the lane-constant tables (disc offsets, pattern) are loaded once per wavefront.  The raw patch and the blurred
  * patch share the LDS region (LDS operations of one wave execute in order). */
-__global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
+#ifndef DESC_THREADS
+#define DESC_THREADS 64               /* the wavefronts of this kernel never synchronise with each other: one per workgroup */
+#endif
+#define DESC_WAVES (DESC_THREADS / WAVE)
+__global__ __launch_bounds__(DESC_THREADS) void k_orient_desc(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel,
                                                      const int* __restrict__ selCount,
@@ -1204,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
                                                      drfe_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                      int* __restrict__ kpCount, int maxKp, uint32_t gxMagic)
 {
-    __shared__ uint32_t sPatch[256 / WAVE][DESC_KPW][DESC_LDS_DW];
+    __shared__ uint32_t sPatch[DESC_WAVES][DESC_KPW][DESC_LDS_DW];
     int bx, by;
     drfe_xcd_swizzle_2d(gxMagic, bx, by);        /* a frame's keypoints on one XCD: overlapping patches share its L2 */
     const int slot = by;
@@ -1212,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const DevGeom* __restrict__
     /* first output index of this wave; readfirstlane makes it (and every level / pointer derived from it) wave-uniform
      * for the compiler: scalar ALU and SGPR base addresses instead of 64-bit vector address arithmetic per gather */
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int g0 = (bx * (256 / WAVE) + wv) * DESC_KPW;
+    const int g0 = (bx * DESC_WAVES + wv) * DESC_KPW;
     const int nl = G->nlevels;
     /* level of every output index: prefix sums of the per-level counts (level-major concatenation, :1103), kept
      * across lanes (lane l = level l) so that the lookup per keypoint is a compare, a ballot and a readlane instead of a
@@ -1532,9 +1536,9 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     prof_end(c, DRFE_STAGE_BLUR, s);
 
     prof_begin(c, DRFE_STAGE_DESC, s);
-    hipLaunchKernelGGL(k_orient_desc, dim3((c->maxKp + 4 * DESC_KPW - 1) / (4 * DESC_KPW), nframes), dim3(256), 0, s, c->d_geom, c->d_pyr,
+    hipLaunchKernelGGL(k_orient_desc, dim3((c->maxKp + DESC_WAVES * DESC_KPW - 1) / (DESC_WAVES * DESC_KPW), nframes), dim3(DESC_THREADS), 0, s, c->d_geom, c->d_pyr,
                        c->d_blur, c->d_sel, c->d_selCount, c->d_pattern, c->d_disc, c->discCount, c->d_kps,
-                       c->d_desc, c->d_kpCount, c->maxKp, drfe_div_magic((uint32_t)((c->maxKp + 4 * DESC_KPW - 1) / (4 * DESC_KPW))));
+                       c->d_desc, c->d_kpCount, c->maxKp, drfe_div_magic((uint32_t)((c->maxKp + DESC_WAVES * DESC_KPW - 1) / (DESC_WAVES * DESC_KPW))));
     prof_end(c, DRFE_STAGE_DESC, s);
     return hipGetLastError();
 }
