@@ -153,6 +153,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->planeLanes = nullptr;
     c->bow = nullptr;
     c->ls = nullptr;
+    c->lsBatch = nullptr;
+    c->lsdDeviceGrow = 1;
     c->lineWorkers = nullptr;
     c->frameLanes = nullptr;
     c->lineHost = nullptr;

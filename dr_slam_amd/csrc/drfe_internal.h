@@ -164,6 +164,8 @@ struct drfe_ctx {
     void* cape;               /* CapeScratch*: device buffers of drfe_planes_cape (planes_internal.h) */
     void* sn;                 /* SnBuffers*: surface-normal scratch (post_internal.h) */
     void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */
+    struct LinesScratch* lsBatch; /* frame slots of drfe_lsd_extract_batch's device region growing (lines_lsd.cpp) */
+    int lsdDeviceGrow;        /* drfe_lsd_configure: 1 = the batch entry grows regions on the device (default) */
     void* frameLanes;         /* std::vector<FrameLane>*: per-slot staging of drfe_frame_submit / drfe_frame_collect (capi.cpp) */
 
     /* profiling */

@@ -5,16 +5,23 @@
 
 struct LineTaps { int n; int t[9]; };   /* 8.8 fixed-point Gaussian taps */
 
+/* device arrays of `frames` consecutive frame slots (dense: slot f of an array starts at f x the per-frame element count) */
 struct LinesScratch {
     int w, h, sw, sh;               /* input and 0.8-scaled sizes */
+    int frames;                     /* frame slots (1 for the single-frame entry) */
     uint8_t* d_img; uint8_t* d_blur; uint8_t* d_scaled;
     uint16_t* d_tmp16;
     double* d_modgrad; double* d_angles;
     float2* d_cs;                   /* (cos, sin) of float(angle) per scaled pixel, 0 where the angle is undefined */
-    unsigned long long* d_maxGrad;
+    unsigned long long* d_meta;     /* per slot two words: [0] bits of the largest gradient magnitude, [1] smallest gradient bin of a pixel with an angle */
     int16_t* d_gx; int16_t* d_gy;
-    struct RectCand* d_cands; int2* d_counts; size_t candCap;   /* grow-only scratch of the NFA rounds */
+    struct RectCand* d_cands; int2* d_counts; size_t candCap;   /* grow-only scratch of the NFA rounds (one lane's) */
     struct LbdLine* d_lbdLines; uint8_t* d_lbdOut; size_t lbdCap;
+    /* device region growing (batch entry): per slot the ordering keys / sorted ordering, member list, shrink scratch,
+     * accepted rectangles, (count, status); the launch's frame table; pinned host mirrors */
+    uint32_t* d_order; uint32_t* d_reg; uint32_t* d_tmp; struct LsdRect* d_rects; int* d_out; struct LsdGrowFrame* d_frames;
+    uint32_t* h_order; unsigned long long* h_meta; struct LsdRect* h_rects; int* h_out; struct LsdGrowFrame* h_frames;
+    int rectCap;
 };
 
 /* one rectangle whose aligned pixels are to be counted: the fields cv::LineSegmentDetectorImpl::rect_nfa reads */
@@ -33,7 +40,29 @@ struct LbdTables { float coefG[63], coefL[21]; };      /* the Gaussian band weig
 hipError_t drfe_launch_lbd(const LbdLine* d_lines, int n, const int16_t* d_gx, const int16_t* d_gy, int w, int h,
                            const LbdTables& tab, uint8_t* d_out, hipStream_t s);
 
+/* ---- device region growing (lsd_grow_kernels.hip) ---- */
+/* a rectangle as cv::LineSegmentDetectorImpl::rect carries it (what region2rect fills; prec, p of the detection) */
+struct LsdRect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+#define DRFE_LSD_STATUS_UNCERTAIN 1     /* a cos / sin whose correct rounding could not be certified (cr_sincos.h) */
+#define DRFE_LSD_STATUS_OVERFLOW 2      /* more accepted regions than rectCap */
+#define DRFE_LSD_OUT_INTS 40             /* ints per frame in LsdGrowFrame::out: count, status, pad, pad, then 16 x u64 phase counters of LSD_PROFILE builds */
+/* one frame of a k_lsd_grow launch: its level-line fields, the sorted pseudo-ordering, scratch and outputs */
+struct LsdGrowFrame {
+    const double* ang; const float2* cs; const double* mod;   /* W x H fields of k_ll_angle */
+    const uint32_t* order;                                    /* keys bin << 22 | y << 11 | x in std::sort's order */
+    uint32_t* reg; uint32_t* tmp;                             /* W x H entries each: member list (y << 16 | x), shrink scratch */
+    LsdRect* rects; int* out;                                 /* accepted rectangles in seed order; out[0] = count, out[1] = status (DRFE_LSD_OUT_INTS ints per frame) */
+    int nOrder; uint32_t minSeedBin;
+};
+size_t drfe_lsd_grow_lds_bytes(int W, int H);
+/* keys of nframes consecutive slots: d_mod / d_ang / d_meta / d_keys point at the first of them */
+hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
+                                int nframes, hipStream_t s);
+hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W, int H, double prec, double p, int minReg,
+                                double densityTh, int rectCap, hipStream_t s);
+
+/* the image passes for slots frame0 .. frame0 + nframes - 1 of sc (d_img = slot frame0's input image, frames w x h apart) */
 hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,
-                                    LinesScratch* sc, double threshold, hipStream_t s);
+                                    LinesScratch* sc, int frame0, int nframes, double threshold, hipStream_t s);
 void drfe_lines_free(drfe_ctx* c);
 #endif

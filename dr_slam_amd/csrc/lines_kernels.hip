@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void k_gauss_h(const uint8_t* __restrict__ src
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    src += (size_t)blockIdx.z * w * h; dst += (size_t)blockIdx.z * w * h;      /* frame */
     const uint8_t* row = src + (size_t)y * w;
     uint32_t acc = 0;
     const int r = taps.n / 2;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void k_gauss_v(const uint16_t* __restrict__ sr
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    src += (size_t)blockIdx.z * w * h; dst += (size_t)blockIdx.z * w * h;      /* frame */
     uint32_t acc = 0;
     const int r = taps.n / 2;
     for (int k = 0; k < taps.n; k++) acc += (uint32_t)taps.t[k] * src[(size_t)refl(y + k - r, h) * w + x];
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(256) void k_resize_exact08(const uint8_t* __restric
 {
     const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
     if (dx >= dw) return;
+    src += (size_t)blockIdx.z * sw * sh; dst += (size_t)blockIdx.z * dw * dh;  /* frame */
     int xo, xc1, yo, yc1;
     exact_tap(dx, sw, &xo, &xc1);
     exact_tap(dy, sh, &yo, &yc1);
@@ -78,6 +81,10 @@ __global__ __launch_bounds__(256) void k_ll_angle(const uint8_t* __restrict__ im
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
+    {   /* frame */
+        const size_t fo = (size_t)blockIdx.z * W * H;
+        img += fo; modgrad += fo; angles += fo; cs += fo; maxGradBits += 2 * (size_t)blockIdx.z;
+    }
     const size_t o = (size_t)y * W + x;
     cs[o] = make_float2(0.f, 0.f);
     if (x == W - 1 || y == H - 1) { angles[o] = -1024.0; modgrad[o] = 0.0; return; }   /* NOTDEF border */
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src,
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    src += (size_t)blockIdx.z * w * h; gx += (size_t)blockIdx.z * w * h; gy += (size_t)blockIdx.z * w * h;   /* frame */
     const int xm = refl(x - 1, w), xp = refl(x + 1, w);
     const uint8_t* r0 = src + (size_t)refl(y - 1, h) * w;
     const uint8_t* r1 = src + (size_t)y * w;
@@ -296,20 +304,24 @@ hipError_t drfe_launch_lbd(const LbdLine* d_lines, int n, const int16_t* d_gx, c
 }
 
 hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,
-                                    LinesScratch* sc, double threshold, hipStream_t s)
+                                    LinesScratch* sc, int frame0, int nframes, double threshold, hipStream_t s)
 {
-    const dim3 g((w + 255) / 256, h), b(256);
+    if (nframes <= 0) return hipSuccess;
+    const dim3 g((w + 255) / 256, h, nframes), b(256);
     const int W = sc->sw, H = sc->sh;
+    const size_t n = (size_t)w * h * frame0, ns = (size_t)W * H * frame0;
+    uint16_t* tmp16 = sc->d_tmp16 + n;
+    uint8_t* blur = sc->d_blur + n;
     /* LSD input: Gaussian(7x7, sigma 0.75) then exact 0.8 downscale */
-    hipLaunchKernelGGL(k_gauss_h, g, b, 0, s, d_img, w, h, lsdTaps, sc->d_tmp16);
-    hipLaunchKernelGGL(k_gauss_v, g, b, 0, s, sc->d_tmp16, w, h, lsdTaps, sc->d_blur);
-    hipLaunchKernelGGL(k_resize_exact08, dim3((W + 255) / 256, H), b, 0, s, sc->d_blur, w, h, sc->d_scaled, W, H);
-    (void)hipMemsetAsync(sc->d_maxGrad, 0, 8, s);
-    hipLaunchKernelGGL(k_ll_angle, dim3((W + 255) / 256, H), b, 0, s, sc->d_scaled, W, H, threshold, sc->d_modgrad,
-                       sc->d_angles, sc->d_cs, sc->d_maxGrad);
+    hipLaunchKernelGGL(k_gauss_h, g, b, 0, s, d_img, w, h, lsdTaps, tmp16);
+    hipLaunchKernelGGL(k_gauss_v, g, b, 0, s, tmp16, w, h, lsdTaps, blur);
+    hipLaunchKernelGGL(k_resize_exact08, dim3((W + 255) / 256, H, nframes), b, 0, s, blur, w, h, sc->d_scaled + ns, W, H);
+    (void)hipMemsetAsync(sc->d_meta + 2 * (size_t)frame0, 0, 16 * (size_t)nframes, s);
+    hipLaunchKernelGGL(k_ll_angle, dim3((W + 255) / 256, H, nframes), b, 0, s, sc->d_scaled + ns, W, H, threshold, sc->d_modgrad + ns,
+                       sc->d_angles + ns, sc->d_cs + ns, sc->d_meta + 2 * (size_t)frame0);
     /* LBD input: Gaussian(5x5, sigma 1) then Sobel */
-    hipLaunchKernelGGL(k_gauss_h, g, b, 0, s, d_img, w, h, lbdTaps, sc->d_tmp16);
-    hipLaunchKernelGGL(k_gauss_v, g, b, 0, s, sc->d_tmp16, w, h, lbdTaps, sc->d_blur);
-    hipLaunchKernelGGL(k_sobel3, g, b, 0, s, sc->d_blur, w, h, sc->d_gx, sc->d_gy);
+    hipLaunchKernelGGL(k_gauss_h, g, b, 0, s, d_img, w, h, lbdTaps, tmp16);
+    hipLaunchKernelGGL(k_gauss_v, g, b, 0, s, tmp16, w, h, lbdTaps, blur);
+    hipLaunchKernelGGL(k_sobel3, g, b, 0, s, blur, w, h, sc->d_gx + n, sc->d_gy + n);
     return hipGetLastError();
 }

@@ -12,11 +12,14 @@
 #include "lines_internal.h"
 #include "../../include/drfe_math.h"
 #include "introsort_restated.h"
+#include "cr_sincos.h"
 
 #include <algorithm>
 #include <cfloat>
 #include <functional>
 #include <mutex>
+#include <condition_variable>
+#include <deque>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -46,7 +49,141 @@ struct RPt { int x, y; double angle, modgrad; };
 typedef uint32_t OPt;       /* gradient bin (10 bits) << 22 | y (11 bits) << 11 | x (11 bits): 4-byte keys, the array of a 512 x 384
                                field fits the L2; fields up to 2048 x 2048 (checked by the caller) */
 #define LSD_ORDER_IDX_BITS 22
-struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+typedef LsdRect RectD;             /* rect of lsd.cpp: what region2rect fills (lines_internal.h) */
+
+/* cv::LineSegmentDetectorImpl's validation half: rect_improve + rect_nfa + nfa over the rectangles region growing accepted.
+ * It reads the angle field only through the pixel counts (device: k_rect_counts), so it serves the host finder and the device
+ * one (lsd_grow_kernels.hip) alike. */
+class RectValidator {
+public:
+    /* counts(cands, out): (pixels, aligned pixels) of every rectangle - the device kernel k_rect_counts */
+    typedef std::function<bool(const std::vector<RectCand>&, std::vector<int2>&)> CountFn;
+
+    RectValidator(int W, int H) { logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0); }
+    double logNT() const { return logNT_; }
+    size_t minReg(double p) const { return size_t(-logNT_ / std::log10(p)); }
+
+    /* rect_improve for all rectangles, then the segments whose NFA passes, as LineSegmentDetectorImpl::detect emits them */
+    bool emit(std::vector<RectD>& pending, std::vector<float>& lines, const CountFn& counts) const
+    {
+        const double scale = 0.8, logEps = 0;
+        std::vector<double> logNfa;
+        if (!improveAll(pending, logNfa, counts)) return false;
+        for (size_t i = 0; i < pending.size(); i++) {
+            if (logNfa[i] <= logEps) continue;
+            RectD rec = pending[i];
+            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+            rec.x1 /= scale; rec.y1 /= scale; rec.x2 /= scale; rec.y2 /= scale;
+            lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1));
+            lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
+        }
+        return true;
+    }
+private:
+    double logNT_;
+    static double logGamma(double x)
+    {
+        if (x > 15.0)
+            return 0.918938533204673 + (x - 0.5) * std::log(x) - x +
+                   0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+        static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+        double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), b = 0;
+        for (int n = 0; n < 7; ++n) { a -= std::log(x + double(n)); b += q[n] * std::pow(x, double(n)); }
+        return a + std::log(b);
+    }
+    /* logGamma at the integer arguments nfa() asks for, from a table filled once by logGamma itself (identical values; the
+     * seven log + seven pow per call were most of the NFA stage's host time) */
+    static double logGammaInt(int x)
+    {
+        static const int kTable = 1 << 16;
+        static std::vector<double> table;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            table.resize(kTable);
+            for (int i = 0; i < kTable; i++) table[i] = logGamma(double(i));
+        });
+        return (x >= 0 && x < kTable) ? table[x] : logGamma(double(x));
+    }
+    static bool nearlyEqual(double a, double b)
+    {
+        if (a == b) return true;
+        const double aa = std::fabs(a), bb = std::fabs(b);
+        double m = aa > bb ? aa : bb;
+        if (m < DBL_MIN) m = DBL_MIN;
+        return (std::fabs(a - b) / m) <= (100.0 * DBL_EPSILON);
+    }
+    double nfa(int n, int k, double p) const
+    {
+        if (n == 0 || k == 0) return -logNT_;
+        if (n == k) return -logNT_ - double(n) * std::log10(p);
+        const double pTerm = p / (1 - p);
+        const double log1 = logGammaInt(n + 1) - logGammaInt(k + 1) - logGammaInt(n - k + 1) +
+                            double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
+        double term = std::exp(log1);
+        if (nearlyEqual(term, 0)) return (k > n * p) ? -log1 / M_LN10 - logNT_ : -logNT_;
+        double tail = term;
+        for (int i = k + 1; i <= n; ++i) {
+            const double binTerm = double(n - i + 1) / double(i), mult = binTerm * pTerm;
+            term *= mult;
+            tail += term;
+            if (binTerm < 1) {
+                const double err = term * ((1 - std::pow(mult, double(n - i + 1))) / (1 - mult) - 1);
+                if (err < 0.1 * std::fabs(-std::log10(tail) - logNT_) * tail) break;
+            }
+        }
+        return -std::log10(tail) - logNT_;
+    }
+    static RectCand cand(const RectD& r) { return RectCand{r.x1, r.y1, r.x2, r.y2, r.width, r.dx, r.dy, r.theta, r.prec}; }
+
+    /* cv::LineSegmentDetectorImpl::rect_improve for every rectangle of the frame, level-synchronous: the five candidates of
+     * a refinement stage depend only on the rectangle the stage starts from, so a stage is ONE counting launch over all
+     * live rectangles (device) followed by the NFA comparisons in the reference's order (host, the caller's libm).
+     * Stages: the rectangle itself; 5 x precision halved; 5 x width reduced; 5 x one side; 5 x the other side; 5 x precision. */
+    bool improveAll(std::vector<RectD>& rects, std::vector<double>& best, const CountFn& counts) const
+    {
+        const double delta = 0.5, d2 = delta / 2.0, logEps = 0;
+        const size_t R = rects.size();
+        best.assign(R, 0.0);
+        std::vector<char> done(R, 0);
+        std::vector<RectCand> cands;
+        std::vector<RectD> trial;              /* the candidate rectangles of the current stage */
+        std::vector<int> owner;                /* rectangle a candidate belongs to */
+        std::vector<int2> cnt;
+        for (int stage = 0; stage < 6; stage++) {
+            cands.clear(); trial.clear(); owner.clear();
+            for (size_t i = 0; i < R; i++) {
+                if (done[i]) continue;
+                RectD r = rects[i];
+                if (stage == 0) { trial.push_back(r); owner.push_back((int)i); continue; }
+                for (int n = 0; n < 5; ++n) {
+                    if (stage == 1) { r.p /= 2; r.prec = r.p * M_PI; }
+                    else {
+                        if (!((r.width - delta) >= 0.5)) continue;        /* guards the last precision stage too */
+                        if (stage == 5) { r.p /= 2; r.prec = r.p * M_PI; }
+                        else if (stage == 2) r.width -= delta;
+                        else if (stage == 3) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; r.width -= delta; }
+                        else { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; r.width -= delta; }
+                    }
+                    trial.push_back(r); owner.push_back((int)i);
+                }
+            }
+            if (trial.empty()) continue;
+            cands.reserve(trial.size());
+            for (const RectD& r : trial) cands.push_back(cand(r));
+            if (!counts(cands, cnt)) return false;
+            for (size_t k = 0; k < trial.size(); k++) {
+                const int i = owner[k];
+                const double v = nfa(cnt[k].x, cnt[k].y, trial[k].p);
+                if (stage == 0) best[i] = v;
+                else if (v > best[i]) { best[i] = v; rects[i] = trial[k]; }
+            }
+            if (stage < 5)
+                for (size_t i = 0; i < R; i++)
+                    if (!done[i] && best[i] > logEps) done[i] = 1;
+        }
+        return true;
+    }
+};
 
 /* sequential half of cv::LineSegmentDetectorImpl, fed with the device-computed gradient fields */
 class SegmentFinder {
@@ -55,7 +192,7 @@ public:
      * allocation, hence no mmap/page-fault traffic, per frame) */
     SegmentFinder(int W, int H, const double* modgrad, const double* angles, const float* cs, double maxGrad,
                   std::vector<uint8_t>& used, std::vector<OPt>& order, std::vector<OPt>& orderTmp)
-        : W_(W), H_(H), mod_(modgrad), ang_(angles), cs_(cs), used_(used), order_(order), orderTmp_(orderTmp)
+        : val_(W, H), W_(W), H_(H), mod_(modgrad), ang_(angles), cs_(cs), used_(used), order_(order), orderTmp_(orderTmp)
     {
         /* 0 = free, 1 = claimed, 2 = no level-line angle (never joins a region): the probe of a neighbour then reads the
          * compact byte map only, not the angle field, for the third of the pixels that can never pass */
@@ -79,21 +216,29 @@ public:
          * seed bin are left unsorted and the seed loop stops where they begin */
         if (stdSort) std::sort(order_.begin(), order_.end(), lsd_order::Before());
         else lsd_order::sort(order_.data(), order_.size(), orderTmp_, -1, -1, minSeedBin_);
-        logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     }
 
-    /* counts(cands, out): (pixels, aligned pixels) of every rectangle - the device kernel k_rect_counts */
-    typedef std::function<bool(const std::vector<RectCand>&, std::vector<int2>&)> CountFn;
+    typedef RectValidator::CountFn CountFn;
 
     bool run(std::vector<float>& lines, const CountFn& counts)
     {
-        const double angTh = 22.5, scale = 0.8, densityTh = 0.7, logEps = 0;
-        const double prec = M_PI * angTh / 180, p = angTh / 180;
-        const size_t minReg = size_t(-logNT_ / std::log10(p));
-        std::vector<RPt> reg;
         /* rect_improve only READS the angle field and decides whether the segment is kept: it is taken out of the seed loop
          * (whose `used` bookkeeping is the sequential part) and evaluated for all rectangles of the frame at once */
         std::vector<RectD> pending;
+        findRects(pending);
+        const auto t2 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        if (!val_.emit(pending, lines, counts)) return false;
+        if (timed_) tImprove_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+        return true;
+    }
+
+    /* the seed loop: region_grow -> region2rect -> refine for every seed of the ordering; accepted rectangles in seed order */
+    void findRects(std::vector<RectD>& pending)
+    {
+        const double angTh = 22.5, densityTh = 0.7;
+        const double prec = M_PI * angTh / 180, p = angTh / 180;
+        const size_t minReg = val_.minReg(p);
+        std::vector<RPt> reg;
         for (const OPt& key : order_) {
             if ((key >> LSD_ORDER_IDX_BITS) < minSeedBin_) break;          /* bins descend: no seed from here on */
             const struct { int x, y; } s = {(int)(key & 0x7FFu), (int)((key >> 11) & 0x7FFu)};
@@ -119,23 +264,11 @@ public:
             if (!okr) continue;
             pending.push_back(rec);
         }
-        const auto t2 = timed_ ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        std::vector<double> logNfa;
-        if (!improveAll(pending, logNfa, counts)) return false;
-        if (timed_) tImprove_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
-        for (size_t i = 0; i < pending.size(); i++) {
-            if (logNfa[i] <= logEps) continue;
-            RectD rec = pending[i];
-            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-            rec.x1 /= scale; rec.y1 /= scale; rec.x2 /= scale; rec.y2 /= scale;
-            lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1));
-            lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
-        }
-        return true;
     }
 
     double tGrow_ = 0, tRefine_ = 0, tImprove_ = 0; long nGrow_ = 0, nRect_ = 0, nGrowPx_ = 0; bool timed_ = false;
 private:
+    RectValidator val_;
     int W_, H_;
     const double *mod_, *ang_;
     const float* cs_;                /* device-computed (cos, sin) of float(angle) per pixel */
@@ -143,7 +276,6 @@ private:
     std::vector<OPt>& order_;
     std::vector<OPt>& orderTmp_;
     uint32_t minSeedBin_ = 0;
-    double logNT_;
 
     static double sq(double v) { return v * v; }
     static double dist(double x1, double y1, double x2, double y2) { return std::sqrt(sq(x2 - x1) + sq(y2 - y1)); }
@@ -163,6 +295,18 @@ private:
         if (n < 0) n = -n;
         if (n > kThreeHalfPi) { n -= kTwoPi; if (n < 0) n = -n; }
         return n <= prec;
+    }
+    /* `float(cos(reg_angle))`, `float(sin(reg_angle))` at the start of region_grow and `cos(theta)`, `sin(theta)` of region2rect:
+     * the reference takes them from the host's libm (glibc >= 2.28: within 0.55 ulp, i.e. one time in ten thousand the
+     * neighbour of the correctly rounded double).  Canonical here, on the host and on the device: the correctly rounded value
+     * (cr_sincos.h; what glibc <= 2.27 returned), libm only if the routine cannot certify its rounding. */
+    static void seedDirection(double a, float& c, float& s)
+    {
+        if (!drfe_cr_sincos_f(a, &s, &c)) { c = float(std::cos(a)); s = float(std::sin(a)); }
+    }
+    static void rectDirection(double theta, double& c, double& s)
+    {
+        if (!drfe_cr_sincos(theta, &s, &c)) { c = std::cos(theta); s = std::sin(theta); }
     }
     /* region_grow.  The gradient magnitude of a member is filled in by fillModgrad() for the regions that reach the minimum
      * size only (one in twenty: the rest are dropped without ever reading it). */
@@ -188,7 +332,7 @@ private:
             if (dn <= prec) {
                 u = 1;
                 reg.push_back({xx, yy, a, 0.0});
-                if (!seeded) { sumdx = float(std::cos(seedAngle)); sumdy = float(std::sin(seedAngle)); seeded = true; }
+                if (!seeded) { seedDirection(seedAngle, sumdx, sumdy); seeded = true; }
                 sumdx += cs_[2 * at];        /* cos(float(angle)), shared routine (device) */
                 sumdy += cs_[2 * at + 1];    /* sin(float(angle)) */
                 regAngle = drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
@@ -252,7 +396,8 @@ private:
         for (const RPt& r : reg) { x += double(r.x) * r.modgrad; y += double(r.y) * r.modgrad; sum += r.modgrad; }
         x /= sum; y /= sum;
         const double theta = thetaOf(reg, x, y, regAngle, prec);
-        const double dx = std::cos(theta), dy = std::sin(theta);
+        double dx, dy;
+        rectDirection(theta, dx, dy);
         double lmin = 0, lmax = 0, wmin = 0, wmax = 0;
         for (const RPt& r : reg) {
             const double rx = double(r.x) - x, ry = double(r.y) - y;
@@ -308,58 +453,6 @@ private:
         if (density < densityTh) return shrink(reg, regAngle, prec, p, rec, density, densityTh);
         return true;
     }
-    static double logGamma(double x)
-    {
-        if (x > 15.0)
-            return 0.918938533204673 + (x - 0.5) * std::log(x) - x +
-                   0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
-        static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
-        double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), b = 0;
-        for (int n = 0; n < 7; ++n) { a -= std::log(x + double(n)); b += q[n] * std::pow(x, double(n)); }
-        return a + std::log(b);
-    }
-    /* logGamma at the integer arguments nfa() asks for, from a table filled once by logGamma itself (identical values; the
-     * seven log + seven pow per call were most of the NFA stage's host time) */
-    static double logGammaInt(int x)
-    {
-        static const int kTable = 1 << 16;
-        static std::vector<double> table;
-        static std::once_flag once;
-        std::call_once(once, [] {
-            table.resize(kTable);
-            for (int i = 0; i < kTable; i++) table[i] = logGamma(double(i));
-        });
-        return (x >= 0 && x < kTable) ? table[x] : logGamma(double(x));
-    }
-    static bool nearlyEqual(double a, double b)
-    {
-        if (a == b) return true;
-        const double aa = std::fabs(a), bb = std::fabs(b);
-        double m = aa > bb ? aa : bb;
-        if (m < DBL_MIN) m = DBL_MIN;
-        return (std::fabs(a - b) / m) <= (100.0 * DBL_EPSILON);
-    }
-    double nfa(int n, int k, double p) const
-    {
-        if (n == 0 || k == 0) return -logNT_;
-        if (n == k) return -logNT_ - double(n) * std::log10(p);
-        const double pTerm = p / (1 - p);
-        const double log1 = logGammaInt(n + 1) - logGammaInt(k + 1) - logGammaInt(n - k + 1) +
-                            double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
-        double term = std::exp(log1);
-        if (nearlyEqual(term, 0)) return (k > n * p) ? -log1 / M_LN10 - logNT_ : -logNT_;
-        double tail = term;
-        for (int i = k + 1; i <= n; ++i) {
-            const double binTerm = double(n - i + 1) / double(i), mult = binTerm * pTerm;
-            term *= mult;
-            tail += term;
-            if (binTerm < 1) {
-                const double err = term * ((1 - std::pow(mult, double(n - i + 1))) / (1 - mult) - 1);
-                if (err < 0.1 * std::fabs(-std::log10(tail) - logNT_) * tail) break;
-            }
-        }
-        return -std::log10(tail) - logNT_;
-    }
 public:
     /* DRFE_LSD_CHECK=1: the same pixel loop on the host, to cross-check k_rect_counts (debug only) */
     void countHost(const RectCand& rec, int& total, int& alg) const
@@ -401,57 +494,6 @@ public:
             rx += rstep;
         }
     }
-private:
-    static RectCand cand(const RectD& r) { return RectCand{r.x1, r.y1, r.x2, r.y2, r.width, r.dx, r.dy, r.theta, r.prec}; }
-
-    /* cv::LineSegmentDetectorImpl::rect_improve for every rectangle of the frame, level-synchronous: the five candidates of
-     * a refinement stage depend only on the rectangle the stage starts from, so a stage is ONE counting launch over all
-     * live rectangles (device) followed by the NFA comparisons in the reference's order (host, the caller's libm).
-     * Stages: the rectangle itself; 5 x precision halved; 5 x width reduced; 5 x one side; 5 x the other side; 5 x precision. */
-    bool improveAll(std::vector<RectD>& rects, std::vector<double>& best, const CountFn& counts) const
-    {
-        const double delta = 0.5, d2 = delta / 2.0, logEps = 0;
-        const size_t R = rects.size();
-        best.assign(R, 0.0);
-        std::vector<char> done(R, 0);
-        std::vector<RectCand> cands;
-        std::vector<RectD> trial;              /* the candidate rectangles of the current stage */
-        std::vector<int> owner;                /* rectangle a candidate belongs to */
-        std::vector<int2> cnt;
-        for (int stage = 0; stage < 6; stage++) {
-            cands.clear(); trial.clear(); owner.clear();
-            for (size_t i = 0; i < R; i++) {
-                if (done[i]) continue;
-                RectD r = rects[i];
-                if (stage == 0) { trial.push_back(r); owner.push_back((int)i); continue; }
-                for (int n = 0; n < 5; ++n) {
-                    if (stage == 1) { r.p /= 2; r.prec = r.p * M_PI; }
-                    else {
-                        if (!((r.width - delta) >= 0.5)) continue;        /* guards the last precision stage too */
-                        if (stage == 5) { r.p /= 2; r.prec = r.p * M_PI; }
-                        else if (stage == 2) r.width -= delta;
-                        else if (stage == 3) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; r.width -= delta; }
-                        else { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; r.width -= delta; }
-                    }
-                    trial.push_back(r); owner.push_back((int)i);
-                }
-            }
-            if (trial.empty()) continue;
-            cands.reserve(trial.size());
-            for (const RectD& r : trial) cands.push_back(cand(r));
-            if (!counts(cands, cnt)) return false;
-            for (size_t k = 0; k < trial.size(); k++) {
-                const int i = owner[k];
-                const double v = nfa(cnt[k].x, cnt[k].y, trial[k].p);
-                if (stage == 0) best[i] = v;
-                else if (v > best[i]) { best[i] = v; rects[i] = trial[k]; }
-            }
-            if (stage < 5)
-                for (size_t i = 0; i < R; i++)
-                    if (!done[i] && best[i] > logEps) done[i] = 1;
-        }
-        return true;
-    }
 };
 
 /* the Gaussian weights of BinaryDescriptor::computeLBD: local (3 x 7 rows, sigma 7) and global (63 rows, sigma 31), cast to
@@ -484,8 +526,10 @@ static LineTaps gaussTaps(int n, double sigma)
 
 } // namespace
 
-/* One line-extraction lane: device scratch + stream + its own error string.  The context owns one (the
- * single-frame entry) and, for drfe_lsd_extract_batch, a pool of them, one per host thread. */
+/* One line-extraction lane: stream, NFA / LBD scratch, host buffers, its own error string.  The context owns one (the
+ * single-frame entry) and, for drfe_lsd_extract_batch, a pool of them, one per host thread.  `ls` of a lane holds the image
+ * arrays of ONE frame slot (host-grow path); the batch's device-grow path keeps the frames' arrays in the context's batch
+ * arena and uses a lane for its stream and small scratch only. */
 struct LineHost {                     /* per-lane host buffers reused across frames */
     std::vector<double> modgrad, angles;
     std::vector<float> cs;
@@ -503,9 +547,11 @@ struct LineWorker {
 static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
-    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_maxGrad, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
-                    s->d_lbdLines, s->d_lbdOut};
+    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
+                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames};
+    for (void* p : hptrs) if (p) (void)hipHostFree(p);
     delete s;
     s = nullptr;
 }
@@ -513,6 +559,7 @@ static void scratch_free(LinesScratch*& s)
 void drfe_lines_free(drfe_ctx* c)
 {
     scratch_free(c->ls);
+    scratch_free(c->lsBatch);
     delete static_cast<LineHost*>(c->lineHost);
     c->lineHost = nullptr;
     auto* pool = static_cast<std::vector<LineWorker>*>(c->lineWorkers);
@@ -527,72 +574,81 @@ void drfe_lines_free(drfe_ctx* c)
     }
 }
 
-static int ensure_lines(LineWorker* c, int w, int h)
+#define LSD_RECT_CAP 4096            /* accepted regions per frame the device path can hold (a 640 x 480 frame has ~1500) */
+
+/* image arrays for `frames` slots of w x h; grow = the device region-growing buffers and their pinned mirrors as well;
+ * images = false: a lane that only needs the NFA / LBD scratch (its frames live in the batch arena) */
+static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int frames, bool images, bool grow)
 {
-    if (c->ls && c->ls->w == w && c->ls->h == h) return DRFE_OK;
-    scratch_free(c->ls);
+    struct E { std::string& err; } e{err};
+#define LCHK(call)                                                                              \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) { e.err = std::string(#call) + ": " + hipGetErrorString(e__); return DRFE_ERR_HIP; } \
+    } while (0)
+    if (ls && ls->w == w && ls->h == h && ls->frames >= frames && (!images || ls->d_img) && (!grow || ls->d_order)) return DRFE_OK;
+    scratch_free(ls);
     LinesScratch* s = new (std::nothrow) LinesScratch();
     if (!s) return DRFE_ERR_INVALID;
     std::memset(s, 0, sizeof(*s));
-    c->ls = s;
-    s->w = w; s->h = h;
+    ls = s;
+    s->w = w; s->h = h; s->frames = frames;
     s->sw = (int)std::rint(w * 0.8); s->sh = (int)std::rint(h * 0.8);   /* saturate_cast<int>(size * inv_scale) */
-    const size_t n = (size_t)w * h, ns = (size_t)s->sw * s->sh;
-    HIPCHK(c, hipMalloc((void**)&s->d_img, n));
-    HIPCHK(c, hipMalloc((void**)&s->d_blur, n));
-    HIPCHK(c, hipMalloc((void**)&s->d_scaled, ns));
-    HIPCHK(c, hipMalloc((void**)&s->d_tmp16, n * 2));
-    HIPCHK(c, hipMalloc((void**)&s->d_modgrad, ns * 8));
-    HIPCHK(c, hipMalloc((void**)&s->d_angles, ns * 8));
-    HIPCHK(c, hipMalloc((void**)&s->d_cs, ns * 8));
-    HIPCHK(c, hipMalloc((void**)&s->d_maxGrad, 8));
-    HIPCHK(c, hipMalloc((void**)&s->d_gx, n * 2));
-    HIPCHK(c, hipMalloc((void**)&s->d_gy, n * 2));
+    const size_t F = (size_t)frames, n = (size_t)w * h * F, ns = (size_t)s->sw * s->sh * F;
+    if (images) {
+        LCHK(hipMalloc((void**)&s->d_img, n));
+        LCHK(hipMalloc((void**)&s->d_blur, n));
+        LCHK(hipMalloc((void**)&s->d_scaled, ns));
+        LCHK(hipMalloc((void**)&s->d_tmp16, n * 2));
+        LCHK(hipMalloc((void**)&s->d_modgrad, ns * 8));
+        LCHK(hipMalloc((void**)&s->d_angles, ns * 8));
+        LCHK(hipMalloc((void**)&s->d_cs, ns * 8));
+        LCHK(hipMalloc((void**)&s->d_meta, 16 * F));
+        LCHK(hipMalloc((void**)&s->d_gx, n * 2));
+        LCHK(hipMalloc((void**)&s->d_gy, n * 2));
+    }
+    if (grow) {
+        const size_t nk = (size_t)(s->sw - 1) * (s->sh - 1) * F;
+        s->rectCap = LSD_RECT_CAP;
+        LCHK(hipMalloc((void**)&s->d_order, nk * 4));
+        LCHK(hipMalloc((void**)&s->d_reg, ns * 4));
+        LCHK(hipMalloc((void**)&s->d_tmp, ns * 4));
+        LCHK(hipMalloc((void**)&s->d_rects, F * s->rectCap * sizeof(LsdRect)));
+        LCHK(hipMalloc((void**)&s->d_out, F * DRFE_LSD_OUT_INTS * sizeof(int)));
+        LCHK(hipMalloc((void**)&s->d_frames, F * sizeof(LsdGrowFrame)));
+        LCHK(hipHostMalloc((void**)&s->h_order, nk * 4, hipHostMallocDefault));
+        LCHK(hipHostMalloc((void**)&s->h_meta, 16 * F, hipHostMallocDefault));
+        LCHK(hipHostMalloc((void**)&s->h_rects, F * s->rectCap * sizeof(LsdRect), hipHostMallocDefault));
+        LCHK(hipHostMalloc((void**)&s->h_out, F * DRFE_LSD_OUT_INTS * sizeof(int), hipHostMallocDefault));
+        LCHK(hipHostMalloc((void**)&s->h_frames, F * sizeof(LsdGrowFrame), hipHostMallocDefault));
+    }
+#undef LCHK
     return DRFE_OK;
 }
 
-/* LineSegment::ExtractLineSegment for one frame on one lane */
-static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int w, int h, size_t stride, int max_lines,
-                            drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected)
-{
-    *n_lines = 0;
-    HIPCHK(c, hipSetDevice(device));
-    int rc = ensure_lines(c, w, h);
-    if (rc != DRFE_OK) return rc;
-    LinesScratch* s = c->ls;
-    if (s->sw > 2048 || s->sh > 2048) { c->err = "lsd_extract: image larger than 2560 x 2560 (pixel-ordering keys)"; return DRFE_ERR_INVALID; }
-    /* LineSegmentDetector defaults: scale 0.8, sigma_scale 0.6 -> sigma 0.75, 7x7 kernel; quant 2, ang_th 22.5 */
-    const double sigma = 0.6 / 0.8;
-    const int hk = (int)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
-    const LineTaps lsdTaps = gaussTaps(1 + 2 * hk, sigma), lbdTaps = gaussTaps(5, 1.0);
-    const double rho = 2.0 / std::sin(M_PI * 22.5 / 180);
-    hipStream_t st = c->stream;
-    const bool trace = std::getenv("DRFE_TRACE_LINES") != nullptr;
-    const auto tStart = std::chrono::steady_clock::now();
-    HIPCHK(c, hipMemcpy2DAsync(s->d_img, (size_t)w, gray, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
-    HIPCHK(c, drfe_launch_lines_passes(s->d_img, w, h, lsdTaps, lbdTaps, s, rho, st));
-    const size_t ns = (size_t)s->sw * s->sh;
-    if (!c->host) c->host = new LineHost();
-    LineHost& H = *c->host;
-    std::vector<double>&modgrad = H.modgrad, &angles = H.angles;
-    modgrad.resize(ns); angles.resize(ns); H.cs.resize(2 * ns);
-    unsigned long long maxBits = 0;
-    HIPCHK(c, hipMemcpyAsync(modgrad.data(), s->d_modgrad, ns * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(angles.data(), s->d_angles, ns * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(H.cs.data(), s->d_cs, ns * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(&maxBits, s->d_maxGrad, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    double maxGrad = -1;
-    if (maxBits) std::memcpy(&maxGrad, &maxBits, 8);
+struct LsdParams {
+    LineTaps lsdTaps, lbdTaps;
+    double rho;
+    LsdParams()
+    {
+        /* LineSegmentDetector defaults: scale 0.8, sigma_scale 0.6 -> sigma 0.75, 7x7 kernel; quant 2, ang_th 22.5 */
+        const double sigma = 0.6 / 0.8;
+        const int hk = (int)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
+        lsdTaps = gaussTaps(1 + 2 * hk, sigma);
+        lbdTaps = gaussTaps(5, 1.0);
+        rho = 2.0 / std::sin(M_PI * 22.5 / 180);
+    }
+};
 
-    const auto tDev = std::chrono::steady_clock::now();
-    std::vector<float> segs;
-    SegmentFinder finder(s->sw, s->sh, modgrad.data(), angles.data(), H.cs.data(), maxGrad, H.used, H.order, H.orderTmp);
-    const auto tSort = std::chrono::steady_clock::now();
-    finder.timed_ = trace;
-    int countRc = DRFE_OK;
-    const bool checkCounts = std::getenv("DRFE_LSD_CHECK") != nullptr;
-    auto counts = [&](const std::vector<RectCand>& cands, std::vector<int2>& out) -> bool {
+/* the device arrays of one frame that the validation / descriptor stages read */
+struct FrameView { int w, h, sw, sh; const double* d_angles; const int16_t* d_gx; const int16_t* d_gy; };
+
+/* rect_nfa's pixel counts on the device (k_rect_counts) through lane c's stream and grow-only scratch */
+static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, int& countRc, const SegmentFinder* check)
+{
+    return [c, v, &countRc, check](const std::vector<RectCand>& cands, std::vector<int2>& out) -> bool {
+        LinesScratch* s = c->ls;
+        hipStream_t st = c->stream;
         const size_t nc = cands.size();
         out.resize(nc);
         if (nc > s->candCap) {
@@ -606,26 +662,30 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
             }
         }
         hipError_t e = hipMemcpyAsync(s->d_cands, cands.data(), nc * sizeof(RectCand), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, s->d_angles, s->sw, s->sh, s->d_counts, st);
+        if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, v.d_angles, v.sw, v.sh, s->d_counts, st);
         if (e == hipSuccess) e = hipMemcpyAsync(out.data(), s->d_counts, nc * sizeof(int2), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { c->err = std::string("lsd_extract: rectangle counting: ") + hipGetErrorString(e); countRc = DRFE_ERR_HIP; return false; }
-        if (checkCounts)
+        if (check)
             for (size_t k = 0; k < nc; k++) {
                 int t = 0, a = 0;
-                finder.countHost(cands[k], t, a);
+                check->countHost(cands[k], t, a);
                 if (t != out[k].x || a != out[k].y)
                     std::fprintf(stderr, "k_rect_counts mismatch: cand %zu device (%d, %d) host (%d, %d)  x1 %.17g y1 %.17g x2 %.17g y2 %.17g w %.17g dx %.17g dy %.17g theta %.17g prec %.17g\n",
                                  k, out[k].x, out[k].y, t, a, cands[k].x1, cands[k].y1, cands[k].x2, cands[k].y2, cands[k].width, cands[k].dx, cands[k].dy, cands[k].theta, cands[k].prec);
             }
         return true;
     };
-    if (!finder.run(segs, counts)) return countRc;
-    const auto tSeg = std::chrono::steady_clock::now();
-    if (trace) std::fprintf(stderr, "drfe_lsd_extract: pixel ordering (bins + std::sort) %.2f ms; grow %.2f ms (%ld regions, %ld pixels); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
-                            std::chrono::duration<double, std::milli>(tSort - tDev).count(), finder.tGrow_, finder.nGrow_, finder.nGrowPx_, finder.tRefine_, finder.nRect_, finder.tImprove_);
+}
 
-    /* LSDDetector::detect: KeyLine fields for octave 0 (octaveScale = 1) */
+/* from the detector's segments to the caller's buffers: LSDDetector::detect's KeyLine fields (octave 0), the reference's
+ * response cut (src/LSDextractor.cpp:23-28), LBD descriptors on the device (k_lbd), line equations (:32-42) */
+static int keylines_and_descriptors(LineWorker* c, const FrameView& v, const std::vector<float>& segs, int max_lines, drfe_keyline* lines,
+                                    uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected)
+{
+    const int w = v.w, h = v.h;
+    LinesScratch* s = c->ls;
+    hipStream_t st = c->stream;
     std::vector<drfe_keyline> kls;
     int classCounter = -1;
     for (size_t k = 0; k + 3 < segs.size(); k += 4) {
@@ -662,15 +722,6 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
     const int nl = (int)kls.size();
     *n_lines = nl;
     if (nl > cap) { c->err = "lsd_extract: line buffer too small"; return DRFE_ERR_CAPACITY; }
-    struct TraceAtExit {   /* DRFE_TRACE_LINES=1: where a call spends its time (device passes + copies | LSD host | LBD host) */
-        bool on; std::chrono::steady_clock::time_point a, b, cc;
-        ~TraceAtExit() {
-            if (!on) return;
-            const auto e = std::chrono::steady_clock::now();
-            auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
-            std::fprintf(stderr, "drfe_lsd_extract: device+copies %.2f ms, LSD host %.2f ms, keylines+LBD host %.2f ms\n", ms(a, b), ms(b, cc), ms(cc, e));
-        }
-    } traceAtExit{trace, tStart, tDev, tSeg};
     /* LBD descriptors of the kept lines on the device (k_lbd); the direction cosines come from this host's libm, as the
      * reference's do */
     if (nl > 0 && ldesc) {
@@ -692,7 +743,7 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
             ll[i].len = kl.num_of_pixels; ll[i].pad = 0;
         }
         HIPCHK(c, hipMemcpyAsync(s->d_lbdLines, ll.data(), nl * sizeof(LbdLine), hipMemcpyHostToDevice, st));
-        HIPCHK(c, drfe_launch_lbd(s->d_lbdLines, nl, s->d_gx, s->d_gy, w, h, lbdTables(), s->d_lbdOut, st));
+        HIPCHK(c, drfe_launch_lbd(s->d_lbdLines, nl, v.d_gx, v.d_gy, w, h, lbdTables(), s->d_lbdOut, st));
         HIPCHK(c, hipMemcpyAsync(ldesc, s->d_lbdOut, (size_t)nl * 32, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
@@ -705,6 +756,326 @@ static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int 
             line_f[3 * i] = l0 / nrm; line_f[3 * i + 1] = l1 / nrm; line_f[3 * i + 2] = l2 / nrm;
         }
     }
+    return DRFE_OK;
+}
+
+/* the sequential half on the HOST for one frame whose fields lie at slot `slot` of `fields` (copied back over lane c's stream),
+ * then validation + key lines + descriptors */
+static int host_grow_and_finish(LineWorker* c, LinesScratch* fields, int slot, int max_lines, drfe_keyline* lines, uint8_t* ldesc,
+                                double* line_f, int cap, int* n_lines, int* n_detected, std::chrono::steady_clock::time_point tStart)
+{
+    hipStream_t st = c->stream;
+    const bool trace = std::getenv("DRFE_TRACE_LINES") != nullptr;
+    const size_t ns = (size_t)fields->sw * fields->sh, n = (size_t)fields->w * fields->h;
+    if (!c->host) c->host = new LineHost();
+    LineHost& H = *c->host;
+    std::vector<double>&modgrad = H.modgrad, &angles = H.angles;
+    modgrad.resize(ns); angles.resize(ns); H.cs.resize(2 * ns);
+    unsigned long long meta[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(modgrad.data(), fields->d_modgrad + ns * slot, ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(angles.data(), fields->d_angles + ns * slot, ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(H.cs.data(), fields->d_cs + ns * slot, ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(meta, fields->d_meta + 2 * (size_t)slot, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    double maxGrad = -1;
+    if (meta[0]) std::memcpy(&maxGrad, &meta[0], 8);
+
+    const auto tDev = std::chrono::steady_clock::now();
+    std::vector<float> segs;
+    SegmentFinder finder(fields->sw, fields->sh, modgrad.data(), angles.data(), H.cs.data(), maxGrad, H.used, H.order, H.orderTmp);
+    const auto tSort = std::chrono::steady_clock::now();
+    finder.timed_ = trace;
+    int countRc = DRFE_OK;
+    const FrameView v = {fields->w, fields->h, fields->sw, fields->sh, fields->d_angles + ns * slot, fields->d_gx + n * slot, fields->d_gy + n * slot};
+    const bool checkCounts = std::getenv("DRFE_LSD_CHECK") != nullptr;
+    if (!finder.run(segs, device_counts(c, v, countRc, checkCounts ? &finder : nullptr))) return countRc;
+    const auto tSeg = std::chrono::steady_clock::now();
+    if (trace) std::fprintf(stderr, "drfe_lsd_extract: pixel ordering (bins + std::sort) %.2f ms; grow %.2f ms (%ld regions, %ld pixels); rect+refine %.2f ms (%ld); improve/NFA %.2f ms\n",
+                            std::chrono::duration<double, std::milli>(tSort - tDev).count(), finder.tGrow_, finder.nGrow_, finder.nGrowPx_, finder.tRefine_, finder.nRect_, finder.tImprove_);
+    struct TraceAtExit {   /* DRFE_TRACE_LINES=1: where a call spends its time (device passes + copies | LSD host | LBD host) */
+        bool on; std::chrono::steady_clock::time_point a, b, cc;
+        ~TraceAtExit() {
+            if (!on) return;
+            const auto e = std::chrono::steady_clock::now();
+            auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+            std::fprintf(stderr, "drfe_lsd_extract: device+copies %.2f ms, LSD host %.2f ms, keylines+LBD host %.2f ms\n", ms(a, b), ms(b, cc), ms(cc, e));
+        }
+    } traceAtExit{trace, tStart, tDev, tSeg};
+    return keylines_and_descriptors(c, v, segs, max_lines, lines, ldesc, line_f, cap, n_lines, n_detected);
+}
+
+/* LineSegment::ExtractLineSegment for one frame on one lane, region growing on the host (the low-latency path) */
+static int lsd_extract_core(LineWorker* c, int device, const uint8_t* gray, int w, int h, size_t stride, int max_lines,
+                            drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines, int* n_detected)
+{
+    *n_lines = 0;
+    HIPCHK(c, hipSetDevice(device));
+    int rc = ensure_lines(c->err, c->ls, w, h, 1, true, false);
+    if (rc != DRFE_OK) return rc;
+    LinesScratch* s = c->ls;
+    if (s->sw > 2048 || s->sh > 2048) { c->err = "lsd_extract: image larger than 2560 x 2560 (pixel-ordering keys)"; return DRFE_ERR_INVALID; }
+    static const LsdParams P;
+    hipStream_t st = c->stream;
+    const auto tStart = std::chrono::steady_clock::now();
+    HIPCHK(c, hipMemcpy2DAsync(s->d_img, (size_t)w, gray, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
+    HIPCHK(c, drfe_launch_lines_passes(s->d_img, w, h, P.lsdTaps, P.lbdTaps, s, 0, 1, P.rho, st));
+    return host_grow_and_finish(c, s, 0, max_lines, lines, ldesc, line_f, cap, n_lines, n_detected, tStart);
+}
+
+/* ---- the batch entry with region growing on the device -------------------------------------------------------------------
+ * Per chunk of frames: image passes + ordering keys (device) -> keys to the host -> the ordering (host: std::sort's
+ * permutation, introsort_restated.h, one task per frame on the pool) -> orderings to the device -> k_lsd_grow, one
+ * wavefront per frame -> accepted rectangles to the host -> per frame on the pool: rect_improve / NFA with k_rect_counts,
+ * key lines, k_lbd.  Chunks overlap: while one chunk's frames grow on the device, the pool orders the next and validates
+ * the previous. */
+namespace {
+
+struct BatchJob {
+    drfe_ctx* c;
+    LinesScratch* A;                   /* the batch arena (frame slots) */
+    std::vector<LineWorker>* pool;
+    const uint8_t* gray; size_t frameStride, stride;
+    int w, h, nframes, maxLines, cap;
+    drfe_keyline* lines; uint8_t* ldesc; double* lineF; int* nLines; int* nDetected;
+    int chunk, nChunks;
+    std::vector<hipStream_t> chunkStream;
+    std::vector<hipEvent_t> keysReady, growDone;
+    std::vector<std::atomic<int>> sortedInChunk;
+    std::vector<int> chunkState;         /* 0 = ordering, 1 = growing on the device, 2 = released to validation (under mu) */
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> sortQ, finishQ;      /* frame indices */
+    int pendingFinish = 0;               /* frames not yet finished */
+    int firstRc = DRFE_OK; std::string firstErr;
+    bool abort = false;
+    double prec, p; int minReg;
+    std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
+    std::chrono::steady_clock::time_point t0, tLastSort, tFirstFinish; std::atomic<int> nFirst{0};
+    BatchJob(int nChunks_) : sortedInChunk(nChunks_), chunkState(nChunks_, 0) {}
+};
+
+} // namespace
+
+static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
+{
+    LinesScratch* A = J.A;
+    const int f0 = ch * J.chunk, nf = std::min(J.chunk, J.nframes - f0);
+    const size_t ns = (size_t)A->sw * A->sh, nk = (size_t)(A->sw - 1) * (A->sh - 1);
+    hipStream_t st = J.chunkStream[ch];
+    for (int f = f0; f < f0 + nf; f++) {
+        LsdGrowFrame& g = A->h_frames[f];
+        g.ang = A->d_angles + ns * f; g.cs = A->d_cs + ns * f; g.mod = A->d_modgrad + ns * f;
+        g.order = A->d_order + nk * f; g.reg = A->d_reg + ns * f; g.tmp = A->d_tmp + ns * f;
+        g.rects = A->d_rects + (size_t)A->rectCap * f; g.out = A->d_out + DRFE_LSD_OUT_INTS * (size_t)f;
+        g.nOrder = (int)nk;
+        g.minSeedBin = 1024u - (uint32_t)(A->h_meta[2 * (size_t)f + 1] & 0xFFFFFFFFull);
+    }
+#define BCHK(call)                                                                              \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e__); return DRFE_ERR_HIP; } \
+    } while (0)
+    BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
+    BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
+    BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st));
+    BCHK(hipMemcpyAsync(A->h_out + DRFE_LSD_OUT_INTS * (size_t)f0, A->d_out + DRFE_LSD_OUT_INTS * (size_t)f0, DRFE_LSD_OUT_INTS * sizeof(int) * nf, hipMemcpyDeviceToHost, st));
+    BCHK(hipEventRecord(J.growDone[ch], st));
+#undef BCHK
+    return DRFE_OK;
+}
+
+static void batch_fail(BatchJob& J, int rc, const std::string& err)
+{
+    std::lock_guard<std::mutex> lk(J.mu);
+    if (J.firstRc == DRFE_OK) { J.firstRc = rc; J.firstErr = err; }
+    J.abort = true;
+    J.cv.notify_all();
+}
+
+static void batch_worker(BatchJob& J, LineWorker* lw)
+{
+    LinesScratch* A = J.A;
+    const size_t ns = (size_t)A->sw * A->sh, n = (size_t)A->w * A->h, nk = (size_t)(A->sw - 1) * (A->sh - 1);
+    (void)hipSetDevice(J.c->device);
+    std::vector<OPt> tmp;
+    const RectValidator val(A->sw, A->sh);
+    for (;;) {
+        int f = -1, waitCh = -1; bool fin = false;
+        {
+            std::unique_lock<std::mutex> lk(J.mu);
+            for (;;) {
+                if (J.abort) return;
+                /* chunks whose regions have grown: their frames become validation tasks */
+                for (int ch = 0; ch < J.nChunks; ch++)
+                    if (J.chunkState[ch] == 1 && hipEventQuery(J.growDone[ch]) == hipSuccess) {
+                        J.chunkState[ch] = 2;
+                        const int nf = std::min(J.chunk, J.nframes - ch * J.chunk);
+                        for (int k = 0; k < nf; k++) J.finishQ.push_back(ch * J.chunk + k);
+                        J.cv.notify_all();
+                    }
+                if (!J.finishQ.empty()) { f = J.finishQ.front(); J.finishQ.pop_front(); fin = true; break; }
+                if (!J.sortQ.empty()) { f = J.sortQ.front(); J.sortQ.pop_front(); break; }
+                if (J.pendingFinish == 0) return;
+                /* nothing to do until a chunk has grown: sleep on the oldest one (outside the lock), or on the other workers */
+                for (int ch = 0; ch < J.nChunks && waitCh < 0; ch++) if (J.chunkState[ch] == 1) waitCh = ch;
+                if (waitCh >= 0) break;
+                J.cv.wait(lk);
+            }
+        }
+        if (waitCh >= 0) {
+            const auto tw = std::chrono::steady_clock::now();
+            if (hipEventSynchronize(J.growDone[waitCh]) != hipSuccess) { batch_fail(J, DRFE_ERR_HIP, "lsd_extract_batch: grow"); return; }
+            J.usWait += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw).count();
+            continue;
+        }
+        const auto tTask = std::chrono::steady_clock::now();
+        const int ch = f / J.chunk;
+        if (!fin) {
+            /* the ordering of frame f: std::sort's permutation of its keys */
+            if (hipEventSynchronize(J.keysReady[ch]) != hipSuccess) { batch_fail(J, DRFE_ERR_HIP, "lsd_extract_batch: keys"); return; }
+            OPt* keys = A->h_order + nk * f;
+            const uint32_t minSeedBin = 1024u - (uint32_t)(A->h_meta[2 * (size_t)f + 1] & 0xFFFFFFFFull);
+            static const bool stdSort = std::getenv("DRFE_LSD_STD_SORT") != nullptr;
+            if (stdSort) std::sort(keys, keys + nk, lsd_order::Before());
+            else lsd_order::sort(keys, nk, tmp, -1, -1, minSeedBin);
+            J.usSort += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tTask).count();
+            const int nf = std::min(J.chunk, J.nframes - ch * J.chunk);
+            if (J.sortedInChunk[ch].fetch_add(1) + 1 == nf) {
+                std::string err;
+                const int rc = batch_launch_grow(J, ch, err);
+                if (rc != DRFE_OK) { batch_fail(J, rc, err); return; }
+                std::lock_guard<std::mutex> lk(J.mu);
+                J.chunkState[ch] = 1;
+                J.cv.notify_all();
+            }
+            continue;
+        }
+        /* validation + key lines + descriptors of frame f (its chunk has grown) */
+        int rc = ensure_lines(lw->err, lw->ls, J.w, J.h, 1, false, false);
+        int nd = 0;
+        if (rc == DRFE_OK) {
+            const int nRects = A->h_out[DRFE_LSD_OUT_INTS * (size_t)f], status = A->h_out[DRFE_LSD_OUT_INTS * (size_t)f + 1];
+            drfe_keyline* lo = J.lines ? J.lines + (size_t)f * J.cap : nullptr;
+            uint8_t* dout = J.ldesc ? J.ldesc + (size_t)f * J.cap * 32 : nullptr;
+            double* lf = J.lineF ? J.lineF + (size_t)f * J.cap * 3 : nullptr;
+            if (status != 0) {
+                /* a rounding the device could not certify, or more regions than the rectangle list holds: this frame's
+                 * sequential half again on the host, from the fields the device still has */
+                rc = ensure_lines(lw->err, lw->ls, J.w, J.h, 1, false, false);
+                if (rc == DRFE_OK) rc = host_grow_and_finish(lw, A, f, J.maxLines, lo, dout, lf, J.cap, &J.nLines[f], &nd, std::chrono::steady_clock::now());
+            } else {
+                std::vector<RectD> pending(nRects);
+                if (nRects > 0 && hipMemcpyAsync(pending.data(), A->d_rects + (size_t)A->rectCap * f, sizeof(LsdRect) * nRects, hipMemcpyDeviceToHost, lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
+                if (rc == DRFE_OK && nRects > 0 && hipStreamSynchronize(lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
+                if (rc != DRFE_OK) lw->err = "lsd_extract_batch: rectangle download";
+                if (rc == DRFE_OK) {
+                    const FrameView v = {A->w, A->h, A->sw, A->sh, A->d_angles + ns * f, A->d_gx + n * f, A->d_gy + n * f};
+                    int countRc = DRFE_OK;
+                    std::vector<float> segs;
+                    const auto tn = std::chrono::steady_clock::now();
+                    J.usRectDl += std::chrono::duration_cast<std::chrono::microseconds>(tn - tTask).count();
+                    const bool okE = val.emit(pending, segs, device_counts(lw, v, countRc, nullptr));
+                    const auto tk = std::chrono::steady_clock::now();
+                    J.usNfa += std::chrono::duration_cast<std::chrono::microseconds>(tk - tn).count();
+                    if (!okE) rc = countRc;
+                    else rc = keylines_and_descriptors(lw, v, segs, J.maxLines, lo, dout, lf, J.cap, &J.nLines[f], &nd);
+                    J.usKeyl += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tk).count();
+                }
+            }
+        }
+        if (J.nDetected) J.nDetected[f] = nd;
+        J.usFinish += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tTask).count();
+        if (rc != DRFE_OK) { batch_fail(J, rc, lw->err); return; }
+        {
+            std::lock_guard<std::mutex> lk(J.mu);
+            if (--J.pendingFinish == 0) J.cv.notify_all();
+        }
+    }
+}
+
+/* 1 if k_lsd_grow can take frames of this size: its `used` bitmap + member ring must fit the LDS of a CU, coordinates the
+ * 11-bit fields of the ordering keys */
+static bool device_grow_fits(int w, int h)
+{
+    const int sw = (int)std::rint(w * 0.8), sh = (int)std::rint(h * 0.8);
+    return sw <= 2048 && sh <= 2048 && sw >= 8 && sh >= 8 && drfe_lsd_grow_lds_bytes(sw, sh) <= 160 * 1024;
+}
+
+static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, int T, const uint8_t* gray, size_t frame_stride, int w, int h,
+                                    size_t stride, int nframes, int max_lines, drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap,
+                                    int* n_lines, int* n_detected)
+{
+    const auto tBegin = std::chrono::steady_clock::now();
+    int rc = ensure_lines(c->err, c->lsBatch, w, h, nframes, true, true);
+    if (rc != DRFE_OK) return rc;
+    LinesScratch* A = c->lsBatch;
+    static const LsdParams P;
+    /* at most four chunks: one hardware queue each (streams that share a queue run one behind the other) */
+    const int chunk = std::max(1, std::min(nframes, std::max(16, (nframes + 3) / 4)));
+    const int nChunks = (nframes + chunk - 1) / chunk;
+    BatchJob J(nChunks);
+    J.c = c; J.A = A; J.pool = pool; J.gray = gray; J.frameStride = frame_stride; J.stride = stride;
+    J.w = w; J.h = h; J.nframes = nframes; J.maxLines = max_lines; J.cap = cap;
+    J.lines = lines; J.ldesc = ldesc; J.lineF = line_f; J.nLines = n_lines; J.nDetected = n_detected;
+    J.chunk = chunk; J.nChunks = nChunks;
+    J.pendingFinish = nframes;
+    const RectValidator val(A->sw, A->sh);
+    J.prec = M_PI * 22.5 / 180; J.p = 22.5 / 180; J.minReg = (int)val.minReg(J.p);
+    for (int ch = 0; ch < nChunks; ch++) J.sortedInChunk[ch].store(0);
+    J.chunkStream.resize(nChunks); J.keysReady.resize(nChunks); J.growDone.resize(nChunks);
+    /* one stream per chunk: kernels of different chunks overlap, the work of one chunk stays ordered.  LOW priority: the
+     * runtime keeps a pool of hardware queues per priority, so the lanes' normal-priority streams (NFA counts, descriptors:
+     * microsecond kernels a host thread waits for) never queue behind a chunk that grows for a hundred milliseconds */
+    int prLow = 0, prHigh = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+    for (int ch = 0; ch < nChunks; ch++) {
+        HIPCHK(c, hipStreamCreateWithPriority(&J.chunkStream[ch], hipStreamNonBlocking, prLow));
+        HIPCHK(c, hipEventCreateWithFlags(&J.keysReady[ch], hipEventDisableTiming | hipEventBlockingSync));
+        HIPCHK(c, hipEventCreateWithFlags(&J.growDone[ch], hipEventDisableTiming | hipEventBlockingSync));
+    }
+    const size_t n = (size_t)w * h, ns = (size_t)A->sw * A->sh, nk = (size_t)(A->sw - 1) * (A->sh - 1);
+    int launchRc = DRFE_OK;
+    for (int ch = 0; ch < nChunks && launchRc == DRFE_OK; ch++) {
+        const int f0 = ch * chunk, nf = std::min(chunk, nframes - f0);
+        hipStream_t st = J.chunkStream[ch];
+        hipError_t e = hipSuccess;
+        if (stride == (size_t)w && frame_stride == n) e = hipMemcpyAsync(A->d_img + n * f0, gray + frame_stride * f0, n * nf, hipMemcpyHostToDevice, st);
+        else
+            for (int f = f0; f < f0 + nf && e == hipSuccess; f++)
+                e = hipMemcpy2DAsync(A->d_img + n * f, (size_t)w, gray + frame_stride * f, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = drfe_launch_lines_passes(A->d_img + n * f0, w, h, P.lsdTaps, P.lbdTaps, A, f0, nf, P.rho, st);
+        if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, nf, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(A->h_order + nk * f0, A->d_order + nk * f0, nk * 4 * nf, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(A->h_meta + 2 * (size_t)f0, A->d_meta + 2 * (size_t)f0, 16 * (size_t)nf, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(J.keysReady[ch], st);
+        if (e != hipSuccess) { c->err = std::string("lsd_extract_batch: image passes: ") + hipGetErrorString(e); launchRc = DRFE_ERR_HIP; }
+    }
+    const auto tLaunched = std::chrono::steady_clock::now();
+    if (launchRc == DRFE_OK) {
+        for (int f = 0; f < nframes; f++) J.sortQ.push_back(f);
+        std::vector<std::thread> th;
+        th.reserve(T);
+        for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { batch_worker(J, &(*pool)[k]); });
+        for (std::thread& t : th) t.join();
+    }
+    if (std::getenv("DRFE_TRACE_LINES"))
+        std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f, key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device\n",
+                     nframes, nChunks, chunk, T, std::chrono::duration<double, std::milli>(tLaunched - tBegin).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBegin).count(), J.usSort / 1e3 / nframes,
+                     J.usRectDl / 1e3 / nframes, J.usNfa / 1e3 / nframes, J.usKeyl / 1e3 / nframes, J.usFinish / 1e3 / nframes, J.usWait / 1e3 / T);
+    if (std::getenv("DRFE_LSD_PROFILE")) {       /* LSD_PROFILE builds of k_lsd_grow: phase times of frame 0 (100 MHz ticks -> ms) and counts */
+        const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
+        std::fprintf(stderr, "k_lsd_grow frame 0: total %.2f ms: bitmap %.2f, scan %.2f (%llu chunks), window loads %.2f (%llu groups), window growth %.2f (%llu regions, %llu member visits), "
+                     "queue growth %.2f (%llu steps), region2rect %.2f (%llu), refine incl. its growth %.2f\n", pr[7] / 1e5, pr[0] / 1e5, pr[1] / 1e5, pr[8], pr[2] / 1e5, pr[9], pr[3] / 1e5, pr[10], pr[11],
+                     pr[4] / 1e5, pr[12], pr[5] / 1e5, pr[13], pr[6] / 1e5);
+    }
+    for (int ch = 0; ch < nChunks; ch++) {
+        (void)hipStreamSynchronize(J.chunkStream[ch]);
+        (void)hipStreamDestroy(J.chunkStream[ch]);
+        (void)hipEventDestroy(J.keysReady[ch]); (void)hipEventDestroy(J.growDone[ch]);
+    }
+    if (launchRc != DRFE_OK) return launchRc;
+    if (J.firstRc != DRFE_OK) { c->err = J.firstErr; return J.firstRc; }
     return DRFE_OK;
 }
 
@@ -728,12 +1099,17 @@ int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
     return rc;
 }
 
-/* LineSegment::ExtractLineSegment for nframes host images at once.  The device passes are microseconds; the
- * sequential host stages (region growing, rectangle refinement, NFA: ~25 ms per 640x480 frame) are what a frame
- * costs, and they are independent between frames — so the batch runs on a pool of host threads, one lane (device
- * scratch + stream) per thread, the way the reference spreads its four extractors over four threads
- * (src/Frame.cc:116-126).  Outputs are per frame: lines[f * cap ..], ldesc[f * cap * 32 ..], line_f[f * cap * 3 ..],
- * n_lines[f], n_detected[f].  n_threads <= 0: one thread per frame up to the hardware concurrency. */
+/* where drfe_lsd_extract_batch grows its regions: 1 (default) on the device (k_lsd_grow, one wavefront per frame), 0 on the
+ * pool's host threads (the path of drfe_lsd_extract, frame by frame).  Results are identical. */
+int drfe_lsd_configure(drfe_ctx* c, int device_grow)
+{
+    if (!c || device_grow < 0 || device_grow > 1) { if (c) c->err = "lsd_configure: invalid argument"; return DRFE_ERR_INVALID; }
+    c->lsdDeviceGrow = device_grow;
+    return DRFE_OK;
+}
+
+/* LineSegment::ExtractLineSegment for nframes host images at once.  Outputs are per frame: lines[f * cap ..],
+ * ldesc[f * cap * 32 ..], line_f[f * cap * 3 ..], n_lines[f], n_detected[f].  n_threads <= 0: 1.25 threads per CPU. */
 int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride, int w, int h, size_t stride, int nframes,
                            int max_lines, drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines,
                            int* n_detected, int n_threads)
@@ -756,6 +1132,9 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
         lw.ownsStream = true;
         pool->push_back(lw);
     }
+    static const bool envHost = std::getenv("DRFE_LSD_HOST_GROW") != nullptr;
+    if (c->lsdDeviceGrow && !envHost && device_grow_fits(w, h))
+        return lsd_extract_batch_device(c, pool, T, gray, frame_stride, w, h, stride, nframes, max_lines, lines, ldesc, line_f, cap, n_lines, n_detected);
     std::vector<int> rcs(T, DRFE_OK);
     std::vector<std::thread> th;
     th.reserve(T);
@@ -802,6 +1181,13 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
     *n_segs = (int)(out.size() / 4);
     if (*n_segs > cap) return DRFE_ERR_CAPACITY;
     if (segs && !out.empty()) std::memcpy(segs, out.data(), out.size() * sizeof(float));
+    return DRFE_OK;
+}
+
+int drfe_debug_cr_sincos(const double* x, int n, double* s, double* c, int32_t* ok)
+{
+    if (!x || !s || !c || !ok || n < 0) return DRFE_ERR_INVALID;
+    for (int i = 0; i < n; i++) ok[i] = drfe_cr_sincos(x[i], &s[i], &c[i]);
     return DRFE_OK;
 }
 

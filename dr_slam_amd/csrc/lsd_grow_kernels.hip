@@ -1,0 +1,630 @@
+/* lsd_grow_kernels.hip — the sequential core of cv::LineSegmentDetectorImpl on the device: seed loop, region_grow,
+ * region2rect / get_theta, refine and reduce_region_radius (OpenCV 3.4 imgproc/src/lsd.cpp, the detector behind reference
+ * src/LSDextractor.cpp:12-43; restated for the host in lines_lsd.cpp and for the oracle in oracle/lsd_oracle.cpp).
+ *
+ * The loop is order-defined: seeds are visited in the pseudo-ordering, a region claims pixels through a `used` map the
+ * later seeds read, its running angle is a float sum in joining order, the rectangle moments are double sums in member
+ * order.  One frame is therefore ONE WAVEFRONT that executes the reference's sequence exactly - wave-uniform control flow,
+ * every order-defined value held identically by all lanes - and uses its 64 lanes where the sequence leaves room:
+ *   - the seed scan reads 64 entries of the ordering at a time; entries whose pixel is already claimed are skipped by a
+ *     ballot, and a seed none of whose free neighbours is aligned with its own angle is a one-pixel region whatever happens
+ *     before its turn (the free set only shrinks), so a run of such seeds ahead of the first growing one is retired in one
+ *     step;
+ *   - region_grow visits up to seven queued members per step: 63 lanes fetch the level-line angle and (cos, sin) of their
+ *     3 x 3 neighbours at once (the fields never change), then the members are resolved in order - per member one LDS read
+ *     of the neighbours' state, a ballot, and a scalar walk over the free ones with the running angle;
+ *   - products, coordinate differences, rectangle extents and the alignment statistics are lane-parallel; only the
+ *     additions of the order-defined sums run one member after the other (v_readlane + v_add_f64);
+ *   - reduce_region_radius' swap-with-last removal is evaluated in closed form (the k-th removed position below the new
+ *     size receives the k-th kept member from the back).
+ * The `used` map is a bitmap in LDS (24 KB at 512 x 384); member lists live in HBM with the newest 512 entries mirrored in
+ * LDS for the growth frontier.  Throughput comes from frames in flight: a frame is a dependency chain of ~10^5 steps, a
+ * launch carries one wavefront per frame and a CU holds as many as its LDS allows.
+ *
+ * cos / sin of region2rect and of the seed direction come from cr_sincos.h (correctly rounded, the same routine on the host
+ * path); a frame whose rounding cannot be certified, or whose rectangle list overflows, is flagged and redone on the host. */
+#include "drfe_internal.h"
+#include "lines_internal.h"
+#include "../../include/drfe_math.h"
+#include "cr_sincos.h"
+
+#define LSD_RING 512          /* newest members mirrored in LDS */
+#ifdef LSD_PROFILE
+#define PROF_T() wall_clock64()
+#define PROF_ADD(k, t0) w.prof[k] += wall_clock64() - (t0)
+#define PROF_CNT(k, v) w.prof[k] += (v)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(k, t0) (void)(t0)
+#define PROF_CNT(k, v) (void)0
+#endif
+
+namespace {
+
+__device__ __forceinline__ int rl_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float rl_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double rl_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+/* a wave-uniform condition as a scalar: keeps the control flow on the scalar unit and EXEC full */
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni_d(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+/* the frame's arrays as GLOBAL-address-space pointers: pointers read from the frame table are generic to the compiler, and a
+ * generic (flat) store counts against the LDS counter as well - every member appended would stall the next bitmap read for a
+ * full HBM round trip */
+#define GLOBAL_AS __attribute__((address_space(1)))
+struct FramePtrs {
+    const GLOBAL_AS double* ang; const GLOBAL_AS float* cs; const GLOBAL_AS double* mod; const GLOBAL_AS uint32_t* order;
+    GLOBAL_AS uint32_t* reg; GLOBAL_AS uint32_t* tmp; GLOBAL_AS double* rects; GLOBAL_AS int* out;
+    int nOrder; uint32_t minSeedBin;
+};
+
+struct Wave {
+    FramePtrs F;
+    uint32_t* bm;             /* LDS: bit set = pixel cannot join (claimed, or no level-line angle) */
+    uint32_t* ring;           /* LDS: reg[j] for the newest LSD_RING members at ring[j & (LSD_RING - 1)] */
+    int W, H, lane;
+    int status;
+#ifdef LSD_PROFILE
+    unsigned long long prof[16];
+#endif
+
+    __device__ __forceinline__ bool bit(uint32_t q) const { return (bm[q >> 5] >> (q & 31)) & 1u; }
+    __device__ __forceinline__ void set_bit_uniform(uint32_t q)           /* q wave-uniform */
+    {
+        if (lane == 0) atomicOr(&bm[q >> 5], 1u << (q & 31));      /* ds_or_b32 without return: nothing to wait for */
+    }
+};
+
+/* the two libm replacements as real functions: one copy each in the code object (inlined at their seven call sites they
+ * pushed the kernel past the 64 KB instruction cache) */
+struct SinCos { double s, c; int ok; };
+struct SinCosF { float s, c; int ok; };
+__device__ __noinline__ SinCos cr_sincos_call(double x)
+{
+    SinCos r;
+    r.ok = drfe_cr_sincos(x, &r.s, &r.c);
+    return r;
+}
+__device__ __noinline__ SinCosF cr_sincos_f_call(double x)
+{
+    SinCosF r;
+    r.ok = drfe_cr_sincos_f(x, &r.s, &r.c);
+    return r;
+}
+
+__device__ __forceinline__ bool aligned_with(double theta, double a, double prec)
+{
+    double n = theta - a;
+    if (n < 0) n = -n;
+    if (n > 3.0 * 3.14159265358979323846 / 2.0) { n -= 2.0 * 3.14159265358979323846; if (n < 0) n = -n; }
+    return n <= prec;
+}
+
+/* The 7 x 7 neighbourhood of a seed, one pixel per lane (lane t < 49 holds pixel (sx - 3 + t % 7, sy - 3 + t / 7)): level-line
+ * angle and (cos, sin), fetched once per seed - and for the next seeds of the scan ahead of their turn, the fields never
+ * change.  A region that stays inside it (nineteen in twenty do) grows without touching memory again: the neighbourhood's
+ * state is a 49-bit scalar mask. */
+struct Window { double a; float2 c; };
+
+__device__ __forceinline__ Window load_window(const Wave& w, int sx, int sy)
+{
+    Window win;
+    win.a = 0.0; win.c = make_float2(0.f, 0.f);
+    const int t = w.lane, wy = (t * 37) >> 8, wx = t - 7 * wy;
+    const int px = sx - 3 + wx, py = sy - 3 + wy;
+    if (t < 49 && px >= 0 && py >= 0 && px < w.W && py < w.H) {
+        const size_t q = (size_t)py * w.W + px;
+        win.a = w.F.ang[q]; win.c = make_float2(w.F.cs[2 * q], w.F.cs[2 * q + 1]);
+    }
+    return win;
+}
+
+/* region_grow from seed (sx, sy): members to F.reg[0..n), their pixels claimed in the bitmap.  Returns n; regAngle out.
+ * win = load_window(sx, sy) */
+__device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double& regAngleOut, const Window& win)
+{
+    const int W = w.W, H = w.H, lane = w.lane;
+    const double kDeg2Rad = 3.14159265358979323846 / 180.0;
+    const uint32_t seedQ = (uint32_t)(sy * W + sx);
+    const double seedAngle = rl_f64(win.a, 24);
+    double regAngle = seedAngle;
+    float sumdx = 0.f, sumdy = 0.f;
+    bool seeded = false;
+    int n = 1, i = 0;
+    if (lane == 0) { w.F.reg[0] = (uint32_t)(sy << 16 | sx); w.ring[0] = (uint32_t)(sy << 16 | sx); }
+    w.set_bit_uniform(seedQ);
+    const unsigned long long tg0 = PROF_T();
+    PROF_CNT(10, 1);
+    {
+        /* inside the window: state of its pixels as a scalar mask, members as window indices in the lanes of `member` */
+        const int wy0 = (lane * 37) >> 8, wx0 = lane - 7 * wy0;
+        const int px = sx - 3 + wx0, py = sy - 3 + wy0;
+        const bool inw = lane < 49 && px >= 0 && py >= 0 && px < W && py < H;
+        unsigned long long wfree = __ballot(inw && !w.bit((uint32_t)(py * W + px)));
+        /* which window pixels are aligned with the running angle: every lane tests its own pixel, so a member's probes are
+         * scalar mask arithmetic and only a JOIN (which moves the angle) costs vector work */
+        unsigned long long walign = __ballot(lane < 49 && aligned_with(regAngle, win.a, prec));
+        int member = 24;                               /* lane j: window index of member j */
+        while (i < n) {
+            const int t = rl_i32(member, i);
+            const int ty = (t * 37) >> 8, tx = t - 7 * ty;
+            if (tx == 0 || tx == 6 || ty == 0 || ty == 6) break;          /* its neighbours leave the window */
+            unsigned long long nb = 0x1C287ull << (t - 8);                /* the 3 x 3 ring around t, raster order */
+            for (;;) {
+                const unsigned long long hit = nb & wfree & walign;       /* free neighbours that join now */
+                if (!hit) break;
+                const int l = __builtin_ctzll(hit);
+                nb &= ~((2ull << l) - 1ull);                              /* the probes behind it come after the join */
+                const int ly = (l * 37) >> 8, lx = l - 7 * ly;
+                const int jx = sx - 3 + lx, jy = sy - 3 + ly;
+                wfree &= ~(1ull << l);
+                w.set_bit_uniform((uint32_t)(jy * W + jx));
+                if (lane == 0) { w.F.reg[n] = (uint32_t)(jy << 16 | jx); w.ring[n & (LSD_RING - 1)] = (uint32_t)(jy << 16 | jx); }
+                member = lane == n ? l : member;
+                n++;
+                if (!seeded) {
+                    /* only regions that get a second member need the seed's direction */
+                    const SinCosF sc = cr_sincos_f_call(seedAngle);
+                    sumdx = sc.c; sumdy = sc.s;
+                    if (!sc.ok) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
+                    seeded = true;
+                }
+                sumdx += rl_f32(win.c.x, l);
+                sumdy += rl_f32(win.c.y, l);
+                regAngle = (double)drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
+                walign = __ballot(lane < 49 && aligned_with(regAngle, win.a, prec));
+            }
+            i++;
+        }
+    }
+    PROF_ADD(3, tg0);
+    PROF_CNT(11, i);
+    const unsigned long long tg1 = PROF_T();
+    /* beyond the window: up to seven queued members per step, their neighbours' fields fetched together */
+    const int m = lane / 9, k = lane - 9 * m;
+    const int dyk = k / 3 - 1, dxk = k - 3 * (k / 3) - 1;
+    while (i < n) {
+        const int cnt = min(7, n - i);
+        const bool act = m < cnt && lane < 63 && k != 4;
+        uint32_t mxy = 0;
+        if (uni(n - i <= LSD_RING)) { if (act) mxy = w.ring[(i + m) & (LSD_RING - 1)]; }
+        else { wg_fence(); if (act) mxy = w.F.reg[i + m]; }
+        const int nx = (int)(mxy & 0xFFFFu) + dxk, ny = (int)(mxy >> 16) + dyk;
+        const bool inb = act && nx >= 0 && ny >= 0 && nx < W && ny < H;
+        const uint32_t q = inb ? (uint32_t)(ny * W + nx) : 0u;
+        /* fields of the neighbours that are free now (a superset of those free when their member's turn comes) */
+        const bool want = inb && !w.bit(q);
+        double a = 0.0;
+        float2 c = make_float2(0.f, 0.f);
+        if (want) { a = w.F.ang[q]; c = make_float2(w.F.cs[2 * (size_t)q], w.F.cs[2 * (size_t)q + 1]); }
+        const uint32_t nxy = (uint32_t)(ny << 16 | nx);
+        for (int mm = 0; mm < cnt; mm++) {
+            const bool fb = want && m == mm && !w.bit(q);
+            unsigned long long mask = __ballot(fb);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const double av = rl_f64(a, l);
+                if (uni(aligned_with(regAngle, av, prec))) {
+                    const uint32_t ql = rl_u32(q, l), xy = rl_u32(nxy, l);
+                    w.set_bit_uniform(ql);
+                    if (lane == 0) { w.F.reg[n] = xy; w.ring[n & (LSD_RING - 1)] = xy; }
+                    n++;
+                    if (!seeded) {
+                        /* only regions that get a second member need the seed's direction */
+                        const SinCosF sc = cr_sincos_f_call(seedAngle);
+                        sumdx = sc.c; sumdy = sc.s;
+                        if (!sc.ok) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
+                        seeded = true;
+                    }
+                    sumdx += rl_f32(c.x, l);
+                    sumdy += rl_f32(c.y, l);
+                    regAngle = (double)drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
+                }
+            }
+        }
+        i += cnt;
+        PROF_CNT(12, 1);
+    }
+    PROF_ADD(4, tg1);
+    regAngleOut = regAngle;
+    return n;
+}
+
+struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
+
+__device__ __forceinline__ double sq(double v) { return v * v; }
+__device__ __forceinline__ double dist2d(double x1, double y1, double x2, double y2) { return sqrt(sq(x2 - x1) + sq(y2 - y1)); }
+__device__ __forceinline__ double diff_signed(double a, double b)
+{
+    double d = a - b;
+    while (d <= -3.14159265358979323846) d += 2.0 * 3.14159265358979323846;
+    while (d > 3.14159265358979323846) d -= 2.0 * 3.14159265358979323846;
+    return d;
+}
+
+/* region2rect (with get_theta) over F.reg[0..n): sums in member order, extents by wave reduction.  fromRing: the region
+ * was just grown and has at most LSD_RING members, so the LDS mirror holds all of them (not after reduce_region_radius, which
+ * reorders the list in HBM only).  A region of at most 64 members is fetched once and stays in registers for the three passes. */
+__device__ __forceinline__ void to_rect(Wave& w, int n, double regAngle, double prec, Rect& rec, bool fromRing)
+{
+    const int lane = w.lane, W = w.W;
+    const double kDeg2Rad = 3.14159265358979323846 / 180.0;
+    const unsigned long long tr0 = PROF_T();
+    PROF_CNT(13, 1);
+    const bool ring = fromRing && n <= LSD_RING, cached = n <= 64;
+    if (!ring) wg_fence();
+    int cmx = 0, cmy = 0;
+    double cmg = 0;
+    if (cached && lane < n) {
+        const uint32_t xy = ring ? w.ring[lane] : w.F.reg[lane];
+        cmx = (int)(xy & 0xFFFFu); cmy = (int)(xy >> 16);
+        cmg = w.F.mod[(size_t)cmy * W + cmx];
+    }
+    double x = 0, y = 0, sum = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane, cnt = min(64, n - base);
+        double px = 0, py = 0, mg = 0;
+        if (j < n) {
+            int mx = cmx, my = cmy;
+            mg = cmg;
+            if (!cached) {
+                const uint32_t xy = ring ? w.ring[j & (LSD_RING - 1)] : w.F.reg[j];
+                mx = (int)(xy & 0xFFFFu); my = (int)(xy >> 16);
+                mg = w.F.mod[(size_t)my * W + mx];
+            }
+            px = (double)mx * mg; py = (double)my * mg;
+        }
+        for (int t = 0; t < cnt; t++) { x += rl_f64(px, t); y += rl_f64(py, t); sum += rl_f64(mg, t); }
+    }
+    x /= sum; y /= sum;
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane, cnt = min(64, n - base);
+        double a = 0, b = 0, c = 0;
+        if (j < n) {
+            int mx = cmx, my = cmy;
+            double mg = cmg;
+            if (!cached) {
+                const uint32_t xy = ring ? w.ring[j & (LSD_RING - 1)] : w.F.reg[j];
+                mx = (int)(xy & 0xFFFFu); my = (int)(xy >> 16);
+                mg = w.F.mod[(size_t)my * W + mx];
+            }
+            const double dx = (double)mx - x, dy = (double)my - y;
+            a = dy * dy * mg; b = dx * dx * mg; c = dx * dy * mg;
+        }
+        for (int t = 0; t < cnt; t++) { Ixx += rl_f64(a, t); Iyy += rl_f64(b, t); Ixy -= rl_f64(c, t); }
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)drfe_fast_atan2((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)drfe_fast_atan2((float)Ixy, (float)(lambda - Iyy));
+    theta *= kDeg2Rad;
+    if (fabs(diff_signed(theta, regAngle)) > prec) theta += 3.14159265358979323846;
+    theta = uni_d(theta);
+    const SinCos sc = cr_sincos_call(theta);
+    const double dx = sc.c, dy = sc.s;
+    if (!sc.ok) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
+    double lmin = 0, lmax = 0, wmin = 0, wmax = 0;
+    for (int j = lane; j < n; j += 64) {
+        int mx = cmx, my = cmy;
+        if (!cached) {
+            const uint32_t xy = ring ? w.ring[j & (LSD_RING - 1)] : w.F.reg[j];
+            mx = (int)(xy & 0xFFFFu); my = (int)(xy >> 16);
+        }
+        const double rx = (double)mx - x, ry = (double)my - y;
+        const double l = rx * dx + ry * dy, ww = -rx * dy + ry * dx;
+        lmax = fmax(lmax, l); lmin = fmin(lmin, l);
+        wmax = fmax(wmax, ww); wmin = fmin(wmin, ww);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lmax = fmax(lmax, __shfl_xor(lmax, o)); lmin = fmin(lmin, __shfl_xor(lmin, o));
+        wmax = fmax(wmax, __shfl_xor(wmax, o)); wmin = fmin(wmin, __shfl_xor(wmin, o));
+    }
+    rec.x1 = x + lmin * dx; rec.y1 = y + lmin * dy; rec.x2 = x + lmax * dx; rec.y2 = y + lmax * dy;
+    rec.width = wmax - wmin;
+    rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
+    if (rec.width < 1.0) rec.width = 1.0;
+    PROF_ADD(5, tr0);
+}
+
+__device__ __forceinline__ double density_of(const Rect& rec, int n)
+{
+    return (double)n / (dist2d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+}
+
+/* reduce_region_radius: members farther than the shrinking radius from the seed are released and removed by
+ * swap-with-last; the surviving order (it feeds the next region2rect's sums) in closed form */
+__device__ __forceinline__ bool shrink(Wave& w, int& n, double regAngle, double prec, Rect& rec, double density, double densityTh)
+{
+    const int lane = w.lane, W = w.W;
+    wg_fence();
+    const uint32_t xy0 = w.F.reg[0];
+    const double xc = (double)(int)(xy0 & 0xFFFFu), yc = (double)(int)(xy0 >> 16);
+    const double r1 = sq(rec.x1 - xc) + sq(rec.y1 - yc), r2 = sq(rec.x2 - xc) + sq(rec.y2 - yc);
+    double radSq = r1 > r2 ? r1 : r2;
+    while (uni(density < densityTh)) {
+        radSq *= 0.75 * 0.75;
+        /* members kept; the removed ones are released */
+        int K = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int j = base + lane;
+            bool good = false;
+            if (j < n) {
+                const uint32_t xy = w.F.reg[j];
+                const int mx = (int)(xy & 0xFFFFu), my = (int)(xy >> 16);
+                good = !(sq((double)mx - xc) + sq((double)my - yc) > radSq);
+                if (!good) { const uint32_t q = (uint32_t)(my * W + mx); atomicAnd(&w.bm[q >> 5], ~(1u << (q & 31))); }
+            }
+            K += __popcll(__ballot(good));
+        }
+        if (K < n) {
+            /* kept members at positions >= K, from the back */
+            int cf = 0;
+            for (int base = ((n - 1) >> 6) << 6; base >= 0 && base + 63 >= K; base -= 64) {
+                const int j = base + lane;
+                bool f = false;
+                uint32_t xy = 0;
+                if (j >= K && j < n) {
+                    xy = w.F.reg[j];
+                    f = !(sq((double)(int)(xy & 0xFFFFu) - xc) + sq((double)(int)(xy >> 16) - yc) > radSq);
+                }
+                const unsigned long long mk = __ballot(f);
+                if (f) w.F.tmp[cf + __popcll(lane < 63 ? (mk >> (lane + 1)) : 0ull)] = xy;
+                cf += __popcll(mk);
+            }
+            wg_fence();
+            /* removed positions below K, ascending, take them in that order */
+            int cb = 0;
+            for (int base = 0; base < K; base += 64) {
+                const int j = base + lane;
+                bool b = false;
+                if (j < K) {
+                    const uint32_t xy = w.F.reg[j];
+                    b = sq((double)(int)(xy & 0xFFFFu) - xc) + sq((double)(int)(xy >> 16) - yc) > radSq;
+                }
+                const unsigned long long mk = __ballot(b);
+                if (b) w.F.reg[j] = w.F.tmp[cb + __popcll(mk & ((1ull << lane) - 1ull))];
+                cb += __popcll(mk);
+            }
+            n = K;
+        }
+        if (n < 2) return false;
+        to_rect(w, n, regAngle, prec, rec, false);
+        density = density_of(rec, n);
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double prec, Rect& rec, double densityTh, const Window& win)
+{
+    const int lane = w.lane, W = w.W;
+    double density = density_of(rec, n);
+    if (uni(density >= densityTh)) return true;
+    wg_fence();
+    const uint32_t xy0 = w.F.reg[0];
+    const int sx = (int)(xy0 & 0xFFFFu), sy = (int)(xy0 >> 16);
+    const double xc = (double)sx, yc = (double)sy, angC = w.F.ang[(size_t)sy * W + sx];
+    double sum = 0, ssum = 0;
+    int cntIn = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        bool in = false;
+        double d = 0, dd = 0;
+        if (j < n) {
+            const uint32_t xy = w.F.reg[j];
+            const int mx = (int)(xy & 0xFFFFu), my = (int)(xy >> 16);
+            const uint32_t q = (uint32_t)(my * W + mx);
+            atomicAnd(&w.bm[q >> 5], ~(1u << (q & 31)));
+            if (dist2d(xc, yc, (double)mx, (double)my) < rec.width) {
+                in = true;
+                d = diff_signed(w.F.ang[q], angC);
+                dd = d * d;
+            }
+        }
+        unsigned long long mk = __ballot(in);
+        cntIn += __popcll(mk);
+        while (mk) {
+            const int l = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            sum += rl_f64(d, l); ssum += rl_f64(dd, l);
+        }
+    }
+    const double mean = sum / (double)cntIn;
+    const double tau = 2.0 * sqrt((ssum - 2.0 * mean * sum) / (double)cntIn + mean * mean);
+    n = grow(w, sx, sy, uni_d(tau), regAngle, win);
+    if (n < 2) return false;
+    to_rect(w, n, regAngle, prec, rec, true);
+    density = density_of(rec, n);
+    if (uni(density < densityTh)) return shrink(w, n, regAngle, prec, rec, density, densityTh);
+    return true;
+}
+
+} // namespace
+
+extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* __restrict__ frames, int W, int H, double prec, double p,
+                                                            int minReg, double densityTh, int rectCap)
+{
+    extern __shared__ uint32_t lds[];
+    Wave w;
+    {
+        const LsdGrowFrame f = frames[blockIdx.x];
+        w.F.ang = (const GLOBAL_AS double*)f.ang; w.F.cs = (const GLOBAL_AS float*)f.cs; w.F.mod = (const GLOBAL_AS double*)f.mod;
+        w.F.order = (const GLOBAL_AS uint32_t*)f.order; w.F.reg = (GLOBAL_AS uint32_t*)f.reg; w.F.tmp = (GLOBAL_AS uint32_t*)f.tmp;
+        w.F.rects = (GLOBAL_AS double*)f.rects; w.F.out = (GLOBAL_AS int*)f.out; w.F.nOrder = f.nOrder; w.F.minSeedBin = f.minSeedBin;
+    }
+    w.W = W; w.H = H; w.lane = threadIdx.x; w.status = 0;
+#ifdef LSD_PROFILE
+    for (int k = 0; k < 16; k++) w.prof[k] = 0;
+#endif
+    const unsigned long long tAll = PROF_T();
+    const int lane = w.lane, npx = W * H, nWords = (npx + 31) >> 5;
+    w.bm = lds;
+    w.ring = lds + ((nWords + 1) & ~1);
+    /* bitmap: pixels without a level-line angle never join (NOTDEF, incl. the last row and column) */
+    for (int base = 0; base < npx; base += 256) {
+        bool nd[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = base + 64 * u + lane; nd[u] = q >= npx || w.F.ang[q] == -1024.0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long b = __ballot(nd[u]);
+            const int wd = (base >> 5) + 2 * u;
+            if (lane == 0) { if (wd < nWords) w.bm[wd] = (uint32_t)b; if (wd + 1 < nWords) w.bm[wd + 1] = (uint32_t)(b >> 32); }
+        }
+    }
+    PROF_ADD(0, tAll);
+    int nRects = 0;
+    const int nOrder = w.F.nOrder;
+    const uint32_t minSeedBin = w.F.minSeedBin;
+    bool done = false;
+    for (int base = 0; base < nOrder && !done; base += 64) {
+        const unsigned long long ts0 = PROF_T();
+        PROF_CNT(8, 1);
+        const int pos = base + lane;
+        uint32_t key = 0;
+        bool valid = false;
+        if (pos < nOrder) { key = w.F.order[pos]; valid = (key >> 22) >= minSeedBin; }
+        if (__ballot(!valid)) done = true;                     /* bins descend: nothing seeds from the first low bin on */
+        const int sx = (int)(key & 0x7FFu), sy = (int)((key >> 11) & 0x7FFu);
+        const uint32_t q = (uint32_t)(sy * W + sx);
+        const bool cand = valid && !w.bit(q);
+        if (!__ballot(cand)) { PROF_ADD(1, ts0); continue; }
+        /* does any free neighbour join on the seed's own angle?  If not now, then not at its turn either: the free set only
+         * shrinks, so such a seed is a one-pixel region (or dead) whatever happens before it */
+        bool nontrivial = false;
+        if (cand) {
+            const double sa = w.F.ang[q];
+            double na[8];
+            bool nf[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int jj = j < 4 ? j : j + 1, dx = jj % 3 - 1, dy = jj / 3 - 1;
+                const int nx = sx + dx, ny = sy + dy;
+                const bool inb = nx >= 0 && ny >= 0 && nx < W && ny < H;
+                const uint32_t nq = inb ? (uint32_t)(ny * W + nx) : 0u;
+                nf[j] = inb && !w.bit(nq);
+                na[j] = nf[j] ? w.F.ang[nq] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) nontrivial |= nf[j] && aligned_with(sa, na[j], prec);
+        }
+        int from = 0;
+        unsigned long long pend = __ballot(cand && nontrivial);
+        PROF_ADD(1, ts0);
+        while (pend) {
+            const unsigned long long tw0 = PROF_T();
+            PROF_CNT(9, 1);
+            /* the next (up to) four growing seeds: their windows fetched together */
+            int lk[4], cnt = 0;
+            while (pend && cnt < 4) { lk[cnt++] = __builtin_ctzll(pend); pend &= pend - 1; }
+            Window w0 = load_window(w, rl_i32(sx, lk[0]), rl_i32(sy, lk[0])), w1 = w0, w2 = w0, w3 = w0;
+            if (cnt > 1) w1 = load_window(w, rl_i32(sx, lk[1]), rl_i32(sy, lk[1]));
+            if (cnt > 2) w2 = load_window(w, rl_i32(sx, lk[2]), rl_i32(sy, lk[2]));
+            if (cnt > 3) w3 = load_window(w, rl_i32(sx, lk[3]), rl_i32(sy, lk[3]));
+#ifdef LSD_PROFILE
+            if (w0.a + w1.a + w2.a + w3.a == 12345.678) w.status |= 4;         /* wait for the loads here */
+#endif
+            PROF_ADD(2, tw0);
+            uint32_t packed = (uint32_t)lk[0] | (uint32_t)(cnt > 1 ? lk[1] : 0) << 8 | (uint32_t)(cnt > 2 ? lk[2] : 0) << 16 | (uint32_t)(cnt > 3 ? lk[3] : 0) << 24;
+            for (int k = 0; k < cnt; k++) {
+                const int f = (int)(packed & 0xFFu);
+                packed >>= 8;
+                /* one-pixel regions between the previous growing seed and this one */
+                if (cand && !nontrivial && lane >= from && lane < f && !w.bit(q)) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+                from = f + 1;
+                const int gx = rl_i32(sx, f), gy = rl_i32(sy, f);
+                if (!uni(w.bit((uint32_t)(gy * W + gx)))) {
+                    double regAngle;
+                    int n = grow(w, gx, gy, prec, regAngle, w0);
+                    if (n >= minReg) {
+                        Rect rec;
+                        to_rect(w, n, regAngle, prec, rec, true);
+                        const unsigned long long tf0 = PROF_T();
+                        const bool okr = refine(w, n, regAngle, prec, rec, densityTh, w0);
+                        PROF_ADD(6, tf0);
+                        if (okr) {
+                            if (nRects < rectCap) {
+                                if (lane == 0) {
+                                    const double o[12] = {rec.x1, rec.y1, rec.x2, rec.y2, rec.width, rec.x, rec.y, rec.theta, rec.dx, rec.dy, prec, p};   /* LsdRect */
+                                    for (int k = 0; k < 12; k++) w.F.rects[(size_t)nRects * 12 + k] = o[k];
+                                }
+                                nRects++;
+                            } else w.status |= DRFE_LSD_STATUS_OVERFLOW;
+                        }
+                    }
+                }
+                w0 = w1; w1 = w2; w2 = w3;
+            }
+        }
+        if (cand && !nontrivial && lane >= from && !w.bit(q)) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+    }
+    if (lane == 0) { w.F.out[0] = nRects; w.F.out[1] = w.status; }
+#ifdef LSD_PROFILE
+    PROF_ADD(7, tAll);
+    if (lane == 0) for (int k = 0; k < 16; k++) ((GLOBAL_AS unsigned long long*)(w.F.out + 4))[k] = w.prof[k];
+#endif
+}
+
+/* pseudo-ordering keys: gradient bin << 22 | y << 11 | x for the (W - 1) x (H - 1) pixels ll_angle visits, in raster order
+ * (what the host sorts), and the smallest bin of a pixel that has a level-line angle (kept as 1024 - bin under atomicMax in
+ * the low half of the slot's second meta word, which the image passes zeroed).  blockIdx.z = frame slot. */
+__global__ __launch_bounds__(256) void k_lsd_keys(const double* __restrict__ mod, const double* __restrict__ ang, int W, int H,
+                                                  unsigned long long* __restrict__ meta, uint32_t* __restrict__ keys)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    mod += (size_t)blockIdx.z * W * H; ang += (size_t)blockIdx.z * W * H;
+    meta += 2 * (size_t)blockIdx.z; keys += (size_t)blockIdx.z * (W - 1) * (H - 1);
+    uint32_t seedBin = 1024;
+    if (x < W - 1) {
+        const unsigned long long mb = meta[0];
+        const double maxGrad = mb ? __longlong_as_double((long long)mb) : -1.0;
+        const double binCoef = (maxGrad > 0) ? (double)(1024 - 1) / maxGrad : 0;
+        const size_t o = (size_t)y * W + x;
+        const uint32_t bin = (uint32_t)(int)(mod[o] * binCoef);
+        keys[(size_t)y * (W - 1) + x] = (bin << 22) | ((uint32_t)y << 11) | (uint32_t)x;
+        if (ang[o] != -1024.0) seedBin = bin;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) seedBin = min(seedBin, (uint32_t)__shfl_xor((int)seedBin, o));
+    if ((threadIdx.x & 63) == 0 && seedBin < 1024) atomicMax((uint32_t*)(meta + 1), 1024u - seedBin);
+}
+
+size_t drfe_lsd_grow_lds_bytes(int W, int H)
+{
+    const size_t nWords = ((size_t)W * H + 31) >> 5;
+    return (((nWords + 1) & ~(size_t)1) + LSD_RING) * 4;
+}
+
+hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
+                                int nframes, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lsd_keys, dim3((W - 1 + 255) / 256, H - 1, nframes), dim3(256), 0, s, d_mod, d_ang, W, H, d_meta, d_keys);
+    return hipGetLastError();
+}
+
+hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W, int H, double prec, double p, int minReg,
+                                double densityTh, int rectCap, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    const size_t lds = drfe_lsd_grow_lds_bytes(W, H);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lsd_grow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_lsd_grow, dim3(nframes), dim3(64), lds, s, d_frames, W, H, prec, p, minReg, densityTh, rectCap);
+    return hipGetLastError();
+}

@@ -40,6 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
+    "drfe_lsd_configure", "drfe_debug_cr_sincos",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -197,6 +198,8 @@ def load() -> C.CDLL:
     L.drfe_surface_normals_batch.argtypes = [vp, vp, sz, sz, i32, i32, vp, f32, f32, i32, vp]
     L.drfe_surface_normals_download.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_segments_host.argtypes = [vp, vp, vp, i32, i32, f64, vp, i32, C.POINTER(i32)]
+    L.drfe_lsd_configure.argtypes = [vp, i32]
+    L.drfe_debug_cr_sincos.argtypes = [vp, i32, vp, vp, vp]
     L.drfe_profile_enable.argtypes = [vp, i32]
     L.drfe_profile_stage_ms.argtypes = [vp, vp]
     L.drfe_stream_sync.argtypes = [vp]
@@ -806,9 +809,14 @@ class Context:
             out.update(scaled=scaled, modgrad=modgrad, angles=angles, gx=gx, gy=gy)
         return out
 
+    def lsd_configure(self, device_grow=True):
+        """Where lsd_extract_batch grows its regions: on the device (one wavefront per frame, default) or on the host pool."""
+        self._chk(self.L.drfe_lsd_configure(self.h, 1 if device_grow else 0), "drfe_lsd_configure")
+
     def lsd_extract_batch(self, gray_batch: np.ndarray, max_lines=40, n_threads=0):
-        """LineSegment::ExtractLineSegment for a [B, H, W] uint8 host array on a pool of host threads (one device lane
-        each); returns a list of dicts like lsd_extract."""
+        """LineSegment::ExtractLineSegment for a [B, H, W] uint8 host array: region growing on the device (or, after
+        lsd_configure(False), on the host pool), ordering + NFA on a pool of host threads; returns a list of dicts like
+        lsd_extract."""
         g = np.ascontiguousarray(gray_batch, np.uint8)
         B, h, w = g.shape
         cap = max_lines

@@ -300,15 +300,25 @@ int drfe_lsd_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t st
  * floats (x1, y1, x2, y2 in input-image coordinates).  Host code: CPU tests and profiling. */
 int drfe_lsd_segments_host(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad, float* segs,
                            int cap, int* n_segs);
-/* The same for nframes host images (gray + f * frame_stride): the sequential host stages of LSD (~25 ms per 640x480
- * frame) are independent between frames and run on a pool of n_threads host threads, one device lane (scratch +
- * stream) each — frames instead of the reference's four extractors across threads (src/Frame.cc:116-126).  Outputs per
- * frame f at lines[f * cap], ldesc[f * cap * 32], line_f[f * cap * 3], n_lines[f], n_detected[f]; results are identical
- * to nframes calls of drfe_lsd_extract.  n_threads <= 0: 1.25 x the CPUs this process may use (affinity mask clipped by the cgroup
- * quota; a lane sleeps in stream synchronisations for about a fifth of a frame's time). */
+/* The same for nframes host images (gray + f * frame_stride).  Default (drfe_lsd_configure(ctx, 1)): the detector's
+ * sequential core - seed loop, region_grow, region2rect, refine - runs on the DEVICE, one wavefront per frame executing the
+ * reference's order of operations (lsd_grow_kernels.hip), frames in flight side by side; the host keeps std::sort's
+ * permutation of the pixel ordering and the NFA arithmetic (libm) and runs them on a pool of n_threads host threads.
+ * drfe_lsd_configure(ctx, 0): every frame through drfe_lsd_extract's host path on the pool, one device lane per thread
+ * (frames instead of the reference's four extractors across threads, src/Frame.cc:116-126).  Outputs per frame f at
+ * lines[f * cap], ldesc[f * cap * 32], line_f[f * cap * 3], n_lines[f], n_detected[f]; results are identical to nframes
+ * calls of drfe_lsd_extract either way.  n_threads <= 0: 1.25 x the CPUs this process may use (affinity mask clipped by the
+ * cgroup quota). */
 int drfe_lsd_extract_batch(drfe_ctx* ctx, const uint8_t* gray, size_t frame_stride, int w, int h, size_t stride, int nframes,
                            int max_lines, drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines,
                            int* n_detected, int n_threads);
+/* 1 (default): drfe_lsd_extract_batch grows regions on the device; 0: on the host threads.  Frames whose 0.8-scaled size
+ * exceeds the device path's LDS bitmap (about 1.2 M pixels) take the host path regardless. */
+int drfe_lsd_configure(drfe_ctx* ctx, int device_grow);
+/* Test hook of dr_slam_amd/csrc/cr_sincos.h: correctly rounded sin / cos of n doubles in [0, 64) (host build of the routine the
+ * device path uses for region2rect's direction and region_grow's seed direction); ok[i] = 0 where the rounding could not be
+ * certified.  Host code. */
+int drfe_debug_cr_sincos(const double* x, int n, double* s, double* c, int32_t* ok);
 /* Parity taps of the device image passes of the last drfe_lsd_extract call (any pointer may be NULL):
  * 0.8-scaled image, gradient magnitude and level-line angle (sw x sh), Sobel dx/dy of the LBD image. */
 int drfe_lsd_stages(drfe_ctx* ctx, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy,

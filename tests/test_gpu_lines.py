@@ -142,19 +142,87 @@ def test_lsd_search_by_projection_empty(ctx):
     assert n == 0 and len(ml) == 0
 
 
-def test_lsd_extract_batch_equals_single(ctx):
-    """drfe_lsd_extract_batch (host thread pool, one device lane per thread) == per-frame calls, any thread count."""
+def _same_lines(a, b):
+    assert a["detected"] == b["detected"] and len(a["lines"]) == len(b["lines"])
+    assert np.array_equal(a["lines"].view(np.uint8), b["lines"].view(np.uint8))
+    assert np.array_equal(a["desc"], b["desc"])
+    assert np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
+
+
+@pytest.mark.parametrize("device_grow", [True, False])
+def test_lsd_extract_batch_equals_single(ctx, device_grow):
+    """drfe_lsd_extract_batch == per-frame calls for any thread count, with region growing on the device (k_lsd_grow: one
+    wavefront per frame replays the detector's seed loop) and on the host pool."""
     from dr_slam_amd import synth
     frames = [f[0] for f in synth.sequence(2, 6, kind="room_boxes")] + [_frame(5, "corridor")]
     single = [ctx.lsd_extract(g) for g in frames]
-    for threads in (1, 3, 16):
-        batch = ctx.lsd_extract_batch(np.stack(frames), n_threads=threads)
-        assert len(batch) == len(frames)
-        for a, b in zip(batch, single):
-            assert a["detected"] == b["detected"] and len(a["lines"]) == len(b["lines"]) > 5
-            assert np.array_equal(a["lines"].view(np.uint8), b["lines"].view(np.uint8))
-            assert np.array_equal(a["desc"], b["desc"])
-            assert np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
+    ctx.lsd_configure(device_grow)
+    try:
+        for threads in (1, 3, 16):
+            batch = ctx.lsd_extract_batch(np.stack(frames), n_threads=threads)
+            assert len(batch) == len(frames)
+            for a, b in zip(batch, single):
+                assert len(a["lines"]) > 5
+                _same_lines(a, b)
+    finally:
+        ctx.lsd_configure(True)
+
+
+@pytest.mark.parametrize("kind,seed", [("living_room", 3), ("room_boxes", 7), ("corridor", 5), ("planar_lowtexture", 4)])
+def test_lsd_device_grow_matches_oracle(ctx, oracle_mod, kind, seed):
+    """The device region growing against the CPU oracle (own restatement, glibc cos / sin) on every scene kind: key lines,
+    LBD descriptors and line equations of 12 frames per kind, bit for bit; more chunks than one (chunking is by 16 frames)."""
+    from dr_slam_amd import synth
+    frames = [f[0] for f in synth.sequence(seed, 12, cam=synth.ICL if kind == "living_room" else synth.TUM3, kind=kind)]
+    frames = frames + frames[:8]                      # 20 frames: two chunks
+    batch = ctx.lsd_extract_batch(np.stack(frames), n_threads=4)
+    for g, a in zip(frames[:12], batch):
+        o = oracle_mod.extract_lines(g)
+        assert a["detected"] == o["detected"] and len(a["lines"]) == len(o["lines"])
+        for gk, ok in PAIRS:
+            assert np.array_equal(a["lines"][gk].view(np.uint32), o["lines"][ok].view(np.uint32)), gk
+        assert np.array_equal(a["desc"], o["desc"])
+        assert np.array_equal(a["lineF"].view(np.uint64), o["lineF"].view(np.uint64))
+    for a, b in zip(batch[12:], batch[:8]):
+        _same_lines(a, b)
+
+
+def test_lsd_device_grow_polygons_and_odd_size(ctx, oracle_mod):
+    """Analytic polygons (every edge must be found where it was drawn) and a frame size whose scaled width is not a multiple
+    of 64 through the device path; flat and noise-only images give no lines."""
+    imgs = []
+    rng = np.random.default_rng(5)
+    for k in range(3):
+        img = np.full((480, 640), 40, np.uint8)
+        import itertools
+        pts = np.array([[120 + 60 * k, 90], [520, 130 + 40 * k], [470 - 30 * k, 400], [150, 350]], np.int32)
+        yy, xx = np.mgrid[0:480, 0:640]
+        inside = np.ones((480, 640), bool)
+        for i in range(4):
+            (x0, y0), (x1, y1) = pts[i], pts[(i + 1) % 4]
+            inside &= ((x1 - x0) * (yy - y0) - (y1 - y0) * (xx - x0)) >= 0
+        img[inside] = 200
+        imgs.append(img)
+    from line_scenarios import analytic_polygons
+    gp, edges = analytic_polygons()
+    if gp.shape == (480, 640):
+        imgs.append(gp)
+    imgs.append(np.full((480, 640), 90, np.uint8))
+    imgs.append(rng.integers(0, 255, (480, 640)).astype(np.uint8))
+    batch = ctx.lsd_extract_batch(np.stack(imgs), n_threads=2)
+    for g, a in zip(imgs, batch):
+        _same_lines(a, ctx.lsd_extract(g))
+    assert all(len(b["lines"]) >= 4 for b in batch[:3]) and len(batch[-2]["lines"]) == 0
+    if gp.shape == (480, 640):
+        assert batch[3]["detected"] == len(edges)
+    odd = [f[0][:403, :531].copy() for f in synth_frames_odd()]
+    for g, a in zip(odd, ctx.lsd_extract_batch(np.stack(odd), n_threads=2)):
+        _same_lines(a, ctx.lsd_extract(g))
+
+
+def synth_frames_odd():
+    from dr_slam_amd import synth
+    return list(synth.sequence(9, 3, kind="room_boxes"))
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 11])
