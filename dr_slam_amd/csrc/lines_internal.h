@@ -20,6 +20,7 @@ struct LinesScratch {
     /* device region growing (batch entry): per slot the ordering keys / sorted ordering, member list, shrink scratch,
      * accepted rectangles, (count, status); the launch's frame table; pinned host mirrors */
     uint32_t* d_order; uint32_t* d_reg; uint32_t* d_tmp; struct LsdRect* d_rects; int* d_out; struct LsdGrowFrame* d_frames;
+    int* d_ordStatus; int* h_ordStatus;   /* k_lsd_order's status word per slot */
     uint32_t* h_order; unsigned long long* h_meta; struct LsdRect* h_rects; int* h_out; struct LsdGrowFrame* h_frames;
     int rectCap;
 };
@@ -53,11 +54,17 @@ struct LsdGrowFrame {
     uint32_t* reg; uint32_t* tmp;                             /* W x H entries each: member list (y << 16 | x), shrink scratch */
     LsdRect* rects; int* out;                                 /* accepted rectangles in seed order; out[0] = count, out[1] = status (DRFE_LSD_OUT_INTS ints per frame) */
     int nOrder; uint32_t minSeedBin;
+    const unsigned long long* meta;                           /* non-null: minSeedBin = 1024 - low word of meta[1] (k_lsd_keys), read on the device */
 };
 size_t drfe_lsd_grow_lds_bytes(int W, int H);
 /* keys of nframes consecutive slots: d_mod / d_ang / d_meta / d_keys point at the first of them */
 hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
                                 int nframes, hipStream_t s);
+/* std::sort's permutation of nframes key arrays (n keys each, keyStride apart) in place: introsort's moves on the device
+ * (lsd_order_kernels.hip).  d_posL / d_posR: scratch of >= n entries per frame, posStride apart.  d_status[f * statusStride]:
+ * 0, or 1 = a range ran out of introsort's depth limit (heap sort in libstdc++), 2 = internal queue overflow: order on the host. */
+hipError_t drfe_launch_lsd_order(uint32_t* d_keys, size_t keyStride, int n, uint32_t* d_posL, uint32_t* d_posR, size_t posStride,
+                                 int* d_status, int statusStride, int nframes, hipStream_t s);
 hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W, int H, double prec, double p, int minReg,
                                 double densityTh, int rectCap, hipStream_t s);
 

@@ -548,9 +548,9 @@ static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
     void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
-                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames};
+                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames};
+    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     delete s;
     s = nullptr;
@@ -616,6 +616,8 @@ static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int f
         LCHK(hipMalloc((void**)&s->d_rects, F * s->rectCap * sizeof(LsdRect)));
         LCHK(hipMalloc((void**)&s->d_out, F * DRFE_LSD_OUT_INTS * sizeof(int)));
         LCHK(hipMalloc((void**)&s->d_frames, F * sizeof(LsdGrowFrame)));
+        LCHK(hipMalloc((void**)&s->d_ordStatus, F * sizeof(int)));
+        LCHK(hipHostMalloc((void**)&s->h_ordStatus, F * sizeof(int), hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_order, nk * 4, hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_meta, 16 * F, hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_rects, F * s->rectCap * sizeof(LsdRect), hipHostMallocDefault));
@@ -849,6 +851,7 @@ struct BatchJob {
     int firstRc = DRFE_OK; std::string firstErr;
     bool abort = false;
     double prec, p; int minReg;
+    bool deviceOrder = true;            /* the ordering by k_lsd_order (default) or by the pool (DRFE_LSD_HOST_ORDER=1: A/B, tests) */
     std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
     std::chrono::steady_clock::time_point t0, tLastSort, tFirstFinish; std::atomic<int> nFirst{0};
     BatchJob(int nChunks_) : sortedInChunk(nChunks_), chunkState(nChunks_, 0) {}
@@ -868,14 +871,21 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
         g.order = A->d_order + nk * f; g.reg = A->d_reg + ns * f; g.tmp = A->d_tmp + ns * f;
         g.rects = A->d_rects + (size_t)A->rectCap * f; g.out = A->d_out + DRFE_LSD_OUT_INTS * (size_t)f;
         g.nOrder = (int)nk;
-        g.minSeedBin = 1024u - (uint32_t)(A->h_meta[2 * (size_t)f + 1] & 0xFFFFFFFFull);
+        g.meta = J.deviceOrder ? A->d_meta + 2 * (size_t)f : nullptr;
+        g.minSeedBin = J.deviceOrder ? 0u : 1024u - (uint32_t)(A->h_meta[2 * (size_t)f + 1] & 0xFFFFFFFFull);
     }
 #define BCHK(call)                                                                              \
     do {                                                                                        \
         hipError_t e__ = (call);                                                                \
         if (e__ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e__); return DRFE_ERR_HIP; } \
     } while (0)
-    BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
+    if (J.deviceOrder) {
+        /* std::sort's permutation on the device, in place; the member-list arrays serve as its scratch (the growth that
+         * follows on the same stream overwrites them) */
+        BCHK(drfe_launch_lsd_order(A->d_order + nk * f0, nk, (int)nk, A->d_reg + ns * f0, A->d_tmp + ns * f0, ns, A->d_ordStatus + f0, 1, nf, st));
+        BCHK(hipMemcpyAsync(A->h_ordStatus + f0, A->d_ordStatus + f0, sizeof(int) * nf, hipMemcpyDeviceToHost, st));
+    } else
+        BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
     BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
     BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st));
     BCHK(hipMemcpyAsync(A->h_out + DRFE_LSD_OUT_INTS * (size_t)f0, A->d_out + DRFE_LSD_OUT_INTS * (size_t)f0, DRFE_LSD_OUT_INTS * sizeof(int) * nf, hipMemcpyDeviceToHost, st));
@@ -954,7 +964,8 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
         int rc = ensure_lines(lw->err, lw->ls, J.w, J.h, 1, false, false);
         int nd = 0;
         if (rc == DRFE_OK) {
-            const int nRects = A->h_out[DRFE_LSD_OUT_INTS * (size_t)f], status = A->h_out[DRFE_LSD_OUT_INTS * (size_t)f + 1];
+            const int nRects = A->h_out[DRFE_LSD_OUT_INTS * (size_t)f];
+            const int status = A->h_out[DRFE_LSD_OUT_INTS * (size_t)f + 1] | (J.deviceOrder ? A->h_ordStatus[f] << 8 : 0);
             drfe_keyline* lo = J.lines ? J.lines + (size_t)f * J.cap : nullptr;
             uint8_t* dout = J.ldesc ? J.ldesc + (size_t)f * J.cap * 32 : nullptr;
             double* lf = J.lineF ? J.lineF + (size_t)f * J.cap * 3 : nullptr;
@@ -1019,6 +1030,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     J.lines = lines; J.ldesc = ldesc; J.lineF = line_f; J.nLines = n_lines; J.nDetected = n_detected;
     J.chunk = chunk; J.nChunks = nChunks;
     J.pendingFinish = nframes;
+    J.deviceOrder = std::getenv("DRFE_LSD_HOST_ORDER") == nullptr;
     const RectValidator val(A->sw, A->sh);
     J.prec = M_PI * 22.5 / 180; J.p = 22.5 / 180; J.minReg = (int)val.minReg(J.p);
     for (int ch = 0; ch < nChunks; ch++) J.sortedInChunk[ch].store(0);
@@ -1045,14 +1057,23 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
                 e = hipMemcpy2DAsync(A->d_img + n * f, (size_t)w, gray + frame_stride * f, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = drfe_launch_lines_passes(A->d_img + n * f0, w, h, P.lsdTaps, P.lbdTaps, A, f0, nf, P.rho, st);
         if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, nf, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(A->h_order + nk * f0, A->d_order + nk * f0, nk * 4 * nf, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(A->h_meta + 2 * (size_t)f0, A->d_meta + 2 * (size_t)f0, 16 * (size_t)nf, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipEventRecord(J.keysReady[ch], st);
+        if (e == hipSuccess && !J.deviceOrder) {
+            e = hipMemcpyAsync(A->h_order + nk * f0, A->d_order + nk * f0, nk * 4 * nf, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(A->h_meta + 2 * (size_t)f0, A->d_meta + 2 * (size_t)f0, 16 * (size_t)nf, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipEventRecord(J.keysReady[ch], st);
+        }
         if (e != hipSuccess) { c->err = std::string("lsd_extract_batch: image passes: ") + hipGetErrorString(e); launchRc = DRFE_ERR_HIP; }
+        if (launchRc == DRFE_OK && J.deviceOrder) {
+            /* ordering and growth follow on the same stream: nothing returns to the host before the rectangles */
+            std::string err;
+            launchRc = batch_launch_grow(J, ch, err);
+            if (launchRc != DRFE_OK) c->err = err;
+            else J.chunkState[ch] = 1;
+        }
     }
     const auto tLaunched = std::chrono::steady_clock::now();
     if (launchRc == DRFE_OK) {
-        for (int f = 0; f < nframes; f++) J.sortQ.push_back(f);
+        if (!J.deviceOrder) for (int f = 0; f < nframes; f++) J.sortQ.push_back(f);
         std::vector<std::thread> th;
         th.reserve(T);
         for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { batch_worker(J, &(*pool)[k]); });
@@ -1181,6 +1202,29 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
     *n_segs = (int)(out.size() / 4);
     if (*n_segs > cap) return DRFE_ERR_CAPACITY;
     if (segs && !out.empty()) std::memcpy(segs, out.data(), out.size() * sizeof(float));
+    return DRFE_OK;
+}
+
+/* Test hook of lsd_order_kernels.hip: n LSD ordering keys (bin << 22 | y << 11 | x) sorted in place by k_lsd_order on the
+ * device, to be compared with std::sort under compare_norm (drfe_debug_order_sort, mode 0).  *status = the kernel's status word
+ * (0: done; 1: a range ran out of the depth limit, the heap-sort branch the device does not take). */
+int drfe_debug_device_order_sort(drfe_ctx* c, uint32_t* keys, size_t n, int* status)
+{
+    if (!c || !keys || !status || n < 1 || n > (1u << 22)) { if (c) c->err = "debug_device_order_sort: invalid argument"; return DRFE_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t *d = nullptr, *pl = nullptr, *pr = nullptr;
+    int* ds = nullptr;
+    hipError_t e = hipMalloc((void**)&d, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&pl, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&pr, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ds, 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, keys, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = drfe_launch_lsd_order(d, n, (int)n, pl, pr, n, ds, 1, 1, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(keys, d, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(status, ds, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d); (void)hipFree(pl); (void)hipFree(pr); (void)hipFree(ds);
+    if (e != hipSuccess) { c->err = std::string("debug_device_order_sort: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     return DRFE_OK;
 }
 

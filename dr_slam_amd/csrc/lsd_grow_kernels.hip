@@ -461,7 +461,8 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         const LsdGrowFrame f = frames[blockIdx.x];
         w.F.ang = (const GLOBAL_AS double*)f.ang; w.F.cs = (const GLOBAL_AS float*)f.cs; w.F.mod = (const GLOBAL_AS double*)f.mod;
         w.F.order = (const GLOBAL_AS uint32_t*)f.order; w.F.reg = (GLOBAL_AS uint32_t*)f.reg; w.F.tmp = (GLOBAL_AS uint32_t*)f.tmp;
-        w.F.rects = (GLOBAL_AS double*)f.rects; w.F.out = (GLOBAL_AS int*)f.out; w.F.nOrder = f.nOrder; w.F.minSeedBin = f.minSeedBin;
+        w.F.rects = (GLOBAL_AS double*)f.rects; w.F.out = (GLOBAL_AS int*)f.out; w.F.nOrder = f.nOrder;
+        w.F.minSeedBin = f.meta ? 1024u - (uint32_t)(f.meta[1] & 0xFFFFFFFFull) : f.minSeedBin;
     }
     w.W = W; w.H = H; w.lane = threadIdx.x; w.status = 0;
 #ifdef LSD_PROFILE

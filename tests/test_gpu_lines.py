@@ -335,3 +335,50 @@ def test_lsd_search_by_sim3(oracle_mod, seed):
         assert found > n // 4
     finally:
         ctx.close()
+
+
+def test_device_order_sort_equals_std_sort(ctx):
+    """k_lsd_order (introsort's element moves on the device) against std::sort itself under lsd.cpp's compare_norm: the
+    permutation of equal bins must be libstdc++'s.  Random / few-valued / constant / sorted / organ-pipe / image-like key arrays
+    around the range thresholds of the kernel (16, 64, 1024, 8192) and at the size of a 640 x 480 frame."""
+    import ctypes as C
+    from dr_slam_amd import lib, synth
+    L = lib.load()
+    rng = np.random.default_rng(11)
+
+    def keys_of(bins):
+        n = len(bins)
+        idx = np.arange(n, dtype=np.uint32)
+        return (bins.astype(np.uint32) << 22) | ((idx // 2047) << 11) | (idx % 2047)
+
+    def check(bins, what):
+        k = keys_of(np.asarray(bins))
+        dev, ref = k.copy(), k.copy()
+        st = C.c_int(-1)
+        assert L.drfe_debug_device_order_sort(ctx.h, dev.ctypes.data_as(C.c_void_p), len(dev), C.byref(st)) == 0, ctx.last_error()
+        assert L.drfe_debug_order_sort(ref.ctypes.data_as(C.c_void_p), len(ref), 0, 0, -1, 0) == 0
+        if what == "organ pipe" and st.value == 1:
+            return                       # median-of-three's bad case: introsort falls to heap sort, the device hands the frame to the host
+        assert st.value == 0, (what, st.value)
+        assert np.array_equal(dev, ref), (what, len(k), int(np.argmax(dev != ref)))
+
+    for n in (1, 2, 16, 17, 33, 64, 65, 100, 1000, 1024, 1025, 4097, 8192, 8193, 20000, 70001):
+        check(rng.integers(0, 1024, n), "random")
+        check(rng.integers(0, 3, n), "three bins")
+        check(np.full(n, 7), "constant")
+        check(np.sort(rng.integers(0, 1024, n)), "ascending")
+        check(np.sort(rng.integers(0, 1024, n))[::-1], "descending")
+        check(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) % 1024, "organ pipe")
+        check(np.minimum(1023, rng.exponential(40, n).astype(np.int64)), "exponential")
+    # the keys of real level-line fields, as the batch path sorts them
+    for kind, seed in (("living_room", 3), ("room_boxes", 2), ("planar_lowtexture", 1)):
+        g = next(synth.sequence(seed, 1, cam=synth.ICL if kind == "living_room" else synth.TUM3, kind=kind))[0]
+        a = ctx.lsd_extract(g, stages=True)
+        mod = a["modgrad"][:-1, :-1]
+        bins = (mod * (1023.0 / mod.max())).astype(np.int64).ravel()
+        k = (bins.astype(np.uint32) << 22) | (np.repeat(np.arange(mod.shape[0], dtype=np.uint32), mod.shape[1]) << 11) | np.tile(np.arange(mod.shape[1], dtype=np.uint32), mod.shape[0])
+        dev, ref = k.copy(), k.copy()
+        st = C.c_int(-1)
+        assert L.drfe_debug_device_order_sort(ctx.h, dev.ctypes.data_as(C.c_void_p), len(dev), C.byref(st)) == 0
+        assert L.drfe_debug_order_sort(ref.ctypes.data_as(C.c_void_p), len(ref), 0, 0, -1, 0) == 0
+        assert st.value == 0 and np.array_equal(dev, ref), kind
