@@ -353,7 +353,8 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     split = {"lines": max(1, (nthr * 3) // 4)}
     split["planes"] = max(1, nthr - split["lines"])
     ctx_planes = lib.Context(max_batch=1)
-    ctx_cape = lib.Context(max_batch=1)
+    n_cape = 2                       # CAPE lanes: one context per Python thread (the C call releases the GIL)
+    ctx_cape = [lib.Context(max_batch=1) for _ in range(n_cape)]
     wall = {}
 
     def timed(name, fn):
@@ -366,13 +367,16 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
         _, n, _, na, _ = ctx_planes.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=split["planes"])
         return len(n), int(na.sum())
 
-    def cape():
-        return sum(len(ctx_cape.planes_cape(depth_m[f], K4, 20)["planes"]) for f in range(n_frames))
+    def cape_lane(k):
+        return sum(len(ctx_cape[k].planes_cape(depth_m[f], K4, 20)["planes"]) for f in range(k, n_frames, n_cape))
+
+    def cape(pool):
+        return sum(f.result() for f in [pool.submit(cape_lane, k) for k in range(n_cape)])
 
     def step(pool):
         fl = pool.submit(timed, "lines", lambda: fe.ctx.lsd_extract_batch(gray, n_threads=split["lines"]))
         fp = pool.submit(timed, "ahc_planes", planes)
-        fc = pool.submit(timed, "cape", cape)
+        fc = pool.submit(timed, "cape", lambda: cape(pool))
         t = time.perf_counter()
         fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
         fe.ctx.surface_normals_batch_ptr(depth_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, K4, inv, 9.0, n_frames, stream)
@@ -382,24 +386,26 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
         assert nl == n_frames and npl == n_frames and ncp > 0
         return nacc
 
-    with ThreadPoolExecutor(3) as pool:
+    with ThreadPoolExecutor(3 + n_cape) as pool:
         step(pool)
         # the two host pools are balanced from the warm-up step's own timing: thread-ms per frame of lines against planes
         cl, cp = wall["lines"] * split["lines"], wall["ahc_planes"] * split["planes"]
         split["lines"] = min(nthr - 1, max(1, round(nthr * cl / (cl + cp))))
         split["planes"] = max(1, nthr - split["lines"])
+        if os.environ.get("DRFE_FF_SPLIT"):          # experiments: "lines,planes"
+            split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
         step(pool)
         t0 = time.perf_counter()
         for _ in range(reps):
             nacc = step(pool)
         el = (time.perf_counter() - t0) / reps
-    for c in (ctx_planes, ctx_cape):
+    for c in [ctx_planes] + ctx_cape:
         c.close()
     fe.ctx.close()
     return {"workload": "BASELINE config 3: living_room scene, ICL intrinsics, 640x480: ORB + glue + SearchByProjection + surface "
                         "normals batched on the device; LSD+LBD lines, AHC planes + post-processing, CAPE planes for every frame",
             "value": n_frames / el, "unit": "frames/s", "frames_per_step": n_frames, "ms_per_step": el * 1e3,
-            "host_threads": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": 1}, "host_cpus_available": ncpu,
+            "host_threads": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": n_cape}, "host_cpus_available": ncpu,
             "stage_wall_ms_last_step": {k: round(v, 2) for k, v in wall.items()},
             "planes_accepted_per_step": int(nacc),
             "note": "bound by the sequential host stages of LSD (pixel ordering + region growing) and AHC (clustering): "
@@ -429,21 +435,37 @@ def launch(args) -> int:
                  MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = procs[0].stdout.read().decode()
+    # rank 0's output is read on a thread while ALL children are polled: a rank that dies during start-up leaves the others
+    # waiting in the rendezvous / first collective, so the first non-zero exit (or the deadline) ends the whole job
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
     deadline = time.time() + 1800
-    for p in procs:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-        rc = rc or p.returncode
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc = 124
+            break
+        time.sleep(0.2)
     if rc:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    out0 = b"".join(chunks).decode()
+    if rc:
         sys.stderr.write(out0)
-        return rc or 1
+        return rc
     sys.stdout.write(out0)
     return 0
 

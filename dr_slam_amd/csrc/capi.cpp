@@ -68,6 +68,9 @@ static int upload_geometry(drfe_ctx* c, int w, int h)
     c->geom = g;
     c->lastBatch = 0;
     c->glueValid = false;
+    /* no slot holds a frame of this geometry yet: a slot-addressed call on a slot that drfe_frame_submit has not filled
+     * (lastBatch only remembers the highest one) finds zero keypoints instead of another geometry's leftovers */
+    HIPCHK(c, hipMemset(c->d_kpCount, 0, sizeof(int) * (size_t)c->cfg.max_batch));
     return DRFE_OK;
 }
 
@@ -381,6 +384,32 @@ int drfe_batch_download_async(drfe_ctx* c, int nframes, drfe_keypoint* kps, uint
     return DRFE_OK;
 }
 
+/* The device status words of the batch path, asynchronously like drfe_batch_download_async: status[0] = extraction (bit 0:
+ * FAST candidate arena overflow, bit 1: quadtree node pool overflow), status[1] = drfe_match_consecutive_batch (bit 2: more
+ * than DRFE_MATCH_MAX_CAND keypoints in a search window).  Non-zero = the batch's keypoints / matches are truncated. */
+int drfe_batch_status_async(drfe_ctx* c, int32_t* status, void* stream)
+{
+    if (!c || !status) { if (c) c->err = "drfe_batch_status_async: invalid argument"; return DRFE_ERR_INVALID; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, hipMemcpyAsync(&status[0], c->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&status[1], c->d_status + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    return DRFE_OK;
+}
+
+/* the same, blocking, as an error code: DRFE_ERR_CAPACITY (with the reason in drfe_last_error) if the batch most recently
+ * extracted / matched on this context overflowed an arena.  Waits for the context's stream. */
+int drfe_batch_check(drfe_ctx* c)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int st[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(st, c->d_status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st[0] & 1) { c->err = "FAST candidate arena overflow"; return DRFE_ERR_CAPACITY; }
+    if (st[0] & 2) { c->err = "quadtree node pool overflow"; return DRFE_ERR_CAPACITY; }
+    if (st[2] & 4) { c->err = "match candidate list overflow (DRFE_MATCH_MAX_CAND)"; return DRFE_ERR_CAPACITY; }
+    return DRFE_OK;
+}
+
 } /* extern "C" */
 
 /* The single-frame entry as ONE graph launch: pinned input -> H2D -> the 20-odd kernels of drfe_launch_orb -> status, count,
@@ -424,10 +453,13 @@ static int one_shot_prepare(drfe_ctx* c, int w, int h)
     }
     OrbOneShot* o = c->oneShot;
     if (o->disabled) return DRFE_OK;
+    /* the device tables must be this size's before the graph (whose launches carry this size's arguments) replays: a batch or
+     * per-frame call at another size may have re-uploaded them since the capture.  No-op when the geometry is unchanged;
+     * table uploads are not capturable, so also before a capture. */
+    int rc = upload_geometry(c, w, h);
+    if (rc != DRFE_OK) return rc;
     if (o->exec && o->w == w && o->h == h) return DRFE_OK;
     one_shot_release(o);
-    int rc = upload_geometry(c, w, h);        /* table uploads are not capturable: before the capture */
-    if (rc != DRFE_OK) return rc;
     const size_t K = (size_t)c->maxKp, outBytes = 8 + K * sizeof(drfe_keypoint) + K * 32;
     if (o->inBytes < (size_t)w * h) {
         if (o->h_in) (void)hipHostFree(o->h_in);

@@ -88,10 +88,10 @@ static void motion_flags(const float* TcwCur, const float* TcwLast, float mb, in
     *bwd = (-tlc[2] > mb && !mono) ? 1 : 0;
 }
 
-static int match_status(drfe_ctx* c)
+static int match_status(drfe_ctx* c, int word = 1)
 {
     int st = 0;
-    HIPCHK(c, hipMemcpy(&st, c->d_status + 1, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&st, c->d_status + word, sizeof(int), hipMemcpyDeviceToHost));
     if (st & 4) { c->err = "match candidate list overflow (DRFE_MATCH_MAX_CAND)"; return DRFE_ERR_CAPACITY; }
     return DRFE_OK;
 }
@@ -164,6 +164,9 @@ int drfe_frame_stereo_grid_batch(drfe_ctx* c, const uint16_t* d_depth, size_t fr
     if (!c || !d_depth || !cam) return DRFE_ERR_INVALID;
     if (nframes < 1 || nframes > c->lastBatch) { c->err = "glue: extract the batch first"; return DRFE_ERR_STATE; }
     if (!(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { c->err = "glue: empty image bounds"; return DRFE_ERR_INVALID; }
+    /* a depth IMAGE: rows at least a frame wide (row stride 0 is the internal per-keypoint addressing of
+     * drfe_frame_stereo_grid_batch_kpdepth and must not be reachable from here) */
+    if (row_stride < (size_t)c->geom.imgW || frame_stride < row_stride * (size_t)c->geom.imgH) { c->err = "glue: depth row / frame stride smaller than the image"; return DRFE_ERR_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     HIPCHK(c, drfe_launch_glue(c, d_depth, frame_stride, row_stride, *cam, nframes, s));
@@ -366,7 +369,7 @@ int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc
     HIPCHK(c, hipMemsetAsync(c->d_match, 0xFF, sizeof(int) * (size_t)nframes * c->maxKp, s));
     HIPCHK(c, hipMemsetAsync(c->d_matchCount, 0, sizeof(int) * nframes, s));
     HIPCHK(c, drfe_launch_mappoints_last(c, *m, *cam, c->d_poses, nframes, s));
-    HIPCHK(c, drfe_launch_window_match(c, *m, *cam, np, c->maxKp, 0, th, 0.f, check_ori, nullptr, s));
+    HIPCHK(c, drfe_launch_window_match(c, *m, *cam, np, c->maxKp, 0, th, 0.f, check_ori, nullptr, s, 2));      /* its own overflow word */
     if (c->profile) (void)hipEventRecord(c->ev[DRFE_STAGE_MATCH][1], s);
     return DRFE_OK;
 }
@@ -376,7 +379,7 @@ int drfe_match_download(drfe_ctx* c, int slot, int32_t* cur_to_last, int cap, in
     if (!c || slot < 0 || slot >= c->lastBatch) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
     int rc = drfe_stream_sync(c);
     if (rc != DRFE_OK) return rc;
-    rc = match_status(c);
+    rc = match_status(c, 2);            /* the batch matcher's own word: later searches do not clear it */
     if (rc != DRFE_OK) return rc;
     int n = 0;
     HIPCHK(c, hipMemcpy(&n, c->d_kpCount + slot, sizeof(int), hipMemcpyDeviceToHost));

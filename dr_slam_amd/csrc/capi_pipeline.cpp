@@ -83,6 +83,9 @@ int drfe_pipeline_sync(drfe_pipeline* p, int k)
             p->err = "drfe_pipeline_sync: stream synchronisation failed";
             return DRFE_ERR_HIP;
         }
+        /* the throughput path reports arena overflows here: a truncated batch must not pass silently */
+        const int rc = drfe_batch_check(c);
+        if (rc != DRFE_OK) { p->err = drfe_last_error(c); return rc; }
     }
     return DRFE_OK;
 }

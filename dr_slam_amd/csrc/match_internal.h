@@ -44,7 +44,7 @@ struct MatchBuffers {
 
 hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,
                                     int maxQueries, int mode, float th, float nnratio, int checkOri,
-                                    const uint8_t* d_initObs, hipStream_t s);
+                                    const uint8_t* d_initObs, hipStream_t s, int statusWord = 1);
 hipError_t drfe_launch_window_candidates(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs, int maxQueries,
                                          hipStream_t s);
 hipError_t drfe_launch_mappoints_last(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, const float* d_Twc,

@@ -782,20 +782,22 @@ hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameSt
 
 hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,
                                     int maxQueries, int mode, float th, float nnratio, int checkOri,
-                                    const uint8_t* d_initObs, hipStream_t s)
+                                    const uint8_t* d_initObs, hipStream_t s, int statusWord)
 {
     const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
     const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
     if (mode == 0 && maxQueries > RS_THREADS * RS_MAX_T) return hipErrorInvalidValue;
-    /* the matcher's overflow flag is its own word (d_status[1]) and is cleared by every search: an overflowing
-     * window fails THAT call only, the next call on the same extracted batch starts clean */
-    (void)hipMemsetAsync(c->d_status + 1, 0, sizeof(int), s);
+    /* the matcher's overflow flag is its own word and is cleared by the search that owns it: d_status[1] for the host-buffer
+     * searches (an overflowing window fails THAT call only, the next call on the same extracted batch starts clean),
+     * d_status[2] for drfe_match_consecutive_batch, whose check is deferred to the download / pipeline sync - no other
+     * search in between can erase it */
+    (void)hipMemsetAsync(c->d_status + statusWord, 0, sizeof(int), s);
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);
     hipLaunchKernelGGL(k_window_candidates, dim3((maxQueries + WQ_PER_BLOCK - 1) / WQ_PER_BLOCK, npairs), dim3(WQ_THREADS), 0, s, mb.d_pairs,
                        mb.d_queries, c->d_kpCount, c->maxKp, c->d_gridOff, c->d_cellKp, c->d_cellDesc, cam, invW, invH,
-                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status + 1,
+                       mb.d_candIdx, mb.d_candKey, mb.d_candCnt, mb.d_candBest, c->d_status + statusWord,
                        drfe_div_magic((uint32_t)((maxQueries + WQ_PER_BLOCK - 1) / WQ_PER_BLOCK)));
     const size_t lds = (size_t)c->maxKp;
     if (mode == 0)

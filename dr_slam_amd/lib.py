@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort",
+    "drfe_lsd_configure", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -199,6 +199,8 @@ def load() -> C.CDLL:
     L.drfe_surface_normals_download.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_segments_host.argtypes = [vp, vp, vp, i32, i32, f64, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_configure.argtypes = [vp, i32]
+    L.drfe_batch_status_async.argtypes = [vp, vp, vp]
+    L.drfe_batch_check.argtypes = [vp]
     L.drfe_debug_cr_sincos.argtypes = [vp, i32, vp, vp, vp]
     L.drfe_debug_device_order_sort.argtypes = [vp, vp, sz, C.POINTER(i32)]
     L.drfe_profile_enable.argtypes = [vp, i32]

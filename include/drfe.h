@@ -103,6 +103,14 @@ int drfe_orb_download(drfe_ctx* ctx, int slot, drfe_keypoint* kps, uint8_t* desc
  * unspecified.  The caller synchronises the stream before reading. */
 int drfe_batch_download_async(drfe_ctx* ctx, int nframes, drfe_keypoint* kps, uint8_t* desc, int32_t* kp_counts,
                               int32_t* matches, int32_t* match_counts, void* stream);
+/* The device status words of the batch most recently extracted / matched on ctx, copied asynchronously on `stream` (NULL: the
+ * context's): status[0] = extraction (bit 0: FAST candidate arena overflow, bit 1: quadtree node pool overflow), status[1] =
+ * drfe_match_consecutive_batch (bit 2: more than 256 keypoints in one search window).  Non-zero = keypoints / matches of that
+ * batch are truncated.  The batch matcher's word is its own: no other search clears it. */
+int drfe_batch_status_async(drfe_ctx* ctx, int32_t* status, void* stream);
+/* The same check, blocking (waits for the context's stream): DRFE_ERR_CAPACITY with the reason in drfe_last_error if an arena
+ * overflowed.  drfe_pipeline_sync calls it for every context it waits for. */
+int drfe_batch_check(drfe_ctx* ctx);
 /* Per-slot keypoint counts (host array of nframes ints; synchronises). */
 int drfe_orb_counts(drfe_ctx* ctx, int nframes, int* counts);
 

@@ -224,3 +224,29 @@ def test_other_scale_factors(frames_room, oracle_mod, scale, nlevels):
         c.close()
     with pytest.raises(lib.DrfeError):
         lib.Context(scale_factor=3.0, nlevels=3).orb_extract(g)
+
+
+def test_single_frame_graph_survives_a_geometry_change(frames_room):
+    """the captured graph of drfe_orb_extract at size A must not replay against the tables of size B.
+    extract(A) -> extract_batch(B) on the same context -> extract(A) == a fresh context's extract(A); and a slot that no call
+    has filled after a geometry change holds zero keypoints."""
+    import torch
+    from dr_slam_amd import lib
+    gA = frames_room[0][0]
+    gB = np.ascontiguousarray(frames_room[1][0][:360, :480])
+    fresh = lib.Context(max_batch=2)
+    want = fresh.orb_extract(gA)
+    fresh.close()
+    c = lib.Context(max_batch=2)
+    k0, d0 = c.orb_extract(gA)
+    tB = torch.from_numpy(np.stack([gB, gB])).cuda()
+    c.orb_extract_batch_ptr(tB.data_ptr(), 480 * 360, 480, 480, 360, 2, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    k1, d1 = c.orb_extract(gA)
+    for k, d in ((k0, d0), (k1, d1)):
+        assert np.array_equal(k.view(np.uint8), want[0].view(np.uint8)) and np.array_equal(d, want[1])
+    # geometry is A's again and only slot 0 was written: slot 1 must read as empty, not as B's leftovers
+    cnt = c.orb_counts(1)
+    assert cnt[0] == len(want[0])
+    assert c.L.drfe_batch_check(c.h) == 0
+    c.close()
