@@ -643,7 +643,16 @@ struct FrameLane {
     drfe_camera cam;
     DrfeDistortion dist;
     bool pending = false, graphOff = false;
+    /* drfe_frame_submit_tracked: SearchByProjection(this frame, LastFrame) behind the glue.  The pair record, LastFrame's Twc
+     * and (caller-supplied) map points travel in the staging behind the images; everything a kernel takes by value is part
+     * of the graph's key */
+    int tracked = 0, lastSlot = -1, mpsFromCaller = 0, checkOri = 0;
+    float th = 0.f;
+    size_t trackOff = 0;          /* byte offset of the tracking block inside h_in / d_in */
 };
+
+/* tracking block of a staged frame: MatchPair | Twc of LastFrame | map points */
+static size_t track_block_bytes(const drfe_ctx* c) { return 256 + (size_t)c->maxKp * sizeof(drfe_map_point); }
 
 /* The kernels address a slot as base + slot * stride.  One slot of a larger arena is therefore the same launches on
  * shifted bases: this shifts every per-slot base the ORB and glue launchers read, for the duration of the enqueue. */
@@ -693,29 +702,64 @@ static hipError_t frame_enqueue(drfe_ctx* c, FrameLane& L, int slot, int w, int 
 {
     const size_t K = (size_t)c->maxKp, px = (size_t)w * h;
     hipError_t e = hipMemcpyAsync(L.d_in, L.h_in, L.withDepth ? px * 3 : px, hipMemcpyHostToDevice, s);
-    SlotShift shift(c, slot);
-    if (e == hipSuccess) e = drfe_launch_orb(c, L.d_in, px, (size_t)w, 1, s);
-    if (e == hipSuccess && L.withDepth)
-        e = drfe_launch_glue(c, reinterpret_cast<const uint16_t*>(L.d_in + px), px, (size_t)w, L.cam, 1, s);
+    if (L.tracked && e == hipSuccess)
+        e = hipMemcpyAsync(L.d_in + L.trackOff, L.h_in + L.trackOff, track_block_bytes(c), hipMemcpyHostToDevice, s);
+    {
+        SlotShift shift(c, slot);
+        if (e == hipSuccess) e = drfe_launch_orb(c, L.d_in, px, (size_t)w, 1, s);
+        if (e == hipSuccess && L.withDepth)
+            e = drfe_launch_glue(c, reinterpret_cast<const uint16_t*>(L.d_in + px), px, (size_t)w, L.cam, 1, s);
+    }
+    if (L.tracked && e == hipSuccess) {
+        /* ORBmatcher::SearchByProjection(CurrentFrame = this slot, LastFrame = lastSlot, th, mono), src/Tracking.cc:2181-2202:
+         * claims start empty (TrackWithMotionModel fills mvpMapPoints with NULL first) */
+        MatchBuffers mb = *c->mb;
+        mb.d_pairs = reinterpret_cast<MatchPair*>(L.d_in + L.trackOff);
+        const float* d_Twc = reinterpret_cast<const float*>(L.d_in + L.trackOff + 128);
+        if (L.mpsFromCaller) mb.d_mps = reinterpret_cast<drfe_map_point*>(L.d_in + L.trackOff + 256);
+        else {
+            /* LastFrame's map points as Tracking::UpdateLastFrame leaves them on an RGB-D stream: its keypoints with depth,
+             * unprojected with its Twc (the launcher works on slot 0 of shifted bases; it writes d_mps[0..]) */
+            SlotShift last(c, L.lastSlot);
+            e = drfe_launch_mappoints_last(c, mb, L.cam, d_Twc, 1, s);
+        }
+        if (e == hipSuccess) e = drfe_launch_fill_i32(c->d_match + (size_t)slot * K, (int)K, -1, s);
+        if (e == hipSuccess) e = drfe_launch_fill_i32(c->d_matchCount + slot, 1, 0, s);
+        if (e == hipSuccess) e = drfe_launch_window_match(c, mb, L.cam, 1, c->maxKp, 0, L.th, 0.f, L.checkOri, nullptr, s, 3);
+    }
     uint8_t* o = L.h_out;
     if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_status, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(o + 4, c->d_kpCount, 4, hipMemcpyDeviceToHost, s);
-    o += 8;
-    if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_kps, K * sizeof(drfe_keypoint), hipMemcpyDeviceToHost, s);
-    o += K * sizeof(drfe_keypoint);
-    if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_desc, K * 32, hipMemcpyDeviceToHost, s);
-    o += K * 32;
-    if (L.withDepth) {
-        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_uRight, K * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4, c->d_depth, K * 4, hipMemcpyDeviceToHost, s);
+    {
+        SlotShift shift(c, slot);                    /* the slot's own arrays */
+        if (e == hipSuccess) e = hipMemcpyAsync(o + 4, c->d_kpCount, 4, hipMemcpyDeviceToHost, s);
+        o += 8;
+        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_kps, K * sizeof(drfe_keypoint), hipMemcpyDeviceToHost, s);
+        o += K * sizeof(drfe_keypoint);
+        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_desc, K * 32, hipMemcpyDeviceToHost, s);
+        o += K * 32;
+        if (L.withDepth) {
+            if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_uRight, K * 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4, c->d_depth, K * 4, hipMemcpyDeviceToHost, s);
+        }
+    }
+    o += K * 8;
+    if (L.tracked) {
+        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_match + (size_t)slot * K, K * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4, c->d_matchCount + slot, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4 + 4, c->d_status + 3, 4, hipMemcpyDeviceToHost, s);
     }
     return e;
 }
 
 extern "C" {
 
-int drfe_frame_submit(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, size_t stride, const uint16_t* depth,
-                      size_t depth_stride_elems, const drfe_camera* cam)
+struct TrackArgs {
+    int lastSlot; const float* TcwCur; const float* TcwLast; const float* TwcLast; const drfe_map_point* lastMp; int nLast;
+    float th; int mono, checkOri;
+};
+
+static int frame_submit_impl(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, size_t stride, const uint16_t* depth,
+                             size_t depth_stride_elems, const drfe_camera* cam, const TrackArgs* tr)
 {
     if (!c) return DRFE_ERR_INVALID;
     if (slot < 0 || slot >= c->cfg.max_batch || !gray || w < 1 || h < 1 || stride < (size_t)w || (size_t)w * h > c->stageBytes ||
@@ -724,6 +768,14 @@ int drfe_frame_submit(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, 
         return DRFE_ERR_INVALID;
     }
     if (depth && (!(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y))) { c->err = "drfe_frame_submit: empty image bounds"; return DRFE_ERR_INVALID; }
+    if (tr) {
+        if (!depth || !tr->TcwCur || !tr->TcwLast || (!tr->lastMp && !tr->TwcLast) || tr->lastSlot < 0 || tr->lastSlot >= c->cfg.max_batch ||
+            tr->lastSlot == slot || (tr->lastMp && (tr->nLast < 0 || tr->nLast > c->maxKp))) {
+            c->err = "drfe_frame_submit_tracked: invalid argument (needs a depth image, both poses, another slot as LastFrame)";
+            return DRFE_ERR_INVALID;
+        }
+        if (tr->lastSlot >= c->lastBatch || !c->glueValid) { c->err = "drfe_frame_submit_tracked: LastFrame's slot holds no frame with its grid"; return DRFE_ERR_STATE; }
+    }
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->frameLanes) {
         auto* v = new (std::nothrow) std::vector<FrameLane>((size_t)c->cfg.max_batch);
@@ -735,28 +787,46 @@ int drfe_frame_submit(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, 
     /* geometry tables first: an upload synchronises the device and invalidates every slot */
     int rc = upload_geometry(c, w, h);
     if (rc != DRFE_OK) return rc;
+    if (tr && !drfe_match_buffers(c)) return DRFE_ERR_HIP;
     const size_t K = (size_t)c->maxKp, px = (size_t)w * h;
-    if (L.inBytes < px * 3) {
+    const size_t trackOff = (px * 3 + 255) & ~(size_t)255, need = trackOff + track_block_bytes(c);
+    if (L.inBytes < need) {
         if (L.h_in) (void)hipHostFree(L.h_in);
         if (L.d_in) (void)hipFree(L.d_in);
         L.h_in = nullptr; L.d_in = nullptr; L.inBytes = 0;
         frame_lane_release_graph(L);
-        HIPCHK(c, hipHostMalloc((void**)&L.h_in, px * 3, hipHostMallocDefault));
-        HIPCHK(c, hipMalloc((void**)&L.d_in, px * 3));
-        L.inBytes = px * 3;
+        HIPCHK(c, hipHostMalloc((void**)&L.h_in, need, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&L.d_in, need));
+        L.inBytes = need;
     }
-    if (!L.h_out) HIPCHK(c, hipHostMalloc((void**)&L.h_out, 8 + K * (sizeof(drfe_keypoint) + 32 + 8), hipHostMallocDefault));
+    if (!L.h_out) HIPCHK(c, hipHostMalloc((void**)&L.h_out, 8 + K * (sizeof(drfe_keypoint) + 32 + 8 + 4) + 8, hipHostMallocDefault));
     if (!L.done) HIPCHK(c, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     for (int y = 0; y < h; y++) std::memcpy(L.h_in + (size_t)y * w, gray + (size_t)y * stride, (size_t)w);
     if (depth)
         for (int y = 0; y < h; y++) std::memcpy(L.h_in + px + (size_t)y * w * 2, depth + (size_t)y * depth_stride_elems, (size_t)w * 2);
-    const int withDepth = depth ? 1 : 0;
-    /* a captured graph holds kernel arguments by value: camera, distortion model and sizes are part of its key */
-    const bool sameKey = L.w == w && L.h == h && L.withDepth == withDepth &&
-                         (!withDepth || (std::memcmp(&L.cam, cam, sizeof(drfe_camera)) == 0 && std::memcmp(&L.dist, &c->dist, sizeof(DrfeDistortion)) == 0));
+    const int withDepth = depth ? 1 : 0, tracked = tr ? 1 : 0, fromCaller = tr && tr->lastMp ? 1 : 0;
+    if (tr) {
+        MatchPair P;
+        std::memset(&P, 0, sizeof(P));
+        P.curSlot = slot; P.lastSlot = tr->lastSlot; P.queryBase = 0; P.mpBase = 0;
+        if (fromCaller) { P.mpSlot = -1; P.nQueries = tr->nLast; }
+        else { P.mpSlot = tr->lastSlot; P.nQueries = 0; }
+        std::memcpy(P.Tcw, tr->TcwCur, sizeof(float) * 16);
+        drfe_motion_flags(tr->TcwCur, tr->TcwLast, cam->bf / cam->fx, tr->mono, &P.forward, &P.backward);
+        static_assert(sizeof(MatchPair) <= 128, "tracking block layout");
+        std::memcpy(L.h_in + trackOff, &P, sizeof(P));
+        if (tr->TwcLast) std::memcpy(L.h_in + trackOff + 128, tr->TwcLast, 64);
+        if (fromCaller && tr->nLast) std::memcpy(L.h_in + trackOff + 256, tr->lastMp, sizeof(drfe_map_point) * (size_t)tr->nLast);
+    }
+    /* a captured graph holds kernel arguments by value: camera, distortion model, sizes and the matcher's slot / thresholds
+     * are part of its key */
+    const bool sameKey = L.w == w && L.h == h && L.withDepth == withDepth && L.tracked == tracked && L.trackOff == trackOff &&
+                         (!withDepth || (std::memcmp(&L.cam, cam, sizeof(drfe_camera)) == 0 && std::memcmp(&L.dist, &c->dist, sizeof(DrfeDistortion)) == 0)) &&
+                         (!tracked || (L.lastSlot == tr->lastSlot && L.mpsFromCaller == fromCaller && L.th == tr->th && L.checkOri == tr->checkOri));
     if (!sameKey) frame_lane_release_graph(L);
-    L.w = w; L.h = h; L.withDepth = withDepth;
+    L.w = w; L.h = h; L.withDepth = withDepth; L.tracked = tracked; L.trackOff = trackOff;
     if (withDepth) { L.cam = *cam; L.dist = c->dist; }
+    if (tracked) { L.lastSlot = tr->lastSlot; L.mpsFromCaller = fromCaller; L.th = tr->th; L.checkOri = tr->checkOri; }
     hipStream_t s = c->stream;
     static const bool noGraph = [] { const char* e = std::getenv("DRFE_NO_GRAPH"); return e && e[0] == '1'; }();
     if (!L.exec && !L.graphOff && !noGraph && !c->profile) {
@@ -775,6 +845,26 @@ int drfe_frame_submit(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, 
     c->lastBatch = std::max(c->lastBatch, slot + 1);
     if (withDepth) { c->glueValid = true; c->cam = *cam; }
     return DRFE_OK;
+}
+
+int drfe_frame_submit(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, size_t stride, const uint16_t* depth,
+                      size_t depth_stride_elems, const drfe_camera* cam)
+{
+    return frame_submit_impl(c, slot, gray, w, h, stride, depth, depth_stride_elems, cam, nullptr);
+}
+
+/* drfe_frame_submit followed, in the same captured graph, by ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono)
+ * of TrackWithMotionModel (src/Tracking.cc:2181-2202): ONE submission per tracked frame.  LastFrame lives in last_slot (an
+ * earlier submission).  last_mp != NULL: LastFrame.mvpMapPoints as the caller's map holds them (n_last = its keypoint count);
+ * NULL: its keypoints with depth unprojected with Twc_last - what Tracking::UpdateLastFrame leaves on an RGB-D stream.
+ * Tcw_cur = the predicted pose (mVelocity * LastFrame.mTcw). */
+int drfe_frame_submit_tracked(drfe_ctx* c, int slot, const uint8_t* gray, int w, int h, size_t stride, const uint16_t* depth,
+                              size_t depth_stride_elems, const drfe_camera* cam, int last_slot, const float* Tcw_cur,
+                              const float* Tcw_last, const float* Twc_last, const drfe_map_point* last_mp, int n_last, float th,
+                              int mono, int check_ori)
+{
+    const TrackArgs tr = {last_slot, Tcw_cur, Tcw_last, Twc_last, last_mp, n_last, th, mono, check_ori};
+    return frame_submit_impl(c, slot, gray, w, h, stride, depth, depth_stride_elems, cam, &tr);
 }
 
 int drfe_frame_collect(drfe_ctx* c, int slot, drfe_keypoint* kps, uint8_t* desc, float* u_right, float* depth_m, int cap, int* n_out)
@@ -806,6 +896,30 @@ int drfe_frame_collect(drfe_ctx* c, int slot, drfe_keypoint* kps, uint8_t* desc,
     o += K * 32;
     if (n > 0 && u_right) std::memcpy(u_right, o, (size_t)n * 4);
     if (n > 0 && depth_m) std::memcpy(depth_m, o + K * 4, (size_t)n * 4);
+    return DRFE_OK;
+}
+
+/* drfe_frame_collect of a drfe_frame_submit_tracked submission, plus the matcher's result: cur_to_last[i] = index of the
+ * LastFrame keypoint / map point matched to current keypoint i, or -1 (CurrentFrame.mvpMapPoints), *n_matches = nmatches. */
+int drfe_frame_collect_tracked(drfe_ctx* c, int slot, drfe_keypoint* kps, uint8_t* desc, float* u_right, float* depth_m, int cap,
+                               int* n_out, int32_t* cur_to_last, int* n_matches)
+{
+    if (!c || !n_out || !n_matches) return DRFE_ERR_INVALID;
+    auto* v = static_cast<std::vector<FrameLane>*>(c->frameLanes);
+    if (slot < 0 || slot >= c->cfg.max_batch || !v || !(*v)[(size_t)slot].pending || !(*v)[(size_t)slot].tracked) {
+        c->err = "drfe_frame_collect_tracked: no tracked submission in this slot";
+        return DRFE_ERR_STATE;
+    }
+    const int rc = drfe_frame_collect(c, slot, kps, desc, u_right, depth_m, cap, n_out);
+    if (rc != DRFE_OK) return rc;
+    const FrameLane& L = (*v)[(size_t)slot];
+    const size_t K = (size_t)c->maxKp;
+    const uint8_t* o = L.h_out + 8 + K * (sizeof(drfe_keypoint) + 32 + 8);
+    int st = 0;
+    std::memcpy(n_matches, o + K * 4, 4);
+    std::memcpy(&st, o + K * 4 + 4, 4);
+    if (st & 4) { c->err = "match candidate list overflow (DRFE_MATCH_MAX_CAND)"; return DRFE_ERR_CAPACITY; }
+    if (cur_to_last && *n_out > 0) std::memcpy(cur_to_last, o, (size_t)*n_out * 4);
     return DRFE_OK;
 }
 

@@ -72,7 +72,7 @@ MatchBuffers* drfe_match_buffers(drfe_ctx* c)
 
 /* bForward / bBackward of reference src/ORBmatcher.cc:1406-1414.  `-Rcw.t()*tcw` takes OpenCV's general
  * gemm path (double accumulation, alpha = -1); `Rlw*twc+tlw` the float small-matrix path. */
-static void motion_flags(const float* TcwCur, const float* TcwLast, float mb, int mono, int* fwd, int* bwd)
+void drfe_motion_flags(const float* TcwCur, const float* TcwLast, float mb, int mono, int* fwd, int* bwd)
 {
     float twc[3], tlc[3];
     for (int i = 0; i < 3; i++) {
@@ -360,7 +360,7 @@ int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc
         P.queryBase = p * c->maxKp;
         P.mpBase = p * c->maxKp;   /* k_mappoints_last writes slot-major */
         std::memcpy(P.Tcw, Tcw + (size_t)(p + 1) * 16, sizeof(float) * 16);
-        motion_flags(Tcw + (size_t)(p + 1) * 16, Tcw + (size_t)p * 16, mb, mono, &P.forward, &P.backward);
+        drfe_motion_flags(Tcw + (size_t)(p + 1) * 16, Tcw + (size_t)p * 16, mb, mono, &P.forward, &P.backward);
     }
     HIPCHK(c, hipMemcpyAsync(m->d_pairs, pairs, sizeof(MatchPair) * np, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 16 * nframes, hipMemcpyHostToDevice, s));
@@ -411,7 +411,7 @@ int drfe_search_by_projection_last(drfe_ctx* c, int cur_slot, int last_slot, con
     MatchPair P;
     P.curSlot = cur_slot; P.lastSlot = last_slot; P.mpSlot = -1; P.nQueries = n_last; P.queryBase = 0; P.mpBase = 0;
     std::memcpy(P.Tcw, Tcw_cur, sizeof(float) * 16);
-    motion_flags(Tcw_cur, Tcw_last, cam->bf / cam->fx, mono, &P.forward, &P.backward);
+    drfe_motion_flags(Tcw_cur, Tcw_last, cam->bf / cam->fx, mono, &P.forward, &P.backward);
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpy(m->d_pairs, &P, sizeof(P), hipMemcpyHostToDevice));
     if (n_last) HIPCHK(c, hipMemcpy(m->d_mps, last_mp, sizeof(drfe_map_point) * n_last, hipMemcpyHostToDevice));
@@ -686,7 +686,7 @@ int drfe_lsd_search_by_projection_last(drfe_ctx* c, const float* Tcw_cur, const 
             return DRFE_ERR_INVALID;
         }
     int fwd = 0, bwd = 0;
-    motion_flags(Tcw_cur, Tcw_last, cam->bf / cam->fx, mono, &fwd, &bwd);
+    drfe_motion_flags(Tcw_cur, Tcw_last, cam->bf / cam->fx, mono, &fwd, &bwd);
     return line_search_run(c, nullptr, last_lines, n_last, Tcw_cur, cam, fwd, bwd, th, cur_lines, cur_desc, n_cur, nnratio,
                            cur_obs, cur_ml, nmatches);
 }

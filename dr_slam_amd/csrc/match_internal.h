@@ -45,6 +45,9 @@ struct MatchBuffers {
 hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,
                                     int maxQueries, int mode, float th, float nnratio, int checkOri,
                                     const uint8_t* d_initObs, hipStream_t s, int statusWord = 1);
+hipError_t drfe_launch_fill_i32(int* d_p, int n, int v, hipStream_t s);
+/* bForward / bBackward of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame), src/ORBmatcher.cc:1406-1414 (capi_match.cpp) */
+void drfe_motion_flags(const float* TcwCur, const float* TcwLast, float mb, int mono, int* fwd, int* bwd);
 hipError_t drfe_launch_window_candidates(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs, int maxQueries,
                                          hipStream_t s);
 hipError_t drfe_launch_mappoints_last(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, const float* d_Twc,

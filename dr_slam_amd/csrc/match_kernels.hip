@@ -780,6 +780,20 @@ hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameSt
     return hipGetLastError();
 }
 
+/* p[0..n) = v as a kernel: memset nodes of a captured graph did not execute on this ROCm (see drfe_launch_orb), and the
+ * per-frame flow replays the matcher from one */
+__global__ __launch_bounds__(256) void k_fill_i32(int* __restrict__ p, int n, int v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t drfe_launch_fill_i32(int* d_p, int n, int v, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, d_p, n, v);
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,
                                     int maxQueries, int mode, float th, float nnratio, int checkOri,
                                     const uint8_t* d_initObs, hipStream_t s, int statusWord)
@@ -791,7 +805,7 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
      * searches (an overflowing window fails THAT call only, the next call on the same extracted batch starts clean),
      * d_status[2] for drfe_match_consecutive_batch, whose check is deferred to the download / pipeline sync - no other
      * search in between can erase it */
-    (void)hipMemsetAsync(c->d_status + statusWord, 0, sizeof(int), s);
+    (void)drfe_launch_fill_i32(c->d_status + statusWord, 1, 0, s);
     if (mode == 0)
         hipLaunchKernelGGL(k_queries_last, dim3((maxQueries + 255) / 256, npairs), dim3(256), 0, s, mb.d_pairs,
                            drfe_kps_un(c), c->d_kpCount, c->maxKp, mb.d_mps, cam, mb.d_scale, th, mb.d_queries);

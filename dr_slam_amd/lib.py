@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check",
+    "drfe_lsd_configure", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -126,6 +126,8 @@ def load() -> C.CDLL:
     L.drfe_pipeline_sync.argtypes = [vp, i32]
     L.drfe_frame_submit.argtypes = [vp, i32, vp, i32, i32, sz, vp, sz, C.POINTER(Camera)]
     L.drfe_frame_collect.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.POINTER(i32)]
+    L.drfe_frame_submit_tracked.argtypes = [vp, i32, vp, i32, i32, sz, vp, sz, C.POINTER(Camera), i32, vp, vp, vp, vp, i32, f32, i32, i32]
+    L.drfe_frame_collect_tracked.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.POINTER(i32), vp, C.POINTER(i32)]
     L.drfe_orb_download.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
     L.drfe_orb_counts.argtypes = [vp, i32, vp]
     L.drfe_orb_fast_partition.argtypes = [vp, i32, i32, vp, vp]
@@ -432,6 +434,32 @@ class Context:
                                             _p(z) if stereo else None, self.max_kp, C.byref(n)), "drfe_frame_collect")
         out = (kps[:n.value].copy(), desc[:n.value].copy())
         return out + (ur[:n.value].copy(), z[:n.value].copy()) if stereo else out
+
+    def frame_submit_tracked(self, slot: int, gray: np.ndarray, depth16: np.ndarray, cam: Camera, last_slot: int, Tcw_cur, Tcw_last,
+                             Twc_last=None, last_mp=None, th=15.0, mono=False, check_ori=True):
+        """One submission per tracked frame: frame_submit + SearchByProjection(this frame, the frame in last_slot) in the same
+        captured graph.  last_mp (MAPPOINT_DTYPE array) = LastFrame.mvpMapPoints; None = its keypoints with depth, unprojected
+        with Twc_last on the device."""
+        assert gray.dtype == np.uint8 and depth16.dtype == np.uint16 and depth16.shape == gray.shape
+        tc = np.ascontiguousarray(Tcw_cur, np.float32); tl = np.ascontiguousarray(Tcw_last, np.float32)
+        tw = np.ascontiguousarray(Twc_last, np.float32) if Twc_last is not None else None
+        mp = np.ascontiguousarray(last_mp, MAPPOINT_DTYPE) if last_mp is not None else None
+        self._chk(self.L.drfe_frame_submit_tracked(self.h, slot, _p(gray), gray.shape[1], gray.shape[0], gray.strides[0], _p(depth16),
+                                                   C.c_size_t(depth16.strides[0] // 2), C.byref(cam), last_slot, _p(tc), _p(tl), _p(tw),
+                                                   _p(mp), 0 if mp is None else len(mp), float(th), int(mono), int(check_ori)),
+                  "drfe_frame_submit_tracked")
+
+    def frame_collect_tracked(self, slot: int):
+        """-> (mvKeys, mDescriptors, mvuRight, mvDepth, cur_to_last, nmatches) of the slot's tracked submission."""
+        kps = np.zeros(self.max_kp, KP_DTYPE)
+        desc = np.zeros((self.max_kp, 32), np.uint8)
+        ur = np.zeros(self.max_kp, np.float32); z = np.zeros(self.max_kp, np.float32)
+        m = np.full(self.max_kp, -1, np.int32)
+        n, nm = C.c_int(0), C.c_int(0)
+        self._chk(self.L.drfe_frame_collect_tracked(self.h, slot, _p(kps), _p(desc), _p(ur), _p(z), self.max_kp, C.byref(n), _p(m),
+                                                    C.byref(nm)), "drfe_frame_collect_tracked")
+        k = n.value
+        return kps[:k].copy(), desc[:k].copy(), ur[:k].copy(), z[:k].copy(), m[:k].copy(), nm.value
 
     def orb_extract_batch_ptr(self, d_gray: int, frame_stride: int, row_stride: int, w: int, h: int, nframes: int,
                               stream: int = 0):

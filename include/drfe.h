@@ -235,6 +235,26 @@ int drfe_search_by_projection_last(drfe_ctx* ctx, int cur_slot, int last_slot, c
                                    int n_last, float th, int mono, int check_ori, const uint8_t* cur_obs,
                                    int32_t* cur_mp, int n_cur, int* nmatches);
 
+/* ONE submission per tracked frame: drfe_frame_submit (above) followed, inside the same captured graph, by
+ * ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) as Tracking::TrackWithMotionModel calls it
+ * (src/Tracking.cc:2181-2202; src/ORBmatcher.cc:1396-1535) - H2D -> ORB -> glue -> map points -> window search + claim
+ * resolution + rotation histogram -> D2H of keypoints, descriptors, mvuRight / mvDepth AND the match array.  CurrentFrame goes
+ * to `slot`, LastFrame is the frame an earlier submission left in `last_slot` (with its grid: submitted with a depth image).
+ * Tcw_cur = the pose the search projects with (mVelocity * LastFrame.mTcw), Tcw_last = LastFrame.mTcw (forward / backward
+ * test).  last_mp != NULL: LastFrame.mvpMapPoints as the caller's map holds them, n_last = LastFrame's keypoint count;
+ * last_mp == NULL: every keypoint of LastFrame with depth, unprojected with Twc_last (Frame::UnprojectStereo) - the
+ * temporal points Tracking::UpdateLastFrame creates on an RGB-D stream - built on the device, so a frame can be submitted
+ * before the previous one has been collected.  CurrentFrame's claims start empty, as TrackWithMotionModel's do.  Needs a depth
+ * image.  drfe_frame_collect_tracked returns what drfe_frame_collect does plus cur_to_last[n] (index of the matched
+ * LastFrame keypoint per current keypoint, -1 = none) and the number of matches; results are identical to
+ * drfe_frame_submit + drfe_frame_collect + drfe_search_by_projection_last (tests/test_gpu_match.py). */
+int drfe_frame_submit_tracked(drfe_ctx* ctx, int slot, const uint8_t* gray, int w, int h, size_t stride, const uint16_t* depth,
+                              size_t depth_stride_elems, const drfe_camera* cam, int last_slot, const float* Tcw_cur,
+                              const float* Tcw_last, const float* Twc_last, const drfe_map_point* last_mp, int n_last, float th,
+                              int mono, int check_ori);
+int drfe_frame_collect_tracked(drfe_ctx* ctx, int slot, drfe_keypoint* kps, uint8_t* desc, float* u_right, float* depth_m, int cap,
+                               int* n_out, int32_t* cur_to_last, int* n_matches);
+
 /* What SearchByProjection(Frame&, vector<MapPoint*>&, th) reads (fields written by
  * Frame::isInFrustum, src/Frame.cc:602-657). */
 typedef struct drfe_tracked_point {

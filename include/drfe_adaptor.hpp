@@ -173,6 +173,37 @@ public:
         std::memcpy(descriptors.data, desc.data, (size_t)n * 32);
     }
 
+    /* One submission per tracked frame (drfe_frame_submit_tracked): what Frame::Frame extracts AND what TrackWithMotionModel's
+     * ORBmatcher(0.9, true).SearchByProjection(mCurrentFrame, mLastFrame, th, mono) returns (src/Tracking.cc:2181-2202), in one
+     * captured graph.  TcwCur = mVelocity * mLastFrame.mTcw; lastMapPoints = mLastFrame.mvpMapPoints flattened to drfe_map_point
+     * records (NULL: the RGB-D temporal points, built on the device from LastFrame's depth and TwcLast).  CollectTracked fills
+     * matches[i] = index into LastFrame of the map point current keypoint i received, -1 = none, and returns nmatches. */
+    void SubmitTracked(int slot, const drfe_cv::Mat& image, const uint16_t* depth16, size_t depthStrideElems, const drfe_camera& cam,
+                       int lastSlot, const float* TcwCur, const float* TcwLast, const float* TwcLast, const drfe_map_point* lastMapPoints,
+                       int nLast, float th, bool mono, bool checkOrientation = true)
+    {
+        drfe_detail::check(drfe_frame_submit_tracked(mCtx.get(), slot, drfe_cv::mat_data(image), image.cols, image.rows, drfe_cv::mat_step(image),
+                                                     depth16, depthStrideElems, &cam, lastSlot, TcwCur, TcwLast, TwcLast, lastMapPoints, nLast,
+                                                     th, mono ? 1 : 0, checkOrientation ? 1 : 0),
+                           mCtx.get(), "drfe_frame_submit_tracked");
+    }
+    int CollectTracked(int slot, std::vector<drfe_cv::KeyPoint>& keypoints, drfe_cv::Mat& descriptors, std::vector<float>& mvuRight,
+                       std::vector<float>& mvDepth, std::vector<int32_t>& matches)
+    {
+        const int cap = drfe_orb_max_keypoints(mCtx.get());
+        keypoints.resize(cap); mvuRight.resize(cap); mvDepth.resize(cap); matches.assign(cap, -1);
+        drfe_cv::Mat desc = drfe_cv::mat_u8(cap, 32);
+        int n = 0, nmatches = 0;
+        drfe_detail::check(drfe_frame_collect_tracked(mCtx.get(), slot, reinterpret_cast<drfe_keypoint*>(keypoints.data()), desc.data,
+                                                      mvuRight.data(), mvDepth.data(), cap, &n, matches.data(), &nmatches),
+                           mCtx.get(), "drfe_frame_collect_tracked");
+        keypoints.resize(n); mvuRight.resize(n); mvDepth.resize(n); matches.resize(n);
+        if (n == 0) { descriptors.release(); return 0; }
+        descriptors = drfe_cv::mat_u8(n, 32);
+        std::memcpy(descriptors.data, desc.data, (size_t)n * 32);
+        return nmatches;
+    }
+
     int inline GetLevels() { return nlevels; }
     float inline GetScaleFactor() { return scaleFactor; }
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }

@@ -571,6 +571,62 @@ def test_per_frame_pipelined_flow(oracle_mod, camname):
     c.close()
 
 
+@pytest.mark.parametrize("camname", ["TUM3", "TUM1"])
+def test_tracked_submission_one_graph_per_frame(oracle_mod, camname):
+    """drfe_frame_submit_tracked / drfe_frame_collect_tracked: H2D -> ORB -> glue -> SearchByProjection(Cur, Last) -> D2H as ONE
+    submission per frame (src/Tracking.cc:2181-2202).  (a) LastFrame's map points supplied by the caller, lock-step, against the
+    oracle's SearchByProjection; (b) map points built on the device from LastFrame's depth (RGB-D temporal points), two
+    submissions in flight, against the same oracle call with the unprojected points - and against the batch matcher."""
+    from dr_slam_amd import lib, synth
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = getattr(synth, camname)
+    frames = list(synth.sequence(9, 6, cam=cam))
+    Tcw, Twc = _poses(frames)
+    o = oracle_mod.OrbOracle()
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    dist = tuple(getattr(cam, "dist", ()) or ())
+    ofr = []
+    for g, d, _ in frames:
+        kps, desc = o(g)
+        df = oracle_mod.depth_to_float(d, np.float32(1.0) / np.float32(cam.depth_factor))
+        kw = dict(dist=cam.dist) if dist and dist[0] != 0.0 else {}
+        ofr.append(oracle_mod.FrameOracle(kps, desc, df, K4, cam.bf, cam.w, cam.h, o.scale, **kw))
+    want = [None]
+    for k in range(1, len(frames)):
+        mp = _last_mp(oracle_mod, ofr[k - 1], Twc[k - 1])
+        want.append((mp,) + tuple(oracle_mod.search_by_projection_last(ofr[k], ofr[k - 1], Tcw[k], Tcw[k - 1], mp, 15.0, False, True)))
+    # (a) caller-supplied map points, lock-step
+    fe = FrontEnd(cam, max_batch=2)
+    c = fe.ctx
+    c.frame_submit(0, frames[0][0], frames[0][1], fe.cam)
+    c.frame_collect(0)
+    with pytest.raises(lib.DrfeError):
+        c.frame_collect_tracked(0)                              # not a tracked submission
+    for k in range(1, len(frames)):
+        mp = want[k][0]
+        gmp = np.zeros(ofr[k - 1].N, lib.MAPPOINT_DTYPE)
+        gmp["valid"], gmp["obs_positive"], gmp["world"], gmp["desc"] = mp["valid"], mp["obsPositive"], mp["world"], mp["desc"]
+        c.frame_submit_tracked(k % 2, frames[k][0], frames[k][1], fe.cam, (k - 1) % 2, Tcw[k], Tcw[k - 1], last_mp=gmp)
+        kps, desc, ur, z, m, nm = c.frame_collect_tracked(k % 2)
+        assert np.array_equal(kps.view(np.uint8), ofr[k].kps.view(np.uint8)) and np.array_equal(desc, ofr[k].desc)
+        assert np.array_equal(ur.view(np.uint32), ofr[k].uRight.view(np.uint32)) and np.array_equal(z.view(np.uint32), ofr[k].depth.view(np.uint32))
+        assert nm == want[k][1] and np.array_equal(m, want[k][2]) and nm > 200, (k, nm, want[k][1])
+    c.close()
+    # (b) map points from LastFrame's depth on the device, frame k + 1 submitted before frame k is collected
+    fe = FrontEnd(cam, max_batch=3)
+    c = fe.ctx
+    c.frame_submit(0, frames[0][0], frames[0][1], fe.cam)
+    c.frame_submit_tracked(1, frames[1][0], frames[1][1], fe.cam, 0, Tcw[1], Tcw[0], Twc_last=Twc[0])
+    c.frame_collect(0)
+    for k in range(1, len(frames)):
+        if k + 1 < len(frames):
+            c.frame_submit_tracked((k + 1) % 3, frames[k + 1][0], frames[k + 1][1], fe.cam, k % 3, Tcw[k + 1], Tcw[k], Twc_last=Twc[k])
+        kps, desc, ur, z, m, nm = c.frame_collect_tracked(k % 3)
+        assert np.array_equal(kps.view(np.uint8), ofr[k].kps.view(np.uint8)) and np.array_equal(desc, ofr[k].desc)
+        assert nm == want[k][1] and np.array_equal(m, want[k][2]), (k, nm, want[k][1])
+    c.close()
+
+
 def test_per_frame_flow_survives_reconfiguration(oracle_mod):
     """The per-slot graphs of drfe_frame_submit are keyed by image size, camera and distortion model: a change of any of
     them between submissions (another resolution - which also re-uploads the geometry tables -, a distortion model switched
