@@ -322,10 +322,14 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
     return B * steps / el, el / steps * 1e3, threads
 
 
-def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
+def full_frontend(cam_name, n_frames: int = 512, reps: int = 2):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
-    SearchByProjection and the surface normals batched on the device; LSD + LBD lines, AHC planes with their PCL-style
-    post-processing and CAPE planes per frame (device passes + the sequential host stages on a pool of host threads)."""
+    SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
+    the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame,
+    the step's frames side by side; NFA arithmetic and key lines on host threads); AHC planes with their PCL-style
+    post-processing and CAPE planes per frame (device passes + the sequential host stages on a pool of host threads).
+    512 frames per step: a frame's region growing is a dependency chain of ~0.12 s on one wavefront, so the device path's rate
+    is frames in flight / that latency."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from dr_slam_amd import lib, sharding, synth
@@ -350,7 +354,8 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
     # planes) for about a fifth of its time: 1.25 threads per CPU fill it (tools/host_pool_scaling.py: 16 CPUs, lines 94 ms with
     # 16 threads, 76 ms with 20)
     nthr = max(2, (ncpu * 5) // 4)
-    split = {"lines": max(1, (nthr * 3) // 4)}
+    # host work per frame: lines ~3 ms (NFA rounds + key lines; ordering and growth are on the device), planes ~7 ms
+    split = {"lines": max(1, nthr // 4)}
     split["planes"] = max(1, nthr - split["lines"])
     ctx_planes = lib.Context(max_batch=1)
     n_cape = 2                       # CAPE lanes: one context per Python thread (the C call releases the GIL)
@@ -388,10 +393,8 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
 
     with ThreadPoolExecutor(3 + n_cape) as pool:
         step(pool)
-        # the two host pools are balanced from the warm-up step's own timing: thread-ms per frame of lines against planes
-        cl, cp = wall["lines"] * split["lines"], wall["ahc_planes"] * split["planes"]
-        split["lines"] = min(nthr - 1, max(1, round(nthr * cl / (cl + cp))))
-        split["planes"] = max(1, nthr - split["lines"])
+        # (the lines pool waits for the device most of a step: its wall time says nothing about the threads it needs, so the
+        # split is not re-balanced from the warm-up step's timing any more)
         if os.environ.get("DRFE_FF_SPLIT"):          # experiments: "lines,planes"
             split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
         step(pool)
@@ -408,8 +411,9 @@ def full_frontend(cam_name, n_frames: int = 96, reps: int = 2):
             "host_threads": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": n_cape}, "host_cpus_available": ncpu,
             "stage_wall_ms_last_step": {k: round(v, 2) for k, v in wall.items()},
             "planes_accepted_per_step": int(nacc),
-            "note": "bound by the sequential host stages of LSD (pixel ordering + region growing) and AHC (clustering): "
-                    "scales with host threads, not with the GPU"}
+            "lines_path": "pixel ordering, region growing, region2rect, refine on the device (k_lsd_order, k_lsd_grow); NFA + key lines on host threads",
+            "note": "bound by the host stages that remain: AHC clustering / flood fill / voxel grid (~7 thread-ms per frame) and the "
+                    "NFA rounds of the lines (~3)"}
 
 
 def launch(args) -> int:
@@ -520,7 +524,9 @@ def main():
     profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) \
         or any(k.startswith("ROCPROF") for k in os.environ)
     workers = 1 if profiled else (args.render_workers or max(1, sharding.host_cpus() // local_world))
+    t_r0 = time.perf_counter()
     base = sharding.render_sequence(seed, n_distinct, cam, kind, workers=workers)
+    t_render = time.perf_counter() - t_r0
 
     import torch
     import torch.distributed as dist
@@ -557,7 +563,9 @@ def main():
     depth_t = torch.from_numpy(depth.view(np.int16)).to(dev)
     torch.cuda.synchronize()                           # the inputs are in HBM before any context's stream reads them
 
+    exchange = None
     if world > 1 or args.bow:
+        t_x = time.perf_counter()
         # the one initial exchange of the sharded mode: rank 0 owns the ORB vocabulary
         # (k=10, L=6, ~50 MB flattened; synthetic because the reference's ORBvoc blob is missing) and
         # broadcasts it over RCCL/xGMI; every rank uploads its copy into its own context(s).
@@ -571,6 +579,10 @@ def main():
         if rank != 0:
             blob = np.zeros(int(size[0]), np.uint8)
         blob = sharding.broadcast_tables(blob, dev, dist if world > 1 else None)
+        torch.cuda.synchronize()
+        exchange = {"collective": "broadcast of the ORB vocabulary from rank 0 (%s)" % ("RCCL" if backend == "nccl" else backend),
+                    "world_size_seen_by_the_collective": dist.get_world_size() if world > 1 else 1, "bytes": int(blob.size),
+                    "ms": round((time.perf_counter() - t_x) * 1e3, 2), "data_path_collectives": 0}
         voc = V.Vocabulary.unpack(blob)
         for f in (fes if args.bow else fes[:1]):
             voc.upload(f.ctx)
@@ -660,18 +672,21 @@ def main():
         achieved = algo / (stage_ms[roof_stage] * 1e-3) / 1e9
         # HBM traffic and VALU utilisation of that kernel from the committed PMC passes (rocprofv3 --pmc, separate runs;
         # cannot be collected from inside this process). Only valid for the same batch size.
-        traffic, traffic_src, valu = None, None, None
+        traffic, traffic_src, valu, valu_cyc = None, None, None, 4.0
         kname = {"pyramid": "k_pyr_resize_lds", "fast": "k_fast_cells_cols<8>" if cells[1] else "k_fast_cells",
                  "fast_b": "k_fast_cells_cols<12>", "blur": "k_blur", "desc": "k_orient_desc",
                  "match": "k_window_candidates"}[roof_stage]
         try:
-            pmc_name = ("r02_pmc_traffic_c5_b%d.json" if config == 5 else "r02_pmc_traffic_b%d.json") % B
+            pmc_name = ("r02_pmc_traffic_c5_b%d.json" if config == 5 else "r03_pmc_traffic_b%d.json") % B
+            if not os.path.exists(os.path.join(ROOT, "profiles", pmc_name)):
+                pmc_name = pmc_name.replace("r03_", "r02_")
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
                 k = pmc["kernels"][kname]
                 traffic = float(k["HBM_BYTES_per_launch"])
                 traffic_src = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 half-count correction, calibrated, see its _about)" % pmc_name
                 valu = k.get("valu_issue_utilisation")
+                valu_cyc = k.get("cycles_per_valu_instruction", 4.0)
         except Exception:
             pass
         fps = total_frames / el
@@ -691,11 +706,16 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": stage_ms[roof_stage],
                          "algorithmic_bytes_per_launch": algo,
-                         "valu_issue_utilisation": valu, "valu_source": "SQ_INSTS_VALU x 4 / 1024 SIMDs against SQ_BUSY_CYCLES / 32 "
-                                                                         "(profiles/r02_pmc_sq_pass1_b512.csv via tools/pmc_traffic.py)"},
+                         "valu_issue_utilisation": valu,
+                         "valu_source": "SQ_INSTS_VALU x %.2f cycles (the kernel's own mix priced with the measured per-instruction issue costs: "
+                                        "profiles/r03_valu_issue.txt, tools/valu_mix.py) / 1024 SIMDs against SQ_BUSY_CYCLES / 32 "
+                                        "(tools/pmc_traffic.py)" % valu_cyc},
         }
         if one_at_a_time:
             out["one_batch_at_a_time"] = one_at_a_time
+        if exchange:
+            out["initial_exchange"] = exchange
+        out["render"] = {"frames": len(base), "workers": workers, "seconds": round(t_render, 2)}
         out["parity"] = "bit-exact vs the in-repo CPU oracle; the oracle restates OpenCV 3.4 / Eigen 3.3.7 / PCL 1.9 and is UNPINNED " \
                         "against the real libraries (none can be built here)"
         if config == 5:

@@ -3,7 +3,12 @@
 holding SQ_INSTS_VALU + SQ_BUSY_CYCLES of the same bench command, collected without any tracing) into the per-kernel table
 bench.py reads: HBM traffic per launch and the VALU issue utilisation.
 
-usage: tools/pmc_traffic.py <fetch.csv> <write.csv> <batch> <out.json> [sq.csv]"""
+usage: tools/pmc_traffic.py <fetch.csv> <write.csv> <batch> <out.json> [sq.csv [valu_mix.json]]
+
+valu_mix.json (tools/valu_mix.py): the kernel's own average issue cost per VALU instruction from its static mix and the measured
+per-instruction costs (profiles/rNN_valu_issue.txt) - ~2.3 cycles for plain 32-bit VOP1/VOP2 forms, ~4.1 for packed / three-input /
+permute / multiply / f64 forms.  Without it every instruction is priced at 4 cycles (round 2's model: right for the FAST
+kernel, whose mix is 90 % 4-cycle forms, 15-20 % too high for resize / descriptor / quadtree)."""
 import collections
 import csv
 import json
@@ -40,12 +45,21 @@ def main():
         # (SQ_BUSY_CYCLES is reported summed over the 32 shader engines x ... of the device: normalised as in round 1 by the
         # ratio that makes a pure-VALU micro-kernel read 1.0: busy / 32)
         vi, bc = fold(sys.argv[5], "SQ_INSTS_VALU"), fold(sys.argv[5], "SQ_BUSY_CYCLES")
+        mix = json.load(open(sys.argv[6]))["kernels"] if len(sys.argv) > 6 else {}
         for k in kernels:
             if k in vi and k in bc and bc[k][0] > 0:
                 inst, busy = vi[k][0] / vi[k][1], bc[k][0] / bc[k][1]
                 kernels[k]["SQ_INSTS_VALU_per_launch"] = round(inst)
                 kernels[k]["SQ_BUSY_CYCLES_per_launch"] = round(busy)
-                kernels[k]["valu_issue_utilisation"] = round(min(1.0, inst * 4.0 / 1024.0 / (busy / 32.0)), 3)
+                cyc = 4.0
+                m = mix.get(k) or next((v for n, v in mix.items() if n.split("<")[0] == k), None)
+                if m:
+                    cyc = m["cycles_per_valu_instruction"]
+                    kernels[k]["cycles_per_valu_instruction"] = cyc
+                    kernels[k]["valu_share_at_2_cycle_rate"] = m["share_at_2_cycle_rate"]
+                # NOT capped: a value above 1 would say the cost model is wrong
+                kernels[k]["valu_issue_utilisation"] = round(inst * cyc / 1024.0 / (busy / 32.0), 3)
+                kernels[k]["valu_issue_utilisation_flat4"] = round(inst * 4.0 / 1024.0 / (busy / 32.0), 3)
     doc = {
         "_about": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) over "
                   f"`python3 bench.py --steps 5 --warmup 2 --distinct 8 --no-cpu-baseline --no-extras` (tools/profile_round.sh) (batch {batch}, 640x480), MI355X. Counter "
