@@ -358,8 +358,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 2):
     split = {"lines": max(1, nthr // 4)}
     split["planes"] = max(1, nthr - split["lines"])
     ctx_planes = lib.Context(max_batch=1)
-    n_cape = 2                       # CAPE lanes: one context per Python thread (the C call releases the GIL)
-    ctx_cape = [lib.Context(max_batch=1) for _ in range(n_cape)]
+    n_cape = 2                       # CAPE lanes (host threads of drfe_planes_cape_batch)
+    ctx_cape = [lib.Context(max_batch=1)]
     wall = {}
 
     def timed(name, fn):
@@ -372,11 +372,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 2):
         _, n, _, na, _ = ctx_planes.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=split["planes"])
         return len(n), int(na.sum())
 
-    def cape_lane(k):
-        return sum(len(ctx_cape[k].planes_cape(depth_m[f], K4, 20)["planes"]) for f in range(k, n_frames, n_cape))
-
     def cape(pool):
-        return sum(f.result() for f in [pool.submit(cape_lane, k) for k in range(n_cape)])
+        return int(ctx_cape[0].planes_cape_batch(depth_m, K4, 20, n_threads=n_cape)[1].sum())
 
     def step(pool):
         fl = pool.submit(timed, "lines", lambda: fe.ctx.lsd_extract_batch(gray, n_threads=split["lines"]))

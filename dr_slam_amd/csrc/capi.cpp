@@ -111,6 +111,7 @@ void drfe_destroy(drfe_ctx* c)
     drfe_planes_free(c);
     drfe_bow_free(c);
     drfe_lines_free(c);
+    drfe_cape_lanes_free(c);
     drfe_post_free(c);
     drfe_one_shot_free(c);
     drfe_frame_lanes_free(c);
@@ -157,6 +158,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->bow = nullptr;
     c->ls = nullptr;
     c->lsBatch = nullptr;
+    c->capeLanes = nullptr;
     c->lsdDeviceGrow = 1;
     c->lineWorkers = nullptr;
     c->frameLanes = nullptr;

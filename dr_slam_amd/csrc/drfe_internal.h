@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -162,6 +163,7 @@ struct drfe_ctx {
     void* lineHost;           /* LineHost*: host buffers of the single-frame line entry */
     struct OrbOneShot* oneShot; /* captured hipGraph of the single-frame ORB entry (capi.cpp) */
     void* cape;               /* CapeScratch*: device buffers of drfe_planes_cape (planes_internal.h) */
+    void* capeLanes;          /* std::vector<CapeLane>*: lanes of drfe_planes_cape_batch (planes_cape.cpp) */
     void* sn;                 /* SnBuffers*: surface-normal scratch (post_internal.h) */
     void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */
     struct LinesScratch* lsBatch; /* frame slots of drfe_lsd_extract_batch's device region growing (lines_lsd.cpp) */
@@ -177,9 +179,27 @@ struct drfe_ctx {
 /* what the matchers and the grid read: mvKeysUn (== mvKeys without distortion) */
 static inline drfe_keypoint* drfe_kps_un(const drfe_ctx* c) { return c->dist.enabled ? c->d_kpsUn : c->d_kps; }
 
+/* Waiting for a stream on a POOL thread: hipStreamSynchronize spins, and a pool that runs more threads than CPUs (the batch
+ * entries do, to cover exactly these waits) then burns the cycles its compute threads need.  Poll an event and sleep in
+ * between: the wait costs microseconds of CPU instead of its whole duration.  (hipEventBlockingSync did not help: measured
+ * more CPU time, not less.)  The single-frame entries keep spinning - there latency is the point. */
+static inline hipError_t drfe_pool_sync(hipStream_t s, hipEvent_t ev)
+{
+    hipError_t e = hipEventRecord(ev, s);
+    if (e != hipSuccess) return e;
+    for (int spins = 0;; spins++) {
+        e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (spins < 4) continue;                             /* a copy of a few KB is done before the first sleep */
+        struct timespec ts = {0, spins < 40 ? 20000 : 100000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 /* capi.cpp: host threads a batch entry point may start by default - the affinity mask clipped by the cgroup CPU quota
  * (std::thread::hardware_concurrency() reports the machine, which oversubscribes a quota-limited container) */
 int drfe_default_host_threads();
+void drfe_cape_lanes_free(drfe_ctx* c);                   /* planes_cape.cpp */
 void drfe_one_shot_free(drfe_ctx* c);                    /* capi.cpp: the captured single-frame ORB graph */
 void drfe_frame_lanes_free(drfe_ctx* c);                 /* capi.cpp: staging + graphs of the per-frame pipelined flow */
 

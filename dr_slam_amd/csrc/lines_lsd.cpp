@@ -542,7 +542,13 @@ struct LineWorker {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     LineHost* host = nullptr;
+    hipEvent_t pollEv = nullptr;      /* pool lanes: drfe_pool_sync sleeps between polls instead of spinning */
 };
+
+static hipError_t lane_sync(LineWorker* c)
+{
+    return c->pollEv ? drfe_pool_sync(c->stream, c->pollEv) : hipStreamSynchronize(c->stream);
+}
 
 static void scratch_free(LinesScratch*& s)
 {
@@ -568,6 +574,7 @@ void drfe_lines_free(drfe_ctx* c)
             scratch_free(w.ls);
             delete w.host;
             if (w.ownsStream && w.stream) (void)hipStreamDestroy(w.stream);
+            if (w.pollEv) (void)hipEventDestroy(w.pollEv);
         }
         delete pool;
         c->lineWorkers = nullptr;
@@ -666,7 +673,7 @@ static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, i
         hipError_t e = hipMemcpyAsync(s->d_cands, cands.data(), nc * sizeof(RectCand), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, v.d_angles, v.sw, v.sh, s->d_counts, st);
         if (e == hipSuccess) e = hipMemcpyAsync(out.data(), s->d_counts, nc * sizeof(int2), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = lane_sync(c);
         if (e != hipSuccess) { c->err = std::string("lsd_extract: rectangle counting: ") + hipGetErrorString(e); countRc = DRFE_ERR_HIP; return false; }
         if (check)
             for (size_t k = 0; k < nc; k++) {
@@ -747,7 +754,7 @@ static int keylines_and_descriptors(LineWorker* c, const FrameView& v, const std
         HIPCHK(c, hipMemcpyAsync(s->d_lbdLines, ll.data(), nl * sizeof(LbdLine), hipMemcpyHostToDevice, st));
         HIPCHK(c, drfe_launch_lbd(s->d_lbdLines, nl, v.d_gx, v.d_gy, w, h, lbdTables(), s->d_lbdOut, st));
         HIPCHK(c, hipMemcpyAsync(ldesc, s->d_lbdOut, (size_t)nl * 32, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, lane_sync(c));
     }
     for (int i = 0; i < nl; i++) {
         if (lines) lines[i] = kls[i];
@@ -778,7 +785,7 @@ static int host_grow_and_finish(LineWorker* c, LinesScratch* fields, int slot, i
     HIPCHK(c, hipMemcpyAsync(angles.data(), fields->d_angles + ns * slot, ns * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(H.cs.data(), fields->d_cs + ns * slot, ns * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(meta, fields->d_meta + 2 * (size_t)slot, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, lane_sync(c));
     double maxGrad = -1;
     if (meta[0]) std::memcpy(&maxGrad, &meta[0], 8);
 
@@ -977,7 +984,7 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
             } else {
                 std::vector<RectD> pending(nRects);
                 if (nRects > 0 && hipMemcpyAsync(pending.data(), A->d_rects + (size_t)A->rectCap * f, sizeof(LsdRect) * nRects, hipMemcpyDeviceToHost, lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
-                if (rc == DRFE_OK && nRects > 0 && hipStreamSynchronize(lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
+                if (rc == DRFE_OK && nRects > 0 && lane_sync(lw) != hipSuccess) rc = DRFE_ERR_HIP;
                 if (rc != DRFE_OK) lw->err = "lsd_extract_batch: rectangle download";
                 if (rc == DRFE_OK) {
                     const FrameView v = {A->w, A->h, A->sw, A->sh, A->d_angles + ns * f, A->d_gx + n * f, A->d_gy + n * f};
@@ -1150,6 +1157,7 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
     while ((int)pool->size() < T) {
         LineWorker lw;
         HIPCHK(c, hipStreamCreateWithFlags(&lw.stream, hipStreamNonBlocking));
+        if (!std::getenv("DRFE_POOL_SPIN")) HIPCHK(c, hipEventCreateWithFlags(&lw.pollEv, hipEventDisableTiming));
         lw.ownsStream = true;
         pool->push_back(lw);
     }

@@ -12,6 +12,8 @@
  */
 #include "drfe_internal.h"
 #include "planes_internal.h"
+#include <thread>
+#include <atomic>
 #include "ahc_math.h"
 
 #include <algorithm>
@@ -77,11 +79,18 @@ struct Grow {
 hipError_t drfe_launch_cape_cells(const float* d_depth, size_t rowStride, int w, int h, const float K4[4], int patch,
                                   float sinCos, float maxMergeDist, CapeCellRec* d_out, hipStream_t s);
 
-extern "C" {
+/* one CAPE lane of drfe_planes_cape_batch: what the core below touches of a context (same member names) */
+struct CapeLane {
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* cape = nullptr;
+};
 
-int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
-                     float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
-                     uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn)
+template <class Ctx>
+static int planes_cape_core(Ctx* c, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
+                            float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
+                            uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn)
 {
     if (!c || !depth_m || !K4 || !n_planes || !seg) return DRFE_ERR_INVALID;
     *n_planes = 0;
@@ -286,6 +295,78 @@ int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t str
                                       cs->d_tab + offGrid, cs->d_tab + offBnd, cs->d_seg, c->stream));
     HIPCHK(c, hipMemcpyAsync(seg, cs->d_seg, (size_t)npx, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DRFE_OK;
+}
+
+static void cape_scratch_free(void*& p)
+{
+    CapeScratch* cs = static_cast<CapeScratch*>(p);
+    if (!cs) return;
+    void* ptrs[] = {cs->d_depth, cs->d_cells, cs->d_seg, cs->d_tab};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    delete cs;
+    p = nullptr;
+}
+
+void drfe_cape_lanes_free(drfe_ctx* c)
+{
+    auto* pool = static_cast<std::vector<CapeLane>*>(c->capeLanes);
+    if (!pool) return;
+    for (CapeLane& l : *pool) { cape_scratch_free(l.cape); if (l.stream) (void)hipStreamDestroy(l.stream); }
+    delete pool;
+    c->capeLanes = nullptr;
+}
+
+extern "C" {
+
+int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
+                     float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
+                     uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn)
+{
+    return planes_cape_core(c, depth_m, w, h, stride, K4, patch, cos_angle_max, max_merge_dist, planes, cap, n_planes, seg, cells16,
+                            cells_mst, cells_pn);
+}
+
+/* PlaneDetection_CAPE for nframes depth images (metres, frame_stride floats apart) on a pool of n_threads host threads, one
+ * device lane (stream + scratch) each: planes[f * cap ..], n_planes[f], seg[f * w * h ..] (may be NULL: the label images
+ * are then not returned).  Results are identical to nframes calls of drfe_planes_cape.  n_threads <= 0: up to 4. */
+int drfe_planes_cape_batch(drfe_ctx* c, const float* depth_m, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                           const float* K4, int patch, float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap,
+                           int* n_planes, uint8_t* seg, int n_threads)
+{
+    if (!c || !depth_m || !K4 || !planes || !n_planes || nframes < 0 || cap < 1 || frame_stride < stride * (size_t)h) {
+        if (c) c->err = "planes_cape_batch: invalid argument";
+        return DRFE_ERR_INVALID;
+    }
+    if (nframes == 0) return DRFE_OK;
+    const int T = std::max(1, std::min(n_threads > 0 ? n_threads : 4, nframes));
+    HIPCHK(c, hipSetDevice(c->device));
+    auto* pool = static_cast<std::vector<CapeLane>*>(c->capeLanes);
+    if (!pool) { pool = new std::vector<CapeLane>(); c->capeLanes = pool; }
+    while ((int)pool->size() < T) {
+        CapeLane l;
+        l.device = c->device;
+        HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        pool->push_back(l);
+    }
+    std::vector<int> rcs(T, DRFE_OK);
+    std::vector<std::thread> th;
+    std::atomic<int> next(0);
+    const size_t px = (size_t)w * h;
+    for (int k = 0; k < T; k++)
+        th.emplace_back([&, k]() {
+            CapeLane* l = &(*pool)[k];
+            std::vector<uint8_t> segTmp(seg ? 0 : px);
+            for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {
+                const int rc = planes_cape_core(l, depth_m + (size_t)f * frame_stride, w, h, stride, K4, patch, cos_angle_max, max_merge_dist,
+                                                planes + (size_t)f * cap, cap, &n_planes[f], seg ? seg + (size_t)f * px : segTmp.data(),
+                                                nullptr, nullptr, nullptr);
+                if (rc != DRFE_OK) { rcs[k] = rc; return; }
+            }
+        });
+    for (std::thread& t : th) t.join();
+    for (int k = 0; k < T; k++)
+        if (rcs[k] != DRFE_OK) { c->err = (*pool)[k].err; return rcs[k]; }
     return DRFE_OK;
 }
 

@@ -622,6 +622,12 @@ typedef struct drfe_cape_plane {
 int drfe_planes_cape(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
                      float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
                      uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn);
+/* The same for nframes depth images (metres; frame f at depth_m + f * frame_stride floats) on a pool of n_threads host threads, one
+ * device lane each: planes[f * cap ..], n_planes[f], seg[f * w * h ..] (seg may be NULL).  Identical to nframes calls of
+ * drfe_planes_cape.  n_threads <= 0: up to 4. */
+int drfe_planes_cape_batch(drfe_ctx* ctx, const float* depth_m, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                           const float* K4, int patch, float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap,
+                           int* n_planes, uint8_t* seg, int n_threads);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* Plane post-processing and surface normals (replaces the PCL part of Frame::ComputePlanes / ComputePlanes_CAPE,  */

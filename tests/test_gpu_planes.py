@@ -106,3 +106,24 @@ def test_ahc_batch_equals_single(ctx):
             assert np.array_equal(a["seg"], b["seg"])
             for ma, mb in zip(a["members"], b["members"]):
                 assert np.array_equal(ma, mb)
+
+
+def test_cape_batch_equals_single():
+    """drfe_planes_cape_batch (pool of host threads, one device lane each) == per-frame drfe_planes_cape: planes, counts, labels."""
+    from dr_slam_amd import lib, synth
+    cam = synth.ICL
+    frames = list(synth.sequence(3, 5, cam=cam, kind="living_room"))
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = np.float32(1.0) / np.float32(cam.depth_factor)
+    dm = np.stack([f[1].astype(np.float32) * inv for f in frames])
+    c = lib.Context(max_batch=1)
+    try:
+        single = [c.planes_cape(d, K4, 20) for d in dm]
+        for T in (1, 3):
+            planes, n, seg = c.planes_cape_batch(dm, K4, 20, n_threads=T, seg=True)
+            for f, s in enumerate(single):
+                assert n[f] == len(s["planes"]) > 0
+                assert np.array_equal(planes[f, :n[f]].view(np.uint8), np.ascontiguousarray(s["planes"]).view(np.uint8))
+                assert np.array_equal(seg[f], s["seg"])
+    finally:
+        c.close()
