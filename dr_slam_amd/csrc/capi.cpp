@@ -160,6 +160,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->lsBatch = nullptr;
     c->capeLanes = nullptr;
     c->lsdDeviceGrow = 1;
+    c->planesDeviceVoxel = 0;
     c->lineWorkers = nullptr;
     c->frameLanes = nullptr;
     c->lineHost = nullptr;

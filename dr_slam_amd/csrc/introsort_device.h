@@ -1,0 +1,237 @@
+/* introsort_device.h — libstdc++'s std::sort (introsort) as a device routine: the element moves of bits/stl_algo.h executed by
+ * one workgroup on an array in HBM, so that the PERMUTATION OF EQUAL KEYS is std::sort's.  Two callers need
+ * exactly that (the same two introsort_restated.h serves on the host):
+ *   LSD's pseudo-ordering     std::sort(ordered_points, compare_norm) of cv::LineSegmentDetectorImpl (lsd_order_kernels.hip)
+ *   pcl::VoxelGrid            std::sort(index_vector) on the leaf index (voxel_kernels.hip)
+ * Traits: `Rec` (record type), `key(Rec)` -> uint32 with "a goes before b" == key(a) < key(b), `KEY_BITS`.
+ *   - median-of-three Hoare partitions down to ranges of 16 under a depth limit of 2 lg n: the two sub-ranges a partition leaves are
+ *     independent, so ranges above ORD_BIG records are partitioned by the whole workgroup one after the other and everything
+ *     below is dealt to the sixteen wavefronts, each of which finishes its range depth-first;
+ *   - a Hoare partition swaps the k-th record from the left that does not go before the pivot ("left stopper") with the k-th
+ *     from the right the pivot does not go before, while the former lies left of the latter, and cuts at min(L[K], R[K-1]):
+ *     stopper positions are compacted in rank order by ballot / popcount prefix sums, K is the length of the prefix of pairs
+ *     still in order, and the K swaps are independent;
+ *   - the final insertion sort moves a record left past records it goes before only - it is the stable sort of what the
+ *     partitions left: stable counting passes over five key bits each.
+ * A range that exhausts the depth limit (heap sort in libstdc++) sets bit 0 of the returned status: the caller sorts on the host. */
+#ifndef DRFE_INTROSORT_DEVICE_H
+#define DRFE_INTROSORT_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+/* NTH = threads of the workgroup (a multiple of 64, template parameter): 1024 for the 196 000 keys of a frame's pixel ordering,
+ * 256 for a plane's voxel records - a workgroup's LDS is 128 bytes per thread for the counting passes plus the range queue, and
+ * a 1024-thread sort fills a CU's LDS alone (no other kernel's wavefronts beside it) */
+#define ORD_BIG 8192             /* ranges above this many records: one at a time by the whole workgroup */
+#define ORD_QCAP 1024            /* pending ranges an array can hold (LDS) */
+#define ORD_STACK 48             /* depth-first stack of a wavefront (>= the depth limit 2 lg n of any array that fits) */
+#define ORD_DYN_LDS_BYTES(NTH) (32 * (NTH) * 4)
+
+namespace isd {
+
+struct Seg { uint32_t first, last; int depth; };
+
+/* LDS state of one sort (declare one per kernel: __shared__ isd::Shared<NTH> sh;) */
+template <int NTH>
+struct Shared {
+    Seg queue[ORD_QCAP];
+    Seg stack[NTH / 64][ORD_STACK];
+    int qHead, qTail, qOverflow, heapNeeded, wcnt[NTH / 64 + 2];
+    uint32_t cutShared;
+};
+
+/* std::__move_median_to_first(result, x, y, z) by one thread */
+template <class T>
+__device__ __forceinline__ void median_to_first(typename T::Rec* a, uint32_t result, uint32_t x, uint32_t y, uint32_t z)
+{
+    const uint32_t kx = T::key(a[x]), ky = T::key(a[y]), kz = T::key(a[z]);
+    uint32_t pick;
+    if (kx < ky) {
+        if (ky < kz) pick = y;
+        else if (kx < kz) pick = z;
+        else pick = x;
+    } else if (kx < kz) pick = x;
+    else if (ky < kz) pick = z;
+    else pick = y;
+    const typename T::Rec t = a[result];
+    a[result] = a[pick];
+    a[pick] = t;
+}
+
+/* std::__unguarded_partition(a + first + 1, a + last, a + first) by a group of NT threads (64: one wavefront; NTH: the
+ * workgroup).  tid = thread index inside the group.  posL / posR: scratch of the range's length at [first, last).  wcnt: LDS,
+ * NT / 64 + 2 ints (workgroup variant).  Returns the cut to every thread. */
+template <int NT, class T>
+__device__ __forceinline__ uint32_t hoare_cut(typename T::Rec* a, uint32_t first, uint32_t last, uint32_t* posL, uint32_t* posR, int tid, int* wcnt)
+{
+    const uint32_t lo = first + 1, hi = last;
+    const uint32_t pk = T::key(a[first]);
+    const int lane = tid & 63, wv = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto group_sync = [&]() { if (NT > 64) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); };
+    /* exclusive rank of a flagged thread inside the group's block + the block's total */
+    auto block_rank = [&](bool f, uint32_t& total) -> uint32_t {
+        const unsigned long long m = __ballot(f);
+        uint32_t r = (uint32_t)__popcll(m & lt);
+        if (NT > 64) {
+            __syncthreads();
+            if (lane == 0) wcnt[wv] = __popcll(m);
+            __syncthreads();
+            uint32_t before_ = 0, all = 0;
+            for (int k = 0; k < NT / 64; k++) { const uint32_t c = (uint32_t)wcnt[k]; if (k < wv) before_ += c; all += c; }
+            r += before_;
+            total = all;
+        } else total = (uint32_t)__popcll(m);
+        return r;
+    };
+    uint32_t cntL = 0, cntR = 0;
+    for (uint32_t base = lo; base < hi; base += NT) {                      /* left stoppers (records that do not go before the pivot), ascending */
+        const uint32_t p = base + tid;
+        const bool f = p < hi && !(T::key(a[p]) < pk);
+        uint32_t tot;
+        const uint32_t r = block_rank(f, tot);
+        if (f) posL[first + cntL + r] = p;
+        cntL += tot;
+    }
+    for (uint32_t off = 0; lo + off < hi; off += NT) {                     /* right stoppers (the pivot does not go before them), descending */
+        const uint32_t back = off + tid;
+        const bool in = back < hi - lo;
+        const uint32_t p = hi - 1 - (in ? back : 0);
+        const bool f = in && !(pk < T::key(a[p]));
+        uint32_t tot;
+        const uint32_t r = block_rank(f, tot);
+        if (f) posR[first + cntR + r] = p;
+        cntR += tot;
+    }
+    group_sync();
+    /* K = pairs still in order: a prefix of the rank order */
+    const uint32_t m = cntL < cntR ? cntL : cntR;
+    uint32_t K = 0;
+    for (uint32_t base = 0; base < m; base += NT) {
+        const uint32_t k = base + tid;
+        const bool f = k < m && posL[first + k] < posR[first + k];
+        uint32_t tot;
+        (void)block_rank(f, tot);
+        K += tot;
+        if (tot < (uint32_t)NT && base + NT < m) break;                   /* the prefix ended inside this block */
+    }
+    for (uint32_t k = tid; k < K; k += NT) {
+        const uint32_t pl = posL[first + k], pr = posR[first + k];
+        const typename T::Rec x = a[pl], y = a[pr];
+        a[pl] = y; a[pr] = x;
+    }
+    const uint32_t l = K < cntL ? posL[first + K] : hi, r = K > 0 ? posR[first + K - 1] : hi;
+    group_sync();
+    return l < r ? l : r;
+}
+
+/* a[0..n) into std::sort's order (the NTH threads of the workgroup call this together).  posL / posR: n uint32 each; tmp: n records
+ * (ping-pong buffer of the counting passes); dyn: ORD_DYN_LDS_BYTES(NTH) of LDS; keyBits: significant bits of the keys present.
+ * Returns (to every thread) 0, or bit 0 = heap sort needed, bit 1 = internal queue overflow: result unusable. */
+template <int NTH, class T>
+__device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, uint32_t* posR, typename T::Rec* tmp, uint32_t* dyn, Shared<NTH>& sh,
+                                    int depthLimit, int keyBits)
+{
+    typedef typename T::Rec Rec;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __syncthreads();
+    if (tid == 0) { sh.qHead = 0; sh.qTail = 0; sh.qOverflow = 0; sh.heapNeeded = 0; }
+    __syncthreads();
+    if (n > 16 && tid == 0) { sh.queue[0].first = 0; sh.queue[0].last = (uint32_t)n; sh.queue[0].depth = depthLimit; sh.qTail = 1; }
+    __syncthreads();
+
+    /* ---- ranges above ORD_BIG: the workgroup partitions them one after the other ---- */
+    for (;;) {
+        if (tid == 0) {
+            int found = -1;
+            for (int k = sh.qHead; k < sh.qTail; k++) if (sh.queue[k].last - sh.queue[k].first > ORD_BIG) { found = k; break; }
+            if (found >= 0) { const Seg s = sh.queue[found]; sh.queue[found] = sh.queue[sh.qHead]; sh.queue[sh.qHead] = s; sh.qHead++; sh.cutShared = 1; }
+            else sh.cutShared = 0;
+        }
+        __syncthreads();
+        if (!sh.cutShared) break;
+        const Seg s = sh.queue[sh.qHead - 1];
+        __syncthreads();
+        if (s.depth == 0) { if (tid == 0) sh.heapNeeded = 1; continue; }
+        if (tid == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
+        __syncthreads();
+        const uint32_t cut = hoare_cut<NTH, T>(a, s.first, s.last, posL, posR, tid, sh.wcnt);
+        if (tid == 0) {
+            if (s.last - cut > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = cut; sh.queue[sh.qTail].last = s.last; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow = 1; }
+            if (cut - s.first > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = s.first; sh.queue[sh.qTail].last = cut; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow = 1; }
+        }
+        __syncthreads();
+    }
+
+    /* ---- everything else: a wavefront takes a range and finishes it depth-first ---- */
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = atomicAdd(&sh.qHead, 1);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= sh.qTail) break;                               /* qTail is final: only the stage above appends */
+        int sp = 0;
+        Seg s = sh.queue[q];
+        for (;;) {
+            /* std::__introsort_loop on s */
+            while (s.last - s.first > 16) {
+                if (s.depth == 0) { if (lane == 0) sh.heapNeeded = 1; break; }
+                s.depth--;
+                if (lane == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                const uint32_t cut = hoare_cut<64, T>(a, s.first, s.last, posL, posR, lane, nullptr);
+                if (s.last - cut > 16) {
+                    if (sp < ORD_STACK) {
+                        if (lane == 0) { sh.stack[wv][sp].first = cut; sh.stack[wv][sp].last = s.last; sh.stack[wv][sp].depth = s.depth; }
+                        sp++;
+                    } else if (lane == 0) sh.qOverflow = 1;
+                }
+                s.last = cut;
+            }
+            if (sp == 0) break;
+            sp--;
+            s = sh.stack[wv][sp];
+        }
+    }
+    __syncthreads();
+
+    /* ---- std::__final_insertion_sort = the stable sort by key: stable counting passes, five bits each ---- */
+    Rec* src = a;
+    Rec* dst = tmp;
+    const uint32_t E = ((uint32_t)n + NTH - 1) / NTH;
+    const uint32_t c0 = min((uint32_t)n, (uint32_t)tid * E), c1 = min((uint32_t)n, c0 + E);
+    const int passes = (keyBits + 4) / 5;
+    for (int pass = 0; pass < passes; pass++) {
+        const int shft = pass * 5;
+        for (int b = 0; b < 32; b++) dyn[b * NTH + tid] = 0;
+        for (uint32_t p = c0; p < c1; p++) dyn[((T::key(src[p]) >> shft) & 31u) * NTH + tid]++;
+        __syncthreads();
+        /* exclusive scan of the 32 x NTH counters in (digit, thread) order: thread i owns entries [32 i, 32 i + 32) */
+        uint32_t loc = 0;
+        for (int k = 0; k < 32; k++) loc += dyn[tid * 32 + k];
+        uint32_t inc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (lane == 63) sh.wcnt[wv] = (int)inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int k = 0; k < wv; k++) wbase += (uint32_t)sh.wcnt[k];
+        uint32_t run = wbase + inc - loc;
+        for (int k = 0; k < 32; k++) { const uint32_t c = dyn[tid * 32 + k]; dyn[tid * 32 + k] = run; run += c; }
+        __syncthreads();
+        for (uint32_t p = c0; p < c1; p++) {
+            const Rec v = src[p];
+            const uint32_t slot = ((T::key(v) >> shft) & 31u) * NTH + tid;
+            dst[dyn[slot]++] = v;
+        }
+        __syncthreads();
+        Rec* t = src; src = dst; dst = t;
+    }
+    if (src != a) {                                         /* odd number of passes: the result sits in tmp */
+        for (uint32_t p = tid; p < (uint32_t)n; p += NTH) a[p] = src[p];
+        __syncthreads();
+    }
+    return (sh.heapNeeded ? 1 : 0) | (sh.qOverflow ? 2 : 0);
+}
+
+} // namespace isd
+#endif

@@ -270,6 +270,7 @@ struct PlaneLane {
     int device = 0;
     PlanesScratch* ps = nullptr;
     hipStream_t stream = nullptr;
+    struct VoxelDevice* vox = nullptr;      /* drfe_planes_ahc_post_batch: the lane's device voxel grid (post_internal.h) */
 };
 
 static void scratch_free(PlanesScratch*& p)
@@ -296,6 +297,7 @@ void drfe_planes_free(drfe_ctx* c)
         for (PlaneLane& l : *pool) {
             scratch_free(l.ps);
             if (l.stream) (void)hipStreamDestroy(l.stream);
+            drfe_voxel_device_free(l.vox);
         }
         delete pool;
         c->planeLanes = nullptr;
@@ -727,6 +729,15 @@ int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, 
 /* drfe_planes_ahc_batch followed, on the same worker thread and frame, by the per-plane loop of Frame::ComputePlanes
  * (drfe_planes_ahc_postprocess): what a frame of the plane path costs end to end, nframes at a time.  post: [nframes][cap];
  * n_accepted / plane_num: [nframes]; the voxel clouds are not returned (use the single-frame call for mvPlanePoints). */
+/* 1: drfe_planes_ahc_post_batch runs pcl::VoxelGrid of every plane on the device (voxel_kernels.hip); 0 (default): on the pool's
+ * host threads.  Results are identical. */
+int drfe_planes_configure(drfe_ctx* c, int device_voxel_grid)
+{
+    if (!c || device_voxel_grid < 0 || device_voxel_grid > 1) { if (c) c->err = "planes_configure: invalid argument"; return DRFE_ERR_INVALID; }
+    c->planesDeviceVoxel = device_voxel_grid;
+    return DRFE_OK;
+}
+
 int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
                                const float* K4, float depth_factor, float max_point_dist, double dist_threshold, drfe_plane* planes,
                                int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num, int n_threads)
@@ -757,6 +768,15 @@ int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_
         th.emplace_back([&, k]() {
             PlaneLane* l = &(*pool)[k];
             std::vector<int32_t> off((size_t)cap + 1), idx(px), voff((size_t)cap + 1);
+            /* pcl::VoxelGrid of the frame's planes on this thread (default) or on the device (drfe_planes_configure(ctx, 1):
+             * voxel_kernels.hip - identical results; it frees ~2.5 ms of CPU per frame, but the thread then sleeps ~3-5 ms per
+             * frame waiting for its ten 256-thread sorts, and beside the line path's long-running kernels the hardware queues
+             * serialise: measured 360-590 frames/s for the whole front-end against 1040-1080 with the host grid) */
+            const bool voxHost = !c->planesDeviceVoxel;
+            if (!voxHost && !l->vox) {
+                l->vox = drfe_voxel_device_create(l->device, &l->err);
+                if (!l->vox) { rcs[k] = DRFE_ERR_HIP; return; }
+            }
             for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {
                 const uint16_t* d = depth + (size_t)f * frame_stride;
                 int rc = planes_ahc_core(l, d, w, h, stride, K4, depth_factor, planes + (size_t)f * cap, cap, &n_planes[f],
@@ -764,7 +784,7 @@ int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_
                 if (rc == DRFE_OK)
                     rc = drfe_ahc_post_core(&l->err, d, w, h, stride, K4, depth_factor, planes + (size_t)f * cap, n_planes[f], off.data(),
                                             idx.data(), max_point_dist, dist_threshold, post + (size_t)f * cap, nullptr, voff.data(), 0,
-                                            &n_accepted[f], plane_num ? &plane_num[f] : nullptr);
+                                            &n_accepted[f], plane_num ? &plane_num[f] : nullptr, voxHost ? nullptr : l->vox);
                 if (rc != DRFE_OK) { rcs[k] = rc; return; }
             }
         });

@@ -8,6 +8,7 @@
 #include "post_internal.h"
 #include "introsort_restated.h"
 
+#include <time.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -257,13 +258,10 @@ struct PostOut {
     drfe_plane_post* post; float* vox; int32_t* voxOff; int capVox; int used; int nAccepted; int failPlanes; bool overflow;
 };
 
-void post_one_plane(const std::vector<Pt>& input, const float coefIn[4], bool gateD, double disTh, bool invalidCountsAsFail, int i,
-                    PostOut* o)
+/* gates + refit of one plane on its voxel cloud */
+void post_one_coarse(const std::vector<Pt>& coarse, const float coefIn[4], bool gateD, double disTh, bool invalidCountsAsFail, int i,
+                     PostOut* o)
 {
-    std::vector<Pt> coarse;
-    const auto tv = std::chrono::steady_clock::now();
-    voxel_downsample(input, 0.05f, &coarse);
-    g_tVoxel += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count();
     drfe_plane_post& P = o->post[i];
     std::memcpy(P.coef, coefIn, 16);
     P.n_voxels = (int32_t)coarse.size();
@@ -283,14 +281,123 @@ void post_one_plane(const std::vector<Pt>& input, const float coefIn[4], bool ga
     }
 }
 
+void post_one_plane(const std::vector<Pt>& input, const float coefIn[4], bool gateD, double disTh, bool invalidCountsAsFail, int i,
+                    PostOut* o)
+{
+    std::vector<Pt> coarse;
+    const auto tv = std::chrono::steady_clock::now();
+    voxel_downsample(input, 0.05f, &coarse);
+    g_tVoxel += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count();
+    post_one_coarse(coarse, coefIn, gateD, disTh, invalidCountsAsFail, i, o);
+}
+
 }  // namespace
+
+/* ---- a lane's device voxel grid ------------------------------------------------------------------------------------------- */
+struct VoxelDevice {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    size_t cap = 0;               /* points the buffers hold */
+    float* d_pts = nullptr; unsigned long long* d_recs = nullptr; unsigned long long* d_tmp = nullptr;
+    uint32_t* d_posL = nullptr; uint32_t* d_posR = nullptr; float* d_out = nullptr;
+    int2* d_jobs = nullptr; int* d_counts = nullptr;
+    float* h_pts = nullptr; float* h_out = nullptr; int2* h_jobs = nullptr; int* h_counts = nullptr;
+};
+#define VOX_MAX_JOBS 256
+
+static void voxel_buffers_free(VoxelDevice* v)
+{
+    void* d[] = {v->d_pts, v->d_recs, v->d_tmp, v->d_posL, v->d_posR, v->d_out};
+    for (void* p : d) if (p) (void)hipFree(p);
+    if (v->h_pts) (void)hipHostFree(v->h_pts);
+    if (v->h_out) (void)hipHostFree(v->h_out);
+    v->d_pts = nullptr; v->d_recs = nullptr; v->d_tmp = nullptr; v->d_posL = nullptr; v->d_posR = nullptr; v->d_out = nullptr;
+    v->h_pts = nullptr; v->h_out = nullptr; v->cap = 0;
+}
+
+VoxelDevice* drfe_voxel_device_create(int device, std::string* err)
+{
+    VoxelDevice* v = new (std::nothrow) VoxelDevice();
+    if (!v) return nullptr;
+    v->device = device;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&v->ev, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc((void**)&v->d_jobs, VOX_MAX_JOBS * sizeof(int2)) == hipSuccess && hipMalloc((void**)&v->d_counts, VOX_MAX_JOBS * sizeof(int)) == hipSuccess &&
+              hipHostMalloc((void**)&v->h_jobs, VOX_MAX_JOBS * sizeof(int2), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void**)&v->h_counts, VOX_MAX_JOBS * sizeof(int), hipHostMallocDefault) == hipSuccess;
+    if (!ok) { if (err) *err = "voxel grid lane: allocation failed"; drfe_voxel_device_free(v); return nullptr; }
+    return v;
+}
+
+void drfe_voxel_device_free(VoxelDevice* v)
+{
+    if (!v) return;
+    voxel_buffers_free(v);
+    if (v->d_jobs) (void)hipFree(v->d_jobs);
+    if (v->d_counts) (void)hipFree(v->d_counts);
+    if (v->h_jobs) (void)hipHostFree(v->h_jobs);
+    if (v->h_counts) (void)hipHostFree(v->h_counts);
+    if (v->ev) (void)hipEventDestroy(v->ev);
+    if (v->stream) (void)hipStreamDestroy(v->stream);
+    delete v;
+}
+
+/* pcl::VoxelGrid(0.05) of every plane's cloud in one launch; coarse[i] filled for the planes the device finished, done[i] = 0
+ * for those it handed back (grid overflow, heap-sort branch) or that did not fit */
+static bool voxel_downsample_device(VoxelDevice* v, const std::vector<Pt>* inputs, int np, std::vector<Pt>* coarse,
+                                    std::vector<char>& done, std::string* err)
+{
+    done.assign(np, 0);
+    if (np == 0) return true;
+    if (np > VOX_MAX_JOBS) return true;                   /* host path for all */
+    size_t total = 0;
+    for (int i = 0; i < np; i++) total += inputs[i].size();
+    if (total == 0) return true;
+    auto fail = [&](const char* what, hipError_t e) { if (err) *err = std::string("voxel grid lane: ") + what + ": " + hipGetErrorString(e); return false; };
+    hipError_t e = hipSetDevice(v->device);
+    if (e != hipSuccess) return fail("hipSetDevice", e);
+    if (v->cap < total) {
+        voxel_buffers_free(v);
+        const size_t cap = std::max<size_t>(total + total / 4, 1 << 16);
+        if ((e = hipMalloc((void**)&v->d_pts, cap * 12)) != hipSuccess || (e = hipMalloc((void**)&v->d_recs, cap * 8)) != hipSuccess ||
+            (e = hipMalloc((void**)&v->d_tmp, cap * 8)) != hipSuccess || (e = hipMalloc((void**)&v->d_posL, cap * 4)) != hipSuccess ||
+            (e = hipMalloc((void**)&v->d_posR, cap * 4)) != hipSuccess || (e = hipMalloc((void**)&v->d_out, cap * 12)) != hipSuccess ||
+            (e = hipHostMalloc((void**)&v->h_pts, cap * 12, hipHostMallocDefault)) != hipSuccess ||
+            (e = hipHostMalloc((void**)&v->h_out, cap * 12, hipHostMallocDefault)) != hipSuccess)
+            return fail("buffer allocation", e);
+        v->cap = cap;
+    }
+    size_t off = 0;
+    for (int i = 0; i < np; i++) {
+        v->h_jobs[i] = make_int2((int)off, (int)inputs[i].size());
+        if (!inputs[i].empty()) std::memcpy(v->h_pts + 3 * off, inputs[i].data(), inputs[i].size() * sizeof(Pt));
+        off += inputs[i].size();
+    }
+    e = hipMemcpyAsync(v->d_pts, v->h_pts, total * 12, hipMemcpyHostToDevice, v->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v->d_jobs, v->h_jobs, np * sizeof(int2), hipMemcpyHostToDevice, v->stream);
+    if (e == hipSuccess) e = drfe_launch_voxel_grid(v->d_pts, v->d_jobs, np, v->d_recs, v->d_tmp, v->d_posL, v->d_posR, v->d_out, v->d_counts, 0.05f, v->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v->h_counts, v->d_counts, np * sizeof(int), hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v->h_out, v->d_out, total * 12, hipMemcpyDeviceToHost, v->stream);
+    if (e == hipSuccess) e = drfe_pool_sync(v->stream, v->ev);
+    if (e != hipSuccess) return fail("launch", e);
+    for (int i = 0; i < np; i++) {
+        const int cnt = v->h_counts[i];
+        if (cnt < 0) continue;                            /* handed back */
+        coarse[i].resize((size_t)cnt);
+        if (cnt) std::memcpy(coarse[i].data(), v->h_out + 3 * (size_t)v->h_jobs[i].x, (size_t)cnt * sizeof(Pt));
+        done[i] = 1;
+    }
+    return true;
+}
+
 
 /* the per-plane loop of Frame::ComputePlanes without a context (error text to *err): shared by drfe_planes_ahc_postprocess
  * and the worker threads of drfe_planes_ahc_post_batch */
 int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, size_t stride, const float* K4, float depth_factor,
                        const drfe_plane* planes, int n_planes, const int32_t* member_offsets, const int32_t* member_idx,
                        float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets,
-                       int cap_voxels, int* n_accepted, int* plane_num)
+                       int cap_voxels, int* n_accepted, int* plane_num, VoxelDevice* vox)
 {
     if (!depth || !K4 || (!planes && n_planes) || n_planes < 0 || !member_offsets || (!member_idx && n_planes) || (!post && n_planes) ||
         !voxel_offsets || !n_accepted) {
@@ -298,14 +405,17 @@ int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, si
         return DRFE_ERR_INVALID;
     }
     PostOut o{post, voxel_xyz, voxel_offsets, cap_voxels, 0, 0, 0, false};
-    std::vector<Pt> input;
+    static thread_local std::vector<std::vector<Pt>> inputs, coarse;
+    inputs.resize(std::max<size_t>(inputs.size(), (size_t)n_planes));
+    coarse.resize(std::max<size_t>(coarse.size(), (size_t)n_planes));
     const double invW = 1.0 / (double)w;
     static const bool trace = std::getenv("DRFE_TRACE_PLANES") != nullptr;      /* wall time per stage on stderr */
     double tGather = 0, tPlane = 0;
     size_t nPts = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < n_planes; i++) {
+        std::vector<Pt>& input = inputs[i];
         input.clear();
-        const auto t0 = std::chrono::steady_clock::now();
         for (int k = member_offsets[i]; k < member_offsets[i + 1]; k++) {
             const int j = member_idx[k];
             if (j < 0 || j >= w * h) { if (err) *err = "planes_ahc_postprocess: member index outside the image"; return DRFE_ERR_INVALID; }
@@ -324,19 +434,30 @@ int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, si
             if (p.z > max_point_dist) continue;
             input.push_back(p);
         }
+        nPts += input.size();
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    struct timespec cpu0, cpu1;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &cpu0);
+    /* pcl::VoxelGrid(0.05) of every plane: on the lane's device grid (one launch for the frame's planes) or on the host */
+    std::vector<char> done((size_t)n_planes, 0);
+    if (vox && !voxel_downsample_device(vox, inputs.data(), n_planes, coarse.data(), done, err)) return DRFE_ERR_HIP;
+    for (int i = 0; i < n_planes; i++)
+        if (!done[i]) voxel_downsample(inputs[i], 0.05f, &coarse[i]);
+    const auto t2 = std::chrono::steady_clock::now();
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &cpu1);
+    const double voxCpuMs = (cpu1.tv_sec - cpu0.tv_sec) * 1e3 + (cpu1.tv_nsec - cpu0.tv_nsec) * 1e-6;
+    g_tVoxel = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    for (int i = 0; i < n_planes; i++) {
         const drfe_plane& e = planes[i];
         const float d = (float)-(e.normal[0] * e.center[0] + e.normal[1] * e.center[1] + e.normal[2] * e.center[2]);
         const float coef[4] = {(float)e.normal[0], (float)e.normal[1], (float)e.normal[2], d};
-        const auto t1 = std::chrono::steady_clock::now();
-        post_one_plane(input, coef, d > max_point_dist, dist_threshold, false, i, &o);
-        if (trace) {
-            tGather += std::chrono::duration<double, std::milli>(t1 - t0).count();
-            tPlane += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-            nPts += input.size();
-        }
+        post_one_coarse(coarse[i], coef, d > max_point_dist, dist_threshold, false, i, &o);
     }
-    if (trace) std::fprintf(stderr, "drfe_ahc_post_core: %d planes, %zu member points; gather %.2f ms; voxel grid %.2f ms; refit %.2f ms\n",
-                            n_planes, nPts, tGather, g_tVoxel, tPlane - g_tVoxel), g_tVoxel = 0;
+    tGather = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    tPlane = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    if (trace) std::fprintf(stderr, "drfe_ahc_post_core: %d planes, %zu member points; gather %.2f ms; voxel grid %.2f ms (%.2f ms of this thread's CPU; %s); refit %.2f ms\n",
+                            n_planes, nPts, tGather, g_tVoxel, voxCpuMs, vox ? "device" : "host", tPlane - g_tVoxel), g_tVoxel = 0;
     voxel_offsets[n_planes] = o.used;
     *n_accepted = o.nAccepted;
     if (plane_num) *plane_num = n_planes - o.failPlanes;     /* planeDetector.plane_num_ -= fail_planes (:1023) */

@@ -663,6 +663,10 @@ int drfe_planes_ahc_postprocess(drfe_ctx* ctx, const uint16_t* depth, int w, int
 int drfe_planes_ahc_post_batch(drfe_ctx* ctx, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
                                const float* K4, float depth_factor, float max_point_dist, double dist_threshold, drfe_plane* planes,
                                int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num, int n_threads);
+/* Where drfe_planes_ahc_post_batch runs pcl::VoxelGrid (leaf 0.05) of a frame's planes: 0 (default) on the pool's host threads,
+ * 1 on the device (voxel_kernels.hip: leaf indices, std::sort's permutation by the device introsort, centroid sums in that
+ * order - one workgroup per plane).  Results are identical (tests/test_gpu_post.py). */
+int drfe_planes_configure(drfe_ctx* ctx, int device_voxel_grid);
 /* The same loop of Frame::ComputePlanes_CAPE (:1111-1141) for the planes / seg image drfe_planes_cape returned: plane_cloud[i]
  * = the points of the pixels labelled i + 1 in raster order (src/PlaneExtractor.cpp:171-188). */
 int drfe_planes_cape_postprocess(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, const uint8_t* seg,

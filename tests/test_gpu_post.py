@@ -181,18 +181,25 @@ def test_post_edge_cases(oracle_mod):
         c.close()
 
 
-def test_ahc_post_batch_equals_single_frame_calls(oracle_mod):
-    """drfe_planes_ahc_post_batch (AHC + the per-plane loop on a pool of host threads) == per-frame drfe_planes_ahc +
-    drfe_planes_ahc_postprocess."""
+@pytest.mark.parametrize("camname,kind,seed", [("TUM3", "room_boxes", 2), ("ICL", "living_room", 3)])
+def test_ahc_post_batch_equals_single_frame_calls(oracle_mod, camname, kind, seed):
+    """drfe_planes_ahc_post_batch (AHC + the per-plane loop on a pool of host threads, pcl::VoxelGrid of every plane ON THE
+    DEVICE: voxel_kernels.hip = std::sort's permutation by introsort_device.h + centroid sums in that order) == per-frame
+    drfe_planes_ahc + drfe_planes_ahc_postprocess (voxel grid on the host): voxel counts and the refitted coefficients, which
+    depend on every bit of every centroid, are identical."""
     from dr_slam_amd import lib, synth
-    cam = synth.TUM3
-    frames = list(synth.sequence(2, 5, cam=cam))
+    cam = getattr(synth, camname)
+    frames = list(synth.sequence(seed, 5, cam=cam, kind=kind))
     depth = np.stack([f[1] for f in frames])
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
     c = lib.Context()
     try:
         planes, n, post, na, pn, seg = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        c.planes_configure(device_voxel_grid=True)
+        planes_d, n_d, post_d, na_d, pn_d, seg_d = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        c.planes_configure(device_voxel_grid=False)
+        assert planes_d.tobytes() == planes.tobytes() and post_d.tobytes() == post.tobytes() and np.array_equal(na_d, na) and np.array_equal(pn_d, pn)
         for f in range(len(frames)):
             ga = c.planes_ahc(depth[f], K4, inv)
             g = c.planes_ahc_postprocess(depth[f], K4, inv, ga, 9.0, 0.10)
