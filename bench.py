@@ -322,14 +322,17 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
     return B * steps / el, el / steps * 1e3, threads
 
 
-def full_frontend(cam_name, n_frames: int = 512, reps: int = 2):
+def full_frontend(cam_name, n_frames: int = 512, reps: int = 2, inflight: int = 2):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
-    the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame,
-    the step's frames side by side; NFA arithmetic and key lines on host threads); AHC planes with their PCL-style
-    post-processing and CAPE planes per frame (device passes + the sequential host stages on a pool of host threads).
-    512 frames per step: a frame's region growing is a dependency chain of ~0.12 s on one wavefront, so the device path's rate
-    is frames in flight / that latency."""
+    the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame);
+    AHC planes with PEAC's extractor on the device (graph, agglomerative clustering, flood fill, re-merge, labels: one
+    wavefront per frame) and their PCL-style post-processing on host threads; CAPE planes per frame; NFA arithmetic and key
+    lines of the line path on host threads.
+    A frame's region growing / plane extraction is a dependency chain of 0.1-0.25 s on ONE wavefront, so the device paths run at
+    (frames in flight) / (that latency): 512 frames per step, and `inflight` steps at a time (each on its own contexts) so that
+    the host stages of one step run while the other step's wavefronts are on the device."""
+    import threading
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from dr_slam_amd import lib, sharding, synth
@@ -346,71 +349,81 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 2):
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
     depth_m = depth.astype(np.float32) * np.float32(inv)
-    fe = FrontEnd(cam, max_batch=n_frames)
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
-    stream = torch.cuda.current_stream().cuda_stream
-    # a host thread of either pool sleeps in stream synchronisations (six NFA rounds per frame of lines, the block fits of the
-    # planes) for about a fifth of its time: 1.25 threads per CPU fill it (tools/host_pool_scaling.py: 16 CPUs, lines 94 ms with
-    # 16 threads, 76 ms with 20)
-    nthr = max(2, (ncpu * 5) // 4)
-    # host work per frame: lines ~3 ms (NFA rounds + key lines; ordering and growth are on the device), planes ~7 ms
-    split = {"lines": max(1, nthr // 4)}
+    inflight = max(1, int(os.environ.get("DRFE_FF_INFLIGHT", inflight)))
+    # host threads per step in flight: a step's pools sleep while its wavefronts are on the device, so the steps together run
+    # ~1.75 threads per CPU; host work per frame: lines ~3 ms (NFA rounds + key lines), planes ~3.5 ms (voxel grids + refit)
+    nthr = max(2, (ncpu * 7) // (4 * inflight))
+    split = {"lines": max(1, (nthr * 2) // 5)}
     split["planes"] = max(1, nthr - split["lines"])
-    ctx_planes = lib.Context(max_batch=1)
+    if os.environ.get("DRFE_FF_SPLIT"):              # experiments: "lines,planes" per step in flight
+        split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
     n_cape = 2                       # CAPE lanes (host threads of drfe_planes_cape_batch)
-    ctx_cape = [lib.Context(max_batch=1)]
-    wall = {}
+    lanes = []
+    for _ in range(inflight):
+        lanes.append({"fe": FrontEnd(cam, max_batch=n_frames), "planes": lib.Context(max_batch=1), "cape": lib.Context(max_batch=1),
+                      "wall": {}, "stream": torch.cuda.Stream()})
 
-    def timed(name, fn):
-        t = time.perf_counter()
-        r = fn()
-        wall[name] = (time.perf_counter() - t) * 1e3
-        return r
+    def step(L, pool):
+        wall = L["wall"]
 
-    def planes():       # AHC planes + Frame::ComputePlanes' per-plane loop, frames across the C++ thread pool
-        _, n, _, na, _ = ctx_planes.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=split["planes"])
-        return len(n), int(na.sum())
+        def timed(name, fn):
+            t = time.perf_counter()
+            r = fn()
+            wall[name] = (time.perf_counter() - t) * 1e3
+            return r
 
-    def cape(pool):
-        return int(ctx_cape[0].planes_cape_batch(depth_m, K4, 20, n_threads=n_cape)[1].sum())
+        def planes():       # AHC planes + Frame::ComputePlanes' per-plane loop
+            _, n, _, na, _ = L["planes"].planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=split["planes"])
+            return len(n), int(na.sum())
 
-    def step(pool):
-        fl = pool.submit(timed, "lines", lambda: fe.ctx.lsd_extract_batch(gray, n_threads=split["lines"]))
+        fl = pool.submit(timed, "lines", lambda: L["fe"].ctx.lsd_extract_batch(gray, n_threads=split["lines"]))
         fp = pool.submit(timed, "ahc_planes", planes)
-        fc = pool.submit(timed, "cape", lambda: cape(pool))
+        fc = pool.submit(timed, "cape", lambda: int(L["cape"].planes_cape_batch(depth_m, K4, 20, n_threads=n_cape)[1].sum()))
         t = time.perf_counter()
-        fe.process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=stream)
-        fe.ctx.surface_normals_batch_ptr(depth_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, K4, inv, 9.0, n_frames, stream)
-        torch.cuda.synchronize()
+        st = L["stream"]
+        with torch.cuda.stream(st):
+            L["fe"].process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=st.cuda_stream)
+            L["fe"].ctx.surface_normals_batch_ptr(depth_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, K4, inv, 9.0, n_frames, st.cuda_stream)
+        st.synchronize()
         wall["orb_match_normals_device"] = (time.perf_counter() - t) * 1e3
         nl, (npl, nacc), ncp = len(fl.result()), fp.result(), fc.result()
         assert nl == n_frames and npl == n_frames and ncp > 0
         return nacc
 
-    with ThreadPoolExecutor(3 + n_cape) as pool:
-        step(pool)
-        # (the lines pool waits for the device most of a step: its wall time says nothing about the threads it needs, so the
-        # split is not re-balanced from the warm-up step's timing any more)
-        if os.environ.get("DRFE_FF_SPLIT"):          # experiments: "lines,planes"
-            split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
-        step(pool)
+    nacc = [0] * inflight
+    with ThreadPoolExecutor(4 * inflight) as pool:
+        for L in lanes:                              # warm-up, one lane at a time: arenas, pinned buffers, graphs
+            step(L, pool)
+            step(L, pool)
+
+        def run(k):
+            for _ in range(reps):
+                nacc[k] = step(lanes[k], pool)
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(inflight)]
         t0 = time.perf_counter()
-        for _ in range(reps):
-            nacc = step(pool)
-        el = (time.perf_counter() - t0) / reps
-    for c in [ctx_planes] + ctx_cape:
-        c.close()
-    fe.ctx.close()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+    for L in lanes:
+        L["planes"].close(); L["cape"].close(); L["fe"].ctx.close()
+    total = inflight * reps * n_frames
     return {"workload": "BASELINE config 3: living_room scene, ICL intrinsics, 640x480: ORB + glue + SearchByProjection + surface "
                         "normals batched on the device; LSD+LBD lines, AHC planes + post-processing, CAPE planes for every frame",
-            "value": n_frames / el, "unit": "frames/s", "frames_per_step": n_frames, "ms_per_step": el * 1e3,
-            "host_threads": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": n_cape}, "host_cpus_available": ncpu,
-            "stage_wall_ms_last_step": {k: round(v, 2) for k, v in wall.items()},
-            "planes_accepted_per_step": int(nacc),
-            "lines_path": "pixel ordering, region growing, region2rect, refine on the device (k_lsd_order, k_lsd_grow); NFA + key lines on host threads",
-            "note": "bound by the host stages that remain: AHC clustering / flood fill / voxel grid (~7 thread-ms per frame) and the "
-                    "NFA rounds of the lines (~3)"}
+            "value": total / el, "unit": "frames/s", "frames_per_step": n_frames, "steps_in_flight": inflight, "steps_timed": inflight * reps,
+            "ms_per_step": el * 1e3 / (inflight * reps),
+            "host_threads_per_step_in_flight": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": n_cape}, "host_cpus_available": ncpu,
+            "stage_wall_ms_last_step": {k: round(v, 2) for k, v in lanes[0]["wall"].items()},
+            "planes_accepted_per_step": int(nacc[0]),
+            "lines_path": "pixel ordering, region growing, region2rect, refine on the device (k_lsd_order, k_lsd_grow: one wavefront per frame); NFA + key lines on host threads",
+            "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels on the device (k_ahc_blocks, k_ahc_frame: one wavefront per frame); "
+                           "voxel grids + gates + RANSAC refit on host threads",
+            "note": "the device paths are latency chains (0.12 s / 0.23 s per frame on one wavefront): their rate is frames in flight over that latency, "
+                    "the host stages that remain cost ~3 ms (lines: NFA rounds) + ~3.5 ms (planes: voxel grids) + ~1 ms (CAPE) of one CPU per frame"}
 
 
 def launch(args) -> int:

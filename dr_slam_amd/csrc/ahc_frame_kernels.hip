@@ -1,0 +1,693 @@
+/* ahc_frame_kernels.hip — PEAC's agglomerative plane extraction for a whole frame on the device: ahc::PlaneFitter::run after
+ * the init-block fits (reference include/peac/AHCPlaneFitter.hpp: initGraph :760-880, ahCluster :986-1192, refineDetails with
+ * findBlockMembership :488-590 and floodFill :431-479, the re-merge and relabel :299-382; restated for the host in
+ * planes_ahc.cpp, which stays the low-latency single-frame path and the checker of this one).
+ *
+ * The algorithm is a chain of order-defined steps - a priority queue of nodes by plane-fit MSE, merges that rewrite the
+ * neighbour lists, a FIFO flood fill whose arrival order decides the labels - so, like the line detector's region growing
+ * (lsd_grow_kernels.hip), ONE WAVEFRONT runs one frame's sequence exactly, wave-uniform, and uses its lanes where the
+ * sequence leaves room:
+ *   - the trial merges of a popped node (one plane fit per neighbour: nine sums added, a 3 x 3 symmetric eigen-solve in f64)
+ *     are independent: one lane each, folded in neighbour order afterwards;
+ *   - rewriting the neighbours' lists after a merge touches a different list per neighbour: one lane each;
+ *   - block membership, seeds, relabelling, member lists are data-parallel passes with ballot / popcount prefix sums;
+ *   - the flood fill evaluates the four neighbours of a queue entry in four lanes (depth -> point -> distance to the plane),
+ *     then applies them in the reference's order.
+ * The priority queue lives in LDS (its size never exceeds the number of init blocks); nodes, neighbour lists, the union-find,
+ * membership / distance maps and the flood-fill queue are in HBM.  Throughput comes from frames in flight: a launch carries one
+ * wavefront per frame.  Overflowing any fixed capacity (neighbour pool, queue, planes) or an uncertified cosine flags the
+ * frame and the host redoes it. */
+#include "drfe_internal.h"
+#include "planes_internal.h"
+#include "ahc_math.h"
+#include "cr_sincos.h"
+
+#define AHCD_HEAP 3200            /* priority-queue capacity (<= init blocks of a 640 x 480 frame) */
+#define AHCD_LIST 768             /* a neighbour list staged in LDS */
+#define AHCD_MAXEX 128            /* extracted planes before the re-merge */
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+namespace {
+
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double rl_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uni_b(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+__device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+struct SinCosR { double s, c; int ok; };
+__device__ __noinline__ SinCosR cr_cos_call(double x)
+{
+    SinCosR r;
+    r.ok = drfe_cr_sincos(x, &r.s, &r.c);
+    return r;
+}
+
+struct Ctx {
+    /* frame arrays (global address space) */
+    const GLOBAL_AS uint16_t* depth; int rowStride;
+    GLOBAL_AS double* S; GLOBAL_AS double* fit; GLOBAL_AS int* N; GLOBAL_AS int* rid; GLOBAL_AS uint8_t* nouse;
+    GLOBAL_AS int* nbOff; GLOBAL_AS int* nbLen; GLOBAL_AS int* pool;
+    GLOBAL_AS int* dsParent; GLOBAL_AS int* dsSize; GLOBAL_AS int* G; GLOBAL_AS int* blkMap; GLOBAL_AS int* ridToPlid;
+    GLOBAL_AS int16_t* mem; GLOBAL_AS float* dist; GLOBAL_AS uint32_t* rf;
+    /* LDS */
+    double* heapKey; uint16_t* heapId; int* lA; int* lB; int* lU; double* win;
+    int heapSize, nNodes, poolUsed, status, lane;
+    AhcDevParams P;
+};
+
+/* --- priority queue: smallest MSE first, ties by the smaller node id (QCmp of planes_ahc.cpp; a total order, so the pop
+ * sequence does not depend on the heap's internals).  Called by lane 0 only. */
+__device__ __forceinline__ bool heap_less(double ka, int ia, double kb, int ib) { return ka < kb || (ka == kb && ia < ib); }
+__device__ void heap_push(Ctx& c, double key, int id)
+{
+    int i = c.heapSize++;
+    while (i > 0) {
+        const int p = (i - 1) >> 1;
+        const double kp = c.heapKey[p];
+        const int ip = c.heapId[p];
+        if (!heap_less(key, id, kp, ip)) break;
+        c.heapKey[i] = kp; c.heapId[i] = (uint16_t)ip;
+        i = p;
+    }
+    c.heapKey[i] = key; c.heapId[i] = (uint16_t)id;
+}
+__device__ int heap_pop(Ctx& c)
+{
+    const int top = c.heapId[0];
+    const int n = --c.heapSize;
+    if (n > 0) {
+        const double key = c.heapKey[n];
+        const int id = c.heapId[n];
+        int i = 0;
+        for (;;) {
+            int ch = 2 * i + 1;
+            if (ch >= n) break;
+            double kc = c.heapKey[ch];
+            int ic = c.heapId[ch];
+            if (ch + 1 < n) {
+                const double k2 = c.heapKey[ch + 1];
+                const int i2 = c.heapId[ch + 1];
+                if (heap_less(k2, i2, kc, ic)) { ch++; kc = k2; ic = i2; }
+            }
+            if (!heap_less(kc, ic, key, id)) break;
+            c.heapKey[i] = kc; c.heapId[i] = (uint16_t)ic;
+            i = ch;
+        }
+        c.heapKey[i] = key; c.heapId[i] = (uint16_t)id;
+    }
+    return top;
+}
+
+/* union-find over the init blocks (DisjointSet.hpp): Find without path compression gives the same roots */
+__device__ __forceinline__ int ds_find(const Ctx& c, int x)
+{
+    int p = c.dsParent[x];
+    while (p != x) { x = p; p = c.dsParent[x]; }
+    return x;
+}
+
+__device__ __forceinline__ double similarity(const Ctx& c, int a, int b)
+{
+    const GLOBAL_AS double* n = c.fit + 8 * (size_t)a + 3;
+    const GLOBAL_AS double* m = c.fit + 8 * (size_t)b + 3;
+    return fabs(n[0] * m[0] + n[1] * m[1] + n[2] * m[2]);
+}
+
+/* insertSorted without duplicates into the list of node a (capacity guaranteed by the caller); one lane */
+__device__ __forceinline__ void list_insert(Ctx& c, int a, int v)
+{
+    GLOBAL_AS int* L = c.pool + c.nbOff[a];
+    int len = c.nbLen[a], pos = 0;
+    while (pos < len && L[pos] < v) pos++;
+    if (pos < len && L[pos] == v) return;
+    for (int k = len; k > pos; k--) L[k] = L[k - 1];
+    L[pos] = v;
+    c.nbLen[a] = len + 1;
+}
+/* eraseSorted; one lane */
+__device__ __forceinline__ void list_erase(Ctx& c, int a, int v)
+{
+    GLOBAL_AS int* L = c.pool + c.nbOff[a];
+    const int len = c.nbLen[a];
+    int pos = 0;
+    while (pos < len && L[pos] < v) pos++;
+    if (pos >= len || L[pos] != v) return;
+    for (int k = pos; k + 1 < len; k++) L[k] = L[k + 1];
+    c.nbLen[a] = len - 1;
+}
+
+/* ParamSet::T_ang(P_INIT, z) with the millimetre defaults (planes_ahc.cpp tAngInit); cosine correctly rounded */
+__device__ double t_ang_init(Ctx& c, double z)
+{
+    const double pi = 3.14159265358979323846;
+    const double z_near = 500, z_far = 4000, a_near = 15.0 * pi / 180.0, a_far = 90.0 * pi / 180.0;
+    double cz = z > z_near ? z : z_near;
+    cz = cz < z_far ? cz : z_far;
+    const double factor = (a_far - a_near) / (z_far - z_near);
+    const SinCosR r = cr_cos_call(factor * cz + a_near - factor * z_near);
+    if (!r.ok) c.status |= 1;
+    return r.c;
+}
+
+/* disconnectAll(p) for the staged list lX of length len (the neighbours of p): every neighbour drops p; lane per neighbour */
+__device__ __forceinline__ void disconnect_staged(Ctx& c, const int* lX, int len, int p)
+{
+    for (int k = c.lane; k < len; k += 64) list_erase(c, lX[k], p);
+    fence();
+}
+
+/* ahCluster (planes_ahc.cpp cluster()): pops until the queue is empty; extracted nodes (N >= minSupport) appended to ex[] */
+__device__ void cluster(Ctx& c, int* ex, int& nEx)
+{
+    const int lane = c.lane;
+    while (uni_i(c.heapSize) > 0) {
+        int p = 0;
+        if (lane == 0) p = heap_pop(c);
+        p = uni_i(p);
+        c.heapSize = uni_i(c.heapSize);
+        if (uni_b(c.nouse[p] != 0)) continue;
+        const int Lp = uni_i(c.nbLen[p]);
+        if (Lp > AHCD_LIST) { c.status |= 2; return; }
+        const GLOBAL_AS int* listP = c.pool + c.nbOff[p];
+        for (int k = lane; k < Lp; k += 64) c.lA[k] = listP[k];
+        double Sp[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Sp[k] = c.S[9 * (size_t)p + k];
+        const int Np = c.N[p], ridP = c.rid[p];
+        /* trial merges, one lane per neighbour; the fold keeps the reference's order and tie rule */
+        bool haveCand = false;
+        double candMse = 0;
+        int candN = 0, candNb = -1;
+        for (int base = 0; base < Lp; base += 64) {
+            const int k = base + lane;
+            bool ok = false;
+            double S[9];
+            AhcFit f;
+            int Nn = 0, ridN = 0, nb = 0;
+            f.mse = 0;
+            if (k < Lp) {
+                nb = c.lA[k];
+                if (!(similarity(c, p, nb) < c.P.cos60)) {
+                    ok = true;
+                    const int Nb = c.N[nb];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) S[q] = Sp[q] + c.S[9 * (size_t)nb + q];
+                    Nn = Np + Nb;
+                    ridN = Np >= Nb ? ridP : c.rid[nb];
+                    ahc_plane_from_sums(S, Nn, &f);
+                }
+            }
+            unsigned long long m = __ballot(ok);
+            int winLane = -1;
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const double mse = rl_d(f.mse, l);
+                if (!haveCand || candMse > mse || (candMse == mse && (double)candN < mse)) {
+                    haveCand = true; candMse = mse; candN = rl_i(Nn, l); candNb = rl_i(nb, l); winLane = l;
+                }
+            }
+            if (winLane >= 0 && lane == winLane) {          /* this chunk's winner parks its merged node in LDS */
+#pragma unroll
+                for (int q = 0; q < 9; q++) c.win[q] = S[q];
+                c.win[9] = f.center[0]; c.win[10] = f.center[1]; c.win[11] = f.center[2];
+                c.win[12] = f.normal[0]; c.win[13] = f.normal[1]; c.win[14] = f.normal[2];
+                c.win[15] = f.mse; c.win[16] = f.curvature;
+                ((int*)(c.win + 17))[0] = Nn; ((int*)(c.win + 17))[1] = ridN;
+            }
+        }
+        bool merge = false;
+        if (haveCand) {
+            const double z = c.win[11];
+            const double t = 1.6e-6 * z * z + 8.0;
+            merge = candMse < t * t;
+        }
+        if (uni_b(merge)) {
+            const int id = c.nNodes;
+            const int Lc = uni_i(c.nbLen[candNb]);
+            if (id >= c.P.maxNodes || Lc > AHCD_LIST) { c.status |= 2; return; }
+            c.nNodes = id + 1;
+            if (lane < 9) c.S[9 * (size_t)id + lane] = c.win[lane];
+            if (lane < 8) c.fit[8 * (size_t)id + lane] = c.win[9 + lane];
+            if (lane == 0) {
+                c.N[id] = ((int*)(c.win + 17))[0]; c.rid[id] = ((int*)(c.win + 17))[1]; c.nouse[id] = 0;
+                heap_push(c, c.win[15], id);
+                /* mergeNbsFrom: union by size of the two root blocks */
+                const int xr = ds_find(c, ridP), yr = ds_find(c, c.rid[candNb]);
+                if (xr != yr) {
+                    if (c.dsSize[xr] < c.dsSize[yr]) { c.dsParent[xr] = yr; c.dsSize[yr] += c.dsSize[xr]; }
+                    else { c.dsParent[yr] = xr; c.dsSize[xr] += c.dsSize[yr]; }
+                }
+            }
+            c.heapSize = uni_i(c.heapSize);
+            const GLOBAL_AS int* listC = c.pool + c.nbOff[candNb];
+            for (int k = lane; k < Lc; k += 64) c.lB[k] = listC[k];
+            /* u = nbs(p) U nbs(cand) \ {p, cand}: two short sorted lists, merged by one lane */
+            int Lu = 0;
+            if (lane == 0) {
+                int i = 0, j = 0;
+                while (i < Lp || j < Lc) {
+                    int v;
+                    if (j >= Lc || (i < Lp && c.lA[i] < c.lB[j])) v = c.lA[i++];
+                    else if (i >= Lp || c.lB[j] < c.lA[i]) v = c.lB[j++];
+                    else { v = c.lA[i]; i++; j++; }
+                    if (v != p && v != candNb) c.lU[Lu++] = v;
+                }
+            }
+            Lu = uni_i(Lu);
+            if (c.poolUsed + Lu > c.P.poolCap) { c.status |= 2; return; }
+            disconnect_staged(c, c.lA, Lp, p);
+            disconnect_staged(c, c.lB, Lc, candNb);
+            /* the new node takes u; every member of u gets it as a neighbour (the largest id so far: appended) */
+            const int off = c.poolUsed;
+            c.poolUsed += Lu;
+            for (int k = lane; k < Lu; k += 64) {
+                const int nb = c.lU[k];
+                c.pool[off + k] = nb;
+                const int len = c.nbLen[nb];
+                c.pool[c.nbOff[nb] + len] = id;
+                c.nbLen[nb] = len + 1;
+            }
+            if (lane == 0) { c.nbOff[id] = off; c.nbLen[id] = Lu; c.nbLen[p] = 0; c.nbLen[candNb] = 0; c.nouse[p] = 1; c.nouse[candNb] = 1; }
+            fence();
+        } else {
+            if (Np >= AHC_MIN_SUPPORT) {
+                if (nEx >= AHCD_MAXEX) { c.status |= 2; return; }
+                if (lane == 0) ex[nEx] = p;
+                nEx++;
+            }
+            disconnect_staged(c, c.lA, Lp, p);
+            if (lane == 0) c.nbLen[p] = 0;
+            fence();
+        }
+    }
+    /* std::stable_sort by N, larger first: a handful of planes, insertion sort */
+    if (lane == 0)
+        for (int i = 1; i < nEx; i++) {
+            const int v = ex[i], nv = c.N[v];
+            int j = i;
+            while (j > 0 && c.N[ex[j - 1]] < nv) { ex[j] = ex[j - 1]; j--; }
+            ex[j] = v;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+} // namespace
+
+extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    __shared__ double heapKey[AHCD_HEAP];
+    __shared__ uint16_t heapId[AHCD_HEAP];
+    __shared__ int lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
+    __shared__ double win[18];
+    __shared__ int ex[AHCD_MAXEX], ex2[AHCD_MAXEX], plidmap[AHCD_MAXEX];
+    __shared__ uint8_t isValid[AHCD_MAXEX];
+    __shared__ double plN[AHCD_MAXEX][3], plC[AHCD_MAXEX][3], plMse[AHCD_MAXEX];
+    __shared__ int counts[AHCD_MAXEX + 1];
+    __shared__ int8_t blkLds[AHCD_HEAP];                      /* flood fill: 1 = the block is kept whole (its pixels are final) */
+    const AhcDevFrame F = frames[blockIdx.x];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    Ctx c;
+    c.depth = (const GLOBAL_AS uint16_t*)F.depth; c.rowStride = (int)F.rowStride;
+    c.S = (GLOBAL_AS double*)F.nodeS; c.fit = (GLOBAL_AS double*)F.nodeFit; c.N = (GLOBAL_AS int*)F.nodeN; c.rid = (GLOBAL_AS int*)F.nodeRid;
+    c.nouse = (GLOBAL_AS uint8_t*)F.nodeNouse; c.nbOff = (GLOBAL_AS int*)F.nbOff; c.nbLen = (GLOBAL_AS int*)F.nbLen; c.pool = (GLOBAL_AS int*)F.nbPool;
+    c.dsParent = (GLOBAL_AS int*)F.dsParent; c.dsSize = (GLOBAL_AS int*)F.dsSize; c.G = (GLOBAL_AS int*)F.G; c.blkMap = (GLOBAL_AS int*)F.blkMap;
+    c.ridToPlid = (GLOBAL_AS int*)F.ridToPlid; c.mem = (GLOBAL_AS int16_t*)F.membership; c.dist = (GLOBAL_AS float*)F.distMap; c.rf = (GLOBAL_AS uint32_t*)F.rf;
+    c.heapKey = heapKey; c.heapId = heapId; c.lA = lA; c.lB = lB; c.lU = lU; c.win = win;
+    c.heapSize = 0; c.nNodes = 0; c.poolUsed = 0; c.status = 0; c.lane = lane; c.P = P;
+    const GLOBAL_AS AhcBlockRec* blocks = (const GLOBAL_AS AhcBlockRec*)F.blocks;
+    GLOBAL_AS int* out = (GLOBAL_AS int*)F.out;
+    const int w = P.w, h = P.h, Nw = P.Nw, Nh = P.Nh, NB = P.NB, npx = w * h;
+    if (NB > AHCD_HEAP || npx > (1 << 20)) { if (lane == 0) { out[0] = 0; out[1] = 4; } return; }
+
+#ifdef AHC_PROFILE
+    unsigned long long tp[8]; int tpi = 0;
+#define TP() tp[tpi++] = wall_clock64()
+#else
+#define TP() (void)0
+#endif
+    TP();
+    /* ---- initGraph: nodes of the valid blocks, in block order ---- */
+    for (int base = 0; base < NB; base += 64) {
+        const int b = base + lane;
+        const bool v = b < NB && blocks[b].valid != 0;
+        const unsigned long long m = __ballot(v);
+        if (b < NB) {
+            c.dsParent[b] = b; c.dsSize[b] = 1;
+            if (v) {
+                const int id = c.nNodes + __popcll(m & lt);
+                c.G[b] = id;
+                for (int k = 0; k < 9; k++) c.S[9 * (size_t)id + k] = blocks[b].sums[k];
+                for (int k = 0; k < 3; k++) { c.fit[8 * (size_t)id + k] = blocks[b].center[k]; c.fit[8 * (size_t)id + 3 + k] = blocks[b].normal[k]; }
+                c.fit[8 * (size_t)id + 6] = blocks[b].mse; c.fit[8 * (size_t)id + 7] = blocks[b].curvature;
+                c.N[id] = blocks[b].N; c.rid[id] = b; c.nouse[id] = 0;
+                c.nbOff[id] = 4 * id; c.nbLen[id] = 0;
+                heapKey[id] = blocks[b].mse; heapId[id] = (uint16_t)id;
+            } else c.G[b] = -1;
+        }
+        c.nNodes += __popcll(m);
+    }
+    c.poolUsed = 4 * c.nNodes;
+    c.heapSize = c.nNodes;
+    fence();
+    if (lane == 0) {                                   /* heapify */
+        const int n = c.heapSize;
+        for (int s = n / 2 - 1; s >= 0; s--) {
+            const double key = heapKey[s];
+            const int id = heapId[s];
+            int i = s;
+            for (;;) {
+                int ch = 2 * i + 1;
+                if (ch >= n) break;
+                double kc = heapKey[ch];
+                int ic = heapId[ch];
+                if (ch + 1 < n && heap_less(heapKey[ch + 1], heapId[ch + 1], kc, ic)) { ch++; kc = heapKey[ch]; ic = heapId[ch]; }
+                if (!heap_less(kc, ic, key, id)) break;
+                heapKey[i] = kc; heapId[i] = (uint16_t)ic;
+                i = ch;
+            }
+            heapKey[i] = key; heapId[i] = (uint16_t)id;
+        }
+    }
+    /* edges: the row pass (a lane per block row), then the column pass (a lane per block column), each with the reference's
+     * skip pattern; a pass only touches the lists of its own row / column */
+    for (int i = lane; i < Nh; i += 64)
+        for (int j = 1; j < Nw; j += 2) {
+            const int cidx = i * Nw + j;
+            if (c.G[cidx - 1] < 0) { --j; continue; }
+            if (c.G[cidx] < 0) continue;
+            if (j < Nw - 1 && c.G[cidx + 1] < 0) { ++j; continue; }
+            const double th = t_ang_init(c, c.fit[8 * (size_t)c.G[cidx] + 2]);
+            if ((j < Nw - 1 && similarity(c, c.G[cidx - 1], c.G[cidx + 1]) >= th) || (j == Nw - 1 && similarity(c, c.G[cidx], c.G[cidx - 1]) >= th)) {
+                list_insert(c, c.G[cidx], c.G[cidx - 1]); list_insert(c, c.G[cidx - 1], c.G[cidx]);
+                if (j < Nw - 1) { list_insert(c, c.G[cidx], c.G[cidx + 1]); list_insert(c, c.G[cidx + 1], c.G[cidx]); }
+            } else --j;
+        }
+    fence();
+    for (int j = lane; j < Nw; j += 64)
+        for (int i = 1; i < Nh; i += 2) {
+            const int cidx = i * Nw + j;
+            if (c.G[cidx - Nw] < 0) { --i; continue; }
+            if (c.G[cidx] < 0) continue;
+            if (i < Nh - 1 && c.G[cidx + Nw] < 0) { ++i; continue; }
+            const double th = t_ang_init(c, c.fit[8 * (size_t)c.G[cidx] + 2]);
+            if ((i < Nh - 1 && similarity(c, c.G[cidx - Nw], c.G[cidx + Nw]) >= th) || (i == Nh - 1 && similarity(c, c.G[cidx], c.G[cidx - Nw]) >= th)) {
+                list_insert(c, c.G[cidx], c.G[cidx - Nw]); list_insert(c, c.G[cidx - Nw], c.G[cidx]);
+                if (i < Nh - 1) { list_insert(c, c.G[cidx], c.G[cidx + Nw]); list_insert(c, c.G[cidx + Nw], c.G[cidx]); }
+            } else --i;
+        }
+    fence();
+    c.status = (int)(__ballot(c.status != 0) != 0);          /* a lane's uncertified cosine */
+
+    TP();
+    /* ---- ahCluster ---- */
+    int nEx = 0;
+    cluster(c, ex, nEx);
+    nEx = uni_i(nEx);
+    if (uni_b(c.status != 0)) { if (lane == 0) { out[0] = 0; out[1] = c.status; } return; }
+
+    TP();
+    /* ---- refineDetails: findBlockMembership ---- */
+    for (int k = lane; k < NB; k += 64) c.ridToPlid[k] = -1;
+    for (int k = lane; k < npx; k += 64) { c.mem[k] = -1; c.dist[k] = 3.402823466e+38f; }
+    for (int k = lane; k < nEx; k += 64) {
+        const int nd = ex[k];
+        for (int q = 0; q < 3; q++) { plC[k][q] = c.fit[8 * (size_t)nd + q]; plN[k][q] = c.fit[8 * (size_t)nd + 3 + q]; }
+        plMse[k] = c.fit[8 * (size_t)nd + 6];
+        isValid[k] = 0;
+    }
+    fence();
+    if (lane == 0)
+        for (int plid = 0; plid < nEx; plid++) {             /* std::map::insert: the first plane of a root keeps it */
+            const int r = c.rid[ex[plid]];
+            if (c.ridToPlid[r] < 0) c.ridToPlid[r] = plid;
+        }
+    fence();
+    for (int b = lane; b < NB; b += 64) {
+        const int i = b / Nw, j = b - i * Nw;
+        const int setid = ds_find(c, b);
+        int bm = -1;
+        if (c.dsSize[setid] * (AHC_WIN * AHC_WIN) >= AHC_MIN_SUPPORT) {
+            bool same = true;
+            if (j > 0 && ds_find(c, b - 1) != setid) same = false;
+            if (same && j < Nw - 1 && ds_find(c, b + 1) != setid) same = false;
+            if (same && i > 0 && ds_find(c, b - Nw) != setid) same = false;
+            if (same && i < Nh - 1 && ds_find(c, b + Nw) != setid) same = false;
+            if (same) { const int v = c.ridToPlid[setid]; bm = v < 0 ? 0 : v; }     /* std::map::operator[]: a missing root reads 0 */
+        }
+        c.blkMap[b] = bm;
+        if (bm >= 0) {
+            isValid[bm] = 1;
+            for (int y = i * AHC_WIN; y < (i + 1) * AHC_WIN; y++)
+                for (int x = j * AHC_WIN; x < (j + 1) * AHC_WIN; x++) c.mem[(size_t)y * w + x] = (int16_t)bm;
+        }
+    }
+    fence();
+    /* seeds of the flood fill, in block raster order: the border pixels between a block and its upper / left neighbour */
+    int nRf = 0;
+    for (int base = 0; base < NB; base += 64) {
+        const int b = base + lane;
+        int cnt = 0, bm = -1, up = -1, left = -1, i = 0, j = 0;
+        if (b < NB) {
+            i = b / Nw; j = b - i * Nw;
+            bm = c.blkMap[b];
+            up = i > 0 ? c.blkMap[b - Nw] : -2;
+            left = j > 0 ? c.blkMap[b - 1] : -2;
+            if (bm < 0) cnt = (up >= 0 ? AHC_WIN - 1 : 0) + (left >= 0 ? AHC_WIN - 1 : 0);
+            else cnt = ((i > 0 && up != bm) ? AHC_WIN - 1 : 0) + ((j > 0 && left != bm) ? AHC_WIN - 1 : 0);
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        const int tot = __shfl(incl, 63);
+        if (nRf + tot > P.rfCap) { c.status |= 2; break; }
+        int at = nRf + incl - cnt;
+        if (cnt) {
+            if (bm < 0) {
+                if (up >= 0) { const int spix = (i * AHC_WIN - 1) * w + j * AHC_WIN; for (int k = 1; k < AHC_WIN; ++k) c.rf[at++] = (uint32_t)(spix + k) | (uint32_t)up << 20; }
+                if (left >= 0) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN - 1; for (int k = 0; k < AHC_WIN - 1; ++k) c.rf[at++] = (uint32_t)(spix + k * w) | (uint32_t)left << 20; }
+            } else {
+                if (i > 0 && up != bm) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN; for (int k = 0; k < AHC_WIN - 1; ++k) c.rf[at++] = (uint32_t)(spix + k) | (uint32_t)bm << 20; }
+                if (j > 0 && left != bm) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN; for (int k = 1; k < AHC_WIN; ++k) c.rf[at++] = (uint32_t)(spix + k * w) | (uint32_t)bm << 20; }
+            }
+        }
+        nRf += tot;
+    }
+    nRf = uni_i(nRf);
+    /* the extracted nodes start the flood fill without neighbours (disconnectAll); connects between them get fresh lists */
+    if (c.poolUsed + nEx * nEx > P.poolCap) c.status |= 2;
+    if (uni_b(__ballot(c.status != 0) != 0)) { if (lane == 0) { out[0] = 0; out[1] = 2; } return; }
+    for (int k = lane; k < nEx; k += 64) { c.nbOff[ex[k]] = c.poolUsed + k * nEx; c.nbLen[ex[k]] = 0; }
+    c.poolUsed += nEx * nEx;
+    fence();
+
+    TP();
+    int rfTotal = 0;
+    /* ---- floodFill: FIFO over (pixel, plane).  Sixteen queue entries per step, their four neighbours each in the 64 lanes.
+     * What a lane needs that never changes (block map, depth -> point -> distance to the entry's plane, the inlier test) and
+     * the fetch of what does change (the neighbour's label and its best distance so far) happen for all 64 at once.  The
+     * reference applies the 64 (entry, neighbour) visits one after the other; the only thing one visit passes to a later one
+     * is the state of a PIXEL both look at - queue appends keep lane order under a ballot prefix, and connecting two planes
+     * is a set insertion.  So every lane finds the previous lane of the step that targets its pixel (a 64-step compare of
+     * lane-broadcast pixel indices), the visits are applied in rounds by depth in those chains (<= 4: a pixel has four
+     * neighbours), a lane taking its input state from its predecessor's output, and the last lane of a chain stores the
+     * pixel.  One memory fence per step. ---- */
+    {
+        int head = 0, tail = nRf;
+        const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy, factor = P.factor;
+        for (int k = lane; k < NB; k += 64) blkLds[k] = (int8_t)(c.blkMap[k] >= 0 ? 1 : 0);
+        fence();
+        const int eLane = lane >> 2, nbLane = lane & 3;          /* entry of the step, neighbour (left, right, up, down) */
+        while (head < tail) {
+            const int cnt = min(16, tail - head);
+            const bool mine = eLane < cnt;
+            uint32_t e = 0;
+            if (mine) e = c.rf[head + eLane];
+            const int sIdx = (int)(e & 0xFFFFFu), plid = (int)(e >> 20);
+            const int sy = sIdx / w, sx = sIdx - sy * w;
+            int cxn = sx, cyn = sy;
+            bool have = false;
+            if (nbLane == 0) { have = sx > 0; cxn = sx - 1; }
+            else if (nbLane == 1) { have = sx < w - 1; cxn = sx + 1; }
+            else if (nbLane == 2) { have = sy > 0; cyn = sy - 1; }
+            else { have = sy < h - 1; cyn = sy + 1; }
+            have = have && mine;
+            const int cIdx = cyn * w + cxn;
+            bool in = false;
+            float cdist = -1.f;
+            int trail = 0;
+            float old = 0.f;
+            if (have) {
+                const int by = cyn / AHC_WIN, bx = cxn / AHC_WIN;
+                if (by < Nh && bx < Nw && blkLds[by * Nw + bx]) have = false;      /* pixels of kept blocks are final */
+            }
+            if (have) {
+                trail = c.mem[cIdx];
+                old = c.dist[cIdx];
+                double z = (double)c.depth[(size_t)cyn * c.rowStride + cxn] * factor;
+                if (z > 5.0) z = 0.0;
+                if (z != 0.0) {
+                    const double px = ((double)cxn - cx) * z / fx, py = ((double)cyn - cy) * z / fy;
+                    const double sd = plN[plid][0] * (px - plC[plid][0]) + plN[plid][1] * (py - plC[plid][1]) + plN[plid][2] * (z - plC[plid][2]);
+                    cdist = (float)fabs(sd);
+                    const double cd = (double)cdist;
+                    in = cd * cd < 9 * plMse[plid] + 1e-5;
+                }
+            }
+            /* chains of lanes that target the same pixel, in lane (= visiting) order */
+            const int key = have ? cIdx : -1 - lane;
+            int prev = -1;
+            bool isLast = true;
+            const int nl = 4 * cnt;
+            for (int l = 0; l < nl; l++) {
+                const int v = rl_i(key, l);
+                if (v == key) { if (l < lane) prev = l; else if (l > lane) isLast = false; }
+            }
+            /* depth in the chain (usually <= 3: a pixel has four neighbours; more when a pixel sits in the queue several times) */
+            int depth = 0, maxDepth = 0;
+            for (;;) {
+                const int dp = __shfl(depth, prev < 0 ? lane : prev);
+                const int nd = prev >= 0 ? dp + 1 : 0;
+                const bool changed = nd != depth;
+                depth = nd;
+                if (!__ballot(changed)) break;
+            }
+            while (__ballot(depth > maxDepth)) maxDepth++;
+            bool push = false, dirty = false, distDirty = false, meets = false;
+            int other = -1;
+            for (int r = 0; r <= maxDepth; r++) {
+                /* a lane of depth r continues from its predecessor's output */
+                const int tIn = __shfl(trail, prev < 0 ? lane : prev);
+                const float oIn = __shfl(old, prev < 0 ? lane : prev);
+                const bool dIn = __shfl((int)dirty, prev < 0 ? lane : prev) != 0, ddIn = __shfl((int)distDirty, prev < 0 ? lane : prev) != 0;
+                if (have && depth == r) {
+                    if (prev >= 0) { trail = tIn; old = oIn; dirty = dIn; distDirty = ddIn; }
+                    const bool active = !(trail <= -6) && !(trail >= 0 && trail == plid);
+                    if (active) {
+                        if (in && trail >= 0) { meets = true; other = trail; }
+                        if (in && cdist < old) { trail = plid; old = cdist; push = true; dirty = true; distDirty = true; }
+                        else if (trail < 0) { trail = trail - 1; dirty = true; }
+                    }
+                }
+            }
+            /* planes that meet and are similar enough are connected for the re-merge (rare: one lane at a time) */
+            unsigned long long cm = __ballot(meets);
+            while (cm) {
+                const int l = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                const int o = ex[rl_i(other, l)], me = ex[rl_i(plid, l)];
+                if (lane == 0 && similarity(c, me, o) >= P.cos30) { list_insert(c, o, me); list_insert(c, me, o); }
+                fence();
+            }
+            if (have && isLast && dirty) {
+                c.mem[cIdx] = (int16_t)trail;
+                if (distDirty) c.dist[cIdx] = old;
+            }
+            const unsigned long long pm = __ballot(push);
+            if (pm) {
+                const int np = __popcll(pm);
+                if (tail + np > P.rfCap) { c.status |= 2; break; }
+                if (push) c.rf[tail + __popcll(pm & lt)] = (uint32_t)cIdx | (uint32_t)plid << 20;
+                tail += np;
+            }
+            head += cnt;
+            fence();
+        }
+        rfTotal = tail;
+    }
+    if (uni_b(c.status != 0)) { if (lane == 0) { out[0] = 0; out[1] = c.status; } return; }
+    TP();
+
+    /* ---- re-merge the grown planes (the valid ones, by MSE) and relabel ---- */
+    c.heapSize = 0;
+    if (lane == 0) {
+        for (int i = 0; i < nEx; i++)
+            if (isValid[i]) heap_push(c, c.fit[8 * (size_t)ex[i] + 6], ex[i]);
+    }
+    c.heapSize = uni_i(c.heapSize);
+    int nFinal = 0;
+    cluster(c, ex2, nFinal);
+    nFinal = uni_i(nFinal);
+    if (uni_b(c.status != 0) || nFinal > P.planeCap || nFinal > 254) { if (lane == 0) { out[0] = nFinal; out[1] = c.status | 2; } return; }
+    for (int i = lane; i < nEx; i += 64) {
+        int pm = -1;
+        if (isValid[i]) {
+            const int r = ds_find(c, c.rid[ex[i]]);
+            for (int j = 0; j < nFinal; j++)
+                if (r == c.rid[ex2[j]]) { pm = j; break; }
+        }
+        plidmap[i] = pm;
+    }
+    for (int i = lane; i <= nFinal; i += 64) counts[i] = 0;
+    GLOBAL_AS drfe_plane* planes = (GLOBAL_AS drfe_plane*)F.planes;
+    for (int i = lane; i < nFinal; i += 64) {
+        const int nd = ex2[i];
+        for (int q = 0; q < 3; q++) { planes[i].normal[q] = c.fit[8 * (size_t)nd + 3 + q]; planes[i].center[q] = c.fit[8 * (size_t)nd + q]; }
+        planes[i].mse = c.fit[8 * (size_t)nd + 6]; planes[i].curvature = c.fit[8 * (size_t)nd + 7];
+        planes[i].n_points = c.N[nd]; planes[i].rid = c.rid[nd];
+    }
+    fence();
+    TP();
+    /* final plane per pixel, the label image, the member lists (raster order per plane) */
+    GLOBAL_AS uint8_t* seg = (GLOBAL_AS uint8_t*)F.seg;
+    for (int base = 0; base < npx; base += 64) {
+        const int k = base + lane;
+        int pl = -1;
+        if (k < npx) {
+            const int raw = c.mem[k];
+            pl = raw >= 0 ? plidmap[raw] : -1;
+            c.mem[k] = (int16_t)pl;
+            seg[k] = (uint8_t)(pl + 1);
+        }
+        /* per-plane counts: the lanes of a plane are counted once per chunk */
+        unsigned long long todo = __ballot(pl >= 0);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            const int v = rl_i(pl, l);
+            const unsigned long long same = __ballot(pl == v);
+            if (lane == l) counts[v + 1] += __popcll(same);
+            todo &= ~same;
+        }
+    }
+    fence();
+    GLOBAL_AS int* memberOff = (GLOBAL_AS int*)F.memberOff;
+    GLOBAL_AS int* memberIdx = (GLOBAL_AS int*)F.memberIdx;
+    if (lane == 0) {
+        for (int i = 0; i < nFinal; i++) counts[i + 1] += counts[i];
+        for (int i = 0; i <= nFinal; i++) memberOff[i] = counts[i];
+    }
+    fence();
+    for (int base = 0; base < npx; base += 64) {
+        const int k = base + lane;
+        const int pl = k < npx ? (int)c.mem[k] : -1;
+        unsigned long long todo = __ballot(pl >= 0);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            const int v = rl_i(pl, l);
+            const unsigned long long same = __ballot(pl == v);
+            if (pl == v) memberIdx[counts[v] + __popcll(same & lt)] = k;
+            fence();
+            if (lane == l) counts[v] += __popcll(same);
+            todo &= ~same;
+        }
+        fence();
+    }
+    TP();
+    if (lane == 0) { out[0] = nFinal; out[1] = 0; out[2] = rfTotal; out[3] = c.nNodes; }
+#ifdef AHC_PROFILE
+    /* phase times (100 MHz ticks) into the head of the flood-fill queue, which nobody reads any more */
+    if (lane == 0) for (int k = 0; k + 1 < tpi; k++) c.rf[k] = (uint32_t)(tp[k + 1] - tp[k]);
+#endif
+}
+
+hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ahc_frame, dim3(nframes), dim3(64), 0, s, d_frames, P);
+    return hipGetLastError();
+}

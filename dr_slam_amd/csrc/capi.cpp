@@ -161,6 +161,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->capeLanes = nullptr;
     c->lsdDeviceGrow = 1;
     c->planesDeviceVoxel = 0;
+    c->planesDeviceAhc = 1;
+    c->ahcArena = nullptr;
     c->lineWorkers = nullptr;
     c->frameLanes = nullptr;
     c->lineHost = nullptr;

@@ -168,6 +168,8 @@ struct drfe_ctx {
     void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */
     struct LinesScratch* lsBatch; /* frame slots of drfe_lsd_extract_batch's device region growing (lines_lsd.cpp) */
     int lsdDeviceGrow;        /* drfe_lsd_configure: 1 = the batch entry grows regions on the device (default) */
+    int planesDeviceAhc;      /* drfe_planes_configure_extractor: 1 = drfe_planes_ahc_post_batch runs the extractor on the device (default) */
+    void* ahcArena;           /* AhcArena*: frame slots of the device extractor (planes_ahc.cpp) */
     int planesDeviceVoxel;    /* drfe_planes_configure: 1 = drfe_planes_ahc_post_batch runs the voxel grids on the device (default 0) */
     void* frameLanes;         /* std::vector<FrameLane>*: per-slot staging of drfe_frame_submit / drfe_frame_collect (capi.cpp) */
 

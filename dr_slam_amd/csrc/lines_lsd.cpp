@@ -1029,7 +1029,10 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     LinesScratch* A = c->lsBatch;
     static const LsdParams P;
     /* at most four chunks: one hardware queue each (streams that share a queue run one behind the other) */
-    const int chunk = std::max(1, std::min(nframes, std::max(16, (nframes + 3) / 4)));
+    /* chunks (= low-priority streams = hardware queues) of this call: the runtime has four queues per priority, and the line and the
+     * plane batch of a front-end step run side by side - two each (DRFE_BATCH_CHUNKS overrides) */
+    static const int nch = [] { const char* e = std::getenv("DRFE_BATCH_CHUNKS"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    const int chunk = std::max(1, std::min(nframes, std::max(16, (nframes + nch - 1) / nch)));
     const int nChunks = (nframes + chunk - 1) / chunk;
     BatchJob J(nChunks);
     J.c = c; J.A = A; J.pool = pool; J.gray = gray; J.frameStride = frame_stride; J.stride = stride;

@@ -18,6 +18,10 @@
 #include "ahc_math.h"
 #include "ahc_math_simd.h"
 #include "post_internal.h"
+#include "cr_sincos.h"
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -111,7 +115,12 @@ static double tAngInit(double z)
     double cz = std::max(z, z_near);
     cz = std::min(cz, z_far);
     const double factor = (a_far - a_near) / (z_far - z_near);
-    return std::cos(factor * cz + a_near - factor * z_near);
+    /* the cosine correctly rounded (cr_sincos.h), as the device path computes it (ahc_frame_kernels.hip); the host's libm
+     * agrees except where it is not correctly rounded (glibc >= 2.28: one argument in ~10^4, by one ulp) */
+    const double a = factor * cz + a_near - factor * z_near;
+    double sn, cs;
+    if (drfe_cr_sincos(a, &sn, &cs)) return cs;
+    return std::cos(a);
 }
 
 /* merged statistics of two nodes (ahc::PlaneSeg(pa, pb): sums added, plane refitted) without the neighbour list */
@@ -292,6 +301,7 @@ void drfe_planes_free(drfe_ctx* c)
         delete cs;
         c->cape = nullptr;
     }
+    drfe_ahc_arena_free(c);
     auto* pool = static_cast<std::vector<PlaneLane>*>(c->planeLanes);
     if (pool) {
         for (PlaneLane& l : *pool) {
@@ -729,12 +739,272 @@ int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, 
 /* drfe_planes_ahc_batch followed, on the same worker thread and frame, by the per-plane loop of Frame::ComputePlanes
  * (drfe_planes_ahc_postprocess): what a frame of the plane path costs end to end, nframes at a time.  post: [nframes][cap];
  * n_accepted / plane_num: [nframes]; the voxel clouds are not returned (use the single-frame call for mvPlanePoints). */
+} /* extern "C" */
+
+/* ---- the extractor on the device for a batch (ahc_frame_kernels.hip): frame slots in HBM ------------------------------------ */
+struct AhcArena {
+    int w = 0, h = 0, frames = 0, cap = 0;
+    AhcDevParams P;
+    uint16_t* d_depth = nullptr; AhcBlockRec* d_blocks = nullptr;
+    uint8_t* d_scratch = nullptr; size_t slotBytes = 0;      /* per-frame scratch + outputs, one block per slot */
+    AhcDevFrame* d_frames = nullptr; AhcDevFrame* h_frames = nullptr;
+    int* h_out = nullptr; drfe_plane* h_planes = nullptr; int* h_memberOff = nullptr;
+    uint16_t* h_depth = nullptr;                              /* pinned staging of the caller's depth images */
+    /* offsets of the outputs inside a slot */
+    size_t offPlanes = 0, offSeg = 0, offMemberOff = 0, offMemberIdx = 0, offOut = 0;
+};
+
+static void arena_free(AhcArena*& a)
+{
+    if (!a) return;
+    void* d[] = {a->d_depth, a->d_blocks, a->d_scratch, a->d_frames};
+    for (void* p : d) if (p) (void)hipFree(p);
+    void* hp[] = {a->h_frames, a->h_out, a->h_planes, a->h_memberOff, a->h_depth};
+    for (void* p : hp) if (p) (void)hipHostFree(p);
+    delete a;
+    a = nullptr;
+}
+
+void drfe_ahc_arena_free(drfe_ctx* c)
+{
+    AhcArena* a = static_cast<AhcArena*>(c->ahcArena);
+    arena_free(a);
+    c->ahcArena = nullptr;
+}
+
+#define AHC_DEV_PLANE_CAP 64
+
+static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, float depth_factor)
+{
+    AhcArena* a = static_cast<AhcArena*>(c->ahcArena);
+    if (a && (a->w != w || a->h != h || a->frames < frames)) { arena_free(a); c->ahcArena = nullptr; }
+    if (!a) {
+        a = new (std::nothrow) AhcArena();
+        if (!a) return DRFE_ERR_INVALID;
+        c->ahcArena = a;
+        a->w = w; a->h = h; a->frames = frames;
+        const int Nw = w / AHC_WIN, Nh = h / AHC_WIN, NB = Nw * Nh;
+        const size_t npx = (size_t)w * h;
+        AhcDevParams& P = a->P;
+        P.w = w; P.h = h; P.Nw = Nw; P.Nh = Nh; P.NB = NB;
+        P.maxNodes = 2 * NB + 256; P.poolCap = 1 << 19; P.rfCap = 1 << 20; P.planeCap = AHC_DEV_PLANE_CAP;
+        /* per-slot layout, every array 256-byte aligned */
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t oS = take((size_t)P.maxNodes * 72), oFit = take((size_t)P.maxNodes * 64), oN = take((size_t)P.maxNodes * 4), oRid = take((size_t)P.maxNodes * 4),
+                     oNouse = take((size_t)P.maxNodes), oNbOff = take((size_t)P.maxNodes * 4), oNbLen = take((size_t)P.maxNodes * 4), oPool = take((size_t)P.poolCap * 4),
+                     oDsP = take((size_t)NB * 4), oDsS = take((size_t)NB * 4), oG = take((size_t)NB * 4), oBlk = take((size_t)NB * 4), oR2P = take((size_t)NB * 4),
+                     oMem = take(npx * 2), oDist = take(npx * 4), oRf = take((size_t)P.rfCap * 4);
+        a->offPlanes = take((size_t)P.planeCap * sizeof(drfe_plane)); a->offSeg = take(npx); a->offMemberOff = take(((size_t)P.planeCap + 1) * 4);
+        a->offMemberIdx = take(npx * 4); a->offOut = take(16);
+        a->slotBytes = off;
+        const size_t F = (size_t)frames;
+        HIPCHK(c, hipMalloc((void**)&a->d_depth, npx * 2 * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_blocks, (size_t)NB * sizeof(AhcBlockRec) * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_scratch, a->slotBytes * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_frames, sizeof(AhcDevFrame) * F));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_frames, sizeof(AhcDevFrame) * F, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_out, 16 * F, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_planes, (size_t)P.planeCap * sizeof(drfe_plane) * F, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_memberOff, ((size_t)P.planeCap + 1) * 4 * F, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_depth, npx * 2 * F, hipHostMallocDefault));
+        for (size_t f = 0; f < F; f++) {
+            uint8_t* s = a->d_scratch + a->slotBytes * f;
+            AhcDevFrame& g = a->h_frames[f];
+            g.depth = a->d_depth + npx * f; g.rowStride = (size_t)w;
+            g.blocks = a->d_blocks + (size_t)NB * f;
+            g.nodeS = (double*)(s + oS); g.nodeFit = (double*)(s + oFit); g.nodeN = (int*)(s + oN); g.nodeRid = (int*)(s + oRid);
+            g.nodeNouse = s + oNouse; g.nbOff = (int*)(s + oNbOff); g.nbLen = (int*)(s + oNbLen); g.nbPool = (int*)(s + oPool);
+            g.dsParent = (int*)(s + oDsP); g.dsSize = (int*)(s + oDsS); g.G = (int*)(s + oG); g.blkMap = (int*)(s + oBlk); g.ridToPlid = (int*)(s + oR2P);
+            g.membership = (int16_t*)(s + oMem); g.distMap = (float*)(s + oDist); g.rf = (uint32_t*)(s + oRf);
+            g.planes = (drfe_plane*)(s + a->offPlanes); g.seg = s + a->offSeg; g.memberOff = (int*)(s + a->offMemberOff);
+            g.memberIdx = (int*)(s + a->offMemberIdx); g.out = (int*)(s + a->offOut);
+        }
+        HIPCHK(c, hipMemcpy(a->d_frames, a->h_frames, sizeof(AhcDevFrame) * F, hipMemcpyHostToDevice));
+    }
+    AhcDevParams& P = a->P;
+    P.fx = (double)K4[0]; P.fy = (double)K4[1]; P.cx = (double)K4[2]; P.cy = (double)K4[3]; P.factor = (double)depth_factor;
+    P.cos60 = kCos60; P.cos30 = kCos30;
+    return DRFE_OK;
+}
+
+namespace {
+struct AhcBatchJob {
+    drfe_ctx* c; AhcArena* A; std::vector<PlaneLane>* pool;
+    const uint16_t* depth; size_t frameStride, stride; int w, h, nframes, cap;
+    const float* K4; float depthFactor, maxPointDist; double distThreshold;
+    drfe_plane* planes; int* nPlanes; uint8_t* seg; drfe_plane_post* post; int* nAccepted; int* planeNum;
+    int chunk, nChunks;
+    std::vector<hipStream_t> chunkStream; std::vector<hipEvent_t> chunkDone; std::vector<int> chunkState;   /* 1 = on the device, 2 = released */
+    std::mutex mu; std::condition_variable cv; std::deque<int> finishQ; int pending = 0;
+    int firstRc = DRFE_OK; std::string firstErr; bool abort = false;
+    std::atomic<int> fallbacks{0};
+};
+}
+
+static void ahc_batch_fail(AhcBatchJob& J, int rc, const std::string& err)
+{
+    std::lock_guard<std::mutex> lk(J.mu);
+    if (J.firstRc == DRFE_OK) { J.firstRc = rc; J.firstErr = err; }
+    J.abort = true;
+    J.cv.notify_all();
+}
+
+/* a worker: takes frames whose chunk has left the device, fetches the frame's member lists and runs the per-plane loop */
+static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
+{
+    AhcArena* A = J.A;
+    const size_t px = (size_t)J.w * J.h;
+    (void)hipSetDevice(J.c->device);
+    std::vector<int32_t> off((size_t)J.cap + 1), idx(px), voff((size_t)J.cap + 1);
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, "planes batch: event"); return; }
+    for (;;) {
+        int f = -1, waitCh = -1;
+        {
+            std::unique_lock<std::mutex> lk(J.mu);
+            for (;;) {
+                if (J.abort) { (void)hipEventDestroy(ev); return; }
+                for (int ch = 0; ch < J.nChunks; ch++)
+                    if (J.chunkState[ch] == 1 && hipEventQuery(J.chunkDone[ch]) == hipSuccess) {
+                        J.chunkState[ch] = 2;
+                        const int nf = std::min(J.chunk, J.nframes - ch * J.chunk);
+                        for (int k = 0; k < nf; k++) J.finishQ.push_back(ch * J.chunk + k);
+                        J.cv.notify_all();
+                    }
+                if (!J.finishQ.empty()) { f = J.finishQ.front(); J.finishQ.pop_front(); break; }
+                if (J.pending == 0) { (void)hipEventDestroy(ev); return; }
+                for (int ch = 0; ch < J.nChunks && waitCh < 0; ch++) if (J.chunkState[ch] == 1) waitCh = ch;
+                if (waitCh >= 0) break;
+                J.cv.wait(lk);
+            }
+        }
+        if (waitCh >= 0) {
+            if (hipEventSynchronize(J.chunkDone[waitCh]) != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, "planes batch: device"); (void)hipEventDestroy(ev); return; }
+            continue;
+        }
+        const uint16_t* d = J.depth + (size_t)f * J.frameStride;
+        drfe_plane* pl = J.planes + (size_t)f * J.cap;
+        int rc = DRFE_OK;
+        const int nP = A->h_out[4 * (size_t)f], status = A->h_out[4 * (size_t)f + 1];
+        if (status != 0 || nP > J.cap) {
+            /* a capacity of the device path ran out (or a cosine could not be certified): this frame on the host */
+            J.fallbacks++;
+            rc = planes_ahc_core(l, d, J.w, J.h, J.stride, J.K4, J.depthFactor, pl, J.cap, &J.nPlanes[f], J.seg ? J.seg + f * px : nullptr, off.data(), idx.data());
+        } else {
+            J.nPlanes[f] = nP;
+            if (nP) std::memcpy(pl, A->h_planes + (size_t)A->P.planeCap * f, sizeof(drfe_plane) * nP);
+            const int* mo = A->h_memberOff + ((size_t)A->P.planeCap + 1) * f;
+            for (int i = 0; i <= nP; i++) off[i] = mo[i];
+            const uint8_t* slot = A->d_scratch + A->slotBytes * f;
+            hipError_t e = hipSuccess;
+            if (off[nP] > 0) e = hipMemcpyAsync(idx.data(), slot + A->offMemberIdx, sizeof(int) * (size_t)off[nP], hipMemcpyDeviceToHost, l->stream);
+            if (e == hipSuccess && J.seg) e = hipMemcpyAsync(J.seg + f * px, slot + A->offSeg, px, hipMemcpyDeviceToHost, l->stream);
+            if (e == hipSuccess) e = drfe_pool_sync(l->stream, ev);
+            if (e != hipSuccess) { l->err = std::string("planes batch: member lists: ") + hipGetErrorString(e); rc = DRFE_ERR_HIP; }
+        }
+        if (rc == DRFE_OK)
+            rc = drfe_ahc_post_core(&l->err, d, J.w, J.h, J.stride, J.K4, J.depthFactor, pl, J.nPlanes[f], off.data(), idx.data(), J.maxPointDist,
+                                    J.distThreshold, J.post + (size_t)f * J.cap, nullptr, voff.data(), 0, &J.nAccepted[f],
+                                    J.planeNum ? &J.planeNum[f] : nullptr, nullptr);
+        if (rc != DRFE_OK) { ahc_batch_fail(J, rc, l->err); (void)hipEventDestroy(ev); return; }
+        {
+            std::lock_guard<std::mutex> lk(J.mu);
+            if (--J.pending == 0) J.cv.notify_all();
+        }
+    }
+}
+
+static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* pool, int T, const uint16_t* depth, size_t frame_stride, int w, int h,
+                                        size_t stride, int nframes, const float* K4, float depth_factor, float max_point_dist, double dist_threshold,
+                                        drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num)
+{
+    int rc = ensure_arena(c, w, h, nframes, K4, depth_factor);
+    if (rc != DRFE_OK) return rc;
+    AhcArena* A = static_cast<AhcArena*>(c->ahcArena);
+    AhcBatchJob J;
+    J.c = c; J.A = A; J.pool = pool; J.depth = depth; J.frameStride = frame_stride; J.stride = stride; J.w = w; J.h = h; J.nframes = nframes; J.cap = cap;
+    J.K4 = K4; J.depthFactor = depth_factor; J.maxPointDist = max_point_dist; J.distThreshold = dist_threshold;
+    J.planes = planes; J.nPlanes = n_planes; J.seg = seg; J.post = post; J.nAccepted = n_accepted; J.planeNum = plane_num;
+    /* chunks (= low-priority streams = hardware queues) of this call: the runtime has four queues per priority, and the line and the
+     * plane batch of a front-end step run side by side - two each (DRFE_BATCH_CHUNKS overrides) */
+    static const int nch = [] { const char* e = std::getenv("DRFE_BATCH_CHUNKS"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    J.chunk = std::max(1, std::min(nframes, std::max(16, (nframes + nch - 1) / nch)));
+    J.nChunks = (nframes + J.chunk - 1) / J.chunk;
+    J.pending = nframes;
+    J.chunkStream.resize(J.nChunks); J.chunkDone.resize(J.nChunks); J.chunkState.assign(J.nChunks, 0);
+    int prLow = 0, prHigh = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+    const size_t px = (size_t)w * h;
+    const int NB = A->P.NB;
+    int launchRc = DRFE_OK;
+    for (int ch = 0; ch < J.nChunks; ch++) {
+        /* low priority, like the line path's growth: the runtime keeps separate hardware queues per priority, so the pools'
+         * short kernels never queue behind a chunk that runs for a hundred milliseconds */
+        HIPCHK(c, hipStreamCreateWithPriority(&J.chunkStream[ch], hipStreamNonBlocking, prLow));
+        HIPCHK(c, hipEventCreateWithFlags(&J.chunkDone[ch], hipEventDisableTiming | hipEventBlockingSync));
+    }
+    for (int ch = 0; ch < J.nChunks && launchRc == DRFE_OK; ch++) {
+        const int f0 = ch * J.chunk, nf = std::min(J.chunk, nframes - f0);
+        hipStream_t st = J.chunkStream[ch];
+        for (int f = f0; f < f0 + nf; f++)
+            for (int y = 0; y < h; y++) std::memcpy(A->h_depth + px * f + (size_t)y * w, depth + (size_t)f * frame_stride + (size_t)y * stride, (size_t)w * 2);
+        hipError_t e = hipMemcpyAsync(A->d_depth + px * f0, A->h_depth + px * f0, px * 2 * nf, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = drfe_launch_ahc_blocks(A->d_depth + px * f0, px, (size_t)w, w, h, K4, depth_factor, nf, A->d_blocks + (size_t)NB * f0, st);
+        if (e == hipSuccess) e = drfe_launch_ahc_frames(A->d_frames + f0, nf, A->P, st);
+        /* the small results of every frame of the chunk; member lists and label images are fetched per frame by the workers */
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(A->h_out + 4 * (size_t)f0, 16, A->d_scratch + A->slotBytes * f0 + A->offOut, A->slotBytes, 16, nf, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(A->h_planes + (size_t)A->P.planeCap * f0, sizeof(drfe_plane) * A->P.planeCap, A->d_scratch + A->slotBytes * f0 + A->offPlanes, A->slotBytes,
+                                 sizeof(drfe_plane) * A->P.planeCap, nf, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(A->h_memberOff + ((size_t)A->P.planeCap + 1) * f0, 4 * ((size_t)A->P.planeCap + 1), A->d_scratch + A->slotBytes * f0 + A->offMemberOff,
+                                 A->slotBytes, 4 * ((size_t)A->P.planeCap + 1), nf, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(J.chunkDone[ch], st);
+        if (e != hipSuccess) { c->err = std::string("planes_ahc_post_batch: device path: ") + hipGetErrorString(e); launchRc = DRFE_ERR_HIP; }
+        else J.chunkState[ch] = 1;
+    }
+    if (launchRc == DRFE_OK) {
+        std::vector<std::thread> th;
+        for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { ahc_batch_worker(J, &(*pool)[k]); });
+        for (std::thread& t : th) t.join();
+    }
+    for (int ch = 0; ch < J.nChunks; ch++) {
+        (void)hipStreamSynchronize(J.chunkStream[ch]);
+        (void)hipStreamDestroy(J.chunkStream[ch]);
+        (void)hipEventDestroy(J.chunkDone[ch]);
+    }
+    if (std::getenv("DRFE_AHC_PROFILE")) {      /* AHC_PROFILE builds of k_ahc_frame: phase times of frame 0 */
+        uint32_t t[8] = {0};
+        (void)hipMemcpy(t, A->h_frames[0].rf, sizeof(t), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "k_ahc_frame frame 0: initGraph %.2f ms, ahCluster %.2f, membership + seeds %.2f, floodFill %.2f (%d queue entries), re-merge %.2f, labels + member lists %.2f; %d nodes\n",
+                     t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, A->h_out[2], t[4] / 1e5, t[5] / 1e5, A->h_out[3]);
+    }
+    if (std::getenv("DRFE_TRACE_PLANES"))
+        std::fprintf(stderr, "drfe_planes_ahc_post_batch (device extractor): %d frames, %d chunks, %d frames redone on the host\n", nframes, J.nChunks, J.fallbacks.load());
+    if (launchRc != DRFE_OK) return launchRc;
+    if (J.firstRc != DRFE_OK) { c->err = J.firstErr; return J.firstRc; }
+    return DRFE_OK;
+}
+
+extern "C" {
+
 /* 1: drfe_planes_ahc_post_batch runs pcl::VoxelGrid of every plane on the device (voxel_kernels.hip); 0 (default): on the pool's
  * host threads.  Results are identical. */
 int drfe_planes_configure(drfe_ctx* c, int device_voxel_grid)
 {
     if (!c || device_voxel_grid < 0 || device_voxel_grid > 1) { if (c) c->err = "planes_configure: invalid argument"; return DRFE_ERR_INVALID; }
     c->planesDeviceVoxel = device_voxel_grid;
+    return DRFE_OK;
+}
+
+/* 1 (default): drfe_planes_ahc_post_batch runs PEAC's extractor (graph, clustering, flood fill, re-merge, labels) on the device,
+ * one wavefront per frame (ahc_frame_kernels.hip); 0: on the pool's host threads.  Results are identical. */
+int drfe_planes_configure_extractor(drfe_ctx* c, int on_device)
+{
+    if (!c || on_device < 0 || on_device > 1) { if (c) c->err = "planes_configure_extractor: invalid argument"; return DRFE_ERR_INVALID; }
+    c->planesDeviceAhc = on_device;
     return DRFE_OK;
 }
 
@@ -759,6 +1029,11 @@ int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_
         HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         pool->push_back(l);
     }
+    /* the extractor itself on the device (drfe_planes_configure bit 1; 640 x 480-class frames: the kernel's queue holds 3200 init
+     * blocks and its pixel index 20 bits) */
+    if ((c->planesDeviceAhc) && (w / AHC_WIN) * (h / AHC_WIN) <= 3200 && (size_t)w * h <= (1u << 20) && !std::getenv("DRFE_AHC_HOST"))
+        return planes_ahc_post_batch_device(c, pool, T, depth, frame_stride, w, h, stride, nframes, K4, depth_factor, max_point_dist, dist_threshold, planes,
+                                            cap, n_planes, seg, post, n_accepted, plane_num);
     std::vector<int> rcs(T, DRFE_OK);
     std::vector<std::thread> th;
     th.reserve(T);

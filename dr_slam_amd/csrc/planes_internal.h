@@ -43,7 +43,27 @@ hipError_t drfe_launch_cape_refine(const float* d_depth, size_t rowStride, int w
                                    const CapeRefinePlane* d_planes, int nplanes, const uint8_t* d_gridEroded,
                                    const uint8_t* d_boundary, uint8_t* d_seg, hipStream_t s);
 
+/* ---- the whole extractor on the device (ahc_frame_kernels.hip) ---- */
+struct AhcDevParams {
+    int w, h, Nw, Nh, NB;
+    int maxNodes, poolCap, rfCap, planeCap;
+    double fx, fy, cx, cy, factor;       /* K floats promoted, depth factor: PlaneDetection::readDepthImage */
+    double cos60, cos30;                 /* similarityTh_merge / _refine, from the host's libm as the host path's constants */
+};
+/* one frame of a k_ahc_frame launch: inputs, per-frame scratch, outputs */
+struct AhcDevFrame {
+    const uint16_t* depth; size_t rowStride;                 /* device CV_16U image */
+    const AhcBlockRec* blocks;                               /* k_ahc_blocks' records of this frame */
+    double* nodeS; double* nodeFit; int* nodeN; int* nodeRid; uint8_t* nodeNouse; int* nbOff; int* nbLen; int* nbPool;
+    int* dsParent; int* dsSize; int* G; int* blkMap; int* ridToPlid;
+    int16_t* membership; float* distMap; uint32_t* rf;
+    drfe_plane* planes; uint8_t* seg; int* memberOff; int* memberIdx;      /* final planes, label image, member lists */
+    int* out;                                                /* out[0] = planes, out[1] = status (0 = done; else: redo on the host) */
+};
+hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s);
+
 hipError_t drfe_launch_ahc_blocks(const uint16_t* d_depth, size_t frameStride, size_t rowStride, int w, int h,
                                   const float K4[4], float depthFactor, int nframes, AhcBlockRec* d_out, hipStream_t s);
 void drfe_planes_free(drfe_ctx* c);
+void drfe_ahc_arena_free(drfe_ctx* c);        /* planes_ahc.cpp: frame slots of the device extractor */
 #endif

@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure",
+    "drfe_lsd_configure", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -202,6 +202,7 @@ def load() -> C.CDLL:
     L.drfe_lsd_segments_host.argtypes = [vp, vp, vp, i32, i32, f64, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_configure.argtypes = [vp, i32]
     L.drfe_planes_configure.argtypes = [vp, i32]
+    L.drfe_planes_configure_extractor.argtypes = [vp, i32]
     L.drfe_planes_cape_batch.argtypes = [vp, vp, sz, i32, i32, sz, i32, vp, i32, f32, f32, vp, i32, vp, vp, i32]
     L.drfe_batch_status_async.argtypes = [vp, vp, vp]
     L.drfe_batch_check.argtypes = [vp]
@@ -953,6 +954,10 @@ class Context:
     def planes_configure(self, device_voxel_grid=False):
         """Where planes_ahc_post_batch runs the per-plane voxel grids: host threads (default) or the device."""
         self._chk(self.L.drfe_planes_configure(self.h, 1 if device_voxel_grid else 0), "drfe_planes_configure")
+
+    def planes_configure_extractor(self, on_device=True):
+        """Where planes_ahc_post_batch runs PEAC's extractor: the device (one wavefront per frame, default) or the host pool."""
+        self._chk(self.L.drfe_planes_configure_extractor(self.h, 1 if on_device else 0), "drfe_planes_configure_extractor")
 
     def planes_cape_batch(self, depth_m: np.ndarray, K4, patch=20, cos_angle_max=None, max_merge_dist=50.0, cap=64, n_threads=0, seg=False):
         """PlaneDetection_CAPE for a [B, H, W] float32 batch on a pool of host threads -> (planes [B, cap], n [B][, seg [B, H, W]])."""

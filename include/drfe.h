@@ -667,6 +667,11 @@ int drfe_planes_ahc_post_batch(drfe_ctx* ctx, const uint16_t* depth, size_t fram
  * 1 on the device (voxel_kernels.hip: leaf indices, std::sort's permutation by the device introsort, centroid sums in that
  * order - one workgroup per plane).  Results are identical (tests/test_gpu_post.py). */
 int drfe_planes_configure(drfe_ctx* ctx, int device_voxel_grid);
+/* Where drfe_planes_ahc_post_batch runs PEAC's extractor after the init-block fits (graph, agglomerative clustering, block
+ * membership, flood fill, re-merge, labels and member lists): 1 (default) on the device, one wavefront per frame executing the
+ * reference's sequence (ahc_frame_kernels.hip), the batch's frames side by side; 0 on the pool's host threads (the path of
+ * drfe_planes_ahc).  Results are identical (tests/test_gpu_post.py, tests/test_gpu_planes.py). */
+int drfe_planes_configure_extractor(drfe_ctx* ctx, int on_device);
 /* The same loop of Frame::ComputePlanes_CAPE (:1111-1141) for the planes / seg image drfe_planes_cape returned: plane_cloud[i]
  * = the points of the pixels labelled i + 1 in raster order (src/PlaneExtractor.cpp:171-188). */
 int drfe_planes_cape_postprocess(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, const uint8_t* seg,

@@ -195,7 +195,13 @@ def test_ahc_post_batch_equals_single_frame_calls(oracle_mod, camname, kind, see
     inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
     c = lib.Context()
     try:
+        # the extractor on the host pool (the checker) and on the device (the default): identical planes, labels, post results
+        c.planes_configure_extractor(on_device=False)
+        planes_h, n_h, post_h, na_h, pn_h, seg_h = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        c.planes_configure_extractor(on_device=True)
         planes, n, post, na, pn, seg = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        assert np.array_equal(n, n_h) and planes.tobytes() == planes_h.tobytes() and np.array_equal(seg, seg_h)
+        assert post.tobytes() == post_h.tobytes() and np.array_equal(na, na_h) and np.array_equal(pn, pn_h)
         c.planes_configure(device_voxel_grid=True)
         planes_d, n_d, post_d, na_d, pn_d, seg_d = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
         c.planes_configure(device_voxel_grid=False)
