@@ -307,7 +307,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* 
     __shared__ int ex[AHCD_MAXEX], ex2[AHCD_MAXEX], plidmap[AHCD_MAXEX];
     __shared__ uint8_t isValid[AHCD_MAXEX];
     __shared__ double plN[AHCD_MAXEX][3], plC[AHCD_MAXEX][3], plMse[AHCD_MAXEX];
-    __shared__ int counts[AHCD_MAXEX + 1];
+    __shared__ int counts[AHCD_MAXEX + 1], kcounts[AHCD_MAXEX + 1];
     __shared__ int8_t blkLds[AHCD_HEAP];                      /* flood fill: 1 = the block is kept whole (its pixels are final) */
     const AhcDevFrame F = frames[blockIdx.x];
     const int lane = threadIdx.x;
@@ -323,6 +323,8 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* 
     const GLOBAL_AS AhcBlockRec* blocks = (const GLOBAL_AS AhcBlockRec*)F.blocks;
     GLOBAL_AS int* out = (GLOBAL_AS int*)F.out;
     const int w = P.w, h = P.h, Nw = P.Nw, Nh = P.Nh, NB = P.NB, npx = w * h;
+    /* no cloud for k_voxel_grid unless the frame runs to its end */
+    if (F.jobs) for (int i = lane; i < 2 * P.planeCap; i += 64) ((GLOBAL_AS int*)F.jobs)[i] = 0;
     if (NB > AHCD_HEAP || npx > (1 << 20)) { if (lane == 0) { out[0] = 0; out[1] = 4; } return; }
 
 #ifdef AHC_PROFILE
@@ -633,46 +635,82 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* 
     }
     fence();
     TP();
-    /* final plane per pixel, the label image, the member lists (raster order per plane) */
+    /* final plane per pixel, the label image, the member lists (raster order per plane) and each plane's cloud as Frame::ComputePlanes
+     * gathers it (src/Frame.cc:985-1000: float points of the members, those beyond max_point_dist left out) for k_voxel_grid */
     GLOBAL_AS uint8_t* seg = (GLOBAL_AS uint8_t*)F.seg;
+    const double gfx = P.fx, gfy = P.fy, gcx = P.cx, gcy = P.cy, gfactor = P.factor;
+    const float maxPointDist = P.maxPointDist;
+    for (int i = lane; i <= nFinal; i += 64) kcounts[i] = 0;
+    fence();
     for (int base = 0; base < npx; base += 64) {
         const int k = base + lane;
         int pl = -1;
+        bool keep = false;
         if (k < npx) {
             const int raw = c.mem[k];
             pl = raw >= 0 ? plidmap[raw] : -1;
             c.mem[k] = (int16_t)pl;
             seg[k] = (uint8_t)(pl + 1);
+            if (pl >= 0) {
+                const int row = k / w, col = k - row * w;
+                double z = (double)c.depth[(size_t)row * c.rowStride + col] * gfactor;
+                if (z > 5.0) z = 0.0;
+                keep = !((float)z > maxPointDist);
+            }
         }
         /* per-plane counts: the lanes of a plane are counted once per chunk */
+        const unsigned long long kept = __ballot(keep);
         unsigned long long todo = __ballot(pl >= 0);
         while (todo) {
             const int l = __builtin_ctzll(todo);
             const int v = rl_i(pl, l);
             const unsigned long long same = __ballot(pl == v);
-            if (lane == l) counts[v + 1] += __popcll(same);
+            if (lane == l) { counts[v + 1] += __popcll(same); kcounts[v + 1] += __popcll(same & kept); }
             todo &= ~same;
         }
     }
     fence();
     GLOBAL_AS int* memberOff = (GLOBAL_AS int*)F.memberOff;
     GLOBAL_AS int* memberIdx = (GLOBAL_AS int*)F.memberIdx;
+    GLOBAL_AS int* jobs = (GLOBAL_AS int*)F.jobs;
+    GLOBAL_AS float* pts = (GLOBAL_AS float*)F.pts;
     if (lane == 0) {
-        for (int i = 0; i < nFinal; i++) counts[i + 1] += counts[i];
+        for (int i = 0; i < nFinal; i++) { counts[i + 1] += counts[i]; kcounts[i + 1] += kcounts[i]; }
         for (int i = 0; i <= nFinal; i++) memberOff[i] = counts[i];
+        if (jobs) for (int i = 0; i < nFinal; i++) { jobs[2 * i] = F.ptsBase + kcounts[i]; jobs[2 * i + 1] = kcounts[i + 1] - kcounts[i]; }
     }
     fence();
     for (int base = 0; base < npx; base += 64) {
         const int k = base + lane;
         const int pl = k < npx ? (int)c.mem[k] : -1;
+        bool keep = false;
+        float X = 0.f, Y = 0.f, Z = 0.f;
+        if (pl >= 0 && pts) {
+            /* PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:39-52): doubles, K floats promoted; the cloud holds floats */
+            const int row = k / w, col = k - row * w;
+            const double z = (double)c.depth[(size_t)row * c.rowStride + col] * gfactor;
+            if (!(z > 5.0)) {
+                X = (float)(((double)col - gcx) * z / gfx);
+                Y = (float)(((double)row - gcy) * z / gfy);
+                Z = (float)z;
+            }
+            keep = !(Z > maxPointDist);
+        }
+        const unsigned long long kept = __ballot(keep);
         unsigned long long todo = __ballot(pl >= 0);
         while (todo) {
             const int l = __builtin_ctzll(todo);
             const int v = rl_i(pl, l);
             const unsigned long long same = __ballot(pl == v);
-            if (pl == v) memberIdx[counts[v] + __popcll(same & lt)] = k;
+            if (pl == v) {
+                memberIdx[counts[v] + __popcll(same & lt)] = k;
+                if (keep) {
+                    const size_t q = 3 * (size_t)(kcounts[v] + __popcll(same & kept & lt));
+                    pts[q] = X; pts[q + 1] = Y; pts[q + 2] = Z;
+                }
+            }
             fence();
-            if (lane == l) counts[v] += __popcll(same);
+            if (lane == l) { counts[v] += __popcll(same); kcounts[v] += __popcll(same & kept); }
             todo &= ~same;
         }
         fence();

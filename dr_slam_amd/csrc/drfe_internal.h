@@ -170,7 +170,7 @@ struct drfe_ctx {
     int lsdDeviceGrow;        /* drfe_lsd_configure: 1 = the batch entry grows regions on the device (default) */
     int planesDeviceAhc;      /* drfe_planes_configure_extractor: 1 = drfe_planes_ahc_post_batch runs the extractor on the device (default) */
     void* ahcArena;           /* AhcArena*: frame slots of the device extractor (planes_ahc.cpp) */
-    int planesDeviceVoxel;    /* drfe_planes_configure: 1 = drfe_planes_ahc_post_batch runs the voxel grids on the device (default 0) */
+    int planesDeviceVoxel;    /* drfe_planes_configure: where drfe_planes_ahc_post_batch runs the voxel grids (default 1: device, behind the device extractor) */
     void* frameLanes;         /* std::vector<FrameLane>*: per-slot staging of drfe_frame_submit / drfe_frame_collect (capi.cpp) */
 
     /* profiling */

@@ -27,6 +27,12 @@
 #define ORD_STACK 48             /* depth-first stack of a wavefront (>= the depth limit 2 lg n of any array that fits) */
 #define ORD_DYN_LDS_BYTES(NTH) (32 * (NTH) * 4)
 
+/* phase marks of a profiling build: the includer defines ISD_TP(k) (k = 0: workgroup partitions done, 1: wavefront phase done,
+ * 2: counting passes done) */
+#ifndef ISD_TP
+#define ISD_TP(k)
+#endif
+
 namespace isd {
 
 struct Seg { uint32_t first, last; int depth; };
@@ -38,11 +44,12 @@ struct Shared {
     Seg stack[NTH / 64][ORD_STACK];
     int qHead, qTail, qOverflow, heapNeeded, wcnt[NTH / 64 + 2];
     uint32_t cutShared;
+    unsigned long long tp;          /* profiling builds: thread 0's last phase mark */
 };
 
 /* std::__move_median_to_first(result, x, y, z) by one thread */
-template <class T>
-__device__ __forceinline__ void median_to_first(typename T::Rec* a, uint32_t result, uint32_t x, uint32_t y, uint32_t z)
+template <class T, class RecPtr>
+__device__ __forceinline__ void median_to_first(RecPtr a, uint32_t result, uint32_t x, uint32_t y, uint32_t z)
 {
     const uint32_t kx = T::key(a[x]), ky = T::key(a[y]), kz = T::key(a[z]);
     uint32_t pick;
@@ -61,8 +68,8 @@ __device__ __forceinline__ void median_to_first(typename T::Rec* a, uint32_t res
 /* std::__unguarded_partition(a + first + 1, a + last, a + first) by a group of NT threads (64: one wavefront; NTH: the
  * workgroup).  tid = thread index inside the group.  posL / posR: scratch of the range's length at [first, last).  wcnt: LDS,
  * NT / 64 + 2 ints (workgroup variant).  Returns the cut to every thread. */
-template <int NT, class T>
-__device__ __forceinline__ uint32_t hoare_cut(typename T::Rec* a, uint32_t first, uint32_t last, uint32_t* posL, uint32_t* posR, int tid, int* wcnt)
+template <int NT, class T, class RecPtr, class PosPtr>
+__device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t last, PosPtr posL, PosPtr posR, int tid, int* wcnt)
 {
     const uint32_t lo = first + 1, hi = last;
     const uint32_t pk = T::key(a[first]);
@@ -85,23 +92,49 @@ __device__ __forceinline__ uint32_t hoare_cut(typename T::Rec* a, uint32_t first
         return r;
     };
     uint32_t cntL = 0, cntR = 0;
-    for (uint32_t base = lo; base < hi; base += NT) {                      /* left stoppers (records that do not go before the pivot), ascending */
-        const uint32_t p = base + tid;
-        const bool f = p < hi && !(T::key(a[p]) < pk);
-        uint32_t tot;
-        const uint32_t r = block_rank(f, tot);
-        if (f) posL[first + cntL + r] = p;
-        cntL += tot;
-    }
-    for (uint32_t off = 0; lo + off < hi; off += NT) {                     /* right stoppers (the pivot does not go before them), descending */
-        const uint32_t back = off + tid;
-        const bool in = back < hi - lo;
-        const uint32_t p = hi - 1 - (in ? back : 0);
-        const bool f = in && !(pk < T::key(a[p]));
-        uint32_t tot;
-        const uint32_t r = block_rank(f, tot);
-        if (f) posR[first + cntR + r] = p;
-        cntR += tot;
+    if (NT == 64) {
+        /* one wavefront: four blocks of 64 per round, their loads in flight together (the scan is bound by memory latency) */
+        for (uint32_t base = lo; base < hi; base += 256) {                 /* left stoppers (records that do not go before the pivot), ascending */
+            bool f[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t p = base + 64 * u + lane; f[u] = p < hi && !(T::key(a[p < hi ? p : lo]) < pk); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long m = __ballot(f[u]);
+                if (f[u]) posL[first + cntL + (uint32_t)__popcll(m & lt)] = base + 64 * u + lane;
+                cntL += (uint32_t)__popcll(m);
+            }
+        }
+        for (uint32_t off = 0; lo + off < hi; off += 256) {                /* right stoppers (the pivot does not go before them), descending */
+            bool f[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t back = off + 64 * u + lane; const bool in = back < hi - lo; f[u] = in && !(pk < T::key(a[hi - 1 - (in ? back : 0)])); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long m = __ballot(f[u]);
+                if (f[u]) posR[first + cntR + (uint32_t)__popcll(m & lt)] = hi - 1 - (off + 64 * u + lane);
+                cntR += (uint32_t)__popcll(m);
+            }
+        }
+    } else {
+        for (uint32_t base = lo; base < hi; base += NT) {
+            const uint32_t p = base + tid;
+            const bool f = p < hi && !(T::key(a[p < hi ? p : lo]) < pk);
+            uint32_t tot;
+            const uint32_t r = block_rank(f, tot);
+            if (f) posL[first + cntL + r] = p;
+            cntL += tot;
+        }
+        for (uint32_t off = 0; lo + off < hi; off += NT) {
+            const uint32_t back = off + tid;
+            const bool in = back < hi - lo;
+            const uint32_t p = hi - 1 - (in ? back : 0);
+            const bool f = in && !(pk < T::key(a[p]));
+            uint32_t tot;
+            const uint32_t r = block_rank(f, tot);
+            if (f) posR[first + cntR + r] = p;
+            cntR += tot;
+        }
     }
     group_sync();
     /* K = pairs still in order: a prefix of the rank order */
@@ -120,7 +153,7 @@ __device__ __forceinline__ uint32_t hoare_cut(typename T::Rec* a, uint32_t first
         const typename T::Rec x = a[pl], y = a[pr];
         a[pl] = y; a[pr] = x;
     }
-    const uint32_t l = K < cntL ? posL[first + K] : hi, r = K > 0 ? posR[first + K - 1] : hi;
+    const uint32_t l = K < cntL ? (uint32_t)posL[first + K] : hi, r = K > 0 ? (uint32_t)posR[first + K - 1] : hi;
     group_sync();
     return l < r ? l : r;
 }
@@ -163,7 +196,15 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
         __syncthreads();
     }
 
-    /* ---- everything else: a wavefront takes a range and finishes it depth-first ---- */
+    ISD_TP(0);
+    /* ---- everything else: a wavefront takes a range and finishes it depth-first.  A range of at most LCAP records moves into the
+     * wavefront's share of the dynamic LDS (records + 16-bit stopper positions) and is partitioned there down to the ranges of 16:
+     * the partitions of small ranges are chains of dependent accesses, a few per range, and most ranges are small ---- */
+    constexpr uint32_t LBYTES = ORD_DYN_LDS_BYTES(NTH) / (NTH / 64);
+    constexpr uint32_t LCAP = LBYTES / (sizeof(Rec) + 4);
+    Rec* lrec = (Rec*)((uint8_t*)dyn + (size_t)wv * LBYTES);
+    uint16_t* lposL = (uint16_t*)(lrec + LCAP);
+    uint16_t* lposR = lposL + LCAP;
     for (;;) {
         int q = 0;
         if (lane == 0) q = atomicAdd(&sh.qHead, 1);
@@ -175,6 +216,35 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
             /* std::__introsort_loop on s */
             while (s.last - s.first > 16) {
                 if (s.depth == 0) { if (lane == 0) sh.heapNeeded = 1; break; }
+                const uint32_t m = s.last - s.first;
+                if (m <= LCAP) {
+                    for (uint32_t i = lane; i < m; i += 64) lrec[i] = a[s.first + i];
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    const int base = sp;
+                    Seg t; t.first = 0; t.last = m; t.depth = s.depth;
+                    for (;;) {
+                        while (t.last - t.first > 16) {
+                            if (t.depth == 0) { if (lane == 0) sh.heapNeeded = 1; break; }
+                            t.depth--;
+                            if (lane == 0) median_to_first<T>(lrec, t.first, t.first + 1, t.first + (t.last - t.first) / 2, t.last - 1);
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            const uint32_t cut = hoare_cut<64, T>(lrec, t.first, t.last, lposL, lposR, lane, nullptr);
+                            if (t.last - cut > 16) {
+                                if (sp < ORD_STACK) {
+                                    if (lane == 0) { sh.stack[wv][sp].first = cut; sh.stack[wv][sp].last = t.last; sh.stack[wv][sp].depth = t.depth; }
+                                    sp++;
+                                } else if (lane == 0) sh.qOverflow = 1;
+                            }
+                            t.last = cut;
+                        }
+                        if (sp == base) break;
+                        sp--;
+                        t = sh.stack[wv][sp];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    for (uint32_t i = lane; i < m; i += 64) a[s.first + i] = lrec[i];
+                    break;
+                }
                 s.depth--;
                 if (lane == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -193,6 +263,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
         }
     }
     __syncthreads();
+    ISD_TP(1);
 
     /* ---- std::__final_insertion_sort = the stable sort by key: stable counting passes, five bits each ---- */
     Rec* src = a;
@@ -230,6 +301,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
         for (uint32_t p = tid; p < (uint32_t)n; p += NTH) a[p] = src[p];
         __syncthreads();
     }
+    ISD_TP(2);
     return (sh.heapNeeded ? 1 : 0) | (sh.qOverflow ? 2 : 0);
 }
 

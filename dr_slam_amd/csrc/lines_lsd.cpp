@@ -850,7 +850,7 @@ struct BatchJob {
     std::vector<hipStream_t> chunkStream;
     std::vector<hipEvent_t> keysReady, growDone;
     std::vector<std::atomic<int>> sortedInChunk;
-    std::vector<int> chunkState;         /* 0 = ordering, 1 = growing on the device, 2 = released to validation (under mu) */
+    std::vector<int> chunkState;         /* 0 = ordering, 1 = growing on the device, 3 = a worker fetches its status words, 2 = released to validation (under mu) */
     std::mutex mu;
     std::condition_variable cv;
     std::deque<int> sortQ, finishQ;      /* frame indices */
@@ -890,12 +890,13 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
         /* std::sort's permutation on the device, in place; the member-list arrays serve as its scratch (the growth that
          * follows on the same stream overwrites them) */
         BCHK(drfe_launch_lsd_order(A->d_order + nk * f0, nk, (int)nk, A->d_reg + ns * f0, A->d_tmp + ns * f0, ns, A->d_ordStatus + f0, 1, nf, st));
-        BCHK(hipMemcpyAsync(A->h_ordStatus + f0, A->d_ordStatus + f0, sizeof(int) * nf, hipMemcpyDeviceToHost, st));
     } else
         BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
     BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
     BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st));
-    BCHK(hipMemcpyAsync(A->h_out + DRFE_LSD_OUT_INTS * (size_t)f0, A->d_out + DRFE_LSD_OUT_INTS * (size_t)f0, DRFE_LSD_OUT_INTS * sizeof(int) * nf, hipMemcpyDeviceToHost, st));
+    /* no download behind the growth: a copy queued on a DMA ring waits there for its kernel and holds up every other stream's
+     * copies behind it (measured: the plane path's kernels and CAPE's transfers stalled for the whole growth); the worker that
+     * sees the event fetches the chunk's status words */
     BCHK(hipEventRecord(J.growDone[ch], st));
 #undef BCHK
     return DRFE_OK;
@@ -917,19 +918,16 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
     std::vector<OPt> tmp;
     const RectValidator val(A->sw, A->sh);
     for (;;) {
-        int f = -1, waitCh = -1; bool fin = false;
+        int f = -1, waitCh = -1, fetchCh = -1; bool fin = false;
         {
             std::unique_lock<std::mutex> lk(J.mu);
             for (;;) {
                 if (J.abort) return;
-                /* chunks whose regions have grown: their frames become validation tasks */
-                for (int ch = 0; ch < J.nChunks; ch++)
-                    if (J.chunkState[ch] == 1 && hipEventQuery(J.growDone[ch]) == hipSuccess) {
-                        J.chunkState[ch] = 2;
-                        const int nf = std::min(J.chunk, J.nframes - ch * J.chunk);
-                        for (int k = 0; k < nf; k++) J.finishQ.push_back(ch * J.chunk + k);
-                        J.cv.notify_all();
-                    }
+                /* chunks whose regions have grown: this worker fetches their status words (outside the lock), then their frames
+                 * become validation tasks */
+                for (int ch = 0; ch < J.nChunks && fetchCh < 0; ch++)
+                    if (J.chunkState[ch] == 1 && hipEventQuery(J.growDone[ch]) == hipSuccess) { J.chunkState[ch] = 3; fetchCh = ch; }
+                if (fetchCh >= 0) break;
                 if (!J.finishQ.empty()) { f = J.finishQ.front(); J.finishQ.pop_front(); fin = true; break; }
                 if (!J.sortQ.empty()) { f = J.sortQ.front(); J.sortQ.pop_front(); break; }
                 if (J.pendingFinish == 0) return;
@@ -938,6 +936,19 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
                 if (waitCh >= 0) break;
                 J.cv.wait(lk);
             }
+        }
+        if (fetchCh >= 0) {
+            const int f0 = fetchCh * J.chunk, nf = std::min(J.chunk, J.nframes - f0);
+            hipError_t e = hipMemcpyAsync(A->h_out + DRFE_LSD_OUT_INTS * (size_t)f0, A->d_out + DRFE_LSD_OUT_INTS * (size_t)f0, DRFE_LSD_OUT_INTS * sizeof(int) * nf,
+                                          hipMemcpyDeviceToHost, lw->stream);
+            if (e == hipSuccess && J.deviceOrder) e = hipMemcpyAsync(A->h_ordStatus + f0, A->d_ordStatus + f0, sizeof(int) * nf, hipMemcpyDeviceToHost, lw->stream);
+            if (e == hipSuccess) e = lane_sync(lw);
+            if (e != hipSuccess) { batch_fail(J, DRFE_ERR_HIP, "lsd_extract_batch: status words of a chunk"); return; }
+            std::lock_guard<std::mutex> lk(J.mu);
+            J.chunkState[fetchCh] = 2;
+            for (int k = 0; k < nf; k++) J.finishQ.push_back(f0 + k);
+            J.cv.notify_all();
+            continue;
         }
         if (waitCh >= 0) {
             const auto tw = std::chrono::steady_clock::now();

@@ -280,6 +280,7 @@ struct PlaneLane {
     PlanesScratch* ps = nullptr;
     hipStream_t stream = nullptr;
     struct VoxelDevice* vox = nullptr;      /* drfe_planes_ahc_post_batch: the lane's device voxel grid (post_internal.h) */
+    float* h_coarse = nullptr; size_t coarseCap = 0;   /* pinned: a frame's voxel clouds as the device extractor's pipeline left them */
 };
 
 static void scratch_free(PlanesScratch*& p)
@@ -308,6 +309,7 @@ void drfe_planes_free(drfe_ctx* c)
             scratch_free(l.ps);
             if (l.stream) (void)hipStreamDestroy(l.stream);
             drfe_voxel_device_free(l.vox);
+            if (l.h_coarse) (void)hipHostFree(l.h_coarse);
         }
         delete pool;
         c->planeLanes = nullptr;
@@ -750,6 +752,10 @@ struct AhcArena {
     AhcDevFrame* d_frames = nullptr; AhcDevFrame* h_frames = nullptr;
     int* h_out = nullptr; drfe_plane* h_planes = nullptr; int* h_memberOff = nullptr;
     uint16_t* h_depth = nullptr;                              /* pinned staging of the caller's depth images */
+    /* pcl::VoxelGrid behind the extractor (voxel_kernels.hip): every frame's plane clouds, the sort's scratch, centroids, jobs */
+    float* d_vpts = nullptr; unsigned long long* d_vrecs = nullptr; unsigned long long* d_vtmp = nullptr; uint32_t* d_vposL = nullptr;
+    uint32_t* d_vposR = nullptr; float* d_vout = nullptr; int2* d_jobs = nullptr; int* d_vcounts = nullptr; int* d_vlist = nullptr;
+    int2* h_jobs = nullptr; int* h_vcounts = nullptr;
     /* offsets of the outputs inside a slot */
     size_t offPlanes = 0, offSeg = 0, offMemberOff = 0, offMemberIdx = 0, offOut = 0;
 };
@@ -757,9 +763,9 @@ struct AhcArena {
 static void arena_free(AhcArena*& a)
 {
     if (!a) return;
-    void* d[] = {a->d_depth, a->d_blocks, a->d_scratch, a->d_frames};
+    void* d[] = {a->d_depth, a->d_blocks, a->d_scratch, a->d_frames, a->d_vpts, a->d_vrecs, a->d_vtmp, a->d_vposL, a->d_vposR, a->d_vout, a->d_jobs, a->d_vcounts, a->d_vlist};
     for (void* p : d) if (p) (void)hipFree(p);
-    void* hp[] = {a->h_frames, a->h_out, a->h_planes, a->h_memberOff, a->h_depth};
+    void* hp[] = {a->h_frames, a->h_out, a->h_planes, a->h_memberOff, a->h_depth, a->h_jobs, a->h_vcounts};
     for (void* p : hp) if (p) (void)hipHostFree(p);
     delete a;
     a = nullptr;
@@ -774,7 +780,7 @@ void drfe_ahc_arena_free(drfe_ctx* c)
 
 #define AHC_DEV_PLANE_CAP 64
 
-static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, float depth_factor)
+static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, float depth_factor, float max_point_dist)
 {
     AhcArena* a = static_cast<AhcArena*>(c->ahcArena);
     if (a && (a->w != w || a->h != h || a->frames < frames)) { arena_free(a); c->ahcArena = nullptr; }
@@ -808,6 +814,18 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
         HIPCHK(c, hipHostMalloc((void**)&a->h_planes, (size_t)P.planeCap * sizeof(drfe_plane) * F, hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void**)&a->h_memberOff, ((size_t)P.planeCap + 1) * 4 * F, hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void**)&a->h_depth, npx * 2 * F, hipHostMallocDefault));
+        if (npx * F > (size_t)0x7fffffff) { c->err = "planes_ahc_post_batch: batch too large"; return DRFE_ERR_CAPACITY; }
+        HIPCHK(c, hipMalloc((void**)&a->d_vpts, npx * 12 * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_vrecs, npx * 8 * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_vtmp, npx * 8 * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_vposL, npx * 4 * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_vposR, npx * 4 * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_vout, npx * 12 * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_jobs, sizeof(int2) * P.planeCap * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_vcounts, sizeof(int) * P.planeCap * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_vlist, sizeof(int) * (P.planeCap * F + 2 * 16)));      /* job order of each chunk (<= 16 chunks) */
+        HIPCHK(c, hipHostMalloc((void**)&a->h_jobs, sizeof(int2) * P.planeCap * F, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_vcounts, sizeof(int) * P.planeCap * F, hipHostMallocDefault));
         for (size_t f = 0; f < F; f++) {
             uint8_t* s = a->d_scratch + a->slotBytes * f;
             AhcDevFrame& g = a->h_frames[f];
@@ -819,12 +837,13 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
             g.membership = (int16_t*)(s + oMem); g.distMap = (float*)(s + oDist); g.rf = (uint32_t*)(s + oRf);
             g.planes = (drfe_plane*)(s + a->offPlanes); g.seg = s + a->offSeg; g.memberOff = (int*)(s + a->offMemberOff);
             g.memberIdx = (int*)(s + a->offMemberIdx); g.out = (int*)(s + a->offOut);
+            g.ptsBase = (int)(npx * f); g.pts = a->d_vpts + 3 * npx * f; g.jobs = a->d_jobs + (size_t)P.planeCap * f;
         }
         HIPCHK(c, hipMemcpy(a->d_frames, a->h_frames, sizeof(AhcDevFrame) * F, hipMemcpyHostToDevice));
     }
     AhcDevParams& P = a->P;
     P.fx = (double)K4[0]; P.fy = (double)K4[1]; P.cx = (double)K4[2]; P.cy = (double)K4[3]; P.factor = (double)depth_factor;
-    P.cos60 = kCos60; P.cos30 = kCos30;
+    P.cos60 = kCos60; P.cos30 = kCos30; P.maxPointDist = max_point_dist;
     return DRFE_OK;
 }
 
@@ -835,10 +854,11 @@ struct AhcBatchJob {
     const float* K4; float depthFactor, maxPointDist; double distThreshold;
     drfe_plane* planes; int* nPlanes; uint8_t* seg; drfe_plane_post* post; int* nAccepted; int* planeNum;
     int chunk, nChunks;
-    std::vector<hipStream_t> chunkStream; std::vector<hipEvent_t> chunkDone; std::vector<int> chunkState;   /* 1 = on the device, 2 = released */
+    bool voxDevice;          /* k_voxel_grid ran behind the extractor: the workers fetch centroids instead of member lists */
+    std::vector<hipStream_t> chunkStream; std::vector<hipEvent_t> chunkDone; std::vector<int> chunkState;   /* 1 = on the device, 3 = a worker fetches its results, 2 = released */
     std::mutex mu; std::condition_variable cv; std::deque<int> finishQ; int pending = 0;
     int firstRc = DRFE_OK; std::string firstErr; bool abort = false;
-    std::atomic<int> fallbacks{0};
+    std::atomic<int> fallbacks{0}, voxFallbacks{0};
 };
 }
 
@@ -857,27 +877,48 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
     const size_t px = (size_t)J.w * J.h;
     (void)hipSetDevice(J.c->device);
     std::vector<int32_t> off((size_t)J.cap + 1), idx(px), voff((size_t)J.cap + 1);
+    std::vector<const float*> cptr((size_t)A->P.planeCap);
+    std::vector<int> vcl((size_t)A->P.planeCap);
+    std::vector<std::vector<float>> redo;
     hipEvent_t ev = nullptr;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, "planes batch: event"); return; }
     for (;;) {
-        int f = -1, waitCh = -1;
+        int f = -1, waitCh = -1, fetchCh = -1;
         {
             std::unique_lock<std::mutex> lk(J.mu);
             for (;;) {
                 if (J.abort) { (void)hipEventDestroy(ev); return; }
-                for (int ch = 0; ch < J.nChunks; ch++)
-                    if (J.chunkState[ch] == 1 && hipEventQuery(J.chunkDone[ch]) == hipSuccess) {
-                        J.chunkState[ch] = 2;
-                        const int nf = std::min(J.chunk, J.nframes - ch * J.chunk);
-                        for (int k = 0; k < nf; k++) J.finishQ.push_back(ch * J.chunk + k);
-                        J.cv.notify_all();
-                    }
+                for (int ch = 0; ch < J.nChunks && fetchCh < 0; ch++)
+                    if (J.chunkState[ch] == 1 && hipEventQuery(J.chunkDone[ch]) == hipSuccess) { J.chunkState[ch] = 3; fetchCh = ch; }
+                if (fetchCh >= 0) break;
                 if (!J.finishQ.empty()) { f = J.finishQ.front(); J.finishQ.pop_front(); break; }
                 if (J.pending == 0) { (void)hipEventDestroy(ev); return; }
                 for (int ch = 0; ch < J.nChunks && waitCh < 0; ch++) if (J.chunkState[ch] == 1) waitCh = ch;
                 if (waitCh >= 0) break;
                 J.cv.wait(lk);
             }
+        }
+        if (fetchCh >= 0) {
+            /* the small results of every frame of the chunk; member lists, centroids and label images are fetched per frame */
+            const int f0 = fetchCh * J.chunk, nf = std::min(J.chunk, J.nframes - f0);
+            const size_t pc = (size_t)A->P.planeCap;
+            hipStream_t st = l->stream;
+            hipError_t e = hipMemcpy2DAsync(A->h_out + 4 * (size_t)f0, 16, A->d_scratch + A->slotBytes * f0 + A->offOut, A->slotBytes, 16, nf, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(A->h_planes + pc * f0, sizeof(drfe_plane) * pc, A->d_scratch + A->slotBytes * f0 + A->offPlanes, A->slotBytes, sizeof(drfe_plane) * pc, nf,
+                                     hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(A->h_memberOff + (pc + 1) * f0, 4 * (pc + 1), A->d_scratch + A->slotBytes * f0 + A->offMemberOff, A->slotBytes, 4 * (pc + 1), nf,
+                                     hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && J.voxDevice) e = hipMemcpyAsync(A->h_jobs + pc * f0, A->d_jobs + pc * f0, sizeof(int2) * pc * nf, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && J.voxDevice) e = hipMemcpyAsync(A->h_vcounts + pc * f0, A->d_vcounts + pc * f0, sizeof(int) * pc * nf, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = drfe_pool_sync(st, ev);
+            if (e != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, std::string("planes batch: results of a chunk: ") + hipGetErrorString(e)); (void)hipEventDestroy(ev); return; }
+            std::lock_guard<std::mutex> lk(J.mu);
+            J.chunkState[fetchCh] = 2;
+            for (int k = 0; k < nf; k++) J.finishQ.push_back(f0 + k);
+            J.cv.notify_all();
+            continue;
         }
         if (waitCh >= 0) {
             if (hipEventSynchronize(J.chunkDone[waitCh]) != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, "planes batch: device"); (void)hipEventDestroy(ev); return; }
@@ -886,6 +927,7 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
         const uint16_t* d = J.depth + (size_t)f * J.frameStride;
         drfe_plane* pl = J.planes + (size_t)f * J.cap;
         int rc = DRFE_OK;
+        bool viaCoarse = false;
         const int nP = A->h_out[4 * (size_t)f], status = A->h_out[4 * (size_t)f + 1];
         if (status != 0 || nP > J.cap) {
             /* a capacity of the device path ran out (or a cosine could not be certified): this frame on the host */
@@ -897,13 +939,55 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             const int* mo = A->h_memberOff + ((size_t)A->P.planeCap + 1) * f;
             for (int i = 0; i <= nP; i++) off[i] = mo[i];
             const uint8_t* slot = A->d_scratch + A->slotBytes * f;
+            const int2* jobs = A->h_jobs + (size_t)A->P.planeCap * f;
+            const int* vc = A->h_vcounts + (size_t)A->P.planeCap * f;
+            /* planes the device handed back (vc < 0: the sort's heap-sort branch, a grid beyond int32): their gathered clouds come
+             * back instead and this thread runs their grids */
+            const bool coarseReady = J.voxDevice;
+            size_t nCoarse = 0;
+            int handedBack = 0;
+            for (int i = 0; i < nP && coarseReady; i++) { vcl[i] = vc[i]; if (vc[i] < 0) handedBack++; nCoarse += (size_t)(vc[i] < 0 ? jobs[i].y : vc[i]); }
             hipError_t e = hipSuccess;
-            if (off[nP] > 0) e = hipMemcpyAsync(idx.data(), slot + A->offMemberIdx, sizeof(int) * (size_t)off[nP], hipMemcpyDeviceToHost, l->stream);
+            if (coarseReady) {
+                /* the centroids of every plane, packed, into the lane's pinned buffer */
+                if (l->coarseCap < nCoarse) {
+                    if (l->h_coarse) (void)hipHostFree(l->h_coarse);
+                    l->h_coarse = nullptr; l->coarseCap = 0;
+                    const size_t capPts = std::max<size_t>(nCoarse + nCoarse / 2, 1 << 15);
+                    e = hipHostMalloc((void**)&l->h_coarse, capPts * 12, hipHostMallocDefault);
+                    if (e == hipSuccess) l->coarseCap = capPts;
+                }
+                size_t at = 0;
+                for (int i = 0; i < nP && e == hipSuccess; i++) {
+                    cptr[i] = l->h_coarse + 3 * at;
+                    const size_t cnt = (size_t)(vc[i] < 0 ? jobs[i].y : vc[i]);
+                    if (cnt > 0) e = hipMemcpyAsync(l->h_coarse + 3 * at, (vc[i] < 0 ? A->d_vpts : A->d_vout) + 3 * (size_t)jobs[i].x, cnt * 12, hipMemcpyDeviceToHost, l->stream);
+                    at += cnt;
+                }
+            } else if (off[nP] > 0)
+                e = hipMemcpyAsync(idx.data(), slot + A->offMemberIdx, sizeof(int) * (size_t)off[nP], hipMemcpyDeviceToHost, l->stream);
             if (e == hipSuccess && J.seg) e = hipMemcpyAsync(J.seg + f * px, slot + A->offSeg, px, hipMemcpyDeviceToHost, l->stream);
-            if (e == hipSuccess) e = drfe_pool_sync(l->stream, ev);
-            if (e != hipSuccess) { l->err = std::string("planes batch: member lists: ") + hipGetErrorString(e); rc = DRFE_ERR_HIP; }
+            if (e == hipSuccess && (nCoarse > 0 || !coarseReady || J.seg)) e = drfe_pool_sync(l->stream, ev);
+            if (e != hipSuccess) { l->err = std::string("planes batch: results of a frame: ") + hipGetErrorString(e); rc = DRFE_ERR_HIP; }
+            if (rc == DRFE_OK && coarseReady && handedBack) {
+                J.voxFallbacks += handedBack;
+                redo.resize((size_t)handedBack);
+                int r = 0;
+                for (int i = 0; i < nP; i++)
+                    if (vc[i] < 0) {
+                        int cnt = 0;
+                        redo[r].resize(3 * (size_t)jobs[i].y);
+                        (void)drfe_plane_voxel_grid(cptr[i], jobs[i].y, 0.05f, redo[r].data(), jobs[i].y, &cnt);
+                        cptr[i] = redo[r].data(); vcl[i] = cnt; r++;
+                    }
+            }
+            if (rc == DRFE_OK && coarseReady) {
+                rc = drfe_ahc_post_from_coarse(&l->err, pl, nP, cptr.data(), vcl.data(), J.maxPointDist, J.distThreshold, J.post + (size_t)f * J.cap, nullptr, voff.data(),
+                                               0, &J.nAccepted[f], J.planeNum ? &J.planeNum[f] : nullptr);
+                viaCoarse = true;
+            }
         }
-        if (rc == DRFE_OK)
+        if (rc == DRFE_OK && !viaCoarse)
             rc = drfe_ahc_post_core(&l->err, d, J.w, J.h, J.stride, J.K4, J.depthFactor, pl, J.nPlanes[f], off.data(), idx.data(), J.maxPointDist,
                                     J.distThreshold, J.post + (size_t)f * J.cap, nullptr, voff.data(), 0, &J.nAccepted[f],
                                     J.planeNum ? &J.planeNum[f] : nullptr, nullptr);
@@ -919,7 +1003,7 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
                                         size_t stride, int nframes, const float* K4, float depth_factor, float max_point_dist, double dist_threshold,
                                         drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num)
 {
-    int rc = ensure_arena(c, w, h, nframes, K4, depth_factor);
+    int rc = ensure_arena(c, w, h, nframes, K4, depth_factor, max_point_dist);
     if (rc != DRFE_OK) return rc;
     AhcArena* A = static_cast<AhcArena*>(c->ahcArena);
     AhcBatchJob J;
@@ -932,12 +1016,17 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
     J.chunk = std::max(1, std::min(nframes, std::max(16, (nframes + nch - 1) / nch)));
     J.nChunks = (nframes + J.chunk - 1) / J.chunk;
     J.pending = nframes;
+    J.voxDevice = c->planesDeviceVoxel != 0 && !std::getenv("DRFE_VOXEL_HOST");
     J.chunkStream.resize(J.nChunks); J.chunkDone.resize(J.nChunks); J.chunkState.assign(J.nChunks, 0);
     int prLow = 0, prHigh = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
     const size_t px = (size_t)w * h;
     const int NB = A->P.NB;
     int launchRc = DRFE_OK;
+    static const bool traceStages = std::getenv("DRFE_TRACE_PLANES") != nullptr;
+    hipEvent_t stageEv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       /* chunk 0: start, depth up, blocks, extractor, voxel grids */
+    if (traceStages) for (hipEvent_t& e : stageEv) HIPCHK(c, hipEventCreate(&e));
+    const auto tCall = std::chrono::steady_clock::now();
     for (int ch = 0; ch < J.nChunks; ch++) {
         /* low priority, like the line path's growth: the runtime keeps separate hardware queues per priority, so the pools'
          * short kernels never queue behind a chunk that runs for a hundred milliseconds */
@@ -949,26 +1038,39 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         hipStream_t st = J.chunkStream[ch];
         for (int f = f0; f < f0 + nf; f++)
             for (int y = 0; y < h; y++) std::memcpy(A->h_depth + px * f + (size_t)y * w, depth + (size_t)f * frame_stride + (size_t)y * stride, (size_t)w * 2);
+        const bool tr = traceStages && ch == 0;
+        if (tr) (void)hipEventRecord(stageEv[0], st);
         hipError_t e = hipMemcpyAsync(A->d_depth + px * f0, A->h_depth + px * f0, px * 2 * nf, hipMemcpyHostToDevice, st);
+        if (tr) (void)hipEventRecord(stageEv[1], st);
         if (e == hipSuccess) e = drfe_launch_ahc_blocks(A->d_depth + px * f0, px, (size_t)w, w, h, K4, depth_factor, nf, A->d_blocks + (size_t)NB * f0, st);
+        if (tr) (void)hipEventRecord(stageEv[2], st);
         if (e == hipSuccess) e = drfe_launch_ahc_frames(A->d_frames + f0, nf, A->P, st);
-        /* the small results of every frame of the chunk; member lists and label images are fetched per frame by the workers */
-        if (e == hipSuccess)
-            e = hipMemcpy2DAsync(A->h_out + 4 * (size_t)f0, 16, A->d_scratch + A->slotBytes * f0 + A->offOut, A->slotBytes, 16, nf, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess)
-            e = hipMemcpy2DAsync(A->h_planes + (size_t)A->P.planeCap * f0, sizeof(drfe_plane) * A->P.planeCap, A->d_scratch + A->slotBytes * f0 + A->offPlanes, A->slotBytes,
-                                 sizeof(drfe_plane) * A->P.planeCap, nf, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess)
-            e = hipMemcpy2DAsync(A->h_memberOff + ((size_t)A->P.planeCap + 1) * f0, 4 * ((size_t)A->P.planeCap + 1), A->d_scratch + A->slotBytes * f0 + A->offMemberOff,
-                                 A->slotBytes, 4 * ((size_t)A->P.planeCap + 1), nf, hipMemcpyDeviceToHost, st);
+        if (tr) (void)hipEventRecord(stageEv[3], st);
+        if (e == hipSuccess && J.voxDevice) {
+            const size_t pc = (size_t)A->P.planeCap;
+            e = drfe_launch_voxel_grid(A->d_vpts, A->d_jobs + pc * f0, (int)(pc * nf), A->d_vlist + pc * f0 + 2 * (size_t)ch, A->d_vrecs, A->d_vtmp, A->d_vposL, A->d_vposR, A->d_vout, A->d_vcounts + pc * f0,
+                                       0.05f, st);
+            if (tr) (void)hipEventRecord(stageEv[4], st);
+        }
+        /* no download behind the kernels: a copy queued on a DMA ring waits there for its kernel and holds up the copies of every
+         * other stream behind it (the line path's, CAPE's); the worker that sees the event fetches the chunk's small results */
         if (e == hipSuccess) e = hipEventRecord(J.chunkDone[ch], st);
         if (e != hipSuccess) { c->err = std::string("planes_ahc_post_batch: device path: ") + hipGetErrorString(e); launchRc = DRFE_ERR_HIP; }
         else J.chunkState[ch] = 1;
     }
+    const auto tLaunched = std::chrono::steady_clock::now();
     if (launchRc == DRFE_OK) {
         std::vector<std::thread> th;
         for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { ahc_batch_worker(J, &(*pool)[k]); });
         for (std::thread& t : th) t.join();
+    }
+    if (traceStages) {
+        float ms[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; k++) if (k < 3 || J.voxDevice) (void)hipEventElapsedTime(&ms[k], stageEv[k], stageEv[k + 1]);
+        const double tl = std::chrono::duration<double, std::milli>(tLaunched - tCall).count(), ta = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tCall).count();
+        std::fprintf(stderr, "drfe_planes_ahc_post_batch stages (chunk 0): staging + enqueue %.1f ms of host time; depth upload %.1f ms, k_ahc_blocks %.1f, k_ahc_frame %.1f, k_voxel_grid %.1f; call %.1f ms\n",
+                     tl, ms[0], ms[1], ms[2], ms[3], ta);
+        for (hipEvent_t& e : stageEv) (void)hipEventDestroy(e);
     }
     for (int ch = 0; ch < J.nChunks; ch++) {
         (void)hipStreamSynchronize(J.chunkStream[ch]);
@@ -982,7 +1084,8 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
                      t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, A->h_out[2], t[4] / 1e5, t[5] / 1e5, A->h_out[3]);
     }
     if (std::getenv("DRFE_TRACE_PLANES"))
-        std::fprintf(stderr, "drfe_planes_ahc_post_batch (device extractor): %d frames, %d chunks, %d frames redone on the host\n", nframes, J.nChunks, J.fallbacks.load());
+        std::fprintf(stderr, "drfe_planes_ahc_post_batch (device extractor): %d frames, %d chunks, %d frames redone on the host; voxel grids on the %s (%d planes' grids redone on the host)\n",
+                     nframes, J.nChunks, J.fallbacks.load(), J.voxDevice ? "device" : "host", J.voxFallbacks.load());
     if (launchRc != DRFE_OK) return launchRc;
     if (J.firstRc != DRFE_OK) { c->err = J.firstErr; return J.firstRc; }
     return DRFE_OK;
@@ -990,11 +1093,13 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
 
 extern "C" {
 
-/* 1: drfe_planes_ahc_post_batch runs pcl::VoxelGrid of every plane on the device (voxel_kernels.hip); 0 (default): on the pool's
- * host threads.  Results are identical. */
+/* pcl::VoxelGrid of every plane in drfe_planes_ahc_post_batch.  1 (default): on the device (voxel_kernels.hip) behind the device
+ * extractor - one launch for all planes of a chunk of frames, the workers fetch centroids; the host-extractor mode keeps the host
+ * grid.  2: on the device in the host-extractor mode too (a launch per frame from each worker).  0: always on the pool's host
+ * threads.  Results are identical. */
 int drfe_planes_configure(drfe_ctx* c, int device_voxel_grid)
 {
-    if (!c || device_voxel_grid < 0 || device_voxel_grid > 1) { if (c) c->err = "planes_configure: invalid argument"; return DRFE_ERR_INVALID; }
+    if (!c || device_voxel_grid < 0 || device_voxel_grid > 2) { if (c) c->err = "planes_configure: invalid argument"; return DRFE_ERR_INVALID; }
     c->planesDeviceVoxel = device_voxel_grid;
     return DRFE_OK;
 }
@@ -1047,7 +1152,7 @@ int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_
              * voxel_kernels.hip - identical results; it frees ~2.5 ms of CPU per frame, but the thread then sleeps ~3-5 ms per
              * frame waiting for its ten 256-thread sorts, and beside the line path's long-running kernels the hardware queues
              * serialise: measured 360-590 frames/s for the whole front-end against 1040-1080 with the host grid) */
-            const bool voxHost = !c->planesDeviceVoxel;
+            const bool voxHost = c->planesDeviceVoxel != 2;
             if (!voxHost && !l->vox) {
                 l->vox = drfe_voxel_device_create(l->device, &l->err);
                 if (!l->vox) { rcs[k] = DRFE_ERR_HIP; return; }

@@ -49,6 +49,7 @@ struct AhcDevParams {
     int maxNodes, poolCap, rfCap, planeCap;
     double fx, fy, cx, cy, factor;       /* K floats promoted, depth factor: PlaneDetection::readDepthImage */
     double cos60, cos30;                 /* similarityTh_merge / _refine, from the host's libm as the host path's constants */
+    float maxPointDist;                  /* Frame::ComputePlanes' gather: points beyond it stay out of the plane's cloud */
 };
 /* one frame of a k_ahc_frame launch: inputs, per-frame scratch, outputs */
 struct AhcDevFrame {
@@ -58,6 +59,7 @@ struct AhcDevFrame {
     int* dsParent; int* dsSize; int* G; int* blkMap; int* ridToPlid;
     int16_t* membership; float* distMap; uint32_t* rf;
     drfe_plane* planes; uint8_t* seg; int* memberOff; int* memberIdx;      /* final planes, label image, member lists */
+    float* pts; int2* jobs; int ptsBase;                     /* plane clouds for k_voxel_grid: pts = arena cloud + 3 * ptsBase, jobs[planeCap] (or null) */
     int* out;                                                /* out[0] = planes, out[1] = status (0 = done; else: redo on the host) */
 };
 hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s);

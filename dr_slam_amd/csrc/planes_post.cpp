@@ -301,7 +301,7 @@ struct VoxelDevice {
     size_t cap = 0;               /* points the buffers hold */
     float* d_pts = nullptr; unsigned long long* d_recs = nullptr; unsigned long long* d_tmp = nullptr;
     uint32_t* d_posL = nullptr; uint32_t* d_posR = nullptr; float* d_out = nullptr;
-    int2* d_jobs = nullptr; int* d_counts = nullptr;
+    int2* d_jobs = nullptr; int* d_counts = nullptr; int* d_list = nullptr;
     float* h_pts = nullptr; float* h_out = nullptr; int2* h_jobs = nullptr; int* h_counts = nullptr;
 };
 #define VOX_MAX_JOBS 256
@@ -323,7 +323,7 @@ VoxelDevice* drfe_voxel_device_create(int device, std::string* err)
     v->device = device;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&v->ev, hipEventDisableTiming) == hipSuccess &&
-              hipMalloc((void**)&v->d_jobs, VOX_MAX_JOBS * sizeof(int2)) == hipSuccess && hipMalloc((void**)&v->d_counts, VOX_MAX_JOBS * sizeof(int)) == hipSuccess &&
+              hipMalloc((void**)&v->d_jobs, VOX_MAX_JOBS * sizeof(int2)) == hipSuccess && hipMalloc((void**)&v->d_list, (VOX_MAX_JOBS + 2) * sizeof(int)) == hipSuccess && hipMalloc((void**)&v->d_counts, VOX_MAX_JOBS * sizeof(int)) == hipSuccess &&
               hipHostMalloc((void**)&v->h_jobs, VOX_MAX_JOBS * sizeof(int2), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void**)&v->h_counts, VOX_MAX_JOBS * sizeof(int), hipHostMallocDefault) == hipSuccess;
     if (!ok) { if (err) *err = "voxel grid lane: allocation failed"; drfe_voxel_device_free(v); return nullptr; }
@@ -336,6 +336,7 @@ void drfe_voxel_device_free(VoxelDevice* v)
     voxel_buffers_free(v);
     if (v->d_jobs) (void)hipFree(v->d_jobs);
     if (v->d_counts) (void)hipFree(v->d_counts);
+    if (v->d_list) (void)hipFree(v->d_list);
     if (v->h_jobs) (void)hipHostFree(v->h_jobs);
     if (v->h_counts) (void)hipHostFree(v->h_counts);
     if (v->ev) (void)hipEventDestroy(v->ev);
@@ -376,7 +377,7 @@ static bool voxel_downsample_device(VoxelDevice* v, const std::vector<Pt>* input
     }
     e = hipMemcpyAsync(v->d_pts, v->h_pts, total * 12, hipMemcpyHostToDevice, v->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(v->d_jobs, v->h_jobs, np * sizeof(int2), hipMemcpyHostToDevice, v->stream);
-    if (e == hipSuccess) e = drfe_launch_voxel_grid(v->d_pts, v->d_jobs, np, v->d_recs, v->d_tmp, v->d_posL, v->d_posR, v->d_out, v->d_counts, 0.05f, v->stream);
+    if (e == hipSuccess) e = drfe_launch_voxel_grid(v->d_pts, v->d_jobs, np, v->d_list, v->d_recs, v->d_tmp, v->d_posL, v->d_posR, v->d_out, v->d_counts, 0.05f, v->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(v->h_counts, v->d_counts, np * sizeof(int), hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(v->h_out, v->d_out, total * 12, hipMemcpyDeviceToHost, v->stream);
     if (e == hipSuccess) e = drfe_pool_sync(v->stream, v->ev);
@@ -461,6 +462,27 @@ int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, si
     voxel_offsets[n_planes] = o.used;
     *n_accepted = o.nAccepted;
     if (plane_num) *plane_num = n_planes - o.failPlanes;     /* planeDetector.plane_num_ -= fail_planes (:1023) */
+    if (o.overflow) { if (err) *err = "planes_ahc_postprocess: voxel buffer too small"; return DRFE_ERR_CAPACITY; }
+    return DRFE_OK;
+}
+
+/* the same loop when every plane's voxel cloud is already there (k_voxel_grid ran behind k_ahc_frame): gates + refit only */
+int drfe_ahc_post_from_coarse(std::string* err, const drfe_plane* planes, int n_planes, const float* const* coarse_xyz, const int* coarse_n,
+                              float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets,
+                              int cap_voxels, int* n_accepted, int* plane_num)
+{
+    PostOut o{post, voxel_xyz, voxel_offsets, cap_voxels, 0, 0, 0, false};
+    static thread_local std::vector<Pt> coarse;
+    for (int i = 0; i < n_planes; i++) {
+        const drfe_plane& e = planes[i];
+        const float d = (float)-(e.normal[0] * e.center[0] + e.normal[1] * e.center[1] + e.normal[2] * e.center[2]);
+        const float coef[4] = {(float)e.normal[0], (float)e.normal[1], (float)e.normal[2], d};
+        coarse.assign((const Pt*)coarse_xyz[i], (const Pt*)coarse_xyz[i] + coarse_n[i]);
+        post_one_coarse(coarse, coef, d > max_point_dist, dist_threshold, false, i, &o);
+    }
+    voxel_offsets[n_planes] = o.used;
+    *n_accepted = o.nAccepted;
+    if (plane_num) *plane_num = n_planes - o.failPlanes;
     if (o.overflow) { if (err) *err = "planes_ahc_postprocess: voxel buffer too small"; return DRFE_ERR_CAPACITY; }
     return DRFE_OK;
 }

@@ -23,9 +23,9 @@ hipError_t drfe_launch_surface_normals(const void* d_depth, int isU16, float fac
 void drfe_post_free(drfe_ctx* c);
 #include <string>
 /* pcl::VoxelGrid for njobs point clouds at once (voxel_kernels.hip): job j = points [jobs[j].x, jobs[j].x + jobs[j].y) of d_pts
- * (xyz packed); scratch arrays span all points; centroids of job j to d_out at the job's offset, their number to d_counts[j]
+ * (xyz packed); d_list: njobs + 2 ints of scratch (the job order); scratch arrays span all points; centroids of job j to d_out at the job's offset, their number to d_counts[j]
  * (-1: grid overflows int32, PCL keeps the input cloud; -2: the sort needs the heap-sort branch: run the job on the host) */
-hipError_t drfe_launch_voxel_grid(const float* d_pts, const int2* d_jobs, int njobs, unsigned long long* d_recs, unsigned long long* d_tmp,
+hipError_t drfe_launch_voxel_grid(const float* d_pts, const int2* d_jobs, int njobs, int* d_list, unsigned long long* d_recs, unsigned long long* d_tmp,
                                   uint32_t* d_posL, uint32_t* d_posR, float* d_out, int* d_counts, float leafSize, hipStream_t s);
 /* a lane's device voxel grid (planes_post.cpp): buffers + stream; NULL = the host voxel grid */
 struct VoxelDevice;
@@ -35,4 +35,7 @@ int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, si
                        const drfe_plane* planes, int n_planes, const int32_t* member_offsets, const int32_t* member_idx,
                        float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets,
                        int cap_voxels, int* n_accepted, int* plane_num, VoxelDevice* vox = nullptr);
+int drfe_ahc_post_from_coarse(std::string* err, const drfe_plane* planes, int n_planes, const float* const* coarse_xyz, const int* coarse_n,
+                              float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets,
+                              int cap_voxels, int* n_accepted, int* plane_num);
 #endif

@@ -4,7 +4,11 @@
  *
  * VoxelGrid sorts (leaf index, point index) records with std::sort ON THE LEAF INDEX ALONE and sums a leaf's points in that
  * order in float: the centroid's last bits are introsort's permutation of equal keys.  introsort_device.h reproduces it; the
- * rest is parallel by construction.  One workgroup of 256 threads per plane ("job"):
+ * rest is parallel by construction.  One workgroup of 256 threads works on a plane ("job") at a time; the launch holds as many
+ * workgroups as the device keeps resident and each takes the next job from a list ordered by size, largest first
+ * (k_voxel_jobs_order) - a grid of one workgroup per job, walked in index order, left the planes of equal index (the large
+ * first plane of every frame) on one XCD and seven XCDs nearly idle (measured: 134 ms for the 4974 clouds of 512 frames whose
+ * workgroup times add up to 9.3 s).  Per job:
  *   bounds (float min / max, order-free) -> grid origin and divisions as the host computes them -> leaf index per point ->
  *   std::sort's order (introsort's moves + stable counting passes) -> run heads by prefix sums -> one thread per leaf adds
  *   its points in sorted order and divides by the count.
@@ -12,6 +16,19 @@
  * branch reports a negative count: the caller runs that plane on the host. */
 #include "drfe_internal.h"
 #include "post_internal.h"
+#ifdef VOX_PROFILE
+/* phase times summed over workgroups (100 MHz ticks of thread 0): 0 bounds + keys, 1 workgroup partitions, 2 wavefront phase,
+ * 3 counting passes, 4 leaf heads, 5 centroids, 6 = workgroups, 7 = points */
+__device__ unsigned long long g_voxProf[8];
+/* 0 = longest workgroup (ticks), 1 = workgroups above 5 ms, 2 = above 20 ms, 3 = ticks of those that ended in the heap-sort flag, 4 = their number */
+__device__ unsigned long long g_voxTail[8];
+/* [0..7] workgroup ticks per XCD, [8..15] non-empty workgroups per XCD, [16] sum over workgroups of the number running when each began, [17] running now */
+__device__ unsigned long long g_voxXcd[18];
+#define ISD_TP(k) do { if (threadIdx.x == 0) { const unsigned long long t__ = wall_clock64(); atomicAdd(&g_voxProf[(k) + 1], t__ - sh.tp); sh.tp = t__; } } while (0)
+#define VOX_TP(k) do { if (threadIdx.x == 0) { const unsigned long long t__ = wall_clock64(); atomicAdd(&g_voxProf[k], t__ - sh.tp); sh.tp = t__; } } while (0)
+#else
+#define VOX_TP(k)
+#endif
 #include "introsort_device.h"
 #define VOX_T 256                 /* threads per plane: 47 KB of LDS per workgroup, so three fit a CU beside other kernels' wavefronts */
 #define VOX_WAVES (VOX_T / 64)
@@ -33,7 +50,35 @@ __device__ __forceinline__ float floor_f(float v)
 
 } // namespace
 
+/* the non-empty jobs in descending order of size (by power-of-two class); empty jobs get their count of 0 here.
+ * ctl[0] = the next list entry to take (0), ctl[1] = entries.  One workgroup. */
+extern "C" __global__ __launch_bounds__(1024) void k_voxel_jobs_order(const int2* __restrict__ jobs, int njobs, int* __restrict__ list,
+                                                                      int* __restrict__ ctl, int* __restrict__ counts)
+{
+    __shared__ int hist[32], cursor[32];
+    const int tid = threadIdx.x;
+    if (tid < 32) hist[tid] = 0;
+    __syncthreads();
+    for (int j = tid; j < njobs; j += 1024) {
+        const int n = jobs[j].y;
+        if (n > 0) atomicAdd(&hist[31 - __clz(n)], 1);
+        else counts[j] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int b = 31; b >= 0; b--) { cursor[b] = run; run += hist[b]; }
+        ctl[0] = 0; ctl[1] = run;
+    }
+    __syncthreads();
+    for (int j = tid; j < njobs; j += 1024) {
+        const int n = jobs[j].y;
+        if (n > 0) list[atomicAdd(&cursor[31 - __clz(n)], 1)] = j;
+    }
+}
+
 extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __restrict__ pts, const int2* __restrict__ jobs,
+                                                                 const int* __restrict__ list, int* __restrict__ ctl,
                                                                  unsigned long long* __restrict__ recs, unsigned long long* __restrict__ tmp,
                                                                  uint32_t* __restrict__ posL, uint32_t* __restrict__ posR,
                                                                  float* __restrict__ out, int* __restrict__ counts, float leafSize)
@@ -42,12 +87,27 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
     __shared__ isd::Shared<VOX_T> sh;
     __shared__ float red[6][VOX_WAVES];
     __shared__ int grid[8];                 /* bx by bz sx sxy keyBits ok total */
-    const int2 job = jobs[blockIdx.x];
-    const int off = job.x, n = job.y;
+    __shared__ int nextJob;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nList = ctl[1];
+  for (;;) {
+    /* the next job of the list; every workgroup reaches the end of the list and leaves */
+    __syncthreads();
+    if (tid == 0) nextJob = atomicAdd(&ctl[0], 1);
+    __syncthreads();
+    const int li = nextJob;
+    if (li >= nList) break;
+    const int jb = list[li];
+    const int2 job = jobs[jb];
+    const int off = job.x, n = job.y;
     const float* P = pts + 3 * (size_t)off;
     unsigned long long* a = recs + off;
-    if (n <= 0) { if (tid == 0) counts[blockIdx.x] = 0; return; }
+    if (n <= 0) { if (tid == 0) counts[jb] = 0; continue; }
+#ifdef VOX_PROFILE
+    const unsigned long long voxT0 = wall_clock64();
+    if (tid == 0) { const unsigned long long r = atomicAdd(&g_voxXcd[17], 1ull); atomicAdd(&g_voxXcd[16], r); }
+    if (tid == 0) { sh.tp = voxT0; atomicAdd(&g_voxProf[6], 1ull); atomicAdd(&g_voxProf[7], (unsigned long long)n); }
+#endif
     const float inv = 1.0f / leafSize;
     /* getMinMax3D */
     float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
@@ -74,7 +134,7 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
         grid[5] = bits;
     }
     __syncthreads();
-    if (!grid[6]) { if (tid == 0) counts[blockIdx.x] = -1; return; }        /* "leaf size too small": PCL keeps the input */
+    if (!grid[6]) { if (tid == 0) counts[jb] = -1; continue; }        /* "leaf size too small": PCL keeps the input */
     const int bx = grid[0], by = grid[1], bz = grid[2], sx = grid[3], sxy = grid[4], keyBits = grid[5];
     for (int i = tid; i < n; i += VOX_T) {
         const int ia = (int)(floor_f(P[3 * (size_t)i] * inv) - (float)bx);
@@ -84,8 +144,13 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
     }
     int lg = 0;
     for (unsigned v = (unsigned)n; v > 1; v >>= 1) lg++;
+    __syncthreads();
+    VOX_TP(0);
     const int st = isd::sort<VOX_T, VoxTraits>(a, n, posL + off, posR + off, tmp + off, dyn, sh, 2 * lg, keyBits);
-    if (st != 0) { if (tid == 0) counts[blockIdx.x] = -2; return; }
+#ifdef VOX_PROFILE
+    if (st != 0 && tid == 0) { atomicAdd(&g_voxTail[3], wall_clock64() - voxT0); atomicAdd(&g_voxTail[4], 1ull); atomicAdd(&g_voxXcd[17], ~0ull); }
+#endif
+    if (st != 0) { if (tid == 0) counts[jb] = -2; continue; }
     /* leaves = runs of equal keys: heads numbered by prefix sums, head positions to posL */
     uint32_t* heads = posL + off;
     int total = 0;
@@ -103,6 +168,7 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
         total += all;
     }
     __syncthreads();
+    VOX_TP(4);
     /* centroid of a leaf: its points added in sorted order (float), divided by the count */
     float* O = out + 3 * (size_t)off;
     for (int r = tid; r < total; r += VOX_T) {
@@ -115,19 +181,44 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
         const float cnt = (float)(last - first);
         O[3 * (size_t)r] = ax / cnt; O[3 * (size_t)r + 1] = ay / cnt; O[3 * (size_t)r + 2] = az / cnt;
     }
-    if (tid == 0) counts[blockIdx.x] = total;
+    if (tid == 0) counts[jb] = total;
+    __syncthreads();
+    VOX_TP(5);
+#ifdef VOX_PROFILE
+    if (tid == 0) { const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u; atomicAdd(&g_voxXcd[xcc], wall_clock64() - voxT0); atomicAdd(&g_voxXcd[8 + xcc], 1ull); atomicAdd(&g_voxXcd[17], ~0ull); }
+    if (tid == 0) { const unsigned long long d = wall_clock64() - voxT0; atomicMax(&g_voxTail[0], d); if (d > 500000ull) atomicAdd(&g_voxTail[1], 1ull); if (d > 2000000ull) atomicAdd(&g_voxTail[2], 1ull); }
+#endif
+  }
 }
 
-hipError_t drfe_launch_voxel_grid(const float* d_pts, const int2* d_jobs, int njobs, unsigned long long* d_recs, unsigned long long* d_tmp,
+hipError_t drfe_launch_voxel_grid(const float* d_pts, const int2* d_jobs, int njobs, int* d_list, unsigned long long* d_recs, unsigned long long* d_tmp,
                                   uint32_t* d_posL, uint32_t* d_posR, float* d_out, int* d_counts, float leafSize, hipStream_t s)
 {
     if (njobs <= 0) return hipSuccess;
-    static bool configured = false;
-    if (!configured) {
+    static int resident = 0;
+    if (!resident) {
         hipError_t e = hipFuncSetAttribute((const void*)k_voxel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, ORD_DYN_LDS_BYTES(VOX_T));
         if (e != hipSuccess) return e;
-        configured = true;
+        int dev = 0, cus = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        resident = 3 * (cus > 0 ? cus : 256);               /* 47 KB of LDS each: three per CU */
     }
-    hipLaunchKernelGGL(k_voxel_grid, dim3(njobs), dim3(VOX_T), ORD_DYN_LDS_BYTES(VOX_T), s, d_pts, d_jobs, d_recs, d_tmp, d_posL, d_posR, d_out, d_counts, leafSize);
+    hipLaunchKernelGGL(k_voxel_jobs_order, dim3(1), dim3(1024), 0, s, d_jobs, njobs, d_list + 2, d_list, d_counts);
+    hipLaunchKernelGGL(k_voxel_grid, dim3(njobs < resident ? njobs : resident), dim3(VOX_T), ORD_DYN_LDS_BYTES(VOX_T), s, d_pts, d_jobs, (const int*)(d_list + 2), d_list,
+                       d_recs, d_tmp, d_posL, d_posR, d_out, d_counts, leafSize);
     return hipGetLastError();
 }
+
+#ifdef VOX_PROFILE
+extern "C" int drfe_debug_voxel_profile(unsigned long long* out8 /* 34 */)
+{
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_voxProf), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(g_voxTail), sizeof(z)) != hipSuccess) return -1;
+    unsigned long long z18[18] = {0};
+    if (hipMemcpyFromSymbol(out8 + 16, HIP_SYMBOL(g_voxXcd), sizeof(z18)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_voxXcd), z18, sizeof(z18)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_voxTail), z, sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_voxProf), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

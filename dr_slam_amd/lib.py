@@ -951,9 +951,10 @@ class Context:
             out.append(r)
         return out
 
-    def planes_configure(self, device_voxel_grid=False):
-        """Where planes_ahc_post_batch runs the per-plane voxel grids: host threads (default) or the device."""
-        self._chk(self.L.drfe_planes_configure(self.h, 1 if device_voxel_grid else 0), "drfe_planes_configure")
+    def planes_configure(self, device_voxel_grid=1):
+        """Where planes_ahc_post_batch runs the per-plane voxel grids: 1 (default) the device behind the device extractor, 2 the
+        device in the host-extractor mode too, 0 the pool's host threads."""
+        self._chk(self.L.drfe_planes_configure(self.h, int(device_voxel_grid)), "drfe_planes_configure")
 
     def planes_configure_extractor(self, on_device=True):
         """Where planes_ahc_post_batch runs PEAC's extractor: the device (one wavefront per frame, default) or the host pool."""

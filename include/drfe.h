@@ -663,9 +663,12 @@ int drfe_planes_ahc_postprocess(drfe_ctx* ctx, const uint16_t* depth, int w, int
 int drfe_planes_ahc_post_batch(drfe_ctx* ctx, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
                                const float* K4, float depth_factor, float max_point_dist, double dist_threshold, drfe_plane* planes,
                                int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num, int n_threads);
-/* Where drfe_planes_ahc_post_batch runs pcl::VoxelGrid (leaf 0.05) of a frame's planes: 0 (default) on the pool's host threads,
- * 1 on the device (voxel_kernels.hip: leaf indices, std::sort's permutation by the device introsort, centroid sums in that
- * order - one workgroup per plane).  Results are identical (tests/test_gpu_post.py). */
+/* Where drfe_planes_ahc_post_batch runs pcl::VoxelGrid (leaf 0.05) of a frame's planes (voxel_kernels.hip: leaf indices,
+ * std::sort's permutation by the device introsort, centroid sums in that order - one workgroup per plane).  1 (default): on the
+ * device behind the device extractor, which also gathers each plane's cloud (one launch for all planes of the batch; the pool's
+ * threads fetch centroids and run gates + refit); the host-extractor mode keeps the host grid.  2: on the device in the
+ * host-extractor mode too (one launch per frame from each pool thread).  0: always on the pool's host threads.  Results are
+ * identical (tests/test_gpu_post.py). */
 int drfe_planes_configure(drfe_ctx* ctx, int device_voxel_grid);
 /* Where drfe_planes_ahc_post_batch runs PEAC's extractor after the init-block fits (graph, agglomerative clustering, block
  * membership, flood fill, re-merge, labels and member lists): 1 (default) on the device, one wavefront per frame executing the

@@ -195,17 +195,31 @@ def test_ahc_post_batch_equals_single_frame_calls(oracle_mod, camname, kind, see
     inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
     c = lib.Context()
     try:
-        # the extractor on the host pool (the checker) and on the device (the default): identical planes, labels, post results
+        # extractor on the host pool or on the device (default), voxel grids on the host or on the device (default: behind the
+        # device extractor): identical planes, labels, post results in every combination
         c.planes_configure_extractor(on_device=False)
+        c.planes_configure(device_voxel_grid=0)
         planes_h, n_h, post_h, na_h, pn_h, seg_h = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        c.planes_configure(device_voxel_grid=2)
+        planes_d, n_d, post_d, na_d, pn_d, seg_d = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        assert planes_d.tobytes() == planes_h.tobytes() and post_d.tobytes() == post_h.tobytes() and np.array_equal(na_d, na_h) and np.array_equal(pn_d, pn_h)
         c.planes_configure_extractor(on_device=True)
+        c.planes_configure(device_voxel_grid=0)
+        planes_e, n_e, post_e, na_e, pn_e, seg_e = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+        assert np.array_equal(n_e, n_h) and planes_e.tobytes() == planes_h.tobytes() and np.array_equal(seg_e, seg_h)
+        assert post_e.tobytes() == post_h.tobytes() and np.array_equal(na_e, na_h) and np.array_equal(pn_e, pn_h)
+        c.planes_configure(device_voxel_grid=1)
         planes, n, post, na, pn, seg = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
         assert np.array_equal(n, n_h) and planes.tobytes() == planes_h.tobytes() and np.array_equal(seg, seg_h)
         assert post.tobytes() == post_h.tobytes() and np.array_equal(na, na_h) and np.array_equal(pn, pn_h)
-        c.planes_configure(device_voxel_grid=True)
-        planes_d, n_d, post_d, na_d, pn_d, seg_d = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
-        c.planes_configure(device_voxel_grid=False)
-        assert planes_d.tobytes() == planes.tobytes() and post_d.tobytes() == post.tobytes() and np.array_equal(na_d, na) and np.array_equal(pn_d, pn)
+        # without the label image (the bench's call), and with points beyond max_point_dist left out of the clouds
+        r2 = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=2)
+        assert r2[2].tobytes() == post.tobytes()
+        near = c.planes_ahc_post_batch(depth, K4, inv, 2.5, 0.10, n_threads=2)
+        c.planes_configure(device_voxel_grid=0)
+        near_h = c.planes_ahc_post_batch(depth, K4, inv, 2.5, 0.10, n_threads=2)
+        c.planes_configure(device_voxel_grid=1)
+        assert near[2].tobytes() == near_h[2].tobytes() and np.array_equal(near[3], near_h[3]) and near[2].tobytes() != post.tobytes()
         for f in range(len(frames)):
             ga = c.planes_ahc(depth[f], K4, inv)
             g = c.planes_ahc_postprocess(depth[f], K4, inv, ga, 9.0, 0.10)
