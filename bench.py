@@ -322,7 +322,7 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
     return B * steps / el, el / steps * 1e3, threads
 
 
-def full_frontend(cam_name, n_frames: int = 512, reps: int = 2, inflight: int = 2):
+def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 3):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
     the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame);
@@ -353,9 +353,10 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 2, inflight: int = 
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     inflight = max(1, int(os.environ.get("DRFE_FF_INFLIGHT", inflight)))
     # host threads per step in flight: a step's pools sleep while its wavefronts are on the device, so the steps together run
-    # ~1.75 threads per CPU; host work per frame: lines ~3 ms (NFA rounds + key lines), planes ~3.5 ms (voxel grids + refit)
-    nthr = max(2, (ncpu * 7) // (4 * inflight))
-    split = {"lines": max(1, (nthr * 2) // 5)}
+    # ~1.9 threads per CPU; host work per frame: lines ~2.4 ms (NFA rounds + key lines), planes ~0.5 ms (gates + RANSAC refit
+    # on the voxel clouds the device left), CAPE ~1 ms
+    nthr = max(2, (ncpu * 19 + 5 * inflight) // (10 * inflight))
+    split = {"lines": max(1, (nthr * 7) // 10)}
     split["planes"] = max(1, nthr - split["lines"])
     if os.environ.get("DRFE_FF_SPLIT"):              # experiments: "lines,planes" per step in flight
         split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
@@ -386,7 +387,10 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 2, inflight: int = 
         with torch.cuda.stream(st):
             L["fe"].process(gray_t, depth_t, Tcw, Twc, th=15.0, check_ori=True, stream=st.cuda_stream)
             L["fe"].ctx.surface_normals_batch_ptr(depth_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, K4, inv, 9.0, n_frames, st.cuda_stream)
-        st.synchronize()
+        ev = torch.cuda.Event()
+        ev.record(st)
+        while not ev.query():                        # sleep, not spin: the step's pools need the CPUs
+            time.sleep(0.0005)
         wall["orb_match_normals_device"] = (time.perf_counter() - t) * 1e3
         nl, (npl, nacc), ncp = len(fl.result()), fp.result(), fc.result()
         assert nl == n_frames and npl == n_frames and ncp > 0
@@ -403,12 +407,22 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 2, inflight: int = 
                 nacc[k] = step(lanes[k], pool)
 
         th = [threading.Thread(target=run, args=(k,)) for k in range(inflight)]
+        import ctypes
+        pool_ns = (ctypes.c_longlong * 3)()
+        dbg = getattr(lanes[0]["planes"].L, "drfe_debug_pool_cpu_ns", None)     # measurement hook: CPU time of the pools' threads
+        if dbg is not None:
+            dbg.restype = None
+            dbg(pool_ns)                                                       # clear
+        cpu0 = time.process_time()
         t0 = time.perf_counter()
         for t in th:
             t.start()
         for t in th:
             t.join()
         el = time.perf_counter() - t0
+        cpu = time.process_time() - cpu0
+        if dbg is not None:
+            dbg(pool_ns)
     for L in lanes:
         L["planes"].close(); L["cape"].close(); L["fe"].ctx.close()
     total = inflight * reps * n_frames
@@ -416,14 +430,18 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 2, inflight: int = 
                         "normals batched on the device; LSD+LBD lines, AHC planes + post-processing, CAPE planes for every frame",
             "value": total / el, "unit": "frames/s", "frames_per_step": n_frames, "steps_in_flight": inflight, "steps_timed": inflight * reps,
             "ms_per_step": el * 1e3 / (inflight * reps),
+            "host_cpu_ms_per_frame": cpu * 1e3 / total, "host_cpu_utilisation": cpu / (el * ncpu),
+            "host_cpu_ms_per_frame_by_pool": {"lines": pool_ns[0] / 1e6 / total, "ahc_planes": pool_ns[1] / 1e6 / total, "cape": pool_ns[2] / 1e6 / total,
+                                              "other (python, HIP runtime threads)": (cpu * 1e3 - sum(pool_ns) / 1e6) / total},
             "host_threads_per_step_in_flight": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": n_cape}, "host_cpus_available": ncpu,
             "stage_wall_ms_last_step": {k: round(v, 2) for k, v in lanes[0]["wall"].items()},
             "planes_accepted_per_step": int(nacc[0]),
             "lines_path": "pixel ordering, region growing, region2rect, refine on the device (k_lsd_order, k_lsd_grow: one wavefront per frame); NFA + key lines on host threads",
-            "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels on the device (k_ahc_blocks, k_ahc_frame: one wavefront per frame); "
-                           "voxel grids + gates + RANSAC refit on host threads",
-            "note": "the device paths are latency chains (0.12 s / 0.23 s per frame on one wavefront): their rate is frames in flight over that latency, "
-                    "the host stages that remain cost ~3 ms (lines: NFA rounds) + ~3.5 ms (planes: voxel grids) + ~1 ms (CAPE) of one CPU per frame"}
+            "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels, plane clouds (k_ahc_blocks, k_ahc_cluster + k_ahc_refine: one wavefront per frame) and "
+                           "pcl::VoxelGrid of every plane (k_voxel_grid) on the device; gates + RANSAC refit on host threads",
+            "note": "the device paths are latency chains (~0.12 s of region growing, ~0.085 s of plane extraction per frame on one wavefront): their rate is frames in "
+                    "flight over that latency, so steps run side by side; the host stages that remain cost ~2.4 ms (lines: NFA rounds, key lines) + ~0.5 ms "
+                    "(planes: gates + refit) + ~1 ms (CAPE) of one CPU per frame"}
 
 
 def launch(args) -> int:

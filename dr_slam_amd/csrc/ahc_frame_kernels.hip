@@ -25,6 +25,11 @@
 #define AHCD_HEAP 3200            /* priority-queue capacity (<= init blocks of a 640 x 480 frame) */
 #define AHCD_LIST 768             /* a neighbour list staged in LDS */
 #define AHCD_MAXEX 128            /* extracted planes before the re-merge */
+/* the words k_ahc_cluster leaves for k_ahc_refine (AhcDevFrame::handoff, AHC_HANDOFF_INTS of planes_internal.h): [0] extracted
+ * nodes, [1] flood-fill seeds, [2] nodes, [3] neighbour pool fill, then the node ids, their kept-block flags, phase timers */
+#define AHCD_HO_EX 4
+#define AHCD_HO_VALID (4 + AHCD_MAXEX)
+#define AHCD_HO_TP (4 + 2 * AHCD_MAXEX)
 #define GLOBAL_AS __attribute__((address_space(1)))
 
 namespace {
@@ -298,17 +303,14 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
 
 } // namespace
 
-extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
 {
     __shared__ double heapKey[AHCD_HEAP];
     __shared__ uint16_t heapId[AHCD_HEAP];
     __shared__ int lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
     __shared__ double win[18];
-    __shared__ int ex[AHCD_MAXEX], ex2[AHCD_MAXEX], plidmap[AHCD_MAXEX];
+    __shared__ int ex[AHCD_MAXEX];
     __shared__ uint8_t isValid[AHCD_MAXEX];
-    __shared__ double plN[AHCD_MAXEX][3], plC[AHCD_MAXEX][3], plMse[AHCD_MAXEX];
-    __shared__ int counts[AHCD_MAXEX + 1], kcounts[AHCD_MAXEX + 1];
-    __shared__ int8_t blkLds[AHCD_HEAP];                      /* flood fill: 1 = the block is kept whole (its pixels are final) */
     const AhcDevFrame F = frames[blockIdx.x];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -418,9 +420,6 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* 
     for (int k = lane; k < NB; k += 64) c.ridToPlid[k] = -1;
     for (int k = lane; k < npx; k += 64) { c.mem[k] = -1; c.dist[k] = 3.402823466e+38f; }
     for (int k = lane; k < nEx; k += 64) {
-        const int nd = ex[k];
-        for (int q = 0; q < 3; q++) { plC[k][q] = c.fit[8 * (size_t)nd + q]; plN[k][q] = c.fit[8 * (size_t)nd + 3 + q]; }
-        plMse[k] = c.fit[8 * (size_t)nd + 6];
         isValid[k] = 0;
     }
     fence();
@@ -488,6 +487,58 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* 
     c.poolUsed += nEx * nEx;
     fence();
 
+    /* ---- hand over to k_ahc_refine: the extracted nodes, which of them kept blocks, the seeds' count, the graph's fill ---- */
+    GLOBAL_AS int* ho = (GLOBAL_AS int*)F.handoff;
+    for (int k = lane; k < nEx; k += 64) { ho[AHCD_HO_EX + k] = ex[k]; ho[AHCD_HO_VALID + k] = isValid[k]; }
+    if (lane == 0) { ho[0] = nEx; ho[1] = nRf; ho[2] = c.nNodes; ho[3] = c.poolUsed; out[0] = 0; out[1] = -1; }
+#ifdef AHC_PROFILE
+    TP();
+    if (lane == 0) for (int k = 0; k + 1 < tpi; k++) ho[AHCD_HO_TP + k] = (int)(tp[k + 1] - tp[k]);
+#endif
+}
+
+/* the second half of a frame: flood fill from the seeds, the re-merge of the grown planes, labels, member lists, plane clouds.
+ * Its own kernel because its LDS need is half of the clustering's (no 3200-entry queue): the CU holds five of these wavefronts,
+ * or three of k_ahc_cluster, where the single kernel's 57 KB allowed two - and whatever LDS these long-running wavefronts hold
+ * is what the line path's growth (27 KB per frame) cannot use. */
+extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    __shared__ double heapKey[AHCD_MAXEX];                    /* the re-merge's queue: at most the extracted planes */
+    __shared__ uint16_t heapId[AHCD_MAXEX];
+    __shared__ int lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
+    __shared__ double win[18];
+    __shared__ int ex[AHCD_MAXEX], ex2[AHCD_MAXEX], plidmap[AHCD_MAXEX];
+    __shared__ uint8_t isValid[AHCD_MAXEX];
+    __shared__ double plN[AHCD_MAXEX][3], plC[AHCD_MAXEX][3], plMse[AHCD_MAXEX];
+    __shared__ int counts[AHCD_MAXEX + 1], kcounts[AHCD_MAXEX + 1];
+    __shared__ int8_t blkLds[AHCD_HEAP];                      /* flood fill: 1 = the block is kept whole (its pixels are final) */
+    const AhcDevFrame F = frames[blockIdx.x];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    Ctx c;
+    c.depth = (const GLOBAL_AS uint16_t*)F.depth; c.rowStride = (int)F.rowStride;
+    c.S = (GLOBAL_AS double*)F.nodeS; c.fit = (GLOBAL_AS double*)F.nodeFit; c.N = (GLOBAL_AS int*)F.nodeN; c.rid = (GLOBAL_AS int*)F.nodeRid;
+    c.nouse = (GLOBAL_AS uint8_t*)F.nodeNouse; c.nbOff = (GLOBAL_AS int*)F.nbOff; c.nbLen = (GLOBAL_AS int*)F.nbLen; c.pool = (GLOBAL_AS int*)F.nbPool;
+    c.dsParent = (GLOBAL_AS int*)F.dsParent; c.dsSize = (GLOBAL_AS int*)F.dsSize; c.G = (GLOBAL_AS int*)F.G; c.blkMap = (GLOBAL_AS int*)F.blkMap;
+    c.ridToPlid = (GLOBAL_AS int*)F.ridToPlid; c.mem = (GLOBAL_AS int16_t*)F.membership; c.dist = (GLOBAL_AS float*)F.distMap; c.rf = (GLOBAL_AS uint32_t*)F.rf;
+    c.heapKey = heapKey; c.heapId = heapId; c.lA = lA; c.lB = lB; c.lU = lU; c.win = win;
+    c.heapSize = 0; c.status = 0; c.lane = lane; c.P = P;
+    GLOBAL_AS int* out = (GLOBAL_AS int*)F.out;
+    const GLOBAL_AS int* ho = (const GLOBAL_AS int*)F.handoff;
+    const int w = P.w, h = P.h, Nw = P.Nw, Nh = P.Nh, NB = P.NB, npx = w * h;
+    if (out[1] != -1) return;                                 /* k_ahc_cluster gave the frame back to the host */
+    const int nEx = ho[0], nRf = ho[1];
+    c.nNodes = ho[2]; c.poolUsed = ho[3];
+    for (int k = lane; k < nEx; k += 64) {
+        const int nd = ho[AHCD_HO_EX + k];
+        ex[k] = nd; isValid[k] = (uint8_t)ho[AHCD_HO_VALID + k];
+        for (int q = 0; q < 3; q++) { plC[k][q] = c.fit[8 * (size_t)nd + q]; plN[k][q] = c.fit[8 * (size_t)nd + 3 + q]; }
+        plMse[k] = c.fit[8 * (size_t)nd + 6];
+    }
+    fence();
+#ifdef AHC_PROFILE
+    unsigned long long tp[8]; int tpi = 0;
+#endif
     TP();
     int rfTotal = 0;
     /* ---- floodFill: FIFO over (pixel, plane).  Sixteen queue entries per step, their four neighbours each in the 64 lanes.
@@ -719,13 +770,18 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_frame(const AhcDevFrame* 
     if (lane == 0) { out[0] = nFinal; out[1] = 0; out[2] = rfTotal; out[3] = c.nNodes; }
 #ifdef AHC_PROFILE
     /* phase times (100 MHz ticks) into the head of the flood-fill queue, which nobody reads any more */
-    if (lane == 0) for (int k = 0; k + 1 < tpi; k++) c.rf[k] = (uint32_t)(tp[k + 1] - tp[k]);
+    if (lane == 0) {
+        for (int k = 0; k < 3; k++) c.rf[k] = (uint32_t)ho[AHCD_HO_TP + k];
+        for (int k = 0; k + 1 < tpi; k++) c.rf[3 + k] = (uint32_t)(tp[k + 1] - tp[k]);
+    }
 #endif
 }
 
 hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_ahc_frame, dim3(nframes), dim3(64), 0, s, d_frames, P);
+    static_assert(AHC_HANDOFF_INTS >= AHCD_HO_TP + 8, "handoff words");
+    hipLaunchKernelGGL(k_ahc_cluster, dim3(nframes), dim3(64), 0, s, d_frames, P);
+    hipLaunchKernelGGL(k_ahc_refine, dim3(nframes), dim3(64), 0, s, d_frames, P);
     return hipGetLastError();
 }

@@ -2,6 +2,7 @@
  * staging.  No compute happens on the host: every entry point either launches the HIP kernels or
  * copies their results.  There is no CPU fallback — a missing GPU / HIP failure is DRFE_ERR_HIP. */
 #include "drfe_internal.h"
+#include <atomic>
 #include "post_internal.h"
 #include "match_internal.h"
 #include "planes_internal.h"
@@ -95,6 +96,10 @@ int drfe_default_host_threads()
     if (n <= 0) n = (int)std::thread::hardware_concurrency();
     return std::max(1, n);
 }
+
+static std::atomic<long long> g_poolCpuNs[3];
+void drfe_pool_cpu_add(int pool, long long ns) { if (pool >= 0 && pool < 3) g_poolCpuNs[pool] += ns; }
+extern "C" void drfe_debug_pool_cpu_ns(long long* out3) { for (int k = 0; k < 3; k++) out3[k] = g_poolCpuNs[k].exchange(0); }
 
 extern "C" {
 

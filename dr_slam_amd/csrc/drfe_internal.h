@@ -199,6 +199,15 @@ static inline hipError_t drfe_pool_sync(hipStream_t s, hipEvent_t ev)
     }
 }
 
+/* CPU time of the batch entries' pool threads, summed per pool (0 lines, 1 AHC planes, 2 CAPE): a worker adds its thread's CPU time when
+ * it ends (drfe_debug_pool_cpu_ns reads and clears).  Measurement only. */
+void drfe_pool_cpu_add(int pool, long long ns);
+struct DrfePoolCpuScope {
+    int pool; struct timespec t0;
+    explicit DrfePoolCpuScope(int p) : pool(p) { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0); }
+    ~DrfePoolCpuScope() { struct timespec t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1); drfe_pool_cpu_add(pool, (t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec)); }
+};
+
 /* capi.cpp: host threads a batch entry point may start by default - the affinity mask clipped by the cgroup CPU quota
  * (std::thread::hardware_concurrency() reports the machine, which oversubscribes a quota-limited container) */
 int drfe_default_host_threads();

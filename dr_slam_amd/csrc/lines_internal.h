@@ -16,6 +16,7 @@ struct LinesScratch {
     unsigned long long* d_meta;     /* per slot two words: [0] bits of the largest gradient magnitude, [1] smallest gradient bin of a pixel with an angle */
     int16_t* d_gx; int16_t* d_gy;
     struct RectCand* d_cands; int2* d_counts; size_t candCap;   /* grow-only scratch of the NFA rounds (one lane's) */
+    struct RectCand* h_cands; int2* h_counts;                   /* their pinned mirrors: no staging / pinning inside the copy calls */
     struct LbdLine* d_lbdLines; uint8_t* d_lbdOut; size_t lbdCap;
     /* device region growing (batch entry): per slot the ordering keys / sorted ordering, member list, shrink scratch,
      * accepted rectangles, (count, status); the launch's frame table; pinned host mirrors */

@@ -556,7 +556,7 @@ static void scratch_free(LinesScratch*& s)
     void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
                     s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus};
+    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     delete s;
     s = nullptr;
@@ -652,6 +652,10 @@ struct LsdParams {
 /* the device arrays of one frame that the validation / descriptor stages read */
 struct FrameView { int w, h, sw, sh; const double* d_angles; const int16_t* d_gx; const int16_t* d_gy; };
 
+/* DRFE_TRACE_LINES accounting of the counting rounds: wall and CPU time of this thread inside them */
+static thread_local double g_countsWallUs = 0, g_countsCpuUs = 0;
+static inline double thread_cpu_us() { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
+
 /* rect_nfa's pixel counts on the device (k_rect_counts) through lane c's stream and grow-only scratch */
 static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, int& countRc, const SegmentFinder* check)
 {
@@ -659,21 +663,34 @@ static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, i
         LinesScratch* s = c->ls;
         hipStream_t st = c->stream;
         const size_t nc = cands.size();
+        const auto tw0 = std::chrono::steady_clock::now();
+        const double tc0 = thread_cpu_us();
+        struct Acc { std::chrono::steady_clock::time_point w; double c; ~Acc() { g_countsWallUs += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w).count(); g_countsCpuUs += thread_cpu_us() - c; } } acc{tw0, tc0};
         out.resize(nc);
         if (nc > s->candCap) {
             if (s->d_cands) (void)hipFree(s->d_cands);
             if (s->d_counts) (void)hipFree(s->d_counts);
-            s->d_cands = nullptr; s->d_counts = nullptr;
+            if (s->h_cands) (void)hipHostFree(s->h_cands);
+            if (s->h_counts) (void)hipHostFree(s->h_counts);
+            s->d_cands = nullptr; s->d_counts = nullptr; s->h_cands = nullptr; s->h_counts = nullptr;
             s->candCap = std::max<size_t>(nc * 2, 4096);
             if (hipMalloc((void**)&s->d_cands, s->candCap * sizeof(RectCand)) != hipSuccess ||
-                hipMalloc((void**)&s->d_counts, s->candCap * sizeof(int2)) != hipSuccess) {
+                hipMalloc((void**)&s->d_counts, s->candCap * sizeof(int2)) != hipSuccess ||
+                hipHostMalloc((void**)&s->h_cands, s->candCap * sizeof(RectCand), hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void**)&s->h_counts, s->candCap * sizeof(int2), hipHostMallocDefault) != hipSuccess) {
                 s->candCap = 0; c->err = "lsd_extract: hipMalloc of the NFA scratch failed"; countRc = DRFE_ERR_HIP; return false;
             }
         }
-        hipError_t e = hipMemcpyAsync(s->d_cands, cands.data(), nc * sizeof(RectCand), hipMemcpyHostToDevice, st);
+        std::memcpy(s->h_cands, cands.data(), nc * sizeof(RectCand));
+        hipError_t e = hipMemcpyAsync(s->d_cands, s->h_cands, nc * sizeof(RectCand), hipMemcpyHostToDevice, st);
+        /* the download is issued only when the kernel has finished: queued behind it, it would sit in a DMA ring until then and
+         * hold up the other lanes' copies behind it (a kernel writing straight into pinned host memory is worse: measured 2.3x
+         * slower for the whole front-end - every such kernel ends in a system-scope write-back) */
         if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, v.d_angles, v.sw, v.sh, s->d_counts, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(out.data(), s->d_counts, nc * sizeof(int2), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = lane_sync(c);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->h_counts, s->d_counts, nc * sizeof(int2), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = lane_sync(c);
+        if (e == hipSuccess) std::memcpy(out.data(), s->h_counts, nc * sizeof(int2));
         if (e != hipSuccess) { c->err = std::string("lsd_extract: rectangle counting: ") + hipGetErrorString(e); countRc = DRFE_ERR_HIP; return false; }
         if (check)
             for (size_t k = 0; k < nc; k++) {
@@ -859,7 +876,7 @@ struct BatchJob {
     bool abort = false;
     double prec, p; int minReg;
     bool deviceOrder = true;            /* the ordering by k_lsd_order (default) or by the pool (DRFE_LSD_HOST_ORDER=1: A/B, tests) */
-    std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
+    std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0}, usCountsWall{0}, usCountsCpu{0}, nCountRounds{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
     std::chrono::steady_clock::time_point t0, tLastSort, tFirstFinish; std::atomic<int> nFirst{0};
     BatchJob(int nChunks_) : sortedInChunk(nChunks_), chunkState(nChunks_, 0) {}
 };
@@ -994,8 +1011,11 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
                 if (rc == DRFE_OK) rc = host_grow_and_finish(lw, A, f, J.maxLines, lo, dout, lf, J.cap, &J.nLines[f], &nd, std::chrono::steady_clock::now());
             } else {
                 std::vector<RectD> pending(nRects);
-                if (nRects > 0 && hipMemcpyAsync(pending.data(), A->d_rects + (size_t)A->rectCap * f, sizeof(LsdRect) * nRects, hipMemcpyDeviceToHost, lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
+                /* through the arena's pinned mirror: a download into pageable memory stages inside the copy call */
+                LsdRect* hr = A->h_rects + (size_t)A->rectCap * f;
+                if (nRects > 0 && hipMemcpyAsync(hr, A->d_rects + (size_t)A->rectCap * f, sizeof(LsdRect) * nRects, hipMemcpyDeviceToHost, lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
                 if (rc == DRFE_OK && nRects > 0 && lane_sync(lw) != hipSuccess) rc = DRFE_ERR_HIP;
+                if (rc == DRFE_OK && nRects > 0) std::memcpy(pending.data(), hr, sizeof(LsdRect) * nRects);
                 if (rc != DRFE_OK) lw->err = "lsd_extract_batch: rectangle download";
                 if (rc == DRFE_OK) {
                     const FrameView v = {A->w, A->h, A->sw, A->sh, A->d_angles + ns * f, A->d_gx + n * f, A->d_gy + n * f};
@@ -1003,8 +1023,10 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
                     std::vector<float> segs;
                     const auto tn = std::chrono::steady_clock::now();
                     J.usRectDl += std::chrono::duration_cast<std::chrono::microseconds>(tn - tTask).count();
+                    g_countsWallUs = g_countsCpuUs = 0;
                     const bool okE = val.emit(pending, segs, device_counts(lw, v, countRc, nullptr));
                     const auto tk = std::chrono::steady_clock::now();
+                    J.usCountsWall += (long)g_countsWallUs; J.usCountsCpu += (long)g_countsCpuUs;
                     J.usNfa += std::chrono::duration_cast<std::chrono::microseconds>(tk - tn).count();
                     if (!okE) rc = countRc;
                     else rc = keylines_and_descriptors(lw, v, segs, J.maxLines, lo, dout, lf, J.cap, &J.nLines[f], &nd);
@@ -1097,14 +1119,14 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         if (!J.deviceOrder) for (int f = 0; f < nframes; f++) J.sortQ.push_back(f);
         std::vector<std::thread> th;
         th.reserve(T);
-        for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { batch_worker(J, &(*pool)[k]); });
+        for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { DrfePoolCpuScope cpu(0); batch_worker(J, &(*pool)[k]); });
         for (std::thread& t : th) t.join();
     }
     if (std::getenv("DRFE_TRACE_LINES"))
-        std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f, key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device\n",
+        std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f (of which in the counting round trips: %.2f wall, %.2f CPU), key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device\n",
                      nframes, nChunks, chunk, T, std::chrono::duration<double, std::milli>(tLaunched - tBegin).count(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBegin).count(), J.usSort / 1e3 / nframes,
-                     J.usRectDl / 1e3 / nframes, J.usNfa / 1e3 / nframes, J.usKeyl / 1e3 / nframes, J.usFinish / 1e3 / nframes, J.usWait / 1e3 / T);
+                     J.usRectDl / 1e3 / nframes, J.usNfa / 1e3 / nframes, J.usCountsWall / 1e3 / nframes, J.usCountsCpu / 1e3 / nframes, J.usKeyl / 1e3 / nframes, J.usFinish / 1e3 / nframes, J.usWait / 1e3 / T);
     if (std::getenv("DRFE_LSD_PROFILE")) {       /* LSD_PROFILE builds of k_lsd_grow: phase times of frame 0 (100 MHz ticks -> ms) and counts */
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
         std::fprintf(stderr, "k_lsd_grow frame 0: total %.2f ms: bitmap %.2f, scan %.2f (%llu chunks), window loads %.2f (%llu groups), window growth %.2f (%llu regions, %llu member visits), "

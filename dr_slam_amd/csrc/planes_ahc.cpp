@@ -800,7 +800,7 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
         const size_t oS = take((size_t)P.maxNodes * 72), oFit = take((size_t)P.maxNodes * 64), oN = take((size_t)P.maxNodes * 4), oRid = take((size_t)P.maxNodes * 4),
                      oNouse = take((size_t)P.maxNodes), oNbOff = take((size_t)P.maxNodes * 4), oNbLen = take((size_t)P.maxNodes * 4), oPool = take((size_t)P.poolCap * 4),
                      oDsP = take((size_t)NB * 4), oDsS = take((size_t)NB * 4), oG = take((size_t)NB * 4), oBlk = take((size_t)NB * 4), oR2P = take((size_t)NB * 4),
-                     oMem = take(npx * 2), oDist = take(npx * 4), oRf = take((size_t)P.rfCap * 4);
+                     oMem = take(npx * 2), oDist = take(npx * 4), oRf = take((size_t)P.rfCap * 4), oHo = take(AHC_HANDOFF_INTS * 4);
         a->offPlanes = take((size_t)P.planeCap * sizeof(drfe_plane)); a->offSeg = take(npx); a->offMemberOff = take(((size_t)P.planeCap + 1) * 4);
         a->offMemberIdx = take(npx * 4); a->offOut = take(16);
         a->slotBytes = off;
@@ -834,7 +834,7 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
             g.nodeS = (double*)(s + oS); g.nodeFit = (double*)(s + oFit); g.nodeN = (int*)(s + oN); g.nodeRid = (int*)(s + oRid);
             g.nodeNouse = s + oNouse; g.nbOff = (int*)(s + oNbOff); g.nbLen = (int*)(s + oNbLen); g.nbPool = (int*)(s + oPool);
             g.dsParent = (int*)(s + oDsP); g.dsSize = (int*)(s + oDsS); g.G = (int*)(s + oG); g.blkMap = (int*)(s + oBlk); g.ridToPlid = (int*)(s + oR2P);
-            g.membership = (int16_t*)(s + oMem); g.distMap = (float*)(s + oDist); g.rf = (uint32_t*)(s + oRf);
+            g.membership = (int16_t*)(s + oMem); g.distMap = (float*)(s + oDist); g.rf = (uint32_t*)(s + oRf); g.handoff = (int*)(s + oHo);
             g.planes = (drfe_plane*)(s + a->offPlanes); g.seg = s + a->offSeg; g.memberOff = (int*)(s + a->offMemberOff);
             g.memberIdx = (int*)(s + a->offMemberIdx); g.out = (int*)(s + a->offOut);
             g.ptsBase = (int)(npx * f); g.pts = a->d_vpts + 3 * npx * f; g.jobs = a->d_jobs + (size_t)P.planeCap * f;
@@ -1061,14 +1061,14 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
     const auto tLaunched = std::chrono::steady_clock::now();
     if (launchRc == DRFE_OK) {
         std::vector<std::thread> th;
-        for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { ahc_batch_worker(J, &(*pool)[k]); });
+        for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { DrfePoolCpuScope cpu(1); ahc_batch_worker(J, &(*pool)[k]); });
         for (std::thread& t : th) t.join();
     }
     if (traceStages) {
         float ms[4] = {0, 0, 0, 0};
         for (int k = 0; k < 4; k++) if (k < 3 || J.voxDevice) (void)hipEventElapsedTime(&ms[k], stageEv[k], stageEv[k + 1]);
         const double tl = std::chrono::duration<double, std::milli>(tLaunched - tCall).count(), ta = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tCall).count();
-        std::fprintf(stderr, "drfe_planes_ahc_post_batch stages (chunk 0): staging + enqueue %.1f ms of host time; depth upload %.1f ms, k_ahc_blocks %.1f, k_ahc_frame %.1f, k_voxel_grid %.1f; call %.1f ms\n",
+        std::fprintf(stderr, "drfe_planes_ahc_post_batch stages (chunk 0): staging + enqueue %.1f ms of host time; depth upload %.1f ms, k_ahc_blocks %.1f, k_ahc_cluster + k_ahc_refine %.1f, k_voxel_grid %.1f; call %.1f ms\n",
                      tl, ms[0], ms[1], ms[2], ms[3], ta);
         for (hipEvent_t& e : stageEv) (void)hipEventDestroy(e);
     }
@@ -1077,10 +1077,10 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         (void)hipStreamDestroy(J.chunkStream[ch]);
         (void)hipEventDestroy(J.chunkDone[ch]);
     }
-    if (std::getenv("DRFE_AHC_PROFILE")) {      /* AHC_PROFILE builds of k_ahc_frame: phase times of frame 0 */
+    if (std::getenv("DRFE_AHC_PROFILE")) {      /* AHC_PROFILE builds of k_ahc_cluster + k_ahc_refine: phase times of frame 0 */
         uint32_t t[8] = {0};
         (void)hipMemcpy(t, A->h_frames[0].rf, sizeof(t), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "k_ahc_frame frame 0: initGraph %.2f ms, ahCluster %.2f, membership + seeds %.2f, floodFill %.2f (%d queue entries), re-merge %.2f, labels + member lists %.2f; %d nodes\n",
+        std::fprintf(stderr, "k_ahc_cluster + k_ahc_refine, frame 0: initGraph %.2f ms, ahCluster %.2f, membership + seeds %.2f, floodFill %.2f (%d queue entries), re-merge %.2f, labels + member lists %.2f; %d nodes\n",
                      t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, A->h_out[2], t[4] / 1e5, t[5] / 1e5, A->h_out[3]);
     }
     if (std::getenv("DRFE_TRACE_PLANES"))

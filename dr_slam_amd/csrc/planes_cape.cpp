@@ -57,13 +57,13 @@ struct Grow {
     int W, H;
     const std::vector<char>* in;
     std::vector<char>* out;
-    const std::vector<CapeCellRec>* cells;
+    const CapeCellRec* cells;
     float minCos;
     void run(int x, int y, const double* n1, double d)
     {
         const int idx = x + W * y;
         if (!(*in)[idx] || (*out)[idx]) return;
-        const CapeCellRec& c = (*cells)[idx];
+        const CapeCellRec& c = cells[idx];
         const double v = n1[0] * c.mean[0] + n1[1] * c.mean[1] + n1[2] * c.mean[2] + d;
         if (n1[0] * c.normal[0] + n1[1] * c.normal[1] + n1[2] * c.normal[2] < minCos || v * v > c.tol) return;
         (*out)[idx] = 1;
@@ -85,7 +85,12 @@ struct CapeLane {
     int device = 0;
     hipStream_t stream = nullptr;
     void* cape = nullptr;
+    hipEvent_t pollEv = nullptr;      /* drfe_pool_sync: the batch's threads sleep between polls instead of spinning */
 };
+
+/* the single-frame entry spins (latency is the point there), a batch lane sleeps */
+static inline hipError_t cape_sync(drfe_ctx* c) { return hipStreamSynchronize(c->stream); }
+static inline hipError_t cape_sync(CapeLane* l) { return l->pollEv ? drfe_pool_sync(l->stream, l->pollEv) : hipStreamSynchronize(l->stream); }
 
 template <class Ctx>
 static int planes_cape_core(Ctx* c, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
@@ -106,26 +111,36 @@ static int planes_cape_core(Ctx* c, const float* depth_m, int w, int h, size_t s
     if (cs->depthCap < (size_t)npx) {
         if (cs->d_depth) (void)hipFree(cs->d_depth);
         if (cs->d_seg) (void)hipFree(cs->d_seg);
-        cs->d_depth = nullptr; cs->d_seg = nullptr; cs->depthCap = cs->segCap = 0;
+        if (cs->h_depth) (void)hipHostFree(cs->h_depth);
+        if (cs->h_seg) (void)hipHostFree(cs->h_seg);
+        cs->d_depth = nullptr; cs->d_seg = nullptr; cs->h_depth = nullptr; cs->h_seg = nullptr; cs->depthCap = cs->segCap = 0;
         HIPCHK(c, hipMalloc((void**)&cs->d_depth, (size_t)npx * sizeof(float)));
         HIPCHK(c, hipMalloc((void**)&cs->d_seg, (size_t)npx));
+        HIPCHK(c, hipHostMalloc((void**)&cs->h_depth, (size_t)npx * sizeof(float), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&cs->h_seg, (size_t)npx, hipHostMallocDefault));
         cs->depthCap = cs->segCap = (size_t)npx;
     }
     if (cs->cellCap < (size_t)ncell) {
         if (cs->d_cells) (void)hipFree(cs->d_cells);
-        cs->d_cells = nullptr; cs->cellCap = 0;
+        if (cs->h_cells) (void)hipHostFree(cs->h_cells);
+        cs->d_cells = nullptr; cs->h_cells = nullptr; cs->cellCap = 0;
         HIPCHK(c, hipMalloc((void**)&cs->d_cells, (size_t)ncell * sizeof(CapeCellRec)));
+        HIPCHK(c, hipHostMalloc((void**)&cs->h_cells, (size_t)ncell * sizeof(CapeCellRec), hipHostMallocDefault));
         cs->cellCap = (size_t)ncell;
     }
     float* d_depth = cs->d_depth;
     CapeCellRec* d_cells = cs->d_cells;
     const float sinCos = (float)std::sqrt(1 - (double)cos_angle_max * (double)cos_angle_max);
-    std::vector<CapeCellRec> cells(ncell);
-    hipError_t e = hipMemcpy2DAsync(d_depth, (size_t)w * 4, depth_m, stride * 4, (size_t)w * 4, (size_t)h,
-                                    hipMemcpyHostToDevice, c->stream);
+    /* through the pinned mirrors: a copy call on pageable memory stages or pins inside the call, on this thread */
+    for (int y = 0; y < h; y++) std::memcpy(cs->h_depth + (size_t)y * w, depth_m + (size_t)y * stride, (size_t)w * 4);
+    const CapeCellRec* cells = cs->h_cells;
+    hipError_t e = hipMemcpyAsync(d_depth, cs->h_depth, (size_t)npx * 4, hipMemcpyHostToDevice, c->stream);
+    /* downloads are issued only when their kernel has finished: queued behind it, a copy sits in a DMA ring until then and holds
+     * up the copies of every other stream behind it */
     if (e == hipSuccess) e = drfe_launch_cape_cells(d_depth, (size_t)w, w, h, K4, patch, sinCos, max_merge_dist, d_cells, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(cells.data(), d_cells, (size_t)ncell * sizeof(CapeCellRec), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = cape_sync(c);
+    if (e == hipSuccess) e = hipMemcpyAsync(cs->h_cells, d_cells, (size_t)ncell * sizeof(CapeCellRec), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = cape_sync(c);
     if (e != hipSuccess) { c->err = std::string("planes_cape: ") + hipGetErrorString(e); return DRFE_ERR_HIP; }
     for (int i = 0; i < ncell && cells16; i++) {
         const CapeCellRec& r = cells[i];
@@ -176,7 +191,7 @@ static int planes_cape_core(Ctx* c, const float* depth_m, int w, int h, size_t s
         std::memcpy(ps.normal, cells[seed].normal, 24);
         ps.d = cells[seed].d; ps.MSE = cells[seed].MSE; ps.score = cells[seed].score;
         std::fill(act.begin(), act.end(), 0);
-        Grow g{nh, nv, &unassigned, &act, &cells, cos_angle_max};
+        Grow g{nh, nv, &unassigned, &act, cells, cos_angle_max};
         const double sn[3] = {ps.normal[0], ps.normal[1], ps.normal[2]};
         g.run(seed % nh, seed / nh, sn, ps.d);
         int nact = 0;
@@ -293,8 +308,10 @@ static int planes_cape_core(Ctx* c, const float* depth_m, int w, int h, size_t s
     if (!boundary.empty()) HIPCHK(c, hipMemcpyAsync(cs->d_tab + offBnd, boundary.data(), boundary.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, drfe_launch_cape_refine(cs->d_depth, (size_t)w, w, h, K4, patch, reinterpret_cast<const CapeRefinePlane*>(cs->d_tab), nFinal,
                                       cs->d_tab + offGrid, cs->d_tab + offBnd, cs->d_seg, c->stream));
-    HIPCHK(c, hipMemcpyAsync(seg, cs->d_seg, (size_t)npx, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, cape_sync(c));
+    HIPCHK(c, hipMemcpyAsync(cs->h_seg, cs->d_seg, (size_t)npx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, cape_sync(c));
+    std::memcpy(seg, cs->h_seg, (size_t)npx);
     return DRFE_OK;
 }
 
@@ -304,6 +321,8 @@ static void cape_scratch_free(void*& p)
     if (!cs) return;
     void* ptrs[] = {cs->d_depth, cs->d_cells, cs->d_seg, cs->d_tab};
     for (void* q : ptrs) if (q) (void)hipFree(q);
+    void* hptrs[] = {cs->h_depth, cs->h_cells, cs->h_seg};
+    for (void* q : hptrs) if (q) (void)hipHostFree(q);
     delete cs;
     p = nullptr;
 }
@@ -312,7 +331,7 @@ void drfe_cape_lanes_free(drfe_ctx* c)
 {
     auto* pool = static_cast<std::vector<CapeLane>*>(c->capeLanes);
     if (!pool) return;
-    for (CapeLane& l : *pool) { cape_scratch_free(l.cape); if (l.stream) (void)hipStreamDestroy(l.stream); }
+    for (CapeLane& l : *pool) { cape_scratch_free(l.cape); if (l.stream) (void)hipStreamDestroy(l.stream); if (l.pollEv) (void)hipEventDestroy(l.pollEv); }
     delete pool;
     c->capeLanes = nullptr;
 }
@@ -347,6 +366,7 @@ int drfe_planes_cape_batch(drfe_ctx* c, const float* depth_m, size_t frame_strid
         CapeLane l;
         l.device = c->device;
         HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&l.pollEv, hipEventDisableTiming));
         pool->push_back(l);
     }
     std::vector<int> rcs(T, DRFE_OK);
@@ -355,6 +375,7 @@ int drfe_planes_cape_batch(drfe_ctx* c, const float* depth_m, size_t frame_strid
     const size_t px = (size_t)w * h;
     for (int k = 0; k < T; k++)
         th.emplace_back([&, k]() {
+            DrfePoolCpuScope cpu(2);
             CapeLane* l = &(*pool)[k];
             std::vector<uint8_t> segTmp(seg ? 0 : px);
             for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {

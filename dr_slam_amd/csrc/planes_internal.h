@@ -31,6 +31,7 @@ struct CapeScratch {
     CapeCellRec* d_cells; size_t cellCap;
     uint8_t* d_seg; size_t segCap;             /* w*h labels */
     uint8_t* d_tab; size_t tabCap;             /* CapeRefinePlane[n] | gridEroded[ncell] | boundary[n][ncell] */
+    float* h_depth; CapeCellRec* h_cells; uint8_t* h_seg;   /* pinned mirrors (sized with the device buffers): the copy calls neither stage nor pin */
 };
 
 /* one final plane of the boundary refinement (src/CAPE/CAPE.cpp:294-319): float copies of normal and d, 9 * MSE */
@@ -51,13 +52,15 @@ struct AhcDevParams {
     double cos60, cos30;                 /* similarityTh_merge / _refine, from the host's libm as the host path's constants */
     float maxPointDist;                  /* Frame::ComputePlanes' gather: points beyond it stay out of the plane's cloud */
 };
-/* one frame of a k_ahc_frame launch: inputs, per-frame scratch, outputs */
+#define AHC_HANDOFF_INTS 272
+/* one frame of a drfe_launch_ahc_frames launch (k_ahc_cluster, then k_ahc_refine): inputs, per-frame scratch, outputs */
 struct AhcDevFrame {
     const uint16_t* depth; size_t rowStride;                 /* device CV_16U image */
     const AhcBlockRec* blocks;                               /* k_ahc_blocks' records of this frame */
     double* nodeS; double* nodeFit; int* nodeN; int* nodeRid; uint8_t* nodeNouse; int* nbOff; int* nbLen; int* nbPool;
     int* dsParent; int* dsSize; int* G; int* blkMap; int* ridToPlid;
     int16_t* membership; float* distMap; uint32_t* rf;
+    int* handoff;                                            /* AHC_HANDOFF_INTS words from k_ahc_cluster to k_ahc_refine */
     drfe_plane* planes; uint8_t* seg; int* memberOff; int* memberIdx;      /* final planes, label image, member lists */
     float* pts; int2* jobs; int ptsBase;                     /* plane clouds for k_voxel_grid: pts = arena cloud + 3 * ptsBase, jobs[planeCap] (or null) */
     int* out;                                                /* out[0] = planes, out[1] = status (0 = done; else: redo on the host) */

@@ -466,7 +466,7 @@ int drfe_ahc_post_core(std::string* err, const uint16_t* depth, int w, int h, si
     return DRFE_OK;
 }
 
-/* the same loop when every plane's voxel cloud is already there (k_voxel_grid ran behind k_ahc_frame): gates + refit only */
+/* the same loop when every plane's voxel cloud is already there (k_voxel_grid ran behind k_ahc_refine): gates + refit only */
 int drfe_ahc_post_from_coarse(std::string* err, const drfe_plane* planes, int n_planes, const float* const* coarse_xyz, const int* coarse_n,
                               float max_point_dist, double dist_threshold, drfe_plane_post* post, float* voxel_xyz, int32_t* voxel_offsets,
                               int cap_voxels, int* n_accepted, int* plane_num)

@@ -1,5 +1,5 @@
 """Throughput of drfe_lsd_extract_batch with region growing on the device (k_lsd_grow) and on the host pool:
-python tools/lsd_batch_timing.py [frames] [threads].  DRFE_TRACE_LINES_BATCH=1 prints the batch's own phase times."""
+python tools/lsd_batch_timing.py [frames] [threads].  DRFE_TRACE_LINES=1 prints the batch's own phase times."""
 import sys, time, numpy as np
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from dr_slam_amd import lib, synth
