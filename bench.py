@@ -352,11 +352,11 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     inflight = max(1, int(os.environ.get("DRFE_FF_INFLIGHT", inflight)))
-    # host threads per step in flight: a step's pools sleep while its wavefronts are on the device, so the steps together run
-    # ~1.9 threads per CPU; host work per frame: lines ~2.4 ms (NFA rounds + key lines), planes ~0.5 ms (gates + RANSAC refit
-    # on the voxel clouds the device left), CAPE ~1 ms
-    nthr = max(2, (ncpu * 19 + 5 * inflight) // (10 * inflight))
-    split = {"lines": max(1, (nthr * 7) // 10)}
+    # host threads per step in flight: a step's pools sleep while its wavefronts are on the device and inside every round trip of
+    # the NFA rounds, so the steps together run ~2.6 threads per CPU; host work per frame: lines ~2.2 ms (NFA arithmetic, key lines),
+    # planes ~0.6 ms (gates + RANSAC refit on the voxel clouds the device left), CAPE ~0.2 ms
+    nthr = max(2, (ncpu * 26 + 5 * inflight) // (10 * inflight))
+    split = {"lines": max(1, (nthr * 5 + 3) // 7)}
     split["planes"] = max(1, nthr - split["lines"])
     if os.environ.get("DRFE_FF_SPLIT"):              # experiments: "lines,planes" per step in flight
         split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
@@ -440,8 +440,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
             "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels, plane clouds (k_ahc_blocks, k_ahc_cluster + k_ahc_refine: one wavefront per frame) and "
                            "pcl::VoxelGrid of every plane (k_voxel_grid) on the device; gates + RANSAC refit on host threads",
             "note": "the device paths are latency chains (~0.12 s of region growing, ~0.085 s of plane extraction per frame on one wavefront): their rate is frames in "
-                    "flight over that latency, so steps run side by side; the host stages that remain cost ~2.4 ms (lines: NFA rounds, key lines) + ~0.5 ms "
-                    "(planes: gates + refit) + ~1 ms (CAPE) of one CPU per frame"}
+                    "flight over that latency, so steps run side by side; the host stages that remain cost ~2.2 ms (lines: NFA arithmetic, key lines) + ~0.6 ms "
+                    "(planes: gates + refit) + ~0.2 ms (CAPE) of one CPU per frame (host_cpu_ms_per_frame_by_pool is the measurement)"}
 
 
 def launch(args) -> int:
