@@ -876,7 +876,7 @@ struct BatchJob {
     bool abort = false;
     double prec, p; int minReg;
     bool deviceOrder = true;            /* the ordering by k_lsd_order (default) or by the pool (DRFE_LSD_HOST_ORDER=1: A/B, tests) */
-    std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0}, usCountsWall{0}, usCountsCpu{0}, nCountRounds{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
+    std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0}, usCountsWall{0}, usCountsCpu{0}, nCountRounds{0}, handedBack{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
     std::chrono::steady_clock::time_point t0, tLastSort, tFirstFinish; std::atomic<int> nFirst{0};
     BatchJob(int nChunks_) : sortedInChunk(nChunks_), chunkState(nChunks_, 0) {}
 };
@@ -1005,6 +1005,7 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
             uint8_t* dout = J.ldesc ? J.ldesc + (size_t)f * J.cap * 32 : nullptr;
             double* lf = J.lineF ? J.lineF + (size_t)f * J.cap * 3 : nullptr;
             if (status != 0) {
+                J.handedBack++;
                 /* a rounding the device could not certify, or more regions than the rectangle list holds: this frame's
                  * sequential half again on the host, from the fields the device still has */
                 rc = ensure_lines(lw->err, lw->ls, J.w, J.h, 1, false, false);
@@ -1123,10 +1124,10 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         for (std::thread& t : th) t.join();
     }
     if (std::getenv("DRFE_TRACE_LINES"))
-        std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f (of which in the counting round trips: %.2f wall, %.2f CPU), key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device\n",
+        std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f (of which in the counting round trips: %.2f wall, %.2f CPU), key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device; %ld frames redone on the host\n",
                      nframes, nChunks, chunk, T, std::chrono::duration<double, std::milli>(tLaunched - tBegin).count(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBegin).count(), J.usSort / 1e3 / nframes,
-                     J.usRectDl / 1e3 / nframes, J.usNfa / 1e3 / nframes, J.usCountsWall / 1e3 / nframes, J.usCountsCpu / 1e3 / nframes, J.usKeyl / 1e3 / nframes, J.usFinish / 1e3 / nframes, J.usWait / 1e3 / T);
+                     J.usRectDl / 1e3 / nframes, J.usNfa / 1e3 / nframes, J.usCountsWall / 1e3 / nframes, J.usCountsCpu / 1e3 / nframes, J.usKeyl / 1e3 / nframes, J.usFinish / 1e3 / nframes, J.usWait / 1e3 / T, J.handedBack.load());
     if (std::getenv("DRFE_LSD_PROFILE")) {       /* LSD_PROFILE builds of k_lsd_grow: phase times of frame 0 (100 MHz ticks -> ms) and counts */
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
         std::fprintf(stderr, "k_lsd_grow frame 0: total %.2f ms: bitmap %.2f, scan %.2f (%llu chunks), window loads %.2f (%llu groups), window growth %.2f (%llu regions, %llu member visits), "
