@@ -432,6 +432,7 @@ struct OrbOneShot {
     int w = 0, h = 0;
     uint8_t* h_in = nullptr;      /* pinned, w * h */
     uint8_t* h_out = nullptr;     /* pinned: int status | int count | kps[maxKp] | desc[maxKp][32] */
+    uint8_t* d_out = nullptr;     /* the same layout on the device: the graph ends in one download */
     size_t inBytes = 0;
     bool disabled = false;
 };
@@ -449,6 +450,7 @@ void drfe_one_shot_free(drfe_ctx* c)
     one_shot_release(c->oneShot);
     if (c->oneShot->h_in) (void)hipHostFree(c->oneShot->h_in);
     if (c->oneShot->h_out) (void)hipHostFree(c->oneShot->h_out);
+    if (c->oneShot->d_out) (void)hipFree(c->oneShot->d_out);
     delete c->oneShot;
     c->oneShot = nullptr;
 }
@@ -478,14 +480,22 @@ static int one_shot_prepare(drfe_ctx* c, int w, int h)
         o->inBytes = (size_t)w * h;
     }
     if (!o->h_out) HIPCHK(c, hipHostMalloc((void**)&o->h_out, outBytes, hipHostMallocDefault));
+    if (!o->d_out) HIPCHK(c, hipMalloc((void**)&o->d_out, outBytes));
     hipStream_t s = c->stream;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { o->disabled = true; (void)hipGetLastError(); return DRFE_OK; }
     hipError_t e = hipMemcpyAsync(c->d_stage, o->h_in, (size_t)w * h, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = drfe_launch_orb(c, c->d_stage, (size_t)w * h, (size_t)w, 1, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out, c->d_status, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out + 4, c->d_kpCount, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out + 8, c->d_kps, K * sizeof(drfe_keypoint), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(o->h_out + 8 + K * sizeof(drfe_keypoint), c->d_desc, K * 32, hipMemcpyDeviceToHost, s);
+    {   /* results gathered into one staging buffer, one download (see frame_enqueue) */
+        DrfePackArgs A;
+        std::memset(&A, 0, sizeof(A));
+        A.src[0] = reinterpret_cast<const uint32_t*>(c->d_status); A.dwords[0] = 1;
+        A.src[1] = reinterpret_cast<const uint32_t*>(c->d_kpCount); A.dwords[1] = 1;
+        A.src[2] = reinterpret_cast<const uint32_t*>(c->d_kps); A.dwords[2] = (uint32_t)(K * sizeof(drfe_keypoint) / 4);
+        A.src[3] = reinterpret_cast<const uint32_t*>(c->d_desc); A.dwords[3] = (uint32_t)(K * 8);
+        A.n = 4;
+        if (e == hipSuccess) e = drfe_launch_pack_segments(A, reinterpret_cast<uint32_t*>(o->d_out), s);
+        if (e == hipSuccess) e = hipMemcpyAsync(o->h_out, o->d_out, outBytes, hipMemcpyDeviceToHost, s);
+    }
     hipGraph_t g = nullptr;
     const hipError_t ee = hipStreamEndCapture(s, &g);
     if (e != hipSuccess || ee != hipSuccess || !g || hipGraphInstantiate(&o->exec, g, nullptr, nullptr, 0) != hipSuccess) {
@@ -645,6 +655,7 @@ struct FrameLane {
     uint8_t* h_in = nullptr;      /* pinned: gray w*h, then raw depth w*h*2 */
     uint8_t* h_out = nullptr;     /* pinned: int status | int count | kps[K] | desc[K][32] | uRight[K] | depth[K] */
     uint8_t* d_in = nullptr;      /* device staging, same layout as h_in */
+    uint8_t* d_out = nullptr;     /* device staging of the results, same layout as h_out: one download per frame */
     size_t inBytes = 0;
     hipEvent_t done = nullptr;
     hipGraph_t graph = nullptr;
@@ -701,6 +712,7 @@ void drfe_frame_lanes_free(drfe_ctx* c)
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.h_in) (void)hipHostFree(L.h_in);
         if (L.h_out) (void)hipHostFree(L.h_out);
+        if (L.d_out) (void)hipFree(L.d_out);
         if (L.d_in) (void)hipFree(L.d_in);
     }
     delete v;
@@ -711,9 +723,10 @@ void drfe_frame_lanes_free(drfe_ctx* c)
 static hipError_t frame_enqueue(drfe_ctx* c, FrameLane& L, int slot, int w, int h, hipStream_t s)
 {
     const size_t K = (size_t)c->maxKp, px = (size_t)w * h;
-    hipError_t e = hipMemcpyAsync(L.d_in, L.h_in, L.withDepth ? px * 3 : px, hipMemcpyHostToDevice, s);
-    if (L.tracked && e == hipSuccess)
-        e = hipMemcpyAsync(L.d_in + L.trackOff, L.h_in + L.trackOff, track_block_bytes(c), hipMemcpyHostToDevice, s);
+    /* one upload: the images and, behind them, the tracking block (pair record, Twc and - caller-supplied only - map points) */
+    size_t up = L.withDepth ? px * 3 : px;
+    if (L.tracked) up = L.trackOff + (L.mpsFromCaller ? track_block_bytes(c) : 256);
+    hipError_t e = hipMemcpyAsync(L.d_in, L.h_in, up, hipMemcpyHostToDevice, s);
     {
         SlotShift shift(c, slot);
         if (e == hipSuccess) e = drfe_launch_orb(c, L.d_in, px, (size_t)w, 1, s);
@@ -733,31 +746,27 @@ static hipError_t frame_enqueue(drfe_ctx* c, FrameLane& L, int slot, int w, int 
             SlotShift last(c, L.lastSlot);
             e = drfe_launch_mappoints_last(c, mb, L.cam, d_Twc, 1, s);
         }
-        if (e == hipSuccess) e = drfe_launch_fill_i32(c->d_match + (size_t)slot * K, (int)K, -1, s);
-        if (e == hipSuccess) e = drfe_launch_fill_i32(c->d_matchCount + slot, 1, 0, s);
+        if (e == hipSuccess) e = drfe_launch_fill_i32_and_word(c->d_match + (size_t)slot * K, (int)K, -1, c->d_matchCount + slot, 0, s);
         if (e == hipSuccess) e = drfe_launch_window_match(c, mb, L.cam, 1, c->maxKp, 0, L.th, 0.f, L.checkOri, nullptr, s, 3);
     }
-    uint8_t* o = L.h_out;
-    if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_status, 4, hipMemcpyDeviceToHost, s);
+    /* results: gathered on the device into the h_out layout (status | count | kps | desc | uRight | depth | matches | match
+     * count | matcher status), then ONE download - nine copy nodes cost the graph ~40 us of its 0.26 ms */
+    DrfePackArgs A;
+    std::memset(&A, 0, sizeof(A));
+    auto seg = [&A](const void* src, size_t bytes) { A.src[A.n] = static_cast<const uint32_t*>(src); A.dwords[A.n] = (uint32_t)(bytes / 4); A.n++; };
+    seg(c->d_status, 4);
     {
         SlotShift shift(c, slot);                    /* the slot's own arrays */
-        if (e == hipSuccess) e = hipMemcpyAsync(o + 4, c->d_kpCount, 4, hipMemcpyDeviceToHost, s);
-        o += 8;
-        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_kps, K * sizeof(drfe_keypoint), hipMemcpyDeviceToHost, s);
-        o += K * sizeof(drfe_keypoint);
-        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_desc, K * 32, hipMemcpyDeviceToHost, s);
-        o += K * 32;
-        if (L.withDepth) {
-            if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_uRight, K * 4, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4, c->d_depth, K * 4, hipMemcpyDeviceToHost, s);
-        }
+        seg(c->d_kpCount, 4);
+        seg(c->d_kps, K * sizeof(drfe_keypoint));
+        seg(c->d_desc, K * 32);
+        if (L.withDepth || L.tracked) { seg(L.withDepth ? c->d_uRight : nullptr, K * 4); seg(L.withDepth ? c->d_depth : nullptr, K * 4); }
     }
-    o += K * 8;
-    if (L.tracked) {
-        if (e == hipSuccess) e = hipMemcpyAsync(o, c->d_match + (size_t)slot * K, K * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4, c->d_matchCount + slot, 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(o + K * 4 + 4, c->d_status + 3, 4, hipMemcpyDeviceToHost, s);
-    }
+    if (L.tracked) { seg(c->d_match + (size_t)slot * K, K * 4); seg(c->d_matchCount + slot, 4); seg(c->d_status + 3, 4); }
+    size_t outBytes = 0;
+    for (int k = 0; k < A.n; k++) outBytes += (size_t)A.dwords[k] * 4;
+    if (e == hipSuccess) e = drfe_launch_pack_segments(A, reinterpret_cast<uint32_t*>(L.d_out), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(L.h_out, L.d_out, outBytes, hipMemcpyDeviceToHost, s);
     return e;
 }
 
@@ -810,6 +819,7 @@ static int frame_submit_impl(drfe_ctx* c, int slot, const uint8_t* gray, int w, 
         L.inBytes = need;
     }
     if (!L.h_out) HIPCHK(c, hipHostMalloc((void**)&L.h_out, 8 + K * (sizeof(drfe_keypoint) + 32 + 8 + 4) + 8, hipHostMallocDefault));
+    if (!L.d_out) HIPCHK(c, hipMalloc((void**)&L.d_out, 8 + K * (sizeof(drfe_keypoint) + 32 + 8 + 4) + 8));
     if (!L.done) HIPCHK(c, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     for (int y = 0; y < h; y++) std::memcpy(L.h_in + (size_t)y * w, gray + (size_t)y * stride, (size_t)w);
     if (depth)

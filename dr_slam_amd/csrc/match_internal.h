@@ -46,6 +46,10 @@ hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const d
                                     int maxQueries, int mode, float th, float nnratio, int checkOri,
                                     const uint8_t* d_initObs, hipStream_t s, int statusWord = 1);
 hipError_t drfe_launch_fill_i32(int* d_p, int n, int v, hipStream_t s);
+hipError_t drfe_launch_fill_i32_and_word(int* d_p, int n, int v, int* d_q, int w, hipStream_t s);
+/* up to 10 dword ranges laid end to end (match_kernels.hip: k_pack_segments) */
+struct DrfePackArgs { const uint32_t* src[10]; uint32_t dwords[10]; int n; };
+hipError_t drfe_launch_pack_segments(const DrfePackArgs& A, uint32_t* d_dst, hipStream_t s);
 /* bForward / bBackward of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame), src/ORBmatcher.cc:1406-1414 (capi_match.cpp) */
 void drfe_motion_flags(const float* TcwCur, const float* TcwLast, float mb, int mono, int* fwd, int* bwd);
 hipError_t drfe_launch_window_candidates(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs, int maxQueries,

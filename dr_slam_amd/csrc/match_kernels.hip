@@ -794,6 +794,43 @@ hipError_t drfe_launch_fill_i32(int* d_p, int n, int v, hipStream_t s)
     return hipGetLastError();
 }
 
+/* p[0..n) = v and *q = w in one launch (the per-frame flow clears a slot's matches and their count) */
+__global__ __launch_bounds__(256) void k_fill_i32_and_word(int* __restrict__ p, int n, int v, int* __restrict__ q, int w)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+    if (i == 0) *q = w;
+}
+hipError_t drfe_launch_fill_i32_and_word(int* d_p, int n, int v, int* d_q, int w, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill_i32_and_word, dim3((n > 0 ? n + 255 : 256) / 256), dim3(256), 0, s, d_p, n, v, d_q, w);
+    return hipGetLastError();
+}
+
+/* The results of one frame slot gathered into one staging buffer, so that a captured per-frame graph ends in ONE download
+ * instead of one copy node per array (a copy node costs ~5 us of graph time; the arrays are a few KB each).  Segments are
+ * dword ranges laid end to end in dst; a null source leaves its range untouched. */
+__global__ __launch_bounds__(256) void k_pack_segments(DrfePackArgs A, uint32_t* __restrict__ dst)
+{
+    uint32_t total = 0;
+    for (int k = 0; k < A.n; k++) total += A.dwords[k];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        uint32_t base = 0;
+        int k = 0;
+        while (i - base >= A.dwords[k]) { base += A.dwords[k]; k++; }
+        if (A.src[k]) dst[i] = A.src[k][i - base];
+    }
+}
+hipError_t drfe_launch_pack_segments(const DrfePackArgs& A, uint32_t* d_dst, hipStream_t s)
+{
+    uint32_t total = 0;
+    for (int k = 0; k < A.n; k++) total += A.dwords[k];
+    if (!total) return hipSuccess;
+    const unsigned blocks = (total + 1023) / 1024;            /* four dwords per thread */
+    hipLaunchKernelGGL(k_pack_segments, dim3(blocks), dim3(256), 0, s, A, d_dst);
+    return hipGetLastError();
+}
+
 hipError_t drfe_launch_window_match(drfe_ctx* c, const MatchBuffers& mb, const drfe_camera& cam, int npairs,
                                     int maxQueries, int mode, float th, float nnratio, int checkOri,
                                     const uint8_t* d_initObs, hipStream_t s, int statusWord)
