@@ -97,6 +97,29 @@ int drfe_default_host_threads()
     return std::max(1, n);
 }
 
+hipError_t drfe_long_kernel_stream(hipStream_t* s, int part)
+{
+    static const int share = [] { const char* e = std::getenv("DRFE_CU_SPLIT"); const int v = e ? std::atoi(e) : 0; return v < 0 ? 0 : v > 95 ? 95 : v; }();
+    if (share <= 0) {
+        int prLow = 0, prHigh = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
+        if (e != hipSuccess) return e;
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prLow);
+    }
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    /* the same share of every group of 32 CUs, whichever way the mask's bits map onto XCDs */
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+    const int cut = 32 * share / 100;
+    for (int i = 0; i < cus; i++) {
+        const bool first = (i % 32) < cut;
+        if (first == (part == 0)) mask[(size_t)i / 32] |= 1u << (i % 32);
+    }
+    return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+
 static std::atomic<long long> g_poolCpuNs[3];
 void drfe_pool_cpu_add(int pool, long long ns) { if (pool >= 0 && pool < 3) g_poolCpuNs[pool] += ns; }
 extern "C" void drfe_debug_pool_cpu_ns(long long* out3) { for (int k = 0; k < 3; k++) out3[k] = g_poolCpuNs[k].exchange(0); }

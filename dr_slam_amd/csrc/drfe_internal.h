@@ -208,6 +208,11 @@ struct DrfePoolCpuScope {
     ~DrfePoolCpuScope() { struct timespec t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1); drfe_pool_cpu_add(pool, (t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec)); }
 };
 
+/* The stream a batch entry runs its long one-wavefront-per-frame kernels on: low priority (the pools' short kernels must not
+ * queue behind them) or, with DRFE_CU_SPLIT=<lines share in percent>, restricted to one part of the CUs - part 0 for the line
+ * path, part 1 for the plane path (capi.cpp) */
+hipError_t drfe_long_kernel_stream(hipStream_t* s, int part);
+
 /* capi.cpp: host threads a batch entry point may start by default - the affinity mask clipped by the cgroup CPU quota
  * (std::thread::hardware_concurrency() reports the machine, which oversubscribes a quota-limited container) */
 int drfe_default_host_threads();

@@ -876,6 +876,7 @@ struct BatchJob {
     bool abort = false;
     double prec, p; int minReg;
     bool deviceOrder = true;            /* the ordering by k_lsd_order (default) or by the pool (DRFE_LSD_HOST_ORDER=1: A/B, tests) */
+    hipEvent_t stageEv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* DRFE_TRACE_LINES, chunk 0: start | upload | passes | keys | ordering | growth */
     std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0}, usCountsWall{0}, usCountsCpu{0}, nCountRounds{0}, handedBack{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
     std::chrono::steady_clock::time_point t0, tLastSort, tFirstFinish; std::atomic<int> nFirst{0};
     BatchJob(int nChunks_) : sortedInChunk(nChunks_), chunkState(nChunks_, 0) {}
@@ -907,6 +908,7 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
         /* std::sort's permutation on the device, in place; the member-list arrays serve as its scratch (the growth that
          * follows on the same stream overwrites them) */
         BCHK(drfe_launch_lsd_order(A->d_order + nk * f0, nk, (int)nk, A->d_reg + ns * f0, A->d_tmp + ns * f0, ns, A->d_ordStatus + f0, 1, nf, st));
+        if (ch == 0 && J.stageEv[4]) (void)hipEventRecord(J.stageEv[4], st);
     } else
         BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
     BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
@@ -914,6 +916,7 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
     /* no download behind the growth: a copy queued on a DMA ring waits there for its kernel and holds up every other stream's
      * copies behind it (measured: the plane path's kernels and CAPE's transfers stalled for the whole growth); the worker that
      * sees the event fetches the chunk's status words */
+    if (ch == 0 && J.stageEv[5]) (void)hipEventRecord(J.stageEv[5], st);
     BCHK(hipEventRecord(J.growDone[ch], st));
 #undef BCHK
     return DRFE_OK;
@@ -1084,8 +1087,9 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
      * microsecond kernels a host thread waits for) never queue behind a chunk that grows for a hundred milliseconds */
     int prLow = 0, prHigh = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+    if (std::getenv("DRFE_TRACE_LINES")) for (hipEvent_t& e : J.stageEv) HIPCHK(c, hipEventCreate(&e));
     for (int ch = 0; ch < nChunks; ch++) {
-        HIPCHK(c, hipStreamCreateWithPriority(&J.chunkStream[ch], hipStreamNonBlocking, prLow));
+        HIPCHK(c, drfe_long_kernel_stream(&J.chunkStream[ch], 0));
         HIPCHK(c, hipEventCreateWithFlags(&J.keysReady[ch], hipEventDisableTiming | hipEventBlockingSync));
         HIPCHK(c, hipEventCreateWithFlags(&J.growDone[ch], hipEventDisableTiming | hipEventBlockingSync));
     }
@@ -1095,12 +1099,17 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         const int f0 = ch * chunk, nf = std::min(chunk, nframes - f0);
         hipStream_t st = J.chunkStream[ch];
         hipError_t e = hipSuccess;
+        const bool tr = ch == 0 && J.stageEv[0];
+        if (tr) (void)hipEventRecord(J.stageEv[0], st);
         if (stride == (size_t)w && frame_stride == n) e = hipMemcpyAsync(A->d_img + n * f0, gray + frame_stride * f0, n * nf, hipMemcpyHostToDevice, st);
         else
             for (int f = f0; f < f0 + nf && e == hipSuccess; f++)
                 e = hipMemcpy2DAsync(A->d_img + n * f, (size_t)w, gray + frame_stride * f, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st);
+        if (tr) (void)hipEventRecord(J.stageEv[1], st);
         if (e == hipSuccess) e = drfe_launch_lines_passes(A->d_img + n * f0, w, h, P.lsdTaps, P.lbdTaps, A, f0, nf, P.rho, st);
+        if (tr) (void)hipEventRecord(J.stageEv[2], st);
         if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, nf, st);
+        if (tr) (void)hipEventRecord(J.stageEv[3], st);
         if (e == hipSuccess && !J.deviceOrder) {
             e = hipMemcpyAsync(A->h_order + nk * f0, A->d_order + nk * f0, nk * 4 * nf, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipMemcpyAsync(A->h_meta + 2 * (size_t)f0, A->d_meta + 2 * (size_t)f0, 16 * (size_t)nf, hipMemcpyDeviceToHost, st);
@@ -1123,6 +1132,13 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         for (int k = 0; k < T; k++) th.emplace_back([&J, pool, k]() { DrfePoolCpuScope cpu(0); batch_worker(J, &(*pool)[k]); });
         for (std::thread& t : th) t.join();
     }
+    if (J.stageEv[0] && J.deviceOrder && launchRc == DRFE_OK) {
+        float ms[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < 5; k++) (void)hipEventElapsedTime(&ms[k], J.stageEv[k], J.stageEv[k + 1]);
+        std::fprintf(stderr, "drfe_lsd_extract_batch stages on the device (chunk 0, waiting for resources included): upload %.1f ms, image passes %.1f, k_lsd_keys %.1f, k_lsd_order %.1f, k_lsd_grow %.1f\n",
+                     ms[0], ms[1], ms[2], ms[3], ms[4]);
+    }
+    for (hipEvent_t& e : J.stageEv) if (e) (void)hipEventDestroy(e);
     if (std::getenv("DRFE_TRACE_LINES"))
         std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f (of which in the counting round trips: %.2f wall, %.2f CPU), key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device; %ld frames redone on the host\n",
                      nframes, nChunks, chunk, T, std::chrono::duration<double, std::milli>(tLaunched - tBegin).count(),

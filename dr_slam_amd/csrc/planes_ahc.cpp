@@ -1030,7 +1030,7 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
     for (int ch = 0; ch < J.nChunks; ch++) {
         /* low priority, like the line path's growth: the runtime keeps separate hardware queues per priority, so the pools'
          * short kernels never queue behind a chunk that runs for a hundred milliseconds */
-        HIPCHK(c, hipStreamCreateWithPriority(&J.chunkStream[ch], hipStreamNonBlocking, prLow));
+        HIPCHK(c, drfe_long_kernel_stream(&J.chunkStream[ch], 1));
         HIPCHK(c, hipEventCreateWithFlags(&J.chunkDone[ch], hipEventDisableTiming | hipEventBlockingSync));
     }
     for (int ch = 0; ch < J.nChunks && launchRc == DRFE_OK; ch++) {

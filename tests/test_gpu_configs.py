@@ -2,6 +2,7 @@
 C-ABI vs the CPU oracle (bit-exact), on top of the per-stage files.
   config 2 (index 2): ICL-NUIM living-room style scene, ICL intrinsics (fy < 0): ORB + glue + SearchByProjection on a
                       short sequence, LSD + LBD lines, CAPE and AHC planes of its first frame;
+  config 3 again, every frame of a 12-frame sequence through the frame-batch entries (device sequential cores);
   config 5 (index 4): 1280x960 RealSense-style frame: LSD + LBD lines and CAPE planes at 4x the pixels (the ORB part
                       of this configuration is tests/test_gpu_orb.py::test_1280x960_config5)."""
 import numpy as np
@@ -70,6 +71,50 @@ def test_config2_icl_living_room_full_front_end(oracle_mod):
         assert len(ga["planes"]) == len(oa["planes"]) >= 2 and np.array_equal(ga["seg"], oa["seg"])
     finally:
         fe.ctx.close()
+
+
+def test_config3_every_frame_through_the_batch_entries(oracle_mod):
+    """BASELINE config 3 as bench.py's full_frontend runs it - EVERY frame's lines, AHC planes + Frame::ComputePlanes' per-plane
+    loop and CAPE planes through the frame-batch entries, whose sequential cores run on the device (k_lsd_order / k_lsd_grow,
+    k_ahc_cluster / k_ahc_refine, k_voxel_grid) - against the CPU oracle, frame by frame, bit for bit."""
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = synth.ICL
+    frames = list(synth.sequence(3, 12, cam=cam, kind="living_room"))
+    gray = np.stack([f[0] for f in frames]); depth = np.stack([f[1] for f in frames])
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = np.float32(1.0) / np.float32(cam.depth_factor)
+    depth_m = np.stack([O.depth_to_float(d, inv) for d in depth])
+    c = lib.Context(max_batch=1)
+    try:
+        lines = c.lsd_extract_batch(gray, n_threads=4)
+        planes, n, post, na, pn, seg = c.planes_ahc_post_batch(depth, K4, float(inv), 9.0, 0.10, n_threads=4, seg=True)
+        cplanes, cn, cseg = c.planes_cape_batch(depth_m, K4, 20, n_threads=2, seg=True)
+        nl = 0
+        for f in range(len(frames)):
+            a, b = lines[f], O.extract_lines(gray[f])
+            assert a["detected"] == b["detected"] and len(a["lines"]) == len(b["lines"])
+            assert np.array_equal(a["desc"], b["desc"]) and np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
+            for pa, pb in (("start_point_x", "startPointX"), ("start_point_y", "startPointY"), ("end_point_x", "endPointX"),
+                           ("end_point_y", "endPointY"), ("angle", "angle"), ("response", "response"), ("line_length", "lineLength")):
+                assert np.array_equal(a["lines"][pa].view(np.uint32), b["lines"][pb].view(np.uint32)), (f, pa)
+            nl += len(a["lines"])
+            oa = O.ahc_planes(depth[f], K4, float(inv))
+            assert n[f] == len(oa["planes"]) and np.array_equal(seg[f], oa["seg"]) and np.array_equal(planes[f, :n[f]]["n_points"], oa["N"])
+            assert np.array_equal(planes[f, :n[f]]["normal"].view(np.uint64), oa["planes"][:, 0:3].view(np.uint64))
+            assert np.array_equal(planes[f, :n[f]]["center"].view(np.uint64), oa["planes"][:, 3:6].view(np.uint64))
+            assert np.array_equal(planes[f, :n[f]]["mse"].view(np.uint64), oa["planes"][:, 6].view(np.uint64))
+            o2, opn = O.ahc_post_planes(depth[f], K4, float(inv), oa, 9.0, 0.10)
+            assert pn[f] == opn and na[f] == sum(1 for r in o2 if r["accepted"])
+            for k, rec in enumerate(o2):
+                assert bool(post[f, k]["accepted"]) == rec["accepted"] and post[f, k]["n_voxels"] == len(rec["voxels"])
+                assert np.array_equal(post[f, k]["coef"].view(np.uint32), rec["coef"].view(np.uint32))
+            oc = O.cape_planes(depth_m[f], K4, 20)
+            assert cn[f] == len(oc["planes"]) and np.array_equal(cseg[f], oc["seg"])
+            assert np.array_equal(cplanes[f, :cn[f]]["normal"].view(np.uint64), oc["planes"][:, 0:3].view(np.uint64))
+        assert nl >= 10 * len(frames) and na.sum() >= 2 * len(frames) and cn.sum() >= 3 * len(frames)
+    finally:
+        c.close()
 
 
 def test_config5_1280x960_lines_and_cape_planes(oracle_mod):
