@@ -546,21 +546,28 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
      * the fetch of what does change (the neighbour's label and its best distance so far) happen for all 64 at once.  The
      * reference applies the 64 (entry, neighbour) visits one after the other; the only thing one visit passes to a later one
      * is the state of a PIXEL both look at - queue appends keep lane order under a ballot prefix, and connecting two planes
-     * is a set insertion.  So every lane finds the previous lane of the step that targets its pixel (a 64-step compare of
-     * lane-broadcast pixel indices), the visits are applied in rounds by depth in those chains (<= 4: a pixel has four
-     * neighbours), a lane taking its input state from its predecessor's output, and the last lane of a chain stores the
-     * pixel.  One memory fence per step. ---- */
+     * is a set insertion.  So every lane finds the previous lane of the step that targets its pixel, the visits are applied in
+     * rounds by depth in those chains (94 % of the steps have one; usually depth 1, more when a pixel sits in the queue several
+     * times), a lane taking its input state from its predecessor's output, and the last lane of a chain stores the pixel.  One
+     * memory fence per step. ---- */
     {
+#ifdef AHC_PROFILE
+        unsigned ffSteps = 0, ffDup = 0, ffDepth = 0, ffHave = 0;
+#endif
         int head = 0, tail = nRf;
         const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy, factor = P.factor;
         for (int k = lane; k < NB; k += 64) blkLds[k] = (int8_t)(c.blkMap[k] >= 0 ? 1 : 0);
         fence();
         const int eLane = lane >> 2, nbLane = lane & 3;          /* entry of the step, neighbour (left, right, up, down) */
+        uint32_t eNext = 0;
+        int nextFrom = -1;                                       /* queue position eNext was prefetched for (this lane) */
         while (head < tail) {
             const int cnt = min(16, tail - head);
             const bool mine = eLane < cnt;
             uint32_t e = 0;
-            if (mine) e = c.rf[head + eLane];
+            if (mine) e = nextFrom == head + eLane ? eNext : c.rf[head + eLane];
+            /* the next step's entries, when the queue already holds them: their fetch overlaps this step */
+            if (head + 16 + eLane < tail) { eNext = c.rf[head + 16 + eLane]; nextFrom = head + 16 + eLane; }
             const int sIdx = (int)(e & 0xFFFFFu), plid = (int)(e >> 20);
             const int sy = sIdx / w, sx = sIdx - sy * w;
             int cxn = sx, cyn = sy;
@@ -592,34 +599,39 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
                     in = cd * cd < 9 * plMse[plid] + 1e-5;
                 }
             }
-            /* chains of lanes that target the same pixel, in lane (= visiting) order */
-            const int key = have ? cIdx : -1 - lane;
-            int prev = -1;
+            /* chains of lanes that target the same pixel, in lane (= visiting) order.  A lane's pixel is a neighbour of entry j
+             * iff it lies one step left / right / up / down of j's pixel, and then the lane that visits it from j is 4 j + that
+             * direction: sixteen broadcasts of the entries' pixels find every other visitor of the pixel (a visitor that exists
+             * has the same pixel, hence the same kept-block verdict; one that fell off the image row is not live).  The depth in
+             * the chain is the number of visitors before this lane. */
+            const unsigned long long live = __ballot(have);
+            int prev = -1, depth = 0;
             bool isLast = true;
-            const int nl = 4 * cnt;
-            for (int l = 0; l < nl; l++) {
-                const int v = rl_i(key, l);
-                if (v == key) { if (l < lane) prev = l; else if (l > lane) isLast = false; }
+            for (int j = 0; j < cnt; j++) {
+                const int d = cIdx - rl_i(sIdx, 4 * j);
+                const int dir = d == -1 ? 0 : d == 1 ? 1 : d == -w ? 2 : d == w ? 3 : -1;
+                const int l2 = 4 * j + dir;
+                if (have && dir >= 0 && ((live >> l2) & 1ull)) {
+                    if (l2 < lane) { prev = l2; depth++; }
+                    else if (l2 > lane) isLast = false;
+                }
             }
-            /* depth in the chain (usually <= 3: a pixel has four neighbours; more when a pixel sits in the queue several times) */
-            int depth = 0, maxDepth = 0;
-            for (;;) {
-                const int dp = __shfl(depth, prev < 0 ? lane : prev);
-                const int nd = prev >= 0 ? dp + 1 : 0;
-                const bool changed = nd != depth;
-                depth = nd;
-                if (!__ballot(changed)) break;
-            }
+            int maxDepth = 0;
             while (__ballot(depth > maxDepth)) maxDepth++;
+#ifdef AHC_PROFILE
+            ffSteps++; if (maxDepth > 0) ffDup++; ffDepth += maxDepth; ffHave += __popcll(live);
+#endif
             bool push = false, dirty = false, distDirty = false, meets = false;
             int other = -1;
             for (int r = 0; r <= maxDepth; r++) {
-                /* a lane of depth r continues from its predecessor's output */
-                const int tIn = __shfl(trail, prev < 0 ? lane : prev);
-                const float oIn = __shfl(old, prev < 0 ? lane : prev);
-                const bool dIn = __shfl((int)dirty, prev < 0 ? lane : prev) != 0, ddIn = __shfl((int)distDirty, prev < 0 ? lane : prev) != 0;
+                if (r > 0) {
+                    /* a lane of depth r continues from its predecessor's output: label | flags in one word, the distance */
+                    const int src = prev < 0 ? lane : prev;
+                    const int sIn = __shfl((trail & 0xFFFF) | (dirty ? 0x10000 : 0) | (distDirty ? 0x20000 : 0), src);
+                    const float oIn = __shfl(old, src);
+                    if (have && depth == r) { trail = (int)(int16_t)(sIn & 0xFFFF); dirty = (sIn & 0x10000) != 0; distDirty = (sIn & 0x20000) != 0; old = oIn; }
+                }
                 if (have && depth == r) {
-                    if (prev >= 0) { trail = tIn; old = oIn; dirty = dIn; distDirty = ddIn; }
                     const bool active = !(trail <= -6) && !(trail >= 0 && trail == plid);
                     if (active) {
                         if (in && trail >= 0) { meets = true; other = trail; }
@@ -652,6 +664,9 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
             fence();
         }
         rfTotal = tail;
+#ifdef AHC_PROFILE
+        if (lane == 0) { ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 4] = (int)ffSteps; ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 5] = (int)ffDup; ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 6] = (int)ffDepth; ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 7] = (int)ffHave; }
+#endif
     }
     if (uni_b(c.status != 0)) { if (lane == 0) { out[0] = 0; out[1] = c.status; } return; }
     TP();

@@ -1082,6 +1082,9 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         (void)hipMemcpy(t, A->h_frames[0].rf, sizeof(t), hipMemcpyDeviceToHost);
         std::fprintf(stderr, "k_ahc_cluster + k_ahc_refine, frame 0: initGraph %.2f ms, ahCluster %.2f, membership + seeds %.2f, floodFill %.2f (%d queue entries), re-merge %.2f, labels + member lists %.2f; %d nodes\n",
                      t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, A->h_out[2], t[4] / 1e5, t[5] / 1e5, A->h_out[3]);
+        int ff[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(ff, A->h_frames[0].handoff + 4 + 2 * 128 + 4, sizeof(ff), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "  flood fill: %d steps, %d with two visits of one pixel (chain depth summed: %d), %d live visits\n", ff[0], ff[1], ff[2], ff[3]);
     }
     if (std::getenv("DRFE_TRACE_PLANES"))
         std::fprintf(stderr, "drfe_planes_ahc_post_batch (device extractor): %d frames, %d chunks, %d frames redone on the host; voxel grids on the %s (%d planes' grids redone on the host)\n",
