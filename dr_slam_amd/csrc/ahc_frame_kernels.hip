@@ -133,16 +133,56 @@ __device__ __forceinline__ void list_insert(Ctx& c, int a, int v)
     L[pos] = v;
     c.nbLen[a] = len + 1;
 }
-/* eraseSorted; one lane */
+/* eraseSorted; one lane.  Lists of up to eight neighbours (nearly all) are fetched with eight independent loads instead of a
+ * chain of dependent ones */
 __device__ __forceinline__ void list_erase(Ctx& c, int a, int v)
 {
     GLOBAL_AS int* L = c.pool + c.nbOff[a];
     const int len = c.nbLen[a];
+    if (len <= 8) {
+        int e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = k < len ? L[k] : 0x7fffffff;
+        int w = 0;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < len) {
+                if (e[k] == v) found = true;
+                else { if (found) L[w] = e[k]; w++; }
+            }
+        if (found) c.nbLen[a] = len - 1;
+        return;
+    }
     int pos = 0;
     while (pos < len && L[pos] < v) pos++;
     if (pos >= len || L[pos] != v) return;
     for (int k = pos; k + 1 < len; k++) L[k] = L[k + 1];
     c.nbLen[a] = len - 1;
+}
+
+/* what a merge of p and q into the new node id does to the list of a common neighbour a: p and q leave, id (the largest id so
+ * far) is appended - disconnectAll(p), disconnectAll(q) and the connects of the new node in one pass over the list */
+__device__ __forceinline__ void list_replace2(Ctx& c, int a, int p, int q, int id)
+{
+    GLOBAL_AS int* L = c.pool + c.nbOff[a];
+    const int len = c.nbLen[a];
+    int w = 0;
+    if (len <= 8) {
+        int e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = k < len ? L[k] : 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < len && e[k] != p && e[k] != q) { if (w != k) L[w] = e[k]; w++; }
+    } else {
+        for (int k = 0; k < len; k++) {
+            const int v = L[k];
+            if (v != p && v != q) { if (w != k) L[w] = v; w++; }
+        }
+    }
+    L[w] = id;
+    c.nbLen[a] = w + 1;
 }
 
 /* ParamSet::T_ang(P_INIT, z) with the millimetre defaults (planes_ahc.cpp tAngInit); cosine correctly rounded */
@@ -174,8 +214,9 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         if (lane == 0) p = heap_pop(c);
         p = uni_i(p);
         c.heapSize = uni_i(c.heapSize);
-        if (uni_b(c.nouse[p] != 0)) continue;
-        const int Lp = uni_i(c.nbLen[p]);
+        const int nouseP = c.nouse[p], lenP = c.nbLen[p];          /* one round trip for both */
+        if (uni_b(nouseP != 0)) continue;
+        const int Lp = uni_i(lenP);
         if (Lp > AHCD_LIST) { c.status |= 2; return; }
         const GLOBAL_AS int* listP = c.pool + c.nbOff[p];
         for (int k = lane; k < Lp; k += 64) c.lA[k] = listP[k];
@@ -186,18 +227,24 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         /* trial merges, one lane per neighbour; the fold keeps the reference's order and tie rule */
         bool haveCand = false;
         double candMse = 0;
-        int candN = 0, candNb = -1;
+        int candN = 0, candNb = -1, candLen = 0;
         for (int base = 0; base < Lp; base += 64) {
             const int k = base + lane;
             bool ok = false;
             double S[9];
             AhcFit f;
-            int Nn = 0, ridN = 0, nb = 0;
+            int Nn = 0, ridN = 0, nb = 0, nbLenK = 0, nbHead[8];
             f.mse = 0;
             if (k < Lp) {
                 nb = c.lA[k];
                 if (!(similarity(c, p, nb) < c.P.cos60)) {
                     ok = true;
+                    /* the neighbour's own list (its first eight entries: nearly always all of it) is fetched beside the sums: if
+                     * this trial wins, the merge needs it and would wait two more round trips for it */
+                    nbLenK = c.nbLen[nb];
+                    const GLOBAL_AS int* listN = c.pool + c.nbOff[nb];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) nbHead[q] = q < nbLenK ? listN[q] : 0;
                     const int Nb = c.N[nb];
 #pragma unroll
                     for (int q = 0; q < 9; q++) S[q] = Sp[q] + c.S[9 * (size_t)nb + q];
@@ -213,7 +260,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 m &= m - 1;
                 const double mse = rl_d(f.mse, l);
                 if (!haveCand || candMse > mse || (candMse == mse && (double)candN < mse)) {
-                    haveCand = true; candMse = mse; candN = rl_i(Nn, l); candNb = rl_i(nb, l); winLane = l;
+                    haveCand = true; candMse = mse; candN = rl_i(Nn, l); candNb = rl_i(nb, l); candLen = rl_i(nbLenK, l); winLane = l;
                 }
             }
             if (winLane >= 0 && lane == winLane) {          /* this chunk's winner parks its merged node in LDS */
@@ -223,6 +270,8 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 c.win[12] = f.normal[0]; c.win[13] = f.normal[1]; c.win[14] = f.normal[2];
                 c.win[15] = f.mse; c.win[16] = f.curvature;
                 ((int*)(c.win + 17))[0] = Nn; ((int*)(c.win + 17))[1] = ridN;
+#pragma unroll
+                for (int q = 0; q < 8; q++) c.lB[q] = nbHead[q];
             }
         }
         bool merge = false;
@@ -233,7 +282,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         }
         if (uni_b(merge)) {
             const int id = c.nNodes;
-            const int Lc = uni_i(c.nbLen[candNb]);
+            const int Lc = candLen;
             if (id >= c.P.maxNodes || Lc > AHCD_LIST) { c.status |= 2; return; }
             c.nNodes = id + 1;
             if (lane < 9) c.S[9 * (size_t)id + lane] = c.win[lane];
@@ -249,11 +298,33 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 }
             }
             c.heapSize = uni_i(c.heapSize);
-            const GLOBAL_AS int* listC = c.pool + c.nbOff[candNb];
-            for (int k = lane; k < Lc; k += 64) c.lB[k] = listC[k];
-            /* u = nbs(p) U nbs(cand) \ {p, cand}: two short sorted lists, merged by one lane */
+            if (Lc > 8) {                                       /* the winner parked the first eight: the rest of a long list */
+                const GLOBAL_AS int* listC = c.pool + c.nbOff[candNb];
+                for (int k = 8 + lane; k < Lc; k += 64) c.lB[k] = listC[k];
+            }
+            fence();
+            /* u = nbs(p) U nbs(cand) \ {p, cand}, sorted.  Short lists (the rule): lane i holds one element of A ++ B; it is kept
+             * unless it is p, cand or an element of B that A holds too, and its place in u is the number of kept elements
+             * smaller than it.  Long lists: merged by one lane. */
             int Lu = 0;
-            if (lane == 0) {
+            if (Lp + Lc <= 64) {
+                const int tot = Lp + Lc;
+                const bool fromB = lane >= Lp;
+                const int v = lane < tot ? (fromB ? c.lB[lane - Lp] : c.lA[lane]) : 0x7fffffff;
+                bool keep = lane < tot && v != p && v != candNb;
+                int smaller = 0;
+                for (int l = 0; l < tot; l++) {
+                    const int o = rl_i(v, l);
+                    if (fromB && l < Lp && o == v) keep = false;          /* A holds it too */
+                }
+                const unsigned long long km = __ballot(keep);
+                for (int l = 0; l < tot; l++) {
+                    const int o = rl_i(v, l);
+                    if (((km >> l) & 1ull) && o < v) smaller++;
+                }
+                if (keep) c.lU[smaller] = v;
+                Lu = __popcll(km);
+            } else if (lane == 0) {
                 int i = 0, j = 0;
                 while (i < Lp || j < Lc) {
                     int v;
@@ -264,18 +335,17 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 }
             }
             Lu = uni_i(Lu);
+            fence();
             if (c.poolUsed + Lu > c.P.poolCap) { c.status |= 2; return; }
-            disconnect_staged(c, c.lA, Lp, p);
-            disconnect_staged(c, c.lB, Lc, candNb);
-            /* the new node takes u; every member of u gets it as a neighbour (the largest id so far: appended) */
+            /* disconnectAll(p), disconnectAll(cand) and the new node's connects: every member of u (a neighbour of p, of cand
+             * or of both) drops them and gets the new node - the largest id so far: appended - in one pass over its list; the
+             * lists of p and cand themselves die with the nodes.  The new node takes u. */
             const int off = c.poolUsed;
             c.poolUsed += Lu;
             for (int k = lane; k < Lu; k += 64) {
                 const int nb = c.lU[k];
                 c.pool[off + k] = nb;
-                const int len = c.nbLen[nb];
-                c.pool[c.nbOff[nb] + len] = id;
-                c.nbLen[nb] = len + 1;
+                list_replace2(c, nb, p, candNb, id);
             }
             if (lane == 0) { c.nbOff[id] = off; c.nbLen[id] = Lu; c.nbLen[p] = 0; c.nbLen[candNb] = 0; c.nouse[p] = 1; c.nouse[candNb] = 1; }
             fence();
