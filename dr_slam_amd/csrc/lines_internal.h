@@ -13,6 +13,7 @@ struct LinesScratch {
     uint16_t* d_tmp16;
     double* d_modgrad; double* d_angles;
     float2* d_cs;                   /* (cos, sin) of float(angle) per scaled pixel, 0 where the angle is undefined */
+    float2* d_cs0;                  /* batch arena: float(cos(angle)), float(sin(angle)) per scaled pixel - a seed's direction (k_lsd_keys) */
     unsigned long long* d_meta;     /* per slot two words: [0] bits of the largest gradient magnitude, [1] smallest gradient bin of a pixel with an angle */
     int16_t* d_gx; int16_t* d_gy;
     struct RectCand* d_cands; int2* d_counts; size_t candCap;   /* grow-only scratch of the NFA rounds (one lane's) */
@@ -51,6 +52,7 @@ struct LsdRect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 /* one frame of a k_lsd_grow launch: its level-line fields, the sorted pseudo-ordering, scratch and outputs */
 struct LsdGrowFrame {
     const double* ang; const float2* cs; const double* mod;   /* W x H fields of k_ll_angle */
+    const float2* cs0;                                        /* W x H: float(cos), float(sin) of the pixel's angle (k_lsd_keys): a region's first direction */
     const uint32_t* order;                                    /* keys bin << 22 | y << 11 | x in std::sort's order */
     uint32_t* reg; uint32_t* tmp;                             /* W x H entries each: member list (y << 16 | x), shrink scratch */
     LsdRect* rects; int* out;                                 /* accepted rectangles in seed order; out[0] = count, out[1] = status (DRFE_LSD_OUT_INTS ints per frame) */
@@ -60,7 +62,7 @@ struct LsdGrowFrame {
 size_t drfe_lsd_grow_lds_bytes(int W, int H);
 /* keys of nframes consecutive slots: d_mod / d_ang / d_meta / d_keys point at the first of them */
 hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
-                                int nframes, hipStream_t s);
+                                float2* d_cs0, int nframes, hipStream_t s);
 /* std::sort's permutation of nframes key arrays (n keys each, keyStride apart) in place: introsort's moves on the device
  * (lsd_order_kernels.hip).  d_posL / d_posR: scratch of >= n entries per frame, posStride apart.  d_status[f * statusStride]:
  * 0, or 1 = a range ran out of introsort's depth limit (heap sort in libstdc++), 2 = internal queue overflow: order on the host. */

@@ -553,7 +553,7 @@ static hipError_t lane_sync(LineWorker* c)
 static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
-    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
+    void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_cs0, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
                     s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts};
@@ -619,6 +619,7 @@ static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int f
         s->rectCap = LSD_RECT_CAP;
         LCHK(hipMalloc((void**)&s->d_order, nk * 4));
         LCHK(hipMalloc((void**)&s->d_reg, ns * 4));
+        LCHK(hipMalloc((void**)&s->d_cs0, ns * 8));
         LCHK(hipMalloc((void**)&s->d_tmp, ns * 4));
         LCHK(hipMalloc((void**)&s->d_rects, F * s->rectCap * sizeof(LsdRect)));
         LCHK(hipMalloc((void**)&s->d_out, F * DRFE_LSD_OUT_INTS * sizeof(int)));
@@ -892,7 +893,7 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
     hipStream_t st = J.chunkStream[ch];
     for (int f = f0; f < f0 + nf; f++) {
         LsdGrowFrame& g = A->h_frames[f];
-        g.ang = A->d_angles + ns * f; g.cs = A->d_cs + ns * f; g.mod = A->d_modgrad + ns * f;
+        g.ang = A->d_angles + ns * f; g.cs = A->d_cs + ns * f; g.cs0 = A->d_cs0 + ns * f; g.mod = A->d_modgrad + ns * f;
         g.order = A->d_order + nk * f; g.reg = A->d_reg + ns * f; g.tmp = A->d_tmp + ns * f;
         g.rects = A->d_rects + (size_t)A->rectCap * f; g.out = A->d_out + DRFE_LSD_OUT_INTS * (size_t)f;
         g.nOrder = (int)nk;
@@ -1108,7 +1109,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         if (tr) (void)hipEventRecord(J.stageEv[1], st);
         if (e == hipSuccess) e = drfe_launch_lines_passes(A->d_img + n * f0, w, h, P.lsdTaps, P.lbdTaps, A, f0, nf, P.rho, st);
         if (tr) (void)hipEventRecord(J.stageEv[2], st);
-        if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, nf, st);
+        if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, A->d_cs0 + ns * f0, nf, st);
         if (tr) (void)hipEventRecord(J.stageEv[3], st);
         if (e == hipSuccess && !J.deviceOrder) {
             e = hipMemcpyAsync(A->h_order + nk * f0, A->d_order + nk * f0, nk * 4 * nf, hipMemcpyDeviceToHost, st);

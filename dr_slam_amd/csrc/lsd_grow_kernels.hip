@@ -63,7 +63,7 @@ __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ
  * full HBM round trip */
 #define GLOBAL_AS __attribute__((address_space(1)))
 struct FramePtrs {
-    const GLOBAL_AS double* ang; const GLOBAL_AS float* cs; const GLOBAL_AS double* mod; const GLOBAL_AS uint32_t* order;
+    const GLOBAL_AS double* ang; const GLOBAL_AS float* cs; const GLOBAL_AS float* cs0; const GLOBAL_AS double* mod; const GLOBAL_AS uint32_t* order;
     GLOBAL_AS uint32_t* reg; GLOBAL_AS uint32_t* tmp; GLOBAL_AS double* rects; GLOBAL_AS int* out;
     int nOrder; uint32_t minSeedBin;
 };
@@ -88,17 +88,10 @@ struct Wave {
 /* the two libm replacements as real functions: one copy each in the code object (inlined at their seven call sites they
  * pushed the kernel past the 64 KB instruction cache) */
 struct SinCos { double s, c; int ok; };
-struct SinCosF { float s, c; int ok; };
 __device__ __noinline__ SinCos cr_sincos_call(double x)
 {
     SinCos r;
     r.ok = drfe_cr_sincos(x, &r.s, &r.c);
-    return r;
-}
-__device__ __noinline__ SinCosF cr_sincos_f_call(double x)
-{
-    SinCosF r;
-    r.ok = drfe_cr_sincos_f(x, &r.s, &r.c);
     return r;
 }
 
@@ -114,17 +107,18 @@ __device__ __forceinline__ bool aligned_with(double theta, double a, double prec
  * angle and (cos, sin), fetched once per seed - and for the next seeds of the scan ahead of their turn, the fields never
  * change.  A region that stays inside it (nineteen in twenty do) grows without touching memory again: the neighbourhood's
  * state is a 49-bit scalar mask. */
-struct Window { double a; float2 c; };
+struct Window { double a; float2 c; float2 s0; };      /* s0 (centre lane only): the seed's own direction, k_lsd_keys' field */
 
 __device__ __forceinline__ Window load_window(const Wave& w, int sx, int sy)
 {
     Window win;
-    win.a = 0.0; win.c = make_float2(0.f, 0.f);
+    win.a = 0.0; win.c = make_float2(0.f, 0.f); win.s0 = make_float2(0.f, 0.f);
     const int t = w.lane, wy = (t * 37) >> 8, wx = t - 7 * wy;
     const int px = sx - 3 + wx, py = sy - 3 + wy;
     if (t < 49 && px >= 0 && py >= 0 && px < w.W && py < w.H) {
         const size_t q = (size_t)py * w.W + px;
         win.a = w.F.ang[q]; win.c = make_float2(w.F.cs[2 * q], w.F.cs[2 * q + 1]);
+        if (t == 24) win.s0 = make_float2(w.F.cs0[2 * q], w.F.cs0[2 * q + 1]);
     }
     return win;
 }
@@ -174,9 +168,9 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
                 n++;
                 if (!seeded) {
                     /* only regions that get a second member need the seed's direction */
-                    const SinCosF sc = cr_sincos_f_call(seedAngle);
-                    sumdx = sc.c; sumdy = sc.s;
-                    if (!sc.ok) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
+                    /* float(cos), float(sin) of the seed's angle: correctly rounded per pixel by k_lsd_keys (NaN: not certified) */
+                    sumdx = rl_f32(win.s0.x, 24); sumdy = rl_f32(win.s0.y, 24);
+                    if (sumdx != sumdx) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
                     seeded = true;
                 }
                 sumdx += rl_f32(win.c.x, l);
@@ -222,9 +216,9 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
                     n++;
                     if (!seeded) {
                         /* only regions that get a second member need the seed's direction */
-                        const SinCosF sc = cr_sincos_f_call(seedAngle);
-                        sumdx = sc.c; sumdy = sc.s;
-                        if (!sc.ok) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
+                        /* float(cos), float(sin) of the seed's angle: correctly rounded per pixel by k_lsd_keys (NaN: not certified) */
+                        sumdx = rl_f32(win.s0.x, 24); sumdy = rl_f32(win.s0.y, 24);
+                        if (sumdx != sumdx) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
                         seeded = true;
                     }
                     sumdx += rl_f32(c.x, l);
@@ -459,7 +453,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
     Wave w;
     {
         const LsdGrowFrame f = frames[blockIdx.x];
-        w.F.ang = (const GLOBAL_AS double*)f.ang; w.F.cs = (const GLOBAL_AS float*)f.cs; w.F.mod = (const GLOBAL_AS double*)f.mod;
+        w.F.ang = (const GLOBAL_AS double*)f.ang; w.F.cs = (const GLOBAL_AS float*)f.cs; w.F.cs0 = (const GLOBAL_AS float*)f.cs0; w.F.mod = (const GLOBAL_AS double*)f.mod;
         w.F.order = (const GLOBAL_AS uint32_t*)f.order; w.F.reg = (GLOBAL_AS uint32_t*)f.reg; w.F.tmp = (GLOBAL_AS uint32_t*)f.tmp;
         w.F.rects = (GLOBAL_AS double*)f.rects; w.F.out = (GLOBAL_AS int*)f.out; w.F.nOrder = f.nOrder;
         w.F.minSeedBin = f.meta ? 1024u - (uint32_t)(f.meta[1] & 0xFFFFFFFFull) : f.minSeedBin;
@@ -578,13 +572,13 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
 }
 
 /* pseudo-ordering keys: gradient bin << 22 | y << 11 | x for the (W - 1) x (H - 1) pixels ll_angle visits, in raster order
- * (what the host sorts), and the smallest bin of a pixel that has a level-line angle (kept as 1024 - bin under atomicMax in
+ * (what the host sorts), the seed direction of every pixel with an angle, and the smallest bin of a pixel that has a level-line angle (kept as 1024 - bin under atomicMax in
  * the low half of the slot's second meta word, which the image passes zeroed).  blockIdx.z = frame slot. */
 __global__ __launch_bounds__(256) void k_lsd_keys(const double* __restrict__ mod, const double* __restrict__ ang, int W, int H,
-                                                  unsigned long long* __restrict__ meta, uint32_t* __restrict__ keys)
+                                                  unsigned long long* __restrict__ meta, uint32_t* __restrict__ keys, float2* __restrict__ cs0)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    mod += (size_t)blockIdx.z * W * H; ang += (size_t)blockIdx.z * W * H;
+    mod += (size_t)blockIdx.z * W * H; ang += (size_t)blockIdx.z * W * H; cs0 += (size_t)blockIdx.z * W * H;
     meta += 2 * (size_t)blockIdx.z; keys += (size_t)blockIdx.z * (W - 1) * (H - 1);
     uint32_t seedBin = 1024;
     if (x < W - 1) {
@@ -594,7 +588,16 @@ __global__ __launch_bounds__(256) void k_lsd_keys(const double* __restrict__ mod
         const size_t o = (size_t)y * W + x;
         const uint32_t bin = (uint32_t)(int)(mod[o] * binCoef);
         keys[(size_t)y * (W - 1) + x] = (bin << 22) | ((uint32_t)y << 11) | (uint32_t)x;
-        if (ang[o] != -1024.0) seedBin = bin;
+        const double a = ang[o];
+        if (a != -1024.0) {
+            seedBin = bin;
+            /* the direction a region starts with when this pixel seeds it: float(cos(a)), float(sin(a)), correctly rounded
+             * (cr_sincos.h) - here, for every pixel side by side, instead of inside the frame's sequential wavefront */
+            float sn, cn;
+            const bool ok = drfe_cr_sincos_f(a, &sn, &cn) != 0;
+            const float nanv = __int_as_float(0x7fc00000);
+            cs0[o] = ok ? make_float2(cn, sn) : make_float2(nanv, nanv);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) seedBin = min(seedBin, (uint32_t)__shfl_xor((int)seedBin, o));
@@ -608,10 +611,10 @@ size_t drfe_lsd_grow_lds_bytes(int W, int H)
 }
 
 hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
-                                int nframes, hipStream_t s)
+                                float2* d_cs0, int nframes, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lsd_keys, dim3((W - 1 + 255) / 256, H - 1, nframes), dim3(256), 0, s, d_mod, d_ang, W, H, d_meta, d_keys);
+    hipLaunchKernelGGL(k_lsd_keys, dim3((W - 1 + 255) / 256, H - 1, nframes), dim3(256), 0, s, d_mod, d_ang, W, H, d_meta, d_keys, d_cs0);
     return hipGetLastError();
 }
 
