@@ -382,3 +382,28 @@ def test_device_order_sort_equals_std_sort(ctx):
         assert L.drfe_debug_device_order_sort(ctx.h, dev.ctypes.data_as(C.c_void_p), len(dev), C.byref(st)) == 0
         assert L.drfe_debug_order_sort(ref.ctypes.data_as(C.c_void_p), len(ref), 0, 0, -1, 0) == 0
         assert st.value == 0 and np.array_equal(dev, ref), kind
+
+
+def test_lsd_batch_device_edge_cases(ctx):
+    """drfe_lsd_extract_batch with the sequential core on the device, on frames at the edges of what the kernels assume, all in
+    one batch: a constant image (no pixel has a level-line angle: nothing to order, no seed), uniform noise (every pixel a seed,
+    tens of thousands of one-pixel regions), a step edge (one long region: the queue phase beyond the 7 x 7 window, the
+    largest rectangle), a dense checkerboard (thousands of accepted rectangles), and an odd size.  Identical to the single-frame
+    entry (host growth)."""
+    rng = np.random.default_rng(5)
+    h, w = 480, 640
+    flat = np.full((h, w), 97, np.uint8)
+    noise = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    step = np.zeros((h, w), np.uint8); step[:, w // 2:] = 200
+    yy, xx = np.mgrid[0:h, 0:w]
+    checker = ((((yy // 12) + (xx // 12)) % 2) * 180 + 30).astype(np.uint8)
+    diag = (((xx + 2 * yy) // 40) % 2 * 150 + 40).astype(np.uint8)
+    batch = np.stack([flat, noise, step, checker, diag])
+    ctx.lsd_configure(True)
+    for frames in (batch, batch[:, :257, :333].copy()):
+        got = ctx.lsd_extract_batch(frames, n_threads=3)
+        for f in range(len(frames)):
+            a = ctx.lsd_extract(frames[f])
+            assert a["detected"] == got[f]["detected"] and a["lines"].tobytes() == got[f]["lines"].tobytes()
+            assert np.array_equal(a["desc"], got[f]["desc"]) and a["lineF"].tobytes() == got[f]["lineF"].tobytes()
+    assert len(got[0]["lines"]) == 0 and got[2]["detected"] >= 1 and got[3]["detected"] >= 40

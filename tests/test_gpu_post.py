@@ -229,3 +229,38 @@ def test_ahc_post_batch_equals_single_frame_calls(oracle_mod, camname, kind, see
         assert na.sum() >= 5
     finally:
         c.close()
+
+
+def test_ahc_post_batch_device_edge_cases():
+    """The device extractor + device voxel grids on inputs at the edges of what the kernels assume: no depth at all (no block is
+    valid: empty queue, no seeds), one fronto-parallel wall filling the image (a single plane of ~3000 blocks: the longest
+    clustering chain, a 300 000-point cloud for the voxel grid), sensor-noise depth (hundreds of tiny clusters, none with
+    support), frames in one batch that differ completely, and an odd image size (333 x 257: blocks do not tile the image).
+    Identical to the host extractor + host voxel grids in every case."""
+    from dr_slam_amd import lib, synth
+    cam = synth.TUM3
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    rng = np.random.default_rng(11)
+    h, w = cam.h, cam.w
+    wall = np.full((h, w), int(2.0 * cam.depth_factor), np.uint16)
+    tilt = (1.5 * cam.depth_factor + 3.0 * np.arange(w)[None, :] + 2.0 * np.arange(h)[:, None]).astype(np.uint16)
+    noise = rng.integers(500, 60000, (h, w)).astype(np.uint16)
+    room = next(synth.sequence(5, 1, cam=cam, kind="room_boxes"))[1]
+    half = room.copy(); half[:, w // 2:] = 0
+    batch = np.stack([np.zeros((h, w), np.uint16), wall, tilt, noise, room, half])
+    odd = np.stack([room[:257, :333].copy(), wall[:257, :333].copy()])
+    c = lib.Context(max_batch=1)
+    try:
+        for depth in (batch, odd):
+            c.planes_configure_extractor(on_device=False); c.planes_configure(device_voxel_grid=0)
+            ref = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+            c.planes_configure_extractor(on_device=True); c.planes_configure(device_voxel_grid=1)
+            got = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=3, seg=True)
+            for a, b in zip(ref, got):
+                assert a.tobytes() == b.tobytes()
+        assert ref[1][1] >= 1                   # the odd-sized wall is a plane
+        n = got and c.planes_ahc_post_batch(batch, K4, inv, 9.0, 0.10, n_threads=2)[1]
+        assert n[0] == 0 and n[1] == 1 and n[2] >= 1 and n[3] == 0 and n[4] >= 2
+    finally:
+        c.close()
