@@ -949,19 +949,31 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             for (int i = 0; i < nP && coarseReady; i++) { vcl[i] = vc[i]; if (vc[i] < 0) handedBack++; nCoarse += (size_t)(vc[i] < 0 ? jobs[i].y : vc[i]); }
             hipError_t e = hipSuccess;
             if (coarseReady) {
-                /* the centroids of every plane, packed, into the lane's pinned buffer */
-                if (l->coarseCap < nCoarse) {
+                /* ONE download for the frame: the planes' centroid ranges lie in job order inside the frame's part of d_vout, so the
+                 * span from the first plane's range to the end of the last one's centroids is fetched whole (the gaps - a plane's
+                 * unused tail - cost PCIe bytes, a copy per plane cost ten stream operations per frame, and the rate of those is what
+                 * saturates first with hundreds of frames in flight).  A plane the device handed back sends its gathered cloud. */
+                size_t at = 0;
+                const size_t first = nP ? (size_t)jobs[0].x : 0;
+                size_t spanEnd = first;
+                for (int i = 0; i < nP; i++) if (vc[i] > 0) spanEnd = std::max(spanEnd, (size_t)jobs[i].x + (size_t)vc[i]);
+                const size_t span = spanEnd - first;
+                size_t extra = 0;
+                for (int i = 0; i < nP; i++) if (vc[i] < 0) extra += (size_t)jobs[i].y;
+                if (e == hipSuccess && l->coarseCap < span + extra) {
                     if (l->h_coarse) (void)hipHostFree(l->h_coarse);
                     l->h_coarse = nullptr; l->coarseCap = 0;
-                    const size_t capPts = std::max<size_t>(nCoarse + nCoarse / 2, 1 << 15);
+                    const size_t capPts = std::max<size_t>(span + extra + (span + extra) / 2, 1 << 15);
                     e = hipHostMalloc((void**)&l->h_coarse, capPts * 12, hipHostMallocDefault);
                     if (e == hipSuccess) l->coarseCap = capPts;
                 }
-                size_t at = 0;
+                if (e == hipSuccess && span > 0) e = hipMemcpyAsync(l->h_coarse, A->d_vout + 3 * first, span * 12, hipMemcpyDeviceToHost, l->stream);
+                at = span;
                 for (int i = 0; i < nP && e == hipSuccess; i++) {
+                    if (vc[i] >= 0) { cptr[i] = l->h_coarse + 3 * ((size_t)jobs[i].x - first); continue; }
                     cptr[i] = l->h_coarse + 3 * at;
-                    const size_t cnt = (size_t)(vc[i] < 0 ? jobs[i].y : vc[i]);
-                    if (cnt > 0) e = hipMemcpyAsync(l->h_coarse + 3 * at, (vc[i] < 0 ? A->d_vpts : A->d_vout) + 3 * (size_t)jobs[i].x, cnt * 12, hipMemcpyDeviceToHost, l->stream);
+                    const size_t cnt = (size_t)jobs[i].y;
+                    if (cnt > 0) e = hipMemcpyAsync(l->h_coarse + 3 * at, A->d_vpts + 3 * (size_t)jobs[i].x, cnt * 12, hipMemcpyDeviceToHost, l->stream);
                     at += cnt;
                 }
             } else if (off[nP] > 0)
