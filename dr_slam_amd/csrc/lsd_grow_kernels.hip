@@ -51,7 +51,6 @@ __device__ __forceinline__ double rl_f64(double v, int l)
 }
 /* a wave-uniform condition as a scalar: keeps the control flow on the scalar unit and EXEC full */
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
-__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uni_d(double v)
 {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
