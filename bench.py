@@ -439,7 +439,7 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
             "lines_path": "pixel ordering, region growing, region2rect, refine on the device (k_lsd_order, k_lsd_grow: one wavefront per frame); NFA + key lines on host threads",
             "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels, plane clouds (k_ahc_blocks, k_ahc_cluster + k_ahc_refine: one wavefront per frame) and "
                            "pcl::VoxelGrid of every plane (k_voxel_grid) on the device; gates + RANSAC refit on host threads",
-            "note": "the device paths are latency chains (~0.12 s of region growing, ~0.085 s of plane extraction per frame on one wavefront): their rate is frames in "
+            "note": "the device paths are latency chains (~0.12 s of region growing, ~0.075 s of plane extraction per frame on one wavefront): their rate is frames in "
                     "flight over that latency, so steps run side by side; the host stages that remain cost ~2.2 ms (lines: NFA arithmetic, key lines) + ~0.6 ms "
                     "(planes: gates + refit) + ~0.2 ms (CAPE) of one CPU per frame (host_cpu_ms_per_frame_by_pool is the measurement)"}
 
