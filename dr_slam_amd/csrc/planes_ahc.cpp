@@ -654,6 +654,13 @@ int drfe_planes_ahc(drfe_ctx* c, const uint16_t* depth, int w, int h, size_t str
  * frames, so the batch runs on n_threads host threads with one device lane each.  Outputs per frame f:
  * planes[f * cap], n_planes[f], seg + f * w * h, member_offsets[f * (cap + 1)], member_idx + f * w * h (any of the
  * last three may be NULL).  Results equal nframes calls of drfe_planes_ahc. */
+} /* extern "C" */
+static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* pool, int T, const uint16_t* depth, size_t frame_stride, int w, int h,
+                                        size_t stride, int nframes, const float* K4, float depth_factor, float max_point_dist, double dist_threshold,
+                                        drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num,
+                                        int32_t* member_offsets, int32_t* member_idx);
+extern "C" {
+
 int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_stride, int w, int h, size_t stride, int nframes,
                           const float* K4, float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
                           int32_t* member_offsets, int32_t* member_idx, int n_threads)
@@ -675,6 +682,10 @@ int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_strid
         HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         pool->push_back(l);
     }
+    /* the extractor on the device, one wavefront per frame (drfe_planes_configure_extractor; same limits as the post batch) */
+    if (c->planesDeviceAhc && nframes > 1 && (w / AHC_WIN) * (h / AHC_WIN) <= 3200 && (size_t)w * h <= (1u << 20) && !std::getenv("DRFE_AHC_HOST"))
+        return planes_ahc_post_batch_device(c, pool, T, depth, frame_stride, w, h, stride, nframes, K4, depth_factor, 0.f, 0.0, planes, cap, n_planes, seg,
+                                            nullptr, nullptr, nullptr, member_offsets, member_idx);
     std::vector<int> rcs(T, DRFE_OK);
     std::vector<std::thread> th;
     th.reserve(T);
@@ -853,6 +864,7 @@ struct AhcBatchJob {
     const uint16_t* depth; size_t frameStride, stride; int w, h, nframes, cap;
     const float* K4; float depthFactor, maxPointDist; double distThreshold;
     drfe_plane* planes; int* nPlanes; uint8_t* seg; drfe_plane_post* post; int* nAccepted; int* planeNum;
+    int32_t* memberOffsets; int32_t* memberIdx;      /* drfe_planes_ahc_batch (post == null): the member lists go to the caller */
     int chunk, nChunks;
     bool voxDevice;          /* k_voxel_grid ran behind the extractor: the workers fetch centroids instead of member lists */
     std::vector<hipStream_t> chunkStream; std::vector<hipEvent_t> chunkDone; std::vector<int> chunkState;   /* 1 = on the device, 3 = a worker fetches its results, 2 = released */
@@ -976,10 +988,10 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
                     if (cnt > 0) e = hipMemcpyAsync(l->h_coarse + 3 * at, A->d_vpts + 3 * (size_t)jobs[i].x, cnt * 12, hipMemcpyDeviceToHost, l->stream);
                     at += cnt;
                 }
-            } else if (off[nP] > 0)
+            } else if (off[nP] > 0 && (J.post || J.memberIdx))
                 e = hipMemcpyAsync(idx.data(), slot + A->offMemberIdx, sizeof(int) * (size_t)off[nP], hipMemcpyDeviceToHost, l->stream);
             if (e == hipSuccess && J.seg) e = hipMemcpyAsync(J.seg + f * px, slot + A->offSeg, px, hipMemcpyDeviceToHost, l->stream);
-            if (e == hipSuccess && (nCoarse > 0 || !coarseReady || J.seg)) e = drfe_pool_sync(l->stream, ev);
+            if (e == hipSuccess && (nCoarse > 0 || (!coarseReady && (J.post || J.memberIdx)) || J.seg)) e = drfe_pool_sync(l->stream, ev);
             if (e != hipSuccess) { l->err = std::string("planes batch: results of a frame: ") + hipGetErrorString(e); rc = DRFE_ERR_HIP; }
             if (rc == DRFE_OK && coarseReady && handedBack) {
                 J.voxFallbacks += handedBack;
@@ -999,7 +1011,12 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
                 viaCoarse = true;
             }
         }
-        if (rc == DRFE_OK && !viaCoarse)
+        if (rc == DRFE_OK && !J.post) {
+            /* drfe_planes_ahc_batch: the extractor's outputs only */
+            const int np = J.nPlanes[f];
+            if (J.memberOffsets) std::memcpy(J.memberOffsets + (size_t)f * (J.cap + 1), off.data(), sizeof(int32_t) * (size_t)(np + 1));
+            if (J.memberIdx && off[np] > 0) std::memcpy(J.memberIdx + f * px, idx.data(), sizeof(int32_t) * (size_t)off[np]);
+        } else if (rc == DRFE_OK && !viaCoarse)
             rc = drfe_ahc_post_core(&l->err, d, J.w, J.h, J.stride, J.K4, J.depthFactor, pl, J.nPlanes[f], off.data(), idx.data(), J.maxPointDist,
                                     J.distThreshold, J.post + (size_t)f * J.cap, nullptr, voff.data(), 0, &J.nAccepted[f],
                                     J.planeNum ? &J.planeNum[f] : nullptr, nullptr);
@@ -1013,7 +1030,8 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
 
 static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* pool, int T, const uint16_t* depth, size_t frame_stride, int w, int h,
                                         size_t stride, int nframes, const float* K4, float depth_factor, float max_point_dist, double dist_threshold,
-                                        drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num)
+                                        drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num,
+                                        int32_t* member_offsets, int32_t* member_idx)
 {
     int rc = ensure_arena(c, w, h, nframes, K4, depth_factor, max_point_dist);
     if (rc != DRFE_OK) return rc;
@@ -1022,13 +1040,14 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
     J.c = c; J.A = A; J.pool = pool; J.depth = depth; J.frameStride = frame_stride; J.stride = stride; J.w = w; J.h = h; J.nframes = nframes; J.cap = cap;
     J.K4 = K4; J.depthFactor = depth_factor; J.maxPointDist = max_point_dist; J.distThreshold = dist_threshold;
     J.planes = planes; J.nPlanes = n_planes; J.seg = seg; J.post = post; J.nAccepted = n_accepted; J.planeNum = plane_num;
+    J.memberOffsets = member_offsets; J.memberIdx = member_idx;
     /* chunks (= low-priority streams = hardware queues) of this call: the runtime has four queues per priority, and the line and the
      * plane batch of a front-end step run side by side - two each (DRFE_BATCH_CHUNKS overrides) */
     static const int nch = [] { const char* e = std::getenv("DRFE_BATCH_CHUNKS"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }();
     J.chunk = std::max(1, std::min(nframes, std::max(16, (nframes + nch - 1) / nch)));
     J.nChunks = (nframes + J.chunk - 1) / J.chunk;
     J.pending = nframes;
-    J.voxDevice = c->planesDeviceVoxel != 0 && !std::getenv("DRFE_VOXEL_HOST");
+    J.voxDevice = post != nullptr && c->planesDeviceVoxel != 0 && !std::getenv("DRFE_VOXEL_HOST");
     J.chunkStream.resize(J.nChunks); J.chunkDone.resize(J.nChunks); J.chunkState.assign(J.nChunks, 0);
     int prLow = 0, prHigh = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
@@ -1153,7 +1172,7 @@ int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_
      * blocks and its pixel index 20 bits) */
     if ((c->planesDeviceAhc) && (w / AHC_WIN) * (h / AHC_WIN) <= 3200 && (size_t)w * h <= (1u << 20) && !std::getenv("DRFE_AHC_HOST"))
         return planes_ahc_post_batch_device(c, pool, T, depth, frame_stride, w, h, stride, nframes, K4, depth_factor, max_point_dist, dist_threshold, planes,
-                                            cap, n_planes, seg, post, n_accepted, plane_num);
+                                            cap, n_planes, seg, post, n_accepted, plane_num, nullptr, nullptr);
     std::vector<int> rcs(T, DRFE_OK);
     std::vector<std::thread> th;
     th.reserve(T);

@@ -568,9 +568,10 @@ typedef struct drfe_plane {
 int drfe_planes_ahc(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
                     float depth_factor, drfe_plane* planes, int cap, int* n_planes, uint8_t* seg,
                     int32_t* member_offsets, int32_t* member_idx);
-/* drfe_planes_ahc for nframes host depth images (depth + f * frame_stride elements): the block fits take
- * microseconds on the device, the per-frame clustering / erosion / flood fill (~7 ms) is sequential host code that is
- * independent between frames and runs on n_threads host threads, one device lane each.  Outputs per frame f at
+/* drfe_planes_ahc for nframes host depth images (depth + f * frame_stride elements).  Default (drfe_planes_configure_extractor
+ * (ctx, 1), frames up to 640 x 480 class, nframes > 1): clustering / flood fill / re-merge run on the device, one wavefront per
+ * frame (ahc_frame_kernels.hip), the n_threads host threads only fetch results; otherwise the per-frame sequential host code
+ * (~3.5 ms) runs on n_threads host threads, one device lane each.  Outputs per frame f at
  * planes[f * cap], n_planes[f], seg + f * w * h, member_offsets[f * (cap + 1)], member_idx + f * w * h (the last three
  * may be NULL); identical to nframes single calls.  n_threads <= 0: 1.25 x the CPUs this process may use (affinity mask clipped by
  * the cgroup quota). */

@@ -91,15 +91,18 @@ def test_no_depth_gives_no_planes(ctx, oracle_mod):
 
 
 def test_ahc_batch_equals_single(ctx):
-    """drfe_planes_ahc_batch (host thread pool, one device lane per thread) == per-frame calls, any thread count."""
+    """drfe_planes_ahc_batch - the extractor on the device, one wavefront per frame (default), or on the host thread pool -
+    == per-frame calls (host extractor), any thread count: planes, label images, member lists."""
     from dr_slam_amd import synth
     cam = synth.TUM3
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
     depth = np.stack([f[1] for f in synth.sequence(2, 5, kind="room_boxes")] + [next(synth.sequence(5, 1, kind="corridor"))[1]])
     single = [ctx.planes_ahc(d, K4, inv) for d in depth]
-    for threads in (1, 4, 16):
+    for threads, on_device in ((1, True), (4, True), (16, True), (4, False)):
+        ctx.planes_configure_extractor(on_device=on_device)
         batch = ctx.planes_ahc_batch(depth, K4, inv, n_threads=threads)
+        ctx.planes_configure_extractor(on_device=True)
         for a, b in zip(batch, single):
             assert len(a["planes"]) == len(b["planes"]) >= 2
             assert np.array_equal(a["planes"].view(np.uint8), b["planes"].view(np.uint8))
