@@ -626,7 +626,6 @@ static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int f
         LCHK(hipMalloc((void**)&s->d_frames, F * sizeof(LsdGrowFrame)));
         LCHK(hipMalloc((void**)&s->d_ordStatus, F * sizeof(int)));
         LCHK(hipHostMalloc((void**)&s->h_ordStatus, F * sizeof(int), hipHostMallocDefault));
-        LCHK(hipHostMalloc((void**)&s->h_order, nk * 4, hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_meta, 16 * F, hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_rects, F * s->rectCap * sizeof(LsdRect), hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_out, F * DRFE_LSD_OUT_INTS * sizeof(int), hipHostMallocDefault));
@@ -1079,6 +1078,8 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     J.chunk = chunk; J.nChunks = nChunks;
     J.pendingFinish = nframes;
     J.deviceOrder = std::getenv("DRFE_LSD_HOST_ORDER") == nullptr;
+    if (!J.deviceOrder && !A->h_order)           /* the host-ordering experiment's pinned key mirror (0.4 GB per 512 frames): on demand */
+        HIPCHK(c, hipHostMalloc((void**)&A->h_order, (size_t)(A->sw - 1) * (A->sh - 1) * (size_t)A->frames * 4, hipHostMallocDefault));
     const RectValidator val(A->sw, A->sh);
     J.prec = M_PI * 22.5 / 180; J.p = 22.5 / 180; J.minReg = (int)val.minReg(J.p);
     for (int ch = 0; ch < nChunks; ch++) J.sortedInChunk[ch].store(0);
