@@ -360,7 +360,7 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
     split["planes"] = max(1, nthr - split["lines"])
     if os.environ.get("DRFE_FF_SPLIT"):              # experiments: "lines,planes" per step in flight
         split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
-    n_cape = 2                       # CAPE lanes (host threads of drfe_planes_cape_batch)
+    n_cape = int(os.environ.get("DRFE_FF_CAPE", 2))   # CAPE lanes (host threads of drfe_planes_cape_batch)
     lanes = []
     for _ in range(inflight):
         lanes.append({"fe": FrontEnd(cam, max_batch=n_frames), "planes": lib.Context(max_batch=1), "cape": lib.Context(max_batch=1),
