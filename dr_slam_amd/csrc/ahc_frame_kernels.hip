@@ -13,7 +13,7 @@
  *   - block membership, seeds, relabelling, member lists are data-parallel passes with ballot / popcount prefix sums;
  *   - the flood fill evaluates the four neighbours of a queue entry in four lanes (depth -> point -> distance to the plane),
  *     then applies them in the reference's order.
- * The priority queue lives in LDS (its size never exceeds the number of init blocks); nodes, neighbour lists, the union-find,
+ * The priority queue lives in LDS (its size never exceeds the number of init blocks; keys as floats, exact ties from the nodes); nodes, neighbour lists, the union-find,
  * membership / distance maps and the flood-fill queue are in HBM.  Throughput comes from frames in flight: a launch carries one
  * wavefront per frame.  Overflowing any fixed capacity (neighbour pool, queue, planes) or an uncertified cosine flags the
  * frame and the host redoes it. */
@@ -59,46 +59,63 @@ struct Ctx {
     GLOBAL_AS int* dsParent; GLOBAL_AS int* dsSize; GLOBAL_AS int* G; GLOBAL_AS int* blkMap; GLOBAL_AS int* ridToPlid;
     GLOBAL_AS int16_t* mem; GLOBAL_AS float* dist; GLOBAL_AS uint32_t* rf;
     /* LDS */
-    double* heapKey; uint16_t* heapId; int* lA; int* lB; int* lU; double* win;
+    float* heapKey; uint16_t* heapId; int* lA; int* lB; int* lU; double* win;
     int heapSize, nNodes, poolUsed, status, lane;
     AhcDevParams P;
 };
 
 /* --- priority queue: smallest MSE first, ties by the smaller node id (QCmp of planes_ahc.cpp; a total order, so the pop
  * sequence does not depend on the heap's internals).  Called by lane 0 only. */
-__device__ __forceinline__ bool heap_less(double ka, int ia, double kb, int ib) { return ka < kb || (ka == kb && ia < ib); }
+/* The queue keeps the keys as FLOATS (half the LDS: the clustering kernel's footprint decides how many frames a CU holds):
+ * rounding to float is monotone, so two different floats order the doubles; equal floats (the doubles agree to 24 bits: rare)
+ * are settled by the exact MSEs, which every node keeps in its fit record. */
+__device__ __forceinline__ double heap_exact(const Ctx& c, int id) { return c.fit[8 * (size_t)id + 6]; }
+__device__ __forceinline__ bool heap_less(const Ctx& c, float ka, int ia, float kb, int ib)
+{
+    if (ka != kb) return ka < kb;
+    const double da = heap_exact(c, ia), db = heap_exact(c, ib);
+    return da < db || (da == db && ia < ib);
+}
+/* (key, id) not in the node's record yet, or just written: its exact key comes along */
+__device__ __forceinline__ bool heap_less_new(const Ctx& c, double key, float kf, int id, float kb, int ib)
+{
+    if (kf != kb) return kf < kb;
+    const double db = heap_exact(c, ib);
+    return key < db || (key == db && id < ib);
+}
 __device__ void heap_push(Ctx& c, double key, int id)
 {
+    const float kf = (float)key;
     int i = c.heapSize++;
     while (i > 0) {
         const int p = (i - 1) >> 1;
-        const double kp = c.heapKey[p];
+        const float kp = c.heapKey[p];
         const int ip = c.heapId[p];
-        if (!heap_less(key, id, kp, ip)) break;
+        if (!heap_less_new(c, key, kf, id, kp, ip)) break;
         c.heapKey[i] = kp; c.heapId[i] = (uint16_t)ip;
         i = p;
     }
-    c.heapKey[i] = key; c.heapId[i] = (uint16_t)id;
+    c.heapKey[i] = kf; c.heapId[i] = (uint16_t)id;
 }
 __device__ int heap_pop(Ctx& c)
 {
     const int top = c.heapId[0];
     const int n = --c.heapSize;
     if (n > 0) {
-        const double key = c.heapKey[n];
+        const float key = c.heapKey[n];
         const int id = c.heapId[n];
         int i = 0;
         for (;;) {
             int ch = 2 * i + 1;
             if (ch >= n) break;
-            double kc = c.heapKey[ch];
+            float kc = c.heapKey[ch];
             int ic = c.heapId[ch];
             if (ch + 1 < n) {
-                const double k2 = c.heapKey[ch + 1];
+                const float k2 = c.heapKey[ch + 1];
                 const int i2 = c.heapId[ch + 1];
-                if (heap_less(k2, i2, kc, ic)) { ch++; kc = k2; ic = i2; }
+                if (heap_less(c, k2, i2, kc, ic)) { ch++; kc = k2; ic = i2; }
             }
-            if (!heap_less(kc, ic, key, id)) break;
+            if (!heap_less(c, kc, ic, key, id)) break;
             c.heapKey[i] = kc; c.heapId[i] = (uint16_t)ic;
             i = ch;
         }
@@ -375,7 +392,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
 
 extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
 {
-    __shared__ double heapKey[AHCD_HEAP];
+    __shared__ float heapKey[AHCD_HEAP];
     __shared__ uint16_t heapId[AHCD_HEAP];
     __shared__ int lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
     __shared__ double win[18];
@@ -421,7 +438,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
                 c.fit[8 * (size_t)id + 6] = blocks[b].mse; c.fit[8 * (size_t)id + 7] = blocks[b].curvature;
                 c.N[id] = blocks[b].N; c.rid[id] = b; c.nouse[id] = 0;
                 c.nbOff[id] = 4 * id; c.nbLen[id] = 0;
-                heapKey[id] = blocks[b].mse; heapId[id] = (uint16_t)id;
+                heapKey[id] = (float)blocks[b].mse; heapId[id] = (uint16_t)id;
             } else c.G[b] = -1;
         }
         c.nNodes += __popcll(m);
@@ -432,16 +449,16 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
     if (lane == 0) {                                   /* heapify */
         const int n = c.heapSize;
         for (int s = n / 2 - 1; s >= 0; s--) {
-            const double key = heapKey[s];
+            const float key = heapKey[s];
             const int id = heapId[s];
             int i = s;
             for (;;) {
                 int ch = 2 * i + 1;
                 if (ch >= n) break;
-                double kc = heapKey[ch];
+                float kc = heapKey[ch];
                 int ic = heapId[ch];
-                if (ch + 1 < n && heap_less(heapKey[ch + 1], heapId[ch + 1], kc, ic)) { ch++; kc = heapKey[ch]; ic = heapId[ch]; }
-                if (!heap_less(kc, ic, key, id)) break;
+                if (ch + 1 < n && heap_less(c, heapKey[ch + 1], heapId[ch + 1], kc, ic)) { ch++; kc = heapKey[ch]; ic = heapId[ch]; }
+                if (!heap_less(c, kc, ic, key, id)) break;
                 heapKey[i] = kc; heapId[i] = (uint16_t)ic;
                 i = ch;
             }
@@ -573,7 +590,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
  * is what the line path's growth (27 KB per frame) cannot use. */
 extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
 {
-    __shared__ double heapKey[AHCD_MAXEX];                    /* the re-merge's queue: at most the extracted planes */
+    __shared__ float heapKey[AHCD_MAXEX];                     /* the re-merge's queue: at most the extracted planes */
     __shared__ uint16_t heapId[AHCD_MAXEX];
     __shared__ int lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
     __shared__ double win[18];
