@@ -42,6 +42,9 @@ __device__ __forceinline__ double rl_d(double v, int l)
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool uni_b(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+/* ordering between the LDS accesses of this one wavefront: the LDS serves a wavefront's instructions in order, so only the compiler
+ * must not move them - no wait for the global stores in flight (the workgroup fence waits for those: ~1 us each) */
+__device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 struct SinCosR { double s, c; int ok; };
 __device__ __noinline__ SinCosR cr_cos_call(double x)
@@ -795,18 +798,24 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
     const float maxPointDist = P.maxPointDist;
     for (int i = lane; i <= nFinal; i += 64) kcounts[i] = 0;
     fence();
+    /* both passes fetch the next chunk's label and depth while they work on the current one: a chunk is a handful of ballots,
+     * and without the prefetch every chunk waits a full round trip for its two loads */
+    auto depth_at = [&](int k) -> uint16_t { const int row = k / w, col = k - row * w; return c.depth[(size_t)row * c.rowStride + col]; };
+    int rawNext = lane < npx ? (int)c.mem[lane] : -1;
+    uint16_t depNext = lane < npx ? depth_at(lane) : (uint16_t)0;
     for (int base = 0; base < npx; base += 64) {
         const int k = base + lane;
+        const int raw = rawNext;
+        const uint16_t dep = depNext;
+        if (k + 64 < npx) { rawNext = c.mem[k + 64]; depNext = depth_at(k + 64); }
         int pl = -1;
         bool keep = false;
         if (k < npx) {
-            const int raw = c.mem[k];
             pl = raw >= 0 ? plidmap[raw] : -1;
             c.mem[k] = (int16_t)pl;
             seg[k] = (uint8_t)(pl + 1);
             if (pl >= 0) {
-                const int row = k / w, col = k - row * w;
-                double z = (double)c.depth[(size_t)row * c.rowStride + col] * gfactor;
+                double z = (double)dep * gfactor;
                 if (z > 5.0) z = 0.0;
                 keep = !((float)z > maxPointDist);
             }
@@ -833,15 +842,19 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
         if (jobs) for (int i = 0; i < nFinal; i++) { jobs[2 * i] = F.ptsBase + kcounts[i]; jobs[2 * i + 1] = kcounts[i + 1] - kcounts[i]; }
     }
     fence();
+    rawNext = lane < npx ? (int)c.mem[lane] : -1;
+    depNext = lane < npx ? depth_at(lane) : (uint16_t)0;
     for (int base = 0; base < npx; base += 64) {
         const int k = base + lane;
-        const int pl = k < npx ? (int)c.mem[k] : -1;
+        const int pl = k < npx ? rawNext : -1;
+        const uint16_t dep = depNext;
+        if (k + 64 < npx) { rawNext = c.mem[k + 64]; depNext = depth_at(k + 64); }
         bool keep = false;
         float X = 0.f, Y = 0.f, Z = 0.f;
         if (pl >= 0 && pts) {
             /* PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:39-52): doubles, K floats promoted; the cloud holds floats */
             const int row = k / w, col = k - row * w;
-            const double z = (double)c.depth[(size_t)row * c.rowStride + col] * gfactor;
+            const double z = (double)dep * gfactor;
             if (!(z > 5.0)) {
                 X = (float)(((double)col - gcx) * z / gfx);
                 Y = (float)(((double)row - gcy) * z / gfy);
@@ -862,11 +875,11 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
                     pts[q] = X; pts[q + 1] = Y; pts[q + 2] = Z;
                 }
             }
-            fence();
+            wave_order();
             if (lane == l) { counts[v] += __popcll(same); kcounts[v] += __popcll(same & kept); }
             todo &= ~same;
         }
-        fence();
+        wave_order();
     }
     TP();
     if (lane == 0) { out[0] = nFinal; out[1] = 0; out[2] = rfTotal; out[3] = c.nNodes; }
