@@ -160,7 +160,8 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
 
 /* a[0..n) into std::sort's order (the NTH threads of the workgroup call this together).  posL / posR: n uint32 each; tmp: n records
  * (ping-pong buffer of the counting passes); dyn: ORD_DYN_LDS_BYTES(NTH) of LDS; keyBits: significant bits of the keys present.
- * Returns (to every thread) 0, or bit 0 = heap sort needed, bit 1 = internal queue overflow: result unusable. */
+ * Returns (to every thread) 0, or bit 0 = heap sort needed, bit 1 = internal queue overflow or a loop bound exceeded (bits 2-4: which):
+ * result unusable. */
 template <int NTH, class T>
 __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, uint32_t* posR, typename T::Rec* tmp, uint32_t* dyn, Shared<NTH>& sh,
                                     int depthLimit, int keyBits)
@@ -174,6 +175,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
     __syncthreads();
 
     /* ---- ranges above ORD_BIG: the workgroup partitions them one after the other ---- */
+    uint32_t wgIter = 0;
     for (;;) {
         if (tid == 0) {
             int found = -1;
@@ -183,15 +185,24 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
         }
         __syncthreads();
         if (!sh.cutShared) break;
+        /* every data-dependent loop of this routine carries a bound far above what a correct run needs: a workgroup that ran past it
+         * would otherwise hold its CU for ever (bit 2 / 3 / 4 of the status: which loop) */
+        if (++wgIter > 4u * ORD_QCAP + 64u) { if (tid == 0) sh.qOverflow |= 4; break; }
         const Seg s = sh.queue[sh.qHead - 1];
         __syncthreads();
-        if (s.depth == 0) { if (tid == 0) sh.heapNeeded = 1; continue; }
-        if (tid == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
-        __syncthreads();
-        const uint32_t cut = hoare_cut<NTH, T>(a, s.first, s.last, posL, posR, tid, sh.wcnt);
-        if (tid == 0) {
-            if (s.last - cut > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = cut; sh.queue[sh.qTail].last = s.last; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow = 1; }
-            if (cut - s.first > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = s.first; sh.queue[sh.qTail].last = cut; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow = 1; }
+        /* every thread runs the same barriers on both arms and meets the others at the one below: no `continue` around it.  (With a
+         * `continue` here a workgroup stopped for good the first time a range above ORD_BIG ran out of depth - a 10 270-record
+         * range of a 12 905-point plane cloud, found by a parity soak; ranges that run out of depth in the wavefront phase, the
+         * common case, were never affected.) */
+        if (s.depth == 0) { if (tid == 0) sh.heapNeeded = 1; }
+        else {
+            if (tid == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
+            __syncthreads();
+            const uint32_t cut = hoare_cut<NTH, T>(a, s.first, s.last, posL, posR, tid, sh.wcnt);
+            if (tid == 0) {
+                if (s.last - cut > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = cut; sh.queue[sh.qTail].last = s.last; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow |= 1; }
+                if (cut - s.first > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = s.first; sh.queue[sh.qTail].last = cut; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow |= 1; }
+            }
         }
         __syncthreads();
     }
@@ -205,16 +216,20 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
     Rec* lrec = (Rec*)((uint8_t*)dyn + (size_t)wv * LBYTES);
     uint16_t* lposL = (uint16_t*)(lrec + LCAP);
     uint16_t* lposR = lposL + LCAP;
-    for (;;) {
+    uint32_t waveIter = 0;
+    const uint32_t waveMax = 8u * (uint32_t)n + 4096u;           /* partitions one wavefront can legitimately run: far fewer */
+    bool runaway = false;
+    for (; !runaway;) {
         int q = 0;
         if (lane == 0) q = atomicAdd(&sh.qHead, 1);
         q = __builtin_amdgcn_readfirstlane(q);
         if (q >= sh.qTail) break;                               /* qTail is final: only the stage above appends */
         int sp = 0;
         Seg s = sh.queue[q];
-        for (;;) {
+        for (; !runaway;) {
             /* std::__introsort_loop on s */
             while (s.last - s.first > 16) {
+                if (++waveIter > waveMax) { if (lane == 0) sh.qOverflow |= 8; runaway = true; break; }
                 if (s.depth == 0) { if (lane == 0) sh.heapNeeded = 1; break; }
                 const uint32_t m = s.last - s.first;
                 if (m <= LCAP) {
@@ -222,8 +237,9 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     const int base = sp;
                     Seg t; t.first = 0; t.last = m; t.depth = s.depth;
-                    for (;;) {
+                    for (; !runaway;) {
                         while (t.last - t.first > 16) {
+                            if (++waveIter > waveMax) { if (lane == 0) sh.qOverflow |= 16; runaway = true; break; }
                             if (t.depth == 0) { if (lane == 0) sh.heapNeeded = 1; break; }
                             t.depth--;
                             if (lane == 0) median_to_first<T>(lrec, t.first, t.first + 1, t.first + (t.last - t.first) / 2, t.last - 1);
@@ -233,7 +249,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                                 if (sp < ORD_STACK) {
                                     if (lane == 0) { sh.stack[wv][sp].first = cut; sh.stack[wv][sp].last = t.last; sh.stack[wv][sp].depth = t.depth; }
                                     sp++;
-                                } else if (lane == 0) sh.qOverflow = 1;
+                                } else if (lane == 0) sh.qOverflow |= 1;
                             }
                             t.last = cut;
                         }
@@ -253,7 +269,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                     if (sp < ORD_STACK) {
                         if (lane == 0) { sh.stack[wv][sp].first = cut; sh.stack[wv][sp].last = s.last; sh.stack[wv][sp].depth = s.depth; }
                         sp++;
-                    } else if (lane == 0) sh.qOverflow = 1;
+                    } else if (lane == 0) sh.qOverflow |= 1;
                 }
                 s.last = cut;
             }
@@ -302,7 +318,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
         __syncthreads();
     }
     ISD_TP(2);
-    return (sh.heapNeeded ? 1 : 0) | (sh.qOverflow ? 2 : 0);
+    return (sh.heapNeeded ? 1 : 0) | (sh.qOverflow ? 2 : 0) | (sh.qOverflow & ~3);
 }
 
 } // namespace isd

@@ -995,6 +995,10 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             if (e != hipSuccess) { l->err = std::string("planes batch: results of a frame: ") + hipGetErrorString(e); rc = DRFE_ERR_HIP; }
             if (rc == DRFE_OK && coarseReady && handedBack) {
                 J.voxFallbacks += handedBack;
+                static const bool traceBack = std::getenv("DRFE_TRACE_PLANES") != nullptr;
+                if (traceBack)
+                    for (int i = 0; i < nP; i++)
+                        if (vc[i] < 0) std::fprintf(stderr, "frame %d plane %d (%d points): voxel grid handed back by the device, code %d (-1 grid beyond int32, -2 heap-sort branch, <= -9 loop bound)\n", f, i, jobs[i].y, vc[i]);
                 redo.resize((size_t)handedBack);
                 int r = 0;
                 for (int i = 0; i < nP; i++)

@@ -150,7 +150,7 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
 #ifdef VOX_PROFILE
     if (st != 0 && tid == 0) { atomicAdd(&g_voxTail[3], wall_clock64() - voxT0); atomicAdd(&g_voxTail[4], 1ull); atomicAdd(&g_voxXcd[17], ~0ull); }
 #endif
-    if (st != 0) { if (tid == 0) counts[jb] = -2; continue; }
+    if (st != 0) { if (tid == 0) counts[jb] = (st & ~3) ? -(8 + (st >> 2)) : -2; continue; }       /* -2: heap-sort branch; <= -9: a loop bound */
     /* leaves = runs of equal keys: heads numbered by prefix sums, head positions to posL */
     uint32_t* heads = posL + off;
     int total = 0;
@@ -172,7 +172,9 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
     /* centroid of a leaf: its points added in sorted order (float), divided by the count */
     float* O = out + 3 * (size_t)off;
     for (int r = tid; r < total; r += VOX_T) {
-        const uint32_t first = heads[r], last = r + 1 < total ? heads[r + 1] : (uint32_t)n;
+        const uint32_t first = heads[r];
+        uint32_t last = r + 1 < total ? heads[r + 1] : (uint32_t)n;
+        if (last > (uint32_t)n) last = (uint32_t)n;
         float ax = 0.f, ay = 0.f, az = 0.f;
         for (uint32_t p = first; p < last; p++) {
             const uint32_t i = (uint32_t)a[p];

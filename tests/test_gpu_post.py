@@ -264,3 +264,29 @@ def test_ahc_post_batch_device_edge_cases():
         assert n[0] == 0 and n[1] == 1 and n[2] >= 1 and n[3] == 0 and n[4] >= 2
     finally:
         c.close()
+
+
+@pytest.mark.timeout(180)
+def test_voxel_sort_runs_out_of_depth_in_the_workgroup_phase():
+    """Regression (found by tools/parity_soak_batch.py at 256 frames per scene kind): the fourth plane of this frame is a
+    12 905-point cloud whose leaf indices drive libstdc++'s introsort to its depth limit while a range is still above the
+    8192 records the WORKGROUP partitions (the usual place to run out of depth is a wavefront's small range).  The device
+    sort must flag it and hand the cloud back - it used to stop the workgroup for good - and the results must equal the host's."""
+    from dr_slam_amd import lib, synth
+    cam = synth.TUM3
+    frames = list(synth.sequence(3000 + 17 * 2 + 200, 8, cam=cam, kind="living_room", start=0))
+    depth = frames[7][1][None]
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    c = lib.Context(max_batch=1)
+    try:
+        c.planes_configure_extractor(on_device=False); c.planes_configure(device_voxel_grid=0)
+        ref = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=1, seg=True)
+        for extractor, vox in ((True, 1), (False, 2)):
+            c.planes_configure_extractor(on_device=extractor); c.planes_configure(device_voxel_grid=vox)
+            got = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=1, seg=True)
+            for a, b in zip(ref, got):
+                assert a.tobytes() == b.tobytes()
+        assert ref[1][0] == 6 and ref[2]["n_voxels"][0, 3] == 127
+    finally:
+        c.close()

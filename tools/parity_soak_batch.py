@@ -29,6 +29,8 @@ def main():
         frames = []
         for s in range(0, per_kind, 8):                       # eight consecutive frames of several seeded sequences
             frames += list(synth.sequence(3000 + 17 * ki + s, min(8, per_kind - s), cam=cam, kind=kind, start=(s * 3) % 24))
+            if s % 64 == 56:
+                print(f"  {kind}: {len(frames)} frames rendered", flush=True)
         gray = np.stack([f[0] for f in frames]); depth = np.stack([f[1] for f in frames])
         depth_m = depth.astype(np.float32) * np.float32(inv)
         B = len(frames)
@@ -37,6 +39,8 @@ def main():
         planes, n, post, na, pn, seg = ctx.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=8, seg=True)
         cplanes, cn, cseg = ctx.planes_cape_batch(depth_m, K4, 20, n_threads=4, seg=True)
         for f in range(B):
+            if f % 64 == 63:
+                print(f"  {kind}: {f + 1} frames compared", flush=True)
             a = ctx.lsd_extract(gray[f])
             ok = a["detected"] == lb[f]["detected"] and a["lines"].tobytes() == lb[f]["lines"].tobytes() and \
                 np.array_equal(a["desc"], lb[f]["desc"]) and a["lineF"].tobytes() == lb[f]["lineF"].tobytes()
