@@ -2,7 +2,7 @@
 """Parity soak of the frame-batch entries whose sequential cores run on the device (drfe_lsd_extract_batch,
 drfe_planes_ahc_post_batch, drfe_planes_cape_batch) against the single-frame entries - the path tools/parity_soak_aux.py and the
 -m gpu tests hold to the CPU oracle - over many seeded frames of every scene kind, and how many frames the device handed back
-to the host.  Run on a GPU box: python tools/parity_soak_batch.py [frames per scene kind]   (DRFE_TRACE_LINES / _PLANES=1: counts)"""
+to the host.  Run on a GPU box: python tools/parity_soak_batch.py [frames per scene kind] [first seed]   (DRFE_TRACE_LINES / _PLANES=1: counts)"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 def main():
     from dr_slam_amd import lib, synth
     per_kind = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 3000          # other seeds: other sequences
     kinds = ["room_boxes", "planar_lowtexture", "living_room", "corridor"]
     cams = [synth.TUM3, synth.ICL]
     ctx = lib.Context(max_batch=1)
@@ -28,7 +29,7 @@ def main():
         inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
         frames = []
         for s in range(0, per_kind, 8):                       # eight consecutive frames of several seeded sequences
-            frames += list(synth.sequence(3000 + 17 * ki + s, min(8, per_kind - s), cam=cam, kind=kind, start=(s * 3) % 24))
+            frames += list(synth.sequence(seed0 + 17 * ki + s, min(8, per_kind - s), cam=cam, kind=kind, start=(s * 3) % 24))
             if s % 64 == 56:
                 print(f"  {kind}: {len(frames)} frames rendered", flush=True)
         gray = np.stack([f[0] for f in frames]); depth = np.stack([f[1] for f in frames])
