@@ -2,7 +2,7 @@
 """Parity soak of the frame-batch entries whose sequential cores run on the device (drfe_lsd_extract_batch,
 drfe_planes_ahc_post_batch, drfe_planes_cape_batch) against the single-frame entries - the path tools/parity_soak_aux.py and the
 -m gpu tests hold to the CPU oracle - over many seeded frames of every scene kind, and how many frames the device handed back
-to the host.  Run on a GPU box: python tools/parity_soak_batch.py [frames per scene kind] [first seed]   (DRFE_TRACE_LINES / _PLANES=1: counts)"""
+to the host.  Run on a GPU box: python tools/parity_soak_batch.py [frames per scene kind] [first seed] [image scale]   (DRFE_TRACE_LINES / _PLANES=1: counts)"""
 import os
 import sys
 import time
@@ -17,6 +17,7 @@ def main():
     from dr_slam_amd import lib, synth
     per_kind = int(sys.argv[1]) if len(sys.argv) > 1 else 48
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 3000          # other seeds: other sequences
+    scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0           # camera / image scale (0.5: 320 x 240)
     kinds = ["room_boxes", "planar_lowtexture", "living_room", "corridor"]
     cams = [synth.TUM3, synth.ICL]
     ctx = lib.Context(max_batch=1)
@@ -24,7 +25,7 @@ def main():
     total = 0
     t0 = time.time()
     for ki, kind in enumerate(kinds):
-        cam = cams[ki % 2]
+        cam = cams[ki % 2] if scale == 1.0 else cams[ki % 2].scaled(scale)
         K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
         inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
         frames = []
