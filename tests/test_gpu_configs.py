@@ -198,3 +198,60 @@ def test_config4_rank_workload_batched(oracle_mod, rank):
         assert total > 100 * (n - 1)
     finally:
         fe.ctx.close()
+
+
+def test_batch_entries_of_three_contexts_side_by_side():
+    """What bench.py's full_frontend does - steps in flight on separate contexts, each running its line, plane and CAPE batch on
+    its own threads at the same time - must give every context the results it gets alone (no state shared between contexts)."""
+    import threading
+    from dr_slam_amd import lib, synth
+    cams = [synth.ICL, synth.TUM3, synth.ICL]
+    kinds = ["living_room", "room_boxes", "corridor"]
+    data = []
+    for k in range(3):
+        frames = list(synth.sequence(40 + k, 6, cam=cams[k], kind=kinds[k]))
+        cam = cams[k]
+        K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+        inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+        gray = np.stack([f[0] for f in frames]); depth = np.stack([f[1] for f in frames])
+        data.append((gray, depth, depth.astype(np.float32) * np.float32(inv), K4, inv))
+    ctxs = [lib.Context(max_batch=1) for _ in range(3)]
+
+    def run(k, out):
+        gray, depth, depth_m, K4, inv = data[k]
+        c = ctxs[k]
+        res = {}
+        th = [threading.Thread(target=lambda: res.__setitem__("lines", c.lsd_extract_batch(gray, n_threads=3))),
+              threading.Thread(target=lambda: res.__setitem__("planes", c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=2, seg=True))),
+              threading.Thread(target=lambda: res.__setitem__("cape", c.planes_cape_batch(depth_m, K4, 20, n_threads=2, seg=True)))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        out[k] = res
+
+    def same(a, b):
+        for la, lb in zip(a["lines"], b["lines"]):
+            assert la["lines"].tobytes() == lb["lines"].tobytes() and np.array_equal(la["desc"], lb["desc"]) and la["detected"] == lb["detected"]
+        for x, y in zip(a["planes"], b["planes"]):
+            assert x.tobytes() == y.tobytes()
+        for x, y in zip(a["cape"], b["cape"]):
+            assert x.tobytes() == y.tobytes()
+
+    try:
+        alone = {}
+        for k in range(3):
+            run(k, alone)
+        for _ in range(2):
+            together = {}
+            th = [threading.Thread(target=run, args=(k, together)) for k in range(3)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for k in range(3):
+                same(alone[k], together[k])
+        assert sum(len(l["lines"]) for l in alone[0]["lines"]) > 50 and alone[1]["planes"][1].sum() > 6
+    finally:
+        for c in ctxs:
+            c.close()
