@@ -48,6 +48,22 @@ int main(int argc, char** argv)
             if (k2.size() != kps.size() || std::memcmp(k2.data(), kps.data(), kps.size() * sizeof(drfe_cv::KeyPoint)) != 0 ||
                 std::memcmp(d2.data, desc.data, kps.size() * 32) != 0 || ur.size() != kps.size() || z.size() != kps.size()) return 6;
         }
+        {   /* one submission per tracked frame: the same image as LastFrame (slot 0) and CurrentFrame (slot 1) under the identity pose -
+             * Frame::Frame's outputs and TrackWithMotionModel's SearchByProjection(Cur, Last) from one captured graph */
+            Planar_SLAM::ORBextractor ex3(1000, 1.2f, 8, 20, 7, w, h, 0, 3);
+            const drfe_camera cam = {535.4f, 539.2f, 320.1f, 247.6f, 40.0f, 1.0f / 5000.0f, 0.0f, (float)w, 0.0f, (float)h};
+            const uint16_t* d16 = reinterpret_cast<const uint16_t*>(depth.data());
+            const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+            std::vector<drfe_cv::KeyPoint> k0, k1; drfe_cv::Mat d0, d1; std::vector<float> ur0, z0, ur1, z1; std::vector<int32_t> m;
+            ex3.Submit(0, image, d16, (size_t)w, &cam);
+            ex3.Collect(0, k0, d0, &ur0, &z0);
+            ex3.SubmitTracked(1, image, d16, (size_t)w, cam, 0, I, I, I, nullptr, 0, 15.0f, false, true);
+            const int nm = ex3.CollectTracked(1, k1, d1, ur1, z1, m);
+            if (k1.size() != kps.size() || std::memcmp(k1.data(), kps.data(), kps.size() * sizeof(drfe_cv::KeyPoint)) != 0) return 7;
+            int self = 0, valid = 0;
+            for (size_t i = 0; i < m.size(); i++) { if (m[i] >= (int)k0.size()) return 8; if (m[i] >= 0) { valid++; if (m[i] == (int)i) self++; } }
+            if (nm != valid || nm < 100 || self * 10 < nm * 9) return 9;          /* a keypoint under the identity pose finds itself */
+        }
         FILE* f = std::fopen(argv[5], "wb");
         const int32_t hdr[4] = {(int32_t)kps.size(), (int32_t)kl.size(), pd.plane_num_, Planar_SLAM::ORBmatcher::DescriptorDistance(desc.data, desc.data + 32)};
         std::fwrite(hdr, 4, 4, f);
