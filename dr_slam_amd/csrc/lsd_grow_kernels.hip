@@ -27,6 +27,7 @@
 #include "lines_internal.h"
 #include "../../include/drfe_math.h"
 #include "cr_sincos.h"
+#include <type_traits>
 
 #define LSD_RING 512          /* newest members mirrored in LDS */
 #ifdef LSD_PROFILE
@@ -234,6 +235,26 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
     return n;
 }
 
+
+/* max (MAX) or min of a double over the wavefront, to every lane */
+template <bool MAX>
+__device__ __forceinline__ double wave_ext_f64(double v)
+{
+    auto step = [&](auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), C, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), C, 0xF, 0xF, false);
+        const double o = __hiloint2double(hi, lo);
+        v = MAX ? fmax(v, o) : fmin(v, o);
+    };
+    step(std::integral_constant<int, 0xB1>());      /* quad_perm [1, 0, 3, 2] */
+    step(std::integral_constant<int, 0x4E>());      /* quad_perm [2, 3, 0, 1] */
+    step(std::integral_constant<int, 0x141>());     /* row_half_mirror */
+    step(std::integral_constant<int, 0x140>());     /* row_mirror */
+    const double r0 = rl_f64(v, 0), r1 = rl_f64(v, 16), r2 = rl_f64(v, 32), r3 = rl_f64(v, 48);
+    return MAX ? fmax(fmax(r0, r1), fmax(r2, r3)) : fmin(fmin(r0, r1), fmin(r2, r3));
+}
+
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
 
 __device__ __forceinline__ double sq(double v) { return v * v; }
@@ -278,7 +299,15 @@ __device__ __forceinline__ void to_rect(Wave& w, int n, double regAngle, double 
             }
             px = (double)mx * mg; py = (double)my * mg;
         }
-        for (int t = 0; t < cnt; t++) { x += rl_f64(px, t); y += rl_f64(py, t); sum += rl_f64(mg, t); }
+        /* the order-defined sums: one member after the other, four lane broadcasts in flight ahead of the additions */
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) {
+            const double a0 = rl_f64(px, t), a1 = rl_f64(px, t + 1), a2 = rl_f64(px, t + 2), a3 = rl_f64(px, t + 3);
+            const double b0 = rl_f64(py, t), b1 = rl_f64(py, t + 1), b2 = rl_f64(py, t + 2), b3 = rl_f64(py, t + 3);
+            const double c0 = rl_f64(mg, t), c1 = rl_f64(mg, t + 1), c2 = rl_f64(mg, t + 2), c3 = rl_f64(mg, t + 3);
+            x += a0; y += b0; sum += c0; x += a1; y += b1; sum += c1; x += a2; y += b2; sum += c2; x += a3; y += b3; sum += c3;
+        }
+        for (; t < cnt; t++) { x += rl_f64(px, t); y += rl_f64(py, t); sum += rl_f64(mg, t); }
     }
     x /= sum; y /= sum;
     double Ixx = 0, Iyy = 0, Ixy = 0;
@@ -296,7 +325,14 @@ __device__ __forceinline__ void to_rect(Wave& w, int n, double regAngle, double 
             const double dx = (double)mx - x, dy = (double)my - y;
             a = dy * dy * mg; b = dx * dx * mg; c = dx * dy * mg;
         }
-        for (int t = 0; t < cnt; t++) { Ixx += rl_f64(a, t); Iyy += rl_f64(b, t); Ixy -= rl_f64(c, t); }
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) {
+            const double a0 = rl_f64(a, t), a1 = rl_f64(a, t + 1), a2 = rl_f64(a, t + 2), a3 = rl_f64(a, t + 3);
+            const double b0 = rl_f64(b, t), b1 = rl_f64(b, t + 1), b2 = rl_f64(b, t + 2), b3 = rl_f64(b, t + 3);
+            const double c0 = rl_f64(c, t), c1 = rl_f64(c, t + 1), c2 = rl_f64(c, t + 2), c3 = rl_f64(c, t + 3);
+            Ixx += a0; Iyy += b0; Ixy -= c0; Ixx += a1; Iyy += b1; Ixy -= c1; Ixx += a2; Iyy += b2; Ixy -= c2; Ixx += a3; Iyy += b3; Ixy -= c3;
+        }
+        for (; t < cnt; t++) { Ixx += rl_f64(a, t); Iyy += rl_f64(b, t); Ixy -= rl_f64(c, t); }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)drfe_fast_atan2((float)(lambda - Ixx), (float)Ixy)
@@ -319,11 +355,11 @@ __device__ __forceinline__ void to_rect(Wave& w, int n, double regAngle, double 
         lmax = fmax(lmax, l); lmin = fmin(lmin, l);
         wmax = fmax(wmax, ww); wmin = fmin(wmin, ww);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lmax = fmax(lmax, __shfl_xor(lmax, o)); lmin = fmin(lmin, __shfl_xor(lmin, o));
-        wmax = fmax(wmax, __shfl_xor(wmax, o)); wmin = fmin(wmin, __shfl_xor(wmin, o));
-    }
+    /* wave-wide extremes: inside a row of 16 lanes by four DPP exchanges (the neighbour, the other pair, the mirrored half, the mirrored
+     * row - max / min do not mind meeting a value twice), the four rows by lane broadcasts; a shuffle butterfly goes through the LDS
+     * crossbar twelve times per value */
+    lmax = wave_ext_f64<true>(lmax); lmin = wave_ext_f64<false>(lmin);
+    wmax = wave_ext_f64<true>(wmax); wmin = wave_ext_f64<false>(wmin);
     rec.x1 = x + lmin * dx; rec.y1 = y + lmin * dy; rec.x2 = x + lmax * dx; rec.y2 = y + lmax * dy;
     rec.width = wmax - wmin;
     rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
