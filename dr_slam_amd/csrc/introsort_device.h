@@ -184,11 +184,15 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
             else sh.cutShared = 0;
         }
         __syncthreads();
-        if (!sh.cutShared) break;
+        /* the loop's conditions come out of LDS: made wave-uniform scalars, so that the branches around the barriers below are scalar
+         * branches and not EXEC-masked regions a wavefront could skip */
+        if (!__builtin_amdgcn_readfirstlane((int)sh.cutShared)) break;
         /* every data-dependent loop of this routine carries a bound far above what a correct run needs: a workgroup that ran past it
          * would otherwise hold its CU for ever (bit 2 / 3 / 4 of the status: which loop) */
         if (++wgIter > 4u * ORD_QCAP + 64u) { if (tid == 0) sh.qOverflow |= 4; break; }
-        const Seg s = sh.queue[sh.qHead - 1];
+        Seg s = sh.queue[sh.qHead - 1];
+        s.first = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.first); s.last = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.last);
+        s.depth = __builtin_amdgcn_readfirstlane(s.depth);
         __syncthreads();
         /* every thread runs the same barriers on both arms and meets the others at the one below: no `continue` around it.  (With a
          * `continue` here a workgroup stopped for good the first time a range above ORD_BIG ran out of depth - a 10 270-record

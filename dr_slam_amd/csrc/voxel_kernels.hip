@@ -89,17 +89,17 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
     __shared__ int grid[8];                 /* bx by bz sx sxy keyBits ok total */
     __shared__ int nextJob;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nList = ctl[1];
+    const int nList = __builtin_amdgcn_readfirstlane(ctl[1]);
   for (;;) {
     /* the next job of the list; every workgroup reaches the end of the list and leaves */
     __syncthreads();
     if (tid == 0) nextJob = atomicAdd(&ctl[0], 1);
     __syncthreads();
-    const int li = nextJob;
+    const int li = __builtin_amdgcn_readfirstlane(nextJob);          /* wave-uniform scalars: the branches around this loop's barriers are scalar */
     if (li >= nList) break;
-    const int jb = list[li];
+    const int jb = __builtin_amdgcn_readfirstlane(list[li]);
     const int2 job = jobs[jb];
-    const int off = job.x, n = job.y;
+    const int off = __builtin_amdgcn_readfirstlane(job.x), n = __builtin_amdgcn_readfirstlane(job.y);
     const float* P = pts + 3 * (size_t)off;
     unsigned long long* a = recs + off;
     if (n <= 0) { if (tid == 0) counts[jb] = 0; continue; }
@@ -134,7 +134,7 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
         grid[5] = bits;
     }
     __syncthreads();
-    if (!grid[6]) { if (tid == 0) counts[jb] = -1; continue; }        /* "leaf size too small": PCL keeps the input */
+    if (!__builtin_amdgcn_readfirstlane(grid[6])) { if (tid == 0) counts[jb] = -1; continue; }        /* "leaf size too small": PCL keeps the input */
     const int bx = grid[0], by = grid[1], bz = grid[2], sx = grid[3], sxy = grid[4], keyBits = grid[5];
     for (int i = tid; i < n; i += VOX_T) {
         const int ia = (int)(floor_f(P[3 * (size_t)i] * inv) - (float)bx);
@@ -146,7 +146,7 @@ extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __
     for (unsigned v = (unsigned)n; v > 1; v >>= 1) lg++;
     __syncthreads();
     VOX_TP(0);
-    const int st = isd::sort<VOX_T, VoxTraits>(a, n, posL + off, posR + off, tmp + off, dyn, sh, 2 * lg, keyBits);
+    const int st = __builtin_amdgcn_readfirstlane(isd::sort<VOX_T, VoxTraits>(a, n, posL + off, posR + off, tmp + off, dyn, sh, 2 * lg, keyBits));
 #ifdef VOX_PROFILE
     if (st != 0 && tid == 0) { atomicAdd(&g_voxTail[3], wall_clock64() - voxT0); atomicAdd(&g_voxTail[4], 1ull); atomicAdd(&g_voxXcd[17], ~0ull); }
 #endif
