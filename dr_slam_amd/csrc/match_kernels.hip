@@ -569,7 +569,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_resolve_last(const MatchPair* __
         }
         if (changed) sChanged[sweep % 3] = 1;
         __syncthreads();
-        if (!sChanged[sweep % 3]) break;
+        if (!__builtin_amdgcn_readfirstlane(sChanged[sweep % 3])) break;      /* an LDS flag as a wave-uniform scalar: a scalar branch around the sweep's barriers */
     }
     /* commit: M[k] = the LAST point that took k (an obs == 0 claim does not block, a later point overwrites
      * it, :1507-1510 / :1518); every success counts and enters the rotation histogram */

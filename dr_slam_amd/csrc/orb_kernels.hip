@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(QT_THREADS, QT_THREADS == 256 ? 8 : 4) void k_quadt
             S.nExp = 0; S.take = 0x7FFFFFFF;
         }
         __syncthreads();
-        if (S.err) break;
+        if (__builtin_amdgcn_readfirstlane(S.err)) break;          /* LDS flags as wave-uniform scalars: scalar branches around the barriers */
         /* F. keys follow their node */
         QT_FOR_KEYS({
             const int i = (int)NODE;
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(QT_THREADS, QT_THREADS == 256 ? 8 : 4) void k_quadt
         })
         cur = nxt;
         __syncthreads();
-        if (S.finish) break;
+        if (__builtin_amdgcn_readfirstlane(S.finish)) break;
     }
     if (S.err) {
         if (tid == 0) { atomicOr(status, 2); selCount[slot * G->nlevels + level] = 0; }
