@@ -27,12 +27,14 @@ for ln in open(os.path.join(ROOT, "profiles", f"{tag}_valu_issue.txt")):
 cost.pop("v_cndmask_b32", None)          # its row measures a serial VCC chain, not the pipe
 
 objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-so = os.path.join(ROOT, "dr_slam_amd", "csrc", "libdrfe.so")
-tmp = "/tmp/drfe_co"
-os.makedirs(tmp, exist_ok=True)
-subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--type=o", f"--input={so}", "--list"], capture_output=True)
-# the device code object is embedded in .hip_fatbin: let roc-obj-ls / objdump --offloading find it
-dis = subprocess.run([objdump, "-d", "--offloading", so], capture_output=True, text=True).stdout
+import shutil
+import tempfile
+tmp = tempfile.mkdtemp(prefix="drfe_co_")
+# objdump --offloading drops the extracted code objects NEXT TO its input: work on a copy in a scratch directory so that
+# nothing lands in the source tree (round 3 committed twenty such files by accident)
+so = shutil.copy(os.path.join(ROOT, "dr_slam_amd", "csrc", "libdrfe.so"), os.path.join(tmp, "libdrfe.so"))
+# the device code object is embedded in .hip_fatbin: let objdump --offloading find it
+dis = subprocess.run([objdump, "-d", "--offloading", so], capture_output=True, text=True, cwd=tmp).stdout
 if "v_" not in dis:
     # extract the bundle by hand
     subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, f"{tmp}/fat.bin"], check=True)
