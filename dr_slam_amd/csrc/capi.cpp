@@ -188,6 +188,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->lsBatch = nullptr;
     c->capeLanes = nullptr;
     c->lsdDeviceGrow = 1;
+    c->lsdRectMode = 0;
     c->planesDeviceVoxel = 1;
     c->planesDeviceAhc = 1;
     c->ahcArena = nullptr;

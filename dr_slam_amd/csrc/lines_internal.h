@@ -32,8 +32,8 @@ struct RectCand { double x1, y1, x2, y2, width, dx, dy, theta, prec; };
 
 /* (pixels inside the rectangle, pixels among them aligned with theta up to prec) for n rectangles: the pixel loop of
  * rect_nfa, one wavefront per rectangle.  d_angles = the level-line angle field k_ll_angle left on the device. */
-hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double* d_angles, int W, int H, int2* d_counts,
-                                   hipStream_t s);
+hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double* d_angles, int W, int H, int rectMode,
+                                   int2* d_counts, hipStream_t s);
 
 /* one key line as BinaryDescriptor::computeLBD reads it (octave 0); dL = (cos, sin) of the line angle from the host's libm */
 struct LbdLine { float midX, midY, dL0, dL1; int len, pad; };

@@ -124,23 +124,22 @@ __global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src,
 /* The pixel loop of cv::LineSegmentDetectorImpl::rect_nfa (OpenCV 3.4 imgproc/src/lsd.cpp) for one rectangle per wavefront.
  * The corner bookkeeping and the scan-line walk are order-defined double arithmetic (lx += step per row) and run
  * wave-uniformly; the pixels of a row are spread over the lanes (coalesced reads of the angle row), the two counters meet
- * in a wave reduction.  Only integers leave the kernel: the NFA itself (lgamma, log, exp of the counts) stays with the
- * caller's libm so that the host decides with exactly the values the CPU path would compute. */
-__global__ __launch_bounds__(64) void k_rect_counts(const RectCand* __restrict__ cands, int n, const double* __restrict__ ang, int W,
-                                                    int H, int2* __restrict__ out)
+ * in a wave reduction.
+ * rectMode 0 (default) is the literal source: `struct edge { cv::Point p; bool taken; }` has INTEGER corners, the four edge
+ * steps are integer quotients, and the second steps divide by (y - tailp->p.x), the x / y mix their guards test (so never
+ * by zero).  rectMode 1 is the real-valued reading of round 3 (double quotients, (y - tailp->p.y) denominators, a step
+ * that would divide by zero taken as 0), kept selectable until a pin against a real OpenCV 3.4.4 decides. */
+struct RectWalk { int loX, loY, hiY, leftY, rightY; double fl, sl, fr, sr; };
+
+__device__ __forceinline__ RectWalk rect_walk_setup(const RectCand& rc, int rectMode)
 {
-    const int id = blockIdx.x, lane = threadIdx.x;
-    if (id >= n) return;
-    const RectCand rc = cands[id];
-    const double kNotDef = -1024.0, kTwoPi = 2.0 * 3.14159265358979323846, kThreeHalfPi = 3.0 * 3.14159265358979323846 / 2.0;
     const double hw = rc.width / 2.0, dyhw = rc.dy * hw, dxhw = rc.dx * hw;
-    /* integer-valued corners kept as doubles (cv::Point2d built from ints) */
-    double cx[4] = {(double)(int)(rc.x1 - dyhw), (double)(int)(rc.x2 - dyhw), (double)(int)(rc.x2 + dyhw), (double)(int)(rc.x1 + dyhw)};
-    double cy[4] = {(double)(int)(rc.y1 + dxhw), (double)(int)(rc.y2 + dxhw), (double)(int)(rc.y2 - dxhw), (double)(int)(rc.y1 - dxhw)};
+    int cx[4] = {(int)(rc.x1 - dyhw), (int)(rc.x2 - dyhw), (int)(rc.x2 + dyhw), (int)(rc.x1 + dyhw)};
+    int cy[4] = {(int)(rc.y1 + dxhw), (int)(rc.y2 + dxhw), (int)(rc.y2 - dxhw), (int)(rc.y1 - dxhw)};
     /* ascending (x, y): five compare-exchanges */
 #define CSWAP(a, b)                                                                     \
     if (cx[a] > cx[b] || (cx[a] == cx[b] && cy[a] > cy[b])) {                           \
-        const double tx = cx[a], ty = cy[a]; cx[a] = cx[b]; cy[a] = cy[b]; cx[b] = tx; cy[b] = ty; \
+        const int tx = cx[a], ty = cy[a]; cx[a] = cx[b]; cy[a] = cy[b]; cx[b] = tx; cy[b] = ty; \
     }
     CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
 #undef CSWAP
@@ -154,21 +153,36 @@ __global__ __launch_bounds__(64) void k_rect_counts(const RectCand* __restrict__
     for (int i = 0; i < 4; i++) if (!taken[i] && (right < 0 || cx[right] < cx[i])) right = i;
     taken[right] = true;
     for (int i = 0; i < 4; i++) if (!taken[i] && (tail < 0 || cx[tail] > cx[i])) tail = i;
-    const double loX = cx[lo], loY = cy[lo], hiY = cy[hi], leftX = cx[left], leftY = cy[left], rightX = cx[right], rightY = cy[right],
-                 tailX = cx[tail], tailY = cy[tail];
-    /* edge steps dx/dy; the second-step guards compare y against tail.x as rect_nfa does, a step that would divide by zero
-     * counts as 0 */
-    const double fl = (loY != leftY) ? (loX - leftX) / (loY - leftY) : 0;
-    double sl = (leftY != tailX) ? (leftX - tailX) / (leftY - tailY) : 0;
-    const double fr = (loY != rightY) ? (loX - rightX) / (loY - rightY) : 0;
-    double sr = (rightY != tailX) ? (rightX - tailX) / (rightY - tailY) : 0;
-    if (!isfinite(sl)) sl = 0;
-    if (!isfinite(sr)) sr = 0;
-    double lstep = fl, rstep = fr, lx = loX, rx = loX;
+    const int loX = cx[lo], loY = cy[lo], leftX = cx[left], leftY = cy[left], rightX = cx[right], rightY = cy[right],
+              tailX = cx[tail], tailY = cy[tail];
+    RectWalk w;
+    w.loX = loX; w.loY = loY; w.hiY = cy[hi]; w.leftY = leftY; w.rightY = rightY;
+    if (rectMode == 0) {
+        w.fl = (loY != leftY) ? (double)((loX - leftX) / (loY - leftY)) : 0.0;
+        w.sl = (leftY != tailX) ? (double)((leftX - tailX) / (leftY - tailX)) : 0.0;
+        w.fr = (loY != rightY) ? (double)((loX - rightX) / (loY - rightY)) : 0.0;
+        w.sr = (rightY != tailX) ? (double)((rightX - tailX) / (rightY - tailX)) : 0.0;
+    } else {
+        w.fl = (loY != leftY) ? (double)(loX - leftX) / (double)(loY - leftY) : 0.0;
+        w.sl = (leftY != tailX) ? (double)(leftX - tailX) / (double)(leftY - tailY) : 0.0;
+        w.fr = (loY != rightY) ? (double)(loX - rightX) / (double)(loY - rightY) : 0.0;
+        w.sr = (rightY != tailX) ? (double)(rightX - tailX) / (double)(rightY - tailY) : 0.0;
+        if (!isfinite(w.sl)) w.sl = 0;
+        if (!isfinite(w.sr)) w.sr = 0;
+    }
+    return w;
+}
+
+/* (pixels, aligned pixels) of one rectangle, lanes over a row's pixels; every lane returns the wave's totals */
+__device__ __forceinline__ int2 rect_walk_count(const RectCand& rc, const RectWalk& w, const double* __restrict__ ang, int W, int H,
+                                                int lane)
+{
+    const double kNotDef = -1024.0, kTwoPi = 2.0 * 3.14159265358979323846, kThreeHalfPi = 3.0 * 3.14159265358979323846 / 2.0;
+    double lstep = w.fl, rstep = w.fr, lx = (double)w.loX, rx = (double)w.loX;
     int total = 0, alg = 0;
     /* rows outside the image change nothing in rect_nfa (its `continue` comes before the edge steps) and pixels outside are
      * not counted: both loops are clamped to the image, which also bounds the work of a degenerate rectangle */
-    const int yBeg = max((int)loY, 0), yEnd = min((int)hiY, H - 1);
+    const int yBeg = max(w.loY, 0), yEnd = min(w.hiY, H - 1);
     for (int y = yBeg; y <= yEnd; ++y) {
         const int xs = max((int)lx, 0), xe = min((int)rx, W - 1);
         const double* row = ang + (size_t)y * W;
@@ -182,21 +196,32 @@ __global__ __launch_bounds__(64) void k_rect_counts(const RectCand* __restrict__
                 if (d <= rc.prec) ++alg;
             }
         }
-        if ((double)y >= leftY) lstep = sl;
-        if ((double)y >= rightY) rstep = sr;
+        if (y >= w.leftY) lstep = w.sl;
+        if (y >= w.rightY) rstep = w.sr;
         lx += lstep;
         rx += rstep;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { total += __shfl_xor(total, o); alg += __shfl_xor(alg, o); }
-    if (lane == 0) out[id] = make_int2(total, alg);
+    return make_int2(total, alg);
 }
 
-hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double* d_angles, int W, int H, int2* d_counts,
+__global__ __launch_bounds__(64) void k_rect_counts(const RectCand* __restrict__ cands, int n, const double* __restrict__ ang, int W,
+                                                    int H, int rectMode, int2* __restrict__ out)
+{
+    const int id = blockIdx.x, lane = threadIdx.x;
+    if (id >= n) return;
+    const RectCand rc = cands[id];
+    const RectWalk w = rect_walk_setup(rc, rectMode);
+    const int2 r = rect_walk_count(rc, w, ang, W, H, lane);
+    if (lane == 0) out[id] = r;
+}
+
+hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double* d_angles, int W, int H, int rectMode, int2* d_counts,
                                    hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rect_counts, dim3(n), dim3(64), 0, s, d_cands, n, d_angles, W, H, d_counts);
+    hipLaunchKernelGGL(k_rect_counts, dim3(n), dim3(64), 0, s, d_cands, n, d_angles, W, H, rectMode, d_counts);
     return hipGetLastError();
 }
 

@@ -454,15 +454,17 @@ private:
         return true;
     }
 public:
-    /* DRFE_LSD_CHECK=1: the same pixel loop on the host, to cross-check k_rect_counts (debug only) */
-    void countHost(const RectCand& rec, int& total, int& alg) const
+    /* rect_nfa's pixel loop on the host: DRFE_LSD_CHECK=1 cross-checks k_rect_counts with it, drfe_lsd_segments_host counts
+     * with it.  rectMode 0: the literal OpenCV 3.4 source (integer corners and step quotients, (y - tailp->p.x) in the
+     * second steps' guards and denominators); 1: the real-valued reading of round 3 (lines_kernels.hip, rect_walk_setup) */
+    void countHost(const RectCand& rec, int rectMode, int& total, int& alg) const
     {
-        struct Corner { double x, y; bool taken; };
+        struct Corner { int x, y; bool taken; };
         const double hw = rec.width / 2.0, dyhw = rec.dy * hw, dxhw = rec.dx * hw;
-        Corner c[4] = {{double(int(rec.x1 - dyhw)), double(int(rec.y1 + dxhw)), false},
-                       {double(int(rec.x2 - dyhw)), double(int(rec.y2 + dxhw)), false},
-                       {double(int(rec.x2 + dyhw)), double(int(rec.y2 - dxhw)), false},
-                       {double(int(rec.x1 + dyhw)), double(int(rec.y1 - dxhw)), false}};
+        Corner c[4] = {{int(rec.x1 - dyhw), int(rec.y1 + dxhw), false},
+                       {int(rec.x2 - dyhw), int(rec.y2 + dxhw), false},
+                       {int(rec.x2 + dyhw), int(rec.y2 - dxhw), false},
+                       {int(rec.x1 + dyhw), int(rec.y1 - dxhw), false}};
         std::sort(c, c + 4, [](const Corner& a, const Corner& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
         Corner *lo = &c[0], *hi = &c[0];
         for (int i = 1; i < 4; ++i) { if (lo->y > c[i].y) lo = &c[i]; if (hi->y < c[i].y) hi = &c[i]; }
@@ -473,15 +475,23 @@ public:
         for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!right || right->x < c[i].x) right = &c[i]; }
         right->taken = true;
         for (int i = 0; i < 4; ++i) if (!c[i].taken) { if (!tail || tail->x > c[i].x) tail = &c[i]; }
-        const double fl = (lo->y != left->y) ? (lo->x - left->x) / (lo->y - left->y) : 0;
-        double sl = (left->y != tail->x) ? (left->x - tail->x) / (left->y - tail->y) : 0;
-        const double fr = (lo->y != right->y) ? (lo->x - right->x) / (lo->y - right->y) : 0;
-        double sr = (right->y != tail->x) ? (right->x - tail->x) / (right->y - tail->y) : 0;
-        if (!std::isfinite(sl)) sl = 0;
-        if (!std::isfinite(sr)) sr = 0;
+        double fl, sl, fr, sr;
+        if (rectMode == 0) {
+            fl = (lo->y != left->y) ? (lo->x - left->x) / (lo->y - left->y) : 0;
+            sl = (left->y != tail->x) ? (left->x - tail->x) / (left->y - tail->x) : 0;
+            fr = (lo->y != right->y) ? (lo->x - right->x) / (lo->y - right->y) : 0;
+            sr = (right->y != tail->x) ? (right->x - tail->x) / (right->y - tail->x) : 0;
+        } else {
+            fl = (lo->y != left->y) ? double(lo->x - left->x) / double(lo->y - left->y) : 0;
+            sl = (left->y != tail->x) ? double(left->x - tail->x) / double(left->y - tail->y) : 0;
+            fr = (lo->y != right->y) ? double(lo->x - right->x) / double(lo->y - right->y) : 0;
+            sr = (right->y != tail->x) ? double(right->x - tail->x) / double(right->y - tail->y) : 0;
+            if (!std::isfinite(sl)) sl = 0;
+            if (!std::isfinite(sr)) sr = 0;
+        }
         double lstep = fl, rstep = fr, lx = lo->x, rx = lo->x;
         total = 0; alg = 0;
-        for (int y = (int)lo->y; y <= (int)hi->y; ++y) {
+        for (int y = lo->y; y <= hi->y; ++y) {
             if (y < 0 || y >= H_) continue;
             for (int x = int(lx); x <= int(rx); ++x) {
                 if (x < 0 || x >= W_) continue;
@@ -543,6 +553,7 @@ struct LineWorker {
     bool ownsStream = false;
     LineHost* host = nullptr;
     hipEvent_t pollEv = nullptr;      /* pool lanes: drfe_pool_sync sleeps between polls instead of spinning */
+    int rectMode = 0;                 /* rect_nfa's reading (drfe_lsd_configure_rect): 0 literal OpenCV 3.4, 1 real-valued */
 };
 
 static hipError_t lane_sync(LineWorker* c)
@@ -686,7 +697,7 @@ static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, i
         /* the download is issued only when the kernel has finished: queued behind it, it would sit in a DMA ring until then and
          * hold up the other lanes' copies behind it (a kernel writing straight into pinned host memory is worse: measured 2.3x
          * slower for the whole front-end - every such kernel ends in a system-scope write-back) */
-        if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, v.d_angles, v.sw, v.sh, s->d_counts, st);
+        if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, v.d_angles, v.sw, v.sh, c->rectMode, s->d_counts, st);
         if (e == hipSuccess) e = lane_sync(c);
         if (e == hipSuccess) e = hipMemcpyAsync(s->h_counts, s->d_counts, nc * sizeof(int2), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = lane_sync(c);
@@ -695,7 +706,7 @@ static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, i
         if (check)
             for (size_t k = 0; k < nc; k++) {
                 int t = 0, a = 0;
-                check->countHost(cands[k], t, a);
+                check->countHost(cands[k], c->rectMode, t, a);
                 if (t != out[k].x || a != out[k].y)
                     std::fprintf(stderr, "k_rect_counts mismatch: cand %zu device (%d, %d) host (%d, %d)  x1 %.17g y1 %.17g x2 %.17g y2 %.17g w %.17g dx %.17g dy %.17g theta %.17g prec %.17g\n",
                                  k, out[k].x, out[k].y, t, a, cands[k].x1, cands[k].y1, cands[k].x2, cands[k].y2, cands[k].width, cands[k].dx, cands[k].dy, cands[k].theta, cands[k].prec);
@@ -1175,6 +1186,7 @@ int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
     lw.ls = c->ls;
     lw.stream = c->stream;
     lw.host = static_cast<LineHost*>(c->lineHost);
+    lw.rectMode = c->lsdRectMode;
     const int rc = lsd_extract_core(&lw, c->device, gray, w, h, stride, max_lines, lines, ldesc, line_f, cap, n_lines, n_detected);
     c->ls = lw.ls;
     c->lineHost = lw.host;
@@ -1188,6 +1200,17 @@ int drfe_lsd_configure(drfe_ctx* c, int device_grow)
 {
     if (!c || device_grow < 0 || device_grow > 1) { if (c) c->err = "lsd_configure: invalid argument"; return DRFE_ERR_INVALID; }
     c->lsdDeviceGrow = device_grow;
+    return DRFE_OK;
+}
+
+/* Which reading of cv::LineSegmentDetectorImpl::rect_nfa (OpenCV 3.4 lsd.cpp, behind reference src/LSDextractor.cpp:14-17)
+ * validates the rectangles: 0 (default) the literal source - `struct edge { cv::Point p; ... }`, so integer corners and
+ * integer step quotients, and (y - tailp->p.x) in the second steps' guards AND denominators; 1 the real-valued reading
+ * round 3 shipped (double quotients, (y - tailp->p.y) denominators).  SURVEY.md section 9: library bugs are preserved. */
+int drfe_lsd_configure_rect(drfe_ctx* c, int rect_mode)
+{
+    if (!c || rect_mode < 0 || rect_mode > 1) { if (c) c->err = "lsd_configure_rect: invalid argument"; return DRFE_ERR_INVALID; }
+    c->lsdRectMode = rect_mode;
     return DRFE_OK;
 }
 
@@ -1216,6 +1239,7 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
         lw.ownsStream = true;
         pool->push_back(lw);
     }
+    for (LineWorker& lw : *pool) lw.rectMode = c->lsdRectMode;
     static const bool envHost = std::getenv("DRFE_LSD_HOST_GROW") != nullptr;
     if (c->lsdDeviceGrow && !envHost && device_grow_fits(w, h))
         return lsd_extract_batch_device(c, pool, T, gray, frame_stride, w, h, stride, nframes, max_lines, lines, ldesc, line_f, cap, n_lines, n_detected);
@@ -1247,6 +1271,14 @@ int drfe_lsd_extract_batch(drfe_ctx* c, const uint8_t* gray, size_t frame_stride
 int drfe_lsd_segments_host(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad, float* segs,
                            int cap, int* n_segs)
 {
+    return drfe_lsd_segments_host_mode(modgrad, angles, cs, W, H, max_grad, 0, segs, cap, n_segs);
+}
+
+/* the same with rect_nfa's reading chosen by the caller (drfe_lsd_configure_rect: 0 literal OpenCV 3.4, 1 real-valued) */
+int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad,
+                                int rect_mode, float* segs, int cap, int* n_segs)
+{
+    if (rect_mode < 0 || rect_mode > 1) return DRFE_ERR_INVALID;
     if (!modgrad || !angles || !cs || !n_segs || W < 4 || H < 4 || W > 2048 || H > 2048) return DRFE_ERR_INVALID;
     std::vector<uint8_t> used;
     std::vector<OPt> order, orderTmp;
@@ -1254,7 +1286,7 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
     std::vector<float> out;
     auto counts = [&](const std::vector<RectCand>& cands, std::vector<int2>& res) -> bool {
         res.resize(cands.size());
-        for (size_t k = 0; k < cands.size(); k++) finder.countHost(cands[k], res[k].x, res[k].y);
+        for (size_t k = 0; k < cands.size(); k++) finder.countHost(cands[k], rect_mode, res[k].x, res[k].y);
         return true;
     };
     finder.timed_ = std::getenv("DRFE_TRACE_LINES") != nullptr;

@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor",
+    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -201,6 +201,8 @@ def load() -> C.CDLL:
     L.drfe_surface_normals_download.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_segments_host.argtypes = [vp, vp, vp, i32, i32, f64, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_configure.argtypes = [vp, i32]
+    L.drfe_lsd_configure_rect.argtypes = [vp, i32]
+    L.drfe_lsd_segments_host_mode.argtypes = [vp, vp, vp, i32, i32, f64, i32, vp, i32, C.POINTER(i32)]
     L.drfe_planes_configure.argtypes = [vp, i32]
     L.drfe_planes_configure_extractor.argtypes = [vp, i32]
     L.drfe_planes_cape_batch.argtypes = [vp, vp, sz, i32, i32, sz, i32, vp, i32, f32, f32, vp, i32, vp, vp, i32]
@@ -219,8 +221,9 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def lsd_segments_host(modgrad, angles, cs, max_grad):
-    """The sequential half of LSD on given level-line fields (host code, no device): [n, 4] float32 segments."""
+def lsd_segments_host(modgrad, angles, cs, max_grad, rect_mode=0):
+    """The sequential half of LSD on given level-line fields (host code, no device): [n, 4] float32 segments.
+    rect_mode: rect_nfa's reading (0 literal OpenCV 3.4, 1 real-valued)."""
     L = load()
     m = np.ascontiguousarray(modgrad, np.float64)
     a = np.ascontiguousarray(angles, np.float64)
@@ -228,7 +231,7 @@ def lsd_segments_host(modgrad, angles, cs, max_grad):
     H, W = m.shape
     out = np.zeros((20000, 4), np.float32)
     n = C.c_int()
-    rc = L.drfe_lsd_segments_host(_p(m), _p(a), _p(c), W, H, float(max_grad), _p(out), len(out), C.byref(n))
+    rc = L.drfe_lsd_segments_host_mode(_p(m), _p(a), _p(c), W, H, float(max_grad), int(rect_mode), _p(out), len(out), C.byref(n))
     if rc != 0:
         raise DrfeError(f"drfe_lsd_segments_host failed ({rc})")
     return out[:n.value].copy()
@@ -846,6 +849,11 @@ class Context:
     def lsd_configure(self, device_grow=True):
         """Where lsd_extract_batch grows its regions: on the device (one wavefront per frame, default) or on the host pool."""
         self._chk(self.L.drfe_lsd_configure(self.h, 1 if device_grow else 0), "drfe_lsd_configure")
+
+    def lsd_configure_rect(self, rect_mode=0):
+        """rect_nfa's reading (OpenCV 3.4 lsd.cpp): 0 the literal source (integer corners and step quotients, default),
+        1 the real-valued reading of rounds 2-3."""
+        self._chk(self.L.drfe_lsd_configure_rect(self.h, int(rect_mode)), "drfe_lsd_configure_rect")
 
     def lsd_extract_batch(self, gray_batch: np.ndarray, max_lines=40, n_threads=0):
         """LineSegment::ExtractLineSegment for a [B, H, W] uint8 host array: region growing on the device (or, after

@@ -343,6 +343,19 @@ int drfe_lsd_extract_batch(drfe_ctx* ctx, const uint8_t* gray, size_t frame_stri
 /* 1 (default): drfe_lsd_extract_batch grows regions on the device; 0: on the host threads.  Frames whose 0.8-scaled size
  * exceeds the device path's LDS bitmap (about 1.2 M pixels) take the host path regardless. */
 int drfe_lsd_configure(drfe_ctx* ctx, int device_grow);
+/* Which reading of cv::LineSegmentDetectorImpl::rect_nfa (OpenCV 3.4 imgproc/src/lsd.cpp, the detector behind reference
+ * src/LSDextractor.cpp:14-17) validates the rectangles of this context's line entries.
+ * 0 (default) - the literal source: `struct edge { cv::Point p; bool taken; }` has integer corners, so the four edge steps
+ *   are INTEGER quotients, and the second steps use (y - tailp->p.x) in their guards and in their denominators.  The scan
+ *   lines of an oblique rectangle are then not the rectangle's own; that is the library's behaviour and it is preserved
+ *   (SURVEY.md section 9), not repaired.
+ * 1 - the real-valued reading rounds 2-3 shipped (double quotients, (y - tailp->p.y) denominators, a step that would
+ *   divide by zero taken as 0), kept until a pin against a real OpenCV 3.4.4 build decides (tools/dump_opencv_reference.py
+ *   dumps the per-rectangle counts such a pin compares). */
+int drfe_lsd_configure_rect(drfe_ctx* ctx, int rect_mode);
+/* drfe_lsd_segments_host with rect_nfa's reading chosen by the caller (drfe_lsd_segments_host: 0). */
+int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad,
+                                int rect_mode, float* segs, int cap, int* n_segs);
 /* Test hook of dr_slam_amd/csrc/cr_sincos.h: correctly rounded sin / cos of n doubles in [0, 64) (host build of the routine the
  * device path uses for region2rect's direction and region_grow's seed direction); ok[i] = 0 where the rounding could not be
  * certified.  Host code. */

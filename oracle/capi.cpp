@@ -438,6 +438,26 @@ void* orc_lines_run(const uint8_t* img, int w, int h, int maxLines)
     catch (const std::exception& e) { g_err = e.what(); delete H; return nullptr; }
     return H;
 }
+/* rect_nfa's reading chosen per call: 0 literal OpenCV 3.4 (default of orc_lines_run), 1 the real-valued one */
+void* orc_lines_run_mode(const uint8_t* img, int w, int h, int maxLines, int rectMode)
+{
+    LineHandle* H = new LineHandle();
+    try { H->r = extract_lines(img, w, h, maxLines, &H->st, rectMode); }
+    catch (const std::exception& e) { g_err = e.what(); delete H; return nullptr; }
+    return H;
+}
+/* the detector's raw output: number of rect_nfa calls and of segments; then their (total_pts, alg_pts) pairs / x1 y1 x2 y2 */
+void orc_lines_trace_info(void* h, int32_t* out2)
+{
+    LineHandle* H = (LineHandle*)h;
+    out2[0] = (int)(H->st.rectCounts.size() / 2); out2[1] = (int)(H->st.segments.size() / 4);
+}
+void orc_lines_trace_get(void* h, int32_t* counts, float* segs)
+{
+    LineHandle* H = (LineHandle*)h;
+    if (counts && !H->st.rectCounts.empty()) std::memcpy(counts, H->st.rectCounts.data(), H->st.rectCounts.size() * sizeof(int));
+    if (segs && !H->st.segments.empty()) std::memcpy(segs, H->st.segments.data(), H->st.segments.size() * sizeof(float));
+}
 void orc_lines_free(void* h) { delete (LineHandle*)h; }
 void orc_lines_info(void* h, int32_t* out4)
 {

@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace orc {
 
@@ -139,6 +140,8 @@ struct Lsd {
     double LOG_NT = 0;
     const double SCALE = 0.8, SIGMA_SCALE = 0.6, QUANT = 2.0, ANG_TH = 22.5, LOG_EPS = 0, DENSITY_TH = 0.7;
     const int N_BINS = 1024;
+    int rect_mode = 0;                         /* rect_nfa's reading: 0 literal OpenCV 3.4 (integer corners), 1 real-valued */
+    std::vector<int>* count_log = nullptr;     /* (total_pts, alg_pts) of every rect_nfa call, in call order */
 
     static double distSq(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
     static double dist(double x1, double y1, double x2, double y2) { return std::sqrt(distSq(x1, y1, x2, y2)); }
@@ -364,16 +367,24 @@ struct Lsd {
         return -std::log10(bin_tail) - LOG_NT;
     }
 
-    double rect_nfa(const Rect& rec) const
+    /* rect_nfa (OpenCV 3.4 imgproc/src/lsd.cpp), rect_mode 0 - THE LITERAL READING, default: `struct edge { cv::Point p; bool
+     * taken; }` holds INTEGER corners, so the four edge steps are integer quotients (truncated towards zero), and the two
+     * second steps divide by (y - tailp->p.x) - the same x / y mix their guards test, hence never by zero.  The scan lines
+     * of an oblique rectangle are then not the rectangle's own (a step of magnitude below one is 0); that is the library's
+     * behaviour in 3.4.x and a reference bug to preserve, not to repair.
+     * rect_mode 1 - the round-3 reading kept for comparison: corners as doubles holding the truncated integers, real-valued
+     * quotients, (y - tailp->p.y) in the second-step denominators, a step that would divide by zero taken as 0. */
+    template <typename T> struct EdgeT { T x, y; bool taken; };
+    template <typename T> void rect_counts(const Rect& rec, int& total_pts, int& alg_pts) const
     {
-        struct Edge { double x, y; bool taken; };   /* cv::Point2d holding truncated integer coordinates */
-        int total_pts = 0, alg_pts = 0;
+        typedef EdgeT<T> Edge;
+        total_pts = 0; alg_pts = 0;
         const double half_width = rec.width / 2.0, dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
         Edge e[4];
-        e[0] = {double(int(rec.x1 - dyhw)), double(int(rec.y1 + dxhw)), false};
-        e[1] = {double(int(rec.x2 - dyhw)), double(int(rec.y2 + dxhw)), false};
-        e[2] = {double(int(rec.x2 + dyhw)), double(int(rec.y2 - dxhw)), false};
-        e[3] = {double(int(rec.x1 + dyhw)), double(int(rec.y1 - dxhw)), false};
+        e[0] = {T(int(rec.x1 - dyhw)), T(int(rec.y1 + dxhw)), false};
+        e[1] = {T(int(rec.x2 - dyhw)), T(int(rec.y2 + dxhw)), false};
+        e[2] = {T(int(rec.x2 + dyhw)), T(int(rec.y2 - dxhw)), false};
+        e[3] = {T(int(rec.x1 + dyhw)), T(int(rec.y1 - dxhw)), false};
         std::sort(e, e + 4, [](const Edge& a, const Edge& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
         Edge *min_y = &e[0], *max_y = &e[0];
         for (unsigned i = 1; i < 4; ++i) {
@@ -393,16 +404,25 @@ struct Lsd {
         for (unsigned i = 0; i < 4; ++i)
             if (!e[i].taken) { if (!tailp) tailp = &e[i]; else if (tailp->x > e[i].x) tailp = &e[i]; }
         tailp->taken = true;
-        /* edge slopes dx/dy; the second-step guards compare against tailp->p.x as the OpenCV source does */
-        const double flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
-        const double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->y) : 0;
-        const double frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
-        const double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->y) : 0;
+        double flstep, slstep, frstep, srstep;
+        if (std::is_integral<T>::value) {
+            /* the expressions of lsd.cpp, evaluated in int and converted to double by the assignment */
+            flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
+            slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->x) : 0;
+            frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
+            srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->x) : 0;
+        } else {
+            flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
+            slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->y) : 0;
+            frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
+            srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->y) : 0;
+            /* a guard that misses (equal y, different x) would divide by zero; such a step is taken as 0 */
+            if (!std::isfinite(slstep)) slstep = 0;
+            if (!std::isfinite(srstep)) srstep = 0;
+        }
         double lstep = flstep, rstep = frstep;
         double left_x = min_y->x, right_x = min_y->x;
         const int min_iter = (int)min_y->y, max_iter = (int)max_y->y;
-        /* a guard that misses (equal y, different x) would divide by zero; such a step is taken as 0 */
-        const double slstepF = std::isfinite(slstep) ? slstep : 0, srstepF = std::isfinite(srstep) ? srstep : 0;
         for (int y = min_iter; y <= max_iter; ++y) {
             if (y < 0 || y >= H) continue;
             for (int x = int(left_x); x <= int(right_x); ++x) {
@@ -410,11 +430,19 @@ struct Lsd {
                 ++total_pts;
                 if (isAligned(x, y, rec.theta, rec.prec)) ++alg_pts;
             }
-            if (y >= leftmost->y) lstep = slstepF;
-            if (y >= rightmost->y) rstep = srstepF;
+            if (y >= leftmost->y) lstep = slstep;
+            if (y >= rightmost->y) rstep = srstep;
             left_x += lstep;
             right_x += rstep;
         }
+    }
+
+    double rect_nfa(const Rect& rec) const
+    {
+        int total_pts = 0, alg_pts = 0;
+        if (rect_mode == 0) rect_counts<int>(rec, total_pts, alg_pts);
+        else rect_counts<double>(rec, total_pts, alg_pts);
+        if (count_log) { count_log->push_back(total_pts); count_log->push_back(alg_pts); }
         return nfa(total_pts, alg_pts, rec.p);
     }
 
@@ -626,13 +654,16 @@ void lbd_descriptor(const int16_t* dxImg, const int16_t* dyImg, int realWidth, i
 }
 
 /* LineSegment::ExtractLineSegment, reference src/LSDextractor.cpp:12-43 */
-LineResult extract_lines(const uint8_t* img, int w, int h, int maxLines, LsdStages* stages)
+LineResult extract_lines(const uint8_t* img, int w, int h, int maxLines, LsdStages* stages, int rectMode)
 {
     LineResult out;
     /* LSDDetector::detect(img, keylines, scale = 1 (int from 1.2f), numOctaves = 1): octave 0 = the image */
     Lsd lsd;
+    lsd.rect_mode = rectMode;
+    if (stages) lsd.count_log = &stages->rectCounts;
     std::vector<float> segs;
     lsd.detect(img, w, h, segs, stages);
+    if (stages) stages->segments = segs;
     int class_counter = -1;
     for (size_t k = 0; k + 3 < segs.size(); k += 4) {
         float e[4] = {segs[k], segs[k + 1], segs[k + 2], segs[k + 3]};

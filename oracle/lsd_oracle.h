@@ -22,6 +22,8 @@ struct LsdStages {   /* intermediates for stage-by-stage parity of the device im
     std::vector<uint8_t> scaled;          /* Gaussian + 0.8 downscale */
     std::vector<double> modgrad, angles;  /* ll_angle */
     std::vector<int16_t> gx, gy;          /* Sobel of the 5x5-blurred image (LBD input) */
+    std::vector<int> rectCounts;          /* (total_pts, alg_pts) of every rect_nfa call in call order */
+    std::vector<float> segments;          /* the detector's x1 y1 x2 y2 per accepted segment, before the key-line stage */
 };
 
 struct LineResult {
@@ -37,7 +39,9 @@ void resize_linear_exact_08(const uint8_t* src, int sw, int sh, uint8_t* dst, in
 void sobel3_s16(const uint8_t* src, int w, int h, int16_t* gx, int16_t* gy);
 void lbd_descriptor(const int16_t* dxImg, const int16_t* dyImg, int realWidth, int realHeight, const KeyLine& kl,
                     float* desVec72, uint8_t* desc32);
-LineResult extract_lines(const uint8_t* img, int w, int h, int maxLines = 40, LsdStages* stages = nullptr);
+/* rectMode: rect_nfa's reading - 0 the literal OpenCV 3.4 source (integer corners and step quotients; default), 1 the
+ * real-valued reading of round 3 (see lsd_oracle.cpp) */
+LineResult extract_lines(const uint8_t* img, int w, int h, int maxLines = 40, LsdStages* stages = nullptr, int rectMode = 0);
 
 } // namespace orc
 #endif

@@ -680,21 +680,25 @@ KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4
                           ("lineLength", "<f4"), ("numOfPixels", "<i4")])
 
 
-def extract_lines(gray, max_lines=40, stages=False):
+def extract_lines(gray, max_lines=40, stages=False, rect_mode=0, trace=False):
     """LineSegment::ExtractLineSegment (reference src/LSDextractor.cpp:12-43): LSD detect, keep the 40
     highest-response lines, LBD descriptors, normalised line equations.
-    Returns dict(lines (KEYLINE_DTYPE), desc [n,32], descf [n,72], lineF [n,3], detected[, stage images])."""
+    rect_mode: rect_nfa's reading - 0 literal OpenCV 3.4 (integer corners, default), 1 real-valued (round 3).
+    Returns dict(lines (KEYLINE_DTYPE), desc [n,32], descf [n,72], lineF [n,3], detected[, stage images]
+    [, rect_counts [calls,2] int32 in call order, segments [n,4] float32 before the key-line stage])."""
     g = _c(gray, np.uint8)
     h, w = g.shape
     L = lib()
-    L.orc_lines_run.restype = C.c_void_p
-    L.orc_lines_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_lines_run_mode.restype = C.c_void_p
+    L.orc_lines_run_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_lines_trace_info.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_lines_trace_get.argtypes = [C.c_void_p] * 3
     L.orc_lines_free.argtypes = [C.c_void_p]
     L.orc_lines_info.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_lines_get.argtypes = [C.c_void_p] * 5
     L.orc_lines_get_stages.argtypes = [C.c_void_p] * 6
     assert L.orc_sizeof_keyline() == KEYLINE_DTYPE.itemsize
-    H = L.orc_lines_run(_p(g), w, h, max_lines)
+    H = L.orc_lines_run_mode(_p(g), w, h, max_lines, int(rect_mode))
     if not H:
         raise RuntimeError(L.orc_last_error().decode())
     try:
@@ -713,6 +717,12 @@ def extract_lines(gray, max_lines=40, stages=False):
             gx, gy = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
             L.orc_lines_get_stages(H, _p(scaled), _p(modgrad), _p(angles), _p(gx), _p(gy))
             out.update(scaled=scaled, modgrad=modgrad, angles=angles, gx=gx, gy=gy)
+        if trace:
+            tn = np.zeros(2, np.int32)
+            L.orc_lines_trace_info(H, _p(tn))
+            rc, sg = np.zeros((int(tn[0]), 2), np.int32), np.zeros((int(tn[1]), 4), np.float32)
+            L.orc_lines_trace_get(H, _p(rc), _p(sg))
+            out.update(rect_counts=rc, segments=sg)
     finally:
         L.orc_lines_free(H)
     return out

@@ -255,3 +255,45 @@ def test_batch_entries_of_three_contexts_side_by_side():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_bench_size_three_in_flight_against_oracle(oracle_mod):
+    """The bench's own configuration under the oracle: batches of 512 frames through drfe_pipeline_submit with three contexts
+    in flight (bench.py's timed loop), two rounds so that every context is reused while the others run; then 16 random slots
+    of every context's last batch - keypoint records, descriptors, SearchByProjection match arrays - against the CPU oracle
+    (oracle/spot_check.py, the same checker bench.py runs after its timed loop)."""
+    import torch
+    from dr_slam_amd import lib, sharding, synth
+    from dr_slam_amd.pipeline import FrontEnd
+    from oracle.spot_check import SlotChecker
+    cam = synth.TUM3
+    B, depth_n, distinct = 512, 3, 24
+    batches = []
+    for i in range(depth_n):
+        base = sharding.render_sequence(50 + i, distinct, cam, ("room_boxes", "living_room", "corridor")[i], workers=min(8, sharding.host_cpus()))
+        order = sharding.pingpong_order(B, distinct)
+        gray = np.stack([base[k][0] for k in order])
+        depth = np.stack([base[k][1] for k in order])
+        Twc = np.stack([base[k][2] for k in order]).astype(np.float64)
+        Tcw = np.linalg.inv(Twc).astype(np.float32)
+        batches.append((gray, depth, Tcw, Twc.astype(np.float32), order,
+                        torch.from_numpy(gray).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()))
+    torch.cuda.synchronize()
+    pipe = lib.Pipeline(depth_n, max_width=cam.w, max_height=cam.h, max_batch=B)
+    try:
+        views = [FrontEnd(cam, max_batch=B, ctx=c) for c in pipe.contexts]
+        for rnd in range(2):
+            for i, (gray, depth, Tcw, Twc, order, g_t, d_t) in enumerate(batches):
+                k = pipe.submit(g_t.data_ptr(), d_t.data_ptr(), cam.w * cam.h, cam.w, cam.w, cam.h, Tcw, Twc, views[0].cam, 15.0, False, True, B)
+                assert k == i
+        pipe.sync()
+        rng = np.random.default_rng(7)
+        checked = 0
+        for i, (gray, depth, Tcw, Twc, order, g_t, d_t) in enumerate(batches):
+            slots = np.sort(rng.choice(np.arange(1, B), size=16, replace=False))
+            slots[0], slots[-1] = 1, B - 1                       # the batch's first pair and its last slot are always among them
+            checked += SlotChecker(cam).check(views[i], gray, depth, Tcw, Twc, slots, keys=order, what="context %d " % i)
+            assert views[i].ctx.orb_counts(B).min() > 300
+        assert checked == 16 * depth_n
+    finally:
+        pipe.close()

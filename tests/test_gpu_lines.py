@@ -29,11 +29,20 @@ def _frame(seed, kind):
     return g
 
 
+@pytest.fixture(params=[0, 1], ids=["rect_literal", "rect_real"])
+def rect_mode(request, ctx):
+    """rect_nfa's reading (drfe_lsd_configure_rect): 0 the literal OpenCV 3.4 source (default), 1 the real-valued one of
+    rounds 2-3.  Every oracle-parity test of the line path runs under both."""
+    ctx.lsd_configure_rect(request.param)
+    yield request.param
+    ctx.lsd_configure_rect(0)
+
+
 @pytest.mark.parametrize("seed,kind", [(2, "room_boxes"), (1, "planar_lowtexture"), (5, "corridor"), (3, "living_room")])
-def test_lines_bit_exact(ctx, oracle_mod, seed, kind):
+def test_lines_bit_exact(ctx, oracle_mod, seed, kind, rect_mode):
     g = _frame(seed, kind)
     a = ctx.lsd_extract(g, stages=True)
-    o = oracle_mod.extract_lines(g, stages=True)
+    o = oracle_mod.extract_lines(g, stages=True, rect_mode=rect_mode)
     for k in ("scaled", "gx", "gy"):
         assert np.array_equal(a[k], o[k]), k
     assert np.array_equal(a["modgrad"].view(np.uint64), o["modgrad"].view(np.uint64))
@@ -47,14 +56,16 @@ def test_lines_bit_exact(ctx, oracle_mod, seed, kind):
     assert (np.unpackbits(a["desc"], axis=1).sum(1) > 20).all()
 
 
-def test_lines_analytic_polygons_bit_exact(ctx, oracle_mod):
+def test_lines_analytic_polygons_bit_exact(ctx, oracle_mod, rect_mode):
     """The analytic polygon scene whose segments tests/test_oracle_cpu2.py checks in closed form: the device path reports
-    the same 11 segments as the oracle, bit for bit."""
+    the same segments as the oracle, bit for bit - all 11 under the real-valued rect_nfa, the ones the literal OpenCV 3.4
+    rect_nfa validates (it rejects most oblique rectangles) under the default."""
     from line_scenarios import analytic_polygons
     g, edges = analytic_polygons()
     a = ctx.lsd_extract(g)
-    o = oracle_mod.extract_lines(g)
-    assert a["detected"] == o["detected"] == len(edges) == 11
+    o = oracle_mod.extract_lines(g, rect_mode=rect_mode)
+    assert a["detected"] == o["detected"] and len(edges) == 11
+    assert (o["detected"] == 11) if rect_mode == 1 else (2 <= o["detected"] < 11)
     for gk, ok in PAIRS:
         assert np.array_equal(a["lines"][gk].view(np.uint32), o["lines"][ok].view(np.uint32)), gk
     assert np.array_equal(a["desc"], o["desc"])
@@ -169,7 +180,7 @@ def test_lsd_extract_batch_equals_single(ctx, device_grow):
 
 
 @pytest.mark.parametrize("kind,seed", [("living_room", 3), ("room_boxes", 7), ("corridor", 5), ("planar_lowtexture", 4)])
-def test_lsd_device_grow_matches_oracle(ctx, oracle_mod, kind, seed):
+def test_lsd_device_grow_matches_oracle(ctx, oracle_mod, kind, seed, rect_mode):
     """The device region growing against the CPU oracle (own restatement, glibc cos / sin) on every scene kind: key lines,
     LBD descriptors and line equations of 12 frames per kind, bit for bit; more chunks than one (chunking is by 16 frames)."""
     from dr_slam_amd import synth
@@ -177,7 +188,7 @@ def test_lsd_device_grow_matches_oracle(ctx, oracle_mod, kind, seed):
     frames = frames + frames[:8]                      # 20 frames: two chunks
     batch = ctx.lsd_extract_batch(np.stack(frames), n_threads=4)
     for g, a in zip(frames[:12], batch):
-        o = oracle_mod.extract_lines(g)
+        o = oracle_mod.extract_lines(g, rect_mode=rect_mode)
         assert a["detected"] == o["detected"] and len(a["lines"]) == len(o["lines"])
         for gk, ok in PAIRS:
             assert np.array_equal(a["lines"][gk].view(np.uint32), o["lines"][ok].view(np.uint32)), gk
@@ -187,7 +198,7 @@ def test_lsd_device_grow_matches_oracle(ctx, oracle_mod, kind, seed):
         _same_lines(a, b)
 
 
-def test_lsd_device_grow_polygons_and_odd_size(ctx, oracle_mod):
+def test_lsd_device_grow_polygons_and_odd_size(ctx, oracle_mod, rect_mode):
     """Analytic polygons (every edge must be found where it was drawn) and a frame size whose scaled width is not a multiple
     of 64 through the device path; flat and noise-only images give no lines."""
     imgs = []
@@ -212,9 +223,10 @@ def test_lsd_device_grow_polygons_and_odd_size(ctx, oracle_mod):
     batch = ctx.lsd_extract_batch(np.stack(imgs), n_threads=2)
     for g, a in zip(imgs, batch):
         _same_lines(a, ctx.lsd_extract(g))
-    assert all(len(b["lines"]) >= 4 for b in batch[:3]) and len(batch[-2]["lines"]) == 0
+    # four sides under the real-valued rect_nfa; the literal one validates one or two of these oblique quadrilaterals' sides
+    assert all(len(b["lines"]) >= (4 if rect_mode == 1 else 1) for b in batch[:3]) and len(batch[-2]["lines"]) == 0
     if gp.shape == (480, 640):
-        assert batch[3]["detected"] == len(edges)
+        assert batch[3]["detected"] == (len(edges) if rect_mode == 1 else oracle_mod.extract_lines(gp)["detected"])
     odd = [f[0][:403, :531].copy() for f in synth_frames_odd()]
     for g, a in zip(odd, ctx.lsd_extract_batch(np.stack(odd), n_threads=2)):
         _same_lines(a, ctx.lsd_extract(g))

@@ -260,9 +260,9 @@ def test_lsd_host_stages_without_a_device(oracle_mod):
     rect_improve with host pixel counts, NFA) on the oracle's level-line fields: same segments as the oracle's own
     sequential implementation.  No device involved (drfe_lsd_segments_host)."""
     from dr_slam_amd import lib, synth
-    for seed, kind in ((2, "room_boxes"), (5, "corridor")):
+    for seed, kind, mode in ((2, "room_boxes", 0), (5, "corridor", 0), (2, "room_boxes", 1), (5, "corridor", 1)):
         g, _, _ = next(synth.sequence(seed, 1, kind=kind))
-        o = oracle_mod.extract_lines(g, max_lines=100000, stages=True)
+        o = oracle_mod.extract_lines(g, max_lines=100000, stages=True, rect_mode=mode)
         ang = o["angles"]
         cs = np.zeros(ang.shape + (2,), np.float32)
         defined = ang != -1024.0
@@ -270,7 +270,7 @@ def test_lsd_host_stages_without_a_device(oracle_mod):
         # canonical cos/sin of float(angle): the exactly rounded value (oracle_math.h / drfe_math.h agree on it)
         cs[..., 0] = np.where(defined, np.cos(a32.astype(np.float64)).astype(np.float32), 0)
         cs[..., 1] = np.where(defined, np.sin(a32.astype(np.float64)).astype(np.float32), 0)
-        segs = lib.lsd_segments_host(o["modgrad"], ang, cs, float(o["modgrad"].max()))
+        segs = lib.lsd_segments_host(o["modgrad"], ang, cs, float(o["modgrad"].max()), rect_mode=mode)
         assert len(segs) == o["detected"] > 40
         h, w = g.shape
         e = segs.copy()
