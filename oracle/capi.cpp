@@ -452,6 +452,11 @@ void orc_lines_trace_info(void* h, int32_t* out2)
     LineHandle* H = (LineHandle*)h;
     out2[0] = (int)(H->st.rectCounts.size() / 2); out2[1] = (int)(H->st.segments.size() / 4);
 }
+void orc_lines_trace_get_info(void* h, double* info3)
+{
+    LineHandle* H = (LineHandle*)h;
+    if (info3 && !H->st.segInfo.empty()) std::memcpy(info3, H->st.segInfo.data(), H->st.segInfo.size() * sizeof(double));
+}
 void orc_lines_trace_get(void* h, int32_t* counts, float* segs)
 {
     LineHandle* H = (LineHandle*)h;

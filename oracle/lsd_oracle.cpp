@@ -527,6 +527,8 @@ struct Lsd {
                 rec.x1 /= SCALE; rec.y1 /= SCALE; rec.x2 /= SCALE; rec.y2 /= SCALE; rec.width /= SCALE;
                 lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1));
                 lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
+                /* what LineSegmentDetector::detect also reports per segment (LSD_REFINE_ADV): width, precision, -log10(NFA) */
+                if (st) { st->segInfo.push_back(rec.width); st->segInfo.push_back(rec.p); st->segInfo.push_back(log_nfa); }
             }
         }
     }

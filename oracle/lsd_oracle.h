@@ -24,6 +24,7 @@ struct LsdStages {   /* intermediates for stage-by-stage parity of the device im
     std::vector<int16_t> gx, gy;          /* Sobel of the 5x5-blurred image (LBD input) */
     std::vector<int> rectCounts;          /* (total_pts, alg_pts) of every rect_nfa call in call order */
     std::vector<float> segments;          /* the detector's x1 y1 x2 y2 per accepted segment, before the key-line stage */
+    std::vector<double> segInfo;          /* per accepted segment: width, p (precision / pi), -log10(NFA) - detect()'s optional outputs */
 };
 
 struct LineResult {

@@ -685,7 +685,8 @@ def extract_lines(gray, max_lines=40, stages=False, rect_mode=0, trace=False):
     highest-response lines, LBD descriptors, normalised line equations.
     rect_mode: rect_nfa's reading - 0 literal OpenCV 3.4 (integer corners, default), 1 real-valued (round 3).
     Returns dict(lines (KEYLINE_DTYPE), desc [n,32], descf [n,72], lineF [n,3], detected[, stage images]
-    [, rect_counts [calls,2] int32 in call order, segments [n,4] float32 before the key-line stage])."""
+    [, rect_counts [calls,2] int32 in call order, segments [n,4] float32 before the key-line stage, seg_width / seg_prec /
+    seg_nfa: what cv::LineSegmentDetector::detect reports beside the segments])."""
     g = _c(gray, np.uint8)
     h, w = g.shape
     L = lib()
@@ -722,7 +723,10 @@ def extract_lines(gray, max_lines=40, stages=False, rect_mode=0, trace=False):
             L.orc_lines_trace_info(H, _p(tn))
             rc, sg = np.zeros((int(tn[0]), 2), np.int32), np.zeros((int(tn[1]), 4), np.float32)
             L.orc_lines_trace_get(H, _p(rc), _p(sg))
-            out.update(rect_counts=rc, segments=sg)
+            L.orc_lines_trace_get_info.argtypes = [C.c_void_p, C.c_void_p]
+            si = np.zeros((int(tn[1]), 3))
+            L.orc_lines_trace_get_info(H, _p(si))
+            out.update(rect_counts=rc, segments=sg, seg_width=si[:, 0], seg_prec=si[:, 1] * np.pi, seg_nfa=si[:, 2])
     finally:
         L.orc_lines_free(H)
     return out

@@ -52,9 +52,18 @@ def test_undistort_points_equal_opencv(oracle_mod, pins):
     assert np.array_equal(np.asarray(got, np.float32).view(np.uint32), pins["undist_out"].reshape(-1, 2).view(np.uint32))
 
 
-def test_lsd_segments_equal_opencv(oracle_mod, pins):
-    o = oracle_mod.extract_lines(pins["lsd_img"], max_lines=100000)
-    L = o["lines"]
-    got = np.stack([L["startPointX"], L["startPointY"], L["endPointX"], L["endPointY"]], 1)
-    assert len(got) == len(pins["lsd_segments"])
-    assert np.abs(got - pins["lsd_segments"]).max() < 1e-3     # KeyLine end points are clamped copies of the segments
+@pytest.mark.parametrize("tag", ["lsd", "lsd_oblique", "lsd_diag45"])
+def test_lsd_segments_equal_opencv(oracle_mod, pins, tag):
+    """The detector's segments with their exact float32 bits, and width / precision / -log10(NFA) per segment (the NFA is a
+    function of rect_nfa's pixel counts: it tells which reading of rect_nfa - drfe_lsd_configure_rect 0 or 1 - the library
+    implements; the oblique-edge scene decides it outright: the literal reading rejects that segment)."""
+    if tag + "_img" not in pins:
+        pytest.skip("opencv_pins.npz predates the per-segment dump: regenerate it with tools/dump_opencv_reference.py")
+    o = oracle_mod.extract_lines(pins[tag + "_img"], max_lines=100000, trace=True)
+    ref = pins[tag + "_segments"]
+    assert len(o["segments"]) == len(ref)
+    assert np.array_equal(o["segments"].view(np.uint32), ref.view(np.uint32))
+    if tag + "_nfa" in pins and len(ref):
+        assert np.array_equal(o["seg_width"], pins[tag + "_width"])
+        assert np.allclose(o["seg_prec"], pins[tag + "_prec"], rtol=1e-15, atol=0)
+        assert np.allclose(o["seg_nfa"], pins[tag + "_nfa"], rtol=1e-12, atol=1e-12)     # libm of the dumping host

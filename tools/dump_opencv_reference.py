@@ -58,9 +58,30 @@ def main():
     out["undist_out"] = cv2.undistortPoints(pts, K, dist, None, None, K)
     lines_img = np.load(os.path.join(GOLD, "planes_lines_bow.npz"))["gray"] if "gray" in np.load(os.path.join(GOLD, "planes_lines_bow.npz")) else gray
     lsd = cv2.createLineSegmentDetector(cv2.LSD_REFINE_ADV)
-    segs = lsd.detect(lines_img)[0]
-    out["lsd_img"] = lines_img
-    out["lsd_segments"] = np.zeros((0, 4), np.float32) if segs is None else segs.reshape(-1, 4).astype(np.float32)
+
+    def detect(img, tag):
+        """segments with their exact float32 bits plus the detector's optional outputs: width, precision and -log10(NFA) of
+        every segment.  The NFA is a function of rect_nfa's (total_pts, alg_pts, p) alone, so these values say which pixels
+        the library's rect_nfa walked - the question drfe_lsd_configure_rect leaves open (integer or real-valued steps)."""
+        segs, width, prec, nfa = lsd.detect(img)
+        n = 0 if segs is None else len(segs)
+        out[tag + "_img"] = img
+        out[tag + "_segments"] = np.zeros((0, 4), np.float32) if n == 0 else np.asarray(segs, np.float32).reshape(-1, 4)
+        out[tag + "_width"] = np.zeros(0) if n == 0 else np.asarray(width, np.float64).reshape(-1)
+        out[tag + "_prec"] = np.zeros(0) if n == 0 else np.asarray(prec, np.float64).reshape(-1)
+        out[tag + "_nfa"] = np.zeros(0) if n == 0 else np.asarray(nfa, np.float64).reshape(-1)
+
+    detect(lines_img, "lsd")
+    # the decisive scenes: one long oblique step edge (slope 0.6) and its 45-degree sibling.  Under the literal reading of
+    # rect_nfa (integer step quotients) the first one is REJECTED by LSD_REFINE_ADV and the second kept; under the real-valued
+    # reading both are kept (tests/test_oracle_cpu2.py::test_lsd_lines_on_clean_edges).
+    yy, xx = np.mgrid[0:480, 0:640]
+    ob = np.full((480, 640), 50, np.uint8)
+    ob[(yy - 0.6 * xx) > 40] = 200
+    detect(ob, "lsd_oblique")
+    d45 = np.full((480, 640), 50, np.uint8)
+    d45[(yy - xx) > 40] = 200
+    detect(d45, "lsd_diag45")
     np.savez_compressed(os.path.join(GOLD, "opencv_pins.npz"), **out)
     print("wrote", os.path.join(GOLD, "opencv_pins.npz"), "with OpenCV", cv2.__version__)
 
