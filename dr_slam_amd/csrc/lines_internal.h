@@ -25,6 +25,8 @@ struct LinesScratch {
     int* d_ordStatus; int* h_ordStatus;   /* k_lsd_order's status word per slot */
     uint32_t* h_order; unsigned long long* h_meta; struct LsdRect* h_rects; int* h_out; struct LsdGrowFrame* h_frames;
     int rectCap;
+    /* rect_improve + NFA on the device: validated segments per rectangle slot, pinned mirror, the host-filled log-gamma table */
+    struct LsdSegOut* d_segs; struct LsdSegOut* h_segs; double* d_lgamma; int lgammaN;
 };
 
 /* one rectangle whose aligned pixels are to be counted: the fields cv::LineSegmentDetectorImpl::rect_nfa reads */
@@ -42,6 +44,24 @@ struct LbdTables { float coefG[63], coefL[21]; };      /* the Gaussian band weig
  * the 63 band rows for the row sums, lane = (moment, band) for the band accumulation; every float sum in the reference's order */
 hipError_t drfe_launch_lbd(const LbdLine* d_lines, int n, const int16_t* d_gx, const int16_t* d_gy, int w, int h,
                            const LbdTables& tab, uint8_t* d_out, hipStream_t s);
+
+/* ---- rect_improve + NFA on the device (lsd_nfa_kernels.hip) ---- */
+/* the constants of cv::LineSegmentDetectorImpl::nfa as the HOST's libm computes them: the device never evaluates a log-gamma
+ * or a log of p itself.  p[j] = p0 / 2^j (rect_improve halves the precision at most ten times); lgamma[i] = log_gamma(double(i))
+ * for every i a W x H field can ask for (i <= W x H + 1) */
+struct LsdNfaTables {
+    double logNT;
+    double p[11], logP[11], log1mP[11], log10P[11];
+    const double* lgamma; int lgammaN;
+};
+/* one validated rectangle: the segment LineSegmentDetectorImpl::detect would emit (input-image scale), flag 1 = kept */
+struct LsdSegOut { float x1, y1, x2, y2; int flag; };
+#define DRFE_LSD_NFA_UNCERTAIN 1        /* LsdGrowFrame::out[2]: a decision of rect_improve the device could not certify */
+struct LsdGrowFrame;
+/* rect_improve for every rectangle of nframes frames (d_frames[f].rects / out[0]): d_segs[f * rectCap + i] per rectangle in
+ * seed order; d_frames[f].out[2] |= DRFE_LSD_NFA_UNCERTAIN when a decision was too close to certify */
+hipError_t drfe_launch_rect_improve(const LsdGrowFrame* d_frames, int nframes, int W, int H, int rectMode, const LsdNfaTables& tab,
+                                    int rectCap, LsdSegOut* d_segs, hipStream_t s);
 
 /* ---- device region growing (lsd_grow_kernels.hip) ---- */
 /* a rectangle as cv::LineSegmentDetectorImpl::rect carries it (what region2rect fills; prec, p of the detection) */

@@ -79,6 +79,21 @@ public:
         }
         return true;
     }
+    /* the constants nfa() takes from the libm, for the device's rect_improve (lsd_nfa_kernels.hip): log10 / log of the up to
+     * eleven precisions p0 / 2^j, and log_gamma at every integer a W x H field can ask for - the host's values, so the
+     * device's NFA differs from this class's only where exp / log10 / pow enter */
+    void fillTables(double p0, int W, int H, LsdNfaTables& t, std::vector<double>& lg) const
+    {
+        t.logNT = logNT_;
+        double p = p0;
+        for (int j = 0; j < 11; j++) {
+            t.p[j] = p; t.logP[j] = std::log(p); t.log1mP[j] = std::log(1.0 - p); t.log10P[j] = std::log10(p);
+            p /= 2;
+        }
+        lg.resize((size_t)W * H + 2);
+        for (size_t i = 0; i < lg.size(); i++) lg[i] = logGammaInt((int)i);
+        t.lgamma = nullptr; t.lgammaN = (int)lg.size();
+    }
 private:
     double logNT_;
     static double logGamma(double x)
@@ -565,9 +580,9 @@ static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
     void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_cs0, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
-                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus};
+                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus, s->d_segs, s->d_lgamma};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts};
+    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts, s->h_segs};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     delete s;
     s = nullptr;
@@ -641,6 +656,11 @@ static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int f
         LCHK(hipHostMalloc((void**)&s->h_rects, F * s->rectCap * sizeof(LsdRect), hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_out, F * DRFE_LSD_OUT_INTS * sizeof(int), hipHostMallocDefault));
         LCHK(hipHostMalloc((void**)&s->h_frames, F * sizeof(LsdGrowFrame), hipHostMallocDefault));
+        LCHK(hipMalloc((void**)&s->d_segs, F * s->rectCap * sizeof(LsdSegOut)));
+        LCHK(hipHostMalloc((void**)&s->h_segs, F * s->rectCap * sizeof(LsdSegOut), hipHostMallocDefault));
+        /* log_gamma at the integers, by the host's libm (RectValidator::fillTables fills and uploads it on first use) */
+        s->lgammaN = 0;
+        LCHK(hipMalloc((void**)&s->d_lgamma, ((size_t)s->sw * s->sh + 2) * sizeof(double)));
     }
 #undef LCHK
     return DRFE_OK;
@@ -886,6 +906,10 @@ struct BatchJob {
     int firstRc = DRFE_OK; std::string firstErr;
     bool abort = false;
     double prec, p; int minReg;
+    bool deviceNfa = true;              /* rect_improve + NFA decisions by k_rect_improve (default) or on the pool with the host's libm (DRFE_LSD_HOST_NFA=1) */
+    LsdNfaTables nfaTab;
+    int rectMode = 0;
+    std::atomic<long> nfaToHost{0};     /* frames whose NFA decisions the device could not certify */
     bool deviceOrder = true;            /* the ordering by k_lsd_order (default) or by the pool (DRFE_LSD_HOST_ORDER=1: A/B, tests) */
     hipEvent_t stageEv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* DRFE_TRACE_LINES, chunk 0: start | upload | passes | keys | ordering | growth */
     std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0}, usCountsWall{0}, usCountsCpu{0}, nCountRounds{0}, handedBack{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
@@ -924,6 +948,9 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
         BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
     BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
     BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st));
+    /* rect_improve + the NFA decisions of every accepted rectangle, behind the growth on the same stream: no host round trip */
+    if (J.deviceNfa)
+        BCHK(drfe_launch_rect_improve(A->d_frames + f0, nf, A->sw, A->sh, J.rectMode, J.nfaTab, A->rectCap, A->d_segs + (size_t)A->rectCap * f0, st));
     /* no download behind the growth: a copy queued on a DMA ring waits there for its kernel and holds up every other stream's
      * copies behind it (measured: the plane path's kernels and CAPE's transfers stalled for the whole growth); the worker that
      * sees the event fetches the chunk's status words */
@@ -1024,7 +1051,25 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
                  * sequential half again on the host, from the fields the device still has */
                 rc = ensure_lines(lw->err, lw->ls, J.w, J.h, 1, false, false);
                 if (rc == DRFE_OK) rc = host_grow_and_finish(lw, A, f, J.maxLines, lo, dout, lf, J.cap, &J.nLines[f], &nd, std::chrono::steady_clock::now());
+            } else if (J.deviceNfa && A->h_out[DRFE_LSD_OUT_INTS * (size_t)f + 2] == 0) {
+                /* the device validated the rectangles (k_rect_improve): fetch the segments, keep the accepted ones in seed order */
+                LsdSegOut* hs = A->h_segs + (size_t)A->rectCap * f;
+                if (nRects > 0 && hipMemcpyAsync(hs, A->d_segs + (size_t)A->rectCap * f, sizeof(LsdSegOut) * nRects, hipMemcpyDeviceToHost, lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
+                if (rc == DRFE_OK && nRects > 0 && lane_sync(lw) != hipSuccess) rc = DRFE_ERR_HIP;
+                if (rc != DRFE_OK) lw->err = "lsd_extract_batch: segment download";
+                if (rc == DRFE_OK) {
+                    std::vector<float> segs;
+                    segs.reserve((size_t)nRects * 4);
+                    for (int i = 0; i < nRects; i++)
+                        if (hs[i].flag) { segs.push_back(hs[i].x1); segs.push_back(hs[i].y1); segs.push_back(hs[i].x2); segs.push_back(hs[i].y2); }
+                    const FrameView v = {A->w, A->h, A->sw, A->sh, A->d_angles + ns * f, A->d_gx + n * f, A->d_gy + n * f};
+                    const auto tk = std::chrono::steady_clock::now();
+                    J.usRectDl += std::chrono::duration_cast<std::chrono::microseconds>(tk - tTask).count();
+                    rc = keylines_and_descriptors(lw, v, segs, J.maxLines, lo, dout, lf, J.cap, &J.nLines[f], &nd);
+                    J.usKeyl += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tk).count();
+                }
             } else {
+                if (J.deviceNfa) J.nfaToHost++;
                 std::vector<RectD> pending(nRects);
                 /* through the arena's pinned mirror: a download into pageable memory stages inside the copy call */
                 LsdRect* hr = A->h_rects + (size_t)A->rectCap * f;
@@ -1093,6 +1138,17 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         HIPCHK(c, hipHostMalloc((void**)&A->h_order, (size_t)(A->sw - 1) * (A->sh - 1) * (size_t)A->frames * 4, hipHostMallocDefault));
     const RectValidator val(A->sw, A->sh);
     J.prec = M_PI * 22.5 / 180; J.p = 22.5 / 180; J.minReg = (int)val.minReg(J.p);
+    J.rectMode = c->lsdRectMode;
+    J.deviceNfa = c->lsdDeviceNfa && std::getenv("DRFE_LSD_HOST_NFA") == nullptr;
+    if (J.deviceNfa) {
+        std::vector<double> lg;
+        val.fillTables(J.p, A->sw, A->sh, J.nfaTab, lg);
+        if (A->lgammaN != (int)lg.size()) {          /* once per arena: 1.5 MB at 640 x 480 */
+            HIPCHK(c, hipMemcpy(A->d_lgamma, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice));
+            A->lgammaN = (int)lg.size();
+        }
+        J.nfaTab.lgamma = A->d_lgamma;
+    }
     for (int ch = 0; ch < nChunks; ch++) J.sortedInChunk[ch].store(0);
     J.chunkStream.resize(nChunks); J.keysReady.resize(nChunks); J.growDone.resize(nChunks);
     /* one stream per chunk: kernels of different chunks overlap, the work of one chunk stays ordered.  LOW priority: the
@@ -1152,6 +1208,10 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
                      ms[0], ms[1], ms[2], ms[3], ms[4]);
     }
     for (hipEvent_t& e : J.stageEv) if (e) (void)hipEventDestroy(e);
+    c->lsdStats[0] += nframes; c->lsdStats[1] += J.handedBack.load(); c->lsdStats[2] += J.nfaToHost.load();
+    if (std::getenv("DRFE_TRACE_LINES"))
+        std::fprintf(stderr, "drfe_lsd_extract_batch: rect_improve / NFA %s; %ld of %d frames back to the host's validation (a decision too close to certify)\n",
+                     J.deviceNfa ? "on the device (k_rect_improve)" : "on the host pool", J.nfaToHost.load(), nframes);
     if (std::getenv("DRFE_TRACE_LINES"))
         std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f (of which in the counting round trips: %.2f wall, %.2f CPU), key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device; %ld frames redone on the host\n",
                      nframes, nChunks, chunk, T, std::chrono::duration<double, std::milli>(tLaunched - tBegin).count(),
@@ -1200,6 +1260,24 @@ int drfe_lsd_configure(drfe_ctx* c, int device_grow)
 {
     if (!c || device_grow < 0 || device_grow > 1) { if (c) c->err = "lsd_configure: invalid argument"; return DRFE_ERR_INVALID; }
     c->lsdDeviceGrow = device_grow;
+    return DRFE_OK;
+}
+
+/* where drfe_lsd_extract_batch takes rect_improve's decisions: 1 (default) on the device (k_rect_improve: certified
+ * comparisons, uncertain frames return to the host), 0 on the pool threads with the host's libm.  Results are identical. */
+int drfe_lsd_configure_nfa(drfe_ctx* c, int device_nfa)
+{
+    if (!c || device_nfa < 0 || device_nfa > 1) { if (c) c->err = "lsd_configure_nfa: invalid argument"; return DRFE_ERR_INVALID; }
+    c->lsdDeviceNfa = device_nfa;
+    return DRFE_OK;
+}
+
+/* counters of this context's drfe_lsd_extract_batch calls since creation: [0] frames through the device path, [1] frames whose
+ * region growing went back to the host (uncertified rounding, capacity), [2] frames whose NFA decisions went back to the host */
+int drfe_lsd_stats(drfe_ctx* c, long long* out3)
+{
+    if (!c || !out3) return DRFE_ERR_INVALID;
+    for (int i = 0; i < 3; i++) out3[i] = c->lsdStats[i];
     return DRFE_OK;
 }
 

@@ -599,7 +599,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         }
         if (cand && !nontrivial && lane >= from && !w.bit(q)) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
     }
-    if (lane == 0) { w.F.out[0] = nRects; w.F.out[1] = w.status; }
+    if (lane == 0) { w.F.out[0] = nRects; w.F.out[1] = w.status; w.F.out[2] = 0; /* k_rect_improve's status word */ }
 #ifdef LSD_PROFILE
     PROF_ADD(7, tAll);
     if (lane == 0) for (int k = 0; k < 16; k++) ((GLOBAL_AS unsigned long long*)(w.F.out + 4))[k] = w.prof[k];

@@ -353,6 +353,15 @@ int drfe_lsd_configure(drfe_ctx* ctx, int device_grow);
  *   divide by zero taken as 0), kept until a pin against a real OpenCV 3.4.4 build decides (tools/dump_opencv_reference.py
  *   dumps the per-rectangle counts such a pin compares). */
 int drfe_lsd_configure_rect(drfe_ctx* ctx, int rect_mode);
+/* Where drfe_lsd_extract_batch takes the decisions of cv::LineSegmentDetectorImpl::rect_improve (OpenCV 3.4 lsd.cpp: which
+ * refinement candidate replaces a rectangle, whether its NFA passes): 1 (default) on the device behind the region growing
+ * (k_rect_improve: the host libm's log-gamma / log tables, its own exp / log10 / pow, every comparison certified against a
+ * bound on the difference to the host's value - a frame with a comparison too close to call is validated on the host), 0 on
+ * the pool threads with the caller's libm (rounds 2-3).  Results are identical. */
+int drfe_lsd_configure_nfa(drfe_ctx* ctx, int device_nfa);
+/* counters since drfe_create: out3[0] frames through drfe_lsd_extract_batch's device path, [1] frames whose region growing
+ * returned to the host, [2] frames whose NFA decisions returned to the host */
+int drfe_lsd_stats(drfe_ctx* ctx, long long* out3);
 /* drfe_lsd_segments_host with rect_nfa's reading chosen by the caller (drfe_lsd_segments_host: 0). */
 int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad,
                                 int rect_mode, float* segs, int cap, int* n_segs);

@@ -419,3 +419,38 @@ def test_lsd_batch_device_edge_cases(ctx):
             assert a["detected"] == got[f]["detected"] and a["lines"].tobytes() == got[f]["lines"].tobytes()
             assert np.array_equal(a["desc"], got[f]["desc"]) and a["lineF"].tobytes() == got[f]["lineF"].tobytes()
     assert len(got[0]["lines"]) == 0 and got[2]["detected"] >= 1 and got[3]["detected"] >= 40
+
+
+def test_lsd_device_nfa_equals_host_nfa(ctx, oracle_mod, rect_mode):
+    """rect_improve's decisions on the device (k_rect_improve: certified comparisons on its own exp / log10 / pow) against
+    the host pool's (the caller's libm) for every scene kind, and against the oracle; frames whose decisions the device
+    could not certify return to the host and are counted."""
+    from dr_slam_amd import synth
+    frames = []
+    for kind, seed in (("living_room", 3), ("room_boxes", 7), ("corridor", 5), ("planar_lowtexture", 4)):
+        frames += [f[0] for f in synth.sequence(seed, 5, cam=synth.ICL if kind == "living_room" else synth.TUM3, kind=kind)]
+    yy, xx = np.mgrid[0:480, 0:640]
+    for sl in (0.2, 0.6, 1.0, 1.7):                       # long clean edges: NFA values far out in the tail (subnormal first terms)
+        g = np.full((480, 640), 50, np.uint8)
+        g[(yy - sl * xx) > 40] = 200
+        frames.append(g)
+    batch = np.stack(frames)
+    s0 = ctx.lsd_stats()
+    dev = ctx.lsd_extract_batch(batch, n_threads=4)
+    s1 = ctx.lsd_stats()
+    assert s1["frames"] - s0["frames"] == len(frames)
+    assert s1["nfa_to_host"] - s0["nfa_to_host"] <= 1            # certification failures are rare events
+    ctx.lsd_configure_nfa(False)
+    try:
+        host = ctx.lsd_extract_batch(batch, n_threads=4)
+    finally:
+        ctx.lsd_configure_nfa(True)
+    assert ctx.lsd_stats()["nfa_to_host"] == s1["nfa_to_host"]
+    for a, b in zip(dev, host):
+        _same_lines(a, b)
+    for g, a in list(zip(frames, dev))[::5] + list(zip(frames, dev))[-4:]:
+        o = oracle_mod.extract_lines(g, rect_mode=rect_mode)
+        assert a["detected"] == o["detected"]
+        for gk, ok in PAIRS:
+            assert np.array_equal(a["lines"][gk].view(np.uint32), o["lines"][ok].view(np.uint32)), gk
+        assert np.array_equal(a["desc"], o["desc"])
