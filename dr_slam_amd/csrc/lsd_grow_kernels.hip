@@ -29,7 +29,9 @@
 #include "cr_sincos.h"
 #include <type_traits>
 
+#ifndef LSD_RING
 #define LSD_RING 512          /* newest members mirrored in LDS */
+#endif
 #ifdef LSD_PROFILE
 #define PROF_T() wall_clock64()
 #define PROF_ADD(k, t0) w.prof[k] += wall_clock64() - (t0)

@@ -8,7 +8,9 @@
 #include "drfe_internal.h"
 #include "lines_internal.h"
 #include "introsort_device.h"
-#define ORD_T 1024
+#ifndef ORD_T
+#define ORD_T 256
+#endif
 
 namespace {
 /* key bin << 22 | y << 11 | x; compare_norm: a goes before b iff its bin is larger */

@@ -32,7 +32,7 @@ int main(int argc, char** argv)
         if (!none.empty() || desc.rows != (int)kps.size()) return 3;
         if (ex.GetLevels() != 8 || ex.GetScaleFactors().size() != 8 || ex.mvImagePyramid[0].cols != w) return 4;
         LineSegment ls(ex.context());
-        std::vector<drfe_cv::KeyLine> kl; drfe_cv::Mat ldesc; std::vector<std::vector<double>> lf;
+        std::vector<drfe_cv::KeyLine> kl; drfe_cv::Mat ldesc; std::vector<drfe_cv::Vector3d> lf;
         ls.ExtractLineSegment(image, kl, ldesc, lf);
         Planar_SLAM::PlaneDetection pd(ex.context());
         const float K[9] = {535.4f, 0, 320.1f, 0, 539.2f, 247.6f, 0, 0, 1};
