@@ -190,7 +190,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->lsdDeviceGrow = 1;
     c->lsdRectMode = 0;
     c->lsdDeviceNfa = 1;
-    c->lsdStats[0] = c->lsdStats[1] = c->lsdStats[2] = 0;
+    c->lsdStats[0] = c->lsdStats[1] = c->lsdStats[2] = c->lsdStats[3] = 0;
     c->planesDeviceVoxel = 1;
     c->planesDeviceAhc = 1;
     c->ahcArena = nullptr;

@@ -169,7 +169,7 @@ struct drfe_ctx {
     struct LinesScratch* lsBatch; /* frame slots of drfe_lsd_extract_batch's device region growing (lines_lsd.cpp) */
     int lsdDeviceGrow;        /* drfe_lsd_configure: 1 = the batch entry grows regions on the device (default) */
     int lsdDeviceNfa;         /* drfe_lsd_configure_nfa: 1 = rect_improve's decisions on the device in the batch entry (default) */
-    long long lsdStats[3];    /* drfe_lsd_stats */
+    long long lsdStats[4];    /* drfe_lsd_stats */
     int lsdRectMode;          /* drfe_lsd_configure_rect: rect_nfa's reading, 0 = literal OpenCV 3.4 (default), 1 = real-valued */
     int planesDeviceAhc;      /* drfe_planes_configure_extractor: 1 = drfe_planes_ahc_post_batch runs the extractor on the device (default) */
     void* ahcArena;           /* AhcArena*: frame slots of the device extractor (planes_ahc.cpp) */

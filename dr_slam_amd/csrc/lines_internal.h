@@ -27,6 +27,10 @@ struct LinesScratch {
     int rectCap;
     /* rect_improve + NFA on the device: validated segments per rectangle slot, pinned mirror, the host-filled log-gamma table */
     struct LsdSegOut* d_segs; struct LsdSegOut* h_segs; double* d_lgamma; int lgammaN;
+    /* key lines on the device (k_lsd_keylines + k_lbd batch form): klCap slots per frame; pinned mirrors of what the caller receives */
+    int klCap;
+    drfe_keyline* d_kl; double* d_klLineF; struct LbdLine* d_klLbd; uint8_t* d_klDesc; int* d_klOut;
+    drfe_keyline* h_kl; double* h_klLineF; uint8_t* h_klDesc; int* h_klOut;
 };
 
 /* one rectangle whose aligned pixels are to be counted: the fields cv::LineSegmentDetectorImpl::rect_nfa reads */
@@ -62,6 +66,14 @@ struct LsdGrowFrame;
  * seed order; d_frames[f].out[2] |= DRFE_LSD_NFA_UNCERTAIN when a decision was too close to certify */
 hipError_t drfe_launch_rect_improve(const LsdGrowFrame* d_frames, int nframes, int W, int H, int rectMode, const LsdNfaTables& tab,
                                     int rectCap, LsdSegOut* d_segs, hipStream_t s);
+
+/* key lines, response cut, LBD parameters and line equations of nframes frames from k_rect_improve's segments (one wavefront per
+ * frame): d_kl / d_lineF / d_lbd hold klCap slots per frame; d_frameOut[4 f] = {lines kept, lines detected, status (0 = done,
+ * otherwise the host finishes the frame), pad} */
+hipError_t drfe_launch_lsd_keylines(const LsdGrowFrame* d_frames, const LsdSegOut* d_segs, int rectCap, int nframes, int w, int h, int maxLines,
+                                    int klCap, drfe_keyline* d_kl, double* d_lineF, LbdLine* d_lbd, int* d_frameOut, hipStream_t s);
+hipError_t drfe_launch_lbd_batch(const LbdLine* d_lines, const int* d_frameCounts, int klCap, int nframes, const int16_t* d_gx, const int16_t* d_gy,
+                                 int w, int h, const LbdTables& tab, uint8_t* d_out, hipStream_t s);
 
 /* ---- device region growing (lsd_grow_kernels.hip) ---- */
 /* a rectangle as cv::LineSegmentDetectorImpl::rect carries it (what region2rect fills; prec, p of the detection) */

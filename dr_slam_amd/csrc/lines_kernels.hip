@@ -188,13 +188,21 @@ hipError_t drfe_launch_rect_counts(const RectCand* d_cands, int n, const double*
  * in row order (lane = one moment of one band); the normalisation chain is a single lane. */
 __global__ __launch_bounds__(64) void k_lbd(const LbdLine* __restrict__ lines, int n, const int16_t* __restrict__ gx,
                                             const int16_t* __restrict__ gy, int realW, int realH, LbdTables tab,
-                                            uint8_t* __restrict__ out)
+                                            uint8_t* __restrict__ out, const int* __restrict__ frameCounts, int klCap)
 {
     const int NB = 9, WB = 7, height = 63;
     __shared__ float rowv[63][8];
     __shared__ float acc[8][9];
     __shared__ float des[72];
     const int id = blockIdx.x, lane = threadIdx.x;
+    if (frameCounts) {
+        /* batch form (k_lsd_keylines' outputs): blockIdx.y = frame, its line count at frameCounts[4 f], klCap line slots and
+         * descriptor rows per frame, the Sobel images of the frames realW x realH apart */
+        const int f = blockIdx.y;
+        n = frameCounts[4 * (size_t)f];
+        lines += (size_t)f * klCap; out += (size_t)f * klCap * 32;
+        gx += (size_t)f * realW * realH; gy += (size_t)f * realW * realH;
+    }
     if (id >= n) return;
     const LbdLine L = lines[id];
     const short maxX = (short)(realW - 1), maxY = (short)(realH - 1);
@@ -281,7 +289,17 @@ hipError_t drfe_launch_lbd(const LbdLine* d_lines, int n, const int16_t* d_gx, c
                            const LbdTables& tab, uint8_t* d_out, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lbd, dim3(n), dim3(64), 0, s, d_lines, n, d_gx, d_gy, w, h, tab, d_out);
+    hipLaunchKernelGGL(k_lbd, dim3(n), dim3(64), 0, s, d_lines, n, d_gx, d_gy, w, h, tab, d_out, (const int*)nullptr, 0);
+    return hipGetLastError();
+}
+
+/* the same for nframes frames at once: frame f's lines at d_lines[f * klCap ..], its count at d_frameCounts[4 f], its Sobel
+ * images at d_gx / d_gy + f * w * h, its descriptor rows at d_out[f * klCap * 32 ..] */
+hipError_t drfe_launch_lbd_batch(const LbdLine* d_lines, const int* d_frameCounts, int klCap, int nframes, const int16_t* d_gx, const int16_t* d_gy,
+                                 int w, int h, const LbdTables& tab, uint8_t* d_out, hipStream_t s)
+{
+    if (nframes <= 0 || klCap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lbd, dim3(klCap, nframes), dim3(64), 0, s, d_lines, 0, d_gx, d_gy, w, h, tab, d_out, d_frameCounts, klCap);
     return hipGetLastError();
 }
 

@@ -580,9 +580,9 @@ static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
     void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_cs0, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
-                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus, s->d_segs, s->d_lgamma};
+                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus, s->d_segs, s->d_lgamma, s->d_kl, s->d_klLineF, s->d_klLbd, s->d_klDesc, s->d_klOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts, s->h_segs};
+    void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts, s->h_segs, s->h_kl, s->h_klLineF, s->h_klDesc, s->h_klOut};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     delete s;
     s = nullptr;
@@ -907,6 +907,8 @@ struct BatchJob {
     bool abort = false;
     double prec, p; int minReg;
     bool deviceNfa = true;              /* rect_improve + NFA decisions by k_rect_improve (default) or on the pool with the host's libm (DRFE_LSD_HOST_NFA=1) */
+    bool deviceKl = true;               /* key lines, response cut, LBD and line equations on the device too (k_lsd_keylines + k_lbd): the workers only copy */
+    std::atomic<long> klToHost{0};
     LsdNfaTables nfaTab;
     int rectMode = 0;
     std::atomic<long> nfaToHost{0};     /* frames whose NFA decisions the device could not certify */
@@ -951,6 +953,13 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
     /* rect_improve + the NFA decisions of every accepted rectangle, behind the growth on the same stream: no host round trip */
     if (J.deviceNfa)
         BCHK(drfe_launch_rect_improve(A->d_frames + f0, nf, A->sw, A->sh, J.rectMode, J.nfaTab, A->rectCap, A->d_segs + (size_t)A->rectCap * f0, st));
+    if (J.deviceNfa && J.deviceKl) {
+        const size_t k0 = (size_t)A->klCap * f0, px = (size_t)A->w * A->h;
+        BCHK(drfe_launch_lsd_keylines(A->d_frames + f0, A->d_segs + (size_t)A->rectCap * f0, A->rectCap, nf, A->w, A->h, J.maxLines, A->klCap,
+                                      A->d_kl + k0, A->d_klLineF + 3 * k0, A->d_klLbd + k0, A->d_klOut + 4 * (size_t)f0, st));
+        BCHK(drfe_launch_lbd_batch(A->d_klLbd + k0, A->d_klOut + 4 * (size_t)f0, A->klCap, nf, A->d_gx + px * f0, A->d_gy + px * f0, A->w, A->h, lbdTables(),
+                                   A->d_klDesc + 32 * k0, st));
+    }
     /* no download behind the growth: a copy queued on a DMA ring waits there for its kernel and holds up every other stream's
      * copies behind it (measured: the plane path's kernels and CAPE's transfers stalled for the whole growth); the worker that
      * sees the event fetches the chunk's status words */
@@ -1000,6 +1009,14 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
             hipError_t e = hipMemcpyAsync(A->h_out + DRFE_LSD_OUT_INTS * (size_t)f0, A->d_out + DRFE_LSD_OUT_INTS * (size_t)f0, DRFE_LSD_OUT_INTS * sizeof(int) * nf,
                                           hipMemcpyDeviceToHost, lw->stream);
             if (e == hipSuccess && J.deviceOrder) e = hipMemcpyAsync(A->h_ordStatus + f0, A->d_ordStatus + f0, sizeof(int) * nf, hipMemcpyDeviceToHost, lw->stream);
+            if (e == hipSuccess && J.deviceNfa && J.deviceKl) {
+                /* the chunk's finished key lines, descriptors and line equations: four copies for all of its frames */
+                const size_t k0 = (size_t)A->klCap * f0, kn = (size_t)A->klCap * nf;
+                e = hipMemcpyAsync(A->h_klOut + 4 * (size_t)f0, A->d_klOut + 4 * (size_t)f0, 4 * sizeof(int) * nf, hipMemcpyDeviceToHost, lw->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(A->h_kl + k0, A->d_kl + k0, kn * sizeof(drfe_keyline), hipMemcpyDeviceToHost, lw->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(A->h_klLineF + 3 * k0, A->d_klLineF + 3 * k0, kn * 3 * sizeof(double), hipMemcpyDeviceToHost, lw->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(A->h_klDesc + 32 * k0, A->d_klDesc + 32 * k0, kn * 32, hipMemcpyDeviceToHost, lw->stream);
+            }
             if (e == hipSuccess) e = lane_sync(lw);
             if (e != hipSuccess) { batch_fail(J, DRFE_ERR_HIP, "lsd_extract_batch: status words of a chunk"); return; }
             std::lock_guard<std::mutex> lk(J.mu);
@@ -1051,7 +1068,20 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
                  * sequential half again on the host, from the fields the device still has */
                 rc = ensure_lines(lw->err, lw->ls, J.w, J.h, 1, false, false);
                 if (rc == DRFE_OK) rc = host_grow_and_finish(lw, A, f, J.maxLines, lo, dout, lf, J.cap, &J.nLines[f], &nd, std::chrono::steady_clock::now());
+            } else if (J.deviceNfa && J.deviceKl && A->h_klOut[4 * (size_t)f + 2] == 0) {
+                /* everything happened on the device: copy the frame's results out of the chunk's pinned mirrors */
+                const int nl = A->h_klOut[4 * (size_t)f];
+                nd = A->h_klOut[4 * (size_t)f + 1];
+                J.nLines[f] = nl;
+                if (nl > J.cap) { lw->err = "lsd_extract: line buffer too small"; rc = DRFE_ERR_CAPACITY; }
+                else {
+                    const size_t k0 = (size_t)A->klCap * f;
+                    if (lo) std::memcpy(lo, A->h_kl + k0, sizeof(drfe_keyline) * nl);
+                    if (dout) std::memcpy(dout, A->h_klDesc + 32 * k0, (size_t)nl * 32);
+                    if (lf) std::memcpy(lf, A->h_klLineF + 3 * k0, (size_t)nl * 3 * sizeof(double));
+                }
             } else if (J.deviceNfa && A->h_out[DRFE_LSD_OUT_INTS * (size_t)f + 2] == 0) {
+                if (J.deviceKl) J.klToHost++;
                 /* the device validated the rectangles (k_rect_improve): fetch the segments, keep the accepted ones in seed order */
                 LsdSegOut* hs = A->h_segs + (size_t)A->rectCap * f;
                 if (nRects > 0 && hipMemcpyAsync(hs, A->d_segs + (size_t)A->rectCap * f, sizeof(LsdSegOut) * nRects, hipMemcpyDeviceToHost, lw->stream) != hipSuccess) rc = DRFE_ERR_HIP;
@@ -1140,6 +1170,26 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     J.prec = M_PI * 22.5 / 180; J.p = 22.5 / 180; J.minReg = (int)val.minReg(J.p);
     J.rectMode = c->lsdRectMode;
     J.deviceNfa = c->lsdDeviceNfa && std::getenv("DRFE_LSD_HOST_NFA") == nullptr;
+    J.deviceKl = J.deviceNfa && std::getenv("DRFE_LSD_HOST_KEYLINES") == nullptr;
+    if (J.deviceKl && (A->klCap < max_lines || !A->d_kl)) {
+        void* dp[] = {A->d_kl, A->d_klLineF, A->d_klLbd, A->d_klDesc, A->d_klOut};
+        for (void* q : dp) if (q) (void)hipFree(q);
+        void* hp[] = {A->h_kl, A->h_klLineF, A->h_klDesc, A->h_klOut};
+        for (void* q : hp) if (q) (void)hipHostFree(q);
+        A->d_kl = nullptr; A->d_klLineF = nullptr; A->d_klLbd = nullptr; A->d_klDesc = nullptr; A->d_klOut = nullptr;
+        A->h_kl = nullptr; A->h_klLineF = nullptr; A->h_klDesc = nullptr; A->h_klOut = nullptr;
+        A->klCap = max_lines;
+        const size_t kn = (size_t)A->klCap * A->frames;
+        HIPCHK(c, hipMalloc((void**)&A->d_kl, kn * sizeof(drfe_keyline)));
+        HIPCHK(c, hipMalloc((void**)&A->d_klLineF, kn * 3 * sizeof(double)));
+        HIPCHK(c, hipMalloc((void**)&A->d_klLbd, kn * sizeof(LbdLine)));
+        HIPCHK(c, hipMalloc((void**)&A->d_klDesc, kn * 32));
+        HIPCHK(c, hipMalloc((void**)&A->d_klOut, (size_t)A->frames * 4 * sizeof(int)));
+        HIPCHK(c, hipHostMalloc((void**)&A->h_kl, kn * sizeof(drfe_keyline), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&A->h_klLineF, kn * 3 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&A->h_klDesc, kn * 32, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&A->h_klOut, (size_t)A->frames * 4 * sizeof(int), hipHostMallocDefault));
+    }
     if (J.deviceNfa) {
         std::vector<double> lg;
         val.fillTables(J.p, A->sw, A->sh, J.nfaTab, lg);
@@ -1208,7 +1258,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
                      ms[0], ms[1], ms[2], ms[3], ms[4]);
     }
     for (hipEvent_t& e : J.stageEv) if (e) (void)hipEventDestroy(e);
-    c->lsdStats[0] += nframes; c->lsdStats[1] += J.handedBack.load(); c->lsdStats[2] += J.nfaToHost.load();
+    c->lsdStats[0] += nframes; c->lsdStats[1] += J.handedBack.load(); c->lsdStats[2] += J.nfaToHost.load(); c->lsdStats[3] += J.klToHost.load();
     if (std::getenv("DRFE_TRACE_LINES"))
         std::fprintf(stderr, "drfe_lsd_extract_batch: rect_improve / NFA %s; %ld of %d frames back to the host's validation (a decision too close to certify)\n",
                      J.deviceNfa ? "on the device (k_rect_improve)" : "on the host pool", J.nfaToHost.load(), nframes);
@@ -1273,11 +1323,12 @@ int drfe_lsd_configure_nfa(drfe_ctx* c, int device_nfa)
 }
 
 /* counters of this context's drfe_lsd_extract_batch calls since creation: [0] frames through the device path, [1] frames whose
- * region growing went back to the host (uncertified rounding, capacity), [2] frames whose NFA decisions went back to the host */
-int drfe_lsd_stats(drfe_ctx* c, long long* out3)
+ * region growing went back to the host (uncertified rounding, capacity), [2] frames whose NFA decisions went back to the host,
+ * [3] frames whose key-line stage went back to the host (an atan2 / cos / sin rounding not certified, the sort's heap branch) */
+int drfe_lsd_stats(drfe_ctx* c, long long* out3 /* four entries */)
 {
     if (!c || !out3) return DRFE_ERR_INVALID;
-    for (int i = 0; i < 3; i++) out3[i] = c->lsdStats[i];
+    for (int i = 0; i < 4; i++) out3[i] = c->lsdStats[i];
     return DRFE_OK;
 }
 

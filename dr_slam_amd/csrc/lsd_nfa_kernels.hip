@@ -16,6 +16,7 @@
 
 #include "lines_internal.h"
 #include "lsd_rect_walk.h"
+#include "cr_sincos.h"
 
 namespace {
 
@@ -209,5 +210,216 @@ hipError_t drfe_launch_rect_improve(const LsdGrowFrame* d_frames, int nframes, i
     if (nframes <= 0) return hipSuccess;
     /* 192 wavefronts per frame stride over its rectangles (a 640 x 480 frame has ~1500; each takes tens of microseconds) */
     hipLaunchKernelGGL(k_rect_improve, dim3(192, nframes), dim3(64), 0, s, d_frames, W, H, rectMode, tab, rectCap, d_segs);
+    return hipGetLastError();
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * From the validated segments to the caller's key lines on the device: LSDDetector::detect's KeyLine fields (octave 0), the
+ * reference's response cut (src/LSDextractor.cpp:18-28: std::sort by response, keep lsdNFeatures, renumber class_id), the
+ * LBD sampling parameters k_lbd reads and the line equations (:32-42).  One wavefront per frame.
+ *
+ * std::sort is not stable and the comparator sees the response only, so the survivors of a tie at the cut - and their order -
+ * are whatever libstdc++'s introsort leaves: its element moves are executed here by one lane on (response, index) records in
+ * LDS (median of three to the front, unguarded Hoare partition, recursion on the right part, final insertion sort; a range
+ * that exhausts the depth limit - heap sort in libstdc++ - sends the frame to the host).
+ * atan2 (KeyLine::angle) and cos / sin (the LBD direction) are the host libm's in the reference, rounded to float: the device
+ * certifies that rounding (the double moved by 2^-45 either way gives the same float; cr_sincos.h for cos / sin) and flags
+ * the frame for the host otherwise. */
+namespace {
+
+#define KL_MAX_KEPT 2048           /* kept segments per frame the LDS sort holds (a 640 x 480 frame has ~250) */
+
+struct KlShared {
+    float resp[KL_MAX_KEPT];
+    uint16_t idx[KL_MAX_KEPT];      /* position in the frame's rectangle list */
+    int stackLo[64], stackHi[64], stackDepth[64];
+};
+
+/* comp(a, b) of the reference's lambda: a.response > b.response */
+__device__ __forceinline__ bool kl_before(float a, float b) { return a > b; }
+
+__device__ __forceinline__ void kl_swap(KlShared& S, int a, int b)
+{
+    const float r = S.resp[a]; S.resp[a] = S.resp[b]; S.resp[b] = r;
+    const uint16_t i = S.idx[a]; S.idx[a] = S.idx[b]; S.idx[b] = i;
+}
+
+/* std::sort(first, last, comp) of libstdc++ (bits/stl_algo.h: __sort -> __introsort_loop + __final_insertion_sort) on
+ * [0, n); returns false when a range runs out of its depth limit (the __partial_sort heap branch is not restated) */
+__device__ bool kl_std_sort(KlShared& S, int n)
+{
+    if (n < 2) return true;
+    int lg = 0;
+    for (int v = n; v > 1; v >>= 1) lg++;
+    int sp = 0;
+    S.stackLo[0] = 0; S.stackHi[0] = n; S.stackDepth[0] = 2 * lg; sp = 1;
+    /* __introsort_loop(first, last, depth): while (last - first > 16) { cut = partition; __introsort_loop(cut, last, depth); last = cut; }
+     * - the recursion on the right part runs to completion before the left part is touched: a stack of pending LEFT parts
+     * would reverse that, so the loop below keeps (first, last, depth) of the current call and pushes the left remainder. */
+    while (sp > 0) {
+        --sp;
+        int first = S.stackLo[sp], last = S.stackHi[sp], depth = S.stackDepth[sp];
+        while (last - first > 16) {
+            if (depth == 0) return false;
+            --depth;
+            /* __unguarded_partition_pivot: __move_median_to_first(first, first + 1, mid, last - 1), then partition (first + 1, last) around *first */
+            const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+            const float ra = S.resp[a], rb = S.resp[b], rc = S.resp[c];
+            if (kl_before(ra, rb)) {
+                if (kl_before(rb, rc)) kl_swap(S, first, b);
+                else if (kl_before(ra, rc)) kl_swap(S, first, c);
+                else kl_swap(S, first, a);
+            } else if (kl_before(ra, rc)) kl_swap(S, first, a);
+            else if (kl_before(rb, rc)) kl_swap(S, first, c);
+            else kl_swap(S, first, b);
+            const float pivot = S.resp[first];
+            int lo = first + 1, hi = last;
+            for (;;) {
+                while (kl_before(S.resp[lo], pivot)) ++lo;
+                --hi;
+                while (kl_before(pivot, S.resp[hi])) --hi;
+                if (!(lo < hi)) break;
+                kl_swap(S, lo, hi);
+                ++lo;
+            }
+            const int cut = lo;
+            /* recursion on [cut, last) first: continue with it, remember [first, cut) for afterwards */
+            if (sp >= 64) return false;
+            S.stackLo[sp] = first; S.stackHi[sp] = cut; S.stackDepth[sp] = depth; ++sp;
+            first = cut;
+        }
+    }
+    /* __final_insertion_sort: __insertion_sort on the first 16, __unguarded_insertion_sort on the rest */
+    const int head = n > 16 ? 16 : n;
+    for (int i = 1; i < head; ++i) {
+        const float v = S.resp[i]; const uint16_t vi = S.idx[i];
+        if (kl_before(v, S.resp[0])) {
+            for (int j = i; j > 0; --j) { S.resp[j] = S.resp[j - 1]; S.idx[j] = S.idx[j - 1]; }      /* move_backward(first, i, i + 1) */
+            S.resp[0] = v; S.idx[0] = vi;
+        } else {
+            int j = i;
+            while (kl_before(v, S.resp[j - 1])) { S.resp[j] = S.resp[j - 1]; S.idx[j] = S.idx[j - 1]; --j; }
+            S.resp[j] = v; S.idx[j] = vi;
+        }
+    }
+    for (int i = head; i < n; ++i) {
+        const float v = S.resp[i]; const uint16_t vi = S.idx[i];
+        int j = i;
+        while (kl_before(v, S.resp[j - 1])) { S.resp[j] = S.resp[j - 1]; S.idx[j] = S.idx[j - 1]; --j; }
+        S.resp[j] = v; S.idx[j] = vi;
+    }
+    return true;
+}
+
+struct KlEnds { float e0, e1, e2, e3; };
+
+/* checkLineExtremes of LSDDetector::detectImpl */
+__device__ __forceinline__ KlEnds kl_clamp(const LsdSegOut& s, int w, int h)
+{
+    KlEnds e = {s.x1, s.y1, s.x2, s.y2};
+    if (e.e0 < 0) e.e0 = 0;
+    if (e.e0 >= w) e.e0 = (float)w - 1.0f;
+    if (e.e2 < 0) e.e2 = 0;
+    if (e.e2 >= w) e.e2 = (float)w - 1.0f;
+    if (e.e1 < 0) e.e1 = 0;
+    if (e.e1 >= h) e.e1 = (float)h - 1.0f;
+    if (e.e3 < 0) e.e3 = 0;
+    if (e.e3 >= h) e.e3 = (float)h - 1.0f;
+    return e;
+}
+
+__device__ __forceinline__ float kl_length(const KlEnds& e)
+{
+    const double dx = (double)(e.e0 - e.e2), dy = (double)(e.e1 - e.e3);       /* std::pow(float, 2): the exact square in double */
+    return (float)sqrt(dx * dx + dy * dy);
+}
+
+} // namespace
+
+__global__ __launch_bounds__(64) void k_lsd_keylines(const LsdGrowFrame* __restrict__ frames, const LsdSegOut* __restrict__ segs, int rectCap,
+                                                     int w, int h, int maxLines, int klCap, drfe_keyline* __restrict__ klOut,
+                                                     double* __restrict__ lineFOut, LbdLine* __restrict__ lbdOut, int* __restrict__ frameOut)
+{
+    __shared__ KlShared S;
+    __shared__ int sortOk;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const LsdGrowFrame F = frames[f];
+    int* fo = frameOut + 4 * (size_t)f;                 /* nLines, nDetected, status, pad */
+    if (F.out[1] != 0 || F.out[2] != 0) { if (lane == 0) { fo[0] = 0; fo[1] = 0; fo[2] = 1; } return; }      /* the host validates this frame */
+    const int count = min(F.out[0], rectCap);
+    const LsdSegOut* sg = segs + (size_t)f * rectCap;
+    /* kept segments in seed order */
+    int nKept = 0;
+    int status = 0;
+    for (int base = 0; base < count; base += 64) {
+        const int i = base + lane;
+        const bool keep = i < count && sg[i].flag != 0;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int pos = nKept + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < KL_MAX_KEPT) {
+                S.idx[pos] = (uint16_t)i;
+                const KlEnds e = kl_clamp(sg[i], w, h);
+                S.resp[pos] = kl_length(e) / (float)max(w, h);
+            }
+        }
+        nKept += __popcll(m);
+    }
+    if (nKept > KL_MAX_KEPT) status = 2;
+    __syncthreads();
+    const bool cut = nKept > maxLines;
+    if (cut && status == 0) {
+        if (lane == 0) sortOk = kl_std_sort(S, nKept) ? 1 : 0;
+        __syncthreads();
+        if (!sortOk) status = 2;
+    }
+    const int nl = cut ? maxLines : nKept;
+    if (nl > klCap) status = 2;
+    int unc = 0;
+    if (status == 0)
+        for (int k = lane; k < nl; k += 64) {
+            const int i = S.idx[k];
+            const KlEnds e = kl_clamp(sg[i], w, h);
+            drfe_keyline kl;
+            kl.start_point_x = e.e0; kl.start_point_y = e.e1; kl.end_point_x = e.e2; kl.end_point_y = e.e3;
+            kl.s_point_in_octave_x = e.e0; kl.s_point_in_octave_y = e.e1; kl.e_point_in_octave_x = e.e2; kl.e_point_in_octave_y = e.e3;
+            kl.line_length = kl_length(e);
+            const int x0 = (int)rintf(e.e0), y0 = (int)rintf(e.e1), x1 = (int)rintf(e.e2), y1 = (int)rintf(e.e3);
+            kl.num_of_pixels = max(abs(x1 - x0), abs(y1 - y0)) + 1;               /* LineIterator(...).count */
+            const double a = atan2((double)(e.e3 - e.e1), (double)(e.e2 - e.e0));
+            const float af = (float)a;
+            if ((float)(a * (1.0 - 0x1p-45)) != af || (float)(a * (1.0 + 0x1p-45)) != af) unc = 1;
+            kl.angle = af;
+            kl.class_id = k;          /* the running index before the cut == the position when nothing is cut; the position after it */
+            kl.octave = 0;
+            kl.size = (e.e2 - e.e0) * (e.e3 - e.e1);
+            kl.response = kl.line_length / (float)max(w, h);
+            kl.pt_x = (e.e2 + e.e0) / 2; kl.pt_y = (e.e3 + e.e1) / 2;
+            klOut[(size_t)f * klCap + k] = kl;
+            /* BinaryDescriptor::computeLBD's line: midpoint, direction (cos, sin of the float angle by the libm, rounded to float), length */
+            LbdLine L;
+            L.midX = (float)(0.5 * (e.e0 + e.e2)); L.midY = (float)(0.5 * (e.e1 + e.e3));
+            float sn, cn;
+            const double aa = fabs((double)af);
+            if (!drfe_cr_sincos_f(aa, &sn, &cn)) unc = 1;
+            L.dL0 = cn; L.dL1 = (af < 0 || (af == 0 && signbit(af))) ? -sn : sn;      /* sin is odd, and so is its rounding */
+            L.len = kl.num_of_pixels; L.pad = 0;
+            lbdOut[(size_t)f * klCap + k] = L;
+            /* keylineFunctions: normalised cross product of the homogeneous end points */
+            const double sx = e.e0, sy = e.e1, ex = e.e2, ey = e.e3;
+            const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
+            const double nrm = sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+            double* lf = lineFOut + ((size_t)f * klCap + k) * 3;
+            lf[0] = l0 / nrm; lf[1] = l1 / nrm; lf[2] = l2 / nrm;
+        }
+    if (__ballot(unc)) status |= 1;
+    if (lane == 0) { fo[0] = status ? 0 : nl; fo[1] = nKept; fo[2] = status; fo[3] = 0; }
+}
+
+hipError_t drfe_launch_lsd_keylines(const LsdGrowFrame* d_frames, const LsdSegOut* d_segs, int rectCap, int nframes, int w, int h, int maxLines,
+                                    int klCap, drfe_keyline* d_kl, double* d_lineF, LbdLine* d_lbd, int* d_frameOut, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lsd_keylines, dim3(nframes), dim3(64), 0, s, d_frames, d_segs, rectCap, w, h, maxLines, klCap, d_kl, d_lineF, d_lbd, d_frameOut);
     return hipGetLastError();
 }

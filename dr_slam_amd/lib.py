@@ -858,10 +858,10 @@ class Context:
         self._chk(self.L.drfe_lsd_configure_nfa(self.h, 1 if device_nfa else 0), "drfe_lsd_configure_nfa")
 
     def lsd_stats(self):
-        """dict(frames, grow_to_host, nfa_to_host): counters of lsd_extract_batch's device path since the context was created"""
-        out = np.zeros(3, np.int64)
+        """dict(frames, grow_to_host, nfa_to_host, keylines_to_host): counters of lsd_extract_batch's device path since the context was created"""
+        out = np.zeros(4, np.int64)
         self._chk(self.L.drfe_lsd_stats(self.h, _p(out)), "drfe_lsd_stats")
-        return dict(frames=int(out[0]), grow_to_host=int(out[1]), nfa_to_host=int(out[2]))
+        return dict(frames=int(out[0]), grow_to_host=int(out[1]), nfa_to_host=int(out[2]), keylines_to_host=int(out[3]))
 
     def lsd_configure_rect(self, rect_mode=0):
         """rect_nfa's reading (OpenCV 3.4 lsd.cpp): 0 the literal source (integer corners and step quotients, default),

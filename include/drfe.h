@@ -359,9 +359,10 @@ int drfe_lsd_configure_rect(drfe_ctx* ctx, int rect_mode);
  * bound on the difference to the host's value - a frame with a comparison too close to call is validated on the host), 0 on
  * the pool threads with the caller's libm (rounds 2-3).  Results are identical. */
 int drfe_lsd_configure_nfa(drfe_ctx* ctx, int device_nfa);
-/* counters since drfe_create: out3[0] frames through drfe_lsd_extract_batch's device path, [1] frames whose region growing
- * returned to the host, [2] frames whose NFA decisions returned to the host */
-int drfe_lsd_stats(drfe_ctx* ctx, long long* out3);
+/* counters since drfe_create: out4[0] frames through drfe_lsd_extract_batch's device path, [1] frames whose region growing
+ * returned to the host, [2] frames whose NFA decisions returned to the host, [3] frames whose key-line stage (KeyLine fields,
+ * the response cut's std::sort, LBD direction: k_lsd_keylines) returned to the host */
+int drfe_lsd_stats(drfe_ctx* ctx, long long* out4);
 /* drfe_lsd_segments_host with rect_nfa's reading chosen by the caller (drfe_lsd_segments_host: 0). */
 int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad,
                                 int rect_mode, float* segs, int cap, int* n_segs);

@@ -448,6 +448,16 @@ def test_lsd_device_nfa_equals_host_nfa(ctx, oracle_mod, rect_mode):
     assert ctx.lsd_stats()["nfa_to_host"] == s1["nfa_to_host"]
     for a, b in zip(dev, host):
         _same_lines(a, b)
+    # the key-line stage alone back on the host (k_rect_improve stays): KeyLine fields, the std::sort cut, LBD direction, equations
+    import os
+    assert s1["keylines_to_host"] - s0["keylines_to_host"] <= 1
+    os.environ["DRFE_LSD_HOST_KEYLINES"] = "1"
+    try:
+        hostkl = ctx.lsd_extract_batch(batch, n_threads=4)
+    finally:
+        del os.environ["DRFE_LSD_HOST_KEYLINES"]
+    for a, b in zip(dev, hostkl):
+        _same_lines(a, b)
     for g, a in list(zip(frames, dev))[::5] + list(zip(frames, dev))[-4:]:
         o = oracle_mod.extract_lines(g, rect_mode=rect_mode)
         assert a["detected"] == o["detected"]
