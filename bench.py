@@ -363,12 +363,12 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     inflight = max(1, int(os.environ.get("DRFE_FF_INFLIGHT", inflight)))
-    # host threads per step in flight: a step's pools sleep while its wavefronts are on the device and inside every round trip of
-    # the NFA rounds, so the steps together run ~2.6 threads per CPU; host work per frame: lines ~2.2 ms (NFA arithmetic, key lines),
-    # planes ~0.6 ms (gates + RANSAC refit on the voxel clouds the device left), CAPE ~0.2 ms
+    # host threads per step in flight.  Round 4: the line path's threads only upload the frames, launch, and copy the finished key
+    # lines out (ordering, growth, rect_improve / NFA, key lines and LBD all run on the device): three of them; the plane pool
+    # still runs gates + RANSAC refit on the voxel clouds the device left (~0.6 ms per frame), CAPE ~0.2 ms
     nthr = max(2, (ncpu * 26 + 5 * inflight) // (10 * inflight))
-    split = {"lines": max(1, (nthr * 5 + 3) // 7)}
-    split["planes"] = max(1, nthr - split["lines"])
+    split = {"lines": 3}
+    split["planes"] = max(1, min(6, nthr - split["lines"]))
     if os.environ.get("DRFE_FF_SPLIT"):              # experiments: "lines,planes" per step in flight
         split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))
     n_cape = int(os.environ.get("DRFE_FF_CAPE", 2))   # CAPE lanes (host threads of drfe_planes_cape_batch)
@@ -434,6 +434,10 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
         cpu = time.process_time() - cpu0
         if dbg is not None:
             dbg(pool_ns)
+    lsd = {"frames": 0, "grow_to_host": 0, "nfa_to_host": 0, "keylines_to_host": 0}
+    for L in lanes:
+        for k, v in L["fe"].ctx.lsd_stats().items():
+            lsd[k] += v
     for L in lanes:
         L["planes"].close(); L["cape"].close(); L["fe"].ctx.close()
     total = inflight * reps * n_frames
@@ -445,14 +449,20 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
             "host_cpu_ms_per_frame_by_pool": {"lines": pool_ns[0] / 1e6 / total, "ahc_planes": pool_ns[1] / 1e6 / total, "cape": pool_ns[2] / 1e6 / total,
                                               "other (python, HIP runtime threads)": (cpu * 1e3 - sum(pool_ns) / 1e6) / total},
             "host_threads_per_step_in_flight": {"lines": split["lines"], "ahc_planes": split["planes"], "cape": n_cape}, "host_cpus_available": ncpu,
+            "host_cores_busy_at_this_rate": round(cpu / el, 2),
+            "host_cores_busy_at_8_gpus_at_this_rate": round(8 * cpu / el, 1),
+            "lines_frames_returned_to_the_host": {"of_frames": lsd["frames"], "region_growing": lsd["grow_to_host"], "nfa_decisions_not_certified": lsd["nfa_to_host"],
+                                                  "keyline_roundings_not_certified": lsd["keylines_to_host"]},
             "stage_wall_ms_last_step": {k: round(v, 2) for k, v in lanes[0]["wall"].items()},
             "planes_accepted_per_step": int(nacc[0]),
-            "lines_path": "pixel ordering, region growing, region2rect, refine on the device (k_lsd_order, k_lsd_grow: one wavefront per frame); NFA + key lines on host threads",
+            "lines_path": "everything on the device: pixel ordering, region growing, region2rect, refine (k_lsd_order, k_lsd_grow: one wavefront per frame), rect_improve + NFA "
+                          "decisions with certified comparisons (k_rect_improve), key lines + the response cut + line equations (k_lsd_keylines), LBD (k_lbd); host threads upload, launch and copy",
             "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels, plane clouds (k_ahc_blocks, k_ahc_cluster + k_ahc_refine: one wavefront per frame) and "
                            "pcl::VoxelGrid of every plane (k_voxel_grid) on the device; gates + RANSAC refit on host threads",
             "note": "the device paths are latency chains (~0.12 s of region growing, ~0.075 s of plane extraction per frame on one wavefront): their rate is frames in "
-                    "flight over that latency, so steps run side by side; the host stages that remain cost ~2.2 ms (lines: NFA arithmetic, key lines) + ~0.6 ms "
-                    "(planes: gates + refit) + ~0.2 ms (CAPE) of one CPU per frame (host_cpu_ms_per_frame_by_pool is the measurement)"}
+                    "flight over that latency - bounded by the LDS the resident frames hold (27 KB per growing frame, 32 / 26 KB per plane frame) - so steps run side by side; "
+                    "the host stages that remain are the planes' gates + refit and CAPE's cell growing (host_cpu_ms_per_frame_by_pool is the measurement; "
+                    "host_cores_busy_at_8_gpus_at_this_rate = 8 x the busy cores measured here)"}
 
 
 def launch(args) -> int:

@@ -189,6 +189,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->capeLanes = nullptr;
     c->lsdDeviceGrow = 1;
     c->lsdRectMode = 0;
+    c->capeBatch = nullptr;
+    c->planesDeviceCape = 1;
     c->lsdDeviceNfa = 1;
     c->lsdStats[0] = c->lsdStats[1] = c->lsdStats[2] = c->lsdStats[3] = 0;
     c->planesDeviceVoxel = 1;

@@ -163,6 +163,8 @@ struct drfe_ctx {
     void* lineHost;           /* LineHost*: host buffers of the single-frame line entry */
     struct OrbOneShot* oneShot; /* captured hipGraph of the single-frame ORB entry (capi.cpp) */
     void* cape;               /* CapeScratch*: device buffers of drfe_planes_cape (planes_internal.h) */
+    void* capeBatch;          /* CapeBatchArena*: device path of drfe_planes_cape_batch (planes_cape.cpp) */
+    int planesDeviceCape;     /* drfe_planes_configure_cape: 1 = CAPE::process on the device in the batch entry (default) */
     void* capeLanes;          /* std::vector<CapeLane>*: lanes of drfe_planes_cape_batch (planes_cape.cpp) */
     void* sn;                 /* SnBuffers*: surface-normal scratch (post_internal.h) */
     void* lineWorkers;        /* std::vector<LineWorker>*: lanes of drfe_lsd_extract_batch (lines_lsd.cpp) */

@@ -327,8 +327,36 @@ static void cape_scratch_free(void*& p)
     p = nullptr;
 }
 
+/* device arena of drfe_planes_cape_batch's device path (grow-only, kept by the context) */
+struct CapeBatchArena {
+    int frames = 0, w = 0, h = 0, ncell = 0;
+    bool withSeg = false;
+    float* d_depth = nullptr; CapeCellRec* d_cells = nullptr; drfe_cape_plane* d_planes = nullptr; uint8_t* d_tabs = nullptr;
+    CapeFrameOut* d_out = nullptr; uint8_t* d_seg = nullptr;
+    float* h_stage[2] = {nullptr, nullptr}; hipEvent_t stageFree[2] = {nullptr, nullptr};      /* pinned upload staging, CAPE_STAGE_FRAMES frames each */
+    drfe_cape_plane* h_planes = nullptr; CapeFrameOut* h_out = nullptr; uint8_t* h_seg = nullptr;
+    hipStream_t stream = nullptr;
+    long long toHost = 0, total = 0;
+};
+#define CAPE_STAGE_FRAMES 32
+
+static void cape_batch_free(void*& p)
+{
+    CapeBatchArena* A = static_cast<CapeBatchArena*>(p);
+    if (!A) return;
+    void* dp[] = {A->d_depth, A->d_cells, A->d_planes, A->d_tabs, A->d_out, A->d_seg};
+    for (void* q : dp) if (q) (void)hipFree(q);
+    void* hp[] = {A->h_stage[0], A->h_stage[1], A->h_planes, A->h_out, A->h_seg};
+    for (void* q : hp) if (q) (void)hipHostFree(q);
+    for (hipEvent_t e : A->stageFree) if (e) (void)hipEventDestroy(e);
+    if (A->stream) (void)hipStreamDestroy(A->stream);
+    delete A;
+    p = nullptr;
+}
+
 void drfe_cape_lanes_free(drfe_ctx* c)
 {
+    cape_batch_free(c->capeBatch);
     auto* pool = static_cast<std::vector<CapeLane>*>(c->capeLanes);
     if (!pool) return;
     for (CapeLane& l : *pool) { cape_scratch_free(l.cape); if (l.stream) (void)hipStreamDestroy(l.stream); if (l.pollEv) (void)hipEventDestroy(l.pollEv); }
@@ -336,7 +364,97 @@ void drfe_cape_lanes_free(drfe_ctx* c)
     c->capeLanes = nullptr;
 }
 
+/* drfe_planes_cape_batch with CAPE::process on the device: k_cape_cells (batch) -> k_cape_frame (one wavefront per frame:
+ * histogram seeding, cell growing, segment fits, merging, masks) -> k_cape_refine (batch), frames uploaded through two pinned
+ * staging buffers while the previous ones compute.  hostFrames: the frames whose status word asks for the host path. */
+static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t frame_stride, int w, int h, size_t stride, int nframes,
+                                    const float* K4, int patch, float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap,
+                                    int* n_planes, uint8_t* seg, std::vector<int>& hostFrames)
+{
+    const int nh = w / patch, nv = h / patch, ncell = nh * nv;
+    const size_t npx = (size_t)w * h, tabStride = drfe_cape_tab_bytes(ncell);
+    CapeBatchArena* A = static_cast<CapeBatchArena*>(c->capeBatch);
+    if (!A || A->frames < nframes || A->w != w || A->h != h || A->ncell != ncell || (seg && !A->withSeg)) {
+        cape_batch_free(c->capeBatch);
+        A = new (std::nothrow) CapeBatchArena();
+        if (!A) return DRFE_ERR_INVALID;
+        c->capeBatch = A;
+        A->frames = nframes; A->w = w; A->h = h; A->ncell = ncell; A->withSeg = seg != nullptr;
+        const size_t F = (size_t)nframes;
+        HIPCHK(c, hipMalloc((void**)&A->d_depth, F * npx * sizeof(float)));
+        HIPCHK(c, hipMalloc((void**)&A->d_cells, F * ncell * sizeof(CapeCellRec)));
+        HIPCHK(c, hipMalloc((void**)&A->d_planes, F * CAPE_DEV_MAXP * sizeof(drfe_cape_plane)));
+        HIPCHK(c, hipMalloc((void**)&A->d_tabs, F * tabStride));
+        HIPCHK(c, hipMalloc((void**)&A->d_out, F * sizeof(CapeFrameOut)));
+        HIPCHK(c, hipMalloc((void**)&A->d_seg, F * npx));
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(c, hipHostMalloc((void**)&A->h_stage[k], (size_t)CAPE_STAGE_FRAMES * npx * sizeof(float), hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&A->stageFree[k], hipEventDisableTiming));
+        }
+        HIPCHK(c, hipHostMalloc((void**)&A->h_planes, F * CAPE_DEV_MAXP * sizeof(drfe_cape_plane), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&A->h_out, F * sizeof(CapeFrameOut), hipHostMallocDefault));
+        if (seg) HIPCHK(c, hipHostMalloc((void**)&A->h_seg, F * npx, hipHostMallocDefault));
+        HIPCHK(c, hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking));
+    }
+    hipStream_t st = A->stream;
+    const float sinCos = (float)std::sqrt(1 - (double)cos_angle_max * (double)cos_angle_max);
+    int chunkNo = 0;
+    for (int f0 = 0; f0 < nframes; f0 += CAPE_STAGE_FRAMES, chunkNo++) {
+        const int nf = std::min(CAPE_STAGE_FRAMES, nframes - f0), b = chunkNo & 1;
+        if (chunkNo >= 2) HIPCHK(c, hipEventSynchronize(A->stageFree[b]));            /* the upload that last read this staging buffer is done */
+        float* hs = A->h_stage[b];
+        for (int k = 0; k < nf; k++) {
+            const float* src = depth_m + (size_t)(f0 + k) * frame_stride;
+            if (stride == (size_t)w) std::memcpy(hs + (size_t)k * npx, src, npx * sizeof(float));
+            else for (int y = 0; y < h; y++) std::memcpy(hs + (size_t)k * npx + (size_t)y * w, src + (size_t)y * stride, (size_t)w * 4);
+        }
+        HIPCHK(c, hipMemcpyAsync(A->d_depth + (size_t)f0 * npx, hs, (size_t)nf * npx * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(A->stageFree[b], st));
+        HIPCHK(c, drfe_launch_cape_cells_batch(A->d_depth + (size_t)f0 * npx, npx, (size_t)w, w, h, K4, patch, sinCos, max_merge_dist, nf,
+                                               A->d_cells + (size_t)f0 * ncell, st));
+        HIPCHK(c, drfe_launch_cape_frames(A->d_cells + (size_t)f0 * ncell, nh, nv, cos_angle_max, max_merge_dist, nf,
+                                          A->d_planes + (size_t)f0 * CAPE_DEV_MAXP, A->d_tabs + (size_t)f0 * tabStride, tabStride, A->d_out + f0, st));
+        HIPCHK(c, drfe_launch_cape_refine_batch(A->d_depth + (size_t)f0 * npx, npx, (size_t)w, w, h, K4, patch, A->d_tabs + (size_t)f0 * tabStride,
+                                                tabStride, A->d_out + f0, nf, A->d_seg + (size_t)f0 * npx, st));
+    }
+    HIPCHK(c, hipMemcpyAsync(A->h_out, A->d_out, (size_t)nframes * sizeof(CapeFrameOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(A->h_planes, A->d_planes, (size_t)nframes * CAPE_DEV_MAXP * sizeof(drfe_cape_plane), hipMemcpyDeviceToHost, st));
+    if (seg) HIPCHK(c, hipMemcpyAsync(A->h_seg, A->d_seg, (size_t)nframes * npx, hipMemcpyDeviceToHost, st));
+    {
+        hipEvent_t done = A->stageFree[0];
+        HIPCHK(c, drfe_pool_sync(st, done));                                          /* sleeps between polls: the other pools need the CPUs */
+    }
+    for (int f = 0; f < nframes; f++) {
+        if (A->h_out[f].status != 0) { hostFrames.push_back(f); continue; }
+        const int np = A->h_out[f].nPlanes;
+        n_planes[f] = np;
+        if (np > cap) { c->err = "planes_cape: plane buffer too small"; return DRFE_ERR_CAPACITY; }
+        std::memcpy(planes + (size_t)f * cap, A->h_planes + (size_t)f * CAPE_DEV_MAXP, (size_t)np * sizeof(drfe_cape_plane));
+        if (seg) std::memcpy(seg + (size_t)f * npx, A->h_seg + (size_t)f * npx, npx);
+    }
+    A->total += nframes; A->toHost += (long long)hostFrames.size();
+    return DRFE_OK;
+}
+
 extern "C" {
+
+/* 1 (default): drfe_planes_cape_batch runs CAPE::process on the device (cape_frame_kernels.hip), 0: on the pool's host threads
+ * between the device's cell fits and per-pixel refinement (rounds 1-3).  Results are identical. */
+int drfe_planes_configure_cape(drfe_ctx* c, int on_device)
+{
+    if (!c || on_device < 0 || on_device > 1) { if (c) c->err = "planes_configure_cape: invalid argument"; return DRFE_ERR_INVALID; }
+    c->planesDeviceCape = on_device;
+    return DRFE_OK;
+}
+
+/* out2[0] = frames through drfe_planes_cape_batch's device path since drfe_create, out2[1] = of those, finished by the host */
+int drfe_planes_cape_stats(drfe_ctx* c, long long* out2)
+{
+    if (!c || !out2) return DRFE_ERR_INVALID;
+    CapeBatchArena* A = static_cast<CapeBatchArena*>(c->capeBatch);
+    out2[0] = A ? A->total : 0; out2[1] = A ? A->toHost : 0;
+    return DRFE_OK;
+}
 
 int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
                      float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
@@ -360,6 +478,18 @@ int drfe_planes_cape_batch(drfe_ctx* c, const float* depth_m, size_t frame_strid
     if (nframes == 0) return DRFE_OK;
     const int T = std::max(1, std::min(n_threads > 0 ? n_threads : 4, nframes));
     HIPCHK(c, hipSetDevice(c->device));
+    /* the whole extractor on the device (drfe_planes_configure_cape; cape_frame_kernels.hip): the calling thread uploads, launches
+     * and copies the results out; a frame the device could not finish (status word) goes through the host path below */
+    std::vector<int> hostFrames;
+    bool deviceDone = false;
+    if (c->planesDeviceCape && nframes > 1 && !std::getenv("DRFE_CAPE_HOST") && patch >= 4 && patch <= 64 && w % patch == 0 && h % patch == 0 &&
+        (w / patch) * (h / patch) <= CAPE_DEV_MAXCELLS && stride >= (size_t)w && cap >= 1) {
+        const int rc = planes_cape_batch_device(c, depth_m, frame_stride, w, h, stride, nframes, K4, patch, cos_angle_max, max_merge_dist, planes, cap,
+                                                n_planes, seg, hostFrames);
+        if (rc != DRFE_OK) return rc;
+        deviceDone = true;
+        if (hostFrames.empty()) return DRFE_OK;
+    }
     auto* pool = static_cast<std::vector<CapeLane>*>(c->capeLanes);
     if (!pool) { pool = new std::vector<CapeLane>(); c->capeLanes = pool; }
     while ((int)pool->size() < T) {
@@ -378,7 +508,9 @@ int drfe_planes_cape_batch(drfe_ctx* c, const float* depth_m, size_t frame_strid
             DrfePoolCpuScope cpu(2);
             CapeLane* l = &(*pool)[k];
             std::vector<uint8_t> segTmp(seg ? 0 : px);
-            for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {
+            const int todo = deviceDone ? (int)hostFrames.size() : nframes;
+            for (int q = next.fetch_add(1); q < todo; q = next.fetch_add(1)) {
+                const int f = deviceDone ? hostFrames[q] : q;
                 const int rc = planes_cape_core(l, depth_m + (size_t)f * frame_stride, w, h, stride, K4, patch, cos_angle_max, max_merge_dist,
                                                 planes + (size_t)f * cap, cap, &n_planes[f], seg ? seg + (size_t)f * px : segTmp.data(),
                                                 nullptr, nullptr, nullptr);

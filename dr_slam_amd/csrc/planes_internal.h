@@ -34,6 +34,26 @@ struct CapeScratch {
     float* h_depth; CapeCellRec* h_cells; uint8_t* h_seg;   /* pinned mirrors (sized with the device buffers): the copy calls neither stage nor pin */
 };
 
+/* ---- CAPE's cell stage on the device (cape_frame_kernels.hip): histogram seeding, cell growing, merging, masks ---- */
+#define CAPE_DEV_MAXP 64             /* plane segments / final planes per frame the device path holds */
+#define CAPE_DEV_MAXCELLS 3072       /* 64 x 48 cells */
+#define CAPE_STATUS_UNCERTAIN 1      /* a histogram bin the device's acos / atan2 could not certify */
+#define CAPE_STATUS_CAPACITY 2       /* more segments than CAPE_DEV_MAXP, or an iteration bound hit */
+struct CapeFrameOut { int nPlanes, status, pad0, pad1; };
+/* bytes of one frame's table block: CapeRefinePlane[CAPE_DEV_MAXP] | gridEroded[ncell] | boundary[CAPE_DEV_MAXP][ncell] */
+static inline size_t drfe_cape_tab_bytes(int ncell) { return ((size_t)CAPE_DEV_MAXP * 20 + (size_t)ncell * (1 + CAPE_DEV_MAXP) + 255) & ~(size_t)255; }
+struct drfe_cape_plane;
+hipError_t drfe_launch_cape_cells_batch(const float* d_depth, size_t frameStride, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                        float sinCos, float maxMergeDist, int nframes, CapeCellRec* d_out, hipStream_t s);
+/* CAPE::process between the cell fits and the per-pixel refinement (src/CAPE/CAPE.cpp:81-293) for nframes frames, one
+ * wavefront each: planes of frame f at d_planes[f * CAPE_DEV_MAXP ..], its refinement tables at d_tabs + f * tabStride,
+ * d_out[f] = {planes, status} */
+hipError_t drfe_launch_cape_frames(const CapeCellRec* d_cells, int nh, int nv, float cosAngleMax, float maxMergeDist, int nframes,
+                                   drfe_cape_plane* d_planes, uint8_t* d_tabs, size_t tabStride, CapeFrameOut* d_out, hipStream_t s);
+hipError_t drfe_launch_cape_refine_batch(const float* d_depth, size_t frameStride, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                         const uint8_t* d_tabs, size_t tabStride, const CapeFrameOut* d_frameOut, int nframes, uint8_t* d_seg,
+                                         hipStream_t s);
+
 /* one final plane of the boundary refinement (src/CAPE/CAPE.cpp:294-319): float copies of normal and d, 9 * MSE */
 struct CapeRefinePlane { float nx, ny, nz, d, maxDist; };
 

@@ -94,11 +94,12 @@ __device__ __forceinline__ float cape_z(const float* d, size_t rowStride, int r0
 
 __global__ __launch_bounds__(64) void k_cape_cells(const float* __restrict__ depth, size_t rowStride, int w, int h,
                                                    float fx, float fy, float cx, float cy, int patch, float sinCos,
-                                                   float maxMergeDist, CapeCellRec* __restrict__ out)
+                                                   float maxMergeDist, CapeCellRec* __restrict__ out, size_t frameStride)
 {
     const int nh = w / patch, nv = h / patch;
     const int cell = blockIdx.x * 64 + threadIdx.x;
     if (cell >= nh * nv) return;
+    depth += frameStride * blockIdx.y; out += (size_t)nh * nv * blockIdx.y;       /* blockIdx.y = frame of a batch (frameStride 0: one frame) */
     const int r0 = (cell / nh) * patch, c0 = (cell % nh) * patch;
     const int n = patch * patch;
     CapeCellRec rec;
@@ -188,18 +189,42 @@ hipError_t drfe_launch_cape_cells(const float* d_depth, size_t rowStride, int w,
 {
     const int ncell = (w / patch) * (h / patch);
     hipLaunchKernelGGL(k_cape_cells, dim3((ncell + 63) / 64), dim3(64), 0, s, d_depth, rowStride, w, h, K4[0], K4[1],
-                       K4[2], K4[3], patch, sinCos, maxMergeDist, d_out);
+                       K4[2], K4[3], patch, sinCos, maxMergeDist, d_out, (size_t)0);
+    return hipGetLastError();
+}
+
+/* nframes depth images frameStride floats apart: cell records of frame f at d_out[f * ncell ..] */
+hipError_t drfe_launch_cape_cells_batch(const float* d_depth, size_t frameStride, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                        float sinCos, float maxMergeDist, int nframes, CapeCellRec* d_out, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    const int ncell = (w / patch) * (h / patch);
+    hipLaunchKernelGGL(k_cape_cells, dim3((ncell + 63) / 64, nframes), dim3(64), 0, s, d_depth, rowStride, w, h, K4[0], K4[1],
+                       K4[2], K4[3], patch, sinCos, maxMergeDist, d_out, frameStride);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k_cape_refine(const float* __restrict__ depth, size_t rowStride, int w, int h, float fx,
                                                      float fy, float cx, float cy, int patch, const CapeRefinePlane* __restrict__ planes,
                                                      int nplanes, const uint8_t* __restrict__ gridEroded,
-                                                     const uint8_t* __restrict__ boundary, uint8_t* __restrict__ seg)
+                                                     const uint8_t* __restrict__ boundary, uint8_t* __restrict__ seg,
+                                                     const CapeFrameOut* __restrict__ frameOut, size_t frameStride, size_t tabStride)
 {
     const int pc = blockIdx.x * 256 + threadIdx.x, pr = blockIdx.y;
     if (pc >= w) return;
     const int nh = w / patch, ncell = nh * (h / patch);
+    if (frameOut) {
+        /* batch form (k_cape_frame's tables): blockIdx.z = frame; its table block holds CapeRefinePlane[CAPE_DEV_MAXP] |
+         * gridEroded[ncell] | boundary[n][ncell] */
+        const int f = blockIdx.z;
+        if (frameOut[f].status != 0) return;                      /* the host finishes this frame */
+        nplanes = frameOut[f].nPlanes;
+        const uint8_t* tab = reinterpret_cast<const uint8_t*>(planes) + tabStride * f;
+        planes = reinterpret_cast<const CapeRefinePlane*>(tab);
+        gridEroded = tab + CAPE_DEV_MAXP * sizeof(CapeRefinePlane);
+        boundary = gridEroded + ncell;
+        depth += frameStride * f; seg += (size_t)w * h * f;
+    }
     const int cell = (pr / patch) * nh + pc / patch;
     uint8_t v = gridEroded[cell];
     if (v == 0) {
@@ -228,7 +253,18 @@ hipError_t drfe_launch_cape_refine(const float* d_depth, size_t rowStride, int w
                                    const uint8_t* d_boundary, uint8_t* d_seg, hipStream_t s)
 {
     hipLaunchKernelGGL(k_cape_refine, dim3((w + 255) / 256, h), dim3(256), 0, s, d_depth, rowStride, w, h, K4[0], K4[1], K4[2],
-                       K4[3], patch, d_planes, nplanes, d_gridEroded, d_boundary, d_seg);
+                       K4[3], patch, d_planes, nplanes, d_gridEroded, d_boundary, d_seg, (const CapeFrameOut*)nullptr, (size_t)0, (size_t)0);
+    return hipGetLastError();
+}
+
+hipError_t drfe_launch_cape_refine_batch(const float* d_depth, size_t frameStride, size_t rowStride, int w, int h, const float K4[4], int patch,
+                                         const uint8_t* d_tabs, size_t tabStride, const CapeFrameOut* d_frameOut, int nframes, uint8_t* d_seg,
+                                         hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cape_refine, dim3((w + 255) / 256, h, nframes), dim3(256), 0, s, d_depth, rowStride, w, h, K4[0], K4[1], K4[2],
+                       K4[3], patch, reinterpret_cast<const CapeRefinePlane*>(d_tabs), 0, (const uint8_t*)nullptr, (const uint8_t*)nullptr, d_seg,
+                       d_frameOut, frameStride, tabStride);
     return hipGetLastError();
 }
 

@@ -699,6 +699,13 @@ int drfe_planes_configure(drfe_ctx* ctx, int device_voxel_grid);
  * reference's sequence (ahc_frame_kernels.hip), the batch's frames side by side; 0 on the pool's host threads (the path of
  * drfe_planes_ahc).  Results are identical (tests/test_gpu_post.py, tests/test_gpu_planes.py). */
 int drfe_planes_configure_extractor(drfe_ctx* ctx, int on_device);
+/* Where drfe_planes_cape_batch runs CAPE::process between the cell fits and the per-pixel refinement (src/CAPE/CAPE.cpp:81-293:
+ * normal histogram + seeding, cell growing, segment fits, merging, erode / dilate masks): 1 (default) on the device, one wavefront
+ * per frame (cape_frame_kernels.hip; a frame whose histogram bins the device cannot certify - acos / atan2 are the host libm's in
+ * the reference - is finished by the host), 0 on the pool's host threads.  Results are identical. */
+int drfe_planes_configure_cape(drfe_ctx* ctx, int on_device);
+/* out2[0] = frames through drfe_planes_cape_batch's device path since drfe_create, out2[1] = of those, finished by the host */
+int drfe_planes_cape_stats(drfe_ctx* ctx, long long* out2);
 /* The same loop of Frame::ComputePlanes_CAPE (:1111-1141) for the planes / seg image drfe_planes_cape returned: plane_cloud[i]
  * = the points of the pixels labelled i + 1 in raster order (src/PlaneExtractor.cpp:171-188). */
 int drfe_planes_cape_postprocess(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, const uint8_t* seg,

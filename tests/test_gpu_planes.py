@@ -111,8 +111,10 @@ def test_ahc_batch_equals_single(ctx):
                 assert np.array_equal(ma, mb)
 
 
-def test_cape_batch_equals_single():
-    """drfe_planes_cape_batch (pool of host threads, one device lane each) == per-frame drfe_planes_cape: planes, counts, labels."""
+@pytest.mark.parametrize("on_device", [True, False])
+def test_cape_batch_equals_single(on_device):
+    """drfe_planes_cape_batch == per-frame drfe_planes_cape: planes, counts, labels - with CAPE::process on the device (k_cape_frame:
+    histogram seeding, cell growing, segment fits, merging, masks; one wavefront per frame) and on the pool of host threads."""
     from dr_slam_amd import lib, synth
     cam = synth.ICL
     frames = list(synth.sequence(3, 5, cam=cam, kind="living_room"))
@@ -121,6 +123,7 @@ def test_cape_batch_equals_single():
     dm = np.stack([f[1].astype(np.float32) * inv for f in frames])
     c = lib.Context(max_batch=1)
     try:
+        c.planes_configure_cape(on_device)
         single = [c.planes_cape(d, K4, 20) for d in dm]
         for T in (1, 3):
             planes, n, seg = c.planes_cape_batch(dm, K4, 20, n_threads=T, seg=True)
@@ -128,5 +131,36 @@ def test_cape_batch_equals_single():
                 assert n[f] == len(s["planes"]) > 0
                 assert np.array_equal(planes[f, :n[f]].view(np.uint8), np.ascontiguousarray(s["planes"]).view(np.uint8))
                 assert np.array_equal(seg[f], s["seg"])
+        st = c.planes_cape_stats()
+        assert st["frames"] == (10 if on_device else 0) and st["to_host"] <= 1
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("kind,camname,patch", [("living_room", "ICL", 20), ("room_boxes", "TUM3", 20), ("corridor", "TUM3", 10),
+                                                 ("planar_lowtexture", "TUM3", 40)])
+def test_cape_device_batch_matches_oracle(oracle_mod, kind, camname, patch):
+    """The device CAPE (k_cape_cells -> k_cape_frame -> k_cape_refine, batch form) against the CPU oracle on every scene kind and
+    three cell sizes, 40 frames (two upload chunks): plane records bit for bit, label images equal; without the label download too."""
+    from dr_slam_amd import lib, synth
+    cam = getattr(synth, camname)
+    frames = list(synth.sequence(11, 20, cam=cam, kind=kind))
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = np.float32(1.0) / np.float32(cam.depth_factor)
+    dm = np.stack([f[1].astype(np.float32) * inv for f in frames] * 2)
+    c = lib.Context(max_batch=1)
+    try:
+        planes, n, seg = c.planes_cape_batch(dm, K4, patch, n_threads=2, seg=True)
+        planes2, n2 = c.planes_cape_batch(dm, K4, patch, n_threads=2)
+        assert np.array_equal(n, n2) and np.array_equal(planes.view(np.uint8), planes2.view(np.uint8))
+        st = c.planes_cape_stats()
+        assert st["frames"] == 2 * len(dm) and st["to_host"] <= 2
+        for f in list(range(0, 20, 3)) + [39]:
+            o = oracle_mod.cape_planes(dm[f], K4, patch)
+            assert n[f] == len(o["planes"])
+            assert np.array_equal(planes[f, :n[f]]["normal"].view(np.uint64), o["planes"][:, 0:3].view(np.uint64))
+            assert np.array_equal(planes[f, :n[f]]["d"].view(np.uint64), o["planes"][:, 6].view(np.uint64))
+            assert np.array_equal(seg[f], o["seg"])
+        assert n.max() >= 2
     finally:
         c.close()
