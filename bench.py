@@ -367,7 +367,7 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
     # lines out (ordering, growth, rect_improve / NFA, key lines and LBD all run on the device): three of them; the plane pool
     # still runs gates + RANSAC refit on the voxel clouds the device left (~0.6 ms per frame), CAPE ~0.2 ms
     nthr = max(2, (ncpu * 26 + 5 * inflight) // (10 * inflight))
-    split = {"lines": 3}
+    split = {"lines": 2}
     split["planes"] = max(1, min(6, nthr - split["lines"]))
     if os.environ.get("DRFE_FF_SPLIT"):              # experiments: "lines,planes" per step in flight
         split["lines"], split["planes"] = (int(v) for v in os.environ["DRFE_FF_SPLIT"].split(","))

@@ -204,6 +204,18 @@ static inline hipError_t drfe_pool_sync(hipStream_t s, hipEvent_t ev)
     }
 }
 
+/* wait for an already recorded event the same way: poll + sleep instead of the runtime's busy wait */
+static inline hipError_t drfe_event_wait_sleeping(hipEvent_t ev)
+{
+    for (int spins = 0;; spins++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (spins < 4) continue;
+        struct timespec ts = {0, spins < 40 ? 20000 : 100000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 /* CPU time of the batch entries' pool threads, summed per pool (0 lines, 1 AHC planes, 2 CAPE): a worker adds its thread's CPU time when
  * it ends (drfe_debug_pool_cpu_ns reads and clears).  Measurement only. */
 void drfe_pool_cpu_add(int pool, long long ns);

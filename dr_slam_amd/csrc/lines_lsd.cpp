@@ -1027,7 +1027,7 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
         }
         if (waitCh >= 0) {
             const auto tw = std::chrono::steady_clock::now();
-            if (hipEventSynchronize(J.growDone[waitCh]) != hipSuccess) { batch_fail(J, DRFE_ERR_HIP, "lsd_extract_batch: grow"); return; }
+            if (drfe_event_wait_sleeping(J.growDone[waitCh]) != hipSuccess) { batch_fail(J, DRFE_ERR_HIP, "lsd_extract_batch: grow"); return; }
             J.usWait += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw).count();
             continue;
         }

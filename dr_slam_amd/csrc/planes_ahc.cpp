@@ -933,7 +933,7 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             continue;
         }
         if (waitCh >= 0) {
-            if (hipEventSynchronize(J.chunkDone[waitCh]) != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, "planes batch: device"); (void)hipEventDestroy(ev); return; }
+            if (drfe_event_wait_sleeping(J.chunkDone[waitCh]) != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, "planes batch: device"); (void)hipEventDestroy(ev); return; }
             continue;
         }
         const uint16_t* d = J.depth + (size_t)f * J.frameStride;

@@ -397,11 +397,12 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
         HIPCHK(c, hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking));
     }
     hipStream_t st = A->stream;
+    DrfePoolCpuScope cpu(2);                      /* accounted to the CAPE pool: the calling thread is its only worker here */
     const float sinCos = (float)std::sqrt(1 - (double)cos_angle_max * (double)cos_angle_max);
     int chunkNo = 0;
     for (int f0 = 0; f0 < nframes; f0 += CAPE_STAGE_FRAMES, chunkNo++) {
         const int nf = std::min(CAPE_STAGE_FRAMES, nframes - f0), b = chunkNo & 1;
-        if (chunkNo >= 2) HIPCHK(c, hipEventSynchronize(A->stageFree[b]));            /* the upload that last read this staging buffer is done */
+        if (chunkNo >= 2) HIPCHK(c, drfe_event_wait_sleeping(A->stageFree[b]));            /* the upload that last read this staging buffer is done */
         float* hs = A->h_stage[b];
         for (int k = 0; k < nf; k++) {
             const float* src = depth_m + (size_t)(f0 + k) * frame_stride;
