@@ -205,6 +205,46 @@ def config5_aux(ctx, base, cam, n: int = 6):
     return out
 
 
+def scene_stage_times(B, device):
+    """The headline path on the OTHER textures BASELINE's configs name (config 1's namesake is a low-texture scene, config 3 a living
+    room): per-stage HIP-event times of one 512-frame batch and the one-context step rate, per scene kind.  The FAST kernel picks
+    per cell between its plain path and the screened one (compass screen + the strength tree on the compacted survivors)."""
+    import torch
+    from dr_slam_amd import sharding, synth
+    from dr_slam_amd.pipeline import FrontEnd
+    res = {}
+    for kind, cam in (("living_room", synth.ICL), ("planar_lowtexture", synth.TUM3)):
+        base = sharding.render_sequence(3, 16, cam, kind, workers=min(8, sharding.host_cpus()))
+        order = sharding.pingpong_order(B, len(base))
+        gray = torch.from_numpy(np.stack([base[i][0] for i in order])).cuda()
+        depth = torch.from_numpy(np.stack([base[i][1] for i in order]).view(np.int16)).cuda()
+        Twc = np.stack([base[i][2] for i in order]).astype(np.float64)
+        Tcw = np.linalg.inv(Twc).astype(np.float32)
+        Twc = Twc.astype(np.float32)
+        fe = FrontEnd(cam, max_batch=B, device=device)
+        for _ in range(5):
+            fe.process(gray, depth, Tcw, Twc, stream=0)
+        torch.cuda.synchronize()
+        fe.ctx.profile_enable(True)
+        acc = {}
+        for _ in range(10):
+            fe.process(gray, depth, Tcw, Twc, stream=0)
+            for k, v in fe.ctx.profile_stage_ms().items():
+                acc[k] = acc.get(k, 0.0) + v / 10
+        fe.ctx.profile_enable(False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(50):
+            fe.process(gray, depth, Tcw, Twc, stream=0)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t
+        res[kind] = {"stage_ms_per_batch": {k: round(v, 4) for k, v in acc.items()}, "frames_per_s_one_batch_at_a_time": round(B * 50 / el),
+                     "keypoints_per_frame_min": int(fe.ctx.orb_counts(B).min())}
+        fe.ctx.close()
+        del gray, depth
+    return res
+
+
 def host_fed_rate(fe, gray, depth, Tcw, Twc, B, steps, dev):
     """The same step fed from HOST memory: pinned gray + depth copied H2D on a copy stream while the previous batch
     computes (double-buffered inputs), keypoints / descriptors / matches of every batch copied back D2H.  The link, not the
@@ -333,7 +373,7 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
     return B * steps / el, el / steps * 1e3, threads
 
 
-def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 3):
+def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 4):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
     the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame);
@@ -792,6 +832,9 @@ def main():
             if not args.no_extras:
                 out["aux_per_frame"] = config5_aux(fe.ctx, base, cam)
         if world == 1 and not args.no_extras and config != 5:
+            out["other_scenes"] = scene_stage_times(B, local_rank)
+            out["other_scenes"]["_about"] = "the same path on the other textures the configs name, one context, one batch at a time: compare with " \
+                                            "stage_ms_per_batch / one_batch_at_a_time of this line (room_boxes)"
             fps_hf, ms_hf = host_fed_rate(fe, gray, depth, Tcw, Twc, B, max(4, min(args.steps, 10)), dev)
             out["value_host_fed"] = fps_hf
             out["host_fed"] = {"ms_per_step": ms_hf, "h2d_bytes_per_step": int(gray.nbytes + depth.nbytes),

@@ -234,6 +234,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     {
         const char* e = std::getenv("DRFE_FAST_GENERIC");
         c->fastGeneric = (e && e[0] == '1') ? 1 : 0;
+        const char* es = std::getenv("DRFE_FAST_SCREEN");
+        c->fastScreen = (es && es[0] == '0') ? 0 : 1;
     }
 
     /* size the arenas with the geometry of the largest frame */

@@ -136,6 +136,7 @@ struct drfe_ctx {
     uint8_t* d_desc;          /* [slot][maxKp][32] */
     int* d_kpCount;           /* [slot] */
     int* d_status;            /* device-side error flags (overflow) */
+    int fastScreen;           /* 1 (default): k_fast_cells_cols may take its screened path on low-texture cells; DRFE_FAST_SCREEN=0 in the environment: never (A/B, tests) */
     int fastGeneric;          /* DRFE_FAST_GENERIC=1 in the environment: run k_fast_cells even where k_fast_cells_cols fits (A/B, tests) */
 
     /* frame glue + match */

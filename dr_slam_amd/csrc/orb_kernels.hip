@@ -510,7 +510,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
  * Emission order inside a cell differs from k_fast_cells; the order key in cand1 is what the quadtree ties on. */
 #define FASTC_P16 52                              /* pixels per tile row: 26 dwords, so row blocks 8 rows apart start 16 banks apart */
 #define FASTC_PB (FASTC_P16 * 2)
-static inline int fastc_lds_bytes(int rows) { return rows * FASTC_PB + 16; }
+/* tile, then the survivor list of the screened path: FASTC_LIST_CAP 16-bit items (lane | row << 6, later the pair's two scores).  A
+ * quarter of the wavefront's 512 pixel-pair rows: a cell with more survivors takes the plain path (256 bytes of LDS keep the
+ * occupancy of the plain path where it was; 2 KB more per wavefront cost it 7 %) */
+#define FASTC_LIST_CAP 128
+static inline int fastc_list_off(int rows) { return (rows * FASTC_PB + 16 + 15) & ~15; }
+static inline int fastc_lds_bytes(int rows) { return fastc_list_off(rows) + FASTC_LIST_CAP * 2; }
 #define FASTC_DPP_SHR 0x138                        /* wave_shr:1 */
 #define FASTC_DPP_SHL 0x130                        /* wave_shl:1 */
 
@@ -562,6 +567,19 @@ __device__ __forceinline__ uint32_t fastc_strength2(const uint8_t* c)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+/* The compass screen: a 9-arc of the 16-pixel ring always holds two ADJACENT compass pixels (ring positions 0, 4, 8, 12), so a
+ * pixel whose strength reaches th + 1 has two adjacent compass pixels all brighter than v + th or all darker than v - th.
+ * Returns a non-zero half where the half's pixel passes (strength may reach th + 1), zero where it cannot.  d0 / d4 / d8 / d12 =
+ * ring pixels (0, 3), (3, 0), (0, -3), (-3, 0); th as the f16 bit pattern of the integer threshold. */
+__device__ __forceinline__ uint32_t fastc_screen(h16x2 v, h16x2 d0, h16x2 d4, h16x2 d8, h16x2 d12, h16x2 th)
+{
+    const h16x2 hi = v + th, lo = v - th;
+    const h16x2 M = hmax(hmax3(hmin(d0, d4), hmin(d4, d8), hmin(d8, d12)), hmin(d12, d0));     /* brightest adjacent pair's darker pixel */
+    const h16x2 m = hmin(hmin3(hmax(d0, d4), hmax(d4, d8), hmax(d8, d12)), hmax(d12, d0));
+    const h16x2 zero = __builtin_bit_cast(h16x2, 0u);
+    return __builtin_bit_cast(uint32_t, hmax3(M - hi, lo - m, zero));
+}
+
 __device__ __forceinline__ uint32_t u2max(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, umax2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -580,7 +598,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
                                                         int candSlotElems, int iniTh, int minTh,
                                                         const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
                                                         uint32_t* __restrict__ cand1, int* __restrict__ candCount,
-                                                        int* __restrict__ status, uint32_t gxMagic, int cellFirst)
+                                                        int* __restrict__ status, uint32_t gxMagic, int cellFirst, int screen, int listOff)
 {
     int bx, by;
     drfe_xcd_swizzle_2d(gxMagic, bx, by);
@@ -630,12 +648,73 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     const int iInv = eh - (nrb - 1) * R;
     const uint32_t mlast = rb == nrb - 1 ? 0u : mcol;
     uint32_t s[RMAX];
+    /* Which way this cell is scored.  The strength tree costs ~100 instructions per pixel-pair row whatever the pixels hold; on a
+     * low-texture cell a twentieth of the pair rows can reach minThFAST at all.  The compass screen (fastc_screen, ~25
+     * instructions) of every lane's FIRST row - one row of every row block: a sample spread over the cell - decides per
+     * wavefront: fewer than a quarter of the sampled pair rows pass -> the screened path (screen every row, run the tree on the
+     * compacted survivors only - if they fit the list); otherwise the plain path, which costs a textured cell the sample and
+     * nothing else.  A pair row
+     * that fails the screen scores 0 instead of its true strength (< minTh): such a value never reaches an output - a kept
+     * pixel has s > max(N, minTh - 1), and every neighbour changed by this was below minTh anyway. */
+    const h16x2 thScreen = __builtin_bit_cast(h16x2, (uint32_t)minTh * 0x00010001u);
+    bool plain = true;
+    unsigned long long pm[RMAX];                 /* wave-uniform: which lanes' pair row i passed the screen */
+    if (RMAX == 8 && screen) {         /* the 8-row instantiation only (the four large levels: 85 % of the pixels) */
+        const uint32_t p0 = fastc_screen(fastc_ld<0, 0>(base), fastc_ld<0, 3>(base), fastc_ld<3, 0>(base), fastc_ld<0, -3>(base),
+                                         fastc_ld<-3, 0>(base), thScreen) & (0 < iInv ? mcol : mlast);
+        /* fewer than a quarter of the lanes that hold a pixel pair */
+        if (4 * __popcll(__ballot(p0 != 0)) < __popcll(__ballot(mcol != 0))) {
+            uint32_t total = 0;
+            uint16_t* lst = reinterpret_cast<uint16_t*>(fastLds + listOff);
 #pragma unroll
-    for (int i = 0; i < RMAX; i++) {
-        s[i] = 0;
-        if (i < R) {
-            const uint32_t r = fastc_strength2(base + i * FASTC_PB);
-            s[i] = r & (i < iInv ? mcol : mlast);
+            for (int i = 0; i < RMAX; i++) {
+                uint32_t pb = 0;
+                if (i < R)
+                    pb = fastc_screen(fastc_ld<0, 0>(base + i * FASTC_PB), fastc_ld<0, 3>(base + i * FASTC_PB), fastc_ld<3, 0>(base + i * FASTC_PB),
+                                      fastc_ld<0, -3>(base + i * FASTC_PB), fastc_ld<-3, 0>(base + i * FASTC_PB), thScreen) & (i < iInv ? mcol : mlast);
+                pm[i] = __ballot(pb != 0);
+                /* the survivor's place in the list: the rows before it, then the lanes before it in its row */
+                const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u));
+                if (pb != 0 && pos < FASTC_LIST_CAP) lst[pos] = (uint16_t)(lane | (i << 6));
+                total += (uint32_t)__popcll(pm[i]);
+            }
+            if (total <= FASTC_LIST_CAP) {
+                plain = false;
+                __syncthreads();
+                /* the tree on the survivors, 64 at a time; a survivor's list slot then takes its two 8-bit scores, which the owner
+                 * reads back below (no register of the owner is live across the passes: the register budget stays the plain path's) */
+                const uint32_t npass = (total + 63u) >> 6;
+                for (uint32_t k = 0; k < npass; k++) {
+                    const uint32_t p = 64u * k + (uint32_t)lane;
+                    if (p < total) {
+                        const uint32_t item = lst[p], o = item & 63u, r = item >> 6;
+                        const uint32_t rbo = (o * fc.ncpMagic) >> 16, cpo = o - rbo * (uint32_t)ncp;
+                        const uint32_t v2 = fastc_strength2(fastLds + (rbo * (uint32_t)R + r) * FASTC_PB + ((uint32_t)(off & 2) + 2u * cpo) * 2u);
+                        lst[p] = (uint16_t)((v2 & 0xFFu) | ((v2 >> 8) & 0xFF00u));
+                    }
+                }
+                __syncthreads();
+                uint32_t start = 0;
+#pragma unroll
+                for (int i = 0; i < RMAX; i++) {
+                    s[i] = 0;
+                    if ((pm[i] >> lane) & 1ull) {
+                        const uint32_t v2 = lst[start + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u))];
+                        s[i] = ((v2 & 0xFFu) | ((v2 & 0xFF00u) << 8)) & (i < iInv ? mcol : mlast);
+                    }
+                    start += (uint32_t)__popcll(pm[i]);
+                }
+            }
+        }
+    }
+    if (plain) {
+#pragma unroll
+        for (int i = 0; i < RMAX; i++) {
+            s[i] = 0;
+            if (i < R) {
+                const uint32_t r = fastc_strength2(base + i * FASTC_PB);
+                s[i] = r & (i < iInv ? mcol : mlast);
+            }
         }
     }
     /* block seams: the row above this lane's first row is the last row of lane - ncp, the row below its last one the
@@ -1485,7 +1564,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
         if (nSmall > 0)
             hipLaunchKernelGGL((k_fast_cells_cols<8>), dim3(nSmall, nframes), dim3(64), (size_t)fastc_lds_bytes(g.fastColsRows), s,
                                c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr, c->d_cand0,
-                               c->d_cand1, c->d_candCount, c->d_status, drfe_div_magic((uint32_t)nSmall), 0);
+                               c->d_cand1, c->d_candCount, c->d_status, drfe_div_magic((uint32_t)nSmall), 0, c->fastScreen, fastc_list_off(g.fastColsRows));
         if (nBig > 0) {
             prof_end(c, DRFE_STAGE_FAST, s);
             prof_begin(c, DRFE_STAGE_FAST_B, s);
@@ -1494,7 +1573,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
             hipLaunchKernelGGL((k_fast_cells_cols<DRFE_FASTC_MAX_RPL>), dim3(nBig, nframes), dim3(64),
                                (size_t)fastc_lds_bytes(g.fastColsRows), s, c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems,
                                g.iniTh, g.minTh, c->d_pyr, c->d_cand0, c->d_cand1, c->d_candCount, c->d_status,
-                               drfe_div_magic((uint32_t)nBig), nSmall);
+                               drfe_div_magic((uint32_t)nBig), nSmall, c->fastScreen, fastc_list_off(g.fastColsRows));
         if (nBig > 0) prof_end(c, DRFE_STAGE_FAST_B, s);
         else prof_end(c, DRFE_STAGE_FAST, s);
     } else {
