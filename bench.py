@@ -782,9 +782,10 @@ def main():
                  "fast_b": "k_fast_cells_cols<12>", "blur": "k_blur", "desc": "k_orient_desc",
                  "match": "k_window_candidates"}[roof_stage]
         try:
-            pmc_name = ("r02_pmc_traffic_c5_b%d.json" if config == 5 else "r03_pmc_traffic_b%d.json") % B
-            if not os.path.exists(os.path.join(ROOT, "profiles", pmc_name)):
-                pmc_name = pmc_name.replace("r03_", "r02_")
+            # the newest committed counter passes of this configuration and batch size
+            cands = ["r04_pmc_traffic_c5_b%d.json", "r02_pmc_traffic_c5_b%d.json"] if config == 5 else \
+                    ["r04_pmc_traffic_b%d.json", "r03_pmc_traffic_b%d.json", "r02_pmc_traffic_b%d.json"]
+            pmc_name = next((c % B for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c % B))), cands[-1] % B)
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
                 k = pmc["kernels"][kname]

@@ -14,6 +14,7 @@
 #define DRFE_INTERNAL_H
 
 #include <hip/hip_runtime.h>
+#include <roctracer/roctx.h>
 #include <stdint.h>
 #include <time.h>
 #include <string>
@@ -204,6 +205,30 @@ static inline hipError_t drfe_pool_sync(hipStream_t s, hipEvent_t ev)
         nanosleep(&ts, nullptr);
     }
 }
+
+/* Stage brackets of the headline path: HIP events on the launch stream when drfe_profile_enable is on (drfe_profile_stage_ms),
+ * and a roctx range around the stage's launches always (a rocprofv3 --marker-trace / --kernel-trace run shows
+ * "drfe:pyramid", "drfe:fast" ... around the kernels instead of bare kernel names; without a tool attached roctx is a no-op). */
+static inline const char* drfe_stage_name(int stage)
+{
+    static const char* const names[DRFE_STAGE_COUNT] = {"drfe:pyramid", "drfe:fast", "drfe:quadtree", "drfe:blur", "drfe:orient+desc", "drfe:glue", "drfe:match", "drfe:fast_b"};
+    return stage >= 0 && stage < DRFE_STAGE_COUNT ? names[stage] : "drfe:?";
+}
+static inline void prof_begin(drfe_ctx* c, int stage, hipStream_t s)
+{
+    (void)roctxRangePushA(drfe_stage_name(stage));
+    if (c->profile) { (void)hipEventRecord(c->ev[stage][0], s); c->evUsed[stage] = true; }
+}
+static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
+{
+    if (c->profile) (void)hipEventRecord(c->ev[stage][1], s);
+    (void)roctxRangePop();
+}
+/* a named range around a phase of the batch entries (lines / planes / CAPE) */
+struct DrfeRange {
+    explicit DrfeRange(const char* name) { (void)roctxRangePushA(name); }
+    ~DrfeRange() { (void)roctxRangePop(); }
+};
 
 /* wait for an already recorded event the same way: poll + sleep instead of the runtime's busy wait */
 static inline hipError_t drfe_event_wait_sleeping(hipEvent_t ev)

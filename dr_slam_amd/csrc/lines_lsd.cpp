@@ -1147,6 +1147,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
                                     int* n_lines, int* n_detected)
 {
     const auto tBegin = std::chrono::steady_clock::now();
+    DrfeRange range("drfe:lines batch (upload, image passes, order, grow, rect_improve, keylines, LBD)");
     int rc = ensure_lines(c->err, c->lsBatch, w, h, nframes, true, true);
     if (rc != DRFE_OK) return rc;
     LinesScratch* A = c->lsBatch;

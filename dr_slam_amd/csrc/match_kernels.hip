@@ -729,14 +729,6 @@ __global__ __launch_bounds__(64) void k_bf_knn(const uint8_t* __restrict__ Q, in
 /* ------------------------------------------------------------------------------------------------ */
 /* launchers                                                                                         */
 
-static inline void prof_begin(drfe_ctx* c, int stage, hipStream_t s)
-{
-    if (c->profile) { (void)hipEventRecord(c->ev[stage][0], s); c->evUsed[stage] = true; }
-}
-static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
-{
-    if (c->profile) (void)hipEventRecord(c->ev[stage][1], s);
-}
 
 /* the pixel ComputeStereoFromRGBD reads the depth of keypoint i at (u | v << 16; 0xFFFFFFFF = outside the image): what a host
  * that keeps the depth images needs to gather one raw value per keypoint instead of shipping whole depth frames */

@@ -1502,14 +1502,6 @@ __global__ __launch_bounds__(DESC_THREADS) void k_orient_desc(const DevGeom* __r
 /* ------------------------------------------------------------------------------------------------ */
 /* host launcher                                                                                     */
 
-static inline void prof_begin(drfe_ctx* c, int stage, hipStream_t s)
-{
-    if (c->profile) { (void)hipEventRecord(c->ev[stage][0], s); c->evUsed[stage] = true; }
-}
-static inline void prof_end(drfe_ctx* c, int stage, hipStream_t s)
-{
-    if (c->profile) (void)hipEventRecord(c->ev[stage][1], s);
-}
 
 __global__ void k_clear_counts(int* __restrict__ candCount, int n, int* __restrict__ status)
 {

@@ -1037,6 +1037,7 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
                                         drfe_plane* planes, int cap, int* n_planes, uint8_t* seg, drfe_plane_post* post, int* n_accepted, int* plane_num,
                                         int32_t* member_offsets, int32_t* member_idx)
 {
+    DrfeRange range("drfe:planes batch (upload, block fits, clustering, flood fill, clouds, voxel grids; gates + refit on the pool)");
     int rc = ensure_arena(c, w, h, nframes, K4, depth_factor, max_point_dist);
     if (rc != DRFE_OK) return rc;
     AhcArena* A = static_cast<AhcArena*>(c->ahcArena);

@@ -397,6 +397,7 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
         HIPCHK(c, hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking));
     }
     hipStream_t st = A->stream;
+    DrfeRange range("drfe:cape batch (upload, cell fits, frame stage, refinement)");
     DrfePoolCpuScope cpu(2);                      /* accounted to the CAPE pool: the calling thread is its only worker here */
     const float sinCos = (float)std::sqrt(1 - (double)cos_angle_max * (double)cos_angle_max);
     int chunkNo = 0;
