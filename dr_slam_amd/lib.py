@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor",
+    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -202,6 +202,15 @@ def load() -> C.CDLL:
     L.drfe_lsd_segments_host.argtypes = [vp, vp, vp, i32, i32, f64, vp, i32, C.POINTER(i32)]
     L.drfe_lsd_configure.argtypes = [vp, i32]
     L.drfe_lsd_configure_rect.argtypes = [vp, i32]
+    L.drfe_shard_unique_id.argtypes = [vp]
+    L.drfe_shard_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.drfe_shard_destroy.argtypes = [vp]
+    L.drfe_shard_destroy.restype = None
+    L.drfe_shard_broadcast.argtypes = [vp, vp, sz, i32]
+    L.drfe_shard_reduce_report.argtypes = [vp, vp, i32, vp, i32]
+    L.drfe_shard_sequences_of_rank.argtypes = [i32, i32, i32, vp, i32]
+    L.drfe_shard_last_error.argtypes = [vp]
+    L.drfe_shard_last_error.restype = C.c_char_p
     L.drfe_planes_configure_cape.argtypes = [vp, i32]
     L.drfe_planes_cape_stats.argtypes = [vp, vp]
     L.drfe_lsd_configure_nfa.argtypes = [vp, i32]
@@ -309,6 +318,65 @@ def lines_is_good(lines, depth_f32, K9, cx, cy, invfx, invfy, k_as_f64=False, se
     if rc != 0:
         raise RuntimeError(f"drfe_lines_is_good failed ({rc})")
     return dl[:n], l3[:n], ni[:n], good.value
+
+
+class Shard:
+    """drfe_shard_*: the native (RCCL) side of the batched-sequence mode - what a C++ host calls where bench.py uses
+    torch.distributed: unique id on rank 0, communicator per rank, broadcast of host buffers (the vocabulary), end-of-run
+    MAX / SUM reduction."""
+
+    @staticmethod
+    def unique_id():
+        L = load()
+        ident = np.zeros(128, np.uint8)
+        rc = L.drfe_shard_unique_id(_p(ident))
+        if rc != 0:
+            raise DrfeError(f"drfe_shard_unique_id failed ({rc}): {L.drfe_shard_last_error(None).decode()}")
+        return ident
+
+    @staticmethod
+    def sequences_of_rank(n_sequences, nranks, rank):
+        L = load()
+        out = np.zeros(max(1, n_sequences), np.int32)
+        n = L.drfe_shard_sequences_of_rank(n_sequences, nranks, rank, _p(out), len(out))
+        if n < 0:
+            raise DrfeError(f"drfe_shard_sequences_of_rank failed ({n})")
+        return out[:n].copy()
+
+    def __init__(self, ident, nranks, rank, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.drfe_shard_create(_p(np.ascontiguousarray(ident, np.uint8)), nranks, rank, device, C.byref(h))
+        if rc != 0:
+            raise DrfeError(f"drfe_shard_create failed ({rc}): {self.L.drfe_shard_last_error(None).decode()}")
+        self.h = h
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise DrfeError(f"{what} failed ({rc}): {self.L.drfe_shard_last_error(self.h).decode()}")
+
+    def broadcast(self, arr: np.ndarray, root=0):
+        """in place: a C-contiguous host array from rank `root` to every rank"""
+        assert arr.flags.c_contiguous
+        self._chk(self.L.drfe_shard_broadcast(self.h, _p(arr), arr.nbytes, root), "drfe_shard_broadcast")
+        return arr
+
+    def reduce_report(self, maxima, sums):
+        m = np.ascontiguousarray(maxima, np.float64).copy()
+        s = np.ascontiguousarray(sums, np.int64).copy()
+        self._chk(self.L.drfe_shard_reduce_report(self.h, _p(m), len(m), _p(s), len(s)), "drfe_shard_reduce_report")
+        return m, s
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.drfe_shard_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Pipeline:

@@ -531,6 +531,32 @@ int drfe_lsd_search_by_sim3(drfe_ctx* ctx, const drfe_camera* cam, const float* 
                             float th, int32_t* matches12, int* n_found);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Multi-GPU, batched-sequence mode (no counterpart in the reference, whose only parallelism is the three
+ * extractor threads of src/Frame.cc:124-134).  One process (or thread) per GPU, each with its own drfe_ctx / drfe_pipeline;
+ * whole sequences are dealt to the ranks and NO collective runs on the data path.  The one exchange is the ORB vocabulary at
+ * start-up: rank 0 loads it and broadcasts the node table over RCCL (xGMI inside a node); every rank then calls
+ * drfe_voc_upload on its own context.  RCCL is loaded at run time (librccl.so.1): a single-GPU host never needs it.
+ *   rank 0:     drfe_shard_unique_id(id)  -> hand the 128 bytes to the other ranks (file, pipe, MPI, environment ...)
+ *   every rank: drfe_shard_create(id, nranks, rank, device, &sh)
+ *               drfe_shard_broadcast(sh, &header, sizeof header, 0); drfe_shard_broadcast(sh, parent, 4 * n_nodes, 0); ... desc, weight, is_leaf
+ *               drfe_voc_upload(ctx, k, L, scoring, weighting, n_nodes, parent, desc, weight, is_leaf)
+ *               ... its sequences (drfe_shard_sequences_of_rank) through drfe_pipeline_submit ...
+ *               drfe_shard_reduce_report(sh, &seconds, 1, &frames, 1)      MAX of the times, SUM of the frames: whole-job frames/s
+ *               drfe_shard_destroy(sh) */
+typedef struct drfe_shard drfe_shard;
+#define DRFE_SHARD_ID_BYTES 128
+int drfe_shard_unique_id(uint8_t* id /* DRFE_SHARD_ID_BYTES */);
+int drfe_shard_create(const uint8_t* id, int nranks, int rank, int device, drfe_shard** out);
+void drfe_shard_destroy(drfe_shard* shard);
+/* a HOST buffer from rank `root` to every rank (staged through device memory, one ncclBroadcast); collective: every rank calls it */
+int drfe_shard_broadcast(drfe_shard* shard, void* buf, size_t bytes, int root);
+/* in place on every rank: element-wise MAX over the ranks of n_max doubles, SUM of n_sum 64-bit counters; collective */
+int drfe_shard_reduce_report(drfe_shard* shard, double* max_inout, int n_max, long long* sum_inout, int n_sum);
+/* sequences dealt round robin (sequence i -> rank i % nranks): writes up to cap indices of rank's share, returns their number */
+int drfe_shard_sequences_of_rank(int n_sequences, int nranks, int rank, int* out, int cap);
+const char* drfe_shard_last_error(const drfe_shard* shard /* NULL: the calling thread's last creation error */);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* Bag of words (replaces the DBoW2 tree descent of Frame::ComputeBoW, src/Frame.cc:828-833, and
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...), src/ORBmatcher.cc:160-292)                        */
 

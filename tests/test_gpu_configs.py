@@ -297,3 +297,25 @@ def test_bench_size_three_in_flight_against_oracle(oracle_mod):
         assert checked == 16 * depth_n
     finally:
         pipe.close()
+
+
+def test_native_shard_rccl_single_rank():
+    """drfe_shard_* (RCCL loaded at run time) with one rank on this box's one GPU: communicator from a unique id, the vocabulary
+    blob broadcast from rank 0 (identity at one rank, but through ncclBroadcast on device memory), the end-of-run MAX / SUM
+    reduction.  Two ranks need two devices (RCCL refuses two ranks on one): the N > 1 path is covered by the world_size-2 gloo
+    test of dr_slam_amd.sharding on the CPU and runs on the driver's 8-GPU node."""
+    from dr_slam_amd import lib, vocabulary as V
+    ident = lib.Shard.unique_id()
+    assert ident.shape == (128,) and ident.any()
+    sh = lib.Shard(ident, 1, 0, device=0)
+    try:
+        blob = V.make_synthetic(6, 3, seed=2).pack()
+        ref = blob.copy()
+        sh.broadcast(blob, root=0)
+        assert np.array_equal(blob, ref)
+        m, s = sh.reduce_report([1.5, 0.25], [512, 7])
+        assert m.tolist() == [1.5, 0.25] and s.tolist() == [512, 7]
+        with pytest.raises(lib.DrfeError):
+            sh.broadcast(blob, root=1)
+    finally:
+        sh.close()

@@ -462,3 +462,14 @@ def test_cr_sincos_is_correctly_rounded():
             err = abs(dec(got) - exact)
             for nb in (np.nextafter(got, np.inf), np.nextafter(got, -np.inf)):
                 assert err <= abs(dec(nb) - exact)
+
+
+def test_shard_sequences_dealt_round_robin():
+    """drfe_shard_sequences_of_rank (host arithmetic of the native multi-GPU helper): every sequence goes to exactly one rank."""
+    from dr_slam_amd import lib
+    for nseq, nranks in ((8, 8), (8, 3), (5, 8), (0, 2), (17, 4)):
+        got = [lib.Shard.sequences_of_rank(nseq, nranks, r) for r in range(nranks)]
+        assert sorted(int(v) for g in got for v in g) == list(range(nseq))
+        assert all((g % nranks == r).all() for r, g in enumerate(got))
+    with pytest.raises(lib.DrfeError):
+        lib.Shard.sequences_of_rank(4, 2, 2)
