@@ -912,6 +912,7 @@ struct BatchJob {
     LsdNfaTables nfaTab;
     int rectMode = 0;
     std::atomic<long> nfaToHost{0};     /* frames whose NFA decisions the device could not certify */
+    std::atomic<int> nfaWhy{0}; std::atomic<long> nfaWhyCount[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};      /* DRFE_TRACE_LINES: which certification failed (stopping rule | close values | sign | subnormal regime) */
     bool deviceOrder = true;            /* the ordering by k_lsd_order (default) or by the pool (DRFE_LSD_HOST_ORDER=1: A/B, tests) */
     hipEvent_t stageEv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* DRFE_TRACE_LINES, chunk 0: start | upload | passes | keys | ordering | growth */
     std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0}, usCountsWall{0}, usCountsCpu{0}, nCountRounds{0}, handedBack{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
@@ -1099,7 +1100,7 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
                     J.usKeyl += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tk).count();
                 }
             } else {
-                if (J.deviceNfa) J.nfaToHost++;
+                if (J.deviceNfa) { J.nfaToHost++; J.nfaWhy |= A->h_out[DRFE_LSD_OUT_INTS * (size_t)f + 3]; for (int b = 0; b < 8; b++) if (A->h_out[DRFE_LSD_OUT_INTS * (size_t)f + 3] & (1 << b)) J.nfaWhyCount[b]++; }
                 std::vector<RectD> pending(nRects);
                 /* through the arena's pinned mirror: a download into pageable memory stages inside the copy call */
                 LsdRect* hr = A->h_rects + (size_t)A->rectCap * f;
@@ -1263,6 +1264,9 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     if (std::getenv("DRFE_TRACE_LINES"))
         std::fprintf(stderr, "drfe_lsd_extract_batch: rect_improve / NFA %s; %ld of %d frames back to the host's validation (a decision too close to certify)\n",
                      J.deviceNfa ? "on the device (k_rect_improve)" : "on the host pool", J.nfaToHost.load(), nframes);
+    if (std::getenv("DRFE_TRACE_LINES") && J.nfaToHost.load())
+        std::fprintf(stderr, "drfe_lsd_extract_batch: uncertified frames by kind: stopping rule %ld, subnormal regime %ld, hypothesis queue full %ld, no outcome %ld, outcomes differ %ld, too many hypotheses in a stage %ld\n",
+                     J.nfaWhyCount[0].load(), J.nfaWhyCount[3].load(), J.nfaWhyCount[4].load(), J.nfaWhyCount[5].load(), J.nfaWhyCount[6].load(), J.nfaWhyCount[7].load());
     if (std::getenv("DRFE_TRACE_LINES"))
         std::fprintf(stderr, "drfe_lsd_extract_batch (device grow): %d frames, %d chunks of %d, %d threads: enqueue %.1f ms, total %.1f ms; per frame: ordering %.2f ms, rect download %.2f, NFA rounds %.2f (of which in the counting round trips: %.2f wall, %.2f CPU), key lines + LBD %.2f (validation task %.2f); workers slept %.1f ms each waiting for the device; %ld frames redone on the host\n",
                      nframes, nChunks, chunk, T, std::chrono::duration<double, std::milli>(tLaunched - tBegin).count(),

@@ -49,21 +49,29 @@ __device__ NfaVal nfa_device(int n, int k, int pj, const LsdNfaTables& T)
     double term = exp(log1);
     if (log1 < -708.0) r.e = 12.0;               /* a subnormal first term: its bits are the libm's rounding onto the subnormal grid */
     double tail = term;
+    int iters = 0;
     for (int i = k + 1; i <= n; ++i) {
         const double binTerm = (double)(n - i + 1) / (double)i, mult = binTerm * pTerm;
         term *= mult;
         tail += term;
+        ++iters;
         if (binTerm < 1) {
             const double err = term * ((1 - pow(mult, (double)(n - i + 1))) / (1 - mult) - 1);
             const double rhs = 0.1 * fabs(-log10(tail) - T.logNT) * tail;
-            if (fabs(err - rhs) <= 1e-9 * (fabs(err) + fabs(rhs))) r.unc = 1;       /* the host may leave the loop elsewhere */
+            if (fabs(err - rhs) <= 1e-9 * (fabs(err) + fabs(rhs))) r.unc = 1;       /* reason 1 */
+                  /* the host may leave the loop elsewhere */
             if (err < rhs) break;
         }
     }
-    r.v = -log10(tail) - T.logNT;
-    /* exp and log10 within an ulp of the host's, then identical IEEE operations: relative 1e-9 covers the accumulation of a
-     * loop of 10^6 terms with three orders of magnitude to spare */
-    const double e = 1e-9 * fmax(1.0, fabs(r.v));
+    const double lt = log10(tail);
+    r.v = -lt - T.logNT;
+    /* How far the host's value can lie from this one.  log1 is bit-identical on both sides (host tables, IEEE operations); the
+     * two exp results are within an ulp of the true value each; every loop iteration multiplies and adds with identical
+     * factors, so the relative difference of the two tails grows by at most an ulp per iteration: (iters + 2) ulps.  Through
+     * log10 that is an absolute (iters + 2) ulp(1) / ln 10, plus an ulp of each side's log10 result and of the final subtraction.
+     * Sixty-four times that sum: ~1e-12 for a typical candidate.  (The first version used 1e-9 max(1, |v|) and sent a sixth of
+     * the soak's frames to the host: candidates with next to no aligned pixels all sit within 1e-9 of -log NT.) */
+    const double e = 64.0 * 0x1p-52 * ((double)iters + 8.0 + fabs(lt) + fabs(r.v));
     if (e > r.e) r.e = e;
     return r;
 }
@@ -73,22 +81,120 @@ __device__ __forceinline__ bool certain_greater(const NfaVal& a, const NfaVal& b
 {
     if (a.n == b.n && a.k == b.k && a.pj == b.pj) return false;       /* the host computes one value for both */
     if (a.e == 0 && b.e == 0) return a.v > b.v;                         /* bit-identical on both sides */
-    if (fabs(a.v - b.v) <= a.e + b.e) unc = 1;
+    if (fabs(a.v - b.v) <= a.e + b.e) unc |= (a.e >= 1.0 || b.e >= 1.0) ? 8 : 2;      /* reasons 2 (close values) / 8 (a subnormal-regime value involved) */
     return a.v > b.v;
 }
 
 __device__ __forceinline__ bool certain_positive(const NfaVal& a, int& unc)
 {
-    if (a.e != 0 && fabs(a.v) <= a.e) unc = 1;
+    if (a.e != 0 && fabs(a.v) <= a.e) unc |= 4;                                         /* reason 4 */
     return a.v > 0;
 }
+
+/* One hypothesis about a rectangle's state inside rect_improve: the fields the refinement stages modify, the index of its
+ * precision, the best value so far and the stage it continues with */
+struct Hyp {
+    double x1, y1, x2, y2, width, prec;
+    NfaVal best;
+    int pj, stage;
+};
+#define NFA_MAXQ 12                        /* hypotheses per rectangle (queued + explored) */
+#define NFA_MAXLIVE 6                      /* hypotheses alive inside one stage's selection */
 
 struct ImproveShared {
     RectCand cand[NFA_MAX_CAND];
     int pj[NFA_MAX_CAND];
     int total[64], alg[64];
     NfaVal val[NFA_MAX_CAND];
+    Hyp q[NFA_MAXQ];                       /* q[qi] = the hypothesis being explored; entries behind it wait */
+    Hyp live[NFA_MAXLIVE];
+    int nq, finished, nOut, outKeep, flag, why;
+    float outSeg[4];
 };
+
+/* the segment LineSegmentDetectorImpl::detect emits for a kept rectangle (input-image scale), or "rejected": every explored
+ * hypothesis must end in the same one */
+__device__ void improve_outcome(ImproveShared& S, bool keep, const Hyp& h)
+{
+    double x1 = h.x1 + 0.5, y1 = h.y1 + 0.5, x2 = h.x2 + 0.5, y2 = h.y2 + 0.5;
+    x1 /= 0.8; y1 /= 0.8; x2 /= 0.8; y2 /= 0.8;
+    const float f[4] = {(float)x1, (float)y1, (float)x2, (float)y2};
+    if (S.nOut == 0) { S.outKeep = keep ? 1 : 0; for (int k = 0; k < 4; k++) S.outSeg[k] = f[k]; }
+    else {
+        bool same = S.outKeep == (keep ? 1 : 0);
+        if (same && keep) for (int k = 0; k < 4; k++) same = same && __float_as_uint(S.outSeg[k]) == __float_as_uint(f[k]);
+        if (!same) { S.flag = 1; S.why |= 64; }
+    }
+    S.nOut++;
+}
+
+/* The choice among a stage's candidates and the stage's exit test for the hypothesis q[qi], by one lane.  A comparison the
+ * bounds do not settle SPLITS the hypothesis: both answers are followed (a rejected rectangle is rejected whichever of two
+ * all but equal hopeless candidates "won" - the common case on low-texture frames, where half of the frames had such a pair;
+ * a kept one may or may not depend on it), and only outcomes that differ flag the frame. */
+__device__ void improve_select(ImproveShared& S, int qi, int stage, int nc, const LsdNfaTables& T)
+{
+    int nl = 1;
+    S.live[0] = S.q[qi];
+    for (int c = 0; c < nc; c++) {
+        const NfaVal v = S.val[c];
+        if (v.unc) { S.flag = 1; S.why |= 1; }
+        const int nl0 = nl;
+        for (int l = 0; l < nl0; l++) {
+            bool take = true;
+            if (stage != 0) {
+                int u = 0;
+                take = certain_greater(v, S.live[l].best, u);
+                if (u) {
+                    /* the other answer becomes a hypothesis of its own - unless one in that state exists already (a hypothesis
+                     * that takes candidate c IS candidate c: at most nc + 1 distinct states per stage) */
+                    bool dup = false;
+                    if (!take)
+                        for (int m = 0; m < nl; m++) dup = dup || (S.live[m].best.n == v.n && S.live[m].best.k == v.k && S.live[m].best.pj == v.pj && S.live[m].pj == S.pj[c] &&
+                                                                   S.live[m].width == S.cand[c].width && S.live[m].x1 == S.cand[c].x1 && S.live[m].y1 == S.cand[c].y1);
+                    if (dup) { /* nothing to add */ }
+                    else if (nl < NFA_MAXLIVE && !(u & 8)) {
+                        S.live[nl] = S.live[l];
+                        if (!take) {
+                            Hyp& o = S.live[nl];
+                            const RectCand rc = S.cand[c];
+                            o.x1 = rc.x1; o.y1 = rc.y1; o.x2 = rc.x2; o.y2 = rc.y2; o.width = rc.width; o.prec = rc.prec; o.pj = S.pj[c]; o.best = v;
+                        }
+                        nl++;
+                    } else { S.flag = 1; S.why |= (u & 8) ? 8 : 128; }
+                }
+            }
+            if (take) {
+                Hyp& h = S.live[l];
+                h.best = v;
+                if (stage != 0) {
+                    const RectCand rc = S.cand[c];
+                    h.x1 = rc.x1; h.y1 = rc.y1; h.x2 = rc.x2; h.y2 = rc.y2; h.width = rc.width; h.prec = rc.prec; h.pj = S.pj[c];
+                }
+            }
+        }
+    }
+    /* exit test of the stage: log_nfa > LOG_EPS ends rect_improve (kept); after the last stage it is the segment's verdict */
+    bool haveNext = false;
+    for (int l = 0; l < nl; l++) {
+        int u = 0;
+        const bool pos = certain_positive(S.live[l].best, u);
+        if (stage == 5) {
+            improve_outcome(S, pos, S.live[l]);
+            if (u) improve_outcome(S, !pos, S.live[l]);           /* differs by construction: flags */
+            continue;
+        }
+        if (pos || u) improve_outcome(S, true, S.live[l]);
+        if (!pos || u) {
+            Hyp h = S.live[l];
+            h.stage = stage + 1;
+            if (!haveNext) { S.q[qi] = h; haveNext = true; }
+            else if (S.nq < NFA_MAXQ) S.q[S.nq++] = h;
+            else { S.flag = 1; S.why |= 16; }
+        }
+    }
+    S.finished = haveNext ? 0 : 1;
+}
 
 } // namespace
 
@@ -104,103 +210,92 @@ __global__ __launch_bounds__(64) void k_rect_improve(const LsdGrowFrame* __restr
     LsdSegOut* out = segs + (size_t)blockIdx.y * rectCap;
     const double delta = 0.5, d2 = delta / 2.0;
     for (int id = blockIdx.x; id < count; id += gridDim.x) {
-        LsdRect rec = F.rects[id];
-        int recPj = 0, unc = 0;
-        NfaVal best;
-        best.v = 0; best.e = 0; best.n = best.k = best.pj = -1; best.unc = 0;
-        bool done = false;
-        for (int stage = 0; stage < 6 && !done; stage++) {
-            /* the candidates of this stage: rect_improve's cumulative modifications of a copy of the current rectangle */
-            int nc = 0;
-            if (lane == 0) {
-                LsdRect r = rec;
-                int pj = recPj;
-                if (stage == 0) { S.cand[0] = RectCand{r.x1, r.y1, r.x2, r.y2, r.width, r.dx, r.dy, r.theta, r.prec}; S.pj[0] = pj; nc = 1; }
-                else
-                    for (int n = 0; n < 5; ++n) {
-                        if (stage == 1) { r.p /= 2; r.prec = r.p * 3.14159265358979323846; ++pj; }
-                        else {
-                            if (!((r.width - delta) >= 0.5)) continue;        /* guards the last precision stage too */
-                            if (stage == 5) { r.p /= 2; r.prec = r.p * 3.14159265358979323846; ++pj; }
-                            else if (stage == 2) r.width -= delta;
-                            else if (stage == 3) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; r.width -= delta; }
-                            else { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; r.width -= delta; }
+        const LsdRect rec0 = F.rects[id];
+        if (lane == 0) {
+            Hyp h;
+            h.x1 = rec0.x1; h.y1 = rec0.y1; h.x2 = rec0.x2; h.y2 = rec0.y2; h.width = rec0.width; h.prec = rec0.prec;
+            h.best.v = 0; h.best.e = 0; h.best.n = h.best.k = h.best.pj = -1; h.best.unc = 0;
+            h.pj = 0; h.stage = 0;
+            S.q[0] = h; S.nq = 1; S.nOut = 0; S.outKeep = 0; S.flag = 0; S.why = 0;
+        }
+        __syncthreads();
+        for (int qi = 0; qi < S.nq; qi++) {
+            bool finished = false;
+            for (int stage = S.q[qi].stage; stage < 6 && !finished; stage++) {
+                /* the candidates of this stage: rect_improve's cumulative modifications of a copy of the hypothesis' rectangle */
+                int nc = 0;
+                if (lane == 0) {
+                    const Hyp h = S.q[qi];
+                    double x1 = h.x1, y1 = h.y1, x2 = h.x2, y2 = h.y2, width = h.width, prec = h.prec, p = T.p[h.pj];
+                    int pj = h.pj;
+                    if (stage == 0) { S.cand[0] = RectCand{x1, y1, x2, y2, width, rec0.dx, rec0.dy, rec0.theta, prec}; S.pj[0] = pj; nc = 1; }
+                    else
+                        for (int n = 0; n < 5; ++n) {
+                            if (stage == 1) { p /= 2; prec = p * 3.14159265358979323846; ++pj; }
+                            else {
+                                if (!((width - delta) >= 0.5)) continue;        /* guards the last precision stage too */
+                                if (stage == 5) { p /= 2; prec = p * 3.14159265358979323846; ++pj; }
+                                else if (stage == 2) width -= delta;
+                                else if (stage == 3) { x1 += -rec0.dy * d2; y1 += rec0.dx * d2; x2 += -rec0.dy * d2; y2 += rec0.dx * d2; width -= delta; }
+                                else { x1 -= -rec0.dy * d2; y1 -= rec0.dx * d2; x2 -= -rec0.dy * d2; y2 -= rec0.dx * d2; width -= delta; }
+                            }
+                            S.cand[nc] = RectCand{x1, y1, x2, y2, width, rec0.dx, rec0.dy, rec0.theta, prec};
+                            S.pj[nc] = pj;
+                            ++nc;
                         }
-                        S.cand[nc] = RectCand{r.x1, r.y1, r.x2, r.y2, r.width, r.dx, r.dy, r.theta, r.prec};
-                        S.pj[nc] = pj;
-                        ++nc;
-                    }
-            }
-            nc = __shfl(nc, 0);
-            __syncthreads();
-            if (nc == 0) continue;
-            /* pixel loops: candidate g on lanes [12 g, 12 g + 12) */
-            int total = 0, alg = 0;
-            if (g < nc) {
-                const RectCand rc = S.cand[g];
-                const RectWalk w = rect_walk_setup(rc, rectMode);
-                const double kNotDef = -1024.0, kTwoPi = 2.0 * 3.14159265358979323846, kThreeHalfPi = 3.0 * 3.14159265358979323846 / 2.0;
-                double lstep = w.fl, rstep = w.fr, lx = (double)w.loX, rx = (double)w.loX;
-                const int yBeg = max(w.loY, 0), yEnd = min(w.hiY, H - 1);
-                for (int y = yBeg; y <= yEnd; ++y) {
-                    const int xs = max((int)lx, 0), xe = min((int)rx, W - 1);
-                    const double* row = F.ang + (size_t)y * W;
-                    for (int x = xs + gl; x <= xe; x += NFA_GROUP) {
-                        ++total;
-                        const double a = row[x];
-                        if (a != kNotDef) {
-                            double d = rc.theta - a;
-                            if (d < 0) d = -d;
-                            if (d > kThreeHalfPi) { d -= kTwoPi; if (d < 0) d = -d; }
-                            if (d <= rc.prec) ++alg;
-                        }
-                    }
-                    if (y >= w.leftY) lstep = w.sl;
-                    if (y >= w.rightY) rstep = w.sr;
-                    lx += lstep;
-                    rx += rstep;
                 }
-            }
-            S.total[lane] = total; S.alg[lane] = alg;
-            __syncthreads();
-            if (lane < nc) {
-                int t = 0, a = 0;
-                for (int q = 0; q < NFA_GROUP; q++) { t += S.total[lane * NFA_GROUP + q]; a += S.alg[lane * NFA_GROUP + q]; }
-                S.val[lane] = nfa_device(t, a, S.pj[lane], T);
-            }
-            __syncthreads();
-            /* the reference's order: a later candidate replaces an earlier one only when strictly greater */
-            for (int c = 0; c < nc; c++) {
-                const NfaVal v = S.val[c];
-                unc |= v.unc;
-                bool take;
-                if (stage == 0) take = true;
-                else take = certain_greater(v, best, unc);
-                if (take) {
-                    best = v;
-                    if (stage != 0) {
-                        const RectCand rc = S.cand[c];
-                        rec.x1 = rc.x1; rec.y1 = rc.y1; rec.x2 = rc.x2; rec.y2 = rc.y2; rec.width = rc.width; rec.prec = rc.prec;
-                        recPj = S.pj[c]; rec.p = T.p[recPj];
+                nc = __shfl(nc, 0);
+                __syncthreads();
+                /* pixel loops: candidate g on lanes [12 g, 12 g + 12).  (A stage without candidates - the width guard - still
+                 * runs its exit test below: after the last stage that is the segment's verdict.) */
+                int total = 0, alg = 0;
+                if (g < nc) {
+                    const RectCand rc = S.cand[g];
+                    const RectWalk w = rect_walk_setup(rc, rectMode);
+                    const double kNotDef = -1024.0, kTwoPi = 2.0 * 3.14159265358979323846, kThreeHalfPi = 3.0 * 3.14159265358979323846 / 2.0;
+                    double lstep = w.fl, rstep = w.fr, lx = (double)w.loX, rx = (double)w.loX;
+                    const int yBeg = max(w.loY, 0), yEnd = min(w.hiY, H - 1);
+                    for (int y = yBeg; y <= yEnd; ++y) {
+                        const int xs = max((int)lx, 0), xe = min((int)rx, W - 1);
+                        const double* row = F.ang + (size_t)y * W;
+                        for (int x = xs + gl; x <= xe; x += NFA_GROUP) {
+                            ++total;
+                            const double a = row[x];
+                            if (a != kNotDef) {
+                                double d = rc.theta - a;
+                                if (d < 0) d = -d;
+                                if (d > kThreeHalfPi) { d -= kTwoPi; if (d < 0) d = -d; }
+                                if (d <= rc.prec) ++alg;
+                            }
+                        }
+                        if (y >= w.leftY) lstep = w.sl;
+                        if (y >= w.rightY) rstep = w.sr;
+                        lx += lstep;
+                        rx += rstep;
                     }
                 }
+                S.total[lane] = total; S.alg[lane] = alg;
+                __syncthreads();
+                if (lane < nc) {
+                    int t = 0, a = 0;
+                    for (int q = 0; q < NFA_GROUP; q++) { t += S.total[lane * NFA_GROUP + q]; a += S.alg[lane * NFA_GROUP + q]; }
+                    S.val[lane] = nfa_device(t, a, S.pj[lane], T);
+                }
+                __syncthreads();
+                if (lane == 0) improve_select(S, qi, stage, nc, T);
+                __syncthreads();
+                finished = S.finished != 0;
             }
-            if (stage < 5 && certain_positive(best, unc)) done = true;
             __syncthreads();
         }
-        int fin = 0;
-        const bool keep = certain_positive(best, fin);
-        unc |= fin;
         if (lane == 0) {
             LsdSegOut o;
-            /* LineSegmentDetectorImpl::detect: back to the input image's scale */
-            double x1 = rec.x1 + 0.5, y1 = rec.y1 + 0.5, x2 = rec.x2 + 0.5, y2 = rec.y2 + 0.5;
-            x1 /= 0.8; y1 /= 0.8; x2 /= 0.8; y2 /= 0.8;
-            o.x1 = (float)x1; o.y1 = (float)y1; o.x2 = (float)x2; o.y2 = (float)y2;
-            o.flag = keep ? 1 : 0;
+            o.x1 = S.outSeg[0]; o.y1 = S.outSeg[1]; o.x2 = S.outSeg[2]; o.y2 = S.outSeg[3];
+            o.flag = S.outKeep;
             out[id] = o;
-            if (unc) atomicOr(&F.out[2], 1);
+            if (S.flag || S.nOut == 0) { atomicOr(&F.out[2], 1); atomicOr(&F.out[3], S.why ? S.why : 32); }      /* out[3]: why (DRFE_TRACE_LINES) */
         }
+        __syncthreads();
     }
 }
 
