@@ -104,7 +104,16 @@ hipError_t drfe_long_kernel_stream(hipStream_t* s, int part)
         int prLow = 0, prHigh = 0;
         hipError_t e = hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
         if (e != hipSuccess) return e;
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prLow);
+        /* The runtime maps the streams of one priority onto FOUR hardware queues: with eight long streams alive (four steps in
+         * flight x lines + planes) two of them share a queue and their 0.1 s kernels run one behind the other (tools/queue_probe.py:
+         * 4 contexts x 64 frames side by side 165 ms, 8 contexts 331 ms; 168 ms with DRFE_LONG_PRIO=split, which puts the plane
+         * path's long kernels on the middle priority level and so on four queues of their own).  With 512-frame steps it does
+         * not matter - the full front-end is bound by the SIMD time of its one-wavefront-per-frame kernels, 3 250-3 370 frames/s
+         * either way (profiles/r04_queue_probe.txt) - so the default stays the lowest level for both: the ORB batch, CAPE and the
+         * pools' lanes keep the middle level to themselves. */
+        static const bool split = [] { const char* m = std::getenv("DRFE_LONG_PRIO"); return m && m[0] == 's' && m[1] == 'p'; }();
+        const int mid = (prLow + prHigh) / 2;
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, (part == 1 && split && mid != prLow) ? mid : prLow);
     }
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -335,7 +335,8 @@ struct CapeBatchArena {
     CapeFrameOut* d_out = nullptr; uint8_t* d_seg = nullptr;
     float* h_stage[2] = {nullptr, nullptr}; hipEvent_t stageFree[2] = {nullptr, nullptr};      /* pinned upload staging, CAPE_STAGE_FRAMES frames each */
     drfe_cape_plane* h_planes = nullptr; CapeFrameOut* h_out = nullptr; uint8_t* h_seg = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copyStream = nullptr;
+    hipEvent_t kernelsDone = nullptr;
     long long toHost = 0, total = 0;
 };
 #define CAPE_STAGE_FRAMES 32
@@ -350,6 +351,8 @@ static void cape_batch_free(void*& p)
     for (void* q : hp) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : A->stageFree) if (e) (void)hipEventDestroy(e);
     if (A->stream) (void)hipStreamDestroy(A->stream);
+    if (A->copyStream) (void)hipStreamDestroy(A->copyStream);
+    if (A->kernelsDone) (void)hipEventDestroy(A->kernelsDone);
     delete A;
     p = nullptr;
 }
@@ -395,23 +398,31 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
         HIPCHK(c, hipHostMalloc((void**)&A->h_out, F * sizeof(CapeFrameOut), hipHostMallocDefault));
         if (seg) HIPCHK(c, hipHostMalloc((void**)&A->h_seg, F * npx, hipHostMallocDefault));
         HIPCHK(c, hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&A->copyStream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&A->kernelsDone, hipEventDisableTiming));
     }
-    hipStream_t st = A->stream;
+    hipStream_t st = A->stream, cs = A->copyStream;
     DrfeRange range("drfe:cape batch (upload, cell fits, frame stage, refinement)");
     DrfePoolCpuScope cpu(2);                      /* accounted to the CAPE pool: the calling thread is its only worker here */
     const float sinCos = (float)std::sqrt(1 - (double)cos_angle_max * (double)cos_angle_max);
+    /* Copies never sit behind kernels in a queue: a copy whose stream predecessor is a kernel occupies a DMA ring until that kernel
+     * has run - in the full front-end, where these kernels wait for CUs behind 0.1 s wavefronts, that held up every other path's
+     * transfers (this path's 512 frames took 500 ms instead of 25, the line path's upload 317 ms instead of 15).  Uploads go to
+     * their own stream and depend on nothing but their staging buffer; the kernels wait for them through an event; the results
+     * are fetched after the last kernel has finished. */
     int chunkNo = 0;
     for (int f0 = 0; f0 < nframes; f0 += CAPE_STAGE_FRAMES, chunkNo++) {
         const int nf = std::min(CAPE_STAGE_FRAMES, nframes - f0), b = chunkNo & 1;
-        if (chunkNo >= 2) HIPCHK(c, drfe_event_wait_sleeping(A->stageFree[b]));            /* the upload that last read this staging buffer is done */
+        if (chunkNo >= 2) HIPCHK(c, drfe_event_wait_sleeping(A->stageFree[b]));      /* the upload that last read this staging buffer is done */
         float* hs = A->h_stage[b];
         for (int k = 0; k < nf; k++) {
             const float* src = depth_m + (size_t)(f0 + k) * frame_stride;
             if (stride == (size_t)w) std::memcpy(hs + (size_t)k * npx, src, npx * sizeof(float));
             else for (int y = 0; y < h; y++) std::memcpy(hs + (size_t)k * npx + (size_t)y * w, src + (size_t)y * stride, (size_t)w * 4);
         }
-        HIPCHK(c, hipMemcpyAsync(A->d_depth + (size_t)f0 * npx, hs, (size_t)nf * npx * sizeof(float), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipEventRecord(A->stageFree[b], st));
+        HIPCHK(c, hipMemcpyAsync(A->d_depth + (size_t)f0 * npx, hs, (size_t)nf * npx * sizeof(float), hipMemcpyHostToDevice, cs));
+        HIPCHK(c, hipEventRecord(A->stageFree[b], cs));
+        HIPCHK(c, hipStreamWaitEvent(st, A->stageFree[b], 0));
         HIPCHK(c, drfe_launch_cape_cells_batch(A->d_depth + (size_t)f0 * npx, npx, (size_t)w, w, h, K4, patch, sinCos, max_merge_dist, nf,
                                                A->d_cells + (size_t)f0 * ncell, st));
         HIPCHK(c, drfe_launch_cape_frames(A->d_cells + (size_t)f0 * ncell, nh, nv, cos_angle_max, max_merge_dist, nf,
@@ -419,13 +430,11 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
         HIPCHK(c, drfe_launch_cape_refine_batch(A->d_depth + (size_t)f0 * npx, npx, (size_t)w, w, h, K4, patch, A->d_tabs + (size_t)f0 * tabStride,
                                                 tabStride, A->d_out + f0, nf, A->d_seg + (size_t)f0 * npx, st));
     }
-    HIPCHK(c, hipMemcpyAsync(A->h_out, A->d_out, (size_t)nframes * sizeof(CapeFrameOut), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(A->h_planes, A->d_planes, (size_t)nframes * CAPE_DEV_MAXP * sizeof(drfe_cape_plane), hipMemcpyDeviceToHost, st));
-    if (seg) HIPCHK(c, hipMemcpyAsync(A->h_seg, A->d_seg, (size_t)nframes * npx, hipMemcpyDeviceToHost, st));
-    {
-        hipEvent_t done = A->stageFree[0];
-        HIPCHK(c, drfe_pool_sync(st, done));                                          /* sleeps between polls: the other pools need the CPUs */
-    }
+    HIPCHK(c, drfe_pool_sync(st, A->kernelsDone));                                   /* sleeps between polls */
+    HIPCHK(c, hipMemcpyAsync(A->h_out, A->d_out, (size_t)nframes * sizeof(CapeFrameOut), hipMemcpyDeviceToHost, cs));
+    HIPCHK(c, hipMemcpyAsync(A->h_planes, A->d_planes, (size_t)nframes * CAPE_DEV_MAXP * sizeof(drfe_cape_plane), hipMemcpyDeviceToHost, cs));
+    if (seg) HIPCHK(c, hipMemcpyAsync(A->h_seg, A->d_seg, (size_t)nframes * npx, hipMemcpyDeviceToHost, cs));
+    HIPCHK(c, drfe_pool_sync(cs, A->kernelsDone));
     for (int f = 0; f < nframes; f++) {
         if (A->h_out[f].status != 0) { hostFrames.push_back(f); continue; }
         const int np = A->h_out[f].nPlanes;

@@ -15,6 +15,8 @@
  * A job whose grid would overflow int32 (PCL returns the input cloud there) or whose sort needs libstdc++'s heap-sort
  * branch reports a negative count: the caller runs that plane on the host. */
 #include "drfe_internal.h"
+#include <cstdlib>
+#include <algorithm>
 #include "post_internal.h"
 #ifdef VOX_PROFILE
 /* phase times summed over workgroups (100 MHz ticks of thread 0): 0 bounds + keys, 1 workgroup partitions, 2 wavefront phase,
@@ -203,7 +205,11 @@ hipError_t drfe_launch_voxel_grid(const float* d_pts, const int2* d_jobs, int nj
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        resident = 3 * (cus > 0 ? cus : 256);               /* 47 KB of LDS each: three per CU */
+        /* 47 KB of LDS each: three per CU fill the device when the plane path runs alone; DRFE_VOXEL_RESIDENT=<per CU> for
+         * experiments in the mix, where those 36 MB of LDS are what the other paths' wavefronts wait for */
+        const char* er = std::getenv("DRFE_VOXEL_RESIDENT");
+        const int perCu = er ? std::max(1, std::min(3, std::atoi(er))) : 3;
+        resident = perCu * (cus > 0 ? cus : 256);
     }
     hipLaunchKernelGGL(k_voxel_jobs_order, dim3(1), dim3(1024), 0, s, d_jobs, njobs, d_list + 2, d_list, d_counts);
     hipLaunchKernelGGL(k_voxel_grid, dim3(njobs < resident ? njobs : resident), dim3(VOX_T), ORD_DYN_LDS_BYTES(VOX_T), s, d_pts, d_jobs, (const int*)(d_list + 2), d_list,
