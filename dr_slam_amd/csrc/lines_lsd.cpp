@@ -82,7 +82,7 @@ public:
     /* the constants nfa() takes from the libm, for the device's rect_improve (lsd_nfa_kernels.hip): log10 / log of the up to
      * eleven precisions p0 / 2^j, and log_gamma at every integer a W x H field can ask for - the host's values, so the
      * device's NFA differs from this class's only where exp / log10 / pow enter */
-    void fillTables(double p0, int W, int H, LsdNfaTables& t, std::vector<double>& lg) const
+    void fillTables(double p0, int W, int H, LsdNfaTables& t, std::vector<double>* lg) const
     {
         t.logNT = logNT_;
         double p = p0;
@@ -90,9 +90,11 @@ public:
             t.p[j] = p; t.logP[j] = std::log(p); t.log1mP[j] = std::log(1.0 - p); t.log10P[j] = std::log10(p);
             p /= 2;
         }
-        lg.resize((size_t)W * H + 2);
-        for (size_t i = 0; i < lg.size(); i++) lg[i] = logGammaInt((int)i);
-        t.lgamma = nullptr; t.lgammaN = (int)lg.size();
+        t.lgamma = nullptr; t.lgammaN = W * H + 2;
+        if (lg) {                                  /* 13 ms of libm calls at 512 x 384: once per arena, not per call */
+            lg->resize((size_t)t.lgammaN);
+            for (size_t i = 0; i < lg->size(); i++) (*lg)[i] = logGammaInt((int)i);
+        }
     }
 private:
     double logNT_;
@@ -642,7 +644,8 @@ static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int f
     }
     if (grow) {
         const size_t nk = (size_t)(s->sw - 1) * (s->sh - 1) * F;
-        s->rectCap = LSD_RECT_CAP;
+        /* accepted regions scale with the field: 4096 at 512 x 384 (~1500 seen), 16384 at 1024 x 768 (~5800 seen on a 1280 x 960 frame) */
+        s->rectCap = std::max(LSD_RECT_CAP, s->sw * s->sh / 48);
         LCHK(hipMalloc((void**)&s->d_order, nk * 4));
         LCHK(hipMalloc((void**)&s->d_reg, ns * 4));
         LCHK(hipMalloc((void**)&s->d_cs0, ns * 8));
@@ -1194,8 +1197,9 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     }
     if (J.deviceNfa) {
         std::vector<double> lg;
-        val.fillTables(J.p, A->sw, A->sh, J.nfaTab, lg);
-        if (A->lgammaN != (int)lg.size()) {          /* once per arena: 1.5 MB at 640 x 480 */
+        const bool need = A->lgammaN != A->sw * A->sh + 2;
+        val.fillTables(J.p, A->sw, A->sh, J.nfaTab, need ? &lg : nullptr);
+        if (need) {                                  /* once per arena: 1.5 MB at 640 x 480 */
             HIPCHK(c, hipMemcpy(A->d_lgamma, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice));
             A->lgammaN = (int)lg.size();
         }

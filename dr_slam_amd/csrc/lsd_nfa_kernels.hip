@@ -322,7 +322,7 @@ hipError_t drfe_launch_rect_improve(const LsdGrowFrame* d_frames, int nframes, i
  * the frame for the host otherwise. */
 namespace {
 
-#define KL_MAX_KEPT 2048           /* kept segments per frame the LDS sort holds (a 640 x 480 frame has ~250) */
+#define KL_MAX_KEPT 6144           /* kept segments per frame the LDS sort holds (a 640 x 480 frame has ~250, a 1280 x 960 one more than 2000) */
 
 struct KlShared {
     float resp[KL_MAX_KEPT];

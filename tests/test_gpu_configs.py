@@ -139,6 +139,19 @@ def test_config5_1280x960_lines_and_cape_planes(oracle_mod):
         assert np.array_equal(gp["seg"], op["seg"])
         assert np.array_equal(gp["planes"]["normal"].view(np.uint64), op["planes"][:, 0:3].view(np.uint64))
         assert np.array_equal(gp["planes"]["d"].view(np.uint64), op["planes"][:, 6].view(np.uint64))
+        # the batch entries at this size (round 4: the whole line detector and CAPE::process on the device - a 1024 x 768 level-line
+        # field, 3072 CAPE cells = the device path's capacity): the frame twice, identical to the single-frame entries above
+        lb = c.lsd_extract_batch(np.stack([g, g]), n_threads=2)
+        for x in lb:
+            assert x["detected"] == a["detected"] and x["lines"].tobytes() == a["lines"].tobytes()
+            assert np.array_equal(x["desc"], a["desc"]) and x["lineF"].tobytes() == a["lineF"].tobytes()
+        st = c.lsd_stats()
+        assert st["frames"] == 2 and st["grow_to_host"] == 0 and st["keylines_to_host"] == 0
+        cp, cn, cs = c.planes_cape_batch(np.stack([dm, dm]), K4, 20, n_threads=2, seg=True)
+        for f in range(2):
+            assert cn[f] == len(op["planes"]) and np.array_equal(cs[f], op["seg"])
+            assert np.array_equal(cp[f, :cn[f]]["normal"].view(np.uint64), op["planes"][:, 0:3].view(np.uint64))
+        assert c.planes_cape_stats()["frames"] == 2
     finally:
         c.close()
 
