@@ -1276,6 +1276,10 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
                      nframes, nChunks, chunk, T, std::chrono::duration<double, std::milli>(tLaunched - tBegin).count(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBegin).count(), J.usSort / 1e3 / nframes,
                      J.usRectDl / 1e3 / nframes, J.usNfa / 1e3 / nframes, J.usCountsWall / 1e3 / nframes, J.usCountsCpu / 1e3 / nframes, J.usKeyl / 1e3 / nframes, J.usFinish / 1e3 / nframes, J.usWait / 1e3 / T, J.handedBack.load());
+    if (std::getenv("DRFE_NFA_PROFILE")) {       /* -DNFA_PROFILE build of k_rect_improve: phase clocks (100 MHz) of block 0 of frame 0, lane 0 */
+        const unsigned long long* pr = (const unsigned long long*)(A->h_out + 24);
+        std::fprintf(stderr, "k_rect_improve block 0 (lane 0): candidate + walk set-up %.3f ms, pixel walk %.3f, nfa %.3f, selection %.3f, all %.3f\n", pr[0] / 1e5, pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[4] / 1e5);
+    }
     if (std::getenv("DRFE_LSD_PROFILE")) {       /* LSD_PROFILE builds of k_lsd_grow: phase times of frame 0 (100 MHz ticks -> ms) and counts */
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
         std::fprintf(stderr, "k_lsd_grow frame 0: total %.2f ms: bitmap %.2f, scan %.2f (%llu chunks), window loads %.2f (%llu groups), window growth %.2f (%llu regions, %llu member visits), "

@@ -9,9 +9,13 @@
  * sides are bit-identical by construction: equal inputs, the closed-form branches), and the frame is flagged for the host's
  * validation (lines_lsd.cpp, RectValidator) otherwise.  The flagged rate is reported (DRFE_TRACE_LINES, bench.py).
  *
- * One wavefront per rectangle.  The up to five candidates of a stage depend on the stage's starting rectangle only, so their
- * pixel loops run side by side - 12 lanes each, a scan line's pixels across the lanes - and their NFAs in five lanes; the
- * choice among them follows the reference's order. */
+ * One LANE per candidate.  A rectangle of a 640 x 480 frame is tested ~17 times, on 24 pixels and 6 tail-loop iterations a time:
+ * far too little for a wavefront (the first version of this kernel gave every rectangle one, a scan line's pixels across 12
+ * lanes per candidate, and spent 2800 cycles per call on set-up, barriers and its one busy lane: 15 ms per 512 frames, a
+ * tenth of the full front-end's SIMD time).  The up to five candidates of a stage depend on the stage's starting rectangle
+ * only, so a wavefront takes TWELVE rectangles: lane 5 r + c builds candidate c of rectangle r (the reference's cumulative
+ * modifications, replayed), walks its scan lines, counts, and evaluates nfa(); lane 5 r then makes rectangle r's choice among
+ * them in the reference's order.  The twelve advance stage by stage, each at its own stage. */
 #include <hip/hip_runtime.h>
 
 #include "lines_internal.h"
@@ -20,7 +24,6 @@
 
 namespace {
 
-#define NFA_GROUP 12                      /* lanes per candidate: 5 x 12 = 60 of the 64 */
 #define NFA_MAX_CAND 5
 
 struct NfaVal { double v, e; int n, k, pj; int unc; };   /* value, bound on |host - device|, its inputs, 1 = a branch inside could not be certified */
@@ -101,14 +104,15 @@ struct Hyp {
 #define NFA_MAXQ 12                        /* hypotheses per rectangle (queued + explored) */
 #define NFA_MAXLIVE 6                      /* hypotheses alive inside one stage's selection */
 
-struct ImproveShared {
+#define NFA_RECTS 12                       /* rectangles per wavefront: 12 x 5 candidate lanes */
+struct ImproveShared {                     /* one rectangle's slot */
     RectCand cand[NFA_MAX_CAND];
-    int pj[NFA_MAX_CAND];
-    int total[64], alg[64];
+    int pj[NFA_MAX_CAND], ok[NFA_MAX_CAND];
     NfaVal val[NFA_MAX_CAND];
     Hyp q[NFA_MAXQ];                       /* q[qi] = the hypothesis being explored; entries behind it wait */
     Hyp live[NFA_MAXLIVE];
-    int nq, finished, nOut, outKeep, flag, why;
+    double dx, dy, theta;
+    int nq, qi, stage, active, id, finished, nOut, outKeep, flag, why;
     float outSeg[4];
 };
 
@@ -198,113 +202,175 @@ __device__ void improve_select(ImproveShared& S, int qi, int stage, int nc, cons
 
 } // namespace
 
-/* One wavefront per rectangle; blockIdx.y = frame of the launch, blockIdx.x strides over the frame's rectangles. */
+/* (pixels, aligned pixels) of one rectangle by ONE lane: rect_nfa's pixel loop as rect_walk_count walks it, without the lanes */
+__device__ __forceinline__ int2 rect_walk_count_lane(const RectCand& rc, const RectWalk& w, const double* __restrict__ ang, int W, int H)
+{
+    const double kNotDef = -1024.0, kTwoPi = 2.0 * 3.14159265358979323846, kThreeHalfPi = 3.0 * 3.14159265358979323846 / 2.0;
+    double lstep = w.fl, rstep = w.fr, lx = (double)w.loX, rx = (double)w.loX;
+    int total = 0, alg = 0;
+    const int yBeg = max(w.loY, 0), yEnd = min(w.hiY, H - 1);
+    /* A lane's walk is otherwise one L2 round trip per pixel: the first four pixels of TWO scan lines are fetched together (the
+     * loads depend on the edge walk only, not on the counts), counted without branches; what a scan line holds beyond four
+     * pixels follows four at a time. */
+    auto count4 = [&](const double* row, int x, int xe) {
+        double a[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = x + u <= xe ? row[x + u] : kNotDef;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double d = rc.theta - a[u];
+            if (d < 0) d = -d;
+            if (d > kThreeHalfPi) { d -= kTwoPi; if (d < 0) d = -d; }
+            total += x + u <= xe ? 1 : 0;
+            alg += (a[u] != kNotDef && d <= rc.prec) ? 1 : 0;
+        }
+    };
+    for (int y = yBeg; y <= yEnd; y += 2) {
+        const int xs0 = max((int)lx, 0), xe0 = min((int)rx, W - 1);
+        if (y >= w.leftY) lstep = w.sl;
+        if (y >= w.rightY) rstep = w.sr;
+        lx += lstep;
+        rx += rstep;
+        const bool two = y + 1 <= yEnd;
+        int xs1 = 0, xe1 = -1;
+        if (two) {
+            xs1 = max((int)lx, 0); xe1 = min((int)rx, W - 1);
+            if (y + 1 >= w.leftY) lstep = w.sl;
+            if (y + 1 >= w.rightY) rstep = w.sr;
+            lx += lstep;
+            rx += rstep;
+        }
+        const double* row0 = ang + (size_t)y * W;
+        const double* row1 = ang + (size_t)(two ? y + 1 : y) * W;
+        double a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a0[u] = xs0 + u <= xe0 ? row0[xs0 + u] : kNotDef; a1[u] = xs1 + u <= xe1 ? row1[xs1 + u] : kNotDef; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double d = rc.theta - a0[u];
+            if (d < 0) d = -d;
+            if (d > kThreeHalfPi) { d -= kTwoPi; if (d < 0) d = -d; }
+            total += xs0 + u <= xe0 ? 1 : 0;
+            alg += (a0[u] != kNotDef && d <= rc.prec) ? 1 : 0;
+            double e = rc.theta - a1[u];
+            if (e < 0) e = -e;
+            if (e > kThreeHalfPi) { e -= kTwoPi; if (e < 0) e = -e; }
+            total += xs1 + u <= xe1 ? 1 : 0;
+            alg += (a1[u] != kNotDef && e <= rc.prec) ? 1 : 0;
+        }
+        for (int x = xs0 + 4; x <= xe0; x += 4) count4(row0, x, xe0);
+        for (int x = xs1 + 4; x <= xe1; x += 4) count4(row1, x, xe1);
+    }
+    return make_int2(total, alg);
+}
+
+/* blockIdx.y = frame of the launch, blockIdx.x strides over the frame's rectangles in groups of NFA_RECTS */
 __global__ __launch_bounds__(64) void k_rect_improve(const LsdGrowFrame* __restrict__ frames, int W, int H, int rectMode, LsdNfaTables T,
                                                      int rectCap, LsdSegOut* __restrict__ segs)
 {
-    __shared__ ImproveShared S;
+    __shared__ ImproveShared SS[NFA_RECTS];
     const LsdGrowFrame F = frames[blockIdx.y];
-    const int lane = threadIdx.x, g = lane / NFA_GROUP, gl = lane - g * NFA_GROUP;
+    const int lane = threadIdx.x, r = lane / NFA_MAX_CAND, c = lane - r * NFA_MAX_CAND;
+    const bool candLane = lane < NFA_RECTS * NFA_MAX_CAND, selLane = candLane && c == 0;
     if (F.out[1] != 0) return;                      /* the growth already hands this frame to the host */
     const int count = min(F.out[0], rectCap);
     LsdSegOut* out = segs + (size_t)blockIdx.y * rectCap;
     const double delta = 0.5, d2 = delta / 2.0;
-    for (int id = blockIdx.x; id < count; id += gridDim.x) {
-        const LsdRect rec0 = F.rects[id];
-        if (lane == 0) {
-            Hyp h;
-            h.x1 = rec0.x1; h.y1 = rec0.y1; h.x2 = rec0.x2; h.y2 = rec0.y2; h.width = rec0.width; h.prec = rec0.prec;
-            h.best.v = 0; h.best.e = 0; h.best.n = h.best.k = h.best.pj = -1; h.best.unc = 0;
-            h.pj = 0; h.stage = 0;
-            S.q[0] = h; S.nq = 1; S.nOut = 0; S.outKeep = 0; S.flag = 0; S.why = 0;
+#ifdef NFA_PROFILE
+    unsigned long long tp[5] = {0, 0, 0, 0, 0};
+#define NTP(k, t0) tp[k] += wall_clock64() - (t0)
+#else
+#define NTP(k, t0) (void)(t0)
+#endif
+    for (int base = blockIdx.x * NFA_RECTS; base < count; base += gridDim.x * NFA_RECTS) {
+        if (selLane) {
+            ImproveShared& S = SS[r];
+            const int id = base + r;
+            S.id = id; S.active = id < count ? 1 : 0;
+            if (S.active) {
+                const LsdRect rec0 = F.rects[id];
+                Hyp h;
+                h.x1 = rec0.x1; h.y1 = rec0.y1; h.x2 = rec0.x2; h.y2 = rec0.y2; h.width = rec0.width; h.prec = rec0.prec;
+                h.best.v = 0; h.best.e = 0; h.best.n = h.best.k = h.best.pj = -1; h.best.unc = 0;
+                h.pj = 0; h.stage = 0;
+                S.q[0] = h; S.nq = 1; S.qi = 0; S.stage = 0; S.nOut = 0; S.outKeep = 0; S.flag = 0; S.why = 0;
+                S.dx = rec0.dx; S.dy = rec0.dy; S.theta = rec0.theta;
+                for (int k = 0; k < 4; k++) S.outSeg[k] = 0.f;
+            }
         }
         __syncthreads();
-        for (int qi = 0; qi < S.nq; qi++) {
-            bool finished = false;
-            for (int stage = S.q[qi].stage; stage < 6 && !finished; stage++) {
-                /* the candidates of this stage: rect_improve's cumulative modifications of a copy of the hypothesis' rectangle */
-                int nc = 0;
-                if (lane == 0) {
-                    const Hyp h = S.q[qi];
-                    double x1 = h.x1, y1 = h.y1, x2 = h.x2, y2 = h.y2, width = h.width, prec = h.prec, p = T.p[h.pj];
-                    int pj = h.pj;
-                    if (stage == 0) { S.cand[0] = RectCand{x1, y1, x2, y2, width, rec0.dx, rec0.dy, rec0.theta, prec}; S.pj[0] = pj; nc = 1; }
-                    else
-                        for (int n = 0; n < 5; ++n) {
-                            if (stage == 1) { p /= 2; prec = p * 3.14159265358979323846; ++pj; }
-                            else {
-                                if (!((width - delta) >= 0.5)) continue;        /* guards the last precision stage too */
-                                if (stage == 5) { p /= 2; prec = p * 3.14159265358979323846; ++pj; }
-                                else if (stage == 2) width -= delta;
-                                else if (stage == 3) { x1 += -rec0.dy * d2; y1 += rec0.dx * d2; x2 += -rec0.dy * d2; y2 += rec0.dx * d2; width -= delta; }
-                                else { x1 -= -rec0.dy * d2; y1 -= rec0.dx * d2; x2 -= -rec0.dy * d2; y2 -= rec0.dx * d2; width -= delta; }
-                            }
-                            S.cand[nc] = RectCand{x1, y1, x2, y2, width, rec0.dx, rec0.dy, rec0.theta, prec};
-                            S.pj[nc] = pj;
-                            ++nc;
+        while (__ballot(candLane && SS[candLane ? r : 0].active != 0)) {
+            /* candidate c of this stage of rectangle r: rect_improve's cumulative modifications of a copy of the hypothesis'
+             * rectangle, each behind its guard (a guard that fails once fails for the rest of the stage) */
+            const unsigned long long t0 = wall_clock64();
+            if (candLane && SS[r].active) {
+                ImproveShared& S = SS[r];
+                const Hyp h = S.q[S.qi];
+                const int stage = S.stage;
+                double x1 = h.x1, y1 = h.y1, x2 = h.x2, y2 = h.y2, width = h.width, prec = h.prec, p = T.p[h.pj];
+                int pj = h.pj;
+                bool ok = stage == 0 ? c == 0 : true;
+                if (stage != 0)
+                    for (int m = 0; m <= c && ok; ++m) {
+                        if (stage == 1) { p /= 2; prec = p * 3.14159265358979323846; ++pj; }
+                        else {
+                            if (!((width - delta) >= 0.5)) { ok = false; break; }        /* guards the last precision stage too */
+                            if (stage == 5) { p /= 2; prec = p * 3.14159265358979323846; ++pj; }
+                            else if (stage == 2) width -= delta;
+                            else if (stage == 3) { x1 += -S.dy * d2; y1 += S.dx * d2; x2 += -S.dy * d2; y2 += S.dx * d2; width -= delta; }
+                            else { x1 -= -S.dy * d2; y1 -= S.dx * d2; x2 -= -S.dy * d2; y2 -= S.dx * d2; width -= delta; }
                         }
-                }
-                nc = __shfl(nc, 0);
-                __syncthreads();
-                /* pixel loops: candidate g on lanes [12 g, 12 g + 12).  (A stage without candidates - the width guard - still
-                 * runs its exit test below: after the last stage that is the segment's verdict.) */
-                int total = 0, alg = 0;
-                if (g < nc) {
-                    const RectCand rc = S.cand[g];
-                    const RectWalk w = rect_walk_setup(rc, rectMode);
-                    const double kNotDef = -1024.0, kTwoPi = 2.0 * 3.14159265358979323846, kThreeHalfPi = 3.0 * 3.14159265358979323846 / 2.0;
-                    double lstep = w.fl, rstep = w.fr, lx = (double)w.loX, rx = (double)w.loX;
-                    const int yBeg = max(w.loY, 0), yEnd = min(w.hiY, H - 1);
-                    for (int y = yBeg; y <= yEnd; ++y) {
-                        const int xs = max((int)lx, 0), xe = min((int)rx, W - 1);
-                        const double* row = F.ang + (size_t)y * W;
-                        for (int x = xs + gl; x <= xe; x += NFA_GROUP) {
-                            ++total;
-                            const double a = row[x];
-                            if (a != kNotDef) {
-                                double d = rc.theta - a;
-                                if (d < 0) d = -d;
-                                if (d > kThreeHalfPi) { d -= kTwoPi; if (d < 0) d = -d; }
-                                if (d <= rc.prec) ++alg;
-                            }
-                        }
-                        if (y >= w.leftY) lstep = w.sl;
-                        if (y >= w.rightY) rstep = w.sr;
-                        lx += lstep;
-                        rx += rstep;
                     }
+                S.ok[c] = ok ? 1 : 0;
+                if (ok) {
+                    const RectCand rc = RectCand{x1, y1, x2, y2, width, S.dx, S.dy, S.theta, prec};
+                    const RectWalk w = rect_walk_setup(rc, rectMode);
+                    NTP(0, t0);
+                    const unsigned long long t1 = wall_clock64();
+                    const int2 cnt = rect_walk_count_lane(rc, w, F.ang, W, H);
+                    NTP(1, t1);
+                    const unsigned long long t2 = wall_clock64();
+                    S.cand[c] = rc; S.pj[c] = pj;
+                    S.val[c] = nfa_device(cnt.x, cnt.y, pj, T);
+                    NTP(2, t2);
                 }
-                S.total[lane] = total; S.alg[lane] = alg;
-                __syncthreads();
-                if (lane < nc) {
-                    int t = 0, a = 0;
-                    for (int q = 0; q < NFA_GROUP; q++) { t += S.total[lane * NFA_GROUP + q]; a += S.alg[lane * NFA_GROUP + q]; }
-                    S.val[lane] = nfa_device(t, a, S.pj[lane], T);
-                }
-                __syncthreads();
-                if (lane == 0) improve_select(S, qi, stage, nc, T);
-                __syncthreads();
-                finished = S.finished != 0;
             }
             __syncthreads();
-        }
-        if (lane == 0) {
-            LsdSegOut o;
-            o.x1 = S.outSeg[0]; o.y1 = S.outSeg[1]; o.x2 = S.outSeg[2]; o.y2 = S.outSeg[3];
-            o.flag = S.outKeep;
-            out[id] = o;
-            if (S.flag || S.nOut == 0) { atomicOr(&F.out[2], 1); atomicOr(&F.out[3], S.why ? S.why : 32); }      /* out[3]: why (DRFE_TRACE_LINES) */
+            const unsigned long long t3 = wall_clock64();
+            /* rectangle r's choice among them and the stage's exit test; then its next stage, its next hypothesis, or its result */
+            if (selLane && SS[r].active) {
+                ImproveShared& S = SS[r];
+                int nc = 0;
+                while (nc < NFA_MAX_CAND && S.ok[nc]) nc++;
+                improve_select(S, S.qi, S.stage, nc, T);
+                if (!S.finished) S.stage = S.stage + 1;
+                else if (S.qi + 1 < S.nq) { S.qi = S.qi + 1; S.stage = S.q[S.qi].stage; }
+                else {
+                    S.active = 0;
+                    LsdSegOut o;
+                    o.x1 = S.outSeg[0]; o.y1 = S.outSeg[1]; o.x2 = S.outSeg[2]; o.y2 = S.outSeg[3];
+                    o.flag = S.outKeep;
+                    out[S.id] = o;
+                    if (S.flag || S.nOut == 0) { atomicOr(&F.out[2], 1); atomicOr(&F.out[3], S.why ? S.why : 32); }      /* out[3]: why (DRFE_TRACE_LINES) */
+                }
+            }
+            __syncthreads();
+            NTP(3, t3);
+            NTP(4, t0);
         }
         __syncthreads();
     }
+#ifdef NFA_PROFILE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) for (int k = 0; k < 5; k++) ((unsigned long long*)(F.out + 24))[k] = tp[k];
+#endif
 }
 
 hipError_t drfe_launch_rect_improve(const LsdGrowFrame* d_frames, int nframes, int W, int H, int rectMode, const LsdNfaTables& tab,
                                     int rectCap, LsdSegOut* d_segs, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
-    /* 192 wavefronts per frame stride over its rectangles (a 640 x 480 frame has ~1500; each takes tens of microseconds) */
-    hipLaunchKernelGGL(k_rect_improve, dim3(192, nframes), dim3(64), 0, s, d_frames, W, H, rectMode, tab, rectCap, d_segs);
+    /* 128 wavefronts per frame, twelve rectangles each per pass (a 640 x 480 frame has ~1500 rectangles) */
+    hipLaunchKernelGGL(k_rect_improve, dim3(128, nframes), dim3(64), 0, s, d_frames, W, H, rectMode, tab, rectCap, d_segs);
     return hipGetLastError();
 }
 
