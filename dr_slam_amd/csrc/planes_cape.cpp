@@ -475,9 +475,10 @@ int drfe_planes_cape(drfe_ctx* c, const float* depth_m, int w, int h, size_t str
                             cells_mst, cells_pn);
 }
 
-/* PlaneDetection_CAPE for nframes depth images (metres, frame_stride floats apart) on a pool of n_threads host threads, one
- * device lane (stream + scratch) each: planes[f * cap ..], n_planes[f], seg[f * w * h ..] (may be NULL: the label images
- * are then not returned).  Results are identical to nframes calls of drfe_planes_cape.  n_threads <= 0: up to 4. */
+/* PlaneDetection_CAPE for nframes depth images (metres, frame_stride floats apart): planes[f * cap ..], n_planes[f],
+ * seg[f * w * h ..] (may be NULL: the label images are then not returned).  Default: the device path above; the pool of
+ * n_threads host threads (one device lane - stream + scratch - each) takes the frames the device hands back, or all of them
+ * in the host mode.  Results are identical to nframes calls of drfe_planes_cape.  n_threads <= 0: up to 4. */
 int drfe_planes_cape_batch(drfe_ctx* c, const float* depth_m, size_t frame_stride, int w, int h, size_t stride, int nframes,
                            const float* K4, int patch, float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap,
                            int* n_planes, uint8_t* seg, int n_threads)

@@ -328,10 +328,13 @@ int drfe_lsd_extract(drfe_ctx* ctx, const uint8_t* gray, int w, int h, size_t st
  * floats (x1, y1, x2, y2 in input-image coordinates).  Host code: CPU tests and profiling. */
 int drfe_lsd_segments_host(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad, float* segs,
                            int cap, int* n_segs);
-/* The same for nframes host images (gray + f * frame_stride).  Default (drfe_lsd_configure(ctx, 1)): the detector's
- * sequential core - seed loop, region_grow, region2rect, refine - runs on the DEVICE, one wavefront per frame executing the
- * reference's order of operations (lsd_grow_kernels.hip), frames in flight side by side; the host keeps std::sort's
- * permutation of the pixel ordering and the NFA arithmetic (libm) and runs them on a pool of n_threads host threads.
+/* The same for nframes host images (gray + f * frame_stride).  Default: the whole extractor runs on the DEVICE, frames side by
+ * side - the image passes, std::sort's permutation of the pixel ordering (k_lsd_order), the seed loop with region_grow /
+ * region2rect / refine (k_lsd_grow: one wavefront per frame executing the reference's order of operations), rect_improve with
+ * its NFA decisions certified against the host libm's values (k_rect_improve, drfe_lsd_configure_nfa), the key lines, the
+ * response cut's std::sort, the line equations (k_lsd_keylines) and the LBD descriptors (k_lbd); n_threads host threads upload,
+ * launch and copy the results out (two are plenty), and finish on the host the rare frame a device stage hands back (an
+ * uncertified rounding or comparison, a capacity: drfe_lsd_stats counts them).
  * drfe_lsd_configure(ctx, 0): every frame through drfe_lsd_extract's host path on the pool, one device lane per thread
  * (frames instead of the reference's four extractors across threads, src/Frame.cc:116-126).  Outputs per frame f at
  * lines[f * cap], ldesc[f * cap * 32], line_f[f * cap * 3], n_lines[f], n_detected[f]; results are identical to nframes
@@ -672,9 +675,11 @@ typedef struct drfe_cape_plane {
 int drfe_planes_cape(drfe_ctx* ctx, const float* depth_m, int w, int h, size_t stride, const float* K4, int patch,
                      float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap, int* n_planes,
                      uint8_t* seg, double* cells16, float* cells_mst, int32_t* cells_pn);
-/* The same for nframes depth images (metres; frame f at depth_m + f * frame_stride floats) on a pool of n_threads host threads, one
- * device lane each: planes[f * cap ..], n_planes[f], seg[f * w * h ..] (seg may be NULL).  Identical to nframes calls of
- * drfe_planes_cape.  n_threads <= 0: up to 4. */
+/* The same for nframes depth images (metres; frame f at depth_m + f * frame_stride floats): planes[f * cap ..], n_planes[f],
+ * seg[f * w * h ..] (seg may be NULL).  Default (drfe_planes_configure_cape(ctx, 1), nframes > 1): end to end on the device -
+ * cell fits, CAPE::process (one wavefront per frame), per-pixel refinement - from the calling thread, which uploads the frames
+ * through two pinned staging buffers and copies the results out; n_threads host threads (one device lane each) only for frames
+ * the device hands back and in the host mode.  Identical to nframes calls of drfe_planes_cape.  n_threads <= 0: up to 4. */
 int drfe_planes_cape_batch(drfe_ctx* ctx, const float* depth_m, size_t frame_stride, int w, int h, size_t stride, int nframes,
                            const float* K4, int patch, float cos_angle_max, float max_merge_dist, drfe_cape_plane* planes, int cap,
                            int* n_planes, uint8_t* seg, int n_threads);
