@@ -400,6 +400,10 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
     depth_m = depth.astype(np.float32) * np.float32(inv)
+    # the host images the batch entries upload live in PINNED memory, as a capture pipeline's ring buffers would: a copy from
+    # pageable memory is staged by a runtime thread first (1.1 GB per step here: 0.2-0.3 ms of CPU per frame that is not the
+    # front-end's)
+    gray, depth, depth_m = (torch.from_numpy(a).pin_memory().numpy() for a in (gray, depth, depth_m))
     gray_t = torch.from_numpy(gray).cuda()
     depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
     inflight = max(1, int(os.environ.get("DRFE_FF_INFLIGHT", inflight)))

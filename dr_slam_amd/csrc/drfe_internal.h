@@ -206,6 +206,19 @@ static inline hipError_t drfe_pool_sync(hipStream_t s, hipEvent_t ev)
     }
 }
 
+/* 1 if [p, p + bytes) is pinned (hipHostMalloc / hipHostRegister) host memory: the batch entries then upload straight from the
+ * caller's buffer instead of copying it into their own pinned staging first */
+static inline bool drfe_host_is_pinned(const void* p, size_t bytes)
+{
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost) return false;
+    hipPointerAttribute_t b;
+    const char* last = static_cast<const char*>(p) + (bytes ? bytes - 1 : 0);
+    if (hipPointerGetAttributes(&b, last) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return b.type == hipMemoryTypeHost;
+}
+
 /* Stage brackets of the headline path: HIP events on the launch stream when drfe_profile_enable is on (drfe_profile_stage_ms),
  * and a roctx range around the stage's launches always (a rocprofv3 --marker-trace / --kernel-trace run shows
  * "drfe:pyramid", "drfe:fast" ... around the kernels instead of bare kernel names; without a tool attached roctx is a no-op). */

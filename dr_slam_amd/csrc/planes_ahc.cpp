@@ -1072,11 +1072,14 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
     for (int ch = 0; ch < J.nChunks && launchRc == DRFE_OK; ch++) {
         const int f0 = ch * J.chunk, nf = std::min(J.chunk, nframes - f0);
         hipStream_t st = J.chunkStream[ch];
-        for (int f = f0; f < f0 + nf; f++)
-            for (int y = 0; y < h; y++) std::memcpy(A->h_depth + px * f + (size_t)y * w, depth + (size_t)f * frame_stride + (size_t)y * stride, (size_t)w * 2);
+        /* pinned, dense caller frames are uploaded where they lie; anything else through the arena's pinned mirror */
+        const bool direct = stride == (size_t)w && frame_stride == px && drfe_host_is_pinned(depth + px * f0, px * 2 * nf);
+        if (!direct)
+            for (int f = f0; f < f0 + nf; f++)
+                for (int y = 0; y < h; y++) std::memcpy(A->h_depth + px * f + (size_t)y * w, depth + (size_t)f * frame_stride + (size_t)y * stride, (size_t)w * 2);
         const bool tr = traceStages && ch == 0;
         if (tr) (void)hipEventRecord(stageEv[0], st);
-        hipError_t e = hipMemcpyAsync(A->d_depth + px * f0, A->h_depth + px * f0, px * 2 * nf, hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(A->d_depth + px * f0, direct ? depth + px * f0 : A->h_depth + px * f0, px * 2 * nf, hipMemcpyHostToDevice, st);
         if (tr) (void)hipEventRecord(stageEv[1], st);
         if (e == hipSuccess) e = drfe_launch_ahc_blocks(A->d_depth + px * f0, px, (size_t)w, w, h, K4, depth_factor, nf, A->d_blocks + (size_t)NB * f0, st);
         if (tr) (void)hipEventRecord(stageEv[2], st);

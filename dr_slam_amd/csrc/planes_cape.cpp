@@ -410,17 +410,23 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
      * transfers (this path's 512 frames took 500 ms instead of 25, the line path's upload 317 ms instead of 15).  Uploads go to
      * their own stream and depend on nothing but their staging buffer; the kernels wait for them through an event; the results
      * are fetched after the last kernel has finished. */
+    const bool direct = stride == (size_t)w && frame_stride == npx && drfe_host_is_pinned(depth_m, (size_t)nframes * npx * sizeof(float));
     int chunkNo = 0;
     for (int f0 = 0; f0 < nframes; f0 += CAPE_STAGE_FRAMES, chunkNo++) {
         const int nf = std::min(CAPE_STAGE_FRAMES, nframes - f0), b = chunkNo & 1;
-        if (chunkNo >= 2) HIPCHK(c, drfe_event_wait_sleeping(A->stageFree[b]));      /* the upload that last read this staging buffer is done */
-        float* hs = A->h_stage[b];
-        for (int k = 0; k < nf; k++) {
-            const float* src = depth_m + (size_t)(f0 + k) * frame_stride;
-            if (stride == (size_t)w) std::memcpy(hs + (size_t)k * npx, src, npx * sizeof(float));
-            else for (int y = 0; y < h; y++) std::memcpy(hs + (size_t)k * npx + (size_t)y * w, src + (size_t)y * stride, (size_t)w * 4);
+        if (direct) {
+            /* the caller's frames are pinned and dense: the DMA engine reads them where they lie */
+            HIPCHK(c, hipMemcpyAsync(A->d_depth + (size_t)f0 * npx, depth_m + (size_t)f0 * frame_stride, (size_t)nf * npx * sizeof(float), hipMemcpyHostToDevice, cs));
+        } else {
+            if (chunkNo >= 2) HIPCHK(c, drfe_event_wait_sleeping(A->stageFree[b]));      /* the upload that last read this staging buffer is done */
+            float* hs = A->h_stage[b];
+            for (int k = 0; k < nf; k++) {
+                const float* src = depth_m + (size_t)(f0 + k) * frame_stride;
+                if (stride == (size_t)w) std::memcpy(hs + (size_t)k * npx, src, npx * sizeof(float));
+                else for (int y = 0; y < h; y++) std::memcpy(hs + (size_t)k * npx + (size_t)y * w, src + (size_t)y * stride, (size_t)w * 4);
+            }
+            HIPCHK(c, hipMemcpyAsync(A->d_depth + (size_t)f0 * npx, hs, (size_t)nf * npx * sizeof(float), hipMemcpyHostToDevice, cs));
         }
-        HIPCHK(c, hipMemcpyAsync(A->d_depth + (size_t)f0 * npx, hs, (size_t)nf * npx * sizeof(float), hipMemcpyHostToDevice, cs));
         HIPCHK(c, hipEventRecord(A->stageFree[b], cs));
         HIPCHK(c, hipStreamWaitEvent(st, A->stageFree[b], 0));
         HIPCHK(c, drfe_launch_cape_cells_batch(A->d_depth + (size_t)f0 * npx, npx, (size_t)w, w, h, K4, patch, sinCos, max_merge_dist, nf,
