@@ -13,7 +13,12 @@
  *     still in order, and the K swaps are independent;
  *   - the final insertion sort moves a record left past records it goes before only - it is the stable sort of what the
  *     partitions left: stable counting passes over five key bits each.
- * A range that exhausts the depth limit (heap sort in libstdc++) sets bit 0 of the returned status: the caller sorts on the host. */
+ *   - a range that exhausts the depth limit is heap-sorted the way libstdc++ does it (std::__partial_sort(first, last, last) =
+ *     std::__make_heap + std::__sort_heap, every __adjust_heap / __push_heap move in its order) by ONE lane: the moves of a heap
+ *     sort are one dependent chain.  On the data this serves such ranges are a few dozen records (25 on the synthetic planes
+ *     that reach the branch: depth 2 lg n is only exhausted far down the recursion); ranges above ORD_HEAP_MAX records - never
+ *     seen - set bit 0 of the returned status instead and the caller sorts on the host, so that one lane never holds a CU for
+ *     seconds. */
 #ifndef DRFE_INTROSORT_DEVICE_H
 #define DRFE_INTROSORT_DEVICE_H
 #include <hip/hip_runtime.h>
@@ -26,6 +31,7 @@
 #define ORD_QCAP 1024            /* pending ranges an array can hold (LDS) */
 #define ORD_STACK 48             /* depth-first stack of a wavefront (>= the depth limit 2 lg n of any array that fits) */
 #define ORD_DYN_LDS_BYTES(NTH) (32 * (NTH) * 4)
+#define ORD_HEAP_MAX 1024        /* longest range one lane heap-sorts (about 20 000 dependent moves) */
 
 /* phase marks of a profiling build: the includer defines ISD_TP(k) (k = 0: workgroup partitions done, 1: wavefront phase done,
  * 2: counting passes done) */
@@ -63,6 +69,52 @@ __device__ __forceinline__ void median_to_first(RecPtr a, uint32_t result, uint3
     const typename T::Rec t = a[result];
     a[result] = a[pick];
     a[pick] = t;
+}
+
+/* std::__adjust_heap(a + first, hole, len, value, before) of bits/stl_heap.h followed by its std::__push_heap, by one thread */
+template <class T, class RecPtr>
+__device__ __forceinline__ void adjust_heap(RecPtr a, uint32_t first, int hole, int len, typename T::Rec value)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (T::key(a[first + child]) < T::key(a[first + child - 1])) child--;
+        a[first + hole] = a[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[first + hole] = a[first + child - 1];
+        hole = child - 1;
+    }
+    const uint32_t kv = T::key(value);
+    int parent = (hole - 1) / 2;
+    while (hole > top && T::key(a[first + parent]) < kv) {
+        a[first + hole] = a[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[first + hole] = value;
+}
+
+/* std::__partial_sort(a + first, a + last, a + last, before): __heap_select with middle == last is __make_heap alone, then
+ * __sort_heap.  One thread. */
+template <class T, class RecPtr>
+__device__ __forceinline__ void heap_sort_range(RecPtr a, uint32_t first, uint32_t last)
+{
+    const int len = (int)(last - first);
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2;; parent--) {
+        const typename T::Rec v = a[first + parent];
+        adjust_heap<T>(a, first, parent, len, v);
+        if (parent == 0) break;
+    }
+    for (int end = len - 1; end >= 1; end--) {                 /* __pop_heap(first, end, end) */
+        const typename T::Rec v = a[first + end];
+        a[first + end] = a[first];
+        adjust_heap<T>(a, first, 0, end, v);
+    }
 }
 
 /* std::__unguarded_partition(a + first + 1, a + last, a + first) by a group of NT threads (64: one wavefront; NTH: the
@@ -160,7 +212,7 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
 
 /* a[0..n) into std::sort's order (the NTH threads of the workgroup call this together).  posL / posR: n uint32 each; tmp: n records
  * (ping-pong buffer of the counting passes); dyn: ORD_DYN_LDS_BYTES(NTH) of LDS; keyBits: significant bits of the keys present.
- * Returns (to every thread) 0, or bit 0 = heap sort needed, bit 1 = internal queue overflow or a loop bound exceeded (bits 2-4: which):
+ * Returns (to every thread) 0, or bit 0 = a range above ORD_HEAP_MAX records needs heap sort, bit 1 = internal queue overflow or a loop bound exceeded (bits 2-4: which):
  * result unusable. */
 template <int NTH, class T>
 __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, uint32_t* posR, typename T::Rec* tmp, uint32_t* dyn, Shared<NTH>& sh,
@@ -198,7 +250,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
          * `continue` here a workgroup stopped for good the first time a range above ORD_BIG ran out of depth - a 10 270-record
          * range of a 12 905-point plane cloud, found by a parity soak; ranges that run out of depth in the wavefront phase, the
          * common case, were never affected.) */
-        if (s.depth == 0) { if (tid == 0) sh.heapNeeded = 1; }
+        if (s.depth == 0) { if (tid == 0) sh.heapNeeded = 1; }            /* above ORD_BIG > ORD_HEAP_MAX records: the host's */
         else {
             if (tid == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
             __syncthreads();
@@ -234,8 +286,15 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
             /* std::__introsort_loop on s */
             while (s.last - s.first > 16) {
                 if (++waveIter > waveMax) { if (lane == 0) sh.qOverflow |= 8; runaway = true; break; }
-                if (s.depth == 0) { if (lane == 0) sh.heapNeeded = 1; break; }
                 const uint32_t m = s.last - s.first;
+                if (s.depth == 0) {
+                    if (m > ORD_HEAP_MAX) { if (lane == 0) sh.heapNeeded = 1; }
+                    else {
+                        if (lane == 0) heap_sort_range<T>(a, s.first, s.last);
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    }
+                    break;
+                }
                 if (m <= LCAP) {
                     for (uint32_t i = lane; i < m; i += 64) lrec[i] = a[s.first + i];
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -244,7 +303,11 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                     for (; !runaway;) {
                         while (t.last - t.first > 16) {
                             if (++waveIter > waveMax) { if (lane == 0) sh.qOverflow |= 16; runaway = true; break; }
-                            if (t.depth == 0) { if (lane == 0) sh.heapNeeded = 1; break; }
+                            if (t.depth == 0) {
+                                if (lane == 0) heap_sort_range<T>(lrec, t.first, t.last);
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                break;
+                            }
                             t.depth--;
                             if (lane == 0) median_to_first<T>(lrec, t.first, t.first + 1, t.first + (t.last - t.first) / 2, t.last - 1);
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

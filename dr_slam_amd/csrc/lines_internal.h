@@ -99,7 +99,7 @@ hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W,
  * (lsd_order_kernels.hip).  d_posL / d_posR: scratch of >= n entries per frame, posStride apart.  d_status[f * statusStride]:
  * 0, or 1 = a range ran out of introsort's depth limit (heap sort in libstdc++), 2 = internal queue overflow: order on the host. */
 hipError_t drfe_launch_lsd_order(uint32_t* d_keys, size_t keyStride, int n, uint32_t* d_posL, uint32_t* d_posR, size_t posStride,
-                                 int* d_status, int statusStride, int nframes, hipStream_t s);
+                                 int* d_status, int statusStride, int nframes, hipStream_t s, int depthOverride = -1);
 hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W, int H, double prec, double p, int minReg,
                                 double densityTh, int rectCap, hipStream_t s);
 

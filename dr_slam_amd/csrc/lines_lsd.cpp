@@ -1444,8 +1444,11 @@ int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, con
 
 /* Test hook of lsd_order_kernels.hip: n LSD ordering keys (bin << 22 | y << 11 | x) sorted in place by k_lsd_order on the
  * device, to be compared with std::sort under compare_norm (drfe_debug_order_sort, mode 0).  *status = the kernel's status word
- * (0: done; 1: a range ran out of the depth limit, the heap-sort branch the device does not take). */
-int drfe_debug_device_order_sort(drfe_ctx* c, uint32_t* keys, size_t n, int* status)
+ * (0: done; 1: a range above 1024 keys ran out of the depth limit: heap sort of that length is the host's).  depth_limit >= 0
+ * replaces introsort's 2 lg n, so that tests reach libstdc++'s heap-sort branch (std::__partial_sort) on ordinary data. */
+int drfe_debug_device_order_sort(drfe_ctx* c, uint32_t* keys, size_t n, int* status) { return drfe_debug_device_order_sort_depth(c, keys, n, -1, status); }
+
+int drfe_debug_device_order_sort_depth(drfe_ctx* c, uint32_t* keys, size_t n, int depth_limit, int* status)
 {
     if (!c || !keys || !status || n < 1 || n > (1u << 22)) { if (c) c->err = "debug_device_order_sort: invalid argument"; return DRFE_ERR_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
@@ -1456,7 +1459,7 @@ int drfe_debug_device_order_sort(drfe_ctx* c, uint32_t* keys, size_t n, int* sta
     if (e == hipSuccess) e = hipMalloc((void**)&pr, n * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&ds, 4);
     if (e == hipSuccess) e = hipMemcpyAsync(d, keys, n * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = drfe_launch_lsd_order(d, n, (int)n, pl, pr, n, ds, 1, 1, c->stream);
+    if (e == hipSuccess) e = drfe_launch_lsd_order(d, n, (int)n, pl, pr, n, ds, 1, 1, c->stream, depth_limit);
     if (e == hipSuccess) e = hipMemcpyAsync(keys, d, n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(status, ds, 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

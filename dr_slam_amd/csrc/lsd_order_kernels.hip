@@ -36,7 +36,7 @@ extern "C" __global__ __launch_bounds__(ORD_T) void k_lsd_order(uint32_t* __rest
 }
 
 hipError_t drfe_launch_lsd_order(uint32_t* d_keys, size_t keyStride, int n, uint32_t* d_posL, uint32_t* d_posR, size_t posStride,
-                                 int* d_status, int statusStride, int nframes, hipStream_t s)
+                                 int* d_status, int statusStride, int nframes, hipStream_t s, int depthOverride)
 {
     if (nframes <= 0) return hipSuccess;
     int lg = 0;
@@ -48,6 +48,6 @@ hipError_t drfe_launch_lsd_order(uint32_t* d_keys, size_t keyStride, int n, uint
         configured = true;
     }
     hipLaunchKernelGGL(k_lsd_order, dim3(nframes), dim3(ORD_T), ORD_DYN_LDS_BYTES(ORD_T), s, d_keys, keyStride, n, d_posL, d_posR, posStride, d_status,
-                       statusStride, 2 * lg);
+                       statusStride, depthOverride >= 0 ? depthOverride : 2 * lg);       /* the override: tests of the heap-sort branch */
     return hipGetLastError();
 }

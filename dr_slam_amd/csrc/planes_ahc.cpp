@@ -883,6 +883,9 @@ static void ahc_batch_fail(AhcBatchJob& J, int rc, const std::string& err)
 }
 
 /* a worker: takes frames whose chunk has left the device, fetches the frame's member lists and runs the per-plane loop */
+static std::atomic<long long> g_planeCpuNs[4];      /* DRFE_TRACE_PLANES: thread CPU time of the workers by section: fetch | frame download + wait | grids redone | gates + refit */
+static inline long long plane_thread_cpu_ns() { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return t.tv_sec * 1000000000LL + t.tv_nsec; }
+
 static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
 {
     AhcArena* A = J.A;
@@ -911,6 +914,8 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             }
         }
         if (fetchCh >= 0) {
+            const long long tF = plane_thread_cpu_ns();
+            struct AccF { long long t; ~AccF() { g_planeCpuNs[0] += plane_thread_cpu_ns() - t; } } accF{tF};
             /* the small results of every frame of the chunk; member lists, centroids and label images are fetched per frame */
             const int f0 = fetchCh * J.chunk, nf = std::min(J.chunk, J.nframes - f0);
             const size_t pc = (size_t)A->P.planeCap;
@@ -960,6 +965,7 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             int handedBack = 0;
             for (int i = 0; i < nP && coarseReady; i++) { vcl[i] = vc[i]; if (vc[i] < 0) handedBack++; nCoarse += (size_t)(vc[i] < 0 ? jobs[i].y : vc[i]); }
             hipError_t e = hipSuccess;
+            const long long tD = plane_thread_cpu_ns();
             if (coarseReady) {
                 /* ONE download for the frame: the planes' centroid ranges lie in job order inside the frame's part of d_vout, so the
                  * span from the first plane's range to the end of the last one's centroids is fetched whole (the gaps - a plane's
@@ -993,6 +999,8 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             if (e == hipSuccess && J.seg) e = hipMemcpyAsync(J.seg + f * px, slot + A->offSeg, px, hipMemcpyDeviceToHost, l->stream);
             if (e == hipSuccess && (nCoarse > 0 || (!coarseReady && (J.post || J.memberIdx)) || J.seg)) e = drfe_pool_sync(l->stream, ev);
             if (e != hipSuccess) { l->err = std::string("planes batch: results of a frame: ") + hipGetErrorString(e); rc = DRFE_ERR_HIP; }
+            const long long tR = plane_thread_cpu_ns();
+            g_planeCpuNs[1] += tR - tD;
             if (rc == DRFE_OK && coarseReady && handedBack) {
                 J.voxFallbacks += handedBack;
                 static const bool traceBack = std::getenv("DRFE_TRACE_PLANES") != nullptr;
@@ -1009,7 +1017,10 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
                         cptr[i] = redo[r].data(); vcl[i] = cnt; r++;
                     }
             }
+            const long long tP = plane_thread_cpu_ns();
+            g_planeCpuNs[2] += tP - tR;
             if (rc == DRFE_OK && coarseReady) {
+                struct AccP { long long t; ~AccP() { g_planeCpuNs[3] += plane_thread_cpu_ns() - t; } } accP{tP};
                 rc = drfe_ahc_post_from_coarse(&l->err, pl, nP, cptr.data(), vcl.data(), J.maxPointDist, J.distThreshold, J.post + (size_t)f * J.cap, nullptr, voff.data(),
                                                0, &J.nAccepted[f], J.planeNum ? &J.planeNum[f] : nullptr);
                 viaCoarse = true;
@@ -1125,6 +1136,9 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         (void)hipMemcpy(ff, A->h_frames[0].handoff + 4 + 2 * 128 + 4, sizeof(ff), hipMemcpyDeviceToHost);
         std::fprintf(stderr, "  flood fill: %d steps, %d with two visits of one pixel (chain depth summed: %d), %d live visits\n", ff[0], ff[1], ff[2], ff[3]);
     }
+    if (std::getenv("DRFE_TRACE_PLANES"))
+        std::fprintf(stderr, "drfe_planes_ahc_post_batch workers, CPU ms per frame: chunk fetch %.3f, frame download + wait %.3f, grids redone on the host %.3f, gates + refit %.3f\n",
+                     g_planeCpuNs[0].exchange(0) / 1e6 / nframes, g_planeCpuNs[1].exchange(0) / 1e6 / nframes, g_planeCpuNs[2].exchange(0) / 1e6 / nframes, g_planeCpuNs[3].exchange(0) / 1e6 / nframes);
     if (std::getenv("DRFE_TRACE_PLANES"))
         std::fprintf(stderr, "drfe_planes_ahc_post_batch (device extractor): %d frames, %d chunks, %d frames redone on the host; voxel grids on the %s (%d planes' grids redone on the host)\n",
                      nframes, J.nChunks, J.fallbacks.load(), J.voxDevice ? "device" : "host", J.voxFallbacks.load());

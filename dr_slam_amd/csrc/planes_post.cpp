@@ -191,20 +191,74 @@ void least_squares_plane(const std::vector<Pt>& pts, const std::vector<int>& inl
 /* Frame::MaxPointDistanceFromPlane (src/Frame.cc:1222-1307): pcl::SACSegmentation, SACMODEL_PLANE, SAC_RANSAC, 50
  * iterations, probability 0.99, optimize on; sample draws as SampleConsensusModel::drawIndexSample with boost::mt19937
  * (seed 12345) behind uniform_int<>(0, INT_MAX) == std::mt19937 output >> 1 */
+/* The inlier count of a plane over a cloud kept as three float arrays: |c . (p, 1)| < disTh with the reference's float
+ * expression and its double comparison.  A float widens to double exactly, so `fabs((double)e) < disTh` is `|e| <= tLess` with
+ * tLess the largest float whose double lies below disTh: the loop is pure float arithmetic and runs eight points at a time
+ * under AVX2 (same IEEE operations per lane, no contraction), which is what RANSAC's 5-10 counting passes per plane cost. */
+template <int W>
+static inline int count_within_w(const float* X, const float* Y, const float* Z, int n, const float c[4], float tLess)
+{
+    typedef float vf __attribute__((vector_size(W * 4)));
+    typedef int vi __attribute__((vector_size(W * 4)));
+    int k = 0, i = 0;
+    if (W > 1) {
+        vi acc = {};
+        const vf c0 = c[0] - (vf){}, c1 = c[1] - (vf){}, c2 = c[2] - (vf){}, c3 = c[3] * 1.0f - (vf){}, t = tLess - (vf){};
+        for (; i + W <= n; i += W) {
+            vf x, y, z;
+            std::memcpy(&x, X + i, sizeof(vf)); std::memcpy(&y, Y + i, sizeof(vf)); std::memcpy(&z, Z + i, sizeof(vf));
+            vf e = ((c0 * x + c1 * y) + c2 * z) + c3;
+            const vf ne = -e;
+            const vf a = e > ne ? e : ne;                       /* |e|; a NaN stays NaN and fails the comparison below */
+            acc -= (vi)(a <= t);                                /* a true lane is -1 */
+        }
+        for (int q = 0; q < W; q++) k += acc[q];
+    }
+    for (; i < n; i++) {
+        const float e = ((c[0] * X[i] + c[1] * Y[i]) + c[2] * Z[i]) + c[3] * 1.0f;
+        k += std::fabs(e) <= tLess ? 1 : 0;
+    }
+    return k;
+}
+__attribute__((target("avx2"))) static int count_within_avx2(const float* X, const float* Y, const float* Z, int n, const float c[4], float t) { return count_within_w<8>(X, Y, Z, n, c, t); }
+static int count_within_sse(const float* X, const float* Y, const float* Z, int n, const float c[4], float t) { return count_within_w<4>(X, Y, Z, n, c, t); }
+static int count_within(const float* X, const float* Y, const float* Z, int n, const float c[4], float t)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? count_within_avx2(X, Y, Z, n, c, t) : count_within_sse(X, Y, Z, n, c, t);
+}
+
 bool refit_plane(float coef[4], const std::vector<Pt>& pts, double disTh)
 {
-    for (const Pt& p : pts)
-        if (std::fabs((double)(((coef[0] * p.x + coef[1] * p.y) + coef[2] * p.z) + coef[3])) > disTh) return false;
     const int n = (int)pts.size();
+    /* largest float strictly below disTh (as doubles), and the cloud as three arrays */
+    float tLess = (float)disTh;
+    if (!((double)tLess < disTh)) tLess = std::nextafterf(tLess, -std::numeric_limits<float>::infinity());
+    static thread_local std::vector<float> soa;
+    soa.resize((size_t)3 * n);
+    float *X = soa.data(), *Y = X + n, *Z = Y + n;
+    for (int i = 0; i < n; i++) { X[i] = pts[i].x; Y[i] = pts[i].y; Z[i] = pts[i].z; }
+    /* every point within disTh of the extractor's plane: `fabs((double)e) > disTh` for none <=> `|e| <= tMost` for all, tMost the
+     * largest float whose double does not exceed disTh */
+    float tMost = (float)disTh;
+    if ((double)tMost > disTh) tMost = std::nextafterf(tMost, -std::numeric_limits<float>::infinity());
+    {
+        const float cc[4] = {coef[0], coef[1], coef[2], coef[3]};
+        /* the gate's expression ends in `+ coef[3]`, plane_eval's in `+ c[3] * 1.0f`: the same float */
+        int within = count_within(X, Y, Z, n, cc, tMost);
+        if (within != n) {
+            /* a NaN distance does not trip the reference's `>` test: count those as passing, as it does */
+            int nans = 0;
+            for (int i = 0; i < n; i++) { const float e = ((coef[0] * X[i] + coef[1] * Y[i]) + coef[2] * Z[i]) + coef[3]; nans += e != e ? 1 : 0; }
+            if (within + nans != n) return false;
+        }
+    }
     if (n < 3) return false;
-    std::vector<int> order(n);
+    static thread_local std::vector<int> order;
+    order.resize(n);
     for (int i = 0; i < n; i++) order[i] = i;
     std::mt19937 gen(12345u);
-    auto inliers_of = [&](const float c[4]) {
-        int k = 0;
-        for (const Pt& p : pts) k += std::fabs((double)plane_eval(c, p)) < disTh ? 1 : 0;
-        return k;
-    };
+    auto inliers_of = [&](const float c[4]) { return count_within(X, Y, Z, n, c, tLess); };
     float best[4] = {0, 0, 0, 0};
     int bestCount = -std::numeric_limits<int>::max(), iterations = 0;
     unsigned skipped = 0;

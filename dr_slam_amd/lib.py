@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor",
+    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_debug_device_order_sort_depth", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -223,6 +223,7 @@ def load() -> C.CDLL:
     L.drfe_batch_check.argtypes = [vp]
     L.drfe_debug_cr_sincos.argtypes = [vp, i32, vp, vp, vp]
     L.drfe_debug_device_order_sort.argtypes = [vp, vp, sz, C.POINTER(i32)]
+    L.drfe_debug_device_order_sort_depth.argtypes = [vp, vp, sz, i32, C.POINTER(i32)]
     L.drfe_profile_enable.argtypes = [vp, i32]
     L.drfe_profile_stage_ms.argtypes = [vp, vp]
     L.drfe_stream_sync.argtypes = [vp]

@@ -375,8 +375,11 @@ int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, con
 int drfe_debug_cr_sincos(const double* x, int n, double* s, double* c, int32_t* ok);
 /* Test hook of dr_slam_amd/csrc/lsd_order_kernels.hip: n LSD ordering keys (gradient bin << 22 | y << 11 | x) sorted in place on the
  * device into std::sort's order under lsd.cpp's compare_norm (larger bins first, the order of equal bins = libstdc++'s
- * introsort's).  *status: 0, or 1 if a range exhausted introsort's depth limit (the caller orders such a frame on the host). */
+ * introsort's, heap-sort branch included).  *status: 0, or 1 if a range above 1024 keys exhausted introsort's depth limit (one
+ * lane heap-sorts shorter ones; the caller orders such a frame on the host).  _depth: depth_limit >= 0 replaces 2 lg n, so that
+ * tests reach the heap-sort branch (compare with drfe_debug_order_sort, mode 3, same depth_limit). */
 int drfe_debug_device_order_sort(drfe_ctx* ctx, uint32_t* keys, size_t n, int* status);
+int drfe_debug_device_order_sort_depth(drfe_ctx* ctx, uint32_t* keys, size_t n, int depth_limit, int* status);
 /* Parity taps of the device image passes of the last drfe_lsd_extract call (any pointer may be NULL):
  * 0.8-scaled image, gradient magnitude and level-line angle (sw x sh), Sobel dx/dy of the LBD image. */
 int drfe_lsd_stages(drfe_ctx* ctx, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy,

@@ -396,6 +396,43 @@ def test_device_order_sort_equals_std_sort(ctx):
         assert st.value == 0 and np.array_equal(dev, ref), kind
 
 
+def test_device_order_sort_heap_branch_equals_libstdcxx(ctx):
+    """introsort's depth limit forced low, so that ranges of every length reach std::__partial_sort (make_heap + sort_heap):
+    the device's one-lane heap sort (introsort_device.h: heap_sort_range) must leave libstdc++'s permutation - compared with the
+    plain transcription of std::__introsort_loop run at the same depth limit (drfe_debug_order_sort mode 3; at the natural limit
+    that transcription is itself compared with std::sort in tests/test_host_cpu.py).  A range above 1024 keys at depth 0 is not
+    heap-sorted by one lane: status 1, the caller's host path."""
+    import ctypes as C
+    from dr_slam_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(23)
+
+    def keys_of(bins):
+        n = len(bins)
+        idx = np.arange(n, dtype=np.uint32)
+        return (bins.astype(np.uint32) << 22) | ((idx // 2047) << 11) | (idx % 2047)
+
+    reached = 0
+    for n in (17, 18, 25, 33, 64, 100, 257, 1000, 1024, 3000, 20000, 70001):
+        for what, bins in (("random", rng.integers(0, 1024, n)), ("three bins", rng.integers(0, 3, n)), ("constant", np.full(n, 7)),
+                           ("organ pipe", np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) % 1024),
+                           ("exponential", np.minimum(1023, rng.exponential(40, n).astype(np.int64)))):
+            lg = int(np.log2(n))
+            for depth in sorted({0, 1, 2, 3, max(0, lg - 4), max(0, lg - 1), lg + 2}):
+                k = keys_of(np.asarray(bins))
+                dev, ref = k.copy(), k.copy()
+                st = C.c_int(-1)
+                assert L.drfe_debug_device_order_sort_depth(ctx.h, dev.ctypes.data_as(C.c_void_p), len(dev), depth, C.byref(st)) == 0, ctx.last_error()
+                assert L.drfe_debug_order_sort(ref.ctypes.data_as(C.c_void_p), len(ref), 0, 3, depth, 0) == 0
+                if st.value == 1:
+                    assert n > 1024 and depth <= lg, (what, n, depth)        # some range above 1024 keys ran out of depth
+                    continue
+                assert st.value == 0, (what, n, depth, st.value)
+                assert np.array_equal(dev, ref), (what, n, depth, int(np.argmax(dev != ref)))
+                reached += 1
+    assert reached > 200
+
+
 def test_lsd_batch_device_edge_cases(ctx):
     """drfe_lsd_extract_batch with the sequential core on the device, on frames at the edges of what the kernels assume, all in
     one batch: a constant image (no pixel has a level-line angle: nothing to order, no seed), uniform noise (every pixel a seed,
