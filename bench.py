@@ -503,10 +503,10 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
                           "decisions with certified comparisons (k_rect_improve), key lines + the response cut + line equations (k_lsd_keylines), LBD (k_lbd); host threads upload, launch and copy",
             "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels, plane clouds (k_ahc_blocks, k_ahc_cluster + k_ahc_refine: one wavefront per frame) and "
                            "pcl::VoxelGrid of every plane (k_voxel_grid) on the device; gates + RANSAC refit on host threads",
-            "note": "the device paths are latency chains (~0.12 s of region growing, ~0.075 s of plane extraction per frame on one wavefront): their rate is frames in "
-                    "flight over that latency - bounded by the LDS the resident frames hold (27 KB per growing frame, 32 / 26 KB per plane frame) - so steps run side by side; "
-                    "the host stages that remain are the planes' gates + refit and CAPE's cell growing (host_cpu_ms_per_frame_by_pool is the measurement; "
-                    "host_cores_busy_at_8_gpus_at_this_rate = 8 x the busy cores measured here)"}
+            "note": "the device paths are latency chains (~0.12 s of region growing, ~0.075 s of plane extraction per frame on one wavefront), so steps run side by side; "
+                    "with 4 steps in flight the one-wavefront-per-frame kernels keep the SIMDs issuing (their wavefront-seconds per step / 1024 SIMDs is the step time "
+                    "measured - DESIGN.md, what bounds the full front-end).  CAPE runs on the device; the host stage that remains is the planes' gates + RANSAC refit "
+                    "(host_cpu_ms_per_frame_by_pool is the measurement; host_cores_busy_at_8_gpus_at_this_rate = 8 x the busy cores measured here)"}
 
 
 def launch(args) -> int:
