@@ -1283,8 +1283,8 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     if (std::getenv("DRFE_LSD_PROFILE")) {       /* LSD_PROFILE builds of k_lsd_grow: phase times of frame 0 (100 MHz ticks -> ms) and counts */
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
         std::fprintf(stderr, "k_lsd_grow frame 0: total %.2f ms: bitmap %.2f, scan %.2f (%llu chunks), window loads %.2f (%llu groups), window growth %.2f (%llu regions, %llu member visits), "
-                     "queue growth %.2f (%llu steps), region2rect %.2f (%llu), refine incl. its growth %.2f\n", pr[7] / 1e5, pr[0] / 1e5, pr[1] / 1e5, pr[8], pr[2] / 1e5, pr[9], pr[3] / 1e5, pr[10], pr[11],
-                     pr[4] / 1e5, pr[12], pr[5] / 1e5, pr[13], pr[6] / 1e5);
+                     "queue growth %.2f (%llu steps), region2rect %.2f (%llu), refine incl. its growth %.2f; alignment tests decided by the reference's arithmetic %llu; of the queue growth, waiting for the members' fields %.2f\n", pr[7] / 1e5, pr[0] / 1e5, pr[1] / 1e5, pr[8], pr[2] / 1e5, pr[9], pr[3] / 1e5, pr[10], pr[11],
+                     pr[4] / 1e5, pr[12], pr[5] / 1e5, pr[13], pr[6] / 1e5, pr[14], pr[15] / 1e5);
     }
     for (int ch = 0; ch < nChunks; ch++) {
         (void)hipStreamSynchronize(J.chunkStream[ch]);

@@ -28,6 +28,8 @@
 #include "../../include/drfe_math.h"
 #include "cr_sincos.h"
 #include <type_traits>
+#include <cmath>
+#include <cstdlib>
 
 #ifndef LSD_RING
 #define LSD_RING 512          /* newest members mirrored in LDS */
@@ -125,71 +127,118 @@ __device__ __forceinline__ Window load_window(const Wave& w, int sx, int sy)
     return win;
 }
 
+/* The alignment test of region_grow, |fastAtan2(sumdy, sumdx) * DEG2RAD - angle(pixel)| <= prec (mod 2 pi), decided WITHOUT the
+ * arctangent wherever the decision is not close: the pixel's direction (c.x, c.y) is float(cos), float(sin) of its level-line
+ * angle (k_lsd_gradient's field, correctly rounded), so the angle between the running direction S = (sumdx, sumdy) and the
+ * pixel is atan2(cross, dot) of the two; cv::fastAtan2's polynomial is within 0.0096 degrees of the true arctangent (every
+ * float ratio in [0, 1] scanned; its three `90 - a` style reflections add 5e-5) and the float roundings of dot / cross are
+ * 1e-5 degrees, so with tLo = tan(prec - 0.02 deg), tHi = tan(prec + 0.02 deg)
+ *     |cross| <= tLo * dot            : aligned, whatever the last bits of fastAtan2 are
+ *     |cross| >= tHi * dot or dot <= 0: not aligned
+ * and only a pixel in the 0.04-degree band between the two (2e-4 of them) is decided by the reference's own arithmetic.  A
+ * running direction that nearly cancelled, or a NaN (seed direction not certified), is "uncertain" as well. */
+struct AlignTan { float tLo, tHi; };
+/* masks over the wavefront: lanes whose pixel is certainly aligned / not decided by the shortcut.  Plain compares into lane
+ * masks and scalar mask arithmetic: no lane-divergent control flow */
+__device__ __forceinline__ void align_class(float Sx, float Sy, float2 c, const AlignTan& T, unsigned long long& in, unsigned long long& unc)
+{
+    const float dot = __builtin_fmaf(Sx, c.x, Sy * c.y), crs = __builtin_fmaf(Sx, c.y, -(Sy * c.x));
+    const float ac = fabsf(crs);
+    const unsigned long long ok = __ballot(fabsf(dot) + ac > 1e-3f);
+    const unsigned long long mIn = __ballot(ac <= T.tLo * dot), mOut = __ballot(ac >= T.tHi * dot), mNeg = __ballot(dot <= 0.f);
+    in = ok & mIn;
+    unc = ~(in | (ok & (mOut | mNeg)));
+}
+
+/* the float sums of region_grow (before the first join: the seed's own direction - its sums start there) */
+struct RegDir { float sx, sy; };
+
 /* region_grow from seed (sx, sy): members to F.reg[0..n), their pixels claimed in the bitmap.  Returns n; regAngle out.
- * win = load_window(sx, sy) */
-__device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double& regAngleOut, const Window& win)
+ * win = load_window(sx, sy).  CHEAP: the alignment tests go through align_class first (the caller's prec is the one T was
+ * made for); refine's second growth runs with its own tolerance and the reference's arithmetic throughout. */
+template <bool CHEAP>
+__device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double& regAngleOut, const Window& win, const AlignTan T, int minKeep)
 {
     const int W = w.W, H = w.H, lane = w.lane;
     const double kDeg2Rad = 3.14159265358979323846 / 180.0;
-    const uint32_t seedQ = (uint32_t)(sy * W + sx);
     const double seedAngle = rl_f64(win.a, 24);
-    double regAngle = seedAngle;
-    float sumdx = 0.f, sumdy = 0.f;
-    bool seeded = false;
+    /* float(cos), float(sin) of the seed's angle: correctly rounded per pixel by k_lsd_keys (NaN: not certified) */
+    RegDir D;
+    D.sx = rl_f32(win.s0.x, 24); D.sy = rl_f32(win.s0.y, 24);
     int n = 1, i = 0;
-    if (lane == 0) { w.F.reg[0] = (uint32_t)(sy << 16 | sx); w.ring[0] = (uint32_t)(sy << 16 | sx); }
-    w.set_bit_uniform(seedQ);
+    /* the region's angle: the seed's own until a second member joins, then fastAtan2 of the sums - evaluated when a test needs
+     * it (angleAt = the size of the region the cached value belongs to) */
+    double curAngle = seedAngle;
+    int angleAt = 1;
+    auto angle_now = [&]() -> double {
+        if (angleAt != n) { curAngle = (double)drfe_fast_atan2(D.sy, D.sx) * kDeg2Rad; angleAt = n; }
+        return curAngle;
+    };
+    auto join_dir = [&](float cx, float cy) { D.sx += cx; D.sy += cy; };
+    const bool shortcut = CHEAP && T.tLo > 0.f;
     const unsigned long long tg0 = PROF_T();
     PROF_CNT(10, 1);
     {
-        /* inside the window: state of its pixels as a scalar mask, members as window indices in the lanes of `member` */
+        /* inside the window: state of its pixels as a scalar mask, members as window indices in the lanes of `member`.  Nothing
+         * is written while the region stays here: the window's free mask is the only state the growth reads, and the members'
+         * bitmap bits (and, for a region that goes on, their list entries) are stored by their lanes at the end, side by side */
         const int wy0 = (lane * 37) >> 8, wx0 = lane - 7 * wy0;
         const int px = sx - 3 + wx0, py = sy - 3 + wy0;
         const bool inw = lane < 49 && px >= 0 && py >= 0 && px < W && py < H;
-        unsigned long long wfree = __ballot(inw && !w.bit((uint32_t)(py * W + px)));
+        unsigned long long wfree = __ballot(inw && !w.bit((uint32_t)(py * W + px))) & ~(1ull << 24);
         /* which window pixels are aligned with the running angle: every lane tests its own pixel, so a member's probes are
          * scalar mask arithmetic and only a JOIN (which moves the angle) costs vector work */
-        unsigned long long walign = __ballot(lane < 49 && aligned_with(regAngle, win.a, prec));
+        auto aligned_mask = [&]() -> unsigned long long {
+            if (shortcut) {
+                unsigned long long mi, mu;
+                align_class(D.sx, D.sy, win.c, T, mi, mu);
+                if (!(mu & wfree)) return mi;
+                PROF_CNT(14, 1);
+            }
+            return __ballot(lane < 49 && aligned_with(angle_now(), win.a, prec));
+        };
+        unsigned long long walign = aligned_mask();
         int member = 24;                               /* lane j: window index of member j */
         while (i < n) {
             const int t = rl_i32(member, i);
-            const int ty = (t * 37) >> 8, tx = t - 7 * ty;
-            if (tx == 0 || tx == 6 || ty == 0 || ty == 6) break;          /* its neighbours leave the window */
+            if (!((0x1F3E7CF9F00ull >> t) & 1ull)) break;             /* not one of the inner 5 x 5: its neighbours leave the window */
             unsigned long long nb = 0x1C287ull << (t - 8);                /* the 3 x 3 ring around t, raster order */
             for (;;) {
                 const unsigned long long hit = nb & wfree & walign;       /* free neighbours that join now */
                 if (!hit) break;
                 const int l = __builtin_ctzll(hit);
                 nb &= ~((2ull << l) - 1ull);                              /* the probes behind it come after the join */
-                const int ly = (l * 37) >> 8, lx = l - 7 * ly;
-                const int jx = sx - 3 + lx, jy = sy - 3 + ly;
                 wfree &= ~(1ull << l);
-                w.set_bit_uniform((uint32_t)(jy * W + jx));
-                if (lane == 0) { w.F.reg[n] = (uint32_t)(jy << 16 | jx); w.ring[n & (LSD_RING - 1)] = (uint32_t)(jy << 16 | jx); }
                 member = lane == n ? l : member;
                 n++;
-                if (!seeded) {
-                    /* only regions that get a second member need the seed's direction */
-                    /* float(cos), float(sin) of the seed's angle: correctly rounded per pixel by k_lsd_keys (NaN: not certified) */
-                    sumdx = rl_f32(win.s0.x, 24); sumdy = rl_f32(win.s0.y, 24);
-                    if (sumdx != sumdx) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
-                    seeded = true;
-                }
-                sumdx += rl_f32(win.c.x, l);
-                sumdy += rl_f32(win.c.y, l);
-                regAngle = (double)drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
-                walign = __ballot(lane < 49 && aligned_with(regAngle, win.a, prec));
+                join_dir(rl_f32(win.c.x, l), rl_f32(win.c.y, l));
+                walign = aligned_mask();
             }
             i++;
+        }
+        if (lane < n) {
+            const int my = (member * 37) >> 8, mx = member - 7 * my;
+            const int jx = sx - 3 + mx, jy = sy - 3 + my;
+            const uint32_t xy = (uint32_t)(jy << 16 | jx), q = (uint32_t)(jy * W + jx);
+            atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+            /* the list is read by the growth beyond the window and by region2rect: nineteen regions in twenty need neither */
+            if (i < n || n >= minKeep) { w.F.reg[lane] = xy; w.ring[lane] = xy; }
         }
     }
     PROF_ADD(3, tg0);
     PROF_CNT(11, i);
     const unsigned long long tg1 = PROF_T();
-    /* beyond the window: up to seven queued members per step, their neighbours' fields fetched together */
+    /* beyond the window: up to seven queued members per step, their neighbours' fields fetched together.  Lane 9 m + k holds
+     * neighbour k (raster order) of the step's m-th member, so LANE ORDER IS THE VISITING ORDER of region_grow: one pass over
+     * the lanes whose pixel is free, a join removes every lane that holds the joined pixel and moves the direction the later
+     * lanes are tested against.  The joined lanes store their list entries and bitmap bits together when the step ends. */
     const int m = lane / 9, k = lane - 9 * m;
     const int dyk = k / 3 - 1, dxk = k - 3 * (k / 3) - 1;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     while (i < n) {
+#ifdef LSD_PROFILE
+        const unsigned long long tq0 = PROF_T();
+#endif
         const int cnt = min(7, n - i);
         const bool act = m < cnt && lane < 63 && k != 4;
         uint32_t mxy = 0;
@@ -197,43 +246,52 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
         else { wg_fence(); if (act) mxy = w.F.reg[i + m]; }
         const int nx = (int)(mxy & 0xFFFFu) + dxk, ny = (int)(mxy >> 16) + dyk;
         const bool inb = act && nx >= 0 && ny >= 0 && nx < W && ny < H;
-        const uint32_t q = inb ? (uint32_t)(ny * W + nx) : 0u;
-        /* fields of the neighbours that are free now (a superset of those free when their member's turn comes) */
+        const uint32_t q = inb ? (uint32_t)(ny * W + nx) : 0xFFFFFFFFu;
         const bool want = inb && !w.bit(q);
         double a = 0.0;
         float2 c = make_float2(0.f, 0.f);
-        if (want) { a = w.F.ang[q]; c = make_float2(w.F.cs[2 * (size_t)q], w.F.cs[2 * (size_t)q + 1]); }
-        const uint32_t nxy = (uint32_t)(ny << 16 | nx);
-        for (int mm = 0; mm < cnt; mm++) {
-            const bool fb = want && m == mm && !w.bit(q);
-            unsigned long long mask = __ballot(fb);
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const double av = rl_f64(a, l);
-                if (uni(aligned_with(regAngle, av, prec))) {
-                    const uint32_t ql = rl_u32(q, l), xy = rl_u32(nxy, l);
-                    w.set_bit_uniform(ql);
-                    if (lane == 0) { w.F.reg[n] = xy; w.ring[n & (LSD_RING - 1)] = xy; }
-                    n++;
-                    if (!seeded) {
-                        /* only regions that get a second member need the seed's direction */
-                        /* float(cos), float(sin) of the seed's angle: correctly rounded per pixel by k_lsd_keys (NaN: not certified) */
-                        sumdx = rl_f32(win.s0.x, 24); sumdy = rl_f32(win.s0.y, 24);
-                        if (sumdx != sumdx) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
-                        seeded = true;
-                    }
-                    sumdx += rl_f32(c.x, l);
-                    sumdy += rl_f32(c.y, l);
-                    regAngle = (double)drfe_fast_atan2(sumdy, sumdx) * kDeg2Rad;
-                }
+        if (want) { c = make_float2(w.F.cs[2 * (size_t)q], w.F.cs[2 * (size_t)q + 1]); if (!CHEAP) a = w.F.ang[q]; }
+        unsigned long long qin = 0, qunc = ~0ull;
+        auto classes = [&]() {
+            if (!shortcut) return;                         /* the shortcut is off for this tolerance: every test the long way */
+            align_class(D.sx, D.sy, c, T, qin, qunc);
+        };
+#ifdef LSD_PROFILE
+        if (CHEAP) { if (__ballot(c.x == 12345.678f)) w.status |= 4; PROF_ADD(15, tq0); }      /* wait for the fields here */
+#endif
+        classes();
+        unsigned long long mask = __ballot(want), joined = 0;
+        while (mask) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            bool al;
+            if (!((qunc >> l) & 1ull)) al = (qin >> l) & 1ull;
+            else {
+                if (CHEAP) PROF_CNT(14, 1);
+                const double av = CHEAP ? uni_d(w.F.ang[rl_u32(q, l)]) : rl_f64(a, l);
+                al = uni(aligned_with(angle_now(), av, prec));
             }
+            if (al) {
+                joined |= 1ull << l;
+                mask &= ~__ballot(q == rl_u32(q, l));      /* the same pixel as a later member's neighbour: claimed now */
+                n++;
+                join_dir(rl_f32(c.x, l), rl_f32(c.y, l));
+                classes();
+            }
+        }
+        if ((joined >> lane) & 1ull) {
+            const int at = n - __popcll(joined) + __popcll(joined & lt);
+            const uint32_t xy = (uint32_t)(ny << 16 | nx);
+            w.F.reg[at] = xy; w.ring[at & (LSD_RING - 1)] = xy;
+            atomicOr(&w.bm[q >> 5], 1u << (q & 31));
         }
         i += cnt;
         PROF_CNT(12, 1);
     }
     PROF_ADD(4, tg1);
-    regAngleOut = regAngle;
+    /* only regions that get a second member need the seed's direction */
+    if (n > 1 && rl_f32(win.s0.x, 24) != rl_f32(win.s0.x, 24)) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
+    regAngleOut = angle_now();
     return n;
 }
 
@@ -437,7 +495,7 @@ __device__ __forceinline__ bool shrink(Wave& w, int& n, double regAngle, double 
     return true;
 }
 
-__device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double prec, Rect& rec, double densityTh, const Window& win)
+__device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double prec, Rect& rec, double densityTh, const Window& win, const AlignTan T)
 {
     const int lane = w.lane, W = w.W;
     double density = density_of(rec, n);
@@ -473,7 +531,7 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
     }
     const double mean = sum / (double)cntIn;
     const double tau = 2.0 * sqrt((ssum - 2.0 * mean * sum) / (double)cntIn + mean * mean);
-    n = grow(w, sx, sy, uni_d(tau), regAngle, win);
+    n = grow<false>(w, sx, sy, uni_d(tau), regAngle, win, T, 0);
     if (n < 2) return false;
     to_rect(w, n, regAngle, prec, rec, true);
     density = density_of(rec, n);
@@ -484,10 +542,11 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
 } // namespace
 
 extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* __restrict__ frames, int W, int H, double prec, double p,
-                                                            int minReg, double densityTh, int rectCap)
+                                                            int minReg, double densityTh, int rectCap, float tLo, float tHi)
 {
     extern __shared__ uint32_t lds[];
     Wave w;
+    AlignTan T; T.tLo = tLo; T.tHi = tHi;
     {
         const LsdGrowFrame f = frames[blockIdx.x];
         w.F.ang = (const GLOBAL_AS double*)f.ang; w.F.cs = (const GLOBAL_AS float*)f.cs; w.F.cs0 = (const GLOBAL_AS float*)f.cs0; w.F.mod = (const GLOBAL_AS double*)f.mod;
@@ -578,12 +637,12 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
                 const int gx = rl_i32(sx, f), gy = rl_i32(sy, f);
                 if (!uni(w.bit((uint32_t)(gy * W + gx)))) {
                     double regAngle;
-                    int n = grow(w, gx, gy, prec, regAngle, w0);
+                    int n = grow<true>(w, gx, gy, prec, regAngle, w0, T, minReg);
                     if (n >= minReg) {
                         Rect rec;
                         to_rect(w, n, regAngle, prec, rec, true);
                         const unsigned long long tf0 = PROF_T();
-                        const bool okr = refine(w, n, regAngle, prec, rec, densityTh, w0);
+                        const bool okr = refine(w, n, regAngle, prec, rec, densityTh, w0, T);
                         PROF_ADD(6, tf0);
                         if (okr) {
                             if (nRects < rectCap) {
@@ -666,6 +725,14 @@ hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(k_lsd_grow, dim3(nframes), dim3(64), lds, s, d_frames, W, H, prec, p, minReg, densityTh, rectCap);
+    /* thresholds of align_class for this precision: tan(prec -/+ 0.02 degrees), rounded away from the band; a tolerance that
+     * reaches 90 degrees switches the shortcut off (tLo <= 0) */
+    const double band = 0.02 * 3.14159265358979323846 / 180.0;
+    float tLo = 0.f, tHi = 0.f;
+    if (prec - band > 0 && prec + band < 1.5 && !std::getenv("DRFE_LSD_EXACT_ALIGN")) {
+        tLo = nextafterf((float)tan(prec - band), 0.f);
+        tHi = nextafterf((float)tan(prec + band), 1e30f);
+    }
+    hipLaunchKernelGGL(k_lsd_grow, dim3(nframes), dim3(64), lds, s, d_frames, W, H, prec, p, minReg, densityTh, rectCap, tLo, tHi);
     return hipGetLastError();
 }
