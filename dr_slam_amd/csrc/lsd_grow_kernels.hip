@@ -76,6 +76,7 @@ struct Wave {
     FramePtrs F;
     uint32_t* bm;             /* LDS: bit set = pixel cannot join (claimed, or no level-line angle) */
     uint32_t* ring;           /* LDS: reg[j] for the newest LSD_RING members at ring[j & (LSD_RING - 1)] */
+    double* col;              /* LDS: 64 x 3 doubles, the addends of region2rect's order-defined sums (ordered_sums3) */
     int W, H, lane;
     int status;
 #ifdef LSD_PROFILE
@@ -327,6 +328,21 @@ __device__ __forceinline__ double diff_signed(double a, double b)
     return d;
 }
 
+/* acc (lane 0 / 1 / 2: three running sums) += v0 / v1 / v2 of lanes 0 .. cnt - 1, in lane order.  Lanes >= cnt must hold +0.0
+ * (adding it changes nothing: the sums never hold -0.0, they start at +0.0).  Lanes above 2 walk lane 2's column and are ignored. */
+__device__ __forceinline__ double ordered_sums3(Wave& w, double acc, double v0, double v1, double v2, int cnt)
+{
+    double* mine = w.col + 3 * w.lane;
+    mine[0] = v0; mine[1] = v1; mine[2] = v2;
+    const double* walk = w.col + min(w.lane, 2);
+    for (int t = 0; t < cnt; t += 8) {
+        const double e0 = walk[3 * t], e1 = walk[3 * t + 3], e2 = walk[3 * t + 6], e3 = walk[3 * t + 9], e4 = walk[3 * t + 12], e5 = walk[3 * t + 15],
+                     e6 = walk[3 * t + 18], e7 = walk[3 * t + 21];
+        acc += e0; acc += e1; acc += e2; acc += e3; acc += e4; acc += e5; acc += e6; acc += e7;
+    }
+    return acc;
+}
+
 /* region2rect (with get_theta) over F.reg[0..n): sums in member order, extents by wave reduction.  fromRing: the region
  * was just grown and has at most LSD_RING members, so the LDS mirror holds all of them (not after reduce_region_radius, which
  * reorders the list in HBM only).  A region of at most 64 members is fetched once and stays in registers for the three passes. */
@@ -345,7 +361,10 @@ __device__ __forceinline__ void to_rect(Wave& w, int n, double regAngle, double 
         cmx = (int)(xy & 0xFFFFu); cmy = (int)(xy >> 16);
         cmg = w.F.mod[(size_t)cmy * W + cmx];
     }
-    double x = 0, y = 0, sum = 0;
+    /* the order-defined sums: x += px[j], y += py[j], sum += mg[j] for j = 0 .. n - 1.  Three chains that do not touch each
+     * other: lanes 0, 1, 2 each walk one of them through LDS (one ds_read + one add per member for all three, against six
+     * lane broadcasts + three adds on the scalar path) */
+    double acc = 0;
     for (int base = 0; base < n; base += 64) {
         const int j = base + lane, cnt = min(64, n - base);
         double px = 0, py = 0, mg = 0;
@@ -359,18 +378,12 @@ __device__ __forceinline__ void to_rect(Wave& w, int n, double regAngle, double 
             }
             px = (double)mx * mg; py = (double)my * mg;
         }
-        /* the order-defined sums: one member after the other, four lane broadcasts in flight ahead of the additions */
-        int t = 0;
-        for (; t + 4 <= cnt; t += 4) {
-            const double a0 = rl_f64(px, t), a1 = rl_f64(px, t + 1), a2 = rl_f64(px, t + 2), a3 = rl_f64(px, t + 3);
-            const double b0 = rl_f64(py, t), b1 = rl_f64(py, t + 1), b2 = rl_f64(py, t + 2), b3 = rl_f64(py, t + 3);
-            const double c0 = rl_f64(mg, t), c1 = rl_f64(mg, t + 1), c2 = rl_f64(mg, t + 2), c3 = rl_f64(mg, t + 3);
-            x += a0; y += b0; sum += c0; x += a1; y += b1; sum += c1; x += a2; y += b2; sum += c2; x += a3; y += b3; sum += c3;
-        }
-        for (; t < cnt; t++) { x += rl_f64(px, t); y += rl_f64(py, t); sum += rl_f64(mg, t); }
+        acc = ordered_sums3(w, acc, px, py, mg, cnt);
     }
+    double x = rl_f64(acc, 0), y = rl_f64(acc, 1);
+    const double sum = rl_f64(acc, 2);
     x /= sum; y /= sum;
-    double Ixx = 0, Iyy = 0, Ixy = 0;
+    acc = 0;
     for (int base = 0; base < n; base += 64) {
         const int j = base + lane, cnt = min(64, n - base);
         double a = 0, b = 0, c = 0;
@@ -385,15 +398,9 @@ __device__ __forceinline__ void to_rect(Wave& w, int n, double regAngle, double 
             const double dx = (double)mx - x, dy = (double)my - y;
             a = dy * dy * mg; b = dx * dx * mg; c = dx * dy * mg;
         }
-        int t = 0;
-        for (; t + 4 <= cnt; t += 4) {
-            const double a0 = rl_f64(a, t), a1 = rl_f64(a, t + 1), a2 = rl_f64(a, t + 2), a3 = rl_f64(a, t + 3);
-            const double b0 = rl_f64(b, t), b1 = rl_f64(b, t + 1), b2 = rl_f64(b, t + 2), b3 = rl_f64(b, t + 3);
-            const double c0 = rl_f64(c, t), c1 = rl_f64(c, t + 1), c2 = rl_f64(c, t + 2), c3 = rl_f64(c, t + 3);
-            Ixx += a0; Iyy += b0; Ixy -= c0; Ixx += a1; Iyy += b1; Ixy -= c1; Ixx += a2; Iyy += b2; Ixy -= c2; Ixx += a3; Iyy += b3; Ixy -= c3;
-        }
-        for (; t < cnt; t++) { Ixx += rl_f64(a, t); Iyy += rl_f64(b, t); Ixy -= rl_f64(c, t); }
+        acc = ordered_sums3(w, acc, a, b, -c, cnt);                 /* Ixy -= c: adding -c is the same operation */
     }
+    const double Ixx = rl_f64(acc, 0), Iyy = rl_f64(acc, 1), Ixy = rl_f64(acc, 2);
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)drfe_fast_atan2((float)(lambda - Ixx), (float)Ixy)
                                            : (double)drfe_fast_atan2((float)Ixy, (float)(lambda - Iyy));
@@ -562,6 +569,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
     const int lane = w.lane, npx = W * H, nWords = (npx + 31) >> 5;
     w.bm = lds;
     w.ring = lds + ((nWords + 1) & ~1);
+    w.col = (double*)(w.ring + LSD_RING);
     /* bitmap: pixels without a level-line angle never join (NOTDEF, incl. the last row and column) */
     for (int base = 0; base < npx; base += 256) {
         bool nd[4];
@@ -613,21 +621,35 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         int from = 0;
         unsigned long long pend = __ballot(cand && nontrivial);
         PROF_ADD(1, ts0);
-        while (pend) {
+        /* the growing seeds of this chunk in groups of four: a group's windows are fetched while the group before it grows
+         * (the fields never change, so nothing a region does can invalidate them) */
+        auto take_group = [&](uint32_t& packed, int& cnt, Window& a0, Window& a1, Window& a2, Window& a3) {
+            int lk[4] = {0, 0, 0, 0};
+            cnt = 0;
+            while (pend && cnt < 4) { lk[cnt++] = __builtin_ctzll(pend); pend &= pend - 1; }
+            packed = (uint32_t)lk[0] | (uint32_t)lk[1] << 8 | (uint32_t)lk[2] << 16 | (uint32_t)lk[3] << 24;
+            if (cnt > 0) { a0 = load_window(w, rl_i32(sx, lk[0]), rl_i32(sy, lk[0])); a1 = a0; a2 = a0; a3 = a0; }
+            if (cnt > 1) a1 = load_window(w, rl_i32(sx, lk[1]), rl_i32(sy, lk[1]));
+            if (cnt > 2) a2 = load_window(w, rl_i32(sx, lk[2]), rl_i32(sy, lk[2]));
+            if (cnt > 3) a3 = load_window(w, rl_i32(sx, lk[3]), rl_i32(sy, lk[3]));
+        };
+        Window w0, w1, w2, w3, v0, v1, v2, v3;
+        w0.a = 0.0; w0.c = make_float2(0.f, 0.f); w0.s0 = w0.c; w1 = w0; w2 = w0; w3 = w0; v0 = w0; v1 = w0; v2 = w0; v3 = w0;
+        uint32_t packed = 0, packedNext = 0;
+        int cnt = 0, cntNext = 0;
+        {
+            const unsigned long long tw0 = PROF_T();
+            take_group(packed, cnt, w0, w1, w2, w3);
+            PROF_ADD(2, tw0);
+        }
+        while (cnt > 0) {
             const unsigned long long tw0 = PROF_T();
             PROF_CNT(9, 1);
-            /* the next (up to) four growing seeds: their windows fetched together */
-            int lk[4], cnt = 0;
-            while (pend && cnt < 4) { lk[cnt++] = __builtin_ctzll(pend); pend &= pend - 1; }
-            Window w0 = load_window(w, rl_i32(sx, lk[0]), rl_i32(sy, lk[0])), w1 = w0, w2 = w0, w3 = w0;
-            if (cnt > 1) w1 = load_window(w, rl_i32(sx, lk[1]), rl_i32(sy, lk[1]));
-            if (cnt > 2) w2 = load_window(w, rl_i32(sx, lk[2]), rl_i32(sy, lk[2]));
-            if (cnt > 3) w3 = load_window(w, rl_i32(sx, lk[3]), rl_i32(sy, lk[3]));
+            take_group(packedNext, cntNext, v0, v1, v2, v3);
 #ifdef LSD_PROFILE
-            if (w0.a + w1.a + w2.a + w3.a == 12345.678) w.status |= 4;         /* wait for the loads here */
+            if (w0.a + w1.a + w2.a + w3.a == 12345.678) w.status |= 4;         /* wait for this group's loads here */
 #endif
             PROF_ADD(2, tw0);
-            uint32_t packed = (uint32_t)lk[0] | (uint32_t)(cnt > 1 ? lk[1] : 0) << 8 | (uint32_t)(cnt > 2 ? lk[2] : 0) << 16 | (uint32_t)(cnt > 3 ? lk[3] : 0) << 24;
             for (int k = 0; k < cnt; k++) {
                 const int f = (int)(packed & 0xFFu);
                 packed >>= 8;
@@ -657,6 +679,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
                 }
                 w0 = w1; w1 = w2; w2 = w3;
             }
+            w0 = v0; w1 = v1; w2 = v2; w3 = v3; packed = packedNext; cnt = cntNext;
         }
         if (cand && !nontrivial && lane >= from && !w.bit(q)) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
     }
@@ -703,7 +726,7 @@ __global__ __launch_bounds__(256) void k_lsd_keys(const double* __restrict__ mod
 size_t drfe_lsd_grow_lds_bytes(int W, int H)
 {
     const size_t nWords = ((size_t)W * H + 31) >> 5;
-    return (((nWords + 1) & ~(size_t)1) + LSD_RING) * 4;
+    return (((nWords + 1) & ~(size_t)1) + LSD_RING) * 4 + 64 * 3 * sizeof(double);
 }
 
 hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
