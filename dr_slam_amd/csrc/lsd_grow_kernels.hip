@@ -262,12 +262,15 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
 #endif
         classes();
         unsigned long long mask = __ballot(want), joined = 0;
-        while (mask) {
-            const int l = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            bool al;
-            if (!((qunc >> l) & 1ull)) al = (qin >> l) & 1ull;
-            else {
+        for (;;) {
+            /* the next lane whose pixel joins, or may: the free ones before it are certainly not aligned with the direction as
+             * it stands, and it only moves at a join - they have had their turn */
+            const unsigned long long todo = mask & (qin | qunc);
+            if (!todo) break;
+            const int l = __builtin_ctzll(todo);
+            mask &= ~((2ull << l) - 1ull);
+            bool al = true;
+            if ((qunc >> l) & 1ull) {
                 if (CHEAP) PROF_CNT(14, 1);
                 const double av = CHEAP ? uni_d(w.F.ang[rl_u32(q, l)]) : rl_f64(a, l);
                 al = uni(aligned_with(angle_now(), av, prec));
@@ -624,17 +627,22 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         /* the growing seeds of this chunk in groups of four: a group's windows are fetched while the group before it grows
          * (the fields never change, so nothing a region does can invalidate them) */
         auto take_group = [&](uint32_t& packed, int& cnt, Window& a0, Window& a1, Window& a2, Window& a3) {
-            int lk[4] = {0, 0, 0, 0};
+            /* always four fetches, the unused ones at the first seed again (cache hits): no branch around a load, so nothing
+             * merges with a value in flight and the wavefront waits only where a window is used */
+            int lk[4];
             cnt = 0;
-            while (pend && cnt < 4) { lk[cnt++] = __builtin_ctzll(pend); pend &= pend - 1; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                lk[u] = pend ? __builtin_ctzll(pend) : (u ? lk[0] : 0);
+                if (pend) { cnt++; pend &= pend - 1; }
+            }
             packed = (uint32_t)lk[0] | (uint32_t)lk[1] << 8 | (uint32_t)lk[2] << 16 | (uint32_t)lk[3] << 24;
-            if (cnt > 0) { a0 = load_window(w, rl_i32(sx, lk[0]), rl_i32(sy, lk[0])); a1 = a0; a2 = a0; a3 = a0; }
-            if (cnt > 1) a1 = load_window(w, rl_i32(sx, lk[1]), rl_i32(sy, lk[1]));
-            if (cnt > 2) a2 = load_window(w, rl_i32(sx, lk[2]), rl_i32(sy, lk[2]));
-            if (cnt > 3) a3 = load_window(w, rl_i32(sx, lk[3]), rl_i32(sy, lk[3]));
+            a0 = load_window(w, rl_i32(sx, lk[0]), rl_i32(sy, lk[0]));
+            a1 = load_window(w, rl_i32(sx, lk[1]), rl_i32(sy, lk[1]));
+            a2 = load_window(w, rl_i32(sx, lk[2]), rl_i32(sy, lk[2]));
+            a3 = load_window(w, rl_i32(sx, lk[3]), rl_i32(sy, lk[3]));
         };
         Window w0, w1, w2, w3, v0, v1, v2, v3;
-        w0.a = 0.0; w0.c = make_float2(0.f, 0.f); w0.s0 = w0.c; w1 = w0; w2 = w0; w3 = w0; v0 = w0; v1 = w0; v2 = w0; v3 = w0;
         uint32_t packed = 0, packedNext = 0;
         int cnt = 0, cntNext = 0;
         {
