@@ -32,7 +32,9 @@
 #include <cstdlib>
 
 #ifndef LSD_RING
-#define LSD_RING 512          /* newest members mirrored in LDS */
+#define LSD_RING 128          /* newest members mirrored in LDS.  With 128 a 512 x 384 frame needs 26 624 bytes of LDS and SIX frames
+                               * fit a CU (the allocation granule is 1280 bytes: 512 entries = 28 160 bytes = five per CU, and so
+                               * is 256); one call of 3072 frames: 6 195 -> 7 062 frames/s */
 #endif
 #ifdef LSD_PROFILE
 #define PROF_T() wall_clock64()
