@@ -62,7 +62,7 @@ struct Ctx {
     GLOBAL_AS int* dsParent; GLOBAL_AS int* dsSize; GLOBAL_AS int* G; GLOBAL_AS int* blkMap; GLOBAL_AS int* ridToPlid;
     GLOBAL_AS int16_t* mem; GLOBAL_AS float* dist; GLOBAL_AS uint32_t* rf;
     /* LDS */
-    float* heapKey; uint16_t* heapId; int* lA; int* lB; int* lU; double* win;
+    float* heapKey; uint16_t* heapId; uint16_t* lA; uint16_t* lB; uint16_t* lU; double* win;      /* node ids are below 2 NB + 256 = 6400 */
     int heapSize, nNodes, poolUsed, status, lane;
     AhcDevParams P;
 };
@@ -219,7 +219,7 @@ __device__ double t_ang_init(Ctx& c, double z)
 }
 
 /* disconnectAll(p) for the staged list lX of length len (the neighbours of p): every neighbour drops p; lane per neighbour */
-__device__ __forceinline__ void disconnect_staged(Ctx& c, const int* lX, int len, int p)
+__device__ __forceinline__ void disconnect_staged(Ctx& c, const uint16_t* lX, int len, int p)
 {
     for (int k = c.lane; k < len; k += 64) list_erase(c, lX[k], p);
     fence();
@@ -239,7 +239,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         const int Lp = uni_i(lenP);
         if (Lp > AHCD_LIST) { c.status |= 2; return; }
         const GLOBAL_AS int* listP = c.pool + c.nbOff[p];
-        for (int k = lane; k < Lp; k += 64) c.lA[k] = listP[k];
+        for (int k = lane; k < Lp; k += 64) c.lA[k] = (uint16_t)listP[k];
         double Sp[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) Sp[k] = c.S[9 * (size_t)p + k];
@@ -291,7 +291,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 c.win[15] = f.mse; c.win[16] = f.curvature;
                 ((int*)(c.win + 17))[0] = Nn; ((int*)(c.win + 17))[1] = ridN;
 #pragma unroll
-                for (int q = 0; q < 8; q++) c.lB[q] = nbHead[q];
+                for (int q = 0; q < 8; q++) c.lB[q] = (uint16_t)nbHead[q];
             }
         }
         bool merge = false;
@@ -320,7 +320,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             c.heapSize = uni_i(c.heapSize);
             if (Lc > 8) {                                       /* the winner parked the first eight: the rest of a long list */
                 const GLOBAL_AS int* listC = c.pool + c.nbOff[candNb];
-                for (int k = 8 + lane; k < Lc; k += 64) c.lB[k] = listC[k];
+                for (int k = 8 + lane; k < Lc; k += 64) c.lB[k] = (uint16_t)listC[k];
             }
             fence();
             /* u = nbs(p) U nbs(cand) \ {p, cand}, sorted.  Short lists (the rule): lane i holds one element of A ++ B; it is kept
@@ -342,7 +342,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                     const int o = rl_i(v, l);
                     if (((km >> l) & 1ull) && o < v) smaller++;
                 }
-                if (keep) c.lU[smaller] = v;
+                if (keep) c.lU[smaller] = (uint16_t)v;
                 Lu = __popcll(km);
             } else if (lane == 0) {
                 int i = 0, j = 0;
@@ -351,7 +351,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                     if (j >= Lc || (i < Lp && c.lA[i] < c.lB[j])) v = c.lA[i++];
                     else if (i >= Lp || c.lB[j] < c.lA[i]) v = c.lB[j++];
                     else { v = c.lA[i]; i++; j++; }
-                    if (v != p && v != candNb) c.lU[Lu++] = v;
+                    if (v != p && v != candNb) c.lU[Lu++] = (uint16_t)v;
                 }
             }
             Lu = uni_i(Lu);
@@ -397,7 +397,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
 {
     __shared__ float heapKey[AHCD_HEAP];
     __shared__ uint16_t heapId[AHCD_HEAP];
-    __shared__ int lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
+    __shared__ uint16_t lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
     __shared__ double win[18];
     __shared__ int ex[AHCD_MAXEX];
     __shared__ uint8_t isValid[AHCD_MAXEX];
@@ -595,7 +595,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
 {
     __shared__ float heapKey[AHCD_MAXEX];                     /* the re-merge's queue: at most the extracted planes */
     __shared__ uint16_t heapId[AHCD_MAXEX];
-    __shared__ int lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
+    __shared__ uint16_t lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
     __shared__ double win[18];
     __shared__ int ex[AHCD_MAXEX], ex2[AHCD_MAXEX], plidmap[AHCD_MAXEX];
     __shared__ uint8_t isValid[AHCD_MAXEX];

@@ -28,7 +28,10 @@
  * 256 for a plane's voxel records - a workgroup's LDS is 128 bytes per thread for the counting passes plus the range queue, and
  * a 1024-thread sort fills a CU's LDS alone (no other kernel's wavefronts beside it) */
 #define ORD_BIG 8192             /* ranges above this many records: one at a time by the whole workgroup */
-#define ORD_QCAP 1024            /* pending ranges an array can hold (LDS) */
+#define ORD_QCAP 256             /* pending ranges an array can hold (LDS, 12 bytes each).  A workgroup partition leaves at most two and the
+                                  * wavefront phase adds none: ~2 n / ORD_BIG entries for keys that split evenly (48 for a frame's
+                                  * 196 000 pixels); with 1024 entries a sort held 47.5 KB of LDS - three per CU - with 256 it is
+                                  * 38.3 KB, four per CU.  An overflow flags the array for the host. */
 #define ORD_STACK 48             /* depth-first stack of a wavefront (>= the depth limit 2 lg n of any array that fits) */
 #define ORD_DYN_LDS_BYTES(NTH) (32 * (NTH) * 4)
 #define ORD_HEAP_MAX 1024        /* longest range one lane heap-sorts (about 20 000 dependent moves) */

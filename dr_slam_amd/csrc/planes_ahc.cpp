@@ -805,6 +805,7 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
         AhcDevParams& P = a->P;
         P.w = w; P.h = h; P.Nw = Nw; P.Nh = Nh; P.NB = NB;
         P.maxNodes = 2 * NB + 256; P.poolCap = 1 << 19; P.rfCap = 1 << 20; P.planeCap = AHC_DEV_PLANE_CAP;
+        if (P.maxNodes > 65535) { c->ahcArena = nullptr; delete a; c->err = "planes: the device extractor keeps node ids in 16 bits (frame too large)"; return DRFE_ERR_INVALID; }
         /* per-slot layout, every array 256-byte aligned */
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
