@@ -51,7 +51,7 @@ template <int NTH>
 struct Shared {
     Seg queue[ORD_QCAP];
     Seg stack[NTH / 64][ORD_STACK];
-    int qHead, qTail, qOverflow, heapNeeded, wcnt[NTH / 64 + 2];
+    int qHead, qTail, qOverflow, heapNeeded, wcnt[4 * (NTH / 64) + 2];
     uint32_t cutShared;
     unsigned long long tp;          /* profiling builds: thread 0's last phase mark */
 };
@@ -120,6 +120,44 @@ __device__ __forceinline__ void heap_sort_range(RecPtr a, uint32_t first, uint32
     }
 }
 
+/* std::__introsort_loop on a[first, last), at most ORD_TINY records, by ONE LANE (every lane of the wavefront its own range, side
+ * by side): median-of-three, the textbook __unguarded_partition, the right part parked while the left one is finished.  With at
+ * most 64 records three parts wait at most (every parked part has 17 records or more and the part being split at least one
+ * more: a fourth needs 69).  Returns false if that bound failed (never: the caller flags the array). */
+#define ORD_TINY 64
+template <class T, class RecPtr>
+__device__ __forceinline__ bool lane_introsort(RecPtr a, uint32_t first, uint32_t last, int depth)
+{
+    uint32_t e0 = 0, e1 = 0, e2 = 0;           /* parked ranges: first | last << 11 | depth << 22 */
+    int sp = 0;
+    for (;;) {
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort_range<T>(a, first, last); break; }
+            depth--;
+            median_to_first<T>(a, first, first + 1, first + (last - first) / 2, last - 1);
+            const uint32_t pk = T::key(a[first]);
+            uint32_t i = first + 1, j = last;
+            for (;;) {
+                while (T::key(a[i]) < pk) i++;
+                j--;
+                while (pk < T::key(a[j])) j--;
+                if (!(i < j)) break;
+                const typename T::Rec x = a[i], y = a[j];
+                a[i] = y; a[j] = x;
+                i++;
+            }
+            if (last - i > 16) {
+                if (sp >= 3) return false;
+                e2 = e1; e1 = e0; e0 = i | last << 11 | (uint32_t)depth << 22; sp++;
+            }
+            last = i;
+        }
+        if (sp == 0) return true;
+        first = e0 & 0x7FFu; last = (e0 >> 11) & 0x7FFu; depth = (int)(e0 >> 22);
+        e0 = e1; e1 = e2; sp--;
+    }
+}
+
 /* std::__unguarded_partition(a + first + 1, a + last, a + first) by a group of NT threads (64: one wavefront; NTH: the
  * workgroup).  tid = thread index inside the group.  posL / posR: scratch of the range's length at [first, last).  wcnt: LDS,
  * NT / 64 + 2 ints (workgroup variant).  Returns the cut to every thread. */
@@ -172,41 +210,77 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
             }
         }
     } else {
-        for (uint32_t base = lo; base < hi; base += NT) {
-            const uint32_t p = base + tid;
-            const bool f = p < hi && !(T::key(a[p < hi ? p : lo]) < pk);
-            uint32_t tot;
-            const uint32_t r = block_rank(f, tot);
-            if (f) posL[first + cntL + r] = p;
-            cntL += tot;
+        /* the workgroup: four blocks of NT per round - their loads in flight together and ONE pair of barriers for the four
+         * (a round is a chain load -> ballot -> barrier -> LDS -> barrier -> store, ~1 us whatever it carries) */
+        constexpr int NWV = NT / 64;
+        for (uint32_t base = lo; base < hi; base += 4 * NT) {
+            bool f[4];
+            unsigned long long mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t p = base + NT * u + tid; f[u] = p < hi && !(T::key(a[p < hi ? p : lo]) < pk); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) mk[u] = __ballot(f[u]);
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) wcnt[u * NWV + wv] = __popcll(mk[u]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t before_ = 0, all = 0;
+                for (int k = 0; k < NWV; k++) { const uint32_t c = (uint32_t)wcnt[u * NWV + k]; if (k < wv) before_ += c; all += c; }
+                if (f[u]) posL[first + cntL + before_ + (uint32_t)__popcll(mk[u] & lt)] = base + NT * u + tid;
+                cntL += all;
+            }
         }
-        for (uint32_t off = 0; lo + off < hi; off += NT) {
-            const uint32_t back = off + tid;
-            const bool in = back < hi - lo;
-            const uint32_t p = hi - 1 - (in ? back : 0);
-            const bool f = in && !(pk < T::key(a[p]));
-            uint32_t tot;
-            const uint32_t r = block_rank(f, tot);
-            if (f) posR[first + cntR + r] = p;
-            cntR += tot;
+        for (uint32_t off = 0; lo + off < hi; off += 4 * NT) {
+            bool f[4];
+            unsigned long long mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t back = off + NT * u + tid; const bool in = back < hi - lo; f[u] = in && !(pk < T::key(a[hi - 1 - (in ? back : 0)])); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) mk[u] = __ballot(f[u]);
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) wcnt[u * NWV + wv] = __popcll(mk[u]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t before_ = 0, all = 0;
+                for (int k = 0; k < NWV; k++) { const uint32_t c = (uint32_t)wcnt[u * NWV + k]; if (k < wv) before_ += c; all += c; }
+                if (f[u]) posR[first + cntR + before_ + (uint32_t)__popcll(mk[u] & lt)] = hi - 1 - (off + NT * u + tid);
+                cntR += all;
+            }
         }
     }
     group_sync();
     /* K = pairs still in order: a prefix of the rank order */
     const uint32_t m = cntL < cntR ? cntL : cntR;
-    uint32_t K = 0;
-    for (uint32_t base = 0; base < m; base += NT) {
-        const uint32_t k = base + tid;
-        const bool f = k < m && posL[first + k] < posR[first + k];
-        uint32_t tot;
-        (void)block_rank(f, tot);
-        K += tot;
-        if (tot < (uint32_t)NT && base + NT < m) break;                   /* the prefix ended inside this block */
+    /* "the k-th left stopper lies left of the k-th right stopper" holds for a prefix of k (one list ascends, the other descends):
+     * its length by an NT-ary search, log_NT(m) rounds of one probe per thread */
+    uint32_t klo = 0, khi = m;
+    while (klo < khi) {
+        const uint32_t span = khi - klo, step = (span + NT - 1) / NT, np = (span + step - 1) / step;
+        const uint32_t k = klo + (uint32_t)tid * step;
+        const bool f = k < khi && posL[first + k] < posR[first + k];
+        uint32_t c;
+        (void)block_rank(f, c);
+        const uint32_t nlo = c > 0 ? klo + (c - 1) * step + 1 : klo, nhi = c < np ? klo + c * step : khi;
+        klo = nlo; khi = nhi;
     }
-    for (uint32_t k = tid; k < K; k += NT) {
-        const uint32_t pl = posL[first + k], pr = posR[first + k];
-        const typename T::Rec x = a[pl], y = a[pr];
-        a[pl] = y; a[pr] = x;
+    const uint32_t K = klo;
+    for (uint32_t k0 = tid; k0 < K; k0 += 4 * NT) {
+        uint32_t pl[4], pr[4];
+        typename T::Rec x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t k = k0 + NT * u; const bool in = k < K; pl[u] = in ? (uint32_t)posL[first + k] : first; pr[u] = in ? (uint32_t)posR[first + k] : first; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { x[u] = a[pl[u]]; y[u] = a[pr[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (k0 + NT * u < K) { a[pl[u]] = y[u]; a[pr[u]] = x[u]; }
     }
     const uint32_t l = K < cntL ? (uint32_t)posL[first + K] : hi, r = K > 0 ? (uint32_t)posR[first + K - 1] : hi;
     group_sync();
@@ -271,10 +345,15 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
      * wavefront's share of the dynamic LDS (records + 16-bit stopper positions) and is partitioned there down to the ranges of 16:
      * the partitions of small ranges are chains of dependent accesses, a few per range, and most ranges are small ---- */
     constexpr uint32_t LBYTES = ORD_DYN_LDS_BYTES(NTH) / (NTH / 64);
-    constexpr uint32_t LCAP = LBYTES / (sizeof(Rec) + 4);
+    constexpr uint32_t LCAP = (LBYTES - 256) / (sizeof(Rec) + 4);
+    static_assert(LCAP < 2048, "lane_introsort packs positions into 11 bits");
     Rec* lrec = (Rec*)((uint8_t*)dyn + (size_t)wv * LBYTES);
     uint16_t* lposL = (uint16_t*)(lrec + LCAP);
     uint16_t* lposR = lposL + LCAP;
+    /* ranges of at most ORD_TINY records met inside the LDS block: not partitioned by the wavefront (a partition is a chain of a
+     * few dependent LDS accesses whatever its size, and three partitions in four are of such ranges) but listed here, and when the
+     * block's larger ranges are done every lane finishes one of them on its own (lane_introsort) */
+    uint32_t* tiny = (uint32_t*)((uint8_t*)dyn + (size_t)wv * LBYTES + LBYTES - 256);
     uint32_t waveIter = 0;
     const uint32_t waveMax = 8u * (uint32_t)n + 4096u;           /* partitions one wavefront can legitimately run: far fewer */
     bool runaway = false;
@@ -302,10 +381,16 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                     for (uint32_t i = lane; i < m; i += 64) lrec[i] = a[s.first + i];
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     const int base = sp;
+                    int ntiny = 0;
                     Seg t; t.first = 0; t.last = m; t.depth = s.depth;
                     for (; !runaway;) {
                         while (t.last - t.first > 16) {
                             if (++waveIter > waveMax) { if (lane == 0) sh.qOverflow |= 16; runaway = true; break; }
+                            if (t.last - t.first <= ORD_TINY && ntiny < 64) {
+                                if (lane == 0) tiny[ntiny] = t.first | t.last << 11 | (uint32_t)t.depth << 22;
+                                ntiny++;
+                                break;
+                            }
                             if (t.depth == 0) {
                                 if (lane == 0) heap_sort_range<T>(lrec, t.first, t.last);
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -326,6 +411,11 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                         if (sp == base) break;
                         sp--;
                         t = sh.stack[wv][sp];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    if (lane < ntiny) {
+                        const uint32_t e = tiny[lane];
+                        if (!lane_introsort<T>(lrec, e & 0x7FFu, (e >> 11) & 0x7FFu, (int)(e >> 22))) sh.qOverflow |= 32;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     for (uint32_t i = lane; i < m; i += 64) a[s.first + i] = lrec[i];

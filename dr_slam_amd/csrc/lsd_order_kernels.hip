@@ -7,6 +7,11 @@
  * the host).  One workgroup of 1024 threads per frame; keys and results stay in HBM, the device region growing reads them there. */
 #include "drfe_internal.h"
 #include "lines_internal.h"
+#ifdef ORD_PROFILE
+/* phase times summed over frames (100 MHz ticks of thread 0): 0 workgroup partitions, 1 wavefront phase, 2 counting passes, 3 = frames */
+__device__ unsigned long long g_ordProf[4];
+#define ISD_TP(k) do { if (threadIdx.x == 0) { const unsigned long long t__ = wall_clock64(); atomicAdd(&g_ordProf[k], t__ - sh.tp); sh.tp = t__; } } while (0)
+#endif
 #include "introsort_device.h"
 #ifndef ORD_T
 #define ORD_T 256
@@ -30,6 +35,9 @@ extern "C" __global__ __launch_bounds__(ORD_T) void k_lsd_order(uint32_t* __rest
     uint32_t* a = keysBase + keyStride * blockIdx.x;
     uint32_t* posL = posLBase + posStride * blockIdx.x;
     uint32_t* posR = posRBase + posStride * blockIdx.x;
+#ifdef ORD_PROFILE
+    if (threadIdx.x == 0) { sh.tp = wall_clock64(); atomicAdd(&g_ordProf[3], 1ull); }
+#endif
     /* the counting passes ping-pong between the keys and posL: ten key bits = two passes, the result lands in the keys */
     const int st = isd::sort<ORD_T, LsdKeyTraits>(a, n, posL, posR, posL, dyn, sh, depthLimit, 10);
     if (threadIdx.x == 0) statusBase[(size_t)statusStride * blockIdx.x] = st;
@@ -51,3 +59,12 @@ hipError_t drfe_launch_lsd_order(uint32_t* d_keys, size_t keyStride, int n, uint
                        statusStride, depthOverride >= 0 ? depthOverride : 2 * lg);       /* the override: tests of the heap-sort branch */
     return hipGetLastError();
 }
+
+#ifdef ORD_PROFILE
+extern "C" int drfe_debug_order_profile(unsigned long long* out4)
+{
+    unsigned long long z[4] = {0};
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ordProf), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ordProf), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
