@@ -41,6 +41,12 @@
 #ifndef ISD_TP
 #define ISD_TP(k)
 #endif
+/* wavefront-phase split of a profiling build (wavefront 0 only): ISD_WT0() marks, ISD_WT(k) adds the time since the mark to slot k
+ * (0 partitions in HBM, 1 copy into LDS, 2 wavefront partitions in LDS, 3 one range per lane, 4 copy back) and marks again */
+#ifndef ISD_WT
+#define ISD_WT0()
+#define ISD_WT(k)
+#endif
 
 namespace isd {
 
@@ -122,13 +128,18 @@ __device__ __forceinline__ void heap_sort_range(RecPtr a, uint32_t first, uint32
 
 /* std::__introsort_loop on a[first, last), at most ORD_TINY records, by ONE LANE (every lane of the wavefront its own range, side
  * by side): median-of-three, the textbook __unguarded_partition, the right part parked while the left one is finished.  With at
- * most 64 records three parts wait at most (every parked part has 17 records or more and the part being split at least one
- * more: a fourth needs 69).  Returns false if that bound failed (never: the caller flags the array). */
+ * most ORD_TINY records (ORD_TINY + 16) / 17 parts wait at most (every parked part has 17 records or more and the part being split
+ * at least one more).  Returns false if that bound failed (never: the caller flags the array). */
+#ifndef ORD_TINY
 #define ORD_TINY 64
+#endif
+#define ORD_TINY_STACK ((ORD_TINY + 16) / 17)
 template <class T, class RecPtr>
 __device__ __forceinline__ bool lane_introsort(RecPtr a, uint32_t first, uint32_t last, int depth)
 {
-    uint32_t e0 = 0, e1 = 0, e2 = 0;           /* parked ranges: first | last << 11 | depth << 22 */
+    uint32_t e[ORD_TINY_STACK];                /* parked ranges: first | last << 11 | depth << 22; e[0] = the newest (static indices only) */
+#pragma unroll
+    for (int k = 0; k < ORD_TINY_STACK; k++) e[k] = 0;
     int sp = 0;
     for (;;) {
         while (last - first > 16) {
@@ -147,14 +158,18 @@ __device__ __forceinline__ bool lane_introsort(RecPtr a, uint32_t first, uint32_
                 i++;
             }
             if (last - i > 16) {
-                if (sp >= 3) return false;
-                e2 = e1; e1 = e0; e0 = i | last << 11 | (uint32_t)depth << 22; sp++;
+                if (sp >= ORD_TINY_STACK) return false;
+#pragma unroll
+                for (int k = ORD_TINY_STACK - 1; k > 0; k--) e[k] = e[k - 1];
+                e[0] = i | last << 11 | (uint32_t)depth << 22; sp++;
             }
             last = i;
         }
         if (sp == 0) return true;
-        first = e0 & 0x7FFu; last = (e0 >> 11) & 0x7FFu; depth = (int)(e0 >> 22);
-        e0 = e1; e1 = e2; sp--;
+        first = e[0] & 0x7FFu; last = (e[0] >> 11) & 0x7FFu; depth = (int)(e[0] >> 22);
+#pragma unroll
+        for (int k = 0; k + 1 < ORD_TINY_STACK; k++) e[k] = e[k + 1];
+        sp--;
     }
 }
 
@@ -355,6 +370,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
      * block's larger ranges are done every lane finishes one of them on its own (lane_introsort) */
     uint32_t* tiny = (uint32_t*)((uint8_t*)dyn + (size_t)wv * LBYTES + LBYTES - 256);
     uint32_t waveIter = 0;
+    unsigned long long wtMark = 0; (void)wtMark;         /* profiling builds */
     const uint32_t waveMax = 8u * (uint32_t)n + 4096u;           /* partitions one wavefront can legitimately run: far fewer */
     bool runaway = false;
     for (; !runaway;) {
@@ -378,8 +394,10 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                     break;
                 }
                 if (m <= LCAP) {
+                    ISD_WT0();
                     for (uint32_t i = lane; i < m; i += 64) lrec[i] = a[s.first + i];
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    ISD_WT(1);
                     const int base = sp;
                     int ntiny = 0;
                     Seg t; t.first = 0; t.last = m; t.depth = s.depth;
@@ -413,18 +431,23 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                         t = sh.stack[wv][sp];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    ISD_WT(2);
                     if (lane < ntiny) {
                         const uint32_t e = tiny[lane];
                         if (!lane_introsort<T>(lrec, e & 0x7FFu, (e >> 11) & 0x7FFu, (int)(e >> 22))) sh.qOverflow |= 32;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    ISD_WT(3);
                     for (uint32_t i = lane; i < m; i += 64) a[s.first + i] = lrec[i];
+                    ISD_WT(4);
                     break;
                 }
                 s.depth--;
+                ISD_WT0();
                 if (lane == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 const uint32_t cut = hoare_cut<64, T>(a, s.first, s.last, posL, posR, lane, nullptr);
+                ISD_WT(0);
                 if (s.last - cut > 16) {
                     if (sp < ORD_STACK) {
                         if (lane == 0) { sh.stack[wv][sp].first = cut; sh.stack[wv][sp].last = s.last; sh.stack[wv][sp].depth = s.depth; }

@@ -101,8 +101,12 @@ struct Hyp {
     NfaVal best;
     int pj, stage;
 };
+#ifndef NFA_MAXQ
 #define NFA_MAXQ 12                        /* hypotheses per rectangle (queued + explored) */
+#endif
+#ifndef NFA_MAXLIVE
 #define NFA_MAXLIVE 6                      /* hypotheses alive inside one stage's selection */
+#endif
 
 #define NFA_RECTS 12                       /* rectangles per wavefront: 12 x 5 candidate lanes */
 struct ImproveShared {                     /* one rectangle's slot */

@@ -9,7 +9,9 @@
 #include "lines_internal.h"
 #ifdef ORD_PROFILE
 /* phase times summed over frames (100 MHz ticks of thread 0): 0 workgroup partitions, 1 wavefront phase, 2 counting passes, 3 = frames */
-__device__ unsigned long long g_ordProf[4];
+__device__ unsigned long long g_ordProf[4], g_ordWave[5];
+#define ISD_WT0() do { if (threadIdx.x == 0) wtMark = wall_clock64(); } while (0)
+#define ISD_WT(k) do { if (threadIdx.x == 0) { const unsigned long long t__ = wall_clock64(); atomicAdd(&g_ordWave[k], t__ - wtMark); wtMark = t__; } } while (0)
 #define ISD_TP(k) do { if (threadIdx.x == 0) { const unsigned long long t__ = wall_clock64(); atomicAdd(&g_ordProf[k], t__ - sh.tp); sh.tp = t__; } } while (0)
 #endif
 #include "introsort_device.h"
@@ -61,10 +63,12 @@ hipError_t drfe_launch_lsd_order(uint32_t* d_keys, size_t keyStride, int n, uint
 }
 
 #ifdef ORD_PROFILE
-extern "C" int drfe_debug_order_profile(unsigned long long* out4)
+extern "C" int drfe_debug_order_profile(unsigned long long* out9)
 {
-    unsigned long long z[4] = {0};
-    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ordProf), sizeof(z)) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_ordProf), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    unsigned long long z[5] = {0};
+    if (hipMemcpyFromSymbol(out9, HIP_SYMBOL(g_ordProf), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out9 + 4, HIP_SYMBOL(g_ordWave), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ordWave), z, sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ordProf), z, 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -10,10 +10,11 @@ gray = np.stack([base[i][0] for i in order])
 ctx = lib.Context(max_batch=1)
 ctx.lsd_extract_batch(gray, n_threads=2)
 L = ctypes.CDLL(os.environ["DRFE_LIB"])
-out = (ctypes.c_ulonglong * 4)()
+out = (ctypes.c_ulonglong * 9)()
 L.drfe_debug_order_profile(out)
 ctx.lsd_extract_batch(gray, n_threads=2)
 L.drfe_debug_order_profile(out)
 v = list(out)
 print("k_lsd_order, per frame (ms of the workgroup): workgroup partitions %.2f, wavefront phase %.2f, counting passes %.2f; %d frames" % (v[0] / 1e5 / v[3], v[1] / 1e5 / v[3], v[2] / 1e5 / v[3], v[3]))
+print("  wavefront 0 of each frame (ms): partitions in HBM %.2f, copy into LDS %.2f, wavefront partitions in LDS %.2f, one range per lane %.2f, copy back %.2f" % tuple(x / 1e5 / v[3] for x in v[4:9]))
 ctx.close()
