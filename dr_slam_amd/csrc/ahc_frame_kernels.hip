@@ -41,7 +41,9 @@ __device__ __forceinline__ double rl_d(double v, int l)
 }
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool uni_b(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
-__device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+/* one wavefront per workgroup: what a lane stores and another lane loads later goes through the same in-order memory pipeline, so
+ * the fences between the steps are wavefront-scope - the compiler keeps the order, the hardware has nothing to wait for */
+__device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 /* ordering between the LDS accesses of this one wavefront: the LDS serves a wavefront's instructions in order, so only the compiler
  * must not move them - no wait for the global stores in flight (the workgroup fence waits for those: ~1 us each) */
 __device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
@@ -388,7 +390,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             while (j > 0 && c.N[ex[j - 1]] < nv) { ex[j] = ex[j - 1]; j--; }
             ex[j] = v;
         }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    fence();
 }
 
 } // namespace

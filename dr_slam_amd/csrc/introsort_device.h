@@ -13,6 +13,9 @@
  *     still in order, and the K swaps are independent;
  *   - the final insertion sort moves a record left past records it goes before only - it is the stable sort of what the
  *     partitions left: stable counting passes over five key bits each.
+ *   - what one wavefront writes and reads back (a range it owns, in HBM or LDS) needs no wait: a wavefront's memory operations
+ *     are performed in order, so the fences between its steps are wavefront-scope (compiler ordering only); data changes hands
+ *     between wavefronts at the workgroup barriers only.
  *   - a range that exhausts the depth limit is heap-sorted the way libstdc++ does it (std::__partial_sort(first, last, last) =
  *     std::__make_heap + std::__sort_heap, every __adjust_heap / __push_heap move in its order) by ONE lane: the moves of a heap
  *     sort are one dependent chain.  On the data this serves such ranges are a few dozen records (25 on the synthetic planes
@@ -183,7 +186,7 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
     const uint32_t pk = T::key(a[first]);
     const int lane = tid & 63, wv = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    auto group_sync = [&]() { if (NT > 64) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); };
+    auto group_sync = [&]() { if (NT > 64) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); };
     /* exclusive rank of a flagged thread inside the group's block + the block's total */
     auto block_rank = [&](bool f, uint32_t& total) -> uint32_t {
         const unsigned long long m = __ballot(f);
@@ -389,14 +392,14 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                     if (m > ORD_HEAP_MAX) { if (lane == 0) sh.heapNeeded = 1; }
                     else {
                         if (lane == 0) heap_sort_range<T>(a, s.first, s.last);
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     }
                     break;
                 }
                 if (m <= LCAP) {
                     ISD_WT0();
                     for (uint32_t i = lane; i < m; i += 64) lrec[i] = a[s.first + i];
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     ISD_WT(1);
                     const int base = sp;
                     int ntiny = 0;
@@ -411,12 +414,12 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                             }
                             if (t.depth == 0) {
                                 if (lane == 0) heap_sort_range<T>(lrec, t.first, t.last);
-                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                                 break;
                             }
                             t.depth--;
                             if (lane == 0) median_to_first<T>(lrec, t.first, t.first + 1, t.first + (t.last - t.first) / 2, t.last - 1);
-                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                             const uint32_t cut = hoare_cut<64, T>(lrec, t.first, t.last, lposL, lposR, lane, nullptr);
                             if (t.last - cut > 16) {
                                 if (sp < ORD_STACK) {
@@ -430,13 +433,13 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                         sp--;
                         t = sh.stack[wv][sp];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     ISD_WT(2);
                     if (lane < ntiny) {
                         const uint32_t e = tiny[lane];
                         if (!lane_introsort<T>(lrec, e & 0x7FFu, (e >> 11) & 0x7FFu, (int)(e >> 22))) sh.qOverflow |= 32;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     ISD_WT(3);
                     for (uint32_t i = lane; i < m; i += 64) a[s.first + i] = lrec[i];
                     ISD_WT(4);
@@ -445,7 +448,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
                 s.depth--;
                 ISD_WT0();
                 if (lane == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 const uint32_t cut = hoare_cut<64, T>(a, s.first, s.last, posL, posR, lane, nullptr);
                 ISD_WT(0);
                 if (s.last - cut > 16) {

@@ -62,7 +62,9 @@ __device__ __forceinline__ double uni_d(double v)
 {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
-__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+/* between a store and a load of the same address by different lanes of THIS wavefront (the only one of its workgroup): a
+ * wavefront's memory operations are performed in order, so the compiler must keep the order and the hardware has nothing to wait for */
+__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 /* the frame's arrays as GLOBAL-address-space pointers: pointers read from the frame table are generic to the compiler, and a
  * generic (flat) store counts against the LDS counter as well - every member appended would stall the next bitmap read for a
