@@ -48,6 +48,40 @@ __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CS
  * must not move them - no wait for the global stores in flight (the workgroup fence waits for those: ~1 us each) */
 __device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
+
+/* Chains of lanes that target the same pixel, in lane (= visiting) order, for the flood fill: every live lane gets the previous
+ * lane with its pixel (-1: none), its depth in the chain and whether it is the last.  The 64 keys pixel << 6 | lane are sorted
+ * across the wavefront by a bitonic network (21 compare-exchange stages; a dead lane's key sorts behind every live one and is
+ * its own pixel), runs of equal pixels are read off lane masks, and one forward permute takes the answers home.  ~150
+ * instructions whatever the step holds - the search over the step's entries it replaces cost 65 per ENTRY. */
+__device__ __forceinline__ void chain_sort64(bool live, int pixel, int lane, int& prev, int& depth, bool& isLast)
+{
+    uint32_t key = (live ? (uint32_t)pixel : (0x3FFFFC0u | (uint32_t)lane)) << 6 | (uint32_t)lane;   /* pixels are below 2^20 */
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)key, j);
+            const bool keepMin = ((lane & j) == 0) == ((lane & k) == 0);
+            const uint32_t lo = key < other ? key : other, hi = key < other ? other : key;
+            key = keepMin ? lo : hi;
+        }
+    }
+    /* lane i holds the i-th smallest key */
+    const uint32_t before = (uint32_t)__shfl_up((int)key, 1);
+    const bool same = lane > 0 && (before >> 6) == (key >> 6);
+    const unsigned long long S = __ballot(same), H = ~S;                         /* run heads */
+    const unsigned long long le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;
+    const int runStart = 63 - __builtin_clzll(H & le);                           /* bit 0 of H is always set */
+    const bool last = lane == 63 || !((S >> (lane + 1)) & 1ull);
+    const uint32_t packed = (uint32_t)(lane - runStart) | (same ? ((before & 63u) + 1u) << 6 : 0u) | (last ? 1u << 13 : 0u);
+    /* home: the lane a key came from receives its answer (ds_permute: a forward permute, lane i writes to lane key & 63) */
+    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)((key & 63u) << 2), (int)packed);
+    depth = (int)(got & 63u);
+    prev = (int)((got >> 6) & 127u) - 1;
+    isLast = (got >> 13) & 1u;
+}
+
 struct SinCosR { double s, c; int ok; };
 __device__ __noinline__ SinCosR cr_cos_call(double x)
 {
@@ -691,23 +725,12 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
                     in = cd * cd < 9 * plMse[plid] + 1e-5;
                 }
             }
-            /* chains of lanes that target the same pixel, in lane (= visiting) order.  A lane's pixel is a neighbour of entry j
-             * iff it lies one step left / right / up / down of j's pixel, and then the lane that visits it from j is 4 j + that
-             * direction: sixteen broadcasts of the entries' pixels find every other visitor of the pixel (a visitor that exists
-             * has the same pixel, hence the same kept-block verdict; one that fell off the image row is not live).  The depth in
-             * the chain is the number of visitors before this lane. */
+            /* chains of lanes that target the same pixel, in lane (= visiting) order: chain_sort64.  The depth in the chain is the
+             * number of visitors before this lane. */
             const unsigned long long live = __ballot(have);
             int prev = -1, depth = 0;
             bool isLast = true;
-            for (int j = 0; j < cnt; j++) {
-                const int d = cIdx - rl_i(sIdx, 4 * j);
-                const int dir = d == -1 ? 0 : d == 1 ? 1 : d == -w ? 2 : d == w ? 3 : -1;
-                const int l2 = 4 * j + dir;
-                if (have && dir >= 0 && ((live >> l2) & 1ull)) {
-                    if (l2 < lane) { prev = l2; depth++; }
-                    else if (l2 > lane) isLast = false;
-                }
-            }
+            if (live) chain_sort64(have, cIdx, lane, prev, depth, isLast);
             int maxDepth = 0;
             while (__ballot(depth > maxDepth)) maxDepth++;
 #ifdef AHC_PROFILE
