@@ -61,7 +61,12 @@ __device__ __forceinline__ void chain_sort64(bool live, int pixel, int lane, int
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t other = (uint32_t)__shfl_xor((int)key, j);
+            /* the partner's key: inside a quad and across half a row by DPP (no trip through the LDS crossbar), else by permute */
+            uint32_t other;
+            if (j == 1) other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, false);          /* quad_perm [1, 0, 3, 2] */
+            else if (j == 2) other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, false);     /* quad_perm [2, 3, 0, 1] */
+            else if (j == 8) other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x128, 0xF, 0xF, false);    /* row_ror:8 */
+            else other = (uint32_t)__shfl_xor((int)key, j);
             const bool keepMin = ((lane & j) == 0) == ((lane & k) == 0);
             const uint32_t lo = key < other ? key : other, hi = key < other ? other : key;
             key = keepMin ? lo : hi;
@@ -81,6 +86,19 @@ __device__ __forceinline__ void chain_sort64(bool live, int pixel, int lane, int
     prev = (int)((got >> 6) & 127u) - 1;
     isLast = (got >> 13) & 1u;
 }
+
+#ifdef AHC_PROFILE
+/* ahCluster of frame 0 (100 MHz ticks of lane 0): 0 pops, 1 heap pop, 2 loads of the popped node + its list, 3 trial merges, 4 merge
+ * (node, heap push, union-find, list surgery), 5 no merge (extract / disconnect), 6 merges */
+__device__ unsigned long long g_ahcProf[8];
+#define CP_T() wall_clock64()
+#define CP_ADD(k, t0) do { if (blockIdx.x == 0 && c.lane == 0) g_ahcProf[k] += wall_clock64() - (t0); } while (0)
+#define CP_CNT(k) do { if (blockIdx.x == 0 && c.lane == 0) g_ahcProf[k] += 1; } while (0)
+#else
+#define CP_T() 0ull
+#define CP_ADD(k, t0) (void)(t0)
+#define CP_CNT(k) (void)0
+#endif
 
 struct SinCosR { double s, c; int ok; };
 __device__ __noinline__ SinCosR cr_cos_call(double x)
@@ -104,7 +122,7 @@ struct Ctx {
 };
 
 /* --- priority queue: smallest MSE first, ties by the smaller node id (QCmp of planes_ahc.cpp; a total order, so the pop
- * sequence does not depend on the heap's internals).  Called by lane 0 only. */
+ * sequence does not depend on the heap's internals). */
 /* The queue keeps the keys as FLOATS (half the LDS: the clustering kernel's footprint decides how many frames a CU holds):
  * rounding to float is monotone, so two different floats order the doubles; equal floats (the doubles agree to 24 bits: rare)
  * are settled by the exact MSEs, which every node keeps in its fit record. */
@@ -122,12 +140,15 @@ __device__ __forceinline__ bool heap_less_new(const Ctx& c, double key, float kf
     const double db = heap_exact(c, ib);
     return key < db || (key == db && id < ib);
 }
-__device__ void heap_push(Ctx& c, double key, int id)
+/* The queue is a 64-ary heap in LDS (children of entry i: 64 i + 1 .. 64 i + 64): three levels hold 3200 entries, a level of
+ * sift-down is ONE read by the 64 lanes and a minimum across the wavefront, and sift-up looks at two parents at most.  (The binary
+ * heap walked by one lane cost twelve levels of dependent LDS reads per pop: 2.1 us, a fifth of the clustering.) */
+__device__ void heap_push(Ctx& c, double key, int id)                 /* one lane */
 {
     const float kf = (float)key;
     int i = c.heapSize++;
     while (i > 0) {
-        const int p = (i - 1) >> 1;
+        const int p = (i - 1) >> 6;
         const float kp = c.heapKey[p];
         const int ip = c.heapId[p];
         if (!heap_less_new(c, key, kf, id, kp, ip)) break;
@@ -136,29 +157,53 @@ __device__ void heap_push(Ctx& c, double key, int id)
     }
     c.heapKey[i] = kf; c.heapId[i] = (uint16_t)id;
 }
-__device__ int heap_pop(Ctx& c)
+/* smallest float of the wavefront, to every lane */
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));     /* quad_perm [1, 0, 3, 2] */
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));     /* quad_perm [2, 3, 0, 1] */
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));    /* row_half_mirror */
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));    /* row_mirror */
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+/* (key, id) sinks from entry i of a heap of n entries.  The whole wavefront. */
+__device__ void heap_sift_down(Ctx& c, int i, float key, int id, int n)
+{
+    const int lane = c.lane;
+    for (;;) {
+        const int base = 64 * i + 1;
+        if (base >= n) break;
+        const int ch = base + lane;
+        const bool valid = ch < n;
+        const float kc = valid ? c.heapKey[ch] : __int_as_float(0x7f800000);
+        const int ic = valid ? (int)c.heapId[ch] : 0xFFFF;
+        const float kmin = wave_min_f32(kc);
+        unsigned long long ties = __ballot(valid && kc == kmin);
+        int best = __builtin_ctzll(ties);
+        ties &= ties - 1;
+        while (ties) {                                     /* equal floats (rare): the exact keys and the ids decide */
+            const int l = __builtin_ctzll(ties);
+            ties &= ties - 1;
+            if (heap_less(c, kmin, rl_i(ic, l), kmin, rl_i(ic, best))) best = l;
+        }
+        const int ib = rl_i(ic, best);
+        if (!heap_less(c, kmin, ib, key, id)) break;
+        if (lane == 0) { c.heapKey[i] = kmin; c.heapId[i] = (uint16_t)ib; }
+        i = base + best;
+    }
+    if (lane == 0) { c.heapKey[i] = key; c.heapId[i] = (uint16_t)id; }
+    wave_order();
+}
+__device__ int heap_pop(Ctx& c)                                        /* the whole wavefront; c.heapSize uniform */
 {
     const int top = c.heapId[0];
     const int n = --c.heapSize;
     if (n > 0) {
         const float key = c.heapKey[n];
         const int id = c.heapId[n];
-        int i = 0;
-        for (;;) {
-            int ch = 2 * i + 1;
-            if (ch >= n) break;
-            float kc = c.heapKey[ch];
-            int ic = c.heapId[ch];
-            if (ch + 1 < n) {
-                const float k2 = c.heapKey[ch + 1];
-                const int i2 = c.heapId[ch + 1];
-                if (heap_less(c, k2, i2, kc, ic)) { ch++; kc = k2; ic = i2; }
-            }
-            if (!heap_less(c, kc, ic, key, id)) break;
-            c.heapKey[i] = kc; c.heapId[i] = (uint16_t)ic;
-            i = ch;
-        }
-        c.heapKey[i] = key; c.heapId[i] = (uint16_t)id;
+        heap_sift_down(c, 0, key, id, n);
     }
     return top;
 }
@@ -267,19 +312,29 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
     const int lane = c.lane;
     while (uni_i(c.heapSize) > 0) {
         int p = 0;
-        if (lane == 0) p = heap_pop(c);
-        p = uni_i(p);
+        const unsigned long long cp0 = CP_T();
+        CP_CNT(0);
         c.heapSize = uni_i(c.heapSize);
-        const int nouseP = c.nouse[p], lenP = c.nbLen[p];          /* one round trip for both */
-        if (uni_b(nouseP != 0)) continue;
-        const int Lp = uni_i(lenP);
-        if (Lp > AHCD_LIST) { c.status |= 2; return; }
-        const GLOBAL_AS int* listP = c.pool + c.nbOff[p];
-        for (int k = lane; k < Lp; k += 64) c.lA[k] = (uint16_t)listP[k];
+        p = uni_i(heap_pop(c));
+        CP_ADD(1, cp0);
+        const unsigned long long cp1 = CP_T();
+        /* everything that depends on p alone in ONE round trip: flags, list head, sums, normal */
+        const int nouseP = c.nouse[p], lenP = c.nbLen[p], offP = c.nbOff[p];
         double Sp[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) Sp[k] = c.S[9 * (size_t)p + k];
         const int Np = c.N[p], ridP = c.rid[p];
+        const double npx = c.fit[8 * (size_t)p + 3], npy = c.fit[8 * (size_t)p + 4], npz = c.fit[8 * (size_t)p + 5];
+        if (uni_b(nouseP != 0)) continue;
+        const int Lp = uni_i(lenP);
+        if (Lp > AHCD_LIST) { c.status |= 2; return; }
+        const GLOBAL_AS int* listP = c.pool + offP;
+        for (int k = lane; k < Lp; k += 64) c.lA[k] = (uint16_t)listP[k];
+#ifdef AHC_PROFILE
+        if (__ballot(Lp > 0 && c.lA[0] == 0xFFFF && Sp[0] == 12345.678)) c.status |= 4;      /* wait for the loads here */
+#endif
+        CP_ADD(2, cp1);
+        const unsigned long long cp2 = CP_T();
         /* trial merges, one lane per neighbour; the fold keeps the reference's order and tie rule */
         bool haveCand = false;
         double candMse = 0;
@@ -293,19 +348,25 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             f.mse = 0;
             if (k < Lp) {
                 nb = c.lA[k];
-                if (!(similarity(c, p, nb) < c.P.cos60)) {
+                /* what depends on the neighbour alone, fetched together (one round trip): its normal for the similarity gate, its
+                 * sums and size for the trial, and where its own list lies */
+                const double mx = c.fit[8 * (size_t)nb + 3], my = c.fit[8 * (size_t)nb + 4], mz = c.fit[8 * (size_t)nb + 5];
+                nbLenK = c.nbLen[nb];
+                const int nbOffK = c.nbOff[nb];
+                const int Nb = c.N[nb], ridNb = c.rid[nb];
+#pragma unroll
+                for (int q = 0; q < 9; q++) S[q] = c.S[9 * (size_t)nb + q];
+                /* the neighbour's own list (its first eight entries: nearly always all of it): if this trial wins, the merge
+                 * needs it and would wait two more round trips for it */
+                const GLOBAL_AS int* listN = c.pool + nbOffK;
+#pragma unroll
+                for (int q = 0; q < 8; q++) nbHead[q] = q < nbLenK ? listN[q] : 0;
+                if (!(fabs(npx * mx + npy * my + npz * mz) < c.P.cos60)) {
                     ok = true;
-                    /* the neighbour's own list (its first eight entries: nearly always all of it) is fetched beside the sums: if
-                     * this trial wins, the merge needs it and would wait two more round trips for it */
-                    nbLenK = c.nbLen[nb];
-                    const GLOBAL_AS int* listN = c.pool + c.nbOff[nb];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) nbHead[q] = q < nbLenK ? listN[q] : 0;
-                    const int Nb = c.N[nb];
-#pragma unroll
-                    for (int q = 0; q < 9; q++) S[q] = Sp[q] + c.S[9 * (size_t)nb + q];
+                    for (int q = 0; q < 9; q++) S[q] = Sp[q] + S[q];
                     Nn = Np + Nb;
-                    ridN = Np >= Nb ? ridP : c.rid[nb];
+                    ridN = Np >= Nb ? ridP : ridNb;
                     ahc_plane_from_sums(S, Nn, &f);
                 }
             }
@@ -330,6 +391,8 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 for (int q = 0; q < 8; q++) c.lB[q] = (uint16_t)nbHead[q];
             }
         }
+        CP_ADD(3, cp2);
+        const unsigned long long cp3 = CP_T();
         bool merge = false;
         if (haveCand) {
             const double z = c.win[11];
@@ -405,6 +468,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             }
             if (lane == 0) { c.nbOff[id] = off; c.nbLen[id] = Lu; c.nbLen[p] = 0; c.nbLen[candNb] = 0; c.nouse[p] = 1; c.nouse[candNb] = 1; }
             fence();
+            CP_ADD(4, cp3); CP_CNT(6);
         } else {
             if (Np >= AHC_MIN_SUPPORT) {
                 if (nEx >= AHCD_MAXEX) { c.status |= 2; return; }
@@ -414,6 +478,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             disconnect_staged(c, c.lA, Lp, p);
             if (lane == 0) c.nbLen[p] = 0;
             fence();
+            CP_ADD(5, cp3);
         }
     }
     /* std::stable_sort by N, larger first: a handful of planes, insertion sort */
@@ -485,24 +550,10 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
     c.poolUsed = 4 * c.nNodes;
     c.heapSize = c.nNodes;
     fence();
-    if (lane == 0) {                                   /* heapify */
-        const int n = c.heapSize;
-        for (int s = n / 2 - 1; s >= 0; s--) {
-            const float key = heapKey[s];
-            const int id = heapId[s];
-            int i = s;
-            for (;;) {
-                int ch = 2 * i + 1;
-                if (ch >= n) break;
-                float kc = heapKey[ch];
-                int ic = heapId[ch];
-                if (ch + 1 < n && heap_less(c, heapKey[ch + 1], heapId[ch + 1], kc, ic)) { ch++; kc = heapKey[ch]; ic = heapId[ch]; }
-                if (!heap_less(c, kc, ic, key, id)) break;
-                heapKey[i] = kc; heapId[i] = (uint16_t)ic;
-                i = ch;
-            }
-            heapKey[i] = key; heapId[i] = (uint16_t)id;
-        }
+    for (int sidx = (c.heapSize - 2) / 64; sidx >= 0 && c.heapSize > 1; sidx--) {          /* heapify: the parents, last first */
+        const float key = heapKey[sidx];
+        const int id = heapId[sidx];
+        heap_sift_down(c, sidx, key, id, c.heapSize);
     }
     /* edges: the row pass (a lane per block row), then the column pass (a lane per block column), each with the reference's
      * skip pattern; a pass only touches the lists of its own row / column */
@@ -925,3 +976,12 @@ hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, cons
     hipLaunchKernelGGL(k_ahc_refine, dim3(nframes), dim3(64), 0, s, d_frames, P);
     return hipGetLastError();
 }
+
+#ifdef AHC_PROFILE
+extern "C" int drfe_debug_ahc_cluster_profile(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ahcProf), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ahcProf), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

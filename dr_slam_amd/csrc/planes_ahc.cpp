@@ -14,6 +14,7 @@
  * stable.
  */
 #include "drfe_internal.h"
+#include <dlfcn.h>
 #include "planes_internal.h"
 #include "ahc_math.h"
 #include "ahc_math_simd.h"
@@ -1136,6 +1137,13 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         int ff[4] = {0, 0, 0, 0};
         (void)hipMemcpy(ff, A->h_frames[0].handoff + 4 + 2 * 128 + 4, sizeof(ff), hipMemcpyDeviceToHost);
         std::fprintf(stderr, "  flood fill: %d steps, %d with two visits of one pixel (chain depth summed: %d), %d live visits\n", ff[0], ff[1], ff[2], ff[3]);
+        typedef int (*prof_fn)(unsigned long long*);
+        if (prof_fn fn = (prof_fn)dlsym(RTLD_DEFAULT, "drfe_debug_ahc_cluster_profile")) {
+            unsigned long long v[8] = {0};
+            if (fn(v) == 0 && v[0])
+                std::fprintf(stderr, "  ahCluster, frame 0 of every call since the last print: %llu pops (%llu merges); ms per call: heap pop %.2f, node + list loads %.2f, trial merges %.2f, merges %.2f, extract / disconnect %.2f\n",
+                             v[0], v[6], v[1] / 1e5, v[2] / 1e5, v[3] / 1e5, v[4] / 1e5, v[5] / 1e5);
+        }
     }
     if (std::getenv("DRFE_TRACE_PLANES"))
         std::fprintf(stderr, "drfe_planes_ahc_post_batch workers, CPU ms per frame: chunk fetch %.3f, frame download + wait %.3f, grids redone on the host %.3f, gates + refit %.3f\n",
