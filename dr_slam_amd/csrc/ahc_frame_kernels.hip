@@ -338,13 +338,13 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         /* trial merges, one lane per neighbour; the fold keeps the reference's order and tie rule */
         bool haveCand = false;
         double candMse = 0;
-        int candN = 0, candNb = -1, candLen = 0;
+        int candN = 0, candNb = -1, candLen = 0, candRid = 0;
         for (int base = 0; base < Lp; base += 64) {
             const int k = base + lane;
             bool ok = false;
             double S[9];
             AhcFit f;
-            int Nn = 0, ridN = 0, nb = 0, nbLenK = 0, nbHead[8];
+            int Nn = 0, ridN = 0, nb = 0, nbLenK = 0, ridNbK = 0, nbHead[8];
             f.mse = 0;
             if (k < Lp) {
                 nb = c.lA[k];
@@ -354,6 +354,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 nbLenK = c.nbLen[nb];
                 const int nbOffK = c.nbOff[nb];
                 const int Nb = c.N[nb], ridNb = c.rid[nb];
+                ridNbK = ridNb;
 #pragma unroll
                 for (int q = 0; q < 9; q++) S[q] = c.S[9 * (size_t)nb + q];
                 /* the neighbour's own list (its first eight entries: nearly always all of it): if this trial wins, the merge
@@ -377,7 +378,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 m &= m - 1;
                 const double mse = rl_d(f.mse, l);
                 if (!haveCand || candMse > mse || (candMse == mse && (double)candN < mse)) {
-                    haveCand = true; candMse = mse; candN = rl_i(Nn, l); candNb = rl_i(nb, l); candLen = rl_i(nbLenK, l); winLane = l;
+                    haveCand = true; candMse = mse; candN = rl_i(Nn, l); candNb = rl_i(nb, l); candLen = rl_i(nbLenK, l); candRid = rl_i(ridNbK, l); winLane = l;
                 }
             }
             if (winLane >= 0 && lane == winLane) {          /* this chunk's winner parks its merged node in LDS */
@@ -406,14 +407,17 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             c.nNodes = id + 1;
             if (lane < 9) c.S[9 * (size_t)id + lane] = c.win[lane];
             if (lane < 8) c.fit[8 * (size_t)id + lane] = c.win[9 + lane];
+            /* mergeNbsFrom: union by size of the two root blocks.  The two finds (chains of dependent loads) side by side in lanes
+             * 0 and 1, each with its root's size */
+            int root = 0, rsize = 0;
+            if (lane < 2) { root = ds_find(c, lane == 0 ? ridP : candRid); rsize = c.dsSize[root]; }
+            const int xr = rl_i(root, 0), yr = rl_i(root, 1), sxr = rl_i(rsize, 0), syr = rl_i(rsize, 1);
             if (lane == 0) {
                 c.N[id] = ((int*)(c.win + 17))[0]; c.rid[id] = ((int*)(c.win + 17))[1]; c.nouse[id] = 0;
                 heap_push(c, c.win[15], id);
-                /* mergeNbsFrom: union by size of the two root blocks */
-                const int xr = ds_find(c, ridP), yr = ds_find(c, c.rid[candNb]);
                 if (xr != yr) {
-                    if (c.dsSize[xr] < c.dsSize[yr]) { c.dsParent[xr] = yr; c.dsSize[yr] += c.dsSize[xr]; }
-                    else { c.dsParent[yr] = xr; c.dsSize[xr] += c.dsSize[yr]; }
+                    if (sxr < syr) { c.dsParent[xr] = yr; c.dsSize[yr] = syr + sxr; }
+                    else { c.dsParent[yr] = xr; c.dsSize[xr] = sxr + syr; }
                 }
             }
             c.heapSize = uni_i(c.heapSize);
