@@ -545,7 +545,16 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
     }
     const double mean = sum / (double)cntIn;
     const double tau = 2.0 * sqrt((ssum - 2.0 * mean * sum) / (double)cntIn + mean * mean);
-    n = grow<false>(w, sx, sy, uni_d(tau), regAngle, win, T, 0);
+    /* the second growth runs with the tolerance tau: the shortcut's thresholds for it (tan to a relative 1e-6 is ample inside a
+     * band of 0.02 degrees; a tolerance near 0 or 90 degrees switches the shortcut off) */
+    AlignTan T2; T2.tLo = 0.f; T2.tHi = 0.f;
+    const double tauU = uni_d(tau), band = 0.02 * 3.14159265358979323846 / 180.0;
+    if (tauU - band > 1e-3 && tauU + band < 1.5) {
+        T2.tLo = (float)(tan(tauU - band) * (1.0 - 1e-5));
+        T2.tHi = (float)(tan(tauU + band) * (1.0 + 1e-5));
+    }
+    (void)T;
+    n = grow<true>(w, sx, sy, tauU, regAngle, win, T2, 0);
     if (n < 2) return false;
     to_rect(w, n, regAngle, prec, rec, true);
     density = density_of(rec, n);
