@@ -602,37 +602,57 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
     int nRects = 0;
     const int nOrder = w.F.nOrder;
     const uint32_t minSeedBin = w.F.minSeedBin;
+    /* The seed scan runs two chunks (of 64 seeds of the ordering) ahead of the growth: a chunk's keys are fetched two iterations
+     * before its turn, its candidates' own and neighbouring level-line angles one iteration before - with the bitmap of THAT
+     * moment, a superset of what is free at the chunk's turn: a seed no free neighbour of which is aligned with it then has none
+     * later either (the free set only shrinks), one that loses its last aligned neighbour in between grows into a one-pixel
+     * region - the same bit set -, and every seed is looked up again at its turn.  So neither fetch is waited for. */
+    struct Scan { bool valid, cand; int sx, sy; uint32_t q, nfMask; double sa, na[8]; };
+    auto scan_keys = [&](int base) -> uint32_t { const int pos = base + lane; return pos < nOrder ? w.F.order[pos] : 0u; };
+    auto scan_fields = [&](int base, uint32_t key, Scan& sc) {
+        sc.valid = base + lane < nOrder && (key >> 22) >= minSeedBin;
+        sc.sx = (int)(key & 0x7FFu); sc.sy = (int)((key >> 11) & 0x7FFu);
+        sc.q = (uint32_t)(sc.sy * W + sc.sx);
+        sc.cand = sc.valid && !w.bit(sc.q);
+        sc.nfMask = 0; sc.sa = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sc.na[j] = 0.0;
+        if (sc.cand) {
+            sc.sa = w.F.ang[sc.q];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int jj = j < 4 ? j : j + 1, dx = jj % 3 - 1, dy = jj / 3 - 1;
+                const int nx = sc.sx + dx, ny = sc.sy + dy;
+                const bool inb = nx >= 0 && ny >= 0 && nx < W && ny < H;
+                const uint32_t nq = inb ? (uint32_t)(ny * W + nx) : 0u;
+                const bool nf = inb && !w.bit(nq);
+                if (nf) { sc.nfMask |= 1u << j; sc.na[j] = w.F.ang[nq]; }
+            }
+        }
+    };
+    Scan cur, nxt;
+    uint32_t keyNext;
+    {
+        const uint32_t k0 = scan_keys(0);
+        keyNext = scan_keys(64);
+        scan_fields(0, k0, cur);
+    }
     bool done = false;
     for (int base = 0; base < nOrder && !done; base += 64) {
         const unsigned long long ts0 = PROF_T();
         PROF_CNT(8, 1);
-        const int pos = base + lane;
-        uint32_t key = 0;
-        bool valid = false;
-        if (pos < nOrder) { key = w.F.order[pos]; valid = (key >> 22) >= minSeedBin; }
-        if (__ballot(!valid)) done = true;                     /* bins descend: nothing seeds from the first low bin on */
-        const int sx = (int)(key & 0x7FFu), sy = (int)((key >> 11) & 0x7FFu);
-        const uint32_t q = (uint32_t)(sy * W + sx);
-        const bool cand = valid && !w.bit(q);
-        if (!__ballot(cand)) { PROF_ADD(1, ts0); continue; }
-        /* does any free neighbour join on the seed's own angle?  If not now, then not at its turn either: the free set only
-         * shrinks, so such a seed is a one-pixel region (or dead) whatever happens before it */
+        const uint32_t keyAfter = scan_keys(base + 128);
+        scan_fields(base + 64, keyNext, nxt);
+        if (__ballot(!cur.valid)) done = true;                 /* bins descend: nothing seeds from the first low bin on */
+        const int sx = cur.sx, sy = cur.sy;
+        const uint32_t q = cur.q;
+        const bool cand = cur.cand;
+        if (!__ballot(cand)) { PROF_ADD(1, ts0); cur = nxt; keyNext = keyAfter; continue; }
+        /* does any free neighbour join on the seed's own angle? */
         bool nontrivial = false;
         if (cand) {
-            const double sa = w.F.ang[q];
-            double na[8];
-            bool nf[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int jj = j < 4 ? j : j + 1, dx = jj % 3 - 1, dy = jj / 3 - 1;
-                const int nx = sx + dx, ny = sy + dy;
-                const bool inb = nx >= 0 && ny >= 0 && nx < W && ny < H;
-                const uint32_t nq = inb ? (uint32_t)(ny * W + nx) : 0u;
-                nf[j] = inb && !w.bit(nq);
-                na[j] = nf[j] ? w.F.ang[nq] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) nontrivial |= nf[j] && aligned_with(sa, na[j], prec);
+            for (int j = 0; j < 8; j++) nontrivial |= ((cur.nfMask >> j) & 1u) && aligned_with(cur.sa, cur.na[j], prec);
         }
         int from = 0;
         unsigned long long pend = __ballot(cand && nontrivial);
@@ -703,6 +723,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
             w0 = v0; w1 = v1; w2 = v2; w3 = v3; packed = packedNext; cnt = cntNext;
         }
         if (cand && !nontrivial && lane >= from && !w.bit(q)) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+        cur = nxt; keyNext = keyAfter;
     }
     if (lane == 0) { w.F.out[0] = nRects; w.F.out[1] = w.status; w.F.out[2] = 0; w.F.out[3] = 0; /* k_rect_improve's status word and its reasons */ }
 #ifdef LSD_PROFILE
