@@ -373,7 +373,7 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
     return B * steps / el, el / steps * 1e3, threads
 
 
-def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 4):
+def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 5):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
     the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame);
@@ -504,8 +504,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 
             "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels, plane clouds (k_ahc_blocks, k_ahc_cluster + k_ahc_refine: one wavefront per frame) and "
                            "pcl::VoxelGrid of every plane (k_voxel_grid) on the device; gates + RANSAC refit on host threads",
             "note": "the device paths are latency chains (~0.12 s of region growing, ~0.075 s of plane extraction per frame on one wavefront), so steps run side by side; "
-                    "with 4 steps in flight the one-wavefront-per-frame kernels keep the SIMDs issuing (their wavefront-seconds per step / 1024 SIMDs is the step time "
-                    "measured - DESIGN.md, what bounds the full front-end).  CAPE runs on the device; the host stage that remains is the planes' gates + RANSAC refit "
+                    "what bounds the rate is LDS x time: every long kernel holds 20-38 KB of a CU's 160 KB for as long as it runs, and the sum over a frame's "
+                    "kernels of (LDS held x time held) against the device's 40 MB of LDS is the step time measured (DESIGN.md, what bounds the full front-end).  CAPE runs on the device; the host stage that remains is the planes' gates + RANSAC refit "
                     "(host_cpu_ms_per_frame_by_pool is the measurement; host_cores_busy_at_8_gpus_at_this_rate = 8 x the busy cores measured here)"}
 
 
