@@ -467,34 +467,68 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
     __syncthreads();
     ISD_TP(1);
 
-    /* ---- std::__final_insertion_sort = the stable sort by key: stable counting passes, five bits each ---- */
+    /* ---- std::__final_insertion_sort = the stable sort by key: stable counting passes, five bits each.  A wavefront owns a
+     * contiguous share of the array and takes it in tiles of 64 consecutive records (one coalesced load): the lanes of a tile that
+     * hold the same digit find each other with five ballots, the first of them adds their number to the digit's counter of this
+     * wavefront (32 x NTH / 64 counters in LDS - 512 bytes at 256 threads, where a counter per thread and digit took 32 KB and every
+     * thread walked its own stretch of the array, 64 cache lines per load), and in the second sweep a record's place is the
+     * counter's value plus its rank among those lanes.  Order within a digit = wavefront, tile, lane: stable. ---- */
     Rec* src = a;
     Rec* dst = tmp;
-    const uint32_t E = ((uint32_t)n + NTH - 1) / NTH;
-    const uint32_t c0 = min((uint32_t)n, (uint32_t)tid * E), c1 = min((uint32_t)n, c0 + E);
+    constexpr int NW = NTH / 64;
+    const uint32_t tiles = ((uint32_t)n + 63u) >> 6, tilesPerWave = (tiles + NW - 1) / NW;
+    const uint32_t t0 = min(tiles, (uint32_t)wv * tilesPerWave), t1 = min(tiles, t0 + tilesPerWave);
+    uint32_t* cnt = dyn;                                    /* [digit][wavefront] */
+    const unsigned long long ltm = (1ull << lane) - 1ull;
+    /* the lanes of the tile whose digit equals this lane's (valid lanes only) */
+    auto same_digit = [&](bool valid, uint32_t d) -> unsigned long long {
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        return peers;
+    };
     const int passes = (keyBits + 4) / 5;
     for (int pass = 0; pass < passes; pass++) {
         const int shft = pass * 5;
-        for (int b = 0; b < 32; b++) dyn[b * NTH + tid] = 0;
-        for (uint32_t p = c0; p < c1; p++) dyn[((T::key(src[p]) >> shft) & 31u) * NTH + tid]++;
+        for (int i = tid; i < 32 * NW; i += NTH) cnt[i] = 0;
         __syncthreads();
-        /* exclusive scan of the 32 x NTH counters in (digit, thread) order: thread i owns entries [32 i, 32 i + 32) */
-        uint32_t loc = 0;
-        for (int k = 0; k < 32; k++) loc += dyn[tid * 32 + k];
-        uint32_t inc = loc;
+        for (uint32_t t = t0; t < t1; t++) {
+            const uint32_t p = (t << 6) + lane;
+            const bool valid = p < (uint32_t)n;
+            const uint32_t d = valid ? (T::key(src[p]) >> shft) & 31u : 0u;
+            const unsigned long long peers = same_digit(valid, d);
+            if (valid && !(peers & ltm)) atomicAdd(&cnt[d * NW + wv], (uint32_t)__popcll(peers));
+        }
+        __syncthreads();
+        /* exclusive scan of the counters in (digit, wavefront) order by wavefront 0: lane i owns NW / 2 consecutive entries */
+        if (wv == 0) {
+            constexpr int EPL = (32 * NW) / 64;
+            uint32_t loc = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-        if (lane == 63) sh.wcnt[wv] = (int)inc;
+            for (int k = 0; k < EPL; k++) loc += cnt[lane * EPL + k];
+            uint32_t inc = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            uint32_t run = inc - loc;
+#pragma unroll
+            for (int k = 0; k < EPL; k++) { const uint32_t c = cnt[lane * EPL + k]; cnt[lane * EPL + k] = run; run += c; }
+        }
         __syncthreads();
-        uint32_t wbase = 0;
-        for (int k = 0; k < wv; k++) wbase += (uint32_t)sh.wcnt[k];
-        uint32_t run = wbase + inc - loc;
-        for (int k = 0; k < 32; k++) { const uint32_t c = dyn[tid * 32 + k]; dyn[tid * 32 + k] = run; run += c; }
-        __syncthreads();
-        for (uint32_t p = c0; p < c1; p++) {
-            const Rec v = src[p];
-            const uint32_t slot = ((T::key(v) >> shft) & 31u) * NTH + tid;
-            dst[dyn[slot]++] = v;
+        for (uint32_t t = t0; t < t1; t++) {
+            const uint32_t p = (t << 6) + lane;
+            const bool valid = p < (uint32_t)n;
+            const Rec v = valid ? src[p] : src[0];
+            const uint32_t d = valid ? (T::key(v) >> shft) & 31u : 0u;
+            const unsigned long long peers = same_digit(valid, d);
+            if (valid) {
+                const uint32_t base = cnt[d * NW + wv];
+                dst[base + (uint32_t)__popcll(peers & ltm)] = v;
+                if (!(peers & ltm)) cnt[d * NW + wv] = base + (uint32_t)__popcll(peers);
+            }
         }
         __syncthreads();
         Rec* t = src; src = dst; dst = t;
