@@ -36,7 +36,13 @@
                                   * 196 000 pixels); with 1024 entries a sort held 47.5 KB of LDS - three per CU - with 256 it is
                                   * 38.3 KB, four per CU.  An overflow flags the array for the host. */
 #define ORD_STACK 48             /* depth-first stack of a wavefront (>= the depth limit 2 lg n of any array that fits) */
-#define ORD_DYN_LDS_BYTES(NTH) (32 * (NTH) * 4)
+#ifndef ORD_DYN_WORDS
+#define ORD_DYN_WORDS 16         /* LDS words per thread: a wavefront's share (4 KB) holds the ranges it partitions in LDS.  Measured per
+                                  * frame / per plane cloud (k_lsd_order / k_voxel_grid, ms) at 32 | 24 | 16 | 12 | 8 words: 14.1 / 1.99 |
+                                  * 14.5 / 2.09 | 15.4 / 2.27 | 16.0 / 2.38 | 18.3 / 2.63 - and a 256-thread sort holds 38.4 | 30.7 | 21.8 |
+                                  * 17.9 | 14.1 KB of its CU (4 | 5 | 7 | 9 | 11 per CU): LDS x time is what the mix is short of */
+#endif
+#define ORD_DYN_LDS_BYTES(NTH) (ORD_DYN_WORDS * (NTH) * 4)
 #define ORD_HEAP_MAX 1024        /* longest range one lane heap-sorts (about 20 000 dependent moves) */
 
 /* phase marks of a profiling build: the includer defines ISD_TP(k) (k = 0: workgroup partitions done, 1: wavefront phase done,

@@ -32,7 +32,7 @@ __device__ unsigned long long g_voxXcd[18];
 #define VOX_TP(k)
 #endif
 #include "introsort_device.h"
-#define VOX_T 256                 /* threads per plane: 47 KB of LDS per workgroup, so three fit a CU beside other kernels' wavefronts */
+#define VOX_T 256                 /* threads per plane: 21.8 KB of LDS per workgroup (introsort_device.h), six fit a CU by registers */
 #define VOX_WAVES (VOX_T / 64)
 
 namespace {
@@ -205,10 +205,11 @@ hipError_t drfe_launch_voxel_grid(const float* d_pts, const int2* d_jobs, int nj
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        /* 47 KB of LDS each: three per CU fill the device when the plane path runs alone; DRFE_VOXEL_RESIDENT=<per CU> for
-         * experiments in the mix, where those 36 MB of LDS are what the other paths' wavefronts wait for */
+        /* 21.8 KB of LDS and 4 x 80 registers each: six per CU would fit, three are launched - with several steps in flight the
+         * other long kernels want the LDS (measured, planes path at 1 / 4 / 5 steps in flight: 4 550 / 11 400 / 12 600 frames/s with
+         * three per CU, 5 040 / 9 250 / 10 980 with six); DRFE_VOXEL_RESIDENT=<per CU> for experiments */
         const char* er = std::getenv("DRFE_VOXEL_RESIDENT");
-        const int perCu = er ? std::max(1, std::min(3, std::atoi(er))) : 3;
+        const int perCu = er ? std::max(1, std::min(6, std::atoi(er))) : 3;
         resident = perCu * (cus > 0 ? cus : 256);
     }
     hipLaunchKernelGGL(k_voxel_jobs_order, dim3(1), dim3(1024), 0, s, d_jobs, njobs, d_list + 2, d_list, d_counts);
