@@ -66,7 +66,8 @@ template <int NTH>
 struct Shared {
     Seg queue[ORD_QCAP];
     Seg stack[NTH / 64][ORD_STACK];
-    int qHead, qTail, qOverflow, heapNeeded, wcnt[4 * (NTH / 64) + 2];
+    int qHead, qTail, bigTop, qOverflow, heapNeeded, wcnt[4 * (NTH / 64) + 2];
+    Seg cur;                        /* the range the workgroup partitions now */
     uint32_t cutShared;
     unsigned long long tp;          /* profiling builds: thread 0's last phase mark */
 };
@@ -322,18 +323,25 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
     typedef typename T::Rec Rec;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __syncthreads();
-    if (tid == 0) { sh.qHead = 0; sh.qTail = 0; sh.qOverflow = 0; sh.heapNeeded = 0; }
+    /* one array, two lists: ranges of at most ORD_BIG records (the wavefronts' work) fill it from the bottom [qHead, qTail), ranges
+     * above ORD_BIG (the workgroup's) are a stack growing down from the top [bigTop, ORD_QCAP) - no search for the next large
+     * range, and a consumed entry's slot is free again */
+    if (tid == 0) { sh.qHead = 0; sh.qTail = 0; sh.bigTop = ORD_QCAP; sh.qOverflow = 0; sh.heapNeeded = 0; }
     __syncthreads();
-    if (n > 16 && tid == 0) { sh.queue[0].first = 0; sh.queue[0].last = (uint32_t)n; sh.queue[0].depth = depthLimit; sh.qTail = 1; }
+    auto push_range = [&](uint32_t f, uint32_t l, int d) {                /* thread 0 */
+        if (l - f <= 16) return;
+        if (sh.qTail >= sh.bigTop) { sh.qOverflow |= 1; return; }
+        const int at = l - f > ORD_BIG ? --sh.bigTop : sh.qTail++;
+        sh.queue[at].first = f; sh.queue[at].last = l; sh.queue[at].depth = d;
+    };
+    if (tid == 0) push_range(0, (uint32_t)n, depthLimit);
     __syncthreads();
 
     /* ---- ranges above ORD_BIG: the workgroup partitions them one after the other ---- */
     uint32_t wgIter = 0;
     for (;;) {
         if (tid == 0) {
-            int found = -1;
-            for (int k = sh.qHead; k < sh.qTail; k++) if (sh.queue[k].last - sh.queue[k].first > ORD_BIG) { found = k; break; }
-            if (found >= 0) { const Seg s = sh.queue[found]; sh.queue[found] = sh.queue[sh.qHead]; sh.queue[sh.qHead] = s; sh.qHead++; sh.cutShared = 1; }
+            if (sh.bigTop < ORD_QCAP) { sh.cur = sh.queue[sh.bigTop]; sh.bigTop++; sh.cutShared = 1; }
             else sh.cutShared = 0;
         }
         __syncthreads();
@@ -343,7 +351,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
         /* every data-dependent loop of this routine carries a bound far above what a correct run needs: a workgroup that ran past it
          * would otherwise hold its CU for ever (bit 2 / 3 / 4 of the status: which loop) */
         if (++wgIter > 4u * ORD_QCAP + 64u) { if (tid == 0) sh.qOverflow |= 4; break; }
-        Seg s = sh.queue[sh.qHead - 1];
+        Seg s = sh.cur;
         s.first = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.first); s.last = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.last);
         s.depth = __builtin_amdgcn_readfirstlane(s.depth);
         __syncthreads();
@@ -356,10 +364,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
             if (tid == 0) median_to_first<T>(a, s.first, s.first + 1, s.first + (s.last - s.first) / 2, s.last - 1);
             __syncthreads();
             const uint32_t cut = hoare_cut<NTH, T>(a, s.first, s.last, posL, posR, tid, sh.wcnt);
-            if (tid == 0) {
-                if (s.last - cut > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = cut; sh.queue[sh.qTail].last = s.last; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow |= 1; }
-                if (cut - s.first > 16) { if (sh.qTail < ORD_QCAP) { sh.queue[sh.qTail].first = s.first; sh.queue[sh.qTail].last = cut; sh.queue[sh.qTail].depth = s.depth - 1; sh.qTail++; } else sh.qOverflow |= 1; }
-            }
+            if (tid == 0) { push_range(cut, s.last, s.depth - 1); push_range(s.first, cut, s.depth - 1); }
         }
         __syncthreads();
     }
