@@ -108,9 +108,11 @@ hipError_t drfe_long_kernel_stream(hipStream_t* s, int part)
          * flight x lines + planes) two of them share a queue and their 0.1 s kernels run one behind the other (tools/queue_probe.py:
          * 4 contexts x 64 frames side by side 165 ms, 8 contexts 331 ms; 168 ms with DRFE_LONG_PRIO=split, which puts the plane
          * path's long kernels on the middle priority level and so on four queues of their own).  With 512-frame steps it does
-         * not matter - the full front-end is bound by the SIMD time of its one-wavefront-per-frame kernels, 3 250-3 370 frames/s
-         * either way (profiles/r04_queue_probe.txt) - so the default stays the lowest level for both: the ORB batch, CAPE and the
-         * pools' lanes keep the middle level to themselves. */
+         * not matter - the full front-end is bound by the LDS its long kernels hold for as long as they run,
+         * the same rate either way (profiles/r04_queue_probe.txt) - so the default stays the lowest level for both: the ORB batch,
+         * CAPE and the pools' lanes keep the middle level to themselves.  DRFE_CU_SPLIT=<percent> gives the line path that share of
+         * every 32 CUs and the plane path the rest (an experiment: 3 350-3 520 frames/s at 50 / 62 against 4 580-4 850 with every
+         * kernel free to run anywhere - the mix packs the LDS better than a partition). */
         static const bool split = [] { const char* m = std::getenv("DRFE_LONG_PRIO"); return m && m[0] == 's' && m[1] == 'p'; }();
         const int mid = (prLow + prHigh) / 2;
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, (part == 1 && split && mid != prLow) ? mid : prLow);
