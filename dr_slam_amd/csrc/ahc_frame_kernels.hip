@@ -12,8 +12,10 @@
  *   - rewriting the neighbours' lists after a merge touches a different list per neighbour: one lane each;
  *   - block membership, seeds, relabelling, member lists are data-parallel passes with ballot / popcount prefix sums;
  *   - the flood fill evaluates the four neighbours of a queue entry in four lanes (depth -> point -> distance to the plane),
- *     then applies them in the reference's order.
- * The priority queue lives in LDS (its size never exceeds the number of init blocks; keys as floats, exact ties from the nodes); nodes, neighbour lists, the union-find,
+ *     sixteen entries per step, then applies them in the reference's order: visits of the same pixel form chains (found by
+ *     sorting the 64 pixel | lane keys across the wavefront: chain_sort64) and are applied in rounds by depth in the chain.
+ * The priority queue lives in LDS as a 64-ary heap (its size never exceeds the number of init blocks; keys as floats, exact ties
+ * from the nodes; the order is total, so the pop sequence does not depend on the heap's shape); nodes, neighbour lists, the union-find,
  * membership / distance maps and the flood-fill queue are in HBM.  Throughput comes from frames in flight: a launch carries one
  * wavefront per frame.  Overflowing any fixed capacity (neighbour pool, queue, planes) or an uncertified cosine flags the
  * frame and the host redoes it. */

@@ -6,20 +6,24 @@
  * later seeds read, its running angle is a float sum in joining order, the rectangle moments are double sums in member
  * order.  One frame is therefore ONE WAVEFRONT that executes the reference's sequence exactly - wave-uniform control flow,
  * every order-defined value held identically by all lanes - and uses its 64 lanes where the sequence leaves room:
- *   - the seed scan reads 64 entries of the ordering at a time; entries whose pixel is already claimed are skipped by a
- *     ballot, and a seed none of whose free neighbours is aligned with its own angle is a one-pixel region whatever happens
- *     before its turn (the free set only shrinks), so a run of such seeds ahead of the first growing one is retired in one
- *     step;
- *   - region_grow visits up to seven queued members per step: 63 lanes fetch the level-line angle and (cos, sin) of their
- *     3 x 3 neighbours at once (the fields never change), then the members are resolved in order - per member one LDS read
- *     of the neighbours' state, a ballot, and a scalar walk over the free ones with the running angle;
- *   - products, coordinate differences, rectangle extents and the alignment statistics are lane-parallel; only the
- *     additions of the order-defined sums run one member after the other (v_readlane + v_add_f64);
+ *   - the seed scan reads 64 entries of the ordering at a time, two chunks ahead of the growth; entries whose pixel is already
+ *     claimed are skipped by a ballot, and a seed none of whose free neighbours is aligned with its own angle is a one-pixel
+ *     region whatever happens before its turn (the free set only shrinks), so a run of such seeds ahead of the first growing
+ *     one is retired in one step;
+ *   - a region grows inside the 7 x 7 window of its seed first (nineteen in twenty never leave it): one lane per window pixel,
+ *     the window's free / aligned state as two scalar masks, nothing written until the region leaves the window or ends; beyond
+ *     the window up to seven queued members per step, lane 9 m + k holding neighbour k of the step's m-th member, so that lane
+ *     order is the visiting order and one pass over the lanes applies the step;
+ *   - the alignment test |fastAtan2(sums) - angle(pixel)| <= tolerance is decided from the dot and cross product of the sums
+ *     with the pixel's (cos, sin) wherever it is not within 0.02 degrees of the tolerance (fastAtan2's polynomial is within
+ *     0.0096 degrees of the arctangent: align_class); only inside that band is the reference's arithmetic evaluated;
+ *   - products, coordinate differences, rectangle extents and the alignment statistics are lane-parallel; the additions of
+ *     the order-defined sums run one member after the other, three sums at once on three lanes walking LDS (ordered_sums3);
  *   - reduce_region_radius' swap-with-last removal is evaluated in closed form (the k-th removed position below the new
  *     size receives the k-th kept member from the back).
- * The `used` map is a bitmap in LDS (24 KB at 512 x 384); member lists live in HBM with the newest 512 entries mirrored in
- * LDS for the growth frontier.  Throughput comes from frames in flight: a frame is a dependency chain of ~10^5 steps, a
- * launch carries one wavefront per frame and a CU holds as many as its LDS allows.
+ * The `used` map is a bitmap in LDS (24 KB at 512 x 384); member lists live in HBM with the newest 128 entries mirrored in
+ * LDS for the growth frontier - 26 624 bytes per frame, six frames per CU.  Throughput comes from frames in flight: a frame is
+ * a dependency chain of ~10^5 steps, a launch carries one wavefront per frame and a CU holds as many as its LDS allows.
  *
  * cos / sin of region2rect and of the seed direction come from cr_sincos.h (correctly rounded, the same routine on the host
  * path); a frame whose rounding cannot be certified, or whose rectangle list overflows, is flagged and redone on the host. */
