@@ -641,6 +641,40 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         keyNext = scan_keys(64);
         scan_fields(0, k0, cur);
     }
+    /* does any free neighbour join on the seed's own angle?  (the scan's loads of that chunk must have arrived) */
+    auto scan_nontrivial = [&](const Scan& sc) -> bool {
+        bool nt = false;
+        if (sc.cand) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) nt |= ((sc.nfMask >> j) & 1u) && aligned_with(sc.sa, sc.na[j], prec);
+        }
+        return nt;
+    };
+    /* the next (up to) four growing seeds of a chunk: their windows fetched together.  Always four fetches, the unused ones at the
+     * first seed again (cache hits): no branch around a load, so nothing merges with a value in flight and the wavefront waits
+     * only where a window is used */
+    auto take_group = [&](unsigned long long& pend, int sxv, int syv, uint32_t& packed, int& cnt, Window& a0, Window& a1, Window& a2, Window& a3) {
+        int lk[4];
+        cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            lk[u] = pend ? __builtin_ctzll(pend) : (u ? lk[0] : 0);
+            if (pend) { cnt++; pend &= pend - 1; }
+        }
+        packed = (uint32_t)lk[0] | (uint32_t)lk[1] << 8 | (uint32_t)lk[2] << 16 | (uint32_t)lk[3] << 24;
+        a0 = load_window(w, rl_i32(sxv, lk[0]), rl_i32(syv, lk[0]));
+        a1 = load_window(w, rl_i32(sxv, lk[1]), rl_i32(syv, lk[1]));
+        a2 = load_window(w, rl_i32(sxv, lk[2]), rl_i32(syv, lk[2]));
+        a3 = load_window(w, rl_i32(sxv, lk[3]), rl_i32(syv, lk[3]));
+    };
+    /* A chunk's growing seeds go in groups of four, a group's windows fetched while the group before it grows (the fields never
+     * change, so nothing a region does can invalidate them) - across the chunk boundary too: while a chunk's LAST group grows,
+     * the first group of the next chunk is on its way (haveFirst: it is in w0..w3 already when that chunk's turn comes). */
+    Window w0, w1, w2, w3, v0, v1, v2, v3;
+    uint32_t packed = 0, packedNext = 0;
+    int cnt = 0, cntNext = 0;
+    bool haveFirst = false, nontrivial = false, nontrivialNext = false;
+    unsigned long long pend = 0, pendNext = 0;
     bool done = false;
     for (int base = 0; base < nOrder && !done; base += 64) {
         const unsigned long long ts0 = PROF_T();
@@ -651,46 +685,30 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         const int sx = cur.sx, sy = cur.sy;
         const uint32_t q = cur.q;
         const bool cand = cur.cand;
-        if (!__ballot(cand)) { PROF_ADD(1, ts0); cur = nxt; keyNext = keyAfter; continue; }
-        /* does any free neighbour join on the seed's own angle? */
-        bool nontrivial = false;
-        if (cand) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) nontrivial |= ((cur.nfMask >> j) & 1u) && aligned_with(cur.sa, cur.na[j], prec);
-        }
+        if (!haveFirst) {
+            nontrivial = false; pend = 0; cnt = 0;
+            if (__ballot(cand)) {
+                nontrivial = scan_nontrivial(cur);
+                pend = __ballot(cand && nontrivial);
+                PROF_ADD(1, ts0);
+                const unsigned long long tw0 = PROF_T();
+                if (pend) take_group(pend, sx, sy, packed, cnt, w0, w1, w2, w3);
+                PROF_ADD(2, tw0);
+            } else PROF_ADD(1, ts0);
+        } else PROF_ADD(1, ts0);
         int from = 0;
-        unsigned long long pend = __ballot(cand && nontrivial);
-        PROF_ADD(1, ts0);
-        /* the growing seeds of this chunk in groups of four: a group's windows are fetched while the group before it grows
-         * (the fields never change, so nothing a region does can invalidate them) */
-        auto take_group = [&](uint32_t& packed, int& cnt, Window& a0, Window& a1, Window& a2, Window& a3) {
-            /* always four fetches, the unused ones at the first seed again (cache hits): no branch around a load, so nothing
-             * merges with a value in flight and the wavefront waits only where a window is used */
-            int lk[4];
-            cnt = 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                lk[u] = pend ? __builtin_ctzll(pend) : (u ? lk[0] : 0);
-                if (pend) { cnt++; pend &= pend - 1; }
-            }
-            packed = (uint32_t)lk[0] | (uint32_t)lk[1] << 8 | (uint32_t)lk[2] << 16 | (uint32_t)lk[3] << 24;
-            a0 = load_window(w, rl_i32(sx, lk[0]), rl_i32(sy, lk[0]));
-            a1 = load_window(w, rl_i32(sx, lk[1]), rl_i32(sy, lk[1]));
-            a2 = load_window(w, rl_i32(sx, lk[2]), rl_i32(sy, lk[2]));
-            a3 = load_window(w, rl_i32(sx, lk[3]), rl_i32(sy, lk[3]));
-        };
-        Window w0, w1, w2, w3, v0, v1, v2, v3;
-        uint32_t packed = 0, packedNext = 0;
-        int cnt = 0, cntNext = 0;
-        {
-            const unsigned long long tw0 = PROF_T();
-            take_group(packed, cnt, w0, w1, w2, w3);
-            PROF_ADD(2, tw0);
-        }
+        bool nextTaken = false;
         while (cnt > 0) {
             const unsigned long long tw0 = PROF_T();
             PROF_CNT(9, 1);
-            take_group(packedNext, cntNext, v0, v1, v2, v3);
+            if (pend) take_group(pend, sx, sy, packedNext, cntNext, v0, v1, v2, v3);
+            else {
+                /* this is the chunk's last group: the next chunk's first one */
+                nontrivialNext = scan_nontrivial(nxt);
+                pendNext = __ballot(nxt.cand && nontrivialNext);
+                take_group(pendNext, nxt.sx, nxt.sy, packedNext, cntNext, v0, v1, v2, v3);
+                nextTaken = true;
+            }
 #ifdef LSD_PROFILE
             if (w0.a + w1.a + w2.a + w3.a == 12345.678) w.status |= 4;         /* wait for this group's loads here */
 #endif
@@ -724,9 +742,12 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
                 }
                 w0 = w1; w1 = w2; w2 = w3;
             }
-            w0 = v0; w1 = v1; w2 = v2; w3 = v3; packed = packedNext; cnt = cntNext;
+            w0 = v0; w1 = v1; w2 = v2; w3 = v3; packed = packedNext;
+            cnt = nextTaken ? 0 : cntNext;                     /* a group of the next chunk waits for that chunk's turn */
         }
         if (cand && !nontrivial && lane >= from && !w.bit(q)) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+        haveFirst = nextTaken;
+        if (nextTaken) { cnt = cntNext; nontrivial = nontrivialNext; pend = pendNext; }
         cur = nxt; keyNext = keyAfter;
     }
     if (lane == 0) { w.F.out[0] = nRects; w.F.out[1] = w.status; w.F.out[2] = 0; w.F.out[3] = 0; /* k_rect_improve's status word and its reasons */ }
