@@ -328,10 +328,14 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
      * range, and a consumed entry's slot is free again */
     if (tid == 0) { sh.qHead = 0; sh.qTail = 0; sh.bigTop = ORD_QCAP; sh.qOverflow = 0; sh.heapNeeded = 0; }
     __syncthreads();
+    /* what the workgroup partitions together: ranges above ORD_BIG records - and, in an array of fewer than 16 ORD_BIG records,
+     * above a sixteenth of it (not below 1024), so that a plane cloud of a few thousand points still leaves every wavefront a
+     * few ranges instead of the whole array to the one that takes it */
+    const uint32_t bigAbove = min((uint32_t)ORD_BIG, max(1024u, (uint32_t)n >> 4));
     auto push_range = [&](uint32_t f, uint32_t l, int d) {                /* thread 0 */
         if (l - f <= 16) return;
         if (sh.qTail >= sh.bigTop) { sh.qOverflow |= 1; return; }
-        const int at = l - f > ORD_BIG ? --sh.bigTop : sh.qTail++;
+        const int at = l - f > bigAbove ? --sh.bigTop : sh.qTail++;
         sh.queue[at].first = f; sh.queue[at].last = l; sh.queue[at].depth = d;
     };
     if (tid == 0) push_range(0, (uint32_t)n, depthLimit);
