@@ -30,7 +30,15 @@
 /* NTH = threads of the workgroup (a multiple of 64, template parameter): 1024 for the 196 000 keys of a frame's pixel ordering,
  * 256 for a plane's voxel records - a workgroup's LDS is 128 bytes per thread for the counting passes plus the range queue, and
  * a 1024-thread sort fills a CU's LDS alone (no other kernel's wavefronts beside it) */
+#ifndef ORD_BIG
 #define ORD_BIG 8192             /* ranges above this many records: one at a time by the whole workgroup */
+#endif
+#ifndef ORD_BIG_SHIFT
+#define ORD_BIG_SHIFT 4
+#endif
+#ifndef ORD_BIG_FLOOR
+#define ORD_BIG_FLOOR 1024
+#endif
 #define ORD_QCAP 256             /* pending ranges an array can hold (LDS, 12 bytes each).  A workgroup partition leaves at most two and the
                                   * wavefront phase adds none: ~2 n / ORD_BIG entries for keys that split evenly (48 for a frame's
                                   * 196 000 pixels); with 1024 entries a sort held 47.5 KB of LDS - three per CU - with 256 it is
@@ -331,7 +339,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
     /* what the workgroup partitions together: ranges above ORD_BIG records - and, in an array of fewer than 16 ORD_BIG records,
      * above a sixteenth of it (not below 1024), so that a plane cloud of a few thousand points still leaves every wavefront a
      * few ranges instead of the whole array to the one that takes it */
-    const uint32_t bigAbove = min((uint32_t)ORD_BIG, max(1024u, (uint32_t)n >> 4));
+    const uint32_t bigAbove = min((uint32_t)ORD_BIG, max((uint32_t)ORD_BIG_FLOOR, (uint32_t)n >> ORD_BIG_SHIFT));
     auto push_range = [&](uint32_t f, uint32_t l, int d) {                /* thread 0 */
         if (l - f <= 16) return;
         if (sh.qTail >= sh.bigTop) { sh.qOverflow |= 1; return; }
