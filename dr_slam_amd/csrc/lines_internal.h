@@ -80,6 +80,7 @@ hipError_t drfe_launch_lbd_batch(const LbdLine* d_lines, const int* d_frameCount
 struct LsdRect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 #define DRFE_LSD_STATUS_UNCERTAIN 1     /* a cos / sin whose correct rounding could not be certified (cr_sincos.h) */
 #define DRFE_LSD_STATUS_OVERFLOW 2      /* more accepted regions than rectCap */
+#define DRFE_LSD_OUT_NEXT_RECT 36       /* out[36]: the next rectangle k_rect_improve's wavefronts take (zeroed by k_lsd_grow) */
 #define DRFE_LSD_OUT_INTS 40             /* ints per frame in LsdGrowFrame::out: count, status, pad, pad, then 16 x u64 phase counters of LSD_PROFILE builds */
 /* one frame of a k_lsd_grow launch: its level-line fields, the sorted pseudo-ordering, scratch and outputs */
 struct LsdGrowFrame {

@@ -750,7 +750,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         if (nextTaken) { cnt = cntNext; nontrivial = nontrivialNext; pend = pendNext; }
         cur = nxt; keyNext = keyAfter;
     }
-    if (lane == 0) { w.F.out[0] = nRects; w.F.out[1] = w.status; w.F.out[2] = 0; w.F.out[3] = 0; /* k_rect_improve's status word and its reasons */ }
+    if (lane == 0) { w.F.out[DRFE_LSD_OUT_NEXT_RECT] = 0; w.F.out[0] = nRects; w.F.out[1] = w.status; w.F.out[2] = 0; w.F.out[3] = 0; /* k_rect_improve's status word and its reasons */ }
 #ifdef LSD_PROFILE
     PROF_ADD(7, tAll);
     if (lane == 0) for (int k = 0; k < 16; k++) ((GLOBAL_AS unsigned long long*)(w.F.out + 4))[k] = w.prof[k];

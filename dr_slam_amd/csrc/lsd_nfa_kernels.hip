@@ -268,7 +268,7 @@ __device__ __forceinline__ int2 rect_walk_count_lane(const RectCand& rc, const R
     return make_int2(total, alg);
 }
 
-/* blockIdx.y = frame of the launch, blockIdx.x strides over the frame's rectangles in groups of NFA_RECTS */
+/* blockIdx.y = frame of the launch; the frame's gridDim.x wavefronts take its rectangles one by one, NFA_RECTS at a time each */
 __global__ __launch_bounds__(64) void k_rect_improve(const LsdGrowFrame* __restrict__ frames, int W, int H, int rectMode, LsdNfaTables T,
                                                      int rectCap, LsdSegOut* __restrict__ segs)
 {
@@ -286,22 +286,24 @@ __global__ __launch_bounds__(64) void k_rect_improve(const LsdGrowFrame* __restr
 #else
 #define NTP(k, t0) (void)(t0)
 #endif
-    for (int base = blockIdx.x * NFA_RECTS; base < count; base += gridDim.x * NFA_RECTS) {
-        if (selLane) {
-            ImproveShared& S = SS[r];
-            const int id = base + r;
-            S.id = id; S.active = id < count ? 1 : 0;
-            if (S.active) {
-                const LsdRect rec0 = F.rects[id];
-                Hyp h;
-                h.x1 = rec0.x1; h.y1 = rec0.y1; h.x2 = rec0.x2; h.y2 = rec0.y2; h.width = rec0.width; h.prec = rec0.prec;
-                h.best.v = 0; h.best.e = 0; h.best.n = h.best.k = h.best.pj = -1; h.best.unc = 0;
-                h.pj = 0; h.stage = 0;
-                S.q[0] = h; S.nq = 1; S.qi = 0; S.stage = 0; S.nOut = 0; S.outKeep = 0; S.flag = 0; S.why = 0;
-                S.dx = rec0.dx; S.dy = rec0.dy; S.theta = rec0.theta;
-                for (int k = 0; k < 4; k++) S.outSeg[k] = 0.f;
-            }
+    /* A slot takes the frame's next rectangle as soon as its own is decided (a counter in the frame's out words, zeroed by
+     * k_lsd_grow): rectangles need one to a dozen stage rounds, and twelve marching as a group waited for their slowest. */
+    auto next_rect = [&](ImproveShared& S) {                   /* the slot's selection lane */
+        const int id = atomicAdd(&F.out[DRFE_LSD_OUT_NEXT_RECT], 1);
+        S.id = id; S.active = id < count ? 1 : 0;
+        if (S.active) {
+            const LsdRect rec0 = F.rects[id];
+            Hyp h;
+            h.x1 = rec0.x1; h.y1 = rec0.y1; h.x2 = rec0.x2; h.y2 = rec0.y2; h.width = rec0.width; h.prec = rec0.prec;
+            h.best.v = 0; h.best.e = 0; h.best.n = h.best.k = h.best.pj = -1; h.best.unc = 0;
+            h.pj = 0; h.stage = 0;
+            S.q[0] = h; S.nq = 1; S.qi = 0; S.stage = 0; S.nOut = 0; S.outKeep = 0; S.flag = 0; S.why = 0;
+            S.dx = rec0.dx; S.dy = rec0.dy; S.theta = rec0.theta;
+            for (int k = 0; k < 4; k++) S.outSeg[k] = 0.f;
         }
+    };
+    {
+        if (selLane) next_rect(SS[r]);
         __syncthreads();
         while (__ballot(candLane && SS[candLane ? r : 0].active != 0)) {
             /* candidate c of this stage of rectangle r: rect_improve's cumulative modifications of a copy of the hypothesis'
@@ -350,12 +352,12 @@ __global__ __launch_bounds__(64) void k_rect_improve(const LsdGrowFrame* __restr
                 if (!S.finished) S.stage = S.stage + 1;
                 else if (S.qi + 1 < S.nq) { S.qi = S.qi + 1; S.stage = S.q[S.qi].stage; }
                 else {
-                    S.active = 0;
                     LsdSegOut o;
                     o.x1 = S.outSeg[0]; o.y1 = S.outSeg[1]; o.x2 = S.outSeg[2]; o.y2 = S.outSeg[3];
                     o.flag = S.outKeep;
                     out[S.id] = o;
                     if (S.flag || S.nOut == 0) { atomicOr(&F.out[2], 1); atomicOr(&F.out[3], S.why ? S.why : 32); }      /* out[3]: why (DRFE_TRACE_LINES) */
+                    next_rect(S);
                 }
             }
             __syncthreads();
@@ -373,8 +375,9 @@ hipError_t drfe_launch_rect_improve(const LsdGrowFrame* d_frames, int nframes, i
                                     int rectCap, LsdSegOut* d_segs, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
-    /* 128 wavefronts per frame, twelve rectangles each per pass (a 640 x 480 frame has ~1500 rectangles) */
-    hipLaunchKernelGGL(k_rect_improve, dim3(128, nframes), dim3(64), 0, s, d_frames, W, H, rectMode, tab, rectCap, d_segs);
+    /* wavefronts per frame, twelve rectangles in flight each (a 640 x 480 frame has 1500-2500 rectangles) */
+    static const int perFrame = [] { const char* e = std::getenv("DRFE_NFA_BLOCKS"); const int v = e ? std::atoi(e) : 128; return v < 1 ? 1 : v > 1024 ? 1024 : v; }();
+    hipLaunchKernelGGL(k_rect_improve, dim3(perFrame, nframes), dim3(64), 0, s, d_frames, W, H, rectMode, tab, rectCap, d_segs);
     return hipGetLastError();
 }
 
