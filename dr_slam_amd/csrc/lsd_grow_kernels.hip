@@ -581,6 +581,9 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
         w.F.rects = (GLOBAL_AS double*)f.rects; w.F.out = (GLOBAL_AS int*)f.out; w.F.nOrder = f.nOrder;
         w.F.minSeedBin = f.meta ? 1024u - (uint32_t)(f.meta[1] & 0xFFFFFFFFull) : f.minSeedBin;
     }
+#ifdef LSD_SETPRIO
+    __builtin_amdgcn_s_setprio(LSD_SETPRIO);
+#endif
     w.W = W; w.H = H; w.lane = threadIdx.x; w.status = 0;
 #ifdef LSD_PROFILE
     for (int k = 0; k < 16; k++) w.prof[k] = 0;
