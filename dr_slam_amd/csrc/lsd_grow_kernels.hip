@@ -553,11 +553,10 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
      * band of 0.02 degrees; a tolerance near 0 or 90 degrees switches the shortcut off) */
     AlignTan T2; T2.tLo = 0.f; T2.tHi = 0.f;
     const double tauU = uni_d(tau), band = 0.02 * 3.14159265358979323846 / 180.0;
-    if (tauU - band > 1e-3 && tauU + band < 1.5) {
+    if (T.tLo > 0.f && tauU - band > 1e-3 && tauU + band < 1.5) {           /* T.tLo <= 0: the launch runs without the shortcut (DRFE_LSD_EXACT_ALIGN) */
         T2.tLo = (float)(tan(tauU - band) * (1.0 - 1e-5));
         T2.tHi = (float)(tan(tauU + band) * (1.0 + 1e-5));
     }
-    (void)T;
     n = grow<true>(w, sx, sy, tauU, regAngle, win, T2, 0);
     if (n < 2) return false;
     to_rect(w, n, regAngle, prec, rec, true);

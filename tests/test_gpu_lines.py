@@ -433,6 +433,27 @@ def test_device_order_sort_heap_branch_equals_libstdcxx(ctx):
     assert reached > 200
 
 
+def test_lsd_alignment_shortcut_equals_reference_arithmetic(ctx):
+    """k_lsd_grow decides region_grow's alignment test from dot / cross products wherever the decision is not within 0.02 degrees
+    of the tolerance (lsd_grow_kernels.hip: align_class) and evaluates cv::fastAtan2 only inside that band.  With
+    DRFE_LSD_EXACT_ALIGN every test is the reference's arithmetic: both launches must return the same bytes - on top of the
+    comparisons with the oracle, this holds the shortcut to the kernel's own long way on more frames than the oracle has time for."""
+    import os
+    from dr_slam_amd import synth
+    for kind, cam, seed in (("living_room", synth.ICL, 41), ("room_boxes", synth.TUM3, 42), ("planar_lowtexture", synth.TUM3, 43), ("corridor", synth.ICL, 44)):
+        gray = np.stack([f[0] for f in synth.sequence(seed, 12, cam=cam, kind=kind)])
+        a = ctx.lsd_extract_batch(gray, n_threads=2)
+        os.environ["DRFE_LSD_EXACT_ALIGN"] = "1"
+        try:
+            b = ctx.lsd_extract_batch(gray, n_threads=2)
+        finally:
+            del os.environ["DRFE_LSD_EXACT_ALIGN"]
+        assert len(a) == len(b) == 12
+        for x, y in zip(a, b):
+            assert x["detected"] == y["detected"] and x["lines"].tobytes() == y["lines"].tobytes(), kind
+            assert np.array_equal(x["desc"], y["desc"]) and x["lineF"].tobytes() == y["lineF"].tobytes(), kind
+
+
 def test_lsd_batch_device_edge_cases(ctx):
     """drfe_lsd_extract_batch with the sequential core on the device, on frames at the edges of what the kernels assume, all in
     one batch: a constant image (no pixel has a level-line angle: nothing to order, no seed), uniform noise (every pixel a seed,
