@@ -25,7 +25,9 @@
 #include "cr_sincos.h"
 
 #define AHCD_HEAP 3200            /* priority-queue capacity (<= init blocks of a 640 x 480 frame) */
-#define AHCD_LIST 768             /* a neighbour list staged in LDS */
+#define AHCD_LIST 376             /* a neighbour list staged in LDS (a longer one hands the frame to the host).  The longest seen on 256 frames
+                                   * of the four scene kinds is 125; a plane that fills a 64 x 48 grid of blocks has ~224 neighbours.  With 376
+                                   * k_ahc_cluster holds 22 992 bytes of LDS - seven frames per CU - and k_ahc_refine 17 008: nine */
 #define AHCD_MAXEX 128            /* extracted planes before the re-merge */
 /* the words k_ahc_cluster leaves for k_ahc_refine (AhcDevFrame::handoff, AHC_HANDOFF_INTS of planes_internal.h): [0] extracted
  * nodes, [1] flood-fill seeds, [2] nodes, [3] neighbour pool fill, then the node ids, their kept-block flags, phase timers */
@@ -329,6 +331,9 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         const double npx = c.fit[8 * (size_t)p + 3], npy = c.fit[8 * (size_t)p + 4], npz = c.fit[8 * (size_t)p + 5];
         if (uni_b(nouseP != 0)) continue;
         const int Lp = uni_i(lenP);
+#ifdef AHC_PROFILE
+        if (c.lane == 0) atomicMax(&g_ahcProf[7], (unsigned long long)Lp);
+#endif
         if (Lp > AHCD_LIST) { c.status |= 2; return; }
         const GLOBAL_AS int* listP = c.pool + offP;
         for (int k = lane; k < Lp; k += 64) c.lA[k] = (uint16_t)listP[k];

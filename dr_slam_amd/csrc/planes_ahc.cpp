@@ -1141,8 +1141,8 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         if (prof_fn fn = (prof_fn)dlsym(RTLD_DEFAULT, "drfe_debug_ahc_cluster_profile")) {
             unsigned long long v[8] = {0};
             if (fn(v) == 0 && v[0])
-                std::fprintf(stderr, "  ahCluster, frame 0 of every call since the last print: %llu pops (%llu merges); ms per call: heap pop %.2f, node + list loads %.2f, trial merges %.2f, merges %.2f, extract / disconnect %.2f\n",
-                             v[0], v[6], v[1] / 1e5, v[2] / 1e5, v[3] / 1e5, v[4] / 1e5, v[5] / 1e5);
+                std::fprintf(stderr, "  ahCluster, frame 0 of every call since the last print: %llu pops (%llu merges); ms per call: heap pop %.2f, node + list loads %.2f, trial merges %.2f, merges %.2f, extract / disconnect %.2f; longest neighbour list of any frame %llu\n",
+                             v[0], v[6], v[1] / 1e5, v[2] / 1e5, v[3] / 1e5, v[4] / 1e5, v[5] / 1e5, v[7]);
         }
     }
     if (std::getenv("DRFE_TRACE_PLANES"))
