@@ -522,7 +522,9 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
     const uint32_t xy0 = w.F.reg[0];
     const int sx = (int)(xy0 & 0xFFFFu), sy = (int)(xy0 >> 16);
     const double xc = (double)sx, yc = (double)sy, angC = w.F.ang[(size_t)sy * W + sx];
-    double sum = 0, ssum = 0;
+    /* sum / ssum over the members within the rectangle's width of the seed, in member order: ordered_sums3 again (a member outside
+     * adds +0.0, which changes neither sum: they start at +0.0 and a sum that started there never becomes -0.0) */
+    double acc = 0;
     int cntIn = 0;
     for (int base = 0; base < n; base += 64) {
         const int j = base + lane;
@@ -539,14 +541,10 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
                 dd = d * d;
             }
         }
-        unsigned long long mk = __ballot(in);
-        cntIn += __popcll(mk);
-        while (mk) {
-            const int l = __builtin_ctzll(mk);
-            mk &= mk - 1;
-            sum += rl_f64(d, l); ssum += rl_f64(dd, l);
-        }
+        cntIn += __popcll(__ballot(in));
+        acc = ordered_sums3(w, acc, d, dd, 0.0, min(64, n - base));
     }
+    const double sum = rl_f64(acc, 0), ssum = rl_f64(acc, 1);
     const double mean = sum / (double)cntIn;
     const double tau = 2.0 * sqrt((ssum - 2.0 * mean * sum) / (double)cntIn + mean * mean);
     /* the second growth runs with the tolerance tau: the shortcut's thresholds for it (tan to a relative 1e-6 is ample inside a
