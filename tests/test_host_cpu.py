@@ -473,3 +473,49 @@ def test_shard_sequences_dealt_round_robin():
         assert all((g % nranks == r).all() for r, g in enumerate(got))
     with pytest.raises(lib.DrfeError):
         lib.Shard.sequences_of_rank(4, 2, 2)
+
+
+def test_long_kernels_keep_their_lds_budget(tmp_path):
+    """The full front-end is bound by LDS x time: how many of the long kernels' workgroups a CU holds is
+    decided by their LDS against the 1280-byte allocation granule of its 160 KB.  Reads the kernels' static LDS out of the code
+    objects inside libdrfe.so (llvm-objdump --offloading + llvm-readelf --notes; no GPU) and holds each to the residency the
+    design counts on; the dynamic LDS of the two sorts is introsort_device.h's ORD_DYN_WORDS x threads x 4."""
+    import re, shutil, subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = os.path.join(ROOT, "dr_slam_amd", "csrc", "libdrfe.so")
+    if not (os.path.exists(so) and os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("libdrfe.so or the LLVM tools are not here")
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(so, work / "x.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "x.so"], cwd=work, check=True, capture_output=True)
+    lds = {}
+    for f in sorted(os.listdir(work)):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f], cwd=work, capture_output=True, text=True).stdout
+        size = None
+        for line in notes.splitlines():
+            m = re.match(r"\s+\.group_segment_fixed_size:\s+(\d+)", line)
+            if m:
+                size = int(m.group(1))
+            m = re.match(r"\s+\.name:\s+(\S+)", line)
+            if m and size is not None:
+                lds[m.group(1)] = size
+                size = None
+    def find(sub):
+        hits = [v for k, v in lds.items() if sub in k]
+        assert len(hits) == 1, (sub, sorted(lds))
+        return hits[0]
+    granule, cu = 1280, 160 * 1024
+    def per_cu(nbytes):
+        return cu // (-(-nbytes // granule) * granule)
+    words = int(re.search(r"#define ORD_DYN_WORDS (\d+)", open(os.path.join(ROOT, "dr_slam_amd", "csrc", "introsort_device.h")).read()).group(1))
+    assert per_cu(find("k_ahc_cluster")) >= 7
+    assert per_cu(find("k_ahc_refine")) >= 9
+    assert per_cu(find("k_rect_improve")) >= 7
+    assert per_cu(find("k_lsd_order") + words * 256 * 4) >= 7
+    assert per_cu(find("k_voxel_grid") + words * 256 * 4) >= 7
+    # k_lsd_grow: all dynamic - bitmap of the 0.8-scaled 640 x 480 frame + member ring + the three-sum columns (drfe_lsd_grow_lds_bytes)
+    ring = int(re.search(r"#define LSD_RING (\d+)", open(os.path.join(ROOT, "dr_slam_amd", "csrc", "lsd_grow_kernels.hip")).read()).group(1))
+    assert find("k_lsd_grow") == 0 and per_cu(512 * 384 // 8 + ring * 4 + 64 * 3 * 8) >= 6
