@@ -112,10 +112,11 @@ hipError_t drfe_long_kernel_stream(hipStream_t* s, int part)
          * the same rate either way (profiles/r04_queue_probe.txt) - so the default stays the lowest level for both: the ORB batch,
          * CAPE and the pools' lanes keep the middle level to themselves.  DRFE_CU_SPLIT=<percent> gives the line path that share of
          * every 32 CUs and the plane path the rest (an experiment: 3 350-3 520 frames/s at 50 / 62 against 4 580-4 850 with every
-         * kernel free to run anywhere - the mix packs the LDS better than a partition). */
-        static const bool split = [] { const char* m = std::getenv("DRFE_LONG_PRIO"); return m && m[0] == 's' && m[1] == 'p'; }();
+         * kernel free to run anywhere - the mix packs the LDS better than a partition).  Either path's long kernels one priority
+         * level above the other's (DRFE_LONG_PRIO=split / lines) is slower as well: 4 310-4 390 / 3 860-4 190 against 4 940-5 020. */
+        static const int split = [] { const char* m = std::getenv("DRFE_LONG_PRIO"); return !m ? 0 : (m[0] == 's' && m[1] == 'p') ? 1 : (m[0] == 'l' ? 2 : 0); }();      /* "split": planes up, "lines": lines up */
         const int mid = (prLow + prHigh) / 2;
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, (part == 1 && split && mid != prLow) ? mid : prLow);
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, (mid != prLow && ((part == 1 && split == 1) || (part == 0 && split == 2))) ? mid : prLow);
     }
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
