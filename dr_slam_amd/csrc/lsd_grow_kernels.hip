@@ -513,15 +513,17 @@ __device__ __forceinline__ bool shrink(Wave& w, int& n, double regAngle, double 
     return true;
 }
 
-__device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double prec, Rect& rec, double densityTh, const Window& win, const AlignTan T)
+__device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double prec, Rect& rec, double densityTh, const Window& win, const AlignTan T,
+                                       int sx, int sy)
 {
     const int lane = w.lane, W = w.W;
     double density = density_of(rec, n);
     if (uni(density >= densityTh)) return true;
     wg_fence();
-    const uint32_t xy0 = w.F.reg[0];
-    const int sx = (int)(xy0 & 0xFFFFu), sy = (int)(xy0 >> 16);
-    const double xc = (double)sx, yc = (double)sy, angC = w.F.ang[(size_t)sy * W + sx];
+    /* the seed (member 0) and its angle are the caller's and the window's; the members of a region of at most LSD_RING come from
+     * the LDS mirror (the region was grown a moment ago): no trip to HBM before the members' angles can be asked for */
+    const double xc = (double)sx, yc = (double)sy, angC = rl_f64(win.a, 24);
+    const bool fromRing = n <= LSD_RING;
     /* sum / ssum over the members within the rectangle's width of the seed, in member order: ordered_sums3 again (a member outside
      * adds +0.0, which changes neither sum: they start at +0.0 and a sum that started there never becomes -0.0) */
     double acc = 0;
@@ -531,7 +533,7 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
         bool in = false;
         double d = 0, dd = 0;
         if (j < n) {
-            const uint32_t xy = w.F.reg[j];
+            const uint32_t xy = fromRing ? w.ring[j] : w.F.reg[j];
             const int mx = (int)(xy & 0xFFFFu), my = (int)(xy >> 16);
             const uint32_t q = (uint32_t)(my * W + mx);
             atomicAnd(&w.bm[q >> 5], ~(1u << (q & 31)));
@@ -727,7 +729,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
                         Rect rec;
                         to_rect(w, n, regAngle, prec, rec, true);
                         const unsigned long long tf0 = PROF_T();
-                        const bool okr = refine(w, n, regAngle, prec, rec, densityTh, w0, T);
+                        const bool okr = refine(w, n, regAngle, prec, rec, densityTh, w0, T, gx, gy);
                         PROF_ADD(6, tf0);
                         if (okr) {
                             if (nRects < rectCap) {
