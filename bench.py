@@ -373,7 +373,7 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
     return B * steps / el, el / steps * 1e3, threads
 
 
-def full_frontend(cam_name, n_frames: int = 512, reps: int = 3, inflight: int = 5):
+def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 5):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
     the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame);
