@@ -24,10 +24,19 @@
 #include "ahc_math.h"
 #include "cr_sincos.h"
 
-#define AHCD_HEAP 3200            /* priority-queue capacity (<= init blocks of a 640 x 480 frame) */
-#define AHCD_LIST 376             /* a neighbour list staged in LDS (a longer one hands the frame to the host).  The longest seen on 256 frames
-                                   * of the four scene kinds is 125; a plane that fills a 64 x 48 grid of blocks has ~224 neighbours.  With 376
-                                   * k_ahc_cluster holds 22 992 bytes of LDS - seven frames per CU - and k_ahc_refine 17 008: nine */
+/* Two instantiations of each kernel (template parameters HEAP, LIST):
+ *   640 x 480-class frames (<= 3200 init blocks): HEAP 3200, LIST 376.  The longest neighbour list seen on 256 frames of the four
+ *     scene kinds is 125; a plane that fills a 64 x 48 grid of blocks has ~224 neighbours.  k_ahc_cluster then holds 22 992 bytes
+ *     of LDS - seven frames per CU - and k_ahc_refine 17 008: nine;
+ *   up to 12 800 init blocks (BASELINE config 5: 1280 x 960 = 128 x 96 blocks): HEAP 12800, LIST 1024 (a plane that fills the
+ *     grid has ~448 neighbours): 86 KB for k_ahc_cluster_big - one frame per CU, the queue still entirely in LDS.
+ * HEAP = priority-queue capacity (>= init blocks); LIST = a neighbour list staged in LDS (a longer one hands the frame to the host) */
+#define AHCD_HEAP_SMALL 3200
+#define AHCD_LIST_SMALL 376
+#define AHCD_HEAP_BIG 12800
+#define AHCD_LIST_BIG 1024
+#define AHCD_PIXBITS 21           /* a flood-fill queue entry is pixel | plane << 21: pixels below 2^21 (1280 x 960 = 1 228 800), planes below 128 */
+#define AHCD_PIXMASK ((1u << AHCD_PIXBITS) - 1u)
 #define AHCD_MAXEX 128            /* extracted planes before the re-merge */
 /* the words k_ahc_cluster leaves for k_ahc_refine (AhcDevFrame::handoff, AHC_HANDOFF_INTS of planes_internal.h): [0] extracted
  * nodes, [1] flood-fill seeds, [2] nodes, [3] neighbour pool fill, then the node ids, their kept-block flags, phase timers */
@@ -60,7 +69,7 @@ __device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_S
  * instructions whatever the step holds - the search over the step's entries it replaces cost 65 per ENTRY. */
 __device__ __forceinline__ void chain_sort64(bool live, int pixel, int lane, int& prev, int& depth, bool& isLast)
 {
-    uint32_t key = (live ? (uint32_t)pixel : (0x3FFFFC0u | (uint32_t)lane)) << 6 | (uint32_t)lane;   /* pixels are below 2^20 */
+    uint32_t key = (live ? (uint32_t)pixel : (0x3FFFFC0u | (uint32_t)lane)) << 6 | (uint32_t)lane;   /* pixels are below 2^21 */
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
@@ -122,6 +131,7 @@ struct Ctx {
     /* LDS */
     float* heapKey; uint16_t* heapId; uint16_t* lA; uint16_t* lB; uint16_t* lU; double* win;      /* node ids are below 2 NB + 256 = 6400 */
     int heapSize, nNodes, poolUsed, status, lane;
+    int listCap;                                     /* entries of lA / lB (lU: twice that) */
     AhcDevParams P;
 };
 
@@ -144,7 +154,7 @@ __device__ __forceinline__ bool heap_less_new(const Ctx& c, double key, float kf
     const double db = heap_exact(c, ib);
     return key < db || (key == db && id < ib);
 }
-/* The queue is a 64-ary heap in LDS (children of entry i: 64 i + 1 .. 64 i + 64): three levels hold 3200 entries, a level of
+/* The queue is a 64-ary heap in LDS (children of entry i: 64 i + 1 .. 64 i + 64): three levels hold 3200 entries (four: 12 800), a level of
  * sift-down is ONE read by the 64 lanes and a minimum across the wavefront, and sift-up looks at two parents at most.  (The binary
  * heap walked by one lane cost twelve levels of dependent LDS reads per pop: 2.1 us, a fifth of the clustering.) */
 __device__ void heap_push(Ctx& c, double key, int id)                 /* one lane */
@@ -334,7 +344,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
 #ifdef AHC_PROFILE
         if (c.lane == 0) atomicMax(&g_ahcProf[7], (unsigned long long)Lp);
 #endif
-        if (Lp > AHCD_LIST) { c.status |= 2; return; }
+        if (Lp > c.listCap) { c.status |= 2; return; }
         const GLOBAL_AS int* listP = c.pool + offP;
         for (int k = lane; k < Lp; k += 64) c.lA[k] = (uint16_t)listP[k];
 #ifdef AHC_PROFILE
@@ -410,7 +420,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         if (uni_b(merge)) {
             const int id = c.nNodes;
             const int Lc = candLen;
-            if (id >= c.P.maxNodes || Lc > AHCD_LIST) { c.status |= 2; return; }
+            if (id >= c.P.maxNodes || Lc > c.listCap) { c.status |= 2; return; }
             c.nNodes = id + 1;
             if (lane < 9) c.S[9 * (size_t)id + lane] = c.win[lane];
             if (lane < 8) c.fit[8 * (size_t)id + lane] = c.win[9 + lane];
@@ -505,11 +515,12 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
 
 } // namespace
 
-extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+template <int HEAP, int LIST>
+__device__ __forceinline__ void ahc_cluster_frame(const AhcDevFrame* __restrict__ frames, const AhcDevParams& P)
 {
-    __shared__ float heapKey[AHCD_HEAP];
-    __shared__ uint16_t heapId[AHCD_HEAP];
-    __shared__ uint16_t lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
+    __shared__ float heapKey[HEAP];
+    __shared__ uint16_t heapId[HEAP];
+    __shared__ uint16_t lA[LIST], lB[LIST], lU[2 * LIST];
     __shared__ double win[18];
     __shared__ int ex[AHCD_MAXEX];
     __shared__ uint8_t isValid[AHCD_MAXEX];
@@ -523,13 +534,13 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
     c.dsParent = (GLOBAL_AS int*)F.dsParent; c.dsSize = (GLOBAL_AS int*)F.dsSize; c.G = (GLOBAL_AS int*)F.G; c.blkMap = (GLOBAL_AS int*)F.blkMap;
     c.ridToPlid = (GLOBAL_AS int*)F.ridToPlid; c.mem = (GLOBAL_AS int16_t*)F.membership; c.dist = (GLOBAL_AS float*)F.distMap; c.rf = (GLOBAL_AS uint32_t*)F.rf;
     c.heapKey = heapKey; c.heapId = heapId; c.lA = lA; c.lB = lB; c.lU = lU; c.win = win;
-    c.heapSize = 0; c.nNodes = 0; c.poolUsed = 0; c.status = 0; c.lane = lane; c.P = P;
+    c.heapSize = 0; c.nNodes = 0; c.poolUsed = 0; c.status = 0; c.lane = lane; c.listCap = LIST; c.P = P;
     const GLOBAL_AS AhcBlockRec* blocks = (const GLOBAL_AS AhcBlockRec*)F.blocks;
     GLOBAL_AS int* out = (GLOBAL_AS int*)F.out;
     const int w = P.w, h = P.h, Nw = P.Nw, Nh = P.Nh, NB = P.NB, npx = w * h;
     /* no cloud for k_voxel_grid unless the frame runs to its end */
     if (F.jobs) for (int i = lane; i < 2 * P.planeCap; i += 64) ((GLOBAL_AS int*)F.jobs)[i] = 0;
-    if (NB > AHCD_HEAP || npx > (1 << 20)) { if (lane == 0) { out[0] = 0; out[1] = 4; } return; }
+    if (NB > HEAP || npx > (1 << AHCD_PIXBITS)) { if (lane == 0) { out[0] = 0; out[1] = 4; } return; }
 
 #ifdef AHC_PROFILE
     unsigned long long tp[8]; int tpi = 0;
@@ -658,11 +669,11 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
         int at = nRf + incl - cnt;
         if (cnt) {
             if (bm < 0) {
-                if (up >= 0) { const int spix = (i * AHC_WIN - 1) * w + j * AHC_WIN; for (int k = 1; k < AHC_WIN; ++k) c.rf[at++] = (uint32_t)(spix + k) | (uint32_t)up << 20; }
-                if (left >= 0) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN - 1; for (int k = 0; k < AHC_WIN - 1; ++k) c.rf[at++] = (uint32_t)(spix + k * w) | (uint32_t)left << 20; }
+                if (up >= 0) { const int spix = (i * AHC_WIN - 1) * w + j * AHC_WIN; for (int k = 1; k < AHC_WIN; ++k) c.rf[at++] = (uint32_t)(spix + k) | (uint32_t)up << AHCD_PIXBITS; }
+                if (left >= 0) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN - 1; for (int k = 0; k < AHC_WIN - 1; ++k) c.rf[at++] = (uint32_t)(spix + k * w) | (uint32_t)left << AHCD_PIXBITS; }
             } else {
-                if (i > 0 && up != bm) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN; for (int k = 0; k < AHC_WIN - 1; ++k) c.rf[at++] = (uint32_t)(spix + k) | (uint32_t)bm << 20; }
-                if (j > 0 && left != bm) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN; for (int k = 1; k < AHC_WIN; ++k) c.rf[at++] = (uint32_t)(spix + k * w) | (uint32_t)bm << 20; }
+                if (i > 0 && up != bm) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN; for (int k = 0; k < AHC_WIN - 1; ++k) c.rf[at++] = (uint32_t)(spix + k) | (uint32_t)bm << AHCD_PIXBITS; }
+                if (j > 0 && left != bm) { const int spix = (i * AHC_WIN) * w + j * AHC_WIN; for (int k = 1; k < AHC_WIN; ++k) c.rf[at++] = (uint32_t)(spix + k * w) | (uint32_t)bm << AHCD_PIXBITS; }
             }
         }
         nRf += tot;
@@ -685,21 +696,31 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame
 #endif
 }
 
+extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    ahc_cluster_frame<AHCD_HEAP_SMALL, AHCD_LIST_SMALL>(frames, P);
+}
+extern "C" __global__ __launch_bounds__(64) void k_ahc_cluster_big(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    ahc_cluster_frame<AHCD_HEAP_BIG, AHCD_LIST_BIG>(frames, P);
+}
+
 /* the second half of a frame: flood fill from the seeds, the re-merge of the grown planes, labels, member lists, plane clouds.
  * Its own kernel because its LDS need is half of the clustering's (no 3200-entry queue): the CU holds five of these wavefronts,
  * or three of k_ahc_cluster, where the single kernel's 57 KB allowed two - and whatever LDS these long-running wavefronts hold
  * is what the line path's growth (27 KB per frame) cannot use. */
-extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+template <int HEAP, int LIST>
+__device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__ frames, const AhcDevParams& P)
 {
     __shared__ float heapKey[AHCD_MAXEX];                     /* the re-merge's queue: at most the extracted planes */
     __shared__ uint16_t heapId[AHCD_MAXEX];
-    __shared__ uint16_t lA[AHCD_LIST], lB[AHCD_LIST], lU[2 * AHCD_LIST];
+    __shared__ uint16_t lA[LIST], lB[LIST], lU[2 * LIST];
     __shared__ double win[18];
     __shared__ int ex[AHCD_MAXEX], ex2[AHCD_MAXEX], plidmap[AHCD_MAXEX];
     __shared__ uint8_t isValid[AHCD_MAXEX];
     __shared__ double plN[AHCD_MAXEX][3], plC[AHCD_MAXEX][3], plMse[AHCD_MAXEX];
     __shared__ int counts[AHCD_MAXEX + 1], kcounts[AHCD_MAXEX + 1];
-    __shared__ int8_t blkLds[AHCD_HEAP];                      /* flood fill: 1 = the block is kept whole (its pixels are final) */
+    __shared__ int8_t blkLds[HEAP];                           /* flood fill: 1 = the block is kept whole (its pixels are final) */
     const AhcDevFrame F = frames[blockIdx.x];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -710,7 +731,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
     c.dsParent = (GLOBAL_AS int*)F.dsParent; c.dsSize = (GLOBAL_AS int*)F.dsSize; c.G = (GLOBAL_AS int*)F.G; c.blkMap = (GLOBAL_AS int*)F.blkMap;
     c.ridToPlid = (GLOBAL_AS int*)F.ridToPlid; c.mem = (GLOBAL_AS int16_t*)F.membership; c.dist = (GLOBAL_AS float*)F.distMap; c.rf = (GLOBAL_AS uint32_t*)F.rf;
     c.heapKey = heapKey; c.heapId = heapId; c.lA = lA; c.lB = lB; c.lU = lU; c.win = win;
-    c.heapSize = 0; c.status = 0; c.lane = lane; c.P = P;
+    c.heapSize = 0; c.status = 0; c.lane = lane; c.listCap = LIST; c.P = P;
     GLOBAL_AS int* out = (GLOBAL_AS int*)F.out;
     const GLOBAL_AS int* ho = (const GLOBAL_AS int*)F.handoff;
     const int w = P.w, h = P.h, Nw = P.Nw, Nh = P.Nh, NB = P.NB, npx = w * h;
@@ -756,7 +777,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
             if (mine) e = nextFrom == head + eLane ? eNext : c.rf[head + eLane];
             /* the next step's entries, when the queue already holds them: their fetch overlaps this step */
             if (head + 16 + eLane < tail) { eNext = c.rf[head + 16 + eLane]; nextFrom = head + 16 + eLane; }
-            const int sIdx = (int)(e & 0xFFFFFu), plid = (int)(e >> 20);
+            const int sIdx = (int)(e & AHCD_PIXMASK), plid = (int)(e >> AHCD_PIXBITS);
             const int sy = sIdx / w, sx = sIdx - sy * w;
             int cxn = sx, cyn = sy;
             bool have = false;
@@ -834,7 +855,7 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
             if (pm) {
                 const int np = __popcll(pm);
                 if (tail + np > P.rfCap) { c.status |= 2; break; }
-                if (push) c.rf[tail + __popcll(pm & lt)] = (uint32_t)cIdx | (uint32_t)plid << 20;
+                if (push) c.rf[tail + __popcll(pm & lt)] = (uint32_t)cIdx | (uint32_t)plid << AHCD_PIXBITS;
                 tail += np;
             }
             head += cnt;
@@ -979,12 +1000,32 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame*
 #endif
 }
 
+extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    ahc_refine_frame<AHCD_HEAP_SMALL, AHCD_LIST_SMALL>(frames, P);
+}
+extern "C" __global__ __launch_bounds__(64) void k_ahc_refine_big(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    ahc_refine_frame<AHCD_HEAP_BIG, AHCD_LIST_BIG>(frames, P);
+}
+
+int drfe_ahc_device_fits(int w, int h)
+{
+    return w >= AHC_WIN && h >= AHC_WIN && (w / AHC_WIN) * (h / AHC_WIN) <= AHCD_HEAP_BIG && (size_t)w * h <= ((size_t)1 << AHCD_PIXBITS);
+}
+
 hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
     static_assert(AHC_HANDOFF_INTS >= AHCD_HO_TP + 8, "handoff words");
-    hipLaunchKernelGGL(k_ahc_cluster, dim3(nframes), dim3(64), 0, s, d_frames, P);
-    hipLaunchKernelGGL(k_ahc_refine, dim3(nframes), dim3(64), 0, s, d_frames, P);
+    if (P.NB > AHCD_HEAP_BIG || (size_t)P.w * P.h > ((size_t)1 << AHCD_PIXBITS)) return hipErrorInvalidValue;
+    if (P.NB <= AHCD_HEAP_SMALL) {
+        hipLaunchKernelGGL(k_ahc_cluster, dim3(nframes), dim3(64), 0, s, d_frames, P);
+        hipLaunchKernelGGL(k_ahc_refine, dim3(nframes), dim3(64), 0, s, d_frames, P);
+    } else {
+        hipLaunchKernelGGL(k_ahc_cluster_big, dim3(nframes), dim3(64), 0, s, d_frames, P);
+        hipLaunchKernelGGL(k_ahc_refine_big, dim3(nframes), dim3(64), 0, s, d_frames, P);
+    }
     return hipGetLastError();
 }
 

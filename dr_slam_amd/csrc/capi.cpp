@@ -205,6 +205,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->planesDeviceCape = 1;
     c->lsdDeviceNfa = 1;
     c->lsdStats[0] = c->lsdStats[1] = c->lsdStats[2] = c->lsdStats[3] = 0;
+    c->capeStats[0] = c->capeStats[1] = 0;
+    c->ahcStats[0] = c->ahcStats[1] = c->ahcStats[2] = c->ahcStats[3] = 0;
     c->planesDeviceVoxel = 1;
     c->planesDeviceAhc = 1;
     c->ahcArena = nullptr;

@@ -1176,15 +1176,15 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     J.rectMode = c->lsdRectMode;
     J.deviceNfa = c->lsdDeviceNfa && std::getenv("DRFE_LSD_HOST_NFA") == nullptr;
     J.deviceKl = J.deviceNfa && std::getenv("DRFE_LSD_HOST_KEYLINES") == nullptr;
-    if (J.deviceKl && (A->klCap < max_lines || !A->d_kl)) {
+    if (J.deviceKl && (A->klCap < max_lines || A->klCap == 0)) {
         void* dp[] = {A->d_kl, A->d_klLineF, A->d_klLbd, A->d_klDesc, A->d_klOut};
         for (void* q : dp) if (q) (void)hipFree(q);
         void* hp[] = {A->h_kl, A->h_klLineF, A->h_klDesc, A->h_klOut};
         for (void* q : hp) if (q) (void)hipHostFree(q);
         A->d_kl = nullptr; A->d_klLineF = nullptr; A->d_klLbd = nullptr; A->d_klDesc = nullptr; A->d_klOut = nullptr;
         A->h_kl = nullptr; A->h_klLineF = nullptr; A->h_klDesc = nullptr; A->h_klOut = nullptr;
-        A->klCap = max_lines;
-        const size_t kn = (size_t)A->klCap * A->frames;
+        A->klCap = 0;                 /* committed below, once every buffer exists: a failed allocation leaves "no buffers" behind */
+        const size_t kn = (size_t)max_lines * A->frames;
         HIPCHK(c, hipMalloc((void**)&A->d_kl, kn * sizeof(drfe_keyline)));
         HIPCHK(c, hipMalloc((void**)&A->d_klLineF, kn * 3 * sizeof(double)));
         HIPCHK(c, hipMalloc((void**)&A->d_klLbd, kn * sizeof(LbdLine)));
@@ -1194,6 +1194,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         HIPCHK(c, hipHostMalloc((void**)&A->h_klLineF, kn * 3 * sizeof(double), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void**)&A->h_klDesc, kn * 32, hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void**)&A->h_klOut, (size_t)A->frames * 4 * sizeof(int), hipHostMallocDefault));
+        A->klCap = max_lines;
     }
     if (J.deviceNfa) {
         std::vector<double> lg;

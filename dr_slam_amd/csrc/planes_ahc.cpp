@@ -684,7 +684,7 @@ int drfe_planes_ahc_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_strid
         pool->push_back(l);
     }
     /* the extractor on the device, one wavefront per frame (drfe_planes_configure_extractor; same limits as the post batch) */
-    if (c->planesDeviceAhc && nframes > 1 && (w / AHC_WIN) * (h / AHC_WIN) <= 3200 && (size_t)w * h <= (1u << 20) && !std::getenv("DRFE_AHC_HOST"))
+    if (c->planesDeviceAhc && nframes > 1 && drfe_ahc_device_fits(w, h) && !std::getenv("DRFE_AHC_HOST"))
         return planes_ahc_post_batch_device(c, pool, T, depth, frame_stride, w, h, stride, nframes, K4, depth_factor, 0.f, 0.0, planes, cap, n_planes, seg,
                                             nullptr, nullptr, nullptr, member_offsets, member_idx);
     std::vector<int> rcs(T, DRFE_OK);
@@ -758,6 +758,7 @@ int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, 
 /* ---- the extractor on the device for a batch (ahc_frame_kernels.hip): frame slots in HBM ------------------------------------ */
 struct AhcArena {
     int w = 0, h = 0, frames = 0, cap = 0;
+    bool ready = false;       /* every allocation succeeded: a half-built arena is freed, not reused */
     AhcDevParams P;
     uint16_t* d_depth = nullptr; AhcBlockRec* d_blocks = nullptr;
     uint8_t* d_scratch = nullptr; size_t slotBytes = 0;      /* per-frame scratch + outputs, one block per slot */
@@ -795,7 +796,7 @@ void drfe_ahc_arena_free(drfe_ctx* c)
 static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, float depth_factor, float max_point_dist)
 {
     AhcArena* a = static_cast<AhcArena*>(c->ahcArena);
-    if (a && (a->w != w || a->h != h || a->frames < frames)) { arena_free(a); c->ahcArena = nullptr; }
+    if (a && (!a->ready || a->w != w || a->h != h || a->frames < frames)) { arena_free(a); c->ahcArena = nullptr; }
     if (!a) {
         a = new (std::nothrow) AhcArena();
         if (!a) return DRFE_ERR_INVALID;
@@ -805,7 +806,12 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
         const size_t npx = (size_t)w * h;
         AhcDevParams& P = a->P;
         P.w = w; P.h = h; P.Nw = Nw; P.Nh = Nh; P.NB = NB;
-        P.maxNodes = 2 * NB + 256; P.poolCap = 1 << 19; P.rfCap = 1 << 20; P.planeCap = AHC_DEV_PLANE_CAP;
+        /* capacities scale with the frame: 2^19 neighbour-pool words and 2^20 flood-fill queue entries for the 3072 blocks /
+         * 307 200 pixels of a 640 x 480 frame (3.4 entries per pixel) */
+        P.maxNodes = 2 * NB + 256; P.planeCap = AHC_DEV_PLANE_CAP;
+        P.poolCap = 1 << 19; P.rfCap = 1 << 20;
+        while (P.poolCap < 170 * NB) P.poolCap <<= 1;
+        while ((size_t)P.rfCap < npx * 7 / 2) P.rfCap <<= 1;
         if (P.maxNodes > 65535) { c->ahcArena = nullptr; delete a; c->err = "planes: the device extractor keeps node ids in 16 bits (frame too large)"; return DRFE_ERR_INVALID; }
         /* per-slot layout, every array 256-byte aligned */
         size_t off = 0;
@@ -853,6 +859,7 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
             g.ptsBase = (int)(npx * f); g.pts = a->d_vpts + 3 * npx * f; g.jobs = a->d_jobs + (size_t)P.planeCap * f;
         }
         HIPCHK(c, hipMemcpy(a->d_frames, a->h_frames, sizeof(AhcDevFrame) * F, hipMemcpyHostToDevice));
+        a->ready = true;
     }
     AhcDevParams& P = a->P;
     P.fx = (double)K4[0]; P.fy = (double)K4[1]; P.cx = (double)K4[2]; P.cy = (double)K4[3]; P.factor = (double)depth_factor;
@@ -1153,10 +1160,26 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
                      nframes, J.nChunks, J.fallbacks.load(), J.voxDevice ? "device" : "host", J.voxFallbacks.load());
     if (launchRc != DRFE_OK) return launchRc;
     if (J.firstRc != DRFE_OK) { c->err = J.firstErr; return J.firstRc; }
+    c->ahcStats[0] += nframes; c->ahcStats[1] += J.fallbacks.load();
+    if (J.voxDevice) {
+        long long grids = 0;
+        for (int f = 0; f < nframes; f++) if (A->h_out[4 * (size_t)f + 1] == 0 && n_planes[f] <= cap) grids += n_planes[f];
+        c->ahcStats[2] += grids; c->ahcStats[3] += J.voxFallbacks.load();
+    }
     return DRFE_OK;
 }
 
 extern "C" {
+
+/* out4[0] = frames through the device extractor (drfe_planes_ahc_batch / drfe_planes_ahc_post_batch) since drfe_create, out4[1] = of
+ * those, redone on the host (a capacity of the device path, an uncertified cosine), out4[2] = plane voxel grids run on the device,
+ * out4[3] = of those, redone on the host */
+int drfe_planes_ahc_stats(drfe_ctx* c, long long* out4)
+{
+    if (!c || !out4) return DRFE_ERR_INVALID;
+    for (int i = 0; i < 4; i++) out4[i] = c->ahcStats[i];
+    return DRFE_OK;
+}
 
 /* pcl::VoxelGrid of every plane in drfe_planes_ahc_post_batch.  1 (default): on the device (voxel_kernels.hip) behind the device
  * extractor - one launch for all planes of a chunk of frames, the workers fetch centroids; the host-extractor mode keeps the host
@@ -1199,9 +1222,9 @@ int drfe_planes_ahc_post_batch(drfe_ctx* c, const uint16_t* depth, size_t frame_
         HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         pool->push_back(l);
     }
-    /* the extractor itself on the device (drfe_planes_configure bit 1; 640 x 480-class frames: the kernel's queue holds 3200 init
-     * blocks and its pixel index 20 bits) */
-    if ((c->planesDeviceAhc) && (w / AHC_WIN) * (h / AHC_WIN) <= 3200 && (size_t)w * h <= (1u << 20) && !std::getenv("DRFE_AHC_HOST"))
+    /* the extractor itself on the device (drfe_planes_configure_extractor; frames of up to 12 800 init blocks and 2^21 pixels:
+     * 1280 x 960 included - the kernels' queue capacity and pixel index) */
+    if ((c->planesDeviceAhc) && drfe_ahc_device_fits(w, h) && !std::getenv("DRFE_AHC_HOST"))
         return planes_ahc_post_batch_device(c, pool, T, depth, frame_stride, w, h, stride, nframes, K4, depth_factor, max_point_dist, dist_threshold, planes,
                                             cap, n_planes, seg, post, n_accepted, plane_num, nullptr, nullptr);
     std::vector<int> rcs(T, DRFE_OK);

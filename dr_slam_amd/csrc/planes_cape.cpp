@@ -337,7 +337,7 @@ struct CapeBatchArena {
     drfe_cape_plane* h_planes = nullptr; CapeFrameOut* h_out = nullptr; uint8_t* h_seg = nullptr;
     hipStream_t stream = nullptr, copyStream = nullptr;
     hipEvent_t kernelsDone = nullptr;
-    long long toHost = 0, total = 0;
+    bool ready = false;       /* every allocation below succeeded: a half-built arena (an allocation failed) is never reused */
 };
 #define CAPE_STAGE_FRAMES 32
 
@@ -377,7 +377,7 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
     const int nh = w / patch, nv = h / patch, ncell = nh * nv;
     const size_t npx = (size_t)w * h, tabStride = drfe_cape_tab_bytes(ncell);
     CapeBatchArena* A = static_cast<CapeBatchArena*>(c->capeBatch);
-    if (!A || A->frames < nframes || A->w != w || A->h != h || A->ncell != ncell || (seg && !A->withSeg)) {
+    if (!A || !A->ready || A->frames < nframes || A->w != w || A->h != h || A->ncell != ncell || (seg && !A->withSeg)) {
         cape_batch_free(c->capeBatch);
         A = new (std::nothrow) CapeBatchArena();
         if (!A) return DRFE_ERR_INVALID;
@@ -400,6 +400,7 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
         HIPCHK(c, hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&A->copyStream, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&A->kernelsDone, hipEventDisableTiming));
+        A->ready = true;
     }
     hipStream_t st = A->stream, cs = A->copyStream;
     DrfeRange range("drfe:cape batch (upload, cell fits, frame stage, refinement)");
@@ -449,7 +450,7 @@ static int planes_cape_batch_device(drfe_ctx* c, const float* depth_m, size_t fr
         std::memcpy(planes + (size_t)f * cap, A->h_planes + (size_t)f * CAPE_DEV_MAXP, (size_t)np * sizeof(drfe_cape_plane));
         if (seg) std::memcpy(seg + (size_t)f * npx, A->h_seg + (size_t)f * npx, npx);
     }
-    A->total += nframes; A->toHost += (long long)hostFrames.size();
+    c->capeStats[0] += nframes; c->capeStats[1] += (long long)hostFrames.size();
     return DRFE_OK;
 }
 
@@ -468,8 +469,7 @@ int drfe_planes_configure_cape(drfe_ctx* c, int on_device)
 int drfe_planes_cape_stats(drfe_ctx* c, long long* out2)
 {
     if (!c || !out2) return DRFE_ERR_INVALID;
-    CapeBatchArena* A = static_cast<CapeBatchArena*>(c->capeBatch);
-    out2[0] = A ? A->total : 0; out2[1] = A ? A->toHost : 0;
+    out2[0] = c->capeStats[0]; out2[1] = c->capeStats[1];
     return DRFE_OK;
 }
 

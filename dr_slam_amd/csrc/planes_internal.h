@@ -86,6 +86,8 @@ struct AhcDevFrame {
     int* out;                                                /* out[0] = planes, out[1] = status (0 = done; else: redo on the host) */
 };
 hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s);
+/* frames the device extractor takes: up to 12 800 init blocks and 2^21 pixels (1280 x 960 = BASELINE config 5 is 12 288 / 1 228 800) */
+int drfe_ahc_device_fits(int w, int h);
 
 hipError_t drfe_launch_ahc_blocks(const uint16_t* d_depth, size_t frameStride, size_t rowStride, int w, int h,
                                   const float K4[4], float depthFactor, int nframes, AhcBlockRec* d_out, hipStream_t s);

@@ -733,6 +733,11 @@ int drfe_planes_configure(drfe_ctx* ctx, int device_voxel_grid);
  * reference's sequence (ahc_frame_kernels.hip), the batch's frames side by side; 0 on the pool's host threads (the path of
  * drfe_planes_ahc).  Results are identical (tests/test_gpu_post.py, tests/test_gpu_planes.py). */
 int drfe_planes_configure_extractor(drfe_ctx* ctx, int on_device);
+/* out4[0] = frames through the device extractor (drfe_planes_ahc_batch / drfe_planes_ahc_post_batch) since drfe_create, out4[1] = of
+ * those, redone on the host (a capacity of the device path ran out, a cosine could not be certified), out4[2] = plane voxel grids
+ * run on the device, out4[3] = of those, redone on the host.  The device extractor takes frames of up to 12 800 init blocks and
+ * 2^21 pixels (1280 x 960, BASELINE config 5, included); larger frames run on the pool's host threads and are not counted. */
+int drfe_planes_ahc_stats(drfe_ctx* ctx, long long* out4);
 /* Where drfe_planes_cape_batch runs CAPE::process between the cell fits and the per-pixel refinement (src/CAPE/CAPE.cpp:81-293:
  * normal histogram + seeding, cell growing, segment fits, merging, erode / dilate masks): 1 (default) on the device, one wavefront
  * per frame (cape_frame_kernels.hip; a frame whose histogram bins the device cannot certify - acos / atan2 are the host libm's in

@@ -156,6 +156,56 @@ def test_config5_1280x960_lines_and_cape_planes(oracle_mod):
         c.close()
 
 
+def test_config5_1280x960_ahc_planes_on_the_device(oracle_mod):
+    """BASELINE config 5's plane leg with the LIVE extractor (src/Frame.cc:126: PEAC / AHC): 1280 x 960 = 128 x 96 init blocks, four
+    times what the reference's hard-coded 640 x 480 holds (include/PlaneExtractor.h:35-36); the oracle defines the generalised
+    semantics.  The single-frame entry and the batch entries - whose extractor (k_ahc_cluster_big /
+    k_ahc_refine_big: a 12 800-entry queue in LDS, 21-bit pixel indices) and voxel grids run on the device - against
+    ahc_run(w, h), bit for bit, with the counters showing that no frame went back to the host."""
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = synth.REALSENSE.scaled(2.0)
+    frames = list(synth.sequence(5, 2, cam=cam, kind="corridor"))
+    depth = np.stack([f[1] for f in frames])
+    assert depth.shape == (2, 960, 1280)
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    c = lib.Context(nfeatures=800, max_width=1280, max_height=960)
+    try:
+        oas = [O.ahc_planes(d, K4, inv) for d in depth]
+        assert all(len(oa["planes"]) >= 4 for oa in oas)
+        # the single-frame entry (block fits on the device, the sequential core on the host)
+        ga = c.planes_ahc(depth[0], K4, inv)
+        assert len(ga["planes"]) == len(oas[0]["planes"]) and np.array_equal(ga["seg"], oas[0]["seg"])
+        assert np.array_equal(ga["planes"]["normal"].view(np.uint64), oas[0]["planes"][:, 0:3].view(np.uint64))
+        # Realsense.yaml:76-79: Plane.DistanceThreshold 0.10, Point.MaxDistance 5.0
+        planes, n, post, na, pn, seg = c.planes_ahc_post_batch(depth, K4, inv, 5.0, 0.10, n_threads=2, seg=True)
+        for f, oa in enumerate(oas):
+            assert n[f] == len(oa["planes"]) and np.array_equal(seg[f], oa["seg"]) and np.array_equal(planes[f, :n[f]]["n_points"], oa["N"])
+            assert np.array_equal(planes[f, :n[f]]["normal"].view(np.uint64), oa["planes"][:, 0:3].view(np.uint64))
+            assert np.array_equal(planes[f, :n[f]]["center"].view(np.uint64), oa["planes"][:, 3:6].view(np.uint64))
+            assert np.array_equal(planes[f, :n[f]]["mse"].view(np.uint64), oa["planes"][:, 6].view(np.uint64))
+            o2, opn = O.ahc_post_planes(depth[f], K4, inv, oa, 5.0, 0.10)
+            assert pn[f] == opn and na[f] == sum(1 for r in o2 if r["accepted"])
+            for k, rec in enumerate(o2):
+                assert bool(post[f, k]["accepted"]) == rec["accepted"] and post[f, k]["n_voxels"] == len(rec["voxels"])
+                assert np.array_equal(post[f, k]["coef"].view(np.uint32), rec["coef"].view(np.uint32))
+        st = c.planes_ahc_stats()
+        assert st["frames"] == 2 and st["to_host"] == 0, st
+        assert st["voxel_grids"] == int(n.sum()) and st["voxel_grids_to_host"] == 0, st
+        # the extractor-only batch entry: member lists included
+        rb = c.planes_ahc_batch(depth, K4, inv, n_threads=2, members=True)
+        for f, oa in enumerate(oas):
+            assert np.array_equal(rb[f]["seg"], oa["seg"]) and rb[f]["planes"].tobytes() == planes[f, :n[f]].tobytes()
+            assert len(rb[f]["members"]) == len(oa["members"])
+            for a, b in zip(rb[f]["members"], oa["members"]):
+                assert np.array_equal(a, b)
+        st = c.planes_ahc_stats()
+        assert st["frames"] == 4 and st["to_host"] == 0, st
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("rank", [0, 1, 2])
 def test_config4_rank_workload_batched(oracle_mod, rank):
     """BASELINE config 4 (index 3), one rank's share on one GPU: the sequence bench.py gives rank `rank`
