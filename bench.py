@@ -187,9 +187,11 @@ def cpu_baseline(base, cam, frames: int = 220, discard: int = 20, only_orb: bool
 
 
 def config5_aux(ctx, base, cam, n: int = 6):
-    """BASELINE config 5 names ORB + LSD + plane: single-frame latency of the line path (device passes + host LSD / LBD) and
-    of the CAPE plane path at this frame size, on the context the ORB batch ran on (AHC is a 640x480 extractor: the
-    reference hard-codes its 10 x 10 block grid for that size)."""
+    """BASELINE config 5 names ORB + LSD + plane: single-frame latency of the line path (device passes + host LSD / LBD), of the
+    CAPE plane path and of the AHC plane path (the live extractor, src/Frame.cc:126) at this frame size, on the context the ORB
+    batch ran on; and the AHC path + Frame::ComputePlanes' per-plane loop through the batch entry, whose extractor and voxel
+    grids run on the device (round 5: 128 x 96 init blocks - the reference hard-codes 64 x 48, include/PlaneExtractor.h:35-36;
+    the oracle defines the generalised semantics)."""
     K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
     out = {}
     ctx.lsd_extract(base[0][0])
@@ -202,6 +204,25 @@ def config5_aux(ctx, base, cam, n: int = 6):
     npl = [len(ctx.planes_cape(d, K4, 20)["planes"]) for d in dm]
     out["cape_ms"] = (time.perf_counter() - t0) * 1e3 / n
     out["lines_per_frame"], out["planes_per_frame"] = float(np.mean(nl)), float(np.mean(npl))
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    d16 = [base[i % len(base)][1] for i in range(n)]
+    ctx.planes_ahc(d16[0], K4, inv)
+    t0 = time.perf_counter()
+    npa = [len(ctx.planes_ahc(d, K4, inv)["planes"]) for d in d16]
+    out["ahc_ms"] = (time.perf_counter() - t0) * 1e3 / n
+    out["ahc_planes_per_frame"] = float(np.mean(npa))
+    nb = 32
+    db = np.stack([base[i % len(base)][1] for i in range(nb)])
+    ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)                       # Realsense.yaml:76-79; first call allocates the frame slots
+    s0 = ctx.planes_ahc_stats()
+    t0 = time.perf_counter()
+    _, nn, _, na, _ = ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)
+    el = time.perf_counter() - t0
+    s1 = ctx.planes_ahc_stats()
+    out["ahc_post_batch"] = {"frames": nb, "ms_per_frame": el * 1e3 / nb, "frames_per_s": nb / el, "planes_per_frame": float(nn.mean()),
+                             "accepted_per_frame": float(na.mean()), "frames_redone_on_host": s1["to_host"] - s0["to_host"],
+                             "voxel_grids_redone_on_host": s1["voxel_grids_to_host"] - s0["voxel_grids_to_host"],
+                             "note": "host frames uploaded inside the call; extractor (k_ahc_cluster_big / k_ahc_refine_big, one wavefront per frame) + voxel grids on the device, gates + refit on the pool"}
     return out
 
 

@@ -20,7 +20,8 @@ struct BowState {
     int scoring, weighting;
     void* d_vocBlob[5];       /* owning pointers of the five arrays */
     int* d_word; double* d_weight; int* d_nid;            /* [slot][maxKp] transform outputs */
-    int levelsup; int transformedFrames;
+    int levelsup;
+    uint8_t* slotDone; int nSlots;                         /* [max_batch]: 1 = the slot's descriptors went through the transform (at `levelsup`) since they were last written */
     BowGroup* d_groups; int* d_kfIdx; int* d_fIdx; int* d_kfMP; int* d_fMP; int* d_match; int* d_counters; int* d_hist;
     uint16_t* d_entries;
 };
@@ -37,4 +38,5 @@ hipError_t drfe_launch_bow_triangulation(drfe_ctx* c, int slot1, int slot2, cons
                                          const TriParams& P, int* d_match12, int* d_counters, int* d_hist,
                                          uint16_t* d_entries, hipStream_t s);
 void drfe_bow_free(drfe_ctx* c);
+static inline bool drfe_bow_slot_done(const BowState* b, int slot) { return b && slot >= 0 && slot < b->nSlots && b->slotDone[slot]; }
 #endif

@@ -719,27 +719,6 @@ struct FrameLane {
 /* tracking block of a staged frame: MatchPair | Twc of LastFrame | map points */
 static size_t track_block_bytes(const drfe_ctx* c) { return 256 + (size_t)c->maxKp * sizeof(drfe_map_point); }
 
-/* The kernels address a slot as base + slot * stride.  One slot of a larger arena is therefore the same launches on
- * shifted bases: this shifts every per-slot base the ORB and glue launchers read, for the duration of the enqueue. */
-struct SlotShift {
-    drfe_ctx* c; int slot;
-    SlotShift(drfe_ctx* c_, int slot_) : c(c_), slot(slot_) { apply(1); }
-    ~SlotShift() { apply(-1); }
-    void apply(int sgn)
-    {
-        const ptrdiff_t s = (ptrdiff_t)sgn * slot, K = c->maxKp;
-        const DevGeom& g = c->geom;
-        c->d_pyr += s * g.pyrSlotBytes; c->d_blur += s * g.blurSlotBytes;
-        c->d_cand0 += s * g.candSlotElems; c->d_cand1 += s * g.candSlotElems; c->d_node += s * g.candSlotElems;
-        c->d_candCount += s * DRFE_CC_SLOT; c->d_selCount += s * g.nlevels; c->d_sel += s * g.kpSlotElems;
-        c->d_kps += s * K; if (c->d_kpsUn) c->d_kpsUn += s * K;
-        c->d_desc += s * K * 32; c->d_kpCount += s;
-        c->d_uRight += s * K; c->d_depth += s * K;
-        c->d_gridOff += s * (DRFE_GRID_CELLS + 1); c->d_gridIdx += s * K;
-        c->d_cellKp += s * K; c->d_cellDesc += s * K * 2;
-    }
-};
-
 static void frame_lane_release_graph(FrameLane& L)
 {
     if (L.exec) (void)hipGraphExecDestroy(L.exec);

@@ -27,8 +27,15 @@ void drfe_bow_free(drfe_ctx* c)
                     b->d_counters, b->d_hist, b->d_entries};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    delete[] b->slotDone;
     delete b;
     c->bow = nullptr;
+}
+
+void drfe_bow_slot_invalidate(drfe_ctx* c, int slot)
+{
+    BowState* b = c->bow;
+    if (b && slot >= 0 && slot < b->nSlots) b->slotDone[slot] = 0;
 }
 
 extern "C" {
@@ -48,6 +55,9 @@ int drfe_voc_upload(drfe_ctx* c, int k, int L, int scoring, int weighting, int n
     if (!b) return DRFE_ERR_INVALID;
     std::memset(b, 0, sizeof(*b));
     c->bow = b;
+    b->nSlots = c->cfg.max_batch;
+    b->slotDone = new (std::nothrow) uint8_t[(size_t)b->nSlots]();
+    if (!b->slotDone) return DRFE_ERR_INVALID;
     /* children lists in node-id order, as the loader's m_nodes[pid].children.push_back(nid) builds them */
     std::vector<int> cnt(n_nodes + 1, 0), children(n_nodes - 1), wordId(n_nodes, -1);
     for (int i = 1; i < n_nodes; i++) {
@@ -104,14 +114,37 @@ int drfe_bow_transform_batch(drfe_ctx* c, int levelsup, int nframes, void* strea
     BowState* b = c->bow;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     HIPCHK(c, drfe_launch_bow_transform(c, b->voc, levelsup, nframes, b->d_word, b->d_weight, b->d_nid, s));
+    if (b->levelsup != levelsup) std::memset(b->slotDone, 0, (size_t)b->nSlots);      /* node ids of another level */
     b->levelsup = levelsup;
-    b->transformedFrames = nframes;
+    for (int f = 0; f < nframes && f < b->nSlots; f++) b->slotDone[f] = 1;
+    return DRFE_OK;
+}
+
+/* The same for ONE slot (a frame put there by drfe_frame_submit / drfe_frame_load): Frame::ComputeBoW / KeyFrame::ComputeBoW of the
+ * frame in `slot`.  The transform is a pure function of the descriptors and the vocabulary, so a keyframe loaded from the host
+ * gets the mFeatVec / mBowVec entries it stored when it was created. */
+int drfe_bow_transform_slot(drfe_ctx* c, int levelsup, int slot, void* stream)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    if (!c->bow) { c->err = "bow_transform: upload a vocabulary first"; return DRFE_ERR_STATE; }
+    if (slot < 0 || slot >= c->lastBatch) { c->err = "bow_transform_slot: the slot holds no frame"; return DRFE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    BowState* b = c->bow;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t o = (size_t)slot * c->maxKp;
+    {
+        SlotShift shift(c, slot);
+        HIPCHK(c, drfe_launch_bow_transform(c, b->voc, levelsup, 1, b->d_word + o, b->d_weight + o, b->d_nid + o, s));
+    }
+    if (b->levelsup != levelsup) std::memset(b->slotDone, 0, (size_t)b->nSlots);
+    b->levelsup = levelsup;
+    b->slotDone[slot] = 1;
     return DRFE_OK;
 }
 
 int drfe_bow_download(drfe_ctx* c, int slot, int32_t* word, double* weight, int32_t* nid, int cap)
 {
-    if (!c || !c->bow || slot < 0 || slot >= c->bow->transformedFrames) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
+    if (!c || !drfe_bow_slot_done(c->bow, slot)) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;
     int rc = drfe_stream_sync(c);
     if (rc != DRFE_OK) return rc;
     int n = 0;
@@ -130,7 +163,7 @@ static int search_by_bow_impl(drfe_ctx* c, int kf_slot, int f_slot, const int32_
 {
     if (!c || !kf_mp || !f_match || !nmatches) return DRFE_ERR_INVALID;
     BowState* b = c->bow;
-    if (!b || kf_slot < 0 || f_slot < 0 || kf_slot >= b->transformedFrames || f_slot >= b->transformedFrames) {
+    if (!drfe_bow_slot_done(b, kf_slot) || !drfe_bow_slot_done(b, f_slot)) {
         c->err = "search_by_bow: both slots need drfe_bow_transform_batch first";
         return DRFE_ERR_STATE;
     }
@@ -209,7 +242,7 @@ int drfe_search_for_triangulation(drfe_ctx* c, int slot1, int slot2, const int32
 {
     if (!c || !mp1 || !mp2 || !F12 || !Cw1 || !T2w || !cam2 || !matches12 || !nmatches) return DRFE_ERR_INVALID;
     BowState* b = c->bow;
-    if (!b || slot1 < 0 || slot2 < 0 || slot1 >= b->transformedFrames || slot2 >= b->transformedFrames || !c->glueValid) {
+    if (!drfe_bow_slot_done(b, slot1) || !drfe_bow_slot_done(b, slot2) || !c->glueValid) {
         c->err = "search_for_triangulation: both slots need the glue and drfe_bow_transform_batch first";
         return DRFE_ERR_STATE;
     }

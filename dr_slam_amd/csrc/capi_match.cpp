@@ -298,6 +298,49 @@ int drfe_frame_stereo_grid_batch_kpdepth(drfe_ctx* c, const uint16_t* kp_depth, 
     return DRFE_OK;
 }
 
+/* A frame that lives on the HOST - a KeyFrame of the map, a Frame built elsewhere - put into a slot for the slot-based matchers:
+ * what Frame::Frame left in mvKeys / mvKeysUn / mDescriptors / mvuRight / mvDepth is uploaded as it is and only
+ * AssignFeaturesToGrid runs (on the device), so every matcher sees the slot exactly as if the frame had been extracted there. */
+int drfe_frame_load(drfe_ctx* c, int slot, const drfe_keypoint* kps, const drfe_keypoint* kps_un, const uint8_t* desc, const float* u_right,
+                    const float* depth_m, int n, const drfe_camera* cam)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    if (slot < 0 || slot >= c->cfg.max_batch || n < 0 || n > c->maxKp || !cam || (n > 0 && (!kps || !desc))) {
+        c->err = "drfe_frame_load: invalid argument (slot, keypoint count beyond drfe_orb_max_keypoints, or a missing array)";
+        return DRFE_ERR_INVALID;
+    }
+    if (!(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { c->err = "drfe_frame_load: empty image bounds"; return DRFE_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drfe_stream_sync(c);
+    if (rc != DRFE_OK) return rc;
+    const size_t K = (size_t)c->maxKp, o = (size_t)slot * K;
+    hipStream_t s = c->stream;
+    if (n > 0) {
+        /* without a distortion model the context keeps ONE keypoint array (mvKeysUn == mvKeys): the matchers read mvKeysUn */
+        if (c->dist.enabled) {
+            HIPCHK(c, hipMemcpyAsync(c->d_kps + o, kps, sizeof(drfe_keypoint) * (size_t)n, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(c->d_kpsUn + o, kps_un ? kps_un : kps, sizeof(drfe_keypoint) * (size_t)n, hipMemcpyHostToDevice, s));
+        } else
+            HIPCHK(c, hipMemcpyAsync(c->d_kps + o, kps_un ? kps_un : kps, sizeof(drfe_keypoint) * (size_t)n, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_desc + o * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+        if (u_right) HIPCHK(c, hipMemcpyAsync(c->d_uRight + o, u_right, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        else HIPCHK(c, drfe_launch_fill_i32(reinterpret_cast<int*>(c->d_uRight + o), n, (int)0xBF800000u /* -1.0f: no right coordinate */, s));
+        if (depth_m) HIPCHK(c, hipMemcpyAsync(c->d_depth + o, depth_m, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        else HIPCHK(c, drfe_launch_fill_i32(reinterpret_cast<int*>(c->d_depth + o), n, (int)0xBF800000u, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_kpCount + slot, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    {
+        SlotShift shift(c, slot);
+        HIPCHK(c, drfe_launch_grid(c, *cam, 1, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));               /* `n` and the caller's arrays are free to go */
+    c->lastBatch = std::max(c->lastBatch, slot + 1);
+    c->glueValid = true;
+    c->cam = *cam;
+    if (c->bow) drfe_bow_slot_invalidate(c, slot);
+    return DRFE_OK;
+}
+
 int drfe_frame_download_stereo(drfe_ctx* c, int slot, float* u_right, float* depth, int cap)
 {
     if (!c || slot < 0 || slot >= c->lastBatch || !c->glueValid) return c ? DRFE_ERR_STATE : DRFE_ERR_INVALID;

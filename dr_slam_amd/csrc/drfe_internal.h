@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/drfe.h"
+#include "../../include/drfe_debug.h"
 
 #define DRFE_MAX_LEVELS 16
 #define DRFE_EDGE 19          /* EDGE_THRESHOLD, reference src/ORBextractor.cc:72 */
@@ -188,6 +189,27 @@ struct drfe_ctx {
     bool evUsed[DRFE_STAGE_COUNT];
 };
 
+/* The kernels address a slot as base + slot * stride.  One slot of a larger arena is therefore the same launches on
+ * shifted bases: this shifts every per-slot base the ORB and glue launchers read, for the duration of the enqueue. */
+struct SlotShift {
+    drfe_ctx* c; int slot;
+    SlotShift(drfe_ctx* c_, int slot_) : c(c_), slot(slot_) { apply(1); }
+    ~SlotShift() { apply(-1); }
+    void apply(int sgn)
+    {
+        const ptrdiff_t s = (ptrdiff_t)sgn * slot, K = c->maxKp;
+        const DevGeom& g = c->geom;
+        c->d_pyr += s * g.pyrSlotBytes; c->d_blur += s * g.blurSlotBytes;
+        c->d_cand0 += s * g.candSlotElems; c->d_cand1 += s * g.candSlotElems; c->d_node += s * g.candSlotElems;
+        c->d_candCount += s * DRFE_CC_SLOT; c->d_selCount += s * g.nlevels; c->d_sel += s * g.kpSlotElems;
+        c->d_kps += s * K; if (c->d_kpsUn) c->d_kpsUn += s * K;
+        c->d_desc += s * K * 32; c->d_kpCount += s;
+        c->d_uRight += s * K; c->d_depth += s * K;
+        c->d_gridOff += s * (DRFE_GRID_CELLS + 1); c->d_gridIdx += s * K;
+        c->d_cellKp += s * K; c->d_cellDesc += s * K * 2;
+    }
+};
+
 /* what the matchers and the grid read: mvKeysUn (== mvKeys without distortion) */
 static inline drfe_keypoint* drfe_kps_un(const drfe_ctx* c) { return c->dist.enabled ? c->d_kpsUn : c->d_kps; }
 
@@ -275,6 +297,7 @@ hipError_t drfe_long_kernel_stream(hipStream_t* s, int part);
  * (std::thread::hardware_concurrency() reports the machine, which oversubscribes a quota-limited container) */
 int drfe_default_host_threads();
 void drfe_cape_lanes_free(drfe_ctx* c);                   /* planes_cape.cpp */
+void drfe_bow_slot_invalidate(drfe_ctx* c, int slot);     /* capi_bow.cpp: the slot's descriptors changed (drfe_frame_load) */
 void drfe_one_shot_free(drfe_ctx* c);                    /* capi.cpp: the captured single-frame ORB graph */
 void drfe_frame_lanes_free(drfe_ctx* c);                 /* capi.cpp: staging + graphs of the per-frame pipelined flow */
 
@@ -289,6 +312,7 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
 /* match_kernels.hip */
 hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameStride, size_t rowStride,
                             const drfe_camera& cam, int nframes, hipStream_t s);
+hipError_t drfe_launch_grid(drfe_ctx* c, const drfe_camera& cam, int nframes, hipStream_t s);
 hipError_t drfe_launch_kp_pixels(drfe_ctx* c, int nframes, uint32_t* d_uv, hipStream_t s);
 hipError_t drfe_launch_match_consecutive(drfe_ctx* c, const drfe_camera& cam, float th, int mono, int checkOri,
                                          int nframes, hipStream_t s);

@@ -772,6 +772,16 @@ hipError_t drfe_launch_glue(drfe_ctx* c, const uint16_t* d_depth, size_t frameSt
     return hipGetLastError();
 }
 
+/* AssignFeaturesToGrid alone, for slots whose keypoints, mvuRight and descriptors came from the host (drfe_frame_load) */
+hipError_t drfe_launch_grid(drfe_ctx* c, const drfe_camera& cam, int nframes, hipStream_t s)
+{
+    const float invW = (float)DRFE_GRID_COLS / (float)(cam.max_x - cam.min_x);
+    const float invH = (float)DRFE_GRID_ROWS / (float)(cam.max_y - cam.min_y);
+    hipLaunchKernelGGL(k_grid, dim3(nframes), dim3(256), 0, s, drfe_kps_un(c), c->d_kpCount, c->maxKp, cam, invW, invH,
+                       c->d_uRight, c->d_desc, c->d_gridOff, c->d_gridIdx, c->d_cellKp, c->d_cellDesc);
+    return hipGetLastError();
+}
+
 /* p[0..n) = v as a kernel: memset nodes of a captured graph did not execute on this ROCm (see drfe_launch_orb), and the
  * per-frame flow replays the matcher from one */
 __global__ __launch_bounds__(256) void k_fill_i32(int* __restrict__ p, int n, int v)

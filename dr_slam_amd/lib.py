@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_debug_device_order_sort_depth", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor", "drfe_planes_ahc_stats",
+    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_debug_device_order_sort_depth", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor", "drfe_planes_ahc_stats", "drfe_frame_load", "drfe_bow_transform_slot",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -214,6 +214,8 @@ def load() -> C.CDLL:
     L.drfe_planes_configure_cape.argtypes = [vp, i32]
     L.drfe_planes_cape_stats.argtypes = [vp, vp]
     L.drfe_planes_ahc_stats.argtypes = [vp, vp]
+    L.drfe_frame_load.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp]
+    L.drfe_bow_transform_slot.argtypes = [vp, i32, i32, vp]
     L.drfe_lsd_configure_nfa.argtypes = [vp, i32]
     L.drfe_lsd_stats.argtypes = [vp, vp]
     L.drfe_lsd_segments_host_mode.argtypes = [vp, vp, vp, i32, i32, f64, i32, vp, i32, C.POINTER(i32)]
@@ -622,6 +624,17 @@ class Context:
         self._chk(self.L.drfe_frame_download_stereo(self.h, slot, _p(ur), _p(z), self.max_kp), "download_stereo")
         return ur, z
 
+    def frame_load(self, slot, kps, desc, cam: Camera, kps_un=None, u_right=None, depth_m=None):
+        """drfe_frame_load: a host-held frame (KeyFrame members mvKeys / mvKeysUn / mDescriptors / mvuRight / mvDepth) into `slot`;
+        the 64 x 48 grid is rebuilt on the device."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(kps)
+        ku = None if kps_un is None else np.ascontiguousarray(kps_un, KP_DTYPE)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        z = None if depth_m is None else np.ascontiguousarray(depth_m, np.float32)
+        self._chk(self.L.drfe_frame_load(self.h, slot, _p(kps), _p(ku), _p(desc), _p(ur), _p(z), n, C.byref(cam)), "drfe_frame_load")
+
     def download_grid(self, slot):
         off = np.zeros(64 * 48 + 1, np.int32)
         idx = np.zeros(self.max_kp, np.int32)
@@ -984,6 +997,9 @@ class Context:
 
     def bow_transform_batch(self, levelsup, nframes, stream: int = 0):
         self._chk(self.L.drfe_bow_transform_batch(self.h, levelsup, nframes, C.c_void_p(stream)), "drfe_bow_transform_batch")
+
+    def bow_transform_slot(self, levelsup, slot, stream: int = 0):
+        self._chk(self.L.drfe_bow_transform_slot(self.h, levelsup, slot, C.c_void_p(stream)), "drfe_bow_transform_slot")
 
     def bow_download(self, slot):
         word = np.zeros(self.max_kp, np.int32)

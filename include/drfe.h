@@ -202,6 +202,18 @@ int drfe_frame_submit(drfe_ctx* ctx, int slot, const uint8_t* gray, int w, int h
 int drfe_frame_collect(drfe_ctx* ctx, int slot, drfe_keypoint* kps, uint8_t* desc, float* u_right, float* depth_m, int cap,
                        int* n_out);
 
+/* A frame that lives on the HOST into a slot: the KeyFrame* / Frame& arguments of ORBmatcher's methods (include/ORBmatcher.h:41-84)
+ * are objects of the map whose keypoints were extracted long ago (KeyFrame copies mvKeys, mvKeysUn, mDescriptors, mvuRight, mvDepth
+ * from its Frame, src/KeyFrame.cc:36-66).  kps = mvKeys, kps_un = mvKeysUn (NULL: the same array), desc = mDescriptors (n x 32),
+ * u_right = mvuRight, depth_m = mvDepth (either may be NULL: monocular, all -1), cam = intrinsics + the image bounds
+ * mnMinX .. mnMaxY.  The arrays are uploaded as they are and Frame::AssignFeaturesToGrid (src/Frame.cc:224-237) runs on the
+ * device, so the slot is indistinguishable from one the frame was extracted in; every slot-based matcher below then takes it.
+ * n <= drfe_orb_max_keypoints(ctx).  Without a distortion model the context keeps one keypoint array (mvKeysUn == mvKeys) and
+ * stores kps_un.  Synchronous; the slot must have no drfe_frame_submit outstanding.  The slot's BoW transform, if any, is
+ * forgotten (drfe_bow_transform_slot). */
+int drfe_frame_load(drfe_ctx* ctx, int slot, const drfe_keypoint* kps, const drfe_keypoint* kps_un, const uint8_t* desc,
+                    const float* u_right, const float* depth_m, int n, const drfe_camera* cam);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* ORBmatcher (replaces src/ORBmatcher.cc hot paths)                                                 */
 
@@ -369,17 +381,6 @@ int drfe_lsd_stats(drfe_ctx* ctx, long long* out4);
 /* drfe_lsd_segments_host with rect_nfa's reading chosen by the caller (drfe_lsd_segments_host: 0). */
 int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad,
                                 int rect_mode, float* segs, int cap, int* n_segs);
-/* Test hook of dr_slam_amd/csrc/cr_sincos.h: correctly rounded sin / cos of n doubles in [0, 64) (host build of the routine the
- * device path uses for region2rect's direction and region_grow's seed direction); ok[i] = 0 where the rounding could not be
- * certified.  Host code. */
-int drfe_debug_cr_sincos(const double* x, int n, double* s, double* c, int32_t* ok);
-/* Test hook of dr_slam_amd/csrc/lsd_order_kernels.hip: n LSD ordering keys (gradient bin << 22 | y << 11 | x) sorted in place on the
- * device into std::sort's order under lsd.cpp's compare_norm (larger bins first, the order of equal bins = libstdc++'s
- * introsort's, heap-sort branch included).  *status: 0, or 1 if a range above 1024 keys exhausted introsort's depth limit (one
- * lane heap-sorts shorter ones; the caller orders such a frame on the host).  _depth: depth_limit >= 0 replaces 2 lg n, so that
- * tests reach the heap-sort branch (compare with drfe_debug_order_sort, mode 3, same depth_limit). */
-int drfe_debug_device_order_sort(drfe_ctx* ctx, uint32_t* keys, size_t n, int* status);
-int drfe_debug_device_order_sort_depth(drfe_ctx* ctx, uint32_t* keys, size_t n, int depth_limit, int* status);
 /* Parity taps of the device image passes of the last drfe_lsd_extract call (any pointer may be NULL):
  * 0.8-scaled image, gradient magnitude and level-line angle (sw x sh), Sobel dx/dy of the LBD image. */
 int drfe_lsd_stages(drfe_ctx* ctx, uint8_t* scaled, double* modgrad, double* angles, int16_t* gx, int16_t* gy,
@@ -576,6 +577,9 @@ int drfe_voc_upload(drfe_ctx* ctx, int k, int L, int scoring, int weighting, int
  * descriptors of slots 0..nframes-1: per feature the word id, the word weight and the node id at level
  * L-levelsup.  Asynchronous on `stream`. */
 int drfe_bow_transform_batch(drfe_ctx* ctx, int levelsup, int nframes, void* stream);
+/* The same for the frame in ONE slot (drfe_frame_submit / drfe_frame_load): Frame::ComputeBoW / KeyFrame::ComputeBoW.  The transform
+ * is a pure function of descriptors and vocabulary: a keyframe loaded from the host gets the mFeatVec it stored at creation. */
+int drfe_bow_transform_slot(drfe_ctx* ctx, int levelsup, int slot, void* stream);
 /* Per-feature results of a slot.  The caller folds them into BowVector / FeatureVector (std::map) in
  * feature order — addWeight's float64 sums depend on that order (BowVector.cpp). */
 int drfe_bow_download(drfe_ctx* ctx, int slot, int32_t* word, double* weight, int32_t* nid, int cap);
@@ -638,19 +642,6 @@ int drfe_planes_ahc_batch(drfe_ctx* ctx, const uint16_t* depth, size_t frame_str
 int drfe_planes_ahc_blocks(drfe_ctx* ctx, const uint16_t* depth, int w, int h, size_t stride, const float* K4,
                            float depth_factor, double* blocks17, int32_t* valid_n, int cap);
 
-/* Test hook of the vectorised trial-merge solver of the AHC clustering (dr_slam_amd/csrc/ahc_math_simd.h): plane fits of n (nine
- * sums, N) records by the scalar routine (mode 0), its 8-lane AVX2 (1) or 8-lane AVX-512F (2) instantiation; out8 = center,
- * normal, mse, curvature per record.  DRFE_ERR_STATE if this CPU lacks the mode.  Host code. */
-int drfe_debug_ahc_trials(const double* sums9, const int32_t* N, int n, int mode, double* out8);
-/* Test hook of dr_slam_amd/csrc/introsort_restated.h, the two std::sort calls whose permutation of equal keys reaches the output:
- * kind 0 = LSD's pseudo-ordering (uint32 keys: gradient bin << 22 | y << 11 | x, larger bins first: lsd.cpp compare_norm), kind 1 =
- * pcl::VoxelGrid's index sort (uint64 records: leaf << 32 | point, smaller leaves first).  recs[n] sorted in place.  mode 0:
- * std::sort with the reference's comparator; 1 / 2: the product's restatement with scalar / AVX2 stopper masks; 3: the plain
- * transcription of libstdc++'s introsort.  depth_limit >= 0 replaces the 2 lg n of modes 1-3 (reaches the heap-sort branch).
- * skip_below > 0 (kind 0, modes 1 / 2): only the keys whose bin is >= skip_below are wanted - they form a prefix of the result
- * and come out in std::sort's order, the rest follows unsorted within its bins' ranges (what the product asks for: pixels
- * without a level-line angle never seed a region).  DRFE_ERR_STATE if this CPU lacks AVX2 (mode 2).  Host code. */
-int drfe_debug_order_sort(void* recs, size_t n, int kind, int mode, int depth_limit, uint32_t skip_below);
 /* The host half of drfe_planes_ahc on caller-supplied block fits (the records drfe_planes_ahc_blocks returns), without a device:
  * graph, agglomerative clustering, block membership, flood fill, re-merge and labels.  Host code: CPU tests and profiling. */
 int drfe_planes_ahc_from_blocks(const double* blocks17, const int32_t* valid_n, const uint16_t* depth, int w, int h, size_t stride,

@@ -22,6 +22,9 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <set>
+#include <type_traits>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -246,12 +249,118 @@ protected:
     drfe_detail::CtxPtr mCtx;
 };
 
-/* include/ORBmatcher.h:41-84: the parts that do not touch the MapPoint graph.  The MapPoint* overloads of the reference
- * flatten what their loops read into drfe_map_point / drfe_tracked_point records and call these. */
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * ORBmatcher (include/ORBmatcher.h:41-84, src/ORBmatcher.cc) with the reference's thirteen signatures.
+ *
+ * The reference's matchers take Frame& / KeyFrame* / MapPoint* - objects of the map, on the host.  Every method here
+ *   1. makes its frames resident in a device slot (MatcherDevice: a small LRU over the slots of one drfe_ctx; a frame that is
+ *      not there yet is uploaded from its own members - mvKeys, mvKeysUn, mDescriptors, mvuRight, mvDepth - by drfe_frame_load,
+ *      which rebuilds its 64 x 48 grid on the device; a frame is recognised by its type and mnId),
+ *   2. flattens what the reference's loop reads through the pointers (GetWorldPos, GetDescriptor, Observations, isBad, the
+ *      fields Frame::isInFrustum left on the point, ...) into the records of drfe.h,
+ *   3. calls the C entry point (window gathers, Hamming distances, claim order, rotation histogram: on the device),
+ *   4. turns the returned indices back into pointers and applies the graph surgery (Replace / AddObservation / AddMapPoint)
+ *      in the reference's order on the host - that part touches mutex-protected map objects and stays where they live.
+ * The methods are templates over the frame / keyframe / map point types and only use the member names src/ORBmatcher.cc uses, so
+ * they bind to Planar_SLAM::Frame, KeyFrame and MapPoint as they are (cv::Mat members are read through .data: continuous
+ * CV_32F / CV_8U matrices, as the reference creates them) and to the stand-ins of tests/native/matcher_caller.cpp.
+ *
+ * Threading: the reference constructs matchers on the stack of three threads (Tracking, LocalMapping, LoopClosing).  Each thread
+ * binds its own MatcherDevice once (ORBmatcher::BindThread); a matcher object itself holds two scalars, as in the reference. */
+
+namespace drfe_detail {
+template <class M> inline const float* f32(const M& m) { return reinterpret_cast<const float*>(m.data); }
+template <class M> inline const uint8_t* u8(const M& m) { return reinterpret_cast<const uint8_t*>(m.data); }
+template <class T> struct TypeTag { static const char v; };
+template <class T> const char TypeTag<T>::v = 0;
+/* camera block of a Frame or KeyFrame: fx fy cx cy mbf and the image bounds (Frame: static floats; KeyFrame: const members, the
+ * bounds as ints - include/KeyFrame.h:230-233) */
+template <class F> inline drfe_camera camera_of(const F& f)
+{
+    drfe_camera c;
+    c.fx = f.fx; c.fy = f.fy; c.cx = f.cx; c.cy = f.cy; c.bf = f.mbf; c.depth_factor = 0.f;
+    c.min_x = (float)f.mnMinX; c.max_x = (float)f.mnMaxX; c.min_y = (float)f.mnMinY; c.max_y = (float)f.mnMaxY;
+    return c;
+}
+template <class MP> inline void frustum_of(MP* p, drfe_frustum_point& o, uint8_t* desc32)
+{
+    const auto w = p->GetWorldPos(); std::memcpy(o.world, w.data, 12);
+    const auto n = p->GetNormal(); std::memcpy(o.normal, n.data, 12);
+    o.min_distance = p->GetMinDistanceInvariance(); o.max_distance = p->GetMaxDistanceInvariance();
+    const auto d = p->GetDescriptor(); std::memcpy(desc32, d.data, 32);
+}
+}  // namespace drfe_detail
+
+/* The slots of one drfe_ctx as a cache of host frames. */
+class MatcherDevice {
+public:
+    /* ORB parameters as the extractor's (they size a slot: drfe_orb_max_keypoints, and give the scale tables the searches use) */
+    MatcherDevice(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int slots = 8, int maxWidth = 640,
+                  int maxHeight = 480, int device = 0)
+        : mCtx(drfe_detail::make_ctx(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, maxWidth, maxHeight, slots, device)), mSlots((size_t)slots)
+    {
+    }
+    drfe_ctx* ctx() const { return mCtx.get(); }
+    /* ORBVocabulary for SearchByBoW / SearchForTriangulation: the nodes as TemplatedVocabulary::loadFromTextFile holds them */
+    void UploadVocabulary(int k, int L, int scoring, int weighting, int nNodes, const int32_t* parent, const uint8_t* desc, const double* weight,
+                          const uint8_t* isLeaf, int levelsup = 4)
+    {
+        drfe_detail::check(drfe_voc_upload(mCtx.get(), k, L, scoring, weighting, nNodes, parent, desc, weight, isLeaf), mCtx.get(), "drfe_voc_upload");
+        mLevelsUp = levelsup; mHaveVoc = true;
+        for (Slot& s : mSlots) s.bow = false;
+    }
+    /* slot of a frame, loading it when absent; `keep` (another frame's slot of the same call, or -1) is never evicted */
+    template <class F> int Resident(const F& f, bool needBow = false, int keep = -1)
+    {
+        const void* tag = &drfe_detail::TypeTag<F>::v;
+        int at = -1;
+        for (size_t i = 0; i < mSlots.size(); i++) if (mSlots[i].tag == tag && mSlots[i].id == (unsigned long)f.mnId) { at = (int)i; break; }
+        if (at < 0) {
+            unsigned long oldest = ~0ul;
+            for (size_t i = 0; i < mSlots.size(); i++) if ((int)i != keep && mSlots[i].stamp < oldest) { oldest = mSlots[i].stamp; at = (int)i; }
+            if (at < 0) throw std::runtime_error("MatcherDevice: no free slot");
+            const drfe_camera cam = drfe_detail::camera_of(f);
+            const int n = (int)f.mvKeys.size();
+            static_assert(sizeof(f.mvKeys[0]) == sizeof(drfe_keypoint), "cv::KeyPoint layout");
+            drfe_detail::check(drfe_frame_load(mCtx.get(), at, reinterpret_cast<const drfe_keypoint*>(f.mvKeys.data()),
+                                               reinterpret_cast<const drfe_keypoint*>(f.mvKeysUn.data()), drfe_detail::u8(f.mDescriptors),
+                                               f.mvuRight.empty() ? nullptr : f.mvuRight.data(), f.mvDepth.empty() ? nullptr : f.mvDepth.data(), n, &cam),
+                               mCtx.get(), "drfe_frame_load");
+            mSlots[(size_t)at].tag = tag; mSlots[(size_t)at].id = (unsigned long)f.mnId; mSlots[(size_t)at].bow = false;
+            mLoads++;
+        }
+        Slot& s = mSlots[(size_t)at];
+        s.stamp = ++mClock;
+        if (needBow && !s.bow) {
+            if (!mHaveVoc) throw std::runtime_error("MatcherDevice: this matcher needs the vocabulary (UploadVocabulary)");
+            drfe_detail::check(drfe_bow_transform_slot(mCtx.get(), mLevelsUp, at, nullptr), mCtx.get(), "drfe_bow_transform_slot");
+            s.bow = true;
+        }
+        return at;
+    }
+    /* a frame whose keypoints changed in place (never in the reference; a test may) */
+    void Forget() { for (Slot& s : mSlots) { s.tag = nullptr; s.stamp = 0; s.bow = false; } }
+    unsigned long loads() const { return mLoads; }
+private:
+    struct Slot { const void* tag = nullptr; unsigned long id = 0, stamp = 0; bool bow = false; };
+    drfe_detail::CtxPtr mCtx;
+    std::vector<Slot> mSlots;
+    unsigned long mClock = 0, mLoads = 0;
+    int mLevelsUp = 4; bool mHaveVoc = false;
+};
+
 class ORBmatcher {
 public:
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
     ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    /* the calling thread's device (Tracking / LocalMapping / LoopClosing bind one each at start-up) */
+    static void BindThread(MatcherDevice* dev) { tls() = dev; }
+    static MatcherDevice& Device()
+    {
+        if (!tls()) throw std::runtime_error("ORBmatcher: no MatcherDevice bound to this thread (ORBmatcher::BindThread)");
+        return *tls();
+    }
 
     /* src/ORBmatcher.cc:1712-1728 */
     static int DescriptorDistance(const uint8_t* a, const uint8_t* b)
@@ -267,6 +376,341 @@ public:
         }
         return dist;
     }
+    static int DescriptorDistance(const drfe_cv::Mat& a, const drfe_cv::Mat& b) { return DescriptorDistance(drfe_detail::u8(a), drfe_detail::u8(b)); }
+
+    /* ---- src/ORBmatcher.cc:46-130 - Tracking::SearchLocalPoints: the local map into the frame ---- */
+    template <class FrameT, class MapPointT>
+    int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3)
+    {
+        MatcherDevice& D = Device();
+        const int slot = D.Resident(F), m = (int)vpMapPoints.size(), N = (int)F.mvpMapPoints.size();
+        std::vector<drfe_tracked_point> tp((size_t)m);
+        for (int i = 0; i < m; i++) {
+            MapPointT* p = vpMapPoints[(size_t)i];
+            drfe_tracked_point& t = tp[(size_t)i];
+            std::memset(&t, 0, sizeof(t));
+            t.track_in_view = p->mbTrackInView ? 1 : 0;
+            if (!t.track_in_view) continue;
+            t.bad = p->isBad() ? 1 : 0;
+            if (t.bad) continue;
+            t.obs_positive = p->Observations() > 0 ? 1 : 0;
+            t.level = p->mnTrackScaleLevel; t.proj_x = p->mTrackProjX; t.proj_y = p->mTrackProjY; t.proj_xr = p->mTrackProjXR; t.view_cos = p->mTrackViewCos;
+            const auto d = p->GetDescriptor(); std::memcpy(t.desc, d.data, 32);
+        }
+        /* claims the frame already holds: any index >= m (never confused with a new match, which is an index into vpMapPoints) */
+        std::vector<int32_t> claim((size_t)N);
+        std::vector<uint8_t> obs((size_t)N);
+        for (int i = 0; i < N; i++) { MapPointT* p = F.mvpMapPoints[(size_t)i]; claim[(size_t)i] = p ? m + i : -1; obs[(size_t)i] = p && p->Observations() > 0; }
+        int n = 0;
+        drfe_detail::check(drfe_search_by_projection_map(D.ctx(), slot, tp.data(), m, th, mfNNratio, obs.data(), claim.data(), N, &n), D.ctx(),
+                           "drfe_search_by_projection_map");
+        for (int i = 0; i < N; i++) if (claim[(size_t)i] >= 0 && claim[(size_t)i] < m) F.mvpMapPoints[(size_t)i] = vpMapPoints[(size_t)claim[(size_t)i]];
+        return n;
+    }
+
+    /* ---- src/ORBmatcher.cc:1396-1535 - Tracking::TrackWithMotionModel ---- */
+    template <class FrameT, class LastT>
+    typename std::enable_if<std::is_class<LastT>::value, int>::type
+    SearchByProjection(FrameT& CurrentFrame, const LastT& LastFrame, const float th, const bool bMono)
+    {
+        MatcherDevice& D = Device();
+        const int cur = D.Resident(CurrentFrame), last = D.Resident(LastFrame, false, cur);
+        const int nl = (int)LastFrame.mvpMapPoints.size(), nc = (int)CurrentFrame.mvpMapPoints.size();
+        std::vector<drfe_map_point> mp((size_t)nl);
+        for (int i = 0; i < nl; i++) {
+            auto* p = LastFrame.mvpMapPoints[(size_t)i];
+            drfe_map_point& r = mp[(size_t)i];
+            std::memset(&r, 0, sizeof(r));
+            r.valid = p && !LastFrame.mvbOutlier[(size_t)i];
+            if (!r.valid) continue;
+            r.obs_positive = p->Observations() > 0;
+            const auto w = p->GetWorldPos(); std::memcpy(r.world, w.data, 12);
+            const auto d = p->GetDescriptor(); std::memcpy(r.desc, d.data, 32);
+        }
+        std::vector<int32_t> claim((size_t)nc);
+        std::vector<uint8_t> obs((size_t)nc);
+        for (int i = 0; i < nc; i++) { auto* p = CurrentFrame.mvpMapPoints[(size_t)i]; claim[(size_t)i] = p ? nl + i : -1; obs[(size_t)i] = p && p->Observations() > 0; }
+        const drfe_camera cam = drfe_detail::camera_of(CurrentFrame);
+        int n = 0;
+        drfe_detail::check(drfe_search_by_projection_last(D.ctx(), cur, last, drfe_detail::f32(CurrentFrame.mTcw), drfe_detail::f32(LastFrame.mTcw), &cam, mp.data(), nl,
+                                                          th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, obs.data(), claim.data(), nc, &n), D.ctx(),
+                           "drfe_search_by_projection_last");
+        for (int i = 0; i < nc; i++) {
+            const int32_t v = claim[(size_t)i];
+            if (v < 0) CurrentFrame.mvpMapPoints[(size_t)i] = nullptr;        /* also a match the rotation histogram took back (:1524) */
+            else if (v < nl) CurrentFrame.mvpMapPoints[(size_t)i] = LastFrame.mvpMapPoints[(size_t)v];
+        }
+        return n;
+    }
+
+    /* ---- src/ORBmatcher.cc:1332-1394 - the brute-force fallback of TrackWithMotionModel (src/Tracking.cc:2195-2200) ---- */
+    template <class FrameT, class LastT>
+    int MatchORBPoints(FrameT& CurrentFrame, const LastT& LastFrame)
+    {
+        MatcherDevice& D = Device();
+        const int cur = D.Resident(CurrentFrame), last = D.Resident(LastFrame, false, cur);
+        const int nl = (int)LastFrame.mvpMapPoints.size(), nc = (int)CurrentFrame.mvpMapPoints.size();
+        std::vector<int32_t> lastMp((size_t)nl), curMp((size_t)nc);
+        std::vector<uint8_t> outl((size_t)nl);
+        for (int i = 0; i < nl; i++) { lastMp[(size_t)i] = LastFrame.mvpMapPoints[(size_t)i] ? i : -1; outl[(size_t)i] = LastFrame.mvbOutlier[(size_t)i] ? 1 : 0; }
+        for (int i = 0; i < nc; i++) curMp[(size_t)i] = CurrentFrame.mvpMapPoints[(size_t)i] ? nl + i : -1;
+        int nPair = 0;
+        drfe_detail::check(drfe_match_orb_points(D.ctx(), cur, last, lastMp.data(), outl.data(), nl, curMp.data(), nc, &nPair), D.ctx(), "drfe_match_orb_points");
+        for (int i = 0; i < nc; i++) if (curMp[(size_t)i] >= 0 && curMp[(size_t)i] < nl) CurrentFrame.mvpMapPoints[(size_t)i] = LastFrame.mvpMapPoints[(size_t)curMp[(size_t)i]];
+        return nPair;
+    }
+
+    /* ---- src/ORBmatcher.cc:1537-1664 - Tracking::Relocalization (src/Tracking.cc:3638, :3651) ---- */
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, const float th, const int ORBdist)
+    {
+        MatcherDevice& D = Device();
+        const int slot = D.Resident(CurrentFrame);
+        const std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();
+        const int n = (int)vpMPs.size(), nc = (int)CurrentFrame.mvpMapPoints.size();
+        std::vector<drfe_frustum_point> fp((size_t)n);
+        std::vector<uint8_t> descs((size_t)n * 32), skip((size_t)n), matched((size_t)nc);
+        std::vector<float> angles((size_t)n);
+        for (int i = 0; i < n; i++) {
+            MapPointT* p = vpMPs[(size_t)i];
+            std::memset(&fp[(size_t)i], 0, sizeof(drfe_frustum_point));
+            skip[(size_t)i] = !p || p->isBad() || sAlreadyFound.count(p);
+            angles[(size_t)i] = pKF->mvKeysUn[(size_t)i].angle;
+            if (!skip[(size_t)i]) drfe_detail::frustum_of(p, fp[(size_t)i], descs.data() + 32 * (size_t)i);
+        }
+        for (int k = 0; k < nc; k++) matched[(size_t)k] = CurrentFrame.mvpMapPoints[(size_t)k] != nullptr;
+        std::vector<int32_t> nm((size_t)nc, -1);
+        int cnt = 0;
+        drfe_detail::check(drfe_search_by_projection_reloc(D.ctx(), slot, drfe_detail::f32(CurrentFrame.mTcw), fp.data(), descs.data(), angles.data(), skip.data(), n,
+                                                           matched.data(), nc, th, ORBdist, mbCheckOrientation ? 1 : 0, nm.data(), &cnt), D.ctx(),
+                           "drfe_search_by_projection_reloc");
+        for (int k = 0; k < nc; k++) if (nm[(size_t)k] >= 0) CurrentFrame.mvpMapPoints[(size_t)k] = vpMPs[(size_t)nm[(size_t)k]];
+        return cnt;
+    }
+
+    /* ---- src/ORBmatcher.cc:294-407 - LoopClosing::ComputeSim3 after the Sim3 optimisation ---- */
+    template <class KeyFrameT, class MatT, class MapPointT>
+    int SearchByProjection(KeyFrameT* pKF, MatT Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched, int th)
+    {
+        MatcherDevice& D = Device();
+        const int slot = D.Resident(*pKF);
+        const int n = (int)vpPoints.size(), nk = (int)vpMatched.size();
+        std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapPointT*>(nullptr));
+        std::vector<drfe_frustum_point> fp((size_t)n);
+        std::vector<uint8_t> descs((size_t)n * 32), skip((size_t)n), matched((size_t)nk);
+        for (int i = 0; i < n; i++) {
+            MapPointT* p = vpPoints[(size_t)i];
+            std::memset(&fp[(size_t)i], 0, sizeof(drfe_frustum_point));
+            skip[(size_t)i] = p->isBad() || spAlreadyFound.count(p);
+            if (!skip[(size_t)i]) drfe_detail::frustum_of(p, fp[(size_t)i], descs.data() + 32 * (size_t)i);
+        }
+        for (int k = 0; k < nk; k++) matched[(size_t)k] = vpMatched[(size_t)k] != nullptr;
+        std::vector<int32_t> nm((size_t)nk, -1);
+        int cnt = 0;
+        drfe_detail::check(drfe_search_by_projection_kf(D.ctx(), slot, drfe_detail::f32(Scw), fp.data(), descs.data(), skip.data(), n, matched.data(), nk, (float)th,
+                                                        nm.data(), &cnt), D.ctx(), "drfe_search_by_projection_kf");
+        for (int k = 0; k < nk; k++) if (nm[(size_t)k] >= 0) vpMatched[(size_t)k] = vpPoints[(size_t)nm[(size_t)k]];
+        return cnt;
+    }
+
+    /* ---- src/ORBmatcher.cc:160-292 - TrackReferenceKeyFrame / Relocalization ---- */
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    typename std::enable_if<std::is_class<FrameT>::value, int>::type
+    SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches)
+    {
+        MatcherDevice& D = Device();
+        const int kf = D.Resident(*pKF, true), fs = D.Resident(F, true, kf);
+        const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+        const int nk = (int)vpMapPointsKF.size(), nf = (int)F.mvKeys.size();
+        vpMapPointMatches = std::vector<MapPointT*>((size_t)nf, static_cast<MapPointT*>(nullptr));
+        std::vector<int32_t> kfMp((size_t)nk), match((size_t)nf, -1);
+        for (int i = 0; i < nk; i++) { MapPointT* p = vpMapPointsKF[(size_t)i]; kfMp[(size_t)i] = (p && !p->isBad()) ? i : -1; }
+        int n = 0;
+        drfe_detail::check(drfe_search_by_bow(D.ctx(), kf, fs, kfMp.data(), nk, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), nf, &n), D.ctx(),
+                           "drfe_search_by_bow");
+        for (int j = 0; j < nf; j++) if (match[(size_t)j] >= 0) vpMapPointMatches[(size_t)j] = vpMapPointsKF[(size_t)match[(size_t)j]];
+        return n;
+    }
+
+    /* ---- src/ORBmatcher.cc:526-660 - LoopClosing::ComputeSim3 ---- */
+    template <class KeyFrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12)
+    {
+        MatcherDevice& D = Device();
+        const int s1 = D.Resident(*pKF1, true), s2 = D.Resident(*pKF2, true, s1);
+        const std::vector<MapPointT*> vp1 = pKF1->GetMapPointMatches(), vp2 = pKF2->GetMapPointMatches();
+        const int n1 = (int)vp1.size(), n2 = (int)vp2.size();
+        vpMatches12 = std::vector<MapPointT*>((size_t)n1, static_cast<MapPointT*>(nullptr));
+        std::vector<int32_t> mp1((size_t)n1), mp2((size_t)n2), match2((size_t)n2, -1);
+        for (int i = 0; i < n1; i++) mp1[(size_t)i] = (vp1[(size_t)i] && !vp1[(size_t)i]->isBad()) ? i : -1;
+        for (int i = 0; i < n2; i++) mp2[(size_t)i] = (vp2[(size_t)i] && !vp2[(size_t)i]->isBad()) ? i : -1;
+        int n = 0;
+        drfe_detail::check(drfe_search_by_bow_kf(D.ctx(), s1, s2, mp1.data(), n1, mp2.data(), n2, mfNNratio, mbCheckOrientation ? 1 : 0, match2.data(), &n), D.ctx(),
+                           "drfe_search_by_bow_kf");
+        for (int i2 = 0; i2 < n2; i2++) if (match2[(size_t)i2] >= 0) vpMatches12[(size_t)match2[(size_t)i2]] = vp2[(size_t)i2];
+        return n;
+    }
+
+    /* ---- src/ORBmatcher.cc:409-524 - Tracking::MonocularInitialization; PointT = cv::Point2f (two floats) ---- */
+    template <class FrameT, class PointT>
+    int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<PointT>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10)
+    {
+        static_assert(sizeof(PointT) == 8, "cv::Point2f is two floats");
+        MatcherDevice& D = Device();
+        const int s1 = D.Resident(F1), s2 = D.Resident(F2, false, s1);
+        const int n1 = (int)F1.mvKeysUn.size();
+        vnMatches12.assign((size_t)n1, -1);
+        if ((int)vbPrevMatched.size() != n1) throw std::runtime_error("SearchForInitialization: vbPrevMatched must hold one point per keypoint of F1");
+        int n = 0;
+        drfe_detail::check(drfe_search_for_initialization(D.ctx(), s1, s2, reinterpret_cast<float*>(vbPrevMatched.data()), n1, windowSize, mfNNratio,
+                                                          mbCheckOrientation ? 1 : 0, vnMatches12.data(), &n), D.ctx(), "drfe_search_for_initialization");
+        return n;
+    }
+
+    /* ---- src/ORBmatcher.cc:661-827 - LocalMapping::CreateNewMapPoints ---- */
+    template <class KeyFrameT, class MatT>
+    int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, MatT F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo)
+    {
+        MatcherDevice& D = Device();
+        const int s1 = D.Resident(*pKF1, true), s2 = D.Resident(*pKF2, true, s1);
+        const int n1 = (int)pKF1->mvKeysUn.size(), n2 = (int)pKF2->mvKeysUn.size();
+        std::vector<int32_t> mp1((size_t)n1), mp2((size_t)n2), m12((size_t)n1, -1);
+        for (int i = 0; i < n1; i++) mp1[(size_t)i] = pKF1->GetMapPoint((size_t)i) ? i : -1;
+        for (int i = 0; i < n2; i++) mp2[(size_t)i] = pKF2->GetMapPoint((size_t)i) ? i : -1;
+        const auto Cw = pKF1->GetCameraCenter();
+        const auto T2w = pKF2->GetPose();
+        const drfe_camera cam2 = drfe_detail::camera_of(*pKF2);
+        int n = 0;
+        drfe_detail::check(drfe_search_for_triangulation(D.ctx(), s1, s2, mp1.data(), n1, mp2.data(), n2, drfe_detail::f32(F12), drfe_detail::f32(Cw), drfe_detail::f32(T2w),
+                                                         &cam2, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, m12.data(), &n), D.ctx(),
+                           "drfe_search_for_triangulation");
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve((size_t)n);
+        for (int i = 0; i < n1; i++) if (m12[(size_t)i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[(size_t)i]));
+        return n;
+    }
+
+    /* ---- src/ORBmatcher.cc:1106-1330 - LoopClosing::ComputeSim3 ---- */
+    template <class KeyFrameT, class MapPointT, class MatT>
+    int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12, const MatT& R12, const MatT& t12, const float th)
+    {
+        MatcherDevice& D = Device();
+        const int s1 = D.Resident(*pKF1), s2 = D.Resident(*pKF2, false, s1);
+        const std::vector<MapPointT*> vp1 = pKF1->GetMapPointMatches(), vp2 = pKF2->GetMapPointMatches();
+        const int N1 = (int)vp1.size(), N2 = (int)vp2.size();
+        std::vector<uint8_t> skip1((size_t)N1, 0), skip2((size_t)N2, 0);
+        for (int i = 0; i < N1; i++) {                                     /* :1131-1142 */
+            MapPointT* p = vpMatches12[(size_t)i];
+            if (p) {
+                skip1[(size_t)i] = 1;
+                const int idx2 = p->GetIndexInKeyFrame(pKF2);
+                if (idx2 >= 0 && idx2 < N2) skip2[(size_t)idx2] = 1;
+            }
+        }
+        std::vector<drfe_frustum_point> f1((size_t)N1), f2((size_t)N2);
+        std::vector<uint8_t> d1((size_t)N1 * 32), d2((size_t)N2 * 32);
+        for (int i = 0; i < N1; i++) {
+            MapPointT* p = vp1[(size_t)i];
+            std::memset(&f1[(size_t)i], 0, sizeof(drfe_frustum_point));
+            if (!p || p->isBad()) skip1[(size_t)i] = 1;
+            if (!skip1[(size_t)i]) drfe_detail::frustum_of(p, f1[(size_t)i], d1.data() + 32 * (size_t)i);
+        }
+        for (int i = 0; i < N2; i++) {
+            MapPointT* p = vp2[(size_t)i];
+            std::memset(&f2[(size_t)i], 0, sizeof(drfe_frustum_point));
+            if (!p || p->isBad()) skip2[(size_t)i] = 1;
+            if (!skip2[(size_t)i]) drfe_detail::frustum_of(p, f2[(size_t)i], d2.data() + 32 * (size_t)i);
+        }
+        const auto T1w = pKF1->GetPose();
+        const auto T2w = pKF2->GetPose();
+        std::vector<int32_t> m12((size_t)N1, -1);
+        int nFound = 0;
+        drfe_detail::check(drfe_search_by_sim3(D.ctx(), s1, s2, drfe_detail::f32(T1w), drfe_detail::f32(T2w), s12, drfe_detail::f32(R12), drfe_detail::f32(t12), f1.data(),
+                                               d1.data(), skip1.data(), N1, f2.data(), d2.data(), skip2.data(), N2, th, m12.data(), &nFound), D.ctx(),
+                           "drfe_search_by_sim3");
+        for (int i1 = 0; i1 < N1; i1++) if (m12[(size_t)i1] >= 0) vpMatches12[(size_t)i1] = vp2[(size_t)m12[(size_t)i1]];
+        return nFound;
+    }
+
+    /* ---- src/ORBmatcher.cc:829-985 - LocalMapping::SearchInNeighbors.  The search of every point on the device; the loop that
+     * applies it runs here in the reference's order, re-reading isBad() / IsInKeyFrame() / GetMapPoint() at each step exactly where the
+     * reference reads them: an earlier Replace or AddMapPoint of this very loop changes what a later point meets (:845, :957) ---- */
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0)
+    {
+        MatcherDevice& D = Device();
+        const int slot = D.Resident(*pKF);
+        const int n = (int)vpMapPoints.size();
+        std::vector<drfe_frustum_point> fp((size_t)n);
+        std::vector<uint8_t> descs((size_t)n * 32), skip((size_t)n);
+        for (int i = 0; i < n; i++) {
+            MapPointT* p = vpMapPoints[(size_t)i];
+            std::memset(&fp[(size_t)i], 0, sizeof(drfe_frustum_point));
+            skip[(size_t)i] = !p || p->isBad() || p->IsInKeyFrame(pKF);
+            if (!skip[(size_t)i]) drfe_detail::frustum_of(p, fp[(size_t)i], descs.data() + 32 * (size_t)i);
+        }
+        std::vector<int32_t> bestIdx((size_t)n, -1), bestDist((size_t)n, 256);
+        const auto Tcw = pKF->GetPose();
+        drfe_detail::check(drfe_fuse_search(D.ctx(), slot, drfe_detail::f32(Tcw), fp.data(), descs.data(), skip.data(), n, th, bestIdx.data(), bestDist.data()), D.ctx(),
+                           "drfe_fuse_search");
+        int nFused = 0;
+        for (int i = 0; i < n; i++) {
+            MapPointT* pMP = vpMapPoints[(size_t)i];
+            if (!pMP) continue;
+            if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+            if (bestIdx[(size_t)i] < 0 || bestDist[(size_t)i] > TH_LOW) continue;
+            MapPointT* pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, (size_t)bestIdx[(size_t)i]);
+                pKF->AddMapPoint(pMP, (size_t)bestIdx[(size_t)i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    /* ---- src/ORBmatcher.cc:981-1105 - LoopClosing::SearchAndFuse ---- */
+    template <class KeyFrameT, class MatT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, MatT Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint)
+    {
+        MatcherDevice& D = Device();
+        const int slot = D.Resident(*pKF);
+        const std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();
+        const int n = (int)vpPoints.size();
+        std::vector<drfe_frustum_point> fp((size_t)n);
+        std::vector<uint8_t> descs((size_t)n * 32), skip((size_t)n);
+        for (int i = 0; i < n; i++) {
+            MapPointT* p = vpPoints[(size_t)i];
+            std::memset(&fp[(size_t)i], 0, sizeof(drfe_frustum_point));
+            skip[(size_t)i] = p->isBad() || spAlreadyFound.count(p);
+            if (!skip[(size_t)i]) drfe_detail::frustum_of(p, fp[(size_t)i], descs.data() + 32 * (size_t)i);
+        }
+        std::vector<int32_t> bestIdx((size_t)n, -1), bestDist((size_t)n, 256);
+        drfe_detail::check(drfe_fuse_search_sim3(D.ctx(), slot, drfe_detail::f32(Scw), fp.data(), descs.data(), skip.data(), n, th, bestIdx.data(), bestDist.data()), D.ctx(),
+                           "drfe_fuse_search_sim3");
+        int nFused = 0;
+        for (int i = 0; i < n; i++) {
+            if (skip[(size_t)i] || bestIdx[(size_t)i] < 0 || bestDist[(size_t)i] > TH_LOW) continue;
+            MapPointT* pMP = vpPoints[(size_t)i];
+            MapPointT* pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[(size_t)i] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF, (size_t)bestIdx[(size_t)i]);
+                pKF->AddMapPoint(pMP, (size_t)bestIdx[(size_t)i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    /* ---- slot-level forms (the frames already live in slots of `ctx`: the per-frame flow of ORBextractor::Submit / Collect) ---- */
     /* SearchByProjection(CurrentFrame, LastFrame, th, bMono) on the slots `cur` / `last` of ctx (extract + glue done):
      * lastPoints[i] = what the loop reads of LastFrame.mvpMapPoints[i]; curClaims in/out = index into lastPoints or -1 */
     int SearchByProjection(drfe_ctx* ctx, int cur, int last, const float* TcwCur, const float* TcwLast, const drfe_camera& cam,
@@ -291,6 +735,7 @@ public:
         return n;
     }
 protected:
+    static MatcherDevice*& tls() { static thread_local MatcherDevice* d = nullptr; return d; }
     float mfNNratio; bool mbCheckOrientation;
 };
 

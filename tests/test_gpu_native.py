@@ -192,3 +192,239 @@ def test_cpp_reference_member_accesses(frames_room, tmp_path):
     assert n2 == n_tr == nmp and np.array_equal(pairs, np.stack([np.flatnonzero(m_tr >= 0), m_tr[m_tr >= 0]], 1))
     assert int(take(np.int32, 1)[0]) == int(np.unpackbits(l0["desc"][0] ^ l1["desc"][0]).sum())
     assert o == len(raw)
+
+
+def test_cpp_orbmatcher_thirteen_methods(frames_room, tmp_path):
+    """tests/native/matcher_caller.cpp: Planar_SLAM::ORBmatcher with the reference's thirteen signatures (include/ORBmatcher.h:41-84)
+    on stand-in Frame / KeyFrame / MapPoint types that live on the HOST - include/drfe_adaptor.hpp loads them into slots
+    (drfe_frame_load, three slots for eight frame objects: evictions included), flattens the pointer graph, calls the C-ABI and writes
+    pointers back / applies Fuse's graph surgery.  Every resulting pointer vector must equal what the ctypes path gives on the slots
+    the frames were EXTRACTED in (so drfe_frame_load == extraction residency too); the ctypes matchers are held to the oracle in
+    tests/test_gpu_match.py and tests/test_gpu_bow.py."""
+    import torch
+    from dr_slam_amd import lib, synth, vocabulary as V
+    from dr_slam_amd.pipeline import FrontEnd
+    cam = synth.TUM3
+    rng = np.random.RandomState(77)
+    fe = FrontEnd(cam, max_batch=4)
+    try:
+        c = fe.ctx
+        gray = torch.from_numpy(np.stack([f[0] for f in frames_room])).cuda()
+        depth = torch.from_numpy(np.stack([f[1] for f in frames_room]).view(np.int16)).cuda()
+        Twc64 = np.stack([f[2] for f in frames_room]).astype(np.float64)
+        Tcw, Twc = np.linalg.inv(Twc64).astype(np.float32), Twc64.astype(np.float32)
+        fe.process(gray, depth, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        kps, desc, ur, z = [], [], [], []
+        for s in range(4):
+            k, d = fe.keypoints(s)
+            u, zz = c.download_stereo(s)
+            kps.append(k); desc.append(d); ur.append(u[:len(k)].copy()); z.append(zz[:len(k)].copy())
+        N = [len(k) for k in kps]
+        scale = c.scale_tables()[0]
+        voc = V.make_synthetic(10, 4, seed=5, stop_fraction=0.02)
+        voc.upload(c)
+        c.bow_transform_batch(voc.L - 2, 4)
+
+        # ---- the map: points A = frame 0's keypoints with depth, B = frame 3's ----
+        def unproject(s):
+            ok = z[s] > 0
+            x = (kps[s]["x"] - np.float32(cam.cx)) * z[s] / np.float32(cam.fx)
+            y = (kps[s]["y"] - np.float32(cam.cy)) * z[s] / np.float32(cam.fy)
+            pc = np.stack([x, y, z[s], np.ones_like(x)], 1).astype(np.float32)
+            return (pc @ Twc[s].T)[:, :3].astype(np.float32), ok
+
+        rows = []
+        frame_mp = [np.full(n, -1, np.int32) for n in N]
+        for s in (0, 3):
+            world, ok = unproject(s)
+            for i in np.flatnonzero(ok):
+                frame_mp[s][i] = len(rows)
+                rows.append((s, i, world[i]))
+        M = len(rows)
+        mp_world = np.stack([r[2] for r in rows]).astype(np.float32)
+        mp_kf = np.array([r[0] for r in rows], np.int32)
+        mp_idx = np.array([r[1] for r in rows], np.int32)
+        Ow = np.stack([Twc[s][:3, 3] for s in range(4)]).astype(np.float32)
+        v = mp_world - Ow[mp_kf]
+        dist = np.linalg.norm(v, axis=1).astype(np.float32)
+        mp_normal = (v / dist[:, None]).astype(np.float32)
+        lvl = np.array([kps[s]["octave"][i] for s, i, _ in rows])
+        mp_max = (dist * scale[lvl] * rng.uniform(0.9, 1.3, M)).astype(np.float32)
+        mp_min = (mp_max / scale[-1] * rng.uniform(0.5, 1.0, M)).astype(np.float32)
+        mp_desc = np.stack([desc[s][i] for s, i, _ in rows])
+        mp_nobs = np.where(rng.uniform(size=M) < 0.15, 0, rng.randint(1, 4, M)).astype(np.int32)
+        mp_bad = (rng.uniform(size=M) < 0.03).astype(np.int32)
+        nA = int((mp_kf == 0).sum())
+        for s in (1, 2):                                            # frames 1 and 2 arrive with a few claims on points of A
+            pick = rng.uniform(size=N[s]) < 0.1
+            frame_mp[s][pick] = rng.randint(0, nA, int(pick.sum()))
+        outlier = [(rng.uniform(size=n) < 0.05).astype(np.uint8) for n in N]
+        pts = np.zeros(M, lib.FRUSTUM_POINT_DTYPE)
+        pts["world"], pts["normal"], pts["min_distance"], pts["max_distance"] = mp_world, mp_normal, mp_min, mp_max
+        tracked = c.is_in_frustum(Tcw[1], fe.cam, pts, 0.5)         # what Frame::isInFrustum leaves for frame 1
+        tracked["bad"], tracked["obs_positive"], tracked["desc"] = mp_bad, mp_nobs > 0, mp_desc
+
+        T12 = Tcw[0].astype(np.float64) @ Twc[3].astype(np.float64)
+        R12, t12, s12 = T12[:3, :3].astype(np.float32), T12[:3, 3].astype(np.float32), np.float32(1.0)
+        T12f = Tcw[1].astype(np.float64) @ Twc[2].astype(np.float64)
+        K = np.array([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], np.float64)
+        tx = np.array([[0, -T12f[2, 3], T12f[1, 3]], [T12f[2, 3], 0, -T12f[0, 3]], [-T12f[1, 3], T12f[0, 3], 0]])
+        F12 = (np.linalg.inv(K).T @ tx @ T12f[:3, :3] @ np.linalg.inv(K)).astype(np.float32)
+        Scw8 = Tcw[3].copy()
+        Scw12 = Tcw[2].copy(); Scw12[:3, :] *= np.float32(1.05)
+
+        # ---- scene file ----
+        blob = [np.array([0x4d415443, 4, M, voc.n_nodes, voc.k, voc.L], np.int32).tobytes(),
+                np.array([cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, fe.cam.min_x, fe.cam.max_x, fe.cam.min_y, fe.cam.max_y], np.float32).tobytes(),
+                np.array([1000, 8, 20, 7], np.int32).tobytes(), np.float32(1.2).tobytes()]
+        for s in range(4):
+            blob += [np.int32(N[s]).tobytes(), kps[s].tobytes(), desc[s].tobytes(), ur[s].tobytes(), z[s].tobytes(), Tcw[s].tobytes(),
+                     Ow[s].tobytes(), frame_mp[s].tobytes(), outlier[s].tobytes()]
+        for i in range(M):
+            blob += [mp_world[i].tobytes(), mp_normal[i].tobytes(), mp_min[i].tobytes(), mp_max[i].tobytes(), mp_desc[i].tobytes(),
+                     np.array([mp_nobs[i], mp_bad[i], mp_kf[i], mp_idx[i], tracked["track_in_view"][i], tracked["level"][i]], np.int32).tobytes(),
+                     np.array([tracked["proj_x"][i], tracked["proj_y"][i], tracked["proj_xr"][i], tracked["view_cos"][i]], np.float32).tobytes()]
+        blob += [voc.parent.astype(np.int32).tobytes(), voc.desc.tobytes(), voc.weight.astype(np.float64).tobytes(), voc.is_leaf.astype(np.uint8).tobytes(),
+                 F12.tobytes(), s12.tobytes(), R12.tobytes(), t12.tobytes(), Scw8.tobytes(), Scw12.tobytes()]
+        (tmp_path / "scene.bin").write_bytes(b"".join(blob))
+        out = _run("matcher_caller", tmp_path / "scene.bin", tmp_path / "o.bin")
+        assert "matcher ok" in out
+        raw = np.frombuffer((tmp_path / "o.bin").read_bytes(), np.int32)
+        recs, o = [], 0
+        while o < len(raw):
+            ret, cnt = int(raw[o]), int(raw[o + 1])
+            recs.append((ret, raw[o + 2:o + 2 + cnt]))
+            o += 2 + cnt
+        assert len(recs) == 13
+
+        def frustum(ids):
+            p = np.zeros(len(ids), lib.FRUSTUM_POINT_DTYPE)
+            ok = ids >= 0
+            p[ok] = pts[ids[ok]]
+            d = np.zeros((len(ids), 32), np.uint8)
+            d[ok] = mp_desc[ids[ok]]
+            return p, d
+
+        def decode(res, base, table, n_table):
+            """res: the C-ABI's in/out claim array; entries below n_table are new matches (indices into `table`), the others
+            the claims the frame arrived with (encoded n_table + i)"""
+            outv = base.copy()
+            outv[res < 0] = -1
+            new = (res >= 0) & (res < n_table)
+            outv[new] = table[res[new]]
+            return outv
+
+        mp0, mp1, mp2, mp3 = frame_mp
+        bad_of = lambda ids: np.where(ids >= 0, mp_bad[np.maximum(ids, 0)], 0).astype(bool)
+        obs_of = lambda ids: np.where(ids >= 0, mp_nobs[np.maximum(ids, 0)] > 0, False)
+
+        # 1  SearchByProjection(Cur = 1, Last = 0, 15, false)
+        last = np.zeros(N[0], lib.MAPPOINT_DTYPE)
+        valid = (mp0 >= 0) & (outlier[0] == 0)
+        last["valid"] = valid
+        last["obs_positive"] = valid & obs_of(mp0)
+        last["world"][valid], last["desc"][valid] = mp_world[mp0[valid]], mp_desc[mp0[valid]]
+        init = np.where(mp1 >= 0, N[0] + np.arange(N[1]), -1).astype(np.int32)
+        n, res = c.search_by_projection_last(1, 0, Tcw[1], Tcw[0], fe.cam, last, N[1], 15.0, False, True, cur_mp=init, cur_obs=obs_of(mp1).astype(np.uint8))
+        assert recs[0][0] == n > 100 and np.array_equal(recs[0][1], decode(res, mp1, mp0, N[0]))
+        # 2  MatchORBPoints(Cur = 2, Last = 0)
+        init = np.where(mp2 >= 0, N[0] + np.arange(N[2]), -1).astype(np.int32)
+        n, res = c.match_orb_points(2, 0, np.where(mp0 >= 0, np.arange(N[0]), -1), outlier[0], N[2], cur_mp=init)
+        assert recs[1][0] == n > 50 and np.array_equal(recs[1][1], decode(res, mp2, mp0, N[0]))
+        # 3  SearchByProjection(F = 1, local map, 3), nnratio 0.8
+        init = np.where(mp1 >= 0, M + np.arange(N[1]), -1).astype(np.int32)
+        n, res = c.search_by_projection_map(1, tracked, N[1], 3.0, 0.8, frame_mp=init, claim_obs=obs_of(mp1).astype(np.uint8))
+        assert recs[2][0] == n > 100 and np.array_equal(recs[2][1], decode(res, mp1, np.arange(M, dtype=np.int32), M))
+        # 4  SearchByBoW(KF 0, F 1), ORBmatcher(0.7, true)
+        n, m = c.search_by_bow(0, 1, np.where((mp0 >= 0) & ~bad_of(mp0), np.arange(N[0]), -1), N[1], 0.7, True)
+        assert recs[3][0] == n > 50 and np.array_equal(recs[3][1], np.where(m >= 0, mp0[np.maximum(m, 0)], -1))
+        # 5  SearchByBoW(KF 0, KF 3), ORBmatcher(0.75, true)
+        n, m2 = c.search_by_bow_kf(0, 3, np.where((mp0 >= 0) & ~bad_of(mp0), np.arange(N[0]), -1),
+                                   np.where((mp3 >= 0) & ~bad_of(mp3), np.arange(N[3]), -1), 0.75, True)
+        m12 = np.full(N[0], -1, np.int32)
+        m12[m2[m2 >= 0]] = mp3[np.flatnonzero(m2 >= 0)]
+        assert recs[4][0] == n > 20 and np.array_equal(recs[4][1], m12)
+        # 6  SearchForTriangulation(KF 1, KF 2, F12, pairs, false), ORBmatcher(0.6, false)
+        n, mt = c.search_for_triangulation(1, 2, np.where(mp1 >= 0, np.arange(N[1]), -1), np.where(mp2 >= 0, np.arange(N[2]), -1), F12, Ow[1], Tcw[2],
+                                           fe.cam, False, False)
+        pairs = np.stack([np.flatnonzero(mt >= 0), mt[mt >= 0]], 1).astype(np.int32).reshape(-1)
+        assert recs[5][0] == n and np.array_equal(recs[5][1], pairs)
+        # 7  SearchBySim3(KF 0, KF 3, vpMatches12 of call 5 with every third entry cleared, 1.0, R12, t12, 7.5)
+        start = m12.copy(); start[::3] = -1
+        skip1 = (start >= 0) | (mp0 < 0) | bad_of(mp0)
+        skip2 = (mp3 < 0) | bad_of(mp3)
+        held = start[start >= 0]
+        skip2[mp_idx[held[mp_kf[held] == 3]]] = True
+        p1, d1 = frustum(np.where(skip1, -1, mp0)); p2, d2 = frustum(np.where(skip2, -1, mp3))
+        n, ms = c.search_by_sim3(0, 3, Tcw[0], Tcw[3], 1.0, R12, t12, p1, d1, skip1.astype(np.uint8), p2, d2, skip2.astype(np.uint8), 7.5)
+        want = start.copy(); want[ms >= 0] = mp3[ms[ms >= 0]]
+        assert recs[6][0] == n > 20 and np.array_equal(recs[6][1], want)
+        # 8  SearchByProjection(KF 3, Scw, points of KF 0 twice each, vpMatched, 10)
+        lst = np.repeat(mp0[mp0 >= 0], 2)
+        vm = np.full(N[3], -1, np.int32); vm[::5] = mp3[::5]
+        p, d = frustum(lst)
+        n, new = c.search_by_projection_kf(3, Scw8, p, d, bad_of(lst).astype(np.uint8), (vm >= 0).astype(np.uint8), 10.0)
+        want = vm.copy(); want[new >= 0] = lst[new[new >= 0]]
+        assert recs[7][0] == n > 100 and np.array_equal(recs[7][1], want)
+        # 9  SearchByProjection(Cur = 2, KF 0, sAlreadyFound, 10, 100) (relocalisation)
+        found = set(int(v) for v in mp2[mp2 >= 0]) | set(int(v) for v in mp0[::7] if v >= 0)
+        skip = (mp0 < 0) | bad_of(mp0) | np.array([int(v) in found for v in mp0])
+        p, d = frustum(np.where(skip, -1, mp0))
+        n, new = c.search_by_projection_reloc(2, Tcw[2], p, d, kps[0]["angle"], skip.astype(np.uint8), (mp2 >= 0).astype(np.uint8), 10.0, 100, True)
+        want = mp2.copy(); want[new >= 0] = mp0[new[new >= 0]]
+        assert recs[8][0] == n > 100 and np.array_equal(recs[8][1], want)
+        # 10  SearchForInitialization(F 0, F 1, prev, matches, 100), ORBmatcher(0.9, true)
+        prev = np.stack([kps[0]["x"], kps[0]["y"]], 1).astype(np.float32)
+        n, mi, prev2 = c.search_for_initialization(0, 1, prev, 100, 0.9, True)
+        assert recs[9][0] == n > 50 and np.array_equal(recs[9][1][:N[0]], mi) and np.array_equal(recs[9][1][N[0]:], prev2.reshape(-1).view(np.int32))
+        # 11  Fuse(KF 1, points of KF 0 with NULLs and repeats, 3.0): search through ctypes, the surgery replayed here
+        lst = mp0.copy()
+        for i in range(0, len(lst) - 1, 11):
+            lst[i + 1] = lst[i]
+        bad, nobs, repl = mp_bad.astype(bool).copy(), mp_nobs.copy(), np.full(M, -1, np.int32)
+        in_kf1 = np.zeros(M, bool)
+        p, d = frustum(lst)
+        bi, bd = c.fuse_search(1, Tcw[1], p, d, ((lst < 0) | bad_of(lst)).astype(np.uint8), 3.0)
+        kf1 = mp1.copy()
+        fused = 0
+        for i, pid in enumerate(lst):
+            if pid < 0 or bad[pid] or in_kf1[pid] or bi[i] < 0 or bd[i] > 50:
+                continue
+            inkf = kf1[bi[i]]
+            if inkf >= 0:
+                if not bad[inkf] and inkf != pid:
+                    if nobs[inkf] > nobs[pid]:
+                        bad[pid], repl[pid] = True, inkf
+                    else:
+                        bad[inkf], repl[inkf] = True, pid
+            else:
+                in_kf1[pid] = True; nobs[pid] += 1; kf1[bi[i]] = pid
+            fused += 1
+        assert recs[10][0] == fused > 100
+        assert np.array_equal(recs[10][1][:N[1]], kf1)
+        assert np.array_equal(recs[10][1][N[1]:].reshape(M, 3), np.stack([bad.astype(np.int32), repl, nobs], 1))
+        assert repl.max() >= 0 and (nobs != mp_nobs).any()                      # both branches of the surgery ran
+        # 12  Fuse(KF 2, Scw, points of KF 3, 4.0, vpReplacePoint)
+        lst = mp3[mp3 >= 0]
+        already = set(int(v) for v in mp2[mp2 >= 0] if not bad[v])
+        skip = np.array([bool(bad[v]) or int(v) in already for v in lst])
+        p, d = frustum(lst)
+        bi, bd = c.fuse_search_sim3(2, Scw12, p, d, skip.astype(np.uint8), 4.0)
+        kf2, rp, fused = mp2.copy(), np.full(len(lst), -1, np.int32), 0
+        for i, pid in enumerate(lst):
+            if skip[i] or bi[i] < 0 or bd[i] > 50:
+                continue
+            inkf = kf2[bi[i]]
+            if inkf >= 0:
+                if not bad[inkf]:
+                    rp[i] = inkf
+            else:
+                kf2[bi[i]] = pid
+            fused += 1
+        assert recs[11][0] == fused > 20
+        assert np.array_equal(recs[11][1][:len(lst)], rp) and np.array_equal(recs[11][1][len(lst):], kf2)
+        # 13  DescriptorDistance(cv::Mat, cv::Mat); eight frame objects went through three slots
+        assert recs[12][0] == int(np.unpackbits(mp_desc[0] ^ mp_desc[-1]).sum()) and recs[12][1][0] >= 8
+    finally:
+        fe.ctx.close()

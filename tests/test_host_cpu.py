@@ -12,9 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_functions():
-    txt = open(os.path.join(ROOT, "include", "drfe.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(drfe_[a-z0-9_]+)\s*\(", txt)))
+    """every function include/*.h declares: the drop-in boundary (drfe.h) and the test hooks (drfe_debug.h)"""
+    names = set()
+    for h in ("drfe.h", "drfe_debug.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(drfe_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,6 +30,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"libdrfe.so does not export {n}"
     assert sorted(lib.SYMBOLS) == names
     assert b"gfx950" in L.drfe_version()
+
+
+def test_boundary_header_has_no_test_hooks():
+    txt = open(os.path.join(ROOT, "include", "drfe.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    assert not re.findall(r"\bdrfe_debug_[a-z0-9_]+\s*\(", txt)
 
 
 def test_struct_layouts_match_header():
@@ -503,16 +513,18 @@ def test_long_kernels_keep_their_lds_budget(tmp_path):
             if m and size is not None:
                 lds[m.group(1)] = size
                 size = None
-    def find(sub):
-        hits = [v for k, v in lds.items() if sub in k]
+    def find(sub, exact=False):
+        hits = [v for k, v in lds.items() if (k == sub if exact else sub in k)]
         assert len(hits) == 1, (sub, sorted(lds))
         return hits[0]
     granule, cu = 1280, 160 * 1024
     def per_cu(nbytes):
         return cu // (-(-nbytes // granule) * granule)
     words = int(re.search(r"#define ORD_DYN_WORDS (\d+)", open(os.path.join(ROOT, "dr_slam_amd", "csrc", "introsort_device.h")).read()).group(1))
-    assert per_cu(find("k_ahc_cluster")) >= 7
-    assert per_cu(find("k_ahc_refine")) >= 9
+    assert per_cu(find("k_ahc_cluster", True)) >= 7
+    assert per_cu(find("k_ahc_refine", True)) >= 9
+    # the 1280 x 960 instantiations (12 800-entry queue, 1024-entry lists): one / five frames per CU, the queue still all in LDS
+    assert per_cu(find("k_ahc_cluster_big", True)) >= 1 and per_cu(find("k_ahc_refine_big", True)) >= 4
     assert per_cu(find("k_rect_improve")) >= 7
     assert per_cu(find("k_lsd_order") + words * 256 * 4) >= 7
     assert per_cu(find("k_voxel_grid") + words * 256 * 4) >= 7
