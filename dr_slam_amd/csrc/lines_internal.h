@@ -57,7 +57,15 @@ struct LsdNfaTables {
     double logNT;
     double p[11], logP[11], log1mP[11], log10P[11];
     const double* lgamma; int lgammaN;
+    int lgammaFirst;         /* nfa()'s first term: 0 = `double(n) + 1` as OpenCV 3.4's lsd.cpp spells it, 1 = log_gamma(n + 1) (the LSD paper) */
 };
+/* drfe_lsd_configure_rect's modes.  0 (default) = the OpenCV 3.4 source text throughout: rect_nfa's integer corners / step quotients /
+ * (y - tailp->p.x) denominators AND nfa()'s `log1term = (double(n) + 1) - log_gamma(k + 1) - log_gamma(n - k + 1) + ...` (the first
+ * log_gamma of the LSD paper is missing in the library: nearly every rectangle with k > n p then passes the NFA test at once);
+ * 1 = the LSD paper's reading of both (real-valued corners, log_gamma(n + 1)): rounds 2-3; 2 = integer corners with log_gamma(n + 1):
+ * round 4's default. */
+static inline int lsd_walk_mode(int rectMode) { return rectMode == 1 ? 1 : 0; }
+static inline int lsd_lgamma_first(int rectMode) { return rectMode != 0 ? 1 : 0; }
 /* one validated rectangle: the segment LineSegmentDetectorImpl::detect would emit (input-image scale), flag 1 = kept */
 struct LsdSegOut { float x1, y1, x2, y2; int flag; };
 #define DRFE_LSD_NFA_UNCERTAIN 1        /* LsdGrowFrame::out[2]: a decision of rect_improve the device could not certify */

@@ -59,7 +59,8 @@ public:
     /* counts(cands, out): (pixels, aligned pixels) of every rectangle - the device kernel k_rect_counts */
     typedef std::function<bool(const std::vector<RectCand>&, std::vector<int2>&)> CountFn;
 
-    RectValidator(int W, int H) { logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0); }
+    RectValidator(int W, int H, int rectMode = 0) : lgammaFirst_(lsd_lgamma_first(rectMode) != 0) { logNT_ = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0); }
+    void setRectMode(int rectMode) { lgammaFirst_ = lsd_lgamma_first(rectMode) != 0; }
     double logNT() const { return logNT_; }
     size_t minReg(double p) const { return size_t(-logNT_ / std::log10(p)); }
 
@@ -91,6 +92,7 @@ public:
             p /= 2;
         }
         t.lgamma = nullptr; t.lgammaN = W * H + 2;
+        t.lgammaFirst = lgammaFirst_ ? 1 : 0;
         if (lg) {                                  /* 13 ms of libm calls at 512 x 384: once per arena, not per call */
             lg->resize((size_t)t.lgammaN);
             for (size_t i = 0; i < lg->size(); i++) (*lg)[i] = logGammaInt((int)i);
@@ -98,6 +100,7 @@ public:
     }
 private:
     double logNT_;
+    bool lgammaFirst_;        /* nfa()'s first term: false = the library's `double(n) + 1`, true = log_gamma(n + 1) */
     static double logGamma(double x)
     {
         if (x > 15.0)
@@ -134,7 +137,10 @@ private:
         if (n == 0 || k == 0) return -logNT_;
         if (n == k) return -logNT_ - double(n) * std::log10(p);
         const double pTerm = p / (1 - p);
-        const double log1 = logGammaInt(n + 1) - logGammaInt(k + 1) - logGammaInt(n - k + 1) +
+        /* OpenCV 3.4 lsd.cpp: `double log1term = (double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n-k) + 1) + ...` -
+         * the paper's log_gamma(n + 1) lost its function call in the library (library bugs are preserved) */
+        const double first = lgammaFirst_ ? logGammaInt(n + 1) : (double(n) + 1);
+        const double log1 = first - logGammaInt(k + 1) - logGammaInt(n - k + 1) +
                             double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
         double term = std::exp(log1);
         if (nearlyEqual(term, 0)) return (k > n * p) ? -log1 / M_LN10 - logNT_ : -logNT_;
@@ -236,6 +242,7 @@ public:
     }
 
     typedef RectValidator::CountFn CountFn;
+    void setRectMode(int rectMode) { val_.setRectMode(rectMode); }
 
     bool run(std::vector<float>& lines, const CountFn& counts)
     {
@@ -472,7 +479,7 @@ private:
     }
 public:
     /* rect_nfa's pixel loop on the host: DRFE_LSD_CHECK=1 cross-checks k_rect_counts with it, drfe_lsd_segments_host counts
-     * with it.  rectMode 0: the literal OpenCV 3.4 source (integer corners and step quotients, (y - tailp->p.x) in the
+     * with it.  rectMode (lsd_walk_mode of the configured mode) 0: the literal OpenCV 3.4 source (integer corners and step quotients, (y - tailp->p.x) in the
      * second steps' guards and denominators); 1: the real-valued reading of round 3 (lines_kernels.hip, rect_walk_setup) */
     void countHost(const RectCand& rec, int rectMode, int& total, int& alg) const
     {
@@ -720,7 +727,7 @@ static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, i
         /* the download is issued only when the kernel has finished: queued behind it, it would sit in a DMA ring until then and
          * hold up the other lanes' copies behind it (a kernel writing straight into pinned host memory is worse: measured 2.3x
          * slower for the whole front-end - every such kernel ends in a system-scope write-back) */
-        if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, v.d_angles, v.sw, v.sh, c->rectMode, s->d_counts, st);
+        if (e == hipSuccess) e = drfe_launch_rect_counts(s->d_cands, (int)nc, v.d_angles, v.sw, v.sh, lsd_walk_mode(c->rectMode), s->d_counts, st);
         if (e == hipSuccess) e = lane_sync(c);
         if (e == hipSuccess) e = hipMemcpyAsync(s->h_counts, s->d_counts, nc * sizeof(int2), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = lane_sync(c);
@@ -729,7 +736,7 @@ static RectValidator::CountFn device_counts(LineWorker* c, const FrameView& v, i
         if (check)
             for (size_t k = 0; k < nc; k++) {
                 int t = 0, a = 0;
-                check->countHost(cands[k], c->rectMode, t, a);
+                check->countHost(cands[k], lsd_walk_mode(c->rectMode), t, a);
                 if (t != out[k].x || a != out[k].y)
                     std::fprintf(stderr, "k_rect_counts mismatch: cand %zu device (%d, %d) host (%d, %d)  x1 %.17g y1 %.17g x2 %.17g y2 %.17g w %.17g dx %.17g dy %.17g theta %.17g prec %.17g\n",
                                  k, out[k].x, out[k].y, t, a, cands[k].x1, cands[k].y1, cands[k].x2, cands[k].y2, cands[k].width, cands[k].dx, cands[k].dy, cands[k].theta, cands[k].prec);
@@ -845,6 +852,7 @@ static int host_grow_and_finish(LineWorker* c, LinesScratch* fields, int slot, i
     SegmentFinder finder(fields->sw, fields->sh, modgrad.data(), angles.data(), H.cs.data(), maxGrad, H.used, H.order, H.orderTmp);
     const auto tSort = std::chrono::steady_clock::now();
     finder.timed_ = trace;
+    finder.setRectMode(c->rectMode);
     int countRc = DRFE_OK;
     const FrameView v = {fields->w, fields->h, fields->sw, fields->sh, fields->d_angles + ns * slot, fields->d_gx + n * slot, fields->d_gy + n * slot};
     const bool checkCounts = std::getenv("DRFE_LSD_CHECK") != nullptr;
@@ -956,7 +964,7 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
     BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st));
     /* rect_improve + the NFA decisions of every accepted rectangle, behind the growth on the same stream: no host round trip */
     if (J.deviceNfa)
-        BCHK(drfe_launch_rect_improve(A->d_frames + f0, nf, A->sw, A->sh, J.rectMode, J.nfaTab, A->rectCap, A->d_segs + (size_t)A->rectCap * f0, st));
+        BCHK(drfe_launch_rect_improve(A->d_frames + f0, nf, A->sw, A->sh, lsd_walk_mode(J.rectMode), J.nfaTab, A->rectCap, A->d_segs + (size_t)A->rectCap * f0, st));
     if (J.deviceNfa && J.deviceKl) {
         const size_t k0 = (size_t)A->klCap * f0, px = (size_t)A->w * A->h;
         BCHK(drfe_launch_lsd_keylines(A->d_frames + f0, A->d_segs + (size_t)A->rectCap * f0, A->rectCap, nf, A->w, A->h, J.maxLines, A->klCap,
@@ -987,7 +995,7 @@ static void batch_worker(BatchJob& J, LineWorker* lw)
     const size_t ns = (size_t)A->sw * A->sh, n = (size_t)A->w * A->h, nk = (size_t)(A->sw - 1) * (A->sh - 1);
     (void)hipSetDevice(J.c->device);
     std::vector<OPt> tmp;
-    const RectValidator val(A->sw, A->sh);
+    const RectValidator val(A->sw, A->sh, J.rectMode);
     for (;;) {
         int f = -1, waitCh = -1, fetchCh = -1; bool fin = false;
         {
@@ -1171,9 +1179,9 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     J.deviceOrder = std::getenv("DRFE_LSD_HOST_ORDER") == nullptr;
     if (!J.deviceOrder && !A->h_order)           /* the host-ordering experiment's pinned key mirror (0.4 GB per 512 frames): on demand */
         HIPCHK(c, hipHostMalloc((void**)&A->h_order, (size_t)(A->sw - 1) * (A->sh - 1) * (size_t)A->frames * 4, hipHostMallocDefault));
-    const RectValidator val(A->sw, A->sh);
-    J.prec = M_PI * 22.5 / 180; J.p = 22.5 / 180; J.minReg = (int)val.minReg(J.p);
     J.rectMode = c->lsdRectMode;
+    const RectValidator val(A->sw, A->sh, J.rectMode);
+    J.prec = M_PI * 22.5 / 180; J.p = 22.5 / 180; J.minReg = (int)val.minReg(J.p);
     J.deviceNfa = c->lsdDeviceNfa && std::getenv("DRFE_LSD_HOST_NFA") == nullptr;
     J.deviceKl = J.deviceNfa && std::getenv("DRFE_LSD_HOST_KEYLINES") == nullptr;
     if (J.deviceKl && (A->klCap < max_lines || A->klCap == 0)) {
@@ -1352,7 +1360,7 @@ int drfe_lsd_stats(drfe_ctx* c, long long* out3 /* four entries */)
  * round 3 shipped (double quotients, (y - tailp->p.y) denominators).  SURVEY.md section 9: library bugs are preserved. */
 int drfe_lsd_configure_rect(drfe_ctx* c, int rect_mode)
 {
-    if (!c || rect_mode < 0 || rect_mode > 1) { if (c) c->err = "lsd_configure_rect: invalid argument"; return DRFE_ERR_INVALID; }
+    if (!c || rect_mode < 0 || rect_mode > 2) { if (c) c->err = "lsd_configure_rect: invalid argument"; return DRFE_ERR_INVALID; }
     c->lsdRectMode = rect_mode;
     return DRFE_OK;
 }
@@ -1421,15 +1429,16 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
 int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad,
                                 int rect_mode, float* segs, int cap, int* n_segs)
 {
-    if (rect_mode < 0 || rect_mode > 1) return DRFE_ERR_INVALID;
+    if (rect_mode < 0 || rect_mode > 2) return DRFE_ERR_INVALID;
     if (!modgrad || !angles || !cs || !n_segs || W < 4 || H < 4 || W > 2048 || H > 2048) return DRFE_ERR_INVALID;
     std::vector<uint8_t> used;
     std::vector<OPt> order, orderTmp;
     SegmentFinder finder(W, H, modgrad, angles, cs, max_grad, used, order, orderTmp);
+    finder.setRectMode(rect_mode);
     std::vector<float> out;
     auto counts = [&](const std::vector<RectCand>& cands, std::vector<int2>& res) -> bool {
         res.resize(cands.size());
-        for (size_t k = 0; k < cands.size(); k++) finder.countHost(cands[k], rect_mode, res[k].x, res[k].y);
+        for (size_t k = 0; k < cands.size(); k++) finder.countHost(cands[k], lsd_walk_mode(rect_mode), res[k].x, res[k].y);
         return true;
     };
     finder.timed_ = std::getenv("DRFE_TRACE_LINES") != nullptr;

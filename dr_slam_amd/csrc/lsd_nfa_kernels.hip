@@ -38,7 +38,11 @@ __device__ NfaVal nfa_device(int n, int k, int pj, const LsdNfaTables& T)
     if (n == k) { r.v = -T.logNT - (double)n * T.log10P[pj]; return r; }
     const double p = T.p[pj];
     const double pTerm = p / (1 - p);
-    const double log1 = T.lgamma[n + 1] - T.lgamma[k + 1] - T.lgamma[n - k + 1] + (double)k * T.logP[pj] + (double)(n - k) * T.log1mP[pj];
+    /* the first term as the configured reading has it (lines_internal.h, drfe_lsd_configure_rect): the library's `double(n) + 1`
+     * (default) or the paper's log_gamma(n + 1).  Either way log1 is the same chain of IEEE operations on the same table values as
+     * the host's, and everything below depends on log1 alone: the thresholds on it are properties of exp(), not of how it was summed */
+    const double first = T.lgammaFirst ? T.lgamma[n + 1] : (double)n + 1.0;
+    const double log1 = first - T.lgamma[k + 1] - T.lgamma[n - k + 1] + (double)k * T.logP[pj] + (double)(n - k) * T.log1mP[pj];
     /* term = exp(log1); double_equal(term, 0) holds iff term <= 100 eps x DBL_MIN, i.e. iff exp lands on one of the 99 smallest
      * subnormals: log1 < -739.84.  Clear of that threshold the closed form of the branch is the same IEEE expression on both
      * sides (bound 0); around it, and while the first term is subnormal at all (its bits are the libm's rounding onto the

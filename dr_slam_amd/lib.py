@@ -965,8 +965,9 @@ class Context:
         return dict(frames=int(out[0]), grow_to_host=int(out[1]), nfa_to_host=int(out[2]), keylines_to_host=int(out[3]))
 
     def lsd_configure_rect(self, rect_mode=0):
-        """rect_nfa's reading (OpenCV 3.4 lsd.cpp): 0 the literal source (integer corners and step quotients, default),
-        1 the real-valued reading of rounds 2-3."""
+        """The reading of OpenCV 3.4's lsd.cpp: 0 the source text (rect_nfa's integer corners and step quotients, nfa()'s
+        `double(n) + 1` first term; default), 1 the LSD paper's reading of both (rounds 2-3), 2 integer corners with
+        log_gamma(n + 1) (round 4's default)."""
         self._chk(self.L.drfe_lsd_configure_rect(self.h, int(rect_mode)), "drfe_lsd_configure_rect")
 
     def lsd_extract_batch(self, gray_batch: np.ndarray, max_lines=40, n_threads=0):

@@ -358,15 +358,18 @@ int drfe_lsd_extract_batch(drfe_ctx* ctx, const uint8_t* gray, size_t frame_stri
 /* 1 (default): drfe_lsd_extract_batch grows regions on the device; 0: on the host threads.  Frames whose 0.8-scaled size
  * exceeds the device path's LDS bitmap (about 1.2 M pixels) take the host path regardless. */
 int drfe_lsd_configure(drfe_ctx* ctx, int device_grow);
-/* Which reading of cv::LineSegmentDetectorImpl::rect_nfa (OpenCV 3.4 imgproc/src/lsd.cpp, the detector behind reference
+/* Which reading of cv::LineSegmentDetectorImpl::rect_nfa / nfa (OpenCV 3.4 imgproc/src/lsd.cpp, the detector behind reference
  * src/LSDextractor.cpp:14-17) validates the rectangles of this context's line entries.
- * 0 (default) - the literal source: `struct edge { cv::Point p; bool taken; }` has integer corners, so the four edge steps
- *   are INTEGER quotients, and the second steps use (y - tailp->p.x) in their guards and in their denominators.  The scan
- *   lines of an oblique rectangle are then not the rectangle's own; that is the library's behaviour and it is preserved
- *   (SURVEY.md section 9), not repaired.
- * 1 - the real-valued reading rounds 2-3 shipped (double quotients, (y - tailp->p.y) denominators, a step that would
- *   divide by zero taken as 0), kept until a pin against a real OpenCV 3.4.4 build decides (tools/dump_opencv_reference.py
- *   dumps the per-rectangle counts such a pin compares). */
+ * 0 (default) - the source text.  rect_nfa: `struct edge { cv::Point p; bool taken; }` has integer corners, so the four edge steps
+ *   are INTEGER quotients, and the second steps use (y - tailp->p.x) in their guards and in their denominators (the scan lines of
+ *   an oblique rectangle are then not the rectangle's own).  nfa: `log1term = (double(n) + 1) - log_gamma(double(k) + 1) -
+ *   log_gamma(double(n-k) + 1) + ...` - the first log_gamma of the LSD paper is missing, the binomial tail all but vanishes and
+ *   nearly every rectangle with k > n p passes at rect_improve's first test.  Library behaviour, preserved.
+ * 1 - the LSD paper's reading of both, as rounds 2-3 shipped (double quotients, (y - tailp->p.y) denominators, a step that would
+ *   divide by zero taken as 0; log_gamma(n + 1)).
+ * 2 - integer corners with log_gamma(n + 1): round 4's default.
+ * 1 and 2 stay until a pin against a real OpenCV 3.4.4 build decides (tools/dump_opencv_reference.py dumps the per-rectangle
+ * counts and NFA values such a pin compares). */
 int drfe_lsd_configure_rect(drfe_ctx* ctx, int rect_mode);
 /* Where drfe_lsd_extract_batch takes the decisions of cv::LineSegmentDetectorImpl::rect_improve (OpenCV 3.4 lsd.cpp: which
  * refinement candidate replaces a rectangle, whether its NFA passes): 1 (default) on the device behind the region growing

@@ -140,7 +140,10 @@ struct Lsd {
     double LOG_NT = 0;
     const double SCALE = 0.8, SIGMA_SCALE = 0.6, QUANT = 2.0, ANG_TH = 22.5, LOG_EPS = 0, DENSITY_TH = 0.7;
     const int N_BINS = 1024;
-    int rect_mode = 0;                         /* rect_nfa's reading: 0 literal OpenCV 3.4 (integer corners), 1 real-valued */
+    /* 0 (default): the OpenCV 3.4 source text - rect_nfa's integer corners and nfa()'s `double(n) + 1` first term; 1: the LSD
+     * paper's reading of both (real-valued corners, log_gamma(n + 1)) as rounds 2-3 had it; 2: integer corners with log_gamma(n + 1)
+     * (round 4) */
+    int rect_mode = 0;
     std::vector<int>* count_log = nullptr;     /* (total_pts, alg_pts) of every rect_nfa call, in call order */
 
     static double distSq(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
@@ -345,7 +348,14 @@ struct Lsd {
         if (n == 0 || k == 0) return -LOG_NT;
         if (n == k) return -LOG_NT - double(n) * std::log10(p);
         const double p_term = p / (1 - p);
-        const double log1term = log_gamma(double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1) +
+        /* lsd.cpp, LineSegmentDetectorImpl::nfa: `double log1term = (double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n-k) + 1)
+         * + double(k) * log(p) + (double(n-k)) * log(1.0 - p);` - the LSD paper (and lsd_1.6) has log_gamma(n + 1) for the first term; the
+         * library's text lost the call.  With it gone log1term is lower by log_gamma(n + 1) - (n + 1) (262 at n = 100): the binomial
+         * tail all but vanishes and nearly every rectangle with k > n p passes `log_nfa > LOG_EPS` at rect_improve's first test.
+         * Restated from memory of the library source (not in /root/reference): unpinned, like the rest of this file; the paper's form
+         * stays selectable (rect_mode 1 / 2) and tools/dump_opencv_reference.py dumps what settles it. */
+        const double first = rect_mode == 0 ? (double(n) + 1) : log_gamma(double(n) + 1);
+        const double log1term = first - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1) +
                                 double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
         double term = std::exp(log1term);
         if (double_equal(term, 0)) {
@@ -440,7 +450,7 @@ struct Lsd {
     double rect_nfa(const Rect& rec) const
     {
         int total_pts = 0, alg_pts = 0;
-        if (rect_mode == 0) rect_counts<int>(rec, total_pts, alg_pts);
+        if (rect_mode != 1) rect_counts<int>(rec, total_pts, alg_pts);
         else rect_counts<double>(rec, total_pts, alg_pts);
         if (count_log) { count_log->push_back(total_pts); count_log->push_back(alg_pts); }
         return nfa(total_pts, alg_pts, rec.p);

@@ -40,8 +40,9 @@ void resize_linear_exact_08(const uint8_t* src, int sw, int sh, uint8_t* dst, in
 void sobel3_s16(const uint8_t* src, int w, int h, int16_t* gx, int16_t* gy);
 void lbd_descriptor(const int16_t* dxImg, const int16_t* dyImg, int realWidth, int realHeight, const KeyLine& kl,
                     float* desVec72, uint8_t* desc32);
-/* rectMode: rect_nfa's reading - 0 the literal OpenCV 3.4 source (integer corners and step quotients; default), 1 the
- * real-valued reading of round 3 (see lsd_oracle.cpp) */
+/* rectMode: the reading of OpenCV 3.4's lsd.cpp - 0 the source text (rect_nfa's integer corners and step quotients, nfa()'s
+ * `double(n) + 1` first term; default), 1 the LSD paper's reading of both (rounds 2-3), 2 integer corners with log_gamma(n + 1)
+ * (round 4); see lsd_oracle.cpp */
 LineResult extract_lines(const uint8_t* img, int w, int h, int maxLines = 40, LsdStages* stages = nullptr, int rectMode = 0);
 
 } // namespace orc

@@ -683,7 +683,8 @@ KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4
 def extract_lines(gray, max_lines=40, stages=False, rect_mode=0, trace=False):
     """LineSegment::ExtractLineSegment (reference src/LSDextractor.cpp:12-43): LSD detect, keep the 40
     highest-response lines, LBD descriptors, normalised line equations.
-    rect_mode: rect_nfa's reading - 0 literal OpenCV 3.4 (integer corners, default), 1 real-valued (round 3).
+    rect_mode: lsd.cpp's reading - 0 the OpenCV 3.4 source text (integer corners, `double(n) + 1` in nfa(); default), 1 the LSD paper's
+    (real-valued corners, log_gamma(n + 1): rounds 2-3), 2 integer corners with log_gamma(n + 1) (round 4).
     Returns dict(lines (KEYLINE_DTYPE), desc [n,32], descf [n,72], lineF [n,3], detected[, stage images]
     [, rect_counts [calls,2] int32 in call order, segments [n,4] float32 before the key-line stage, seg_width / seg_prec /
     seg_nfa: what cv::LineSegmentDetector::detect reports beside the segments])."""

@@ -29,10 +29,11 @@ def _frame(seed, kind):
     return g
 
 
-@pytest.fixture(params=[0, 1], ids=["rect_literal", "rect_real"])
+@pytest.fixture(params=[0, 1, 2], ids=["lsd_source_text", "lsd_paper", "lsd_round4"])
 def rect_mode(request, ctx):
-    """rect_nfa's reading (drfe_lsd_configure_rect): 0 the literal OpenCV 3.4 source (default), 1 the real-valued one of
-    rounds 2-3.  Every oracle-parity test of the line path runs under both."""
+    """The reading of OpenCV 3.4's lsd.cpp (drfe_lsd_configure_rect): 0 the source text (rect_nfa's integer corners, nfa()'s
+    `double(n) + 1` first term; default), 1 the LSD paper's reading of both (rounds 2-3), 2 integer corners with log_gamma(n + 1)
+    (round 4's default).  Every oracle-parity test of the line path runs under all three."""
     ctx.lsd_configure_rect(request.param)
     yield request.param
     ctx.lsd_configure_rect(0)
@@ -226,7 +227,7 @@ def test_lsd_device_grow_polygons_and_odd_size(ctx, oracle_mod, rect_mode):
     # four sides under the real-valued rect_nfa; the literal one validates one or two of these oblique quadrilaterals' sides
     assert all(len(b["lines"]) >= (4 if rect_mode == 1 else 1) for b in batch[:3]) and len(batch[-2]["lines"]) == 0
     if gp.shape == (480, 640):
-        assert batch[3]["detected"] == (len(edges) if rect_mode == 1 else oracle_mod.extract_lines(gp)["detected"])
+        assert batch[3]["detected"] == (len(edges) if rect_mode == 1 else oracle_mod.extract_lines(gp, rect_mode=rect_mode)["detected"])
     odd = [f[0][:403, :531].copy() for f in synth_frames_odd()]
     for g, a in zip(odd, ctx.lsd_extract_batch(np.stack(odd), n_threads=2)):
         _same_lines(a, ctx.lsd_extract(g))

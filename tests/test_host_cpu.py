@@ -270,7 +270,7 @@ def test_lsd_host_stages_without_a_device(oracle_mod):
     rect_improve with host pixel counts, NFA) on the oracle's level-line fields: same segments as the oracle's own
     sequential implementation.  No device involved (drfe_lsd_segments_host)."""
     from dr_slam_amd import lib, synth
-    for seed, kind, mode in ((2, "room_boxes", 0), (5, "corridor", 0), (2, "room_boxes", 1), (5, "corridor", 1)):
+    for seed, kind, mode in ((2, "room_boxes", 0), (5, "corridor", 0), (2, "room_boxes", 1), (5, "corridor", 1), (2, "room_boxes", 2), (1, "planar_lowtexture", 0)):
         g, _, _ = next(synth.sequence(seed, 1, kind=kind))
         o = oracle_mod.extract_lines(g, max_lines=100000, stages=True, rect_mode=mode)
         ang = o["angles"]
@@ -283,9 +283,11 @@ def test_lsd_host_stages_without_a_device(oracle_mod):
         segs = lib.lsd_segments_host(o["modgrad"], ang, cs, float(o["modgrad"].max()), rect_mode=mode)
         assert len(segs) == o["detected"] > 40
         h, w = g.shape
+        # LSDDetector's checkLineExtremes: below 0 -> 0, >= size -> size - 1 (an end point inside (size - 1, size) stays)
         e = segs.copy()
-        e[:, 0] = np.clip(e[:, 0], 0, np.float32(w) - np.float32(1)); e[:, 2] = np.clip(e[:, 2], 0, np.float32(w) - np.float32(1))
-        e[:, 1] = np.clip(e[:, 1], 0, np.float32(h) - np.float32(1)); e[:, 3] = np.clip(e[:, 3], 0, np.float32(h) - np.float32(1))
+        for col, lim in ((0, w), (2, w), (1, h), (3, h)):
+            v = e[:, col]
+            e[:, col] = np.where(v < 0, np.float32(0), np.where(v >= np.float32(lim), np.float32(lim) - np.float32(1), v))
         L = o["lines"]
         ref = np.stack([L["startPointX"], L["startPointY"], L["endPointX"], L["endPointY"]], 1)
         assert np.array_equal(e.view(np.uint32), ref.view(np.uint32))

@@ -311,6 +311,9 @@ def test_golden_planes_lines_bow(oracle_mod):
     ln = oracle_mod.extract_lines(g, rect_mode=1)
     assert np.array_equal(ln["lines"].view(np.uint8), z["lines_real"].view(np.uint8))
     assert np.array_equal(ln["desc"], z["ldesc_real"])
+    ln = oracle_mod.extract_lines(g, rect_mode=2)          # round 4's default: these bytes are the ones round 4 committed as `lines`
+    assert np.array_equal(ln["lines"].view(np.uint8), z["lines_r4"].view(np.uint8))
+    assert np.array_equal(ln["desc"], z["ldesc_r4"])
     voc = V.make_synthetic(6, 3, seed=2)
     ov = oracle_mod.VocabularyOracle(voc.to_text())
     w, wt, nid = ov.transform_each(z["orb_desc"], 2)
