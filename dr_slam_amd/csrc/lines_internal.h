@@ -22,6 +22,7 @@ struct LinesScratch {
     /* device region growing (batch entry): per slot the ordering keys / sorted ordering, member list, shrink scratch,
      * accepted rectangles, (count, status); the launch's frame table; pinned host mirrors */
     uint32_t* d_order; uint32_t* d_reg; uint32_t* d_tmp; struct LsdRect* d_rects; int* d_out; struct LsdGrowFrame* d_frames;
+    uint32_t* d_regMw; uint32_t* d_tmpMw; uint32_t* d_gbmMw; int regCapMw;      /* k_lsd_grow_mw: member list / shrink scratch of each of a frame's four wavefronts (regCapMw entries each) */
     int* d_ordStatus; int* h_ordStatus;   /* k_lsd_order's status word per slot */
     uint32_t* h_order; unsigned long long* h_meta; struct LsdRect* h_rects; int* h_out; struct LsdGrowFrame* h_frames;
     int rectCap;
@@ -96,6 +97,8 @@ struct LsdGrowFrame {
     const float2* cs0;                                        /* W x H: float(cos), float(sin) of the pixel's angle (k_lsd_keys): a region's first direction */
     const uint32_t* order;                                    /* keys bin << 22 | y << 11 | x in std::sort's order */
     uint32_t* reg; uint32_t* tmp;                             /* W x H entries each: member list (y << 16 | x), shrink scratch */
+    uint32_t* regMw; uint32_t* tmpMw;                         /* k_lsd_grow_mw: 4 x regCap entries each, one share per wavefront of the frame's workgroup */
+    uint32_t* gbm;                                            /* k_lsd_grow_mw: a W x H bitmap in HBM, the overlay of a region too large for an LDS table */
     LsdRect* rects; int* out;                                 /* accepted rectangles in seed order; out[0] = count, out[1] = status (DRFE_LSD_OUT_INTS ints per frame) */
     int nOrder; uint32_t minSeedBin;
     const unsigned long long* meta;                           /* non-null: minSeedBin = 1024 - low word of meta[1] (k_lsd_keys), read on the device */
@@ -109,8 +112,11 @@ hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W,
  * 0, or 1 = a range ran out of introsort's depth limit (heap sort in libstdc++), 2 = internal queue overflow: order on the host. */
 hipError_t drfe_launch_lsd_order(uint32_t* d_keys, size_t keyStride, int n, uint32_t* d_posL, uint32_t* d_posR, size_t posStride,
                                  int* d_status, int statusStride, int nframes, hipStream_t s, int depthOverride = -1);
+/* regCapMw > 0: the multi-wave kernel (four wavefronts per frame, speculation with in-order commit: k_lsd_grow_mw), each wavefront
+ * owning regCapMw entries of regMw / tmpMw; 0: one wavefront per frame (k_lsd_grow).  Identical results. */
 hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W, int H, double prec, double p, int minReg,
-                                double densityTh, int rectCap, hipStream_t s);
+                                double densityTh, int rectCap, hipStream_t s, int regCapMw = 0);
+size_t drfe_lsd_grow_mw_lds_bytes(int W, int H);
 
 /* the image passes for slots frame0 .. frame0 + nframes - 1 of sc (d_img = slot frame0's input image, frames w x h apart) */
 hipError_t drfe_launch_lines_passes(const uint8_t* d_img, int w, int h, const LineTaps& lsdTaps, const LineTaps& lbdTaps,

@@ -589,7 +589,7 @@ static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
     void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_cs0, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
-                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus, s->d_segs, s->d_lgamma, s->d_kl, s->d_klLineF, s->d_klLbd, s->d_klDesc, s->d_klOut};
+                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_regMw, s->d_tmpMw, s->d_gbmMw, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus, s->d_segs, s->d_lgamma, s->d_kl, s->d_klLineF, s->d_klLbd, s->d_klDesc, s->d_klOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts, s->h_segs, s->h_kl, s->h_klLineF, s->h_klDesc, s->h_klOut};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
@@ -657,6 +657,12 @@ static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int f
         LCHK(hipMalloc((void**)&s->d_reg, ns * 4));
         LCHK(hipMalloc((void**)&s->d_cs0, ns * 8));
         LCHK(hipMalloc((void**)&s->d_tmp, ns * 4));
+        /* the multi-wave growth: each of a frame's four wavefronts owns half a field's worth of member-list entries (a region
+         * beyond that hands the frame to the host) */
+        s->regCapMw = s->sw * s->sh / 2;
+        LCHK(hipMalloc((void**)&s->d_regMw, F * 4 * (size_t)s->regCapMw * 4));
+        LCHK(hipMalloc((void**)&s->d_tmpMw, F * 4 * (size_t)s->regCapMw * 4));
+        LCHK(hipMalloc((void**)&s->d_gbmMw, F * (((size_t)s->sw * s->sh + 31) / 32) * 4));
         LCHK(hipMalloc((void**)&s->d_rects, F * s->rectCap * sizeof(LsdRect)));
         LCHK(hipMalloc((void**)&s->d_out, F * DRFE_LSD_OUT_INTS * sizeof(int)));
         LCHK(hipMalloc((void**)&s->d_frames, F * sizeof(LsdGrowFrame)));
@@ -943,6 +949,8 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
         LsdGrowFrame& g = A->h_frames[f];
         g.ang = A->d_angles + ns * f; g.cs = A->d_cs + ns * f; g.cs0 = A->d_cs0 + ns * f; g.mod = A->d_modgrad + ns * f;
         g.order = A->d_order + nk * f; g.reg = A->d_reg + ns * f; g.tmp = A->d_tmp + ns * f;
+        g.regMw = A->d_regMw + 4 * (size_t)A->regCapMw * f; g.tmpMw = A->d_tmpMw + 4 * (size_t)A->regCapMw * f;
+        g.gbm = A->d_gbmMw + ((ns + 31) / 32) * f;
         g.rects = A->d_rects + (size_t)A->rectCap * f; g.out = A->d_out + DRFE_LSD_OUT_INTS * (size_t)f;
         g.nOrder = (int)nk;
         g.meta = J.deviceOrder ? A->d_meta + 2 * (size_t)f : nullptr;
@@ -961,7 +969,9 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
     } else
         BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
     BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
-    BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st));
+    /* four wavefronts per frame (speculation with in-order commit) unless DRFE_LSD_GROW_WAVES=1 asks for the single-wave kernel */
+    static const bool growMw = [] { const char* e = std::getenv("DRFE_LSD_GROW_WAVES"); return !(e && e[0] == '1'); }();
+    BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st, growMw ? A->regCapMw : 0));
     /* rect_improve + the NFA decisions of every accepted rectangle, behind the growth on the same stream: no host round trip */
     if (J.deviceNfa)
         BCHK(drfe_launch_rect_improve(A->d_frames + f0, nf, A->sw, A->sh, lsd_walk_mode(J.rectMode), J.nfaTab, A->rectCap, A->d_segs + (size_t)A->rectCap * f0, st));
@@ -1289,7 +1299,13 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 24);
         std::fprintf(stderr, "k_rect_improve block 0 (lane 0): candidate + walk set-up %.3f ms, pixel walk %.3f, nfa %.3f, selection %.3f, all %.3f\n", pr[0] / 1e5, pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[4] / 1e5);
     }
-    if (std::getenv("DRFE_LSD_PROFILE")) {       /* LSD_PROFILE builds of k_lsd_grow: phase times of frame 0 (100 MHz ticks -> ms) and counts */
+    if (std::getenv("DRFE_LSD_PROFILE") && !(std::getenv("DRFE_LSD_GROW_WAVES") && std::getenv("DRFE_LSD_GROW_WAVES")[0] == '1')) {
+        /* LSD_PROFILE builds of k_lsd_grow_mw, frame 0: times summed over its four wavefronts */
+        const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
+        std::fprintf(stderr, "k_lsd_grow_mw frame 0: %.2f ms wall; summed over 4 waves: drain %.2f ms (of it run-at-head %.2f: %llu deferred, %llu conflicts, %llu direct-mode), scanning %.2f, take incl. scanning and waits %.2f, "
+                     "small speculation %.2f (%llu), big speculation %.2f (%llu, %llu dropped), waiting for a table %.2f, (unused %.2f), idle at the end %.2f\n",
+                     pr[14] / 1e5, pr[0] / 1e5, pr[12] / 1e5, pr[10], pr[11], pr[13], pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[8], pr[4] / 1e5, pr[9], pr[15], pr[5] / 1e5, pr[6] / 1e5, pr[7] / 1e5);
+    } else if (std::getenv("DRFE_LSD_PROFILE")) {       /* LSD_PROFILE builds of k_lsd_grow: phase times of frame 0 (100 MHz ticks -> ms) and counts */
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
         std::fprintf(stderr, "k_lsd_grow frame 0: total %.2f ms: bitmap %.2f, scan %.2f (%llu chunks), window loads %.2f (%llu groups), window growth %.2f (%llu regions, %llu member visits), "
                      "queue growth %.2f (%llu steps), region2rect %.2f (%llu), refine incl. its growth %.2f; alignment tests decided by the reference's arithmetic %llu; of the queue growth, waiting for the members' fields %.2f\n", pr[7] / 1e5, pr[0] / 1e5, pr[1] / 1e5, pr[8], pr[2] / 1e5, pr[9], pr[3] / 1e5, pr[10], pr[11],

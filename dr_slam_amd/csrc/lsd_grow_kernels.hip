@@ -66,6 +66,12 @@ __device__ __forceinline__ double uni_d(double v)
 {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
+{
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
 /* between a store and a load of the same address by different lanes of THIS wavefront (the only one of its workgroup): a
  * wavefront's memory operations are performed in order, so the compiler must keep the order and the hardware has nothing to wait for */
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
@@ -80,6 +86,18 @@ struct FramePtrs {
     int nOrder; uint32_t minSeedBin;
 };
 
+/* Overlay of one seed's processing in the multi-wave kernel (k_lsd_grow_mw, below): the pixels the seed being processed has
+ * claimed so far - and the ones it claimed and released again - kept apart from the shared bitmap until the seed's turn to commit
+ * comes.  An open-addressing table in LDS: entry = pixel index | OV_PRESENT while claimed (a released pixel keeps its entry: the
+ * table is also the set J of every pixel the seed ever joined, which is what the commit validates). */
+#define OV_SLOTS 128
+#define OV_EMPTY 0xFFFFFFFFu
+#define OV_PRESENT 0x40000000u
+#define OV_PIX 0x3FFFFFFFu
+#define OV_MAXLOAD 96                   /* entries beyond which a speculation gives up (99 regions in 100 join fewer pixels; the rest is processed at its turn with
+                                         * the frame's overlay bitmap in HBM) */
+#define LSD_STATUS_SPEC_OVERFLOW 0x100  /* internal to k_lsd_grow_mw: the overlay (or a wave's share of the member list) ran out */
+
 struct Wave {
     FramePtrs F;
     uint32_t* bm;             /* LDS: bit set = pixel cannot join (claimed, or no level-line angle) */
@@ -87,6 +105,15 @@ struct Wave {
     double* col;              /* LDS: 64 x 3 doubles, the addends of region2rect's order-defined sums (ordered_sums3) */
     int W, H, lane;
     int status;
+    /* multi-wave kernel only */
+    uint32_t* ov;             /* LDS: this wave's overlay table (OV_SLOTS entries) */
+    int ovl;                  /* 1: claims / releases go to the overlay table, `used` = bitmap | table; 2: to the frame's overlay BITMAP in HBM
+                               * (regions too large for a table, processed at their turn); 0: straight to the bitmap (single-wave kernel) */
+    GLOBAL_AS uint32_t* gbm;  /* the overlay bitmap in HBM (all zero between uses) */
+    int ovCount;              /* entries in the overlay (wave-uniform) */
+    int regCap;               /* entries of F.reg / F.tmp this wave owns */
+    unsigned long long smallMask;   /* out of grow(): the window cells of a region that stayed small (nothing claimed) */
+    int small;
 #ifdef LSD_PROFILE
     unsigned long long prof[16];
 #endif
@@ -95,6 +122,69 @@ struct Wave {
     __device__ __forceinline__ void set_bit_uniform(uint32_t q)           /* q wave-uniform */
     {
         if (lane == 0) atomicOr(&bm[q >> 5], 1u << (q & 31));      /* ds_or_b32 without return: nothing to wait for */
+    }
+    __device__ __forceinline__ uint32_t ov_slot(uint32_t q) const { return (q * 2654435761u) >> 25; }
+    __device__ __forceinline__ bool ov_has(uint32_t q) const
+    {
+        uint32_t s = ov_slot(q);
+        for (int k = 0; k < OV_SLOTS; k++) {
+            const uint32_t e = ov[s];
+            if (e == OV_EMPTY) return false;
+            if ((e & OV_PIX) == q) return (e & OV_PRESENT) != 0;
+            s = (s + 1) & (OV_SLOTS - 1);
+        }
+        return false;
+    }
+    /* per lane; returns true when a new entry was made */
+    __device__ __forceinline__ bool ov_add(uint32_t q)
+    {
+        uint32_t s = ov_slot(q);
+        for (int k = 0; k < OV_SLOTS; k++) {
+            const uint32_t old = atomicCAS(&ov[s], OV_EMPTY, q | OV_PRESENT);
+            if (old == OV_EMPTY) return true;
+            if ((old & OV_PIX) == q) { atomicOr(&ov[s], OV_PRESENT); return false; }
+            s = (s + 1) & (OV_SLOTS - 1);
+        }
+        return true;                                  /* full: the count below trips the overflow */
+    }
+    __device__ __forceinline__ void ov_drop(uint32_t q)
+    {
+        uint32_t s = ov_slot(q);
+        for (int k = 0; k < OV_SLOTS; k++) {
+            const uint32_t e = ov[s];
+            if (e == OV_EMPTY) return;
+            if ((e & OV_PIX) == q) { atomicAnd(&ov[s], ~OV_PRESENT); return; }
+            s = (s + 1) & (OV_SLOTS - 1);
+        }
+    }
+    /* can pixel q not join?  MW: the multi-wave kernel's form */
+    template <bool MW> __device__ __forceinline__ bool used(uint32_t q) const
+    {
+        if (MW) {
+            const bool b = bit(q);
+            if (ovl == 2) return b || ((__hip_atomic_load(&gbm[q >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (q & 31)) & 1u);
+            return b || (ovl && ov_has(q));
+        }
+        return bit(q);
+    }
+    /* the lanes for which `mine` holds claim their pixel q (called by all lanes of the wavefront) */
+    template <bool MW> __device__ __forceinline__ void claim(bool mine, uint32_t q)
+    {
+        if (MW && ovl == 2) {
+            /* returning atomics: the claim has reached L2 when the wave goes on, and the probes (agent-scope loads) read it there */
+            if (mine) (void)__hip_atomic_fetch_or(&gbm[q >> 5], 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MW && ovl) {
+            bool fresh = false;
+            if (mine) fresh = ov_add(q);
+            ovCount += __popcll(__ballot(fresh));
+            if (ovCount > OV_MAXLOAD) status |= LSD_STATUS_SPEC_OVERFLOW;
+        } else if (mine) atomicOr(&bm[q >> 5], 1u << (q & 31));
+    }
+    template <bool MW> __device__ __forceinline__ void release(bool mine, uint32_t q)
+    {
+        if (MW && ovl == 2) { if (mine) (void)__hip_atomic_fetch_and(&gbm[q >> 5], ~(1u << (q & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else if (MW && ovl) { if (mine) ov_drop(q); }
+        else if (mine) atomicAnd(&bm[q >> 5], ~(1u << (q & 31)));
     }
 };
 
@@ -165,7 +255,7 @@ struct RegDir { float sx, sy; };
 /* region_grow from seed (sx, sy): members to F.reg[0..n), their pixels claimed in the bitmap.  Returns n; regAngle out.
  * win = load_window(sx, sy).  CHEAP: the alignment tests go through align_class first (the caller's prec is the one T was
  * made for); refine's second growth runs with its own tolerance and the reference's arithmetic throughout. */
-template <bool CHEAP>
+template <bool CHEAP, bool MW = false>
 __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double& regAngleOut, const Window& win, const AlignTan T, int minKeep)
 {
     const int W = w.W, H = w.H, lane = w.lane;
@@ -194,7 +284,8 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
         const int wy0 = (lane * 37) >> 8, wx0 = lane - 7 * wy0;
         const int px = sx - 3 + wx0, py = sy - 3 + wy0;
         const bool inw = lane < 49 && px >= 0 && py >= 0 && px < W && py < H;
-        unsigned long long wfree = __ballot(inw && !w.bit((uint32_t)(py * W + px))) & ~(1ull << 24);
+        unsigned long long wfree = __ballot(inw && !w.template used<MW>((uint32_t)(py * W + px))) & ~(1ull << 24);
+        const unsigned long long wfree0 = wfree;
         /* which window pixels are aligned with the running angle: every lane tests its own pixel, so a member's probes are
          * scalar mask arithmetic and only a JOIN (which moves the angle) costs vector work */
         auto aligned_mask = [&]() -> unsigned long long {
@@ -225,13 +316,19 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
             }
             i++;
         }
-        if (lane < n) {
+        if (MW) {
+            /* the multi-wave kernel: a region that ended inside the window below the size that matters claims NOTHING here - its
+             * cells go out as a mask (the cells that were free and are not any more, and the seed) and the commit writes them */
+            w.small = (i >= n && n < minKeep) ? 1 : 0;
+            w.smallMask = (wfree0 & ~wfree) | (1ull << 24);
+        }
+        if (!MW || !w.small) {
             const int my = (member * 37) >> 8, mx = member - 7 * my;
             const int jx = sx - 3 + mx, jy = sy - 3 + my;
             const uint32_t xy = (uint32_t)(jy << 16 | jx), q = (uint32_t)(jy * W + jx);
-            atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+            w.template claim<MW>(lane < n, q);
             /* the list is read by the growth beyond the window and by region2rect: nineteen regions in twenty need neither */
-            if (i < n || n >= minKeep) { w.F.reg[lane] = xy; w.ring[lane] = xy; }
+            if (lane < n && (i < n || n >= minKeep)) { w.F.reg[lane] = xy; w.ring[lane] = xy; }
         }
     }
     PROF_ADD(3, tg0);
@@ -245,6 +342,7 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
     const int dyk = k / 3 - 1, dxk = k - 3 * (k / 3) - 1;
     const unsigned long long lt = (1ull << lane) - 1ull;
     while (i < n) {
+        if (MW && uni((w.status & LSD_STATUS_SPEC_OVERFLOW) != 0 || n + 64 > w.regCap)) { w.status |= LSD_STATUS_SPEC_OVERFLOW; break; }
 #ifdef LSD_PROFILE
         const unsigned long long tq0 = PROF_T();
 #endif
@@ -256,7 +354,7 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
         const int nx = (int)(mxy & 0xFFFFu) + dxk, ny = (int)(mxy >> 16) + dyk;
         const bool inb = act && nx >= 0 && ny >= 0 && nx < W && ny < H;
         const uint32_t q = inb ? (uint32_t)(ny * W + nx) : 0xFFFFFFFFu;
-        const bool want = inb && !w.bit(q);
+        const bool want = inb && !w.template used<MW>(q);
         double a = 0.0;
         float2 c = make_float2(0.f, 0.f);
         if (want) { c = make_float2(w.F.cs[2 * (size_t)q], w.F.cs[2 * (size_t)q + 1]); if (!CHEAP) a = w.F.ang[q]; }
@@ -295,8 +393,8 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
             const int at = n - __popcll(joined) + __popcll(joined & lt);
             const uint32_t xy = (uint32_t)(ny << 16 | nx);
             w.F.reg[at] = xy; w.ring[at & (LSD_RING - 1)] = xy;
-            atomicOr(&w.bm[q >> 5], 1u << (q & 31));
         }
+        w.template claim<MW>((joined >> lane) & 1ull, q);
         i += cnt;
         PROF_CNT(12, 1);
     }
@@ -452,6 +550,7 @@ __device__ __forceinline__ double density_of(const Rect& rec, int n)
 
 /* reduce_region_radius: members farther than the shrinking radius from the seed are released and removed by
  * swap-with-last; the surviving order (it feeds the next region2rect's sums) in closed form */
+template <bool MW = false>
 __device__ __forceinline__ bool shrink(Wave& w, int& n, double regAngle, double prec, Rect& rec, double density, double densityTh)
 {
     const int lane = w.lane, W = w.W;
@@ -471,7 +570,7 @@ __device__ __forceinline__ bool shrink(Wave& w, int& n, double regAngle, double 
                 const uint32_t xy = w.F.reg[j];
                 const int mx = (int)(xy & 0xFFFFu), my = (int)(xy >> 16);
                 good = !(sq((double)mx - xc) + sq((double)my - yc) > radSq);
-                if (!good) { const uint32_t q = (uint32_t)(my * W + mx); atomicAnd(&w.bm[q >> 5], ~(1u << (q & 31))); }
+                if (!good) { const uint32_t q = (uint32_t)(my * W + mx); w.template release<MW>(true, q); }
             }
             K += __popcll(__ballot(good));
         }
@@ -513,6 +612,7 @@ __device__ __forceinline__ bool shrink(Wave& w, int& n, double regAngle, double 
     return true;
 }
 
+template <bool MW = false>
 __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double prec, Rect& rec, double densityTh, const Window& win, const AlignTan T,
                                        int sx, int sy)
 {
@@ -536,7 +636,7 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
             const uint32_t xy = fromRing ? w.ring[j] : w.F.reg[j];
             const int mx = (int)(xy & 0xFFFFu), my = (int)(xy >> 16);
             const uint32_t q = (uint32_t)(my * W + mx);
-            atomicAnd(&w.bm[q >> 5], ~(1u << (q & 31)));
+            w.template release<MW>(true, q);
             if (dist2d(xc, yc, (double)mx, (double)my) < rec.width) {
                 in = true;
                 d = diff_signed(w.F.ang[q], angC);
@@ -557,11 +657,12 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
         T2.tLo = (float)(tan(tauU - band) * (1.0 - 1e-5));
         T2.tHi = (float)(tan(tauU + band) * (1.0 + 1e-5));
     }
-    n = grow<true>(w, sx, sy, tauU, regAngle, win, T2, 0);
+    n = grow<true, MW>(w, sx, sy, tauU, regAngle, win, T2, 0);
+    if (MW && uni((w.status & LSD_STATUS_SPEC_OVERFLOW) != 0)) return false;
     if (n < 2) return false;
     to_rect(w, n, regAngle, prec, rec, true);
     density = density_of(rec, n);
-    if (uni(density < densityTh)) return shrink(w, n, regAngle, prec, rec, density, densityTh);
+    if (uni(density < densityTh)) return shrink<MW>(w, n, regAngle, prec, rec, density, densityTh);
     return true;
 }
 
@@ -584,6 +685,7 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
     __builtin_amdgcn_s_setprio(LSD_SETPRIO);
 #endif
     w.W = W; w.H = H; w.lane = threadIdx.x; w.status = 0;
+    w.ov = nullptr; w.ovl = 0; w.gbm = nullptr; w.ovCount = 0; w.regCap = 0x7fffffff; w.small = 0; w.smallMask = 0;
 #ifdef LSD_PROFILE
     for (int k = 0; k < 16; k++) w.prof[k] = 0;
 #endif
@@ -759,6 +861,517 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
 #endif
 }
 
+/* ================================================================================================================================
+ * k_lsd_grow_mw - the same seed loop with MORE THAN ONE WAVEFRONT PER FRAME (round 5).
+ *
+ * The loop is order-defined only through the `used` map: a seed's processing (region_grow, region2rect, refine, reduce_region_
+ * radius) reads the map and the constant fields, and leaves its final members marked.  So the seeds of the ordering are processed
+ * SPECULATIVELY by the four wavefronts of the frame's workgroup and COMMITTED IN SEED ORDER:
+ *   - the shared bitmap holds committed state only: nothing transient is ever written to it (a seed's own claims and releases live
+ *     in an overlay table until its turn), so it only ever gains bits;
+ *   - a speculation reads the bitmap at whatever moment it runs.  Every pixel it found claimed IS claimed at its turn (bits are
+ *     never taken back); a pixel it found free and did not join fails the alignment test whatever the map says; so its run equals
+ *     the sequential one iff every pixel it ever JOINED (J: the overlay's entries, released ones included) is still free when its
+ *     turn comes.  That is the commit's validation; a seed that fails it is processed again at its turn, when the map is final
+ *     for it;
+ *   - every growing seed of the ordering and every chunk end is an ITEM with a ticket (its place in the commit order); a wave takes
+ *     the next ticket with one atomic add and publishes the item's result in a ring of slots; whichever wave is between items
+ *     drains the ring's head: one-pixel regions of the seeds without an aligned free neighbour (marks applied in passing), small
+ *     regions (nineteen in twenty stay inside the seed's 7 x 7 window below the minimum size: a 49-bit mask of cells, no overlay),
+ *     big ones (overlay table + rectangle, parked in a pool of tables so that their wave moves on at once);
+ *   - a region that outgrows an overlay table (one in a hundred) is processed at its turn with the frame's overlay BITMAP in HBM:
+ *     any size, and still nothing transient in the shared bitmap.
+ * Accepted rectangles are emitted at commit: seed order, as the single-wave kernel's.  Every wait is bounded; a wave that waits
+ * longer than the budget raises the abort flag and the frame is handed to the host (status overflow). */
+#define MW_WAVES 4
+#define MW_NCH 8                       /* chunk records (64 seeds of the ordering each) */
+#define MW_RING 64                     /* result slots */
+#define MW_TABS 16                     /* overlay tables (128 entries each): one in each wave's hands, the rest for parked results */
+#define MW_TAKEN 1
+#define MW_SMALL 2
+#define MW_END 3
+#define MW_BIG 4
+#define MW_DEFER 5
+struct MwChunk { unsigned long long cand, grow; int base, last, idx, pad; uint32_t key[64]; };      /* base = ticket of its first item; its end item = base + popc(grow) */
+struct MwSlot { int chunk, lane, tab, haveRect; unsigned long long mask; };
+struct MwShared {
+    int commitNext, ticketNext, commitLock, scanLock, abortFlag, nRects, status, pad1;
+    int scanned, totalTickets, tabFree, pad0;
+    unsigned long long prof[16];       /* LSD_PROFILE builds: 100 MHz ticks / counts summed over the four waves (see the host's print) */
+    MwChunk ch[MW_NCH];
+    int word[MW_RING];                 /* ticket << 3 | state: a slot's fields are valid once its word carries the ticket */
+    MwSlot slot[MW_RING];
+    double tabRect[MW_TABS][12];
+};
+
+namespace {
+
+__device__ __forceinline__ int mw_ld(int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ int mw_ldr(int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void mw_st(int* p, int v, int lane) { if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ bool mw_trylock(int* p, int lane)
+{
+    int got = 0;
+    if (lane == 0) got = __hip_atomic_exchange(p, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+    return __builtin_amdgcn_readfirstlane(got) != 0;
+}
+__device__ __forceinline__ void mw_unlock(int* p, int lane) { mw_st(p, 0, lane); }
+__device__ __forceinline__ int mw_add(int* p, int v, int lane)
+{
+    int r = 0;
+    if (lane == 0) r = __hip_atomic_fetch_add(p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(r);
+}
+#ifdef LSD_PROFILE
+#define MWP_T() wall_clock64()
+#define MWP_ADD(k, t0) do { if (C.lane == 0) atomicAdd(&C.S->prof[k], wall_clock64() - (t0)); } while (0)
+#define MWP_CNT(k) do { if (C.lane == 0) atomicAdd(&C.S->prof[k], 1ull); } while (0)
+#else
+#define MWP_T() 0ull
+#define MWP_ADD(k, t0) (void)(t0)
+#define MWP_CNT(k) (void)0
+#endif
+#define MW_BUDGET 300000000ull          /* 3 s of the 100 MHz clock: a wait longer than this gives the frame to the host */
+
+struct MwCtx {
+    Wave w;
+    MwShared* S;
+    uint32_t* tabs;                     /* MW_TABS x OV_SLOTS */
+    AlignTan T;
+    double prec, p, densityTh;
+    int minReg, rectCap, W, H, lane;
+    int tab;                            /* the table in this wave's hands (w.ov points at it) */
+    unsigned long long t00;
+};
+
+/* window cell t of seed (sx, sy) as a pixel index, or -1 */
+__device__ __forceinline__ int mw_cell_pixel(int sx, int sy, int t, int W, int H)
+{
+    const int wy = (t * 37) >> 8, wx = t - 7 * wy;
+    const int px = sx - 3 + wx, py = sy - 3 + wy;
+    return (t < 49 && px >= 0 && py >= 0 && px < W && py < H) ? py * W + px : -1;
+}
+
+__device__ __forceinline__ void mw_tab_clear(uint32_t* tab, int lane)
+{
+    for (int k = lane; k < OV_SLOTS; k += 64) tab[k] = OV_EMPTY;
+    wg_fence();
+}
+__device__ __forceinline__ void mw_ov_clear(Wave& w) { mw_tab_clear(w.ov, w.lane); w.ovCount = 0; }
+
+/* the one-pixel regions of chunk record R between its growing seeds: lanes [from, to) that were candidates without an aligned
+ * free neighbour at scan time and are still free */
+__device__ __forceinline__ void mw_trivial_marks(Wave& w, unsigned long long cand, unsigned long long grow, const uint32_t* keys, int to)
+{
+    const unsigned long long below = to >= 64 ? ~0ull : (1ull << to) - 1ull;
+    const unsigned long long g = grow & below;
+    const int from = g ? 64 - __builtin_clzll(g) : 0;
+    const unsigned long long todo = (cand & ~grow) & below & ~(from ? ((1ull << from) - 1ull) : 0ull);
+    if (!todo) return;
+    if ((todo >> w.lane) & 1ull) {
+        const uint32_t key = keys[w.lane];
+        const uint32_t q = ((key >> 11) & 0x7FFu) * (uint32_t)w.W + (key & 0x7FFu);
+        if (!w.bit(q)) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+    }
+}
+
+struct MwBig { Rect rec; int haveRect; };
+
+/* One seed through region_grow / region2rect / refine in the mode the wave is in (w.ovl).  Returns 0 = the seed was claimed
+ * already (nothing to do), 1 = small (w.smallMask holds its cells, nothing claimed), 2 = big (claims in the overlay or, in direct
+ * mode, in the bitmap; B.haveRect / B.rec = the accepted rectangle).  LSD_STATUS_SPEC_OVERFLOW in w.status = gave up. */
+__device__ __forceinline__ int mw_process(MwCtx& C, int gx, int gy, const Window& win, MwBig& B, bool allowSmall)
+{
+    Wave& w = C.w;
+    B.haveRect = 0;
+    if (uni(w.bit((uint32_t)(gy * C.W + gx)))) return 0;
+    double regAngle;
+    int n = grow<true, true>(w, gx, gy, C.prec, regAngle, win, C.T, allowSmall ? C.minReg : 0);
+    if (uni(w.small != 0)) return 1;
+    if (uni((w.status & LSD_STATUS_SPEC_OVERFLOW) != 0)) return 2;
+    if (n >= C.minReg) {
+        to_rect(w, n, regAngle, C.prec, B.rec, true);
+        const bool okr = refine<true>(w, n, regAngle, C.prec, B.rec, C.densityTh, win, C.T, gx, gy);
+        if (okr && !(w.status & LSD_STATUS_SPEC_OVERFLOW)) B.haveRect = 1;
+    }
+    return 2;
+}
+
+/* the holder of the commit lock appends an accepted rectangle (12 doubles, LsdRect) */
+__device__ __forceinline__ void mw_emit_rect(MwCtx& C, const double* o12)
+{
+    MwShared* S = C.S;
+    const int at = uni_i32(S->nRects);
+    if (at < C.rectCap) {
+        if (C.lane < 12) C.w.F.rects[(size_t)at * 12 + C.lane] = o12[C.lane];
+        if (C.lane == 0) S->nRects = at + 1;
+    } else C.w.status |= DRFE_LSD_STATUS_OVERFLOW;
+    wg_fence();
+}
+__device__ __forceinline__ void mw_rect12(const MwCtx& C, const Rect& rec, double* o)
+{
+    o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y; o[7] = rec.theta; o[8] = rec.dx; o[9] = rec.dy;
+    o[10] = C.prec; o[11] = C.p;
+}
+
+__device__ __forceinline__ void mw_emit_rec(MwCtx& C, const Rect& rec)
+{
+    double o[12];
+    mw_rect12(C, rec, o);
+    double mine = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) if (C.lane == k) mine = o[k];
+    const int at = uni_i32(C.S->nRects);
+    if (at < C.rectCap) {
+        if (C.lane < 12) C.w.F.rects[(size_t)at * 12 + C.lane] = mine;
+        if (C.lane == 0) C.S->nRects = at + 1;
+    } else C.w.status |= DRFE_LSD_STATUS_OVERFLOW;
+    wg_fence();
+}
+
+/* commit of a small region: its cells must still be free; returns false on a conflict (nothing written) */
+__device__ __forceinline__ bool mw_commit_small(Wave& w, int gx, int gy, unsigned long long mask)
+{
+    const int q = mw_cell_pixel(gx, gy, w.lane, w.W, w.H);
+    const bool mine = q >= 0 && ((mask >> w.lane) & 1ull);
+    if (__ballot(mine && w.bit((uint32_t)q))) return false;
+    if (mine) atomicOr(&w.bm[q >> 5], 1u << (q & 31));
+    return true;
+}
+
+/* validation of an overlay table (every pixel ever joined still free) and, if it holds, its commit (the claimed ones marked) */
+__device__ __forceinline__ bool mw_commit_table(Wave& w, const uint32_t* tab)
+{
+    uint32_t e[OV_SLOTS / 64];
+    bool conflict = false;
+#pragma unroll
+    for (int k = 0; k < OV_SLOTS / 64; k++) e[k] = tab[k * 64 + w.lane];
+#pragma unroll
+    for (int k = 0; k < OV_SLOTS / 64; k++) if (e[k] != OV_EMPTY && w.bit(e[k] & OV_PIX)) conflict = true;
+    if (__ballot(conflict)) return false;
+#pragma unroll
+    for (int k = 0; k < OV_SLOTS / 64; k++)
+        if (e[k] != OV_EMPTY && (e[k] & OV_PRESENT)) { const uint32_t q = e[k] & OV_PIX; atomicOr(&w.bm[q >> 5], 1u << (q & 31)); }
+    return true;
+}
+
+/* a seed at the head of the commit order, by the holder of the commit lock: the map is final for it.  With an empty table in its
+ * hands (C.tab >= 0) the wave runs it with that table; without one - every table parked behind the head - or when the table runs
+ * out, with the overlay bitmap in HBM */
+__device__ __forceinline__ void mw_run_at_head(MwCtx& C, int gx, int gy)
+{
+    Wave& w = C.w;
+    if (uni(w.bit((uint32_t)(gy * C.W + gx)))) return;
+    const Window win = load_window(w, gx, gy);
+    MwBig B;
+    if (C.tab >= 0) {
+        w.ovl = 1; w.status &= ~LSD_STATUS_SPEC_OVERFLOW;
+        const int kind = mw_process(C, gx, gy, win, B, true);
+        if (kind == 1) { (void)mw_commit_small(w, gx, gy, w.smallMask); return; }
+        if (kind == 0) return;
+        if (!(w.status & LSD_STATUS_SPEC_OVERFLOW)) {
+            (void)mw_commit_table(w, w.ov);                 /* cannot conflict: nothing was committed since it started */
+            if (B.haveRect) mw_emit_rec(C, B.rec);
+            mw_ov_clear(w);
+            return;
+        }
+        mw_ov_clear(w);
+    }
+    /* once more, with the frame's overlay bitmap in HBM: any size, and still nothing transient in the shared bitmap.  What is set
+     * in the overlay at the end are the region's final members: OR-ed into the bitmap and cleared, word by word */
+    w.status &= ~LSD_STATUS_SPEC_OVERFLOW;
+    MWP_CNT(13);
+    w.ovl = 2;
+    (void)mw_process(C, gx, gy, win, B, false);
+    const int nWords = (C.W * C.H + 31) >> 5;
+    for (int base = 0; base < nWords; base += 64 * 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + 64 * u + C.lane; v[u] = i < nWords ? __hip_atomic_load(&w.gbm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + 64 * u + C.lane; if (v[u]) { atomicOr(&w.bm[i], v[u]); w.gbm[i] = 0u; } }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (w.status & LSD_STATUS_SPEC_OVERFLOW) { w.status = (w.status & ~LSD_STATUS_SPEC_OVERFLOW) | DRFE_LSD_STATUS_OVERFLOW; }     /* a wave's share of the member list ran out: the host takes the frame */
+    else if (B.haveRect) mw_emit_rec(C, B.rec);
+    w.ovl = 1;
+    wg_fence();
+}
+
+/* the ring's head forward as far as finished results reach.  Called by a wave between items: the table in its hands is empty. */
+__device__ __forceinline__ void mw_drain(MwCtx& C)
+{
+    MwShared* S = C.S;
+    Wave& w = C.w;
+    {   /* anything at the head?  (one read, no lock traffic, when there is not) */
+        const int t = mw_ldr(&S->commitNext);
+        const int wd = mw_ldr(&S->word[t & (MW_RING - 1)]);
+        const int st = wd & 7;
+        if ((wd >> 3) != t || st == MW_TAKEN) return;
+    }
+    if (!mw_trylock(&S->commitLock, C.lane)) return;
+    const unsigned long long td0 = MWP_T();
+    for (;;) {
+        const int t = mw_ldr(&S->commitNext);
+        const int wd = mw_ld(&S->word[t & (MW_RING - 1)]);
+        const int st = wd & 7;
+        if ((wd >> 3) != t || st == MW_TAKEN) break;
+        const MwSlot sl = S->slot[t & (MW_RING - 1)];
+        const int c = uni_i32(sl.chunk), f = uni_i32(sl.lane);
+        const MwChunk& R = S->ch[c & (MW_NCH - 1)];
+        mw_trivial_marks(w, uni_u64(R.cand), uni_u64(R.grow), R.key, st == MW_END ? 64 : f);
+        if (st != MW_END) {
+            const uint32_t key = uni_u32(R.key[f]);
+            const int gx = (int)(key & 0x7FFu), gy = (int)((key >> 11) & 0x7FFu);
+            bool done = false;
+            if (st == MW_SMALL) { const unsigned long long mask = uni_u64(sl.mask); done = mask == 0 || mw_commit_small(w, gx, gy, mask); }
+            else if (st == MW_BIG) {
+                const int tb = uni_i32(sl.tab);
+                uint32_t* tab = C.tabs + (size_t)tb * OV_SLOTS;
+                if (mw_commit_table(w, tab)) {
+                    if (uni_i32(sl.haveRect)) mw_emit_rect(C, S->tabRect[tb]);
+                    done = true;
+                }
+                mw_tab_clear(tab, C.lane);
+                if (C.lane == 0) atomicOr(&S->tabFree, 1 << tb);
+            }
+            if (!done) { const unsigned long long th0 = MWP_T(); MWP_CNT(st == MW_DEFER ? 10 : 11); mw_run_at_head(C, gx, gy); MWP_ADD(12, th0); }
+        }
+        wg_fence();
+        mw_st(&S->commitNext, t + 1, C.lane);
+        if (mw_ldr(&S->abortFlag)) break;
+    }
+    MWP_ADD(0, td0);
+    mw_unlock(&S->commitLock, C.lane);
+}
+
+/* one chunk of the ordering into its record: candidates (free at this moment) and which of them have an aligned free neighbour.
+ * Called under the scan lock, chunks in order. */
+__device__ __forceinline__ bool mw_scan_chunk(MwCtx& C, int c)
+{
+    Wave& w = C.w;
+    MwShared* S = C.S;
+    const int lane = C.lane, W = C.W, H = C.H;
+    const int pos = c * 64 + lane;
+    const uint32_t key = pos < w.F.nOrder ? w.F.order[pos] : 0u;
+    const bool valid = pos < w.F.nOrder && (key >> 22) >= w.F.minSeedBin;
+    const int sx = (int)(key & 0x7FFu), sy = (int)((key >> 11) & 0x7FFu);
+    const uint32_t q = (uint32_t)(sy * W + sx);
+    const bool cand = valid && !w.bit(q);
+    bool nt = false;
+    if (cand) {
+        const double sa = w.F.ang[q];
+        double na[8];
+        uint32_t nf = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int jj = j < 4 ? j : j + 1, dx = jj % 3 - 1, dy = jj / 3 - 1;
+            const int nx = sx + dx, ny = sy + dy;
+            const bool inb = nx >= 0 && ny >= 0 && nx < W && ny < H;
+            const uint32_t nq = inb ? (uint32_t)(ny * W + nx) : 0u;
+            na[j] = 0.0;
+            if (inb && !w.bit(nq)) { nf |= 1u << j; na[j] = w.F.ang[nq]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) nt |= ((nf >> j) & 1u) && aligned_with(sa, na[j], C.prec);
+    }
+    const unsigned long long mc = __ballot(cand), mg = __ballot(cand && nt), inv = __ballot(!valid);
+    MwChunk& R = S->ch[c & (MW_NCH - 1)];
+    int base = 0;
+    if (c > 0) { const MwChunk& P = S->ch[(c - 1) & (MW_NCH - 1)]; base = uni_i32(P.base) + __popcll(uni_u64(P.grow)) + 1; }
+    const int last = (inv != 0 || (c + 1) * 64 >= w.F.nOrder) ? 1 : 0;
+    R.key[lane] = key;
+    if (lane == 0) { R.cand = mc; R.grow = mg; R.base = base; R.last = last; R.idx = c; }
+    wg_fence();
+    if (last) mw_st(&S->totalTickets, base + __popcll(mg) + 1, lane);
+    return true;
+}
+
+__device__ __forceinline__ bool mw_over_budget(MwCtx& C)
+{
+    if (wall_clock64() - C.t00 > MW_BUDGET) { mw_st(&C.S->abortFlag, 1, C.lane); return true; }
+    return false;
+}
+
+}  // namespace
+
+#ifndef MW_WAVES_PER_EU
+#define MW_WAVES_PER_EU 2              /* measured: capping the kernel at 168 VGPRs for three workgroups per CU spills into its hot loops (38 -> 52 ms per 512 frames) */
+#endif
+extern "C" __global__ __launch_bounds__(64 * MW_WAVES) __attribute__((amdgpu_waves_per_eu(MW_WAVES_PER_EU, MW_WAVES_PER_EU))) void k_lsd_grow_mw(const LsdGrowFrame* __restrict__ frames, int W, int H, double prec, double p,
+                                                                         int minReg, double densityTh, int rectCap, float tLo, float tHi, int regCap)
+{
+    extern __shared__ uint32_t lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int npx = W * H, nWords = (npx + 31) >> 5;
+    MwCtx C;
+    Wave& w = C.w;
+    {
+        const LsdGrowFrame f = frames[blockIdx.x];
+        w.F.ang = (const GLOBAL_AS double*)f.ang; w.F.cs = (const GLOBAL_AS float*)f.cs; w.F.cs0 = (const GLOBAL_AS float*)f.cs0; w.F.mod = (const GLOBAL_AS double*)f.mod;
+        w.F.order = (const GLOBAL_AS uint32_t*)f.order;
+        w.F.reg = (GLOBAL_AS uint32_t*)f.regMw + (size_t)wave * regCap; w.F.tmp = (GLOBAL_AS uint32_t*)f.tmpMw + (size_t)wave * regCap;
+        w.F.rects = (GLOBAL_AS double*)f.rects; w.F.out = (GLOBAL_AS int*)f.out; w.F.nOrder = f.nOrder;
+        w.F.minSeedBin = f.meta ? 1024u - (uint32_t)(f.meta[1] & 0xFFFFFFFFull) : f.minSeedBin;
+        w.gbm = (GLOBAL_AS uint32_t*)f.gbm;
+    }
+    w.W = W; w.H = H; w.lane = lane; w.status = 0;
+    w.ovl = 1; w.ovCount = 0; w.regCap = regCap; w.small = 0; w.smallMask = 0;
+#ifdef LSD_PROFILE
+    for (int k = 0; k < 16; k++) w.prof[k] = 0;
+#endif
+    /* LDS: bitmap | shared control block | overlay tables | per wave: ring, ordered-sum columns */
+    uint32_t* at = lds;
+    w.bm = at; at += (nWords + 1) & ~1;
+    MwShared* S = (MwShared*)at; at += (sizeof(MwShared) + 7) / 8 * 2;
+    C.tabs = at; at += MW_TABS * OV_SLOTS;
+    at += (size_t)wave * (LSD_RING + 64 * 3 * 2);
+    w.ring = at; w.col = (double*)(at + LSD_RING);
+    C.tab = wave; w.ov = C.tabs + (size_t)wave * OV_SLOTS;
+    C.S = S; C.T.tLo = tLo; C.T.tHi = tHi; C.prec = prec; C.p = p; C.densityTh = densityTh; C.minReg = minReg; C.rectCap = rectCap; C.W = W; C.H = H; C.lane = lane;
+
+    /* bitmap: pixels without a level-line angle never join (NOTDEF, incl. the last row and column); the four waves side by side */
+    for (int base = wave * 64; base < npx; base += 64 * MW_WAVES) {
+        const int q = base + lane;
+        const bool nd = q >= npx || w.F.ang[q] == -1024.0;
+        const unsigned long long b = __ballot(nd);
+        const int wd = base >> 5;
+        if (lane == 0) { if (wd < nWords) w.bm[wd] = (uint32_t)b; if (wd + 1 < nWords) w.bm[wd + 1] = (uint32_t)(b >> 32); }
+    }
+    for (int k = tid; k < (int)(sizeof(MwShared) / 4); k += 64 * MW_WAVES) ((uint32_t*)S)[k] = 0;
+    for (int k = tid; k < MW_TABS * OV_SLOTS; k += 64 * MW_WAVES) C.tabs[k] = OV_EMPTY;
+    for (int k = tid; k < nWords; k += 64 * MW_WAVES) w.gbm[k] = 0u;                  /* the HBM overlay starts, and is left, all zero */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) { S->totalTickets = 0x7fffffff; S->tabFree = ((1 << MW_TABS) - 1) & ~((1 << MW_WAVES) - 1); for (int k = 0; k < MW_RING; k++) S->word[k] = -8; }
+    __syncthreads();
+    C.t00 = wall_clock64();
+
+    int myChunk = 0;                       /* the chunk this wave's last ticket lay in: tickets only go up */
+    for (;;) {
+        if (mw_ldr(&S->abortFlag)) break;
+        const int total = mw_ldr(&S->totalTickets);
+        if (mw_ldr(&S->commitNext) >= total) break;
+        mw_drain(C);
+        /* the next item of the commit order */
+        const unsigned long long tk0 = MWP_T();
+        if (mw_ldr(&S->ticketNext) >= total) { const unsigned long long ti0 = MWP_T(); if (mw_over_budget(C)) break; __builtin_amdgcn_s_sleep(4); MWP_ADD(7, ti0); continue; }      /* all taken: drain until the end */
+        const int ticket = mw_add(&S->ticketNext, 1, lane);
+        /* which chunk / seed is it?  The chunk may have to be scanned first (chunks in order, one scanner at a time), and the
+         * ring must have room for the ticket */
+        int f = -1;
+        bool stop = false;
+        for (;;) {
+            const int sc = mw_ld(&S->scanned);
+            if (myChunk < sc) {
+                const MwChunk& R = S->ch[myChunk & (MW_NCH - 1)];
+                if (uni_i32(R.idx) != myChunk) { myChunk++; continue; }        /* committed to its end long ago and its record reused: the ticket lies further on */
+                const int base = uni_i32(R.base), cnt = __popcll(uni_u64(R.grow));
+                if (ticket > base + cnt) { if (uni_i32(R.last)) { stop = true; break; } myChunk++; continue; }
+                if (ticket - mw_ldr(&S->commitNext) < MW_RING) {
+                    f = 64;
+                    if (ticket < base + cnt) { unsigned long long g = uni_u64(R.grow); for (int k = ticket - base; k > 0; k--) g &= g - 1; f = __builtin_ctzll(g); }
+                    break;
+                }
+            } else if (sc - 1 >= 0 && uni_i32(S->ch[(sc - 1) & (MW_NCH - 1)].last)) { stop = true; break; }
+            else if (mw_trylock(&S->scanLock, lane)) {
+                const unsigned long long ts0 = MWP_T();
+                const int sc2 = mw_ld(&S->scanned);
+                /* the record's previous chunk (sc2 - MW_NCH) must be committed to its end */
+                bool roomy = sc2 < MW_NCH;
+                if (!roomy) { const MwChunk& O = S->ch[sc2 & (MW_NCH - 1)]; roomy = mw_ldr(&S->commitNext) > uni_i32(O.base) + __popcll(uni_u64(O.grow)); }
+                const bool ended = sc2 > 0 && uni_i32(S->ch[(sc2 - 1) & (MW_NCH - 1)].last) != 0;
+                if (roomy && !ended && mw_scan_chunk(C, sc2)) mw_st(&S->scanned, sc2 + 1, lane);
+                mw_unlock(&S->scanLock, lane);
+                MWP_ADD(1, ts0);
+                if (roomy) continue;
+            }
+            /* waiting for the scanner, for a record to free up or for room in the ring: help the head along */
+            if (mw_ldr(&S->abortFlag) || mw_over_budget(C)) { stop = true; break; }
+            mw_drain(C);
+            __builtin_amdgcn_s_sleep(1);
+        }
+        MWP_ADD(2, tk0);
+        if (stop) { if (mw_ldr(&S->abortFlag)) break; continue; }      /* a ticket beyond the last item */
+        MwSlot* sl = &S->slot[ticket & (MW_RING - 1)];
+        int* word = &S->word[ticket & (MW_RING - 1)];
+        if (lane == 0) { sl->chunk = myChunk; sl->lane = f; sl->mask = 0; sl->tab = -1; sl->haveRect = 0; }
+        wg_fence();
+        if (f == 64) { mw_st(word, ticket << 3 | MW_END, lane); continue; }
+        mw_st(word, ticket << 3 | MW_TAKEN, lane);
+
+        /* ---- speculate on the seed ---- */
+        const unsigned long long tp0 = MWP_T();
+        const uint32_t key = uni_u32(S->ch[myChunk & (MW_NCH - 1)].key[f]);
+        const int gx = (int)(key & 0x7FFu), gy = (int)((key >> 11) & 0x7FFu);
+        if (uni(w.bit((uint32_t)(gy * W + gx)))) { mw_st(word, ticket << 3 | MW_SMALL, lane); MWP_ADD(3, tp0); continue; }      /* mask 0: claimed already */
+        const Window win = load_window(w, gx, gy);
+        MwBig B;
+        w.ovl = 1; w.status &= ~LSD_STATUS_SPEC_OVERFLOW;
+        const int kind = mw_process(C, gx, gy, win, B, true);
+        if (kind == 0) { mw_st(word, ticket << 3 | MW_SMALL, lane); MWP_ADD(3, tp0); continue; }
+        if (kind == 1) {
+            if (lane == 0) sl->mask = w.smallMask;
+            wg_fence();
+            mw_st(word, ticket << 3 | MW_SMALL, lane);
+            MWP_ADD(3, tp0); MWP_CNT(8);
+            continue;
+        }
+        MWP_CNT(9);
+#ifdef LSD_PROFILE_JHIST
+        if (w.ovCount <= 48) MWP_CNT(6); else if (w.ovCount <= 96) MWP_CNT(10); else if (w.ovCount <= 192) MWP_CNT(13); else MWP_CNT(7);
+#endif
+        /* big: finished speculatively in this wave's table - unless the table ran out: such a region waits for its turn */
+        if ((w.status & LSD_STATUS_SPEC_OVERFLOW) != 0) {
+            w.status &= ~LSD_STATUS_SPEC_OVERFLOW;
+            mw_ov_clear(w);
+            mw_st(word, ticket << 3 | MW_DEFER, lane);
+            MWP_ADD(4, tp0); MWP_CNT(15);
+            continue;
+        }
+        /* park the result: the table and the rectangle stay where they are until the head reaches the ticket */
+        if (B.haveRect) { double o[12]; mw_rect12(C, B.rec, o); double mine = 0; for (int k = 0; k < 12; k++) if (lane == k) mine = o[k]; if (lane < 12) S->tabRect[C.tab][lane] = mine; }
+        if (lane == 0) { sl->tab = C.tab; sl->haveRect = B.haveRect; }
+        wg_fence();
+        mw_st(word, ticket << 3 | MW_BIG, lane);
+        MWP_ADD(4, tp0);
+        /* another table */
+        const unsigned long long tw0 = MWP_T();
+        C.tab = -1;
+        int got = -1;
+        for (;;) {
+            int fr = mw_ldr(&S->tabFree);
+            if (fr) {
+                const int b = __builtin_ctz(fr);
+                int old = 0;
+                if (lane == 0) old = atomicAnd(&S->tabFree, ~(1 << b));
+                old = uni_i32(old);
+                if (old & (1 << b)) { got = b; break; }
+                continue;
+            }
+            if (mw_ldr(&S->abortFlag) || mw_over_budget(C)) break;
+            /* none free: every table is in a wave's hands or parked.  The head may be a parked one: help it along (C.tab < 0: a
+             * head that has to be run again goes the direct way) */
+            mw_drain(C);
+            __builtin_amdgcn_s_sleep(1);
+        }
+        MWP_ADD(5, tw0);
+        if (got < 0) break;
+        C.tab = got; w.ov = C.tabs + (size_t)got * OV_SLOTS; w.ovCount = 0;
+    }
+    if (lane == 0 && w.status) atomicOr(&S->status, w.status & ~LSD_STATUS_SPEC_OVERFLOW);
+    __syncthreads();
+    if (tid == 0) {
+        int st = S->status;
+        if (S->abortFlag || S->commitNext < S->totalTickets) st |= DRFE_LSD_STATUS_OVERFLOW;      /* did not finish: the host takes the frame */
+        w.F.out[DRFE_LSD_OUT_NEXT_RECT] = 0; w.F.out[0] = S->nRects; w.F.out[1] = st; w.F.out[2] = 0; w.F.out[3] = 0;
+#ifdef LSD_PROFILE
+        S->prof[14] = wall_clock64() - C.t00;
+        for (int k = 0; k < 16; k++) ((GLOBAL_AS unsigned long long*)(w.F.out + 4))[k] = S->prof[k];
+#endif
+    }
+}
+
 /* pseudo-ordering keys: gradient bin << 22 | y << 11 | x for the (W - 1) x (H - 1) pixels ll_angle visits, in raster order
  * (what the host sorts), the seed direction of every pixel with an angle, and the smallest bin of a pixel that has a level-line angle (kept as 1024 - bin under atomicMax in
  * the low half of the slot's second meta word, which the image passes zeroed).  blockIdx.z = frame slot. */
@@ -806,16 +1419,22 @@ hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W,
     return hipGetLastError();
 }
 
+size_t drfe_lsd_grow_mw_lds_bytes(int W, int H)
+{
+    const size_t nWords = ((size_t)W * H + 31) >> 5;
+    return (((nWords + 1) & ~(size_t)1) + (sizeof(MwShared) + 7) / 8 * 2 + (size_t)MW_TABS * OV_SLOTS + (size_t)MW_WAVES * (LSD_RING + 64 * 3 * 2)) * 4;
+}
+
 hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W, int H, double prec, double p, int minReg,
-                                double densityTh, int rectCap, hipStream_t s)
+                                double densityTh, int rectCap, hipStream_t s, int regCapMw)
 {
     if (nframes <= 0) return hipSuccess;
-    const size_t lds = drfe_lsd_grow_lds_bytes(W, H);
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_lsd_grow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = regCapMw > 0 ? drfe_lsd_grow_mw_lds_bytes(W, H) : drfe_lsd_grow_lds_bytes(W, H);
+    static size_t configured = 0, configuredMw = 0;
+    if (lds > 64 * 1024 && lds > (regCapMw > 0 ? configuredMw : configured)) {
+        hipError_t e = hipFuncSetAttribute(regCapMw > 0 ? (const void*)k_lsd_grow_mw : (const void*)k_lsd_grow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
+        (regCapMw > 0 ? configuredMw : configured) = lds;
     }
     /* thresholds of align_class for this precision: tan(prec -/+ 0.02 degrees), rounded away from the band; a tolerance that
      * reaches 90 degrees switches the shortcut off (tLo <= 0) */
@@ -825,6 +1444,9 @@ hipError_t drfe_launch_lsd_grow(const LsdGrowFrame* d_frames, int nframes, int W
         tLo = nextafterf((float)tan(prec - band), 0.f);
         tHi = nextafterf((float)tan(prec + band), 1e30f);
     }
-    hipLaunchKernelGGL(k_lsd_grow, dim3(nframes), dim3(64), lds, s, d_frames, W, H, prec, p, minReg, densityTh, rectCap, tLo, tHi);
+    if (regCapMw > 0)
+        hipLaunchKernelGGL(k_lsd_grow_mw, dim3(nframes), dim3(64 * MW_WAVES), lds, s, d_frames, W, H, prec, p, minReg, densityTh, rectCap, tLo, tHi, regCapMw);
+    else
+        hipLaunchKernelGGL(k_lsd_grow, dim3(nframes), dim3(64), lds, s, d_frames, W, H, prec, p, minReg, densityTh, rectCap, tLo, tHi);
     return hipGetLastError();
 }
