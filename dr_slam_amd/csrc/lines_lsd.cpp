@@ -969,8 +969,14 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
     } else
         BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
     BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
-    /* four wavefronts per frame (speculation with in-order commit) unless DRFE_LSD_GROW_WAVES=1 asks for the single-wave kernel */
-    static const bool growMw = [] { const char* e = std::getenv("DRFE_LSD_GROW_WAVES"); return !(e && e[0] == '1'); }();
+    /* Region growing: one wavefront per frame (k_lsd_grow: the least wave-time per frame - what counts when calls of hundreds of
+     * frames run side by side and the device is full) or four (k_lsd_grow_mw: speculation with in-order commit, 75 -> 45 ms per
+     * frame - what counts when the call cannot fill the device by itself).  Measured on one MI355X (profiles/r05a_path_saturation.txt):
+     * one 512-frame call at a time 6 100 frames/s with four waves against 4 600, five calls in flight 7 700 against 8 900.
+     * Default: four waves up to 256 frames per call (fewer than one wavefront per CU each); DRFE_LSD_GROW_WAVES=1 / 4 forces one. */
+    static const int growWavesEnv = [] { const char* e = std::getenv("DRFE_LSD_GROW_WAVES"); return e ? std::atoi(e) : 0; }();
+    const int growMode = J.c->lsdDeviceGrow;          /* drfe_lsd_configure: 2 / 3 force a kernel */
+    const bool growMw = growMode == 3 || growWavesEnv == 4 || (growMode != 2 && growWavesEnv != 1 && J.nframes <= 256);
     BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st, growMw ? A->regCapMw : 0));
     /* rect_improve + the NFA decisions of every accepted rectangle, behind the growth on the same stream: no host round trip */
     if (J.deviceNfa)
@@ -1299,7 +1305,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 24);
         std::fprintf(stderr, "k_rect_improve block 0 (lane 0): candidate + walk set-up %.3f ms, pixel walk %.3f, nfa %.3f, selection %.3f, all %.3f\n", pr[0] / 1e5, pr[1] / 1e5, pr[2] / 1e5, pr[3] / 1e5, pr[4] / 1e5);
     }
-    if (std::getenv("DRFE_LSD_PROFILE") && !(std::getenv("DRFE_LSD_GROW_WAVES") && std::getenv("DRFE_LSD_GROW_WAVES")[0] == '1')) {
+    if (std::getenv("DRFE_LSD_PROFILE") && std::getenv("DRFE_LSD_GROW_WAVES") && std::getenv("DRFE_LSD_GROW_WAVES")[0] == '4') {
         /* LSD_PROFILE builds of k_lsd_grow_mw, frame 0: times summed over its four wavefronts */
         const unsigned long long* pr = (const unsigned long long*)(A->h_out + 4);
         std::fprintf(stderr, "k_lsd_grow_mw frame 0: %.2f ms wall; summed over 4 waves: drain %.2f ms (of it run-at-head %.2f: %llu deferred, %llu conflicts, %llu direct-mode), scanning %.2f, take incl. scanning and waits %.2f, "
@@ -1342,11 +1348,12 @@ int drfe_lsd_extract(drfe_ctx* c, const uint8_t* gray, int w, int h, size_t stri
     return rc;
 }
 
-/* where drfe_lsd_extract_batch grows its regions: 1 (default) on the device (k_lsd_grow, one wavefront per frame), 0 on the
- * pool's host threads (the path of drfe_lsd_extract, frame by frame).  Results are identical. */
+/* where drfe_lsd_extract_batch grows its regions: 0 on the pool's host threads (the path of drfe_lsd_extract, frame by frame);
+ * on the device: 1 (default) the kernel chosen by the size of the call, 2 one wavefront per frame (k_lsd_grow), 3 four wavefronts
+ * per frame (k_lsd_grow_mw: speculation with in-order commit).  Results are identical. */
 int drfe_lsd_configure(drfe_ctx* c, int device_grow)
 {
-    if (!c || device_grow < 0 || device_grow > 1) { if (c) c->err = "lsd_configure: invalid argument"; return DRFE_ERR_INVALID; }
+    if (!c || device_grow < 0 || device_grow > 3) { if (c) c->err = "lsd_configure: invalid argument"; return DRFE_ERR_INVALID; }
     c->lsdDeviceGrow = device_grow;
     return DRFE_OK;
 }

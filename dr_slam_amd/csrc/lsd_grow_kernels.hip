@@ -885,8 +885,12 @@ extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* 
  * longer than the budget raises the abort flag and the frame is handed to the host (status overflow). */
 #define MW_WAVES 4
 #define MW_NCH 8                       /* chunk records (64 seeds of the ordering each) */
+#ifndef MW_RING
 #define MW_RING 64                     /* result slots */
-#define MW_TABS 16                     /* overlay tables (128 entries each): one in each wave's hands, the rest for parked results */
+#endif
+#ifndef MW_TABS
+#define MW_TABS 16                     /* overlay tables (128 entries each): one in each wave's hands, the rest for parked results (at most 31) */
+#endif
 #define MW_TAKEN 1
 #define MW_SMALL 2
 #define MW_END 3
@@ -1243,7 +1247,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_WAVES) __attribute__((amdgpu_wav
     for (int k = tid; k < nWords; k += 64 * MW_WAVES) w.gbm[k] = 0u;                  /* the HBM overlay starts, and is left, all zero */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (tid == 0) { S->totalTickets = 0x7fffffff; S->tabFree = ((1 << MW_TABS) - 1) & ~((1 << MW_WAVES) - 1); for (int k = 0; k < MW_RING; k++) S->word[k] = -8; }
+    if (tid == 0) { S->totalTickets = 0x7fffffff; S->tabFree = (int)(((1u << MW_TABS) - 1u) & ~((1u << MW_WAVES) - 1u)); for (int k = 0; k < MW_RING; k++) S->word[k] = -8; }
     __syncthreads();
     C.t00 = wall_clock64();
 

@@ -934,8 +934,9 @@ class Context:
         return out
 
     def lsd_configure(self, device_grow=True):
-        """Where lsd_extract_batch grows its regions: on the device (one wavefront per frame, default) or on the host pool."""
-        self._chk(self.L.drfe_lsd_configure(self.h, 1 if device_grow else 0), "drfe_lsd_configure")
+        """Where lsd_extract_batch grows its regions: False / 0 the host pool; True / 1 the device, kernel chosen by the size of the
+        call (default); 2 the device with one wavefront per frame; 3 with four (speculation + in-order commit)."""
+        self._chk(self.L.drfe_lsd_configure(self.h, int(device_grow)), "drfe_lsd_configure")
 
     def planes_configure_cape(self, on_device=True):
         """Where planes_cape_batch runs CAPE::process (histogram seeding, cell growing, merging, masks): device or host pool."""

@@ -355,8 +355,11 @@ int drfe_lsd_segments_host(const double* modgrad, const double* angles, const fl
 int drfe_lsd_extract_batch(drfe_ctx* ctx, const uint8_t* gray, size_t frame_stride, int w, int h, size_t stride, int nframes,
                            int max_lines, drfe_keyline* lines, uint8_t* ldesc, double* line_f, int cap, int* n_lines,
                            int* n_detected, int n_threads);
-/* 1 (default): drfe_lsd_extract_batch grows regions on the device; 0: on the host threads.  Frames whose 0.8-scaled size
- * exceeds the device path's LDS bitmap (about 1.2 M pixels) take the host path regardless. */
+/* Where drfe_lsd_extract_batch grows regions: 0 on the host threads; on the device 1 (default) with the kernel chosen by the size of
+ * the call, 2 with one wavefront per frame (the least device time per frame: what counts when calls of hundreds of frames run side by
+ * side), 3 with four wavefronts per frame (seeds speculated against a commit-only `used` map and committed in seed order: 1.6x
+ * shorter per frame, what counts when the call cannot fill the device; the default up to 256 frames per call).  Frames whose
+ * 0.8-scaled size exceeds the device path's LDS bitmap (about 1.2 M pixels) take the host path regardless.  Results are identical. */
 int drfe_lsd_configure(drfe_ctx* ctx, int device_grow);
 /* Which reading of cv::LineSegmentDetectorImpl::rect_nfa / nfa (OpenCV 3.4 imgproc/src/lsd.cpp, the detector behind reference
  * src/LSDextractor.cpp:14-17) validates the rectangles of this context's line entries.

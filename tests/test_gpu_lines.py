@@ -161,7 +161,7 @@ def _same_lines(a, b):
     assert np.array_equal(a["lineF"].view(np.uint64), b["lineF"].view(np.uint64))
 
 
-@pytest.mark.parametrize("device_grow", [True, False])
+@pytest.mark.parametrize("device_grow", [True, False, 2, 3], ids=["device_auto", "host", "one_wave_per_frame", "four_waves_per_frame"])
 def test_lsd_extract_batch_equals_single(ctx, device_grow):
     """drfe_lsd_extract_batch == per-frame calls for any thread count, with region growing on the device (k_lsd_grow: one
     wavefront per frame replays the detector's seed loop) and on the host pool."""
@@ -197,6 +197,30 @@ def test_lsd_device_grow_matches_oracle(ctx, oracle_mod, kind, seed, rect_mode):
         assert np.array_equal(a["lineF"].view(np.uint64), o["lineF"].view(np.uint64))
     for a, b in zip(batch[12:], batch[:8]):
         _same_lines(a, b)
+
+
+@pytest.mark.parametrize("grow", [2, 3], ids=["one_wave_per_frame", "four_waves_per_frame"])
+@pytest.mark.parametrize("kind,seed", [("living_room", 13), ("planar_lowtexture", 14)])
+def test_lsd_each_growth_kernel_matches_oracle(ctx, oracle_mod, kind, seed, grow):
+    """k_lsd_grow (one wavefront per frame) and k_lsd_grow_mw (four: seeds speculated, committed in seed order), each forced by
+    drfe_lsd_configure, against the CPU oracle: key lines, descriptors, line equations bit for bit, and no frame handed back."""
+    from dr_slam_amd import synth
+    frames = [f[0] for f in synth.sequence(seed, 10, cam=synth.ICL if kind == "living_room" else synth.TUM3, kind=kind)]
+    ctx.lsd_configure(grow)
+    try:
+        s0 = ctx.lsd_stats()
+        batch = ctx.lsd_extract_batch(np.stack(frames), n_threads=4)
+        s1 = ctx.lsd_stats()
+    finally:
+        ctx.lsd_configure(True)
+    assert s1["frames"] - s0["frames"] == len(frames) and s1["grow_to_host"] == s0["grow_to_host"]
+    for g, a in zip(frames, batch):
+        o = oracle_mod.extract_lines(g)
+        assert a["detected"] == o["detected"] and len(a["lines"]) == len(o["lines"])
+        for gk, ok in PAIRS:
+            assert np.array_equal(a["lines"][gk].view(np.uint32), o["lines"][ok].view(np.uint32)), gk
+        assert np.array_equal(a["desc"], o["desc"])
+        assert np.array_equal(a["lineF"].view(np.uint64), o["lineF"].view(np.uint64))
 
 
 def test_lsd_device_grow_polygons_and_odd_size(ctx, oracle_mod, rect_mode):

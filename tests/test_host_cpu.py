@@ -532,4 +532,5 @@ def test_long_kernels_keep_their_lds_budget(tmp_path):
     assert per_cu(find("k_voxel_grid") + words * 256 * 4) >= 7
     # k_lsd_grow: all dynamic - bitmap of the 0.8-scaled 640 x 480 frame + member ring + the three-sum columns (drfe_lsd_grow_lds_bytes)
     ring = int(re.search(r"#define LSD_RING (\d+)", open(os.path.join(ROOT, "dr_slam_amd", "csrc", "lsd_grow_kernels.hip")).read()).group(1))
-    assert find("k_lsd_grow") == 0 and per_cu(512 * 384 // 8 + ring * 4 + 64 * 3 * 8) >= 6
+    assert find("k_lsd_grow", True) == 0 and per_cu(512 * 384 // 8 + ring * 4 + 64 * 3 * 8) >= 6
+    assert find("k_lsd_grow_mw", True) == 0            # dynamic LDS: bitmap + control block + 16 overlay tables + 4 x (ring + columns) = 46.8 KB at 512 x 384: three workgroups per CU

@@ -19,5 +19,5 @@ for n in (1, 3):
     for t in th: t.start()
     for t in th: t.join()
     el = time.perf_counter() - t0
-    print("waves=%s: %d steps in flight: %6.0f frames/s; stats %s" % (os.environ.get("DRFE_LSD_GROW_WAVES", "4"), n, n * reps * B / el, ctxs[0].lsd_stats()), flush=True)
+    print("waves=%s: %d steps in flight: %6.0f frames/s; stats %s" % (os.environ.get("DRFE_LSD_GROW_WAVES", "auto"), n, n * reps * B / el, ctxs[0].lsd_stats()), flush=True)
     for c in ctxs: c.close()
