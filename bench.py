@@ -394,6 +394,39 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
     return B * steps / el, el / steps * 1e3, threads
 
 
+# SURVEY.md section 8(d), algorithmic bytes per 640x480 frame of the stages full_frontend adds to the headline path
+FF_ALGO_BYTES = {"orb_extract": 7225354, "window_match": 676000, "lsd_lbd": 307200 + 3145728 + 1228800, "ahc_planes": 614400 + 307200 + 245760}
+
+
+def full_frontend_roofline(frames_per_s: float, n_frames: int):
+    """HBM roofline of what bounds BASELINE config 3: the aggregate (section 8(d)'s algorithmic bytes of all four stages x the measured
+    rate, against 8 TB/s) and, per long kernel of the line and plane paths, its stage's algorithmic bytes for the frames of one launch
+    over the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summaries of one 512-frame step
+    (profiles/r05_kernel_stats_{lines,planes}_batch512.csv) - those kernels run one or four wavefronts per frame, so the fraction
+    says how far a latency chain is from a streaming pass, which is the point; lane utilisation = SQ_THREAD_CYCLES_VALU /
+    (64 x SQ_ACTIVE_INST_VALU) from profiles/r05a_long_kernels_summary.txt."""
+    import csv
+    per_frame = sum(FF_ALGO_BYTES.values())
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_frame": per_frame,
+           "achieved": per_frame * frames_per_s / 1e9, "frac": per_frame * frames_per_s / 1e9 / HBM_PEAK_GBS,
+           "limited_by": "latency chains: every frame's region growing / plane clustering / flood fill is an order-defined sequence on one or four wavefronts; "
+                         "the rate is (frames resident) / (chain latency), and residency is bounded by LDS (a frame's `used` bitmap, queues, tables)"}
+    lanes = {"k_lsd_grow_mw": 0.625, "k_lsd_grow": None, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.594, "k_voxel_grid": 0.589}
+    kern = {}
+    for path, stage in (("lines", "lsd_lbd"), ("planes", "ahc_planes")):
+        f = os.path.join(ROOT, "profiles", "r05_kernel_stats_%s_batch512.csv" % path)
+        if not os.path.exists(f):
+            continue
+        for r in csv.DictReader(open(f)):
+            name = r["Name"].split("(")[0]
+            if name in lanes and float(r["AverageNs"]) > 1e6:
+                ach = FF_ALGO_BYTES[stage] * 512 / (float(r["AverageNs"]) * 1e-9) / 1e9
+                kern[name] = {"stage": stage, "ms_per_512_frame_launch": float(r["AverageNs"]) / 1e6, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                              "valu_lane_utilisation": lanes[name], "source": "profiles/r05_kernel_stats_%s_batch512.csv" % path}
+    out["long_kernels"] = kern
+    return out
+
+
 def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 5):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
@@ -411,6 +444,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
     from dr_slam_amd.pipeline import FrontEnd
     cam = getattr(synth, cam_name)
     ncpu = sharding.host_cpus()
+    if ncpu < 3:                                      # 2.3 cores busy per GPU at the measured rate: with fewer the host, not the device, is measured
+        raise RuntimeError("full_frontend: %d host CPUs - the whole front-end of config 3 keeps 2.5 busy per GPU (planes' gates + RANSAC refit, upload threads)" % ncpu)
     base = sharding.render_sequence(3, 8, cam, "living_room", workers=1)
     order = sharding.pingpong_order(n_frames, len(base))
     gray = np.stack([base[i][0] for i in order])
@@ -519,6 +554,7 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
             "lines_frames_returned_to_the_host": {"of_frames": lsd["frames"], "region_growing": lsd["grow_to_host"], "nfa_decisions_not_certified": lsd["nfa_to_host"],
                                                   "keyline_roundings_not_certified": lsd["keylines_to_host"]},
             "stage_wall_ms_last_step": {k: round(v, 2) for k, v in lanes[0]["wall"].items()},
+            "roofline": full_frontend_roofline(total / el, n_frames),
             "planes_accepted_per_step": int(nacc[0]),
             "lines_path": "everything on the device: pixel ordering, region growing, region2rect, refine (k_lsd_order, k_lsd_grow: one wavefront per frame), rect_improve + NFA "
                           "decisions with certified comparisons (k_rect_improve), key lines + the response cut + line equations (k_lsd_keylines), LBD (k_lbd); host threads upload, launch and copy",
@@ -530,6 +566,59 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
                     "(host_cpu_ms_per_frame_by_pool is the measurement; host_cores_busy_at_8_gpus_at_this_rate = 8 x the busy cores measured here)"}
 
 
+def per_frame_latency(cam_name, frames: int = 240, discard: int = 20):
+    """BASELINE config 3 in the shape Frame::Frame has (reference src/Frame.cc:124-134): ONE frame at a time, its three extractors
+    side by side on three threads and joined - ORB + the Frame glue through drfe_frame_submit / drfe_frame_collect (device), the
+    line segment detector through drfe_lsd_extract and the AHC planes + Frame::ComputePlanes' per-plane loop through drfe_planes_ahc
+    + drfe_planes_ahc_postprocess (device image passes / block fits, the sequential cores on the calling threads: the low-latency
+    entries).  Wall time per frame from the first call to the last join, host frames in, host results out; median and p95.
+    The CPU oracle in the same shape is cpu_baseline.shapes.ii_orb_lsd_ahc_3threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dr_slam_amd import lib, sharding, synth
+    cam = getattr(synth, cam_name)
+    base = sharding.render_sequence(3, 16, cam, "living_room", workers=1)
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    cc = lib.make_camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.depth_factor, cam.w, cam.h)
+    orb, lines, planes = lib.Context(max_batch=2), lib.Context(max_batch=1), lib.Context(max_batch=1)
+    ms, parts = [], {"orb_glue": [], "lsd_lbd": [], "ahc_planes_post": []}
+
+    def timed(key, fn):
+        t = time.perf_counter()
+        r = fn()
+        parts[key].append((time.perf_counter() - t) * 1e3)
+        return r
+
+    def do_planes(d):
+        a = planes.planes_ahc(d, K4, inv)
+        return planes.planes_ahc_postprocess(d, K4, inv, a, 9.0, 0.10)["n_accepted"]
+
+    try:
+        with ThreadPoolExecutor(2) as pool:
+            for k in range(frames + discard):
+                g, d, _ = base[k % len(base)]
+                t0 = time.perf_counter()
+                fl = pool.submit(timed, "lsd_lbd", lambda: len(lines.lsd_extract(g)["lines"]))
+                fp = pool.submit(timed, "ahc_planes_post", lambda: do_planes(d))
+                t1 = time.perf_counter()
+                orb.frame_submit(k & 1, g, d, cc)
+                kps = orb.frame_collect(k & 1, stereo=True)[0]
+                parts["orb_glue"].append((time.perf_counter() - t1) * 1e3)
+                nl, na = fl.result(), fp.result()
+                ms.append((time.perf_counter() - t0) * 1e3)
+                assert len(kps) > 500 and nl > 5 and na >= 1
+    finally:
+        orb.close(); lines.close(); planes.close()
+    a = np.array(ms[discard:])
+    return {"shape": "Frame::Frame (src/Frame.cc:124-134): ORB + glue || LSD + LBD || AHC planes + per-plane post-processing, three threads joined, one frame at a time, host in / host out",
+            "frames": int(len(a)), "median_ms": float(np.median(a)), "p95_ms": float(np.percentile(a, 95)), "frames_per_s_one_sequence": float(1e3 / np.median(a)),
+            "median_ms_by_thread": {k: float(np.median(v[discard:])) for k, v in parts.items()},
+            "entries": "drfe_frame_submit / drfe_frame_collect; drfe_lsd_extract; drfe_planes_ahc + drfe_planes_ahc_postprocess",
+            "note": "the single-frame entries keep the detectors' sequential cores on the calling threads: one frame's region growing is a 45 ms chain on four "
+                    "wavefronts (75 on one) against 13 ms on one host core, its plane clustering + flood fill 48 ms against 3.4 ms - the device wins by "
+                    "holding hundreds of frames at once (full_frontend), not one.  Compare with cpu_baseline.shapes.ii_orb_lsd_ahc_3threads."}
+
+
 def launch(args) -> int:
     """`--gpus N` without a launcher around us: start N fresh rank processes (one per GPU) BEFORE this process makes
     any GPU call - the parent never initialises HIP, it only counts devices - and pass rank 0's JSON line through.
@@ -539,6 +628,13 @@ def launch(args) -> int:
     import subprocess
     import torch
     n = args.gpus
+    from dr_slam_amd import sharding
+    # every rank needs a host core of its own to drive its GPU (render its sequence, submit, collect); the whole front-end of
+    # config 3 needs 2.3 more per GPU for the planes' gates + RANSAC refit (full_frontend.host_cores_busy_at_this_rate)
+    if sharding.host_cpus() < n:
+        sys.stderr.write("bench.py --gpus %d: only %d host CPUs are available to this job - one per rank is the least the sharded mode needs "
+                         "(2.5 per GPU for the whole front-end of config 3); refusing to report a number bound by the host\n" % (n, sharding.host_cpus()))
+        return 3
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.device_count() < n:
@@ -894,6 +990,7 @@ def main():
             pipe.close()
             del gray_t, depth_t, gray_ts, depth_ts
             out["full_frontend"] = full_frontend("ICL")
+            out["per_frame_latency"] = per_frame_latency("ICL")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -126,6 +126,31 @@ def test_two_rank_gloo_sharding():
         assert seed == 10 + rank                             # one independent sequence per rank
 
 
+def test_eight_rank_gloo_sharding():
+    """BASELINE config 4's world size (eight ranks, one sequence each) over gloo on the CPU: the one initial exchange reaches every
+    rank, the report reduces MAX of time / SUM of frames over all eight, every rank draws its own sequence and intrinsics."""
+    import torch.multiprocessing as mp
+    from dr_slam_amd import sharding
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(8))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(8))
+    for rank, tab, el, n, seed in res:
+        assert tab == list(np.arange(8, dtype=np.float32))
+        assert el == 8.0 and n == 64 * sum(range(1, 9))
+        assert seed == 10 + rank
+    cams = [sharding.rank_camera(r).name for r in range(8)] if hasattr(sharding, "rank_camera") else None
+    if cams:
+        assert len(set(cams)) == 3                               # TUM1 / TUM2 / TUM3 cycling
+
+
 def test_image_bounds_host_entry_matches_oracle(oracle_mod):
     """drfe_frame_image_bounds is pure host code (Frame::ComputeImageBounds): callable without a GPU, bit-equal to
     the oracle's restatement of cv::undistortPoints on the four corners."""
