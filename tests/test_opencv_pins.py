@@ -67,3 +67,15 @@ def test_lsd_segments_equal_opencv(oracle_mod, pins, tag):
         assert np.array_equal(o["seg_width"], pins[tag + "_width"])
         assert np.allclose(o["seg_prec"], pins[tag + "_prec"], rtol=1e-15, atol=0)
         assert np.allclose(o["seg_nfa"], pins[tag + "_nfa"], rtol=1e-12, atol=1e-12)     # libm of the dumping host
+
+
+def test_lsd_reading_decided_by_opencv(oracle_mod, pins):
+    """Which of drfe_lsd_configure_rect's readings of lsd.cpp the real library implements: the segment COUNT on the line fixture alone
+    separates them (mode 0 keeps four to five times as many as modes 1 / 2).  The default (0) must be the one."""
+    if "lsd_img" not in pins:
+        pytest.skip("opencv_pins.npz predates the per-segment dump")
+    ref = pins["lsd_segments"]
+    same = [m for m in (0, 1, 2)
+            if (lambda o: len(o["segments"]) == len(ref) and np.array_equal(o["segments"].view(np.uint32), ref.view(np.uint32)))(
+                oracle_mod.extract_lines(pins["lsd_img"], max_lines=100000, trace=True, rect_mode=m))]
+    assert same == [0], "OpenCV %s matches drfe_lsd_configure_rect mode(s) %s, the default is 0" % (str(pins["cv_version"]), same)

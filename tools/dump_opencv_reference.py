@@ -62,7 +62,11 @@ def main():
     def detect(img, tag):
         """segments with their exact float32 bits plus the detector's optional outputs: width, precision and -log10(NFA) of
         every segment.  The NFA is a function of rect_nfa's (total_pts, alg_pts, p) alone, so these values say which pixels
-        the library's rect_nfa walked - the question drfe_lsd_configure_rect leaves open (integer or real-valued steps)."""
+        the library's rect_nfa walked AND how nfa() sums its first term - the two questions drfe_lsd_configure_rect leaves open:
+        integer or real-valued steps (modes 0 / 2 against 1), and `double(n) + 1` against log_gamma(n + 1) (mode 0 against 1 / 2:
+        the values differ by log_gamma(n + 1) - (n + 1) over ln 10, hundreds for any real segment, and the library's reading lets
+        four to five times as many segments through - 1397 against 298 on the committed line fixture).
+        tests/test_opencv_pins.py::test_lsd_reading_decided_by_opencv names the mode that matches."""
         segs, width, prec, nfa = lsd.detect(img)
         n = 0 if segs is None else len(segs)
         out[tag + "_img"] = img
