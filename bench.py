@@ -535,9 +535,12 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
         if dbg is not None:
             dbg(pool_ns)
     lsd = {"frames": 0, "grow_to_host": 0, "nfa_to_host": 0, "keylines_to_host": 0}
+    refit = {"frames": 0, "to_host": 0}
     for L in lanes:
         for k, v in L["fe"].ctx.lsd_stats().items():
             lsd[k] += v
+        for k, v in L["planes"].planes_refit_stats().items():
+            refit[k] += v
     for L in lanes:
         L["planes"].close(); L["cape"].close(); L["fe"].ctx.close()
     total = inflight * reps * n_frames
@@ -553,16 +556,18 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
             "host_cores_busy_at_8_gpus_at_this_rate": round(8 * cpu / el, 1),
             "lines_frames_returned_to_the_host": {"of_frames": lsd["frames"], "region_growing": lsd["grow_to_host"], "nfa_decisions_not_certified": lsd["nfa_to_host"],
                                                   "keyline_roundings_not_certified": lsd["keylines_to_host"]},
+            "planes_frames_sent_to_the_host_refit": {"of_frames": refit["frames"], "refit_not_certified_or_grid_returned": refit["to_host"]},
             "stage_wall_ms_last_step": {k: round(v, 2) for k, v in lanes[0]["wall"].items()},
             "roofline": full_frontend_roofline(total / el, n_frames),
             "planes_accepted_per_step": int(nacc[0]),
-            "lines_path": "everything on the device: pixel ordering, region growing, region2rect, refine (k_lsd_order, k_lsd_grow: one wavefront per frame), rect_improve + NFA "
+            "lines_path": "everything on the device: pixel ordering, region growing, region2rect, refine (k_lsd_order, k_lsd_grow: one wavefront per frame at this call size; k_lsd_grow_mw, four per frame, up to 256 frames per call), rect_improve + NFA "
                           "decisions with certified comparisons (k_rect_improve), key lines + the response cut + line equations (k_lsd_keylines), LBD (k_lbd); host threads upload, launch and copy",
             "planes_path": "init-block fits, graph, agglomerative clustering, flood fill, re-merge, labels, plane clouds (k_ahc_blocks, k_ahc_cluster + k_ahc_refine: one wavefront per frame) and "
-                           "pcl::VoxelGrid of every plane (k_voxel_grid) on the device; gates + RANSAC refit on host threads",
+                           "pcl::VoxelGrid of every plane (k_voxel_grid) and, round 5, the gates + RANSAC / least-squares refit of Frame::MaxPointDistanceFromPlane (k_plane_refit: one wavefront per plane) "
+                           "on the device; the pool's threads upload, launch and copy 24-byte post records",
             "note": "the device paths are latency chains (~0.12 s of region growing, ~0.075 s of plane extraction per frame on one wavefront), so steps run side by side; "
                     "what bounds the rate is LDS x time: every long kernel holds 20-38 KB of a CU's 160 KB for as long as it runs, and the sum over a frame's "
-                    "kernels of (LDS held x time held) against the device's 40 MB of LDS is the step time measured (DESIGN.md, what bounds the full front-end).  CAPE runs on the device; the host stage that remains is the planes' gates + RANSAC refit "
+                    "kernels of (LDS held x time held) against the device's 40 MB of LDS is the step time measured (DESIGN.md, what bounds the full front-end).  CAPE and, since round 5, the planes' gates + RANSAC refit run on the device: no per-frame host stage remains "
                     "(host_cpu_ms_per_frame_by_pool is the measurement; host_cores_busy_at_8_gpus_at_this_rate = 8 x the busy cores measured here)"}
 
 

@@ -208,6 +208,8 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
     c->capeStats[0] = c->capeStats[1] = 0;
     c->ahcStats[0] = c->ahcStats[1] = c->ahcStats[2] = c->ahcStats[3] = 0;
     c->planesDeviceVoxel = 1;
+    c->planesDeviceRefit = 1;
+    c->ahcRefitStats[0] = c->ahcRefitStats[1] = 0;
     c->planesDeviceAhc = 1;
     c->ahcArena = nullptr;
     c->lineWorkers = nullptr;

@@ -180,6 +180,8 @@ struct drfe_ctx {
     int lsdRectMode;          /* drfe_lsd_configure_rect: rect_nfa's reading, 0 = literal OpenCV 3.4 (default), 1 = real-valued */
     int planesDeviceAhc;      /* drfe_planes_configure_extractor: 1 = drfe_planes_ahc_post_batch runs the extractor on the device (default) */
     void* ahcArena;           /* AhcArena*: frame slots of the device extractor (planes_ahc.cpp) */
+    int planesDeviceRefit;    /* drfe_planes_configure_refit: 1 = gates + RANSAC refit on the device behind the device voxel grids (default) */
+    long long ahcRefitStats[2];
     int planesDeviceVoxel;    /* drfe_planes_configure: where drfe_planes_ahc_post_batch runs the voxel grids (default 1: device, behind the device extractor) */
     void* frameLanes;         /* std::vector<FrameLane>*: per-slot staging of drfe_frame_submit / drfe_frame_collect (capi.cpp) */
 

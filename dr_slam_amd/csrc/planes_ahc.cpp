@@ -769,6 +769,9 @@ struct AhcArena {
     float* d_vpts = nullptr; unsigned long long* d_vrecs = nullptr; unsigned long long* d_vtmp = nullptr; uint32_t* d_vposL = nullptr;
     uint32_t* d_vposR = nullptr; float* d_vout = nullptr; int2* d_jobs = nullptr; int* d_vcounts = nullptr; int* d_vlist = nullptr;
     int2* h_jobs = nullptr; int* h_vcounts = nullptr;
+    /* gates + RANSAC refit behind the voxel grids (refit_kernels.hip): per plane slot the post record and its status */
+    drfe_plane_post* d_post = nullptr; int* d_postStatus = nullptr; uint32_t* d_mtState = nullptr;
+    drfe_plane_post* h_post = nullptr; int* h_postStatus = nullptr;
     /* offsets of the outputs inside a slot */
     size_t offPlanes = 0, offSeg = 0, offMemberOff = 0, offMemberIdx = 0, offOut = 0;
 };
@@ -776,9 +779,10 @@ struct AhcArena {
 static void arena_free(AhcArena*& a)
 {
     if (!a) return;
-    void* d[] = {a->d_depth, a->d_blocks, a->d_scratch, a->d_frames, a->d_vpts, a->d_vrecs, a->d_vtmp, a->d_vposL, a->d_vposR, a->d_vout, a->d_jobs, a->d_vcounts, a->d_vlist};
+    void* d[] = {a->d_depth, a->d_blocks, a->d_scratch, a->d_frames, a->d_vpts, a->d_vrecs, a->d_vtmp, a->d_vposL, a->d_vposR, a->d_vout, a->d_jobs, a->d_vcounts, a->d_vlist,
+                 a->d_post, a->d_postStatus, a->d_mtState};
     for (void* p : d) if (p) (void)hipFree(p);
-    void* hp[] = {a->h_frames, a->h_out, a->h_planes, a->h_memberOff, a->h_depth, a->h_jobs, a->h_vcounts};
+    void* hp[] = {a->h_frames, a->h_out, a->h_planes, a->h_memberOff, a->h_depth, a->h_jobs, a->h_vcounts, a->h_post, a->h_postStatus};
     for (void* p : hp) if (p) (void)hipHostFree(p);
     delete a;
     a = nullptr;
@@ -845,6 +849,18 @@ static int ensure_arena(drfe_ctx* c, int w, int h, int frames, const float* K4, 
         HIPCHK(c, hipMalloc((void**)&a->d_vlist, sizeof(int) * (P.planeCap * F + 2 * 16)));      /* job order of each chunk (<= 16 chunks) */
         HIPCHK(c, hipHostMalloc((void**)&a->h_jobs, sizeof(int2) * P.planeCap * F, hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void**)&a->h_vcounts, sizeof(int) * P.planeCap * F, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&a->d_post, sizeof(drfe_plane_post) * P.planeCap * F));
+        HIPCHK(c, hipMalloc((void**)&a->d_postStatus, sizeof(int) * P.planeCap * F));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_post, sizeof(drfe_plane_post) * P.planeCap * F, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&a->h_postStatus, sizeof(int) * P.planeCap * F, hipHostMallocDefault));
+        {
+            /* std::mt19937(12345): the state after seeding (its first draw twists it) */
+            uint32_t mt[624];
+            mt[0] = 12345u;
+            for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+            HIPCHK(c, hipMalloc((void**)&a->d_mtState, sizeof(mt)));
+            HIPCHK(c, hipMemcpy(a->d_mtState, mt, sizeof(mt), hipMemcpyHostToDevice));
+        }
         for (size_t f = 0; f < F; f++) {
             uint8_t* s = a->d_scratch + a->slotBytes * f;
             AhcDevFrame& g = a->h_frames[f];
@@ -876,6 +892,8 @@ struct AhcBatchJob {
     int32_t* memberOffsets; int32_t* memberIdx;      /* drfe_planes_ahc_batch (post == null): the member lists go to the caller */
     int chunk, nChunks;
     bool voxDevice;          /* k_voxel_grid ran behind the extractor: the workers fetch centroids instead of member lists */
+    bool refitDevice;        /* k_plane_refit ran behind the voxel grids: the workers fetch 24-byte post records instead of centroids */
+    std::atomic<int> refitFallbacks{0};
     std::vector<hipStream_t> chunkStream; std::vector<hipEvent_t> chunkDone; std::vector<int> chunkState;   /* 1 = on the device, 3 = a worker fetches its results, 2 = released */
     std::mutex mu; std::condition_variable cv; std::deque<int> finishQ; int pending = 0;
     int firstRc = DRFE_OK; std::string firstErr; bool abort = false;
@@ -938,6 +956,8 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
                                      hipMemcpyDeviceToHost, st);
             if (e == hipSuccess && J.voxDevice) e = hipMemcpyAsync(A->h_jobs + pc * f0, A->d_jobs + pc * f0, sizeof(int2) * pc * nf, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess && J.voxDevice) e = hipMemcpyAsync(A->h_vcounts + pc * f0, A->d_vcounts + pc * f0, sizeof(int) * pc * nf, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && J.refitDevice) e = hipMemcpyAsync(A->h_post + pc * f0, A->d_post + pc * f0, sizeof(drfe_plane_post) * pc * nf, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && J.refitDevice) e = hipMemcpyAsync(A->h_postStatus + pc * f0, A->d_postStatus + pc * f0, sizeof(int) * pc * nf, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = drfe_pool_sync(st, ev);
             if (e != hipSuccess) { ahc_batch_fail(J, DRFE_ERR_HIP, std::string("planes batch: results of a chunk: ") + hipGetErrorString(e)); (void)hipEventDestroy(ev); return; }
             std::lock_guard<std::mutex> lk(J.mu);
@@ -969,7 +989,28 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             const int* vc = A->h_vcounts + (size_t)A->P.planeCap * f;
             /* planes the device handed back (vc < 0: the sort's heap-sort branch, a grid beyond int32): their gathered clouds come
              * back instead and this thread runs their grids */
-            const bool coarseReady = J.voxDevice;
+            /* gates + refit ran on the device too (k_plane_refit): the frame's post records are here already; only a plane whose
+             * decision the device could not certify, or whose grid came back, sends the frame down the centroid path below */
+            bool postReady = false;
+            if (J.refitDevice) {
+                const int* ps = A->h_postStatus + (size_t)A->P.planeCap * f;
+                postReady = true;
+                for (int i = 0; i < nP; i++) if (ps[i] != 0) postReady = false;
+                if (postReady) {
+                    const drfe_plane_post* hp = A->h_post + (size_t)A->P.planeCap * f;
+                    int nAcc = 0, fail = 0;
+                    for (int i = 0; i < nP; i++) {
+                        J.post[(size_t)f * J.cap + i] = hp[i];
+                        nAcc += hp[i].accepted;
+                        const drfe_plane& e = pl[i];
+                        const float d = (float)-(e.normal[0] * e.center[0] + e.normal[1] * e.center[1] + e.normal[2] * e.center[2]);
+                        if (d > J.maxPointDist || hp[i].n_voxels < 100) fail++;
+                    }
+                    J.nAccepted[f] = nAcc;
+                    if (J.planeNum) J.planeNum[f] = nP - fail;
+                } else J.refitFallbacks++;
+            }
+            const bool coarseReady = J.voxDevice && !postReady;
             size_t nCoarse = 0;
             int handedBack = 0;
             for (int i = 0; i < nP && coarseReady; i++) { vcl[i] = vc[i]; if (vc[i] < 0) handedBack++; nCoarse += (size_t)(vc[i] < 0 ? jobs[i].y : vc[i]); }
@@ -1003,10 +1044,10 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
                     if (cnt > 0) e = hipMemcpyAsync(l->h_coarse + 3 * at, A->d_vpts + 3 * (size_t)jobs[i].x, cnt * 12, hipMemcpyDeviceToHost, l->stream);
                     at += cnt;
                 }
-            } else if (off[nP] > 0 && (J.post || J.memberIdx))
+            } else if (!postReady && off[nP] > 0 && (J.post || J.memberIdx))
                 e = hipMemcpyAsync(idx.data(), slot + A->offMemberIdx, sizeof(int) * (size_t)off[nP], hipMemcpyDeviceToHost, l->stream);
             if (e == hipSuccess && J.seg) e = hipMemcpyAsync(J.seg + f * px, slot + A->offSeg, px, hipMemcpyDeviceToHost, l->stream);
-            if (e == hipSuccess && (nCoarse > 0 || (!coarseReady && (J.post || J.memberIdx)) || J.seg)) e = drfe_pool_sync(l->stream, ev);
+            if (e == hipSuccess && (nCoarse > 0 || (!coarseReady && !postReady && (J.post || J.memberIdx)) || J.seg)) e = drfe_pool_sync(l->stream, ev);
             if (e != hipSuccess) { l->err = std::string("planes batch: results of a frame: ") + hipGetErrorString(e); rc = DRFE_ERR_HIP; }
             const long long tR = plane_thread_cpu_ns();
             g_planeCpuNs[1] += tR - tD;
@@ -1028,6 +1069,7 @@ static void ahc_batch_worker(AhcBatchJob& J, PlaneLane* l)
             }
             const long long tP = plane_thread_cpu_ns();
             g_planeCpuNs[2] += tP - tR;
+            if (rc == DRFE_OK && postReady) viaCoarse = true;
             if (rc == DRFE_OK && coarseReady) {
                 struct AccP { long long t; ~AccP() { g_planeCpuNs[3] += plane_thread_cpu_ns() - t; } } accP{tP};
                 rc = drfe_ahc_post_from_coarse(&l->err, pl, nP, cptr.data(), vcl.data(), J.maxPointDist, J.distThreshold, J.post + (size_t)f * J.cap, nullptr, voff.data(),
@@ -1073,6 +1115,7 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
     J.nChunks = (nframes + J.chunk - 1) / J.chunk;
     J.pending = nframes;
     J.voxDevice = post != nullptr && c->planesDeviceVoxel != 0 && !std::getenv("DRFE_VOXEL_HOST");
+    J.refitDevice = J.voxDevice && c->planesDeviceRefit != 0 && !std::getenv("DRFE_REFIT_HOST");
     J.chunkStream.resize(J.nChunks); J.chunkDone.resize(J.nChunks); J.chunkState.assign(J.nChunks, 0);
     int prLow = 0, prHigh = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
@@ -1109,6 +1152,9 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
             const size_t pc = (size_t)A->P.planeCap;
             e = drfe_launch_voxel_grid(A->d_vpts, A->d_jobs + pc * f0, (int)(pc * nf), A->d_vlist + pc * f0 + 2 * (size_t)ch, A->d_vrecs, A->d_vtmp, A->d_vposL, A->d_vposR, A->d_vout, A->d_vcounts + pc * f0,
                                        0.05f, st);
+            if (e == hipSuccess && J.refitDevice)
+                e = drfe_launch_plane_refit(A->d_frames + f0, A->d_jobs + pc * f0, A->d_vcounts + pc * f0, A->d_vout, A->d_mtState, (int)(pc * nf), (int)pc, max_point_dist,
+                                            dist_threshold, std::log(1.0 - 0.99), A->d_post + pc * f0, A->d_postStatus + pc * f0, st);
             if (tr) (void)hipEventRecord(stageEv[4], st);
         }
         /* no download behind the kernels: a copy queued on a DMA ring waits there for its kernel and holds up the copies of every
@@ -1156,8 +1202,8 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         std::fprintf(stderr, "drfe_planes_ahc_post_batch workers, CPU ms per frame: chunk fetch %.3f, frame download + wait %.3f, grids redone on the host %.3f, gates + refit %.3f\n",
                      g_planeCpuNs[0].exchange(0) / 1e6 / nframes, g_planeCpuNs[1].exchange(0) / 1e6 / nframes, g_planeCpuNs[2].exchange(0) / 1e6 / nframes, g_planeCpuNs[3].exchange(0) / 1e6 / nframes);
     if (std::getenv("DRFE_TRACE_PLANES"))
-        std::fprintf(stderr, "drfe_planes_ahc_post_batch (device extractor): %d frames, %d chunks, %d frames redone on the host; voxel grids on the %s (%d planes' grids redone on the host)\n",
-                     nframes, J.nChunks, J.fallbacks.load(), J.voxDevice ? "device" : "host", J.voxFallbacks.load());
+        std::fprintf(stderr, "drfe_planes_ahc_post_batch (device extractor): %d frames, %d chunks, %d frames redone on the host; voxel grids on the %s (%d planes' grids redone on the host); gates + refit on the %s (%d frames sent to the host's refit)\n",
+                     nframes, J.nChunks, J.fallbacks.load(), J.voxDevice ? "device" : "host", J.voxFallbacks.load(), J.refitDevice ? "device" : "host", J.refitFallbacks.load());
     if (launchRc != DRFE_OK) return launchRc;
     if (J.firstRc != DRFE_OK) { c->err = J.firstErr; return J.firstRc; }
     c->ahcStats[0] += nframes; c->ahcStats[1] += J.fallbacks.load();
@@ -1166,6 +1212,7 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         for (int f = 0; f < nframes; f++) if (A->h_out[4 * (size_t)f + 1] == 0 && n_planes[f] <= cap) grids += n_planes[f];
         c->ahcStats[2] += grids; c->ahcStats[3] += J.voxFallbacks.load();
     }
+    if (J.refitDevice) { c->ahcRefitStats[0] += nframes - J.fallbacks.load(); c->ahcRefitStats[1] += J.refitFallbacks.load(); }
     return DRFE_OK;
 }
 
@@ -1194,6 +1241,24 @@ int drfe_planes_configure(drfe_ctx* c, int device_voxel_grid)
 
 /* 1 (default): drfe_planes_ahc_post_batch runs PEAC's extractor (graph, clustering, flood fill, re-merge, labels) on the device,
  * one wavefront per frame (ahc_frame_kernels.hip); 0: on the pool's host threads.  Results are identical. */
+/* 1 (default): gates + Frame::MaxPointDistanceFromPlane (RANSAC + least-squares refit) of drfe_planes_ahc_post_batch on the device
+ * behind the device voxel grids (refit_kernels.hip, one wavefront per plane); 0: on the pool's host threads.  Results are identical. */
+int drfe_planes_configure_refit(drfe_ctx* c, int on_device)
+{
+    if (!c || on_device < 0 || on_device > 1) { if (c) c->err = "planes_configure_refit: invalid argument"; return DRFE_ERR_INVALID; }
+    c->planesDeviceRefit = on_device;
+    return DRFE_OK;
+}
+
+/* out2[0] = frames whose gates + refit ran on the device since drfe_create, out2[1] = of those, sent to the host's refit (a decision
+ * that could not be certified, a voxel grid that came back) */
+int drfe_planes_refit_stats(drfe_ctx* c, long long* out2)
+{
+    if (!c || !out2) return DRFE_ERR_INVALID;
+    out2[0] = c->ahcRefitStats[0]; out2[1] = c->ahcRefitStats[1];
+    return DRFE_OK;
+}
+
 int drfe_planes_configure_extractor(drfe_ctx* c, int on_device)
 {
     if (!c || on_device < 0 || on_device > 1) { if (c) c->err = "planes_configure_extractor: invalid argument"; return DRFE_ERR_INVALID; }

@@ -27,6 +27,14 @@ void drfe_post_free(drfe_ctx* c);
  * (-1: grid overflows int32, PCL keeps the input cloud; -2: the sort needs the heap-sort branch: run the job on the host) */
 hipError_t drfe_launch_voxel_grid(const float* d_pts, const int2* d_jobs, int njobs, int* d_list, unsigned long long* d_recs, unsigned long long* d_tmp,
                                   uint32_t* d_posL, uint32_t* d_posR, float* d_out, int* d_counts, float leafSize, hipStream_t s);
+/* Gates + Frame::MaxPointDistanceFromPlane (RANSAC + least-squares refit) of njobs planes on the centroids k_voxel_grid left
+ * (refit_kernels.hip): job j = plane j % planeCap of frame j / planeCap of the extractor's frame table; d_post[j] / d_status[j]
+ * (0 final, 1 not certified: refit on the host, 2 the voxel grid came back: grid + refit on the host, -1 no such plane).
+ * d_mtState: std::mt19937(12345)'s 624 state words after seeding; logP = log(1 - 0.99) by the host's libm. */
+struct AhcDevFrame;
+hipError_t drfe_launch_plane_refit(const AhcDevFrame* d_frames, const int2* d_jobs, const int* d_vcounts, const float* d_vout, const uint32_t* d_mtState,
+                                   int njobs, int planeCap, float maxPointDist, double distThreshold, double logP, drfe_plane_post* d_post, int* d_status,
+                                   hipStream_t s);
 /* a lane's device voxel grid (planes_post.cpp): buffers + stream; NULL = the host voxel grid */
 struct VoxelDevice;
 VoxelDevice* drfe_voxel_device_create(int device, std::string* err);

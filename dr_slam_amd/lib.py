@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_debug_device_order_sort_depth", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor", "drfe_planes_ahc_stats", "drfe_frame_load", "drfe_bow_transform_slot",
+    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_debug_device_order_sort_depth", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor", "drfe_planes_ahc_stats", "drfe_planes_configure_refit", "drfe_planes_refit_stats", "drfe_frame_load", "drfe_bow_transform_slot",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -214,6 +214,8 @@ def load() -> C.CDLL:
     L.drfe_planes_configure_cape.argtypes = [vp, i32]
     L.drfe_planes_cape_stats.argtypes = [vp, vp]
     L.drfe_planes_ahc_stats.argtypes = [vp, vp]
+    L.drfe_planes_configure_refit.argtypes = [vp, i32]
+    L.drfe_planes_refit_stats.argtypes = [vp, vp]
     L.drfe_frame_load.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp]
     L.drfe_bow_transform_slot.argtypes = [vp, i32, i32, vp]
     L.drfe_lsd_configure_nfa.argtypes = [vp, i32]
@@ -948,6 +950,15 @@ class Context:
         out = np.zeros(4, np.int64)
         self._chk(self.L.drfe_planes_ahc_stats(self.h, _p(out)), "drfe_planes_ahc_stats")
         return dict(frames=int(out[0]), to_host=int(out[1]), voxel_grids=int(out[2]), voxel_grids_to_host=int(out[3]))
+
+    def planes_configure_refit(self, on_device=True):
+        """Where planes_ahc_post_batch runs gates + RANSAC refit: the device behind the device voxel grids (default) or the host pool."""
+        self._chk(self.L.drfe_planes_configure_refit(self.h, 1 if on_device else 0), "drfe_planes_configure_refit")
+
+    def planes_refit_stats(self):
+        out = np.zeros(2, np.int64)
+        self._chk(self.L.drfe_planes_refit_stats(self.h, _p(out)), "drfe_planes_refit_stats")
+        return dict(frames=int(out[0]), to_host=int(out[1]))
 
     def planes_cape_stats(self):
         out = np.zeros(2, np.int64)

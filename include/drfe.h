@@ -725,6 +725,14 @@ int drfe_planes_ahc_post_batch(drfe_ctx* ctx, const uint16_t* depth, size_t fram
  * host-extractor mode too (one launch per frame from each pool thread).  0: always on the pool's host threads.  Results are
  * identical (tests/test_gpu_post.py). */
 int drfe_planes_configure(drfe_ctx* ctx, int device_voxel_grid);
+/* Where drfe_planes_ahc_post_batch runs the gates and Frame::MaxPointDistanceFromPlane (src/Frame.cc:1003-1011, 1222-1307: RANSAC with
+ * pcl's mt19937 sample sequence, adaptive iteration bound, least-squares refit, sign) of every plane: 1 (default) on the device behind
+ * the device voxel grids, one wavefront per plane (refit_kernels.hip) - the pool's threads then receive 24-byte post records instead of
+ * voxel clouds; 0 on the pool's host threads.  A plane whose libm-dependent roundings the device cannot certify sends its frame to the
+ * host's refit (drfe_planes_refit_stats counts them).  Results are identical (tests/test_gpu_post.py). */
+int drfe_planes_configure_refit(drfe_ctx* ctx, int on_device);
+/* out2[0] = frames whose gates + refit ran on the device since drfe_create, out2[1] = of those, sent to the host's refit */
+int drfe_planes_refit_stats(drfe_ctx* ctx, long long* out2);
 /* Where drfe_planes_ahc_post_batch runs PEAC's extractor after the init-block fits (graph, agglomerative clustering, block
  * membership, flood fill, re-merge, labels and member lists): 1 (default) on the device, one wavefront per frame executing the
  * reference's sequence (ahc_frame_kernels.hip), the batch's frames side by side; 0 on the pool's host threads (the path of

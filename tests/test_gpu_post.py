@@ -231,6 +231,45 @@ def test_ahc_post_batch_equals_single_frame_calls(oracle_mod, camname, kind, see
         c.close()
 
 
+@pytest.mark.parametrize("camname,kind,seed", [("TUM3", "room_boxes", 12), ("ICL", "living_room", 13), ("TUM3", "corridor", 15)])
+def test_device_refit_equals_host_refit(oracle_mod, camname, kind, seed):
+    """Gates + Frame::MaxPointDistanceFromPlane on the device (k_plane_refit: one wavefront per plane, pcl's mt19937 sample sequence,
+    adaptive iteration bound, covariance sums in inlier order, pcl::eigen33) against the host's refit_plane and against the oracle:
+    accepted flags, voxel counts and every bit of the refitted coefficients, for three thresholds and two distance limits."""
+    from dr_slam_amd import lib, synth
+    O = oracle_mod
+    cam = getattr(synth, camname)
+    frames = list(synth.sequence(seed, 6, cam=cam, kind=kind))
+    depth = np.stack([f[1] for f in frames])
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    c = lib.Context(max_batch=1)
+    try:
+        accepted = 0
+        for maxd, th in ((9.0, 0.10), (9.0, 0.05), (2.5, 0.03)):
+            c.planes_configure_refit(False)
+            ref = c.planes_ahc_post_batch(depth, K4, inv, maxd, th, n_threads=2)
+            c.planes_configure_refit(True)
+            s0 = c.planes_refit_stats()
+            got = c.planes_ahc_post_batch(depth, K4, inv, maxd, th, n_threads=2)
+            s1 = c.planes_refit_stats()
+            for a, b in zip(ref, got):
+                assert a.tobytes() == b.tobytes()
+            assert s1["frames"] - s0["frames"] == len(frames) and s1["to_host"] - s0["to_host"] <= 1
+            accepted += int(got[3].sum())
+            planes, n, post, na, pn = got
+            for f in (0, len(frames) - 1):
+                oa = O.ahc_planes(depth[f], K4, inv)
+                o2, opn = O.ahc_post_planes(depth[f], K4, inv, oa, maxd, th)
+                assert pn[f] == opn and na[f] == sum(1 for r in o2 if r["accepted"])
+                for k, rec in enumerate(o2):
+                    assert bool(post[f, k]["accepted"]) == rec["accepted"] and post[f, k]["n_voxels"] == len(rec["voxels"])
+                    assert np.array_equal(post[f, k]["coef"].view(np.uint32), rec["coef"].view(np.uint32))
+        assert accepted >= 10
+    finally:
+        c.close()
+
+
 def test_ahc_post_batch_device_edge_cases():
     """The device extractor + device voxel grids on inputs at the edges of what the kernels assume: no depth at all (no block is
     valid: empty queue, no seeds), one fronto-parallel wall filling the image (a single plane of ~3000 blocks: the longest

@@ -63,7 +63,8 @@ def main():
         total += len(frames)
         print(f"{kind:18s} {len(frames)} frames against the oracle: {int(n.sum())} AHC planes, {int(cn.sum())} CAPE planes, {sum(len(x['lines']) for x in lines)} key lines", flush=True)
     print(f"{total} frames, mismatches {bad}, {time.time() - t0:.0f} s")
-    print(f"frames the device handed back to the host: lines {ctx.lsd_stats()}, CAPE {ctx.planes_cape_stats()}")
+    print(f"frames the device handed back to the host: lines {ctx.lsd_stats()}, CAPE {ctx.planes_cape_stats()}, AHC extractor / voxel grids {ctx.planes_ahc_stats()}, "
+          f"gates + refit {ctx.planes_refit_stats()}")
     ctx.close()
     return 1 if any(bad.values()) else 0
 
