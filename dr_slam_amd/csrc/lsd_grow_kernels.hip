@@ -1184,9 +1184,13 @@ __device__ __forceinline__ bool mw_scan_chunk(MwCtx& C, int c)
     int base = 0;
     if (c > 0) { const MwChunk& P = S->ch[(c - 1) & (MW_NCH - 1)]; base = uni_i32(P.base) + __popcll(uni_u64(P.grow)) + 1; }
     const int last = (inv != 0 || (c + 1) * 64 >= w.F.nOrder) ? 1 : 0;
+    /* a wave that is looking for its ticket's chunk may be reading this record as the (long committed) chunk c - MW_NCH: the index goes
+     * invalid first and valid last, and the reader checks it on both sides of its reads */
+    mw_st(&R.idx, -1, lane);
     R.key[lane] = key;
-    if (lane == 0) { R.cand = mc; R.grow = mg; R.base = base; R.last = last; R.idx = c; }
+    if (lane == 0) { R.cand = mc; R.grow = mg; R.base = base; R.last = last; }
     wg_fence();
+    mw_st(&R.idx, c, lane);
     if (last) mw_st(&S->totalTickets, base + __popcll(mg) + 1, lane);
     return true;
 }
@@ -1268,13 +1272,19 @@ extern "C" __global__ __launch_bounds__(64 * MW_WAVES) __attribute__((amdgpu_wav
         for (;;) {
             const int sc = mw_ld(&S->scanned);
             if (myChunk < sc) {
-                const MwChunk& R = S->ch[myChunk & (MW_NCH - 1)];
-                if (uni_i32(R.idx) != myChunk) { myChunk++; continue; }        /* committed to its end long ago and its record reused: the ticket lies further on */
-                const int base = uni_i32(R.base), cnt = __popcll(uni_u64(R.grow));
-                if (ticket > base + cnt) { if (uni_i32(R.last)) { stop = true; break; } myChunk++; continue; }
+                MwChunk& R = S->ch[myChunk & (MW_NCH - 1)];
+                const int idx1 = mw_ld(&R.idx);
+                const int base = uni_i32(R.base), isLast = uni_i32(R.last);
+                const unsigned long long grow = uni_u64(R.grow);
+                wg_fence();
+                const int idx2 = mw_ld(&R.idx);
+                /* not this chunk (any more): it was committed to its end long ago and its record reused - the ticket lies further on */
+                if (idx1 != myChunk || idx2 != myChunk) { myChunk++; continue; }
+                const int cnt = __popcll(grow);
+                if (ticket > base + cnt) { if (isLast) { stop = true; break; } myChunk++; continue; }
                 if (ticket - mw_ldr(&S->commitNext) < MW_RING) {
                     f = 64;
-                    if (ticket < base + cnt) { unsigned long long g = uni_u64(R.grow); for (int k = ticket - base; k > 0; k--) g &= g - 1; f = __builtin_ctzll(g); }
+                    if (ticket < base + cnt) { unsigned long long g = grow; for (int k = ticket - base; k > 0; k--) g &= g - 1; f = __builtin_ctzll(g); }
                     break;
                 }
             } else if (sc - 1 >= 0 && uni_i32(S->ch[(sc - 1) & (MW_NCH - 1)].last)) { stop = true; break; }
