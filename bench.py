@@ -920,8 +920,8 @@ def main():
                  "match": "k_window_candidates"}[roof_stage]
         try:
             # the newest committed counter passes of this configuration and batch size
-            cands = ["r04_pmc_traffic_c5_b%d.json", "r02_pmc_traffic_c5_b%d.json"] if config == 5 else \
-                    ["r04_pmc_traffic_b%d.json", "r03_pmc_traffic_b%d.json", "r02_pmc_traffic_b%d.json"]
+            cands = ["r05_pmc_traffic_c5_b%d.json", "r04_pmc_traffic_c5_b%d.json", "r02_pmc_traffic_c5_b%d.json"] if config == 5 else \
+                    ["r05_pmc_traffic_b%d.json", "r04_pmc_traffic_b%d.json", "r03_pmc_traffic_b%d.json", "r02_pmc_traffic_b%d.json"]
             pmc_name = next((c % B for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c % B))), cands[-1] % B)
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":

@@ -20,7 +20,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 cost = {}
-for ln in open(os.path.join(ROOT, "profiles", f"{tag}_valu_issue.txt")):
+issue = os.path.join(ROOT, "profiles", f"{tag}_valu_issue.txt")
+if not os.path.exists(issue):              # the issue costs are the hardware's: a round that did not re-measure them prices with the newest table
+    import glob
+    issue = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.txt")))[-1]
+for ln in open(issue):
     f = ln.split()
     if len(f) >= 6 and f[0].startswith("v_") and f[1] == "8":
         cost[f[0]] = float(f[4])
