@@ -222,7 +222,7 @@ def config5_aux(ctx, base, cam, n: int = 6):
     out["ahc_post_batch"] = {"frames": nb, "ms_per_frame": el * 1e3 / nb, "frames_per_s": nb / el, "planes_per_frame": float(nn.mean()),
                              "accepted_per_frame": float(na.mean()), "frames_redone_on_host": s1["to_host"] - s0["to_host"],
                              "voxel_grids_redone_on_host": s1["voxel_grids_to_host"] - s0["voxel_grids_to_host"],
-                             "note": "host frames uploaded inside the call; extractor (k_ahc_cluster_big / k_ahc_refine_big, one wavefront per frame) + voxel grids on the device, gates + refit on the pool"}
+                             "note": "host frames uploaded inside the call; extractor (k_ahc_cluster_big / k_ahc_refine_big, one wavefront per frame) + voxel grids + gates and RANSAC refit (k_plane_refit) on the device; the pool uploads, launches and copies the post records"}
     return out
 
 
