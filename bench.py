@@ -404,14 +404,14 @@ def full_frontend_roofline(frames_per_s: float, n_frames: int):
     over the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summaries of one 512-frame step
     (profiles/r05_kernel_stats_{lines,planes}_batch512.csv) - those kernels run one or four wavefronts per frame, so the fraction
     says how far a latency chain is from a streaming pass, which is the point; lane utilisation = SQ_THREAD_CYCLES_VALU /
-    (64 x SQ_ACTIVE_INST_VALU) from profiles/r05a_long_kernels_summary.txt."""
+    (64 x SQ_ACTIVE_INST_VALU) from profiles/r05_long_kernels_summary.txt (k_lsd_grow_mw: r05a_long_kernels_summary.txt, collected with that kernel forced)."""
     import csv
     per_frame = sum(FF_ALGO_BYTES.values())
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_frame": per_frame,
            "achieved": per_frame * frames_per_s / 1e9, "frac": per_frame * frames_per_s / 1e9 / HBM_PEAK_GBS,
            "limited_by": "latency chains: every frame's region growing / plane clustering / flood fill is an order-defined sequence on one or four wavefronts; "
                          "the rate is (frames resident) / (chain latency), and residency is bounded by LDS (a frame's `used` bitmap, queues, tables)"}
-    lanes = {"k_lsd_grow_mw": 0.625, "k_lsd_grow": None, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.594, "k_voxel_grid": 0.589}
+    lanes = {"k_lsd_grow_mw": 0.625, "k_lsd_grow": 0.746, "k_plane_refit": 0.331, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.594, "k_voxel_grid": 0.589}
     kern = {}
     for path, stage in (("lines", "lsd_lbd"), ("planes", "ahc_planes")):
         f = os.path.join(ROOT, "profiles", "r05_kernel_stats_%s_batch512.csv" % path)
