@@ -14,7 +14,12 @@
 #define DRFE_INTERNAL_H
 
 #include <hip/hip_runtime.h>
+#ifndef DRFE_NO_ROCTX
 #include <roctracer/roctx.h>
+#else                                   /* a build host without the roctracer headers: make DEFS=-DDRFE_NO_ROCTX ROCTX_LIB= ; the stage ranges become no-ops */
+static inline int roctxRangePushA(const char*) { return 0; }
+static inline int roctxRangePop() { return 0; }
+#endif
 #include <stdint.h>
 #include <time.h>
 #include <string>
