@@ -1000,7 +1000,12 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
 #endif
 }
 
-extern "C" __global__ __launch_bounds__(64) void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+#ifdef AHC_REFINE_WAVES_PER_EU         /* experiment builds: cap the allocation (3 -> 168 VGPRs, 19 spilled) */
+#define AHC_REFINE_OCC __attribute__((amdgpu_waves_per_eu(AHC_REFINE_WAVES_PER_EU, AHC_REFINE_WAVES_PER_EU)))
+#else
+#define AHC_REFINE_OCC
+#endif
+extern "C" __global__ __launch_bounds__(64) AHC_REFINE_OCC void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
 {
     ahc_refine_frame<AHCD_HEAP_SMALL, AHCD_LIST_SMALL>(frames, P);
 }

@@ -668,7 +668,12 @@ __device__ __forceinline__ bool refine(Wave& w, int& n, double& regAngle, double
 
 } // namespace
 
-extern "C" __global__ __launch_bounds__(64) void k_lsd_grow(const LsdGrowFrame* __restrict__ frames, int W, int H, double prec, double p,
+#ifdef LSD_GROW_WAVES_PER_EU           /* experiment builds: cap the allocation (3 -> 168 VGPRs, 14 spilled) */
+#define LSD_GROW_OCC __attribute__((amdgpu_waves_per_eu(LSD_GROW_WAVES_PER_EU, LSD_GROW_WAVES_PER_EU)))
+#else
+#define LSD_GROW_OCC
+#endif
+extern "C" __global__ __launch_bounds__(64) LSD_GROW_OCC void k_lsd_grow(const LsdGrowFrame* __restrict__ frames, int W, int H, double prec, double p,
                                                             int minReg, double densityTh, int rectCap, float tLo, float tHi)
 {
     extern __shared__ uint32_t lds[];
