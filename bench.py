@@ -211,18 +211,21 @@ def config5_aux(ctx, base, cam, n: int = 6):
     npa = [len(ctx.planes_ahc(d, K4, inv)["planes"]) for d in d16]
     out["ahc_ms"] = (time.perf_counter() - t0) * 1e3 / n
     out["ahc_planes_per_frame"] = float(np.mean(npa))
-    nb = 32
-    db = np.stack([base[i % len(base)][1] for i in range(nb)])
-    ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)                       # Realsense.yaml:76-79; first call allocates the frame slots
-    s0 = ctx.planes_ahc_stats()
-    t0 = time.perf_counter()
-    _, nn, _, na, _ = ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)
-    el = time.perf_counter() - t0
-    s1 = ctx.planes_ahc_stats()
-    out["ahc_post_batch"] = {"frames": nb, "ms_per_frame": el * 1e3 / nb, "frames_per_s": nb / el, "planes_per_frame": float(nn.mean()),
-                             "accepted_per_frame": float(na.mean()), "frames_redone_on_host": s1["to_host"] - s0["to_host"],
-                             "voxel_grids_redone_on_host": s1["voxel_grids_to_host"] - s0["voxel_grids_to_host"],
-                             "note": "host frames uploaded inside the call; extractor (k_ahc_cluster_big / k_ahc_refine_big, one wavefront per frame) + voxel grids + gates and RANSAC refit (k_plane_refit) on the device; the pool uploads, launches and copies the post records"}
+    res = {}
+    for nb in (32, 128):        # a frame is a ~0.4 s chain on one wavefront at this size (12 288 blocks): the rate is frames per call over that latency
+        db = np.stack([base[i % len(base)][1] for i in range(nb)])
+        ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)                   # Realsense.yaml:76-79; the first call of a size allocates the frame slots
+        s0 = ctx.planes_ahc_stats()
+        t0 = time.perf_counter()
+        _, nn, _, na, _ = ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)
+        el = time.perf_counter() - t0
+        s1 = ctx.planes_ahc_stats()
+        res[nb] = {"frames": nb, "ms_per_frame": el * 1e3 / nb, "frames_per_s": nb / el, "ms_per_call": el * 1e3, "planes_per_frame": float(nn.mean()),
+                   "accepted_per_frame": float(na.mean()), "frames_redone_on_host": s1["to_host"] - s0["to_host"],
+                   "voxel_grids_redone_on_host": s1["voxel_grids_to_host"] - s0["voxel_grids_to_host"]}
+    out["ahc_post_batch"] = dict(res[128], at_32_frames_per_call=res[32],
+                                 note="host frames uploaded inside the call; extractor (k_ahc_cluster_big / k_ahc_refine_big, one wavefront per frame, one frame per CU by LDS) + voxel grids + "
+                                      "gates and RANSAC refit (k_plane_refit) on the device; the pool uploads, launches and copies the post records")
     return out
 
 
