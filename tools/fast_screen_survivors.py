@@ -30,7 +30,7 @@ def score(c, d):
     return best
 
 
-def main():
+def main(TH=7):
     o = O.OrbOracle()
     for kind, cam in (("room_boxes", synth.TUM3), ("living_room", synth.ICL), ("planar_lowtexture", synth.TUM3)):
         g = next(synth.sequence(2, 1, cam=cam, kind=kind))[0]
@@ -53,13 +53,15 @@ def main():
             def pair(m):
                 m = m[:, :W]
                 return (m[:, 0::2] | m[:, 1::2]).mean()
-            a, b, q = s >= 7, ub >= 7, uq >= 7
+            a, b, q = s >= TH, ub >= TH, uq >= TH
             n = c.size
             tot += np.array([n, a.sum(), b.sum(), q.sum(), pair(a) * n, pair(b) * n, pair(q) * n])
         n = tot[0]
-        print("%-18s pixels %8d: score>=7 %5.1f%%  compass screen %5.1f%%  quad screen %5.1f%% | pairs: score %5.1f%%  compass %5.1f%%  quad %5.1f%%"
+        print("%-18s pixels %8d: score>=TH %5.1f%%  compass screen %5.1f%%  quad screen %5.1f%% | pairs: score %5.1f%%  compass %5.1f%%  quad %5.1f%%"
               % (kind, n, 100 * tot[1] / n, 100 * tot[2] / n, 100 * tot[3] / n, 100 * tot[4] / n, 100 * tot[5] / n, 100 * tot[6] / n))
 
 
 if __name__ == "__main__":
-    main()
+    for th in (7, 20):            # minThFAST and iniThFAST (ORBextractor.cc:809-815)
+        print("threshold", th)
+        main(th)
