@@ -251,7 +251,7 @@ int drfe_create(const drfe_config* cfg, drfe_ctx** out)
         const char* e = std::getenv("DRFE_FAST_GENERIC");
         c->fastGeneric = (e && e[0] == '1') ? 1 : 0;
         const char* es = std::getenv("DRFE_FAST_SCREEN");
-        c->fastScreen = (es && es[0] == '0') ? 0 : 1;
+        c->fastScreen = (es && es[0] >= '0' && es[0] <= '2') ? es[0] - '0' : 2;     /* 0 never, 1 at minThFAST only (rounds 3-4), 2 at iniThFAST first */
     }
 
     /* size the arenas with the geometry of the largest frame */

@@ -143,7 +143,8 @@ struct drfe_ctx {
     uint8_t* d_desc;          /* [slot][maxKp][32] */
     int* d_kpCount;           /* [slot] */
     int* d_status;            /* device-side error flags (overflow) */
-    int fastScreen;           /* 1 (default): k_fast_cells_cols may take its screened path on low-texture cells; DRFE_FAST_SCREEN=0 in the environment: never (A/B, tests) */
+    int fastScreen;           /* k_fast_cells_cols' screened paths; 2 (default): at iniThFAST first (textured cells), then at minThFAST (low-texture cells); 1: at
+                               * minThFAST only; 0: never.  DRFE_FAST_SCREEN in the environment sets it (A/B, tests) */
     int fastGeneric;          /* DRFE_FAST_GENERIC=1 in the environment: run k_fast_cells even where k_fast_cells_cols fits (A/B, tests) */
 
     /* frame glue + match */

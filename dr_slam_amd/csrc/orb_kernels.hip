@@ -510,10 +510,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
  * Emission order inside a cell differs from k_fast_cells; the order key in cand1 is what the quadtree ties on. */
 #define FASTC_P16 52                              /* pixels per tile row: 26 dwords, so row blocks 8 rows apart start 16 banks apart */
 #define FASTC_PB (FASTC_P16 * 2)
-/* tile, then the survivor list of the screened path: FASTC_LIST_CAP 16-bit items (lane | row << 6, later the pair's two scores).  A
- * quarter of the wavefront's 512 pixel-pair rows: a cell with more survivors takes the plain path (256 bytes of LDS keep the
- * occupancy of the plain path where it was; 2 KB more per wavefront cost it 7 %) */
-#define FASTC_LIST_CAP 128
+/* tile, then the survivor list of the screened paths: FASTC_LIST_CAP 16-bit items (lane | row << 6, later the pair's two scores).
+ * 320 of the wavefront's 512 pixel-pair rows: on textured frames 24-50 % of a cell's pair rows pass the screen at iniThFAST
+ * (profiles/r05_fast_screen_survivors.txt); a cell with more survivors takes the plain path.  640 bytes = one LDS granule more per
+ * workgroup than the 128-entry list of rounds 3-4 (25 instead of 32 workgroups per CU); measured: the plain path does not notice */
+#define FASTC_LIST_CAP 320
 static inline int fastc_list_off(int rows) { return (rows * FASTC_PB + 16 + 15) & ~15; }
 static inline int fastc_lds_bytes(int rows) { return fastc_list_off(rows) + FASTC_LIST_CAP * 2; }
 #define FASTC_DPP_SHR 0x138                        /* wave_shr:1 */
@@ -649,63 +650,158 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     const uint32_t mlast = rb == nrb - 1 ? 0u : mcol;
     uint32_t s[RMAX];
     /* Which way this cell is scored.  The strength tree costs ~100 instructions per pixel-pair row whatever the pixels hold; on a
-     * low-texture cell a twentieth of the pair rows can reach minThFAST at all.  The compass screen (fastc_screen, ~25
-     * instructions) of every lane's FIRST row - one row of every row block: a sample spread over the cell - decides per
-     * wavefront: fewer than a quarter of the sampled pair rows pass -> the screened path (screen every row, run the tree on the
-     * compacted survivors only - if they fit the list); otherwise the plain path, which costs a textured cell the sample and
-     * nothing else.  A pair row
-     * that fails the screen scores 0 instead of its true strength (< minTh): such a value never reaches an output - a kept
-     * pixel has s > max(N, minTh - 1), and every neighbour changed by this was below minTh anyway. */
-    const h16x2 thScreen = __builtin_bit_cast(h16x2, (uint32_t)minTh * 0x00010001u);
-    bool plain = true;
-    unsigned long long pm[RMAX];                 /* wave-uniform: which lanes' pair row i passed the screen */
-    if (RMAX == 8 && screen) {         /* the 8-row instantiation only (the four large levels: 85 % of the pixels) */
+     * low-texture cell a twentieth of the pair rows can reach minThFAST at all, and on a textured one a third can reach iniThFAST.
+     * The compass screen (fastc_screen, ~25 instructions) of every lane's FIRST row - one row of every row block: a sample spread
+     * over the cell - decides per wavefront:
+     *   first (screen >= 2; round 5): a sixteenth to two thirds of the sampled pair rows pass the screen AT iniTh -> screen
+     *     every row at iniTh and run the tree on the compacted survivors only (if they fit the list).  A pair row that fails scores 0
+     *     instead of its true strength (< iniTh): no comparison at iniTh can see that - a pixel kept there has s > max(N, iniTh - 1) -
+     *     so if the cell HAS a corner at iniTh (the reference's first cv::FAST call returns something, ORBextractor.cc:809-812)
+     *     its candidates are exact and the wavefront is done; if it has none the strengths below iniTh are needed and the cell
+     *     starts again below;
+     *   then: fewer than a quarter of the sampled pair rows pass the screen at minTh -> the same at minTh (exact for both
+     *     thresholds: a value below minTh never reaches an output); otherwise the plain path, which costs a textured cell the
+     *     samples and nothing else.
+     * The stages are lambdas inlined at their two uses, straight-line code on both ways (a loop over the two attempts kept the
+     * score arrays of one attempt alive across the other: 81 VGPRs instead of 56). */
+    const uint32_t th7 = (uint32_t)(minTh - 1) * 0x00010001u, th20 = (uint32_t)(iniTh - 1) * 0x00010001u;
+    const uint32_t selA = cp == 0 ? 0x05040C0Cu : 0x05040302u;          /* [own col x   | left lane's col x-1] */
+    const uint32_t selB = cp == ncp - 1 ? 0x0C0C0302u : 0x05040302u;    /* [right lane's col x+2 | own col x+1] */
+    uint32_t dm[RMAX], nb[RMAX];
+    /* the first row of every lane through the screen at thS: how many of the lanes that hold a pixel pair pass */
+    auto sample = [&](h16x2 thS, int& nS, int& nAll) {
         const uint32_t p0 = fastc_screen(fastc_ld<0, 0>(base), fastc_ld<0, 3>(base), fastc_ld<3, 0>(base), fastc_ld<0, -3>(base),
-                                         fastc_ld<-3, 0>(base), thScreen) & (0 < iInv ? mcol : mlast);
-        /* fewer than a quarter of the lanes that hold a pixel pair */
-        if (4 * __popcll(__ballot(p0 != 0)) < __popcll(__ballot(mcol != 0))) {
-            uint32_t total = 0;
-            uint16_t* lst = reinterpret_cast<uint16_t*>(fastLds + listOff);
+                                         fastc_ld<-3, 0>(base), thS) & (0 < iInv ? mcol : mlast);
+        nS = __popcll(__ballot(p0 != 0)); nAll = __popcll(__ballot(mcol != 0));
+    };
+    /* screen every row at thS, the tree on the compacted survivors, their scores back into s[]; false: they do not fit the list */
+    auto screened_fill = [&](h16x2 thS) -> bool {
+        unsigned long long pm[RMAX];                 /* wave-uniform: which lanes' pair row i passed the screen */
+        uint32_t total = 0;
+        uint16_t* lst = reinterpret_cast<uint16_t*>(fastLds + listOff);
 #pragma unroll
-            for (int i = 0; i < RMAX; i++) {
-                uint32_t pb = 0;
-                if (i < R)
-                    pb = fastc_screen(fastc_ld<0, 0>(base + i * FASTC_PB), fastc_ld<0, 3>(base + i * FASTC_PB), fastc_ld<3, 0>(base + i * FASTC_PB),
-                                      fastc_ld<0, -3>(base + i * FASTC_PB), fastc_ld<-3, 0>(base + i * FASTC_PB), thScreen) & (i < iInv ? mcol : mlast);
-                pm[i] = __ballot(pb != 0);
-                /* the survivor's place in the list: the rows before it, then the lanes before it in its row */
-                const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u));
-                if (pb != 0 && pos < FASTC_LIST_CAP) lst[pos] = (uint16_t)(lane | (i << 6));
-                total += (uint32_t)__popcll(pm[i]);
-            }
-            if (total <= FASTC_LIST_CAP) {
-                plain = false;
-                __syncthreads();
-                /* the tree on the survivors, 64 at a time; a survivor's list slot then takes its two 8-bit scores, which the owner
-                 * reads back below (no register of the owner is live across the passes: the register budget stays the plain path's) */
-                const uint32_t npass = (total + 63u) >> 6;
-                for (uint32_t k = 0; k < npass; k++) {
-                    const uint32_t p = 64u * k + (uint32_t)lane;
-                    if (p < total) {
-                        const uint32_t item = lst[p], o = item & 63u, r = item >> 6;
-                        const uint32_t rbo = (o * fc.ncpMagic) >> 16, cpo = o - rbo * (uint32_t)ncp;
-                        const uint32_t v2 = fastc_strength2(fastLds + (rbo * (uint32_t)R + r) * FASTC_PB + ((uint32_t)(off & 2) + 2u * cpo) * 2u);
-                        lst[p] = (uint16_t)((v2 & 0xFFu) | ((v2 >> 8) & 0xFF00u));
-                    }
-                }
-                __syncthreads();
-                uint32_t start = 0;
-#pragma unroll
-                for (int i = 0; i < RMAX; i++) {
-                    s[i] = 0;
-                    if ((pm[i] >> lane) & 1ull) {
-                        const uint32_t v2 = lst[start + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u))];
-                        s[i] = ((v2 & 0xFFu) | ((v2 & 0xFF00u) << 8)) & (i < iInv ? mcol : mlast);
-                    }
-                    start += (uint32_t)__popcll(pm[i]);
-                }
+        for (int i = 0; i < RMAX; i++) {
+            uint32_t pb = 0;
+            if (i < R)
+                pb = fastc_screen(fastc_ld<0, 0>(base + i * FASTC_PB), fastc_ld<0, 3>(base + i * FASTC_PB), fastc_ld<3, 0>(base + i * FASTC_PB),
+                                  fastc_ld<0, -3>(base + i * FASTC_PB), fastc_ld<-3, 0>(base + i * FASTC_PB), thS) & (i < iInv ? mcol : mlast);
+            pm[i] = __ballot(pb != 0);
+            /* the survivor's place in the list: the rows before it, then the lanes before it in its row */
+            const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u));
+            if (pb != 0 && pos < FASTC_LIST_CAP) lst[pos] = (uint16_t)(lane | (i << 6));
+            total += (uint32_t)__popcll(pm[i]);
+        }
+        if (total > FASTC_LIST_CAP) return false;
+        __syncthreads();
+        /* the tree on the survivors, 64 at a time; a survivor's list slot then takes its two 8-bit scores, which the owner
+         * reads back below (no register of the owner is live across the passes: the register budget stays the plain path's) */
+        const uint32_t npass = (total + 63u) >> 6;
+        for (uint32_t k = 0; k < npass; k++) {
+            const uint32_t p = 64u * k + (uint32_t)lane;
+            if (p < total) {
+                const uint32_t item = lst[p], o = item & 63u, r = item >> 6;
+                const uint32_t rbo = (o * fc.ncpMagic) >> 16, cpo = o - rbo * (uint32_t)ncp;
+                const uint32_t v2 = fastc_strength2(fastLds + (rbo * (uint32_t)R + r) * FASTC_PB + ((uint32_t)(off & 2) + 2u * cpo) * 2u);
+                lst[p] = (uint16_t)((v2 & 0xFFu) | ((v2 >> 8) & 0xFF00u));
             }
         }
+        __syncthreads();
+        uint32_t start = 0;
+#pragma unroll
+        for (int i = 0; i < RMAX; i++) {
+            s[i] = 0;
+            if ((pm[i] >> lane) & 1ull) {
+                const uint32_t v2 = lst[start + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u))];
+                s[i] = ((v2 & 0xFFu) | ((v2 & 0xFF00u) << 8)) & (i < iInv ? mcol : mlast);
+            }
+            start += (uint32_t)__popcll(pm[i]);
+        }
+        return true;
+    };
+    /* strict 3x3 maximum of s[] into nb[], dm[] = how far each score is above max(N, iniTh - 1); true: the cell has a corner at iniTh.
+     * Block seams: the row above this lane's first row is the last row of lane - ncp, the row below its last one the first row of
+     * lane + ncp.  C3 = column maximum incl. the pixel; the left / right column maxima come from the neighbouring lanes (wave shifts;
+     * the selectors blank the cell's outer columns); N = the eight neighbours' maximum.  A pixel is kept at threshold t iff
+     * s > max(N, t - 1).  Rows i >= R hold zero scores: they run through the same instructions (no control flow around register
+     * arrays) and come out as "no maximum". */
+    auto nms_ini = [&]() -> bool {
+        uint32_t last = 0;
+#pragma unroll
+        for (int i = 0; i < RMAX; i++)
+            if (i == R - 1) last = s[i];
+        uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - ncp) << 2, (int)last);
+        uint32_t down = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + ncp) << 2, (int)s[0]);
+        if (rb == 0) up = 0;
+        if (rb + 1 >= nrb) down = 0;
+        uint32_t acc20 = 0;
+#pragma unroll
+        for (int i = 0; i < RMAX; i++) {
+            const uint32_t sup = i == 0 ? up : s[i > 0 ? i - 1 : 0];
+            const uint32_t sdn = (i == R - 1 || i == RMAX - 1) ? down : s[i + 1 < RMAX ? i + 1 : i];
+            const uint32_t V = u2max(sup, sdn), C3 = u2max(V, s[i]);
+            const uint32_t L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHR, 0xF, 0xF, true);
+            const uint32_t Rr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHL, 0xF, 0xF, true);
+            const uint32_t A = __builtin_amdgcn_perm(C3, L, selA), B = __builtin_amdgcn_perm(Rr, C3, selB);
+            nb[i] = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(h16x2, V), __builtin_bit_cast(h16x2, A),
+                                                       __builtin_bit_cast(h16x2, B)));     /* small integers = exact f16 subnormals */
+            dm[i] = u2subs(s[i], u2max(nb[i], th20));
+            acc20 |= dm[i];
+        }
+        return __any(acc20 != 0) != 0;
+    };
+    auto emit = [&]() {
+        /* where a candidate goes inside the cell's run: row by row, the lanes of a row in lane order - one ballot per row, the
+         * row's start is a scalar popcount sum and a lane's place two v_mbcnt (the order inside a run is free: the quadtree ties on
+         * the order key of cand1, not on the array position) */
+        unsigned long long rowMask[RMAX];
+        int total = 0;
+#pragma unroll
+        for (int i = 0; i < RMAX; i++) { rowMask[i] = __ballot(dm[i] != 0); total += __popcll(rowMask[i]); }
+        if (total == 0) return;
+        int cbase = 0;
+        if (lane == 0) cbase = atomicAdd(&candCount[DRFE_CC_IDX(slot, fc.level)], total);
+        cbase = __builtin_amdgcn_readfirstlane(cbase);
+        if (cbase + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
+        /* the cell's output run starts at a wave-uniform element (scalar base); a lane adds its 32-bit offset */
+        const size_t run = (size_t)__builtin_amdgcn_readfirstlane(slot) * (size_t)candSlotElems + fc.candOff + (size_t)cbase;
+        uint32_t* const out0 = cand0 + run;
+        uint32_t* const out1 = cand1 + run;
+        uint32_t rowStart = 0;                            /* scalar: candidates of the rows before this one */
+        /* the constant parts of the two records: keypoint coordinates as the reference leaves them in vToDistributeKeys
+         * (:822-823), and the emission-order key */
+        const uint32_t k0base = ((uint32_t)x + 3 + fc.offX) | (((uint32_t)y0 + 3 + fc.offY) << 12);
+        const uint32_t k1base = (fc.cellIdx << 12) | ((uint32_t)y0 << 6) | (uint32_t)x;
+#pragma unroll
+        for (int i = 0; i < RMAX; i++) {
+            if (dm[i] != 0) {
+                const uint32_t hi = dm[i] >> 16 ? 1u : 0u;
+                const uint32_t sc = hi ? s[i] >> 16 : s[i] & 0xFFFFu;
+                /* x + hi and y0 + i never carry out of their fields (x + 1 < 64, y0 + i < 64; kx, ky < 4096) */
+                /* byte offset in 32-bit arithmetic: the store address stays scalar base + VGPR offset */
+                const uint32_t pos = (rowStart + __builtin_amdgcn_mbcnt_hi((uint32_t)(rowMask[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rowMask[i], 0u))) * 4u;
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out0) + pos) = (k0base + hi + ((uint32_t)i << 12)) | (sc << 24);
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out1) + pos) = k1base + hi + ((uint32_t)i << 6);
+            }
+            rowStart += (uint32_t)__popcll(rowMask[i]);
+        }
+    };
+    if (RMAX == 8 && screen >= 2) {    /* the 8-row instantiation only (the four large levels: 85 % of the pixels) */
+        int nS, nAll;
+        const h16x2 thIni = __builtin_bit_cast(h16x2, (uint32_t)iniTh * 0x00010001u);
+        sample(thIni, nS, nAll);
+        /* a sample with (nearly) no survivor says "probably no corner at iniTh here" - a low-texture cell, which would pay for both
+         * attempts: straight to the exact ways.  Between a sixteenth and two thirds of the sampled pair rows: worth trying */
+        if (16 * nS >= nAll && 3 * nS < 2 * nAll && screened_fill(thIni)) {
+            if (nms_ini()) { emit(); return; }
+            __syncthreads();           /* the list is written again below */
+        }
+    }
+    bool plain = true;
+    if (RMAX == 8 && screen) {
+        int nS, nAll;
+        const h16x2 thMin = __builtin_bit_cast(h16x2, (uint32_t)minTh * 0x00010001u);
+        sample(thMin, nS, nAll);
+        if (4 * nS < nAll) plain = !screened_fill(thMin);          /* fewer than a quarter of the lanes that hold a pixel pair */
     }
     if (plain) {
 #pragma unroll
@@ -717,75 +813,11 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
             }
         }
     }
-    /* block seams: the row above this lane's first row is the last row of lane - ncp, the row below its last one the
-       first row of lane + ncp */
-    uint32_t last = 0;
-#pragma unroll
-    for (int i = 0; i < RMAX; i++)
-        if (i == R - 1) last = s[i];
-    uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - ncp) << 2, (int)last);
-    uint32_t down = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + ncp) << 2, (int)s[0]);
-    if (rb == 0) up = 0;
-    if (rb + 1 >= nrb) down = 0;
-    /* strict 3x3 maximum: C3 = column maximum incl. the pixel; the left / right column maxima come from the neighbouring
-       lanes (wave shifts; the selectors blank the cell's outer columns); N = the eight neighbours' maximum.  A pixel is
-       kept at threshold t iff s > max(N, t - 1).  Rows i >= R hold zero scores: they run through the same instructions
-       (no control flow around register arrays) and come out as "no maximum". */
-    const uint32_t selA = cp == 0 ? 0x05040C0Cu : 0x05040302u;          /* [own col x   | left lane's col x-1] */
-    const uint32_t selB = cp == ncp - 1 ? 0x0C0C0302u : 0x05040302u;    /* [right lane's col x+2 | own col x+1] */
-    const uint32_t th7 = (uint32_t)(minTh - 1) * 0x00010001u, th20 = (uint32_t)(iniTh - 1) * 0x00010001u;
-    uint32_t dm[RMAX], nb[RMAX], acc20 = 0;
-#pragma unroll
-    for (int i = 0; i < RMAX; i++) {
-        const uint32_t sup = i == 0 ? up : s[i > 0 ? i - 1 : 0];
-        const uint32_t sdn = (i == R - 1 || i == RMAX - 1) ? down : s[i + 1 < RMAX ? i + 1 : i];
-        const uint32_t V = u2max(sup, sdn), C3 = u2max(V, s[i]);
-        const uint32_t L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHR, 0xF, 0xF, true);
-        const uint32_t Rr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C3, FASTC_DPP_SHL, 0xF, 0xF, true);
-        const uint32_t A = __builtin_amdgcn_perm(C3, L, selA), B = __builtin_amdgcn_perm(Rr, C3, selB);
-        nb[i] = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(h16x2, V), __builtin_bit_cast(h16x2, A),
-                                                   __builtin_bit_cast(h16x2, B)));     /* small integers = exact f16 subnormals */
-        dm[i] = u2subs(s[i], u2max(nb[i], th20));
-        acc20 |= dm[i];
-    }
-    if (!__any(acc20 != 0)) {                                          /* fallback decided per cell after NMS@ini */
+    if (!nms_ini()) {                                                  /* fallback decided per cell after NMS@ini */
 #pragma unroll
         for (int i = 0; i < RMAX; i++) dm[i] = u2subs(s[i], u2max(nb[i], th7));
     }
-    /* where a candidate goes inside the cell's run: row by row, the lanes of a row in lane order - one ballot per row, the
-     * row's start is a scalar popcount sum and a lane's place two v_mbcnt (the order inside a run is free: the quadtree ties on
-     * the order key of cand1, not on the array position) */
-    unsigned long long rowMask[RMAX];
-    int total = 0;
-#pragma unroll
-    for (int i = 0; i < RMAX; i++) { rowMask[i] = __ballot(dm[i] != 0); total += __popcll(rowMask[i]); }
-    if (total == 0) return;
-    int cbase = 0;
-    if (lane == 0) cbase = atomicAdd(&candCount[DRFE_CC_IDX(slot, fc.level)], total);
-    cbase = __builtin_amdgcn_readfirstlane(cbase);
-    if (cbase + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
-    /* the cell's output run starts at a wave-uniform element (scalar base); a lane adds its 32-bit offset */
-    const size_t run = (size_t)__builtin_amdgcn_readfirstlane(slot) * (size_t)candSlotElems + fc.candOff + (size_t)cbase;
-    uint32_t* const out0 = cand0 + run;
-    uint32_t* const out1 = cand1 + run;
-    uint32_t rowStart = 0;                            /* scalar: candidates of the rows before this one */
-    /* the constant parts of the two records: keypoint coordinates as the reference leaves them in vToDistributeKeys
-     * (:822-823), and the emission-order key */
-    const uint32_t k0base = ((uint32_t)x + 3 + fc.offX) | (((uint32_t)y0 + 3 + fc.offY) << 12);
-    const uint32_t k1base = (fc.cellIdx << 12) | ((uint32_t)y0 << 6) | (uint32_t)x;
-#pragma unroll
-    for (int i = 0; i < RMAX; i++) {
-        if (dm[i] != 0) {
-            const uint32_t hi = dm[i] >> 16 ? 1u : 0u;
-            const uint32_t sc = hi ? s[i] >> 16 : s[i] & 0xFFFFu;
-            /* x + hi and y0 + i never carry out of their fields (x + 1 < 64, y0 + i < 64; kx, ky < 4096) */
-            /* byte offset in 32-bit arithmetic: the store address stays scalar base + VGPR offset */
-            const uint32_t pos = (rowStart + __builtin_amdgcn_mbcnt_hi((uint32_t)(rowMask[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rowMask[i], 0u))) * 4u;
-            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out0) + pos) = (k0base + hi + ((uint32_t)i << 12)) | (sc << 24);
-            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out1) + pos) = k1base + hi + ((uint32_t)i << 6);
-        }
-        rowStart += (uint32_t)__popcll(rowMask[i]);
-    }
+    emit();
 }
 
 /* ------------------------------------------------------------------------------------------------ */

@@ -250,3 +250,44 @@ def test_single_frame_graph_survives_a_geometry_change(frames_room):
     assert cnt[0] == len(want[0])
     assert c.L.drfe_batch_check(c.h) == 0
     c.close()
+
+
+@pytest.mark.parametrize("screen", ["0", "1", "2"])
+def test_fast_screen_modes_on_mixed_texture(oracle_mod, screen, monkeypatch):
+    """k_fast_cells_cols picks per cell between the plain strength tree, the compass screen at minThFAST (low-texture cells) and,
+    round 5, the screen at iniThFAST with the exact path as the fallback for a cell without a corner at iniThFAST
+    (src/ORBextractor.cc:809-816).  Frames whose cells fall on every side of those decisions - a textured half beside a low-texture
+    half, a frame of faint noise whose corner scores sit between the two thresholds, the plain scene kinds - through a context of
+    each DRFE_FAST_SCREEN mode: candidates of every level, keypoints and descriptors equal the oracle's."""
+    from dr_slam_amd import lib, synth
+    monkeypatch.setenv("DRFE_FAST_SCREEN", screen)
+    c = lib.Context(max_batch=4)
+    try:
+        room = next(synth.sequence(2, 1, kind="room_boxes"))[0]
+        low = next(synth.sequence(1, 1, kind="planar_lowtexture"))[0]
+        living = next(synth.sequence(3, 1, kind="living_room"))[0]
+        half = room.copy(); half[:, 320:] = low[:, 320:]
+        bands = low.copy(); bands[96:200] = room[96:200]; bands[330:400, 100:500] = living[330:400, 100:500]
+        rng = np.random.default_rng(11)
+        faint = np.clip(120 + rng.integers(-9, 10, (480, 640)), 0, 255).astype(np.uint8)        # scores mostly in [7, 20)
+        faint[200:280, 260:380] = room[200:280, 260:380]
+        for name, g in (("room", room), ("low", low), ("half", half), ("bands", bands), ("faint", faint)):
+            o = oracle_mod.OrbOracle()
+            kps, desc = c.orb_extract(g)
+            okps, odesc = o(g)
+            for l in range(8):
+                assert np.array_equal(c.candidates(0, l), o.candidates(l)), (name, "FAST candidates level", l)
+            _same_kps(kps, okps)
+            assert np.array_equal(desc, odesc), name
+        # the batch entry runs the same kernel over frames side by side
+        import torch
+        batch = np.stack([half, faint, bands, room])
+        gray = torch.from_numpy(batch).cuda()
+        c.orb_extract_batch_ptr(gray.data_ptr(), 640 * 480, 640, 640, 480, 4, torch.cuda.current_stream().cuda_stream)
+        for f, g in enumerate(batch):
+            kps, desc = c.orb_download(f)
+            okps, odesc = oracle_mod.OrbOracle()(g)
+            _same_kps(kps, okps)
+            assert np.array_equal(desc, odesc)
+    finally:
+        c.close()
