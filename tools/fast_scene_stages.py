@@ -1,6 +1,6 @@
 """FAST stage and whole-step time of the headline path per scene kind (the textures BASELINE's configs name): 512-frame batches of
 room_boxes / living_room / planar_lowtexture, HIP-event stage times (one context, one batch at a time) and the step rate.
-    python tools/fast_scene_stages.py [batch=512]        (DRFE_FAST_SCREEN=0: the screened path off, for A/B)"""
+    python tools/fast_scene_stages.py [batch=512]        (DRFE_FAST_SCREEN=0 / 1 / 2: no screened path / at minThFAST only / at iniThFAST first - the default - for A/B)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -9,7 +9,7 @@ from dr_slam_amd import sharding, synth
 from dr_slam_amd.pipeline import FrontEnd
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-out = {"batch": B, "fast_screen": os.environ.get("DRFE_FAST_SCREEN", "1"), "scenes": {}}
+out = {"batch": B, "fast_screen": os.environ.get("DRFE_FAST_SCREEN", "2"), "scenes": {}}
 for kind, cam in (("room_boxes", synth.TUM3), ("living_room", synth.ICL), ("planar_lowtexture", synth.TUM3)):
     base = sharding.render_sequence(3, 16, cam, kind, workers=8)
     order = sharding.pingpong_order(B, len(base))
