@@ -653,7 +653,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
      * low-texture cell a twentieth of the pair rows can reach minThFAST at all, and on a textured one a third can reach iniThFAST.
      * The compass screen (fastc_screen, ~25 instructions) of every lane's FIRST row - one row of every row block: a sample spread
      * over the cell - decides per wavefront:
-     *   first (screen >= 2; round 5): a sixteenth to two thirds of the sampled pair rows pass the screen AT iniTh -> screen
+     *   first (screen >= 2; round 5): an eighth to two thirds of the sampled pair rows pass the screen AT iniTh -> screen
      *     every row at iniTh and run the tree on the compacted survivors only (if they fit the list).  A pair row that fails scores 0
      *     instead of its true strength (< iniTh): no comparison at iniTh can see that - a pixel kept there has s > max(N, iniTh - 1) -
      *     so if the cell HAS a corner at iniTh (the reference's first cv::FAST call returns something, ORBextractor.cc:809-812)
@@ -790,8 +790,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
         const h16x2 thIni = __builtin_bit_cast(h16x2, (uint32_t)iniTh * 0x00010001u);
         sample(thIni, nS, nAll);
         /* a sample with (nearly) no survivor says "probably no corner at iniTh here" - a low-texture cell, which would pay for both
-         * attempts: straight to the exact ways.  Between a sixteenth and two thirds of the sampled pair rows: worth trying */
-        if (16 * nS >= nAll && 3 * nS < 2 * nAll && screened_fill(thIni)) {
+         * attempts: straight to the exact ways.  Between an eighth and two thirds of the sampled pair rows: worth trying */
+        if (8 * nS >= nAll && 3 * nS < 2 * nAll && screened_fill(thIni)) {
             if (nms_ini()) { emit(); return; }
             __syncthreads();           /* the list is written again below */
         }
