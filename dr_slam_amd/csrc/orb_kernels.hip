@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
  * Emission order inside a cell differs from k_fast_cells; the order key in cand1 is what the quadtree ties on. */
 #define FASTC_P16 52                              /* pixels per tile row: 26 dwords, so row blocks 8 rows apart start 16 banks apart */
 #define FASTC_PB (FASTC_P16 * 2)
-/* tile, then the survivor list of the screened paths: FASTC_LIST_CAP 16-bit items (lane | row << 6, later the pair's two scores).
+/* tile, then the survivor list of the screened paths: FASTC_LIST_CAP 16-bit items (the tile offset of a surviving pair row's patch, later the pair's two scores).
  * 320 of the wavefront's 512 pixel-pair rows: on textured frames 24-50 % of a cell's pair rows pass the screen at iniThFAST
  * (profiles/r05_fast_screen_survivors.txt); a cell with more survivors takes the plain path.  640 bytes = one LDS granule more per
  * workgroup than the 128-entry list of rounds 3-4 (25 instead of 32 workgroups per CU); measured: the plain path does not notice */
@@ -669,26 +669,30 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     const uint32_t selB = cp == ncp - 1 ? 0x0C0C0302u : 0x05040302u;    /* [right lane's col x+2 | own col x+1] */
     uint32_t dm[RMAX], nb[RMAX];
     /* the first row of every lane through the screen at thS: how many of the lanes that hold a pixel pair pass */
-    auto sample = [&](h16x2 thS, int& nS, int& nAll) {
+    auto sample = [&](h16x2 thS, int& nS, int& nAll) -> uint32_t {
         const uint32_t p0 = fastc_screen(fastc_ld<0, 0>(base), fastc_ld<0, 3>(base), fastc_ld<3, 0>(base), fastc_ld<0, -3>(base),
                                          fastc_ld<-3, 0>(base), thS) & (0 < iInv ? mcol : mlast);
         nS = __popcll(__ballot(p0 != 0)); nAll = __popcll(__ballot(mcol != 0));
+        return p0;
     };
     /* screen every row at thS, the tree on the compacted survivors, their scores back into s[]; false: they do not fit the list */
-    auto screened_fill = [&](h16x2 thS) -> bool {
+    /* p0: the first row's screen (the sample's) */
+    auto screened_fill = [&](h16x2 thS, uint32_t p0) -> bool {
         unsigned long long pm[RMAX];                 /* wave-uniform: which lanes' pair row i passed the screen */
         uint32_t total = 0;
         uint16_t* lst = reinterpret_cast<uint16_t*>(fastLds + listOff);
+        const uint32_t baseOff = (uint32_t)(base - fastLds);
 #pragma unroll
         for (int i = 0; i < RMAX; i++) {
-            uint32_t pb = 0;
-            if (i < R)
+            uint32_t pb = p0;
+            if (i > 0) pb = 0;
+            if (i > 0 && i < R)
                 pb = fastc_screen(fastc_ld<0, 0>(base + i * FASTC_PB), fastc_ld<0, 3>(base + i * FASTC_PB), fastc_ld<3, 0>(base + i * FASTC_PB),
                                   fastc_ld<0, -3>(base + i * FASTC_PB), fastc_ld<-3, 0>(base + i * FASTC_PB), thS) & (i < iInv ? mcol : mlast);
             pm[i] = __ballot(pb != 0);
             /* the survivor's place in the list: the rows before it, then the lanes before it in its row */
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u));
-            if (pb != 0 && pos < FASTC_LIST_CAP) lst[pos] = (uint16_t)(lane | (i << 6));
+            if (pb != 0 && pos < FASTC_LIST_CAP) lst[pos] = (uint16_t)(baseOff + (uint32_t)(i * FASTC_PB));    /* where the pair's patch starts in the tile */
             total += (uint32_t)__popcll(pm[i]);
         }
         if (total > FASTC_LIST_CAP) return false;
@@ -699,9 +703,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
         for (uint32_t k = 0; k < npass; k++) {
             const uint32_t p = 64u * k + (uint32_t)lane;
             if (p < total) {
-                const uint32_t item = lst[p], o = item & 63u, r = item >> 6;
-                const uint32_t rbo = (o * fc.ncpMagic) >> 16, cpo = o - rbo * (uint32_t)ncp;
-                const uint32_t v2 = fastc_strength2(fastLds + (rbo * (uint32_t)R + r) * FASTC_PB + ((uint32_t)(off & 2) + 2u * cpo) * 2u);
+                const uint32_t v2 = fastc_strength2(fastLds + lst[p]);
                 lst[p] = (uint16_t)((v2 & 0xFFu) | ((v2 >> 8) & 0xFF00u));
             }
         }
@@ -788,10 +790,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     if (RMAX == 8 && screen >= 2) {    /* the 8-row instantiation only (the four large levels: 85 % of the pixels) */
         int nS, nAll;
         const h16x2 thIni = __builtin_bit_cast(h16x2, (uint32_t)iniTh * 0x00010001u);
-        sample(thIni, nS, nAll);
+        const uint32_t p0 = sample(thIni, nS, nAll);
         /* a sample with (nearly) no survivor says "probably no corner at iniTh here" - a low-texture cell, which would pay for both
          * attempts: straight to the exact ways.  Between an eighth and two thirds of the sampled pair rows: worth trying */
-        if (8 * nS >= nAll && 3 * nS < 2 * nAll && screened_fill(thIni)) {
+        if (8 * nS >= nAll && 3 * nS < 2 * nAll && screened_fill(thIni, p0)) {
             if (nms_ini()) { emit(); return; }
             __syncthreads();           /* the list is written again below */
         }
@@ -800,8 +802,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
     if (RMAX == 8 && screen) {
         int nS, nAll;
         const h16x2 thMin = __builtin_bit_cast(h16x2, (uint32_t)minTh * 0x00010001u);
-        sample(thMin, nS, nAll);
-        if (4 * nS < nAll) plain = !screened_fill(thMin);          /* fewer than a quarter of the lanes that hold a pixel pair */
+        const uint32_t p0 = sample(thMin, nS, nAll);
+        if (4 * nS < nAll) plain = !screened_fill(thMin, p0);          /* fewer than a quarter of the lanes that hold a pixel pair */
     }
     if (plain) {
 #pragma unroll
