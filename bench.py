@@ -232,7 +232,7 @@ def config5_aux(ctx, base, cam, n: int = 6):
 def scene_stage_times(B, device):
     """The headline path on the OTHER textures BASELINE's configs name (config 1's namesake is a low-texture scene, config 3 a living
     room): per-stage HIP-event times of one 512-frame batch and the one-context step rate, per scene kind.  The FAST kernel picks
-    per cell between its plain path and the screened one (compass screen + the strength tree on the compacted survivors)."""
+    per cell between its plain path and the screened ones (compass screen at iniThFAST on textured cells, at minThFAST on low-texture ones, + the strength tree on the compacted survivors)."""
     import torch
     from dr_slam_amd import sharding, synth
     from dr_slam_amd.pipeline import FrontEnd
