@@ -244,9 +244,10 @@ __device__ __forceinline__ void align_class(float Sx, float Sy, float2 c, const 
     const float dot = __builtin_fmaf(Sx, c.x, Sy * c.y), crs = __builtin_fmaf(Sx, c.y, -(Sy * c.x));
     const float ac = fabsf(crs);
     const unsigned long long ok = __ballot(fabsf(dot) + ac > 1e-3f);
-    const unsigned long long mIn = __ballot(ac <= T.tLo * dot), mOut = __ballot(ac >= T.tHi * dot), mNeg = __ballot(dot <= 0.f);
+    /* dot <= 0 needs no test of its own: tHi > 0, so tHi * dot <= 0 <= |cross| and the pixel is "out" already */
+    const unsigned long long mIn = __ballot(ac <= T.tLo * dot), mOut = __ballot(ac >= T.tHi * dot);
     in = ok & mIn;
-    unc = ~(in | (ok & (mOut | mNeg)));
+    unc = ~(in | (ok & mOut));
 }
 
 /* the float sums of region_grow (before the first join: the seed's own direction - its sums start there) */
