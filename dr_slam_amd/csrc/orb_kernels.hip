@@ -908,7 +908,7 @@ template <class SH> __device__ __forceinline__ int qt_child_slot(const SH& S, in
  * rule of SURVEY.md §9.1) and stop as soon as the list holds N nodes (:730).  Keys never move: each
  * carries the list position of its node. */
 template <int QT_THREADS, int QT_KPT, int QT_MAXN>
-__global__ __launch_bounds__(QT_THREADS, QT_THREADS == 256 ? 8 : 4) void k_quadtree(const DevGeom* __restrict__ G, int levelBase,
+__global__ __launch_bounds__(QT_THREADS, QT_THREADS == 256 ? 8 : 6) void k_quadtree(const DevGeom* __restrict__ G, int levelBase,
                                                          const uint32_t* __restrict__ cand0,
                                                          const uint32_t* __restrict__ cand1,
                                                          uint16_t* __restrict__ node,
