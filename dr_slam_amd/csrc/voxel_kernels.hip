@@ -79,7 +79,13 @@ extern "C" __global__ __launch_bounds__(1024) void k_voxel_jobs_order(const int2
     }
 }
 
-extern "C" __global__ __launch_bounds__(VOX_T) void k_voxel_grid(const float* __restrict__ pts, const int2* __restrict__ jobs,
+/* 96 VGPRs (four of them spilled) instead of the 112 the compiler takes: five workgroups per CU instead of four; the planes path at
+ * saturation +1.6 ... +9 % depending on the box (four alternations each, profiles/r05_occupancy3_variants.txt).  -DVOX_WAVES_PER_EU=4 / 6: A/B */
+#ifndef VOX_WAVES_PER_EU
+#define VOX_WAVES_PER_EU 5
+#endif
+#define VOX_OCC __attribute__((amdgpu_waves_per_eu(VOX_WAVES_PER_EU, VOX_WAVES_PER_EU)))
+extern "C" __global__ __launch_bounds__(VOX_T) VOX_OCC void k_voxel_grid(const float* __restrict__ pts, const int2* __restrict__ jobs,
                                                                  const int* __restrict__ list, int* __restrict__ ctl,
                                                                  unsigned long long* __restrict__ recs, unsigned long long* __restrict__ tmp,
                                                                  uint32_t* __restrict__ posL, uint32_t* __restrict__ posR,
