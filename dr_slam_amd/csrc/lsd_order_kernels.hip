@@ -27,7 +27,12 @@ struct LsdKeyTraits {
 };
 } // namespace
 
-extern "C" __global__ __launch_bounds__(ORD_T) void k_lsd_order(uint32_t* __restrict__ keysBase, size_t keyStride, int n,
+#ifdef ORD_WAVES_PER_EU                 /* experiment builds: 8 -> 64 VGPRs (2 spilled): seven workgroups per CU (the LDS bound) instead of six */
+#define ORD_OCC __attribute__((amdgpu_waves_per_eu(ORD_WAVES_PER_EU, ORD_WAVES_PER_EU)))
+#else
+#define ORD_OCC
+#endif
+extern "C" __global__ __launch_bounds__(ORD_T) ORD_OCC void k_lsd_order(uint32_t* __restrict__ keysBase, size_t keyStride, int n,
                                                                 uint32_t* __restrict__ posLBase, uint32_t* __restrict__ posRBase,
                                                                 size_t posStride, int* __restrict__ statusBase, int statusStride,
                                                                 int depthLimit)
