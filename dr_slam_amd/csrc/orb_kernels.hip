@@ -516,7 +516,15 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
  * workgroup than the 128-entry list of rounds 3-4 (25 instead of 32 workgroups per CU); measured: the plain path does not notice */
 #define FASTC_LIST_CAP 320
 static inline int fastc_list_off(int rows) { return (rows * FASTC_PB + 16 + 15) & ~15; }
-static inline int fastc_lds_bytes(int rows) { return fastc_list_off(rows) + FASTC_LIST_CAP * 2; }
+/* entries of the list: at least FASTC_LIST_CAP, and whatever else the LDS allocation granule (1280 bytes) leaves behind them - up to `want`
+ * (every pair row of the wavefront: 512 for the 8-row instantiation, 768 for the 12-row one) - so that a cell never falls off the list
+ * when a longer one costs nothing */
+static inline int fastc_list_cap(int rows, int want)
+{
+    const int off = fastc_list_off(rows), total = (off + FASTC_LIST_CAP * 2 + 1279) / 1280 * 1280;
+    return std::max(FASTC_LIST_CAP, std::min(want, (total - off) / 2));
+}
+static inline int fastc_lds_bytes(int rows, int want) { return fastc_list_off(rows) + fastc_list_cap(rows, want) * 2; }
 #define FASTC_DPP_SHR 0x138                        /* wave_shr:1 */
 #define FASTC_DPP_SHL 0x130                        /* wave_shl:1 */
 
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
                                                         int candSlotElems, int iniTh, int minTh,
                                                         const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand0,
                                                         uint32_t* __restrict__ cand1, int* __restrict__ candCount,
-                                                        int* __restrict__ status, uint32_t gxMagic, int cellFirst, int screen, int listOff)
+                                                        int* __restrict__ status, uint32_t gxMagic, int cellFirst, int screen, int listOff, int listCap)
 {
     int bx, by;
     drfe_xcd_swizzle_2d(gxMagic, bx, by);
@@ -694,10 +702,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
             pm[i] = __ballot(pb != 0);
             /* the survivor's place in the list: the rows before it, then the lanes before it in its row */
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm[i], 0u));
-            if (pb != 0 && pos < FASTC_LIST_CAP) lst[pos] = (uint16_t)(baseOff + (uint32_t)(i * FASTC_PB));    /* where the pair's patch starts in the tile */
+            if (pb != 0 && pos < (uint32_t)listCap) lst[pos] = (uint16_t)(baseOff + (uint32_t)(i * FASTC_PB));    /* where the pair's patch starts in the tile */
             total += (uint32_t)__popcll(pm[i]);
         }
-        if (total > FASTC_LIST_CAP) return false;
+        if (total > (uint32_t)listCap) return false;
         __syncthreads();
         /* the tree on the survivors, 64 at a time; a survivor's list slot then takes its two 8-bit scores, which the owner
          * reads back below (no register of the owner is live across the passes: the register budget stays the plain path's) */
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
             rowStart += (uint32_t)__popcll(rowMask[i]);
         }
     };
-    if (RMAX == 8 && screen >= 2) {    /* the 8-row instantiation only (the four large levels: 85 % of the pixels) */
+    if (screen >= 2) {
         int nS, nAll;
         const h16x2 thIni = __builtin_bit_cast(h16x2, (uint32_t)iniTh * 0x00010001u);
         const uint32_t p0 = sample(thIni, nS, nAll);
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_cols(const FastCell* __restri
         }
     }
     bool plain = true;
-    if (RMAX == 8 && screen) {
+    if (screen) {
         int nS, nAll;
         const h16x2 thMin = __builtin_bit_cast(h16x2, (uint32_t)minTh * 0x00010001u);
         const uint32_t p0 = sample(thMin, nS, nAll);
@@ -1590,18 +1598,18 @@ hipError_t drfe_launch_orb(drfe_ctx* c, const uint8_t* d_gray, size_t frameStrid
     if (g.fastCols && !c->fastGeneric) {
         const int nSmall = g.fastColsSmall, nBig = g.totalCells - nSmall;
         if (nSmall > 0)
-            hipLaunchKernelGGL((k_fast_cells_cols<8>), dim3(nSmall, nframes), dim3(64), (size_t)fastc_lds_bytes(g.fastColsRows), s,
+            hipLaunchKernelGGL((k_fast_cells_cols<8>), dim3(nSmall, nframes), dim3(64), (size_t)fastc_lds_bytes(g.fastColsRows, 8 * 64), s,
                                c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems, g.iniTh, g.minTh, c->d_pyr, c->d_cand0,
-                               c->d_cand1, c->d_candCount, c->d_status, drfe_div_magic((uint32_t)nSmall), 0, c->fastScreen, fastc_list_off(g.fastColsRows));
+                               c->d_cand1, c->d_candCount, c->d_status, drfe_div_magic((uint32_t)nSmall), 0, c->fastScreen, fastc_list_off(g.fastColsRows), fastc_list_cap(g.fastColsRows, 8 * 64));
         if (nBig > 0) {
             prof_end(c, DRFE_STAGE_FAST, s);
             prof_begin(c, DRFE_STAGE_FAST_B, s);
         }
         if (nBig > 0)
             hipLaunchKernelGGL((k_fast_cells_cols<DRFE_FASTC_MAX_RPL>), dim3(nBig, nframes), dim3(64),
-                               (size_t)fastc_lds_bytes(g.fastColsRows), s, c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems,
+                               (size_t)fastc_lds_bytes(g.fastColsRows, DRFE_FASTC_MAX_RPL * 64), s, c->d_cells, g.nlevels, g.pyrSlotBytes, g.candSlotElems,
                                g.iniTh, g.minTh, c->d_pyr, c->d_cand0, c->d_cand1, c->d_candCount, c->d_status,
-                               drfe_div_magic((uint32_t)nBig), nSmall, c->fastScreen, fastc_list_off(g.fastColsRows));
+                               drfe_div_magic((uint32_t)nBig), nSmall, c->fastScreen, fastc_list_off(g.fastColsRows), fastc_list_cap(g.fastColsRows, DRFE_FASTC_MAX_RPL * 64));
         if (nBig > 0) prof_end(c, DRFE_STAGE_FAST_B, s);
         else prof_end(c, DRFE_STAGE_FAST, s);
     } else {
