@@ -43,6 +43,7 @@
 #define AHCD_HO_EX 4
 #define AHCD_HO_VALID (4 + AHCD_MAXEX)
 #define AHCD_HO_TP (4 + 2 * AHCD_MAXEX)
+#define AHCD_HO_LABELS (AHCD_HO_TP + 8)   /* 1: k_ahc_refine left the frame's raw labels, plane map and plane count for the k_ahc_labels_* kernels */
 #define GLOBAL_AS __attribute__((address_space(1)))
 
 namespace {
@@ -689,7 +690,7 @@ __device__ __forceinline__ void ahc_cluster_frame(const AhcDevFrame* __restrict_
     /* ---- hand over to k_ahc_refine: the extracted nodes, which of them kept blocks, the seeds' count, the graph's fill ---- */
     GLOBAL_AS int* ho = (GLOBAL_AS int*)F.handoff;
     for (int k = lane; k < nEx; k += 64) { ho[AHCD_HO_EX + k] = ex[k]; ho[AHCD_HO_VALID + k] = isValid[k]; }
-    if (lane == 0) { ho[0] = nEx; ho[1] = nRf; ho[2] = c.nNodes; ho[3] = c.poolUsed; out[0] = 0; out[1] = -1; }
+    if (lane == 0) { ho[0] = nEx; ho[1] = nRf; ho[2] = c.nNodes; ho[3] = c.poolUsed; ho[AHCD_HO_LABELS] = 0; out[0] = 0; out[1] = -1; }
 #ifdef AHC_PROFILE
     TP();
     if (lane == 0) for (int k = 0; k + 1 < tpi; k++) ho[AHCD_HO_TP + k] = (int)(tp[k + 1] - tp[k]);
@@ -719,7 +720,6 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
     __shared__ int ex[AHCD_MAXEX], ex2[AHCD_MAXEX], plidmap[AHCD_MAXEX];
     __shared__ uint8_t isValid[AHCD_MAXEX];
     __shared__ double plN[AHCD_MAXEX][3], plC[AHCD_MAXEX][3], plMse[AHCD_MAXEX];
-    __shared__ int counts[AHCD_MAXEX + 1], kcounts[AHCD_MAXEX + 1];
     __shared__ int8_t blkLds[HEAP];                           /* flood fill: 1 = the block is kept whole (its pixels are final) */
     const AhcDevFrame F = frames[blockIdx.x];
     const int lane = threadIdx.x;
@@ -734,7 +734,7 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
     c.heapSize = 0; c.status = 0; c.lane = lane; c.listCap = LIST; c.P = P;
     GLOBAL_AS int* out = (GLOBAL_AS int*)F.out;
     const GLOBAL_AS int* ho = (const GLOBAL_AS int*)F.handoff;
-    const int w = P.w, h = P.h, Nw = P.Nw, Nh = P.Nh, NB = P.NB, npx = w * h;
+    const int w = P.w, h = P.h, Nw = P.Nw, Nh = P.Nh, NB = P.NB;
     if (out[1] != -1) return;                                 /* k_ahc_cluster gave the frame back to the host */
     const int nEx = ho[0], nRf = ho[1];
     c.nNodes = ho[2]; c.poolUsed = ho[3];
@@ -889,7 +889,6 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
         }
         plidmap[i] = pm;
     }
-    for (int i = lane; i <= nFinal; i += 64) counts[i] = 0;
     GLOBAL_AS drfe_plane* planes = (GLOBAL_AS drfe_plane*)F.planes;
     for (int i = lane; i < nFinal; i += 64) {
         const int nd = ex2[i];
@@ -899,28 +898,94 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
     }
     fence();
     TP();
-    /* final plane per pixel, the label image, the member lists (raster order per plane) and each plane's cloud as Frame::ComputePlanes
-     * gathers it (src/Frame.cc:985-1000: float points of the members, those beyond max_point_dist left out) for k_voxel_grid */
-    GLOBAL_AS uint8_t* seg = (GLOBAL_AS uint8_t*)F.seg;
-    const double gfx = P.fx, gfy = P.fy, gcx = P.cx, gcy = P.cy, gfactor = P.factor;
-    const float maxPointDist = P.maxPointDist;
-    for (int i = lane; i <= nFinal; i += 64) kcounts[i] = 0;
+    /* final plane per pixel, the label image, the member lists (raster order per plane) and each plane's cloud are pure functions of
+     * what is in memory now - the raw labels, this map and the depth image: the k_ahc_labels_* kernels compute them with 128
+     * wavefronts per frame instead of this one (round 5; they were 5 of this kernel's 22 ms) */
+    {
+        GLOBAL_AS int* how = (GLOBAL_AS int*)F.handoff;
+        for (int i = lane; i < nEx; i += 64) how[AHCD_HO_EX + i] = plidmap[i];
+        fence();
+        if (lane == 0) how[AHCD_HO_LABELS] = 1;
+    }
+    TP();
+    if (lane == 0) { out[0] = nFinal; out[1] = 0; out[2] = rfTotal; out[3] = c.nNodes; }
+#ifdef AHC_PROFILE
+    /* phase times (100 MHz ticks) into the head of the flood-fill queue, which nobody reads any more */
+    if (lane == 0) {
+        for (int k = 0; k < 3; k++) c.rf[k] = (uint32_t)ho[AHCD_HO_TP + k];
+        for (int k = 0; k + 1 < tpi; k++) c.rf[3 + k] = (uint32_t)(tp[k + 1] - tp[k]);
+    }
+#endif
+}
+
+#ifdef AHC_REFINE_WAVES_PER_EU         /* experiment builds: cap the allocation (3 -> 168 VGPRs, 19 spilled) */
+#define AHC_REFINE_OCC __attribute__((amdgpu_waves_per_eu(AHC_REFINE_WAVES_PER_EU, AHC_REFINE_WAVES_PER_EU)))
+#else
+#define AHC_REFINE_OCC
+#endif
+extern "C" __global__ __launch_bounds__(64) AHC_REFINE_OCC void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    ahc_refine_frame<AHCD_HEAP_SMALL, AHCD_LIST_SMALL>(frames, P);
+}
+extern "C" __global__ __launch_bounds__(64) void k_ahc_refine_big(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    ahc_refine_frame<AHCD_HEAP_BIG, AHCD_LIST_BIG>(frames, P);
+}
+
+
+/* ---- labels, member lists, plane clouds: three small kernels behind k_ahc_refine -------------------------------------------------
+ * AHCL_NBLK wavefronts per frame, each on a contiguous range of pixels (raster order):
+ *   k_ahc_labels_count    final label of every pixel (raw label -> plane through the re-merge's map), the label image, and per range
+ *                         the number of members / of kept cloud points of every plane;
+ *   k_ahc_labels_prefix   one wavefront per frame: the ranges' counts into offsets (plane by plane, range by range), memberOff, jobs;
+ *   k_ahc_labels_scatter  member indices and cloud points of a range written from its offsets on: raster order per plane, exactly
+ *                         the single wavefront's lists (PlaneFitter's membership lists and Frame::ComputePlanes' gather,
+ *                         src/Frame.cc:985-1000).
+ * Scratch: the flood-fill queue, which nobody reads any more (behind the words the profile build keeps there). */
+#define AHCL_NBLK 128
+#define AHCL_STRIDE 128                  /* counts per range: one per final plane (<= planeCap < 128) */
+#define AHCL_SCRATCH 64                  /* first word of the scratch inside rf */
+__device__ __forceinline__ void ahcl_range(int npx, int b, int& k0, int& k1)
+{
+    const int per = (((npx + AHCL_NBLK - 1) / AHCL_NBLK) + 63) & ~63;
+    k0 = min(npx, b * per); k1 = min(npx, k0 + per);
+}
+
+extern "C" __global__ __launch_bounds__(64) void k_ahc_labels_count(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    __shared__ int plidmap[AHCD_MAXEX];
+    __shared__ int cnt[AHCL_STRIDE], kcnt[AHCL_STRIDE];
+    const AhcDevFrame F = frames[blockIdx.y];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const GLOBAL_AS int* out = (const GLOBAL_AS int*)F.out;
+    const GLOBAL_AS int* ho = (const GLOBAL_AS int*)F.handoff;
+    if (out[1] != 0 || ho[AHCD_HO_LABELS] != 1) return;
+    const int nFinal = out[0], nEx = ho[0];
+    const int w = P.w, npx = P.w * P.h;
+    for (int i = lane; i < nEx; i += 64) plidmap[i] = ho[AHCD_HO_EX + i];
+    for (int i = lane; i < AHCL_STRIDE; i += 64) { cnt[i] = 0; kcnt[i] = 0; }
     fence();
-    /* both passes fetch the next chunk's label and depth while they work on the current one: a chunk is a handful of ballots,
-     * and without the prefetch every chunk waits a full round trip for its two loads */
-    auto depth_at = [&](int k) -> uint16_t { const int row = k / w, col = k - row * w; return c.depth[(size_t)row * c.rowStride + col]; };
-    int rawNext = lane < npx ? (int)c.mem[lane] : -1;
-    uint16_t depNext = lane < npx ? depth_at(lane) : (uint16_t)0;
-    for (int base = 0; base < npx; base += 64) {
+    GLOBAL_AS int16_t* mem = (GLOBAL_AS int16_t*)F.membership;
+    GLOBAL_AS uint8_t* seg = (GLOBAL_AS uint8_t*)F.seg;
+    const GLOBAL_AS uint16_t* depth = (const GLOBAL_AS uint16_t*)F.depth;
+    const int rowStride = (int)F.rowStride;
+    const double gfactor = P.factor;
+    const float maxPointDist = P.maxPointDist;
+    auto depth_at = [&](int k) -> uint16_t { const int row = k / w, col = k - row * w; return depth[(size_t)row * rowStride + col]; };
+    int k0, k1;
+    ahcl_range(npx, b, k0, k1);
+    int rawNext = k0 + lane < k1 ? (int)mem[k0 + lane] : -1;
+    uint16_t depNext = k0 + lane < k1 ? depth_at(k0 + lane) : (uint16_t)0;
+    for (int base = k0; base < k1; base += 64) {
         const int k = base + lane;
         const int raw = rawNext;
         const uint16_t dep = depNext;
-        if (k + 64 < npx) { rawNext = c.mem[k + 64]; depNext = depth_at(k + 64); }
+        if (k + 64 < k1) { rawNext = mem[k + 64]; depNext = depth_at(k + 64); }
         int pl = -1;
         bool keep = false;
-        if (k < npx) {
+        if (k < k1) {
             pl = raw >= 0 ? plidmap[raw] : -1;
-            c.mem[k] = (int16_t)pl;
+            mem[k] = (int16_t)pl;
             seg[k] = (uint8_t)(pl + 1);
             if (pl >= 0) {
                 double z = (double)dep * gfactor;
@@ -935,28 +1000,89 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
             const int l = __builtin_ctzll(todo);
             const int v = rl_i(pl, l);
             const unsigned long long same = __ballot(pl == v);
-            if (lane == l) { counts[v + 1] += __popcll(same); kcounts[v + 1] += __popcll(same & kept); }
+            if (lane == l) { cnt[v] += __popcll(same); kcnt[v] += __popcll(same & kept); }
             todo &= ~same;
         }
     }
     fence();
+    GLOBAL_AS int* sc = (GLOBAL_AS int*)F.rf + AHCL_SCRATCH;
+    for (int v = lane; v < nFinal; v += 64) {
+        sc[(size_t)b * AHCL_STRIDE + v] = cnt[v];
+        sc[(size_t)(AHCL_NBLK + b) * AHCL_STRIDE + v] = kcnt[v];
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64) void k_ahc_labels_prefix(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    __shared__ int tot[AHCL_STRIDE + 1], ktot[AHCL_STRIDE + 1];
+    const AhcDevFrame F = frames[blockIdx.x];
+    const int lane = threadIdx.x;
+    const GLOBAL_AS int* out = (const GLOBAL_AS int*)F.out;
+    const GLOBAL_AS int* ho = (const GLOBAL_AS int*)F.handoff;
+    if (out[1] != 0 || ho[AHCD_HO_LABELS] != 1) return;
+    const int nFinal = out[0];
+    GLOBAL_AS int* sc = (GLOBAL_AS int*)F.rf + AHCL_SCRATCH;
+    /* range by range, for the lane's plane(s): a range's count becomes the number of the plane's members in the ranges before it */
+    for (int v = lane; v < nFinal; v += 64) {
+        int run = 0, krun = 0;
+        for (int b = 0; b < AHCL_NBLK; b++) {
+            const int x = sc[(size_t)b * AHCL_STRIDE + v], kx = sc[(size_t)(AHCL_NBLK + b) * AHCL_STRIDE + v];
+            sc[(size_t)b * AHCL_STRIDE + v] = run; sc[(size_t)(AHCL_NBLK + b) * AHCL_STRIDE + v] = krun;
+            run += x; krun += kx;
+        }
+        tot[v + 1] = run; ktot[v + 1] = krun;
+    }
+    if (lane == 0) { tot[0] = 0; ktot[0] = 0; }
+    fence();
     GLOBAL_AS int* memberOff = (GLOBAL_AS int*)F.memberOff;
-    GLOBAL_AS int* memberIdx = (GLOBAL_AS int*)F.memberIdx;
     GLOBAL_AS int* jobs = (GLOBAL_AS int*)F.jobs;
-    GLOBAL_AS float* pts = (GLOBAL_AS float*)F.pts;
     if (lane == 0) {
-        for (int i = 0; i < nFinal; i++) { counts[i + 1] += counts[i]; kcounts[i + 1] += kcounts[i]; }
-        for (int i = 0; i <= nFinal; i++) memberOff[i] = counts[i];
-        if (jobs) for (int i = 0; i < nFinal; i++) { jobs[2 * i] = F.ptsBase + kcounts[i]; jobs[2 * i + 1] = kcounts[i + 1] - kcounts[i]; }
+        for (int i = 0; i < nFinal; i++) { tot[i + 1] += tot[i]; ktot[i + 1] += ktot[i]; }
+        for (int i = 0; i <= nFinal; i++) memberOff[i] = tot[i];
+        if (jobs) for (int i = 0; i < nFinal; i++) { jobs[2 * i] = F.ptsBase + ktot[i]; jobs[2 * i + 1] = ktot[i + 1] - ktot[i]; }
     }
     fence();
-    rawNext = lane < npx ? (int)c.mem[lane] : -1;
-    depNext = lane < npx ? depth_at(lane) : (uint16_t)0;
-    for (int base = 0; base < npx; base += 64) {
+    /* where each plane's list / cloud starts: behind the ranges' tables */
+    for (int v = lane; v < nFinal; v += 64) {
+        sc[(size_t)(2 * AHCL_NBLK) * AHCL_STRIDE + v] = tot[v];
+        sc[(size_t)(2 * AHCL_NBLK + 1) * AHCL_STRIDE + v] = ktot[v];
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64) void k_ahc_labels_scatter(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
+{
+    __shared__ int counts[AHCL_STRIDE], kcounts[AHCL_STRIDE];
+    const AhcDevFrame F = frames[blockIdx.y];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const GLOBAL_AS int* out = (const GLOBAL_AS int*)F.out;
+    const GLOBAL_AS int* ho = (const GLOBAL_AS int*)F.handoff;
+    if (out[1] != 0 || ho[AHCD_HO_LABELS] != 1) return;
+    const int nFinal = out[0];
+    const int w = P.w, npx = P.w * P.h;
+    const GLOBAL_AS int* sc = (const GLOBAL_AS int*)F.rf + AHCL_SCRATCH;
+    for (int v = lane; v < nFinal; v += 64) {
+        counts[v] = sc[(size_t)(2 * AHCL_NBLK) * AHCL_STRIDE + v] + sc[(size_t)b * AHCL_STRIDE + v];
+        kcounts[v] = sc[(size_t)(2 * AHCL_NBLK + 1) * AHCL_STRIDE + v] + sc[(size_t)(AHCL_NBLK + b) * AHCL_STRIDE + v];
+    }
+    fence();
+    const GLOBAL_AS int16_t* mem = (const GLOBAL_AS int16_t*)F.membership;
+    const GLOBAL_AS uint16_t* depth = (const GLOBAL_AS uint16_t*)F.depth;
+    const int rowStride = (int)F.rowStride;
+    GLOBAL_AS int* memberIdx = (GLOBAL_AS int*)F.memberIdx;
+    GLOBAL_AS float* pts = (GLOBAL_AS float*)F.pts;
+    const double gfx = P.fx, gfy = P.fy, gcx = P.cx, gcy = P.cy, gfactor = P.factor;
+    const float maxPointDist = P.maxPointDist;
+    auto depth_at = [&](int k) -> uint16_t { const int row = k / w, col = k - row * w; return depth[(size_t)row * rowStride + col]; };
+    int k0, k1;
+    ahcl_range(npx, b, k0, k1);
+    int rawNext = k0 + lane < k1 ? (int)mem[k0 + lane] : -1;
+    uint16_t depNext = k0 + lane < k1 ? depth_at(k0 + lane) : (uint16_t)0;
+    for (int base = k0; base < k1; base += 64) {
         const int k = base + lane;
-        const int pl = k < npx ? rawNext : -1;
+        const int pl = k < k1 ? rawNext : -1;
         const uint16_t dep = depNext;
-        if (k + 64 < npx) { rawNext = c.mem[k + 64]; depNext = depth_at(k + 64); }
+        if (k + 64 < k1) { rawNext = mem[k + 64]; depNext = depth_at(k + 64); }
         bool keep = false;
         float X = 0.f, Y = 0.f, Z = 0.f;
         if (pl >= 0 && pts) {
@@ -989,29 +1115,6 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
         }
         wave_order();
     }
-    TP();
-    if (lane == 0) { out[0] = nFinal; out[1] = 0; out[2] = rfTotal; out[3] = c.nNodes; }
-#ifdef AHC_PROFILE
-    /* phase times (100 MHz ticks) into the head of the flood-fill queue, which nobody reads any more */
-    if (lane == 0) {
-        for (int k = 0; k < 3; k++) c.rf[k] = (uint32_t)ho[AHCD_HO_TP + k];
-        for (int k = 0; k + 1 < tpi; k++) c.rf[3 + k] = (uint32_t)(tp[k + 1] - tp[k]);
-    }
-#endif
-}
-
-#ifdef AHC_REFINE_WAVES_PER_EU         /* experiment builds: cap the allocation (3 -> 168 VGPRs, 19 spilled) */
-#define AHC_REFINE_OCC __attribute__((amdgpu_waves_per_eu(AHC_REFINE_WAVES_PER_EU, AHC_REFINE_WAVES_PER_EU)))
-#else
-#define AHC_REFINE_OCC
-#endif
-extern "C" __global__ __launch_bounds__(64) AHC_REFINE_OCC void k_ahc_refine(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
-{
-    ahc_refine_frame<AHCD_HEAP_SMALL, AHCD_LIST_SMALL>(frames, P);
-}
-extern "C" __global__ __launch_bounds__(64) void k_ahc_refine_big(const AhcDevFrame* __restrict__ frames, AhcDevParams P)
-{
-    ahc_refine_frame<AHCD_HEAP_BIG, AHCD_LIST_BIG>(frames, P);
 }
 
 int drfe_ahc_device_fits(int w, int h)
@@ -1022,7 +1125,7 @@ int drfe_ahc_device_fits(int w, int h)
 hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
-    static_assert(AHC_HANDOFF_INTS >= AHCD_HO_TP + 8, "handoff words");
+    static_assert(AHC_HANDOFF_INTS >= AHCD_HO_LABELS + 1, "handoff words");
     if (P.NB > AHCD_HEAP_BIG || (size_t)P.w * P.h > ((size_t)1 << AHCD_PIXBITS)) return hipErrorInvalidValue;
     if (P.NB <= AHCD_HEAP_SMALL) {
         hipLaunchKernelGGL(k_ahc_cluster, dim3(nframes), dim3(64), 0, s, d_frames, P);
@@ -1031,6 +1134,10 @@ hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, cons
         hipLaunchKernelGGL(k_ahc_cluster_big, dim3(nframes), dim3(64), 0, s, d_frames, P);
         hipLaunchKernelGGL(k_ahc_refine_big, dim3(nframes), dim3(64), 0, s, d_frames, P);
     }
+    if (P.planeCap >= AHCL_STRIDE || (size_t)P.rfCap < (size_t)AHCL_SCRATCH + (size_t)(2 * AHCL_NBLK + 2) * AHCL_STRIDE) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ahc_labels_count, dim3(AHCL_NBLK, nframes), dim3(64), 0, s, d_frames, P);
+    hipLaunchKernelGGL(k_ahc_labels_prefix, dim3(nframes), dim3(64), 0, s, d_frames, P);
+    hipLaunchKernelGGL(k_ahc_labels_scatter, dim3(AHCL_NBLK, nframes), dim3(64), 0, s, d_frames, P);
     return hipGetLastError();
 }
 
