@@ -22,6 +22,7 @@ struct LinesScratch {
     /* device region growing (batch entry): per slot the ordering keys / sorted ordering, member list, shrink scratch,
      * accepted rectangles, (count, status); the launch's frame table; pinned host mirrors */
     uint32_t* d_order; uint32_t* d_reg; uint32_t* d_tmp; struct LsdRect* d_rects; int* d_out; struct LsdGrowFrame* d_frames;
+    uint32_t* d_notdef;             /* one bit per scaled pixel: no level-line angle (k_lsd_notdef): the start of the growth kernels' `used` map */
     uint32_t* d_regMw; uint32_t* d_tmpMw; uint32_t* d_gbmMw; int regCapMw;      /* k_lsd_grow_mw: member list / shrink scratch of each of a frame's four wavefronts (regCapMw entries each) */
     int* d_ordStatus; int* h_ordStatus;   /* k_lsd_order's status word per slot */
     uint32_t* h_order; unsigned long long* h_meta; struct LsdRect* h_rects; int* h_out; struct LsdGrowFrame* h_frames;
@@ -96,6 +97,7 @@ struct LsdGrowFrame {
     const double* ang; const float2* cs; const double* mod;   /* W x H fields of k_ll_angle */
     const float2* cs0;                                        /* W x H: float(cos), float(sin) of the pixel's angle (k_lsd_keys): a region's first direction */
     const uint32_t* order;                                    /* keys bin << 22 | y << 11 | x in std::sort's order */
+    const uint32_t* notdef;                                   /* (W x H + 31) / 32 words, bit q set = pixel q has no angle (k_lsd_notdef); null: the growth kernel reads the angles itself */
     uint32_t* reg; uint32_t* tmp;                             /* W x H entries each: member list (y << 16 | x), shrink scratch */
     uint32_t* regMw; uint32_t* tmpMw;                         /* k_lsd_grow_mw: 4 x regCap entries each, one share per wavefront of the frame's workgroup */
     uint32_t* gbm;                                            /* k_lsd_grow_mw: a W x H bitmap in HBM, the overlay of a region too large for an LDS table */
@@ -106,7 +108,7 @@ struct LsdGrowFrame {
 size_t drfe_lsd_grow_lds_bytes(int W, int H);
 /* keys of nframes consecutive slots: d_mod / d_ang / d_meta / d_keys point at the first of them */
 hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
-                                float2* d_cs0, int nframes, hipStream_t s);
+                                float2* d_cs0, uint32_t* d_notdef, int nframes, hipStream_t s);
 /* std::sort's permutation of nframes key arrays (n keys each, keyStride apart) in place: introsort's moves on the device
  * (lsd_order_kernels.hip).  d_posL / d_posR: scratch of >= n entries per frame, posStride apart.  d_status[f * statusStride]:
  * 0, or 1 = a range ran out of introsort's depth limit (heap sort in libstdc++), 2 = internal queue overflow: order on the host. */

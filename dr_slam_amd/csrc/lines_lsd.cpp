@@ -589,7 +589,7 @@ static void scratch_free(LinesScratch*& s)
 {
     if (!s) return;
     void* ptrs[] = {s->d_img, s->d_blur, s->d_scaled, s->d_tmp16, s->d_modgrad, s->d_angles, s->d_cs, s->d_cs0, s->d_meta, s->d_gx, s->d_gy, s->d_cands, s->d_counts,
-                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_regMw, s->d_tmpMw, s->d_gbmMw, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus, s->d_segs, s->d_lgamma, s->d_kl, s->d_klLineF, s->d_klLbd, s->d_klDesc, s->d_klOut};
+                    s->d_lbdLines, s->d_lbdOut, s->d_order, s->d_reg, s->d_tmp, s->d_notdef, s->d_regMw, s->d_tmpMw, s->d_gbmMw, s->d_rects, s->d_out, s->d_frames, s->d_ordStatus, s->d_segs, s->d_lgamma, s->d_kl, s->d_klLineF, s->d_klLbd, s->d_klDesc, s->d_klOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {s->h_order, s->h_meta, s->h_rects, s->h_out, s->h_frames, s->h_ordStatus, s->h_cands, s->h_counts, s->h_segs, s->h_kl, s->h_klLineF, s->h_klDesc, s->h_klOut};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
@@ -657,6 +657,7 @@ static int ensure_lines(std::string& err, LinesScratch*& ls, int w, int h, int f
         LCHK(hipMalloc((void**)&s->d_reg, ns * 4));
         LCHK(hipMalloc((void**)&s->d_cs0, ns * 8));
         LCHK(hipMalloc((void**)&s->d_tmp, ns * 4));
+        LCHK(hipMalloc((void**)&s->d_notdef, (((size_t)s->sw * s->sh + 31) / 32) * 4 * F));
         /* the multi-wave growth: each of a frame's four wavefronts owns half a field's worth of member-list entries (a region
          * beyond that hands the frame to the host) */
         s->regCapMw = s->sw * s->sh / 2;
@@ -949,6 +950,7 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
         LsdGrowFrame& g = A->h_frames[f];
         g.ang = A->d_angles + ns * f; g.cs = A->d_cs + ns * f; g.cs0 = A->d_cs0 + ns * f; g.mod = A->d_modgrad + ns * f;
         g.order = A->d_order + nk * f; g.reg = A->d_reg + ns * f; g.tmp = A->d_tmp + ns * f;
+        g.notdef = A->d_notdef + ((ns + 31) / 32) * f;
         g.regMw = A->d_regMw + 4 * (size_t)A->regCapMw * f; g.tmpMw = A->d_tmpMw + 4 * (size_t)A->regCapMw * f;
         g.gbm = A->d_gbmMw + ((ns + 31) / 32) * f;
         g.rects = A->d_rects + (size_t)A->rectCap * f; g.out = A->d_out + DRFE_LSD_OUT_INTS * (size_t)f;
@@ -1258,7 +1260,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         if (tr) (void)hipEventRecord(J.stageEv[1], st);
         if (e == hipSuccess) e = drfe_launch_lines_passes(A->d_img + n * f0, w, h, P.lsdTaps, P.lbdTaps, A, f0, nf, P.rho, st);
         if (tr) (void)hipEventRecord(J.stageEv[2], st);
-        if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, A->d_cs0 + ns * f0, nf, st);
+        if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, A->d_cs0 + ns * f0, A->d_notdef + ((ns + 31) / 32) * f0, nf, st);
         if (tr) (void)hipEventRecord(J.stageEv[3], st);
         if (e == hipSuccess && !J.deviceOrder) {
             e = hipMemcpyAsync(A->h_order + nk * f0, A->d_order + nk * f0, nk * 4 * nf, hipMemcpyDeviceToHost, st);

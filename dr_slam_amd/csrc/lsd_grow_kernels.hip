@@ -700,7 +700,11 @@ extern "C" __global__ __launch_bounds__(64) LSD_GROW_OCC void k_lsd_grow(const L
     w.bm = lds;
     w.ring = lds + ((nWords + 1) & ~1);
     w.col = (double*)(w.ring + LSD_RING);
-    /* bitmap: pixels without a level-line angle never join (NOTDEF, incl. the last row and column) */
+    /* bitmap: pixels without a level-line angle never join (NOTDEF, incl. the last row and column).  k_lsd_notdef left the words
+     * (a wide kernel over all frames: this wavefront would spend 1.4 ms of its 73 reading 1.5 MB of angles for them) */
+    const GLOBAL_AS uint32_t* notdef = (const GLOBAL_AS uint32_t*)frames[blockIdx.x].notdef;
+    if (notdef) { for (int k = lane; k < nWords; k += 64) w.bm[k] = notdef[k]; }
+    else
     for (int base = 0; base < npx; base += 256) {
         bool nd[4];
 #pragma unroll
@@ -1245,6 +1249,9 @@ extern "C" __global__ __launch_bounds__(64 * MW_WAVES) __attribute__((amdgpu_wav
     C.S = S; C.T.tLo = tLo; C.T.tHi = tHi; C.prec = prec; C.p = p; C.densityTh = densityTh; C.minReg = minReg; C.rectCap = rectCap; C.W = W; C.H = H; C.lane = lane;
 
     /* bitmap: pixels without a level-line angle never join (NOTDEF, incl. the last row and column); the four waves side by side */
+    const GLOBAL_AS uint32_t* notdef = (const GLOBAL_AS uint32_t*)frames[blockIdx.x].notdef;
+    if (notdef) { for (int k = tid; k < nWords; k += 64 * MW_WAVES) w.bm[k] = notdef[k]; }
+    else
     for (int base = wave * 64; base < npx; base += 64 * MW_WAVES) {
         const int q = base + lane;
         const bool nd = q >= npx || w.F.ang[q] == -1024.0;
@@ -1431,10 +1438,25 @@ size_t drfe_lsd_grow_lds_bytes(int W, int H)
     return (((nWords + 1) & ~(size_t)1) + LSD_RING) * 4 + 64 * 3 * sizeof(double);
 }
 
+/* bit q of a frame's words = pixel q (row-major over the W x H field) has no level-line angle; bits past the field are set */
+__global__ __launch_bounds__(256) void k_lsd_notdef(const double* __restrict__ ang, int npx, int nWords, uint32_t* __restrict__ words)
+{
+    ang += (size_t)blockIdx.y * npx; words += (size_t)blockIdx.y * nWords;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool nd = q >= npx || ang[q] == -1024.0;
+    const unsigned long long b = __ballot(nd);
+    const int wd = (q & ~63) >> 5;
+    if ((threadIdx.x & 63) == 0) { if (wd < nWords) words[wd] = (uint32_t)b; if (wd + 1 < nWords) words[wd + 1] = (uint32_t)(b >> 32); }
+}
+
 hipError_t drfe_launch_lsd_keys(const double* d_mod, const double* d_ang, int W, int H, unsigned long long* d_meta, uint32_t* d_keys,
-                                float2* d_cs0, int nframes, hipStream_t s)
+                                float2* d_cs0, uint32_t* d_notdef, int nframes, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
+    if (d_notdef) {
+        const int npx = W * H, nWords = (npx + 31) >> 5;
+        hipLaunchKernelGGL(k_lsd_notdef, dim3((npx + 255) / 256, nframes), dim3(256), 0, s, d_ang, npx, nWords, d_notdef);
+    }
     hipLaunchKernelGGL(k_lsd_keys, dim3((W - 1 + 255) / 256, H - 1, nframes), dim3(256), 0, s, d_mod, d_ang, W, H, d_meta, d_keys, d_cs0);
     return hipGetLastError();
 }
