@@ -414,7 +414,7 @@ def full_frontend_roofline(frames_per_s: float, n_frames: int):
            "achieved": per_frame * frames_per_s / 1e9, "frac": per_frame * frames_per_s / 1e9 / HBM_PEAK_GBS,
            "limited_by": "latency chains: every frame's region growing / plane clustering / flood fill is an order-defined sequence on one or four wavefronts; "
                          "the rate is (frames resident) / (chain latency), and residency is bounded by LDS (a frame's `used` bitmap, queues, tables)"}
-    lanes = {"k_lsd_grow_mw": 0.625, "k_lsd_grow": 0.746, "k_plane_refit": 0.331, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.594, "k_voxel_grid": 0.589}
+    lanes = {"k_lsd_grow_mw": 0.625, "k_lsd_grow": 0.746, "k_plane_refit": 0.331, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.713, "k_voxel_grid": 0.589}
     kern = {}
     for path, stage in (("lines", "lsd_lbd"), ("planes", "ahc_planes")):
         f = os.path.join(ROOT, "profiles", "r05_kernel_stats_%s_batch512.csv" % path)
