@@ -402,7 +402,9 @@ __device__ __forceinline__ int grow(Wave& w, int sx, int sy, double prec, double
     PROF_ADD(4, tg1);
     /* only regions that get a second member need the seed's direction */
     if (n > 1 && rl_f32(win.s0.x, 24) != rl_f32(win.s0.x, 24)) w.status |= DRFE_LSD_STATUS_UNCERTAIN;
-    regAngleOut = angle_now();
+    /* the region's angle is region2rect's input: a region below the size its caller keeps (eighteen in twenty) never gets there, and
+     * its fastAtan2 - a division and a polynomial on the chain - is not computed */
+    regAngleOut = n >= minKeep ? angle_now() : 0.0;
     return n;
 }
 
