@@ -516,9 +516,20 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
             step(L, pool)
             step(L, pool)
 
+        step_ms, step_back = [], []
+
+        def handed_back(L):                           # frames the device handed back to the host so far, by stage (cumulative counters of the lane's contexts)
+            a = L["fe"].ctx.lsd_stats()
+            b = L["planes"].planes_refit_stats()
+            c = L["planes"].planes_ahc_stats()
+            return np.array([a["grow_to_host"], a["nfa_to_host"], a["keylines_to_host"], b["to_host"], c["to_host"], c["voxel_grids_to_host"]], np.int64)
+
         def run(k):
             for _ in range(reps):
+                h0, t = handed_back(lanes[k]), time.perf_counter()
                 nacc[k] = step(lanes[k], pool)
+                step_ms.append((time.perf_counter() - t) * 1e3)
+                step_back.append(handed_back(lanes[k]) - h0)
 
         th = [threading.Thread(target=run, args=(k,)) for k in range(inflight)]
         import ctypes
@@ -561,6 +572,16 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
                                                   "keyline_roundings_not_certified": lsd["keylines_to_host"]},
             "planes_frames_sent_to_the_host_refit": {"of_frames": refit["frames"], "refit_not_certified_or_grid_returned": refit["to_host"]},
             "stage_wall_ms_last_step": {k: round(v, 2) for k, v in lanes[0]["wall"].items()},
+            # the tail: wall time of one step (512 frames through every stage, `steps_in_flight` of them side by side) and what the device handed
+            # back to the host inside it - a frame whose refit / voxel grid / NFA decision could not be certified is redone on the pool's threads
+            # and the whole batch call waits for it
+            "step_wall_ms": {"p50": float(np.percentile(step_ms, 50)), "p95": float(np.percentile(step_ms, 95)), "p99": float(np.percentile(step_ms, 99)),
+                             "max": float(np.max(step_ms)), "steps": len(step_ms)},
+            "frames_handed_back_per_step": {k: {"mean": float(v.mean()), "max": int(v.max())} for k, v in zip(
+                ("lines_region_growing", "lines_nfa", "lines_keylines", "planes_refit", "planes_extractor", "planes_voxel_grid"), np.array(step_back).T)},
+            "step_wall_ms_with_and_without_hand_back": (lambda b, m: {"steps_with": int((b > 0).sum()), "median_with": float(np.median(m[b > 0])) if (b > 0).any() else None,
+                                                                       "median_without": float(np.median(m[b == 0])) if (b == 0).any() else None})(
+                np.array(step_back).sum(1), np.array(step_ms)),
             "roofline": full_frontend_roofline(total / el, n_frames),
             "planes_accepted_per_step": int(nacc[0]),
             "lines_path": "everything on the device: pixel ordering, region growing, region2rect, refine (k_lsd_order, k_lsd_grow: one wavefront per frame at this call size; k_lsd_grow_mw, four per frame, up to 256 frames per call), rect_improve + NFA "

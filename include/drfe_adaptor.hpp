@@ -6,8 +6,8 @@
  *   LineSegment::ExtractLineSegment    include/LSDextractor.h:342-350
  *   Planar_SLAM::PlaneDetection        include/PlaneExtractor.h:61-82
  *   Planar_SLAM::PlaneDetection_CAPE   include/PlaneExtractor.h:84-115
- *   Planar_SLAM::ORBmatcher (DescriptorDistance + the index-level SearchByProjection the MapPoint* overloads wrap)
- *   Planar_SLAM::LSDmatcher            include/LSDmatcher.h:19-50 (index level, like ORBmatcher)
+ *   Planar_SLAM::ORBmatcher            include/ORBmatcher.h:41-84  - the reference's thirteen signatures (templates over Frame / KeyFrame / MapPoint)
+ *   Planar_SLAM::LSDmatcher            include/LSDmatcher.h:21-36  - the reference's ten signatures (templates over Frame / KeyFrame / MapLine)
  * With -DDRFE_WITH_OPENCV the container types are OpenCV's (cv::Mat, cv::KeyPoint, cv::line_descriptor::KeyLine);
  * without it (this image has no OpenCV) minimal stand-ins with the same member names and memory layout are used, so the
  * header is compiled and exercised here (tests/native/adaptor_caller.cpp, run by tests/test_gpu_native.py).
@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <type_traits>
 #include <utility>
@@ -115,6 +116,8 @@ inline CtxPtr make_ctx(int nfeatures, float scaleFactor, int nlevels, int iniThF
     if (drfe_create(&cfg, &c) != DRFE_OK) throw std::runtime_error(std::string("drfe_create: ") + drfe_last_error(nullptr));
     return CtxPtr(c, CtxDeleter());
 }
+/* the context the calling thread's matchers / line extractor work on (ORBmatcher::BindThread, LSDmatcher::BindThread) */
+inline drfe_ctx*& thread_ctx() { static thread_local drfe_ctx* c = nullptr; return c; }
 }  // namespace drfe_detail
 
 /* include/ORBextractor.h:51-85 */
@@ -355,7 +358,7 @@ public:
     ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
     /* the calling thread's device (Tracking / LocalMapping / LoopClosing bind one each at start-up) */
-    static void BindThread(MatcherDevice* dev) { tls() = dev; }
+    static void BindThread(MatcherDevice* dev) { tls() = dev; drfe_detail::thread_ctx() = dev ? dev->ctx() : nullptr; }
     static MatcherDevice& Device()
     {
         if (!tls()) throw std::runtime_error("ORBmatcher: no MatcherDevice bound to this thread (ORBmatcher::BindThread)");
@@ -939,15 +942,362 @@ private:
     drfe_ctx* mCtx; float mK4[4] = {0, 0, 0, 0};
 };
 
-/* include/LSDmatcher.h:19-50: the parts that do not touch the MapLine graph.  The MapLine* / KeyFrame* overloads of the reference
- * flatten what their loops read (descriptor rows, key lines, `has a MapLine` flags, drfe_map_line / drfe_tracked_line /
- * drfe_frustum_line records - INTEGRATION.md section 3b) and call these; results come back as index arrays in the reference's
- * conventions. */
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * LSDmatcher (include/LSDmatcher.h:21-36, src/LSDmatcher.cpp) with the reference's ten signatures, the same way as ORBmatcher above:
+ * member templates over the frame / keyframe / map-line types that use only the member names src/LSDmatcher.cpp reads
+ *   Frame:    mTcw, fx fy cx cy mbf, mnMinX .. mnMaxY, NL, mvKeylinesUn, mLdesc, mvpMapLines, mvbLineOutlier
+ *   KeyFrame: fx fy cx cy mbf, mnMinX .. mnMaxY, mvKeyLines, mLineDescriptors, GetMapLineMatches(), GetMapLine(idx), GetMapLines(),
+ *             AddMapLine(pML, idx), GetPose(), mnId (through MapLine::GetIndexInKeyFrame)
+ *   MapLine:  isBad(), Observations(), GetWorldPos() (six doubles through operator()), GetNormal() (three), GetDescriptor(),
+ *             GetMinDistanceInvariance(), GetMaxDistanceInvariance(), GetIndexInKeyFrame(pKF), AddObservation(pKF, idx), Replace(pML),
+ *             mbTrackInView, mnTrackScaleLevel, mTrackViewCos, mTrackProjX1 / Y1 / X2 / Y2
+ * so they bind to Planar_SLAM::Frame, KeyFrame and MapLine as they are and to the stand-ins of tests/native/linematcher_caller.cpp.
+ * A line frame needs no device residency (a frame holds at most 40 key lines: they travel with the call), only a context: the one
+ * bound to the calling thread (LSDmatcher::BindThread, or ORBmatcher::BindThread's device).  mvScaleFactors / mfLogScaleFactor are
+ * the context's own tables (same ORB parameters as the frames': include/drfe.h drfe_orb_scale_tables).
+ * Every method flattens what the reference's loop reads through the pointers, calls the C entry point (projection, GetLinesInArea,
+ * Hamming distances, claim order: on the device), writes MapLine* back, and - Fuse - applies Replace / AddObservation / AddMapLine
+ * on the host in the reference's order, re-reading isBad() / GetMapLine() where the reference reads them. */
+namespace drfe_detail {
+template <class KL> inline drfe_keyline keyline_of(const KL& k)
+{
+    drfe_keyline o;
+    o.angle = k.angle; o.class_id = k.class_id; o.octave = k.octave; o.pt_x = k.pt.x; o.pt_y = k.pt.y; o.response = k.response; o.size = k.size;
+    o.start_point_x = k.startPointX; o.start_point_y = k.startPointY; o.end_point_x = k.endPointX; o.end_point_y = k.endPointY;
+    o.s_point_in_octave_x = k.sPointInOctaveX; o.s_point_in_octave_y = k.sPointInOctaveY;
+    o.e_point_in_octave_x = k.ePointInOctaveX; o.e_point_in_octave_y = k.ePointInOctaveY;
+    o.line_length = k.lineLength; o.num_of_pixels = k.numOfPixels;
+    return o;
+}
+template <class V> inline std::vector<drfe_keyline> keylines_of(const V& v)
+{
+    std::vector<drfe_keyline> o(v.size());
+    for (size_t i = 0; i < v.size(); i++) o[i] = keyline_of(v[i]);
+    return o;
+}
+/* what the projection loops read of a MapLine: GetWorldPos (Vector6d), GetNormal (Vector3d), the distance band, GetDescriptor */
+template <class ML> inline void frustum_line_of(ML* p, drfe_frustum_line& o, uint8_t* desc32)
+{
+    const auto P = p->GetWorldPos();
+    for (int k = 0; k < 6; k++) o.world[k] = P(k);
+    const auto Pn = p->GetNormal();
+    for (int k = 0; k < 3; k++) o.normal[k] = Pn(k);
+    o.min_distance = p->GetMinDistanceInvariance(); o.max_distance = p->GetMaxDistanceInvariance();
+    const auto d = p->GetDescriptor(); std::memcpy(desc32, d.data, 32);
+}
+}  // namespace drfe_detail
+
 class LSDmatcher {
 public:
     static const int TH_HIGH = 100, TH_LOW = 50;                          /* src/LSDmatcher.cpp:13-14 */
     LSDmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
+    /* the calling thread's context: once per thread that constructs line matchers (ORBmatcher::BindThread does it too) */
+    static void BindThread(drfe_ctx* ctx) { drfe_detail::thread_ctx() = ctx; }
+    static drfe_ctx* Context()
+    {
+        drfe_ctx* c = drfe_detail::thread_ctx();
+        if (!c) throw std::runtime_error("LSDmatcher: no context bound to this thread (LSDmatcher::BindThread / ORBmatcher::BindThread)");
+        return c;
+    }
+
+    /* ---- src/LSDmatcher.cpp:242-279 - Tracking::TrackReferenceKeyFrame / TrackWithMotionModel / Relocalization
+     * (src/Tracking.cc:2189, :2323, :2445, :2572) ---- */
+    template <class KeyFrameT, class FrameT, class MapLineT>
+    typename std::enable_if<std::is_class<FrameT>::value, int>::type
+    SearchByDescriptor(KeyFrameT* pKF, FrameT& currentF, std::vector<MapLineT*>& vpMapLineMatches)
+    {
+        drfe_ctx* c = Context();
+        const std::vector<MapLineT*> vpMapLinesKF = pKF->GetMapLineMatches();
+        vpMapLineMatches = std::vector<MapLineT*>((size_t)currentF.NL, static_cast<MapLineT*>(nullptr));
+        const int nq = pKF->mLineDescriptors.rows, nt = currentF.mLdesc.rows;
+        std::vector<uint8_t> has((size_t)nq, 0);
+        for (int q = 0; q < nq && q < (int)vpMapLinesKF.size(); q++) has[(size_t)q] = vpMapLinesKF[(size_t)q] != nullptr;
+        std::vector<int32_t> m((size_t)nt, -1);
+        int n = 0;
+        drfe_detail::check(drfe_lsd_search_by_descriptor(c, drfe_detail::u8(pKF->mLineDescriptors), nq, drfe_detail::u8(currentF.mLdesc), nt, has.data(), 0,
+                                                         m.data(), &n), c, "drfe_lsd_search_by_descriptor");
+        for (int t = 0; t < nt && t < (int)vpMapLineMatches.size(); t++) if (m[(size_t)t] >= 0) vpMapLineMatches[(size_t)t] = vpMapLinesKF[(size_t)m[(size_t)t]];
+        return n;
+    }
+
+    /* ---- src/LSDmatcher.cpp:281-314 ---- */
+    template <class KeyFrameT, class MapLineT>
+    int SearchByDescriptor(KeyFrameT* pKF, KeyFrameT* pKF2, std::vector<MapLineT*>& vpMapLineMatches)
+    {
+        drfe_ctx* c = Context();
+        const std::vector<MapLineT*> vpMapLinesKF = pKF->GetMapLineMatches();
+        const std::vector<MapLineT*> vpMapLinesKF2 = pKF2->GetMapLineMatches();
+        vpMapLineMatches = std::vector<MapLineT*>(vpMapLinesKF.size(), static_cast<MapLineT*>(nullptr));
+        const int nq = pKF->mLineDescriptors.rows, nt = pKF2->mLineDescriptors.rows;
+        std::vector<uint8_t> has((size_t)nt, 0);
+        for (int t = 0; t < nt && t < (int)vpMapLinesKF2.size(); t++) has[(size_t)t] = vpMapLinesKF2[(size_t)t] != nullptr;
+        std::vector<int32_t> m((size_t)nq, -1);
+        int n = 0;
+        drfe_detail::check(drfe_lsd_search_by_descriptor(c, drfe_detail::u8(pKF->mLineDescriptors), nq, drfe_detail::u8(pKF2->mLineDescriptors), nt, has.data(), 1,
+                                                         m.data(), &n), c, "drfe_lsd_search_by_descriptor");
+        for (int q = 0; q < nq && q < (int)vpMapLineMatches.size(); q++) if (m[(size_t)q] >= 0) vpMapLineMatches[(size_t)q] = vpMapLinesKF2[(size_t)m[(size_t)q]];
+        return n;
+    }
+
+    /* ---- src/LSDmatcher.cpp:20-139 - the motion-model search of the line tracker ---- */
+    template <class FrameT, class LastT>
+    typename std::enable_if<std::is_class<LastT>::value, int>::type
+    SearchByProjection(FrameT& CurrentFrame, const LastT& LastFrame, const float th, const bool bMono)
+    {
+        drfe_ctx* c = Context();
+        const int nl = (int)LastFrame.NL, nc = (int)CurrentFrame.mvKeylinesUn.size();
+        std::vector<drfe_map_line> ml((size_t)nl);
+        for (int i = 0; i < nl; i++) {
+            auto* p = LastFrame.mvpMapLines[(size_t)i];
+            drfe_map_line& r = ml[(size_t)i];
+            std::memset(&r, 0, sizeof(r));
+            r.valid = p && !p->isBad() && !LastFrame.mvbLineOutlier[(size_t)i];
+            if (!r.valid) continue;
+            r.octave = LastFrame.mvKeylinesUn[(size_t)i].octave;
+            r.obs_positive = p->Observations() > 0;
+            const auto P = p->GetWorldPos();
+            for (int k = 0; k < 6; k++) r.world[k] = P(k);
+            const auto d = p->GetDescriptor(); std::memcpy(r.desc, d.data, 32);
+        }
+        const std::vector<drfe_keyline> kl = drfe_detail::keylines_of(CurrentFrame.mvKeylinesUn);
+        /* claims the frame already holds: any index >= nl (a new match is an index into LastFrame) */
+        std::vector<int32_t> claim((size_t)nc);
+        std::vector<uint8_t> obs((size_t)nc);
+        for (int i = 0; i < nc; i++) { auto* p = CurrentFrame.mvpMapLines[(size_t)i]; claim[(size_t)i] = p ? nl + i : -1; obs[(size_t)i] = p && p->Observations() > 0; }
+        const drfe_camera cam = drfe_detail::camera_of(CurrentFrame);
+        int n = 0;
+        drfe_detail::check(drfe_lsd_search_by_projection_last(c, drfe_detail::f32(CurrentFrame.mTcw), drfe_detail::f32(LastFrame.mTcw), &cam, ml.data(), nl, kl.data(),
+                                                              drfe_detail::u8(CurrentFrame.mLdesc), nc, th, bMono ? 1 : 0, mfNNratio, obs.data(), claim.data(), &n), c,
+                           "drfe_lsd_search_by_projection_last");
+        for (int i = 0; i < nc; i++) if (claim[(size_t)i] >= 0 && claim[(size_t)i] < nl) CurrentFrame.mvpMapLines[(size_t)i] = LastFrame.mvpMapLines[(size_t)claim[(size_t)i]];
+        return n;
+    }
+
+    /* ---- src/LSDmatcher.cpp:141-211 - the local map's lines into the frame, after Frame::isInFrustum(MapLine*) ---- */
+    template <class FrameT, class MapLineT>
+    int SearchByProjection(FrameT& F, const std::vector<MapLineT*>& vpMapLines, const float th = 3)
+    {
+        drfe_ctx* c = Context();
+        const int m = (int)vpMapLines.size(), nc = (int)F.mvKeylinesUn.size();
+        std::vector<drfe_tracked_line> tl((size_t)m);
+        for (int i = 0; i < m; i++) {
+            MapLineT* p = vpMapLines[(size_t)i];
+            drfe_tracked_line& t = tl[(size_t)i];
+            std::memset(&t, 0, sizeof(t));
+            t.in_view = p && !p->isBad() && p->mbTrackInView;
+            if (!t.in_view) continue;
+            t.level = p->mnTrackScaleLevel; t.obs_positive = p->Observations() > 0;
+            t.x1 = p->mTrackProjX1; t.y1 = p->mTrackProjY1; t.x2 = p->mTrackProjX2; t.y2 = p->mTrackProjY2; t.view_cos = p->mTrackViewCos;
+            const auto d = p->GetDescriptor(); std::memcpy(t.desc, d.data, 32);
+        }
+        const std::vector<drfe_keyline> kl = drfe_detail::keylines_of(F.mvKeylinesUn);
+        std::vector<int32_t> claim((size_t)nc);
+        std::vector<uint8_t> obs((size_t)nc);
+        for (int i = 0; i < nc; i++) { auto* p = F.mvpMapLines[(size_t)i]; claim[(size_t)i] = p ? m + i : -1; obs[(size_t)i] = p && p->Observations() > 0; }
+        int n = 0;
+        drfe_detail::check(drfe_lsd_search_by_projection_map(c, tl.data(), m, kl.data(), drfe_detail::u8(F.mLdesc), nc, th, mfNNratio, obs.data(), claim.data(), &n), c,
+                           "drfe_lsd_search_by_projection_map");
+        for (int i = 0; i < nc; i++) if (claim[(size_t)i] >= 0 && claim[(size_t)i] < m) F.mvpMapLines[(size_t)i] = vpMapLines[(size_t)claim[(size_t)i]];
+        return n;
+    }
+
+    /* ---- src/LSDmatcher.cpp:377-502 - a keyframe against the lines of a loop candidate's neighbourhood ---- */
+    template <class KeyFrameT, class MatT, class MapLineT>
+    int SearchByProjection(KeyFrameT* pKF, MatT Scw, const std::vector<MapLineT*>& vpLines, std::vector<MapLineT*>& vpMatched, int th)
+    {
+        drfe_ctx* c = Context();
+        const int n = (int)vpLines.size(), nk = (int)pKF->mvKeyLines.size();
+        if ((int)vpMatched.size() < nk) throw std::runtime_error("LSDmatcher::SearchByProjection: vpMatched must hold one entry per key line of pKF");
+        std::set<MapLineT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapLineT*>(nullptr));
+        std::vector<drfe_frustum_line> fl((size_t)n);
+        std::vector<uint8_t> descs((size_t)n * 32), skip((size_t)n), matched((size_t)nk);
+        for (int i = 0; i < n; i++) {
+            MapLineT* p = vpLines[(size_t)i];
+            std::memset(&fl[(size_t)i], 0, sizeof(drfe_frustum_line));
+            skip[(size_t)i] = !p || p->isBad() || spAlreadyFound.count(p);
+            if (!skip[(size_t)i]) drfe_detail::frustum_line_of(p, fl[(size_t)i], descs.data() + 32 * (size_t)i);
+        }
+        for (int k = 0; k < nk; k++) matched[(size_t)k] = vpMatched[(size_t)k] != nullptr;
+        const std::vector<drfe_keyline> kl = drfe_detail::keylines_of(pKF->mvKeyLines);
+        const drfe_camera cam = drfe_detail::camera_of(*pKF);
+        std::vector<int32_t> nm((size_t)nk, -1);
+        int cnt = 0;
+        drfe_detail::check(drfe_lsd_search_by_projection_kf(c, drfe_detail::f32(Scw), &cam, fl.data(), descs.data(), skip.data(), n, kl.data(),
+                                                            drfe_detail::u8(pKF->mLineDescriptors), nk, matched.data(), th, nm.data(), &cnt), c,
+                           "drfe_lsd_search_by_projection_kf");
+        for (int k = 0; k < nk; k++) if (nm[(size_t)k] >= 0) vpMatched[(size_t)k] = vpLines[(size_t)nm[(size_t)k]];
+        return cnt;
+    }
+
+    /* ---- src/LSDmatcher.cpp:504-748 ---- */
+    template <class KeyFrameT, class MapLineT, class MatT>
+    int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapLineT*>& vpMatches12, const float& s12, const MatT& R12, const MatT& t12, const float th)
+    {
+        drfe_ctx* c = Context();
+        const std::vector<MapLineT*> vp1 = pKF1->GetMapLineMatches(), vp2 = pKF2->GetMapLineMatches();
+        const int N1 = (int)vp1.size(), N2 = (int)vp2.size();
+        if ((int)pKF1->mvKeyLines.size() != N1 || (int)pKF2->mvKeyLines.size() != N2)
+            throw std::runtime_error("LSDmatcher::SearchBySim3: GetMapLineMatches() must hold one entry per key line");
+        std::vector<uint8_t> skip1((size_t)N1, 0), skip2((size_t)N2, 0);
+        for (int i = 0; i < N1; i++) {                                     /* :533-543 */
+            MapLineT* p = vpMatches12[(size_t)i];
+            if (p) {
+                skip1[(size_t)i] = 1;
+                const int idx2 = p->GetIndexInKeyFrame(pKF2);
+                if (idx2 >= 0 && idx2 < N2) skip2[(size_t)idx2] = 1;
+            }
+        }
+        std::vector<drfe_frustum_line> f1((size_t)N1), f2((size_t)N2);
+        std::vector<uint8_t> d1((size_t)N1 * 32), d2((size_t)N2 * 32);
+        for (int i = 0; i < N1; i++) {
+            MapLineT* p = vp1[(size_t)i];
+            std::memset(&f1[(size_t)i], 0, sizeof(drfe_frustum_line));
+            if (!p || p->isBad()) skip1[(size_t)i] = 1;
+            if (!skip1[(size_t)i]) drfe_detail::frustum_line_of(p, f1[(size_t)i], d1.data() + 32 * (size_t)i);
+        }
+        for (int i = 0; i < N2; i++) {
+            MapLineT* p = vp2[(size_t)i];
+            std::memset(&f2[(size_t)i], 0, sizeof(drfe_frustum_line));
+            if (!p || p->isBad()) skip2[(size_t)i] = 1;
+            if (!skip2[(size_t)i]) drfe_detail::frustum_line_of(p, f2[(size_t)i], d2.data() + 32 * (size_t)i);
+        }
+        const std::vector<drfe_keyline> kl1 = drfe_detail::keylines_of(pKF1->mvKeyLines), kl2 = drfe_detail::keylines_of(pKF2->mvKeyLines);
+        const auto T1w = pKF1->GetPose();
+        const auto T2w = pKF2->GetPose();
+        const drfe_camera cam = drfe_detail::camera_of(*pKF1);
+        std::vector<int32_t> m12((size_t)N1, -1);
+        int nFound = 0;
+        drfe_detail::check(drfe_lsd_search_by_sim3(c, &cam, drfe_detail::f32(T1w), drfe_detail::f32(T2w), s12, drfe_detail::f32(R12), drfe_detail::f32(t12), f1.data(),
+                                                   d1.data(), skip1.data(), kl1.data(), drfe_detail::u8(pKF1->mLineDescriptors), N1, f2.data(), d2.data(), skip2.data(),
+                                                   kl2.data(), drfe_detail::u8(pKF2->mLineDescriptors), N2, th, m12.data(), &nFound), c, "drfe_lsd_search_by_sim3");
+        for (int i1 = 0; i1 < N1; i1++) if (m12[(size_t)i1] >= 0) vpMatches12[(size_t)i1] = vp2[(size_t)m12[(size_t)i1]];
+        return nFound;
+    }
+
+    /* ---- src/LSDmatcher.cpp:213-240 - Tracking::MonocularInitialization (src/Tracking.cc:1697); the reference spells it "Serach" ---- */
+    template <class FrameT>
+    typename std::enable_if<std::is_class<FrameT>::value, int>::type
+    SerachForInitialize(FrameT& InitialFrame, FrameT& CurrentFrame, std::vector<std::pair<int, int>>& LineMatches)
+    {
+        drfe_ctx* c = Context();
+        LineMatches.clear();
+        const int nq = InitialFrame.mLdesc.rows, nt = CurrentFrame.mLdesc.rows;
+        std::vector<int32_t> m((size_t)nq, -1);
+        int n = 0;
+        drfe_detail::check(drfe_lsd_search_by_descriptor(c, drfe_detail::u8(InitialFrame.mLdesc), nq, drfe_detail::u8(CurrentFrame.mLdesc), nt, nullptr, 1, m.data(), &n), c,
+                           "drfe_lsd_search_by_descriptor");
+        for (int q = 0; q < nq; q++) if (m[(size_t)q] >= 0) LineMatches.push_back(std::make_pair(q, (int)m[(size_t)q]));
+        return n;
+    }
+
+    /* ---- src/LSDmatcher.cpp:334-367 - LocalMapping::CreateNewMapLines (src/LocalMapping.cc:606, :858) ---- */
+    template <class KeyFrameT>
+    typename std::enable_if<std::is_class<KeyFrameT>::value, int>::type
+    SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs)
+    {
+        drfe_ctx* c = Context();
+        vMatchedPairs.clear();
+        const int n1 = pKF1->mLineDescriptors.rows, n2 = pKF2->mLineDescriptors.rows;
+        std::vector<uint8_t> has1((size_t)n1), has2((size_t)n2);
+        for (int i = 0; i < n1; i++) has1[(size_t)i] = pKF1->GetMapLine((size_t)i) != nullptr;
+        for (int i = 0; i < n2; i++) has2[(size_t)i] = pKF2->GetMapLine((size_t)i) != nullptr;
+        std::vector<int32_t> m((size_t)n1, -1);
+        int n = 0;
+        drfe_detail::check(drfe_lsd_search_for_triangulation(c, drfe_detail::u8(pKF1->mLineDescriptors), n1, drfe_detail::u8(pKF2->mLineDescriptors), n2, has1.data(),
+                                                             has2.data(), m.data(), &n), c, "drfe_lsd_search_for_triangulation");
+        for (int i = 0; i < n1; i++) if (m[(size_t)i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m[(size_t)i]));
+        return n;
+    }
+
+    /* ---- src/LSDmatcher.cpp:884-1015 - LocalMapping::SearchInNeighbors (src/LocalMapping.cc:1103, :1124).  The search of every line on
+     * the device (it reads the keyframe's key lines and descriptors, never its MapLine assignments); the loop that applies it runs here
+     * in the reference's order and re-reads isBad() / GetMapLine() at each step: an earlier Replace or AddMapLine of this very loop
+     * changes what a later line meets (:907, :995).  A predicted level outside the pyramid (the reference reads mvScaleFactors out of
+     * bounds there) fuses nothing. ---- */
+    template <class KeyFrameT, class MapLineT>
+    int Fuse(KeyFrameT* pKF, const std::vector<MapLineT*>& vpMapLines, const float th = 3.0)
+    {
+        drfe_ctx* c = Context();
+        const int n = (int)vpMapLines.size(), nk = (int)pKF->mvKeyLines.size();
+        std::vector<drfe_frustum_line> fl((size_t)n);
+        std::vector<uint8_t> descs((size_t)n * 32), skip((size_t)n);
+        for (int i = 0; i < n; i++) {
+            MapLineT* p = vpMapLines[(size_t)i];
+            std::memset(&fl[(size_t)i], 0, sizeof(drfe_frustum_line));
+            skip[(size_t)i] = !p || p->isBad();
+            if (!skip[(size_t)i]) drfe_detail::frustum_line_of(p, fl[(size_t)i], descs.data() + 32 * (size_t)i);
+        }
+        const std::vector<drfe_keyline> kl = drfe_detail::keylines_of(pKF->mvKeyLines);
+        const drfe_camera cam = drfe_detail::camera_of(*pKF);
+        const auto Tcw = pKF->GetPose();
+        std::vector<int32_t> bestIdx((size_t)n, -1), bestDist((size_t)n, 0);
+        drfe_detail::check(drfe_lsd_fuse_search(c, drfe_detail::f32(Tcw), &cam, fl.data(), descs.data(), skip.data(), n, kl.data(), drfe_detail::u8(pKF->mLineDescriptors),
+                                                nk, th, bestIdx.data(), bestDist.data()), c, "drfe_lsd_fuse_search");
+        int nFused = 0;
+        for (int i = 0; i < n; i++) {
+            MapLineT* pML = vpMapLines[(size_t)i];
+            if (!pML || pML->isBad()) continue;
+            if (bestIdx[(size_t)i] < 0 || bestDist[(size_t)i] > TH_LOW) continue;
+            MapLineT* pMLinKF = pKF->GetMapLine((size_t)bestIdx[(size_t)i]);
+            if (pMLinKF) {
+                if (!pMLinKF->isBad()) {
+                    if (pMLinKF->Observations() > pML->Observations()) pML->Replace(pMLinKF);
+                    else pMLinKF->Replace(pML);
+                }
+            } else {
+                pML->AddObservation(pKF, (size_t)bestIdx[(size_t)i]);
+                pKF->AddMapLine(pML, (size_t)bestIdx[(size_t)i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    /* ---- src/LSDmatcher.cpp:750-882 ---- */
+    template <class KeyFrameT, class MatT, class MapLineT>
+    int Fuse(KeyFrameT* pKF, MatT Scw, const std::vector<MapLineT*>& vpLines, float th, std::vector<MapLineT*>& vpReplaceLine)
+    {
+        drfe_ctx* c = Context();
+        const std::set<MapLineT*> spAlreadyFound = pKF->GetMapLines();
+        const int n = (int)vpLines.size(), nk = (int)pKF->mvKeyLines.size();
+        std::vector<drfe_frustum_line> fl((size_t)n);
+        std::vector<uint8_t> descs((size_t)n * 32), skip((size_t)n);
+        for (int i = 0; i < n; i++) {
+            MapLineT* p = vpLines[(size_t)i];
+            std::memset(&fl[(size_t)i], 0, sizeof(drfe_frustum_line));
+            skip[(size_t)i] = !p || p->isBad() || spAlreadyFound.count(p);
+            if (!skip[(size_t)i]) drfe_detail::frustum_line_of(p, fl[(size_t)i], descs.data() + 32 * (size_t)i);
+        }
+        const std::vector<drfe_keyline> kl = drfe_detail::keylines_of(pKF->mvKeyLines);
+        const drfe_camera cam = drfe_detail::camera_of(*pKF);
+        std::vector<int32_t> bestIdx((size_t)n, -1), bestDist((size_t)n, 0);
+        drfe_detail::check(drfe_lsd_fuse_search_sim3(c, drfe_detail::f32(Scw), &cam, fl.data(), descs.data(), skip.data(), n, kl.data(), drfe_detail::u8(pKF->mLineDescriptors),
+                                                     nk, th, bestIdx.data(), bestDist.data()), c, "drfe_lsd_fuse_search_sim3");
+        int nFused = 0;
+        for (int i = 0; i < n; i++) {
+            if (skip[(size_t)i] || bestIdx[(size_t)i] < 0 || bestDist[(size_t)i] > TH_LOW) continue;
+            MapLineT* pML = vpLines[(size_t)i];
+            MapLineT* pMLinKF = pKF->GetMapLine((size_t)bestIdx[(size_t)i]);
+            if (pMLinKF) {
+                if (!pMLinKF->isBad()) vpReplaceLine[(size_t)i] = pMLinKF;
+            } else {
+                pML->AddObservation(pKF, (size_t)bestIdx[(size_t)i]);
+                pKF->AddMapLine(pML, (size_t)bestIdx[(size_t)i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    /* src/LSDmatcher.cpp:316-332 on two 1 x 32 CV_8U rows */
+    template <class MatT>
+    static typename std::enable_if<std::is_class<MatT>::value, int>::type
+    DescriptorDistance(const MatT& a, const MatT& b) { return DescriptorDistance(drfe_detail::u8(a), drfe_detail::u8(b)); }
+
+    /* ---- flat forms (descriptor rows / key lines / records handed over directly: what the templates above call, for callers that
+     * hold the flattened data already - tests/native/members_caller.cpp) ---- */
     /* SearchByDescriptor(KeyFrame* pKF, Frame& currentF, vpMapLineMatches), src/LSDmatcher.cpp:242-279: descKF / descF = the LBD rows,
      * kfHasLine[i] = pKF's line i has a MapLine; matches[line of currentF] = line of pKF or -1 */
     int SearchByDescriptor(drfe_ctx* ctx, const drfe_cv::Mat& descKF, const std::vector<uint8_t>& kfHasLine, const drfe_cv::Mat& descF,
@@ -1037,22 +1387,38 @@ protected:
 
 }  // namespace Planar_SLAM
 
-/* include/LSDextractor.h:342-350 (global namespace in the reference) */
+/* include/LSDextractor.h:342-350 (global namespace in the reference).
+ * The reference reaches this class through `LineSegment* mpLineSegment` (include/Frame.h:157), a member no constructor ever
+ * initialises: `mpLineSegment->ExtractLineSegment(...)` (src/Frame.cc:241) works there only because the method touches no member.
+ * The same holds here: ExtractLineSegment reads NO member of `this` - the object is default-constructible and empty - and takes its
+ * context from the calling thread's binding (LineSegment::BindThread, LSDmatcher::BindThread or ORBmatcher::BindThread), else from
+ * the process-wide one (LineSegment::BindProcess: Frame::Frame starts a fresh thread for ExtractLSD on every frame, src/Frame.cc:129,
+ * which has no binding of its own; calls through the process-wide context are serialised). */
 class LineSegment {
 public:
-    explicit LineSegment(drfe_ctx* ctx) : mCtx(ctx) {}
+    LineSegment() {}
+    explicit LineSegment(drfe_ctx* ctx) { BindThread(ctx); }
+    static void BindThread(drfe_ctx* ctx) { Planar_SLAM::drfe_detail::thread_ctx() = ctx; }
+    static void BindProcess(drfe_ctx* ctx) { std::lock_guard<std::mutex> g(process_mutex()); process_ctx() = ctx; }
     /* keylineFunctions[i] = normalised sp x ep: std::vector<Eigen::Vector3d> as in the reference (include/LSDextractor.h:349) when
      * built with -DDRFE_WITH_EIGEN, the three-double stand-in with the same element access otherwise */
     void ExtractLineSegment(const drfe_cv::Mat& img, std::vector<drfe_cv::KeyLine>& keylines, drfe_cv::Mat& ldesc,
                             std::vector<drfe_cv::Vector3d>& keylineFunctions, float /*scale*/ = 1.2f, int /*numOctaves*/ = 1)
     {
+        drfe_ctx* ctx = Planar_SLAM::drfe_detail::thread_ctx();
+        std::unique_lock<std::mutex> guard;
+        if (!ctx) {
+            guard = std::unique_lock<std::mutex>(process_mutex());
+            ctx = process_ctx();
+            if (!ctx) throw std::runtime_error("LineSegment: no context bound (LineSegment::BindThread / BindProcess)");
+        }
         const int cap = 40;                                            /* lsdNFeatures, src/LSDextractor.cpp:20-28 */
         std::vector<drfe_keyline> kl(cap);
         drfe_cv::Mat desc = drfe_cv::mat_u8(cap, 32);
         std::vector<double> lf(3 * cap);
         int n = 0, found = 0;
-        Planar_SLAM::drfe_detail::check(drfe_lsd_extract(mCtx, drfe_cv::mat_data(img), img.cols, img.rows, drfe_cv::mat_step(img), cap,
-                                                         kl.data(), desc.data, lf.data(), cap, &n, &found), mCtx, "drfe_lsd_extract");
+        Planar_SLAM::drfe_detail::check(drfe_lsd_extract(ctx, drfe_cv::mat_data(img), img.cols, img.rows, drfe_cv::mat_step(img), cap,
+                                                         kl.data(), desc.data, lf.data(), cap, &n, &found), ctx, "drfe_lsd_extract");
         keylines.resize(n);
         keylineFunctions.clear();
         for (int i = 0; i < n; i++) {
@@ -1069,7 +1435,8 @@ public:
         if (n) std::memcpy(ldesc.data, desc.data, (size_t)n * 32);
     }
 private:
-    drfe_ctx* mCtx;
+    static drfe_ctx*& process_ctx() { static drfe_ctx* c = nullptr; return c; }
+    static std::mutex& process_mutex() { static std::mutex m; return m; }
 };
 
 #endif /* DRFE_ADAPTOR_HPP */

@@ -428,3 +428,310 @@ def test_cpp_orbmatcher_thirteen_methods(frames_room, tmp_path):
         assert recs[12][0] == int(np.unpackbits(mp_desc[0] ^ mp_desc[-1]).sum()) and recs[12][1][0] >= 8
     finally:
         fe.ctx.close()
+
+
+def test_cpp_lsdmatcher_ten_methods(frames_room, tmp_path):
+    """tests/native/linematcher_caller.cpp: Planar_SLAM::LSDmatcher with the reference's ten signatures (include/LSDmatcher.h:21-36) on
+    stand-in Frame / KeyFrame / MapLine types - include/drfe_adaptor.hpp flattens the pointer graph, calls the C-ABI, writes MapLine*
+    back and applies Fuse's Replace / AddObservation / AddMapLine in the reference's order (the stand-in MapLine::Replace moves
+    observations between keyframes as src/MapLine.cpp:178-214 does, so later lines of the loop meet what earlier ones left).  Every
+    resulting pointer vector must equal what the ctypes path gives on the flattened records + a replay of the surgery here; the
+    ctypes searches are held to the oracle in tests/test_gpu_lines.py.  Call 12: LineSegment::ExtractLineSegment from a fresh thread
+    on a default-constructed object (the reference's mpLineSegment is never initialised, include/Frame.h:157)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import line_scenarios as LS
+    from dr_slam_amd import lib
+    rng = np.random.RandomState(4242)
+    KL, MLD, TLD, FLD = lib.KEYLINE_DTYPE, lib.MAPLINE_DTYPE, lib.TRACKED_LINE_DTYPE, lib.FRUSTUM_LINE_DTYPE
+    ML_DT = np.dtype([("world", "<f8", (6,)), ("normal", "<f8", (3,)), ("min", "<f4"), ("max", "<f4"), ("desc", "u1", (32,)), ("nobs", "<i4"),
+                      ("bad", "<i4"), ("okf", "<i4"), ("oidx", "<i4"), ("inview", "<i4"), ("level", "<i4"), ("x1", "<f4"), ("y1", "<f4"),
+                      ("x2", "<f4"), ("y2", "<f4"), ("vcos", "<f4")])
+    assert ML_DT.itemsize == 48 + 24 + 8 + 32 + 24 + 20
+    tabs = []
+
+    def new_lines(n):
+        t = np.zeros(n, ML_DT)
+        t["okf"] = -1
+        base = sum(len(x) for x in tabs)
+        tabs.append(t)
+        return base, t
+
+    # ---- scenario A: SearchByProjection(Cur, Last) and (F, local map lines) ----
+    n_cur, n_last = 40, 48
+    scA = LS.make(1, KL, MLD, TLD, n_cur=n_cur, n_last=n_last)
+    bA, A = new_lines(n_last)
+    A["world"], A["desc"] = scA["last"]["world"], scA["last"]["desc"]
+    A["nobs"] = np.where(scA["last"]["obs_positive"] != 0, 2, 0)
+    A["bad"] = rng.uniform(size=n_last) < 0.06
+    A["inview"] = rng.uniform(size=n_last) < 0.9
+    A["level"] = scA["tracked"]["level"]
+    for k in ("x1", "y1", "x2", "y2"):
+        A[k] = scA["tracked"][k]
+    A["vcos"] = scA["tracked"]["view_cos"]
+    last_ml = np.where(rng.uniform(size=n_last) < 0.08, -1, bA + np.arange(n_last)).astype(np.int32)
+    last_out = (rng.uniform(size=n_last) < 0.06).astype(np.uint8)
+    pre_j = np.flatnonzero(scA["cur_ml"] >= 0)
+    bP, P = new_lines(len(pre_j))
+    P["nobs"] = scA["cur_obs"][pre_j]
+    cur_ml = np.full(n_cur, -1, np.int32)
+    cur_ml[pre_j] = bP + np.arange(len(pre_j))
+    last_kl = np.zeros(n_last, KL)
+    last_kl["octave"] = scA["last"]["octave"]
+    local = (bA + np.arange(n_last)).astype(np.int32)
+    local[::9] = -1
+
+    # ---- scenario B: the descriptor matchers ----
+    n_a, n_b = 40, 37
+    desc_a = rng.randint(0, 256, (n_a, 32)).astype(np.uint8)
+    perm = rng.permutation(n_a)
+    desc_b = rng.randint(0, 256, (n_b, 32)).astype(np.uint8)
+    for t in range(30):
+        desc_b[t] = LS._flip(rng, desc_a[perm[t]], int(rng.choice([0, 5, 20, 45, 80])))
+    bBa, Ba = new_lines(n_a)
+    bBb, Bb = new_lines(n_b)
+    a_ml = np.where(rng.uniform(size=n_a) < 0.8, bBa + np.arange(n_a), -1).astype(np.int32)
+    b_ml = np.where(rng.uniform(size=n_b) < 0.8, bBb + np.arange(n_b), -1).astype(np.int32)
+
+    # ---- scenario C: Fuse x2 and SearchByProjection(KF, Scw) on one keyframe ----
+    n_kf, n_c = 40, 240
+    scC, linesC, rngC = LS.sim3_line_scene(2, n_kf, n_c, KL, MLD, TLD, FLD)
+    bC, Cl = new_lines(n_c)
+    Cl["world"], Cl["normal"], Cl["min"], Cl["max"] = linesC["world"], linesC["normal"], linesC["min_distance"], linesC["max_distance"]
+    Cl["desc"] = scC["last"]["desc"]
+    Cl["nobs"] = rng.randint(0, 4, n_c)
+    Cl["bad"] = rng.uniform(size=n_c) < 0.08
+    bK, Kp = new_lines(n_kf)
+    Kp["nobs"] = rng.randint(0, 4, n_kf)
+    Kp["bad"] = rng.uniform(size=n_kf) < 0.1
+    kf4_ml = np.full(n_kf, -1, np.int32)
+    for k in range(n_kf):
+        if rng.uniform() < 0.35:
+            kf4_ml[k] = bK + k
+            Kp["okf"][k], Kp["oidx"][k] = 4, k
+    for k, i in ((3, 5), (17, 21), (31, 140)):                       # three lines of the candidate list already sit in the keyframe
+        if kf4_ml[k] >= 0:
+            Kp["okf"][kf4_ml[k] - bK] = -1
+        kf4_ml[k] = bC + i
+        Cl["okf"][i], Cl["oidx"][i] = 4, k
+    fuse_lst = (bC + np.arange(n_c)).astype(np.int32)
+    for i in range(0, n_c - 1, 11):
+        fuse_lst[i + 1] = fuse_lst[i]
+    fuse_lst[5::13] = -1
+    fuse2_lst = (bC + np.arange(n_c)).astype(np.int32)
+    fuse2_lst[7::17] = -1
+    proj_lst = np.concatenate([bC + np.arange(n_c), bC + np.arange(n_c)]).astype(np.int32)
+    proj_lst[::23] = -1
+    TcwC = scC["Tcw_cur"].astype(np.float32)
+    Scw9 = TcwC.copy(); Scw9[:3, :] *= np.float32(0.83)
+    Scw10 = TcwC.copy(); Scw10[:3, :] *= np.float32(1.7)
+
+    # ---- scenario D: SearchBySim3 ----
+    K = LS.keyframe_pair_for_sim3(1, KL, FLD)
+    n_d = K["n"]
+    bD1, D1 = new_lines(n_d)
+    bD2, D2 = new_lines(n_d)
+    for D, ln, ds, kfi in ((D1, K["lines1"], K["descs1"], 5), (D2, K["lines2"], K["descs2"], 6)):
+        D["world"], D["normal"], D["min"], D["max"], D["desc"] = ln["world"], ln["normal"], ln["min_distance"], ln["max_distance"], ds
+        D["nobs"] = 1
+        D["okf"], D["oidx"] = kfi, np.arange(n_d)
+    odd = (np.arange(n_d) % 2) == 1
+    D1["bad"] = (K["skip1"] != 0) & odd
+    D2["bad"] = (K["skip2"] != 0) & odd
+    kf5_ml = np.where((K["skip1"] != 0) & ~odd, -1, bD1 + np.arange(n_d)).astype(np.int32)
+    kf6_ml = np.where((K["skip2"] != 0) & ~odd, -1, bD2 + np.arange(n_d)).astype(np.int32)
+    D1["okf"][kf5_ml < 0] = -1
+    D2["okf"][kf6_ml < 0] = -1
+    inv = np.argsort(K["perm"])                                      # key line of KF2 that shows world line i
+    sim3_init = np.full(n_d, -1, np.int32)
+    for i1 in range(0, n_d, 6):
+        if kf6_ml[inv[i1]] >= 0:
+            sim3_init[i1] = bD2 + inv[i1]
+
+    ML = np.concatenate(tabs)
+    nML = len(ML)
+    img = frames_room[0][0]
+    h, w = img.shape
+
+    # ---- scene file ----
+    zero16 = np.eye(4, dtype=np.float32)
+    frames = [(scA["cur"], scA["cur_desc"], scA["Tcw_cur"], cur_ml, np.zeros(n_cur, np.uint8)),
+              (last_kl, np.zeros((n_last, 32), np.uint8), scA["Tcw_last"], last_ml, last_out),
+              (np.zeros(n_a, KL), desc_a, zero16, a_ml, np.zeros(n_a, np.uint8)),
+              (np.zeros(n_b, KL), desc_b, zero16, b_ml, np.zeros(n_b, np.uint8)),
+              (scC["cur"], scC["cur_desc"], TcwC, kf4_ml, np.zeros(n_kf, np.uint8)),
+              (K["kl1"], K["kd1"], K["T1w"], kf5_ml, np.zeros(n_d, np.uint8)),
+              (K["kl2"], K["kd2"], K["T2w"], kf6_ml, np.zeros(n_d, np.uint8))]
+    ints = lambda v: np.int32(len(v)).tobytes() + np.ascontiguousarray(v, np.int32).tobytes()
+    blob = [np.array([0x4c494e45, nML, len(frames)], np.int32).tobytes(),
+            np.array([LS.CAM[k] for k in ("fx", "fy", "cx", "cy", "bf", "min_x", "max_x", "min_y", "max_y")], np.float32).tobytes(),
+            np.array([1000, 8, 20, 7], np.int32).tobytes(), np.float32(1.2).tobytes(), ML.tobytes()]
+    for kl, ds, T, mlid, outl in frames:
+        blob += [np.int32(len(kl)).tobytes(), np.ascontiguousarray(kl, KL).tobytes(), np.ascontiguousarray(ds, np.uint8).tobytes(),
+                 np.ascontiguousarray(T, np.float32).tobytes(), np.ascontiguousarray(mlid, np.int32).tobytes(), outl.tobytes()]
+    blob += [ints(local), np.float32(15.0).tobytes(), np.float32(2.0).tobytes(), ints(fuse_lst), np.float32(12.0).tobytes(), Scw9.tobytes(), Scw10.tobytes(), ints(fuse2_lst),
+             ints(proj_lst)]
+    # vpMatched of call 9 depends on what calls 7 and 8 leave in the keyframe: computed by the replay below, so the file is
+    # written after it
+
+    ctx = lib.Context(max_batch=1)
+    try:
+        cam = lib.Camera(**LS.CAM)
+        bad = ML["bad"].astype(bool).copy()
+        nobs = ML["nobs"].copy()
+        repl = np.full(nML, -1, np.int32)
+        obs = [dict() for _ in range(nML)]
+        for i in range(nML):
+            if ML["okf"][i] >= 0:
+                obs[i][int(ML["okf"][i])] = int(ML["oidx"][i])
+        kfml = {4: kf4_ml.copy(), 5: kf5_ml.copy(), 6: kf6_ml.copy()}
+
+        def add_observation(p, kf, idx):
+            if kf in obs[p]:
+                return
+            obs[p][kf] = idx
+            nobs[p] += 1
+
+        def replace(a, b):                                           # a->Replace(b), src/MapLine.cpp:178-214
+            if a == b:
+                return
+            o, obs[a] = obs[a], dict()
+            bad[a], repl[a] = True, b
+            for kf in sorted(o):
+                if kf not in obs[b]:
+                    kfml[kf][o[kf]] = b
+                    add_observation(b, kf, o[kf])
+                else:
+                    kfml[kf][o[kf]] = -1
+
+        def frustum(lst):
+            f = np.zeros(len(lst), FLD)
+            d = np.zeros((len(lst), 32), np.uint8)
+            ok = lst >= 0
+            src = ML[lst[ok]]
+            f["world"][ok], f["normal"][ok], f["min_distance"][ok], f["max_distance"][ok] = src["world"], src["normal"], src["min"], src["max"]
+            d[ok] = src["desc"]
+            return f, d
+
+        want = []
+        # 1
+        rec = scA["last"].copy()
+        rec["valid"] = (last_ml >= 0) & ~bad[np.maximum(last_ml, 0)] & (last_out == 0)
+        init = np.where(cur_ml >= 0, n_last + np.arange(n_cur), -1).astype(np.int32)
+        n, res = ctx.lsd_search_by_projection_last(scA["Tcw_cur"], scA["Tcw_last"], cam, rec, scA["cur"], scA["cur_desc"], 15.0, False, 0.9, init,
+                                                   scA["cur_obs"])
+        w1 = cur_ml.copy()
+        new = (res >= 0) & (res < n_last)
+        w1[new] = last_ml[res[new]]
+        assert n > 5 and new.sum() > 5
+        want.append((n, w1))
+        # 2
+        rec = scA["tracked"].copy()
+        rec["in_view"] = (local >= 0) & ~bad[bA:bA + n_last] & (A["inview"] != 0)
+        rec["obs_positive"] = A["nobs"] > 0
+        init = np.where(cur_ml >= 0, n_last + np.arange(n_cur), -1).astype(np.int32)
+        n, res = ctx.lsd_search_by_projection_map(rec, scA["cur"], scA["cur_desc"], 2.0, 0.9, init, scA["cur_obs"])
+        w2 = cur_ml.copy()
+        new = (res >= 0) & (res < n_last)
+        w2[new] = local[res[new]]
+        assert n > 5
+        want.append((n, w2))
+        # 3 - 6
+        n, m = ctx.lsd_search_by_descriptor(desc_a, desc_b, (a_ml >= 0).astype(np.uint8), mode=0)
+        assert n >= 5
+        want.append((n, np.where(m >= 0, a_ml[np.maximum(m, 0)], -1)))
+        n, m = ctx.lsd_search_by_descriptor(desc_a, desc_b, (b_ml >= 0).astype(np.uint8), mode=1)
+        assert n >= 5
+        want.append((n, np.where(m >= 0, b_ml[np.maximum(m, 0)], -1)))
+        n, m = ctx.lsd_search_by_descriptor(desc_a, desc_b, None, mode=1)
+        assert n >= 5
+        want.append((n, np.stack([np.flatnonzero(m >= 0), m[m >= 0]], 1).reshape(-1)))
+        n, m = ctx.lsd_search_for_triangulation(desc_a, desc_b, (a_ml >= 0).astype(np.uint8), (b_ml >= 0).astype(np.uint8))
+        want.append((n, np.stack([np.flatnonzero(m >= 0), m[m >= 0]], 1).reshape(-1)))
+        # 7  Fuse(KF 4, lines with NULLs and repeats, 12.0)
+        kl4, kd4 = scC["cur"], scC["cur_desc"]
+        f, d = frustum(fuse_lst)
+        skip = (fuse_lst < 0) | bad[np.maximum(fuse_lst, 0)]
+        bi, bd = ctx.lsd_fuse_search(TcwC, cam, f, d, skip.astype(np.uint8), kl4, kd4, 12.0)
+        fused = 0
+        for i, p in enumerate(fuse_lst):
+            if p < 0 or bad[p] or bi[i] < 0 or bd[i] > 50:
+                continue
+            inkf = kfml[4][bi[i]]
+            if inkf >= 0:
+                if not bad[inkf]:
+                    if nobs[inkf] > nobs[p]:
+                        replace(p, inkf)
+                    else:
+                        replace(inkf, p)
+            else:
+                add_observation(p, 4, int(bi[i]))
+                kfml[4][bi[i]] = p
+            fused += 1
+        assert fused > 8 and (repl >= 0).sum() >= 2 and (nobs != ML["nobs"]).any()
+        want.append((fused, np.concatenate([kfml[4], np.stack([bad.astype(np.int32), repl, nobs], 1).reshape(-1)])))
+        # 8  Fuse(KF 4, Scw, lines, 4.0, vpReplaceLine) on that state
+        f, d = frustum(fuse2_lst)
+        already = set(int(v) for v in kfml[4] if v >= 0 and not bad[v])
+        skip = np.array([(p < 0) or bool(bad[p]) or (int(p) in already) for p in fuse2_lst])
+        bi, bd = ctx.lsd_fuse_search_sim3(Scw9, cam, f, d, skip.astype(np.uint8), kl4, kd4, 4.0)
+        rp, fused = np.full(len(fuse2_lst), -1, np.int32), 0
+        for i, p in enumerate(fuse2_lst):
+            if skip[i] or bi[i] < 0 or bd[i] > 50:
+                continue
+            inkf = kfml[4][bi[i]]
+            if inkf >= 0:
+                if not bad[inkf]:
+                    rp[i] = inkf
+            else:
+                add_observation(p, 4, int(bi[i]))
+                kfml[4][bi[i]] = p
+            fused += 1
+        assert fused > 3
+        want.append((fused, np.concatenate([rp, kfml[4]])))
+        # 9  SearchByProjection(KF 4, Scw, lines twice, vpMatched, 10)
+        vm = np.where(np.arange(n_kf) % 3 == 0, kfml[4], -1).astype(np.int32)
+        f, d = frustum(proj_lst)
+        found = set(int(v) for v in vm if v >= 0)
+        skip = np.array([(p < 0) or bool(bad[p]) or (int(p) in found) for p in proj_lst])
+        n, new = ctx.lsd_search_by_projection_kf(Scw10, cam, f, d, skip.astype(np.uint8), kl4, kd4, (vm >= 0).astype(np.uint8), 10)
+        w9 = vm.copy()
+        w9[new >= 0] = proj_lst[new[new >= 0]]
+        assert n > 5
+        want.append((n, w9))
+        # 10  SearchBySim3(KF 5, KF 6, vpMatches12, s12, R12, t12, 7.5)
+        skip1 = (kf5_ml < 0) | bad[np.maximum(kf5_ml, 0)] | (sim3_init >= 0)
+        skip2 = (kf6_ml < 0) | bad[np.maximum(kf6_ml, 0)]
+        for v in sim3_init[sim3_init >= 0]:
+            skip2[obs[v][6]] = True
+        n, m = ctx.lsd_search_by_sim3(cam, K["T1w"], K["T2w"], K["s12"], K["R12"], K["t12"], K["lines1"], K["descs1"], skip1.astype(np.uint8), K["kl1"],
+                                      K["kd1"], K["lines2"], K["descs2"], skip2.astype(np.uint8), K["kl2"], K["kd2"], 7.5)
+        w10 = sim3_init.copy()
+        w10[m >= 0] = kf6_ml[m[m >= 0]]
+        assert n > 5 and (sim3_init >= 0).sum() >= 3
+        want.append((n, w10))
+        # 11
+        want.append((int(np.unpackbits(ML["desc"][0] ^ ML["desc"][-1]).sum()), np.zeros(0, np.int32)))
+        # 12
+        lines = ctx.lsd_extract(img)
+        want.append((len(lines["lines"]), np.concatenate([lines["desc"].reshape(-1).view(np.int32),
+                                                          np.stack([lines["lines"]["start_point_x"], lines["lines"]["end_point_y"]], 1).reshape(-1).view(np.int32)])))
+        assert len(lines["lines"]) > 5
+    finally:
+        ctx.close()
+
+    blob += [ints(vm), ints(sim3_init), np.float32(K["s12"]).tobytes(), np.ascontiguousarray(K["R12"], np.float32).tobytes(),
+             np.ascontiguousarray(K["t12"], np.float32).tobytes(), np.array([w, h], np.int32).tobytes(), img.tobytes()]
+    (tmp_path / "scene.bin").write_bytes(b"".join(blob))
+    out = _run("linematcher_caller", tmp_path / "scene.bin", tmp_path / "o.bin")
+    assert "linematcher ok" in out
+    raw = np.frombuffer((tmp_path / "o.bin").read_bytes(), np.int32)
+    recs, o = [], 0
+    while o < len(raw):
+        ret, cnt = int(raw[o]), int(raw[o + 1])
+        recs.append((ret, raw[o + 2:o + 2 + cnt]))
+        o += 2 + cnt
+    assert len(recs) == len(want) == 12
+    for k, ((ret, vec), (wret, wvec)) in enumerate(zip(recs, want)):
+        assert ret == wret, (k + 1, ret, wret)
+        assert np.array_equal(vec, np.asarray(wvec, np.int32)), k + 1
