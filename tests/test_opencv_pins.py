@@ -79,3 +79,35 @@ def test_lsd_reading_decided_by_opencv(oracle_mod, pins):
             if (lambda o: len(o["segments"]) == len(ref) and np.array_equal(o["segments"].view(np.uint32), ref.view(np.uint32)))(
                 oracle_mod.extract_lines(pins["lsd_img"], max_lines=100000, trace=True, rect_mode=m))]
     assert same == [0], "OpenCV %s matches drfe_lsd_configure_rect mode(s) %s, the default is 0" % (str(pins["cv_version"]), same)
+
+
+@pytest.mark.parametrize("tag", ["impulse", "noise"])
+def test_gaussian_kernel_equal_opencv(oracle_mod, pins, tag):
+    """The 8-bit 7 x 7 sigma-2 Gaussian itself: a grid of isolated impulses of every amplitude (each 7 x 7 response is the fixed-point
+    product of the two 1-D kernels, rounding included) and a noise image.  The oracle's taps {18, 34, 49, 55, 49, 34, 18} / 256 sum to
+    257 (oracle/orb_oracle.cpp); whether OpenCV 3.4.4's getGaussianKernel + its 8-bit fixed-point path normalise them the same way
+    decides every blurred byte and therefore every rBRIEF bit.  A failure here lists the amplitudes and tap pairs that differ."""
+    if f"blur_{tag}_in" not in pins:
+        pytest.skip("opencv_pins.npz predates the impulse dump: regenerate it with tools/dump_opencv_reference.py")
+    got = oracle_mod.gaussian_blur(pins[f"blur_{tag}_in"])
+    ref = pins[f"blur_{tag}_out"]
+    bad = np.argwhere(got != ref)
+    assert len(bad) == 0, ("first differing pixels (row, col, oracle, OpenCV)", [(int(r), int(c), int(got[r, c]), int(ref[r, c])) for r, c in bad[:12]])
+
+
+@pytest.mark.parametrize("tag", ["lbd", "lbd_oblique", "lbd_diag45"])
+def test_lbd_rows_equal_opencv(oracle_mod, pins, tag):
+    """LineSegment::ExtractLineSegment's library half (src/LSDextractor.cpp:14-30): LSDDetector::detect + BinaryDescriptor::compute
+    on every detected line - all KeyLine fields with their float32 bits and all 32-byte LBD rows."""
+    if tag + "_img" not in pins:
+        pytest.skip("opencv_pins.npz carries no LBD rows (dumped without opencv-contrib's line_descriptor)")
+    o = oracle_mod.extract_lines(pins[tag + "_img"], max_lines=100000)
+    ref_kl, ref_desc = pins[tag + "_keylines"], pins[tag + "_desc"]
+    assert len(o["lines"]) == len(ref_kl)
+    names = o["lines"].dtype.names                       # cv::line_descriptor::KeyLine's declaration order, 17 scalars
+    assert len(names) == 17 == ref_kl.shape[1]
+    for j, f in enumerate(names):
+        col = o["lines"][f]
+        want = ref_kl[:, j].astype(col.dtype)
+        assert np.array_equal(col.view(np.uint32) if col.dtype == np.float32 else col, want.view(np.uint32) if col.dtype == np.float32 else want), f
+    assert np.array_equal(o["desc"], ref_desc)

@@ -10,6 +10,9 @@ from memory:
   cv2.fastAtan2 on a grid of (y, x)                               -> degrees
   cv2.undistortPoints on a grid, TUM1 coefficients                -> mvKeysUn arithmetic                 (Frame.cc:835-871)
   cv2.createLineSegmentDetector(LSD_REFINE_ADV).detect            -> segments of the line fixture        (LSDextractor.cpp:14-17)
+  cv2.GaussianBlur(7x7, sigma 2) on a grid of isolated impulses   -> the 8-bit fixed-point kernel itself (every amplitude 1..255 through
+                                                                     every tap pair: decides ALL descriptor bits; the oracle's taps sum to 257)
+  cv2.line_descriptor LSDDetector.detect + BinaryDescriptor.compute -> key lines + 32-byte LBD rows     (LSDextractor.cpp:14-30; needs opencv-contrib)
 
 tests/test_opencv_pins.py compares the oracle with the file when it exists and SKIPS (reporting "parity unpinned") when it
 does not - which is the state of this repository: no OpenCV is installed or installable in the build container.
@@ -86,6 +89,44 @@ def main():
     d45 = np.full((480, 640), 50, np.uint8)
     d45[(yy - xx) > 40] = 200
     detect(d45, "lsd_diag45")
+    # ---- round 6: the two items that decide the most output bits and were not pinned yet ----
+    # (1) the 7-tap 8-bit Gaussian OpenCV really applies for sigma 2: a 16 x 16 grid of isolated impulses, 8 px apart (the 7 x 7 responses
+    #     do not overlap), amplitudes 1 .. 255 (the last one repeated): each response is the fixed-point product of the two 1-D kernels with
+    #     its rounding - any other tap set or rounding rule differs somewhere on this image.  Plus one noise image for the general case.
+    imp = np.zeros((16 * 8 + 8, 16 * 8 + 8), np.uint8)
+    amp = np.minimum(np.arange(256) + 1, 255).astype(np.uint8).reshape(16, 16)
+    imp[8:8 + 16 * 8:8, 8:8 + 16 * 8:8] = amp
+    out["blur_impulse_in"] = imp
+    out["blur_impulse_out"] = cv2.GaussianBlur(imp.copy(), (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
+    noise = np.random.RandomState(11).randint(0, 256, (97, 131)).astype(np.uint8)
+    out["blur_noise_in"] = noise
+    out["blur_noise_out"] = cv2.GaussianBlur(noise.copy(), (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
+    # (2) LineSegment::ExtractLineSegment as the reference spells it (src/LSDextractor.cpp:14-30): LSDDetector::detect(img, keylines, 1.2, 1)
+    #     and BinaryDescriptor::compute on ALL detected lines (no top-40 cut: the cut is std::sort on the response and is checked apart) -
+    #     every KeyLine field and every LBD row.  LBD stays unpinned even with the LSD segments pinned: band sums, the float walks, the
+    #     normalisation chain and the binary conversion are restated from memory of descriptor.cpp / binary_descriptor.cpp.
+    try:
+        ld = cv2.line_descriptor
+        det = ld.LSDDetector_createLSDDetector() if hasattr(ld, "LSDDetector_createLSDDetector") else ld.LSDDetector.createLSDDetector()
+        bd = ld.BinaryDescriptor_createBinaryDescriptor() if hasattr(ld, "BinaryDescriptor_createBinaryDescriptor") else ld.BinaryDescriptor.createBinaryDescriptor()
+        fields = ("angle", "class_id", "octave", "pt", "response", "size", "startPointX", "startPointY", "endPointX", "endPointY",
+                  "sPointInOctaveX", "sPointInOctaveY", "ePointInOctaveX", "ePointInOctaveY", "lineLength", "numOfPixels")
+        for tag, img in (("lbd", lines_img), ("lbd_oblique", ob), ("lbd_diag45", d45)):
+            kls = det.detect(img, 1.2, 1)
+            kls, desc = bd.compute(img, kls)
+            rows = []
+            for k in kls:
+                r = []
+                for f in fields:
+                    v = getattr(k, f)
+                    r += [float(v[0]), float(v[1])] if f == "pt" else [float(v)]
+                rows.append(r)
+            out[tag + "_img"] = img
+            out[tag + "_keylines"] = np.array(rows, np.float64).reshape(-1, 17)       # field order of cv::line_descriptor::KeyLine
+            out[tag + "_desc"] = np.zeros((0, 32), np.uint8) if desc is None else np.asarray(desc, np.uint8).reshape(-1, 32)
+    except (AttributeError, cv2.error) as e:
+        sys.stderr.write("note: cv2.line_descriptor is not usable in this OpenCV build (%s): the LBD rows stay unpinned; install "
+                         "opencv-contrib-python 3.4.x\n" % e)
     np.savez_compressed(os.path.join(GOLD, "opencv_pins.npz"), **out)
     print("wrote", os.path.join(GOLD, "opencv_pins.npz"), "with OpenCV", cv2.__version__)
 
