@@ -223,6 +223,26 @@ def config5_aux(ctx, base, cam, n: int = 6):
         res[nb] = {"frames": nb, "ms_per_frame": el * 1e3 / nb, "frames_per_s": nb / el, "ms_per_call": el * 1e3, "planes_per_frame": float(nn.mean()),
                    "accepted_per_frame": float(na.mean()), "frames_redone_on_host": s1["to_host"] - s0["to_host"],
                    "voxel_grids_redone_on_host": s1["voxel_grids_to_host"] - s0["voxel_grids_to_host"]}
+    # BASELINE config 5 asks for an HBM roofline report of ORB + LSD + plane: the long kernels of the line and plane batch entries at this frame
+    # size, each call alone on the device with the kernel clock on; algorithmic bytes = section 8(d)'s per-frame formulas on this geometry
+    px = cam.w * cam.h
+    algo5 = {"lsd_lbd": px + 2 * (px * 0.64) * 8 + 4 * px, "ahc_planes": 2 * px + px + 0.8 * px}      # gray + (modgrad, angle f64 at 0.8 scale) + Sobel i16 x2; depth u16 + label u8 + member lists
+    nb = 128
+    gb = np.stack([base[i % len(base)][0] for i in range(nb)])
+    db = np.stack([base[i % len(base)][1] for i in range(nb)])
+    ctx.lsd_extract_batch(gb, n_threads=2)                                  # arenas
+    ctx.long_kernel_clock(True)
+    t0 = time.perf_counter()
+    lb = ctx.lsd_extract_batch(gb, n_threads=2)
+    t_l = time.perf_counter() - t0
+    ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)
+    ms = ctx.long_kernel_ms()
+    ctx.long_kernel_clock(False)
+    out["lsd_batch"] = {"frames": nb, "ms_per_call": t_l * 1e3, "frames_per_s": nb / t_l, "lines_per_frame": float(np.mean([len(a["lines"]) for a in lb])),
+                        "frames_returned_to_host": ctx.lsd_stats()}
+    out["roofline_long_kernels"] = long_kernel_roofline(ms, nb, algo5)
+    out["kernel_ms_one_call_alone"] = {k: round(v, 3) for k, v in ms.items() if v > 0}
+    out["algorithmic_bytes_per_frame_lines_planes"] = {k: int(v) for k, v in algo5.items()}
     out["ahc_post_batch"] = dict(res[128], at_32_frames_per_call=res[32],
                                  note="host frames uploaded inside the call; extractor (k_ahc_cluster_big / k_ahc_refine_big, one wavefront per frame, one frame per CU by LDS) + voxel grids + "
                                       "gates and RANSAC refit (k_plane_refit) on the device; the pool uploads, launches and copies the post records")
@@ -401,36 +421,40 @@ def host_fed_sparse_rate(fes, gray, depth, Tcw, Twc, B, steps, dev, _skip=(), _t
 FF_ALGO_BYTES = {"orb_extract": 7225354, "window_match": 676000, "lsd_lbd": 307200 + 3145728 + 1228800, "ahc_planes": 614400 + 307200 + 245760}
 
 
-def full_frontend_roofline(frames_per_s: float, n_frames: int):
+LONG_KERNEL_STAGE = {"k_lsd_order": "lsd_lbd", "k_lsd_grow": "lsd_lbd", "k_rect_improve": "lsd_lbd", "k_ahc_cluster": "ahc_planes", "k_ahc_refine": "ahc_planes",
+                     "k_voxel_grid": "ahc_planes", "k_plane_refit": "ahc_planes"}
+# SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the committed counter passes (profiles/r05_long_kernels_summary.txt; a --pmc pass cannot run inside this process)
+LONG_KERNEL_LANES = {"k_lsd_grow": 0.746, "k_plane_refit": 0.331, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.713, "k_voxel_grid": 0.589}
+
+
+def long_kernel_roofline(ms_by_kernel, frames, algo_bytes=None):
+    """per long kernel of the line / plane paths: its stage's algorithmic bytes for the frames of one launch over the
+    kernel's duration - measured LIVE in this run by HIP events on the launch stream (drfe_long_kernel_clock: one call alone on the device) -
+    against the HBM peak.  These kernels run one wavefront per frame, so the fraction says how far a latency chain is from a streaming pass."""
+    ab = algo_bytes or FF_ALGO_BYTES
+    out = {}
+    for name, ms in ms_by_kernel.items():
+        if name in LONG_KERNEL_STAGE and ms > 0:
+            ach = ab[LONG_KERNEL_STAGE[name]] * frames / (ms * 1e-3) / 1e9
+            out[name] = {"stage": LONG_KERNEL_STAGE[name], "ms_per_launch": ms, "frames_per_launch": frames, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                         "valu_lane_utilisation": LONG_KERNEL_LANES.get(name), "source": "HIP events around the kernel on its launch stream, this run (one call alone on the device)"}
+    return out
+
+
+def full_frontend_roofline(frames_per_s: float, n_frames: int, live_ms=None):
     """HBM roofline of what bounds BASELINE config 3: the aggregate (section 8(d)'s algorithmic bytes of all four stages x the measured
-    rate, against 8 TB/s) and, per long kernel of the line and plane paths, its stage's algorithmic bytes for the frames of one launch
-    over the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summaries of one 512-frame step
-    (profiles/r05_kernel_stats_{lines,planes}_batch512.csv) - those kernels run one or four wavefronts per frame, so the fraction
-    says how far a latency chain is from a streaming pass, which is the point; lane utilisation = SQ_THREAD_CYCLES_VALU /
-    (64 x SQ_ACTIVE_INST_VALU) from profiles/r05_long_kernels_summary.txt (k_lsd_grow_mw: r05a_long_kernels_summary.txt, collected with that kernel forced)."""
-    import csv
+    rate, against 8 TB/s) and, per long kernel of the line and plane paths, long_kernel_roofline of the durations measured in this run."""
     per_frame = sum(FF_ALGO_BYTES.values())
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_frame": per_frame,
            "achieved": per_frame * frames_per_s / 1e9, "frac": per_frame * frames_per_s / 1e9 / HBM_PEAK_GBS,
            "limited_by": "latency chains: every frame's region growing / plane clustering / flood fill is an order-defined sequence on one or four wavefronts; "
                          "the rate is (frames resident) / (chain latency), and residency is bounded by LDS (a frame's `used` bitmap, queues, tables)"}
-    lanes = {"k_lsd_grow_mw": 0.625, "k_lsd_grow": 0.746, "k_plane_refit": 0.331, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.713, "k_voxel_grid": 0.589}
-    kern = {}
-    for path, stage in (("lines", "lsd_lbd"), ("planes", "ahc_planes")):
-        f = os.path.join(ROOT, "profiles", "r05_kernel_stats_%s_batch512.csv" % path)
-        if not os.path.exists(f):
-            continue
-        for r in csv.DictReader(open(f)):
-            name = r["Name"].split("(")[0]
-            if name in lanes and float(r["AverageNs"]) > 1e6:
-                ach = FF_ALGO_BYTES[stage] * 512 / (float(r["AverageNs"]) * 1e-9) / 1e9
-                kern[name] = {"stage": stage, "ms_per_512_frame_launch": float(r["AverageNs"]) / 1e6, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                              "valu_lane_utilisation": lanes[name], "source": "profiles/r05_kernel_stats_%s_batch512.csv" % path}
-    out["long_kernels"] = kern
+    out["long_kernels"] = long_kernel_roofline(live_ms or {}, n_frames)
+    out["long_kernels_lane_utilisation_source"] = "profiles/r05_long_kernels_summary.txt (rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU)"
     return out
 
 
-def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 5):
+def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 5, device: int = 0, ranks_on_host: int = 1, sync=None):
     """BASELINE config 3 (ICL-NUIM living-room style, ICL intrinsics): the whole per-frame front-end - ORB + glue +
     SearchByProjection and the surface normals batched on the device; LSD + LBD lines with the detector's sequential core on
     the device (pixel ordering = std::sort's permutation, region growing, rectangle fit / refinement: one wavefront per frame);
@@ -439,16 +463,19 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
     lines of the line path on host threads.
     A frame's region growing / plane extraction is a dependency chain of 0.1-0.25 s on ONE wavefront, so the device paths run at
     (frames in flight) / (that latency): 512 frames per step, and `inflight` steps at a time (each on its own contexts) so that
-    the host stages of one step run while the other step's wavefronts are on the device."""
+    the host stages of one step run while the other step's wavefronts are on the device.
+    Sharded (`bench.py --gpus N --full-frontend`): every rank runs this on its own device with its share of the host's CPUs
+    (`ranks_on_host`), `sync` = the ranks' barrier, called right before and right after the timed region; the caller reduces
+    (frames, seconds) over the ranks - whole sequences per rank, no data-path collective."""
     import threading
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from dr_slam_amd import lib, sharding, synth
     from dr_slam_amd.pipeline import FrontEnd
     cam = getattr(synth, cam_name)
-    ncpu = sharding.host_cpus()
+    ncpu = sharding.host_cpus() // max(1, ranks_on_host)
     if ncpu < 3:                                      # 2.3 cores busy per GPU at the measured rate: with fewer the host, not the device, is measured
-        raise RuntimeError("full_frontend: %d host CPUs - the whole front-end of config 3 keeps 2.5 busy per GPU (planes' gates + RANSAC refit, upload threads)" % ncpu)
+        raise RuntimeError("full_frontend: %d host CPUs per rank - the whole front-end of config 3 keeps 2.5 busy per GPU (upload threads, pools, Python)" % ncpu)
     base = sharding.render_sequence(3, 8, cam, "living_room", workers=1)
     order = sharding.pingpong_order(n_frames, len(base))
     gray = np.stack([base[i][0] for i in order])
@@ -463,8 +490,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
     # pageable memory is staged by a runtime thread first (1.1 GB per step here: 0.2-0.3 ms of CPU per frame that is not the
     # front-end's)
     gray, depth, depth_m = (torch.from_numpy(a).pin_memory().numpy() for a in (gray, depth, depth_m))
-    gray_t = torch.from_numpy(gray).cuda()
-    depth_t = torch.from_numpy(depth.view(np.int16)).cuda()
+    gray_t = torch.from_numpy(gray).to("cuda:%d" % device)
+    depth_t = torch.from_numpy(depth.view(np.int16)).to("cuda:%d" % device)
     inflight = max(1, int(os.environ.get("DRFE_FF_INFLIGHT", inflight)))
     # host threads per step in flight.  Round 4: the line path's threads only upload the frames, launch, and copy the finished key
     # lines out (ordering, growth, rect_improve / NFA, key lines and LBD all run on the device): three of them; the plane pool
@@ -477,8 +504,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
     n_cape = int(os.environ.get("DRFE_FF_CAPE", 2))   # CAPE lanes (host threads of drfe_planes_cape_batch)
     lanes = []
     for _ in range(inflight):
-        lanes.append({"fe": FrontEnd(cam, max_batch=n_frames), "planes": lib.Context(max_batch=1), "cape": lib.Context(max_batch=1),
-                      "wall": {}, "stream": torch.cuda.Stream()})
+        lanes.append({"fe": FrontEnd(cam, max_batch=n_frames, device=device), "planes": lib.Context(max_batch=1, device=device),
+                      "cape": lib.Context(max_batch=1, device=device), "wall": {}, "stream": torch.cuda.Stream(device)})
 
     def step(L, pool):
         wall = L["wall"]
@@ -516,6 +543,14 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
             step(L, pool)
             step(L, pool)
 
+        # every long kernel's duration, live: one call of each path ALONE on the device with the kernel clock on (HIP events on the launch stream)
+        L0 = lanes[0]
+        L0["fe"].ctx.long_kernel_clock(True); L0["planes"].long_kernel_clock(True)
+        L0["fe"].ctx.lsd_extract_batch(gray, n_threads=split["lines"])
+        L0["planes"].planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=split["planes"])
+        live_ms = dict(L0["fe"].ctx.long_kernel_ms())
+        live_ms.update({k: v for k, v in L0["planes"].long_kernel_ms().items() if v > 0})
+        L0["fe"].ctx.long_kernel_clock(False); L0["planes"].long_kernel_clock(False)
         step_ms, step_back = [], []
 
         def handed_back(L):                           # frames the device handed back to the host so far, by stage (cumulative counters of the lane's contexts)
@@ -538,12 +573,16 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
         if dbg is not None:
             dbg.restype = None
             dbg(pool_ns)                                                       # clear
+        if sync:
+            sync()
         cpu0 = time.process_time()
         t0 = time.perf_counter()
         for t in th:
             t.start()
         for t in th:
             t.join()
+        if sync:
+            sync()
         el = time.perf_counter() - t0
         cpu = time.process_time() - cpu0
         if dbg is not None:
@@ -560,7 +599,7 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
     total = inflight * reps * n_frames
     return {"workload": "BASELINE config 3: living_room scene, ICL intrinsics, 640x480: ORB + glue + SearchByProjection + surface "
                         "normals batched on the device; LSD+LBD lines, AHC planes + post-processing, CAPE planes for every frame",
-            "value": total / el, "unit": "frames/s", "frames_per_step": n_frames, "steps_in_flight": inflight, "steps_timed": inflight * reps,
+            "value": total / el, "unit": "frames/s", "frames_timed": total, "seconds_timed": el, "frames_per_step": n_frames, "steps_in_flight": inflight, "steps_timed": inflight * reps,
             "ms_per_step": el * 1e3 / (inflight * reps),
             "host_cpu_ms_per_frame": cpu * 1e3 / total, "host_cpu_utilisation": cpu / (el * ncpu),
             "host_cpu_ms_per_frame_by_pool": {"lines": pool_ns[0] / 1e6 / total, "ahc_planes": pool_ns[1] / 1e6 / total, "cape": pool_ns[2] / 1e6 / total,
@@ -582,7 +621,8 @@ def full_frontend(cam_name, n_frames: int = 512, reps: int = 6, inflight: int = 
             "step_wall_ms_with_and_without_hand_back": (lambda b, m: {"steps_with": int((b > 0).sum()), "median_with": float(np.median(m[b > 0])) if (b > 0).any() else None,
                                                                        "median_without": float(np.median(m[b == 0])) if (b == 0).any() else None})(
                 np.array(step_back).sum(1), np.array(step_ms)),
-            "roofline": full_frontend_roofline(total / el, n_frames),
+            "roofline": full_frontend_roofline(total / el, n_frames, live_ms),
+            "kernel_ms_one_call_alone": {k: round(v, 3) for k, v in live_ms.items() if v > 0},
             "planes_accepted_per_step": int(nacc[0]),
             "lines_path": "everything on the device: pixel ordering, region growing, region2rect, refine (k_lsd_order, k_lsd_grow: one wavefront per frame at this call size; k_lsd_grow_mw, four per frame, up to 256 frames per call), rect_improve + NFA "
                           "decisions with certified comparisons (k_rect_improve), key lines + the response cut + line equations (k_lsd_keylines), LBD (k_lbd); host threads upload, launch and copy",
@@ -664,6 +704,10 @@ def launch(args) -> int:
         sys.stderr.write("bench.py --gpus %d: only %d host CPUs are available to this job - one per rank is the least the sharded mode needs "
                          "(2.5 per GPU for the whole front-end of config 3); refusing to report a number bound by the host\n" % (n, sharding.host_cpus()))
         return 3
+    if getattr(args, "full_frontend", False) and sharding.host_cpus() < 3 * n:
+        sys.stderr.write("bench.py --gpus %d --full-frontend: %d host CPUs are available to this job and the whole front-end of config 3 keeps ~2.5 busy "
+                         "per GPU (upload threads, pools, Python): 3 per rank is the least; refusing to report a number bound by the host\n" % (n, sharding.host_cpus()))
+        return 3
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.device_count() < n:
@@ -743,6 +787,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-fed rate and the config-3 full front-end block")
     ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
+    ap.add_argument("--full-frontend", action="store_true",
+                    help="at --gpus N > 1: after the headline, every rank also runs BASELINE config 3's whole front-end (ORB + LSD + AHC + CAPE + match) on "
+                         "its own device and sequence; rank 0 reports total frames over the slowest rank's time.  Needs 3 host CPUs per rank")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1020,6 +1067,24 @@ def main():
             del gray_t, depth_t, gray_ts, depth_ts
             out["full_frontend"] = full_frontend("ICL")
             out["per_frame_latency"] = per_frame_latency("ICL")
+    if world > 1 and args.full_frontend:
+        # the whole front-end, sharded: every rank on its own device (the rehearsal: all on device 0) with its share of the host's CPUs
+        pipe.close()
+        del gray_t, depth_t, gray_ts, depth_ts
+        torch.cuda.empty_cache()
+
+        def ranks_sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+
+        ff = full_frontend("ICL", n_frames=int(os.environ.get("DRFE_FF_FRAMES", 512)), reps=int(os.environ.get("DRFE_FF_REPS", 4)), inflight=int(os.environ.get("DRFE_FF_INFLIGHT", 3)),
+                           device=local_rank, ranks_on_host=world, sync=ranks_sync)
+        ff_el, ff_frames = sharding.reduce_elapsed_and_frames(ff["seconds_timed"], ff["frames_timed"], dev, dist)
+        if out is not None:
+            out["full_frontend_sharded"] = {"value": ff_frames / ff_el, "unit": "frames/s", "ranks": world, "frames": ff_frames, "seconds_slowest_rank": ff_el,
+                                            "rank0": {k: ff[k] for k in ("value", "frames_per_step", "steps_in_flight", "steps_timed", "host_cpus_available", "host_cores_busy_at_this_rate",
+                                                                         "step_wall_ms", "frames_handed_back_per_step")},
+                                            "sharding": "one sequence per rank, no data-path collective; barrier before and after the timed region, total frames over the slowest rank's time"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1122,22 +1122,26 @@ int drfe_ahc_device_fits(int w, int h)
     return w >= AHC_WIN && h >= AHC_WIN && (w / AHC_WIN) * (h / AHC_WIN) <= AHCD_HEAP_BIG && (size_t)w * h <= ((size_t)1 << AHCD_PIXBITS);
 }
 
-hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s)
+hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s, hipEvent_t* ev3)
 {
     if (nframes <= 0) return hipSuccess;
     static_assert(AHC_HANDOFF_INTS >= AHCD_HO_LABELS + 1, "handoff words");
     if (P.NB > AHCD_HEAP_BIG || (size_t)P.w * P.h > ((size_t)1 << AHCD_PIXBITS)) return hipErrorInvalidValue;
     if (P.NB <= AHCD_HEAP_SMALL) {
         hipLaunchKernelGGL(k_ahc_cluster, dim3(nframes), dim3(64), 0, s, d_frames, P);
+        if (ev3) (void)hipEventRecord(ev3[0], s);
         hipLaunchKernelGGL(k_ahc_refine, dim3(nframes), dim3(64), 0, s, d_frames, P);
     } else {
         hipLaunchKernelGGL(k_ahc_cluster_big, dim3(nframes), dim3(64), 0, s, d_frames, P);
+        if (ev3) (void)hipEventRecord(ev3[0], s);
         hipLaunchKernelGGL(k_ahc_refine_big, dim3(nframes), dim3(64), 0, s, d_frames, P);
     }
+    if (ev3) (void)hipEventRecord(ev3[1], s);
     if (P.planeCap >= AHCL_STRIDE || (size_t)P.rfCap < (size_t)AHCL_SCRATCH + (size_t)(2 * AHCL_NBLK + 2) * AHCL_STRIDE) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_ahc_labels_count, dim3(AHCL_NBLK, nframes), dim3(64), 0, s, d_frames, P);
     hipLaunchKernelGGL(k_ahc_labels_prefix, dim3(nframes), dim3(64), 0, s, d_frames, P);
     hipLaunchKernelGGL(k_ahc_labels_scatter, dim3(AHCL_NBLK, nframes), dim3(64), 0, s, d_frames, P);
+    if (ev3) (void)hipEventRecord(ev3[2], s);
     return hipGetLastError();
 }
 

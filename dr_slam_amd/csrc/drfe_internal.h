@@ -181,6 +181,8 @@ struct drfe_ctx {
     int lsdDeviceGrow;        /* drfe_lsd_configure: 1 = the batch entry grows regions on the device (default) */
     int lsdDeviceNfa;         /* drfe_lsd_configure_nfa: 1 = rect_improve's decisions on the device in the batch entry (default) */
     long long lsdStats[4];    /* drfe_lsd_stats */
+    int longClock = 0;        /* drfe_long_kernel_clock: the batch entries of the line / plane paths bracket every kernel of their first chunk with events */
+    float longMs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   /* drfe_long_kernel_ms: [0..6] lines, [8..14] planes */
     long long capeStats[2];   /* drfe_planes_cape_stats: frames through the device path, of those finished by the host (kept here: the arena is rebuilt when a batch grows) */
     long long ahcStats[4];    /* drfe_planes_ahc_stats: frames through the device extractor, of those redone on the host, plane voxel grids on the device, of those redone on the host */
     int lsdRectMode;          /* drfe_lsd_configure_rect: rect_nfa's reading, 0 = literal OpenCV 3.4 (default), 1 = real-valued */

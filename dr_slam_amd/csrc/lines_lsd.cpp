@@ -933,6 +933,7 @@ struct BatchJob {
     std::atomic<int> nfaWhy{0}; std::atomic<long> nfaWhyCount[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};      /* DRFE_TRACE_LINES: which certification failed (stopping rule | close values | sign | subnormal regime) */
     bool deviceOrder = true;            /* the ordering by k_lsd_order (default) or by the pool (DRFE_LSD_HOST_ORDER=1: A/B, tests) */
     hipEvent_t stageEv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* DRFE_TRACE_LINES, chunk 0: start | upload | passes | keys | ordering | growth */
+    hipEvent_t clk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* drfe_long_kernel_clock, chunk 0: start | upload | passes | k_lsd_keys | k_lsd_order | k_lsd_grow | k_rect_improve | key lines + LBD */
     std::atomic<long> usSort{0}, usFinish{0}, usWait{0}, usNfa{0}, usKeyl{0}, usRectDl{0}, usCountsWall{0}, usCountsCpu{0}, nCountRounds{0}, handedBack{0};   /* DRFE_TRACE_LINES: task time by kind, summed over the workers */
     std::chrono::steady_clock::time_point t0, tLastSort, tFirstFinish; std::atomic<int> nFirst{0};
     BatchJob(int nChunks_) : sortedInChunk(nChunks_), chunkState(nChunks_, 0) {}
@@ -968,6 +969,7 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
          * follows on the same stream overwrites them) */
         BCHK(drfe_launch_lsd_order(A->d_order + nk * f0, nk, (int)nk, A->d_reg + ns * f0, A->d_tmp + ns * f0, ns, A->d_ordStatus + f0, 1, nf, st));
         if (ch == 0 && J.stageEv[4]) (void)hipEventRecord(J.stageEv[4], st);
+        if (ch == 0 && J.clk[4]) (void)hipEventRecord(J.clk[4], st);
     } else
         BCHK(hipMemcpyAsync(A->d_order + nk * f0, A->h_order + nk * f0, nk * 4 * nf, hipMemcpyHostToDevice, st));
     BCHK(hipMemcpyAsync(A->d_frames + f0, A->h_frames + f0, sizeof(LsdGrowFrame) * nf, hipMemcpyHostToDevice, st));
@@ -980,15 +982,18 @@ static int batch_launch_grow(BatchJob& J, int ch, std::string& err)
     const int growMode = J.c->lsdDeviceGrow;          /* drfe_lsd_configure: 2 / 3 force a kernel */
     const bool growMw = growMode == 3 || growWavesEnv == 4 || (growMode != 2 && growWavesEnv != 1 && J.nframes <= 256);
     BCHK(drfe_launch_lsd_grow(A->d_frames + f0, nf, A->sw, A->sh, J.prec, J.p, J.minReg, 0.7, A->rectCap, st, growMw ? A->regCapMw : 0));
+    if (ch == 0 && J.clk[5]) (void)hipEventRecord(J.clk[5], st);
     /* rect_improve + the NFA decisions of every accepted rectangle, behind the growth on the same stream: no host round trip */
     if (J.deviceNfa)
         BCHK(drfe_launch_rect_improve(A->d_frames + f0, nf, A->sw, A->sh, lsd_walk_mode(J.rectMode), J.nfaTab, A->rectCap, A->d_segs + (size_t)A->rectCap * f0, st));
+    if (ch == 0 && J.clk[6] && J.deviceNfa) (void)hipEventRecord(J.clk[6], st);
     if (J.deviceNfa && J.deviceKl) {
         const size_t k0 = (size_t)A->klCap * f0, px = (size_t)A->w * A->h;
         BCHK(drfe_launch_lsd_keylines(A->d_frames + f0, A->d_segs + (size_t)A->rectCap * f0, A->rectCap, nf, A->w, A->h, J.maxLines, A->klCap,
                                       A->d_kl + k0, A->d_klLineF + 3 * k0, A->d_klLbd + k0, A->d_klOut + 4 * (size_t)f0, st));
         BCHK(drfe_launch_lbd_batch(A->d_klLbd + k0, A->d_klOut + 4 * (size_t)f0, A->klCap, nf, A->d_gx + px * f0, A->d_gy + px * f0, A->w, A->h, lbdTables(),
                                    A->d_klDesc + 32 * k0, st));
+        if (ch == 0 && J.clk[7]) (void)hipEventRecord(J.clk[7], st);
     }
     /* no download behind the growth: a copy queued on a DMA ring waits there for its kernel and holds up every other stream's
      * copies behind it (measured: the plane path's kernels and CAPE's transfers stalled for the whole growth); the worker that
@@ -1240,6 +1245,7 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
     int prLow = 0, prHigh = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
     if (std::getenv("DRFE_TRACE_LINES")) for (hipEvent_t& e : J.stageEv) HIPCHK(c, hipEventCreate(&e));
+    if (c->longClock) for (hipEvent_t& e : J.clk) HIPCHK(c, hipEventCreate(&e));
     for (int ch = 0; ch < nChunks; ch++) {
         HIPCHK(c, drfe_long_kernel_stream(&J.chunkStream[ch], 0));
         HIPCHK(c, hipEventCreateWithFlags(&J.keysReady[ch], hipEventDisableTiming | hipEventBlockingSync));
@@ -1252,16 +1258,21 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
         hipStream_t st = J.chunkStream[ch];
         hipError_t e = hipSuccess;
         const bool tr = ch == 0 && J.stageEv[0];
+        const bool ck = ch == 0 && J.clk[0];
         if (tr) (void)hipEventRecord(J.stageEv[0], st);
+        if (ck) (void)hipEventRecord(J.clk[0], st);
         if (stride == (size_t)w && frame_stride == n) e = hipMemcpyAsync(A->d_img + n * f0, gray + frame_stride * f0, n * nf, hipMemcpyHostToDevice, st);
         else
             for (int f = f0; f < f0 + nf && e == hipSuccess; f++)
                 e = hipMemcpy2DAsync(A->d_img + n * f, (size_t)w, gray + frame_stride * f, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st);
         if (tr) (void)hipEventRecord(J.stageEv[1], st);
+        if (ck) (void)hipEventRecord(J.clk[1], st);
         if (e == hipSuccess) e = drfe_launch_lines_passes(A->d_img + n * f0, w, h, P.lsdTaps, P.lbdTaps, A, f0, nf, P.rho, st);
         if (tr) (void)hipEventRecord(J.stageEv[2], st);
+        if (ck) (void)hipEventRecord(J.clk[2], st);
         if (e == hipSuccess) e = drfe_launch_lsd_keys(A->d_modgrad + ns * f0, A->d_angles + ns * f0, A->sw, A->sh, A->d_meta + 2 * (size_t)f0, A->d_order + nk * f0, A->d_cs0 + ns * f0, A->d_notdef + ((ns + 31) / 32) * f0, nf, st);
         if (tr) (void)hipEventRecord(J.stageEv[3], st);
+        if (ck) (void)hipEventRecord(J.clk[3], st);
         if (e == hipSuccess && !J.deviceOrder) {
             e = hipMemcpyAsync(A->h_order + nk * f0, A->d_order + nk * f0, nk * 4 * nf, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipMemcpyAsync(A->h_meta + 2 * (size_t)f0, A->d_meta + 2 * (size_t)f0, 16 * (size_t)nf, hipMemcpyDeviceToHost, st);
@@ -1291,6 +1302,16 @@ static int lsd_extract_batch_device(drfe_ctx* c, std::vector<LineWorker>* pool, 
                      ms[0], ms[1], ms[2], ms[3], ms[4]);
     }
     for (hipEvent_t& e : J.stageEv) if (e) (void)hipEventDestroy(e);
+    if (J.clk[0]) {
+        /* the workers have fetched every chunk's results: chunk 0's stream is idle.  Intervals whose closing event was never recorded
+         * (ordering / NFA / key lines on the host) stay 0 */
+        if (launchRc == DRFE_OK && J.deviceOrder) {
+            (void)hipStreamSynchronize(J.chunkStream[0]);
+            const int last = J.deviceNfa ? (J.deviceKl ? 7 : 6) : 5;
+            for (int k = 0; k < 7; k++) { float ms = 0; if (k < last) (void)hipEventElapsedTime(&ms, J.clk[k], J.clk[k + 1]); c->longMs[k] = ms; }
+        }
+        for (hipEvent_t& e : J.clk) if (e) (void)hipEventDestroy(e);
+    }
     c->lsdStats[0] += nframes; c->lsdStats[1] += J.handedBack.load(); c->lsdStats[2] += J.nfaToHost.load(); c->lsdStats[3] += J.klToHost.load();
     if (std::getenv("DRFE_TRACE_LINES"))
         std::fprintf(stderr, "drfe_lsd_extract_batch: rect_improve / NFA %s; %ld of %d frames back to the host's validation (a decision too close to certify)\n",
@@ -1372,6 +1393,25 @@ int drfe_lsd_configure_nfa(drfe_ctx* c, int device_nfa)
 /* counters of this context's drfe_lsd_extract_batch calls since creation: [0] frames through the device path, [1] frames whose
  * region growing went back to the host (uncertified rounding, capacity), [2] frames whose NFA decisions went back to the host,
  * [3] frames whose key-line stage went back to the host (an atan2 / cos / sin rounding not certified, the sort's heap branch) */
+/* 1: drfe_lsd_extract_batch and drfe_planes_ahc_post_batch bracket every kernel of their first chunk with HIP events on the stream
+ * the kernels are launched on (two event records per kernel: nothing a throughput run notices, off by default) */
+int drfe_long_kernel_clock(drfe_ctx* c, int on)
+{
+    if (!c) return DRFE_ERR_INVALID;
+    c->longClock = on ? 1 : 0;
+    return DRFE_OK;
+}
+/* ms of the last clocked call's first chunk.  Lines [0..6]: upload, image passes, k_lsd_keys (+ k_lsd_notdef), k_lsd_order, k_lsd_grow(_mw),
+ * k_rect_improve, k_lsd_keylines + k_lbd.  Planes [8..14]: upload, k_ahc_blocks, k_ahc_cluster, k_ahc_refine, k_ahc_labels_* (three),
+ * k_voxel_grid, k_plane_refit.  [7], [15]: 0.  An interval includes whatever its kernel waited for on the device: alone on the device
+ * it is the kernel's duration, beside other work it is not */
+int drfe_long_kernel_ms(drfe_ctx* c, float* out16)
+{
+    if (!c || !out16) return DRFE_ERR_INVALID;
+    for (int i = 0; i < 16; i++) out16[i] = c->longMs[i];
+    return DRFE_OK;
+}
+
 int drfe_lsd_stats(drfe_ctx* c, long long* out3 /* four entries */)
 {
     if (!c || !out3) return DRFE_ERR_INVALID;

@@ -1125,6 +1125,9 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
     static const bool traceStages = std::getenv("DRFE_TRACE_PLANES") != nullptr;
     hipEvent_t stageEv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       /* chunk 0: start, depth up, blocks, extractor, voxel grids */
     if (traceStages) for (hipEvent_t& e : stageEv) HIPCHK(c, hipEventCreate(&e));
+    /* drfe_long_kernel_clock: start | upload | k_ahc_blocks | k_ahc_cluster | k_ahc_refine | k_ahc_labels_* | k_voxel_grid | k_plane_refit (chunk 0) */
+    hipEvent_t clk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (c->longClock) for (hipEvent_t& e : clk) HIPCHK(c, hipEventCreate(&e));
     const auto tCall = std::chrono::steady_clock::now();
     for (int ch = 0; ch < J.nChunks; ch++) {
         /* low priority, like the line path's growth: the runtime keeps separate hardware queues per priority, so the pools'
@@ -1141,21 +1144,27 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
             for (int f = f0; f < f0 + nf; f++)
                 for (int y = 0; y < h; y++) std::memcpy(A->h_depth + px * f + (size_t)y * w, depth + (size_t)f * frame_stride + (size_t)y * stride, (size_t)w * 2);
         const bool tr = traceStages && ch == 0;
+        const bool ck = ch == 0 && clk[0];
         if (tr) (void)hipEventRecord(stageEv[0], st);
+        if (ck) (void)hipEventRecord(clk[0], st);
         hipError_t e = hipMemcpyAsync(A->d_depth + px * f0, direct ? depth + px * f0 : A->h_depth + px * f0, px * 2 * nf, hipMemcpyHostToDevice, st);
         if (tr) (void)hipEventRecord(stageEv[1], st);
+        if (ck) (void)hipEventRecord(clk[1], st);
         if (e == hipSuccess) e = drfe_launch_ahc_blocks(A->d_depth + px * f0, px, (size_t)w, w, h, K4, depth_factor, nf, A->d_blocks + (size_t)NB * f0, st);
         if (tr) (void)hipEventRecord(stageEv[2], st);
-        if (e == hipSuccess) e = drfe_launch_ahc_frames(A->d_frames + f0, nf, A->P, st);
+        if (ck) (void)hipEventRecord(clk[2], st);
+        if (e == hipSuccess) e = drfe_launch_ahc_frames(A->d_frames + f0, nf, A->P, st, ck ? clk + 3 : nullptr);
         if (tr) (void)hipEventRecord(stageEv[3], st);
         if (e == hipSuccess && J.voxDevice) {
             const size_t pc = (size_t)A->P.planeCap;
             e = drfe_launch_voxel_grid(A->d_vpts, A->d_jobs + pc * f0, (int)(pc * nf), A->d_vlist + pc * f0 + 2 * (size_t)ch, A->d_vrecs, A->d_vtmp, A->d_vposL, A->d_vposR, A->d_vout, A->d_vcounts + pc * f0,
                                        0.05f, st);
+            if (ck) (void)hipEventRecord(clk[6], st);
             if (e == hipSuccess && J.refitDevice)
                 e = drfe_launch_plane_refit(A->d_frames + f0, A->d_jobs + pc * f0, A->d_vcounts + pc * f0, A->d_vout, A->d_mtState, (int)(pc * nf), (int)pc, max_point_dist,
                                             dist_threshold, std::log(1.0 - 0.99), A->d_post + pc * f0, A->d_postStatus + pc * f0, st);
             if (tr) (void)hipEventRecord(stageEv[4], st);
+            if (ck) (void)hipEventRecord(clk[7], st);
         }
         /* no download behind the kernels: a copy queued on a DMA ring waits there for its kernel and holds up the copies of every
          * other stream behind it (the line path's, CAPE's); the worker that sees the event fetches the chunk's small results */
@@ -1176,6 +1185,14 @@ static int planes_ahc_post_batch_device(drfe_ctx* c, std::vector<PlaneLane>* poo
         std::fprintf(stderr, "drfe_planes_ahc_post_batch stages (chunk 0): staging + enqueue %.1f ms of host time; depth upload %.1f ms, k_ahc_blocks %.1f, k_ahc_cluster + k_ahc_refine %.1f, k_voxel_grid %.1f; call %.1f ms\n",
                      tl, ms[0], ms[1], ms[2], ms[3], ta);
         for (hipEvent_t& e : stageEv) (void)hipEventDestroy(e);
+    }
+    if (clk[0]) {
+        if (launchRc == DRFE_OK) {
+            (void)hipStreamSynchronize(J.chunkStream[0]);
+            const int last = J.voxDevice ? (J.refitDevice ? 7 : 6) : 5;
+            for (int k = 0; k < 7; k++) { float ms = 0; if (k < last) (void)hipEventElapsedTime(&ms, clk[k], clk[k + 1]); c->longMs[8 + k] = ms; }
+        }
+        for (hipEvent_t& e : clk) (void)hipEventDestroy(e);
     }
     for (int ch = 0; ch < J.nChunks; ch++) {
         (void)hipStreamSynchronize(J.chunkStream[ch]);

@@ -85,7 +85,8 @@ struct AhcDevFrame {
     float* pts; int2* jobs; int ptsBase;                     /* plane clouds for k_voxel_grid: pts = arena cloud + 3 * ptsBase, jobs[planeCap] (or null) */
     int* out;                                                /* out[0] = planes, out[1] = status (0 = done; else: redo on the host) */
 };
-hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s);
+/* ev3 (optional): events recorded after k_ahc_cluster, after k_ahc_refine and after the three k_ahc_labels_* kernels */
+hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s, hipEvent_t* ev3 = nullptr);
 /* frames the device extractor takes: up to 12 800 init blocks and 2^21 pixels (1280 x 960 = BASELINE config 5 is 12 288 / 1 228 800) */
 int drfe_ahc_device_fits(int w, int h);
 

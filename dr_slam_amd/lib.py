@@ -40,7 +40,7 @@ SYMBOLS = (
     "drfe_frame_stereo_grid_batch_kpdepth", "drfe_planes_ahc_post_batch", "drfe_planes_ahc_from_blocks", "drfe_debug_ahc_trials", "drfe_debug_order_sort", "drfe_search_for_initialization", "drfe_lsd_fuse_search_sim3", "drfe_lsd_search_by_projection_kf",
     "drfe_lsd_search_by_sim3", "drfe_frame_submit", "drfe_frame_collect", "drfe_pipeline_create", "drfe_pipeline_destroy",
     "drfe_pipeline_depth", "drfe_pipeline_context", "drfe_pipeline_last_error", "drfe_pipeline_submit", "drfe_pipeline_sync",
-    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_debug_device_order_sort_depth", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor", "drfe_planes_ahc_stats", "drfe_planes_configure_refit", "drfe_planes_refit_stats", "drfe_frame_load", "drfe_bow_transform_slot",
+    "drfe_lsd_configure", "drfe_lsd_configure_rect", "drfe_shard_unique_id", "drfe_shard_create", "drfe_shard_destroy", "drfe_shard_broadcast", "drfe_shard_reduce_report", "drfe_shard_sequences_of_rank", "drfe_shard_last_error", "drfe_planes_configure_cape", "drfe_planes_cape_stats", "drfe_lsd_configure_nfa", "drfe_lsd_stats", "drfe_lsd_segments_host_mode", "drfe_debug_cr_sincos", "drfe_debug_device_order_sort", "drfe_debug_device_order_sort_depth", "drfe_batch_status_async", "drfe_batch_check", "drfe_frame_submit_tracked", "drfe_frame_collect_tracked", "drfe_planes_cape_batch", "drfe_planes_configure", "drfe_planes_configure_extractor", "drfe_planes_ahc_stats", "drfe_planes_configure_refit", "drfe_planes_refit_stats", "drfe_frame_load", "drfe_bow_transform_slot", "drfe_long_kernel_clock", "drfe_long_kernel_ms",
 )
 
 FRUSTUM_POINT_DTYPE = np.dtype([("world", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"),
@@ -220,6 +220,8 @@ def load() -> C.CDLL:
     L.drfe_bow_transform_slot.argtypes = [vp, i32, i32, vp]
     L.drfe_lsd_configure_nfa.argtypes = [vp, i32]
     L.drfe_lsd_stats.argtypes = [vp, vp]
+    L.drfe_long_kernel_clock.argtypes = [vp, i32]
+    L.drfe_long_kernel_ms.argtypes = [vp, vp]
     L.drfe_lsd_segments_host_mode.argtypes = [vp, vp, vp, i32, i32, f64, i32, vp, i32, C.POINTER(i32)]
     L.drfe_planes_configure.argtypes = [vp, i32]
     L.drfe_planes_configure_extractor.argtypes = [vp, i32]
@@ -969,6 +971,18 @@ class Context:
         """Where lsd_extract_batch takes rect_improve's NFA decisions: on the device (certified comparisons, default) or on the
         host pool with the caller's libm."""
         self._chk(self.L.drfe_lsd_configure_nfa(self.h, 1 if device_nfa else 0), "drfe_lsd_configure_nfa")
+
+    def long_kernel_clock(self, on=True):
+        """lsd_extract_batch / planes_ahc_post_batch bracket every kernel of their first chunk with HIP events (long_kernel_ms)"""
+        self._chk(self.L.drfe_long_kernel_clock(self.h, int(bool(on))), "drfe_long_kernel_clock")
+
+    def long_kernel_ms(self):
+        """ms of the last clocked batch call's first chunk, by kernel (0 where the stage ran elsewhere)"""
+        out = np.zeros(16, np.float32)
+        self._chk(self.L.drfe_long_kernel_ms(self.h, _p(out)), "drfe_long_kernel_ms")
+        names = ("lines_upload", "lines_image_passes", "k_lsd_keys", "k_lsd_order", "k_lsd_grow", "k_rect_improve", "k_lsd_keylines+k_lbd", None,
+                 "planes_upload", "k_ahc_blocks", "k_ahc_cluster", "k_ahc_refine", "k_ahc_labels", "k_voxel_grid", "k_plane_refit", None)
+        return {n: float(v) for n, v in zip(names, out) if n}
 
     def lsd_stats(self):
         """dict(frames, grow_to_host, nfa_to_host, keylines_to_host): counters of lsd_extract_batch's device path since the context was created"""

@@ -384,6 +384,14 @@ int drfe_lsd_configure_nfa(drfe_ctx* ctx, int device_nfa);
  * returned to the host, [2] frames whose NFA decisions returned to the host, [3] frames whose key-line stage (KeyLine fields,
  * the response cut's std::sort, LBD direction: k_lsd_keylines) returned to the host */
 int drfe_lsd_stats(drfe_ctx* ctx, long long* out4);
+/* Kernel durations of the two long batch entries, measured live: with the clock on, drfe_lsd_extract_batch and
+ * drfe_planes_ahc_post_batch bracket every kernel of their first chunk with HIP events on the stream it is launched on.
+ * drfe_long_kernel_ms: the last clocked call's intervals in ms - lines [0..6]: upload, image passes, k_lsd_keys, k_lsd_order,
+ * k_lsd_grow(_mw), k_rect_improve, k_lsd_keylines + k_lbd; planes [8..14]: upload, k_ahc_blocks, k_ahc_cluster, k_ahc_refine,
+ * k_ahc_labels_*, k_voxel_grid, k_plane_refit ([7], [15] unused).  An interval contains whatever its kernel waited for: it is the
+ * kernel's duration when the call runs alone on the device (bench.py full_frontend's solo steps). */
+int drfe_long_kernel_clock(drfe_ctx* ctx, int on);
+int drfe_long_kernel_ms(drfe_ctx* ctx, float* out16);
 /* drfe_lsd_segments_host with rect_nfa's reading chosen by the caller (drfe_lsd_segments_host: 0). */
 int drfe_lsd_segments_host_mode(const double* modgrad, const double* angles, const float* cs, int W, int H, double max_grad,
                                 int rect_mode, float* segs, int cap, int* n_segs);

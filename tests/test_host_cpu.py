@@ -559,3 +559,16 @@ def test_long_kernels_keep_their_lds_budget(tmp_path):
     ring = int(re.search(r"#define LSD_RING (\d+)", open(os.path.join(ROOT, "dr_slam_amd", "csrc", "lsd_grow_kernels.hip")).read()).group(1))
     assert find("k_lsd_grow", True) == 0 and per_cu(512 * 384 // 8 + ring * 4 + 64 * 3 * 8) >= 6
     assert find("k_lsd_grow_mw", True) == 0            # dynamic LDS: bitmap + control block + 16 overlay tables + 4 x (ring + columns) = 46.8 KB at 512 x 384: three workgroups per CU
+
+
+def test_bench_refuses_the_sharded_full_frontend_without_three_cpus_per_rank():
+    """`bench.py --gpus N --full-frontend` keeps ~2.5 host cores busy per GPU (upload threads, pools, Python): with fewer than 3 CPUs per
+    rank it would report a number bound by the host, so the launcher refuses (exit 3) before any rank - or any GPU call - starts."""
+    import subprocess
+    import sys
+    from dr_slam_amd import sharding
+    n = sharding.host_cpus() // 3 + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--full-frontend", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr[-400:])
+    assert "3 per rank" in p.stderr and p.stdout.strip() == ""
