@@ -63,6 +63,24 @@ __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CS
 __device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 
+/* the key of lane ^ j without a trip through the LDS crossbar: DPP inside a row of sixteen lanes (quad permutes, row rotations), gfx950's
+ * v_permlane16_swap / v_permlane32_swap across rows and halves.  A 64-key bitonic sort on these runs in 0.23 us against 0.72 us on
+ * __shfl_xor (ds_bpermute for j = 4, 16, 32): tools/ubench_permlane.hip, which also checks the forms against __shfl_xor on the device. */
+__device__ __forceinline__ uint32_t xor_partner(uint32_t key, int j, int lane)
+{
+    if (j == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, false);          /* quad_perm [1, 0, 3, 2] */
+    if (j == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, false);          /* quad_perm [2, 3, 0, 1] */
+    if (j == 4) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x124, 0xF, 0xF, false);     /* row_ror:4: from lane - 4 */
+        const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x12C, 0xF, 0xF, false);     /* row_ror:12: from lane + 4 */
+        return (lane & 4) ? a : b;
+    }
+    if (j == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x128, 0xF, 0xF, false);         /* row_ror:8 */
+    if (j == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); return (lane & 16) ? r[0] : r[1]; }
+    const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+
 /* Chains of lanes that target the same pixel, in lane (= visiting) order, for the flood fill: every live lane gets the previous
  * lane with its pixel (-1: none), its depth in the chain and whether it is the last.  The 64 keys pixel << 6 | lane are sorted
  * across the wavefront by a bitonic network (21 compare-exchange stages; a dead lane's key sorts behind every live one and is
@@ -75,12 +93,7 @@ __device__ __forceinline__ void chain_sort64(bool live, int pixel, int lane, int
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            /* the partner's key: inside a quad and across half a row by DPP (no trip through the LDS crossbar), else by permute */
-            uint32_t other;
-            if (j == 1) other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, false);          /* quad_perm [1, 0, 3, 2] */
-            else if (j == 2) other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, false);     /* quad_perm [2, 3, 0, 1] */
-            else if (j == 8) other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x128, 0xF, 0xF, false);    /* row_ror:8 */
-            else other = (uint32_t)__shfl_xor((int)key, j);
+            const uint32_t other = xor_partner(key, j, lane);
             const bool keepMin = ((lane & j) == 0) == ((lane & k) == 0);
             const uint32_t lo = key < other ? key : other, hi = key < other ? other : key;
             key = keepMin ? lo : hi;
@@ -99,6 +112,60 @@ __device__ __forceinline__ void chain_sort64(bool live, int pixel, int lane, int
     depth = (int)(got & 63u);
     prev = (int)((got >> 6) & 127u) - 1;
     isLast = (got >> 13) & 1u;
+}
+
+/* The same for 128 visits, two per lane: visit id = slot * 64 + lane, visiting order = id order (round 6: the flood fill takes 32
+ * queue entries per step).  Keys pixel << 7 | id sorted by a 128-element bitonic network over (slot, lane) - 28 compare-exchange
+ * stages, the one with partner distance 64 inside the lane - then runs of equal pixels are read off two lane masks and every visit's
+ * answer goes home through a 128-word LDS table (tmp). */
+__device__ __forceinline__ void chain_sort128(bool live0, int pixel0, bool live1, int pixel1, int lane, uint32_t* tmp,
+                                              int& prev0, int& depth0, bool& isLast0, int& prev1, int& depth1, bool& isLast1)
+{
+    /* a dead visit's key sorts behind every live one and is its own pixel (pixels are below 2^21, ids below 2^7) */
+    uint32_t k0 = (live0 ? (uint32_t)pixel0 : (0x200000u | (uint32_t)lane)) << 7 | (uint32_t)lane;
+    uint32_t k1 = (live1 ? (uint32_t)pixel1 : (0x200040u | (uint32_t)lane)) << 7 | (uint32_t)(64 + lane);
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {                                   /* k == 128: the partner is the lane's other slot, ascending */
+                const uint32_t lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
+                k0 = lo; k1 = hi;
+            } else {
+                const uint32_t o0 = xor_partner(k0, j, lane), o1 = xor_partner(k1, j, lane);
+                /* element index i = slot * 64 + lane: (i & j) is (lane & j); (i & k) is (lane & k) below 64, the slot at 64, zero at 128 */
+                const bool low = (lane & j) == 0;
+                const bool up0 = k == 128 ? true : (k == 64 ? true : (lane & k) == 0);
+                const bool up1 = k == 128 ? true : (k == 64 ? false : (lane & k) == 0);
+                const uint32_t lo0 = k0 < o0 ? k0 : o0, hi0 = k0 < o0 ? o0 : k0;
+                const uint32_t lo1 = k1 < o1 ? k1 : o1, hi1 = k1 < o1 ? o1 : k1;
+                k0 = (low == up0) ? lo0 : hi0;
+                k1 = (low == up1) ? lo1 : hi1;
+            }
+        }
+    }
+    /* sorted position i = slot * 64 + lane holds the i-th smallest key */
+    const uint32_t b0 = (uint32_t)__shfl_up((int)k0, 1);                     /* slot 0: the element before (lane 0: none) */
+    uint32_t b1 = (uint32_t)__shfl_up((int)k1, 1);                           /* slot 1, lane 0: slot 0's last */
+    const uint32_t k0last = (uint32_t)__builtin_amdgcn_readlane((int)k0, 63);
+    if (lane == 0) b1 = k0last;
+    const bool same0 = lane > 0 && (b0 >> 7) == (k0 >> 7);
+    const bool same1 = (b1 >> 7) == (k1 >> 7);
+    const unsigned long long S0 = __ballot(same0), S1 = __ballot(same1), H0 = ~S0, H1 = ~S1;     /* run heads; bit 0 of H0 is always set */
+    const unsigned long long le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;
+    const int rs0 = 63 - __builtin_clzll(H0 & le);
+    const int rs1 = (H1 & le) ? 64 + 63 - __builtin_clzll(H1 & le) : 63 - __builtin_clzll(H0);
+    const bool last0 = lane == 63 ? !(S1 & 1ull) : !((S0 >> (lane + 1)) & 1ull);
+    const bool last1 = lane == 63 || !((S1 >> (lane + 1)) & 1ull);
+    const uint32_t p0 = (uint32_t)(lane - rs0) | (same0 ? ((b0 & 127u) + 1u) << 7 : 0u) | (last0 ? 1u << 15 : 0u);
+    const uint32_t p1 = (uint32_t)(64 + lane - rs1) | (same1 ? ((b1 & 127u) + 1u) << 7 : 0u) | (last1 ? 1u << 15 : 0u);
+    tmp[k0 & 127u] = p0;
+    tmp[k1 & 127u] = p1;
+    wave_order();
+    const uint32_t g0 = tmp[lane], g1 = tmp[64 + lane];
+    wave_order();
+    depth0 = (int)(g0 & 127u); prev0 = (int)((g0 >> 7) & 255u) - 1; isLast0 = (g0 >> 15) & 1u;
+    depth1 = (int)(g1 & 127u); prev1 = (int)((g1 >> 7) & 255u) - 1; isLast1 = (g1 >> 15) & 1u;
 }
 
 #ifdef AHC_PROFILE
@@ -223,6 +290,14 @@ __device__ int heap_pop(Ctx& c)                                        /* the wh
     return top;
 }
 
+/* A node's rid word: its representative block (low 16 bits: blocks are below 12 800) and the ROOT of that block's set (high 16 bits).
+ * The sets of two living nodes are disjoint and a set changes only when its node merges - which ends the node - so the root a node
+ * was created with stays its root for as long as it lives: a merge reads both roots from the words it has already loaded instead of
+ * walking two chains of dependent loads (round 6: 2-4 memory round trips per merge). */
+__device__ __forceinline__ int rid_block(int word) { return word & 0xFFFF; }
+__device__ __forceinline__ int rid_root(int word) { return (int)((unsigned)word >> 16); }
+__device__ __forceinline__ int rid_pack(int block, int root) { return block | (root << 16); }
+
 /* union-find over the init blocks (DisjointSet.hpp): Find without path compression gives the same roots */
 __device__ __forceinline__ int ds_find(const Ctx& c, int x)
 {
@@ -341,6 +416,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         const int Np = c.N[p], ridP = c.rid[p];
         const double npx = c.fit[8 * (size_t)p + 3], npy = c.fit[8 * (size_t)p + 4], npz = c.fit[8 * (size_t)p + 5];
         if (uni_b(nouseP != 0)) continue;
+        const int sizeP = c.dsSize[rid_root(ridP)];             /* in flight beside the list loads below */
         const int Lp = uni_i(lenP);
 #ifdef AHC_PROFILE
         if (c.lane == 0) atomicMax(&g_ahcProf[7], (unsigned long long)Lp);
@@ -356,13 +432,13 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         /* trial merges, one lane per neighbour; the fold keeps the reference's order and tie rule */
         bool haveCand = false;
         double candMse = 0;
-        int candN = 0, candNb = -1, candLen = 0, candRid = 0;
+        int candN = 0, candNb = -1, candLen = 0, candRid = 0, candSize = 0;
         for (int base = 0; base < Lp; base += 64) {
             const int k = base + lane;
             bool ok = false;
             double S[9];
             AhcFit f;
-            int Nn = 0, ridN = 0, nb = 0, nbLenK = 0, ridNbK = 0, nbHead[8];
+            int Nn = 0, ridN = 0, nb = 0, nbLenK = 0, ridNbK = 0, sizeNbK = 0, nbHead[8];
             f.mse = 0;
             if (k < Lp) {
                 nb = c.lA[k];
@@ -380,12 +456,13 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 const GLOBAL_AS int* listN = c.pool + nbOffK;
 #pragma unroll
                 for (int q = 0; q < 8; q++) nbHead[q] = q < nbLenK ? listN[q] : 0;
+                sizeNbK = c.dsSize[rid_root(ridNb)];            /* its set's size, should this trial win: same round trip as the list head */
                 if (!(fabs(npx * mx + npy * my + npz * mz) < c.P.cos60)) {
                     ok = true;
 #pragma unroll
                     for (int q = 0; q < 9; q++) S[q] = Sp[q] + S[q];
                     Nn = Np + Nb;
-                    ridN = Np >= Nb ? ridP : ridNb;
+                    ridN = rid_block(Np >= Nb ? ridP : ridNb);
                     ahc_plane_from_sums(S, Nn, &f);
                 }
             }
@@ -396,7 +473,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 m &= m - 1;
                 const double mse = rl_d(f.mse, l);
                 if (!haveCand || candMse > mse || (candMse == mse && (double)candN < mse)) {
-                    haveCand = true; candMse = mse; candN = rl_i(Nn, l); candNb = rl_i(nb, l); candLen = rl_i(nbLenK, l); candRid = rl_i(ridNbK, l); winLane = l;
+                    haveCand = true; candMse = mse; candN = rl_i(Nn, l); candNb = rl_i(nb, l); candLen = rl_i(nbLenK, l); candRid = rl_i(ridNbK, l); candSize = rl_i(sizeNbK, l); winLane = l;
                 }
             }
             if (winLane >= 0 && lane == winLane) {          /* this chunk's winner parks its merged node in LDS */
@@ -425,13 +502,11 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             c.nNodes = id + 1;
             if (lane < 9) c.S[9 * (size_t)id + lane] = c.win[lane];
             if (lane < 8) c.fit[8 * (size_t)id + lane] = c.win[9 + lane];
-            /* mergeNbsFrom: union by size of the two root blocks.  The two finds (chains of dependent loads) side by side in lanes
-             * 0 and 1, each with its root's size */
-            int root = 0, rsize = 0;
-            if (lane < 2) { root = ds_find(c, lane == 0 ? ridP : candRid); rsize = c.dsSize[root]; }
-            const int xr = rl_i(root, 0), yr = rl_i(root, 1), sxr = rl_i(rsize, 0), syr = rl_i(rsize, 1);
+            /* mergeNbsFrom: union by size of the two root blocks - both roots and their sizes came with the words loaded above */
+            const int xr = rid_root(ridP), yr = rid_root(candRid), sxr = sizeP, syr = candSize;
             if (lane == 0) {
-                c.N[id] = ((int*)(c.win + 17))[0]; c.rid[id] = ((int*)(c.win + 17))[1]; c.nouse[id] = 0;
+                const int newRoot = (xr != yr && sxr < syr) ? yr : xr;
+                c.N[id] = ((int*)(c.win + 17))[0]; c.rid[id] = rid_pack(((int*)(c.win + 17))[1], newRoot); c.nouse[id] = 0;
                 heap_push(c, c.win[15], id);
                 if (xr != yr) {
                     if (sxr < syr) { c.dsParent[xr] = yr; c.dsSize[yr] = syr + sxr; }
@@ -563,7 +638,7 @@ __device__ __forceinline__ void ahc_cluster_frame(const AhcDevFrame* __restrict_
                 for (int k = 0; k < 9; k++) c.S[9 * (size_t)id + k] = blocks[b].sums[k];
                 for (int k = 0; k < 3; k++) { c.fit[8 * (size_t)id + k] = blocks[b].center[k]; c.fit[8 * (size_t)id + 3 + k] = blocks[b].normal[k]; }
                 c.fit[8 * (size_t)id + 6] = blocks[b].mse; c.fit[8 * (size_t)id + 7] = blocks[b].curvature;
-                c.N[id] = blocks[b].N; c.rid[id] = b; c.nouse[id] = 0;
+                c.N[id] = blocks[b].N; c.rid[id] = rid_pack(b, b); c.nouse[id] = 0;
                 c.nbOff[id] = 4 * id; c.nbLen[id] = 0;
                 heapKey[id] = (float)blocks[b].mse; heapId[id] = (uint16_t)id;
             } else c.G[b] = -1;
@@ -625,7 +700,7 @@ __device__ __forceinline__ void ahc_cluster_frame(const AhcDevFrame* __restrict_
     fence();
     if (lane == 0)
         for (int plid = 0; plid < nEx; plid++) {             /* std::map::insert: the first plane of a root keeps it */
-            const int r = c.rid[ex[plid]];
+            const int r = rid_block(c.rid[ex[plid]]);
             if (c.ridToPlid[r] < 0) c.ridToPlid[r] = plid;
         }
     fence();
@@ -721,6 +796,7 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
     __shared__ uint8_t isValid[AHCD_MAXEX];
     __shared__ double plN[AHCD_MAXEX][3], plC[AHCD_MAXEX][3], plMse[AHCD_MAXEX];
     __shared__ int8_t blkLds[HEAP];                           /* flood fill: 1 = the block is kept whole (its pixels are final) */
+    __shared__ uint32_t ffTmp[128];                           /* flood fill: chain_sort128's way home */
     const AhcDevFrame F = frames[blockIdx.x];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -767,95 +843,138 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
         const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy, factor = P.factor;
         for (int k = lane; k < NB; k += 64) blkLds[k] = (int8_t)(c.blkMap[k] >= 0 ? 1 : 0);
         fence();
-        const int eLane = lane >> 2, nbLane = lane & 3;          /* entry of the step, neighbour (left, right, up, down) */
-        uint32_t eNext = 0;
-        int nextFrom = -1;                                       /* queue position eNext was prefetched for (this lane) */
+        const int eLane = lane >> 2, nbLane = lane & 3;          /* entry of a half-step, neighbour (left, right, up, down) */
+        /* Round 6: THIRTY-TWO queue entries per step - two visits per lane (slot 0: entries 0..15 of the step, slot 1: entries 16..31; visit
+         * id = slot * 64 + lane = visiting order).  What a step pays once whatever it holds - the round trip of the labels / distances /
+         * depths, the fence, the queue bookkeeping - is now paid per 128 visits; the chains of same-pixel visits come from a 128-key sort. */
+        uint32_t eNext0 = 0, eNext1 = 0;
+        int nextFrom0 = -1, nextFrom1 = -1;                      /* queue positions eNext0 / eNext1 were prefetched for (this lane) */
+        struct Visit { bool have, in, push, dirty, distDirty, meets; int cIdx, plid, trail, other; float cdist, old; };
         while (head < tail) {
-            const int cnt = min(16, tail - head);
-            const bool mine = eLane < cnt;
-            uint32_t e = 0;
-            if (mine) e = nextFrom == head + eLane ? eNext : c.rf[head + eLane];
-            /* the next step's entries, when the queue already holds them: their fetch overlaps this step */
-            if (head + 16 + eLane < tail) { eNext = c.rf[head + 16 + eLane]; nextFrom = head + 16 + eLane; }
-            const int sIdx = (int)(e & AHCD_PIXMASK), plid = (int)(e >> AHCD_PIXBITS);
-            const int sy = sIdx / w, sx = sIdx - sy * w;
-            int cxn = sx, cyn = sy;
-            bool have = false;
-            if (nbLane == 0) { have = sx > 0; cxn = sx - 1; }
-            else if (nbLane == 1) { have = sx < w - 1; cxn = sx + 1; }
-            else if (nbLane == 2) { have = sy > 0; cyn = sy - 1; }
-            else { have = sy < h - 1; cyn = sy + 1; }
-            have = have && mine;
-            const int cIdx = cyn * w + cxn;
-            bool in = false;
-            float cdist = -1.f;
-            int trail = 0;
-            float old = 0.f;
-            if (have) {
-                const int by = cyn / AHC_WIN, bx = cxn / AHC_WIN;
-                if (by < Nh && bx < Nw && blkLds[by * Nw + bx]) have = false;      /* pixels of kept blocks are final */
+            const int cnt = min(32, tail - head);
+            Visit V[2];
+            uint32_t e[2];
+            {
+                const int q0 = head + eLane, q1 = head + 16 + eLane;
+                e[0] = eLane < cnt ? (nextFrom0 == q0 ? eNext0 : c.rf[q0]) : 0u;
+                e[1] = 16 + eLane < cnt ? (nextFrom1 == q1 ? eNext1 : c.rf[q1]) : 0u;
+                /* the next step's entries, when the queue already holds them: their fetch overlaps this step */
+                if (q0 + 32 < tail) { eNext0 = c.rf[q0 + 32]; nextFrom0 = q0 + 32; }
+                if (q1 + 32 < tail) { eNext1 = c.rf[q1 + 32]; nextFrom1 = q1 + 32; }
             }
-            if (have) {
-                trail = c.mem[cIdx];
-                old = c.dist[cIdx];
-                double z = (double)c.depth[(size_t)cyn * c.rowStride + cxn] * factor;
-                if (z > 5.0) z = 0.0;
-                if (z != 0.0) {
-                    const double px = ((double)cxn - cx) * z / fx, py = ((double)cyn - cy) * z / fy;
-                    const double sd = plN[plid][0] * (px - plC[plid][0]) + plN[plid][1] * (py - plC[plid][1]) + plN[plid][2] * (z - plC[plid][2]);
-                    cdist = (float)fabs(sd);
-                    const double cd = (double)cdist;
-                    in = cd * cd < 9 * plMse[plid] + 1e-5;
+            int cyn[2], cxn[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                Visit& v = V[sl];
+                const bool mine = 16 * sl + eLane < cnt;
+                const int sIdx = (int)(e[sl] & AHCD_PIXMASK);
+                v.plid = (int)(e[sl] >> AHCD_PIXBITS);
+                const int sy = sIdx / w, sx = sIdx - sy * w;
+                cxn[sl] = sx; cyn[sl] = sy;
+                bool have = false;
+                if (nbLane == 0) { have = sx > 0; cxn[sl] = sx - 1; }
+                else if (nbLane == 1) { have = sx < w - 1; cxn[sl] = sx + 1; }
+                else if (nbLane == 2) { have = sy > 0; cyn[sl] = sy - 1; }
+                else { have = sy < h - 1; cyn[sl] = sy + 1; }
+                have = have && mine;
+                v.cIdx = cyn[sl] * w + cxn[sl];
+                if (have) {
+                    const int by = cyn[sl] / AHC_WIN, bx = cxn[sl] / AHC_WIN;
+                    if (by < Nh && bx < Nw && blkLds[by * Nw + bx]) have = false;      /* pixels of kept blocks are final */
                 }
+                v.have = have; v.in = false; v.push = false; v.dirty = false; v.distDirty = false; v.meets = false;
+                v.trail = 0; v.other = -1; v.cdist = -1.f; v.old = 0.f;
             }
-            /* chains of lanes that target the same pixel, in lane (= visiting) order: chain_sort64.  The depth in the chain is the
-             * number of visitors before this lane. */
-            const unsigned long long live = __ballot(have);
-            int prev = -1, depth = 0;
-            bool isLast = true;
-            if (live) chain_sort64(have, cIdx, lane, prev, depth, isLast);
+            /* both slots' loads in one round trip */
+            uint16_t dz[2] = {0, 0};
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++)
+                if (V[sl].have) {
+                    V[sl].trail = c.mem[V[sl].cIdx];
+                    V[sl].old = c.dist[V[sl].cIdx];
+                    dz[sl] = c.depth[(size_t)cyn[sl] * c.rowStride + cxn[sl]];
+                }
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++)
+                if (V[sl].have) {
+                    Visit& v = V[sl];
+                    double z = (double)dz[sl] * factor;
+                    if (z > 5.0) z = 0.0;
+                    if (z != 0.0) {
+                        const double px = ((double)cxn[sl] - cx) * z / fx, py = ((double)cyn[sl] - cy) * z / fy;
+                        const int pl = v.plid;
+                        const double sd = plN[pl][0] * (px - plC[pl][0]) + plN[pl][1] * (py - plC[pl][1]) + plN[pl][2] * (z - plC[pl][2]);
+                        v.cdist = (float)fabs(sd);
+                        const double cd = (double)v.cdist;
+                        v.in = cd * cd < 9 * plMse[pl] + 1e-5;
+                    }
+                }
+            /* chains of visits that target the same pixel, in visiting order: the depth in the chain is the number of visitors before */
+            const unsigned long long live0 = __ballot(V[0].have), live1 = __ballot(V[1].have);
+            int prev[2] = {-1, -1}, depth[2] = {0, 0};
+            bool isLast[2] = {true, true};
+            if (live1) chain_sort128(V[0].have, V[0].cIdx, V[1].have, V[1].cIdx, lane, ffTmp, prev[0], depth[0], isLast[0], prev[1], depth[1], isLast[1]);
+            else if (live0) chain_sort64(V[0].have, V[0].cIdx, lane, prev[0], depth[0], isLast[0]);
             int maxDepth = 0;
-            while (__ballot(depth > maxDepth)) maxDepth++;
+            while (__ballot(depth[0] > maxDepth || depth[1] > maxDepth)) maxDepth++;
 #ifdef AHC_PROFILE
-            ffSteps++; if (maxDepth > 0) ffDup++; ffDepth += maxDepth; ffHave += __popcll(live);
+            ffSteps++; if (maxDepth > 0) ffDup++; ffDepth += maxDepth; ffHave += __popcll(live0) + __popcll(live1);
 #endif
-            bool push = false, dirty = false, distDirty = false, meets = false;
-            int other = -1;
             for (int r = 0; r <= maxDepth; r++) {
                 if (r > 0) {
-                    /* a lane of depth r continues from its predecessor's output: label | flags in one word, the distance */
-                    const int src = prev < 0 ? lane : prev;
-                    const int sIn = __shfl((trail & 0xFFFF) | (dirty ? 0x10000 : 0) | (distDirty ? 0x20000 : 0), src);
-                    const float oIn = __shfl(old, src);
-                    if (have && depth == r) { trail = (int)(int16_t)(sIn & 0xFFFF); dirty = (sIn & 0x10000) != 0; distDirty = (sIn & 0x20000) != 0; old = oIn; }
+                    /* a visit of depth r continues from its predecessor's output: label | flags in one word, the distance */
+                    const int w0 = (V[0].trail & 0xFFFF) | (V[0].dirty ? 0x10000 : 0) | (V[0].distDirty ? 0x20000 : 0);
+                    const int w1 = (V[1].trail & 0xFFFF) | (V[1].dirty ? 0x10000 : 0) | (V[1].distDirty ? 0x20000 : 0);
+                    const float o0 = V[0].old, o1 = V[1].old;
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        const int src = prev[sl] < 0 ? lane : prev[sl];
+                        const int sa = __shfl(w0, src & 63), sb = __shfl(w1, src & 63);
+                        const float oa = __shfl(o0, src & 63), ob = __shfl(o1, src & 63);
+                        if (V[sl].have && depth[sl] == r) {
+                            const int sIn = (src & 64) ? sb : sa;
+                            V[sl].trail = (int)(int16_t)(sIn & 0xFFFF); V[sl].dirty = (sIn & 0x10000) != 0; V[sl].distDirty = (sIn & 0x20000) != 0;
+                            V[sl].old = (src & 64) ? ob : oa;
+                        }
+                    }
                 }
-                if (have && depth == r) {
-                    const bool active = !(trail <= -6) && !(trail >= 0 && trail == plid);
-                    if (active) {
-                        if (in && trail >= 0) { meets = true; other = trail; }
-                        if (in && cdist < old) { trail = plid; old = cdist; push = true; dirty = true; distDirty = true; }
-                        else if (trail < 0) { trail = trail - 1; dirty = true; }
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    Visit& v = V[sl];
+                    if (v.have && depth[sl] == r) {
+                        const bool active = !(v.trail <= -6) && !(v.trail >= 0 && v.trail == v.plid);
+                        if (active) {
+                            if (v.in && v.trail >= 0) { v.meets = true; v.other = v.trail; }
+                            if (v.in && v.cdist < v.old) { v.trail = v.plid; v.old = v.cdist; v.push = true; v.dirty = true; v.distDirty = true; }
+                            else if (v.trail < 0) { v.trail = v.trail - 1; v.dirty = true; }
+                        }
                     }
                 }
             }
-            /* planes that meet and are similar enough are connected for the re-merge (rare: one lane at a time) */
-            unsigned long long cm = __ballot(meets);
-            while (cm) {
-                const int l = __builtin_ctzll(cm);
-                cm &= cm - 1;
-                const int o = ex[rl_i(other, l)], me = ex[rl_i(plid, l)];
-                if (lane == 0 && similarity(c, me, o) >= P.cos30) { list_insert(c, o, me); list_insert(c, me, o); }
-                fence();
+            /* planes that meet and are similar enough are connected for the re-merge (rare: one lane at a time; a set insertion) */
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                unsigned long long cm = __ballot(V[sl].meets);
+                while (cm) {
+                    const int l = __builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    const int o = ex[rl_i(V[sl].other, l)], me = ex[rl_i(V[sl].plid, l)];
+                    if (lane == 0 && similarity(c, me, o) >= P.cos30) { list_insert(c, o, me); list_insert(c, me, o); }
+                    fence();
+                }
             }
-            if (have && isLast && dirty) {
-                c.mem[cIdx] = (int16_t)trail;
-                if (distDirty) c.dist[cIdx] = old;
-            }
-            const unsigned long long pm = __ballot(push);
-            if (pm) {
-                const int np = __popcll(pm);
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++)
+                if (V[sl].have && isLast[sl] && V[sl].dirty) {
+                    c.mem[V[sl].cIdx] = (int16_t)V[sl].trail;
+                    if (V[sl].distDirty) c.dist[V[sl].cIdx] = V[sl].old;
+                }
+            const unsigned long long pm0 = __ballot(V[0].push), pm1 = __ballot(V[1].push);
+            if (pm0 | pm1) {
+                const int np0 = __popcll(pm0), np = np0 + __popcll(pm1);
                 if (tail + np > P.rfCap) { c.status |= 2; break; }
-                if (push) c.rf[tail + __popcll(pm & lt)] = (uint32_t)cIdx | (uint32_t)plid << AHCD_PIXBITS;
+                if (V[0].push) c.rf[tail + __popcll(pm0 & lt)] = (uint32_t)V[0].cIdx | (uint32_t)V[0].plid << AHCD_PIXBITS;
+                if (V[1].push) c.rf[tail + np0 + __popcll(pm1 & lt)] = (uint32_t)V[1].cIdx | (uint32_t)V[1].plid << AHCD_PIXBITS;
                 tail += np;
             }
             head += cnt;
@@ -883,9 +1002,9 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
     for (int i = lane; i < nEx; i += 64) {
         int pm = -1;
         if (isValid[i]) {
-            const int r = ds_find(c, c.rid[ex[i]]);
+            const int r = ds_find(c, rid_block(c.rid[ex[i]]));
             for (int j = 0; j < nFinal; j++)
-                if (r == c.rid[ex2[j]]) { pm = j; break; }
+                if (r == rid_block(c.rid[ex2[j]])) { pm = j; break; }
         }
         plidmap[i] = pm;
     }
@@ -894,7 +1013,7 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
         const int nd = ex2[i];
         for (int q = 0; q < 3; q++) { planes[i].normal[q] = c.fit[8 * (size_t)nd + 3 + q]; planes[i].center[q] = c.fit[8 * (size_t)nd + q]; }
         planes[i].mse = c.fit[8 * (size_t)nd + 6]; planes[i].curvature = c.fit[8 * (size_t)nd + 7];
-        planes[i].n_points = c.N[nd]; planes[i].rid = c.rid[nd];
+        planes[i].n_points = c.N[nd]; planes[i].rid = rid_block(c.rid[nd]);
     }
     fence();
     TP();
