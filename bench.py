@@ -784,6 +784,10 @@ def main():
     ap.add_argument("--preload", type=int, default=400,
                     help="single-context steps measured BEFORE the timed loop (reported as one_batch_at_a_time; they also carry the "
                          "device through its clock transient under load); 0 under a profiler")
+    ap.add_argument("--settle", type=int, default=300,
+                    help="untimed steps of the TIMED loop's own shape (all contexts in flight) before the warm-up: the device's clocks and the contexts the "
+                         "single-context preload never touched settle under the load the timed region will apply (measured: 20 timed steps straight after "
+                         "the preload 2.06-2.10 ms per step, after 300 such steps 1.92; a 1000-step run 1.88); 0 under a profiler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-fed rate and the config-3 full front-end block")
     ap.add_argument("--bow", action="store_true", help="also run the vocabulary tree descent in every step")
@@ -897,6 +901,8 @@ def main():
     # clocks go through a transient in the first half second under load (one context: 203 k frames/s over 20 steps, 192 k over
     # 200, 203-206 k over 1000), which a 20-step timed loop straight after start-up may or may not hit (200-236 k measured).
     one_at_a_time = None
+    if profiled:                                    # a kernel trace of the timed steps, not of the pre-steps
+        args.preload, args.settle = 0, 0
     n1 = max(0, args.preload)
     if n1:
         for _ in range(5):
@@ -920,6 +926,9 @@ def main():
             acc[k] = acc.get(k, 0.0) + v
     fe.ctx.profile_enable(False)
 
+    for _ in range(max(0, args.settle)):            # untimed, the timed loop's own load pattern
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -405,21 +405,27 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         const unsigned long long cp0 = CP_T();
         CP_CNT(0);
         c.heapSize = uni_i(c.heapSize);
-        p = uni_i(heap_pop(c));
-        CP_ADD(1, cp0);
-        const unsigned long long cp1 = CP_T();
-        /* everything that depends on p alone in ONE round trip: flags, list head, sums, normal */
+        p = uni_i((int)c.heapId[0]);
+        /* everything that depends on p alone in ONE round trip - flags, list head, sums, normal - issued BEFORE the queue is repaired: the
+         * sift-down touches LDS only, so the round trip runs beside it (round 6) */
         const int nouseP = c.nouse[p], lenP = c.nbLen[p], offP = c.nbOff[p];
         double Sp[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) Sp[k] = c.S[9 * (size_t)p + k];
         const int Np = c.N[p], ridP = c.rid[p];
         const double npx = c.fit[8 * (size_t)p + 3], npy = c.fit[8 * (size_t)p + 4], npz = c.fit[8 * (size_t)p + 5];
+        (void)heap_pop(c);
+        CP_ADD(1, cp0);
+        const unsigned long long cp1 = CP_T();
         if (uni_b(nouseP != 0)) continue;
         const int sizeP = c.dsSize[rid_root(ridP)];             /* in flight beside the list loads below */
         const int Lp = uni_i(lenP);
 #ifdef AHC_PROFILE
+#ifdef AHC_PROFILE_HOT
+        if (blockIdx.x == 0 && c.lane == 0 && p == c.nNodes - 1 && p >= c.P.NB / 2) g_ahcProf[7] += 1;      /* pops of the node the last merge made */
+#else
         if (c.lane == 0) atomicMax(&g_ahcProf[7], (unsigned long long)Lp);
+#endif
 #endif
         if (Lp > c.listCap) { c.status |= 2; return; }
         const GLOBAL_AS int* listP = c.pool + offP;

@@ -367,20 +367,16 @@ int drfe_frame_download_grid(drfe_ctx* c, int slot, int32_t* offsets, int32_t* i
     return DRFE_OK;
 }
 
-int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc, const drfe_camera* cam, float th,
-                                 int mono, int check_ori, int nframes, void* stream)
+} /* extern "C": the two helpers below have C++ linkage (match_internal.h) */
+
+/* drfe_match_consecutive_batch in two halves (drfe_pipeline_submit replays the second one from a captured graph):
+ *   stage    the per-pair records and the poses into pinned memory the context owns, two copies onto the stream (returns without waiting)
+ *   enqueue  the memsets and kernels: everything a hipGraph can hold - kernel arguments by value, no host data */
+int drfe_match_consecutive_stage(drfe_ctx* c, const float* Tcw, const float* Twc, const drfe_camera* cam, int mono, int nframes, hipStream_t s)
 {
-    if (!c || !Tcw || !Twc || !cam) return DRFE_ERR_INVALID;
-    if (nframes < 2 || nframes > c->lastBatch || !c->glueValid) {
-        c->err = "match: needs an extracted batch of >= 2 frames with stereo/grid computed";
-        return DRFE_ERR_STATE;
-    }
-    HIPCHK(c, hipSetDevice(c->device));
     MatchBuffers* m = drfe_match_buffers(c);
     if (!m) return DRFE_ERR_HIP;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int np = nframes - 1;
-    /* pairs + poses staged in pinned memory the context owns: the call returns without waiting for the stream */
     const size_t pairBytes = sizeof(MatchPair) * (size_t)c->cfg.max_batch, poseBytes = sizeof(float) * 16 * (size_t)c->cfg.max_batch;
     if (!m->h_stage[0]) {
         m->stageBytes = pairBytes + poseBytes;
@@ -408,11 +404,37 @@ int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc
     HIPCHK(c, hipMemcpyAsync(m->d_pairs, pairs, sizeof(MatchPair) * np, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_poses, poses, sizeof(float) * 16 * nframes, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(m->stageEv[slotK], s));
+    return DRFE_OK;
+}
+
+hipError_t drfe_match_consecutive_enqueue(drfe_ctx* c, const drfe_camera* cam, float th, int check_ori, int nframes, hipStream_t s)
+{
+    MatchBuffers* m = drfe_match_buffers(c);
+    if (!m) return hipErrorOutOfMemory;
+    hipError_t e = hipMemsetAsync(c->d_match, 0xFF, sizeof(int) * (size_t)nframes * c->maxKp, s);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_matchCount, 0, sizeof(int) * nframes, s);
+    if (e == hipSuccess) e = drfe_launch_mappoints_last(c, *m, *cam, c->d_poses, nframes, s);
+    if (e == hipSuccess) e = drfe_launch_window_match(c, *m, *cam, nframes - 1, c->maxKp, 0, th, 0.f, check_ori, nullptr, s, 2);      /* its own overflow word */
+    return e;
+}
+
+extern "C" {
+
+int drfe_match_consecutive_batch(drfe_ctx* c, const float* Tcw, const float* Twc, const drfe_camera* cam, float th,
+                                 int mono, int check_ori, int nframes, void* stream)
+{
+    if (!c || !Tcw || !Twc || !cam) return DRFE_ERR_INVALID;
+    if (nframes < 2 || nframes > c->lastBatch || !c->glueValid) {
+        c->err = "match: needs an extracted batch of >= 2 frames with stereo/grid computed";
+        return DRFE_ERR_STATE;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    /* pairs + poses staged in pinned memory the context owns: the call returns without waiting for the stream */
+    const int rc = drfe_match_consecutive_stage(c, Tcw, Twc, cam, mono, nframes, s);
+    if (rc != DRFE_OK) return rc;
     if (c->profile) { (void)hipEventRecord(c->ev[DRFE_STAGE_MATCH][0], s); c->evUsed[DRFE_STAGE_MATCH] = true; }
-    HIPCHK(c, hipMemsetAsync(c->d_match, 0xFF, sizeof(int) * (size_t)nframes * c->maxKp, s));
-    HIPCHK(c, hipMemsetAsync(c->d_matchCount, 0, sizeof(int) * nframes, s));
-    HIPCHK(c, drfe_launch_mappoints_last(c, *m, *cam, c->d_poses, nframes, s));
-    HIPCHK(c, drfe_launch_window_match(c, *m, *cam, np, c->maxKp, 0, th, 0.f, check_ori, nullptr, s, 2));      /* its own overflow word */
+    HIPCHK(c, drfe_match_consecutive_enqueue(c, cam, th, check_ori, nframes, s));
     if (c->profile) (void)hipEventRecord(c->ev[DRFE_STAGE_MATCH][1], s);
     return DRFE_OK;
 }

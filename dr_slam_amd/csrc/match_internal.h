@@ -112,5 +112,8 @@ hipError_t drfe_launch_fuse_search(drfe_ctx* c, int slot, const drfe_frustum_poi
                                    int* d_listCount = nullptr);
 
 MatchBuffers* drfe_match_buffers(drfe_ctx* c);   /* lazily allocated, owned by the context */
+/* the two halves of drfe_match_consecutive_batch (capi_match.cpp): host staging + copies, then memsets + kernels (capturable) */
+int drfe_match_consecutive_stage(drfe_ctx* c, const float* Tcw, const float* Twc, const drfe_camera* cam, int mono, int nframes, hipStream_t s);
+hipError_t drfe_match_consecutive_enqueue(drfe_ctx* c, const drfe_camera* cam, float th, int check_ori, int nframes, hipStream_t s);
 void drfe_match_buffers_free(drfe_ctx* c);
 #endif
