@@ -743,10 +743,8 @@ __device__ __forceinline__ void ahc_cluster_frame(const AhcDevFrame* __restrict_
             if (bm < 0) cnt = (up >= 0 ? AHC_WIN - 1 : 0) + (left >= 0 ? AHC_WIN - 1 : 0);
             else cnt = ((i > 0 && up != bm) ? AHC_WIN - 1 : 0) + ((j > 0 && left != bm) ? AHC_WIN - 1 : 0);
         }
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        const int tot = __shfl(incl, 63);
+        const int incl = drfe_wave_incl_scan(cnt, lane);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
         if (nRf + tot > P.rfCap) { c.status |= 2; break; }
         int at = nRf + incl - cnt;
         if (cnt) {

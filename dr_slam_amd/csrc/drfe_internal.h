@@ -345,6 +345,42 @@ __device__ __forceinline__ uint32_t drfe_div_by(uint32_t n, uint32_t d, uint32_t
     if (q * d > n) q--;
     return q;
 }
+/* Inclusive prefix sum over the wavefront without a trip through the LDS crossbar: four DPP row shifts inside each row of sixteen
+ * lanes (0 shifted in), the three row totals through v_readlane.  ~12 VALU instructions against six dependent ds_bpermute round
+ * trips of the __shfl_up form (round 6; k_quadtree's three block scans per round sit on its barrier-to-barrier path).  Every
+ * lane of the wavefront must be active. */
+__device__ __forceinline__ int drfe_wave_incl_scan(int v, int lane)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      /* row_shr:8 */
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
+
+/* Sum / minimum over the wavefront, to every lane (wave-uniform): two quad permutes and two row rotations as DPP operands leave every
+ * lane of a row with the row's result; the four rows meet through v_readlane.  Integers only (the order of the additions differs from
+ * the butterfly's).  Every lane must be active. */
+__device__ __forceinline__ int drfe_wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);       /* quad_perm [1, 0, 3, 2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);       /* quad_perm [2, 3, 0, 1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);      /* row_ror:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);      /* row_ror:8 */
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ uint32_t drfe_wave_min_u32(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
 __device__ __forceinline__ void drfe_xcd_swizzle_2d(uint32_t magic, int& lx, int& ly)
 {
     const uint32_t gx = gridDim.x, nwg = gx * gridDim.y;

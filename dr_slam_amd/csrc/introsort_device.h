@@ -533,9 +533,7 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
             uint32_t loc = 0;
 #pragma unroll
             for (int k = 0; k < EPL; k++) loc += cnt[lane * EPL + k];
-            uint32_t inc = loc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            const uint32_t inc = (uint32_t)drfe_wave_incl_scan((int)loc, lane);      /* wavefront 0 whole: wv is wave-uniform */
             uint32_t run = inc - loc;
 #pragma unroll
             for (int k = 0; k < EPL; k++) { const uint32_t c = cnt[lane * EPL + k]; cnt[lane * EPL + k] = run; run += c; }

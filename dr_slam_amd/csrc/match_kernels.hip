@@ -299,13 +299,8 @@ __device__ void window_query_wave(const MatchQuery& q, size_t qo, int lane, int 
         runB = gOff[cb + nMinCellY];
         runN = gOff[cb + nMaxCellY + 1] - runB;
     }
-    int incl = runN;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    const int T = __shfl(incl, 63);
+    const int incl = drfe_wave_incl_scan(runN, lane);
+    const int T = __builtin_amdgcn_readlane(incl, 63);
     int nOut = 0;
     bool overflow = false;
     uint32_t myKey = 0xFFFFFFFFu, myIdx = 0;
@@ -334,11 +329,9 @@ __device__ void window_query_wave(const MatchQuery& q, size_t qo, int lane, int 
     if (__any(overflow) && lane == 0) atomicOr(status, 4);
     /* the query's overall best (min distance, then earliest visit): what the claim replay takes when
      * nobody claimed it first */
-    uint32_t mn = myKey;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    const uint32_t mn = drfe_wave_min_u32(myKey);
     const unsigned long long who = __ballot(myKey == mn);
-    const uint32_t bIdx = (uint32_t)__shfl((int)myIdx, __ffsll((long long)who) - 1);
+    const uint32_t bIdx = (uint32_t)__builtin_amdgcn_readlane((int)myIdx, __ffsll((long long)who) - 1);
     if (lane == 0) {
         candCnt[qo] = min(nOut, DRFE_MATCH_MAX_CAND);
         candBest[qo] = make_uint2(mn, bIdx);
@@ -459,12 +452,7 @@ __global__ __launch_bounds__(WQ_THREADS) void k_window_candidates(const MatchPai
 /* ------------------------------------------------------------------------------------------------ */
 /* sequential claim replay: one wavefront per frame pair                                             */
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return drfe_wave_min_u32(v); }
 
 /* SearchByProjection(CurrentFrame, LastFrame, th, bMono): best unclaimed candidate per map point in
  * index order, TH_HIGH gate, rotation histogram with the reference's 1/HISTO_LENGTH factor quirk
@@ -1291,13 +1279,8 @@ __global__ __launch_bounds__(256) void k_fuse_search(const drfe_frustum_point* _
                 runB = gridOff[cb + nMinCellY];
                 runN = gridOff[cb + nMaxCellY + 1] - runB;
             }
-            int incl = runN;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
-            }
-            const int T = __shfl(incl, 63);
+            const int incl = drfe_wave_incl_scan(runN, lane);
+            const int T = __builtin_amdgcn_readlane(incl, 63);
             uint32_t myKey = 0xFFFFFFFFu, myIdx = 0;
             for (int s0 = 0; s0 < T; s0 += WAVE) {
                 const int sq = s0 + lane;

@@ -466,17 +466,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(const FastCell* __restrict__ 
     }
     unsigned long long emit = __any(m20 != 0) ? m20 : m7;         /* fallback decided per cell after NMS@ini */
     const int cnt = __popcll(emit);
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    const int total = __shfl(incl, 63);
+    const int incl = drfe_wave_incl_scan(cnt, lane);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
     if (total == 0) return;
     int base = 0;
     if (lane == 0) base = atomicAdd(&candCount[DRFE_CC_IDX(slot, fc.level)], total);
-    base = __shfl(base, 0);
+    base = __builtin_amdgcn_readfirstlane(base);
     if (base + total > (int)fc.candCap) { if (lane == 0) atomicOr(status, 1); return; }
     size_t pos = (size_t)slot * candSlotElems + fc.candOff + base + (incl - cnt);
     const uint32_t magic = 0xFFFFFFFFu / (uint32_t)nq + 1u;     /* i / nq == umulhi(i, magic) for i < 2^16, nq > 1 */
@@ -859,12 +854,7 @@ template <int QT_THREADS> __device__ __forceinline__ int qt_scan2(int a, int b, 
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = a + b;
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
+    const int incl = drfe_wave_incl_scan(s, lane);
     if (lane == 63) wtot[w] = incl;
     __syncthreads();
     int before = 0, total = 0;
@@ -887,7 +877,7 @@ __device__ __forceinline__ void qt_wave_add(int* arr, int tgt)
     unsigned long long active = __ballot(tgt >= 0);
     while (active) {
         const int leader = __ffsll((long long)active) - 1;
-        const int t = __shfl(tgt, leader);
+        const int t = __builtin_amdgcn_readlane(tgt, leader);
         const unsigned long long m = __ballot(tgt == t);
         if (lane == leader) atomicAdd(&arr[t], __popcll(m));
         active &= ~m;
@@ -1451,12 +1441,7 @@ __global__ __launch_bounds__(DESC_THREADS) void k_orient_desc(const DevGeom* __r
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int j = 0; j < DESC_KPW; j++) {
-            m10[j] += __shfl_xor(m10[j], o);
-            m01[j] += __shfl_xor(m01[j], o);
-        }
+    for (int j = 0; j < DESC_KPW; j++) { m10[j] = drfe_wave_sum_i32(m10[j]); m01[j] = drfe_wave_sum_i32(m01[j]); }      /* integer moments: any order */
     /* steered BRIEF on the blurred level: lane owns bit `lane` of each of the four 64-bit words */
     uint32_t pat[4];
 #pragma unroll
