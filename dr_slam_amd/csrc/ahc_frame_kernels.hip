@@ -848,6 +848,7 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
         for (int k = lane; k < NB; k += 64) blkLds[k] = (int8_t)(c.blkMap[k] >= 0 ? 1 : 0);
         fence();
         const int eLane = lane >> 2, nbLane = lane & 3;          /* entry of a half-step, neighbour (left, right, up, down) */
+        const uint32_t magicW = 0xFFFFFFFFu / (uint32_t)w + 1u;   /* ceil(2^32 / w): n / w == umulhi(n, magicW) while n * (magicW * w - 2^32) < 2^32, i.e. for every pixel index below 2^21 at w <= 2048 */
         /* Round 6: THIRTY-TWO queue entries per step - two visits per lane (slot 0: entries 0..15 of the step, slot 1: entries 16..31; visit
          * id = slot * 64 + lane = visiting order).  What a step pays once whatever it holds - the round trip of the labels / distances /
          * depths, the fence, the queue bookkeeping - is now paid per 128 visits; the chains of same-pixel visits come from a 128-key sort. */
@@ -873,7 +874,7 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
                 const bool mine = 16 * sl + eLane < cnt;
                 const int sIdx = (int)(e[sl] & AHCD_PIXMASK);
                 v.plid = (int)(e[sl] >> AHCD_PIXBITS);
-                const int sy = sIdx / w, sx = sIdx - sy * w;
+                const int sy = (int)__umulhi((uint32_t)sIdx, magicW), sx = sIdx - sy * w;      /* sIdx / w: exact for sIdx < 2^21, w <= 2048 */
                 cxn[sl] = sx; cyn[sl] = sy;
                 bool have = false;
                 if (nbLane == 0) { have = sx > 0; cxn[sl] = sx - 1; }
@@ -1242,14 +1243,15 @@ extern "C" __global__ __launch_bounds__(64) void k_ahc_labels_scatter(const AhcD
 
 int drfe_ahc_device_fits(int w, int h)
 {
-    return w >= AHC_WIN && h >= AHC_WIN && (w / AHC_WIN) * (h / AHC_WIN) <= AHCD_HEAP_BIG && (size_t)w * h <= ((size_t)1 << AHCD_PIXBITS);
+    /* w <= 2048: the flood fill divides pixel indices by w with a 32-bit reciprocal (exact for indices below 2^21 up to that width) */
+    return w >= AHC_WIN && w <= 2048 && h >= AHC_WIN && (w / AHC_WIN) * (h / AHC_WIN) <= AHCD_HEAP_BIG && (size_t)w * h <= ((size_t)1 << AHCD_PIXBITS);
 }
 
 hipError_t drfe_launch_ahc_frames(const AhcDevFrame* d_frames, int nframes, const AhcDevParams& P, hipStream_t s, hipEvent_t* ev3)
 {
     if (nframes <= 0) return hipSuccess;
     static_assert(AHC_HANDOFF_INTS >= AHCD_HO_LABELS + 1, "handoff words");
-    if (P.NB > AHCD_HEAP_BIG || (size_t)P.w * P.h > ((size_t)1 << AHCD_PIXBITS)) return hipErrorInvalidValue;
+    if (P.NB > AHCD_HEAP_BIG || (size_t)P.w * P.h > ((size_t)1 << AHCD_PIXBITS) || P.w > 2048) return hipErrorInvalidValue;
     if (P.NB <= AHCD_HEAP_SMALL) {
         hipLaunchKernelGGL(k_ahc_cluster, dim3(nframes), dim3(64), 0, s, d_frames, P);
         if (ev3) (void)hipEventRecord(ev3[0], s);
