@@ -345,11 +345,21 @@ __device__ __forceinline__ void list_erase(Ctx& c, int a, int v)
         if (found) c.nbLen[a] = len - 1;
         return;
     }
-    int pos = 0;
-    while (pos < len && L[pos] < v) pos++;
-    if (pos >= len || L[pos] != v) return;
-    for (int k = pos; k + 1 < len; k++) L[k] = L[k + 1];
-    c.nbLen[a] = len - 1;
+    /* longer lists, eight entries at a time: the loads of a group are independent (one round trip per group instead of one per
+     * entry); an entry behind v moves one place to the left - to a place at or before its own, so no group reads what an earlier one wrote */
+    bool found = false;
+    for (int k0 = 0; k0 < len; k0 += 8) {
+        int e[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = k0 + j < len ? L[k0 + j] : 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (k0 + j < len) {
+                if (e[j] == v) found = true;
+                else if (found) L[k0 + j - 1] = e[j];
+            }
+    }
+    if (found) c.nbLen[a] = len - 1;
 }
 
 /* what a merge of p and q into the new node id does to the list of a common neighbour a: p and q leave, id (the largest id so
@@ -367,9 +377,14 @@ __device__ __forceinline__ void list_replace2(Ctx& c, int a, int p, int q, int i
         for (int k = 0; k < 8; k++)
             if (k < len && e[k] != p && e[k] != q) { if (w != k) L[w] = e[k]; w++; }
     } else {
-        for (int k = 0; k < len; k++) {
-            const int v = L[k];
-            if (v != p && v != q) { if (w != k) L[w] = v; w++; }
+        /* eight entries at a time (independent loads: a round trip per group); an entry is stored at or before its own place */
+        for (int k0 = 0; k0 < len; k0 += 8) {
+            int e[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[k] = k0 + k < len ? L[k0 + k] : 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < len && e[k] != p && e[k] != q) { if (w != k0 + k) L[w] = e[k]; w++; }
         }
     }
     L[w] = id;
@@ -421,7 +436,9 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
         const int sizeP = c.dsSize[rid_root(ridP)];             /* in flight beside the list loads below */
         const int Lp = uni_i(lenP);
 #ifdef AHC_PROFILE
-#ifdef AHC_PROFILE_HOT
+#if defined(AHC_PROFILE_CHUNKS)
+        if (blockIdx.x == 0 && c.lane == 0) g_ahcProf[7] += (unsigned long long)((Lp + 63) / 64) | ((unsigned long long)Lp << 32);      /* trial chunks | neighbours, summed over the pops */
+#elif defined(AHC_PROFILE_HOT)
         if (blockIdx.x == 0 && c.lane == 0 && p == c.nNodes - 1 && p >= c.P.NB / 2) g_ahcProf[7] += 1;      /* pops of the node the last merge made */
 #else
         if (c.lane == 0) atomicMax(&g_ahcProf[7], (unsigned long long)Lp);
@@ -527,7 +544,7 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
             fence();
             /* u = nbs(p) U nbs(cand) \ {p, cand}, sorted.  Short lists (the rule): lane i holds one element of A ++ B; it is kept
              * unless it is p, cand or an element of B that A holds too, and its place in u is the number of kept elements
-             * smaller than it.  Long lists: merged by one lane. */
+             * smaller than it.  Long lists: the same count through binary searches (below). */
             int Lu = 0;
             if (Lp + Lc <= 64) {
                 const int tot = Lp + Lc;
@@ -546,15 +563,46 @@ __device__ void cluster(Ctx& c, int* ex, int& nEx)
                 }
                 if (keep) c.lU[smaller] = (uint16_t)v;
                 Lu = __popcll(km);
-            } else if (lane == 0) {
-                int i = 0, j = 0;
-                while (i < Lp || j < Lc) {
-                    int v;
-                    if (j >= Lc || (i < Lp && c.lA[i] < c.lB[j])) v = c.lA[i++];
-                    else if (i >= Lp || c.lB[j] < c.lA[i]) v = c.lB[j++];
-                    else { v = c.lA[i]; i++; j++; }
-                    if (v != p && v != candNb) c.lU[Lu++] = (uint16_t)v;
+            } else {
+                /* long lists (a node in the middle of a big plane: up to a few hundred neighbours), all lanes: an element's place in u is
+                 * the number of kept elements below it, counted without a merge loop - A = nbs(p) and B = nbs(cand) are sorted and free of
+                 * duplicates, cand is in A and p in B (they are neighbours) and nowhere else, a value both lists hold is kept from A:
+                 *   v = A[i], v != cand:   i - [cand < v] + |{b in B: b < v}| - |{common values < v}| - [p < v]
+                 *   v = B[j], v != p, not in A:   |{a in A: a < v}| - [cand < v] + j - |{common values < v}| - [p < v]
+                 * |{... < v}| in the other list is a binary search (LDS), the common values below v a running ballot count in list order.
+                 * (One lane merging the two lists cost ~100 cycles per element: 6 us of a merge's 16 at 1280 x 960.) */
+                auto lower_bound = [&](const uint16_t* L, int n, int v, bool& has) -> int {
+                    int lo = 0, hi = n;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)L[mid] < v) lo = mid + 1; else hi = mid; }
+                    has = lo < n && (int)L[lo] == v;
+                    return lo;
+                };
+                bool pInB = false;
+                (void)lower_bound(c.lB, Lc, p, pInB);              /* adjacency is symmetric, so it is; the count below does not assume it */
+                const int pB = pInB ? 1 : 0;
+                int common = 0;
+                for (int base = 0; base < Lp; base += 64) {
+                    const int i = base + lane;
+                    const bool on = i < Lp;
+                    const int v = on ? (int)c.lA[i] : 0x7fffffff;
+                    bool inB = false;
+                    const int lb = on ? lower_bound(c.lB, Lc, v, inB) : 0;
+                    const unsigned long long cm = __ballot(on && inB);
+                    if (on && v != candNb) c.lU[i - (candNb < v ? 1 : 0) + lb - (common + __popcll(cm & ((1ull << lane) - 1ull))) - (p < v ? pB : 0)] = (uint16_t)v;
+                    common += __popcll(cm);
                 }
+                int commonB = 0;
+                for (int base = 0; base < Lc; base += 64) {
+                    const int j = base + lane;
+                    const bool on = j < Lc;
+                    const int v = on ? (int)c.lB[j] : 0x7fffffff;
+                    bool inA = false;
+                    const int lb = on ? lower_bound(c.lA, Lp, v, inA) : 0;
+                    const unsigned long long cm = __ballot(on && inA);
+                    if (on && !inA && v != p) c.lU[lb - (candNb < v ? 1 : 0) + j - (commonB + __popcll(cm & ((1ull << lane) - 1ull))) - (p < v ? pB : 0)] = (uint16_t)v;
+                    commonB += __popcll(cm);
+                }
+                Lu = Lp + Lc - common - 1 - pB;
             }
             Lu = uni_i(Lu);
             fence();
@@ -855,7 +903,16 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
         uint32_t eNext0 = 0, eNext1 = 0;
         int nextFrom0 = -1, nextFrom1 = -1;                      /* queue positions eNext0 / eNext1 were prefetched for (this lane) */
         struct Visit { bool have, in, push, dirty, distDirty, meets; int cIdx, plid, trail, other; float cdist, old; };
+#ifdef AHC_PROFILE_FF
+        unsigned long long ffc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FFC(k) do { const unsigned long long t__ = __builtin_readcyclecounter(); ffc[k] += t__ - ffT; ffT = t__; } while (0)
+#else
+#define FFC(k) (void)0
+#endif
         while (head < tail) {
+#ifdef AHC_PROFILE_FF
+            unsigned long long ffT = __builtin_readcyclecounter();
+#endif
             const int cnt = min(32, tail - head);
             Visit V[2];
             uint32_t e[2];
@@ -890,6 +947,7 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
                 v.have = have; v.in = false; v.push = false; v.dirty = false; v.distDirty = false; v.meets = false;
                 v.trail = 0; v.other = -1; v.cdist = -1.f; v.old = 0.f;
             }
+            FFC(0);
             /* both slots' loads in one round trip */
             uint16_t dz[2] = {0, 0};
 #pragma unroll
@@ -899,6 +957,10 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
                     V[sl].old = c.dist[V[sl].cIdx];
                     dz[sl] = c.depth[(size_t)cyn[sl] * c.rowStride + cxn[sl]];
                 }
+#ifdef AHC_PROFILE_FF
+            if (__ballot(dz[0] == 65535 && dz[1] == 65535 && V[0].old == 12345.f && V[1].trail == 777) == ~0ull) c.status |= 8;     /* wait for the loads here */
+#endif
+            FFC(1);
 #pragma unroll
             for (int sl = 0; sl < 2; sl++)
                 if (V[sl].have) {
@@ -914,12 +976,14 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
                         v.in = cd * cd < 9 * plMse[pl] + 1e-5;
                     }
                 }
+            FFC(2);
             /* chains of visits that target the same pixel, in visiting order: the depth in the chain is the number of visitors before */
             const unsigned long long live0 = __ballot(V[0].have), live1 = __ballot(V[1].have);
             int prev[2] = {-1, -1}, depth[2] = {0, 0};
             bool isLast[2] = {true, true};
             if (live1) chain_sort128(V[0].have, V[0].cIdx, V[1].have, V[1].cIdx, lane, ffTmp, prev[0], depth[0], isLast[0], prev[1], depth[1], isLast[1]);
             else if (live0) chain_sort64(V[0].have, V[0].cIdx, lane, prev[0], depth[0], isLast[0]);
+            FFC(3);
             int maxDepth = 0;
             while (__ballot(depth[0] > maxDepth || depth[1] > maxDepth)) maxDepth++;
 #ifdef AHC_PROFILE
@@ -956,6 +1020,7 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
                     }
                 }
             }
+            FFC(4);
             /* planes that meet and are similar enough are connected for the re-merge (rare: one lane at a time; a set insertion) */
 #pragma unroll
             for (int sl = 0; sl < 2; sl++) {
@@ -984,7 +1049,11 @@ __device__ __forceinline__ void ahc_refine_frame(const AhcDevFrame* __restrict__
             }
             head += cnt;
             fence();
+            FFC(5);
         }
+#ifdef AHC_PROFILE_FF
+        if (blockIdx.x == 0 && lane == 0) printf("flood fill, frame 0, shader cycles: entries + geometry %llu, loads %llu, f64 distances %llu, chain sort %llu, rounds %llu, connects + stores + appends + fence %llu\n", ffc[0], ffc[1], ffc[2], ffc[3], ffc[4], ffc[5]);
+#endif
         rfTotal = tail;
 #ifdef AHC_PROFILE
         if (lane == 0) { ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 4] = (int)ffSteps; ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 5] = (int)ffDup; ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 6] = (int)ffDepth; ((GLOBAL_AS int*)F.handoff)[AHCD_HO_TP + 7] = (int)ffHave; }

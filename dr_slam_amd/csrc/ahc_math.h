@@ -22,23 +22,27 @@ struct AhcFit {
     double center[3], normal[3], mse, curvature;
 };
 
+/* Eigen's JacobiRotation::makeGivens (real case: Jacobi.h) without lane-divergent branches.  Its two general cases are one
+ * computation with the roles of p and q exchanged - t = small / big, u = +-sqrt(1 + t t) with the sign of `big`, r = 1 / u, m = t r:
+ *   |p| > |q|:  c = 1 / u = r,           s = -t c     = -m
+ *   else:       s = -1 / u = -r,         c = -t s     = (-t)(-r) = m
+ * (sign changes are exact in IEEE arithmetic, so -1.0 / u == -(1.0 / u) and (-t) c == -(t c): the same bits as the branches) - and
+ * the two degenerate cases override the result.  On the device the trial merges run one plane fit per lane: with the branches, a
+ * wavefront whose lanes disagree on the case executes the division / square root / division sequence once per case (round 6). */
 AHC_HD void ahc_givens(double p, double q, double* c, double* s)
 {
-    if (q == 0.0) { *c = p < 0.0 ? -1.0 : 1.0; *s = 0.0; }
-    else if (p == 0.0) { *c = 0.0; *s = q < 0.0 ? 1.0 : -1.0; }
-    else if (fabs(p) > fabs(q)) {
-        const double t = q / p;
-        double u = sqrt(1.0 + t * t);
-        if (p < 0.0) u = -u;
-        *c = 1.0 / u;
-        *s = -t * (*c);
-    } else {
-        const double t = p / q;
-        double u = sqrt(1.0 + t * t);
-        if (q < 0.0) u = -u;
-        *s = -1.0 / u;
-        *c = -t * (*s);
-    }
+    const bool pBig = fabs(p) > fabs(q);
+    const double big = pBig ? p : q, small = pBig ? q : p;
+    const double t = small / big;
+    double u = sqrt(1.0 + t * t);
+    if (big < 0.0) u = -u;
+    const double r = 1.0 / u;
+    const double m = t * r;
+    double cc = pBig ? r : m, ss = pBig ? -m : -r;
+    if (p == 0.0) { cc = 0.0; ss = q < 0.0 ? 1.0 : -1.0; }
+    if (q == 0.0) { cc = p < 0.0 ? -1.0 : 1.0; ss = 0.0; }
+    *c = cc;
+    *s = ss;
 }
 
 /* eigen-decomposition of the symmetric matrix given by its lower triangle; ev ascending,
@@ -89,8 +93,8 @@ AHC_HD void ahc_eig3(double m00, double m10, double m20, double m11, double m21,
         else {
             const double e2 = ee * ee;
             const double ax = fabs(td), ay = fabs(ee);
-            double p, qp;
-            if (ax > ay) { p = ax; qp = ay / p; } else { p = ay; qp = ax / p; }
+            const double p = ax > ay ? ax : ay, lo = ax > ay ? ay : ax;       /* numext::hypot's scaling: one division whichever is larger */
+            const double qp = lo / p;
             const double h = (p == 0.0) ? 0.0 : p * sqrt(1.0 + qp * qp);
             if (e2 == 0.0) mu -= (ee / (td + (td > 0.0 ? 1.0 : -1.0))) * (ee / h);
             else mu -= e2 / (td + (td > 0.0 ? h : -h));
