@@ -212,7 +212,7 @@ def config5_aux(ctx, base, cam, n: int = 6):
     out["ahc_ms"] = (time.perf_counter() - t0) * 1e3 / n
     out["ahc_planes_per_frame"] = float(np.mean(npa))
     res = {}
-    for nb in (32, 128):        # a frame is a ~0.4 s chain on one wavefront at this size (12 288 blocks): the rate is frames per call over that latency
+    for nb in (32, 128, 256):   # a frame is a ~0.3 s chain on one wavefront at this size (12 288 blocks): the rate is frames per call over that latency, until every CU holds a frame (k_ahc_cluster_big: one per CU by LDS)
         db = np.stack([base[i % len(base)][1] for i in range(nb)])
         ctx.planes_ahc_post_batch(db, K4, inv, 5.0, 0.10)                   # Realsense.yaml:76-79; the first call of a size allocates the frame slots
         s0 = ctx.planes_ahc_stats()
@@ -243,7 +243,7 @@ def config5_aux(ctx, base, cam, n: int = 6):
     out["roofline_long_kernels"] = long_kernel_roofline(ms, nb, algo5)
     out["kernel_ms_one_call_alone"] = {k: round(v, 3) for k, v in ms.items() if v > 0}
     out["algorithmic_bytes_per_frame_lines_planes"] = {k: int(v) for k, v in algo5.items()}
-    out["ahc_post_batch"] = dict(res[128], at_32_frames_per_call=res[32],
+    out["ahc_post_batch"] = dict(res[128], at_32_frames_per_call=res[32], at_256_frames_per_call=res[256],
                                  note="host frames uploaded inside the call; extractor (k_ahc_cluster_big / k_ahc_refine_big, one wavefront per frame, one frame per CU by LDS) + voxel grids + "
                                       "gates and RANSAC refit (k_plane_refit) on the device; the pool uploads, launches and copies the post records")
     return out
@@ -423,8 +423,8 @@ FF_ALGO_BYTES = {"orb_extract": 7225354, "window_match": 676000, "lsd_lbd": 3072
 
 LONG_KERNEL_STAGE = {"k_lsd_order": "lsd_lbd", "k_lsd_grow": "lsd_lbd", "k_rect_improve": "lsd_lbd", "k_ahc_cluster": "ahc_planes", "k_ahc_refine": "ahc_planes",
                      "k_voxel_grid": "ahc_planes", "k_plane_refit": "ahc_planes"}
-# SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the committed counter passes (profiles/r05_long_kernels_summary.txt; a --pmc pass cannot run inside this process)
-LONG_KERNEL_LANES = {"k_lsd_grow": 0.746, "k_plane_refit": 0.331, "k_lsd_order": 0.733, "k_rect_improve": 0.083, "k_ahc_cluster": 0.381, "k_ahc_refine": 0.713, "k_voxel_grid": 0.589}
+# SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the committed counter passes (profiles/r06_long_kernels_summary.txt; a --pmc pass cannot run inside this process)
+LONG_KERNEL_LANES = {"k_lsd_grow": 0.729, "k_plane_refit": 0.331, "k_lsd_order": 0.737, "k_rect_improve": 0.083, "k_ahc_cluster": 0.382, "k_ahc_refine": 0.806, "k_voxel_grid": 0.584}
 
 
 def long_kernel_roofline(ms_by_kernel, frames, algo_bytes=None):
@@ -450,7 +450,7 @@ def full_frontend_roofline(frames_per_s: float, n_frames: int, live_ms=None):
            "limited_by": "latency chains: every frame's region growing / plane clustering / flood fill is an order-defined sequence on one or four wavefronts; "
                          "the rate is (frames resident) / (chain latency), and residency is bounded by LDS (a frame's `used` bitmap, queues, tables)"}
     out["long_kernels"] = long_kernel_roofline(live_ms or {}, n_frames)
-    out["long_kernels_lane_utilisation_source"] = "profiles/r05_long_kernels_summary.txt (rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU)"
+    out["long_kernels_lane_utilisation_source"] = "profiles/r06_long_kernels_summary.txt (rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU)"
     return out
 
 
@@ -1001,7 +1001,7 @@ def main():
         try:
             # the newest committed counter passes of this configuration and batch size
             cands = ["r05_pmc_traffic_c5_b%d.json", "r04_pmc_traffic_c5_b%d.json", "r02_pmc_traffic_c5_b%d.json"] if config == 5 else \
-                    ["r05_pmc_traffic_b%d.json", "r04_pmc_traffic_b%d.json", "r03_pmc_traffic_b%d.json", "r02_pmc_traffic_b%d.json"]
+                    ["r06_pmc_traffic_b%d.json", "r05_pmc_traffic_b%d.json", "r04_pmc_traffic_b%d.json", "r03_pmc_traffic_b%d.json", "r02_pmc_traffic_b%d.json"]
             pmc_name = next((c % B for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c % B))), cands[-1] % B)
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if pmc.get("batch") == B and kname in pmc["kernels"] and roof_stage != "pyramid":
