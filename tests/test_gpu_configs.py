@@ -382,3 +382,36 @@ def test_native_shard_rccl_single_rank():
             sh.broadcast(blob, root=1)
     finally:
         sh.close()
+
+
+def test_long_kernel_clock_reports_every_kernel_of_the_batch_entries():
+    """drfe_long_kernel_clock / drfe_long_kernel_ms (what bench.py prices the long kernels' roofline entries with): with the clock on,
+    the line and plane batch entries report a positive duration for every kernel that ran on the device, the results are the ones of
+    an unclocked call, and with it off the last values stay."""
+    from dr_slam_amd import lib, synth
+    cam = synth.ICL
+    frames = list(synth.sequence(3, 6, cam=cam, kind="living_room"))
+    gray = np.stack([f[0] for f in frames]); depth = np.stack([f[1] for f in frames])
+    K4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32)
+    inv = float(np.float32(1.0) / np.float32(cam.depth_factor))
+    c = lib.Context(max_batch=1)
+    try:
+        plain_l = c.lsd_extract_batch(gray, n_threads=2)
+        plain_p = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=2)
+        assert all(v == 0 for v in c.long_kernel_ms().values())
+        c.long_kernel_clock(True)
+        timed_l = c.lsd_extract_batch(gray, n_threads=2)
+        timed_p = c.planes_ahc_post_batch(depth, K4, inv, 9.0, 0.10, n_threads=2)
+        ms = c.long_kernel_ms()
+        for k in ("lines_image_passes", "k_lsd_keys", "k_lsd_order", "k_lsd_grow", "k_rect_improve", "k_lsd_keylines+k_lbd",
+                  "k_ahc_blocks", "k_ahc_cluster", "k_ahc_refine", "k_ahc_labels", "k_voxel_grid", "k_plane_refit"):
+            assert 0.0 < ms[k] < 5000.0, (k, ms)
+        for a, b in zip(plain_l, timed_l):
+            assert np.array_equal(a["lines"].view(np.uint8), b["lines"].view(np.uint8)) and np.array_equal(a["desc"], b["desc"])
+        for a, b in zip(plain_p[:2], timed_p[:2]):
+            assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+        c.long_kernel_clock(False)
+        c.lsd_extract_batch(gray, n_threads=2)
+        assert c.long_kernel_ms() == ms
+    finally:
+        c.close()
