@@ -263,7 +263,29 @@ public:
         const double prec = M_PI * angTh / 180, p = angTh / 180;
         const size_t minReg = val_.minReg(p);
         std::vector<RPt> reg;
-        for (const OPt& key : order_) {
+        /* seeds jump across the image in bin order: a seed's 3 x 3 neighbourhood of the state bytes and of the angles is six cache
+         * lines nobody has touched lately.  Asked for a few seeds ahead they are there when the seed's turn comes (round 6; the fields
+         * never change and a prefetch decides nothing).  Measured on the single-frame entry: 11.2 -> 11.0 ms per frame at 12 seeds ahead,
+         * 11.6 at 24 - the loop is bound by its arithmetic (a fastAtan2 per join), not by these misses */
+        const size_t nOrd = order_.size();
+        const OPt* const ord = order_.data();
+#ifndef LSD_HOST_PREFETCH
+#define LSD_HOST_PREFETCH 12            /* seeds ahead; 0 = off (A/B builds) */
+#endif
+        constexpr size_t kAhead = LSD_HOST_PREFETCH;
+        for (size_t oi = 0; oi < nOrd; oi++) {
+            const OPt key = ord[oi];
+            if (kAhead && oi + kAhead < nOrd) {
+                const OPt k2 = ord[oi + kAhead];
+                const int x2 = (int)(k2 & 0x7FFu), y2 = (int)((k2 >> 11) & 0x7FFu);
+                if (y2 >= 1 && y2 + 1 < H_) {
+                    const size_t at = (size_t)(y2 - 1) * W_ + (size_t)(x2 > 0 ? x2 - 1 : 0);
+                    const uint8_t* u = used_.data() + at;
+                    __builtin_prefetch(u); __builtin_prefetch(u + W_); __builtin_prefetch(u + 2 * (size_t)W_);
+                    const double* a = ang_ + at;
+                    __builtin_prefetch(a); __builtin_prefetch(a + W_); __builtin_prefetch(a + 2 * (size_t)W_);
+                }
+            }
             if ((key >> LSD_ORDER_IDX_BITS) < minSeedBin_) break;          /* bins descend: no seed from here on */
             const struct { int x, y; } s = {(int)(key & 0x7FFu), (int)((key >> 11) & 0x7FFu)};
             if (used_[(size_t)s.y * W_ + s.x]) continue;          /* claimed, or no angle */
