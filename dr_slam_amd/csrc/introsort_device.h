@@ -74,7 +74,7 @@ template <int NTH>
 struct Shared {
     Seg queue[ORD_QCAP];
     Seg stack[NTH / 64][ORD_STACK];
-    int qHead, qTail, bigTop, qOverflow, heapNeeded, wcnt[4 * (NTH / 64) + 2];
+    int qHead, qTail, bigTop, qOverflow, heapNeeded, wcnt[8 * (NTH / 64) + 2];
     Seg cur;                        /* the range the workgroup partitions now */
     uint32_t cutShared;
     unsigned long long tp;          /* profiling builds: thread 0's last phase mark */
@@ -217,29 +217,29 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
         } else total = (uint32_t)__popcll(m);
         return r;
     };
+    /* Round 6: ONE scan finds both kinds of stoppers - a record's key decides "does not go before the pivot" (left stopper) and "the
+     * pivot does not go before it" (right stopper) alike - so every record is read once per partition instead of twice and a round's
+     * chain (load -> ballot -> barrier -> LDS -> barrier -> store) carries both lists.  The right stoppers land in ASCENDING position
+     * order; the k-th from the right - what the pairing below asks for - is entry cntR - 1 - k. */
     uint32_t cntL = 0, cntR = 0;
     if (NT == 64) {
         /* one wavefront: four blocks of 64 per round, their loads in flight together (the scan is bound by memory latency) */
-        for (uint32_t base = lo; base < hi; base += 256) {                 /* left stoppers (records that do not go before the pivot), ascending */
-            bool f[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t p = base + 64 * u + lane; f[u] = p < hi && !(T::key(a[p < hi ? p : lo]) < pk); }
+        for (uint32_t base = lo; base < hi; base += 256) {
+            bool fl[4], fr[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const unsigned long long m = __ballot(f[u]);
-                if (f[u]) posL[first + cntL + (uint32_t)__popcll(m & lt)] = base + 64 * u + lane;
-                cntL += (uint32_t)__popcll(m);
+                const uint32_t p = base + 64 * u + lane;
+                const uint32_t k = T::key(a[p < hi ? p : lo]);
+                fl[u] = p < hi && !(k < pk);
+                fr[u] = p < hi && !(pk < k);
             }
-        }
-        for (uint32_t off = 0; lo + off < hi; off += 256) {                /* right stoppers (the pivot does not go before them), descending */
-            bool f[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t back = off + 64 * u + lane; const bool in = back < hi - lo; f[u] = in && !(pk < T::key(a[hi - 1 - (in ? back : 0)])); }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const unsigned long long m = __ballot(f[u]);
-                if (f[u]) posR[first + cntR + (uint32_t)__popcll(m & lt)] = hi - 1 - (off + 64 * u + lane);
-                cntR += (uint32_t)__popcll(m);
+                const unsigned long long ml = __ballot(fl[u]), mr = __ballot(fr[u]);
+                if (fl[u]) posL[first + cntL + (uint32_t)__popcll(ml & lt)] = base + 64 * u + lane;
+                if (fr[u]) posR[first + cntR + (uint32_t)__popcll(mr & lt)] = base + 64 * u + lane;
+                cntL += (uint32_t)__popcll(ml);
+                cntR += (uint32_t)__popcll(mr);
             }
         }
     } else {
@@ -247,45 +247,35 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
          * (a round is a chain load -> ballot -> barrier -> LDS -> barrier -> store, ~1 us whatever it carries) */
         constexpr int NWV = NT / 64;
         for (uint32_t base = lo; base < hi; base += 4 * NT) {
-            bool f[4];
-            unsigned long long mk[4];
+            bool fl[4], fr[4];
+            unsigned long long ml[4], mr[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t p = base + NT * u + tid; f[u] = p < hi && !(T::key(a[p < hi ? p : lo]) < pk); }
+            for (int u = 0; u < 4; u++) {
+                const uint32_t p = base + NT * u + tid;
+                const uint32_t k = T::key(a[p < hi ? p : lo]);
+                fl[u] = p < hi && !(k < pk);
+                fr[u] = p < hi && !(pk < k);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; u++) mk[u] = __ballot(f[u]);
+            for (int u = 0; u < 4; u++) { ml[u] = __ballot(fl[u]); mr[u] = __ballot(fr[u]); }
             __syncthreads();
             if (lane == 0) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) wcnt[u * NWV + wv] = __popcll(mk[u]);
+                for (int u = 0; u < 4; u++) { wcnt[u * NWV + wv] = __popcll(ml[u]); wcnt[(4 + u) * NWV + wv] = __popcll(mr[u]); }
             }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                uint32_t before_ = 0, all = 0;
-                for (int k = 0; k < NWV; k++) { const uint32_t c = (uint32_t)wcnt[u * NWV + k]; if (k < wv) before_ += c; all += c; }
-                if (f[u]) posL[first + cntL + before_ + (uint32_t)__popcll(mk[u] & lt)] = base + NT * u + tid;
-                cntL += all;
-            }
-        }
-        for (uint32_t off = 0; lo + off < hi; off += 4 * NT) {
-            bool f[4];
-            unsigned long long mk[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t back = off + NT * u + tid; const bool in = back < hi - lo; f[u] = in && !(pk < T::key(a[hi - 1 - (in ? back : 0)])); }
-#pragma unroll
-            for (int u = 0; u < 4; u++) mk[u] = __ballot(f[u]);
-            __syncthreads();
-            if (lane == 0) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) wcnt[u * NWV + wv] = __popcll(mk[u]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t before_ = 0, all = 0;
-                for (int k = 0; k < NWV; k++) { const uint32_t c = (uint32_t)wcnt[u * NWV + k]; if (k < wv) before_ += c; all += c; }
-                if (f[u]) posR[first + cntR + before_ + (uint32_t)__popcll(mk[u] & lt)] = hi - 1 - (off + NT * u + tid);
-                cntR += all;
+                uint32_t bl = 0, al = 0, br = 0, ar = 0;
+                for (int k = 0; k < NWV; k++) {
+                    const uint32_t c = (uint32_t)wcnt[u * NWV + k], d = (uint32_t)wcnt[(4 + u) * NWV + k];
+                    if (k < wv) { bl += c; br += d; }
+                    al += c; ar += d;
+                }
+                if (fl[u]) posL[first + cntL + bl + (uint32_t)__popcll(ml[u] & lt)] = base + NT * u + tid;
+                if (fr[u]) posR[first + cntR + br + (uint32_t)__popcll(mr[u] & lt)] = base + NT * u + tid;
+                cntL += al;
+                cntR += ar;
             }
         }
     }
@@ -298,7 +288,7 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
     while (klo < khi) {
         const uint32_t span = khi - klo, step = (span + NT - 1) / NT, np = (span + step - 1) / step;
         const uint32_t k = klo + (uint32_t)tid * step;
-        const bool f = k < khi && posL[first + k] < posR[first + k];
+        const bool f = k < khi && posL[first + k] < posR[first + cntR - 1 - k];
         uint32_t c;
         (void)block_rank(f, c);
         const uint32_t nlo = c > 0 ? klo + (c - 1) * step + 1 : klo, nhi = c < np ? klo + c * step : khi;
@@ -309,13 +299,13 @@ __device__ __forceinline__ uint32_t hoare_cut(RecPtr a, uint32_t first, uint32_t
         uint32_t pl[4], pr[4];
         typename T::Rec x[4], y[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t k = k0 + NT * u; const bool in = k < K; pl[u] = in ? (uint32_t)posL[first + k] : first; pr[u] = in ? (uint32_t)posR[first + k] : first; }
+        for (int u = 0; u < 4; u++) { const uint32_t k = k0 + NT * u; const bool in = k < K; pl[u] = in ? (uint32_t)posL[first + k] : first; pr[u] = in ? (uint32_t)posR[first + cntR - 1 - k] : first; }
 #pragma unroll
         for (int u = 0; u < 4; u++) { x[u] = a[pl[u]]; y[u] = a[pr[u]]; }
 #pragma unroll
         for (int u = 0; u < 4; u++) if (k0 + NT * u < K) { a[pl[u]] = y[u]; a[pr[u]] = x[u]; }
     }
-    const uint32_t l = K < cntL ? (uint32_t)posL[first + K] : hi, r = K > 0 ? (uint32_t)posR[first + K - 1] : hi;
+    const uint32_t l = K < cntL ? (uint32_t)posL[first + K] : hi, r = K > 0 ? (uint32_t)posR[first + cntR - K] : hi;
     group_sync();
     return l < r ? l : r;
 }
