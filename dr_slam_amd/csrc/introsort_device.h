@@ -509,12 +509,21 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
         const int shft = pass * 5;
         for (int i = tid; i < 32 * NW; i += NTH) cnt[i] = 0;
         __syncthreads();
-        for (uint32_t t = t0; t < t1; t++) {
-            const uint32_t p = (t << 6) + lane;
-            const bool valid = p < (uint32_t)n;
-            const uint32_t d = valid ? (T::key(src[p]) >> shft) & 31u : 0u;
-            const unsigned long long peers = same_digit(valid, d);
-            if (valid && !(peers & ltm)) atomicAdd(&cnt[d * NW + wv], (uint32_t)__popcll(peers));
+        /* four tiles per trip, their loads in flight together: a sweep is a chain of load -> ballots -> LDS per tile, and the load is
+         * most of it (round 6: one tile per trip waited a memory round trip 3 000 times per wavefront and sort) */
+        for (uint32_t tb = t0; tb < t1; tb += 4) {
+            uint32_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t p = ((tb + u) << 6) + lane; kk[u] = (tb + u < t1 && p < (uint32_t)n) ? T::key(src[p]) : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (tb + u >= t1) break;                               /* wave-uniform */
+                const uint32_t p = ((tb + u) << 6) + lane;
+                const bool valid = p < (uint32_t)n;
+                const uint32_t d = valid ? (kk[u] >> shft) & 31u : 0u;
+                const unsigned long long peers = same_digit(valid, d);
+                if (valid && !(peers & ltm)) atomicAdd(&cnt[d * NW + wv], (uint32_t)__popcll(peers));
+            }
         }
         __syncthreads();
         /* exclusive scan of the counters in (digit, wavefront) order by wavefront 0: lane i owns NW / 2 consecutive entries */
@@ -529,16 +538,24 @@ __device__ __forceinline__ int sort(typename T::Rec* a, int n, uint32_t* posL, u
             for (int k = 0; k < EPL; k++) { const uint32_t c = cnt[lane * EPL + k]; cnt[lane * EPL + k] = run; run += c; }
         }
         __syncthreads();
-        for (uint32_t t = t0; t < t1; t++) {
-            const uint32_t p = (t << 6) + lane;
-            const bool valid = p < (uint32_t)n;
-            const Rec v = valid ? src[p] : src[0];
-            const uint32_t d = valid ? (T::key(v) >> shft) & 31u : 0u;
-            const unsigned long long peers = same_digit(valid, d);
-            if (valid) {
-                const uint32_t base = cnt[d * NW + wv];
-                dst[base + (uint32_t)__popcll(peers & ltm)] = v;
-                if (!(peers & ltm)) cnt[d * NW + wv] = base + (uint32_t)__popcll(peers);
+        for (uint32_t tb = t0; tb < t1; tb += 4) {
+            Rec vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t p = ((tb + u) << 6) + lane; vv[u] = (tb + u < t1 && p < (uint32_t)n) ? src[p] : src[0]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (tb + u >= t1) break;                               /* wave-uniform */
+                const uint32_t p = ((tb + u) << 6) + lane;
+                const bool valid = p < (uint32_t)n;
+                const Rec v = vv[u];
+                const uint32_t d = valid ? (T::key(v) >> shft) & 31u : 0u;
+                const unsigned long long peers = same_digit(valid, d);
+                if (valid) {
+                    const uint32_t base = cnt[d * NW + wv];
+                    dst[base + (uint32_t)__popcll(peers & ltm)] = v;
+                    if (!(peers & ltm)) cnt[d * NW + wv] = base + (uint32_t)__popcll(peers);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   /* the next tile reads the counters this one advanced */
             }
         }
         __syncthreads();
